@@ -1,0 +1,630 @@
+// Streaming elementwise + reduction kernels: whole-tensor normalisation (scale_noise), blends,
+// chain accumulation, mask mix, and the fused Sonar momentum steps.  All HBM-bound: 16 B/lane
+// coalesced accesses, grid-stride over <= kMaxGrid blocks of 256 threads, fp64 block reductions.
+#include <math.h>
+
+#include "common.h"
+
+namespace sonar {
+
+// ------------------------------------------------------------------------------------------------
+// V-wide pack of floats (V = 4 -> one dwordx4 access per lane; V = 1 for unaligned buffers).
+template <int V>
+struct Pack {
+    float v[V];
+};
+template <int V>
+__device__ __forceinline__ Pack<V> load(const float* p, int64_t i) {
+    Pack<V> r;
+    if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + i);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else {
+        r.v[0] = p[i];
+    }
+    return r;
+}
+template <int V>
+__device__ __forceinline__ void store(float* p, int64_t i, const Pack<V>& r) {
+    if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(p + i) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    } else {
+        p[i] = r.v[0];
+    }
+}
+
+// Generic driver: op.template run<V>(elem_index) handles V consecutive elements.
+template <int V, typename Op>
+__global__ void __launch_bounds__(kBlock) ew_kernel(Op op, int64_t n) {
+    const int64_t nv = n / V;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += stride) op.template run<V>(i * V);
+    if constexpr (V > 1) {
+        if (blockIdx.x == 0)
+            for (int64_t i = nv * V + threadIdx.x; i < n; i += kBlock) op.template run<1>(i);
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename Op>
+static int launch_ew(Op op, int64_t n, bool vec_ok, hipStream_t st, const char* what) {
+    if (n == 0) return SONAR_OK;
+    if (vec_ok) {
+        hipLaunchKernelGGL((ew_kernel<4, Op>), dim3(grid_for(n / 4 + 1, kBlock * 2)), dim3(kBlock), 0, st, op, n);
+    } else {
+        hipLaunchKernelGGL((ew_kernel<1, Op>), dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, st, op, n);
+    }
+    return check_launch(what);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stats: (sum, sumsq) partials in fp64
+template <int V>
+__global__ void __launch_bounds__(kBlock) stats_kernel(const float* __restrict__ x, int64_t n, double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
+    const int64_t nv = n / V;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    // two independent loads in flight per iteration
+    for (; i + stride < nv; i += 2 * stride) {
+        const Pack<V> a = load<V>(x, i * V);
+        const Pack<V> b = load<V>(x, (i + stride) * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const double da = a.v[k], db = b.v[k];
+            s += da; q += da * da;
+            s += db; q += db * db;
+        }
+    }
+    for (; i < nv; i += stride) {
+        const Pack<V> a = load<V>(x, i * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const double da = a.v[k];
+            s += da; q += da * da;
+        }
+    }
+    if (V > 1 && blockIdx.x == 0)
+        for (int64_t j = nv * V + threadIdx.x; j < n; j += kBlock) {
+            const double da = x[j];
+            s += da; q += da * da;
+        }
+    write_partial<kBlock>(s, q, partials, red);
+}
+
+__global__ void __launch_bounds__(kBlock) stats_finalize_kernel(const double* __restrict__ partials, int64_t npart,
+                                                                 int64_t n, double* out3) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
+    for (int64_t i = threadIdx.x; i < npart; i += kBlock) {
+        s += partials[2 * i];
+        q += partials[2 * i + 1];
+    }
+    block_sum2<kBlock>(s, q, red);
+    if (threadIdx.x == 0) {
+        out3[0] = s;
+        out3[1] = q;
+        out3[2] = (double)n;
+    }
+}
+
+// Decision values shared by every block of the apply kernel: identical fixed-order reduction
+// of the partials in each block -> identical (mean, std, branches) everywhere, no host sync.
+struct NormDecision {
+    float mean, stdv;
+    int do_sub, do_div;
+};
+
+__device__ __forceinline__ NormDecision decide_norm(const double* __restrict__ partials, int64_t npart, int64_t n_total,
+                                                    float thr_sd, double* red, NormDecision* sh) {
+    double s = 0.0, q = 0.0;
+    for (int64_t i = threadIdx.x; i < npart; i += kBlock) {
+        s += partials[2 * i];
+        q += partials[2 * i + 1];
+    }
+    block_sum2<kBlock>(s, q, red);
+    if (threadIdx.x == 0) {
+        const double nt = (double)n_total;
+        const double mean = s / nt;
+        // unbiased (py/utils.py:100: noise.std()); n_total == 1 -> NaN like torch
+        const double var = (q - s * mean) / (nt - 1.0);
+        const double sd = sqrt(var > 0.0 || !(var == var) ? var : 0.0);
+        NormDecision d;
+        d.mean = (float)mean;
+        d.stdv = (float)sd;
+        const double thr = (double)thr_sd / sqrt(nt);
+        d.do_sub = fabs((double)d.mean) > thr;
+        d.do_div = fabs(1.0 - (double)d.stdv) > thr;
+        *sh = d;
+    }
+    __syncthreads();
+    return *sh;
+}
+
+template <int V>
+__global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n, float factor, int normalized,
+                                                             float thr_sd, const double* __restrict__ partials,
+                                                             int64_t npart, int64_t n_total) {
+    __shared__ double red[2 * kBlock / 64];
+    __shared__ NormDecision sh;
+    NormDecision d{0.f, 1.f, 0, 0};
+    if (normalized) d = decide_norm(partials, npart, n_total, thr_sd, red, &sh);
+    const bool do_mul = factor != 1.0f;
+    const int64_t nv = n / V;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    auto f = [&](float v) {
+        if (d.do_sub) v = v - d.mean;
+        if (d.do_div) v = v / d.stdv;
+        if (do_mul) v = v * factor;
+        return v;
+    };
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + stride < nv; i += 2 * stride) {
+        Pack<V> a = load<V>(x, i * V);
+        Pack<V> b = load<V>(x, (i + stride) * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            a.v[k] = f(a.v[k]);
+            b.v[k] = f(b.v[k]);
+        }
+        store<V>(x, i * V, a);
+        store<V>(x, (i + stride) * V, b);
+    }
+    for (; i < nv; i += stride) {
+        Pack<V> a = load<V>(x, i * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a.v[k] = f(a.v[k]);
+        store<V>(x, i * V, a);
+    }
+    if (V > 1 && blockIdx.x == 0)
+        for (int64_t j = nv * V + threadIdx.x; j < n; j += kBlock) x[j] = f(x[j]);
+}
+
+// normalize_dims variant (py/utils.py:96-99): one block per row of `inner` contiguous elements
+__global__ void __launch_bounds__(kBlock) scale_rows_kernel(float* x, int64_t rows, int64_t inner, float factor) {
+    __shared__ double red[2 * kBlock / 64];
+    __shared__ float sh_val;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        float* row = x + r * inner;
+        double s = 0.0, q = 0.0;
+        for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
+            const double v = row[i];
+            s += v; q += v * v;
+        }
+        block_sum2<kBlock>(s, q, red);
+        if (threadIdx.x == 0) {
+            const double nt = (double)inner;
+            const double var = (q - s * (s / nt)) / (nt - 1.0);
+            sh_val = (float)sqrt(var > 0.0 || !(var == var) ? var : 0.0);
+        }
+        __syncthreads();
+        const float sd = sh_val;
+        double s2 = 0.0, q2 = 0.0;
+        for (int64_t i = threadIdx.x; i < inner; i += kBlock) s2 += (double)(row[i] / sd);
+        __syncthreads();
+        block_sum2<kBlock>(s2, q2, red);
+        if (threadIdx.x == 0) sh_val = (float)(s2 / (double)inner);
+        __syncthreads();
+        const float mean = sh_val;
+        for (int64_t i = threadIdx.x; i < inner; i += kBlock) row[i] = (row[i] / sd - mean) * factor;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) minmax_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
+                                                              float* out_min, float* out_max) {
+    __shared__ float smin[kBlock / 64], smax[kBlock / 64];
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* row = x + r * inner;
+        float lo = INFINITY, hi = -INFINITY;
+        for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
+            const float v = row[i];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fminf(lo, __shfl_down(lo, off, 64));
+            hi = fmaxf(hi, __shfl_down(hi, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            smin[threadIdx.x >> 6] = lo;
+            smax[threadIdx.x >> 6] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kBlock / 64; ++w) {
+                lo = fminf(lo, smin[w]);
+                hi = fmaxf(hi, smax[w]);
+            }
+            out_min[r] = lo;
+            out_max[r] = hi;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct BlendOp {
+    int mode;
+    const float *a, *b;
+    float t;
+    float* out;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        const Pack<V> pa = load<V>(a, i), pb = load<V>(b, i);
+        Pack<V> r;
+#pragma unroll
+        for (int k = 0; k < V; ++k) r.v[k] = blend<float>(mode, pa.v[k], pb.v[k], t);
+        store<V>(out, i, r);
+    }
+};
+
+struct BlendTensorOp {
+    int mode;
+    const float *a, *b, *t;
+    int64_t tn;
+    float* out;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        const Pack<V> pa = load<V>(a, i), pb = load<V>(b, i);
+        Pack<V> r;
+#pragma unroll
+        for (int k = 0; k < V; ++k) r.v[k] = blend<float>(mode, pa.v[k], pb.v[k], t[(i + k) % tn]);
+        store<V>(out, i, r);
+    }
+};
+
+struct AxpbyOp {
+    float* y;
+    float ymul;
+    const float* x;
+    float xmul;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        Pack<V> py = load<V>(y, i);
+        const Pack<V> px = load<V>(x, i);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            // y*ymul and x*xmul are skipped when the multiplier is exactly 1 (the reference's
+            // scale_noise/add_ sequence does not multiply then)
+            const float yy = ymul != 1.0f ? py.v[k] * ymul : py.v[k];
+            const float xx = xmul != 1.0f ? px.v[k] * xmul : px.v[k];
+            py.v[k] = yy + xx;
+        }
+        store<V>(y, i, py);
+    }
+};
+
+struct MaskMixOp {
+    const float *dst, *src, *mask;
+    int64_t mask_n;
+    float* out;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        const Pack<V> pd = load<V>(dst, i), ps = load<V>(src, i);
+        Pack<V> r;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float m = mask[(i + k) % mask_n];
+            // py/noise.py:528-530: noise_dst *= (1 - mask); noise_src *= mask; dst + src
+            r.v[k] = pd.v[k] * (1.0f - m) + ps.v[k] * m;
+        }
+        store<V>(out, i, r);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Momentum building blocks (py/sonar.py:227-307), evaluated per element in registers.
+struct HistState {
+    float h;
+    bool present;
+};
+
+// update_hist: h <- v                       when no history yet
+//              h <- hblend(v*ms, h*hs, hr)  otherwise          (py/sonar.py:231-236)
+__device__ __forceinline__ void hist_update(const sonar_momentum_cfg& c, HistState& hs, float v) {
+    if (!c.update_hist) return;
+    if (!hs.present) {
+        hs.h = v;
+        hs.present = true;
+    } else {
+        hs.h = blend<float>(c.history_blend, v * c.md_scale, hs.h * c.hist_scale, c.hist_ratio);
+    }
+}
+
+// init_hist_d for SAMPLE / SAMPLE_NORM (py/sonar.py:184-191)
+__device__ __forceinline__ void hist_init(const sonar_momentum_cfg& c, HistState& hs, float x, float den, float sigma) {
+    if (hs.present || c.init_kind == SONAR_INIT_NONE) return;
+    const float src = c.mode == SONAR_MODE_DENOISED ? den : x;
+    hs.h = c.init_kind == SONAR_INIT_SAMPLE_NORM ? src / sigma : src;
+    hs.present = true;
+}
+
+// get_momentum_denoised (py/sonar.py:262-283): returns den_m, updates history with den/sigma
+__device__ __forceinline__ float momentum_denoised(const sonar_momentum_cfg& c, HistState& hs, bool h_usable, float x,
+                                                   float den, float sigma) {
+    float den_m = den;
+    if (c.mode == SONAR_MODE_DENOISED && hs.present && h_usable && c.momentum != 1.0f)
+        den_m = blend<float>(c.momentum_blend, hs.h * sigma, den, c.momentum);
+    hist_init(c, hs, x, den, sigma);
+    hist_update(c, hs, den / sigma);
+    return c.use_momentum ? den_m : den;
+}
+
+// get_momentum_d (py/sonar.py:285-307) for a given d; `early_out` = momentum==1 || DENOISED mode
+__device__ __forceinline__ float momentum_d(const sonar_momentum_cfg& c, HistState& hs, bool early_out, float x,
+                                            float den, float sigma, float d) {
+    if (early_out) return d;
+    const float md = hs.present ? blend<float>(c.momentum_blend, hs.h, d, c.momentum) : d;
+    hist_init(c, hs, x, den, sigma);
+    hist_update(c, hs, c.mode == SONAR_MODE_NEW ? d : md);
+    return c.use_momentum ? md : d;
+}
+
+struct EulerOp {
+    const float *x, *den, *h_in;
+    float *x_out, *h_out;
+    const float* noise;
+    float noise_scale, sigma, dt;
+    sonar_momentum_cfg c;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        const Pack<V> px = load<V>(x, i), pd = load<V>(den, i);
+        Pack<V> ph, pn, rx, rh;
+        if (h_in) ph = load<V>(h_in, i);
+        if (noise) pn = load<V>(noise, i);
+        const bool early = c.momentum == 1.0f || c.mode == SONAR_MODE_DENOISED;
+        bool present = false;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            HistState hs{h_in ? ph.v[k] : 0.0f, h_in != nullptr};
+            const float den_m = momentum_denoised(c, hs, !c.h_in_fresh, px.v[k], pd.v[k], sigma);
+            const float d = (px.v[k] - den_m) / sigma;  // to_d
+            const float md = momentum_d(c, hs, early, px.v[k], den_m, sigma, d);
+            float xn = md * dt + px.v[k];
+            if (noise) xn = xn + pn.v[k] * noise_scale;
+            rx.v[k] = xn;
+            rh.v[k] = hs.h;
+            present = hs.present;
+        }
+        store<V>(x_out, i, rx);
+        if (present && h_out) store<V>(h_out, i, rh);
+    }
+};
+
+struct Dpmpp1Op {
+    const float *x, *den, *h_in;
+    float *x2_out, *md1_out, *h_out;
+    const float* noise;
+    float noise_scale, sigma, expm1_a, ratio_a;
+    int adj_is_one;
+    sonar_momentum_cfg c;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        const Pack<V> px = load<V>(x, i), pd = load<V>(den, i);
+        Pack<V> ph, pn, rx, rm, rh;
+        if (h_in) ph = load<V>(h_in, i);
+        if (noise) pn = load<V>(noise, i);
+        const bool early = adj_is_one || c.mode == SONAR_MODE_DENOISED;
+        bool present = false;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            HistState hs{h_in ? ph.v[k] : 0.0f, h_in != nullptr};
+            const float md1 = momentum_denoised(c, hs, !c.h_in_fresh, px.v[k], pd.v[k], sigma);
+            const float diff2 = expm1_a * md1;
+            const float m_d = momentum_d(c, hs, early, px.v[k], md1, sigma, diff2);
+            float x2 = ratio_a * px.v[k] - m_d;
+            if (noise) x2 = x2 + pn.v[k] * noise_scale;
+            rx.v[k] = x2;
+            rm.v[k] = md1;
+            rh.v[k] = hs.h;
+            present = hs.present;
+        }
+        store<V>(x2_out, i, rx);
+        store<V>(md1_out, i, rm);
+        if (present && h_out) store<V>(h_out, i, rh);
+    }
+};
+
+struct Dpmpp2Op {
+    const float *x, *den2, *md1, *h_in;
+    float *x_out, *dd_out, *h_out;
+    const float* noise;
+    float noise_scale, sigma_s, expm1_b, ratio_b, fac;
+    int adj_is_one;
+    sonar_momentum_cfg c;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        const Pack<V> px = load<V>(x, i), pd = load<V>(den2, i), pm = load<V>(md1, i);
+        Pack<V> ph, pn, rx, rd, rh;
+        if (h_in) ph = load<V>(h_in, i);
+        if (noise) pn = load<V>(noise, i);
+        const bool early = adj_is_one || c.mode == SONAR_MODE_DENOISED;
+        const float one_minus_fac = 1.0f - fac;
+        bool present = false;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            HistState hs{h_in ? ph.v[k] : 0.0f, h_in != nullptr};
+            const float md2 = momentum_denoised(c, hs, true, px.v[k], pd.v[k], sigma_s);
+            const float dd = one_minus_fac * pm.v[k] + fac * md2;
+            const float diff1 = expm1_b * dd;
+            const float m_d = momentum_d(c, hs, early, px.v[k], md2, sigma_s, diff1);
+            float xn = ratio_b * px.v[k] - m_d;
+            if (noise) xn = xn + pn.v[k] * noise_scale;
+            rx.v[k] = xn;
+            rd.v[k] = dd;
+            rh.v[k] = hs.h;
+            present = hs.present;
+        }
+        store<V>(x_out, i, rx);
+        if (dd_out) store<V>(dd_out, i, rd);
+        if (present && h_out) store<V>(h_out, i, rh);
+    }
+};
+
+// Whether a history exists after the step (host-side mirror of the device logic).
+static int hist_present_after(const sonar_momentum_cfg& c, bool h_in, bool second_update_possible) {
+    if (h_in) return 1;
+    if (c.init_kind != SONAR_INIT_NONE) return 1;
+    if (c.update_hist) return 1;
+    (void)second_update_possible;
+    return 0;
+}
+
+struct CastOp {
+    const float* in;
+    double* out;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        const Pack<V> p = load<V>(in, i);
+        if constexpr (V == 4) {
+            *reinterpret_cast<double2*>(out + i) = make_double2((double)p.v[0], (double)p.v[1]);
+            *reinterpret_cast<double2*>(out + i + 2) = make_double2((double)p.v[2], (double)p.v[3]);
+        } else {
+            out[i] = (double)p.v[0];
+        }
+    }
+};
+
+}  // namespace sonar
+
+using namespace sonar;
+
+// ================================================================================================
+extern "C" int sonar_stats_f32(const float* x, int64_t n, double* partials, void* stream) {
+    SONAR_REQUIRE(x && partials && n >= 0, SONAR_ERR_ARG, "sonar_stats_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (aligned16(x)) {
+        const int g = (int)std::min<int64_t>(kNPart, grid_for(n / 4 + 1, kBlock * 2));
+        hipLaunchKernelGGL((stats_kernel<4>), dim3(g), dim3(kBlock), 0, st, x, n, partials);
+    } else {
+        const int g = (int)std::min<int64_t>(kNPart, grid_for(n, kBlock * 4));
+        hipLaunchKernelGGL((stats_kernel<1>), dim3(g), dim3(kBlock), 0, st, x, n, partials);
+    }
+    return check_launch("sonar_stats_f32");
+}
+
+extern "C" int sonar_stats_finalize(const double* partials, int64_t npart, int64_t n, double* out3, void* stream) {
+    SONAR_REQUIRE(partials && out3 && npart > 0, SONAR_ERR_ARG, "sonar_stats_finalize: bad argument");
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, partials, npart, n, out3);
+    return check_launch("sonar_stats_finalize");
+}
+
+extern "C" int sonar_scale_noise_f32(float* x, int64_t n, float factor, int normalized, float threshold_std_devs,
+                                     const double* partials, int64_t npart, int64_t n_total, void* stream) {
+    SONAR_REQUIRE(x && n >= 0, SONAR_ERR_ARG, "sonar_scale_noise_f32: bad argument");
+    SONAR_REQUIRE(!normalized || (partials && npart > 0 && n_total > 0), SONAR_ERR_ARG,
+                  "sonar_scale_noise_f32: normalized=1 needs partials");
+    if (n == 0 || (!normalized && factor == 1.0f)) return SONAR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (aligned16(x)) {
+        hipLaunchKernelGGL((scale_noise_kernel<4>), dim3(grid_for(n / 4 + 1, kBlock * 2)), dim3(kBlock), 0, st, x, n,
+                           factor, normalized, threshold_std_devs, partials, npart, n_total);
+    } else {
+        hipLaunchKernelGGL((scale_noise_kernel<1>), dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, st, x, n, factor,
+                           normalized, threshold_std_devs, partials, npart, n_total);
+    }
+    return check_launch("sonar_scale_noise_f32");
+}
+
+extern "C" int sonar_scale_noise_rows_f32(float* x, int64_t rows, int64_t inner, float factor, void* stream) {
+    SONAR_REQUIRE(x && rows >= 0 && inner > 0, SONAR_ERR_ARG, "sonar_scale_noise_rows_f32: bad argument");
+    if (rows == 0) return SONAR_OK;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(rows, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner,
+                       factor);
+    return check_launch("sonar_scale_noise_rows_f32");
+}
+
+extern "C" int sonar_minmax_rows_f32(const float* x, int64_t rows, int64_t inner, float* out_min, float* out_max,
+                                     void* stream) {
+    SONAR_REQUIRE(x && out_min && out_max && rows >= 0 && inner > 0, SONAR_ERR_ARG, "sonar_minmax_rows_f32: bad argument");
+    if (rows == 0) return SONAR_OK;
+    hipLaunchKernelGGL(minmax_rows_kernel, dim3(grid_for(rows, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner,
+                       out_min, out_max);
+    return check_launch("sonar_minmax_rows_f32");
+}
+
+extern "C" int sonar_blend_f32(int mode, const float* a, const float* b, float t, float* out, int64_t n, void* stream) {
+    SONAR_REQUIRE(a && b && out && n >= 0 && mode >= 0 && mode <= 2, SONAR_ERR_ARG, "sonar_blend_f32: bad argument");
+    return launch_ew(BlendOp{mode, a, b, t, out}, n, aligned16(a) && aligned16(b) && aligned16(out),
+                     (hipStream_t)stream, "sonar_blend_f32");
+}
+
+extern "C" int sonar_blend_tensor_f32(int mode, const float* a, const float* b, const float* t, int64_t tn, float* out,
+                                      int64_t n, void* stream) {
+    SONAR_REQUIRE(a && b && t && out && n >= 0 && tn > 0 && mode >= 0 && mode <= 2, SONAR_ERR_ARG,
+                  "sonar_blend_tensor_f32: bad argument");
+    return launch_ew(BlendTensorOp{mode, a, b, t, tn, out}, n, aligned16(a) && aligned16(b) && aligned16(out),
+                     (hipStream_t)stream, "sonar_blend_tensor_f32");
+}
+
+extern "C" int sonar_axpby_f32(float* y, float ymul, const float* x, float xmul, int64_t n, void* stream) {
+    SONAR_REQUIRE(x && y && n >= 0, SONAR_ERR_ARG, "sonar_axpby_f32: bad argument");
+    return launch_ew(AxpbyOp{y, ymul, x, xmul}, n, aligned16(x) && aligned16(y), (hipStream_t)stream, "sonar_axpby_f32");
+}
+
+extern "C" int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,
+                                  int64_t n, void* stream) {
+    SONAR_REQUIRE(dst && src && mask && out && n >= 0 && mask_n > 0, SONAR_ERR_ARG, "sonar_mask_mix_f32: bad argument");
+    return launch_ew(MaskMixOp{dst, src, mask, mask_n, out}, n, aligned16(dst) && aligned16(src) && aligned16(out),
+                     (hipStream_t)stream, "sonar_mask_mix_f32");
+}
+
+static bool cfg_ok(const sonar_momentum_cfg* c) {
+    return c && c->mode >= 0 && c->mode <= 2 && c->momentum_blend >= 0 && c->momentum_blend <= 2 &&
+           c->history_blend >= 0 && c->history_blend <= 2 && c->init_kind >= 0 && c->init_kind <= 2;
+}
+
+extern "C" int sonar_momentum_euler_f32(const float* x, const float* denoised, const float* h_in, float* x_out,
+                                        float* h_out, const float* noise, float noise_scale, float sigma, float dt,
+                                        const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, void* stream) {
+    SONAR_REQUIRE(x && denoised && x_out && n >= 0 && cfg_ok(cfg), SONAR_ERR_ARG, "sonar_momentum_euler_f32: bad argument");
+    const int present = hist_present_after(*cfg, h_in != nullptr, true);
+    SONAR_REQUIRE(!present || h_out, SONAR_ERR_ARG, "sonar_momentum_euler_f32: h_out required (history is produced)");
+    if (h_out_present) *h_out_present = present;
+    const bool v = aligned16(x) && aligned16(denoised) && aligned16(x_out) && (!h_in || aligned16(h_in)) &&
+                   (!h_out || aligned16(h_out)) && (!noise || aligned16(noise));
+    return launch_ew(EulerOp{x, denoised, h_in, x_out, h_out, noise, noise_scale, sigma, dt, *cfg}, n, v,
+                     (hipStream_t)stream, "sonar_momentum_euler_f32");
+}
+
+extern "C" int sonar_dpmpp_stage1_f32(const float* x, const float* denoised, const float* h_in, float* x2_out,
+                                      float* md1_out, float* h_out, const float* noise, float noise_scale, float sigma,
+                                      float expm1_a, float ratio_a, int adj_is_one, const sonar_momentum_cfg* cfg,
+                                      int64_t n, int* h_out_present, void* stream) {
+    SONAR_REQUIRE(x && denoised && x2_out && md1_out && n >= 0 && cfg_ok(cfg), SONAR_ERR_ARG,
+                  "sonar_dpmpp_stage1_f32: bad argument");
+    const int present = hist_present_after(*cfg, h_in != nullptr, true);
+    SONAR_REQUIRE(!present || h_out, SONAR_ERR_ARG, "sonar_dpmpp_stage1_f32: h_out required");
+    if (h_out_present) *h_out_present = present;
+    const bool v = aligned16(x) && aligned16(denoised) && aligned16(x2_out) && aligned16(md1_out) &&
+                   (!h_in || aligned16(h_in)) && (!h_out || aligned16(h_out)) && (!noise || aligned16(noise));
+    return launch_ew(Dpmpp1Op{x, denoised, h_in, x2_out, md1_out, h_out, noise, noise_scale, sigma, expm1_a, ratio_a,
+                              adj_is_one, *cfg},
+                     n, v, (hipStream_t)stream, "sonar_dpmpp_stage1_f32");
+}
+
+extern "C" int sonar_dpmpp_stage2_f32(const float* x, const float* denoised2, const float* md1, const float* h_in,
+                                      float* x_out, float* dd_out, float* h_out, const float* noise, float noise_scale,
+                                      float sigma_s, float expm1_b, float ratio_b, float fac, int adj_is_one,
+                                      const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, void* stream) {
+    SONAR_REQUIRE(x && denoised2 && md1 && x_out && n >= 0 && cfg_ok(cfg), SONAR_ERR_ARG,
+                  "sonar_dpmpp_stage2_f32: bad argument");
+    const int present = hist_present_after(*cfg, h_in != nullptr, true);
+    SONAR_REQUIRE(!present || h_out, SONAR_ERR_ARG, "sonar_dpmpp_stage2_f32: h_out required");
+    if (h_out_present) *h_out_present = present;
+    const bool v = aligned16(x) && aligned16(denoised2) && aligned16(md1) && aligned16(x_out) &&
+                   (!dd_out || aligned16(dd_out)) && (!h_in || aligned16(h_in)) && (!h_out || aligned16(h_out)) &&
+                   (!noise || aligned16(noise));
+    return launch_ew(Dpmpp2Op{x, denoised2, md1, h_in, x_out, dd_out, h_out, noise, noise_scale, sigma_s, expm1_b,
+                              ratio_b, fac, adj_is_one, *cfg},
+                     n, v, (hipStream_t)stream, "sonar_dpmpp_stage2_f32");
+}
+
+extern "C" int sonar_cast_f32_f64(const float* in, double* out, int64_t n, void* stream) {
+    SONAR_REQUIRE(in && out && n >= 0, SONAR_ERR_ARG, "sonar_cast_f32_f64: bad argument");
+    return launch_ew(CastOp{in, out}, n, aligned16(in) && aligned16(out), (hipStream_t)stream, "sonar_cast_f32_f64");
+}

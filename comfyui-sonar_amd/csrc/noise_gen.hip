@@ -1,0 +1,451 @@
+// Base generators (Philox normal / uniform), Perlin lattice noise and pyramid (multi-resolution)
+// noise.  Output-write-bound: every kernel streams 16 B/lane stores of contiguous NCHW latents
+// and, when asked, folds the whole-tensor (sum, sumsq) partials of the normaliser into the same pass.
+#include <math.h>
+
+#include "common.h"
+
+namespace sonar {
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------------
+// Element e of a buffer maps to Philox group (elem_offset + e) / 4, lane (elem_offset + e) % 4:
+// the value depends only on the global element index -> independent of how a batch is sharded.
+enum class Dist { Normal, Uniform };
+
+template <Dist D>
+__device__ __forceinline__ void draw4(uint64_t seed, uint64_t stream_id, uint64_t group, float (&v)[4]) {
+    if constexpr (D == Dist::Normal) {
+        philox_normal4(seed, stream_id, group, v);
+    } else {
+        const Philox4 p = philox_group(seed, stream_id, group);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = u01(p.v[k]);
+    }
+}
+
+struct Affine {
+    float sub, mul, add;
+    int active;
+    __device__ __forceinline__ float operator()(float u) const { return active ? (u - sub) * mul + add : u; }
+};
+
+// ALIGNED: elem_offset % 4 == 0 and out 16-B aligned -> one group per lane, dwordx4 stores.
+template <Dist D, bool ALIGNED, bool STATS>
+__global__ void __launch_bounds__(kBlock) philox_fill_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
+                                                             int64_t elem_offset, Affine aff, double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    if constexpr (ALIGNED) {
+        const int64_t ng = (n + 3) / 4;
+        const uint64_t g0 = (uint64_t)(elem_offset >> 2);
+        for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < ng; g += stride) {
+            float v[4];
+            draw4<D>(seed, stream_id, g0 + (uint64_t)g, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = aff(v[k]);
+            const int64_t e = g * 4;
+            if (e + 4 <= n) {
+                *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double d = v[k];
+                        s += d; q += d * d;
+                    }
+                }
+            } else {
+                for (int k = 0; e + k < n; ++k) {
+                    out[e + k] = v[k];
+                    if constexpr (STATS) {
+                        const double d = v[k];
+                        s += d; q += d * d;
+                    }
+                }
+            }
+        }
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+            const uint64_t ge = (uint64_t)(elem_offset + e);
+            float v[4];
+            draw4<D>(seed, stream_id, ge >> 2, v);
+            const float r = aff(v[ge & 3]);
+            out[e] = r;
+            if constexpr (STATS) {
+                const double d = r;
+                s += d; q += d * d;
+            }
+        }
+    }
+    if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+}
+
+template <Dist D>
+static int launch_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset, Affine aff,
+                       double* partials, hipStream_t st, const char* what) {
+    if (n == 0) return SONAR_OK;
+    const bool al = aligned16(out) && (elem_offset & 3) == 0;
+    const int g = (int)std::min<int64_t>(kNPart, grid_for(al ? n / 4 + 1 : n, kBlock));
+#define SONAR_FILL(A, S) \
+    hipLaunchKernelGGL((philox_fill_kernel<D, A, S>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials)
+    if (al) {
+        if (partials) SONAR_FILL(true, true); else SONAR_FILL(true, false);
+    } else {
+        if (partials) SONAR_FILL(false, true); else SONAR_FILL(false, false);
+    }
+#undef SONAR_FILL
+    return check_launch(what);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Perlin: lattice term at cell centre (py/noise_generation.py:388-405 with positions == (0.5, 0.5)).
+__global__ void __launch_bounds__(kBlock) perlin_terms_kernel(const float* __restrict__ angles, float* terms,
+                                                               int64_t planes /*iters*C*/, int H, int W, int blend_mode) {
+    const int64_t total = planes * H * W;
+    const int gw = W + 1;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int64_t p = i / ((int64_t)W * H);
+        const float* a = angles + p * (int64_t)(H + 1) * gw + (int64_t)y * gw + x;
+        const float a00 = a[0], a01 = a[1], a10 = a[gw], a11 = a[gw + 1];
+        // gradient = (cos, sin); corner dot products with (pos - corner), pos = (0.5, 0.5)
+        const float d0 = cosf(a00) * 0.5f + sinf(a00) * 0.5f;      // TL: ( 0.5,  0.5)
+        const float d1 = cosf(a01) * -0.5f + sinf(a01) * 0.5f;     // TR: (-0.5,  0.5)
+        const float d2 = cosf(a10) * 0.5f + sinf(a10) * -0.5f;     // BL: ( 0.5, -0.5)
+        const float d3 = cosf(a11) * -0.5f + sinf(a11) * -0.5f;    // BR: (-0.5, -0.5)
+        // smooth_step(0.5) = 0.5*0.5*(3 - 2*0.5) = 0.5 exactly
+        const float row0 = blend<float>(blend_mode, d0, d1, 0.5f);
+        const float row1 = blend<float>(blend_mode, d2, d3, 0.5f);
+        terms[i] = blend<float>(blend_mode, row0, row1, 0.5f);
+    }
+}
+
+// out[b][i] = base[b][i]/div + terms[0][i] + terms[1][i] + ...   (terms broadcast over batch)
+// GENERATE: base drawn on device.  One float4 per lane; chw % 4 == 0 on the vector path.
+template <bool GENERATE, bool STATS, int V>
+__global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __restrict__ base,
+                                                               const float* __restrict__ terms, float* out, int64_t B,
+                                                               int64_t chw, int iters, float div_fac, uint64_t seed,
+                                                               uint64_t stream_id, int64_t elem_offset,
+                                                               double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
+    const int64_t n = B * chw;
+    const int64_t nv = n / V;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += stride) {
+        const int64_t e = i * V;
+        const int64_t r = e % chw;
+        float v[V];
+        if constexpr (GENERATE) {
+            if constexpr (V == 4) {
+                float u[4];
+                draw4<Dist::Uniform>(seed, stream_id, (uint64_t)((elem_offset + e) >> 2), u);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = u[k];
+            } else {
+                const uint64_t ge = (uint64_t)(elem_offset + e);
+                float u[4];
+                draw4<Dist::Uniform>(seed, stream_id, ge >> 2, u);
+                v[0] = u[ge & 3];
+            }
+        } else {
+            if constexpr (V == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(base + e);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                v[0] = base[e];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] = v[k] / div_fac;
+        for (int it = 0; it < iters; ++it) {
+            const float* t = terms + (int64_t)it * chw + r;
+            if constexpr (V == 4) {
+                const float4 tt = *reinterpret_cast<const float4*>(t);
+                v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
+            } else {
+                v[0] += t[0];
+            }
+        }
+        if constexpr (V == 4) {
+            *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            out[e] = v[0];
+        }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const double d = v[k];
+                s += d; q += d * d;
+            }
+        }
+    }
+    if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+}
+
+template <bool GENERATE>
+static int launch_perlin_apply(const float* base, const float* terms, float* out, int64_t B, int64_t chw, int64_t iters,
+                               float div_fac, uint64_t seed, uint64_t stream_id, int64_t elem_offset, double* partials,
+                               hipStream_t st, const char* what) {
+    const int64_t n = B * chw;
+    if (n == 0) return SONAR_OK;
+    const bool vec = (chw % 4 == 0) && aligned16(out) && aligned16(terms) && (GENERATE ? (elem_offset % 4 == 0) : aligned16(base));
+    const int g = (int)std::min<int64_t>(kNPart, grid_for(vec ? n / 4 : n, kBlock));
+#define SONAR_PA(S, V) \
+    hipLaunchKernelGGL((perlin_apply_kernel<GENERATE, S, V>), dim3(g), dim3(kBlock), 0, st, base, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials)
+    if (vec) {
+        if (partials) SONAR_PA(true, 4); else SONAR_PA(false, 4);
+    } else {
+        if (partials) SONAR_PA(true, 1); else SONAR_PA(false, 1);
+    }
+#undef SONAR_PA
+    return check_launch(what);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resampling (F.interpolate semantics, ATen UpSampleKernel index/weight rules).
+struct Lin {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ Lin lin_coord(int dst, float scale, int in_size) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;   // align_corners=False
+    src = src < 0.0f ? 0.0f : src;
+    int i0 = (int)floorf(src);
+    i0 = i0 < in_size - 1 ? i0 : in_size - 1;
+    float l1 = src - (float)i0;
+    l1 = fminf(fmaxf(l1, 0.0f), 1.0f);
+    Lin r;
+    r.i0 = i0;
+    r.i1 = i0 + 1 < in_size - 1 ? i0 + 1 : in_size - 1;
+    r.w0 = 1.0f - l1;
+    r.w1 = l1;
+    return r;
+}
+__device__ __forceinline__ float bilerp(const float* __restrict__ plane, int w, const Lin& ly, const Lin& lx) {
+    const float* r0 = plane + (int64_t)ly.i0 * w;
+    const float* r1 = plane + (int64_t)ly.i1 * w;
+    const float t0 = r0[lx.i0] * lx.w0 + r0[lx.i1] * lx.w1;
+    const float t1 = r1[lx.i0] * lx.w0 + r1[lx.i1] * lx.w1;
+    return t0 * ly.w0 + t1 * ly.w1;
+}
+__device__ __forceinline__ int nearest_exact_idx(int dst, float scale, int in_size) {
+    const int i = (int)floorf(((float)dst + 0.5f) * scale);
+    return i < in_size - 1 ? i : in_size - 1;
+}
+__device__ __forceinline__ float area_sample(const float* __restrict__ plane, int h, int w, int H, int W, int y, int x) {
+    // adaptive average pooling window: [floor(i*in/out), ceil((i+1)*in/out))
+    const int y0 = (int)(((int64_t)y * h) / H), y1 = (int)((((int64_t)y + 1) * h + H - 1) / H);
+    const int x0 = (int)(((int64_t)x * w) / W), x1 = (int)((((int64_t)x + 1) * w + W - 1) / W);
+    float acc = 0.0f;
+    for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) acc += plane[(int64_t)yy * w + xx];
+    return acc / (float)((y1 - y0) * (x1 - x0));
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock) resample_acc_kernel(float* dst, const float* __restrict__ src, int64_t planes,
+                                                               int H, int W, int h, int w, float scale, int mode,
+                                                               int accumulate, double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
+    const int64_t total = planes * H * W;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int64_t p = i / ((int64_t)W * H);
+        const float* plane = src + p * (int64_t)h * w;
+        float v;
+        if (mode == 0) {
+            v = bilerp(plane, w, lin_coord(y, sy, h), lin_coord(x, sx, w));
+        } else if (mode == 1) {
+            v = plane[(int64_t)nearest_exact_idx(y, sy, h) * w + nearest_exact_idx(x, sx, w)];
+        } else {
+            v = area_sample(plane, h, w, H, W, y, x);
+        }
+        if (scale != 1.0f) v = v * scale;
+        if (accumulate) v = dst[i] + v;
+        dst[i] = v;
+        if constexpr (STATS) {
+            const double d = v;
+            s += d; q += d * d;
+        }
+    }
+    if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+}
+
+// Pyramid, generate mode: out = N(0,1)[stream] + N(0,1)[stream+1]*w0 + sum_l bilerp(level_l)*w_l
+constexpr int kMaxLevels = 12;
+struct PyramidLevels {
+    const float* ptr[kMaxLevels];
+    int h[kMaxLevels], w[kMaxLevels];
+    float weight[kMaxLevels];
+    int count;       // small-grid levels
+    int fullres;     // number of leading full-resolution levels drawn in-kernel (0 or 1)
+    float fullres_weight;
+};
+
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, int64_t planes, int H, int W,
+                                                                  PyramidLevels lv, int mode, uint64_t seed,
+                                                                  uint64_t stream_id, int64_t elem_offset,
+                                                                  double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
+    const int W4 = W >> 2;  // W % 4 == 0 enforced by the launcher
+    const int64_t total = planes * H * W4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int x4 = (int)(i % W4) * 4;
+        const int y = (int)((i / W4) % H);
+        const int64_t p = i / ((int64_t)W4 * H);
+        const int64_t e = (p * H + y) * (int64_t)W + x4;
+        const uint64_t g = (uint64_t)((elem_offset + e) >> 2);
+        float v[4];
+        philox_normal4(seed, stream_id, g, v);
+        if (lv.fullres) {
+            float z[4];
+            philox_normal4(seed, stream_id + 1, g, z);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += lv.fullres_weight != 1.0f ? z[k] * lv.fullres_weight : z[k];
+        }
+        for (int l = 0; l < lv.count; ++l) {
+            const int h = lv.h[l], w = lv.w[l];
+            const float* plane = lv.ptr[l] + p * (int64_t)h * w;
+            const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+            const float wt = lv.weight[l];
+            if (mode == 0) {
+                const Lin ly = lin_coord(y, sy, h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += bilerp(plane, w, ly, lin_coord(x4 + k, sx, w)) * wt;
+            } else if (mode == 1) {
+                const float* row = plane + (int64_t)nearest_exact_idx(y, sy, h) * w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += row[nearest_exact_idx(x4 + k, sx, w)] * wt;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += area_sample(plane, h, w, H, W, y, x4 + k) * wt;
+            }
+        }
+        *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (STATS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double d = v[k];
+                s += d; q += d * d;
+            }
+        }
+    }
+    if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+}
+
+}  // namespace sonar
+
+using namespace sonar;
+
+// ================================================================================================
+extern "C" int sonar_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                       double* partials, void* stream) {
+    SONAR_REQUIRE(out && n >= 0 && elem_offset >= 0, SONAR_ERR_ARG, "sonar_philox_normal_f32: bad argument");
+    return launch_fill<Dist::Normal>(out, n, seed, stream_id, elem_offset, Affine{0.f, 1.f, 0.f, 0}, partials,
+                                     (hipStream_t)stream, "sonar_philox_normal_f32");
+}
+
+extern "C" int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                        float sub, float mul, float add, double* partials, void* stream) {
+    SONAR_REQUIRE(out && n >= 0 && elem_offset >= 0, SONAR_ERR_ARG, "sonar_philox_uniform_f32: bad argument");
+    const int active = !(sub == 0.0f && mul == 1.0f && add == 0.0f);
+    return launch_fill<Dist::Uniform>(out, n, seed, stream_id, elem_offset, Affine{sub, mul, add, active}, partials,
+                                      (hipStream_t)stream, "sonar_philox_uniform_f32");
+}
+
+extern "C" int sonar_perlin_terms_f32(const float* angles, float* terms, int64_t iters, int64_t C, int64_t H, int64_t W,
+                                      int blend_mode, void* stream) {
+    SONAR_REQUIRE(angles && terms && iters >= 0 && C > 0 && H > 0 && W > 0 && blend_mode >= 0 && blend_mode <= 2,
+                  SONAR_ERR_ARG, "sonar_perlin_terms_f32: bad argument");
+    SONAR_REQUIRE(H < (1 << 20) && W < (1 << 20), SONAR_ERR_UNSUPPORTED, "sonar_perlin_terms_f32: plane too large");
+    if (iters == 0) return SONAR_OK;
+    const int64_t total = iters * C * H * W;
+    hipLaunchKernelGGL(perlin_terms_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, angles,
+                       terms, iters * C, (int)H, (int)W, blend_mode);
+    return check_launch("sonar_perlin_terms_f32");
+}
+
+extern "C" int sonar_perlin_apply_f32(const float* base, const float* terms, float* out, int64_t B, int64_t chw,
+                                      int64_t iters, float div_fac, double* partials, void* stream) {
+    SONAR_REQUIRE(base && out && (terms || iters == 0) && B >= 0 && chw > 0 && iters >= 0, SONAR_ERR_ARG,
+                  "sonar_perlin_apply_f32: bad argument");
+    return launch_perlin_apply<false>(base, terms, out, B, chw, iters, div_fac, 0, 0, 0, partials, (hipStream_t)stream,
+                                      "sonar_perlin_apply_f32");
+}
+
+extern "C" int sonar_perlin_generate_f32(const float* terms, float* out, int64_t B, int64_t chw, int64_t iters,
+                                         float div_fac, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                         double* partials, void* stream) {
+    SONAR_REQUIRE(out && (terms || iters == 0) && B >= 0 && chw > 0 && iters >= 0 && elem_offset >= 0, SONAR_ERR_ARG,
+                  "sonar_perlin_generate_f32: bad argument");
+    return launch_perlin_apply<true>(nullptr, terms, out, B, chw, iters, div_fac, seed, stream_id, elem_offset, partials,
+                                     (hipStream_t)stream, "sonar_perlin_generate_f32");
+}
+
+extern "C" int sonar_resample_acc_f32(float* dst, const float* src, int64_t planes, int64_t H, int64_t W, int64_t h,
+                                      int64_t w, float scale, int mode, int accumulate, double* partials, void* stream) {
+    SONAR_REQUIRE(dst && src && planes >= 0 && H > 0 && W > 0 && h > 0 && w > 0 && mode >= 0 && mode <= 2, SONAR_ERR_ARG,
+                  "sonar_resample_acc_f32: bad argument");
+    SONAR_REQUIRE(H < (1 << 24) && W < (1 << 24) && h < (1 << 24) && w < (1 << 24), SONAR_ERR_UNSUPPORTED,
+                  "sonar_resample_acc_f32: plane too large");
+    if (planes == 0) return SONAR_OK;
+    const int g = (int)std::min<int64_t>(kNPart, grid_for(planes * H * W, kBlock * 2));
+    if (partials)
+        hipLaunchKernelGGL((resample_acc_kernel<true>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, dst, src, planes,
+                           (int)H, (int)W, (int)h, (int)w, scale, mode, accumulate, partials);
+    else
+        hipLaunchKernelGGL((resample_acc_kernel<false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, dst, src, planes,
+                           (int)H, (int)W, (int)h, (int)w, scale, mode, accumulate, partials);
+    return check_launch("sonar_resample_acc_f32");
+}
+
+extern "C" int sonar_pyramid_generate_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels,
+                                          const float* const* level_ptrs, const int64_t* level_h, const int64_t* level_w,
+                                          const float* level_weight, int mode, uint64_t seed, uint64_t stream_id,
+                                          int64_t elem_offset, double* partials, void* stream) {
+    SONAR_REQUIRE(out && planes >= 0 && H > 0 && W > 0 && nlevels >= 0 && mode >= 0 && mode <= 2 && elem_offset >= 0,
+                  SONAR_ERR_ARG, "sonar_pyramid_generate_f32: bad argument");
+    SONAR_REQUIRE(nlevels == 0 || (level_ptrs && level_h && level_w && level_weight), SONAR_ERR_ARG,
+                  "sonar_pyramid_generate_f32: level arrays missing");
+    SONAR_REQUIRE(W % 4 == 0 && aligned16(out) && elem_offset % 4 == 0, SONAR_ERR_UNSUPPORTED,
+                  "sonar_pyramid_generate_f32: needs W %% 4 == 0 and 16-byte aligned output");
+    PyramidLevels lv{};
+    lv.count = 0;
+    lv.fullres = 0;
+    lv.fullres_weight = 1.0f;
+    for (int64_t l = 0; l < nlevels; ++l) {
+        if (level_ptrs[l] == nullptr) {
+            // a NULL pointer marks a full-resolution level drawn inside the kernel (stream_id + 1)
+            SONAR_REQUIRE(lv.fullres == 0 && level_h[l] == H && level_w[l] == W, SONAR_ERR_ARG,
+                          "sonar_pyramid_generate_f32: only one in-kernel full-resolution level");
+            lv.fullres = 1;
+            lv.fullres_weight = level_weight[l];
+            continue;
+        }
+        SONAR_REQUIRE(lv.count < kMaxLevels, SONAR_ERR_UNSUPPORTED, "sonar_pyramid_generate_f32: too many levels");
+        lv.ptr[lv.count] = level_ptrs[l];
+        lv.h[lv.count] = (int)level_h[l];
+        lv.w[lv.count] = (int)level_w[l];
+        lv.weight[lv.count] = level_weight[l];
+        ++lv.count;
+    }
+    if (planes == 0) return SONAR_OK;
+    const int g = (int)std::min<int64_t>(kNPart, grid_for(planes * H * (W / 4), kBlock));
+    if (partials)
+        hipLaunchKernelGGL((pyramid_generate_kernel<true>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes,
+                           (int)H, (int)W, lv, mode, seed, stream_id, elem_offset, partials);
+    else
+        hipLaunchKernelGGL((pyramid_generate_kernel<false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes,
+                           (int)H, (int)W, lv, mode, seed, stream_id, elem_offset, partials);
+    return check_launch("sonar_pyramid_generate_f32");
+}

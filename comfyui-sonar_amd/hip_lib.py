@@ -1,0 +1,409 @@
+"""ctypes binding of libsonar_hip.so (the C ABI declared in include/sonar_hip.h).
+
+PyTorch is used for device memory and streams only; every function here hands raw device
+pointers (``tensor.data_ptr()``) and the current HIP stream to a hand-written kernel.
+There is NO fallback: a missing library, a CPU tensor or a non-zero return code raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch  # noqa: F401  (must be imported before the .so so both share one HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsonar_hip.so")
+
+BLEND_IDS = {"lerp": 0, "inject": 1, "subtract_b": 2}
+MODE_IDS = {"CLASSIC": 0, "NEW": 1, "DENOISED": 2}
+INIT_IDS = {"NONE": 0, "SAMPLE": 1, "SAMPLE_NORM": 2}
+RESAMPLE_IDS = {"bilinear": 0, "nearest-exact": 1, "area": 2, "adaptive_avg_pool2d": 2}
+DWT_MODE_IDS = {"zero": 0, "symmetric": 1, "reflect": 2, "periodization": 3, "periodic": 4, "constant": 5, "replicate": 5}
+NPART = 1024
+
+
+class SonarHipError(RuntimeError):
+    pass
+
+
+class MomentumCfg(C.Structure):
+    """Mirror of ``sonar_momentum_cfg`` (include/sonar_hip.h)."""
+
+    _fields_ = [
+        ("momentum", C.c_float),
+        ("hist_ratio", C.c_float),
+        ("hist_scale", C.c_float),
+        ("md_scale", C.c_float),
+        ("mode", C.c_int32),
+        ("momentum_blend", C.c_int32),
+        ("history_blend", C.c_int32),
+        ("use_momentum", C.c_int32),
+        ("update_hist", C.c_int32),
+        ("init_kind", C.c_int32),
+        ("h_in_fresh", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_U64 = C.c_uint64
+_F = C.c_float
+_D = C.c_double
+_I = C.c_int
+_PD = C.POINTER(C.c_double)
+_PI64 = C.POINTER(C.c_int64)
+_PF = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every symbol declared in include/sonar_hip.h
+SIGNATURES = {
+    "sonar_abi_version": (_I, []),
+    "sonar_last_error": (C.c_char_p, []),
+    "sonar_stats_f32": (_I, [_P, _I64, _P, _P]),
+    "sonar_stats_finalize": (_I, [_P, _I64, _I64, _P, _P]),
+    "sonar_scale_noise_f32": (_I, [_P, _I64, _F, _I, _F, _P, _I64, _I64, _P]),
+    "sonar_scale_noise_rows_f32": (_I, [_P, _I64, _I64, _F, _P]),
+    "sonar_blend_f32": (_I, [_I, _P, _P, _F, _P, _I64, _P]),
+    "sonar_blend_tensor_f32": (_I, [_I, _P, _P, _P, _I64, _P, _I64, _P]),
+    "sonar_axpby_f32": (_I, [_P, _F, _P, _F, _I64, _P]),
+    "sonar_mask_mix_f32": (_I, [_P, _P, _P, _I64, _P, _I64, _P]),
+    "sonar_minmax_rows_f32": (_I, [_P, _I64, _I64, _P, _P, _P]),
+    "sonar_momentum_euler_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
+    "sonar_dpmpp_stage1_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
+    "sonar_dpmpp_stage2_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
+    "sonar_philox_normal_f32": (_I, [_P, _I64, _U64, _U64, _I64, _P, _P]),
+    "sonar_philox_uniform_f32": (_I, [_P, _I64, _U64, _U64, _I64, _F, _F, _F, _P, _P]),
+    "sonar_perlin_terms_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
+    "sonar_perlin_apply_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P]),
+    "sonar_perlin_generate_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _P, _P]),
+    "sonar_resample_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I64, _F, _I, _I, _P, _P]),
+    "sonar_pyramid_generate_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _P, _P]),
+    "sonar_power_irfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _P, _P]),
+    "sonar_rfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
+    "sonar_channel_mix_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "sonar_dwt_out_len": (_I64, [_I64, _I64, _I]),
+    "sonar_dwt2_fwd_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
+    "sonar_dwt2_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
+    "sonar_dwt2_inv_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
+    "sonar_dwt2_inv_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
+    "sonar_wcfg_band_f32": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
+    "sonar_wcfg_band_f64": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
+    "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
+    "sonar_cast_f32_f64": (_I, [_P, _P, _I64, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libsonar_hip.so or raise (never falls back to anything else)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SonarHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950). There is no non-HIP implementation of this path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sonar_last_error().decode("utf-8", "replace")
+        raise SonarHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise SonarHipError(f"{name}: tensor lives on {t.device}; the Sonar HIP path only runs on a ROCm device")
+    if t.dtype != dtype:
+        raise SonarHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise SonarHipError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype=torch.float32):
+    return None if t is None else _dev(t, name, dtype)
+
+
+def new_partials(device) -> torch.Tensor:
+    """Workspace for the (sum, sumsq) partial pairs of one normalisation point."""
+    return torch.empty(NPART * 2, dtype=torch.float64, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ stats / scale_noise
+def stats(x: torch.Tensor, partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+    partials = new_partials(x.device) if partials is None else partials
+    _check(load().sonar_stats_f32(_dev(x, "x"), x.numel(), _dev(partials, "partials", torch.float64), _stream()), "sonar_stats_f32")
+    return partials
+
+
+def stats_finalize(partials: torch.Tensor, n: int, npart: int = NPART) -> torch.Tensor:
+    out = torch.empty(3, dtype=torch.float64, device=partials.device)
+    _check(
+        load().sonar_stats_finalize(_dev(partials, "partials", torch.float64), npart, n, _dev(out, "out", torch.float64), _stream()),
+        "sonar_stats_finalize",
+    )
+    return out
+
+
+def scale_noise_(x: torch.Tensor, factor: float, normalized: bool, partials: Optional[torch.Tensor], *,
+                 threshold_std_devs: float = 2.5, npart: int = NPART, n_total: Optional[int] = None) -> torch.Tensor:
+    n = x.numel()
+    _check(
+        load().sonar_scale_noise_f32(
+            _dev(x, "x"), n, float(factor), int(bool(normalized)), float(threshold_std_devs),
+            _opt(partials, "partials", torch.float64), npart, n if n_total is None else n_total, _stream(),
+        ),
+        "sonar_scale_noise_f32",
+    )
+    return x
+
+
+def scale_noise_rows_(x: torch.Tensor, rows: int, inner: int, factor: float) -> torch.Tensor:
+    _check(load().sonar_scale_noise_rows_f32(_dev(x, "x"), rows, inner, float(factor), _stream()), "sonar_scale_noise_rows_f32")
+    return x
+
+
+def minmax_rows(x: torch.Tensor, rows: int, inner: int):
+    lo = torch.empty(rows, dtype=torch.float32, device=x.device)
+    hi = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _check(load().sonar_minmax_rows_f32(_dev(x, "x"), rows, inner, _dev(lo, "lo"), _dev(hi, "hi"), _stream()), "sonar_minmax_rows_f32")
+    return lo, hi
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def blend(mode: str, a: torch.Tensor, b: torch.Tensor, t, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(a) if out is None else out
+    if a.shape != b.shape:
+        raise SonarHipError(f"blend: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    if isinstance(t, torch.Tensor) and t.numel() > 1:
+        if a.numel() % t.numel() != 0:
+            raise SonarHipError("blend: weight tensor does not tile the operands")
+        _check(
+            load().sonar_blend_tensor_f32(BLEND_IDS[mode], _dev(a, "a"), _dev(b, "b"), _dev(t, "t"), t.numel(), _dev(out, "out"), a.numel(), _stream()),
+            "sonar_blend_tensor_f32",
+        )
+    else:
+        _check(
+            load().sonar_blend_f32(BLEND_IDS[mode], _dev(a, "a"), _dev(b, "b"), float(t), _dev(out, "out"), a.numel(), _stream()),
+            "sonar_blend_f32",
+        )
+    return out
+
+
+def axpby_(y: torch.Tensor, ymul: float, x: torch.Tensor, xmul: float) -> torch.Tensor:
+    if x.shape != y.shape:
+        raise SonarHipError(f"axpby: shape mismatch {tuple(x.shape)} vs {tuple(y.shape)}")
+    _check(load().sonar_axpby_f32(_dev(y, "y"), float(ymul), _dev(x, "x"), float(xmul), y.numel(), _stream()), "sonar_axpby_f32")
+    return y
+
+
+def mask_mix(dst: torch.Tensor, src: torch.Tensor, mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(dst) if out is None else out
+    if dst.numel() % mask.numel() != 0:
+        raise SonarHipError("mask_mix: mask does not tile the operands")
+    _check(
+        load().sonar_mask_mix_f32(_dev(dst, "dst"), _dev(src, "src"), _dev(mask, "mask"), mask.numel(), _dev(out, "out"), dst.numel(), _stream()),
+        "sonar_mask_mix_f32",
+    )
+    return out
+
+
+def cast_f32_f64(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(x.shape, dtype=torch.float64, device=x.device)
+    _check(load().sonar_cast_f32_f64(_dev(x, "x"), _dev(out, "out", torch.float64), x.numel(), _stream()), "sonar_cast_f32_f64")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ momentum
+def momentum_euler(x, denoised, h_in, cfg: MomentumCfg, sigma: float, dt: float, *, noise=None, noise_scale: float = 0.0,
+                   x_out=None, h_out=None):
+    x_out = torch.empty_like(x) if x_out is None else x_out
+    h_out = torch.empty_like(x) if h_out is None else h_out
+    present = C.c_int(0)
+    _check(
+        load().sonar_momentum_euler_f32(
+            _dev(x, "x"), _dev(denoised, "denoised"), _opt(h_in, "h_in"), _dev(x_out, "x_out"), _dev(h_out, "h_out"),
+            _opt(noise, "noise"), float(noise_scale), float(sigma), float(dt), C.byref(cfg), x.numel(), C.byref(present), _stream(),
+        ),
+        "sonar_momentum_euler_f32",
+    )
+    return x_out, (h_out if present.value else None)
+
+
+def dpmpp_stage1(x, denoised, h_in, cfg: MomentumCfg, sigma: float, expm1_a: float, ratio_a: float, adj_is_one: bool, *,
+                 noise=None, noise_scale: float = 0.0):
+    x2 = torch.empty_like(x)
+    md1 = torch.empty_like(x)
+    h_out = torch.empty_like(x)
+    present = C.c_int(0)
+    _check(
+        load().sonar_dpmpp_stage1_f32(
+            _dev(x, "x"), _dev(denoised, "denoised"), _opt(h_in, "h_in"), _dev(x2, "x2"), _dev(md1, "md1"), _dev(h_out, "h_out"),
+            _opt(noise, "noise"), float(noise_scale), float(sigma), float(expm1_a), float(ratio_a), int(bool(adj_is_one)),
+            C.byref(cfg), x.numel(), C.byref(present), _stream(),
+        ),
+        "sonar_dpmpp_stage1_f32",
+    )
+    return x2, md1, (h_out if present.value else None)
+
+
+def dpmpp_stage2(x, denoised2, md1, h_in, cfg: MomentumCfg, sigma_s: float, expm1_b: float, ratio_b: float, fac: float,
+                 adj_is_one: bool, *, noise=None, noise_scale: float = 0.0, want_dd: bool = False):
+    x_out = torch.empty_like(x)
+    dd = torch.empty_like(x) if want_dd else None
+    h_out = torch.empty_like(x)
+    present = C.c_int(0)
+    _check(
+        load().sonar_dpmpp_stage2_f32(
+            _dev(x, "x"), _dev(denoised2, "denoised2"), _dev(md1, "md1"), _opt(h_in, "h_in"), _dev(x_out, "x_out"), _opt(dd, "dd"),
+            _dev(h_out, "h_out"), _opt(noise, "noise"), float(noise_scale), float(sigma_s), float(expm1_b), float(ratio_b),
+            float(fac), int(bool(adj_is_one)), C.byref(cfg), x.numel(), C.byref(present), _stream(),
+        ),
+        "sonar_dpmpp_stage2_f32",
+    )
+    return x_out, dd, (h_out if present.value else None)
+
+
+# ------------------------------------------------------------------------------------------------ generators
+def philox_normal(shape, device, seed: int, stream_id: int, elem_offset: int = 0, partials=None, out=None) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=device) if out is None else out
+    _check(
+        load().sonar_philox_normal_f32(_dev(out, "out"), out.numel(), seed & (2**64 - 1), stream_id, elem_offset,
+                                       _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_philox_normal_f32",
+    )
+    return out
+
+
+def philox_uniform(shape, device, seed: int, stream_id: int, elem_offset: int = 0, *, sub=0.0, mul=1.0, add=0.0,
+                   partials=None, out=None) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=device) if out is None else out
+    _check(
+        load().sonar_philox_uniform_f32(_dev(out, "out"), out.numel(), seed & (2**64 - 1), stream_id, elem_offset,
+                                        float(sub), float(mul), float(add), _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_philox_uniform_f32",
+    )
+    return out
+
+
+def perlin_terms(angles: torch.Tensor, blend_mode: str = "lerp") -> torch.Tensor:
+    """angles [iters, C, H+1, W+1] -> terms [iters, C, H, W]"""
+    iters, c, gh, gw = angles.shape
+    terms = torch.empty((iters, c, gh - 1, gw - 1), dtype=torch.float32, device=angles.device)
+    _check(
+        load().sonar_perlin_terms_f32(_dev(angles, "angles"), _dev(terms, "terms"), iters, c, gh - 1, gw - 1, BLEND_IDS[blend_mode], _stream()),
+        "sonar_perlin_terms_f32",
+    )
+    return terms
+
+
+def perlin_apply(base: torch.Tensor, terms: torch.Tensor, div_fac: float, partials=None) -> torch.Tensor:
+    out = torch.empty_like(base)
+    b = base.shape[0]
+    chw = base.numel() // max(b, 1)
+    _check(
+        load().sonar_perlin_apply_f32(_dev(base, "base"), _dev(terms, "terms"), _dev(out, "out"), b, chw, terms.shape[0], float(div_fac),
+                                      _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_perlin_apply_f32",
+    )
+    return out
+
+
+def perlin_generate(shape, terms: torch.Tensor, div_fac: float, seed: int, stream_id: int, elem_offset: int = 0, partials=None) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=terms.device)
+    b = shape[0]
+    chw = out.numel() // max(b, 1)
+    _check(
+        load().sonar_perlin_generate_f32(_dev(terms, "terms"), _dev(out, "out"), b, chw, terms.shape[0], float(div_fac),
+                                         seed & (2**64 - 1), stream_id, elem_offset, _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_perlin_generate_f32",
+    )
+    return out
+
+
+def resample_acc_(dst: torch.Tensor, src: torch.Tensor, scale: float, mode: str = "bilinear", accumulate: bool = True, partials=None) -> torch.Tensor:
+    """dst[..., H, W] (+)= resample(src[..., h, w]) * scale"""
+    H, W = dst.shape[-2:]
+    h, w = src.shape[-2:]
+    planes = dst.numel() // (H * W)
+    if src.numel() // (h * w) != planes:
+        raise SonarHipError("resample_acc: plane count mismatch")
+    _check(
+        load().sonar_resample_acc_f32(_dev(dst, "dst"), _dev(src, "src"), planes, H, W, h, w, float(scale), RESAMPLE_IDS[mode],
+                                      int(bool(accumulate)), _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_resample_acc_f32",
+    )
+    return dst
+
+
+def pyramid_generate(shape, device, levels: Sequence, mode: str, seed: int, stream_id: int, elem_offset: int = 0, partials=None) -> torch.Tensor:
+    """levels: list of (tensor-or-None, h, w, weight); None marks the in-kernel full-resolution level."""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    H, W = shape[-2:]
+    planes = out.numel() // (H * W)
+    n = len(levels)
+    ptrs = (_P * max(n, 1))(*[(None if lv[0] is None else _dev(lv[0], "level")) for lv in levels])
+    hs = (C.c_int64 * max(n, 1))(*[int(lv[1]) for lv in levels])
+    ws = (C.c_int64 * max(n, 1))(*[int(lv[2]) for lv in levels])
+    wts = (C.c_float * max(n, 1))(*[float(lv[3]) for lv in levels])
+    _check(
+        load().sonar_pyramid_generate_f32(_dev(out, "out"), planes, H, W, n, ptrs, hs, ws, wts, RESAMPLE_IDS[mode], seed & (2**64 - 1),
+                                          stream_id, elem_offset, _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_pyramid_generate_f32",
+    )
+    return out
+
+
+def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: int = 0, stream_id: int = 0, cplx_offset: int = 0,
+                 partials=None) -> torch.Tensor:
+    """out[shape] = irfft2(z * filt, norm='ortho'); z = None draws the spectrum on device."""
+    H, W = shape[-2:]
+    out = torch.empty(shape, dtype=torch.float32, device=filt.device)
+    planes = out.numel() // (H * W)
+    zp = None
+    if z is not None:
+        if z.dtype != torch.complex64 or not z.is_cuda or not z.is_contiguous():
+            raise SonarHipError("power_irfft2: z must be a contiguous complex64 device tensor")
+        if z.numel() != planes * H * (W // 2 + 1):
+            raise SonarHipError("power_irfft2: spectrum size mismatch")
+        zp = z.data_ptr()
+    if filt.numel() != H * (W // 2 + 1):
+        raise SonarHipError("power_irfft2: filter size mismatch")
+    _check(
+        load().sonar_power_irfft2_f32(zp, _dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, cplx_offset,
+                                      _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_power_irfft2_f32",
+    )
+    return out
+
+
+def power_supported(H: int, W: int) -> bool:
+    return (H, W) in {(128, 128), (64, 64), (32, 32), (16, 16), (256, 128), (128, 256), (128, 64), (64, 128), (64, 32), (32, 64), (256, 64), (64, 256)}
+
+
+def channel_mix(x: torch.Tensor, mixer: torch.Tensor, partials=None) -> torch.Tensor:
+    b, c = x.shape[:2]
+    hw = x.numel() // (b * c)
+    out = torch.empty_like(x)
+    _check(
+        load().sonar_channel_mix_f32(_dev(x, "x"), _dev(mixer, "mixer"), _dev(out, "out"), b, c, hw, _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_channel_mix_f32",
+    )
+    return out

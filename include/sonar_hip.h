@@ -1,0 +1,219 @@
+/*
+ * sonar_hip.h — C ABI of libsonar_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary for the procedural-noise + momentum-step + wavelet-split hot
+ * path of blepping/ComfyUI-sonar (last row).  The reference is 100 % Python over
+ * torch ops, so it has no FFI of its own; every entry point below replaces one torch-op
+ * sequence of the reference, cited as `file:line` relative to the reference root.
+ *
+ * Conventions (all entry points):
+ *   - returns 0 on success, SONAR_ERR_* (<0) on failure; sonar_last_error() gives the text
+ *   - every buffer is a caller-owned DEVICE pointer (PyTorch-ROCm tensor.data_ptr()),
+ *     contiguous NCHW, fp32 unless the name says f64; sizes are int64_t; scalars by value
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no device sync, no allocation
+ *   - workspace, when needed, is passed in by the caller (sonar_*_ws_bytes gives the size)
+ *   - "partials" = array of `npart` (sum, sum-of-squares) fp64 pairs produced by a producing
+ *     kernel and consumed by sonar_scale_noise_f32 (which reduces them in a fixed order on
+ *     device, so normalisation needs no host sync and no atomics)
+ */
+#ifndef SONAR_HIP_H
+#define SONAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SONAR_OK 0
+#define SONAR_ERR_ARG (-1)         /* null pointer / negative size / bad enum */
+#define SONAR_ERR_UNSUPPORTED (-2) /* shape the kernel does not handle */
+#define SONAR_ERR_HIP (-3)         /* HIP runtime error, see sonar_last_error() */
+
+/* blend modes: py/utils.py:17-21 (BLENDING_MODES) */
+#define SONAR_BLEND_LERP 0       /* torch.lerp(a, b, t) */
+#define SONAR_BLEND_INJECT 1     /* a + b*t */
+#define SONAR_BLEND_SUBTRACT_B 2 /* a - b*t */
+
+/* momentum modes: py/sonar.py:40-43 */
+#define SONAR_MODE_CLASSIC 0
+#define SONAR_MODE_NEW 1
+#define SONAR_MODE_DENOISED 2
+
+/* history init applied inside the step when no history exists yet: py/sonar.py:169-206 */
+#define SONAR_INIT_NONE 0        /* ZERO (history stays unset) or history already present */
+#define SONAR_INIT_SAMPLE 1      /* history = x (denoised in DENOISED mode) */
+#define SONAR_INIT_SAMPLE_NORM 2 /* history = x / sigma (denoised / sigma in DENOISED mode) */
+
+/* number of (sum,sumsq) partial pairs every stats-producing kernel writes */
+#define SONAR_NPART 1024
+
+int sonar_abi_version(void);
+const char* sonar_last_error(void);
+
+/* ---------------------------------------------------------------- normalisation (row N) */
+/* py/utils.py:100 — whole-tensor mean/std inputs: writes SONAR_NPART fp64 (sum,sumsq) pairs */
+int sonar_stats_f32(const float* x, int64_t n, double* partials, void* stream);
+/* reduce partials -> out3 = {sum, sumsq, n} (device fp64[3]); used for the optional cross-rank
+ * all-reduce and by tests */
+int sonar_stats_finalize(const double* partials, int64_t npart, int64_t n, double* out3, void* stream);
+/* py/utils.py:93-106 — scale_noise: normalized=0 -> x*=factor; normalized=1 -> data-dependent
+ * (x-mean)/std with thresholds threshold_std_devs/sqrt(n_total) evaluated ON DEVICE, then *factor.
+ * partials/npart: from any producing kernel; n_total: element count the stats cover (may exceed
+ * n when the stats were all-reduced over ranks).  In place. */
+int sonar_scale_noise_f32(float* x, int64_t n, float factor, int normalized, float threshold_std_devs,
+                          const double* partials, int64_t npart, int64_t n_total, void* stream);
+/* py/utils.py:96-99 — normalize_dims variant: rows = groups, each of `inner` contiguous elements:
+ * y = x/std_row; y -= mean_row(y); y *= factor.  (dims must be trailing & contiguous) */
+int sonar_scale_noise_rows_f32(float* x, int64_t rows, int64_t inner, float factor, void* stream);
+
+/* ---------------------------------------------------------------- elementwise (rows U, C, S, L) */
+/* out = blend(a, b, t) — py/utils.py:17-21; out may alias a or b */
+int sonar_blend_f32(int mode, const float* a, const float* b, float t, float* out, int64_t n, void* stream);
+/* out = blend(a, b, t[i % tn]) with per-element/broadcast weights (BlendedNoise mask, py/noise.py:1364-1379) */
+int sonar_blend_tensor_f32(int mode, const float* a, const float* b, const float* t, int64_t tn, float* out,
+                           int64_t n, void* stream);
+/* y = y*ymul + x*xmul  (chain accumulate py/noise.py:192; ancestral noise add py/sonar.py:565) */
+int sonar_axpby_f32(float* y, float ymul, const float* x, float xmul, int64_t n, void* stream);
+/* CompositeNoise py/noise.py:524-531: out = dst*(1-mask) + src*mask; mask is [mask_n] broadcast over n/mask_n */
+int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,
+                       int64_t n, void* stream);
+/* py/utils.py:452-470 normalize_to_scale: per row min/max rescale to [lo,hi] */
+int sonar_minmax_rows_f32(const float* x, int64_t rows, int64_t inner, float* out_min, float* out_max, void* stream);
+
+/* ---------------------------------------------------------------- momentum step (rows M, M2) */
+typedef struct sonar_momentum_cfg {
+    float momentum;      /* SonarConfig.momentum             py/sonar.py:47 */
+    float hist_ratio;    /* history_ratios[0] = momentum_hist py/sonar.py:208-219 */
+    float hist_scale;    /* history_ratios[1] */
+    float md_scale;      /* history_ratios[2] = direction */
+    int32_t mode;        /* SONAR_MODE_* */
+    int32_t momentum_blend; /* SONAR_BLEND_* for momentum_mix  py/sonar.py:256-260 */
+    int32_t history_blend;  /* SONAR_BLEND_* for update_hist   py/sonar.py:231-236 */
+    int32_t use_momentum;   /* check_step(step)                py/sonar.py:221-225 */
+    int32_t update_hist;    /* momentum_hist != 1 && check_step(step, is_history=True) */
+    int32_t init_kind;      /* SONAR_INIT_* (applies only when h_in == NULL) */
+    int32_t h_in_fresh;     /* 1: h_in was created by RAND init in this very step -> not used by the
+                               denoised-mix of this step (py/sonar.py:273-283 reads hd before init) */
+    int32_t reserved;
+} sonar_momentum_cfg;
+
+/* One Sonar Euler step, fused (py/sonar.py:262-320): x_out = momentum_d*(sigma_down-sigma) + x and
+ * the twice-updated history.  h_in may be NULL (no history yet); h_out must be valid whenever the
+ * step can create/update history; *h_out_present (host int, may be NULL) tells whether h_out holds
+ * a history afterwards.  noise (nullable) adds noise*noise_scale (ancestral, py/sonar.py:563-566).
+ * x_out may alias x; h_out may alias h_in. */
+int sonar_momentum_euler_f32(const float* x, const float* denoised, const float* h_in, float* x_out,
+                             float* h_out, const float* noise, float noise_scale, float sigma, float dt,
+                             const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, void* stream);
+
+/* DPM-Solver++(SDE) half steps, py/sonar.py:649-735.  Stage 1:
+ *   md1 = MD(den, sigma); m_d = D(expm1_a * md1); x2 = ratio_a*x - m_d + noise*noise_scale
+ * Stage 2 (den2 = model(x2, sigma_s)):
+ *   md2 = MD(den2, sigma_s); dd = (1-fac)*md1 + fac*md2; m_d = D(expm1_b * dd);
+ *   x_out = ratio_b*x - m_d (+ noise*noise_scale when noise != NULL)
+ * `adj_is_one` reproduces the `adjusted_momentum == 1` early-out of get_momentum_d while the
+ * blend weight stays cfg->momentum (py/sonar.py:298-303). */
+int sonar_dpmpp_stage1_f32(const float* x, const float* denoised, const float* h_in, float* x2_out, float* md1_out,
+                           float* h_out, const float* noise, float noise_scale, float sigma, float expm1_a,
+                           float ratio_a, int adj_is_one, const sonar_momentum_cfg* cfg, int64_t n,
+                           int* h_out_present, void* stream);
+int sonar_dpmpp_stage2_f32(const float* x, const float* denoised2, const float* md1, const float* h_in,
+                           float* x_out, float* dd_out, float* h_out, const float* noise, float noise_scale,
+                           float sigma_s, float expm1_b, float ratio_b, float fac, int adj_is_one,
+                           const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, void* stream);
+
+/* ---------------------------------------------------------------- base generators (rows G1, G2) */
+/* On-device counter RNG (Philox4x32-10, key=seed, counter=global element index/4, stream id):
+ * value of element e depends only on (seed, stream_id, elem_offset+e) -> shard-count invariant. */
+int sonar_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                            double* partials /*nullable*/, void* stream);
+/* out = (u - sub)*mul + add, u~U[0,1)  (py/noise_generation.py:508-514) */
+int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                             float sub, float mul, float add, double* partials /*nullable*/, void* stream);
+
+/* ---------------------------------------------------------------- Perlin (row P) */
+/* py/noise_generation.py:465-476,388-405 at the only position generate() uses (grid == output,
+ * block 1x1, pos (0.5,0.5)): angles[iters][C][H+1][W+1] -> terms[iters][C][H][W] evaluating the
+ * reference's blend tree.  blend_mode: SONAR_BLEND_* */
+int sonar_perlin_terms_f32(const float* angles, float* terms, int64_t iters, int64_t C, int64_t H, int64_t W,
+                           int blend_mode, void* stream);
+/* replay mode, py/noise_generation.py:478-493: out = base/div_fac (+ terms[i] broadcast over B, in order) */
+int sonar_perlin_apply_f32(const float* base, const float* terms, float* out, int64_t B, int64_t chw,
+                           int64_t iters, float div_fac, double* partials /*nullable*/, void* stream);
+/* generate mode: base u~U[0,1) from Philox(seed, stream_id, elem_offset+e) fused with the above */
+int sonar_perlin_generate_f32(const float* terms, float* out, int64_t B, int64_t chw, int64_t iters, float div_fac,
+                              uint64_t seed, uint64_t stream_id, int64_t elem_offset, double* partials /*nullable*/,
+                              void* stream);
+
+/* ---------------------------------------------------------------- Pyramid (row Y) */
+/* dst[B*C][H][W] += bilinear_upsample(src[B*C][h][w]) * scale   (F.interpolate(mode="bilinear",
+ * align_corners=False), py/utils.py:58-67 <- py/noise_generation.py:629-646).  mode: 0 bilinear,
+ * 1 nearest-exact, 2 area (adaptive average, used when downscaling) */
+int sonar_resample_acc_f32(float* dst, const float* src, int64_t planes, int64_t H, int64_t W, int64_t h, int64_t w,
+                           float scale, int mode, int accumulate, double* partials /*nullable*/, void* stream);
+/* generate mode: out = N(0,1) + sum_l upsample(levels[l])*weights[l]; levels are device pointers to
+ * [planes][h_l][w_l] small grids (level 0 = full-res draws folded in as a second Philox stream) */
+int sonar_pyramid_generate_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels,
+                               const float* const* level_ptrs /*host array of device ptrs*/, const int64_t* level_h,
+                               const int64_t* level_w, const float* level_weight, int mode, uint64_t seed,
+                               uint64_t stream_id, int64_t elem_offset, double* partials /*nullable*/, void* stream);
+
+/* ---------------------------------------------------------------- power-law rFFT noise (row PW) */
+/* py/nodes/powernoise.py:366-377: out = irfft2(z * filter, s=(H,W), norm="ortho").
+ *   z      [planes][H][W/2+1] complex64 (interleaved re,im) or NULL -> drawn on device:
+ *          complex normal (a+ib)*sqrt(1/2) from Philox(seed, stream_id, complex index)
+ *   filter [H][W/2+1] fp32 (broadcast over planes)
+ * Supported: H, W powers of two, 8 <= H,W <= 256 (else SONAR_ERR_UNSUPPORTED; the host falls back
+ * to nothing — it raises). */
+int sonar_power_irfft2_f32(const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,
+                           uint64_t seed, uint64_t stream_id, int64_t cplx_offset, double* partials /*nullable*/,
+                           void* stream);
+/* forward: spec[planes][H][W/2+1] = rfft2(x, norm="ortho") * filter (filter nullable)
+ * (PowerFilterNoiseItem / time_brownian path, py/nodes/powernoise.py:368-370) */
+int sonar_rfft2_f32(const float* x, const float* filter, float* spec, int64_t planes, int64_t H, int64_t W,
+                    void* stream);
+/* py/nodes/powernoise.py:96-101 ChannelMixer.apply: out[b][i] = sum_j mixer[i][j] * in[b][j] over planes of hw */
+int sonar_channel_mix_f32(const float* in, const float* mixer, float* out, int64_t B, int64_t C, int64_t hw,
+                          double* partials /*nullable*/, void* stream);
+
+/* ---------------------------------------------------------------- 2-D DWT / IDWT (rows W, WC, WF) */
+/* pytorch_wavelets DWTForward/DWTInverse semantics == pywt.dwt2/idwt2 per level
+ * (py/wavelet_functions.py:56-105).  One level per call; the host loops levels.
+ *   mode: 0 zero, 1 symmetric, 2 reflect, 3 periodization, 4 periodic(ppd), 5 constant(replicate)
+ *   dec_lo/dec_hi (rec_lo/rec_hi): host arrays of `flen` taps (pywt order)
+ *   forward : x[planes][H][W] -> ll[planes][h][w], hi[planes][3][h][w] (LH,HL,HH == pywt cH,cV,cD)
+ *   inverse : ll, hi -> out[planes][Ho][Wo]  (Ho,Wo = requested output size <= full reconstruction)
+ */
+int64_t sonar_dwt_out_len(int64_t n, int64_t flen, int mode);
+int sonar_dwt2_fwd_f32(const float* x, float* ll, float* hi, int64_t planes, int64_t H, int64_t W,
+                       const double* dec_lo, const double* dec_hi, int flen, int mode, void* stream);
+int sonar_dwt2_fwd_f64(const double* x, double* ll, double* hi, int64_t planes, int64_t H, int64_t W,
+                       const double* dec_lo, const double* dec_hi, int flen, int mode, void* stream);
+int sonar_dwt2_inv_f32(const float* ll, const float* hi, float* out, int64_t planes, int64_t h, int64_t w,
+                       int64_t Ho, int64_t Wo, const double* rec_lo, const double* rec_hi, int flen, int mode,
+                       void* stream);
+int sonar_dwt2_inv_f64(const double* ll, const double* hi, double* out, int64_t planes, int64_t h, int64_t w,
+                       int64_t Ho, int64_t Wo, const double* rec_lo, const double* rec_hi, int flen, int mode,
+                       void* stream);
+/* WaveletCFG band arithmetic, py/wavelet_cfg.py:750-791, for one band tensor of n elements made of
+ * `groups` equal contiguous groups (orientation slices) each with its own scale set:
+ *   c = cond*s_cond[g]; u = uncond*s_uncond[g]; d = (c-u)*s_diff[g]; r = blend(u, d, strength)*s_final[g]
+ * s_* are host arrays of `groups` doubles. */
+int sonar_wcfg_band_f32(const float* cond, const float* uncond, float* out, int64_t n, int64_t groups,
+                        const double* s_cond, const double* s_uncond, const double* s_diff, const double* s_final,
+                        int blend_mode, double strength, void* stream);
+int sonar_wcfg_band_f64(const double* cond, const double* uncond, double* out, int64_t n, int64_t groups,
+                        const double* s_cond, const double* s_uncond, const double* s_diff, const double* s_final,
+                        int blend_mode, double strength, void* stream);
+/* process_output for target=denoised, py/wavelet_cfg.py:740-745: out = x - crop(result) with dtype
+ * conversion; result is [planes][Hr][Wr] (f64 or f32), x/out are [planes][H][W] fp32 */
+int sonar_wcfg_output_f32(const float* x, const void* result, int result_is_f64, float* out, int64_t planes,
+                          int64_t H, int64_t W, int64_t Hr, int64_t Wr, int subtract_from_x, void* stream);
+/* fp32 <-> fp64 conversion of a contiguous buffer (get_context cast, py/wavelet_cfg.py:707,764-765) */
+int sonar_cast_f32_f64(const float* in, double* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SONAR_HIP_H */

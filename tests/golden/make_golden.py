@@ -1,0 +1,421 @@
+"""Generates tests/golden/*.npz by running the REAL reference (imported from /root/reference through
+oracle/ref_import.py) in the build container.  Container-only tool: the reference's Python never
+travels; only these vectors (inputs incl. the captured base random draws, and expected outputs) do.
+
+    python tests/golden/make_golden.py
+
+Each case is also run through oracle/sonar_oracle.py here, and generation aborts if the oracle does
+not reproduce the reference (bit-exact where the op sequence is identical).
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import sonar_oracle as orc  # noqa: E402
+from oracle.ref_import import load_reference  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+ref = load_reference()
+NT = ref.noise_generation.NoiseType
+
+
+def save(name, **arrays):
+    conv = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def must_equal(a, b, what):
+    if not torch.equal(a, b):
+        raise SystemExit(f"oracle != reference for {what}: max |diff| = {(a - b).abs().max().item():.3e}")
+
+
+# ------------------------------------------------------------------------------------------------ scale_noise
+def gen_scale_noise():
+    g = torch.Generator().manual_seed(11)
+    cases = {}
+    shape = (2, 4, 16, 16)
+    n = math.prod(shape)
+    thr = 2.5 / math.sqrt(n)
+    specs = {
+        "plain": (0.0, 1.0, 1.0),          # neither branch
+        "shifted": (0.3, 1.0, 1.0),        # mean branch only (|mean| > thr)
+        "scaled": (0.0, 0.8, 1.0),         # std branch only
+        "both": (-0.4, 1.7, 0.6),          # both + factor
+        "tiny_shift": (thr * 0.5, 1.0, 2.0),   # just inside the mean threshold
+    }
+    for name, (mu, sd, factor) in specs.items():
+        x = torch.randn(shape, generator=g)
+        x = (x - x.mean()) / x.std() * sd + mu
+        dec = {}
+        want = ref.utils.scale_noise(x.clone(), factor, normalized=True)
+        got = orc.scale_noise(x.clone(), factor, normalized=True, decisions=dec)
+        must_equal(want, got, f"scale_noise[{name}]")
+        cases[f"{name}_in"] = x
+        cases[f"{name}_out"] = want
+        cases[f"{name}_meta"] = np.array([factor, float(dec["sub"]), float(dec["div"])], dtype=np.float64)
+    x = torch.randn(shape, generator=g) * 1.3 + 0.2
+    want = ref.utils.scale_noise(x.clone(), 0.7, normalized=True, normalize_dims=(-2, -1))
+    must_equal(want, orc.scale_noise(x.clone(), 0.7, normalized=True, normalize_dims=(-2, -1)), "scale_noise dims")
+    cases["dims_in"], cases["dims_out"] = x, want
+    want = ref.utils.scale_noise(x.clone(), 1.9, normalized=False)
+    cases["unnorm_out"] = want
+    save("scale_noise", **cases)
+
+
+# ------------------------------------------------------------------------------------------------ noise types
+def ref_noise(noise_type, shape, seed, normalized, **kw):
+    x = torch.zeros(shape)
+    torch.manual_seed(seed)
+    ns = ref.noise.get_noise_sampler(noise_type, x, 0.03, 14.6, seed=seed, cpu=True, factor=1.0, normalized=normalized, **kw)
+    return ns(torch.tensor(14.6), torch.tensor(10.0))
+
+
+def gen_perlin():
+    cases = {}
+    for tag, shape, seed, blend_mode in (("a", (2, 4, 16, 16), 0, "lerp"), ("b", (3, 4, 32, 24), 5, "lerp"),
+                                         ("c", (1, 2, 8, 8), 7, "inject")):
+        kw = {} if blend_mode == "lerp" else {"blend_mode": blend_mode}
+        raw = ref_noise(NT.PERLIN, shape, seed, False, **kw)
+        normed = ref_noise(NT.PERLIN, shape, seed, True, **kw)
+        torch.manual_seed(seed)
+        draws = orc.draw_perlin(shape, 2)
+        mine = orc.perlin_noise(draws, 2.0, blend_mode)
+        must_equal(raw, mine, f"perlin[{tag}] raw")
+        must_equal(normed, orc.scale_noise(mine.clone(), 1.0, normalized=True), f"perlin[{tag}] normalised")
+        cases[f"{tag}_base"] = draws.base
+        cases[f"{tag}_angles"] = torch.stack(draws.angles)
+        cases[f"{tag}_raw"] = raw
+        cases[f"{tag}_out"] = normed
+        cases[f"{tag}_seed"] = np.array(seed)
+        cases[f"{tag}_blend"] = np.array(blend_mode)
+    save("perlin", **cases)
+
+
+def gen_pyramid():
+    cases = {}
+    for tag, shape, seed, nt, discount, mode in (("a", (2, 4, 32, 32), 0, NT.PYRAMID, 0.7, "bilinear"),
+                                                ("b", (1, 4, 64, 48), 3, NT.PYRAMID, 0.7, "bilinear"),
+                                                ("c", (2, 3, 32, 32), 9, NT.PYRAMID_DISCOUNT5, 0.5, "bilinear"),
+                                                ("d", (1, 4, 32, 32), 4, NT.PYRAMID_AREA, 0.7, "area")):
+        raw = ref_noise(nt, shape, seed, False)
+        normed = ref_noise(nt, shape, seed, True)
+        torch.manual_seed(seed)
+        draws = orc.draw_pyramid(shape, 10)
+        mine = orc.pyramid_noise(draws, discount, mode)
+        must_equal(raw, mine, f"pyramid[{tag}] raw")
+        must_equal(normed, orc.scale_noise(mine.clone(), 1.0, normalized=True), f"pyramid[{tag}] normalised")
+        assert orc.pyramid_sizes(shape[-2], shape[-1], draws.rs) == [tuple(l.shape[-2:]) for l in draws.levels]
+        cases[f"{tag}_base"] = draws.base
+        cases[f"{tag}_rs"] = np.array(draws.rs, dtype=np.float64)
+        for i, lvl in enumerate(draws.levels):
+            cases[f"{tag}_level{i}"] = lvl
+        cases[f"{tag}_nlevels"] = np.array(len(draws.levels))
+        cases[f"{tag}_raw"] = raw
+        cases[f"{tag}_out"] = normed
+        cases[f"{tag}_seed"] = np.array(seed)
+        cases[f"{tag}_discount"] = np.array(discount)
+        cases[f"{tag}_mode"] = np.array(mode)
+    save("pyramid", **cases)
+
+
+def gen_basic_types():
+    """gaussian / uniform through the NoiseType registry (plumbing: RNG order, factor, normalisation)."""
+    cases = {}
+    for name, nt in (("gaussian", NT.GAUSSIAN), ("uniform", NT.UNIFORM)):
+        for normalized in (False, True):
+            shape = (2, 4, 8, 8)
+            out = ref_noise(nt, shape, 21, normalized)
+            cases[f"{name}_{int(normalized)}"] = out
+    torch.manual_seed(21)
+    cases["gaussian_draw"] = torch.randn(2, 4, 8, 8)
+    torch.manual_seed(21)
+    cases["uniform_draw"] = torch.rand(2, 4, 8, 8)
+    must_equal(cases["gaussian_0"], cases["gaussian_draw"], "gaussian")
+    must_equal(cases["uniform_0"], orc.uniform_noise(cases["uniform_draw"]), "uniform")
+    save("basic_types", **cases)
+
+
+# ------------------------------------------------------------------------------------------------ power noise
+FILTER_CASES = {
+    "white": dict(alpha=0.0),
+    "pink": dict(alpha=1.0),
+    "half": dict(alpha=0.5),
+    "brown": dict(alpha=2.0),
+    "blue": dict(alpha=-0.5),
+    "band": dict(alpha=1.0, min_freq=0.1, max_freq=0.4),
+    "rot_stretch": dict(alpha=1.0, rotate=30.0, stretch=2.0),
+    "squash": dict(alpha=0.5, stretch=0.5),
+    "pnorm1": dict(alpha=1.0, pnorm=1.0),
+}
+
+
+def gen_power_filter():
+    cases = {}
+    PF = ref.powernoise.PowerFilter
+    for name, kw in FILTER_CASES.items():
+        for hw in ((32, 32), (16, 24)):
+            shape = (1, 4, *hw)
+            raw = PF(**kw).build(shape)
+            mine = orc.power_filter_build(shape, **kw)
+            must_equal(raw, mine, f"filter[{name}] build")
+            for mix, nf in ((1.0, 1.0), (0.6, 1.0), (1.0, 0.5)):
+                want = PF.normalize(raw.clone(), shape, mix=mix, normalization_factor=nf)
+                must_equal(want, orc.power_filter_normalize(mine.clone(), shape, mix, nf), f"filter[{name}] normalise")
+                cases[f"{name}_{hw[0]}x{hw[1]}_mix{mix}_nf{nf}"] = want
+            cases[f"{name}_{hw[0]}x{hw[1]}_raw"] = raw
+    # the benchmark filter (cfg2): alpha = 1, 128 x 128
+    shape = (1, 4, 128, 128)
+    want = PF.normalize(PF(alpha=1.0, max_freq=0.7071).build(shape), shape)
+    must_equal(want, orc.power_filter_normalize(orc.power_filter_build(shape, alpha=1.0, max_freq=0.7071), shape), "cfg2 filter")
+    cases["cfg2_128x128"] = want
+    a = PF(alpha=1.0).build((1, 4, 32, 32))
+    b = PF(alpha=0.0, min_freq=0.2, max_freq=0.3).build((1, 4, 32, 32))
+    for mode in ("max", "min", "add", "sub", "mul"):
+        want = PF.compose(a.clone(), b.clone(), mode)
+        must_equal(want, orc.power_filter_compose(a.clone(), b.clone(), mode), f"compose {mode}")
+        cases[f"compose_{mode}"] = want
+    corr = torch.tensor([1.0, 1.0, 1.0, 1.0, 1.0, 1.0])
+    for cm in (0.0, 0.25, -0.2):
+        want = ref.powernoise.ChannelMixer(4, cm, corr).mixer
+        must_equal(want, orc.channel_mixer(4, cm, corr), f"mixer {cm}")
+        cases[f"mixer_{cm}"] = want
+    corr2 = torch.tensor([0.5, -0.3, 0.8])
+    want = ref.powernoise.ChannelMixer(4, 0.4, corr2).mixer
+    must_equal(want, orc.channel_mixer(4, 0.4, corr2), "mixer partial correlation")
+    cases["mixer_partial"] = want
+    save("power_filter", **cases)
+
+
+def ref_power_item(**kw):
+    args = dict(time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                common_mode=0.0, channel_correlation="1,1,1,1,1,1")
+    args.update(kw)
+    return ref.powernoise.PowerNoiseItem(1.0, **args)
+
+
+def gen_power_noise():
+    cases = {}
+    for tag, shape, seed, kw, normalized in (
+        ("cfg2", (1, 4, 128, 128), 0, {}, True),
+        ("b", (2, 4, 32, 32), 1, {"alpha": 0.5}, True),
+        ("c", (2, 4, 64, 64), 2, {"alpha": 2.0, "common_mode": 0.25}, True),
+        ("d", (3, 4, 32, 64), 3, {"alpha": 1.0, "min_freq": 0.1, "max_freq": 0.4}, False),
+        ("e", (1, 2, 16, 16), 4, {"alpha": 0.0, "mix": 0.5}, True),
+    ):
+        item = ref_power_item(**kw)
+        x = torch.zeros(shape)
+        torch.manual_seed(seed)
+        want = item.make_noise_sampler(x, None, None, seed=None, cpu=True, normalized=normalized)(None, None)
+        filt = item.make_filter(shape)
+        torch.manual_seed(seed)
+        z = orc.draw_power(shape)
+        fkw = {k: v for k, v in kw.items() if k in ("alpha", "min_freq", "max_freq", "stretch", "rotate", "pnorm")}
+        fkw.setdefault("max_freq", 0.7071)
+        fkw.setdefault("alpha", 1.0)
+        mine_f = orc.power_filter_normalize(orc.power_filter_build(shape, **fkw), shape, mix=kw.get("mix", 1.0))
+        must_equal(filt, mine_f, f"power[{tag}] filter")
+        cm = kw.get("common_mode", 0.0)
+        mixer = orc.channel_mixer(shape[1], cm, torch.ones(6))
+        dec, pre = {}, []
+        mine = orc.power_noise(z, mine_f, shape, mixer, 1.0, normalized, decisions=dec, pre_norm=pre)
+        must_equal(want, mine, f"power[{tag}]")
+        cases[f"{tag}_z"] = torch.view_as_real(z)
+        cases[f"{tag}_filter"] = filt
+        cases[f"{tag}_mixer"] = mixer
+        cases[f"{tag}_pre"] = pre[0]
+        cases[f"{tag}_out"] = want
+        cases[f"{tag}_seed"] = np.array(seed)
+        cases[f"{tag}_normalized"] = np.array(normalized)
+        cases[f"{tag}_branches"] = np.array([dec.get("sub", False), dec.get("div", False)])
+    save("power_noise", **cases)
+
+
+# ------------------------------------------------------------------------------------------------ composition
+def gen_composition():
+    cases = {}
+    N = ref.noise
+    shape = (2, 4, 16, 16)
+    x = torch.zeros(shape)
+
+    def chain_of(*items):
+        c = N.CustomNoiseChain()
+        for it in items:
+            c.add(it)
+        return c
+
+    def item(nt, f):
+        return N.CustomNoiseItem(f, noise_type=nt)
+
+    # chain: 0.6 gaussian - 0.3 uniform + 0.5 perlin, normalised; and rescaled(1.0)
+    chain = chain_of(item(NT.GAUSSIAN, 0.6), item(NT.UNIFORM, -0.3), item(NT.PERLIN, 0.5))
+    for tag, ch in (("chain", chain), ("chain_rescaled", chain.rescaled(1.0))):
+        torch.manual_seed(31)
+        want = ch.make_noise_sampler(x, 0.03, 14.6, seed=31, cpu=True, normalized=True)(torch.tensor(5.0), torch.tensor(4.0))
+        torch.manual_seed(31)
+        g = orc.draw_gaussian(shape)
+        u = torch.rand(shape)
+        p = orc.draw_perlin(shape, 2)
+        factors = [i.factor for i in ch.items]
+        mine = orc.chain_noise([g, orc.uniform_noise(u), orc.perlin_noise(p)], factors, True)
+        must_equal(want, mine, tag)
+        cases[f"{tag}_out"] = want
+        cases[f"{tag}_factors"] = np.array(factors)
+    cases["chain_gauss"], cases["chain_uniform_u"], cases["chain_perlin_base"] = g, u, p.base
+    cases["chain_perlin_angles"] = torch.stack(p.angles)
+
+    # composite: dst gaussian, src uniform, smooth mask, all normalised
+    mask = torch.linspace(0, 1, 8 * 8).reshape(1, 8, 8)
+    comp = N.CompositeNoise(0.8, dst_noise=chain_of(item(NT.GAUSSIAN, 1.0)), src_noise=chain_of(item(NT.UNIFORM, 1.0)),
+                            normalize_dst=True, normalize_src=True, normalize_result=True, mask=mask)
+    torch.manual_seed(32)
+    want = comp.make_noise_sampler(x, 0.03, 14.6, seed=32, cpu=True, normalized=True)(torch.tensor(5.0), torch.tensor(4.0))
+    torch.manual_seed(32)
+    g = orc.draw_gaussian(shape)
+    u = torch.rand(shape)
+    m = torch.nn.functional.interpolate(mask.reshape(-1, 1, 8, 8), size=shape[-2:], mode="bilinear").repeat(shape[0], 1, 1, 1)
+    dst = orc.chain_noise([g], [1.0], True)
+    src = orc.chain_noise([orc.uniform_noise(u)], [1.0], True)
+    must_equal(want, orc.composite_noise(dst, src, m, 0.8, True), "composite")
+    cases.update(comp_out=want, comp_gauss=g, comp_uniform_u=u, comp_mask=mask, comp_mask_resized=m)
+
+    # blended: lerp(gaussian, uniform, 0.3) normalised; and mask-driven weights
+    bl = N.BlendedNoise(1.2, normalize=True, blend_function=ref.utils.BLENDING_MODES["lerp"],
+                        custom_noise_1=chain_of(item(NT.GAUSSIAN, 1.0)), custom_noise_2=chain_of(item(NT.UNIFORM, 1.0)),
+                        noise_2_percent=0.3)
+    torch.manual_seed(33)
+    want = bl.make_noise_sampler(x, 0.03, 14.6, seed=33, cpu=True, normalized=True)(torch.tensor(5.0), torch.tensor(4.0))
+    torch.manual_seed(33)
+    g = orc.draw_gaussian(shape)
+    u = torch.rand(shape)
+    n1 = orc.chain_noise([g], [1.0], False)
+    n2 = orc.chain_noise([orc.uniform_noise(u)], [1.0], False)
+    must_equal(want, orc.blended_noise(n1, n2, torch.full((1,), 0.3), "lerp", 1.2, True), "blended")
+    cases.update(blend_out=want, blend_gauss=g, blend_uniform_u=u)
+    blm = N.BlendedNoise(1.0, normalize=True, blend_function=ref.utils.BLENDING_MODES["inject"],
+                         custom_noise_1=chain_of(item(NT.GAUSSIAN, 1.0)), custom_noise_2=chain_of(item(NT.UNIFORM, 1.0)),
+                         custom_noise_mask=chain_of(item(NT.GAUSSIAN, 1.0)), noise_2_percent=0.1)
+    torch.manual_seed(34)
+    want = blm.make_noise_sampler(x, 0.03, 14.6, seed=34, cpu=True, normalized=True)(torch.tensor(5.0), torch.tensor(4.0))
+    torch.manual_seed(34)
+    g = orc.draw_gaussian(shape)
+    u = torch.rand(shape)
+    gm = orc.draw_gaussian(shape)
+    wgt = orc.blend_mask_weight(gm.clone(), 0.1)
+    must_equal(want, orc.blended_noise(g.clone(), orc.uniform_noise(u), wgt, "inject", 1.0, True), "blended mask")
+    cases.update(blendmask_out=want, blendmask_gauss=g, blendmask_uniform_u=u, blendmask_maskdraw=gm, blendmask_weight=wgt)
+
+    # scheduled: perlin inside [2, 10], gaussian fallback outside, normalised
+    sch = N.ScheduledNoise(1.0, noise=chain_of(item(NT.PERLIN, 1.0)), start_sigma=10.0, end_sigma=2.0, normalize=True,
+                           fallback_noise=chain_of(item(NT.GAUSSIAN, 1.0)))
+    ns = sch.make_noise_sampler(x, 0.03, 14.6, seed=35, cpu=True, normalized=True)
+    torch.manual_seed(35)
+    inside = ns(torch.tensor(5.0), torch.tensor(4.0))
+    outside = ns(torch.tensor(12.0), torch.tensor(11.0))
+    torch.manual_seed(35)
+    p = orc.draw_perlin(shape, 2)
+    g = orc.draw_gaussian(shape)
+    must_equal(inside, orc.scale_noise(orc.chain_noise([orc.perlin_noise(p)], [1.0], False), 1.0, normalized=True), "scheduled in")
+    must_equal(outside, orc.scale_noise(orc.chain_noise([g], [1.0], False), 1.0, normalized=True), "scheduled out")
+    cases.update(sched_in=inside, sched_out=outside, sched_perlin_base=p.base, sched_perlin_angles=torch.stack(p.angles), sched_gauss=g)
+    save("composition", **cases)
+
+
+# ------------------------------------------------------------------------------------------------ momentum samplers
+def fake_model(x, sigma, **_kw):
+    # smooth, non-linear in x, sigma-dependent: exercises every elementwise path deterministically
+    s = sigma.reshape(-1, *([1] * (x.ndim - 1)))
+    return x * 0.5 + torch.tanh(x) * (0.1 * s / (1.0 + s))
+
+
+MOMENTUM_CASES = {
+    "new_default": dict(),
+    "classic": dict(momentum_mode="CLASSIC"),
+    "denoised": dict(momentum_mode="DENOISED"),
+    "new_negdir": dict(direction=-0.5),
+    "classic_dir15": dict(momentum_mode="CLASSIC", momentum=0.8, momentum_hist=0.5, direction=1.5),
+    "denoised_sample": dict(momentum_mode="DENOISED", init="SAMPLE"),
+    "new_sample_norm": dict(init="SAMPLE_NORM"),
+    "new_sample": dict(init="SAMPLE", momentum=0.7),
+    "steps_gated": dict(momentum_start_step=2, momentum_end_step=4, always_update_history=False),
+    "steps_gated_hist": dict(momentum_start_step=2, momentum_end_step=4),
+    "inject_blend": dict(blend_mode="inject", momentum=0.3, momentum_hist=0.4),
+    "mixed_blend": dict(momentum_blend_mode="subtract_b", history_blend_mode="inject", momentum=0.2, momentum_hist=0.3),
+    "no_momentum": dict(momentum=1.0),
+    "hist_frozen": dict(momentum_hist=1.0, init="SAMPLE"),
+    "low_weight": dict(momentum=0.4, momentum_hist=0.2),
+}
+
+
+def to_oracle_cfg(kw):
+    kw = dict(kw)
+    if "momentum_mode" in kw:
+        kw["mode"] = kw.pop("momentum_mode")
+    return orc.MomentumCfg(**kw)
+
+
+def gen_momentum():
+    S = ref.sonar
+    cases = {}
+    shape = (2, 4, 8, 8)
+    torch.manual_seed(3)
+    x0 = torch.randn(shape) * 14.6
+    sigmas = torch.cat((torch.linspace(14.6, 0.03, 7), torch.zeros(1)))
+    cases["x0"], cases["sigmas"] = x0, sigmas
+    noise_bank = torch.randn(16, *shape)
+    cases["noise_bank"] = noise_bank
+
+    def bank_sampler():
+        it = iter(noise_bank)
+        return lambda s, sn: next(it).clone()
+
+    for name, kw in MOMENTUM_CASES.items():
+        for kind in ("euler", "ancestral", "dpmpp"):
+            trace = []
+            cb = lambda d: trace.append(d["x"].clone())  # noqa: E731
+            extra = {"seed": 0}
+            if kind == "euler":
+                want = S.SonarEuler.sampler(fake_model, x0.clone(), sigmas, extra, cb, True, bank_sampler(), None, dict(kw))
+                mine_trace = []
+                mine = orc.sonar_euler(fake_model, x0.clone(), sigmas, to_oracle_cfg(kw), trace=mine_trace)
+            elif kind == "ancestral":
+                want = S.SonarEulerAncestral.sampler(fake_model, x0.clone(), sigmas, extra, cb, True, None, dict(kw), 0.8, 1.1, bank_sampler())
+                mine_trace = []
+                mine = orc.sonar_euler(fake_model, x0.clone(), sigmas, to_oracle_cfg(kw), ancestral=True, eta=0.8, s_noise=1.1,
+                                       noise_fn=bank_sampler(), trace=mine_trace)
+            else:
+                want = S.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas, extra, cb, True, None, dict(kw), 0.9, 1.05, bank_sampler())
+                mine_trace = []
+                mine = orc.sonar_dpmpp_sde(fake_model, x0.clone(), sigmas, to_oracle_cfg(kw), eta=0.9, s_noise=1.05,
+                                           noise_fn=bank_sampler(), trace=mine_trace)
+            must_equal(want, mine, f"{kind}[{name}] final")
+            for i, (a, b) in enumerate(zip(trace, mine_trace)):
+                must_equal(a, b[0], f"{kind}[{name}] step {i}")
+            cases[f"{kind}_{name}"] = torch.stack(trace)
+    save("momentum", **cases)
+
+
+if __name__ == "__main__":
+    gen_scale_noise()
+    gen_basic_types()
+    gen_perlin()
+    gen_pyramid()
+    gen_power_filter()
+    gen_power_noise()
+    gen_composition()
+    gen_momentum()
+    print("golden vectors written to", OUT)
