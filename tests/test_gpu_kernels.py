@@ -1,0 +1,380 @@
+"""Kernel-level parity (-m gpu): every C-ABI entry point of libsonar_hip.so, called through ctypes on a
+real MI355X, against the CPU oracle (oracle/sonar_oracle.py) on the committed golden vectors and on
+seeded inputs.
+
+Tolerance (fp32 path, stated per north_star "within a stated fp32 tolerance"):
+  elementwise / normalisation / momentum : rtol 1e-5, atol 1e-6  (op order restated; differences are
+      last-bit: device division/transcendentals, fp64-accumulated statistics vs torch's fp32)
+  FFT-based power noise                   : atol 2e-5 on unit-variance outputs (different FFT factorisation)
+Index math (lattice corners, resampling taps, row permutations) must be exact: it is checked through
+values that would differ by O(1) if an index were off.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import sonar_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+FFT_ATOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def hl(pkg):
+    lib = pkg.hip_lib
+    lib.load()
+    return lib
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    assert a.shape == b.shape
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------------ scale_noise
+@pytest.mark.parametrize("case", ["plain", "shifted", "scaled", "both", "tiny_shift"])
+def test_scale_noise_golden(hl, golden, case):
+    g = golden("scale_noise")
+    x = dev(g[f"{case}_in"])
+    factor, sub, div = (float(v) for v in g[f"{case}_meta"])
+    part = hl.stats(x)
+    tot = hl.stats_finalize(part, x.numel()).cpu()
+    ref = g[f"{case}_in"].double()
+    assert abs(tot[0].item() - ref.sum().item()) < 1e-6 * ref.abs().sum().item()
+    assert abs(tot[1].item() - (ref * ref).sum().item()) < 1e-9 * (ref * ref).sum().item() + 1e-9
+    hl.scale_noise_(x, factor, True, part)
+    close(x, g[f"{case}_out"])
+    # the data-dependent branches must match the reference's decisions
+    dec = {}
+    orc.scale_noise(g[f"{case}_in"].clone(), factor, normalized=True, decisions=dec)
+    assert (dec["sub"], dec["div"]) == (bool(sub), bool(div))
+
+
+def test_scale_noise_unnormalized_and_rows(hl, golden):
+    g = golden("scale_noise")
+    x = dev(g["dims_in"])
+    hl.scale_noise_(x, 1.9, False, None)
+    close(x, g["unnorm_out"])
+    x = dev(g["dims_in"])
+    b, c, h, w = x.shape
+    hl.scale_noise_rows_(x, b * c, h * w, 0.7)
+    close(x, g["dims_out"], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 255, 1023, 65536 + 3, 4 * 128 * 128 * 8])
+def test_scale_noise_sizes_and_alignment(hl, n):
+    torch.manual_seed(n)
+    src = torch.randn(n + 1) * 1.5 + 0.25
+    for off in (0, 1):  # off=1 -> 4-byte aligned only: scalar path
+        x = dev(src)[off:off + n]
+        want = orc.scale_noise(src[off:off + n].clone(), 0.9, normalized=True)
+        part = hl.stats(x)
+        hl.scale_noise_(x, 0.9, True, part)
+        if n == 1:
+            assert torch.isnan(want).all() == torch.isnan(x.cpu()).all() or torch.allclose(want, x.cpu(), equal_nan=True)
+        else:
+            close(x, want, rtol=2e-5, atol=2e-6)
+
+
+def test_scale_noise_global_stats_override(hl):
+    """n_total / partials from a wider tensor (the cross-rank all-reduce variant)."""
+    torch.manual_seed(1)
+    full = torch.randn(4, 4, 16, 16) * 0.8 + 0.1
+    want = orc.scale_noise(full.clone(), 1.0, normalized=True)
+    xf = dev(full)
+    tot = hl.stats_finalize(hl.stats(xf), full.numel())
+    shard = dev(full[2:])
+    part = torch.zeros(hl.NPART * 2, dtype=torch.float64, device="cuda")
+    part[:2] = tot[:2]
+    hl.scale_noise_(shard, 1.0, True, part, n_total=full.numel())
+    close(shard, want[2:])
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+@pytest.mark.parametrize("mode", ["lerp", "inject", "subtract_b"])
+@pytest.mark.parametrize("t", [0.0, 0.3, 0.5, 0.75, 1.0, -0.2, 1.4])
+def test_blend_scalar(hl, mode, t):
+    torch.manual_seed(5)
+    a, b = torch.randn(3, 4, 9, 7), torch.randn(3, 4, 9, 7)
+    close(hl.blend(mode, dev(a), dev(b), t), orc.blend(mode, a, b, t))
+
+
+@pytest.mark.parametrize("mode", ["lerp", "inject"])
+def test_blend_tensor_weight(hl, mode):
+    torch.manual_seed(6)
+    a, b = torch.randn(2, 4, 8, 8), torch.randn(2, 4, 8, 8)
+    w = torch.rand(2, 4, 8, 8)
+    close(hl.blend(mode, dev(a), dev(b), dev(w)), orc.blend(mode, a, b, w))
+    w1 = torch.rand(1, 1, 8, 8)
+    close(hl.blend(mode, dev(a), dev(b), dev(w1)), orc.blend(mode, a, b, w1))
+
+
+def test_axpby_and_mask_mix(hl):
+    torch.manual_seed(7)
+    y, x = torch.randn(2, 4, 8, 8), torch.randn(2, 4, 8, 8)
+    close(hl.axpby_(dev(y), 1.0, dev(x), 1.0), y + x)
+    close(hl.axpby_(dev(y), 1.0, dev(x), 0.37), y + x * 0.37)
+    close(hl.axpby_(dev(y), -0.5, dev(x), 2.0), y * -0.5 + x * 2.0)
+    mask = torch.rand(2, 1, 8, 8)
+    want = y * (torch.ones_like(mask) - mask) + x * mask
+    got = hl.mask_mix(dev(y), dev(x), dev(mask.expand(2, 4, 8, 8).contiguous()))
+    close(got, want)
+    m1 = torch.rand(1, 1, 8, 8)
+    close(hl.mask_mix(dev(y), dev(x), dev(m1)), y * (1 - m1) + x * m1)
+
+
+def test_minmax_rows(hl):
+    torch.manual_seed(8)
+    x = torch.randn(6, 1000)
+    lo, hi = hl.minmax_rows(dev(x), 6, 1000)
+    assert torch.equal(lo.cpu(), x.amin(1)) and torch.equal(hi.cpu(), x.amax(1))
+
+
+# ------------------------------------------------------------------------------------------------ momentum kernels
+def make_cfg(hl, c: orc.MomentumCfg, st: orc.MomentumState, step: int, h_present: bool, h_fresh=False):
+    cfg = hl.MomentumCfg()
+    cfg.momentum = c.momentum
+    cfg.hist_ratio, cfg.hist_scale, cfg.md_scale = st.ratios
+    cfg.mode = hl.MODE_IDS[c.mode]
+    cfg.momentum_blend = hl.BLEND_IDS[st.mblend]
+    cfg.history_blend = hl.BLEND_IDS[st.hblend]
+    cfg.use_momentum = int(st.check_step(step))
+    hist_ok = st.check_step(step, is_history=True)
+    cfg.update_hist = int(c.momentum_hist != 1 and hist_ok)
+    cfg.init_kind = hl.INIT_IDS[c.init] if (not h_present and hist_ok and c.init in ("SAMPLE", "SAMPLE_NORM")) else 0
+    cfg.h_in_fresh = int(h_fresh)
+    return cfg
+
+
+CFGS = [
+    orc.MomentumCfg(),
+    orc.MomentumCfg(mode="CLASSIC"),
+    orc.MomentumCfg(mode="DENOISED"),
+    orc.MomentumCfg(direction=-0.5),
+    orc.MomentumCfg(mode="CLASSIC", momentum=0.8, momentum_hist=0.5, direction=1.5),
+    orc.MomentumCfg(mode="DENOISED", init="SAMPLE"),
+    orc.MomentumCfg(init="SAMPLE_NORM"),
+    orc.MomentumCfg(blend_mode="inject", momentum=0.3, momentum_hist=0.4),
+    orc.MomentumCfg(momentum_blend_mode="subtract_b", history_blend_mode="inject", momentum=0.2, momentum_hist=0.3),
+    orc.MomentumCfg(momentum=1.0),
+    orc.MomentumCfg(momentum_hist=1.0, init="SAMPLE"),
+    orc.MomentumCfg(momentum_start_step=1, momentum_end_step=1, always_update_history=False),
+]
+
+
+@pytest.mark.parametrize("cfg", CFGS, ids=lambda c: f"{c.mode}-{c.init}-{c.blend_mode}-m{c.momentum}-h{c.momentum_hist}-d{c.direction}")
+def test_momentum_euler_kernel_three_steps(hl, cfg):
+    """Three consecutive fused steps (no history -> history created -> history updated) vs the oracle."""
+    torch.manual_seed(9)
+    shape = (2, 4, 8, 8)
+    x = torch.randn(shape) * 5
+    st = orc.MomentumState(cfg)
+    xd, hd = dev(x), None
+    sig = [torch.tensor(s) for s in (7.0, 4.0, 2.0, 1.0)]
+    for step in range(3):
+        den = x * 0.5 + torch.tanh(x) * 0.1
+        want = st.euler_step(step, x, den, sig[step], sig[step + 1])
+        kc = make_cfg(hl, cfg, orc.MomentumState(cfg), step, hd is not None)
+        dt = (sig[step + 1] - sig[step]).item()
+        xd, hd = hl.momentum_euler(xd, dev(den), hd, kc, sig[step].item(), dt)
+        close(xd, want, rtol=2e-5, atol=2e-5)
+        assert (hd is None) == (st.h is None)
+        if hd is not None:
+            close(hd, st.h, rtol=2e-5, atol=2e-5)
+        x = want
+
+
+def test_momentum_euler_with_noise(hl):
+    torch.manual_seed(10)
+    cfg = orc.MomentumCfg()
+    x, den, nz = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
+    st = orc.MomentumState(cfg)
+    want = st.euler_step(0, x, den, torch.tensor(3.0), torch.tensor(2.5)) + nz * (1.1 * 0.7)
+    kc = make_cfg(hl, cfg, st, 0, False)
+    got, h = hl.momentum_euler(dev(x), dev(den), None, kc, 3.0, -0.5, noise=dev(nz), noise_scale=1.1 * 0.7)
+    close(got, want)
+    close(h, st.h)
+
+
+# ------------------------------------------------------------------------------------------------ Philox generators
+def test_philox_normal_moments_and_shard_invariance(hl):
+    n = 1 << 22
+    x = hl.philox_normal((n,), "cuda", seed=1234, stream_id=3)
+    m, s = x.mean().item(), x.std().item()
+    assert abs(m) < 4 / math.sqrt(n) and abs(s - 1) < 4 / math.sqrt(2 * n)
+    kurt = ((x - m) ** 4).mean().item() / s**4
+    assert abs(kurt - 3.0) < 0.02
+    # same values regardless of how the range is split across calls ("ranks"), incl. odd offsets
+    for cut in (n // 2, 4 * 1001, 4 * 1001 + 1, 7):
+        a = hl.philox_normal((cut,), "cuda", 1234, 3, 0)
+        b = hl.philox_normal((n - cut,), "cuda", 1234, 3, cut)
+        assert torch.equal(torch.cat((a, b)), x)
+    assert not torch.equal(hl.philox_normal((1024,), "cuda", 1234, 4), x[:1024])  # stream id matters
+    assert not torch.equal(hl.philox_normal((1024,), "cuda", 1235, 3), x[:1024])  # seed matters
+
+
+def test_philox_uniform_range_and_stats_partials(hl):
+    n = 1 << 20
+    part = hl.new_partials("cuda")
+    u = hl.philox_uniform((n,), "cuda", seed=7, stream_id=0, partials=part)
+    assert u.min().item() >= 0.0 and u.max().item() < 1.0
+    assert abs(u.mean().item() - 0.5) < 4 * math.sqrt(1 / 12 / n)
+    tot = hl.stats_finalize(part, n).cpu()
+    assert abs(tot[0].item() - u.double().sum().item()) < 1e-6
+    assert abs(tot[1].item() - (u.double() ** 2).sum().item()) < 1e-6
+    v = hl.philox_uniform((n,), "cuda", seed=7, stream_id=0, sub=0.5, mul=3.46, add=0.0)
+    close(v, (u - 0.5) * 3.46)
+
+
+# ------------------------------------------------------------------------------------------------ Perlin
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_perlin_replay_golden(hl, golden, tag):
+    g = golden("perlin")
+    mode = str(g[f"{tag}_blend"])
+    terms = hl.perlin_terms(dev(g[f"{tag}_angles"]), mode)
+    want_terms = torch.stack([orc.perlin_term(a, mode) for a in g[f"{tag}_angles"]])
+    close(terms, want_terms, rtol=1e-5, atol=2e-6)  # device sinf/cosf vs torch CPU
+    part = hl.new_partials("cuda")
+    raw = hl.perlin_apply(dev(g[f"{tag}_base"]), terms, 2.0, part)
+    close(raw, g[f"{tag}_raw"], rtol=1e-5, atol=2e-6)
+    hl.scale_noise_(raw, 1.0, True, part)
+    close(raw, g[f"{tag}_out"], rtol=2e-5, atol=5e-6)
+
+
+def test_perlin_generate_matches_apply_on_device_draws(hl):
+    shape = (3, 4, 16, 20)
+    torch.manual_seed(0)
+    angles = torch.rand(2, 4, 17, 21) * 2 * math.pi
+    terms = hl.perlin_terms(dev(angles))
+    u = hl.philox_uniform(shape, "cuda", seed=99, stream_id=5, elem_offset=64)
+    want = hl.perlin_apply(u, terms, 2.0)
+    p1, p2 = hl.new_partials("cuda"), hl.new_partials("cuda")
+    got = hl.perlin_generate(shape, terms, 2.0, seed=99, stream_id=5, elem_offset=64, partials=p1)
+    assert torch.equal(got, want)
+    hl.stats(got, p2)
+    t1, t2 = hl.stats_finalize(p1, got.numel()).cpu(), hl.stats_finalize(p2, got.numel()).cpu()
+    assert torch.allclose(t1, t2, rtol=1e-12, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------ resampling / pyramid
+@pytest.mark.parametrize("mode", ["bilinear", "nearest-exact", "area"])
+@pytest.mark.parametrize("src_hw,dst_hw", [((3, 3), (32, 32)), ((32, 32), (32, 32)), ((1, 1), (16, 24)), ((7, 5), (24, 40)),
+                                            ((48, 64), (16, 16)), ((20, 36), (8, 12))])
+def test_resample_matches_interpolate(hl, mode, src_hw, dst_hw):
+    torch.manual_seed(11)
+    src = torch.randn(2, 3, *src_hw)
+    dst0 = torch.randn(2, 3, *dst_hw)
+    want = dst0 + orc.resize(src, dst_hw[1], dst_hw[0], mode).mul_(0.7)
+    got = hl.resample_acc_(dev(dst0), dev(src), 0.7, mode, True)
+    close(got, want, rtol=1e-5, atol=2e-6)
+    got = hl.resample_acc_(dev(dst0), dev(src), 1.0, mode, False)
+    close(got, orc.resize(src, dst_hw[1], dst_hw[0], mode), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_pyramid_replay_golden(hl, golden, tag):
+    g = golden("pyramid")
+    noise = dev(g[f"{tag}_base"])
+    nl = int(g[f"{tag}_nlevels"])
+    discount, mode = float(g[f"{tag}_discount"]), str(g[f"{tag}_mode"])
+    part = hl.new_partials("cuda")
+    for i in range(nl):
+        hl.resample_acc_(noise, dev(g[f"{tag}_level{i}"]), discount**i, mode, True, part if i == nl - 1 else None)
+    close(noise, g[f"{tag}_raw"], rtol=1e-5, atol=3e-6)
+    hl.scale_noise_(noise, 1.0, True, part)
+    close(noise, g[f"{tag}_out"], rtol=2e-5, atol=5e-6)
+
+
+def test_pyramid_generate_is_sum_of_its_levels(hl):
+    shape = (2, 4, 32, 32)
+    planes = 8
+    sizes = [(32, 32), (9, 9), (2, 2), (1, 1)]
+    weights = [1.0, 0.7, 0.49, 0.343]
+    seed = 42
+    small = [hl.philox_normal((planes, h, w), "cuda", seed, 10 + i) for i, (h, w) in enumerate(sizes[1:])]
+    levels = [(None, 32, 32, 1.0)] + [(t, h, w, wt) for t, (h, w), wt in zip(small, sizes[1:], weights[1:])]
+    part = hl.new_partials("cuda")
+    got = hl.pyramid_generate(shape, "cuda", levels, "bilinear", seed, 0, 0, part)
+    want = hl.philox_normal(shape, "cuda", seed, 0)
+    hl.axpby_(want, 1.0, hl.philox_normal(shape, "cuda", seed, 1), 1.0)
+    for t, wt in zip(small, weights[1:]):
+        hl.resample_acc_(want, t, wt, "bilinear", True)
+    close(got, want, rtol=1e-6, atol=1e-6)
+    tot = hl.stats_finalize(part, got.numel()).cpu()
+    assert abs(tot[0].item() - got.double().sum().item()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ power-law rFFT noise
+@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e"])
+def test_power_noise_replay_golden(hl, golden, tag):
+    g = golden("power_noise")
+    z = torch.view_as_complex(g[f"{tag}_z"].contiguous())
+    shape = tuple(z.shape[:-1]) + ((z.shape[-1] - 1) * 2,)
+    filt = g[f"{tag}_filter"]
+    mixer = g[f"{tag}_mixer"]
+    identity = torch.equal(mixer, torch.eye(mixer.shape[0]))
+    part = hl.new_partials("cuda")
+    out = hl.power_irfft2(dev(z), dev(filt.reshape(filt.shape[-2:])), shape, partials=part if identity else None)
+    if not identity:
+        out = hl.channel_mix(out, dev(mixer), part)
+    close(out, g[f"{tag}_pre"], rtol=0, atol=FFT_ATOL)
+    hl.scale_noise_(out, 1.0, bool(g[f"{tag}_normalized"]), part)
+    close(out, g[f"{tag}_out"], rtol=0, atol=2 * FFT_ATOL)
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (32, 32), (64, 64), (128, 128), (64, 128), (128, 64), (32, 64), (64, 32),
+                                (256, 128), (128, 256), (256, 64), (64, 256)])
+def test_power_irfft2_all_supported_shapes(hl, hw):
+    torch.manual_seed(13)
+    h, w = hw
+    z = torch.randn(3, 2, h, w // 2 + 1, dtype=torch.complex64)
+    filt = torch.rand(h, w // 2 + 1) + 0.5
+    want = torch.fft.irfft2(z * filt, s=(h, w), norm="ortho")
+    got = hl.power_irfft2(dev(z), dev(filt), (3, 2, h, w))
+    close(got, want, rtol=0, atol=FFT_ATOL)
+
+
+def test_power_generate_equals_replay_of_device_draws(hl):
+    shape = (5, 4, 128, 128)
+    h, w = shape[-2:]
+    nc = 5 * 4 * h * (w // 2 + 1)
+    filt = dev(torch.rand(h, w // 2 + 1) + 0.25)
+    offs = 2 * 8320 * 3  # as if three planes preceded this shard
+    zr = hl.philox_normal((nc * 2,), "cuda", seed=77, stream_id=9, elem_offset=2 * offs) * math.sqrt(0.5)
+    z = torch.view_as_complex(zr.reshape(5, 4, h, w // 2 + 1, 2))
+    p1 = hl.new_partials("cuda")
+    got = hl.power_irfft2(None, filt, shape, seed=77, stream_id=9, cplx_offset=offs, partials=p1)
+    want = hl.power_irfft2(z.contiguous(), filt, shape)
+    assert torch.equal(got, want)
+    ref = torch.fft.irfft2(z.cpu() * filt.cpu(), s=(h, w), norm="ortho")
+    close(got, ref, rtol=0, atol=FFT_ATOL)
+    tot = hl.stats_finalize(p1, got.numel()).cpu()
+    assert abs(tot[1].item() - (got.double() ** 2).sum().item()) < 1e-6 * tot[1].item()
+
+
+def test_power_unsupported_shape_raises(hl):
+    with pytest.raises(hl.SonarHipError):
+        hl.power_irfft2(None, dev(torch.ones(96, 81)), (1, 4, 96, 160))
+
+
+def test_channel_mix(hl, golden):
+    g = golden("power_filter")
+    torch.manual_seed(14)
+    x = torch.randn(3, 4, 8, 8)
+    for key in ("mixer_0.25", "mixer_-0.2", "mixer_partial"):
+        m = g[key]
+        want = (m @ x.swapaxes(0, 1).reshape(4, -1)).reshape(4, 3, 8, 8).swapaxes(1, 0)
+        close(hl.channel_mix(dev(x), dev(m)), want, rtol=1e-5, atol=2e-6)
+
+
+def test_cpu_tensor_is_rejected(hl):
+    with pytest.raises(hl.SonarHipError):
+        hl.stats(torch.zeros(16))
