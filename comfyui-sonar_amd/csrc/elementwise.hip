@@ -298,6 +298,65 @@ struct AxpbyOp {
     }
 };
 
+struct AffineOp {
+    float* x;
+    float sub, mul, add;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        Pack<V> p = load<V>(x, i);
+#pragma unroll
+        for (int k = 0; k < V; ++k) p.v[k] = (p.v[k] - sub) * mul + add;
+        store<V>(x, i, p);
+    }
+};
+
+struct ScalarOp {
+    int op;
+    const float *a, *b;
+    float s;
+    float* out;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        const Pack<V> pa = load<V>(a, i);
+        Pack<V> pb, r;
+        if (op == 2) pb = load<V>(b, i);
+#pragma unroll
+        for (int k = 0; k < V; ++k) r.v[k] = op == 0 ? pa.v[k] * s : op == 1 ? pa.v[k] / s : (pa.v[k] - pb.v[k]) / s;
+        store<V>(out, i, r);
+    }
+};
+
+__global__ void __launch_bounds__(kBlock) rowstats_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
+                                                           float* mean, float* stdv) {
+    __shared__ double red[2 * kBlock / 64];
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* row = x + r * inner;
+        double s = 0.0, q = 0.0;
+        for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
+            const double v = row[i];
+            s += v; q += v * v;
+        }
+        block_sum2<kBlock>(s, q, red);
+        if (threadIdx.x == 0) {
+            const double nt = (double)inner, m = s / nt;
+            const double var = (q - s * m) / (nt - 1.0);
+            mean[r] = (float)m;
+            stdv[r] = (float)sqrt(var > 0.0 || !(var == var) ? var : 0.0);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) row_affine_kernel(int op, const float* __restrict__ x, int64_t rows,
+                                                             int64_t inner, const float* __restrict__ a,
+                                                             const float* __restrict__ b, float* out) {
+    const int64_t total = rows * inner;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / inner;
+        out[i] = op == 0 ? (x[i] - a[r]) / b[r] : x[i] * b[r] + a[r];
+    }
+}
+
 struct MaskMixOp {
     const float *dst, *src, *mask;
     int64_t mask_n;
@@ -564,6 +623,34 @@ extern "C" int sonar_blend_tensor_f32(int mode, const float* a, const float* b, 
 extern "C" int sonar_axpby_f32(float* y, float ymul, const float* x, float xmul, int64_t n, void* stream) {
     SONAR_REQUIRE(x && y && n >= 0, SONAR_ERR_ARG, "sonar_axpby_f32: bad argument");
     return launch_ew(AxpbyOp{y, ymul, x, xmul}, n, aligned16(x) && aligned16(y), (hipStream_t)stream, "sonar_axpby_f32");
+}
+
+extern "C" int sonar_affine_f32(float* x, float sub, float mul, float add, int64_t n, void* stream) {
+    SONAR_REQUIRE(x && n >= 0, SONAR_ERR_ARG, "sonar_affine_f32: bad argument");
+    return launch_ew(AffineOp{x, sub, mul, add}, n, aligned16(x), (hipStream_t)stream, "sonar_affine_f32");
+}
+
+extern "C" int sonar_scalar_op_f32(int op, const float* a, const float* b, float s, float* out, int64_t n, void* stream) {
+    SONAR_REQUIRE(a && out && n >= 0 && op >= 0 && op <= 2 && (op != 2 || b), SONAR_ERR_ARG, "sonar_scalar_op_f32: bad argument");
+    return launch_ew(ScalarOp{op, a, b, s, out}, n, aligned16(a) && aligned16(out) && (!b || aligned16(b)), (hipStream_t)stream,
+                     "sonar_scalar_op_f32");
+}
+
+extern "C" int sonar_rowstats_f32(const float* x, int64_t rows, int64_t inner, float* mean, float* stdv, void* stream) {
+    SONAR_REQUIRE(x && mean && stdv && rows >= 0 && inner > 0, SONAR_ERR_ARG, "sonar_rowstats_f32: bad argument");
+    if (rows == 0) return SONAR_OK;
+    hipLaunchKernelGGL(rowstats_kernel, dim3(grid_for(rows, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner, mean, stdv);
+    return check_launch("sonar_rowstats_f32");
+}
+
+extern "C" int sonar_row_affine_f32(int op, const float* x, int64_t rows, int64_t inner, const float* a, const float* b,
+                                    float* out, void* stream) {
+    SONAR_REQUIRE(x && a && b && out && rows >= 0 && inner > 0 && (op == 0 || op == 1), SONAR_ERR_ARG,
+                  "sonar_row_affine_f32: bad argument");
+    if (rows == 0) return SONAR_OK;
+    hipLaunchKernelGGL(row_affine_kernel, dim3(grid_for(rows * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, op, x,
+                       rows, inner, a, b, out);
+    return check_launch("sonar_row_affine_f32");
 }
 
 extern "C" int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,

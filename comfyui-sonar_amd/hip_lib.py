@@ -67,6 +67,10 @@ SIGNATURES = {
     "sonar_blend_f32": (_I, [_I, _P, _P, _F, _P, _I64, _P]),
     "sonar_blend_tensor_f32": (_I, [_I, _P, _P, _P, _I64, _P, _I64, _P]),
     "sonar_axpby_f32": (_I, [_P, _F, _P, _F, _I64, _P]),
+    "sonar_affine_f32": (_I, [_P, _F, _F, _F, _I64, _P]),
+    "sonar_scalar_op_f32": (_I, [_I, _P, _P, _F, _P, _I64, _P]),
+    "sonar_rowstats_f32": (_I, [_P, _I64, _I64, _P, _P, _P]),
+    "sonar_row_affine_f32": (_I, [_I, _P, _I64, _I64, _P, _P, _P, _P]),
     "sonar_mask_mix_f32": (_I, [_P, _P, _P, _I64, _P, _I64, _P]),
     "sonar_minmax_rows_f32": (_I, [_P, _I64, _I64, _P, _P, _P]),
     "sonar_momentum_euler_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
@@ -212,6 +216,44 @@ def axpby_(y: torch.Tensor, ymul: float, x: torch.Tensor, xmul: float) -> torch.
         raise SonarHipError(f"axpby: shape mismatch {tuple(x.shape)} vs {tuple(y.shape)}")
     _check(load().sonar_axpby_f32(_dev(y, "y"), float(ymul), _dev(x, "x"), float(xmul), y.numel(), _stream()), "sonar_axpby_f32")
     return y
+
+
+def affine_(x: torch.Tensor, sub: float, mul: float, add: float) -> torch.Tensor:
+    _check(load().sonar_affine_f32(_dev(x, "x"), float(sub), float(mul), float(add), x.numel(), _stream()), "sonar_affine_f32")
+    return x
+
+
+def mul_scalar(a: torch.Tensor, s: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(a) if out is None else out
+    _check(load().sonar_scalar_op_f32(0, _dev(a, "a"), None, float(s), _dev(out, "out"), a.numel(), _stream()), "sonar_scalar_op_f32")
+    return out
+
+
+def div_scalar(a: torch.Tensor, s: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(a) if out is None else out
+    _check(load().sonar_scalar_op_f32(1, _dev(a, "a"), None, float(s), _dev(out, "out"), a.numel(), _stream()), "sonar_scalar_op_f32")
+    return out
+
+
+def to_d(x: torch.Tensor, denoised: torch.Tensor, sigma: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(x) if out is None else out
+    _check(load().sonar_scalar_op_f32(2, _dev(x, "x"), _dev(denoised, "denoised"), float(sigma), _dev(out, "out"), x.numel(), _stream()),
+           "sonar_scalar_op_f32")
+    return out
+
+
+def rowstats(x: torch.Tensor, rows: int, inner: int):
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    std = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _check(load().sonar_rowstats_f32(_dev(x, "x"), rows, inner, _dev(mean, "mean"), _dev(std, "std"), _stream()), "sonar_rowstats_f32")
+    return mean, std
+
+
+def row_affine(op: int, x: torch.Tensor, rows: int, inner: int, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    _check(load().sonar_row_affine_f32(op, _dev(x, "x"), rows, inner, _dev(a, "a"), _dev(b, "b"), _dev(out, "out"), _stream()),
+           "sonar_row_affine_f32")
+    return out
 
 
 def mask_mix(dst: torch.Tensor, src: torch.Tensor, mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

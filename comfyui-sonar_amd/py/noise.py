@@ -1,0 +1,444 @@
+"""Noise composition layer (API of the reference's ``py/noise.py``): items, chains, the sampler
+wrapper, scheduled / composite / blended noise and the ``NoiseType`` registry.
+
+Host code only builds closures; every per-call tensor operation is a HIP kernel launch on the
+current stream (accumulate, mask-mix, blend, normalise).  Object model, argument names and the
+order in which sub-samplers are *called* (it fixes the RNG draw order in replay mode) follow the reference.
+"""
+from __future__ import annotations
+
+import abc
+from functools import partial
+from typing import Callable, Optional
+
+import torch
+import yaml
+
+from .. import hip_lib
+from . import utils
+from .noise_generation import *  # noqa: F401,F403  (the reference re-exports the generators from here)
+from .noise_generation import (
+    BrownianNoiseGenerator,
+    CollatzNoiseGenerator,
+    DistroNoiseGenerator,
+    GaussianNoiseGenerator,
+    GreenTestNoiseGenerator,
+    HighresPyramidNoiseGenerator,
+    LaplacianNoiseGenerator,
+    MixedNoiseGenerator,
+    NoiseType,
+    OneFNoiseGenerator,
+    PerlinOldNoiseGenerator,
+    PinkOldNoiseGenerator,
+    PowerLawNoiseGenerator,
+    PowerOldNoiseGenerator,
+    PyramidNoiseGenerator,
+    PyramidOldNoiseGenerator,
+    StudentTNoiseGenerator,
+    UniformNoiseGenerator,
+    VoronoiNoiseGenerator,
+    WaveletNoiseGenerator,
+)
+from .utils import fallback, pop_stats, scale_noise
+
+Tensor = torch.Tensor
+
+_CLONED_KEYS = frozenset(("custom_noise", "custom_noise_opt", "noise", "noise_opt", "sonar_custom_noise", "sonar_custom_noise_opt"))
+
+
+def _accumulate(total: Optional[Tensor], part: Tensor) -> Tensor:
+    """result.add_(noise) of py/noise.py:192-193 as one fused kernel."""
+    if total is None:
+        return part
+    pop_stats(total)
+    pop_stats(part)
+    return hip_lib.axpby_(total, 1.0, part, 1.0)
+
+
+class CustomNoiseItemBase(abc.ABC):
+    """py/noise.py:30-80."""
+
+    def __init__(self, factor, *, yaml_parameters=None, **kwargs):
+        if yaml_parameters:
+            extra = yaml.safe_load(yaml_parameters)
+            if extra is not None:
+                if not isinstance(extra, dict):
+                    raise ValueError("CustomNoiseItem: yaml_parameters must either be null or an object")
+                kwargs["ns_kwargs"] = extra
+        self.factor = factor
+        self.keys = set(kwargs.keys())
+        for key, val in kwargs.items():
+            setattr(self, key, val.clone() if key in _CLONED_KEYS and hasattr(val, "clone") else val)
+
+    def clone_key(self, k):
+        return getattr(self, k)
+
+    def clone(self):
+        return self.__class__(self.factor, **{k: self.clone_key(k) for k in self.keys})
+
+    def set_factor(self, factor):
+        self.factor = factor
+        return self
+
+    def get_normalize(self, k, default=None):
+        val = getattr(self, k, None)
+        return default if val is None else val
+
+    @abc.abstractmethod
+    def make_noise_sampler(self, x: Tensor, sigma_min=None, sigma_max=None, seed=None, cpu=True, normalized=True, **kwargs):
+        raise NotImplementedError
+
+
+class CustomNoiseItem(CustomNoiseItemBase):
+    """py/noise.py:83-134: one registry noise type with a factor."""
+
+    def __init__(self, factor, **kwargs):
+        super().__init__(factor, **kwargs)
+        if getattr(self, "noise_type", None) is None:
+            raise ValueError("Noise type required!")
+
+    @torch.no_grad()
+    def make_noise_sampler(self, x: Tensor, sigma_min=None, sigma_max=None, seed=None, cpu=True, normalized=True, **kwargs):
+        opts = getattr(self, "ns_kwargs", {}).copy()
+        o_sigma, o_sigma_next, o_min, o_max = (opts.pop(k, None) for k in ("override_sigma", "override_sigma_next", "override_sigma_min", "override_sigma_max"))
+        ns = get_noise_sampler(
+            self.noise_type, x, fallback(o_min, sigma_min), fallback(o_max, sigma_max),
+            seed=opts.pop("seed", seed), cpu=opts.pop("cpu", cpu), factor=self.factor,
+            normalized=opts.pop("normalized", self.get_normalize("normalize", normalized)), **opts, **kwargs,
+        )
+        if o_sigma is None and o_sigma_next is None:
+            return ns
+        return lambda sigma, sigma_next: ns(fallback(o_sigma, sigma), fallback(o_sigma_next, sigma_next))
+
+
+class CustomNoiseChain:
+    """py/noise.py:137-196."""
+
+    def __init__(self, items=None):
+        self.items = items if items is not None else []
+
+    def clone(self):
+        return CustomNoiseChain([i.clone() for i in self.items])
+
+    def add(self, item):
+        if item is None:
+            raise ValueError("Attempt to add nil item")
+        self.items.append(item)
+
+    @property
+    def factor(self):
+        return sum(abs(i.factor) for i in self.items)
+
+    def rescaled(self, scale=1.0):
+        divisor = self.factor / scale
+        divisor = divisor if divisor != 0 else 1.0
+        result = self.clone()
+        if divisor != 1:
+            for i in result.items:
+                i.set_factor(i.factor / divisor)
+        return result
+
+    @torch.no_grad()
+    def make_noise_sampler(self, x: Tensor, sigma_min=None, sigma_max=None, seed=None, cpu=True, normalized=True) -> Callable:
+        samplers = tuple(i.make_noise_sampler(x, sigma_min, sigma_max, seed=seed, cpu=cpu, normalized=False) for i in self.items)
+        if not samplers or not all(samplers):
+            raise ValueError("Failed to get noise sampler")
+        factor = self.factor
+
+        def noise_sampler(sigma, sigma_next):
+            total = None
+            for ns in samplers:
+                total = _accumulate(total, ns(sigma, sigma_next))
+            return scale_noise(total, factor, normalized=normalized)
+
+        return noise_sampler
+
+
+class NoiseSampler:
+    """py/noise.py:199-257: wraps a generator factory; applies the item factor / normalisation."""
+
+    def __init__(self, x: Tensor, sigma_min=None, sigma_max=None, seed=None, cpu: bool = False, transform: Callable = lambda t: t,
+                 normalized=False, factor: float = 1.0, *, make_noise_sampler: Callable, **kwargs):
+        self.factor = factor
+        self.normalized = normalized
+        self.transform = transform
+        self.device = x.device
+        self.dtype = x.dtype
+        try:
+            self.noise_sampler = make_noise_sampler(
+                x,
+                sigma_min=transform(torch.as_tensor(sigma_min)) if sigma_min is not None else None,
+                sigma_max=transform(torch.as_tensor(sigma_max)) if sigma_max is not None else None,
+                seed=seed, cpu=cpu, normalized=False, **kwargs,
+            )
+        except TypeError as exc:
+            if "unexpected keyword" not in str(exc) and "positional argument" not in str(exc):
+                raise
+            self.noise_sampler = make_noise_sampler(x)
+
+    @classmethod
+    def simple(cls, f):
+        return lambda *args, **kwargs: cls(*args, **kwargs, make_noise_sampler=lambda x, *_a, **_k: lambda _s, _sn: f(x))
+
+    @classmethod
+    def wrap(cls, f):
+        return lambda *args, **kwargs: cls(*args, **kwargs, make_noise_sampler=f)
+
+    def __call__(self, *args, **kwargs):
+        args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
+        noise = self.noise_sampler(*args, **kwargs)
+        noise = scale_noise(noise, self.factor, normalized=self.normalized)
+        if hasattr(noise, "to") and (noise.dtype != self.dtype or noise.device != self.device):
+            noise = noise.to(dtype=self.dtype, device=self.device)
+        return noise
+
+
+class AdvancedNoiseBase(CustomNoiseItemBase):
+    """py/noise.py:260-283."""
+
+    ns_factory_arg_keys = ()
+
+    @property
+    def ns_factory(self):
+        raise NotImplementedError
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.ns_factory is None:
+            raise NotImplementedError("ns_factory not implemented")
+        ns_kwargs = {k: getattr(self, k) for k in self.ns_factory_arg_keys if getattr(self, k, None) is not None}
+        self.sampler_factory = NoiseSampler.wrap(partial(self.ns_factory, **ns_kwargs))
+
+    @torch.no_grad()
+    def make_noise_sampler(self, *args, **kwargs):
+        return self.sampler_factory(*args, factor=self.factor, **kwargs)
+
+
+class AdvancedPyramidNoise(AdvancedNoiseBase):
+    """py/noise.py:286-297."""
+
+    ns_factory_arg_keys = ("discount", "iterations", "upscale_mode")
+    pyramid_variants_map = {"pyramid": PyramidNoiseGenerator, "pyramid_old": PyramidOldNoiseGenerator, "highres_pyramid": HighresPyramidNoiseGenerator}
+
+    @property
+    def ns_factory(self):
+        return self.pyramid_variants_map[self.variant]
+
+
+class Advanced1fNoise(AdvancedNoiseBase):
+    ns_factory_arg_keys = ("alpha", "hfac", "wfac", "k", "use_sqrt", "base_power")
+
+    @property
+    def ns_factory(self):
+        return OneFNoiseGenerator
+
+
+class AdvancedPowerLawNoise(AdvancedNoiseBase):
+    ns_factory_arg_keys = ("alpha", "div_max_dims", "use_sign")
+
+    @property
+    def ns_factory(self):
+        return PowerLawNoiseGenerator
+
+
+# --------------------------------------------------------------------------------------------------
+def _prep_mask(mask: Tensor, x: Tensor) -> Tensor:
+    """py/noise.py:516-522: bilinear-resize the mask to the latent size, repeat to the batch."""
+    m = utils.as_f32(mask.to(x.device, copy=True)).reshape((-1, 1, *mask.shape[-2:])).contiguous()
+    if tuple(m.shape[-2:]) != tuple(x.shape[-2:]):
+        m = utils.scale_samples(m, x.shape[-1], x.shape[-2], mode="bilinear")
+    n, b = m.shape[0], x.shape[0]
+    if n > b:
+        m = m[:b]
+    elif n < b:
+        m = m.repeat(-(-b // n), 1, 1, 1)[:b]
+    return m.contiguous()
+
+
+class CompositeNoise(CustomNoiseItemBase):
+    """py/noise.py:470-533: dst*(1-mask) + src*mask; dst is sampled before src."""
+
+    def __init__(self, factor, *, dst_noise, src_noise, normalize_dst, normalize_src, normalize_result, mask):
+        super().__init__(factor, dst_noise=dst_noise.clone(), src_noise=src_noise.clone(), normalize_dst=normalize_dst,
+                         normalize_src=normalize_src, normalize_result=normalize_result, mask=mask.clone())
+
+    def clone_key(self, k):
+        return getattr(self, k).clone() if k in {"mask", "src_noise", "dst_noise"} else super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        n_src, n_dst, n_res = (self.get_normalize(f"normalize_{k}", normalized) for k in ("src", "dst", "result"))
+        ns_dst = self.dst_noise.make_noise_sampler(x, *args, normalized=n_dst, **kwargs)
+        ns_src = self.src_noise.make_noise_sampler(x, *args, normalized=n_src, **kwargs)
+        mask = _prep_mask(self.mask, x)  # [B,1,H,W]
+        b, c = x.shape[:2]
+        # the kernel indexes the mask as flat[i % mask_n]: expand over channels once, at setup
+        mask_full = mask.expand(b, c, *mask.shape[-2:]).contiguous() if (b > 1 and c > 1) else mask
+        factor = self.factor
+
+        def noise_sampler(s, sn):
+            dst = ns_dst(s, sn)
+            src = ns_src(s, sn)
+            pop_stats(dst)
+            pop_stats(src)
+            mixed = hip_lib.mask_mix(dst, src, mask_full, out=dst)
+            return scale_noise(mixed, factor, normalized=n_res)
+
+        return noise_sampler
+
+
+class ScheduledNoise(CustomNoiseItemBase):
+    """py/noise.py:626-678: the wrapped noise inside [end_sigma, start_sigma], the fallback (or zeros) outside."""
+
+    def __init__(self, factor, *, noise, start_sigma, end_sigma, normalize, fallback_noise=None):
+        super().__init__(factor, noise=noise.clone(), start_sigma=start_sigma, end_sigma=end_sigma, normalize=normalize,
+                         fallback_noise=None if fallback_noise is None else fallback_noise.clone())
+
+    def clone_key(self, k):
+        if k == "noise":
+            return self.noise.clone()
+        if k == "fallback_noise":
+            return None if self.fallback_noise is None else self.fallback_noise.clone()
+        return super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        factor, start_sigma, end_sigma = self.factor, self.start_sigma, self.end_sigma
+        normalize = self.get_normalize("normalize", normalized)
+        ns = self.noise.make_noise_sampler(x, *args, normalized=False, **kwargs)
+        if self.fallback_noise:
+            ns_out = self.fallback_noise.make_noise_sampler(x, *args, normalized=False, **kwargs)
+        else:
+            def ns_out(_s, _sn):  # zeros; with normalisation on this yields NaN exactly like the reference
+                return torch.zeros_like(x)
+
+        def noise_sampler(s, sn):
+            if s is None or sn is None:
+                raise ValueError("ScheduledNoise requires sigma, sigma_next to be passed")
+            inside = end_sigma <= float(s) <= start_sigma
+            return scale_noise((ns if inside else ns_out)(s, sn), factor, normalized=normalize)
+
+        return noise_sampler
+
+
+class BlendedNoise(CustomNoiseItemBase):
+    """py/noise.py:1302-1407."""
+
+    def __init__(self, factor, *, normalize, blend_function, custom_noise_1=None, custom_noise_2=None, custom_noise_mask=None,
+                 noise_2_percent=0.5):
+        if custom_noise_1 is None and (custom_noise_mask is not None or noise_2_percent != 1):
+            raise ValueError("When custom_noise_1 is not attached noise_2_percent must be set to 1")
+        if custom_noise_2 is None and (custom_noise_mask is not None or noise_2_percent != 0):
+            raise ValueError("When custom_noise_2 is not attached noise_2_percent must be set to 0")
+        if custom_noise_mask is None and noise_2_percent == 1 and custom_noise_1 is None:
+            custom_noise_1, custom_noise_2, noise_2_percent = custom_noise_2, None, 0.0
+        super().__init__(factor, noise_2_percent=noise_2_percent, blend_function=blend_function, custom_noise_1=custom_noise_1.clone(),
+                         custom_noise_2=None if custom_noise_2 is None else custom_noise_2.clone(),
+                         custom_noise_mask=None if custom_noise_mask is None else custom_noise_mask.clone(), normalize=normalize)
+
+    def clone_key(self, k):
+        if k in {"custom_noise_1", "custom_noise_2", "custom_noise_mask"}:
+            v = getattr(self, k)
+            return None if v is None else v.clone()
+        return super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        factor, pct, blend_function = self.factor, self.noise_2_percent, self.blend_function
+        normalize = self.get_normalize("normalize", normalized)
+
+        def sub(chain):
+            return None if chain is None else chain.make_noise_sampler(x, *args, normalized=False, **kwargs)
+
+        ns_1, ns_2, ns_mask = sub(self.custom_noise_1), sub(self.custom_noise_2), sub(self.custom_noise_mask)
+
+        def noise_sampler(s, sn):
+            n1 = ns_1(s, sn)
+            n2 = None if ns_2 is None else ns_2(s, sn)
+            weight = pct
+            if ns_mask is not None:
+                weight = (utils.normalize_to_scale(ns_mask(s, sn), 0.0, 1.0) + pct).clamp_(0.0, 1.0)
+            if n2 is not None:
+                pop_stats(n1)
+                n1 = blend_function(n1, n2, weight)
+            return scale_noise(n1, factor, normalized=normalize)
+
+        return noise_sampler
+
+
+# --------------------------------------------------------------------------------------------------
+def _scaled(f: float):
+    def fn(t):
+        pop_stats(t)
+        return hip_lib.scale_noise_(t, f, False, None)
+    return fn
+
+
+def _mix(name, *entries, output=None):
+    return NoiseSampler.wrap(partial(MixedNoiseGenerator, name=name, noise_mix=tuple(entries), output_fun=output))
+
+
+def _pyramid_mix(name, mode=None, discount=0.6):
+    extra = {} if mode is None else {"upscale_mode": mode}
+    return _mix(name, (PyramidNoiseGenerator, {"discount": discount, **extra}, _scaled(0.2)),
+                (PyramidNoiseGenerator, {"discount": discount, **extra}, _scaled(-0.8)))
+
+
+# py/noise.py:2244-2457 — NoiseType -> factory (presets are API)
+NOISE_SAMPLERS: dict[NoiseType, Callable] = {
+    NoiseType.BROWNIAN: NoiseSampler.wrap(BrownianNoiseGenerator),
+    NoiseType.DISTRO: NoiseSampler.wrap(DistroNoiseGenerator),
+    NoiseType.GAUSSIAN: NoiseSampler.wrap(GaussianNoiseGenerator),
+    NoiseType.UNIFORM: NoiseSampler.wrap(UniformNoiseGenerator),
+    NoiseType.PERLIN: NoiseSampler.wrap(PerlinOldNoiseGenerator),
+    NoiseType.STUDENTT: NoiseSampler.wrap(StudentTNoiseGenerator),
+    NoiseType.ONEF_PINKISH: NoiseSampler.wrap(partial(OneFNoiseGenerator, alpha=-0.5)),
+    NoiseType.ONEF_GREENISH: NoiseSampler.wrap(partial(OneFNoiseGenerator, alpha=0.5)),
+    NoiseType.ONEF_PINKISHGREENISH: _mix("onef_pinkishgreenish", (OneFNoiseGenerator, {"alpha": 0.5}, None),
+                                         (OneFNoiseGenerator, {"alpha": -0.5}, None), output=_scaled(0.5)),
+    NoiseType.ONEF_PINKISH_MIX: _mix("onef_pinkish_mix", (OneFNoiseGenerator, {"alpha": -0.5}, _scaled(-1.0)),
+                                     (OneFNoiseGenerator, {"alpha": -0.5}, None), output=_scaled(0.5)),
+    NoiseType.ONEF_GREENISH_MIX: _mix("onef_greenish_mix", (OneFNoiseGenerator, {"alpha": 0.5}, _scaled(-1.0)),
+                                      (OneFNoiseGenerator, {"alpha": 0.5}, None), output=_scaled(0.5)),
+    NoiseType.WHITE: NoiseSampler.wrap(partial(PowerLawNoiseGenerator, alpha=0.0, use_sign=True)),
+    NoiseType.GREY: NoiseSampler.wrap(partial(PowerLawNoiseGenerator, alpha=0.0)),
+    NoiseType.VELVET: NoiseSampler.wrap(partial(PowerLawNoiseGenerator, alpha=1.0, use_sign=True, div_max_dims=(-3, -2, -1))),
+    NoiseType.VIOLET: NoiseSampler.wrap(partial(PowerLawNoiseGenerator, alpha=0.5, use_sign=True, div_max_dims=(-3, -2, -1))),
+    NoiseType.PINK_OLD: NoiseSampler.wrap(PinkOldNoiseGenerator),
+    NoiseType.LAPLACIAN: NoiseSampler.wrap(LaplacianNoiseGenerator),
+    NoiseType.HIGHRES_PYRAMID: NoiseSampler.wrap(HighresPyramidNoiseGenerator),
+    NoiseType.PYRAMID: NoiseSampler.wrap(PyramidNoiseGenerator),
+    NoiseType.RAINBOW_MILD: _mix("rainbow_mild", (GreenTestNoiseGenerator, {}, _scaled(0.55)), (GreenTestNoiseGenerator, {}, _scaled(0.7)),
+                                 output=_scaled(1.15)),
+    NoiseType.RAINBOW_INTENSE: _mix("rainbow_intense", (GreenTestNoiseGenerator, {}, _scaled(0.75)), (GreenTestNoiseGenerator, {}, _scaled(0.5)),
+                                    output=_scaled(1.15)),
+    NoiseType.GREEN_TEST: NoiseSampler.wrap(GreenTestNoiseGenerator),
+    NoiseType.POWER_OLD: NoiseSampler.wrap(PowerOldNoiseGenerator),
+    NoiseType.COLLATZ: NoiseSampler.wrap(CollatzNoiseGenerator),
+    NoiseType.PYRAMID_OLD: NoiseSampler.wrap(PyramidOldNoiseGenerator),
+    NoiseType.PYRAMID_BISLERP: NoiseSampler.wrap(partial(PyramidNoiseGenerator, upscale_mode="bislerp")),
+    NoiseType.HIGHRES_PYRAMID_BISLERP: NoiseSampler.wrap(partial(HighresPyramidNoiseGenerator, upscale_mode="bislerp")),
+    NoiseType.PYRAMID_AREA: NoiseSampler.wrap(partial(PyramidNoiseGenerator, upscale_mode="area")),
+    NoiseType.HIGHRES_PYRAMID_AREA: NoiseSampler.wrap(partial(HighresPyramidNoiseGenerator, upscale_mode="area")),
+    NoiseType.PYRAMID_OLD_BISLERP: NoiseSampler.wrap(partial(PyramidOldNoiseGenerator, upscale_mode="bislerp")),
+    NoiseType.PYRAMID_OLD_AREA: NoiseSampler.wrap(partial(PyramidOldNoiseGenerator, upscale_mode="area")),
+    NoiseType.PYRAMID_DISCOUNT5: NoiseSampler.wrap(partial(PyramidNoiseGenerator, discount=0.5)),
+    NoiseType.PYRAMID_MIX: _pyramid_mix("pyramid_mix"),
+    NoiseType.PYRAMID_MIX_BISLERP: _pyramid_mix("pyramid_mix_bislerp", "bislerp", 0.5),
+    NoiseType.PYRAMID_MIX_AREA: _pyramid_mix("pyramid_mix_area", "area", 0.5),
+    NoiseType.WAVELET: NoiseSampler.wrap(WaveletNoiseGenerator),
+    NoiseType.VORONOI_FUZZ: NoiseSampler.wrap(VoronoiNoiseGenerator),
+    NoiseType.VORONOI_MIX: NoiseSampler.wrap(VoronoiNoiseGenerator),
+}
+
+
+def get_noise_sampler(noise_type, x: Tensor, sigma_min, sigma_max, seed=None, cpu: bool = True, factor: float = 1.0,
+                      normalized=False, **kwargs) -> Callable:
+    """py/noise.py:2460-2489."""
+    if noise_type is None:
+        noise_type = NoiseType.GAUSSIAN
+    elif isinstance(noise_type, str):
+        noise_type = NoiseType[noise_type.upper()]
+    if noise_type == NoiseType.BROWNIAN and (sigma_min is None or sigma_max is None):
+        raise ValueError("Must pass sigma min/max when using brownian noise")
+    factory = NOISE_SAMPLERS.get(noise_type)
+    if factory is None:
+        raise ValueError("Unknown noise sampler")
+    return factory(x, sigma_min, sigma_max, seed=seed, cpu=cpu, factor=factor, normalized=normalized, **kwargs)

@@ -1,0 +1,508 @@
+"""Noise generators of the Sonar hot path on MI355X (API of the reference's ``py/noise_generation.py``).
+
+Two RNG modes, selected by the reference's own ``cpu`` flag:
+  * ``cpu=True``  (reference default, *replay*): the base random draws come from the torch CPU
+    generator in exactly the reference's order and are copied to the device; all arithmetic after the
+    draw runs in HIP kernels.  Results match the reference's CPU path within fp32 tolerance.
+  * ``cpu=False`` (*generate*): draws come from the in-kernel Philox4x32-10 counter RNG, keyed by
+    (seed, stream, global element index), fused with the generator arithmetic and with the
+    normaliser's statistics.  Values are independent of how a batch is sharded over GPUs.
+"""
+from __future__ import annotations
+
+import math
+import threading
+from enum import Enum, auto
+from typing import Optional
+
+import torch
+
+from .. import hip_lib
+from . import utils
+from .utils import attach_stats, fallback, scale_noise, tensor_to
+
+Tensor = torch.Tensor
+
+
+class NoiseType(Enum):
+    """py/noise_generation.py:31-80 (names are API: node dropdowns and YAML use them)."""
+
+    BROWNIAN = auto()
+    COLLATZ = auto()
+    DISTRO = auto()
+    GAUSSIAN = auto()
+    GREEN_TEST = auto()
+    GREY = auto()
+    HIGHRES_PYRAMID = auto()
+    HIGHRES_PYRAMID_AREA = auto()
+    HIGHRES_PYRAMID_BISLERP = auto()
+    LAPLACIAN = auto()
+    ONEF_GREENISH = auto()
+    ONEF_GREENISH_MIX = auto()
+    ONEF_PINKISH = auto()
+    ONEF_PINKISH_MIX = auto()
+    ONEF_PINKISHGREENISH = auto()
+    PERLIN = auto()
+    PINK_OLD = auto()
+    POWER_OLD = auto()
+    PYRAMID = auto()
+    PYRAMID_AREA = auto()
+    PYRAMID_BISLERP = auto()
+    PYRAMID_DISCOUNT5 = auto()
+    PYRAMID_MIX = auto()
+    PYRAMID_MIX_AREA = auto()
+    PYRAMID_MIX_BISLERP = auto()
+    PYRAMID_OLD = auto()
+    PYRAMID_OLD_AREA = auto()
+    PYRAMID_OLD_BISLERP = auto()
+    RAINBOW_INTENSE = auto()
+    RAINBOW_MILD = auto()
+    STUDENTT = auto()
+    UNIFORM = auto()
+    VELVET = auto()
+    VIOLET = auto()
+    VORONOI_FUZZ = auto()
+    VORONOI_MIX = auto()
+    WAVELET = auto()
+    WHITE = auto()
+
+    @classmethod
+    def get_names(cls, default=GAUSSIAN, skip=None):
+        if default is not None:
+            if isinstance(default, int):
+                default = cls(default)
+            yield default.name.lower()
+        for nt in cls:
+            if nt == default or (skip and nt in skip):
+                continue
+            yield nt.name.lower()
+
+
+class NoiseError(Exception):
+    pass
+
+
+# --------------------------------------------------------------------------------------------------
+# on-device RNG bookkeeping (generate mode)
+class DeviceRNG:
+    """Hands out Philox stream ids.  The key is torch's current global seed, so ``torch.manual_seed(s)``
+    makes device-generated noise reproducible exactly like it does for the reference's draws; the
+    stream counter restarts whenever the seed changes."""
+
+    _lock = threading.Lock()
+    _seed: Optional[int] = None
+    _next = 0
+
+    @classmethod
+    def take(cls, count: int = 1) -> tuple[int, int]:
+        with cls._lock:
+            seed = torch.initial_seed()
+            if seed != cls._seed:
+                cls._seed, cls._next = seed, 0
+            first = cls._next
+            cls._next += count
+            return seed, first
+
+
+class _Shard(threading.local):
+    batch_offset = 0
+
+
+_SHARD = _Shard()
+
+
+class shard_offset:
+    """Context manager: the latents generated inside are latents [batch_offset, batch_offset + B) of a
+    larger logical batch (one rank's shard) -> per-latent draws use global indices."""
+
+    def __init__(self, batch_offset: int):
+        self.batch_offset = int(batch_offset)
+
+    def __enter__(self):
+        self.prev = _SHARD.batch_offset
+        _SHARD.batch_offset = self.batch_offset
+        return self
+
+    def __exit__(self, *exc):
+        _SHARD.batch_offset = self.prev
+        return False
+
+
+def current_batch_offset() -> int:
+    return _SHARD.batch_offset
+
+
+# --------------------------------------------------------------------------------------------------
+class NoiseGenerator:
+    """py/noise_generation.py:87-179."""
+
+    name = "unknown"
+    MIN_DIMS = 1
+    MAX_DIMS = 0
+
+    def __init__(self, x, **kwargs):
+        if x.ndim < self.MIN_DIMS:
+            raise ValueError(f"Noise generator {self.name} requires at least {self.MIN_DIMS} dimension(s) but got input with shape {x.shape}")
+        if self.MAX_DIMS > 0 and x.ndim > self.MAX_DIMS:
+            raise ValueError(f"Noise generator {self.name} requires at most {self.MAX_DIMS} dimension(s) but got input with shape {x.shape}")
+        defaults = self.ng_params()
+        merged = defaults | kwargs
+        for key in defaults:
+            setattr(self, key, merged.pop(key))
+        self.options = merged  # unknown keys (seed, sigma_min, ...) are kept, not rejected
+        self.update_x(x)
+
+    @classmethod
+    def ng_params(cls):
+        return {"normalized": True, "force_normalize": None, "normalize_dims": None, "cpu": True, "generator": None}
+
+    def update_x(self, x):
+        self.shape = x.shape
+        if x.ndim in {4, 5}:
+            self.batch, self.channels = x.shape[:2]
+            self.height, self.width = x.shape[-2:]
+            self.frames = x.shape[-3] if x.ndim == 5 else None
+        else:
+            self.batch = self.channels = self.frames = self.height = self.width = None
+        self.device = x.device
+        self.gen_device = torch.device("cpu") if self.cpu else self.device
+        self.layout = x.layout
+        self.dtype = x.dtype
+        if not x.is_cuda:
+            raise hip_lib.SonarHipError(
+                f"Noise generator {self.name}: the latent lives on {x.device}; this implementation only runs on a ROCm device"
+            )
+        if x.dtype != torch.float32:
+            raise hip_lib.SonarHipError(f"Noise generator {self.name}: float32 latents only (got {x.dtype})")
+
+    # ---- draws
+    def device_key(self, streams: int = 1) -> tuple[int, int]:
+        """(seed, first stream id) for `streams` consecutive on-device draws."""
+        return DeviceRNG.take(streams)
+
+    def latent_elem_offset(self, per_latent: int) -> int:
+        return current_batch_offset() * per_latent
+
+    def rand_like(self, *, fun=torch.randn, cpu=None, to_device=True, shape=None, dtype=None, layout=None, device=None,
+                  generator=None, partials=None):
+        """py/noise_generation.py:133-155.  ``cpu`` draws on the host generator (replay), otherwise Philox on device."""
+        cpu = fallback(cpu, self.cpu)
+        shape = tuple(fallback(shape, self.shape))
+        if cpu:
+            noise = fun(*shape, generator=fallback(generator, self.generator), dtype=fallback(dtype, self.dtype),
+                        layout=fallback(layout, self.layout), device="cpu")
+            return tensor_to(noise, self.device) if to_device else noise
+        if fun not in (torch.randn, torch.rand):
+            raise NotImplementedError("on-device draws support torch.randn / torch.rand")
+        seed, stream = self.device_key()
+        per_latent = math.prod(shape[1:]) if len(shape) > 1 else 1
+        offs = self.latent_elem_offset(per_latent) if shape[0] == self.shape[0] else 0
+        if fun is torch.randn:
+            return hip_lib.philox_normal(shape, self.device, seed, stream, offs, partials)
+        return hip_lib.philox_uniform(shape, self.device, seed, stream, offs, partials=partials)
+
+    def output_hook(self, noise):
+        """py/noise_generation.py:157-165."""
+        if noise.device != self.device:
+            noise = tensor_to(noise, self.device)
+        return scale_noise(noise, normalized=self.normalized and (self.force_normalize is None or self.force_normalize is True),
+                           normalize_dims=self.normalize_dims)
+
+    def pre_hook(self):
+        pass
+
+    def generate(self, *args):
+        raise NotImplementedError
+
+    def __call__(self, *args, **kwargs):
+        self.pre_hook()
+        return self.output_hook(self.generate(*args, **kwargs))
+
+    def __str__(self):
+        params = ", ".join(f"{k}={getattr(self, k)!s}" for k in self.ng_params())
+        return f"<NoiseGenerator({self.name}): device={self.device}, shape={self.shape}, dtype={self.dtype}, {params}>"
+
+
+class FramesToChannelsNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:182-209: 5-D video latents are handled as (B, C*F, H, W)."""
+
+    MIN_DIMS = 4
+    MAX_DIMS = 5
+
+    def get_adjusted_shape(self):
+        c = self.channels * self.frames if self.frames else self.channels
+        return (self.batch, c, self.height, self.width)
+
+    def fix_output_frames(self, noise):
+        if not self.frames:
+            return noise
+        partials = utils.pop_stats(noise)
+        return attach_stats(noise.reshape(self.batch, self.channels, self.frames, self.height, self.width), partials)
+
+    def rand_like(self, *args, shape=None, **kwargs):
+        noise = super().rand_like(*args, shape=shape, **kwargs)
+        if shape is not None:
+            return noise
+        adjusted = self.get_adjusted_shape()
+        return noise.reshape(*adjusted) if tuple(noise.shape) != adjusted else noise
+
+
+class MixedNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:212-249: sum of transformed sub-generators."""
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"name": "mixed_noise", "normalized": True, "pass_args": frozenset(("cpu",)),
+                                      "noise_mix": (), "output_fun": None}
+
+    def __init__(self, x, *args, **kwargs):
+        lo = hi = None
+        self.name = kwargs["name"]
+        for entry in kwargs["noise_mix"]:
+            klass = entry[0] if isinstance(entry, (tuple, list)) else entry
+            lo = klass.MIN_DIMS if lo is None else max(lo, klass.MIN_DIMS)
+            hi = klass.MAX_DIMS if hi is None else min(hi, klass.MAX_DIMS)
+        self.MIN_DIMS, self.MAX_DIMS = lo, hi
+        super().__init__(x, *args, **kwargs)
+        passed = {k: v for k, v in kwargs.items() if k in self.pass_args}
+        self.ng_list = [(klass(x, **klass_kwargs, **passed), transform) for klass, klass_kwargs, transform in self.noise_mix]
+
+    def generate(self, *args):
+        total = None
+        for gen, transform in self.ng_list:
+            part = gen(*args)
+            utils.pop_stats(part)
+            if transform is not None:
+                part = transform(part)
+            total = part if total is None else hip_lib.axpby_(total, 1.0, part, 1.0)
+        return self.output_fun(total) if self.output_fun is not None else total
+
+
+class GaussianNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:252-260."""
+
+    name = "gaussian"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"normalized": False}
+
+    def generate(self, *_args):
+        if self.cpu:
+            return self.rand_like()
+        partials = hip_lib.new_partials(self.device)
+        return attach_stats(self.rand_like(partials=partials), partials)
+
+
+class UniformNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:496-514: (U[0,1) - sub_fac) * mul_fac + mean_fac."""
+
+    name = "uniform"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"normalized": False, "sub_fac": 0.5, "mul_fac": 3.46, "mean_fac": 0.0}
+
+    def generate(self, *_args):
+        if self.cpu:
+            return hip_lib.affine_(self.rand_like(fun=torch.rand), self.sub_fac, self.mul_fac, self.mean_fac)
+        seed, stream = self.device_key()
+        partials = hip_lib.new_partials(self.device)
+        per_latent = math.prod(self.shape[1:])
+        out = hip_lib.philox_uniform(tuple(self.shape), self.device, seed, stream, self.latent_elem_offset(per_latent),
+                                     sub=self.sub_fac, mul=self.mul_fac, add=self.mean_fac, partials=partials)
+        return attach_stats(out, partials)
+
+
+class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):
+    """py/noise_generation.py:289-493.  ``generate`` always evaluates the lattice with grid == output
+    size, i.e. one pixel per cell sampled at the cell centre, and adds the [C,H,W] lattice term to every
+    latent of the batch; the kernels implement exactly that case (``sonar_perlin_*``)."""
+
+    name = "perlin_old"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"div_fac": 2.0, "iterations": 2, "blend_mode": "lerp"}
+
+    def generate(self, *_args):
+        if self.blend_mode not in hip_lib.BLEND_IDS:
+            raise KeyError(self.blend_mode)
+        b, c, h, w = self.get_adjusted_shape()
+        partials = hip_lib.new_partials(self.device)
+        two_pi = 2.0 * math.pi
+        if self.cpu:
+            base = self.rand_like(fun=torch.rand)  # drawn first (:480), then one lattice per iteration (:465-469)
+            angles = torch.stack([
+                torch.empty(c, h + 1, w + 1, dtype=torch.float32).uniform_(to=two_pi, generator=self.generator)
+                for _ in range(self.iterations)
+            ]) if self.iterations > 0 else torch.empty(0, c, h + 1, w + 1)
+            terms = hip_lib.perlin_terms(tensor_to(angles, self.device).contiguous(), self.blend_mode)
+            out = hip_lib.perlin_apply(base.contiguous(), terms, self.div_fac, partials)
+        else:
+            seed, stream = self.device_key(2)
+            # the lattice is shared by every latent (and every rank): no batch offset in its counter
+            angles = hip_lib.philox_uniform((max(self.iterations, 0), c, h + 1, w + 1), self.device, seed, stream + 1, 0,
+                                            sub=0.0, mul=two_pi, add=0.0)
+            terms = hip_lib.perlin_terms(angles, self.blend_mode)
+            out = hip_lib.perlin_generate((b, c, h, w), terms, self.div_fac, seed, stream, self.latent_elem_offset(c * h * w), partials)
+        return self.fix_output_frames(attach_stats(out, partials))
+
+
+class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
+    """py/noise_generation.py:609-649: Gaussian base plus bilinearly upsampled Gaussian levels whose
+    sizes shrink by a random ratio r in [2,4) per level (cumulative), weighted discount**i."""
+
+    name = "pyramid"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"discount": 0.7, "upscale_mode": "bilinear", "iterations": 10}
+
+    def _plan(self, h, w, draw_r):
+        sizes, cw, ch = [], w, h
+        for i in range(self.iterations):
+            r = draw_r()
+            cw, ch = max(1, int(cw / (r**i))), max(1, int(ch / (r**i)))
+            sizes.append((ch, cw))
+            yield i, ch, cw
+            if cw == 1 or ch == 1:
+                break
+
+    def generate(self, *_args):
+        mode = self.upscale_mode
+        if mode not in hip_lib.RESAMPLE_IDS:
+            raise NotImplementedError(f"pyramid upscale_mode {mode!r} is not on the HIP path")
+        b, c, h, w = self.get_adjusted_shape()
+        partials = hip_lib.new_partials(self.device)
+        if self.cpu:
+            noise = self.rand_like().contiguous()
+            pending = None
+            for i, ch, cw in self._plan(h, w, lambda: torch.rand(1, generator=self.generator).item() * 2 + 2):
+                if pending is not None:
+                    hip_lib.resample_acc_(noise, *pending)
+                level = tensor_to(torch.randn(b, c, ch, cw, dtype=torch.float32), self.device)
+                pending = (level, self.discount**i, mode, True)
+            if pending is not None:
+                hip_lib.resample_acc_(noise, *pending, partials)  # last level also reduces the statistics
+            else:
+                partials = None
+            return self.fix_output_frames(attach_stats(noise, partials))
+        seed, stream = self.device_key(2 + self.iterations)
+        host = torch.Generator().manual_seed((seed * 0x9E3779B97F4A7C15 + stream) % (2**63))  # shared by all ranks
+        levels = []
+        plane_offset = current_batch_offset() * c
+        for i, ch, cw in self._plan(h, w, lambda: torch.rand(1, generator=host).item() * 2 + 2):
+            if (ch, cw) == (h, w) and not any(lv[0] is None for lv in levels):
+                levels.append((None, h, w, self.discount**i))  # full-resolution level drawn inside the kernel
+            else:
+                grid = hip_lib.philox_normal((b * c, ch, cw), self.device, seed, stream + 2 + i, plane_offset * ch * cw)
+                levels.append((grid, ch, cw, self.discount**i))
+        if w % 4 == 0:
+            out = hip_lib.pyramid_generate((b, c, h, w), self.device, levels, mode, seed, stream, self.latent_elem_offset(c * h * w), partials)
+        else:  # rare odd widths: same values through the unfused kernels
+            out = hip_lib.philox_normal((b, c, h, w), self.device, seed, stream, self.latent_elem_offset(c * h * w))
+            for grid, ch, cw, wt in levels:
+                if grid is None:
+                    grid = hip_lib.philox_normal((b, c, h, w), self.device, seed, stream + 1, self.latent_elem_offset(c * h * w))
+                hip_lib.resample_acc_(out, grid, wt, mode, True)
+            hip_lib.stats(out, partials)
+        return self.fix_output_frames(attach_stats(out, partials))
+
+
+class HighresPyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
+    """py/noise_generation.py:517-564: uniform base plus Gaussian levels drawn at up to 15x the
+    resolution and scaled DOWN to the latent size (replay mode only; the draws are ~60x the latent)."""
+
+    name = "highres_pyramid"
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.noise_generator is None:
+            self.noise_generator = UniformNoiseGenerator(*args, **(kwargs | {"normalized": self.normalize_noise}))
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"normalized": True, "discount": 0.7, "upscale_mode": "bilinear", "iterations": 4,
+                                      "noise_generator": None, "normalize_noise": False}
+
+    def generate(self, s, sn):
+        mode = self.upscale_mode
+        if mode not in hip_lib.RESAMPLE_IDS:
+            raise NotImplementedError(f"highres_pyramid upscale_mode {mode!r} is not on the HIP path")
+        b, c, h, w = self.get_adjusted_shape()
+        noise = self.noise_generator(s, sn).reshape(b, c, h, w)
+        utils.pop_stats(noise)
+        rs = torch.rand(self.iterations, dtype=torch.float32, generator=self.generator).cpu() * 2 + 2
+        ch, cw = h, w
+        for i in range(self.iterations):
+            r = rs[i].item()
+            ch, cw = min(h * 15, int(ch * (r**i))), min(w * 15, int(cw * (r**i)))
+            if self.cpu:
+                level = tensor_to(torch.randn(b, c, ch, cw, generator=self.generator), self.device)
+            else:
+                seed, stream = self.device_key()
+                level = hip_lib.philox_normal((b, c, ch, cw), self.device, seed, stream, current_batch_offset() * c * ch * cw)
+            hip_lib.resample_acc_(noise, level, self.discount**i, mode, True)
+            if ch >= h * 15 or cw >= w * 15:
+                break
+        return self.fix_output_frames(noise)
+
+
+class PyramidOldNoiseGenerator(FramesToChannelsNoiseGenerator):
+    """py/noise_generation.py:567-606: levels at 2x..32x resolution, normal(std=0.5**i), scaled down."""
+
+    name = "pyramid_old"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"discount": 0.8, "iterations": 5, "upscale_mode": "nearest-exact", "normalized": False}
+
+    def generate(self, *_args):
+        mode = self.upscale_mode
+        if mode not in hip_lib.RESAMPLE_IDS:
+            raise NotImplementedError(f"pyramid_old upscale_mode {mode!r} is not on the HIP path")
+        b, c, h, w = self.get_adjusted_shape()
+        noise = torch.zeros((b, c, h, w), dtype=torch.float32, device=self.device)
+        r = 1
+        for i in range(self.iterations):
+            r *= 2
+            if self.cpu:
+                level = tensor_to(torch.normal(mean=0, std=0.5**i, size=(b, c, h * r, w * r), dtype=torch.float32, generator=self.generator), self.device)
+            else:
+                seed, stream = self.device_key()
+                level = hip_lib.philox_normal((b, c, h * r, w * r), self.device, seed, stream, current_batch_offset() * c * h * r * w * r)
+                if i:
+                    hip_lib.scale_noise_(level, 0.5**i, False, None)
+            hip_lib.resample_acc_(noise, level, self.discount**i, mode, True)
+        return self.fix_output_frames(noise)
+
+
+def _off_path(type_name: str):
+    class _OffPath(NoiseGenerator):
+        name = type_name
+
+        def __init__(self, x, **kwargs):
+            raise NotImplementedError(
+                f"noise type {type_name!r} is outside the MI355X hot path of this build (SURVEY.md §8: out of scope); "
+                "there is deliberately no CPU fallback"
+            )
+
+    _OffPath.__name__ = f"{type_name.title().replace('_', '')}NoiseGenerator"
+    return _OffPath
+
+
+BrownianNoiseGenerator = _off_path("brownian")
+StudentTNoiseGenerator = _off_path("studentt")
+LaplacianNoiseGenerator = _off_path("laplacian")
+DistroNoiseGenerator = _off_path("distro")
+VoronoiNoiseGenerator = _off_path("voronoi")
+CollatzNoiseGenerator = _off_path("collatz")
+PinkOldNoiseGenerator = _off_path("pink_old")
+PowerOldNoiseGenerator = _off_path("power_old")
+GreenTestNoiseGenerator = _off_path("green_test")
+OneFNoiseGenerator = _off_path("onef")
+PowerLawNoiseGenerator = _off_path("powerlaw")
+WaveletNoiseGenerator = _off_path("wavelet")
+WaveletFilteredNoiseGenerator = _off_path("wavelet_filtered")
+ScatternetFilteredNoiseGenerator = _off_path("scatternet_filtered")

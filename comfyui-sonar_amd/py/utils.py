@@ -1,0 +1,186 @@
+"""Tensor utilities of the Sonar hot path on MI355X (mirrors the reference's ``py/utils.py`` API).
+
+Every arithmetic function launches hand-written HIP kernels (``hip_lib``) on ROCm tensors.  The
+normaliser keeps the reference's whole-tensor, data-dependent semantics (py/utils.py:85-106) but
+evaluates the thresholds on device, so there is no ``.item()`` host sync.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from .. import hip_lib
+
+Tensor = torch.Tensor
+
+UPSCALE_METHODS = ("bilinear", "nearest-exact", "nearest", "area", "bicubic", "bislerp", "adaptive_avg_pool2d")
+_HIP_RESAMPLE = {"bilinear", "nearest-exact", "area", "adaptive_avg_pool2d"}
+
+_STATS_ATTR = "_sonar_partials"
+
+
+def fallback(val, default=None):
+    return val if val is not None else default
+
+
+# --------------------------------------------------------------------------------------------------
+# fused statistics hand-off: a producer kernel that already reduced (sum, sumsq) of the tensor it
+# wrote tags the tensor; the next scale_noise() on that very tensor consumes the tag instead of
+# re-reading the tensor.  Any in-package op that changes the values must drop the tag first.
+def attach_stats(t: Tensor, partials: Optional[Tensor]) -> Tensor:
+    if partials is not None:
+        setattr(t, _STATS_ATTR, partials)
+    return t
+
+
+def pop_stats(t: Tensor) -> Optional[Tensor]:
+    p = getattr(t, _STATS_ATTR, None)
+    if p is not None:
+        delattr(t, _STATS_ATTR)
+    return p
+
+
+def _require_device(t: Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise hip_lib.SonarHipError(f"{what}: got a {t.device} tensor; this implementation only runs on a ROCm device")
+
+
+def as_f32(t: Tensor) -> Tensor:
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+def _tiles(t: Tensor, a: Tensor) -> bool:
+    """True when ``t`` broadcast against ``a`` is a plain tiling of t's flat data (trailing dims match)."""
+    ts = list(t.shape)
+    while ts and ts[0] == 1:
+        ts.pop(0)
+    return ts == list(a.shape[a.ndim - len(ts):])
+
+
+def _blend(mode: str) -> Callable:
+    def fn(a: Tensor, b: Tensor, t, out: Optional[Tensor] = None) -> Tensor:
+        _require_device(a, f"blend[{mode}]")
+        a32, b32 = as_f32(a), as_f32(b.to(a.device))
+        if b32.shape != a32.shape:
+            b32 = b32.expand_as(a32).contiguous()
+        if isinstance(t, Tensor):
+            if t.numel() == 1:
+                t = float(t)  # host scalar weight (syncs only if the weight lives on the device)
+            else:
+                t = as_f32(t.to(a.device))
+                if not _tiles(t, a32):
+                    t = t.expand_as(a32).contiguous()
+        res = hip_lib.blend(mode, a32, b32, t, out)
+        return res if a.dtype == torch.float32 else res.to(a.dtype)
+
+    fn.__name__ = f"blend_{mode}"
+    return fn
+
+
+# py/utils.py:17-21
+BLENDING_MODES = {"lerp": _blend("lerp"), "inject": _blend("inject"), "subtract_b": _blend("subtract_b")}
+
+
+# --------------------------------------------------------------------------------------------------
+def scale_noise(noise: Tensor, factor: float = 1.0, *, normalized: bool = True, threshold_std_devs: float = 2.5,
+                normalize_dims: Optional[Sequence[int]] = None) -> Tensor:
+    """py/utils.py:85-106, in place.  Two kernels (stats -> apply) unless a producer kernel already
+    attached the statistics, in which case only the apply kernel runs."""
+    n = noise.numel()
+    if not normalized or n == 0:
+        if factor == 1:
+            return noise
+        pop_stats(noise)
+        _require_device(noise, "scale_noise")
+        return hip_lib.scale_noise_(noise, factor, False, None)
+    _require_device(noise, "scale_noise")
+    if noise.dtype != torch.float32 or not noise.is_contiguous():
+        raise hip_lib.SonarHipError("scale_noise: expects a contiguous float32 tensor")
+    if normalize_dims is not None:
+        pop_stats(noise)
+        dims = sorted(d % noise.ndim for d in normalize_dims)
+        if dims != list(range(noise.ndim - len(dims), noise.ndim)):
+            raise hip_lib.SonarHipError("scale_noise: normalize_dims must be the trailing dimensions on the HIP path")
+        inner = 1
+        for d in dims:
+            inner *= noise.shape[d]
+        return hip_lib.scale_noise_rows_(noise, n // inner, inner, factor)
+    partials = pop_stats(noise)
+    if partials is None:
+        partials = hip_lib.stats(noise)
+    return hip_lib.scale_noise_(noise, factor, True, partials, threshold_std_devs=threshold_std_devs)
+
+
+def scale_samples(samples: Tensor, width: int, height: int, *, mode: str = "bicubic") -> Tensor:
+    """py/utils.py:58-67.  bilinear / nearest-exact / area / adaptive_avg_pool2d run on the HIP resampler."""
+    _require_device(samples, "scale_samples")
+    if mode in _HIP_RESAMPLE:
+        src = as_f32(samples)
+        out = torch.empty((*src.shape[:-2], height, width), dtype=torch.float32, device=src.device)
+        hip_lib.resample_acc_(out, src, 1.0, mode, accumulate=False)
+        return out if samples.dtype == torch.float32 else out.to(samples.dtype)
+    if mode in {"nearest", "bicubic"}:
+        # outside the HIP hot path (SURVEY.md §8a lists bilinear/nearest-exact/area): device-side library op
+        return torch.nn.functional.interpolate(samples, size=(height, width), mode=mode)
+    raise NotImplementedError(f"upscale mode {mode!r} needs ComfyUI's bislerp, which the reference does not vendor")
+
+
+def normalize_to_scale(latent: Tensor, target_min: float, target_max: float, *, dim=(-3, -2, -1), eps: float = 1e-07) -> Tensor:
+    """py/utils.py:452-470: per-group min/max (HIP reduction) then rescale + clamp."""
+    _require_device(latent, "normalize_to_scale")
+    x = as_f32(latent)
+    dims = sorted(d % x.ndim for d in dim) if len(dim) else list(range(x.ndim))
+    if dims != list(range(x.ndim - len(dims), x.ndim)):
+        raise hip_lib.SonarHipError("normalize_to_scale: dim must be the trailing dimensions on the HIP path")
+    inner = 1
+    for d in dims:
+        inner *= x.shape[d]
+    rows = x.numel() // inner
+    lo, hi = hip_lib.minmax_rows(x, rows, inner)
+    shape = (*x.shape[: x.ndim - len(dims)], *([1] * len(dims)))
+    lo, hi = lo.reshape(shape), hi.reshape(shape)
+    out = x - lo
+    out /= (hi - lo).add_(eps)
+    return out.mul_(target_max - target_min).add_(target_min).clamp_(target_min, target_max)
+
+
+def tensor_to(tensor: Tensor, dest) -> Tensor:
+    """py/utils.py:112-121."""
+    device = dest.device if isinstance(dest, Tensor) else dest
+    return tensor.to(device, non_blocking=True)
+
+
+def crop_samples(tensor: Tensor, width: int, height: int, *, mode: str = "center", offset_width: int = 0, offset_height: int = 0) -> Tensor:
+    """py/utils.py:526-570 (pure indexing)."""
+    if tensor.ndim < 3:
+        raise ValueError("Can only handle >= 3 dimensional tensors")
+    th, tw = tensor.shape[-2:]
+    if (tw, th) == (width, height):
+        return tensor
+    if tw < width or th < height:
+        raise ValueError("Can't crop sample smaller than requested width or height")
+    parts = ("center", "center") if mode == "center" else tuple(mode.split("_"))
+    if len(parts) != 2:
+        raise ValueError("Bad composite mode")
+    starts = []
+    for which, size, want, names in ((parts[0], th, height, ("top", "center", "bottom")), (parts[1], tw, width, ("left", "center", "right"))):
+        if which not in names:
+            raise ValueError("Bad height mode in composite mode" if names[0] == "top" else "Bad width mode in composite mode")
+        starts.append({names[0]: 0, names[1]: (size - want) // 2, names[2]: size - want}[which])
+
+    def shifted(start, want, size, off):
+        if off < 0:
+            return start - min(start, -off)
+        return start + min(size - (start + want), off)
+
+    y0 = shifted(starts[0], height, th, offset_height)
+    x0 = shifted(starts[1], width, tw, offset_width)
+    return tensor[..., y0:y0 + height, x0:x0 + width]
+
+
+def tensor_item(val, *, collapse_function=torch.max) -> float:
+    if isinstance(val, Tensor):
+        return float(collapse_function(val).detach().cpu().item())
+    return float(val)

@@ -78,6 +78,16 @@ int sonar_axpby_f32(float* y, float ymul, const float* x, float xmul, int64_t n,
 /* CompositeNoise py/noise.py:524-531: out = dst*(1-mask) + src*mask; mask is [mask_n] broadcast over n/mask_n */
 int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,
                        int64_t n, void* stream);
+/* x = (x - sub)*mul + add in place (UniformNoiseGenerator, py/noise_generation.py:508-514) */
+int sonar_affine_f32(float* x, float sub, float mul, float add, int64_t n, void* stream);
+/* out = a*s (op 0) | a/s (op 1, true division) | (a-b)/s (op 2: k-diffusion to_d, py/sonar.py:300) */
+int sonar_scalar_op_f32(int op, const float* a, const float* b, float s, float* out, int64_t n, void* stream);
+/* per-row mean and unbiased std over `inner` contiguous elements (guidance_shift / prepare_ref_latent,
+ * py/sonar.py:336-341,372-377) */
+int sonar_rowstats_f32(const float* x, int64_t rows, int64_t inner, float* mean, float* stdv, void* stream);
+/* op 0: out = (x - a[row]) / b[row]   op 1: out = x * b[row] + a[row]   (same call sites) */
+int sonar_row_affine_f32(int op, const float* x, int64_t rows, int64_t inner, const float* a, const float* b,
+                         float* out, void* stream);
 /* py/utils.py:452-470 normalize_to_scale: per row min/max rescale to [lo,hi] */
 int sonar_minmax_rows_f32(const float* x, int64_t rows, int64_t inner, float* out_min, float* out_max, void* stream);
 
