@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the Sonar hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): noise-latents/sec on SDXL 4x128x128 latents.  One "step" = one call of the
+normalised power-law (pink, alpha = 1) rFFT noise sampler for a batch of 512 latents per GPU (cfg2 of
+BASELINE.json at the north_star's batch), through the reference's plugin API
+(PowerNoiseItem.make_noise_sampler -> ns(sigma, sigma_next)), generate mode (cpu=False: spectrum drawn by
+the in-kernel Philox RNG, nothing read from HBM but the 33 KB filter).  N > 1: one process per GPU,
+every rank generates its own 512-latent shard of one logical N*512 batch (weak scaling, no data-path
+collective; shard-invariant counters) — the only collectives are the timing barrier / max.
+
+Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel, HIP-event timed in the timed
+region), `path` (whole step against the 12N accounting of SURVEY.md §8d), `cpu_baseline` (oracle on host
+cores, bounded sample, N = 1 only), `extra` (Perlin / pyramid / momentum-step throughput, untimed region).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BATCH = 512
+C, H, W = 4, 128, 128
+N_LATENT = C * H * W
+
+
+def power_item(pn):
+    return pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
+                             mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1")
+
+
+def cpu_baseline(target_s: float = 12.0):
+    """Oracle (PyTorch-CPU restatement of the reference, `port`) on the host cores: same workload at a bounded batch."""
+    from oracle import sonar_oracle as orc
+
+    shape = (64, C, H, W)
+    filt = orc.power_filter_normalize(orc.power_filter_build(shape, alpha=1.0, max_freq=0.7071), shape)
+    torch.manual_seed(0)
+    orc.power_noise(orc.draw_power(shape), filt, shape, None, 1.0, True)  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        z = orc.draw_power(shape)
+        orc.power_noise(z, filt, shape, None, 1.0, True)
+        reps += 1
+        if time.perf_counter() - t0 >= target_s or reps >= 400:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": reps * shape[0] / dt, "unit": "latents/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} x power-law normalised noise calls at batch {shape[0]} (SDXL 4x128x128), {dt:.1f} s, oracle/sonar_oracle.py"}
+
+
+def time_calls(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if distributed else 1
+    if args.gpus != n_gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+
+    import sonar_pkg
+
+    pkg = sonar_pkg.load()
+    hl = pkg.hip_lib
+    hl.load()
+    pn = importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise")
+    ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
+    nz = importlib.import_module("comfyui_sonar_amd.py.noise")
+
+    torch.manual_seed(0)
+    x = torch.zeros((BATCH, C, H, W), device=device)
+    sig = (torch.tensor(14.6), torch.tensor(10.0))
+    with ng.shard_offset(rank * BATCH):  # this rank's slice of the logical N*512 batch
+        ns = power_item(pn).make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)
+
+        def step():
+            return ns(*sig)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        hl.enable_kernel_timing(("power_irfft2", "scale_noise"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            dist.barrier()
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        kt = hl.collect_kernel_timing()
+
+        out = None
+        if rank == 0:
+            value = n_gpus * BATCH * args.steps / elapsed
+            gen_ms = sum(kt["power_irfft2"]) / max(len(kt["power_irfft2"]), 1)
+            app_ms = sum(kt["scale_noise"]) / max(len(kt["scale_noise"]), 1)
+            # dominant kernel: the fused draw + filter + C2R FFT + statistics kernel writes each latent once (4N)
+            gen_bytes = 4 * N_LATENT * BATCH
+            achieved = gen_bytes / (gen_ms * 1e-3) / 1e9
+            path_bytes = 12 * N_LATENT * BATCH  # write 4N + read 4N + write 4N
+            step_s = elapsed / args.steps
+            out = {
+                "metric": "noise-latents/sec (SDXL 4x128x128)", "value": value, "unit": "latents/s", "n_gpus": n_gpus,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "cfg2: power-law (pink, alpha=1) rFFT noise, normalised, SDXL 4x128x128, batch 512 per GPU, "
+                                       "generate mode (in-kernel Philox4x32-10)", "batch_per_gpu": BATCH, "global_batch": BATCH * n_gpus,
+                           "parallelism": f"batch-shard x{n_gpus}"},
+                "roofline": {"bound": "hbm", "kernel": "power_irfft2_kernel<128,128,GEN,STATS>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": gen_bytes,
+                             "avg_launch_us": gen_ms * 1e3,
+                             "note": "LDS/ALU-bound FFT+RNG kernel; algorithmic bytes = 4N per latent (one write)"},
+                "path": {"bytes_per_latent": 12 * N_LATENT, "achieved_GBps": path_bytes / step_s / 1e9 * 1.0,
+                         "frac_of_hbm_peak": path_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
+                         "kernels_us": {"power_irfft2": gen_ms * 1e3, "scale_noise_apply": app_ms * 1e3},
+                         "apply_kernel_GBps": 8 * N_LATENT * BATCH / (app_ms * 1e-3) / 1e9},
+            }
+            if n_gpus == 1:
+                # secondary workloads of the same path (not part of `value`)
+                extra = {}
+                ns_p = nz.get_noise_sampler("perlin", x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+                extra["perlin_latents_per_s"] = BATCH / time_calls(lambda: ns_p(*sig), 20, 5)
+                x64 = torch.zeros((64, C, H, W), device=device)
+                ns_y = nz.get_noise_sampler("pyramid", x64, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+                extra["pyramid_b64_latents_per_s"] = 64 / time_calls(lambda: ns_y(*sig), 20, 5)
+                sonar = importlib.import_module("comfyui_sonar_amd.py.sonar")
+                sb = sonar.SonarBase(sonar.SonarBase.get_config(None, {}))
+                den = torch.randn_like(x)
+                xs = torch.randn_like(x)
+                sb.momentum_step(0, xs, den, torch.tensor(10.0), torch.tensor(8.0))
+                dt = time_calls(lambda: sb.momentum_step(1, xs, den, torch.tensor(8.0), torch.tensor(6.0)), 20, 5)
+                extra["momentum_euler_latent_steps_per_s"] = BATCH / dt
+                extra["momentum_euler_GBps_at_20N"] = 20 * N_LATENT * BATCH / dt / 1e9
+                out["extra"] = extra
+    if rank == 0:
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
