@@ -1,0 +1,120 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/sonar_hip.h declares (no
+compute calls without a GPU); host-side logic that needs no device."""
+import importlib
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "sonar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sonar_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_header_symbol(pkg):
+    import __graft_entry__
+
+    __graft_entry__.build()
+    lib = pkg.hip_lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 35
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in include/sonar_hip.h but not exported"
+    assert set(syms) == set(pkg.hip_lib.SIGNATURES), "ctypes table and header disagree"
+    assert lib.sonar_abi_version() == 1
+    assert lib.sonar_last_error() is not None
+
+
+def test_product_never_touches_the_oracle():
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "comfyui-sonar_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} references the oracle"
+                assert "/root/reference" not in src
+
+
+def test_cpu_tensors_fail_loudly(pkg):
+    hl = pkg.hip_lib
+    with pytest.raises(hl.SonarHipError):
+        hl.stats(torch.zeros(8))
+    ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
+    with pytest.raises(hl.SonarHipError):
+        ng.GaussianNoiseGenerator(torch.zeros(1, 4, 8, 8))
+
+
+def test_noise_type_enum_and_registry(pkg):
+    nz = importlib.import_module("comfyui_sonar_amd.py.noise")
+    names = [n.name for n in nz.NoiseType]
+    assert len(names) == 38 and names[0] == "BROWNIAN" and names[-1] == "WHITE"
+    listed = list(nz.NoiseType.get_names())
+    assert listed[0] == "gaussian" and len(listed) == 38 and len(set(listed)) == 38
+    assert "brownian" not in list(nz.NoiseType.get_names(skip=(nz.NoiseType.BROWNIAN,)))
+    assert set(nz.NOISE_SAMPLERS) == set(nz.NoiseType)
+
+
+def test_chain_factor_algebra(pkg):
+    nz = importlib.import_module("comfyui_sonar_amd.py.noise")
+    chain = nz.CustomNoiseChain()
+    for f, t in ((0.6, "GAUSSIAN"), (-0.3, "UNIFORM"), (0.5, "PERLIN")):
+        chain.add(nz.CustomNoiseItem(f, noise_type=nz.NoiseType[t]))
+    assert chain.factor == pytest.approx(1.4)
+    r = chain.rescaled(2.0)
+    assert r.factor == pytest.approx(2.0) and [i.factor < 0 for i in r.items] == [False, True, False]
+    assert chain.factor == pytest.approx(1.4)  # rescaled() clones
+    with pytest.raises(ValueError):
+        chain.add(None)
+    with pytest.raises(ValueError):
+        nz.CustomNoiseItem(1.0)
+    item = nz.CustomNoiseItem(1.0, noise_type=nz.NoiseType.PERLIN, yaml_parameters="blend_mode: inject\niterations: 3")
+    assert item.ns_kwargs == {"blend_mode": "inject", "iterations": 3}
+    with pytest.raises(ValueError):
+        nz.CustomNoiseItem(1.0, noise_type=nz.NoiseType.PERLIN, yaml_parameters="- a\n- b")
+
+
+def test_sonar_config_and_ratios(pkg):
+    S = importlib.import_module("comfyui_sonar_amd.py.sonar")
+    assert len(S.SonarConfig._fields) == 17
+    sb = S.SonarBase(S.SonarConfig())
+    assert sb.history_ratios == (0.75, 1.0, 1.0)
+    assert S.SonarBase(S.SonarConfig(direction=-0.5)).history_ratios == (0.75, 1.0 + 0.5 * 0.25, -0.5)
+    assert S.SonarBase(S.SonarConfig(direction=1.5)).history_ratios[1] == 0.5
+    gated = S.SonarBase(S.SonarConfig(momentum_start_step=2, momentum_end_step=4, always_update_history=False))
+    assert [gated.check_step(i) for i in (1, 2, 4, 5)] == [False, True, True, False]
+    assert gated.check_step(0, is_history=True) is False and sb.check_step(0, is_history=True) is True
+    kc = gated.kernel_cfg(0)
+    assert (kc.use_momentum, kc.update_hist) == (0, 0)
+    down, up = S.get_ancestral_step(torch.tensor(10.0), torch.tensor(6.0), 1.0)
+    assert abs(down.item() ** 2 + up.item() ** 2 - 36.0) < 1e-4
+
+
+def test_power_filter_host_build_matches_golden(pkg, golden):
+    pn = importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise")
+    g = golden("power_filter")
+    f = pn.PowerFilter.normalize(pn.PowerFilter(alpha=1.0, max_freq=0.7071).build((1, 4, 128, 128)), (1, 4, 128, 128))
+    torch.testing.assert_close(f, g["cfg2_128x128"], rtol=2e-6, atol=1e-30)
+    a = pn.PowerFilter(alpha=1.0).build((1, 4, 32, 32))
+    b = pn.PowerFilter(alpha=0.0, min_freq=0.2, max_freq=0.3).build((1, 4, 32, 32))
+    for mode in ("max", "min", "add", "sub", "mul"):
+        torch.testing.assert_close(pn.PowerFilter.compose(a.clone(), b.clone(), mode), g[f"compose_{mode}"], rtol=2e-6, atol=1e-30)
+    composed = pn.PowerFilter(alpha=1.0, compose_with=pn.PowerFilter(alpha=0.0, min_freq=0.2, max_freq=0.3)).build((1, 4, 32, 32))
+    torch.testing.assert_close(composed, g["compose_max"], rtol=2e-6, atol=1e-30)
+    clone = pn.PowerFilter(alpha=0.5, rotate=10.0, compose_with=pn.PowerFilter(alpha=2.0)).clone()
+    assert clone.alpha == 0.5 and clone.compose_with.alpha == 2.0
+    assert pn.ChannelMixer(4, 0.0, torch.ones(6)).is_identity and not pn.ChannelMixer(4, 0.25, torch.ones(6)).is_identity
+
+
+def test_crop_samples(pkg):
+    u = importlib.import_module("comfyui_sonar_amd.py.utils")
+    t = torch.arange(6 * 8).reshape(1, 6, 8)
+    assert torch.equal(u.crop_samples(t, 4, 2), t[..., 2:4, 2:6])
+    assert torch.equal(u.crop_samples(t, 4, 2, mode="top_left"), t[..., 0:2, 0:4])
+    assert torch.equal(u.crop_samples(t, 4, 2, mode="bottom_right"), t[..., 4:6, 4:8])
+    assert torch.equal(u.crop_samples(t, 4, 2, mode="center", offset_width=10), t[..., 2:4, 4:8])
+    with pytest.raises(ValueError):
+        u.crop_samples(t, 16, 2)

@@ -1,0 +1,185 @@
+"""CPU: the oracle (oracle/sonar_oracle.py) against the golden vectors captured from the real reference
+(tests/golden/make_golden.py).  Same torch op sequence -> bit-exact on the machine that produced the
+fixtures; on other host CPUs vectorised transcendental/FMA paths may differ in the last bit, so the
+comparison is assert_close at 1-ulp-class tolerances (rtol 2e-6) with exact equality where no such op is involved."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sonar_oracle as orc
+
+TIGHT = dict(rtol=2e-6, atol=1e-7)
+
+
+def close(a, b, **kw):
+    torch.testing.assert_close(a, b, **(TIGHT | kw))
+
+
+@pytest.mark.parametrize("case", ["plain", "shifted", "scaled", "both", "tiny_shift"])
+def test_scale_noise(golden, case):
+    g = golden("scale_noise")
+    factor, sub, div = (float(v) for v in g[f"{case}_meta"])
+    dec = {}
+    out = orc.scale_noise(g[f"{case}_in"].clone(), factor, normalized=True, decisions=dec)
+    close(out, g[f"{case}_out"])
+    assert (dec["sub"], dec["div"]) == (bool(sub), bool(div))
+
+
+def test_scale_noise_dims_and_unnormalized(golden):
+    g = golden("scale_noise")
+    close(orc.scale_noise(g["dims_in"].clone(), 0.7, normalized=True, normalize_dims=(-2, -1)), g["dims_out"])
+    assert torch.equal(orc.scale_noise(g["dims_in"].clone(), 1.9, normalized=False), g["unnorm_out"])
+    assert orc.scale_noise(torch.zeros(0), 2.0).numel() == 0
+    assert torch.isnan(orc.scale_noise(torch.zeros(4, 4), 1.0)).all()  # zeros -> NaN
+
+
+def test_basic_types(golden):
+    g = golden("basic_types")
+    assert torch.equal(g["gaussian_0"], g["gaussian_draw"])
+    assert torch.equal(orc.uniform_noise(g["uniform_draw"]), g["uniform_0"])
+    close(orc.scale_noise(g["gaussian_draw"].clone(), 1.0, normalized=True), g["gaussian_1"])
+    torch.manual_seed(21)
+    assert torch.equal(orc.draw_gaussian((2, 4, 8, 8)), g["gaussian_draw"])  # RNG order / dtype
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_perlin(golden, tag):
+    g = golden("perlin")
+    draws = orc.PerlinDraws(g[f"{tag}_base"], tuple(g[f"{tag}_angles"]))
+    raw = orc.perlin_noise(draws, 2.0, str(g[f"{tag}_blend"]))
+    close(raw, g[f"{tag}_raw"])
+    close(orc.scale_noise(raw.clone(), 1.0, normalized=True), g[f"{tag}_out"], rtol=1e-5, atol=1e-6)
+    torch.manual_seed(int(g[f"{tag}_seed"]))
+    again = orc.draw_perlin(tuple(draws.base.shape), 2)
+    assert torch.equal(again.base, draws.base) and all(torch.equal(a, b) for a, b in zip(again.angles, draws.angles))
+    # lattice term is shared by every latent of the batch
+    if draws.base.shape[0] > 1:
+        d = raw[0] - raw[1]
+        assert torch.allclose(d, (draws.base[0] - draws.base[1]) / 2, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_pyramid(golden, tag):
+    g = golden("pyramid")
+    n = int(g[f"{tag}_nlevels"])
+    draws = orc.PyramidDraws(g[f"{tag}_base"], tuple(g[f"{tag}_rs"].tolist()), tuple(g[f"{tag}_level{i}"] for i in range(n)))
+    raw = orc.pyramid_noise(draws, float(g[f"{tag}_discount"]), str(g[f"{tag}_mode"]))
+    close(raw, g[f"{tag}_raw"])
+    h, w = draws.base.shape[-2:]
+    assert orc.pyramid_sizes(h, w, draws.rs) == [tuple(l.shape[-2:]) for l in draws.levels]
+    assert tuple(draws.levels[0].shape[-2:]) == (h, w)  # level 0 is a second full-resolution draw
+    torch.manual_seed(int(g[f"{tag}_seed"]))
+    again = orc.draw_pyramid(tuple(draws.base.shape), 10)
+    assert torch.equal(again.base, draws.base) and again.rs == draws.rs
+
+
+def test_power_filter_and_mixer(golden):
+    g = golden("power_filter")
+    cases = {"white": dict(alpha=0.0), "pink": dict(alpha=1.0), "half": dict(alpha=0.5), "brown": dict(alpha=2.0),
+             "blue": dict(alpha=-0.5), "band": dict(alpha=1.0, min_freq=0.1, max_freq=0.4),
+             "rot_stretch": dict(alpha=1.0, rotate=30.0, stretch=2.0), "squash": dict(alpha=0.5, stretch=0.5), "pnorm1": dict(alpha=1.0, pnorm=1.0)}
+    for name, kw in cases.items():
+        for hw in ((32, 32), (16, 24)):
+            shape = (1, 4, *hw)
+            raw = orc.power_filter_build(shape, **kw)
+            close(raw, g[f"{name}_{hw[0]}x{hw[1]}_raw"], atol=1e-30)
+            for mix, nf in ((1.0, 1.0), (0.6, 1.0), (1.0, 0.5)):
+                close(orc.power_filter_normalize(raw.clone(), shape, mix, nf), g[f"{name}_{hw[0]}x{hw[1]}_mix{mix}_nf{nf}"], atol=1e-30)
+    f = orc.power_filter_normalize(orc.power_filter_build((1, 4, 128, 128), alpha=1.0, max_freq=0.7071), (1, 4, 128, 128))
+    close(f, g["cfg2_128x128"], atol=1e-30)
+    assert f[0, 0, 0, 0] == 0 and abs(f.square().mean().sqrt().item() - 1.0) < 1e-6
+    corr = torch.ones(6)
+    assert torch.equal(orc.channel_mixer(4, 0.0, corr), torch.eye(4))
+    for cm in (0.25, -0.2):
+        close(orc.channel_mixer(4, cm, corr), g[f"mixer_{cm}"])
+    close(orc.channel_mixer(4, 0.4, torch.tensor([0.5, -0.3, 0.8])), g["mixer_partial"])
+
+
+@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e"])
+def test_power_noise(golden, tag):
+    g = golden("power_noise")
+    z = torch.view_as_complex(g[f"{tag}_z"].contiguous())
+    shape = tuple(g[f"{tag}_out"].shape)
+    mixer = g[f"{tag}_mixer"]
+    mixer = None if torch.equal(mixer, torch.eye(mixer.shape[0])) else mixer
+    dec, pre = {}, []
+    out = orc.power_noise(z, g[f"{tag}_filter"], shape, mixer, 1.0, bool(g[f"{tag}_normalized"]), decisions=dec, pre_norm=pre)
+    close(pre[0], g[f"{tag}_pre"], rtol=1e-5, atol=1e-6)
+    close(out, g[f"{tag}_out"], rtol=1e-5, atol=2e-6)
+    if bool(g[f"{tag}_normalized"]):
+        assert [dec["sub"], dec["div"]] == [bool(v) for v in g[f"{tag}_branches"]]
+    torch.manual_seed(int(g[f"{tag}_seed"]))
+    assert torch.equal(torch.view_as_real(orc.draw_power(shape)), g[f"{tag}_z"])
+
+
+def test_complex_randn_identity():
+    """complex64 randn == view_as_complex(randn(..., 2)) * sqrt(1/2) — defines the replay input of PW."""
+    torch.manual_seed(5)
+    a = torch.randn(3, 7, dtype=torch.complex64)
+    torch.manual_seed(5)
+    b = torch.view_as_complex(torch.randn(3, 7, 2)) * math.sqrt(0.5)
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
+
+
+def test_composition(golden):
+    g = golden("composition")
+    p = orc.PerlinDraws(g["chain_perlin_base"], tuple(g["chain_perlin_angles"]))
+    for tag in ("chain", "chain_rescaled"):
+        out = orc.chain_noise([g["chain_gauss"], orc.uniform_noise(g["chain_uniform_u"]), orc.perlin_noise(p)], g[f"{tag}_factors"].tolist(), True)
+        close(out, g[f"{tag}_out"], rtol=1e-5, atol=1e-6)
+    dst = orc.chain_noise([g["comp_gauss"]], [1.0], True)
+    src = orc.chain_noise([orc.uniform_noise(g["comp_uniform_u"])], [1.0], True)
+    close(orc.composite_noise(dst, src, g["comp_mask_resized"], 0.8, True), g["comp_out"], rtol=1e-5, atol=1e-6)
+    n1, n2 = g["blend_gauss"].clone(), orc.uniform_noise(g["blend_uniform_u"])
+    close(orc.blended_noise(n1, n2, torch.full((1,), 0.3), "lerp", 1.2, True), g["blend_out"], rtol=1e-5, atol=1e-6)
+    w = orc.blend_mask_weight(g["blendmask_maskdraw"].clone(), 0.1)
+    close(w, g["blendmask_weight"])
+    close(orc.blended_noise(g["blendmask_gauss"].clone(), orc.uniform_noise(g["blendmask_uniform_u"]), w, "inject", 1.0, True),
+          g["blendmask_out"], rtol=1e-5, atol=1e-6)
+    sp = orc.PerlinDraws(g["sched_perlin_base"], tuple(g["sched_perlin_angles"]))
+    close(orc.scale_noise(orc.perlin_noise(sp), 1.0, normalized=True), g["sched_in"], rtol=1e-5, atol=1e-6)
+    close(orc.scale_noise(g["sched_gauss"].clone(), 1.0, normalized=True), g["sched_out"], rtol=1e-5, atol=1e-6)
+
+
+def fake_model(x, sigma, **_kw):
+    s = sigma.reshape(-1, *([1] * (x.ndim - 1)))
+    return x * 0.5 + torch.tanh(x) * (0.1 * s / (1.0 + s))
+
+
+from tests.test_gpu_host_api import MOMENTUM_CASES  # noqa: E402  (same case table as the GPU parity test)
+
+
+def to_cfg(kw):
+    kw = dict(kw)
+    if "momentum_mode" in kw:
+        kw["mode"] = kw.pop("momentum_mode")
+    return orc.MomentumCfg(**kw)
+
+
+@pytest.mark.parametrize("kind", ["euler", "ancestral", "dpmpp"])
+@pytest.mark.parametrize("name", list(MOMENTUM_CASES))
+def test_momentum_traces(golden, kind, name):
+    g = golden("momentum")
+    it = iter(g["noise_bank"])
+    ns = lambda s, sn: next(it).clone()  # noqa: E731
+    trace = []
+    cfg = to_cfg(MOMENTUM_CASES[name])
+    if kind == "euler":
+        orc.sonar_euler(fake_model, g["x0"].clone(), g["sigmas"], cfg, trace=trace)
+    elif kind == "ancestral":
+        orc.sonar_euler(fake_model, g["x0"].clone(), g["sigmas"], cfg, ancestral=True, eta=0.8, s_noise=1.1, noise_fn=ns, trace=trace)
+    else:
+        orc.sonar_dpmpp_sde(fake_model, g["x0"].clone(), g["sigmas"], cfg, eta=0.9, s_noise=1.05, noise_fn=ns, trace=trace)
+    want = g[f"{kind}_{name}"]
+    assert len(trace) == want.shape[0]
+    for i, (x, _h) in enumerate(trace):
+        close(x, want[i], rtol=2e-5, atol=2e-5)
+
+
+def test_ancestral_step_formula():
+    down, up = orc.ancestral_step(torch.tensor(10.0), torch.tensor(6.0), 1.0)
+    assert abs(up.item() - min(6.0, math.sqrt(36 * (100 - 36) / 100))) < 1e-6
+    assert abs(down.item() ** 2 + up.item() ** 2 - 36.0) < 1e-4
+    assert orc.ancestral_step(3.0, 2.0, 0.0) == (2.0, 0.0)
