@@ -87,12 +87,13 @@ SIGNATURES = {
     "sonar_rfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_channel_mix_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "sonar_dwt_out_len": (_I64, [_I64, _I64, _I]),
-    "sonar_dwt2_fwd_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
-    "sonar_dwt2_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
-    "sonar_dwt2_inv_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
-    "sonar_dwt2_inv_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
-    "sonar_wcfg_band_f32": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
-    "sonar_wcfg_band_f64": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
+    "sonar_dwt2_ws_bytes": (_I64, [_I64, _I64, _I64, _I, _I, _I, _I]),
+    "sonar_dwt2_fwd_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
+    "sonar_dwt2_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
+    "sonar_dwt2_inv_f32": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
+    "sonar_dwt2_inv_f64": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
+    "sonar_wcfg_band_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
+    "sonar_wcfg_band_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
     "sonar_cast_f32_f64": (_I, [_P, _P, _I64, _P]),
 }
@@ -492,4 +493,86 @@ def channel_mix(x: torch.Tensor, mixer: torch.Tensor, partials=None) -> torch.Te
         load().sonar_channel_mix_f32(_dev(x, "x"), _dev(mixer, "mixer"), _dev(out, "out"), b, c, hw, _opt(partials, "partials", torch.float64), _stream()),
         "sonar_channel_mix_f32",
     )
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ DWT / WaveletCFG
+def _darr(vals):
+    vals = [float(v) for v in vals]
+    return (C.c_double * len(vals))(*vals)
+
+
+def _wavelet_dtype(t: torch.Tensor) -> str:
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.float64:
+        return "f64"
+    raise SonarHipError(f"DWT: float32 or float64 only (got {t.dtype})")
+
+
+def dwt_out_len(n: int, flen: int, mode: str) -> int:
+    return int(load().sonar_dwt_out_len(n, flen, DWT_MODE_IDS[mode]))
+
+
+def dwt2_forward(x: torch.Tensor, dec_lo, dec_hi, mode: str):
+    """One analysis level: x[..., H, W] -> (ll[..., h, w], hi[..., 3, h, w])."""
+    kind = _wavelet_dtype(x)
+    H, W = x.shape[-2:]
+    lead = tuple(x.shape[:-2])
+    planes = x.numel() // (H * W)
+    flen, m = len(dec_lo), DWT_MODE_IDS[mode]
+    h, w = dwt_out_len(H, flen, mode), dwt_out_len(W, flen, mode)
+    ll = torch.empty((*lead, h, w), dtype=x.dtype, device=x.device)
+    hi = torch.empty((*lead, 3, h, w), dtype=x.dtype, device=x.device)
+    ws = torch.empty(max(int(load().sonar_dwt2_ws_bytes(planes, H, W, flen, m, x.element_size(), 0)), 8), dtype=torch.uint8, device=x.device)
+    fn = load().sonar_dwt2_fwd_f32 if kind == "f32" else load().sonar_dwt2_fwd_f64
+    _check(fn(_dev(x, "x", x.dtype), _dev(ll, "ll", x.dtype), _dev(hi, "hi", x.dtype), planes, H, W, _darr(dec_lo), _darr(dec_hi), flen, m,
+              ws.data_ptr(), _stream()), f"sonar_dwt2_fwd_{kind}")
+    return ll, hi
+
+
+def dwt2_inverse(ll: torch.Tensor, hi: torch.Tensor, rec_lo, rec_hi, mode: str, out_hw=None) -> torch.Tensor:
+    """One synthesis level.  ``ll`` may be one row/column larger than the band (its leading block is used)."""
+    kind = _wavelet_dtype(hi)
+    if ll.dtype != hi.dtype:
+        raise SonarHipError("DWT inverse: ll / hi dtype mismatch")
+    h, w = hi.shape[-2:]
+    lead = tuple(hi.shape[:-3])
+    planes = hi.numel() // (3 * h * w)
+    ll_h, ll_w = ll.shape[-2:]
+    flen, m = len(rec_lo), DWT_MODE_IDS[mode]
+    full_h = 2 * h if mode == "periodization" else 2 * h - flen + 2
+    full_w = 2 * w if mode == "periodization" else 2 * w - flen + 2
+    Ho, Wo = (full_h, full_w) if out_hw is None else out_hw
+    out = torch.empty((*lead, Ho, Wo), dtype=hi.dtype, device=hi.device)
+    ws = torch.empty(max(int(load().sonar_dwt2_ws_bytes(planes, h, w, flen, m, hi.element_size(), 1)), 8), dtype=torch.uint8, device=hi.device)
+    fn = load().sonar_dwt2_inv_f32 if kind == "f32" else load().sonar_dwt2_inv_f64
+    _check(fn(_dev(ll, "ll", hi.dtype), ll_h, ll_w, _dev(hi, "hi", hi.dtype), _dev(out, "out", hi.dtype), planes, h, w, Ho, Wo,
+              _darr(rec_lo), _darr(rec_hi), flen, m, ws.data_ptr(), _stream()), f"sonar_dwt2_inv_{kind}")
+    return out
+
+
+def wcfg_band(cond: torch.Tensor, uncond: torch.Tensor, groups: int, s_cond, s_uncond, s_diff, s_final, blend_mode: str, strength: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    kind = _wavelet_dtype(cond)
+    out = torch.empty_like(cond) if out is None else out
+    group_size = cond.shape[-1] * cond.shape[-2]
+    fn = load().sonar_wcfg_band_f32 if kind == "f32" else load().sonar_wcfg_band_f64
+
+    def arr(v):
+        return None if v is None else _darr(v)
+
+    _check(fn(_dev(cond, "cond", cond.dtype), _dev(uncond, "uncond", cond.dtype), _dev(out, "out", cond.dtype), cond.numel(), group_size, groups,
+              arr(s_cond), arr(s_uncond), arr(s_diff), arr(s_final), BLEND_IDS[blend_mode], float(strength), _stream()), f"sonar_wcfg_band_{kind}")
+    return out
+
+
+def wcfg_output(x: Optional[torch.Tensor], result: torch.Tensor, shape, subtract_from_x: bool) -> torch.Tensor:
+    """out[shape] (fp32) = x - (float)crop(result)  or  (float)crop(result)."""
+    H, W = shape[-2:]
+    Hr, Wr = result.shape[-2:]
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=result.device)
+    planes = out.numel() // (H * W)
+    _check(load().sonar_wcfg_output_f32(_opt(x, "x"), _dev(result, "result", result.dtype), int(result.dtype == torch.float64), _dev(out, "out"),
+                                        planes, H, W, Hr, Wr, int(bool(subtract_from_x)), _stream()), "sonar_wcfg_output_f32")
     return out

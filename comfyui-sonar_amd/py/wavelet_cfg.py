@@ -1,0 +1,621 @@
+"""Wavelet-domain CFG on MI355X (API of the reference's ``py/wavelet_cfg.py``).
+
+Device work per call (py/wavelet_cfg.py:750-791): DWT(cond), DWT(uncond) -> per-band
+``result = blend(uncond*s_u, (cond*s_c - uncond*s_u)*s_d, strength)*s_f`` (ONE fused kernel per band,
+``sonar_wcfg_band_*``) -> IDWT -> ``x - result`` with crop and cast (``sonar_wcfg_output_f32``).
+fp64 internally when ``high_precision_mode`` (the reference default).  Rule parsing and the schedule
+arithmetic are host scalars (YAML keys and defaults are API and are kept).
+"""
+from __future__ import annotations
+
+import math
+from enum import Enum, auto
+from typing import Callable, NamedTuple, Optional, Sequence
+
+import torch
+
+from .. import hip_lib
+from . import utils
+from .wavelet_functions import Wavelet, expand_yh_scales, wavelet_scaling
+
+try:
+    from tqdm import tqdm
+
+    _say = tqdm.write
+except ImportError:  # pragma: no cover
+    _say = print
+
+
+def clamp_float(val: float, minval=0.0, maxval=1.0) -> float:
+    return max(minval, min(val, maxval))
+
+
+def filter_dict(d: dict, keep) -> dict:
+    return {k: v for k, v in d.items() if k in keep}
+
+
+def pretty_non_default(obj, *, defaults=None) -> str:
+    parts = []
+    for name in obj._fields:
+        val = getattr(obj, name)
+        if defaults is not None and val == getattr(defaults, name):
+            continue
+        parts.append(f"{name}={val.pretty_non_default()}" if hasattr(val, "pretty_non_default") else f"{name}={val!r}")
+    return f"{obj.__class__.__name__}({', '.join(parts)})"
+
+
+class WCFGSchedule(Enum):
+    LINEAR = auto()
+    LOGARITHMIC = auto()
+    LOG = LOGARITHMIC
+    EXPONENTIAL = auto()
+    EXP = EXPONENTIAL
+    HALF_COSINE = auto()
+    SINE = auto()
+    SIN = SINE
+
+    def interp(self, val: float) -> float:
+        """py/wavelet_cfg.py:43-57."""
+        val = clamp_float(val)
+        if self == WCFGSchedule.LINEAR:
+            return val
+        if self == WCFGSchedule.LOGARITHMIC:
+            out = 0.0 if val == 0 else math.log(val) + 1.0
+        elif self == WCFGSchedule.EXPONENTIAL:
+            out = math.exp(val) - 1.0
+        elif self == WCFGSchedule.HALF_COSINE:
+            out = 1.0 - ((1.0 + math.cos(val * math.pi)) / 2)
+        elif self == WCFGSchedule.SINE:
+            out = math.sin(val * math.pi)
+        else:
+            raise ValueError("Bad interpolation schedule!?")
+        return clamp_float(out)
+
+
+class WCFGSchedMode(Enum):
+    SAMPLING = auto()
+    ENABLED_SAMPLING = auto()
+    SIGMAS = auto()
+    ENABLED_SIGMAS = auto()
+    STEP = auto()
+    ENABLED_STEPS = auto()
+    MODEL_SAMPLING = SAMPLING
+    ENABLED_MODEL_SAMPLING = ENABLED_SAMPLING
+    SIGMA_RANGE = SIGMAS
+    ENABLED_SIGMA_RANGE = ENABLED_SIGMAS
+
+
+class WCFGTarget(Enum):
+    DENOISED = auto()
+    NOISE = auto()
+    NOISE_NORM = auto()
+
+
+def step_from_sigmas(sigma, sigmas: torch.Tensor, *, decimals: Optional[int] = 4, output_decimals: int = 2):
+    """py/utils.py:682-726: fractional step index of ``sigma`` within a descending schedule."""
+    sigma = utils.tensor_item(sigma)
+    sigmas = sigmas.detach().cpu()
+    if sigmas.ndim == 2:
+        sigmas = sigmas.max(dim=0).values
+    elif sigmas.ndim != 1:
+        raise ValueError(f"Unexpected number of dimensions in sigmas, should be 1 or 2 but got shape {sigmas.shape}")
+    sigmas = sigmas[:-1]
+    if not len(sigmas) or torch.any(sigmas <= 0):
+        return None
+    if decimals is not None:
+        sigmas = sigmas.round(decimals=decimals)
+        sigma = round(sigma, decimals)
+    lo, hi = sigmas.aminmax()
+    if not lo <= sigma <= hi:
+        return None
+    last = len(sigmas) - 1
+    idx = int(utils.tensor_item((sigmas - sigma).abs().argmin()))
+    at = utils.tensor_item(sigmas[idx])
+    if decimals is not None:
+        at = round(at, decimals)
+    if sigma == at:
+        return float(idx)
+    below, above = (idx, idx - 1) if sigma > at else (idx + 1, idx)
+    if min(below, above) < 0 or max(below, above) > last:
+        return None
+    s_lo, s_hi = utils.tensor_item(sigmas[below]), utils.tensor_item(sigmas[above])
+    if s_hi == s_lo:
+        return float(idx)
+    return round(above + (1.0 - ((sigma - s_lo) / (s_hi - s_lo))), output_decimals)
+
+
+class WCFGPercentages(NamedTuple):
+    """py/wavelet_cfg.py:82-212."""
+
+    sigma: float
+    sigma_min: float
+    sigma_max: float
+    sigma_first: Optional[float]
+    sigma_last: Optional[float]
+    steps: Optional[int]
+    step: Optional[float]
+    step_first: Optional[int]
+    step_last: Optional[int]
+    pct_sampling: float
+    pct_enabled_sampling: float
+    pct_sigmas: Optional[float]
+    pct_enabled_sigmas: Optional[float]
+    pct_steps: Optional[float]
+    pct_enabled_steps: Optional[float]
+
+    def invert(self) -> "WCFGPercentages":
+        flip = lambda v: None if v is None else 1.0 - v  # noqa: E731
+        return self._replace(pct_sampling=1.0 - self.pct_sampling, pct_enabled_sampling=1.0 - self.pct_enabled_sampling,
+                             pct_sigmas=flip(self.pct_sigmas), pct_enabled_sigmas=flip(self.pct_enabled_sigmas),
+                             pct_steps=flip(self.pct_steps), pct_enabled_steps=flip(self.pct_enabled_steps))
+
+    def pct_from_schedmode(self, mode: WCFGSchedMode):
+        if mode == WCFGSchedMode.MODEL_SAMPLING:
+            return self.pct_sampling
+        if mode == WCFGSchedMode.SIGMA_RANGE:
+            return self.pct_sigmas
+        if mode == WCFGSchedMode.ENABLED_MODEL_SAMPLING:
+            return self.pct_enabled_sampling
+        if mode == WCFGSchedMode.ENABLED_SIGMA_RANGE:
+            return self.pct_enabled_sigmas
+        if mode == WCFGSchedMode.STEP:
+            if self.pct_steps is None:
+                raise RuntimeError("Step percentage not available")
+            return self.pct_steps
+        raise ValueError("Unknown mode")
+
+    @classmethod
+    def build(cls, *, ms, start_sigma: float, end_sigma: float, sigma: float, sigmas: Optional[torch.Tensor], **_kw) -> "WCFGPercentages":
+        if start_sigma < end_sigma:
+            raise ValueError("start/end sigmas out of order")
+        sigma_max, sigma_min = ms.sigma_max.detach().item(), ms.sigma_min.detach().item()
+        start_sigma = min(sigma_max, start_sigma)
+        end_sigma = min(max(sigma_min, end_sigma), sigma_max)
+        sigma = min(max(sigma, sigma_min), sigma_max)
+
+        def pct_of(s):
+            return 1.0 - (ms.timestep(torch.tensor(s)) / 999).clamp(0, 1).detach().item()
+
+        pct_start, pct_end, pct_curr = pct_of(start_sigma), pct_of(end_sigma), pct_of(sigma)
+        pct_range_curr = (pct_curr - pct_start) / (pct_end - pct_start)
+        pct_sigmas = pct_enabled_sigmas = step = steps = pct_steps = pct_enabled_steps = None
+        sigma_first = sigma_last = step_first = step_last = None
+        if sigmas is not None:
+            if sigmas.ndim == 2:
+                sigmas = sigmas.max(dim=0).values
+            elif sigmas.ndim != 1:
+                raise ValueError("Unexpected number of dimensions for sample_sigmas")
+            sigmas = sigmas.detach().cpu()
+            sigma_first, sigma_last = sigmas[0].item(), sigmas[-2].item()
+            if sigma_first <= sigma_last:
+                raise ValueError("Cannot handle non-descending sigmas (possibly Restart or unsampling)")
+            pct_sigmas = (sigma_first - sigma) / (sigma_first - sigma_last)
+            start_sigma, end_sigma = min(start_sigma, sigma_first), max(end_sigma, sigma_last)
+            sigma = min(max(sigma, sigma_last), sigma_first)
+            pct_enabled_sigmas = 1.0 if start_sigma == end_sigma else (start_sigma - sigma) / (start_sigma - end_sigma)
+            steps = len(sigmas) - 1
+            if steps > 1:
+                step = step_from_sigmas(sigma, sigmas)
+                pct_steps = step / (steps - 1) if step is not None else None
+                enabled = torch.arange(len(sigmas), dtype=torch.int32)[(sigmas <= start_sigma) & (sigmas >= end_sigma)]
+                if len(enabled) > 1:
+                    step_first, step_last = enabled[0].item(), enabled[-1].item()
+                    pct_enabled_steps = (step - step_first) / (step_last - step_first)
+            else:
+                step, pct_steps = 0.0, 1.0
+        return WCFGPercentages(sigma=sigma, sigma_min=sigma_min, sigma_max=sigma_max, sigma_first=sigma_first, sigma_last=sigma_last,
+                               steps=steps, step=step, step_first=step_first, step_last=step_last, pct_sampling=pct_curr,
+                               pct_enabled_sampling=pct_range_curr, pct_sigmas=pct_sigmas, pct_enabled_sigmas=pct_enabled_sigmas,
+                               pct_steps=pct_steps, pct_enabled_steps=pct_enabled_steps)
+
+
+class WCFGScales(NamedTuple):
+    yl_scale: float = 1.0
+    yh_scales: object = 1.0
+
+    def get_scales(self, *_a, verbose: bool = False, **_k) -> "WCFGScales":
+        if verbose:
+            _say(f"WCFG:     {self.pretty_scales()}")
+        return self
+
+    def apply_scales(self, yl, yh):
+        return wavelet_scaling(yl, yh, yl_scale=self.yl_scale, yh_scales=self.yh_scales)
+
+    def get_and_apply_scales(self, pcts, yl, yh, *, verbose: bool = False):
+        return self.get_scales(pcts, yh, verbose=verbose).apply_scales(yl, yh)
+
+    def table(self, yh):
+        """(yl_scale, per-band per-orientation scales) for the fused band kernel."""
+        return float(self.yl_scale), expand_yh_scales(yh, yh_scales=1.0 if self.yh_scales is None else self.yh_scales)
+
+    def pretty_scales(self):
+        return f"low={self.yl_scale:.4f}, high={self.yh_scales!r}"
+
+
+class WCFGScheduledScale(NamedTuple):
+    """py/wavelet_cfg.py:265-323."""
+
+    schedule: WCFGSchedule = WCFGSchedule.LINEAR
+    schedule_mode: WCFGSchedMode = WCFGSchedMode.ENABLED_MODEL_SAMPLING
+    schedule_offset: float = 0.0
+    schedule_offset_after: float = 0.0
+    schedule_multiplier: float = 1.0
+    schedule_multiplier_after: float = 1.0
+    reverse_schedule: bool = False
+    reverse_schedule_after: bool = False
+    schedule_min: float = 0.0
+    schedule_max: float = 1.0
+
+    @classmethod
+    def build(cls, **kwargs) -> "WCFGScheduledScale":
+        schedule = kwargs.pop("schedule", WCFGSchedule.LINEAR)
+        if isinstance(schedule, str):
+            schedule = getattr(WCFGSchedule, schedule.upper())
+        mode = kwargs.pop("schedule_mode", WCFGSchedMode.ENABLED_MODEL_SAMPLING)
+        if isinstance(mode, str):
+            mode = getattr(WCFGSchedMode, mode.upper())
+        return WCFGScheduledScale(schedule=schedule, schedule_mode=mode, **filter_dict(kwargs, cls._fields))
+
+    def get_b_scale(self, pcts: WCFGPercentages) -> float:
+        if self.reverse_schedule:
+            pcts = pcts.invert()
+        pct = pcts.pct_from_schedmode(self.schedule_mode)
+        if pct is None:
+            raise RuntimeError("Couldn't get percentage")
+        shaped = self.schedule.interp(clamp_float((pct + self.schedule_offset) * self.schedule_multiplier))
+        pct = clamp_float((shaped + self.schedule_offset_after) * self.schedule_multiplier_after,
+                          minval=clamp_float(self.schedule_min), maxval=clamp_float(self.schedule_max))
+        return clamp_float(1.0 - pct) if self.reverse_schedule_after else pct
+
+    def pretty_non_default(self) -> str:
+        return pretty_non_default(self, defaults=WCFGScheduledScale())
+
+
+def _blend_scalar(a: float, b: float, t: float, mode: str) -> float:
+    """py/utils.py:33-55 (blend_scalar): plain lerp, or the named blend evaluated in fp64."""
+    if mode == "lerp":
+        return a * (1.0 - t) + b * t
+    if mode == "inject":
+        return a + b * t
+    if mode == "subtract_b":
+        return a - b * t
+    raise KeyError(mode)
+
+
+class WCFGScalesRange(NamedTuple):
+    """py/wavelet_cfg.py:326-420."""
+
+    scales_start: WCFGScales = WCFGScales()
+    scales_end: Optional[WCFGScales] = None
+    scheduler: Optional[WCFGScheduledScale] = None
+    blend_mode: str = "lerp"
+
+    @classmethod
+    def build(cls, **kwargs):
+        start = kwargs.pop("scales_start", None)
+        if start is None:
+            start = {"yl_scale": kwargs.pop("yl_scale", 1.0), "yh_scales": kwargs.pop("yh_scales", 1.0)}
+        end = filter_dict(kwargs.pop("scales_end", {}), WCFGScales._fields)
+        if not end or end == start:
+            return WCFGScales(yl_scale=start.get("yl_scale", 1.0), yh_scales=start.get("yh_scales", 1.0))
+        blend_mode = kwargs.pop("blend_mode", "lerp")
+        return WCFGScalesRange(scales_start=WCFGScales(**start), scales_end=WCFGScales(**end),
+                               scheduler=WCFGScheduledScale.build(**kwargs), blend_mode=blend_mode)
+
+    def get_scales(self, pcts: WCFGPercentages, yh, *, verbose: bool = False) -> WCFGScales:
+        if self.scales_end is None or self.scheduler is None:
+            return self.scales_start.get_scales()
+        pct = self.scheduler.get_b_scale(pcts)
+        start, end = self.scales_start, self.scales_end
+        if self.blend_mode == "lerp" and (pct <= 0 or pct >= 1):
+            return start if pct <= 0 else end
+        s_tab = expand_yh_scales(yh, yh_scales=start.yh_scales)
+        e_tab = expand_yh_scales(yh, yh_scales=end.yh_scales)
+        out = WCFGScales(yl_scale=_blend_scalar(start.yl_scale, end.yl_scale, pct, self.blend_mode),
+                         yh_scales=tuple(tuple(_blend_scalar(a, b, pct, self.blend_mode) for a, b in zip(bs, be)) for bs, be in zip(s_tab, e_tab)))
+        if verbose:
+            _say(f"WCFG:     {out.pretty_scales()}")
+        return out
+
+    def apply_scales(self, yl, yh):
+        return self.scales_start.apply_scales(yl, yh)
+
+    def get_and_apply_scales(self, pcts, yl, yh, *, verbose: bool = False):
+        return self.get_scales(pcts, yh, verbose=verbose).apply_scales(yl, yh)
+
+    def pretty_non_default(self) -> str:
+        return pretty_non_default(self, defaults=WCFGScalesRange())
+
+
+class WCFGScheduledFloat(NamedTuple):
+    value_start: float
+    value_end: Optional[float] = None
+    scheduler: Optional[WCFGScheduledScale] = None
+
+    @classmethod
+    def build(cls, val, *, default_start=None, default_end=None, **_kw) -> "WCFGScheduledFloat":
+        if isinstance(val, float):
+            return WCFGScheduledFloat(value_start=val)
+        if not isinstance(val, dict):
+            raise TypeError("Bad type for scheduled float value")
+        val = val.copy()
+        v0, v1 = val.pop("value_start", default_start), val.pop("value_end", default_end)
+        if not isinstance(v0, (float, int)):
+            raise TypeError("Bad type for scheduled float start_value")
+        if v1 is None:
+            return WCFGScheduledFloat(value_start=val)
+        if not isinstance(v1, (float, int)):
+            raise TypeError("Bad type for scheduled float end_value")
+        return WCFGScheduledFloat(value_start=float(v0), value_end=float(v1), scheduler=WCFGScheduledScale.build(**val))
+
+    def get_value(self, pcts: WCFGPercentages) -> float:
+        if self.value_end is None or self.scheduler is None:
+            return self.value_start
+        pct = self.scheduler.get_b_scale(pcts)
+        return (1.0 - pct) * self.value_start + pct * self.value_end
+
+
+class WCFGWaveletSettings(NamedTuple):
+    """py/wavelet_cfg.py:468-503 — defaults are API: db4, level 5, symmetric."""
+
+    wave: str = "db4"
+    level: int = 5
+    padding_mode: str = "symmetric"
+    use_1d_dwt: bool = False
+    use_dtcwt: bool = False
+    biort: str = "near_sym_a"
+    qshift: str = "qshift_a"
+    inv_wave: Optional[str] = None
+    inv_padding_mode: Optional[str] = None
+    inv_biort: Optional[str] = None
+    inv_qshift: Optional[str] = None
+
+    @classmethod
+    def build(cls, **kwargs) -> "WCFGWaveletSettings":
+        return WCFGWaveletSettings(**filter_dict(kwargs, cls._fields))
+
+    def make_wavelet(self, **kwargs) -> Wavelet:
+        return Wavelet(wave=self.wave, level=self.level, mode=self.padding_mode, use_1d_dwt=self.use_1d_dwt, use_dtcwt=self.use_dtcwt,
+                       biort=self.biort, qshift=self.qshift, inv_wave=self.inv_wave, inv_mode=self.inv_padding_mode,
+                       inv_biort=self.inv_biort, inv_qshift=self.inv_qshift, **kwargs)
+
+    def pretty_non_default(self) -> str:
+        return pretty_non_default(self, defaults=DEFAULT_WAVELETSETTINGS)
+
+
+DEFAULT_WAVELETSETTINGS = WCFGWaveletSettings()
+
+
+class WCFGRule(NamedTuple):
+    """py/wavelet_cfg.py:508-597."""
+
+    start_sigma: float = math.inf
+    end_sigma: float = 0.0
+    verbose: bool = False
+    blend_mode: str = "lerp"
+    blend_strength: WCFGScheduledFloat = WCFGScheduledFloat(1.0)
+    fallback_existing: bool = True
+    target_mode: WCFGTarget = WCFGTarget.DENOISED
+    diff: object = None
+    cond: object = None
+    uncond: object = None
+    final: object = None
+    wavelet: WCFGWaveletSettings = DEFAULT_WAVELETSETTINGS
+    high_precision_mode: bool = True
+    difference_blend_mode: str = "inject"
+    difference_blend_strength: WCFGScheduledFloat = WCFGScheduledFloat(1.0)
+
+    @classmethod
+    def build(cls, **kwargs) -> "WCFGRule":
+        target = kwargs.pop("target_mode", WCFGTarget.DENOISED)
+        if isinstance(target, str):
+            target = getattr(WCFGTarget, target.upper())
+        diff = kwargs.pop("diff", None)
+        if diff is None:
+            diff = kwargs.pop("difference", None)
+
+        def scales(v):
+            return None if v is None else WCFGScalesRange.build(**v)
+
+        cond, uncond, final = (kwargs.pop(k, None) for k in ("cond", "uncond", "final"))
+        bs = kwargs.pop("blend_strength", 1.0)
+        if not isinstance(bs, (float, int, dict)):
+            raise TypeError("Bad type for blend_strength, must be float or dict")
+        dbs = kwargs.pop("difference_blend_strength", 1.0)
+        if not isinstance(dbs, (float, int, dict)):
+            raise TypeError("Bad type for difference_blend_strength, must be float or dict")
+        return WCFGRule(target_mode=target, diff=scales(diff), cond=scales(cond), uncond=scales(uncond), final=scales(final),
+                        blend_strength=WCFGScheduledFloat(bs), difference_blend_strength=WCFGScheduledFloat(dbs),
+                        wavelet=WCFGWaveletSettings.build(**kwargs), **filter_dict(kwargs, cls._fields))
+
+    def make_wavelet(self, **kwargs) -> Wavelet:
+        return self.wavelet.make_wavelet(**kwargs)
+
+    def get_and_apply_scales(self, name: str, pcts, yl, yh, *, verbose: bool = False):
+        return getattr(self, name).get_scales(pcts, yh).apply_scales(yl, yh)
+
+    def scale_table(self, name: str, pcts, yh):
+        spec = getattr(self, name)
+        if spec is None:
+            return 1.0, None
+        return spec.get_scales(pcts, yh).table(yh)
+
+    def pretty_non_default(self) -> str:
+        return pretty_non_default(self, defaults=DEFAULT_RULE)
+
+
+DEFAULT_RULE = WCFGRule()
+
+
+class WCFGRules(NamedTuple):
+    rules: Sequence = ()
+
+    def __len__(self) -> int:
+        return len(self.rules)
+
+    def __getitem__(self, idx: int) -> WCFGRule:
+        return self.rules[idx]
+
+    def __bool__(self) -> bool:
+        return bool(self.rules)
+
+    def get_rule(self, sigma: float) -> Optional[WCFGRule]:
+        for rule in self.rules:
+            if rule.end_sigma <= sigma <= (math.inf if rule.start_sigma < 0 else rule.start_sigma):
+                return rule
+        return None
+
+    @classmethod
+    def build(cls, **params) -> "WCFGRules":
+        params = params.copy()
+        extra = params.pop("rules", ())
+        return WCFGRules(rules=(WCFGRule.build(**params), *(WCFGRule.build(**p) for p in extra)))
+
+
+class WCFGContext(NamedTuple):
+    cond: torch.Tensor
+    uncond: torch.Tensor
+    x: torch.Tensor
+    sigma: torch.Tensor
+    wavelet: Wavelet
+    dtype: torch.dtype
+    op_kwargs: dict
+
+
+def _to_dtype(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    if t.dtype == dtype:
+        return t.contiguous()
+    if t.dtype == torch.float32 and dtype == torch.float64 and t.is_cuda:
+        return hip_lib.cast_f32_f64(t.contiguous())
+    return t.to(dtype).contiguous()
+
+
+class WaveletCFG:
+    """py/wavelet_cfg.py:626-842 — a ComfyUI ``sampler_cfg_function``."""
+
+    def __init__(self, *, existing_cfg: Optional[Callable], rules: WCFGRules, operation_cond=None, operation_uncond=None,
+                 operation_fallback_cfg=None, operation_wavelet_cfg=None, operation_result=None):
+        self.wavelet_cache = {}
+        self.rules = rules
+        self.fallback_cfg_function = existing_cfg if existing_cfg is not None and (not rules or rules[0].fallback_existing) else self.basic_cfg_function
+        self.operation_cond = operation_cond
+        self.operation_uncond = operation_uncond
+        self.operation_fallback_cfg = operation_fallback_cfg
+        self.operation_wavelet_cfg = operation_wavelet_cfg
+        self.operation_result = operation_result
+
+    @staticmethod
+    def basic_cfg_function(args: dict) -> torch.Tensor:
+        """py/wavelet_cfg.py:657-660: x - (uncond + (cond - uncond) * scale)."""
+        x, scale = args["input"], args["cond_scale"]
+        uncond, cond = args["uncond_denoised"], args["cond_denoised"]
+        mixed = hip_lib.blend("inject", utils.as_f32(uncond), hip_lib.blend("subtract_b", utils.as_f32(cond), utils.as_f32(uncond), 1.0), scale)
+        return hip_lib.blend("subtract_b", utils.as_f32(x), mixed, 1.0)
+
+    @staticmethod
+    def maybe_op(t, mop, **kwargs):
+        if mop is None:
+            return t
+        return mop(latent=t, **(kwargs if getattr(mop, "EXTENDED_LATENT_OPERATION", None) else {}))
+
+    def get_context(self, *, rule: WCFGRule, args: dict) -> WCFGContext:
+        """py/wavelet_cfg.py:677-727."""
+        sigma_orig = sigma = args["sigma"]
+        x = args["input"]
+        if x.ndim == 3 and not rule.wavelet.use_1d_dwt:
+            raise RuntimeError("Enable use_1d_dwt mode for 3D latents.")
+        if x.ndim < 3:
+            raise RuntimeError("Wavelet CFG can't handle latents with 2 or less dimensions.")
+        if sigma.ndim != x.ndim:
+            sigma = sigma.reshape(x.shape[0], *((1,) * (x.ndim - sigma.ndim)))
+        if rule.target_mode in {WCFGTarget.NOISE, WCFGTarget.NOISE_NORM}:
+            cond, uncond = args["cond"], args["uncond"]
+            if rule.target_mode == WCFGTarget.NOISE_NORM:
+                cond, uncond = cond / sigma, uncond / sigma
+        elif rule.target_mode == WCFGTarget.DENOISED:
+            cond, uncond = args["cond_denoised"], args["uncond_denoised"]
+        else:
+            raise ValueError("Bad target mode")
+        op_kwargs = {"sigma": sigma_orig, "cond": cond, "uncond": uncond, "cond_scale": args["cond_scale"], "raw_args": args}
+        cond = self.maybe_op(cond, self.operation_cond, **op_kwargs)
+        uncond = self.maybe_op(uncond, self.operation_uncond, **op_kwargs)
+        eff_dtype = torch.float64 if rule.high_precision_mode else x.dtype
+        wavelet = self.wavelet_cache.get(id(rule))
+        if wavelet is None:
+            wavelet = self.wavelet_cache[id(rule)] = rule.make_wavelet()
+        wavelet = wavelet.to(device=x.device, dtype=eff_dtype)
+        if x.ndim > 4:
+            cond = cond.flatten(start_dim=1, end_dim=cond.ndim - 3)
+            uncond = uncond.flatten(start_dim=1, end_dim=uncond.ndim - 3)
+        return WCFGContext(cond=cond, uncond=uncond, x=x, sigma=sigma, wavelet=wavelet, dtype=eff_dtype, op_kwargs=op_kwargs)
+
+    @classmethod
+    def wavelet_cfg_raw(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts) -> torch.Tensor:
+        """The transform-domain result in ``ctx.dtype`` at the reconstruction's own size (before cast/crop)."""
+        condw = ctx.wavelet.forward(_to_dtype(ctx.cond, ctx.dtype))
+        uncondw = ctx.wavelet.forward(_to_dtype(ctx.uncond, ctx.dtype))
+        yh = condw[1]
+        tabs = {name: rule.scale_table(name, pcts, yh) for name in ("cond", "uncond", "diff", "final")}
+        strength = rule.difference_blend_strength.get_value(pcts)
+        mode = rule.difference_blend_mode
+
+        def band_scales(j):
+            return [None if tabs[name][1] is None else tabs[name][1][j] if j < len(tabs[name][1]) else None for name in ("cond", "uncond", "diff", "final")]
+
+        yl = hip_lib.wcfg_band(condw[0], uncondw[0], 1, *[[tabs[n][0]] for n in ("cond", "uncond", "diff", "final")], mode, strength, out=condw[0])
+        out_yh = [hip_lib.wcfg_band(c, u, 3, *band_scales(j), mode, strength, out=c) for j, (c, u) in enumerate(zip(condw[1], uncondw[1]))]
+        return ctx.wavelet.inverse(yl, out_yh)
+
+    @classmethod
+    def wavelet_cfg(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts) -> torch.Tensor:
+        """py/wavelet_cfg.py:750-791."""
+        return cls.wavelet_cfg_raw(rule=rule, ctx=ctx, pcts=pcts).to(dtype=ctx.x.dtype)
+
+    def process_output(self, *, result: torch.Tensor, rule: WCFGRule, ctx: WCFGContext) -> torch.Tensor:
+        """py/wavelet_cfg.py:729-748 (crop to x, DENOISED: x - result; NOISE_NORM: * sigma)."""
+        x_shape = ctx.x.shape
+        if ctx.x.ndim > 4:
+            result = result[..., : x_shape[-2], : x_shape[-1]].reshape(x_shape)
+        else:
+            result = result[tuple(slice(None, sz) for sz in x_shape)]
+        if rule.target_mode == WCFGTarget.DENOISED:
+            result = hip_lib.blend("subtract_b", utils.as_f32(ctx.x), utils.as_f32(result), 1.0)
+        elif rule.target_mode == WCFGTarget.NOISE_NORM:
+            result = result * ctx.sigma
+        return self.maybe_op(result, self.operation_wavelet_cfg, **ctx.op_kwargs)
+
+    def __call__(self, args: dict) -> torch.Tensor:
+        """py/wavelet_cfg.py:793-842."""
+        sigma = args["sigma"]
+        sigma_f = sigma.max().item()
+        rule = self.rules.get_rule(sigma_f)
+        if rule is None:
+            return self.fallback_cfg_function(args)
+        if rule.verbose:
+            _say(f"\nWCFG: Rule matched, sigma={sigma_f:.4f}, rule={rule.pretty_non_default()}")
+        model = args["model"]
+        pcts = WCFGPercentages.build(ms=model.model_sampling, start_sigma=rule.start_sigma, end_sigma=rule.end_sigma, sigma=sigma_f,
+                                     sigmas=args.get("model_options", {}).get("transformer_options", {}).get("sample_sigmas"))
+        wcfg_blend = rule.blend_strength.get_value(pcts)
+        if rule.blend_mode == "lerp" and wcfg_blend == 0:
+            return self.maybe_op(self.fallback_cfg_function(args), self.operation_fallback_cfg, sigma=sigma, cond=args["cond_denoised"],
+                                 uncond=args["uncond_denoised"], raw_args=args)
+        ctx = self.get_context(rule=rule, args=args)
+        plain = rule.blend_mode == "lerp" and wcfg_blend == 1.0
+        x = ctx.x
+        if plain and rule.target_mode == WCFGTarget.DENOISED and x.ndim == 4 and x.dtype == torch.float32 and self.operation_wavelet_cfg is None:
+            # fast path: cast + crop + (x - result) fused in one kernel straight from the fp64/fp32 reconstruction
+            raw = self.wavelet_cfg_raw(rule=rule, ctx=ctx, pcts=pcts)
+            result = hip_lib.wcfg_output(x.contiguous(), raw, x.shape, True)
+            return self.maybe_op(result, self.operation_result, **ctx.op_kwargs).contiguous()
+        result = self.wavelet_cfg(rule=rule, ctx=ctx, pcts=pcts)
+        if not plain:
+            normal = self.maybe_op(self.fallback_cfg_function(args), self.operation_fallback_cfg, **ctx.op_kwargs)
+            if rule.target_mode == WCFGTarget.DENOISED:
+                normal = hip_lib.blend("subtract_b", utils.as_f32(ctx.x), utils.as_f32(normal), 1.0)
+            elif rule.target_mode == WCFGTarget.NOISE_NORM:
+                normal = normal / ctx.sigma
+            crop = tuple(slice(None, sz) for sz in normal.shape)
+            result = utils.BLENDING_MODES[rule.blend_mode](normal, result[crop].contiguous(), wcfg_blend)
+        result = self.process_output(result=result, ctx=ctx, rule=rule)
+        return self.maybe_op(result, self.operation_result, **ctx.op_kwargs).contiguous()

@@ -1,0 +1,176 @@
+"""2-D wavelet split on MI355X (API of the reference's ``py/wavelet_functions.py``).
+
+The reference wraps ``pytorch_wavelets`` (DWTForward / DWTInverse) and takes filter taps from ``pywt``;
+here the transform itself is a set of HIP kernels (``sonar_dwt2_{fwd,inv}_{f32,f64}``) with PyWavelets
+semantics, and the taps come from a table generated once with PyWavelets 1.1.1
+(``wavelet_taps.json``, tools/make_wavelet_taps.py).  Output layout is pytorch_wavelets':
+``yl [B,C,h_J,w_J]`` and ``yh[j] [B,C,3,h_j,w_j]`` (finest level first; orientations LH, HL, HH ==
+horizontal, vertical, diagonal == pywt cH, cV, cD).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from .. import hip_lib
+from .utils import fallback
+
+HAVE_WAVELETS = True  # the transform is built in; no optional dependency
+_TABLE = None
+
+
+def _taps(name: str) -> dict:
+    global _TABLE
+    if _TABLE is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wavelet_taps.json")
+        with open(path) as fh:
+            _TABLE = json.load(fh)["wavelets"]
+    try:
+        return _TABLE[name]
+    except KeyError:
+        raise ValueError(f"Unknown wavelet name '{name}', check wavelist() for the list of available builtin wavelets") from None
+
+
+class Wavelet:
+    """py/wavelet_functions.py:23-145 (2-D DWT variant; DTCWT / 1-D DWT are outside this build's hot path)."""
+
+    DEFAULT_MODE = "symmetric"
+    DEFAULT_LEVEL = 3
+    DEFAULT_WAVE = "db4"
+    DEFAULT_USE_1D_DWT = False
+    DEFAULT_USE_DTCWT = False
+    DEFAULT_QSHIFT = "qshift_a"
+    DEFAULT_BIORT = "near_sym_a"
+
+    def __init__(self, *, wave: str = DEFAULT_WAVE, level: int = DEFAULT_LEVEL, mode: str = DEFAULT_MODE,
+                 use_1d_dwt: bool = DEFAULT_USE_1D_DWT, use_dtcwt: bool = DEFAULT_USE_DTCWT, biort: str = DEFAULT_BIORT,
+                 qshift: str = DEFAULT_QSHIFT, inv_wave: Optional[str] = None, inv_mode: Optional[str] = None,
+                 inv_biort: Optional[str] = None, inv_qshift=None, device=None):
+        if use_dtcwt or use_1d_dwt:
+            raise NotImplementedError("DTCWT and 1-D DWT variants are not on the MI355X hot path of this build (SURVEY.md §8f rank 4)")
+        if mode not in hip_lib.DWT_MODE_IDS or fallback(inv_mode, mode) not in hip_lib.DWT_MODE_IDS:
+            raise ValueError(f"Unknown padding mode {mode!r}; valid: {', '.join(self.modelist())}")
+        self.level = int(level)
+        self.mode = mode
+        self.inv_mode = fallback(inv_mode, mode)
+        fwd, inv = _taps(wave), _taps(fallback(inv_wave, wave))
+        self.dec_lo, self.dec_hi = fwd["dec_lo"], fwd["dec_hi"]
+        self.rec_lo, self.rec_hi = inv["rec_lo"], inv["rec_hi"]
+        self.device, self.dtype = device, None
+
+    # ---- transform
+    def forward(self, t: torch.Tensor, *, forward_function: Optional[Callable] = None):
+        """DWTForward(J=level): returns (yl, [yh_0 (finest), ..., yh_{J-1}])."""
+        if forward_function is not None:
+            return forward_function(t)
+        if t.ndim != 4:
+            raise hip_lib.SonarHipError("Wavelet.forward expects a [B, C, H, W] tensor")
+        ll = t.contiguous()
+        yh = []
+        for _ in range(self.level):
+            ll, hi = hip_lib.dwt2_forward(ll, self.dec_lo, self.dec_hi, self.mode)
+            yh.append(hi)
+        return ll, yh
+
+    def _inverse(self, yl: torch.Tensor, yh: Sequence) -> torch.Tensor:
+        ll = yl.contiguous()
+        for hi in reversed(tuple(yh)):
+            # a coarser ll may be one row/column larger than the band; the kernel reads only its leading block
+            ll = hip_lib.dwt2_inverse(ll, hi.contiguous(), self.rec_lo, self.rec_hi, self.inv_mode)
+        return ll
+
+    def inverse(self, yl: torch.Tensor, yh: Sequence, *, inverse_function: Optional[Callable] = None,
+                two_step_inverse: bool = False) -> torch.Tensor:
+        inv = fallback(inverse_function, lambda pair: self._inverse(*pair))
+        if not two_step_inverse:
+            return inv((yl, yh))
+        result = inv((torch.zeros_like(yl), yh))
+        result += inv((yl, tuple(torch.zeros_like(band) for band in yh)))
+        return result
+
+    def to(self, *args, copy: bool = False, **kwargs) -> "Wavelet":
+        """Taps are host constants and the kernels follow the input dtype: nothing to move."""
+        o = Wavelet.__new__(Wavelet) if copy else self
+        if copy:
+            o.__dict__.update(self.__dict__)
+        o.device = kwargs.get("device", o.device)
+        o.dtype = kwargs.get("dtype", o.dtype)
+        return o
+
+    # ---- catalogues
+    @staticmethod
+    def wavelist() -> tuple:
+        _taps("haar")
+        return tuple(_TABLE.keys())
+
+    @staticmethod
+    def biortlist() -> tuple:
+        return ("near_sym_a", "near_sym_b", "antonini", "legall")
+
+    @staticmethod
+    def qshiftlist() -> tuple:
+        return ("qshift_a", "qshift_b", "qshift_c", "qshift_d", "qshift_06")
+
+    @staticmethod
+    def modelist() -> tuple:
+        return ("symmetric", "zero", "reflect", "replicate", "periodization", "periodic", "constant")
+
+
+def expand_yh_scales(yh: Sequence, *, yh_scales=1.0):
+    """py/wavelet_functions.py:148-190: per-band, per-orientation scale table; one ``"fill"`` entry repeats
+    the previous band's scales up to the number of bands."""
+    nbands = len(yh)
+    shape = yh[0].shape
+    norient = shape[2] if len(shape) > 3 else 1
+    if isinstance(yh_scales, (float, int)):
+        return ((float(yh_scales),) * norient,) * nbands
+    ones = (1.0,) * norient
+    rows = []
+    for band in yh_scales:
+        if isinstance(band, (float, int)):
+            rows.append((float(band),) * norient)
+        elif isinstance(band, (tuple, list)):
+            vals = tuple(float(v) for v in band[:norient])
+            rows.append(vals + ones[: norient - len(vals)])
+        else:
+            rows.append(band)
+    rows = tuple(rows)
+    if "fill" in rows:
+        k = rows.index("fill")
+        if "fill" in rows[k + 1:]:
+            raise ValueError("Only one fill allowed.")
+        if k == 0 or len(rows) < 2:
+            raise ValueError("Invalid fill value, cannot be in the first position or the only item.")
+        missing = nbands - (len(rows) - 1)
+        rows = (*rows[:k], *((rows[k - 1],) * max(missing, 0)), *rows[k + 1:])
+    return rows[:nbands]
+
+
+def wavelet_scaling(yl: torch.Tensor, yh: Sequence, yl_scale, yh_scales, *, in_place: bool = False) -> tuple:
+    """py/wavelet_functions.py:193-216."""
+    if not in_place:
+        yl = yl.clone()
+        yh = tuple(band.clone() for band in yh)
+    if yl_scale != 1.0:
+        yl *= yl_scale
+    table = expand_yh_scales(yh, yh_scales=1.0 if yh_scales is None else yh_scales)
+    for scales, band in zip(table, yh):
+        if isinstance(scales, (int, float)):
+            band *= scales
+            continue
+        for o in range(min(band.shape[2], len(scales))):
+            if scales[o] != 1.0:
+                band[:, :, o] *= scales[o]
+    return (yl, yh)
+
+
+def wavelet_blend(a: tuple, b: tuple, *, yl_factor, blend_function: Callable, yh_factor=None,
+                  yh_blend_function: Optional[Callable] = None) -> tuple:
+    """py/wavelet_functions.py:219-238."""
+    if yh_factor is None:
+        yh_factor = yl_factor
+    yh_blend_function = fallback(yh_blend_function, blend_function)
+    return (blend_function(a[0], b[0], yl_factor), tuple(yh_blend_function(ta, tb, yh_factor) for ta, tb in zip(a[1], b[1])))

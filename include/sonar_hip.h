@@ -191,36 +191,41 @@ int sonar_channel_mix_f32(const float* in, const float* mixer, float* out, int64
 /* pytorch_wavelets DWTForward/DWTInverse semantics == pywt.dwt2/idwt2 per level
  * (py/wavelet_functions.py:56-105).  One level per call; the host loops levels.
  *   mode: 0 zero, 1 symmetric, 2 reflect, 3 periodization, 4 periodic(ppd), 5 constant(replicate)
- *   dec_lo/dec_hi (rec_lo/rec_hi): host arrays of `flen` taps (pywt order)
- *   forward : x[planes][H][W] -> ll[planes][h][w], hi[planes][3][h][w] (LH,HL,HH == pywt cH,cV,cD)
- *   inverse : ll, hi -> out[planes][Ho][Wo]  (Ho,Wo = requested output size <= full reconstruction)
+ *   dec_lo/dec_hi (rec_lo/rec_hi): HOST arrays of `flen` (<= 64) taps in pywt order
+ *   forward : x[planes][H][W] -> ll[planes][h][w], hi[planes][3][h][w]  (orientations LH,HL,HH == pywt cH,cV,cD;
+ *             h = sonar_dwt_out_len(H), w = sonar_dwt_out_len(W))
+ *   inverse : ll[planes][ll_h][ll_w] (only its leading h x w block is used: pytorch_wavelets drops the extra
+ *             row/column of a coarser ll), hi[planes][3][h][w] -> out[planes][Ho][Wo], Ho/Wo <= full size
+ *             (2h - flen + 2, or 2h for periodization)
+ *   ws      : caller-provided workspace of sonar_dwt2_ws_bytes(...) bytes (row/column pass intermediate)
  */
 int64_t sonar_dwt_out_len(int64_t n, int64_t flen, int mode);
+int64_t sonar_dwt2_ws_bytes(int64_t planes, int64_t H, int64_t W, int flen, int mode, int elem_size, int inverse);
 int sonar_dwt2_fwd_f32(const float* x, float* ll, float* hi, int64_t planes, int64_t H, int64_t W,
-                       const double* dec_lo, const double* dec_hi, int flen, int mode, void* stream);
+                       const double* dec_lo, const double* dec_hi, int flen, int mode, void* ws, void* stream);
 int sonar_dwt2_fwd_f64(const double* x, double* ll, double* hi, int64_t planes, int64_t H, int64_t W,
-                       const double* dec_lo, const double* dec_hi, int flen, int mode, void* stream);
-int sonar_dwt2_inv_f32(const float* ll, const float* hi, float* out, int64_t planes, int64_t h, int64_t w,
-                       int64_t Ho, int64_t Wo, const double* rec_lo, const double* rec_hi, int flen, int mode,
-                       void* stream);
-int sonar_dwt2_inv_f64(const double* ll, const double* hi, double* out, int64_t planes, int64_t h, int64_t w,
-                       int64_t Ho, int64_t Wo, const double* rec_lo, const double* rec_hi, int flen, int mode,
-                       void* stream);
-/* WaveletCFG band arithmetic, py/wavelet_cfg.py:750-791, for one band tensor of n elements made of
- * `groups` equal contiguous groups (orientation slices) each with its own scale set:
- *   c = cond*s_cond[g]; u = uncond*s_uncond[g]; d = (c-u)*s_diff[g]; r = blend(u, d, strength)*s_final[g]
- * s_* are host arrays of `groups` doubles. */
-int sonar_wcfg_band_f32(const float* cond, const float* uncond, float* out, int64_t n, int64_t groups,
-                        const double* s_cond, const double* s_uncond, const double* s_diff, const double* s_final,
-                        int blend_mode, double strength, void* stream);
-int sonar_wcfg_band_f64(const double* cond, const double* uncond, double* out, int64_t n, int64_t groups,
-                        const double* s_cond, const double* s_uncond, const double* s_diff, const double* s_final,
-                        int blend_mode, double strength, void* stream);
-/* process_output for target=denoised, py/wavelet_cfg.py:740-745: out = x - crop(result) with dtype
- * conversion; result is [planes][Hr][Wr] (f64 or f32), x/out are [planes][H][W] fp32 */
+                       const double* dec_lo, const double* dec_hi, int flen, int mode, void* ws, void* stream);
+int sonar_dwt2_inv_f32(const float* ll, int64_t ll_h, int64_t ll_w, const float* hi, float* out, int64_t planes,
+                       int64_t h, int64_t w, int64_t Ho, int64_t Wo, const double* rec_lo, const double* rec_hi,
+                       int flen, int mode, void* ws, void* stream);
+int sonar_dwt2_inv_f64(const double* ll, int64_t ll_h, int64_t ll_w, const double* hi, double* out, int64_t planes,
+                       int64_t h, int64_t w, int64_t Ho, int64_t Wo, const double* rec_lo, const double* rec_hi,
+                       int flen, int mode, void* ws, void* stream);
+/* WaveletCFG band arithmetic, py/wavelet_cfg.py:750-791, for one band tensor of n elements whose element i
+ * belongs to orientation group g = (i / group_size) % groups (groups = 3 for yh[B,C,3,h,w], 1 for yl):
+ *   c = cond*s_cond[g]; u = uncond*s_uncond[g]; d = (c-u)*s_diff[g]; out = blend(u, d, strength)*s_final[g]
+ * s_* are HOST arrays of `groups` (<= 4) doubles; multiplications by exactly 1 are skipped like the reference. */
+int sonar_wcfg_band_f32(const float* cond, const float* uncond, float* out, int64_t n, int64_t group_size,
+                        int64_t groups, const double* s_cond, const double* s_uncond, const double* s_diff,
+                        const double* s_final, int blend_mode, double strength, void* stream);
+int sonar_wcfg_band_f64(const double* cond, const double* uncond, double* out, int64_t n, int64_t group_size,
+                        int64_t groups, const double* s_cond, const double* s_uncond, const double* s_diff,
+                        const double* s_final, int blend_mode, double strength, void* stream);
+/* process_output, py/wavelet_cfg.py:729-748: out = x - (float)crop(result)  (subtract_from_x = 1, target DENOISED)
+ * or out = (float)crop(result); result is [planes][Hr][Wr] (f64 or f32), x/out are [planes][H][W] fp32 */
 int sonar_wcfg_output_f32(const float* x, const void* result, int result_is_f64, float* out, int64_t planes,
                           int64_t H, int64_t W, int64_t Hr, int64_t Wr, int subtract_from_x, void* stream);
-/* fp32 <-> fp64 conversion of a contiguous buffer (get_context cast, py/wavelet_cfg.py:707,764-765) */
+/* fp32 -> fp64 conversion of a contiguous buffer (get_context cast, py/wavelet_cfg.py:707,764-765) */
 int sonar_cast_f32_f64(const float* in, double* out, int64_t n, void* stream);
 
 #ifdef __cplusplus

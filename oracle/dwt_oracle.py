@@ -1,0 +1,209 @@
+"""CPU oracle for the 2-D DWT / IDWT — TEST INFRASTRUCTURE ONLY (numpy, fp64 or fp32).
+
+The reference never implements wavelet arithmetic itself: ``py/wavelet_functions.py:56-105`` wraps the
+third-party ``pytorch_wavelets`` (``DWTForward(J, wave, mode)`` / ``DWTInverse(wave, mode)``), which takes its
+filter taps from ``pywt``.  Neither package is vendored, pinned (no requirements file) or installed here;
+the reference has no tests at that boundary.  This file therefore restates the *published* algorithm —
+PyWavelets' ``dwt``/``idwt`` (downsampling / upsampling convolution with signal extension) applied
+separably, in pytorch_wavelets' output layout — and is pinned against golden vectors produced by
+PyWavelets 1.1.1 (``tests/golden/make_dwt_golden.py`` -> ``tests/golden/dwt.npz``).
+Parity with the reference for rows W / WC / WF is anchored on those vectors and on the reference's call sites
+(py/wavelet_functions.py:81-105,193-238; py/wavelet_cfg.py:750-791), not on reference-run outputs.
+
+Layout (pytorch_wavelets): ``yl [B,C,h_J,w_J]``, ``yh[j] [B,C,3,h_j,w_j]`` with j = 0 the finest level and the
+orientation axis ordered (LH, HL, HH) == pywt (cH, cV, cD): cH = high-pass along H / low-pass along W.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+MODES = ("zero", "symmetric", "reflect", "periodization", "periodic", "constant")
+_TAPS = None
+
+
+def taps(name: str):
+    """(dec_lo, dec_hi, rec_lo, rec_hi) from the PyWavelets-generated table shipped with the package data."""
+    global _TAPS
+    if _TAPS is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "comfyui-sonar_amd", "wavelet_taps.json")
+        _TAPS = json.load(open(path))["wavelets"]
+    w = _TAPS[name]
+    return tuple(np.asarray(w[k], dtype=np.float64) for k in ("dec_lo", "dec_hi", "rec_lo", "rec_hi"))
+
+
+def out_len(n: int, flen: int, mode: str) -> int:
+    """pywt.dwt_coeff_len."""
+    return (n + 1) // 2 if mode == "periodization" else (n + flen - 1) // 2
+
+
+def _ext_index(idx: np.ndarray, n: int, mode: str):
+    """Map extended-signal indices to (source index, validity mask) for the non-periodization modes."""
+    valid = np.ones(idx.shape, dtype=bool)
+    if mode == "zero":
+        valid = (idx >= 0) & (idx < n)
+        src = np.clip(idx, 0, n - 1)
+    elif mode == "constant":
+        src = np.clip(idx, 0, n - 1)
+    elif mode == "periodic":
+        src = np.mod(idx, n)
+    elif mode == "symmetric":  # ... x1 x0 | x0 x1 ... x_{n-1} | x_{n-1} ...
+        p = np.mod(idx, 2 * n)
+        src = np.where(p < n, p, 2 * n - 1 - p)
+    elif mode == "reflect":    # ... x2 x1 | x0 x1 ... x_{n-1} | x_{n-2} ...
+        if n == 1:
+            src = np.zeros_like(idx)
+        else:
+            p = np.mod(idx, 2 * n - 2)
+            src = np.where(p < n, p, 2 * n - 2 - p)
+    else:
+        raise ValueError(mode)
+    return src, valid
+
+
+def dwt_axis(x: np.ndarray, lo: np.ndarray, hi: np.ndarray, mode: str, axis: int):
+    """One analysis step along ``axis``: out[i] = sum_j f[j] * ext(x)[2i + 1 - j]  (pywt downsampling_convolution);
+    periodization: out[i] = sum_j f[j] * xe[(2i - j + F/2) mod Ne], xe = x with its last sample repeated if n is odd."""
+    x = np.moveaxis(x, axis, -1)
+    n, flen = x.shape[-1], len(lo)
+    m = out_len(n, flen, mode)
+    i = np.arange(m)[:, None]
+    j = np.arange(flen)[None, :]
+    if mode == "periodization":
+        if n % 2:
+            x = np.concatenate([x, x[..., -1:]], axis=-1)
+        ne = x.shape[-1]
+        src = np.mod(2 * i - j + flen // 2, ne)
+        g = x[..., src]  # [..., m, F]
+    else:
+        src, valid = _ext_index(2 * i + 1 - j, n, mode)
+        g = x[..., src] * valid
+    a = (g * lo.astype(x.dtype)).sum(-1)
+    d = (g * hi.astype(x.dtype)).sum(-1)
+    return np.moveaxis(a, -1, axis), np.moveaxis(d, -1, axis)
+
+
+def idwt_axis(a: np.ndarray, d: np.ndarray, lo: np.ndarray, hi: np.ndarray, mode: str, axis: int):
+    """One synthesis step: x[o] = sum_{2i + j = o + F - 2} a[i] lo[j] + d[i] hi[j]  (length 2n - F + 2);
+    periodization: indices modulo 2n with 2i + j == o + F/2 - 1."""
+    a = np.moveaxis(a, axis, -1)
+    d = np.moveaxis(d, axis, -1)
+    n, flen = a.shape[-1], len(lo)
+    if mode == "periodization":
+        nout = 2 * n
+        o = np.arange(nout)[:, None]
+        i = np.arange(n)[None, :]
+        j = np.mod(o + flen // 2 - 1 - 2 * i, nout)          # [nout, n]
+        jj = j[..., None] + nout * np.arange((flen + nout - 1) // nout + 1)  # taps wrap more than once when F > 2n
+        ok = jj < flen
+        wl = np.where(ok, lo[np.minimum(jj, flen - 1)], 0.0).sum(-1)
+        wh = np.where(ok, hi[np.minimum(jj, flen - 1)], 0.0).sum(-1)
+    else:
+        nout = 2 * n - flen + 2
+        o = np.arange(nout)[:, None]
+        i = np.arange(n)[None, :]
+        j = o + flen - 2 - 2 * i
+        ok = (j >= 0) & (j < flen)
+        wl = np.where(ok, lo[np.clip(j, 0, flen - 1)], 0.0)
+        wh = np.where(ok, hi[np.clip(j, 0, flen - 1)], 0.0)
+    x = a @ wl.T.astype(a.dtype) + d @ wh.T.astype(a.dtype)
+    return np.moveaxis(x, -1, axis)
+
+
+def dwt2(x: np.ndarray, wave: str, mode: str):
+    """One 2-D level on [..., H, W] -> (ll, hi[..., 3, h, w]) in (cH, cV, cD) order."""
+    dec_lo, dec_hi, _, _ = taps(wave)
+    lo_w, hi_w = dwt_axis(x, dec_lo, dec_hi, mode, -1)
+    ll, ch = dwt_axis(lo_w, dec_lo, dec_hi, mode, -2)   # cH: high along H, low along W
+    cv, cd = dwt_axis(hi_w, dec_lo, dec_hi, mode, -2)   # cV: low along H, high along W
+    return ll, np.stack([ch, cv, cd], axis=-3)
+
+
+def idwt2(ll: np.ndarray, hi: np.ndarray, wave: str, mode: str):
+    _, _, rec_lo, rec_hi = taps(wave)
+    ch, cv, cd = hi[..., 0, :, :], hi[..., 1, :, :], hi[..., 2, :, :]
+    lo_w = idwt_axis(ll, ch, rec_lo, rec_hi, mode, -2)
+    hi_w = idwt_axis(cv, cd, rec_lo, rec_hi, mode, -2)
+    return idwt_axis(lo_w, hi_w, rec_lo, rec_hi, mode, -1)
+
+
+def wavedec2(x: np.ndarray, wave: str, mode: str, level: int):
+    """pytorch_wavelets DWTForward(J=level): (yl, [yh_finest, ..., yh_coarsest])."""
+    yh = []
+    ll = x
+    for _ in range(level):
+        ll, hi = dwt2(ll, wave, mode)
+        yh.append(hi)
+    return ll, yh
+
+
+def waverec2(yl: np.ndarray, yh, wave: str, mode: str):
+    """pytorch_wavelets DWTInverse: coarse to fine; drop the extra row/col when ll is one larger than the band."""
+    ll = yl
+    for hi in reversed(yh):
+        if ll.shape[-2] > hi.shape[-2]:
+            ll = ll[..., :-1, :]
+        if ll.shape[-1] > hi.shape[-1]:
+            ll = ll[..., :-1]
+        ll = idwt2(ll, hi, wave, mode)
+    return ll
+
+
+# ------------------------------------------------------------------------------------------------ WaveletCFG arithmetic
+def expand_yh_scales(nbands: int, norient: int, yh_scales):
+    """py/wavelet_functions.py:148-190 ("fill" repeats the previous entry up to the band count)."""
+    if isinstance(yh_scales, (float, int)):
+        return ((float(yh_scales),) * norient,) * nbands
+    template = (1.0,) * norient
+    out = []
+    for band in yh_scales:
+        if isinstance(band, (float, int)):
+            out.append((float(band),) * norient)
+        elif isinstance(band, (tuple, list)):
+            vals = tuple(float(v) for v in band[:norient])
+            out.append(vals + template[: norient - len(vals)])
+        else:
+            out.append(band)
+    out = tuple(out)
+    if "fill" in out:
+        k = out.index("fill")
+        if "fill" in out[k + 1:]:
+            raise ValueError("Only one fill allowed.")
+        if k == 0 or len(out) < 2:
+            raise ValueError("Invalid fill value, cannot be in the first position or the only item.")
+        if len(out) - 1 < nbands:
+            out = (*out[:k], *((out[k - 1],) * (nbands - (len(out) - 1))), *out[k + 1:])
+        else:
+            out = (*out[:k], *out[k + 1:])
+    return out[:nbands]
+
+
+def wavelet_scaling(yl, yh, yl_scale, yh_scales):
+    """py/wavelet_functions.py:193-216 (out of place)."""
+    yl = yl * yl_scale if yl_scale != 1.0 else yl.copy()
+    scales = expand_yh_scales(len(yh), yh[0].shape[-3], 1.0 if yh_scales is None else yh_scales)
+    out = []
+    for sc, band in zip(scales, yh):
+        band = band.copy()
+        for o in range(min(band.shape[-3], len(sc))):
+            band[..., o, :, :] *= sc[o]
+        out.append(band)
+    return yl, out
+
+
+def wavelet_cfg(cond, uncond, wave, mode, level, *, diff_yl=1.0, diff_yh=1.0, strength=1.0, blend="inject"):
+    """py/wavelet_cfg.py:750-791 with a `difference` rule only: result = blend(DWT(u), scale(DWT(c) - DWT(u)), s) -> IDWT."""
+    cl, ch = wavedec2(cond, wave, mode, level)
+    ul, uh = wavedec2(uncond, wave, mode, level)
+    dl, dh = wavelet_scaling(cl - ul, [a - b for a, b in zip(ch, uh)], diff_yl, diff_yh)
+
+    def bl(a, b):
+        if blend == "inject":
+            return a + b * strength
+        if blend == "subtract_b":
+            return a - b * strength
+        return a + strength * (b - a) if abs(strength) < 0.5 else b - (b - a) * (1 - strength)
+
+    return waverec2(bl(ul, dl), [bl(a, b) for a, b in zip(uh, dh)], wave, mode)

@@ -1,0 +1,151 @@
+"""-m gpu: 2-D DWT / IDWT kernels and WaveletCFG against PyWavelets 1.1.1 golden vectors and the numpy oracle.
+
+Tolerance: fp64 path 1e-11 (same arithmetic, different summation order); fp32 path rtol 2e-5 / atol 2e-5 on
+O(1) data (taps rounded to fp32, 8-tap dot products over up to 5 levels)."""
+import importlib
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dwt_oracle as dwo
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(f"{GOLDEN}/dwt.npz", allow_pickle=False)
+TAGS = sorted({k.split("__")[0] for k in G.files})
+
+
+@pytest.fixture(scope="module")
+def api(pkg):
+    pkg.hip_lib.load()
+    return types.SimpleNamespace(hl=pkg.hip_lib, wf=importlib.import_module("comfyui_sonar_amd.py.wavelet_functions"),
+                                 wc=importlib.import_module("comfyui_sonar_amd.py.wavelet_cfg"))
+
+
+def tol(dtype):
+    return dict(rtol=1e-11, atol=1e-11) if dtype == torch.float64 else dict(rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("tag", TAGS)
+def test_forward_and_inverse_match_pywt(api, tag, dtype):
+    wave, mode, level = G[f"{tag}__meta"]
+    level = int(level)
+    w = api.wf.Wavelet(wave=str(wave), level=level, mode=str(mode))
+    x = torch.from_numpy(G[f"{tag}__x"]).to(dtype).cuda()
+    yl, yh = w.forward(x)
+    torch.testing.assert_close(yl.cpu().double(), torch.from_numpy(G[f"{tag}__yl"]), **tol(dtype))
+    assert len(yh) == level
+    for j in range(level):
+        want = torch.from_numpy(G[f"{tag}__yh{j}"])
+        assert tuple(yh[j].shape) == tuple(want.shape)
+        torch.testing.assert_close(yh[j].cpu().double(), want, **tol(dtype))
+    gl = torch.from_numpy(G[f"{tag}__yl"]).to(dtype).cuda()
+    gh = [torch.from_numpy(G[f"{tag}__yh{j}"]).to(dtype).cuda() for j in range(level)]
+    rec = w.inverse(gl, gh)
+    torch.testing.assert_close(rec.cpu().double(), torch.from_numpy(G[f"{tag}__rec"]), **tol(dtype))
+    two = w.inverse(gl, gh, two_step_inverse=True)
+    torch.testing.assert_close(two.cpu().double(), torch.from_numpy(G[f"{tag}__rec"]), **tol(dtype))
+
+
+@pytest.mark.parametrize("wave,mode,level", [("db4", "symmetric", 5), ("haar", "periodization", 3), ("sym8", "reflect", 4), ("coif3", "zero", 2)])
+def test_perfect_reconstruction_full_batch(api, wave, mode, level):
+    """cfg4 size: 256 x 4 x 128 x 128 (fp32) — IDWT(DWT(x)) == x."""
+    torch.manual_seed(0)
+    x = torch.randn(256, 4, 128, 128, device="cuda")
+    w = api.wf.Wavelet(wave=wave, level=level, mode=mode)
+    yl, yh = w.forward(x)
+    rec = w.inverse(yl, yh)[..., :128, :128]
+    assert (rec - x).abs().max().item() < 5e-5
+    # linearity: DWT(a x) = a DWT(x)
+    yl2, _ = w.forward(x * 2)
+    torch.testing.assert_close(yl2, yl * 2, rtol=1e-6, atol=1e-6)
+
+
+def test_longest_filter_matches_oracle(api):
+    """dmey (62 taps, only approximately orthogonal: no PR property) — compare with the oracle directly."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 2, 70, 66))
+    w = api.wf.Wavelet(wave="dmey", level=2, mode="symmetric")
+    yl, yh = w.forward(torch.from_numpy(x).cuda())
+    ol, oh = dwo.wavedec2(x, "dmey", "symmetric", 2)
+    np.testing.assert_allclose(yl.cpu().numpy(), ol, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(yh[1].cpu().numpy(), oh[1], rtol=1e-10, atol=1e-10)
+    rec = w.inverse(yl, yh).cpu().numpy()
+    np.testing.assert_allclose(rec, dwo.waverec2(ol, oh, "dmey", "symmetric"), rtol=1e-10, atol=1e-10)
+
+
+def test_wavelist_and_errors(api):
+    names = api.wf.Wavelet.wavelist()
+    assert len(names) == 106 and {"haar", "db4", "sym5", "bior2.2", "coif1", "dmey"} <= set(names)
+    with pytest.raises(ValueError):
+        api.wf.Wavelet(wave="nope")
+    with pytest.raises(NotImplementedError):
+        api.wf.Wavelet(use_dtcwt=True)
+
+
+class FakeSampling:
+    sigma_min = torch.tensor(0.03)
+    sigma_max = torch.tensor(14.6)
+
+    @staticmethod
+    def timestep(sigma):
+        return (999 * (1 - (sigma.log() - np.log(0.03)) / (np.log(14.6) - np.log(0.03)))).clamp(0, 999)
+
+
+class FakeModel:
+    model_sampling = FakeSampling()
+
+
+PLACEHOLDER_RULE = dict(difference=dict(yl_scale=5.0, yh_scales=3.0))  # the node's placeholder YAML (py/nodes/misc.py)
+
+
+@pytest.mark.parametrize("high_precision", [True, False])
+@pytest.mark.parametrize("extra", [{}, {"difference_blend_strength": 0.7}, {"wave": "haar", "level": 3, "padding_mode": "periodization"},
+                                   {"difference": {"yl_scale": 2.0, "yh_scales": [1.5, [2.0, 0.5], "fill", 0.25]}, "difference_blend_mode": "lerp",
+                                    "difference_blend_strength": 0.8}])
+def test_wavelet_cfg_matches_oracle(api, high_precision, extra):
+    torch.manual_seed(1)
+    shape = (2, 4, 128, 128)
+    cond, uncond, x = (torch.randn(shape) for _ in range(3))
+    params = dict(PLACEHOLDER_RULE, high_precision_mode=high_precision)
+    params.update(extra)
+    rules = api.wc.WCFGRules.build(**params)
+    fn = api.wc.WaveletCFG(existing_cfg=None, rules=rules)
+    args = {"input": x.cuda(), "cond_scale": 7.0, "cond": (x - cond).cuda(), "uncond": (x - uncond).cuda(), "cond_denoised": cond.cuda(),
+            "uncond_denoised": uncond.cuda(), "sigma": torch.full((2,), 7.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+    out = fn(args)
+    assert out.is_contiguous() and out.shape == x.shape and out.dtype == torch.float32
+    rule = rules[0]
+    ws = rule.wavelet
+    diff = params["difference"]
+    dt = np.float64 if high_precision else np.float32
+    res = dwo.wavelet_cfg(cond.numpy().astype(dt), uncond.numpy().astype(dt), ws.wave, ws.padding_mode, ws.level, diff_yl=diff["yl_scale"],
+                          diff_yh=diff["yh_scales"], strength=params.get("difference_blend_strength", 1.0),
+                          blend=params.get("difference_blend_mode", "inject"))
+    want = x - torch.from_numpy(res[..., :128, :128].astype(np.float32))
+    torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=(2e-5 if high_precision else 2e-4))
+
+
+def test_wavelet_cfg_rule_window_and_blend(api):
+    torch.manual_seed(2)
+    shape = (1, 4, 64, 64)
+    cond, uncond, x = (torch.randn(shape, device="cuda") for _ in range(3))
+    args = {"input": x, "cond_scale": 5.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
+            "sigma": torch.full((1,), 3.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+    plain = x - (uncond + (cond - uncond) * 5.0)
+    # outside the rule's sigma window -> plain CFG
+    fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(start_sigma=14.0, end_sigma=5.0, **PLACEHOLDER_RULE))
+    torch.testing.assert_close(fn(args), plain, rtol=1e-5, atol=1e-5)
+    # blend_strength 0 -> plain CFG; 0.5 -> halfway between plain CFG and the wavelet result
+    fn0 = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(blend_strength=0.0, **PLACEHOLDER_RULE))
+    torch.testing.assert_close(fn0(args), plain, rtol=1e-5, atol=1e-5)
+    full = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**PLACEHOLDER_RULE))(args)
+    half = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(blend_strength=0.5, **PLACEHOLDER_RULE))(args)
+    torch.testing.assert_close(half, (plain + full) / 2, rtol=1e-4, atol=1e-4)
+    # identity scales: wavelet CFG with all scales 1 and strength s == uncond + s (cond - uncond)
+    ident = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(difference=dict(yl_scale=1.0, yh_scales=1.0), difference_blend_strength=5.0))
+    torch.testing.assert_close(ident(args), plain, rtol=1e-4, atol=1e-4)
