@@ -119,7 +119,7 @@ def main():
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
-        hl.enable_kernel_timing(("power_irfft2", "scale_noise"))
+        hl.enable_kernel_timing(("power_noise",))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -136,28 +136,28 @@ def main():
         out = None
         if rank == 0:
             value = n_gpus * BATCH * args.steps / elapsed
-            gen_ms = sum(kt["power_irfft2"]) / max(len(kt["power_irfft2"]), 1)
-            app_ms = sum(kt["scale_noise"]) / max(len(kt["scale_noise"]), 1)
-            # dominant kernel: the fused draw + filter + C2R FFT + statistics kernel writes each latent once (4N)
+            fused_ms = sum(kt["power_noise"]) / max(len(kt["power_noise"]), 1)
+            # sonar_power_noise_f32 = statistics pass (RNG only, no stores) + final pass (draw, filter, LDS-resident C2R FFT,
+            # normalise, ONE write of each latent): algorithmic bytes of the launch pair = 4N per latent
             gen_bytes = 4 * N_LATENT * BATCH
-            achieved = gen_bytes / (gen_ms * 1e-3) / 1e9
-            path_bytes = 12 * N_LATENT * BATCH  # write 4N + read 4N + write 4N
+            achieved = gen_bytes / (fused_ms * 1e-3) / 1e9
+            path_bytes = 12 * N_LATENT * BATCH  # SURVEY.md §8d accounting of the reference-structured path: write 4N + read 4N + write 4N
             step_s = elapsed / args.steps
             out = {
                 "metric": "noise-latents/sec (SDXL 4x128x128)", "value": value, "unit": "latents/s", "n_gpus": n_gpus,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "cfg2: power-law (pink, alpha=1) rFFT noise, normalised, SDXL 4x128x128, batch 512 per GPU, "
-                                       "generate mode (in-kernel Philox4x32-10)", "batch_per_gpu": BATCH, "global_batch": BATCH * n_gpus,
+                                       "generate mode (in-kernel Philox-seeded xoshiro128++)", "batch_per_gpu": BATCH, "global_batch": BATCH * n_gpus,
                            "parallelism": f"batch-shard x{n_gpus}"},
-                "roofline": {"bound": "hbm", "kernel": "power_irfft2_kernel<128,128,GEN,STATS>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": gen_bytes,
-                             "avg_launch_us": gen_ms * 1e3,
-                             "note": "LDS/ALU-bound FFT+RNG kernel; algorithmic bytes = 4N per latent (one write)"},
-                "path": {"bytes_per_latent": 12 * N_LATENT, "achieved_GBps": path_bytes / step_s / 1e9 * 1.0,
-                         "frac_of_hbm_peak": path_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
-                         "kernels_us": {"power_irfft2": gen_ms * 1e3, "scale_noise_apply": app_ms * 1e3},
-                         "apply_kernel_GBps": 8 * N_LATENT * BATCH / (app_ms * 1e-3) / 1e9},
+                "roofline": {"bound": "hbm", "kernel": "power_stats_kernel<128,128> + power_irfft2_kernel<128,128,GEN,NORM> (one C-ABI call)",
+                             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                             "bytes_per_launch": gen_bytes, "avg_launch_us": fused_ms * 1e3,
+                             "note": "the tensor is written once (4N/latent): statistics come from the spectrum (Parseval); "
+                                     "the kernels are LDS/ALU-bound (FFT + RNG), not HBM-bound"},
+                "path": {"bytes_per_latent_reference_structure": 12 * N_LATENT, "equivalent_GBps_at_12N": path_bytes / step_s / 1e9,
+                         "equivalent_frac_of_hbm_peak_at_12N": path_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
+                         "actual_bytes_per_latent": 4 * N_LATENT, "actual_GBps": gen_bytes / step_s / 1e9},
             }
             if n_gpus == 1:
                 # secondary workloads of the same path (not part of `value`)

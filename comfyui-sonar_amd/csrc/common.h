@@ -1,6 +1,7 @@
 // Shared device/host helpers for libsonar_hip.so (gfx950 only: wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -42,8 +43,11 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        // one 32x32->64 multiply per product (v_mad_u64_u32) instead of separate mul_hi / mul_lo
+        const uint64_t p0 = (uint64_t)M0 * (uint64_t)c0;
+        const uint64_t p1 = (uint64_t)M1 * (uint64_t)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += W0; k1 += W1;
@@ -67,7 +71,7 @@ __device__ __forceinline__ void box_muller(uint32_t ra, uint32_t rb, float& z0, 
     const float u1 = u01_open(ra);
     const float u2 = u01(rb);
     // r = sqrt(-2 ln u1) = sqrt(-2 ln2 * log2 u1)
-    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
     z0 = r * __builtin_amdgcn_cosf(u2);
     z1 = r * __builtin_amdgcn_sinf(u2);
 }
@@ -77,6 +81,43 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t stream_id
     box_muller(p.v[0], p.v[1], z[0], z[1]);
     box_muller(p.v[2], p.v[3], z[2], z[3]);
 }
+
+// ---- tile-keyed xoshiro128++ streams ------------------------------------------------------------
+// 32-bit integer multiplies are ~1/8 rate on CDNA4, so Philox4x32-10 (20 multiplies per 4 words) is
+// used only to SEED short xoshiro128++ bursts (add / rotate / xor, full rate).  A stream is keyed by
+// (seed, stream id, tile, lane): every draw is still a pure function of the global position, so
+// batches can be sharded over GPUs without changing values.
+struct Xoshiro {
+    uint32_t s0, s1, s2, s3;
+    __device__ __forceinline__ uint32_t next() {
+        const uint32_t sum = s0 + s3;
+        const uint32_t r = __builtin_amdgcn_alignbit(sum, sum, 32 - 7) + s0;  // rotl(s0 + s3, 7) + s0
+        const uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t;
+        s3 = __builtin_amdgcn_alignbit(s3, s3, 32 - 11);
+        return r;
+    }
+    __device__ __forceinline__ void normal4(float (&z)[4]) {
+        const uint32_t a = next(), b = next(), c = next(), d = next();
+        box_muller(a, b, z[0], z[1]);
+        box_muller(c, d, z[2], z[3]);
+    }
+    __device__ __forceinline__ void uniform4(float (&u)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = u01(next());
+    }
+};
+
+__device__ __forceinline__ Xoshiro rng_stream(uint64_t seed, uint64_t stream_id, uint64_t tile, uint32_t lane) {
+    const Philox4 p = philox4x32_10((uint32_t)tile, (uint32_t)(tile >> 32), (uint32_t)stream_id,
+                                    (uint32_t)((stream_id >> 32) << 16) ^ lane, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return Xoshiro{p.v[0], p.v[1], p.v[2], p.v[3] | 1u};  // never the all-zero state
+}
+
+// Flat buffers are drawn in tiles of kTileIters x 64 lanes x 4 elements: global element e belongs to
+// tile e / kTileElems, lane (e % 256) / 4, burst step (e % kTileElems) / 256, slot e % 4.
+constexpr int kTileIters = 16;
+constexpr int kTileElems = kTileIters * 256;
 
 // ---- reductions -----------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -129,6 +170,78 @@ __device__ __forceinline__ void write_partial(double s, double q, double* partia
             partials[2 * j + 1] = 0.0;
         }
 }
+
+// ---- normalisation decision (py/utils.py:100-105), identical in every block ---------------------
+struct NormDecision {
+    float mean, stdv;
+    int do_sub, do_div;
+};
+
+template <int BLOCK>
+__device__ __forceinline__ NormDecision decide_norm(const double* __restrict__ partials, int64_t npart, int64_t n_total,
+                                                    float thr_sd, double* red, NormDecision* sh) {
+    double s = 0.0, q = 0.0;
+    for (int64_t i = threadIdx.x; i < npart; i += BLOCK) {
+        s += partials[2 * i];
+        q += partials[2 * i + 1];
+    }
+    block_sum2<BLOCK>(s, q, red);
+    if (threadIdx.x == 0) {
+        const double nt = (double)n_total;
+        const double mean = s / nt;
+        // unbiased (py/utils.py:100: noise.std()); n_total == 1 -> NaN like torch
+        const double var = (q - s * mean) / (nt - 1.0);
+        const double sd = sqrt(var > 0.0 || !(var == var) ? var : 0.0);
+        NormDecision d;
+        d.mean = (float)mean;
+        d.stdv = (float)sd;
+        const double thr = (double)thr_sd / sqrt(nt);
+        d.do_sub = fabs((double)d.mean) > thr;
+        d.do_div = fabs(1.0 - (double)d.stdv) > thr;
+        *sh = d;
+    }
+    __syncthreads();
+    return *sh;
+}
+
+// arguments of the kernels that normalise inside the generating pass
+struct NormArgs {
+    const double* partials;
+    int64_t n_total;
+    float factor, thr_sd;
+};
+
+__device__ __forceinline__ float apply_norm(float v, const NormDecision& d, float factor, bool do_mul) {
+    if (d.do_sub) v = v - d.mean;
+    if (d.do_div) v = v / d.stdv;
+    if (do_mul) v = v * factor;
+    return v;
+}
+
+// Fused generate+normalise kernels (device draws, no bit-parity reference): one reciprocal per block instead of a
+// division per element; differs from apply_norm by at most one ulp.
+struct NormFast {
+    float mean, inv_std, factor;
+    int do_sub, do_scale;
+    __device__ __forceinline__ NormFast(const NormDecision& d, float f)
+        : mean(d.mean), inv_std(d.do_div ? 1.0f / d.stdv : 1.0f), factor(f), do_sub(d.do_sub), do_scale(d.do_div || f != 1.0f) {}
+    __device__ __forceinline__ float operator()(float v) const {
+        if (do_sub) v = v - mean;
+        if (do_scale) v = v * inv_std * factor;
+        return v;
+    }
+};
+
+// x / d as x * (1/d) when d is a power of two (bit-identical), true division otherwise
+struct Divider {
+    float d, inv;
+    int exact;
+    __host__ __device__ explicit Divider(float div) : d(div), inv(1.0f / div) {
+        int e;
+        exact = (frexpf(div, &e) == 0.5f) || (frexpf(div, &e) == -0.5f);
+    }
+    __device__ __forceinline__ float operator()(float x) const { return exact ? x * inv : x / d; }
+};
 
 // ---- blend modes (py/utils.py:17-21) -----------------------------------------------------------
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

@@ -110,39 +110,6 @@ __global__ void __launch_bounds__(kBlock) stats_finalize_kernel(const double* __
     }
 }
 
-// Decision values shared by every block of the apply kernel: identical fixed-order reduction
-// of the partials in each block -> identical (mean, std, branches) everywhere, no host sync.
-struct NormDecision {
-    float mean, stdv;
-    int do_sub, do_div;
-};
-
-__device__ __forceinline__ NormDecision decide_norm(const double* __restrict__ partials, int64_t npart, int64_t n_total,
-                                                    float thr_sd, double* red, NormDecision* sh) {
-    double s = 0.0, q = 0.0;
-    for (int64_t i = threadIdx.x; i < npart; i += kBlock) {
-        s += partials[2 * i];
-        q += partials[2 * i + 1];
-    }
-    block_sum2<kBlock>(s, q, red);
-    if (threadIdx.x == 0) {
-        const double nt = (double)n_total;
-        const double mean = s / nt;
-        // unbiased (py/utils.py:100: noise.std()); n_total == 1 -> NaN like torch
-        const double var = (q - s * mean) / (nt - 1.0);
-        const double sd = sqrt(var > 0.0 || !(var == var) ? var : 0.0);
-        NormDecision d;
-        d.mean = (float)mean;
-        d.stdv = (float)sd;
-        const double thr = (double)thr_sd / sqrt(nt);
-        d.do_sub = fabs((double)d.mean) > thr;
-        d.do_div = fabs(1.0 - (double)d.stdv) > thr;
-        *sh = d;
-    }
-    __syncthreads();
-    return *sh;
-}
-
 template <int V>
 __global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n, float factor, int normalized,
                                                              float thr_sd, const double* __restrict__ partials,
@@ -150,7 +117,7 @@ __global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n
     __shared__ double red[2 * kBlock / 64];
     __shared__ NormDecision sh;
     NormDecision d{0.f, 1.f, 0, 0};
-    if (normalized) d = decide_norm(partials, npart, n_total, thr_sd, red, &sh);
+    if (normalized) d = decide_norm<kBlock>(partials, npart, n_total, thr_sd, red, &sh);
     const bool do_mul = factor != 1.0f;
     const int64_t nv = n / V;
     const int64_t stride = (int64_t)gridDim.x * kBlock;

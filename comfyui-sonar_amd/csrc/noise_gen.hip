@@ -10,18 +10,51 @@ namespace sonar {
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ------------------------------------------------------------------------------------------------
-// Element e of a buffer maps to Philox group (elem_offset + e) / 4, lane (elem_offset + e) % 4:
-// the value depends only on the global element index -> independent of how a batch is sharded.
+// Draw loop shared by every generator: one wave per tile (common.h: kTileElems elements), each lane
+// runs its own Philox-seeded xoshiro128++ burst and hands 4 consecutive elements per step to `f`.
+// `f(e, v)` receives the LOCAL index e (may be < 0 or >= n at the two ends of a shard) of v[0].
 enum class Dist { Normal, Uniform };
 
-template <Dist D>
-__device__ __forceinline__ void draw4(uint64_t seed, uint64_t stream_id, uint64_t group, float (&v)[4]) {
-    if constexpr (D == Dist::Normal) {
-        philox_normal4(seed, stream_id, group, v);
+template <Dist D, typename F>
+__device__ __forceinline__ void for_each_group(int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset, F&& f) {
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
+    for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+        const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
+#pragma unroll 4
+        for (int it = 0; it < kTileIters; ++it) {
+            float v[4];
+            if constexpr (D == Dist::Normal) rng.normal4(v); else rng.uniform4(v);
+            f(base + it * 256, v);
+        }
+    }
+}
+
+// store 4 values at local index e with range / alignment handling; returns how many were in range
+template <bool VEC>
+__device__ __forceinline__ void store_group(float* out, int64_t n, int64_t e, const float (&v)[4], double& s, double& q, bool stats) {
+    if (VEC && e >= 0 && e + 4 <= n) {
+        *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+        if (stats) {
+            const float ps = (v[0] + v[1]) + (v[2] + v[3]);
+            const float pq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3])));
+            s += (double)ps;
+            q += (double)pq;
+        }
     } else {
-        const Philox4 p = philox_group(seed, stream_id, group);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = u01(p.v[k]);
+        for (int k = 0; k < 4; ++k) {
+            if (e + k >= 0 && e + k < n) {
+                out[e + k] = v[k];
+                if (stats) {
+                    s += (double)v[k];
+                    q += (double)v[k] * (double)v[k];
+                }
+            }
+        }
     }
 }
 
@@ -31,66 +64,34 @@ struct Affine {
     __device__ __forceinline__ float operator()(float u) const { return active ? (u - sub) * mul + add : u; }
 };
 
-// ALIGNED: elem_offset % 4 == 0 and out 16-B aligned -> one group per lane, dwordx4 stores.
-template <Dist D, bool ALIGNED, bool STATS>
-__global__ void __launch_bounds__(kBlock) philox_fill_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
+// VEC: out 16-B aligned and elem_offset % 4 == 0 -> dwordx4 stores
+template <Dist D, bool VEC, bool STATS>
+__global__ void __launch_bounds__(kBlock) stream_fill_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
                                                              int64_t elem_offset, Affine aff, double* partials) {
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    if constexpr (ALIGNED) {
-        const int64_t ng = (n + 3) / 4;
-        const uint64_t g0 = (uint64_t)(elem_offset >> 2);
-        for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < ng; g += stride) {
-            float v[4];
-            draw4<D>(seed, stream_id, g0 + (uint64_t)g, v);
+    for_each_group<D>(n, seed, stream_id, elem_offset, [&](int64_t e, float (&v)[4]) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = aff(v[k]);
-            const int64_t e = g * 4;
-            if (e + 4 <= n) {
-                *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
-                if constexpr (STATS) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const double d = v[k];
-                        s += d; q += d * d;
-                    }
-                }
-            } else {
-                for (int k = 0; e + k < n; ++k) {
-                    out[e + k] = v[k];
-                    if constexpr (STATS) {
-                        const double d = v[k];
-                        s += d; q += d * d;
-                    }
-                }
-            }
-        }
-    } else {
-        for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
-            const uint64_t ge = (uint64_t)(elem_offset + e);
-            float v[4];
-            draw4<D>(seed, stream_id, ge >> 2, v);
-            const float r = aff(v[ge & 3]);
-            out[e] = r;
-            if constexpr (STATS) {
-                const double d = r;
-                s += d; q += d * d;
-            }
-        }
-    }
+        for (int k = 0; k < 4; ++k) v[k] = aff(v[k]);
+        store_group<VEC>(out, n, e, v, s, q, STATS);
+    });
     if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+}
+
+static inline int tile_grid(int64_t n, int64_t elem_offset) {
+    const int64_t tiles = (elem_offset + n - 1) / kTileElems - elem_offset / kTileElems + 1;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(kNPart, (tiles + 3) / 4));  // 4 waves (tiles) per block
 }
 
 template <Dist D>
 static int launch_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset, Affine aff,
                        double* partials, hipStream_t st, const char* what) {
     if (n == 0) return SONAR_OK;
-    const bool al = aligned16(out) && (elem_offset & 3) == 0;
-    const int g = (int)std::min<int64_t>(kNPart, grid_for(al ? n / 4 + 1 : n, kBlock));
+    const bool vec = aligned16(out) && (elem_offset & 3) == 0;
+    const int g = tile_grid(n, elem_offset);
 #define SONAR_FILL(A, S) \
-    hipLaunchKernelGGL((philox_fill_kernel<D, A, S>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials)
-    if (al) {
+    hipLaunchKernelGGL((stream_fill_kernel<D, A, S>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials)
+    if (vec) {
         if (partials) SONAR_FILL(true, true); else SONAR_FILL(true, false);
     } else {
         if (partials) SONAR_FILL(false, true); else SONAR_FILL(false, false);
@@ -124,13 +125,11 @@ __global__ void __launch_bounds__(kBlock) perlin_terms_kernel(const float* __res
 }
 
 // out[b][i] = base[b][i]/div + terms[0][i] + terms[1][i] + ...   (terms broadcast over batch)
-// GENERATE: base drawn on device.  One float4 per lane; chw % 4 == 0 on the vector path.
-template <bool GENERATE, bool STATS, int V>
+// replay: base read from memory.  One float4 per lane; chw % 4 == 0 on the vector path.
+template <bool STATS, int V>
 __global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __restrict__ base,
                                                                const float* __restrict__ terms, float* out, int64_t B,
-                                                               int64_t chw, int iters, float div_fac, uint64_t seed,
-                                                               uint64_t stream_id, int64_t elem_offset,
-                                                               double* partials) {
+                                                               int64_t chw, int iters, float div_fac, double* partials) {
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const int64_t n = B * chw;
@@ -140,25 +139,11 @@ __global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __res
         const int64_t e = i * V;
         const int64_t r = e % chw;
         float v[V];
-        if constexpr (GENERATE) {
-            if constexpr (V == 4) {
-                float u[4];
-                draw4<Dist::Uniform>(seed, stream_id, (uint64_t)((elem_offset + e) >> 2), u);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = u[k];
-            } else {
-                const uint64_t ge = (uint64_t)(elem_offset + e);
-                float u[4];
-                draw4<Dist::Uniform>(seed, stream_id, ge >> 2, u);
-                v[0] = u[ge & 3];
-            }
+        if constexpr (V == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(base + e);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
-            if constexpr (V == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(base + e);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
-                v[0] = base[e];
-            }
+            v[0] = base[e];
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) v[k] = v[k] / div_fac;
@@ -187,22 +172,113 @@ __global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __res
     if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
 }
 
-template <bool GENERATE>
+// Normalisation folded into the generating pass (SURVEY.md §8d "stats-before-write"): MODE 0 writes the
+// raw values (+ optional statistics), MODE 1 only reduces the statistics (no stores), MODE 2 re-draws the
+// same values, normalises them with the decision derived from `norm_partials` and writes the final tensor.
+// generate: base u ~ U[0,1) drawn on device.  VEC: chw % 4 == 0, aligned pointers, elem_offset % 4 == 0.
+template <int MODE, bool VEC, bool STATS>
+__global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __restrict__ terms, float* out, int64_t B,
+                                                                  int64_t chw, int iters, float div_fac, uint64_t seed,
+                                                                  uint64_t stream_id, int64_t elem_offset, double* partials,
+                                                                  NormArgs na) {
+    __shared__ double red[2 * kBlock / 64];
+    __shared__ NormDecision sh;
+    NormDecision dec{0.f, 1.f, 0, 0};
+    if constexpr (MODE == 2) dec = decide_norm<kBlock>(na.partials, kNPart, na.n_total, na.thr_sd, red, &sh);
+    const NormFast norm(dec, na.factor);
+    const Divider divide(div_fac);
+    double s = 0.0, q = 0.0;
+    const int64_t n = B * chw;
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
+    const int ichw = (int)chw;  // launcher guarantees chw < 2^31
+    for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+        const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
+        // position inside the latent (terms repeat per latent; shards start on a latent boundary), kept incrementally
+        int r = (int)(((base % chw) + chw) % chw);
+#pragma unroll 4
+        for (int it = 0; it < kTileIters; ++it) {
+            float v[4];
+            rng.uniform4(v);
+            const int64_t e = base + it * 256;
+            const int rr = r;
+            r += 256;
+            while (r >= ichw) r -= ichw;
+            if (e + 4 <= 0 || e >= n) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = divide(v[k]);
+            for (int t_i = 0; t_i < iters; ++t_i) {
+                const float* t = terms + (int64_t)t_i * chw;
+                if (VEC) {
+                    const float4 tt = *reinterpret_cast<const float4*>(t + rr);
+                    v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += t[(rr + k) % ichw];
+                }
+            }
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = norm(v[k]);
+            }
+            if constexpr (MODE == 1) {
+                if (VEC || (e >= 0 && e + 4 <= n)) {
+                    const float ps = (v[0] + v[1]) + (v[2] + v[3]);
+                    const float pq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3])));
+                    s += (double)ps;
+                    q += (double)pq;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (e + k >= 0 && e + k < n) {
+                            s += (double)v[k];
+                            q += (double)v[k] * (double)v[k];
+                        }
+                }
+            } else {
+                store_group<VEC>(out, n, e, v, s, q, STATS);
+            }
+        }
+    }
+    if constexpr (STATS || MODE == 1) write_partial<kBlock>(s, q, partials, red);
+}
+
 static int launch_perlin_apply(const float* base, const float* terms, float* out, int64_t B, int64_t chw, int64_t iters,
-                               float div_fac, uint64_t seed, uint64_t stream_id, int64_t elem_offset, double* partials,
-                               hipStream_t st, const char* what) {
+                               float div_fac, double* partials, hipStream_t st, const char* what) {
     const int64_t n = B * chw;
     if (n == 0) return SONAR_OK;
-    const bool vec = (chw % 4 == 0) && aligned16(out) && aligned16(terms) && (GENERATE ? (elem_offset % 4 == 0) : aligned16(base));
+    const bool vec = (chw % 4 == 0) && aligned16(out) && aligned16(terms) && aligned16(base);
     const int g = (int)std::min<int64_t>(kNPart, grid_for(vec ? n / 4 : n, kBlock));
 #define SONAR_PA(S, V) \
-    hipLaunchKernelGGL((perlin_apply_kernel<GENERATE, S, V>), dim3(g), dim3(kBlock), 0, st, base, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials)
+    hipLaunchKernelGGL((perlin_apply_kernel<S, V>), dim3(g), dim3(kBlock), 0, st, base, terms, out, B, chw, (int)iters, div_fac, partials)
     if (vec) {
         if (partials) SONAR_PA(true, 4); else SONAR_PA(false, 4);
     } else {
         if (partials) SONAR_PA(true, 1); else SONAR_PA(false, 1);
     }
 #undef SONAR_PA
+    return check_launch(what);
+}
+
+template <int MODE>
+static int launch_perlin_generate(const float* terms, float* out, int64_t B, int64_t chw, int64_t iters, float div_fac,
+                                  uint64_t seed, uint64_t stream_id, int64_t elem_offset, double* partials, NormArgs na,
+                                  hipStream_t st, const char* what) {
+    const int64_t n = B * chw;
+    if (n == 0) return SONAR_OK;
+    const bool vec = (chw % 4 == 0) && (MODE == 1 || aligned16(out)) && (iters == 0 || aligned16(terms)) && (elem_offset % 4 == 0);
+    const int g = tile_grid(n, elem_offset);
+#define SONAR_PG(V, S) \
+    hipLaunchKernelGGL((perlin_generate_kernel<MODE, V, S>), dim3(g), dim3(kBlock), 0, st, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials, na)
+    if (vec) {
+        if (partials && MODE == 0) SONAR_PG(true, true); else SONAR_PG(true, false);
+    } else {
+        if (partials && MODE == 0) SONAR_PG(false, true); else SONAR_PG(false, false);
+    }
+#undef SONAR_PG
     return check_launch(what);
 }
 
@@ -290,57 +366,99 @@ struct PyramidLevels {
     float fullres_weight;
 };
 
-template <bool STATS>
+// MODE as in perlin_generate_kernel (0 raw (+stats), 1 statistics only, 2 normalised final).
+template <int MODE, bool STATS>
 __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, int64_t planes, int H, int W,
                                                                   PyramidLevels lv, int mode, uint64_t seed,
                                                                   uint64_t stream_id, int64_t elem_offset,
-                                                                  double* partials) {
+                                                                  double* partials, NormArgs na) {
     __shared__ double red[2 * kBlock / 64];
+    __shared__ NormDecision sh;
+    NormDecision dec{0.f, 1.f, 0, 0};
+    if constexpr (MODE == 2) dec = decide_norm<kBlock>(na.partials, kNPart, na.n_total, na.thr_sd, red, &sh);
+    const NormFast norm(dec, na.factor);
     double s = 0.0, q = 0.0;
-    const int W4 = W >> 2;  // W % 4 == 0 enforced by the launcher
-    const int64_t total = planes * H * W4;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int x4 = (int)(i % W4) * 4;
-        const int y = (int)((i / W4) % H);
-        const int64_t p = i / ((int64_t)W4 * H);
-        const int64_t e = (p * H + y) * (int64_t)W + x4;
-        const uint64_t g = (uint64_t)((elem_offset + e) >> 2);
-        float v[4];
-        philox_normal4(seed, stream_id, g, v);
-        if (lv.fullres) {
-            float z[4];
-            philox_normal4(seed, stream_id + 1, g, z);
+    const int64_t n = planes * (int64_t)H * W;
+    // W % 4 == 0 and elem_offset % 4 == 0 (launcher): a 4-group never straddles a row or the shard ends
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
+    for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+        Xoshiro rng2 = rng_stream(seed, stream_id + 1, (uint64_t)tile, lane);
+        const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
+        for (int it = 0; it < kTileIters; ++it) {
+            float v[4];
+            rng.normal4(v);
+            if (lv.fullres) {
+                float z[4];
+                rng2.normal4(z);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += lv.fullres_weight != 1.0f ? z[k] * lv.fullres_weight : z[k];
-        }
-        for (int l = 0; l < lv.count; ++l) {
-            const int h = lv.h[l], w = lv.w[l];
-            const float* plane = lv.ptr[l] + p * (int64_t)h * w;
-            const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-            const float wt = lv.weight[l];
-            if (mode == 0) {
-                const Lin ly = lin_coord(y, sy, h);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += bilerp(plane, w, ly, lin_coord(x4 + k, sx, w)) * wt;
-            } else if (mode == 1) {
-                const float* row = plane + (int64_t)nearest_exact_idx(y, sy, h) * w;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += row[nearest_exact_idx(x4 + k, sx, w)] * wt;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += area_sample(plane, h, w, H, W, y, x4 + k) * wt;
+                for (int k = 0; k < 4; ++k) v[k] += lv.fullres_weight != 1.0f ? z[k] * lv.fullres_weight : z[k];
             }
-        }
-        *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
-        if constexpr (STATS) {
+            const int64_t e = base + it * 256;
+            if (e < 0 || e >= n) continue;
+            const int x4 = (int)(e % W);
+            const int y = (int)((e / W) % H);
+            const int64_t p = e / ((int64_t)W * H);
+            for (int l = 0; l < lv.count; ++l) {
+                const int h = lv.h[l], w = lv.w[l];
+                const float* plane = lv.ptr[l] + p * (int64_t)h * w;
+                const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+                const float wt = lv.weight[l];
+                if (mode == 0) {
+                    const Lin ly = lin_coord(y, sy, h);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double d = v[k];
-                s += d; q += d * d;
+                    for (int k = 0; k < 4; ++k) v[k] += bilerp(plane, w, ly, lin_coord(x4 + k, sx, w)) * wt;
+                } else if (mode == 1) {
+                    const float* row = plane + (int64_t)nearest_exact_idx(y, sy, h) * w;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += row[nearest_exact_idx(x4 + k, sx, w)] * wt;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += area_sample(plane, h, w, H, W, y, x4 + k) * wt;
+                }
+            }
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = norm(v[k]);
+            }
+            if constexpr (MODE == 1) {
+                const float ps = (v[0] + v[1]) + (v[2] + v[3]);
+                const float pq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3])));
+                s += (double)ps;
+                q += (double)pq;
+            } else {
+                store_group<true>(out, n, e, v, s, q, STATS);
             }
         }
     }
-    if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+    if constexpr (STATS || MODE == 1) write_partial<kBlock>(s, q, partials, red);
+}
+
+static int fill_levels(PyramidLevels& lv, int64_t H, int64_t W, int64_t nlevels, const float* const* level_ptrs,
+                       const int64_t* level_h, const int64_t* level_w, const float* level_weight, const char* what) {
+    lv = PyramidLevels{};
+    lv.fullres_weight = 1.0f;
+    SONAR_REQUIRE(nlevels == 0 || (level_ptrs && level_h && level_w && level_weight), SONAR_ERR_ARG, "%s: level arrays missing", what);
+    for (int64_t l = 0; l < nlevels; ++l) {
+        if (level_ptrs[l] == nullptr) {
+            // a NULL pointer marks a full-resolution level drawn inside the kernel (stream_id + 1)
+            SONAR_REQUIRE(lv.fullres == 0 && level_h[l] == H && level_w[l] == W, SONAR_ERR_ARG,
+                          "%s: only one in-kernel full-resolution level", what);
+            lv.fullres = 1;
+            lv.fullres_weight = level_weight[l];
+            continue;
+        }
+        SONAR_REQUIRE(lv.count < kMaxLevels, SONAR_ERR_UNSUPPORTED, "%s: too many levels", what);
+        lv.ptr[lv.count] = level_ptrs[l];
+        lv.h[lv.count] = (int)level_h[l];
+        lv.w[lv.count] = (int)level_w[l];
+        lv.weight[lv.count] = level_weight[l];
+        ++lv.count;
+    }
+    return SONAR_OK;
 }
 
 }  // namespace sonar
@@ -379,17 +497,30 @@ extern "C" int sonar_perlin_apply_f32(const float* base, const float* terms, flo
                                       int64_t iters, float div_fac, double* partials, void* stream) {
     SONAR_REQUIRE(base && out && (terms || iters == 0) && B >= 0 && chw > 0 && iters >= 0, SONAR_ERR_ARG,
                   "sonar_perlin_apply_f32: bad argument");
-    return launch_perlin_apply<false>(base, terms, out, B, chw, iters, div_fac, 0, 0, 0, partials, (hipStream_t)stream,
-                                      "sonar_perlin_apply_f32");
+    return launch_perlin_apply(base, terms, out, B, chw, iters, div_fac, partials, (hipStream_t)stream, "sonar_perlin_apply_f32");
 }
 
 extern "C" int sonar_perlin_generate_f32(const float* terms, float* out, int64_t B, int64_t chw, int64_t iters,
                                          float div_fac, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                                          double* partials, void* stream) {
-    SONAR_REQUIRE(out && (terms || iters == 0) && B >= 0 && chw > 0 && iters >= 0 && elem_offset >= 0, SONAR_ERR_ARG,
+    SONAR_REQUIRE(out && (terms || iters == 0) && B >= 0 && chw > 0 && chw < (1LL << 31) && iters >= 0 && elem_offset >= 0, SONAR_ERR_ARG,
                   "sonar_perlin_generate_f32: bad argument");
-    return launch_perlin_apply<true>(nullptr, terms, out, B, chw, iters, div_fac, seed, stream_id, elem_offset, partials,
+    return launch_perlin_generate<0>(terms, out, B, chw, iters, div_fac, seed, stream_id, elem_offset, partials, NormArgs{},
                                      (hipStream_t)stream, "sonar_perlin_generate_f32");
+}
+
+extern "C" int sonar_perlin_noise_f32(const float* terms, float* out, int64_t B, int64_t chw, int64_t iters, float div_fac,
+                                      uint64_t seed, uint64_t stream_id, int64_t elem_offset, float factor,
+                                      float threshold_std_devs, double* partials, void* stream) {
+    SONAR_REQUIRE(out && partials && (terms || iters == 0) && B >= 0 && chw > 0 && chw < (1LL << 31) && iters >= 0 && elem_offset >= 0, SONAR_ERR_ARG,
+                  "sonar_perlin_noise_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const NormArgs na{partials, B * chw, factor, threshold_std_devs};
+    int rc = launch_perlin_generate<1>(terms, out, B, chw, iters, div_fac, seed, stream_id, elem_offset, partials, NormArgs{}, st,
+                                       "sonar_perlin_noise_f32(stats)");
+    if (rc != SONAR_OK) return rc;
+    return launch_perlin_generate<2>(terms, out, B, chw, iters, div_fac, seed, stream_id, elem_offset, nullptr, na, st,
+                                     "sonar_perlin_noise_f32(write)");
 }
 
 extern "C" int sonar_resample_acc_f32(float* dst, const float* src, int64_t planes, int64_t H, int64_t W, int64_t h,
@@ -409,43 +540,51 @@ extern "C" int sonar_resample_acc_f32(float* dst, const float* src, int64_t plan
     return check_launch("sonar_resample_acc_f32");
 }
 
+static int pyramid_common(const char* what, float* out, int64_t planes, int64_t H, int64_t W, int mode, int64_t elem_offset) {
+    SONAR_REQUIRE(out && planes >= 0 && H > 0 && W > 0 && mode >= 0 && mode <= 2 && elem_offset >= 0, SONAR_ERR_ARG,
+                  "%s: bad argument", what);
+    SONAR_REQUIRE(W % 4 == 0 && aligned16(out) && elem_offset % 4 == 0, SONAR_ERR_UNSUPPORTED,
+                  "%s: needs W %% 4 == 0 and 16-byte aligned output", what);
+    return SONAR_OK;
+}
+
 extern "C" int sonar_pyramid_generate_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels,
                                           const float* const* level_ptrs, const int64_t* level_h, const int64_t* level_w,
                                           const float* level_weight, int mode, uint64_t seed, uint64_t stream_id,
                                           int64_t elem_offset, double* partials, void* stream) {
-    SONAR_REQUIRE(out && planes >= 0 && H > 0 && W > 0 && nlevels >= 0 && mode >= 0 && mode <= 2 && elem_offset >= 0,
-                  SONAR_ERR_ARG, "sonar_pyramid_generate_f32: bad argument");
-    SONAR_REQUIRE(nlevels == 0 || (level_ptrs && level_h && level_w && level_weight), SONAR_ERR_ARG,
-                  "sonar_pyramid_generate_f32: level arrays missing");
-    SONAR_REQUIRE(W % 4 == 0 && aligned16(out) && elem_offset % 4 == 0, SONAR_ERR_UNSUPPORTED,
-                  "sonar_pyramid_generate_f32: needs W %% 4 == 0 and 16-byte aligned output");
-    PyramidLevels lv{};
-    lv.count = 0;
-    lv.fullres = 0;
-    lv.fullres_weight = 1.0f;
-    for (int64_t l = 0; l < nlevels; ++l) {
-        if (level_ptrs[l] == nullptr) {
-            // a NULL pointer marks a full-resolution level drawn inside the kernel (stream_id + 1)
-            SONAR_REQUIRE(lv.fullres == 0 && level_h[l] == H && level_w[l] == W, SONAR_ERR_ARG,
-                          "sonar_pyramid_generate_f32: only one in-kernel full-resolution level");
-            lv.fullres = 1;
-            lv.fullres_weight = level_weight[l];
-            continue;
-        }
-        SONAR_REQUIRE(lv.count < kMaxLevels, SONAR_ERR_UNSUPPORTED, "sonar_pyramid_generate_f32: too many levels");
-        lv.ptr[lv.count] = level_ptrs[l];
-        lv.h[lv.count] = (int)level_h[l];
-        lv.w[lv.count] = (int)level_w[l];
-        lv.weight[lv.count] = level_weight[l];
-        ++lv.count;
-    }
+    int rc = pyramid_common("sonar_pyramid_generate_f32", out, planes, H, W, mode, elem_offset);
+    if (rc != SONAR_OK) return rc;
+    PyramidLevels lv;
+    rc = fill_levels(lv, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, "sonar_pyramid_generate_f32");
+    if (rc != SONAR_OK) return rc;
     if (planes == 0) return SONAR_OK;
-    const int g = (int)std::min<int64_t>(kNPart, grid_for(planes * H * (W / 4), kBlock));
+    const int g = tile_grid(planes * H * W, elem_offset);
     if (partials)
-        hipLaunchKernelGGL((pyramid_generate_kernel<true>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes,
-                           (int)H, (int)W, lv, mode, seed, stream_id, elem_offset, partials);
+        hipLaunchKernelGGL((pyramid_generate_kernel<0, true>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes,
+                           (int)H, (int)W, lv, mode, seed, stream_id, elem_offset, partials, NormArgs{});
     else
-        hipLaunchKernelGGL((pyramid_generate_kernel<false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes,
-                           (int)H, (int)W, lv, mode, seed, stream_id, elem_offset, partials);
+        hipLaunchKernelGGL((pyramid_generate_kernel<0, false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes,
+                           (int)H, (int)W, lv, mode, seed, stream_id, elem_offset, partials, NormArgs{});
     return check_launch("sonar_pyramid_generate_f32");
+}
+
+extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels,
+                                       const float* const* level_ptrs, const int64_t* level_h, const int64_t* level_w,
+                                       const float* level_weight, int mode, uint64_t seed, uint64_t stream_id,
+                                       int64_t elem_offset, float factor, float threshold_std_devs, double* partials,
+                                       void* stream) {
+    int rc = pyramid_common("sonar_pyramid_noise_f32", out, planes, H, W, mode, elem_offset);
+    if (rc != SONAR_OK) return rc;
+    SONAR_REQUIRE(partials, SONAR_ERR_ARG, "sonar_pyramid_noise_f32: partials workspace required");
+    PyramidLevels lv;
+    rc = fill_levels(lv, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, "sonar_pyramid_noise_f32");
+    if (rc != SONAR_OK) return rc;
+    if (planes == 0) return SONAR_OK;
+    const int g = tile_grid(planes * H * W, elem_offset);
+    const NormArgs na{partials, planes * H * W, factor, threshold_std_devs};
+    hipLaunchKernelGGL((pyramid_generate_kernel<1, false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes, (int)H,
+                       (int)W, lv, mode, seed, stream_id, elem_offset, partials, NormArgs{});
+    hipLaunchKernelGGL((pyramid_generate_kernel<2, false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes, (int)H,
+                       (int)W, lv, mode, seed, stream_id, elem_offset, nullptr, na);
+    return check_launch("sonar_pyramid_noise_f32");
 }

@@ -98,13 +98,23 @@ __device__ __forceinline__ void idft<16>(c32 (&v)[16]) {
     }
 }
 
-// e^{+2 pi i idx / N} for N | 256
-template <int N>
-__device__ __forceinline__ c32 twiddle(int idx) {
-    return c_tw256[(idx * (256 / N)) & 255];
-}
-
 constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4 : n == 16 ? 2 : 1; }
+
+#ifndef SONAR_FFT_THREADS
+#define SONAR_FFT_THREADS 512
+#endif
+#ifndef SONAR_FFT_WAVES
+#define SONAR_FFT_WAVES 4
+#endif
+#ifndef SONAR_FFT_UNROLL
+#define SONAR_FFT_UNROLL 1
+#endif
+#define SONAR_PRAGMA(x) _Pragma(#x)
+#define SONAR_UNROLL_ITEMS SONAR_PRAGMA(unroll SONAR_FFT_UNROLL)
+#ifndef SONAR_FFT_TW_LDS
+#define SONAR_FFT_TW_LDS 0  // measured: constant-memory (scalar) twiddles 78 us vs LDS table 125 us at B=512
+#endif
+constexpr int kFftThreads = SONAR_FFT_THREADS;  // waves per block x two blocks per CU (LDS-bound)
 
 template <int H, int W>
 struct PlaneCfg {
@@ -113,95 +123,116 @@ struct PlaneCfg {
     static constexpr int S = M + 1;       // LDS row stride (complex): odd -> rows hit distinct banks
     static constexpr int CN1 = split_n1(H), CN2 = H / CN1;
     static constexpr int RN1 = split_n1(M), RN2 = M / RN1;
-    static constexpr int kLdsComplex = H * S + H;  // plane + side column
+    // plane + raw columns 0 and M (side buffers) + twiddle table
+    static constexpr int kLdsComplex = H * S + 2 * H + 256;
     static constexpr size_t kLdsBytes = (size_t)kLdsComplex * sizeof(c32);
 };
 
-template <int H, int W, bool GEN, bool STATS>
-__global__ void __launch_bounds__(kBlock) power_irfft2_kernel(const float* __restrict__ z,
-                                                               const float* __restrict__ filter, float* out,
-                                                               int64_t planes, uint64_t seed, uint64_t stream_id,
-                                                               int64_t cplx_offset, double* partials) {
+// One plane's filtered half-spectrum -> sink(ky, kx, value).  GEN: thread-slot `tid` of plane `gplane` owns the
+// stream (seed, stream_id, tile = gplane, lane = tid); burst step `it` yields the complex pair at linear
+// indices j and j + NC/2 (j = it*NT + tid), so consecutive lanes touch consecutive elements.
+template <int H, int W, bool GEN, typename Sink>
+__device__ __forceinline__ void fill_plane(const float* __restrict__ z, const float* __restrict__ filter, int64_t plane,
+                                           int64_t gplane, uint64_t seed, uint64_t stream_id, int tid, Sink&& sink) {
+    constexpr int NT = kFftThreads;
+    constexpr int Wh = W / 2 + 1, NC = H * Wh, HALF = NC / 2;
+    Xoshiro rng{0, 0, 0, 0};
+    if constexpr (GEN) rng = rng_stream(seed, stream_id, (uint64_t)gplane, (uint32_t)tid);
+#pragma unroll 1
+    for (int j = tid; j < HALF; j += NT) {
+        c32 za, zb;
+        if constexpr (GEN) {
+            float n[4];
+            rng.normal4(n);
+            constexpr float rs = 0.70710678118654752f;  // complex normal: (a + ib) * sqrt(1/2)
+            za = make_float2(n[0] * rs, n[1] * rs);
+            zb = make_float2(n[2] * rs, n[3] * rs);
+        } else {
+            const c32* zp = reinterpret_cast<const c32*>(z) + plane * NC;
+            za = zp[j];
+            zb = zp[j + HALF];
+        }
+        const float fa = filter[j], fb = filter[j + HALF];
+        za.x *= fa; za.y *= fa;
+        zb.x *= fb; zb.y *= fb;
+        const int kya = j / Wh, jb = j + HALF, kyb = jb / Wh;
+        sink(kya, j - kya * Wh, za);
+        sink(kyb, jb - kyb * Wh, zb);
+    }
+}
+
+template <int H, int W, bool GEN, bool STATS, bool NORM>
+__global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_kernel(const float* __restrict__ z,
+                                                                       const float* __restrict__ filter, float* out,
+                                                                       int64_t planes, uint64_t seed, uint64_t stream_id,
+                                                                       int64_t plane_offset, double* partials, NormArgs na) {
     using C = PlaneCfg<H, W>;
-    constexpr int M = C::M, Wh = C::Wh, S = C::S;
+    constexpr int NT = kFftThreads;
+    constexpr int M = C::M, S = C::S;
     constexpr int CN1 = C::CN1, CN2 = C::CN2, RN1 = C::RN1, RN2 = C::RN2;
-    constexpr int NC = H * Wh;  // complex per plane (even, H is even)
     __shared__ c32 A[C::kLdsComplex];
-    c32* const T = A + H * S;
-    __shared__ double red[2 * kBlock / 64];
+    c32* const T0 = A + H * S;      // raw column kx = 0
+    c32* const TM = T0 + H;         // raw column kx = M
+    c32* const TW = TM + H;         // e^{2 pi i j / 256}
+    __shared__ double red[2 * NT / 64];
+    __shared__ NormDecision shd;
     const int tid = threadIdx.x;
-    const float scale = 1.0f / sqrtf((float)H * (float)W);  // norm="ortho"
+    float scale = 1.0f / sqrtf((float)H * (float)W);  // norm="ortho"
+    NormDecision dec{0.f, 1.f, 0, 0};
+    float inv_std = 1.0f;
+    if constexpr (NORM) {
+        dec = decide_norm<NT>(na.partials, kNPart, na.n_total, na.thr_sd, red, &shd);
+        inv_std = dec.do_div ? 1.0f / dec.stdv : 1.0f;
+    }
     double s = 0.0, q = 0.0;
+    for (int j = tid; j < 256; j += NT) TW[j] = c_tw256[j];
+#if SONAR_FFT_TW_LDS
+    auto tw = [&](int idx, int n, bool) -> c32 { return TW[(idx * (256 / n)) & 255]; };
+#else
+    // `uni`: the index is wave-uniform (lanes = consecutive columns / rows of one n2) -> scalar load
+    auto tw = [&](int idx, int n, bool uni) -> c32 {
+        return c_tw256[((uni ? __builtin_amdgcn_readfirstlane(idx) : idx) * (256 / n)) & 255];
+    };
+#endif
 
     for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
-        __syncthreads();  // previous plane's LDS reads are done
+        __syncthreads();  // previous plane's LDS reads are done (and TW is visible)
         // ---------------------------------------------------------------- fill: z * filter
-        for (int j = tid; j < NC / 2; j += kBlock) {
-            const int c0 = 2 * j;
-            c32 z0, z1;
-            if constexpr (GEN) {
-                float n[4];
-                philox_normal4(seed, stream_id, (uint64_t)((cplx_offset + plane * NC + c0) >> 1), n);
-                constexpr float rs = 0.70710678118654752f;  // complex normal: (a + ib) * sqrt(1/2)
-                z0 = make_float2(n[0] * rs, n[1] * rs);
-                z1 = make_float2(n[2] * rs, n[3] * rs);
-            } else {
-                const float4 t = *reinterpret_cast<const float4*>(z + (plane * NC + c0) * 2);
-                z0 = make_float2(t.x, t.y);
-                z1 = make_float2(t.z, t.w);
-            }
-            const float2 f = *reinterpret_cast<const float2*>(filter + c0);
-            z0.x *= f.x; z0.y *= f.x;
-            z1.x *= f.y; z1.y *= f.y;
-            const int ky0 = c0 / Wh, kx0 = c0 - ky0 * Wh;
-            const int c1 = c0 + 1;
-            const int ky1 = c1 / Wh, kx1 = c1 - ky1 * Wh;
-            if (kx0 < M) A[ky0 * S + kx0] = z0; else T[ky0] = z0;
-            if (kx1 < M) A[ky1 * S + kx1] = z1; else T[ky1] = z1;
-        }
-        __syncthreads();
-        // ---------------------------------------------------------------- fix-up of columns 0 / M
-        {
-            c32 qv[(H + kBlock - 1) / kBlock];
-#pragma unroll
-            for (int i = 0; i < (H + kBlock - 1) / kBlock; ++i) {
-                const int ky = tid + i * kBlock;
-                if (ky < H) {
-                    const int kn = (H - ky) & (H - 1);
-                    const c32 a = A[ky * S], an = A[kn * S], b = T[ky], bn = T[kn];
-                    const c32 z0s = make_float2(0.5f * (a.x + an.x), 0.5f * (a.y - an.y));
-                    const c32 zms = make_float2(0.5f * (b.x + bn.x), 0.5f * (b.y - bn.y));
-                    qv[i] = make_float2(z0s.x - zms.y, z0s.y + zms.x);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < (H + kBlock - 1) / kBlock; ++i) {
-                const int ky = tid + i * kBlock;
-                if (ky < H) A[ky * S] = qv[i];
-            }
-        }
+        fill_plane<H, W, GEN>(z, filter, plane, plane_offset + plane, seed, stream_id, tid, [&](int ky, int kx, c32 v) {
+            (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v;
+        });
         __syncthreads();
         // ---------------------------------------------------------------- columns, pass a
-        for (int item = tid; item < CN2 * M; item += kBlock) {
+        // Column 0 is built on the fly from the raw kx = 0 / kx = M columns:
+        //   Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky],  sym(Z)[ky] = (Z[ky] + conj Z[-ky]) / 2
+SONAR_UNROLL_ITEMS
+        for (int item = tid; item < CN2 * M; item += NT) {
             const int c = item % M;
-            int n2 = item / M;
-            if constexpr (M % 64 == 0) n2 = __builtin_amdgcn_readfirstlane(n2);
+            const int n2 = item / M;
             c32 v[CN1];
+            if (c != 0) {
 #pragma unroll
-            for (int n1 = 0; n1 < CN1; ++n1) v[n1] = A[(CN2 * n1 + n2) * S + c];
+                for (int n1 = 0; n1 < CN1; ++n1) v[n1] = A[(CN2 * n1 + n2) * S + c];
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < CN1; ++n1) {
+                    const int ky = CN2 * n1 + n2, kn = (H - ky) & (H - 1);
+                    const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
+                    v[n1] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
+                }
+            }
             idft<CN1>(v);
 #pragma unroll
-            for (int k1 = 1; k1 < CN1; ++k1) v[k1] = cmul(v[k1], twiddle<H>(n2 * k1));
+            for (int k1 = 1; k1 < CN1; ++k1) v[k1] = cmul(v[k1], tw(n2 * k1, H, M % 64 == 0));
 #pragma unroll
             for (int k1 = 0; k1 < CN1; ++k1) A[(CN2 * k1 + n2) * S + c] = v[k1];
         }
         __syncthreads();
         // ---------------------------------------------------------------- columns, pass b
-        // LDS row r = CN2*k1 + k2 now holds spatial row y = k1 + CN1*k2
-        for (int item = tid; item < CN1 * M; item += kBlock) {
-            const int c = item % M;
-            const int k1 = item / M;
+        // LDS row r = CN2*k1 + k2 afterwards holds spatial row y = k1 + CN1*k2
+SONAR_UNROLL_ITEMS
+        for (int item = tid; item < CN1 * M; item += NT) {
+            const int c = item % M, k1 = item / M;
             c32 u[CN2];
 #pragma unroll
             for (int n2 = 0; n2 < CN2; ++n2) u[n2] = A[(CN2 * k1 + n2) * S + c];
@@ -212,15 +243,14 @@ __global__ void __launch_bounds__(kBlock) power_irfft2_kernel(const float* __res
         __syncthreads();
         // ---------------------------------------------------------------- rows, pass a (c2r pre-twiddle fused)
         {
-            constexpr int ITEMS = (RN2 * H + kBlock - 1) / kBlock;
+            constexpr int ITEMS = (RN2 * H + NT - 1) / NT;
             c32 g[ITEMS][RN1];
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * kBlock;
+                const int item = tid + it * NT;
                 if (item < RN2 * H) {
                     const int r = item % H;
-                    int n2 = item / H;
-                    if constexpr (H % 64 == 0) n2 = __builtin_amdgcn_readfirstlane(n2);
+                    const int n2 = item / H;
                     const c32* row = A + r * S;
 #pragma unroll
                     for (int n1 = 0; n1 < RN1; ++n1) {
@@ -236,18 +266,19 @@ __global__ void __launch_bounds__(kBlock) power_irfft2_kernel(const float* __res
                         }
                         const c32 e = make_float2(xa.x + xb.x, xa.y - xb.y);
                         const c32 d = make_float2(xa.x - xb.x, xa.y + xb.y);
-                        const c32 o = cmul(d, twiddle<W>(k));
+                        const c32 o = cmul(d, tw(k, W, H % 64 == 0));
                         g[it][n1] = make_float2(e.x - o.y, e.y + o.x);
                     }
                     idft<RN1>(g[it]);
 #pragma unroll
-                    for (int k1 = 1; k1 < RN1; ++k1) g[it][k1] = cmul(g[it][k1], twiddle<M>(n2 * k1));
+                    for (int k1 = 1; k1 < RN1; ++k1) g[it][k1] = cmul(g[it][k1], tw(n2 * k1, M, H % 64 == 0));
                 }
+                __builtin_amdgcn_sched_barrier(0);  // keep item it+1's loads from being hoisted over item it (VGPR budget)
             }
             __syncthreads();  // every mirrored read is done before anyone overwrites
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * kBlock;
+                const int item = tid + it * NT;
                 if (item < RN2 * H) {
                     const int r = item % H;
                     const int n2 = item / H;
@@ -259,9 +290,10 @@ __global__ void __launch_bounds__(kBlock) power_irfft2_kernel(const float* __res
         __syncthreads();
         // ---------------------------------------------------------------- rows, pass b -> global
         float* const oplane = out + plane * (int64_t)H * W;
-        for (int item = tid; item < RN1 * H; item += kBlock) {
-            const int k1 = item % RN1;
-            const int r = item / RN1;
+        float ps = 0.0f, pq = 0.0f;  // per-plane fp32 partials (<= 64 values per thread), folded into fp64 below
+SONAR_UNROLL_ITEMS
+        for (int item = tid; item < RN1 * H; item += NT) {
+            const int k1 = item % RN1, r = item / RN1;
             const int y = (r / CN2) + CN1 * (r % CN2);
             c32 u[RN2];
 #pragma unroll
@@ -270,36 +302,111 @@ __global__ void __launch_bounds__(kBlock) power_irfft2_kernel(const float* __res
             float* orow = oplane + (int64_t)y * W;
 #pragma unroll
             for (int k2 = 0; k2 < RN2; ++k2) {
-                const float a = u[k2].x * scale, b = u[k2].y * scale;
+                float a = u[k2].x * scale, b = u[k2].y * scale;
+                if constexpr (NORM) {
+                    if (dec.do_sub) { a -= dec.mean; b -= dec.mean; }
+                    a = a * inv_std * na.factor;
+                    b = b * inv_std * na.factor;
+                }
                 *reinterpret_cast<float2*>(orow + 2 * (k1 + RN1 * k2)) = make_float2(a, b);
                 if constexpr (STATS) {
-                    const double da = a, db = b;
-                    s += da; q += da * da;
-                    s += db; q += db * db;
+                    ps += a + b;
+                    pq = __builtin_fmaf(a, a, __builtin_fmaf(b, b, pq));
                 }
             }
         }
+        if constexpr (STATS) {
+            s += (double)ps;
+            q += (double)pq;
+        }
     }
-    if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+    if constexpr (STATS) write_partial<NT>(s, q, partials, red);
+}
+
+// Statistics of the output WITHOUT computing it (Parseval, ortho-normalised transform):
+//   sum   x  = sqrt(H W) * Re(Zf[0][0])
+//   sum x^2  = sum_ky ( |sym(Zf[:,0])[ky]|^2 + |sym(Zf[:,M])[ky]|^2 ) + 2 sum_ky sum_{0<kx<M} |Zf[ky][kx]|^2
+// (only the Hermitian-symmetric part of the kx = 0 and kx = M columns survives the c2r stage).
+template <int H, int W>
+__global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* __restrict__ filter, int64_t planes, uint64_t seed,
+                                                                   uint64_t stream_id, int64_t plane_offset, double* partials) {
+    constexpr int NT = kFftThreads, M = W / 2;
+    __shared__ c32 T0[H], TM[H];
+    __shared__ double red[2 * NT / 64];
+    const int tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        __syncthreads();
+        float acc = 0.0f;
+        fill_plane<H, W, true>(nullptr, filter, plane, plane_offset + plane, seed, stream_id, tid, [&](int ky, int kx, c32 v) {
+            if (kx == 0) T0[ky] = v;
+            else if (kx == M) TM[ky] = v;
+            else acc = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, acc));
+        });
+        __syncthreads();
+        float edge = 0.0f;
+        for (int ky = tid; ky < H; ky += NT) {
+            const int kn = (H - ky) & (H - 1);
+            const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
+            const float ar = 0.5f * (a.x + an.x), ai = 0.5f * (a.y - an.y), br = 0.5f * (b.x + bn.x), bi = 0.5f * (b.y - bn.y);
+            edge += (ar * ar + ai * ai) + (br * br + bi * bi);
+            if (ky == 0) s += (double)(sqrtf((float)H * (float)W) * ar);
+        }
+        q += 2.0 * (double)acc + (double)edge;
+    }
+    write_partial<NT>(s, q, partials, red);
 }
 
 template <int H, int W>
-static int launch_power(const float* z, const float* filter, float* out, int64_t planes, uint64_t seed,
-                        uint64_t stream_id, int64_t cplx_offset, double* partials, hipStream_t st) {
+__global__ void __launch_bounds__(kFftThreads) power_spectrum_kernel(float* zout, int64_t planes, uint64_t seed, uint64_t stream_id,
+                                                                      int64_t plane_offset) {
+    constexpr int Wh = W / 2 + 1, NC = H * Wh;
+    // unit filter: read from a one-element "filter" would need H*Wh ones; inline the draw instead
+    const int tid = threadIdx.x;
+    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)(plane_offset + plane), (uint32_t)tid);
+        c32* zp = reinterpret_cast<c32*>(zout) + plane * NC;
+        for (int j = tid; j < NC / 2; j += kFftThreads) {
+            float n[4];
+            rng.normal4(n);
+            constexpr float rs = 0.70710678118654752f;
+            zp[j] = make_float2(n[0] * rs, n[1] * rs);
+            zp[j + NC / 2] = make_float2(n[2] * rs, n[3] * rs);
+        }
+    }
+}
+
+template <int H, int W>
+static int power_grid(int64_t planes) {
     using C = PlaneCfg<H, W>;
-    static_assert(C::kLdsBytes + 64 <= 160 * 1024, "plane does not fit in LDS");
+    static_assert(C::kLdsBytes + 256 <= 160 * 1024, "plane does not fit in LDS");
     // blocks/CU by LDS; persistent grid of resident blocks (<= kNPart so each owns a partial slot)
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (C::kLdsBytes + 64)));
-    const int g = (int)std::min<int64_t>(std::min<int64_t>(planes, (int64_t)256 * per_cu), kNPart);
-#define SONAR_PW(G, ST) \
-    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST>), dim3(g), dim3(kBlock), 0, st, z, filter, out, planes, seed, stream_id, cplx_offset, partials)
-    if (z == nullptr) {
-        if (partials) SONAR_PW(true, true); else SONAR_PW(true, false);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (C::kLdsBytes + 256)));
+    return (int)std::min<int64_t>(std::min<int64_t>(planes, (int64_t)256 * per_cu), kNPart);
+}
+
+// what: 0 = irfft2 (z given or drawn; optional statistics), 1 = normalised generate (stats pass + final pass),
+//       2 = dump the drawn spectrum into `out`
+template <int H, int W>
+static int launch_power(int what, const float* z, const float* filter, float* out, int64_t planes, uint64_t seed,
+                        uint64_t stream_id, int64_t plane_offset, double* partials, NormArgs na, hipStream_t st) {
+    const int g = power_grid<H, W>(planes);
+    const dim3 blk(kFftThreads);
+#define SONAR_PW(G, ST, NM, PART) \
+    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(g), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, PART, na)
+    if (what == 2) {
+        hipLaunchKernelGGL((power_spectrum_kernel<H, W>), dim3(std::min<int64_t>(planes, 2048)), blk, 0, st, out, planes, seed, stream_id, plane_offset);
+    } else if (what == 1) {
+        hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(planes, kNPart)), blk, 0, st, filter, planes, seed, stream_id,
+                           plane_offset, partials);
+        SONAR_PW(true, false, true, nullptr);
+    } else if (z == nullptr) {
+        if (partials) SONAR_PW(true, true, false, partials); else SONAR_PW(true, false, false, partials);
     } else {
-        if (partials) SONAR_PW(false, true); else SONAR_PW(false, false);
+        if (partials) SONAR_PW(false, true, false, partials); else SONAR_PW(false, false, false, partials);
     }
 #undef SONAR_PW
-    return check_launch("sonar_power_irfft2_f32");
+    return check_launch("sonar_power_*");
 }
 
 // C x C channel mixer (py/nodes/powernoise.py:96-101): out[b][i][p] = sum_j mixer[i][j] * in[b][j][p]
@@ -336,19 +443,10 @@ __global__ void __launch_bounds__(kBlock) channel_mix_kernel(const float* __rest
 
 using namespace sonar;
 
-extern "C" int sonar_power_irfft2_f32(const float* z, const float* filter, float* out, int64_t planes, int64_t H,
-                                      int64_t W, uint64_t seed, uint64_t stream_id, int64_t cplx_offset,
-                                      double* partials, void* stream) {
-    SONAR_REQUIRE(filter && out && planes >= 0 && H > 0 && W > 0 && cplx_offset >= 0, SONAR_ERR_ARG,
-                  "sonar_power_irfft2_f32: bad argument");
-    SONAR_REQUIRE((cplx_offset & 1) == 0, SONAR_ERR_ARG, "sonar_power_irfft2_f32: cplx_offset must be even");
-    SONAR_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (reinterpret_cast<uintptr_t>(filter) & 7u) == 0 &&
-                      (z == nullptr || (reinterpret_cast<uintptr_t>(z) & 15u) == 0),
-                  SONAR_ERR_ARG, "sonar_power_irfft2_f32: misaligned buffer");
-    if (planes == 0) return SONAR_OK;
-    hipStream_t st = (hipStream_t)stream;
+static int power_dispatch(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,
+                          uint64_t seed, uint64_t stream_id, int64_t plane_offset, double* partials, NormArgs na, hipStream_t st) {
 #define SONAR_CASE(HH, WW) \
-    if (H == HH && W == WW) return launch_power<HH, WW>(z, filter, out, planes, seed, stream_id, cplx_offset, partials, st)
+    if (H == HH && W == WW) return launch_power<HH, WW>(what, z, filter, out, planes, seed, stream_id, plane_offset, partials, na, st)
     SONAR_CASE(128, 128);
     SONAR_CASE(64, 64);
     SONAR_CASE(32, 32);
@@ -362,9 +460,39 @@ extern "C" int sonar_power_irfft2_f32(const float* z, const float* filter, float
     SONAR_CASE(256, 64);
     SONAR_CASE(64, 256);
 #undef SONAR_CASE
-    set_error("sonar_power_irfft2_f32: unsupported plane %lld x %lld (powers of two, 16..256, LDS-resident)",
-              (long long)H, (long long)W);
+    set_error("sonar_power_*: unsupported plane %lld x %lld (powers of two, 16..256, LDS-resident)", (long long)H, (long long)W);
     return SONAR_ERR_UNSUPPORTED;
+}
+
+extern "C" int sonar_power_irfft2_f32(const float* z, const float* filter, float* out, int64_t planes, int64_t H,
+                                      int64_t W, uint64_t seed, uint64_t stream_id, int64_t plane_offset,
+                                      double* partials, void* stream) {
+    SONAR_REQUIRE(filter && out && planes >= 0 && H > 0 && W > 0 && plane_offset >= 0, SONAR_ERR_ARG,
+                  "sonar_power_irfft2_f32: bad argument");
+    SONAR_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (z == nullptr || (reinterpret_cast<uintptr_t>(z) & 7u) == 0),
+                  SONAR_ERR_ARG, "sonar_power_irfft2_f32: misaligned buffer");
+    if (planes == 0) return SONAR_OK;
+    return power_dispatch(0, z, filter, out, planes, H, W, seed, stream_id, plane_offset, partials, NormArgs{nullptr, 0, 1.0f, 0.0f},
+                          (hipStream_t)stream);
+}
+
+extern "C" int sonar_power_noise_f32(const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
+                                     uint64_t stream_id, int64_t plane_offset, float factor, float threshold_std_devs,
+                                     double* partials, void* stream) {
+    SONAR_REQUIRE(filter && out && partials && planes >= 0 && H > 0 && W > 0 && plane_offset >= 0, SONAR_ERR_ARG,
+                  "sonar_power_noise_f32: bad argument");
+    SONAR_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0, SONAR_ERR_ARG, "sonar_power_noise_f32: misaligned buffer");
+    if (planes == 0) return SONAR_OK;
+    return power_dispatch(1, nullptr, filter, out, planes, H, W, seed, stream_id, plane_offset, partials,
+                          NormArgs{partials, planes * H * W, factor, threshold_std_devs}, (hipStream_t)stream);
+}
+
+extern "C" int sonar_power_spectrum_f32(float* z_out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,
+                                        int64_t plane_offset, void* stream) {
+    SONAR_REQUIRE(z_out && planes >= 0 && H > 0 && W > 0 && plane_offset >= 0, SONAR_ERR_ARG, "sonar_power_spectrum_f32: bad argument");
+    if (planes == 0) return SONAR_OK;
+    return power_dispatch(2, nullptr, nullptr, z_out, planes, H, W, seed, stream_id, plane_offset, nullptr, NormArgs{nullptr, 0, 1.0f, 0.0f},
+                          (hipStream_t)stream);
 }
 
 extern "C" int sonar_channel_mix_f32(const float* in, const float* mixer, float* out, int64_t B, int64_t C, int64_t hw,

@@ -81,8 +81,12 @@ SIGNATURES = {
     "sonar_perlin_terms_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "sonar_perlin_apply_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P]),
     "sonar_perlin_generate_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _P, _P]),
+    "sonar_perlin_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _F, _F, _P, _P]),
     "sonar_resample_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I64, _F, _I, _I, _P, _P]),
     "sonar_pyramid_generate_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _P, _P]),
+    "sonar_pyramid_noise_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _F, _F, _P, _P]),
+    "sonar_power_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _F, _F, _P, _P]),
+    "sonar_power_spectrum_f32": (_I, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _P]),
     "sonar_power_irfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _P, _P]),
     "sonar_rfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_channel_mix_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
@@ -424,6 +428,22 @@ def perlin_generate(shape, terms: torch.Tensor, div_fac: float, seed: int, strea
     return out
 
 
+def perlin_noise(shape, terms: torch.Tensor, div_fac: float, seed: int, stream_id: int, elem_offset: int, factor: float,
+                 threshold_std_devs: float = 2.5) -> torch.Tensor:
+    """generate + scale_noise(factor, normalized=True) with one write of the tensor."""
+    out = torch.empty(shape, dtype=torch.float32, device=terms.device)
+    b = shape[0]
+    chw = out.numel() // max(b, 1)
+    ws = new_partials(terms.device)
+    with _Timed("perlin_noise"):
+        _check(
+            load().sonar_perlin_noise_f32(_dev(terms, "terms"), _dev(out, "out"), b, chw, terms.shape[0], float(div_fac), seed & (2**64 - 1),
+                                          stream_id, elem_offset, float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
+            "sonar_perlin_noise_f32",
+        )
+    return out
+
+
 def resample_acc_(dst: torch.Tensor, src: torch.Tensor, scale: float, mode: str = "bilinear", accumulate: bool = True, partials=None) -> torch.Tensor:
     """dst[..., H, W] (+)= resample(src[..., h, w]) * scale"""
     H, W = dst.shape[-2:]
@@ -439,16 +459,21 @@ def resample_acc_(dst: torch.Tensor, src: torch.Tensor, scale: float, mode: str 
     return dst
 
 
-def pyramid_generate(shape, device, levels: Sequence, mode: str, seed: int, stream_id: int, elem_offset: int = 0, partials=None) -> torch.Tensor:
-    """levels: list of (tensor-or-None, h, w, weight); None marks the in-kernel full-resolution level."""
-    out = torch.empty(shape, dtype=torch.float32, device=device)
-    H, W = shape[-2:]
-    planes = out.numel() // (H * W)
+def _pyramid_args(levels):
     n = len(levels)
     ptrs = (_P * max(n, 1))(*[(None if lv[0] is None else _dev(lv[0], "level")) for lv in levels])
     hs = (C.c_int64 * max(n, 1))(*[int(lv[1]) for lv in levels])
     ws = (C.c_int64 * max(n, 1))(*[int(lv[2]) for lv in levels])
     wts = (C.c_float * max(n, 1))(*[float(lv[3]) for lv in levels])
+    return n, ptrs, hs, ws, wts
+
+
+def pyramid_generate(shape, device, levels: Sequence, mode: str, seed: int, stream_id: int, elem_offset: int = 0, partials=None) -> torch.Tensor:
+    """levels: list of (tensor-or-None, h, w, weight); None marks the in-kernel full-resolution level."""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    H, W = shape[-2:]
+    planes = out.numel() // (H * W)
+    n, ptrs, hs, ws, wts = _pyramid_args(levels)
     _check(
         load().sonar_pyramid_generate_f32(_dev(out, "out"), planes, H, W, n, ptrs, hs, ws, wts, RESAMPLE_IDS[mode], seed & (2**64 - 1),
                                           stream_id, elem_offset, _opt(partials, "partials", torch.float64), _stream()),
@@ -457,7 +482,22 @@ def pyramid_generate(shape, device, levels: Sequence, mode: str, seed: int, stre
     return out
 
 
-def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: int = 0, stream_id: int = 0, cplx_offset: int = 0,
+def pyramid_noise(shape, device, levels: Sequence, mode: str, seed: int, stream_id: int, elem_offset: int, factor: float,
+                  threshold_std_devs: float = 2.5) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    H, W = shape[-2:]
+    planes = out.numel() // (H * W)
+    n, ptrs, hs, ws, wts = _pyramid_args(levels)
+    work = new_partials(device)
+    _check(
+        load().sonar_pyramid_noise_f32(_dev(out, "out"), planes, H, W, n, ptrs, hs, ws, wts, RESAMPLE_IDS[mode], seed & (2**64 - 1),
+                                       stream_id, elem_offset, float(factor), float(threshold_std_devs), _dev(work, "ws", torch.float64), _stream()),
+        "sonar_pyramid_noise_f32",
+    )
+    return out
+
+
+def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: int = 0, stream_id: int = 0, plane_offset: int = 0,
                  partials=None) -> torch.Tensor:
     """out[shape] = irfft2(z * filt, norm='ortho'); z = None draws the spectrum on device."""
     H, W = shape[-2:]
@@ -474,11 +514,37 @@ def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: 
         raise SonarHipError("power_irfft2: filter size mismatch")
     with _Timed("power_irfft2"):
         _check(
-            load().sonar_power_irfft2_f32(zp, _dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, cplx_offset,
+            load().sonar_power_irfft2_f32(zp, _dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
                                           _opt(partials, "partials", torch.float64), _stream()),
             "sonar_power_irfft2_f32",
         )
     return out
+
+
+def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_offset: int, factor: float,
+                threshold_std_devs: float = 2.5) -> torch.Tensor:
+    """draw + filter + irfft2 + scale_noise(factor, normalized=True); the tensor is written once."""
+    H, W = shape[-2:]
+    out = torch.empty(shape, dtype=torch.float32, device=filt.device)
+    planes = out.numel() // (H * W)
+    ws = new_partials(filt.device)
+    with _Timed("power_noise"):
+        _check(
+            load().sonar_power_noise_f32(_dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
+                                         float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
+            "sonar_power_noise_f32",
+        )
+    return out
+
+
+def power_spectrum(shape, device, *, seed: int, stream_id: int, plane_offset: int = 0) -> torch.Tensor:
+    """The complex64 half-spectrum [..., H, W/2+1] the device-mode power kernels draw."""
+    H, W = shape[-2:]
+    z = torch.empty((*shape[:-1], W // 2 + 1), dtype=torch.complex64, device=device)
+    planes = z.numel() // (H * (W // 2 + 1))
+    _check(load().sonar_power_spectrum_f32(z.data_ptr(), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset, _stream()),
+           "sonar_power_spectrum_f32")
+    return z
 
 
 def power_supported(H: int, W: int) -> bool:

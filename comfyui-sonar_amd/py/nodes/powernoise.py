@@ -178,15 +178,17 @@ class PowerNoiseItem(CustomNoiseItemBase):
         identity = mixer.is_identity
         mixer.to(device)
         planes_per_latent = shape[1]
-        spec_per_plane = h * (w // 2 + 1)
 
         def sampler(sigma, sigma_next):
             z = noise_sampler(sigma, sigma_next)
             partials = hip_lib.new_partials(device)
             if z is None:
                 seed, stream = DeviceRNG.take()
-                offs = current_batch_offset() * planes_per_latent * spec_per_plane
-                noise = hip_lib.power_irfft2(None, filt, shape, seed=seed, stream_id=stream, cplx_offset=offs,
+                offs = current_batch_offset() * planes_per_latent
+                if identity and normalized:
+                    # draw + filter + FFT + normalise with a single write of the tensor
+                    return hip_lib.power_noise(filt, shape, seed=seed, stream_id=stream, plane_offset=offs, factor=self.factor)
+                noise = hip_lib.power_irfft2(None, filt, shape, seed=seed, stream_id=stream, plane_offset=offs,
                                              partials=partials if identity else None)
             else:
                 noise = hip_lib.power_irfft2(z.to(device).contiguous(), filt, shape, partials=partials if identity else None)

@@ -186,8 +186,11 @@ class NoiseSampler:
 
     def __call__(self, *args, **kwargs):
         args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
-        noise = self.noise_sampler(*args, **kwargs)
-        noise = scale_noise(noise, self.factor, normalized=self.normalized)
+        fused = getattr(self.noise_sampler, "generate_normalized", None) if self.normalized and not kwargs else None
+        noise = fused(self.factor, *args) if fused is not None else None
+        if noise is None:
+            noise = self.noise_sampler(*args, **kwargs)
+            noise = scale_noise(noise, self.factor, normalized=self.normalized)
         if hasattr(noise, "to") and (noise.dtype != self.dtype or noise.device != self.device):
             noise = noise.to(dtype=self.dtype, device=self.device)
         return noise

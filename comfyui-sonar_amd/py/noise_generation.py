@@ -340,13 +340,33 @@ class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):
             terms = hip_lib.perlin_terms(tensor_to(angles, self.device).contiguous(), self.blend_mode)
             out = hip_lib.perlin_apply(base.contiguous(), terms, self.div_fac, partials)
         else:
-            seed, stream = self.device_key(2)
-            # the lattice is shared by every latent (and every rank): no batch offset in its counter
-            angles = hip_lib.philox_uniform((max(self.iterations, 0), c, h + 1, w + 1), self.device, seed, stream + 1, 0,
-                                            sub=0.0, mul=two_pi, add=0.0)
-            terms = hip_lib.perlin_terms(angles, self.blend_mode)
-            out = hip_lib.perlin_generate((b, c, h, w), terms, self.div_fac, seed, stream, self.latent_elem_offset(c * h * w), partials)
+            out = self._device_generate(partials, None)
         return self.fix_output_frames(attach_stats(out, partials))
+
+    def _device_generate(self, partials, fused_factor):
+        b, c, h, w = self.get_adjusted_shape()
+        seed, stream = self.device_key(2)
+        # the lattice is shared by every latent (and every rank): no batch offset in its counter
+        angles = hip_lib.philox_uniform((max(self.iterations, 0), c, h + 1, w + 1), self.device, seed, stream + 1, 0,
+                                        sub=0.0, mul=2.0 * math.pi, add=0.0)
+        terms = hip_lib.perlin_terms(angles, self.blend_mode)
+        if terms.shape[0] > 1:
+            # device draws have no bit-parity reference: pre-add the lattice terms once ([C,H,W], 256 KiB) so the
+            # streaming kernels read one table instead of `iterations` tables per element
+            total = terms[0].contiguous()
+            for extra in terms[1:]:
+                hip_lib.axpby_(total, 1.0, extra.contiguous(), 1.0)
+            terms = total.unsqueeze(0)
+        offs = self.latent_elem_offset(c * h * w)
+        if fused_factor is None:
+            return hip_lib.perlin_generate((b, c, h, w), terms, self.div_fac, seed, stream, offs, partials)
+        return hip_lib.perlin_noise((b, c, h, w), terms, self.div_fac, seed, stream, offs, fused_factor)
+
+    def generate_normalized(self, factor, *_args):
+        """generate() followed by scale_noise(factor, normalized=True), the tensor written once (device draws only)."""
+        if self.cpu or self.normalize_dims is not None or self.blend_mode not in hip_lib.BLEND_IDS:
+            return None
+        return self.fix_output_frames(self._device_generate(None, factor))
 
 
 class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
@@ -388,6 +408,11 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
             else:
                 partials = None
             return self.fix_output_frames(attach_stats(noise, partials))
+        return self.fix_output_frames(self._device_generate(partials, None))
+
+    def _device_generate(self, partials, fused_factor):
+        mode = self.upscale_mode
+        b, c, h, w = self.get_adjusted_shape()
         seed, stream = self.device_key(2 + self.iterations)
         host = torch.Generator().manual_seed((seed * 0x9E3779B97F4A7C15 + stream) % (2**63))  # shared by all ranks
         levels = []
@@ -398,16 +423,25 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
             else:
                 grid = hip_lib.philox_normal((b * c, ch, cw), self.device, seed, stream + 2 + i, plane_offset * ch * cw)
                 levels.append((grid, ch, cw, self.discount**i))
+        offs = self.latent_elem_offset(c * h * w)
         if w % 4 == 0:
-            out = hip_lib.pyramid_generate((b, c, h, w), self.device, levels, mode, seed, stream, self.latent_elem_offset(c * h * w), partials)
-        else:  # rare odd widths: same values through the unfused kernels
-            out = hip_lib.philox_normal((b, c, h, w), self.device, seed, stream, self.latent_elem_offset(c * h * w))
-            for grid, ch, cw, wt in levels:
-                if grid is None:
-                    grid = hip_lib.philox_normal((b, c, h, w), self.device, seed, stream + 1, self.latent_elem_offset(c * h * w))
-                hip_lib.resample_acc_(out, grid, wt, mode, True)
-            hip_lib.stats(out, partials)
-        return self.fix_output_frames(attach_stats(out, partials))
+            if fused_factor is not None:
+                return hip_lib.pyramid_noise((b, c, h, w), self.device, levels, mode, seed, stream, offs, fused_factor)
+            return attach_stats(hip_lib.pyramid_generate((b, c, h, w), self.device, levels, mode, seed, stream, offs, partials), partials)
+        # rare odd widths: same values through the unfused kernels
+        out = hip_lib.philox_normal((b, c, h, w), self.device, seed, stream, offs)
+        for grid, ch, cw, wt in levels:
+            if grid is None:
+                grid = hip_lib.philox_normal((b, c, h, w), self.device, seed, stream + 1, offs)
+            hip_lib.resample_acc_(out, grid, wt, mode, True)
+        if fused_factor is not None:
+            return hip_lib.scale_noise_(out, fused_factor, True, hip_lib.stats(out))
+        return attach_stats(out, hip_lib.stats(out, partials))
+
+    def generate_normalized(self, factor, *_args):
+        if self.cpu or self.normalize_dims is not None or self.upscale_mode not in hip_lib.RESAMPLE_IDS:
+            return None
+        return self.fix_output_frames(self._device_generate(None, factor))
 
 
 class HighresPyramidNoiseGenerator(FramesToChannelsNoiseGenerator):

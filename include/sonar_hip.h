@@ -134,8 +134,9 @@ int sonar_dpmpp_stage2_f32(const float* x, const float* denoised2, const float* 
                            const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, void* stream);
 
 /* ---------------------------------------------------------------- base generators (rows G1, G2) */
-/* On-device counter RNG (Philox4x32-10, key=seed, counter=global element index/4, stream id):
- * value of element e depends only on (seed, stream_id, elem_offset+e) -> shard-count invariant. */
+/* On-device counter RNG.  Philox4x32-10 (key = seed) seeds one xoshiro128++ burst per (stream id, tile, lane);
+ * a flat buffer is drawn in tiles of 4096 elements, so the value of element e depends only on
+ * (seed, stream_id, elem_offset + e) -> independent of how a batch is sharded over GPUs. */
 int sonar_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                             double* partials /*nullable*/, void* stream);
 /* out = (u - sub)*mul + add, u~U[0,1)  (py/noise_generation.py:508-514) */
@@ -156,6 +157,13 @@ int sonar_perlin_generate_f32(const float* terms, float* out, int64_t B, int64_t
                               uint64_t seed, uint64_t stream_id, int64_t elem_offset, double* partials /*nullable*/,
                               void* stream);
 
+/* generate mode + scale_noise(factor, normalized=True) without a second sweep over the tensor (SURVEY.md §8d
+ * "stats-before-write"): pass 1 re-draws the values and only reduces (sum, sumsq) -> partials; pass 2 re-draws,
+ * applies the on-device normalisation decision and writes the final tensor once. */
+int sonar_perlin_noise_f32(const float* terms, float* out, int64_t B, int64_t chw, int64_t iters, float div_fac,
+                           uint64_t seed, uint64_t stream_id, int64_t elem_offset, float factor, float threshold_std_devs,
+                           double* partials /*workspace, SONAR_NPART pairs*/, void* stream);
+
 /* ---------------------------------------------------------------- Pyramid (row Y) */
 /* dst[B*C][H][W] += bilinear_upsample(src[B*C][h][w]) * scale   (F.interpolate(mode="bilinear",
  * align_corners=False), py/utils.py:58-67 <- py/noise_generation.py:629-646).  mode: 0 bilinear,
@@ -169,16 +177,30 @@ int sonar_pyramid_generate_f32(float* out, int64_t planes, int64_t H, int64_t W,
                                const int64_t* level_w, const float* level_weight, int mode, uint64_t seed,
                                uint64_t stream_id, int64_t elem_offset, double* partials /*nullable*/, void* stream);
 
+/* same, with the normaliser folded in (see sonar_perlin_noise_f32) */
+int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels,
+                            const float* const* level_ptrs, const int64_t* level_h, const int64_t* level_w,
+                            const float* level_weight, int mode, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                            float factor, float threshold_std_devs, double* partials, void* stream);
+
 /* ---------------------------------------------------------------- power-law rFFT noise (row PW) */
 /* py/nodes/powernoise.py:366-377: out = irfft2(z * filter, s=(H,W), norm="ortho").
- *   z      [planes][H][W/2+1] complex64 (interleaved re,im) or NULL -> drawn on device:
- *          complex normal (a+ib)*sqrt(1/2) from Philox(seed, stream_id, complex index)
+ *   z      [planes][H][W/2+1] complex64 (interleaved re,im) or NULL -> drawn on device: complex normal
+ *          (a+ib)*sqrt(1/2); plane p of this call is global plane plane_offset + p of the logical batch
  *   filter [H][W/2+1] fp32 (broadcast over planes)
- * Supported: H, W powers of two, 8 <= H,W <= 256 (else SONAR_ERR_UNSUPPORTED; the host falls back
- * to nothing — it raises). */
+ * Supported: H, W powers of two in 16..256 with the half-spectrum LDS-resident (else SONAR_ERR_UNSUPPORTED). */
 int sonar_power_irfft2_f32(const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,
-                           uint64_t seed, uint64_t stream_id, int64_t cplx_offset, double* partials /*nullable*/,
+                           uint64_t seed, uint64_t stream_id, int64_t plane_offset, double* partials /*nullable*/,
                            void* stream);
+/* draw + filter + irfft2 + scale_noise(factor, normalized=True) writing the tensor ONCE: the output statistics are
+ * obtained from the spectrum by Parseval's identity in a first RNG-only pass (no FFT, no stores). */
+int sonar_power_noise_f32(const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
+                          uint64_t stream_id, int64_t plane_offset, float factor, float threshold_std_devs,
+                          double* partials /*workspace*/, void* stream);
+/* the spectrum the two entry points above draw for (seed, stream_id, plane_offset): z_out[planes][H][W/2+1] complex64
+ * (tests / replaying a device draw) */
+int sonar_power_spectrum_f32(float* z_out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,
+                             int64_t plane_offset, void* stream);
 /* forward: spec[planes][H][W/2+1] = rfft2(x, norm="ortho") * filter (filter nullable)
  * (PowerFilterNoiseItem / time_brownian path, py/nodes/powernoise.py:368-370) */
 int sonar_rfft2_f32(const float* x, const float* filter, float* spec, int64_t planes, int64_t H, int64_t W,

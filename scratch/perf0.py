@@ -39,3 +39,8 @@ xo = torch.empty_like(x); ho = torch.empty_like(x)
 res['momentum_euler'] = timeit(lambda: hl.momentum_euler(x, den, h, cfg, 3.0, -0.5, x_out=xo, h_out=ho))
 for k, v in res.items():
     print(f"{k:28s} {v:9.1f} us   {n*4/v/1e6:8.2f} TB/s-per-4N")
+res2 = {}
+res2['perlin_noise(fused)'] = timeit(lambda: hl.perlin_noise(shape, terms, 2.0, 1, 0, 0, 1.0))
+res2['power_noise(fused)'] = timeit(lambda: hl.power_noise(filt, shape, seed=1, stream_id=0, plane_offset=0, factor=1.0))
+for k, v in res2.items():
+    print(f"{k:28s} {v:9.1f} us   12N-equiv {n*12/v/1e6:8.2f} TB/s")
