@@ -138,6 +138,10 @@ __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const fl
     constexpr int Wh = W / 2 + 1, NC = H * Wh, HALF = NC / 2;
     Xoshiro rng{0, 0, 0, 0};
     if constexpr (GEN) rng = rng_stream(seed, stream_id, (uint64_t)gplane, (uint32_t)tid);
+    // (ky, kx) of linear index j, advanced incrementally (no per-element division); the partner element
+    // j + HALF = j + (H/2) * Wh sits in the same column, H/2 rows below
+    int ky = tid / Wh, kx = tid - ky * Wh;
+    constexpr int DKY = NT / Wh, DKX = NT - DKY * Wh;
 #pragma unroll 1
     for (int j = tid; j < HALF; j += NT) {
         c32 za, zb;
@@ -155,9 +159,14 @@ __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const fl
         const float fa = filter[j], fb = filter[j + HALF];
         za.x *= fa; za.y *= fa;
         zb.x *= fb; zb.y *= fb;
-        const int kya = j / Wh, jb = j + HALF, kyb = jb / Wh;
-        sink(kya, j - kya * Wh, za);
-        sink(kyb, jb - kyb * Wh, zb);
+        sink(ky, kx, za);
+        sink(ky + H / 2, kx, zb);
+        kx += DKX;
+        ky += DKY;
+        if (kx >= Wh) {
+            kx -= Wh;
+            ky += 1;
+        }
     }
 }
 
@@ -169,7 +178,12 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
     using C = PlaneCfg<H, W>;
     constexpr int NT = kFftThreads;
     constexpr int M = C::M, S = C::S;
-    constexpr int CN1 = C::CN1, CN2 = C::CN2, RN1 = C::RN1, RN2 = C::RN2;
+    constexpr int RN1 = C::RN1, RN2 = C::RN2;
+    // FAST shapes (W = 128, H = 64 / 128, 8 waves): every wave owns ONE residue n2 in both twiddled passes, so all
+    // twiddles are wave-uniform AND loop-invariant -> loaded once into scalar registers before the plane loop
+    // (no s_load / lgkmcnt(0) stall inside the passes); the column split is H = (H/8) x 8 instead of 8 x (H/8).
+    constexpr bool FAST = (W == 128) && (H == 128 || H == 64) && (NT == 512) && !SONAR_FFT_TW_LDS;
+    constexpr int CN1 = FAST ? H / 8 : C::CN1, CN2 = FAST ? 8 : C::CN2;
     __shared__ c32 A[C::kLdsComplex];
     c32* const T0 = A + H * S;      // raw column kx = 0
     c32* const TM = T0 + H;         // raw column kx = M
@@ -194,6 +208,17 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
         return c_tw256[((uni ? __builtin_amdgcn_readfirstlane(idx) : idx) * (256 / n)) & 255];
     };
 #endif
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    c32 ctw[CN1], gtw[RN1], ptw[RN1];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int k1 = 0; k1 < CN1; ++k1) ctw[k1] = c_tw256[((wv * k1) * (256 / H)) & 255];
+#pragma unroll
+        for (int n1 = 0; n1 < RN1; ++n1) gtw[n1] = c_tw256[((RN2 * n1 + wv) * (256 / W)) & 255];
+#pragma unroll
+        for (int k1 = 0; k1 < RN1; ++k1) ptw[k1] = c_tw256[((wv * k1) * (256 / M)) & 255];
+    }
 
     for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
         __syncthreads();  // previous plane's LDS reads are done (and TW is visible)
@@ -202,6 +227,77 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
             (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v;
         });
         __syncthreads();
+        if constexpr (FAST) {
+            // fix-up: Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky] -> column 0 of the plane
+            if (tid < H) {
+                const int ky = tid, kn = (H - ky) & (H - 1);
+                const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
+                A[ky * S] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
+            }
+            __syncthreads();
+            // ------------------------------------------------------------ columns, pass a: radix CN1, one item per thread
+            {
+                const int c = lane, n2 = wv;
+                c32 v[CN1];
+#pragma unroll
+                for (int n1 = 0; n1 < CN1; ++n1) v[n1] = A[(CN2 * n1 + n2) * S + c];
+                idft<CN1>(v);
+#pragma unroll
+                for (int k1 = 1; k1 < CN1; ++k1) v[k1] = cmul(v[k1], ctw[k1]);
+#pragma unroll
+                for (int k1 = 0; k1 < CN1; ++k1) A[(CN2 * k1 + n2) * S + c] = v[k1];
+            }
+            __syncthreads();
+            // ------------------------------------------------------------ columns, pass b: radix 8, rows 8 k1 .. 8 k1 + 7
+#pragma unroll
+            for (int it = 0; it < CN1 / 8; ++it) {
+                const int c = lane, k1 = wv + 8 * it;
+                c32 u[CN2];
+#pragma unroll
+                for (int n2 = 0; n2 < CN2; ++n2) u[n2] = A[(CN2 * k1 + n2) * S + c];
+                idft<CN2>(u);
+#pragma unroll
+                for (int k2 = 0; k2 < CN2; ++k2) A[(CN2 * k1 + k2) * S + c] = u[k2];
+            }
+            __syncthreads();
+            // ------------------------------------------------------------ rows, pass a: n2 = wave, rows lane + 64 it
+            {
+                constexpr int ITEMS = H / 64;
+                const int n2 = wv;
+                c32 g[ITEMS][RN1];
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const c32* row = A + (lane + 64 * it) * S;
+#pragma unroll
+                    for (int n1 = 0; n1 < RN1; ++n1) {
+                        const int k = RN2 * n1 + n2;
+                        c32 xa, xb;
+                        if (k == 0) {  // uniform: wave 0, n1 = 0
+                            const c32 p = row[0];
+                            xa = make_float2(p.x, 0.0f);
+                            xb = make_float2(p.y, 0.0f);
+                        } else {
+                            xa = row[k];
+                            xb = row[M - k];
+                        }
+                        const c32 e = make_float2(xa.x + xb.x, xa.y - xb.y);
+                        const c32 d = make_float2(xa.x - xb.x, xa.y + xb.y);
+                        const c32 o = cmul(d, gtw[n1]);
+                        g[it][n1] = make_float2(e.x - o.y, e.y + o.x);
+                    }
+                    idft<RN1>(g[it]);
+#pragma unroll
+                    for (int k1 = 1; k1 < RN1; ++k1) g[it][k1] = cmul(g[it][k1], ptw[k1]);
+                }
+                __syncthreads();  // every mirrored read is done before anyone overwrites
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+#pragma unroll
+                    for (int k1 = 0; k1 < RN1; ++k1) A[(lane + 64 * it) * S + RN2 * k1 + n2] = g[it][k1];
+                }
+            }
+            __syncthreads();
+        } else {
         // ---------------------------------------------------------------- columns, pass a
         // Column 0 is built on the fly from the raw kx = 0 / kx = M columns:
         //   Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky],  sym(Z)[ky] = (Z[ky] + conj Z[-ky]) / 2
@@ -288,6 +384,7 @@ SONAR_UNROLL_ITEMS
             }
         }
         __syncthreads();
+        }  // !FAST
         // ---------------------------------------------------------------- rows, pass b -> global
         float* const oplane = out + plane * (int64_t)H * W;
         float ps = 0.0f, pq = 0.0f;  // per-plane fp32 partials (<= 64 values per thread), folded into fp64 below
