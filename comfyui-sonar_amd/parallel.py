@@ -1,0 +1,99 @@
+"""Batch sharding of the noise path across the GPUs of one node.
+
+The path shards over the batch dimension with NO data-path collective: every latent's draws are keyed by its
+GLOBAL index (``noise_generation.shard_offset``), lattice/pyramid scalars that the reference shares across the
+batch are keyed without a batch offset, so rank r generating latents [start, start+count) produces exactly the
+slice of what one GPU would produce for the whole batch.  One process per GPU (torch.distributed, backend
+"nccl" = RCCL over xGMI); collectives appear only in two OPTIONAL places:
+  * ``allreduce_stats`` / ``normalise_global_``: 3 x fp64 (sum, sumsq, n) all-reduce per normalisation point, for
+    exact whole-batch ``scale_noise`` parity (default semantics = every shard normalises itself, i.e. the reference
+    called with B/N latents);
+  * ``gather_batch``: final all-gather of the shards (the north_star's optional gather).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import hip_lib
+from .py import noise_generation
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition: (first latent, count) of rank `rank`; the first `global_batch % world` ranks get one extra."""
+    if world <= 0 or not 0 <= rank < world or global_batch < 0:
+        raise ValueError(f"bad shard request: batch={global_batch} rank={rank} world={world}")
+    base, extra = divmod(global_batch, world)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def rank_world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+class ShardedNoiseSampler:
+    """Wraps ``make_noise_sampler`` of any noise item / chain so that each rank generates only its shard.
+
+    ``make(x_shard, ...)`` is called with a latent of the SHARD's batch size; calls run inside
+    ``shard_offset(start)`` so on-device draws use global latent indices.  (``cpu=True`` replay draws come from the
+    host generator and are not shard-invariant — same as the reference run on a smaller batch.)"""
+
+    def __init__(self, make: Callable, x_global_shape, device, *, group=None, **make_kwargs):
+        self.rank, self.world = rank_world(group)
+        self.group = group
+        self.start, self.count = shard_range(int(x_global_shape[0]), self.rank, self.world)
+        self.global_shape = tuple(x_global_shape)
+        x = torch.zeros((self.count, *x_global_shape[1:]), device=device)
+        with noise_generation.shard_offset(self.start):
+            self.sampler = make(x, **make_kwargs)
+
+    def __call__(self, sigma, sigma_next) -> torch.Tensor:
+        with noise_generation.shard_offset(self.start):
+            return self.sampler(sigma, sigma_next)
+
+    def gather(self, local: torch.Tensor) -> torch.Tensor:
+        return gather_batch(local, self.global_shape[0], group=self.group)
+
+
+def allreduce_stats(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum the (sum, sumsq, n) fp64 triple over ranks (24 bytes: latency only)."""
+    if local.dtype != torch.float64 or local.numel() != 3:
+        raise ValueError("allreduce_stats expects a float64 tensor of 3 elements")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)
+    return local
+
+
+def normalise_global_(x: torch.Tensor, factor: float = 1.0, *, threshold_std_devs: float = 2.5, group=None) -> torch.Tensor:
+    """scale_noise(x, factor, normalized=True) with statistics of the WHOLE logical batch (all ranks): HIP stats kernel ->
+    3-double all-reduce -> HIP apply kernel with the global element count.  No host sync."""
+    total = allreduce_stats(hip_lib.stats_finalize(hip_lib.stats(x), x.numel()), group)
+    partials = torch.zeros(hip_lib.NPART * 2, dtype=torch.float64, device=x.device)
+    partials[:2] = total[:2]
+    n_total = int(total[2].item())  # optional exact-parity path: one 8-byte read-back
+    return hip_lib.scale_noise_(x, factor, True, partials, threshold_std_devs=threshold_std_devs, n_total=n_total)
+
+
+def gather_batch(local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
+    """All-gather the shards along dim 0 into [global_batch, ...] on every rank (uneven shards are padded to the largest).
+    On MI355X the 7 xGMI links are point-to-point: RCCL's all-gather of 128 MiB shards is per-link bound (~0.9 ms for
+    cfg5); it is outside the timed hot path unless the consumer needs the full batch on one device."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return local
+    counts = [shard_range(global_batch, r, world)[1] for r in range(world)]
+    biggest = max(counts)
+    send = local
+    if local.shape[0] < biggest:
+        pad = torch.zeros((biggest - local.shape[0], *local.shape[1:]), dtype=local.dtype, device=local.device)
+        send = torch.cat((local, pad))
+    out = torch.empty((world * biggest, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    if all(c == biggest for c in counts):
+        return out
+    return torch.cat([out[r * biggest: r * biggest + counts[r]] for r in range(world)])

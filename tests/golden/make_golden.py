@@ -409,7 +409,61 @@ def gen_momentum():
     save("momentum", **cases)
 
 
-if __name__ == "__main__":
+# ------------------------------------------------------------------------------------------------ node ABI (boundary facts)
+def gen_node_abi():
+    """Names / socket types / defaults of every registered node: data only, no code."""
+    import json
+
+    out = {}
+    for key, cls in ref.nodes.NODE_CLASS_MAPPINGS.items():
+        try:
+            spec = cls.INPUT_TYPES()
+        except Exception:  # noqa: BLE001  (first call probes optional third-party packs and may fail once)
+            spec = cls.INPUT_TYPES()
+        inputs = {}
+        for section in ("required", "optional"):
+            for name, item in spec.get(section, {}).items():
+                typ = item[0]
+                opts = item[1] if len(item) > 1 else {}
+                entry = {"section": section, "type": list(typ) if isinstance(typ, (tuple, list)) else str(typ)}
+                for k in ("default", "min", "max"):
+                    if k in opts and isinstance(opts[k], (int, float, str, bool)):
+                        entry[k] = opts[k]
+                inputs[name] = entry
+        out[key] = {"returns": list(cls.RETURN_TYPES), "function": cls.FUNCTION, "category": cls.CATEGORY,
+                    "output_node": bool(getattr(cls, "OUTPUT_NODE", False)), "inputs": inputs}
+    with open(os.path.join(OUT, "node_abi.json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+    print("node_abi.json", len(out), "nodes")
+
+
+
+
+# ------------------------------------------------------------------------------------------------ entry-point nodes
+def gen_entry_nodes():
+    M = ref.nodes.NODE_CLASS_MAPPINGS
+    N = ref.noise
+    cases = {}
+    lat0 = torch.zeros(2, 4, 16, 16)
+    (out,) = M["NoisyLatentLike"].go(noise_type="perlin", seed=5, latent={"samples": lat0}, multiplier=0.7, add_to_latent=False,
+                                     repeat_batch=2, cpu_noise=True, normalize=True)
+    cases["nll_perlin"] = out["samples"]
+    chain = N.CustomNoiseChain()
+    chain.add(N.CustomNoiseItem(0.6, noise_type=NT.GAUSSIAN))
+    chain.add(N.CustomNoiseItem(-0.3, noise_type=NT.UNIFORM))
+    g = torch.Generator().manual_seed(77)
+    lat1 = torch.randn(2, 4, 16, 16, generator=g)
+    (out,) = M["NoisyLatentLike"].go(noise_type="gaussian", seed=6, latent={"samples": lat1}, multiplier=1.3, add_to_latent=True,
+                                     repeat_batch=1, cpu_noise=True, normalize=True, custom_noise_opt=chain)
+    cases["nll_chain_latent"], cases["nll_chain_out"] = lat1, out["samples"]
+    (nobj,) = M["SONAR_CUSTOM_NOISE to NOISE"].go(custom_noise=chain, seed=9, cpu_noise=True, normalize=True, multiplier=0.5)
+    cases["noise_plain"] = nobj.generate_noise({"samples": torch.zeros(3, 4, 8, 8)})
+    cases["noise_batch_index"] = nobj.generate_noise({"samples": torch.zeros(3, 4, 8, 8), "batch_index": [2, 0, 2]})
+    save("entry_nodes", **cases)
+
+
+
+if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_scale_noise()
     gen_basic_types()
     gen_perlin()
@@ -418,4 +472,10 @@ if __name__ == "__main__":
     gen_power_noise()
     gen_composition()
     gen_momentum()
+    globals()["gen_node_abi"]()
+    gen_entry_nodes()
     print("golden vectors written to", OUT)
+
+if __name__ == "__main__" and "--nodes-only" in sys.argv:
+    gen_node_abi()
+    gen_entry_nodes()

@@ -342,3 +342,40 @@ def test_device_mode_distribution_and_shard_invariance(api, name):
     ns = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, normalized=False)
     a, b = ns(*SIG), ns(*SIG)
     assert not torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ entry-point nodes
+def test_noisy_latent_like_and_noise_adapter_nodes(pkg, api, golden):
+    """NoisyLatentLike.go / CustomNOISE.generate_noise (py/nodes/misc.py:73-155,360-419) vs the reference, incl. repeat_batch,
+    add_to_latent, the saved/restored global RNG state and per-batch-index seeding."""
+    g = golden("entry_nodes")
+    M = pkg.NODE_CLASS_MAPPINGS
+    before = torch.random.get_rng_state()
+    (out,) = M["NoisyLatentLike"].go(noise_type="perlin", seed=5, latent={"samples": torch.zeros(2, 4, 16, 16)}, multiplier=0.7,
+                                     add_to_latent=False, repeat_batch=2, cpu_noise=True, normalize=True)
+    assert torch.equal(torch.random.get_rng_state(), before)
+    assert out["samples"].device.type == "cpu"  # returned on the latent's original device
+    close(out["samples"], g["nll_perlin"])
+    chain = chain_of(api, item(api, "gaussian", 0.6), item(api, "uniform", -0.3))
+    (out,) = M["NoisyLatentLike"].go(noise_type="gaussian", seed=6, latent={"samples": g["nll_chain_latent"]}, multiplier=1.3, add_to_latent=True,
+                                     repeat_batch=1, cpu_noise=True, normalize=True, custom_noise_opt=chain)
+    close(out["samples"], g["nll_chain_out"])
+    (nobj,) = M["SONAR_CUSTOM_NOISE to NOISE"].go(custom_noise=chain, seed=9, cpu_noise=True, normalize=True, multiplier=0.5)
+    close(nobj.generate_noise({"samples": torch.zeros(3, 4, 8, 8)}), g["noise_plain"])
+    close(nobj.generate_noise({"samples": torch.zeros(3, 4, 8, 8), "batch_index": [2, 0, 2]}), g["noise_batch_index"])
+    zero = M["SONAR_CUSTOM_NOISE to NOISE"].go(custom_noise=chain, seed=9, multiplier=0.0)[0].generate_noise({"samples": torch.zeros(1, 4, 8, 8)})
+    assert torch.count_nonzero(zero) == 0
+
+
+def test_global_normalisation_and_sharded_sampler_single_process(api):
+    par = __import__("importlib").import_module("comfyui_sonar_amd.parallel")
+    torch.manual_seed(3)
+    x = torch.randn(4, 4, 16, 16) * 0.7 + 0.3
+    from oracle import sonar_oracle as orc
+
+    want = orc.scale_noise(x.clone(), 1.1, normalized=True)
+    close(par.normalise_global_(x.cuda(), 1.1), want)
+    sh = par.ShardedNoiseSampler(lambda xs, **kw: api.noise.get_noise_sampler("perlin", xs, 0.03, 14.6, **kw), (6, 4, 32, 32), "cuda",
+                                 seed=None, cpu=False, normalized=False)
+    out = sh(*SIG)
+    assert out.shape == (6, 4, 32, 32) and torch.equal(sh.gather(out), out)
