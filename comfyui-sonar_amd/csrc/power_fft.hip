@@ -131,7 +131,7 @@ struct PlaneCfg {
 // One plane's filtered half-spectrum -> sink(ky, kx, value).  GEN: thread-slot `tid` of plane `gplane` owns the
 // stream (seed, stream_id, tile = gplane, lane = tid); burst step `it` yields the complex pair at linear
 // indices j and j + NC/2 (j = it*NT + tid), so consecutive lanes touch consecutive elements.
-template <int H, int W, bool GEN, typename Sink>
+template <int H, int W, bool GEN, int UNROLL = 2, typename Sink>
 __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const float* __restrict__ filter, int64_t plane,
                                            int64_t gplane, uint64_t seed, uint64_t stream_id, int tid, Sink&& sink) {
     constexpr int NT = kFftThreads;
@@ -142,7 +142,7 @@ __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const fl
     // j + HALF = j + (H/2) * Wh sits in the same column, H/2 rows below
     int ky = tid / Wh, kx = tid - ky * Wh;
     constexpr int DKY = NT / Wh, DKX = NT - DKY * Wh;
-#pragma unroll 1
+#pragma unroll UNROLL
     for (int j = tid; j < HALF; j += NT) {
         c32 za, zb;
         if constexpr (GEN) {
@@ -428,29 +428,37 @@ template <int H, int W>
 __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* __restrict__ filter, int64_t planes, uint64_t seed,
                                                                    uint64_t stream_id, int64_t plane_offset, double* partials) {
     constexpr int NT = kFftThreads, M = W / 2;
-    __shared__ c32 T0[H], TM[H];
+    __shared__ c32 EDGE[2][2][H];  // [plane parity][kx = 0 | kx = M][ky]: double-buffered -> one barrier per plane
     __shared__ double red[2 * NT / 64];
     const int tid = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
-        __syncthreads();
-        float acc = 0.0f;
-        fill_plane<H, W, true>(nullptr, filter, plane, plane_offset + plane, seed, stream_id, tid, [&](int ky, int kx, c32 v) {
-            if (kx == 0) T0[ky] = v;
-            else if (kx == M) TM[ky] = v;
-            else acc = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, acc));
-        });
-        __syncthreads();
+    int par = 0;
+    auto edge_terms = [&](int p) {
         float edge = 0.0f;
         for (int ky = tid; ky < H; ky += NT) {
             const int kn = (H - ky) & (H - 1);
-            const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
+            const c32 a = EDGE[p][0][ky], an = EDGE[p][0][kn], b = EDGE[p][1][ky], bn = EDGE[p][1][kn];
             const float ar = 0.5f * (a.x + an.x), ai = 0.5f * (a.y - an.y), br = 0.5f * (b.x + bn.x), bi = 0.5f * (b.y - bn.y);
             edge += (ar * ar + ai * ai) + (br * br + bi * bi);
             if (ky == 0) s += (double)(sqrtf((float)H * (float)W) * ar);
         }
-        q += 2.0 * (double)acc + (double)edge;
+        q += (double)edge;
+    };
+    bool pending = false;
+    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+        float acc = 0.0f;
+        fill_plane<H, W, true, 4>(nullptr, filter, plane, plane_offset + plane, seed, stream_id, tid, [&](int ky, int kx, c32 v) {
+            if (kx == 0) EDGE[par][0][ky] = v;
+            else if (kx == M) EDGE[par][1][ky] = v;
+            else acc = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, acc));
+        });
+        q += 2.0 * (double)acc;
+        __syncthreads();           // this plane's edge columns are complete; the other buffer's readers finished last iteration
+        edge_terms(par);           // overlaps with the next plane's fill (which writes the other buffer)
+        par ^= 1;
+        pending = true;
     }
+    (void)pending;
     write_partial<NT>(s, q, partials, red);
 }
 
