@@ -192,8 +192,7 @@ struct BandScales {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(kBlock) wcfg_band_kernel(const T* __restrict__ cond, const T* __restrict__ uncond,
-                                                            T* __restrict__ out, int64_t n, int64_t group_size, int groups,
+__global__ void __launch_bounds__(kBlock) wcfg_band_kernel(const T* cond, const T* uncond, T* out /* may alias cond / uncond */, int64_t n, int64_t group_size, int groups,
                                                             BandScales<T> sc, int blend_mode, T strength) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const int g = groups > 1 ? (int)((i / group_size) % groups) : 0;

@@ -324,6 +324,89 @@ __global__ void __launch_bounds__(kBlock) row_affine_kernel(int op, const float*
     }
 }
 
+__global__ void __launch_bounds__(kBlock) amax_mid_kernel(const float* __restrict__ x, int64_t outer, int64_t mid,
+                                                           int64_t inner, int use_abs, float* peak) {
+    const int64_t total = outer * inner;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t o = t / inner, i = t - o * inner;
+        const float* p = x + o * mid * inner + i;
+        float hi = -INFINITY;
+        bool nan = false;
+        for (int64_t m = 0; m < mid; ++m) {
+            float v = p[m * inner];
+            if (use_abs) v = fabsf(v);
+            nan |= v != v;
+            hi = fmaxf(hi, v);
+        }
+        peak[t] = nan ? NAN : hi;  // torch.amax propagates NaN
+    }
+}
+
+// inner == 1: one workgroup per row of `mid` contiguous elements
+__global__ void __launch_bounds__(kBlock) amax_row_kernel(const float* __restrict__ x, int64_t rows, int64_t len, int use_abs,
+                                                           float* peak) {
+    __shared__ float smax[kBlock / 64];
+    __shared__ int snan[kBlock / 64];
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* row = x + r * len;
+        float hi = -INFINITY;
+        int nan = 0;
+        for (int64_t i = threadIdx.x; i < len; i += kBlock) {
+            float v = row[i];
+            if (use_abs) v = fabsf(v);
+            nan |= v != v;
+            hi = fmaxf(hi, v);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            hi = fmaxf(hi, __shfl_down(hi, off, 64));
+            nan |= __shfl_down(nan, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            smax[threadIdx.x >> 6] = hi;
+            snan[threadIdx.x >> 6] = nan;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kBlock / 64; ++w) {
+                hi = fmaxf(hi, smax[w]);
+                nan |= snan[w];
+            }
+            peak[r] = nan ? NAN : hi;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) div_mid_kernel(float* x, int64_t outer, int64_t mid, int64_t inner,
+                                                          const float* __restrict__ d) {
+    const int64_t total = outer * mid * inner, plane = mid * inner;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t o = t / plane;
+        const int64_t i = (t - o * plane) % inner;
+        x[t] = x[t] / d[o * inner + i];
+    }
+}
+
+struct PowerLawOp {
+    float* x;
+    float alpha;
+    int use_sign;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        Pack<V> p = load<V>(x, i);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float v = p.v[k];
+            const float av = fabsf(v);  // ATen special-cases these exponents (pow_tensor_scalar), keep them exact
+            const float mod = alpha == 0.0f ? 1.0f : alpha == 1.0f ? av : alpha == 0.5f ? sqrtf(av) : alpha == 2.0f ? av * av : powf(av, alpha);
+            const float base = use_sign ? (v > 0.0f ? 1.0f : v < 0.0f ? -1.0f : v) : v;  // torch.sign keeps 0 and NaN
+            p.v[k] = base * mod;
+        }
+        store<V>(x, i, p);
+    }
+};
+
 struct MaskMixOp {
     const float *dst, *src, *mask;
     int64_t mask_n;
@@ -618,6 +701,32 @@ extern "C" int sonar_row_affine_f32(int op, const float* x, int64_t rows, int64_
     hipLaunchKernelGGL(row_affine_kernel, dim3(grid_for(rows * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, op, x,
                        rows, inner, a, b, out);
     return check_launch("sonar_row_affine_f32");
+}
+
+extern "C" int sonar_powerlaw_f32(float* x, float alpha, int use_sign, int64_t n, void* stream) {
+    SONAR_REQUIRE(x && n >= 0, SONAR_ERR_ARG, "sonar_powerlaw_f32: bad argument");
+    return launch_ew(PowerLawOp{x, alpha, use_sign}, n, aligned16(x), (hipStream_t)stream, "sonar_powerlaw_f32");
+}
+
+extern "C" int sonar_amax_mid_f32(const float* x, int64_t outer, int64_t mid, int64_t inner, int use_abs, float* peak,
+                                  void* stream) {
+    SONAR_REQUIRE(x && peak && outer >= 0 && mid > 0 && inner > 0, SONAR_ERR_ARG, "sonar_amax_mid_f32: bad argument");
+    if (outer == 0) return SONAR_OK;
+    if (inner == 1)
+        hipLaunchKernelGGL(amax_row_kernel, dim3(grid_for(outer, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, outer, mid, use_abs,
+                           peak);
+    else
+        hipLaunchKernelGGL(amax_mid_kernel, dim3(grid_for(outer * inner, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, outer,
+                           mid, inner, use_abs, peak);
+    return check_launch("sonar_amax_mid_f32");
+}
+
+extern "C" int sonar_div_mid_f32(float* x, int64_t outer, int64_t mid, int64_t inner, const float* d, void* stream) {
+    SONAR_REQUIRE(x && d && outer >= 0 && mid > 0 && inner > 0, SONAR_ERR_ARG, "sonar_div_mid_f32: bad argument");
+    if (outer == 0) return SONAR_OK;
+    hipLaunchKernelGGL(div_mid_kernel, dim3(grid_for(outer * mid * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x,
+                       outer, mid, inner, d);
+    return check_launch("sonar_div_mid_f32");
 }
 
 extern "C" int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,

@@ -71,6 +71,9 @@ SIGNATURES = {
     "sonar_scalar_op_f32": (_I, [_I, _P, _P, _F, _P, _I64, _P]),
     "sonar_rowstats_f32": (_I, [_P, _I64, _I64, _P, _P, _P]),
     "sonar_row_affine_f32": (_I, [_I, _P, _I64, _I64, _P, _P, _P, _P]),
+    "sonar_powerlaw_f32": (_I, [_P, _F, _I, _I64, _P]),
+    "sonar_amax_mid_f32": (_I, [_P, _I64, _I64, _I64, _I, _P, _P]),
+    "sonar_div_mid_f32": (_I, [_P, _I64, _I64, _I64, _P, _P]),
     "sonar_mask_mix_f32": (_I, [_P, _P, _P, _I64, _P, _I64, _P]),
     "sonar_minmax_rows_f32": (_I, [_P, _I64, _I64, _P, _P, _P]),
     "sonar_momentum_euler_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
@@ -301,6 +304,22 @@ def row_affine(op: int, x: torch.Tensor, rows: int, inner: int, a: torch.Tensor,
     _check(load().sonar_row_affine_f32(op, _dev(x, "x"), rows, inner, _dev(a, "a"), _dev(b, "b"), _dev(out, "out"), _stream()),
            "sonar_row_affine_f32")
     return out
+
+
+def powerlaw_(x: torch.Tensor, alpha: float, use_sign: bool) -> torch.Tensor:
+    _check(load().sonar_powerlaw_f32(_dev(x, "x"), float(alpha), int(bool(use_sign)), x.numel(), _stream()), "sonar_powerlaw_f32")
+    return x
+
+
+def amax_mid(x: torch.Tensor, outer: int, mid: int, inner: int, use_abs: bool) -> torch.Tensor:
+    peak = torch.empty(outer * inner, dtype=torch.float32, device=x.device)
+    _check(load().sonar_amax_mid_f32(_dev(x, "x"), outer, mid, inner, int(bool(use_abs)), _dev(peak, "peak"), _stream()), "sonar_amax_mid_f32")
+    return peak
+
+
+def div_mid_(x: torch.Tensor, outer: int, mid: int, inner: int, d: torch.Tensor) -> torch.Tensor:
+    _check(load().sonar_div_mid_f32(_dev(x, "x"), outer, mid, inner, _dev(d, "d"), _stream()), "sonar_div_mid_f32")
+    return x
 
 
 def mask_mix(dst: torch.Tensor, src: torch.Tensor, mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -631,6 +650,15 @@ def wcfg_band(cond: torch.Tensor, uncond: torch.Tensor, groups: int, s_cond, s_u
     _check(fn(_dev(cond, "cond", cond.dtype), _dev(uncond, "uncond", cond.dtype), _dev(out, "out", cond.dtype), cond.numel(), group_size, groups,
               arr(s_cond), arr(s_uncond), arr(s_diff), arr(s_final), BLEND_IDS[blend_mode], float(strength), _stream()), f"sonar_wcfg_band_{kind}")
     return out
+
+
+def band_scale_(band: torch.Tensor, scales) -> torch.Tensor:
+    """band[..., g, :, :] *= scales[g] in place (wavelet_scaling, py/wavelet_functions.py:193-216).  Uses the WaveletCFG band
+    kernel with uncond scale 0 and lerp strength 1: out = fma(0, d - 0, d) = cond * scale exactly."""
+    groups = len(scales)
+    if all(float(v) == 1.0 for v in scales):
+        return band
+    return wcfg_band(band, band, groups, list(scales), [0.0] * groups, None, None, "lerp", 1.0, out=band)
 
 
 def wcfg_output(x: Optional[torch.Tensor], result: torch.Tensor, shape, subtract_from_x: bool) -> torch.Tensor:

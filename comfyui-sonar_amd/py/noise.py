@@ -37,6 +37,7 @@ from .noise_generation import (
     StudentTNoiseGenerator,
     UniformNoiseGenerator,
     VoronoiNoiseGenerator,
+    WaveletFilteredNoiseGenerator,
     WaveletNoiseGenerator,
 )
 from .utils import fallback, pop_stats, scale_noise
@@ -364,6 +365,34 @@ class BlendedNoise(CustomNoiseItemBase):
             return scale_noise(n1, factor, normalized=normalize)
 
         return noise_sampler
+
+
+class WaveletFilteredNoise(CustomNoiseItemBase):
+    """py/noise.py:1521-1593."""
+
+    def clone_key(self, k):
+        if k in {"noise", "noise_high"} and getattr(self, k) is not None:
+            return getattr(self, k).clone()
+        return super().clone_key(k)
+
+    def make_noise_sampler(self, x, sigma_min, sigma_max, *args, normalized=True, **kwargs):
+        factor = self.factor
+        normalize = self.get_normalize("normalize", normalized)
+
+        def sub(chain):
+            if chain is None:
+                return None
+            return chain.make_noise_sampler(x, *args, sigma_min=sigma_min, sigma_max=sigma_max, normalized=self.normalize_noise, **kwargs)
+
+        ns_low, ns_high = sub(self.noise), sub(getattr(self, "noise_high", None))
+        opts = getattr(self, "ns_kwargs", {}).copy()
+        blends = {}
+        for key in ("yl_blend_function", "yh_blend_function"):
+            fn = opts.pop(key, utils.BLENDING_MODES["lerp"])
+            blends[key] = utils.BLENDING_MODES[fn] if isinstance(fn, str) else fn
+        gen = WaveletFilteredNoiseGenerator(x, *args, sigma_min=sigma_min, sigma_max=sigma_max, normalized=False, noise_sampler=ns_low,
+                                            noise_sampler_high=ns_high, **blends, **(kwargs | opts))
+        return lambda sigma, sigma_next: scale_noise(gen(sigma, sigma_next), factor, normalized=normalize)
 
 
 # --------------------------------------------------------------------------------------------------

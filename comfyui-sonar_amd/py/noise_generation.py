@@ -536,7 +536,80 @@ PinkOldNoiseGenerator = _off_path("pink_old")
 PowerOldNoiseGenerator = _off_path("power_old")
 GreenTestNoiseGenerator = _off_path("green_test")
 OneFNoiseGenerator = _off_path("onef")
-PowerLawNoiseGenerator = _off_path("powerlaw")
 WaveletNoiseGenerator = _off_path("wavelet")
-WaveletFilteredNoiseGenerator = _off_path("wavelet_filtered")
 ScatternetFilteredNoiseGenerator = _off_path("scatternet_filtered")
+
+
+class PowerLawNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:762-786: spatial "power law" (white / grey / velvet / violet presets):
+    (sign(x) or x) * |x|**alpha, optionally divided by the max |.| over ``div_max_dims``."""
+
+    name = "powerlaw"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"alpha": 2.0, "div_max_dims": None, "use_sign": False, "use_div_max_abs": True}
+
+    def generate(self, *_args):
+        noise = hip_lib.powerlaw_(self.rand_like().contiguous(), self.alpha, self.use_sign)
+        if self.div_max_dims is not None:
+            dims = self.div_max_dims
+            dims = tuple(range(noise.ndim)) if dims == () else sorted({d % noise.ndim for d in ((dims,) if isinstance(dims, int) else dims)})
+            if list(dims) != list(range(dims[0], dims[-1] + 1)):
+                raise hip_lib.SonarHipError("powerlaw: div_max_dims must be adjacent dimensions on the HIP path")
+            outer = math.prod(noise.shape[: dims[0]])
+            mid = math.prod(noise.shape[d] for d in dims)
+            inner = math.prod(noise.shape[dims[-1] + 1:])
+            peak = hip_lib.amax_mid(noise, outer, mid, inner, self.use_div_max_abs)
+            hip_lib.div_mid_(noise, outer, mid, inner, peak)
+        return noise
+
+
+class WaveletFilteredNoiseGenerator(FramesToChannelsNoiseGenerator):
+    """py/noise_generation.py:1908-2032: DWT -> optional blend with a second noise's bands -> per-band scaling -> IDWT."""
+
+    name = "waveletfilter"
+    MIN_DIMS = 4
+    MAX_DIMS = 5
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from .wavelet_functions import Wavelet
+
+        inv = {k: self.options[k] for k in ("inv_mode", "inv_biort", "inv_qshift", "inv_wave") if k in self.options}
+        self.wavelet = Wavelet(wave=self.wave, level=self.level, mode=self.mode, use_1d_dwt=self.use_1d_dwt, use_dtcwt=self.use_dtcwt,
+                               biort=self.biort, qshift=self.qshift, device=self.gen_device, **inv)
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {
+            "mode": "periodization", "level": 3, "wave": "haar", "use_1d_dwt": False, "use_dtcwt": False, "qshift": "qshift_a",
+            "biort": "near_sym_a", "yl_scale": 1.0, "yh_scales": 1.0, "two_step_inverse": False, "preblend_yl_scale_low": None,
+            "preblend_yh_scales_low": None, "preblend_yl_scale_high": None, "preblend_yh_scales_high": None,
+            "yl_blend_function": utils.BLENDING_MODES["lerp"], "yh_blend_function": utils.BLENDING_MODES["lerp"],
+            "yl_blend_high": 0.0, "yh_blend_high": 1.0, "noise_sampler": None, "noise_sampler_high": None,
+        }
+
+    def generate(self, *args):
+        from .wavelet_functions import wavelet_blend, wavelet_scaling
+
+        shape = self.get_adjusted_shape()
+        noise = self.rand_like() if self.noise_sampler is None else self.noise_sampler(*args)
+        utils.pop_stats(noise)
+        noise = noise.reshape(*shape).contiguous()
+        yl, yh = self.wavelet.forward(noise)
+        if self.noise_sampler_high is not None:
+            high = self.noise_sampler_high(*args)
+            utils.pop_stats(high)
+            yl_h, yh_h = self.wavelet.forward(high.reshape(*shape).contiguous())
+            if self.preblend_yl_scale_high is not None or self.preblend_yh_scales_high is not None:
+                yl_h, yh_h = wavelet_scaling(yl_h, yh_h, fallback(self.preblend_yl_scale_high, 1.0), fallback(self.preblend_yh_scales_high, 1.0), in_place=True)
+            if self.preblend_yl_scale_low is not None or self.preblend_yh_scales_low is not None:
+                yl, yh = wavelet_scaling(yl, yh, fallback(self.preblend_yl_scale_low, 1.0), fallback(self.preblend_yh_scales_low, 1.0), in_place=True)
+            yl, yh = wavelet_blend((yl, yh), (yl_h, yh_h), yl_factor=self.yl_blend_high, yh_factor=self.yh_blend_high,
+                                   blend_function=self.yl_blend_function, yh_blend_function=self.yh_blend_function)
+        yl, yh = wavelet_scaling(yl, yh, self.yl_scale, self.yh_scales, in_place=True)
+        result = self.wavelet.inverse(yl, yh, two_step_inverse=self.two_step_inverse)
+        if tuple(result.shape) != tuple(shape):
+            result = result[tuple(slice(0, d) for d in shape)].contiguous()
+        return self.fix_output_frames(result)

@@ -155,15 +155,13 @@ def wavelet_scaling(yl: torch.Tensor, yh: Sequence, yl_scale, yh_scales, *, in_p
         yl = yl.clone()
         yh = tuple(band.clone() for band in yh)
     if yl_scale != 1.0:
-        yl *= yl_scale
+        hip_lib.band_scale_(yl, [float(yl_scale)])
     table = expand_yh_scales(yh, yh_scales=1.0 if yh_scales is None else yh_scales)
     for scales, band in zip(table, yh):
         if isinstance(scales, (int, float)):
-            band *= scales
-            continue
-        for o in range(min(band.shape[2], len(scales))):
-            if scales[o] != 1.0:
-                band[:, :, o] *= scales[o]
+            scales = (float(scales),) * band.shape[2]
+        full = tuple(scales) + (1.0,) * (band.shape[2] - len(scales))
+        hip_lib.band_scale_(band, full[: band.shape[2]])
     return (yl, yh)
 
 

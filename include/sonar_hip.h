@@ -88,6 +88,13 @@ int sonar_rowstats_f32(const float* x, int64_t rows, int64_t inner, float* mean,
 /* op 0: out = (x - a[row]) / b[row]   op 1: out = x * b[row] + a[row]   (same call sites) */
 int sonar_row_affine_f32(int op, const float* x, int64_t rows, int64_t inner, const float* a, const float* b,
                          float* out, void* stream);
+/* PowerLawNoiseGenerator, py/noise_generation.py:775-779: x = (use_sign ? sign(x) : x) * |x|^alpha, in place */
+int sonar_powerlaw_f32(float* x, float alpha, int use_sign, int64_t n, void* stream);
+/* x viewed as [outer, mid, inner]: amax over `mid` of x (use_abs 0) or |x| (use_abs 1) -> peak[outer, inner]
+ * (torch.amax over one non-trailing dim, py/noise_generation.py:780-785) */
+int sonar_amax_mid_f32(const float* x, int64_t outer, int64_t mid, int64_t inner, int use_abs, float* peak, void* stream);
+/* x[o, m, i] /= d[o, i], in place, true division (same call site) */
+int sonar_div_mid_f32(float* x, int64_t outer, int64_t mid, int64_t inner, const float* d, void* stream);
 /* py/utils.py:452-470 normalize_to_scale: per row min/max rescale to [lo,hi] */
 int sonar_minmax_rows_f32(const float* x, int64_t rows, int64_t inner, float* out_min, float* out_max, void* stream);
 

@@ -207,3 +207,30 @@ def wavelet_cfg(cond, uncond, wave, mode, level, *, diff_yl=1.0, diff_yh=1.0, st
         return a + strength * (b - a) if abs(strength) < 0.5 else b - (b - a) * (1 - strength)
 
     return waverec2(bl(ul, dl), [bl(a, b) for a, b in zip(uh, dh)], wave, mode)
+
+
+def wavelet_filtered_noise(noise, *, wave="haar", mode="periodization", level=3, yl_scale=1.0, yh_scales=1.0, noise_high=None,
+                           yl_blend_high=0.0, yh_blend_high=1.0, blend="lerp", two_step_inverse=False, preblend_low=None,
+                           preblend_high=None):
+    """py/noise_generation.py:1980-2032 (WaveletFilteredNoiseGenerator.generate), 2-D DWT variant.
+    preblend_* = (yl_scale, yh_scales) pairs applied to the low / high decompositions before blending."""
+
+    def bl(a, b, t):
+        if blend == "inject":
+            return a + b * t
+        return a + t * (b - a) if abs(t) < 0.5 else b - (b - a) * (1 - t)
+
+    yl, yh = wavedec2(noise, wave, mode, level)
+    if noise_high is not None:
+        hl, hh = wavedec2(noise_high, wave, mode, level)
+        if preblend_high is not None:
+            hl, hh = wavelet_scaling(hl, hh, *preblend_high)
+        if preblend_low is not None:
+            yl, yh = wavelet_scaling(yl, yh, *preblend_low)
+        yl, yh = bl(yl, hl, yl_blend_high), [bl(a, b, yh_blend_high) for a, b in zip(yh, hh)]
+    yl, yh = wavelet_scaling(yl, yh, yl_scale, yh_scales)
+    if two_step_inverse:
+        out = waverec2(np.zeros_like(yl), yh, wave, mode) + waverec2(yl, [np.zeros_like(b) for b in yh], wave, mode)
+    else:
+        out = waverec2(yl, yh, wave, mode)
+    return out[tuple(slice(0, d) for d in noise.shape)]

@@ -493,3 +493,35 @@ def sonar_dpmpp_sde(model, x, sigmas, cfg: MomentumCfg, *, eta=1.0, s_noise=1.0,
         if trace is not None:
             trace.append((x.clone(), None if st.h is None else st.h.clone()))
     return x
+
+
+# ------------------------------------------------------------------------------------------------ spatial power law, latent ops
+def powerlaw_noise(draw: Tensor, alpha: float = 2.0, use_sign: bool = False, div_max_dims=None, use_div_max_abs: bool = True) -> Tensor:
+    """py/noise_generation.py:775-786 (white / grey / velvet / violet and AdvancedPowerLawNoise)."""
+    noise = draw.clone()
+    modulation = torch.abs(noise) ** alpha
+    noise = (torch.sign(noise) if use_sign else noise).mul_(modulation)
+    if div_max_dims is not None:
+        noise /= torch.amax(torch.abs(noise) if use_div_max_abs else noise, keepdim=True, dim=div_max_dims)
+    return noise
+
+
+def latent_op_advanced(t: Tensor, ops: Sequence[Callable], *, blend_mode: str, blend_strength: float, input_multiplier: float = 1.0,
+                       output_multiplier: float = 1.0, difference_multiplier: float = 1.0) -> Tensor:
+    """py/latent_ops.py:84-106 with every op enabled (the ==1.0 test on output_multiplier is the reference's)."""
+    output = t * input_multiplier if input_multiplier != 1.0 else t
+    for op in ops:
+        output = op(output)
+    diff = (output * output_multiplier if output_multiplier == 1.0 else output) - t
+    if difference_multiplier != 1.0:
+        diff *= difference_multiplier
+    return blend(blend_mode, t, diff, blend_strength)
+
+
+def latent_op_noise(t: Tensor, noise: Tensor, sigma: Optional[Tensor], scale_to_sigma: bool) -> Tensor:
+    """py/latent_ops.py:180-186."""
+    noise = noise.clone()
+    if scale_to_sigma and sigma is not None:
+        noise *= sigma
+    noise += t
+    return noise

@@ -462,6 +462,86 @@ def gen_entry_nodes():
     save("entry_nodes", **cases)
 
 
+# ------------------------------------------------------------------------------------------------ spatial power law + latent ops
+POWERLAW_TYPES = {"white": dict(alpha=0.0, use_sign=True), "grey": dict(alpha=0.0), "velvet": dict(alpha=1.0, use_sign=True, div_max_dims=(-3, -2, -1)),
+                  "violet": dict(alpha=0.5, use_sign=True, div_max_dims=(-3, -2, -1))}
+POWERLAW_ADV = {"a15_spatial": dict(alpha=1.5, div_max_dims=(-2, -1), use_sign=False, use_div_max_abs=True),
+                "a07_all_noabs": dict(alpha=0.7, div_max_dims=(), use_sign=True, use_div_max_abs=False),
+                "a2_batch": dict(alpha=2.0, div_max_dims=0, use_sign=False, use_div_max_abs=True),
+                "a12_channel": dict(alpha=1.2, div_max_dims=1, use_sign=True, use_div_max_abs=True),
+                "a03_height": dict(alpha=0.3, div_max_dims=2, use_sign=False, use_div_max_abs=True),
+                "a25_width": dict(alpha=2.5, div_max_dims=3, use_sign=True, use_div_max_abs=True),
+                "a1_none": dict(alpha=1.0, div_max_dims=None, use_sign=False, use_div_max_abs=True)}
+
+
+def gen_powerlaw():
+    cases = {}
+    shape = (3, 4, 16, 12)
+    torch.manual_seed(33)
+    draw = torch.randn(shape)
+    cases["draw"] = draw
+    for name, kw in POWERLAW_TYPES.items():
+        for normalized in (False, True):
+            out = ref_noise(getattr(NT, name.upper()), shape, 33, normalized)
+            mine = orc.scale_noise(orc.powerlaw_noise(draw, **kw), 1.0, normalized=normalized)
+            must_equal(out, mine, f"powerlaw type {name}")
+            cases[f"{name}_{int(normalized)}"] = out
+    for name, kw in POWERLAW_ADV.items():
+        item = ref.noise.AdvancedPowerLawNoise(1.0, **kw)
+        torch.manual_seed(33)
+        out = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=33, cpu=True, normalized=False)(torch.tensor(14.6), torch.tensor(10.0))
+        must_equal(out, orc.powerlaw_noise(draw, **kw), f"powerlaw adv {name}")
+        cases["adv_" + name] = out
+    save("powerlaw", **cases)
+
+
+LATENT_OP_CASES = {
+    "lerp_half": dict(blend_mode="lerp", blend_strength=0.5, input_multiplier=1.0, output_multiplier=1.0, difference_multiplier=1.0),
+    "inject_scaled": dict(blend_mode="inject", blend_strength=0.8, input_multiplier=0.5, output_multiplier=2.0, difference_multiplier=0.7),
+    "lerp_big": dict(blend_mode="lerp", blend_strength=0.9, input_multiplier=1.5, output_multiplier=1.0, difference_multiplier=1.3),
+    "subtract_b": dict(blend_mode="subtract_b", blend_strength=0.25, input_multiplier=1.0, output_multiplier=0.5, difference_multiplier=1.0),
+}
+
+
+def gen_latent_ops():
+    lo = ref.latent_ops
+    cases = {}
+    torch.manual_seed(44)
+    t = torch.randn(2, 4, 8, 8)
+    cases["latent"] = t
+    op1 = lambda latent: latent * 1.5 + 0.25  # noqa: E731  (plain LATENT_OPERATION callables)
+    op2 = lambda latent: latent.abs() - 0.5  # noqa: E731
+    for name, kw in LATENT_OP_CASES.items():
+        adv = lo.SonarLatentOperationAdvanced(ops=(lo.SonarLatentOperation(op=op1), lo.SonarLatentOperation(op=op2)), start_sigma=10.0,
+                                              end_sigma=1.0, op_alt=lo.SonarLatentOperation(op=op2), **kw)
+        out = adv(t.clone(), sigma=torch.tensor([5.0]))
+        must_equal(out, orc.latent_op_advanced(t, (op1, op2), **kw), f"latent op advanced {name}")
+        cases[f"adv_{name}"] = out
+        cases[f"adv_{name}_disabled"] = adv(t.clone(), sigma=torch.tensor([12.0]))  # outside [1, 10] -> op_alt
+    chain = ref.noise.CustomNoiseChain()
+    chain.add(ref.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    for scale_to_sigma in (False, True):
+        op = lo.SonarLatentOperationNoise(custom_noise=chain, scale_to_sigma=scale_to_sigma, cpu_noise=True, normalize=True)
+        torch.manual_seed(45)
+        out = op(t.clone(), sigma=torch.tensor([3.0]))
+        cases[f"noise_{int(scale_to_sigma)}"] = out
+    # the noise the op drew: same RNG sequence (randint for the seed, then the sampler)
+    torch.manual_seed(45)
+    seed = torch.randint(1, 1 << 31, (), device="cpu").item()
+    raw = chain.make_noise_sampler(t, sigma_min=None, sigma_max=None, normalized=True, seed=seed, cpu=True)(torch.tensor([3.0]), torch.tensor([3.0]))
+    cases["noise_raw"] = raw
+    must_equal(cases["noise_1"], orc.latent_op_noise(t, raw, torch.tensor([3.0]), True), "latent op noise")
+    setseed = lo.SonarLatentOperationSetSeed(op=lo.SonarLatentOperationNoise(custom_noise=chain, cpu_noise=True), seed=77, restore_rng_state=True)
+    torch.manual_seed(1)
+    before = torch.random.get_rng_state()
+    cases["setseed"] = setseed(latent=t.clone(), sigma=torch.tensor([2.0]))
+    assert torch.equal(before, torch.random.get_rng_state())
+    save("latent_ops", **cases)
+
+
+if __name__ == "__main__" and "--only" in sys.argv:
+    globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_scale_noise()
@@ -472,6 +552,8 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_power_noise()
     gen_composition()
     gen_momentum()
+    gen_powerlaw()
+    gen_latent_ops()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

@@ -1,0 +1,166 @@
+"""-m gpu: the §8a rows either side of the generators — spatial power-law noise (white / grey / velvet / violet,
+AdvancedPowerLawNoise), wavelet-filtered noise (WF) and the sigma-gated latent operations (L) — through the
+reference's plugin API with latents on the MI355X.
+
+Goldens: tests/golden/powerlaw.npz, latent_ops.npz (captured from the real reference).  WF has no reference-run
+golden (pytorch_wavelets is not installed anywhere): compared with oracle/dwt_oracle.py (pinned to PyWavelets 1.1.1).
+Tolerances: elementwise rows rtol 2e-5 / atol 5e-6 (powf differs from ATen's pow by <= 2 ulp); WF rtol/atol 3e-5."""
+import importlib
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dwt_oracle as dwo
+from tests.test_oracle_golden import LATENT_OP_CASES, POWERLAW_ADV, POWERLAW_TYPES
+
+pytestmark = pytest.mark.gpu
+SIG = (torch.tensor(14.6), torch.tensor(10.0))
+
+
+@pytest.fixture(scope="module")
+def api(pkg):
+    pkg.hip_lib.load()
+    mods = {m: importlib.import_module(f"comfyui_sonar_amd.py.{m}") for m in ("utils", "noise_generation", "noise", "latent_ops")}
+    mods["registry"] = importlib.import_module("comfyui_sonar_amd.py.nodes.registry")
+    return types.SimpleNamespace(**mods, hl=pkg.hip_lib)
+
+
+def close(a, b, rtol=2e-5, atol=5e-6):
+    torch.testing.assert_close(a.detach().cpu().float(), b.detach().cpu().float(), rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------------ spatial power law
+@pytest.mark.parametrize("name", list(POWERLAW_TYPES))
+@pytest.mark.parametrize("normalized", [False, True])
+def test_powerlaw_registry_types(api, golden, name, normalized):
+    g = golden("powerlaw")
+    x = torch.zeros(tuple(g["draw"].shape), device="cuda")
+    torch.manual_seed(33)
+    ns = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=33, cpu=True, factor=1.0, normalized=normalized)
+    close(ns(*SIG), g[f"{name}_{int(normalized)}"])
+
+
+@pytest.mark.parametrize("name", list(POWERLAW_ADV))
+def test_powerlaw_advanced_item(api, golden, name):
+    g = golden("powerlaw")
+    x = torch.zeros(tuple(g["draw"].shape), device="cuda")
+    torch.manual_seed(33)
+    item = api.noise.AdvancedPowerLawNoise(1.0, **POWERLAW_ADV[name])
+    close(item.make_noise_sampler(x, 0.03, 14.6, seed=33, cpu=True, normalized=False)(*SIG), g["adv_" + name])
+
+
+def test_powerlaw_node_and_device_mode(api):
+    node = api.registry.NODE_CLASS_MAPPINGS["SonarAdvancedPowerLawNoise"]()
+    (chain,) = node.go(factor=1.0, rescale=0.0, alpha=0.5, div_max_dims="non-batch", use_sign=True, use_div_max_abs=True)
+    x = torch.zeros(8, 4, 64, 64, device="cuda")
+    out = chain.make_noise_sampler(x, 0.03, 14.6, seed=5, cpu=False, normalized=False)(*SIG)
+    api.utils.pop_stats(out)
+    peak = out.abs().flatten(1).amax(dim=1)
+    torch.testing.assert_close(peak.cpu(), torch.ones(8), rtol=1e-6, atol=0)  # each latent divided by its own max |.|
+
+
+# ------------------------------------------------------------------------------------------------ latent operations
+OPS = (lambda latent: latent * 1.5 + 0.25, lambda latent: latent.abs() - 0.5)
+
+
+@pytest.mark.parametrize("name", list(LATENT_OP_CASES))
+def test_latent_operation_advanced(api, golden, name):
+    g = golden("latent_ops")
+    lo = api.latent_ops
+    t = g["latent"].cuda()
+    adv = lo.SonarLatentOperationAdvanced(ops=(lo.SonarLatentOperation(op=OPS[0]), lo.SonarLatentOperation(op=OPS[1])), start_sigma=10.0,
+                                          end_sigma=1.0, op_alt=lo.SonarLatentOperation(op=OPS[1]), **LATENT_OP_CASES[name])
+    close(adv(t.clone(), sigma=torch.tensor([5.0])), g[f"adv_{name}"])
+    close(adv(t.clone(), sigma=torch.tensor([12.0])), g[f"adv_{name}_disabled"])
+
+
+@pytest.mark.parametrize("scale_to_sigma", [False, True])
+def test_latent_operation_noise(api, golden, scale_to_sigma):
+    g = golden("latent_ops")
+    lo = api.latent_ops
+    chain = api.noise.CustomNoiseChain()
+    chain.add(api.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    op = lo.SonarLatentOperationNoise(custom_noise=chain, scale_to_sigma=scale_to_sigma, cpu_noise=True, normalize=True)
+    torch.manual_seed(45)
+    close(op(g["latent"].cuda(), sigma=torch.tensor([3.0])), g[f"noise_{int(scale_to_sigma)}"])
+
+
+def test_latent_operation_setseed_and_nodes(api, golden):
+    g = golden("latent_ops")
+    reg = api.registry.NODE_CLASS_MAPPINGS
+    chain = api.noise.CustomNoiseChain()
+    chain.add(api.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    (noise_op,) = reg["SonarLatentOperationNoise"].go(custom_noise=chain, scale_to_sigma=False, cpu_noise=True, normalize=True, lazy_noise_sampler=False)
+    (seeded,) = reg["SonarLatentOperationSetSeed"].go(operation=noise_op, seed=77, restore_rng_state=True)
+    torch.manual_seed(1)
+    before = torch.random.get_rng_state()
+    close(seeded(latent=g["latent"].cuda(), sigma=torch.tensor([2.0])), g["setseed"])
+    assert torch.equal(before, torch.random.get_rng_state())
+    (adv,) = reg["SonarLatentOperationAdvanced"].go(operation=OPS[0], operation_2=OPS[1], start_sigma=10.0, end_sigma=1.0, operation_alt=OPS[1],
+                                                   **LATENT_OP_CASES["inject_scaled"])
+    close(adv(g["latent"].cuda(), sigma=torch.tensor([5.0])), g["adv_inject_scaled"])
+    assert adv(g["latent"].cuda(), sigma=None) is not None  # sigma None = always enabled
+
+
+# ------------------------------------------------------------------------------------------------ wavelet-filtered noise
+WF_CASES = {
+    "defaults": dict(),
+    "scaled": dict(yl_scale=0.5, yh_scales=[1.5, [1.0, 0.5, 2.0], "fill"]),
+    "db4_sym": dict(wave="db4", mode="symmetric", level=2, yl_scale=0.0, yh_scales=1.25),
+    "two_step": dict(wave="sym5", mode="reflect", level=2, yl_scale=1.5, yh_scales=[0.5, 2.0], two_step_inverse=True),
+}
+
+
+def _gauss_chain(api):
+    chain = api.noise.CustomNoiseChain()
+    chain.add(api.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    return chain
+
+
+@pytest.mark.parametrize("name", list(WF_CASES))
+def test_wavelet_filtered_generator(api, name):
+    kw = WF_CASES[name]
+    shape = (2, 4, 40, 24)
+    x = torch.zeros(shape, device="cuda")
+    torch.manual_seed(9)
+    gen = api.noise_generation.WaveletFilteredNoiseGenerator(x, sigma_min=0.03, sigma_max=14.6, seed=9, cpu=True, normalized=False, **kw)
+    out = gen(*SIG)
+    torch.manual_seed(9)
+    base = torch.randn(shape)
+    want = dwo.wavelet_filtered_noise(base.numpy().astype(np.float64), **kw)
+    close(out, torch.from_numpy(want), rtol=3e-5, atol=3e-5)
+
+
+def test_wavelet_filtered_item_with_high_noise(api):
+    """Low bands from one chain, high bands from another (yl_blend_high = 0, yh_blend_high = 1), then scale_noise."""
+    shape = (2, 4, 32, 32)
+    x = torch.zeros(shape, device="cuda")
+    item = api.noise.WaveletFilteredNoise(1.0, noise=_gauss_chain(api), noise_high=_gauss_chain(api), normalize=None, normalize_noise=False,
+                                          yaml_parameters="wave: db2\nlevel: 2\nmode: periodization\nyh_scales: [1.0, 0.5]\npreblend_yl_scale_high: 2.0\n")
+    torch.manual_seed(12)
+    out = item.make_noise_sampler(x, 0.03, 14.6, seed=12, cpu=True, normalized=True)(*SIG)
+    torch.manual_seed(12)
+    low, high = torch.randn(shape), torch.randn(shape)
+    raw = dwo.wavelet_filtered_noise(low.numpy().astype(np.float64), noise_high=high.numpy().astype(np.float64), wave="db2", level=2,
+                                     mode="periodization", yh_scales=[1.0, 0.5], preblend_high=(2.0, 1.0))
+    from oracle import sonar_oracle as orc
+
+    want = orc.scale_noise(torch.from_numpy(raw).float(), 1.0, normalized=True)
+    close(out, want, rtol=5e-5, atol=5e-5)
+
+
+def test_wavelet_filtered_node(api):
+    """The node wires custom_noise as BOTH sources when no high chain is given (py/nodes/noise_filters.py:952-954): the
+    low band comes from the first draw, the high bands from the second."""
+    node = api.registry.NODE_CLASS_MAPPINGS["SonarWaveletFilteredNoise"]()
+    (chain,) = node.go(factor=1.0, rescale=0.0, normalize="disabled", normalize_noise=False, custom_noise=_gauss_chain(api),
+                       yaml_parameters="wave: bior2.2\nlevel: 3\n")
+    x = torch.zeros(4, 4, 64, 64, device="cuda")
+    torch.manual_seed(3)
+    out = chain.make_noise_sampler(x, 0.03, 14.6, seed=3, cpu=True, normalized=False)(*SIG)
+    torch.manual_seed(3)
+    low, high = torch.randn(4, 4, 64, 64), torch.randn(4, 4, 64, 64)
+    want = dwo.wavelet_filtered_noise(low.numpy().astype(np.float64), noise_high=high.numpy().astype(np.float64), wave="bior2.2", level=3)
+    close(out, torch.from_numpy(want), rtol=3e-5, atol=3e-5)

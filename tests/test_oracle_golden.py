@@ -183,3 +183,43 @@ def test_ancestral_step_formula():
     assert abs(up.item() - min(6.0, math.sqrt(36 * (100 - 36) / 100))) < 1e-6
     assert abs(down.item() ** 2 + up.item() ** 2 - 36.0) < 1e-4
     assert orc.ancestral_step(3.0, 2.0, 0.0) == (2.0, 0.0)
+
+
+# ------------------------------------------------------------------------------------------------ spatial power law, latent ops
+POWERLAW_TYPES = {"white": dict(alpha=0.0, use_sign=True), "grey": dict(alpha=0.0),
+                  "velvet": dict(alpha=1.0, use_sign=True, div_max_dims=(-3, -2, -1)),
+                  "violet": dict(alpha=0.5, use_sign=True, div_max_dims=(-3, -2, -1))}
+POWERLAW_ADV = {"a15_spatial": dict(alpha=1.5, div_max_dims=(-2, -1), use_sign=False, use_div_max_abs=True),
+                "a07_all_noabs": dict(alpha=0.7, div_max_dims=(), use_sign=True, use_div_max_abs=False),
+                "a2_batch": dict(alpha=2.0, div_max_dims=0, use_sign=False, use_div_max_abs=True),
+                "a12_channel": dict(alpha=1.2, div_max_dims=1, use_sign=True, use_div_max_abs=True),
+                "a03_height": dict(alpha=0.3, div_max_dims=2, use_sign=False, use_div_max_abs=True),
+                "a25_width": dict(alpha=2.5, div_max_dims=3, use_sign=True, use_div_max_abs=True),
+                "a1_none": dict(alpha=1.0, div_max_dims=None, use_sign=False, use_div_max_abs=True)}
+LATENT_OP_CASES = {
+    "lerp_half": dict(blend_mode="lerp", blend_strength=0.5, input_multiplier=1.0, output_multiplier=1.0, difference_multiplier=1.0),
+    "inject_scaled": dict(blend_mode="inject", blend_strength=0.8, input_multiplier=0.5, output_multiplier=2.0, difference_multiplier=0.7),
+    "lerp_big": dict(blend_mode="lerp", blend_strength=0.9, input_multiplier=1.5, output_multiplier=1.0, difference_multiplier=1.3),
+    "subtract_b": dict(blend_mode="subtract_b", blend_strength=0.25, input_multiplier=1.0, output_multiplier=0.5, difference_multiplier=1.0),
+}
+
+
+def test_powerlaw(golden):
+    g = golden("powerlaw")
+    for name, kw in POWERLAW_TYPES.items():
+        for normalized in (False, True):
+            close(orc.scale_noise(orc.powerlaw_noise(g["draw"], **kw), 1.0, normalized=normalized), g[f"{name}_{int(normalized)}"])
+    for name, kw in POWERLAW_ADV.items():
+        close(orc.powerlaw_noise(g["draw"], **kw), g["adv_" + name])
+
+
+def test_latent_ops(golden):
+    g = golden("latent_ops")
+    t = g["latent"]
+    ops = (lambda latent: latent * 1.5 + 0.25, lambda latent: latent.abs() - 0.5)
+    for name, kw in LATENT_OP_CASES.items():
+        close(orc.latent_op_advanced(t, ops, **kw), g[f"adv_{name}"])
+        close(ops[1](t), g[f"adv_{name}_disabled"])
+    sigma = torch.tensor([3.0])
+    close(orc.latent_op_noise(t, g["noise_raw"], sigma, False), g["noise_0"])
+    close(orc.latent_op_noise(t, g["noise_raw"], sigma, True), g["noise_1"])
