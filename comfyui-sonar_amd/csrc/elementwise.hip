@@ -118,6 +118,11 @@ __global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n
     __shared__ NormDecision sh;
     NormDecision d{0.f, 1.f, 0, 0};
     if (normalized) d = decide_norm<kBlock>(partials, npart, n_total, thr_sd, red, &sh);
+    if (normalized == 2) {  // x *= factor / std (py/noise_generation.py:702): one multiplier, no mean shift
+        factor = factor / d.stdv;
+        d.do_sub = 0;
+        d.do_div = 0;
+    }
     const bool do_mul = factor != 1.0f;
     const int64_t nv = n / V;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -637,6 +642,20 @@ extern "C" int sonar_scale_noise_f32(float* x, int64_t n, float factor, int norm
                            normalized, threshold_std_devs, partials, npart, n_total);
     }
     return check_launch("sonar_scale_noise_f32");
+}
+
+extern "C" int sonar_std_scale_f32(float* x, int64_t n, float mul, const double* partials, int64_t npart, int64_t n_total,
+                                   void* stream) {
+    SONAR_REQUIRE(x && partials && n >= 0 && npart > 0 && n_total > 1, SONAR_ERR_ARG, "sonar_std_scale_f32: bad argument");
+    if (n == 0) return SONAR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (aligned16(x))
+        hipLaunchKernelGGL((scale_noise_kernel<4>), dim3(grid_for(n / 4 + 1, kBlock * 2)), dim3(kBlock), 0, st, x, n, mul, 2, 0.0f,
+                           partials, npart, n_total);
+    else
+        hipLaunchKernelGGL((scale_noise_kernel<1>), dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, st, x, n, mul, 2, 0.0f, partials,
+                           npart, n_total);
+    return check_launch("sonar_std_scale_f32");
 }
 
 extern "C" int sonar_scale_noise_rows_f32(float* x, int64_t rows, int64_t inner, float factor, void* stream) {

@@ -98,6 +98,19 @@ __device__ __forceinline__ void idft<16>(c32 (&v)[16]) {
     }
 }
 
+// forward (sign -) DFT through the inverse codelet: F(v) = swap(I(swap(v))), swap = exchange Re / Im (free in registers)
+template <int N>
+__device__ __forceinline__ void fdft(c32 (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = make_float2(v[i].y, v[i].x);
+    idft<N>(v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = make_float2(v[i].y, v[i].x);
+}
+__device__ __forceinline__ c32 cmulc(c32 a, c32 b) {  // a * conj(b)
+    return make_float2(__builtin_fmaf(a.x, b.x, a.y * b.y), __builtin_fmaf(a.y, b.x, -(a.x * b.y)));
+}
+
 constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4 : n == 16 ? 2 : 1; }
 
 #ifndef SONAR_FFT_THREADS
@@ -170,7 +183,9 @@ __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const fl
     }
 }
 
-template <int H, int W, bool GEN, bool STATS, bool NORM>
+// SRC: 0 = spectrum `z` supplied (replay), 1 = spectrum drawn on device, 2 = `z` is a REAL H x W plane: forward r2c FFT in
+// LDS, x filter, then the same inverse (spectral filter: out = irfft2(rfft2(x) * filter), py/nodes/powernoise.py:356-366)
+template <int H, int W, int SRC, bool STATS, bool NORM>
 __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_kernel(const float* __restrict__ z,
                                                                        const float* __restrict__ filter, float* out,
                                                                        int64_t planes, uint64_t seed, uint64_t stream_id,
@@ -191,7 +206,9 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
     __shared__ double red[2 * NT / 64];
     __shared__ NormDecision shd;
     const int tid = threadIdx.x;
-    float scale = 1.0f / sqrtf((float)H * (float)W);  // norm="ortho"
+    constexpr bool GEN = SRC == 1;
+    // norm="ortho" on the inverse; the spectral filter also carries the forward transform's 1/sqrt(HW)
+    float scale = SRC == 2 ? 1.0f / ((float)H * (float)W) : 1.0f / sqrtf((float)H * (float)W);
     NormDecision dec{0.f, 1.f, 0, 0};
     float inv_std = 1.0f;
     if constexpr (NORM) {
@@ -222,11 +239,108 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
 
     for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
         __syncthreads();  // previous plane's LDS reads are done (and TW is visible)
+        if constexpr (SRC != 2) {
         // ---------------------------------------------------------------- fill: z * filter
         fill_plane<H, W, GEN>(z, filter, plane, plane_offset + plane, seed, stream_id, tid, [&](int ky, int kx, c32 v) {
             (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v;
         });
         __syncthreads();
+        } else {
+        // ---------------------------------------------------------------- forward r2c of a real plane (mirror of the inverse:
+        // the same four-step splits run backwards, so the spectrum lands in natural (ky, kx) order where the inverse reads it)
+        constexpr int Wh = M + 1;
+        const float* const xin = z + plane * (int64_t)H * W;
+        // rows, pass b': spatial row y sits in LDS row r with y = r / CN2 + CN1 * (r % CN2) (what the column passes expect);
+        // complex element m = k1 + RN1 * k2 is (x[2m], x[2m+1]); DFT over k2 -> n2, twiddle
+        for (int item = tid; item < RN1 * H; item += NT) {
+            const int k1 = item % RN1, r = item / RN1;
+            const int y = (r / CN2) + CN1 * (r % CN2);
+            const float* xrow = xin + (int64_t)y * W;
+            c32 u[RN2];
+#pragma unroll
+            for (int k2 = 0; k2 < RN2; ++k2) u[k2] = *reinterpret_cast<const float2*>(xrow + 2 * (k1 + RN1 * k2));
+            fdft<RN2>(u);
+#pragma unroll
+            for (int n2 = 1; n2 < RN2; ++n2) u[n2] = cmulc(u[n2], tw(n2 * k1, M, false));
+#pragma unroll
+            for (int n2 = 0; n2 < RN2; ++n2) A[r * S + RN2 * k1 + n2] = u[n2];
+        }
+        __syncthreads();
+        // rows, pass a': DFT over k1 -> n1: C[k = RN2 n1 + n2], in place
+        for (int item = tid; item < RN2 * H; item += NT) {
+            const int r = item % H, n2 = item / H;
+            c32 v[RN1];
+#pragma unroll
+            for (int k1 = 0; k1 < RN1; ++k1) v[k1] = A[r * S + RN2 * k1 + n2];
+            fdft<RN1>(v);
+#pragma unroll
+            for (int n1 = 0; n1 < RN1; ++n1) A[r * S + RN2 * n1 + n2] = v[n1];
+        }
+        __syncthreads();
+        // r2c split: X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i,
+        // w = e^{-2 pi i / W}; the two real columns X[0], X[M] are packed into column 0 as X[0] + i X[M]
+        for (int item = tid; item < (M / 2 + 1) * H; item += NT) {
+            const int r = item % H, k = item / H;
+            c32* row = A + r * S;
+            if (k == 0) {
+                const c32 c0 = row[0];
+                row[0] = make_float2(c0.x + c0.y, c0.x - c0.y);
+            } else if (k == M / 2) {
+                const c32 c = row[k];
+                row[k] = make_float2(c.x, -c.y);
+            } else {
+                const c32 a = row[k], b = row[M - k];
+                const c32 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+                const c32 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
+                const c32 t = cmulc(o, tw(k, W, H % 64 == 0));
+                row[k] = make_float2(e.x + t.x, e.y + t.y);
+                row[M - k] = make_float2(e.x - t.x, -(e.y - t.y));
+            }
+        }
+        __syncthreads();
+        // columns, pass b': DFT over k2 -> n2 for fixed k1 (rows CN2 k1 + .), twiddle
+        for (int item = tid; item < CN1 * M; item += NT) {
+            const int c = item % M, k1 = item / M;
+            c32 u[CN2];
+#pragma unroll
+            for (int k2 = 0; k2 < CN2; ++k2) u[k2] = A[(CN2 * k1 + k2) * S + c];
+            fdft<CN2>(u);
+#pragma unroll
+            for (int n2 = 1; n2 < CN2; ++n2) u[n2] = cmulc(u[n2], tw(n2 * k1, H, M % 64 == 0));
+#pragma unroll
+            for (int n2 = 0; n2 < CN2; ++n2) A[(CN2 * k1 + n2) * S + c] = u[n2];
+        }
+        __syncthreads();
+        // columns, pass a': DFT over k1 -> n1: Z[ky = CN2 n1 + n2][c], in place
+        for (int item = tid; item < CN2 * M; item += NT) {
+            const int c = item % M, n2 = item / M;
+            c32 v[CN1];
+#pragma unroll
+            for (int k1 = 0; k1 < CN1; ++k1) v[k1] = A[(CN2 * k1 + n2) * S + c];
+            fdft<CN1>(v);
+#pragma unroll
+            for (int n1 = 0; n1 < CN1; ++n1) A[(CN2 * n1 + n2) * S + c] = v[n1];
+        }
+        __syncthreads();
+        // unpack column 0 (P = DFT(X0 + i XM): Z0 = (P[ky] + conj P[-ky]) / 2, ZM = (P[ky] - conj P[-ky]) / 2i), x filter
+        for (int ky = tid; ky < H; ky += NT) {
+            const int kn = (H - ky) & (H - 1);
+            const c32 p = A[ky * S], pn = A[kn * S];
+            const float f0 = filter[ky * Wh], fm = filter[ky * Wh + M];
+            T0[ky] = make_float2(0.5f * (p.x + pn.x) * f0, 0.5f * (p.y - pn.y) * f0);
+            TM[ky] = make_float2(0.5f * (p.y + pn.y) * fm, -0.5f * (p.x - pn.x) * fm);
+        }
+        for (int j = tid; j < H * M; j += NT) {
+            const int ky = j / M, c = j - ky * M;
+            if (c != 0) {
+                const float f = filter[ky * Wh + c];
+                c32 v = A[ky * S + c];
+                v.x *= f; v.y *= f;
+                A[ky * S + c] = v;
+            }
+        }
+        __syncthreads();
+        }
         if constexpr (FAST) {
             // fix-up: Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky] -> column 0 of the plane
             if (tid < H) {
@@ -491,7 +605,7 @@ static int power_grid(int64_t planes) {
 }
 
 // what: 0 = irfft2 (z given or drawn; optional statistics), 1 = normalised generate (stats pass + final pass),
-//       2 = dump the drawn spectrum into `out`
+//       2 = dump the drawn spectrum into `out`, 3 = spectral filter of the real planes `z`
 template <int H, int W>
 static int launch_power(int what, const float* z, const float* filter, float* out, int64_t planes, uint64_t seed,
                         uint64_t stream_id, int64_t plane_offset, double* partials, NormArgs na, hipStream_t st) {
@@ -499,16 +613,18 @@ static int launch_power(int what, const float* z, const float* filter, float* ou
     const dim3 blk(kFftThreads);
 #define SONAR_PW(G, ST, NM, PART) \
     hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(g), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, PART, na)
-    if (what == 2) {
+    if (what == 3) {
+        if (partials) SONAR_PW(2, true, false, partials); else SONAR_PW(2, false, false, partials);
+    } else if (what == 2) {
         hipLaunchKernelGGL((power_spectrum_kernel<H, W>), dim3(std::min<int64_t>(planes, 2048)), blk, 0, st, out, planes, seed, stream_id, plane_offset);
     } else if (what == 1) {
         hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(planes, kNPart)), blk, 0, st, filter, planes, seed, stream_id,
                            plane_offset, partials);
-        SONAR_PW(true, false, true, nullptr);
+        SONAR_PW(1, false, true, nullptr);
     } else if (z == nullptr) {
-        if (partials) SONAR_PW(true, true, false, partials); else SONAR_PW(true, false, false, partials);
+        if (partials) SONAR_PW(1, true, false, partials); else SONAR_PW(1, false, false, partials);
     } else {
-        if (partials) SONAR_PW(false, true, false, partials); else SONAR_PW(false, false, false, partials);
+        if (partials) SONAR_PW(0, true, false, partials); else SONAR_PW(0, false, false, partials);
     }
 #undef SONAR_PW
     return check_launch("sonar_power_*");
@@ -590,6 +706,16 @@ extern "C" int sonar_power_noise_f32(const float* filter, float* out, int64_t pl
     if (planes == 0) return SONAR_OK;
     return power_dispatch(1, nullptr, filter, out, planes, H, W, seed, stream_id, plane_offset, partials,
                           NormArgs{partials, planes * H * W, factor, threshold_std_devs}, (hipStream_t)stream);
+}
+
+extern "C" int sonar_spectral_filter_f32(const float* x, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,
+                                         double* partials, void* stream) {
+    SONAR_REQUIRE(x && filter && out && x != out && planes >= 0 && H > 0 && W > 0, SONAR_ERR_ARG,
+                  "sonar_spectral_filter_f32: bad argument (in-place not supported)");
+    SONAR_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0, SONAR_ERR_ARG,
+                  "sonar_spectral_filter_f32: misaligned buffer");
+    if (planes == 0) return SONAR_OK;
+    return power_dispatch(3, x, filter, out, planes, H, W, 0, 0, 0, partials, NormArgs{nullptr, 0, 1.0f, 0.0f}, (hipStream_t)stream);
 }
 
 extern "C" int sonar_power_spectrum_f32(float* z_out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,

@@ -91,7 +91,8 @@ SIGNATURES = {
     "sonar_power_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _F, _F, _P, _P]),
     "sonar_power_spectrum_f32": (_I, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _P]),
     "sonar_power_irfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _P, _P]),
-    "sonar_rfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P]),
+    "sonar_spectral_filter_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "sonar_std_scale_f32": (_I, [_P, _I64, _F, _P, _I64, _I64, _P]),
     "sonar_channel_mix_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "sonar_dwt_out_len": (_I64, [_I64, _I64, _I]),
     "sonar_dwt2_ws_bytes": (_I64, [_I64, _I64, _I64, _I, _I, _I, _I]),
@@ -554,6 +555,25 @@ def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_o
             "sonar_power_noise_f32",
         )
     return out
+
+
+def spectral_filter(x: torch.Tensor, filt: torch.Tensor, partials: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = irfft2(rfft2(x, 'ortho') * filt, 'ortho') over the last two dims; filt is real [H, W/2+1]."""
+    H, W = int(x.shape[-2]), int(x.shape[-1])
+    planes = x.numel() // (H * W)
+    if filt.numel() != H * (W // 2 + 1):
+        raise SonarHipError("spectral_filter: filter size mismatch")
+    out = torch.empty_like(x)
+    with _Timed("spectral_filter"):
+        _check(load().sonar_spectral_filter_f32(_dev(x, "x"), _dev(filt, "filter"), _dev(out, "out"), planes, H, W,
+                                                _opt(partials, "partials", torch.float64), _stream()), "sonar_spectral_filter_f32")
+    return out
+
+
+def std_scale_(x: torch.Tensor, mul: float, partials: torch.Tensor) -> torch.Tensor:
+    _check(load().sonar_std_scale_f32(_dev(x, "x"), x.numel(), float(mul), _dev(partials, "partials", torch.float64), NPART, x.numel(),
+                                      _stream()), "sonar_std_scale_f32")
+    return x
 
 
 def power_spectrum(shape, device, *, seed: int, stream_id: int, plane_offset: int = 0) -> torch.Tensor:

@@ -182,7 +182,11 @@ class PowerNoiseItem(CustomNoiseItemBase):
         def sampler(sigma, sigma_next):
             z = noise_sampler(sigma, sigma_next)
             partials = hip_lib.new_partials(device)
-            if z is None:
+            if self.time_brownian:
+                # real noise in: rfft2 -> x filter -> irfft2, forward and inverse both LDS-resident (py/nodes/powernoise.py:356-366)
+                pop_stats(z)
+                noise = hip_lib.spectral_filter(z.to(device).contiguous(), filt, partials if identity else None)
+            elif z is None:
                 seed, stream = DeviceRNG.take()
                 offs = current_batch_offset() * planes_per_latent
                 if identity and normalized:
@@ -210,3 +214,22 @@ class PowerNoiseItem(CustomNoiseItemBase):
             def draw(_s, _sn):
                 return None
         return self.make_noise_sampler_internal(x, draw, filter_rfft, normalized=normalized)
+
+
+class PowerFilterNoiseItem(PowerNoiseItem):
+    """py/nodes/powernoise.py:462-504: a power filter applied to ANOTHER noise chain (node passes time_brownian=True)."""
+
+    def __init__(self, factor, *, noise, normalize_noise, normalize_result, **kwargs):
+        super().__init__(factor, noise=noise.clone(), normalize_noise=normalize_noise, normalize_result=normalize_result, **kwargs)
+
+    def clone_key(self, k):
+        if k == "noise":
+            return self.noise.clone()
+        return super().clone_key(k)
+
+    def make_noise_sampler(self, x: Tensor, sigma_min, sigma_max, *, seed, cpu: bool = True, normalized=True):
+        normalize_noise = self.get_normalize("normalize_noise", False)
+        normalize_result = self.get_normalize("normalize_result", normalized)
+        filter_rfft = self.make_filter(x.shape)
+        noise_sampler = self.noise.make_noise_sampler(x, sigma_min, sigma_max, seed, cpu, normalized=normalize_noise)
+        return self.make_noise_sampler_internal(x, noise_sampler, filter_rfft, normalized=normalize_result)

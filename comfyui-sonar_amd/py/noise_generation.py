@@ -532,10 +532,7 @@ LaplacianNoiseGenerator = _off_path("laplacian")
 DistroNoiseGenerator = _off_path("distro")
 VoronoiNoiseGenerator = _off_path("voronoi")
 CollatzNoiseGenerator = _off_path("collatz")
-PinkOldNoiseGenerator = _off_path("pink_old")
 PowerOldNoiseGenerator = _off_path("power_old")
-GreenTestNoiseGenerator = _off_path("green_test")
-OneFNoiseGenerator = _off_path("onef")
 WaveletNoiseGenerator = _off_path("wavelet")
 ScatternetFilteredNoiseGenerator = _off_path("scatternet_filtered")
 
@@ -613,3 +610,91 @@ class WaveletFilteredNoiseGenerator(FramesToChannelsNoiseGenerator):
         if tuple(result.shape) != tuple(shape):
             result = result[tuple(slice(0, d) for d in shape)].contiguous()
         return self.fix_output_frames(result)
+
+
+class PinkOldNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:707-718 (a scalar gain; the reference itself calls it wrong)."""
+
+    name = "pink_old"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"alpha": 2.0, "k": 1.0, "freq": 1.0}
+
+    def generate(self, *_args):
+        noise = self.rand_like()
+        return hip_lib.mul_scalar(noise, self.k / self.freq**self.alpha, out=noise)
+
+
+def _half_gain(gain: torch.Tensor) -> torch.Tensor:
+    """Re(ifft2(fft2(x) * G)) for real x equals irfft2(rfft2(x) * Gs) with Gs(k) = (G(k) + G(-k)) / 2 (the odd part of G
+    only feeds the discarded imaginary output); returns the [H, W/2+1] half of Gs."""
+    mirrored = torch.roll(torch.flip(gain, dims=(-2, -1)), shifts=(1, 1), dims=(-2, -1))
+    return ((gain + mirrored) * 0.5)[..., : gain.shape[-1] // 2 + 1].contiguous()
+
+
+class _SpectralGainNoiseGenerator(FramesToChannelsNoiseGenerator):
+    """Shared by OneF / GreenTest: white noise -> per-plane LDS-resident rfft2 x gain -> irfft2 (one read, one write)."""
+
+    MIN_DIMS = 4
+    MAX_DIMS = 5
+
+    def spectral_gain(self) -> torch.Tensor:  # full [H, W] real gain, host (setup arithmetic as the reference writes it)
+        raise NotImplementedError
+
+    def filtered(self, partials=None):
+        noise = self.rand_like()
+        utils.pop_stats(noise)
+        if not hip_lib.power_supported(self.height, self.width):
+            raise hip_lib.SonarHipError(f"{self.name}: plane {self.height}x{self.width} is not LDS-resident (powers of two, 16..256)")
+        gain = _half_gain(self.spectral_gain().to(torch.float32)).to(self.device)
+        return hip_lib.spectral_filter(noise.contiguous(), gain, partials)
+
+
+class GreenTestNoiseGenerator(_SpectralGainNoiseGenerator):
+    """py/noise_generation.py:680-704: ifft2(fft2(x) / sqrt(sqrt(fy^p + fx^q))) * scale / std.  The reference takes the std of
+    the COMPLEX ifft2 output; its imaginary part is rounding noise for the (even) default gain, so the real std is used."""
+
+    name = "green_test"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"scale_fac": 1.0, "x_pow": 2, "y_pow": 2, "power_base": 1}
+
+    def spectral_gain(self):
+        fy = torch.fft.fftfreq(self.height)[:, None] ** self.y_pow
+        fx = torch.fft.fftfreq(self.width) ** self.x_pow
+        power = torch.sqrt(fy + fx)
+        power[0, 0] = self.power_base
+        return 1.0 / torch.sqrt(power)
+
+    def generate(self, *_args):
+        partials = hip_lib.new_partials(self.device)
+        noise = self.filtered(partials)
+        hip_lib.std_scale_(noise, self.scale_fac / (self.width * self.height), partials)
+        return self.fix_output_frames(noise)
+
+
+class OneFNoiseGenerator(_SpectralGainNoiseGenerator):
+    """py/noise_generation.py:720-759.  The reference transforms over ALL dims (fftn / ifftn); its gain depends on (h, w)
+    only, so the batch / channel transforms cancel exactly and the result is the per-plane 2-D filter computed here."""
+
+    name = "onef"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"alpha": 2.0, "k": 1.0, "hfac": 1.0, "wfac": 1.0, "base_power": 1.0, "use_sqrt": True}
+
+    def spectral_gain(self):
+        fx, fy = torch.meshgrid(torch.fft.fftfreq(self.height, self.hfac), torch.fft.fftfreq(self.width, self.wfac), indexing="ij")
+        power = (fx**2 + fy**2) ** (-self.alpha / 2.0)
+        if self.k != 0:
+            power = self.k / power
+        power[0, 0] = self.base_power
+        if bool((power < 0).any()):
+            raise hip_lib.SonarHipError("onef: negative spectral power (complex gain) is not supported on the HIP path")
+        return 1.0 / (torch.sqrt(power) if self.use_sqrt else power)
+
+    def generate(self, *_args):
+        partials = hip_lib.new_partials(self.device)
+        return self.fix_output_frames(attach_stats(self.filtered(partials), partials))

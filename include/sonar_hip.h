@@ -208,10 +208,15 @@ int sonar_power_noise_f32(const float* filter, float* out, int64_t planes, int64
  * (tests / replaying a device draw) */
 int sonar_power_spectrum_f32(float* z_out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,
                              int64_t plane_offset, void* stream);
-/* forward: spec[planes][H][W/2+1] = rfft2(x, norm="ortho") * filter (filter nullable)
- * (PowerFilterNoiseItem / time_brownian path, py/nodes/powernoise.py:368-370) */
-int sonar_rfft2_f32(const float* x, const float* filter, float* spec, int64_t planes, int64_t H, int64_t W,
-                    void* stream);
+/* spectral filter of real planes: out = irfft2(rfft2(x, norm="ortho") * filter, s=(H,W), norm="ortho") with
+ * filter[H][W/2+1] real; forward and inverse FFT both LDS-resident, x read once, out written once (x != out).
+ * PowerFilterNoiseItem / time_brownian path (py/nodes/powernoise.py:356-366,471-522) and, with a symmetrised
+ * filter, Re(ifft2(fft2(x) * F)) of OneF / GreenTest (py/noise_generation.py:680-759).  partials: optional (sum, sumsq). */
+int sonar_spectral_filter_f32(const float* x, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,
+                              double* partials, void* stream);
+/* x *= mul / std, std = unbiased standard deviation from the (sum, sumsq) partials of n_total elements
+ * (GreenTestNoiseGenerator, py/noise_generation.py:702: noise *= scale / noise.std()); no host sync */
+int sonar_std_scale_f32(float* x, int64_t n, float mul, const double* partials, int64_t npart, int64_t n_total, void* stream);
 /* py/nodes/powernoise.py:96-101 ChannelMixer.apply: out[b][i] = sum_j mixer[i][j] * in[b][j] over planes of hw */
 int sonar_channel_mix_f32(const float* in, const float* mixer, float* out, int64_t B, int64_t C, int64_t hw,
                           double* partials /*nullable*/, void* stream);

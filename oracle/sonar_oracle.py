@@ -525,3 +525,32 @@ def latent_op_noise(t: Tensor, noise: Tensor, sigma: Optional[Tensor], scale_to_
         noise *= sigma
     noise += t
     return noise
+
+
+# ------------------------------------------------------------------------------------------------ spectral-gain generators (F1, F2)
+def onef_noise(draw: Tensor, alpha: float = 2.0, k: float = 1.0, hfac: float = 1.0, wfac: float = 1.0, base_power: float = 1.0,
+               use_sqrt: bool = True) -> Tensor:
+    """py/noise_generation.py:735-759 (4-D input): fftn over ALL dims / sqrt(power[h, w]) -> ifftn -> real."""
+    batch, _c, height, width = draw.shape
+    fx, fy = torch.meshgrid(torch.fft.fftfreq(height, hfac), torch.fft.fftfreq(width, wfac), indexing="ij")
+    power = (fx**2 + fy**2) ** (-alpha / 2.0)
+    if k != 0:
+        power = k / power
+    power[0, 0] = base_power
+    power = power.unsqueeze(0).expand(batch, 1, height, width)
+    noise_fft = torch.fft.fftn(draw)
+    noise_fft /= torch.sqrt(power.to(noise_fft.dtype)) if use_sqrt else power.to(noise_fft.dtype)
+    return torch.fft.ifftn(noise_fft).real
+
+
+def green_test_noise(draw: Tensor, scale_fac: float = 1.0, x_pow=2, y_pow=2, power_base=1) -> Tensor:
+    """py/noise_generation.py:693-704."""
+    height, width = draw.shape[-2:]
+    scale = scale_fac / (width * height)
+    fy = torch.fft.fftfreq(height)[:, None] ** y_pow
+    fx = torch.fft.fftfreq(width) ** x_pow
+    power = torch.sqrt(fy + fx)
+    power[0, 0] = power_base
+    noise = torch.fft.ifft2(torch.fft.fft2(draw) / torch.sqrt(power))
+    noise *= scale / noise.std()
+    return torch.real(noise)

@@ -539,6 +539,55 @@ def gen_latent_ops():
     save("latent_ops", **cases)
 
 
+# ------------------------------------------------------------------------------------------------ spectral-gain generators
+SPECTRAL_TYPES = ("onef_pinkish", "onef_greenish", "onef_pinkishgreenish", "onef_pinkish_mix", "onef_greenish_mix", "green_test",
+                  "rainbow_mild", "rainbow_intense", "pink_old")
+ONEF_ADV = {"sqrt": dict(alpha=0.25, k=2.0, hfac=2.0, wfac=0.5, use_sqrt=True), "nosqrt": dict(alpha=1.0, k=0.5, hfac=1.0, wfac=1.0, use_sqrt=False),
+            "k0": dict(alpha=-1.0, k=0.0, hfac=1.0, wfac=1.0, use_sqrt=True)}
+
+
+def gen_spectral():
+    cases = {}
+    shape = (2, 4, 32, 32)
+    torch.manual_seed(51)
+    d1, d2 = torch.randn(shape), torch.randn(shape)
+    cases["draw1"], cases["draw2"] = d1, d2
+    for name in SPECTRAL_TYPES:
+        for normalized in (False, True):
+            cases[f"{name}_{int(normalized)}"] = ref_noise(getattr(NT, name.upper()), shape, 51, normalized)
+    must_equal(cases["onef_pinkish_0"], orc.onef_noise(d1, alpha=-0.5), "onef_pinkish")
+    must_equal(cases["onef_greenish_1"], orc.scale_noise(orc.onef_noise(d1, alpha=0.5), 1.0, normalized=True), "onef_greenish")
+    sn = lambda t: orc.scale_noise(t, 1.0, normalized=True)  # noqa: E731  (sub-generators of a mix normalise themselves)
+    must_equal(cases["onef_pinkish_mix_0"], (sn(orc.onef_noise(d1, alpha=-0.5)).mul_(-1.0) + sn(orc.onef_noise(d2, alpha=-0.5))).mul_(0.5), "onef_pinkish_mix")
+    must_equal(cases["green_test_0"], orc.green_test_noise(d1), "green_test")
+    must_equal(cases["rainbow_mild_0"], (sn(orc.green_test_noise(d1)).mul_(0.55) + sn(orc.green_test_noise(d2)).mul_(0.7)).mul_(1.15), "rainbow_mild")
+    for name, kw in ONEF_ADV.items():
+        item = ref.noise.Advanced1fNoise(1.0, **kw)
+        torch.manual_seed(51)
+        out = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=51, cpu=True, normalized=False)(torch.tensor(14.6), torch.tensor(10.0))
+        must_equal(out, orc.onef_noise(d1, **kw), f"onef adv {name}")
+        cases["adv_" + name] = out
+    # PowerFilterNoiseItem: a power filter over a gaussian chain (time_brownian=True is what the node passes)
+    pn = ref.powernoise
+    chain = ref.noise.CustomNoiseChain()
+    chain.add(ref.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    for tag, fkw, ikw in (("pf_a", dict(alpha=1.0, max_freq=0.5), dict(mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1")),
+                          ("pf_b", dict(alpha=-0.5, min_freq=0.1, max_freq=0.7071, rotate=20.0, stretch=1.5), dict(mix=0.7, common_mode=0.25, channel_correlation="1,0.5,0.2,1,0.3,0.1"))):
+        filt = pn.PowerFilter(**fkw)
+        item = pn.PowerFilterNoiseItem(1.0, noise=chain, normalize_noise=None, normalize_result=None, time_brownian=True, power_filter=filt,
+                                       filter_norm_factor=1.0, **ikw)
+        for normalized in (False, True):
+            torch.manual_seed(52)
+            out = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=52, cpu=True, normalized=normalized)(torch.tensor(14.6), torch.tensor(10.0))
+            cases[f"{tag}_{int(normalized)}"] = out
+        cases[f"{tag}_filter"] = item.make_filter(shape)
+    torch.manual_seed(52)
+    cases["pf_draw"] = torch.randn(shape)
+    filt_a = cases["pf_a_filter"]
+    must_equal(cases["pf_a_0"], orc.spectral_filter(cases["pf_draw"], filt_a), "power filter noise item")
+    save("spectral", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -554,6 +603,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_momentum()
     gen_powerlaw()
     gen_latent_ops()
+    gen_spectral()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

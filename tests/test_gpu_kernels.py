@@ -342,6 +342,40 @@ def test_power_irfft2_all_supported_shapes(hl, hw):
     close(got, want, rtol=0, atol=FFT_ATOL)
 
 
+@pytest.mark.parametrize("hw", [(16, 16), (32, 32), (64, 64), (128, 128), (64, 128), (128, 64), (32, 64), (64, 32),
+                                (256, 128), (128, 256), (256, 64), (64, 256)])
+def test_spectral_filter_all_supported_shapes(hl, hw):
+    """Forward r2c + filter + inverse c2r, all in LDS, against torch.fft on the host (oracle.spectral_filter)."""
+    torch.manual_seed(17)
+    h, w = hw
+    x = torch.randn(3, 2, h, w)
+    filt = torch.rand(h, w // 2 + 1) + 0.5
+    part = hl.new_partials("cuda")
+    got = hl.spectral_filter(dev(x), dev(filt), part)
+    want = orc.spectral_filter(x, filt)
+    close(got, want, rtol=0, atol=FFT_ATOL)
+    tot = hl.stats_finalize(part, got.numel()).cpu()
+    assert abs(tot[0].item() - got.double().sum().item()) < 1e-6 * got.numel()
+    # unit filter: the transform pair is the identity
+    close(hl.spectral_filter(dev(x), dev(torch.ones(h, w // 2 + 1))), x, rtol=0, atol=FFT_ATOL)
+
+
+def test_spectral_filter_full_batch_linearity_and_std_scale(hl):
+    """BASELINE size (512 x 4 x 128 x 128): linearity F(a x + b y) = a F(x) + b F(y), and x *= mul / std."""
+    torch.manual_seed(2)
+    x = torch.randn(512, 4, 128, 128, device="cuda")
+    y = torch.randn(512, 4, 128, 128, device="cuda")
+    filt = (torch.rand(128, 65) + 0.25).cuda()
+    fx, fy = hl.spectral_filter(x, filt), hl.spectral_filter(y, filt)
+    part = hl.new_partials("cuda")
+    fz = hl.spectral_filter(0.5 * x - 2.0 * y, filt, part)
+    close(fz, 0.5 * fx - 2.0 * fy, rtol=0, atol=4 * FFT_ATOL)
+    sd = fz.double().std().item()
+    hl.std_scale_(fz, 3.0, part)
+    assert abs(fz.double().std().item() - 3.0) < 1e-5
+    assert sd > 0
+
+
 def test_power_generate_equals_replay_of_device_draws(hl):
     shape = (5, 4, 128, 128)
     h, w = shape[-2:]

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle import dwt_oracle as dwo
-from tests.test_oracle_golden import LATENT_OP_CASES, POWERLAW_ADV, POWERLAW_TYPES
+from tests.test_oracle_golden import LATENT_OP_CASES, ONEF_ADV, POWERLAW_ADV, POWERLAW_TYPES, SPECTRAL_TYPES
 
 pytestmark = pytest.mark.gpu
 SIG = (torch.tensor(14.6), torch.tensor(10.0))
@@ -24,6 +24,7 @@ def api(pkg):
     pkg.hip_lib.load()
     mods = {m: importlib.import_module(f"comfyui_sonar_amd.py.{m}") for m in ("utils", "noise_generation", "noise", "latent_ops")}
     mods["registry"] = importlib.import_module("comfyui_sonar_amd.py.nodes.registry")
+    mods["powernoise"] = importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise")
     return types.SimpleNamespace(**mods, hl=pkg.hip_lib)
 
 
@@ -164,3 +165,65 @@ def test_wavelet_filtered_node(api):
     low, high = torch.randn(4, 4, 64, 64), torch.randn(4, 4, 64, 64)
     want = dwo.wavelet_filtered_noise(low.numpy().astype(np.float64), noise_high=high.numpy().astype(np.float64), wave="bior2.2", level=3)
     close(out, torch.from_numpy(want), rtol=3e-5, atol=3e-5)
+
+
+# ------------------------------------------------------------------------------------------------ spectral-gain rows (F1, F2, PowerFilterNoiseItem)
+def near(a, b, rel=2e-5):
+    """FFT rows: absolute tolerance relative to the reference output's peak (different FFT factorisation, fp32)."""
+    b = b.detach().cpu().float()
+    torch.testing.assert_close(a.detach().cpu().float(), b, rtol=0, atol=rel * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("name", list(SPECTRAL_TYPES))
+@pytest.mark.parametrize("normalized", [False, True])
+def test_spectral_registry_types(api, golden, name, normalized):
+    g = golden("spectral")
+    x = torch.zeros(tuple(g["draw1"].shape), device="cuda")
+    torch.manual_seed(51)
+    ns = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=51, cpu=True, factor=1.0, normalized=normalized)
+    near(ns(*SIG), g[f"{name}_{int(normalized)}"])
+
+
+@pytest.mark.parametrize("name", list(ONEF_ADV))
+def test_advanced_1f_item_and_node(api, golden, name):
+    g = golden("spectral")
+    kw = ONEF_ADV[name]
+    x = torch.zeros(tuple(g["draw1"].shape), device="cuda")
+    node = api.registry.NODE_CLASS_MAPPINGS["SonarAdvanced1fNoise"]()
+    (chain,) = node.go(factor=1.0, rescale=0.0, alpha=kw["alpha"], k=kw["k"], vertical_factor=kw["hfac"], horizontal_factor=kw["wfac"],
+                       use_sqrt=kw["use_sqrt"])
+    torch.manual_seed(51)
+    near(chain.make_noise_sampler(x, 0.03, 14.6, seed=51, cpu=True, normalized=False)(*SIG), g["adv_" + name])
+
+
+PF_CASES = {"pf_a": (dict(alpha=1.0, max_freq=0.5), dict(mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1")),
+            "pf_b": (dict(alpha=-0.5, min_freq=0.1, max_freq=0.7071, rotate=20.0, stretch=1.5),
+                     dict(mix=0.7, common_mode=0.25, channel_correlation="1,0.5,0.2,1,0.3,0.1"))}
+
+
+@pytest.mark.parametrize("tag", list(PF_CASES))
+@pytest.mark.parametrize("normalized", [False, True])
+def test_power_filter_noise_item(api, golden, tag, normalized):
+    g = golden("spectral")
+    fkw, ikw = PF_CASES[tag]
+    x = torch.zeros(tuple(g["pf_draw"].shape), device="cuda")
+    item = api.powernoise.PowerFilterNoiseItem(1.0, noise=_gauss_chain(api), normalize_noise=None, normalize_result=None, time_brownian=True,
+                                               power_filter=api.powernoise.PowerFilter(**fkw), filter_norm_factor=1.0, **ikw)
+    torch.manual_seed(52)
+    near(item.make_noise_sampler(x, 0.03, 14.6, seed=52, cpu=True, normalized=normalized)(*SIG), g[f"{tag}_{int(normalized)}"], rel=4e-5)
+
+
+def test_power_filter_noise_node_device_mode(api):
+    """Node wiring + generate mode at SDXL size: the filtered chain keeps unit variance after normalisation."""
+    reg = api.registry.NODE_CLASS_MAPPINGS
+    (filt,) = reg["SonarPowerFilter"].go(min_freq=0.0, max_freq=0.7071, stretch=1.0, rotate=0.0, pnorm=2.0, alpha=1.0, blur=0.0, scale=1.0)
+    node = reg["SonarPowerFilterNoise"]()
+    (chain,) = node.go(factor=1.0, rescale=0.0, sonar_custom_noise=_gauss_chain(api), sonar_power_filter=filt, filter_norm_factor=1.0,
+                       normalize_noise="default", normalize_result="default", mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1")
+    x = torch.zeros(16, 4, 128, 128, device="cuda")
+    out = chain.make_noise_sampler(x, 0.03, 14.6, seed=1, cpu=False, normalized=True)(*SIG)
+    api.utils.pop_stats(out)
+    assert abs(out.double().std().item() - 1.0) < 5e-3 and abs(out.double().mean().item()) < 5e-3
+    # pink: low radial frequencies carry more energy than high ones
+    spec = torch.fft.rfft2(out).abs().square().mean(dim=(0, 1))
+    assert spec[1:4, 1:4].mean() > 4 * spec[40:60, 40:60].mean()

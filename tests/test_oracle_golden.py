@@ -223,3 +223,45 @@ def test_latent_ops(golden):
     sigma = torch.tensor([3.0])
     close(orc.latent_op_noise(t, g["noise_raw"], sigma, False), g["noise_0"])
     close(orc.latent_op_noise(t, g["noise_raw"], sigma, True), g["noise_1"])
+
+
+SPECTRAL_TYPES = ("onef_pinkish", "onef_greenish", "onef_pinkishgreenish", "onef_pinkish_mix", "onef_greenish_mix", "green_test",
+                  "rainbow_mild", "rainbow_intense", "pink_old")
+ONEF_ADV = {"sqrt": dict(alpha=0.25, k=2.0, hfac=2.0, wfac=0.5, use_sqrt=True), "nosqrt": dict(alpha=1.0, k=0.5, hfac=1.0, wfac=1.0, use_sqrt=False),
+            "k0": dict(alpha=-1.0, k=0.0, hfac=1.0, wfac=1.0, use_sqrt=True)}
+
+
+def test_spectral_gain_generators(golden):
+    """FFT-based rows: pocketfft on another host CPU may round differently -> relative-to-peak tolerance 2e-6."""
+    g = golden("spectral")
+    d1, d2 = g["draw1"], g["draw2"]
+
+    def near(a, b):
+        close(a, b, rtol=0, atol=4e-6 * float(b.abs().max()))
+
+    sn = lambda t: orc.scale_noise(t, 1.0, normalized=True)  # noqa: E731
+    near(orc.onef_noise(d1, alpha=-0.5), g["onef_pinkish_0"])
+    near(sn(orc.onef_noise(d1, alpha=0.5)), g["onef_greenish_1"])
+    near((sn(orc.onef_noise(d1, alpha=0.5)) + sn(orc.onef_noise(d2, alpha=-0.5))).mul_(0.5), g["onef_pinkishgreenish_0"])
+    near((sn(orc.onef_noise(d1, alpha=0.5)).mul_(-1.0) + sn(orc.onef_noise(d2, alpha=0.5))).mul_(0.5), g["onef_greenish_mix_0"])
+    near(orc.green_test_noise(d1), g["green_test_0"])
+    near(sn(orc.green_test_noise(d1)), g["green_test_1"])
+    near((sn(orc.green_test_noise(d1)).mul_(0.75) + sn(orc.green_test_noise(d2)).mul_(0.5)).mul_(1.15), g["rainbow_intense_0"])
+    close(g["pink_old_0"], d1)
+    for name, kw in ONEF_ADV.items():
+        near(orc.onef_noise(d1, **kw), g["adv_" + name])
+    near(orc.spectral_filter(g["pf_draw"], g["pf_a_filter"]), g["pf_a_0"])
+    near(sn(orc.spectral_filter(g["pf_draw"], g["pf_a_filter"])), g["pf_a_1"])
+
+
+def test_onef_is_a_per_plane_filter():
+    """The identity the HIP path relies on: fftn over all dims with an (h, w)-only gain == per-plane rfft2 filter."""
+    torch.manual_seed(8)
+    x = torch.randn(3, 4, 16, 32)
+    want = orc.onef_noise(x, alpha=0.5, k=1.5)
+    fx, fy = torch.meshgrid(torch.fft.fftfreq(16), torch.fft.fftfreq(32), indexing="ij")
+    power = 1.5 / (fx**2 + fy**2) ** (-0.25)
+    power[0, 0] = 1.0
+    gain = (1.0 / torch.sqrt(power))[:, :17]
+    got = torch.fft.irfft2(torch.fft.rfft2(x) * gain, s=(16, 32))
+    close(got, want, rtol=0, atol=2e-5)
