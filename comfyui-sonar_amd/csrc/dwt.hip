@@ -6,50 +6,10 @@
 //              x[o]   = sum_{2i + j == o + F/2 - 1 (mod 2n)} ...              (periodization, length 2n)
 // Row pass and column pass are separate launches through a caller-provided intermediate; both are
 // coalesced along W.  Taps travel as kernel arguments (wave-uniform index -> scalar loads).
-#include "common.h"
+#include "dwt_common.h"
+#include "dwt_tile.h"
 
 namespace sonar {
-
-constexpr int kMaxTaps = 64;
-enum DwtMode { kZero = 0, kSymmetric = 1, kReflect = 2, kPeriodization = 3, kPeriodic = 4, kConstant = 5 };
-
-template <typename T>
-struct Taps {
-    T lo[kMaxTaps];
-    T hi[kMaxTaps];
-    int len;
-};
-
-__host__ __device__ inline int64_t dwt_len(int64_t n, int64_t flen, int mode) {
-    return mode == kPeriodization ? (n + 1) / 2 : (n + flen - 1) / 2;
-}
-
-// extended-signal index -> source index (or -1 for an implicit zero)
-__device__ __forceinline__ int ext_index(int idx, int n, int mode) {
-    if (idx >= 0 && idx < n) return idx;
-    switch (mode) {
-        case kZero: return -1;
-        case kConstant: return idx < 0 ? 0 : n - 1;
-        case kPeriodic: {
-            int r = idx % n;
-            return r < 0 ? r + n : r;
-        }
-        case kSymmetric: {
-            const int period = 2 * n;
-            int p = idx % period;
-            if (p < 0) p += period;
-            return p < n ? p : period - 1 - p;
-        }
-        case kReflect: {
-            if (n == 1) return 0;
-            const int period = 2 * n - 2;
-            int p = idx % period;
-            if (p < 0) p += period;
-            return p < n ? p : period - p;
-        }
-        default: return -1;
-    }
-}
 
 // ---- analysis along W: x[rows][W] -> tmp[rows][2][w]
 template <typename T>
@@ -123,33 +83,6 @@ __global__ void __launch_bounds__(kBlock) dwt_cols_kernel(const T* __restrict__ 
     }
 }
 
-// one synthesis output from two coefficient sequences a (stride sa) and d (stride sd)
-template <typename T>
-__device__ __forceinline__ T synth(const T* __restrict__ a, int64_t sa, const T* __restrict__ d, int64_t sd, int n, int o,
-                                   const Taps<T>& tp, int mode) {
-    const int F = tp.len;
-    T acc = T(0);
-    if (mode == kPeriodization) {
-        const int N = 2 * n;
-        for (int i = 0; i < n; ++i) {
-            int j = (o + F / 2 - 1 - 2 * i) % N;
-            if (j < 0) j += N;
-            for (; j < F; j += N) acc += a[(int64_t)i * sa] * tp.lo[j] + d[(int64_t)i * sd] * tp.hi[j];
-        }
-    } else {
-        // 2i + j = o + F - 2 with 0 <= j < F  ->  i in [ceil((o - 1) / 2), floor((o + F - 2) / 2)]
-        const int t = o + F - 2;
-        int i0 = o > 0 ? (o >> 1) : 0;   // ceil((o - 1) / 2) for o >= 0
-        int i1 = t >> 1;
-        if (i1 > n - 1) i1 = n - 1;
-        for (int i = i0; i <= i1; ++i) {
-            const int j = t - 2 * i;
-            acc += a[(int64_t)i * sa] * tp.lo[j] + d[(int64_t)i * sd] * tp.hi[j];
-        }
-    }
-    return acc;
-}
-
 // ---- synthesis along H: (ll, cH) -> lo_w ; (cV, cD) -> hi_w ; tmp[planes][2][Hr][w]
 template <typename T>
 __global__ void __launch_bounds__(kBlock) idwt_cols_kernel(const T* __restrict__ ll, int ll_h, int ll_w,
@@ -185,25 +118,12 @@ __global__ void __launch_bounds__(kBlock) idwt_rows_kernel(const T* __restrict__
     }
 }
 
-// ---- WaveletCFG band arithmetic
-template <typename T>
-struct BandScales {
-    T cond[4], uncond[4], diff[4], fin[4];
-};
-
 template <typename T>
 __global__ void __launch_bounds__(kBlock) wcfg_band_kernel(const T* cond, const T* uncond, T* out /* may alias cond / uncond */, int64_t n, int64_t group_size, int groups,
                                                             BandScales<T> sc, int blend_mode, T strength) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const int g = groups > 1 ? (int)((i / group_size) % groups) : 0;
-        T c = cond[i], u = uncond[i];
-        if (sc.cond[g] != T(1)) c = c * sc.cond[g];
-        if (sc.uncond[g] != T(1)) u = u * sc.uncond[g];
-        T d = c - u;
-        if (sc.diff[g] != T(1)) d = d * sc.diff[g];
-        T r = blend<T>(blend_mode, u, d, strength);
-        if (sc.fin[g] != T(1)) r = r * sc.fin[g];
-        out[i] = r;
+        out[i] = band_combine<T>(cond[i], uncond[i], sc, g, blend_mode, strength);
     }
 }
 
@@ -222,19 +142,6 @@ __global__ void __launch_bounds__(kBlock) wcfg_output_kernel(const float* __rest
 }
 
 template <typename T>
-static bool make_taps(Taps<T>& tp, const double* lo, const double* hi, int flen) {
-    if (!lo || !hi || flen < 1 || flen > kMaxTaps) return false;
-    tp.len = flen;
-    for (int j = 0; j < kMaxTaps; ++j) {
-        tp.lo[j] = j < flen ? (T)lo[j] : T(0);
-        tp.hi[j] = j < flen ? (T)hi[j] : T(0);
-    }
-    return true;
-}
-
-static bool dims_ok(int64_t a, int64_t b) { return a > 0 && b > 0 && a < (1 << 24) && b < (1 << 24); }
-
-template <typename T>
 static int dwt2_fwd(const T* x, T* ll, T* hi, int64_t planes, int64_t H, int64_t W, const double* dec_lo, const double* dec_hi,
                     int flen, int mode, void* ws, hipStream_t st, const char* what) {
     SONAR_REQUIRE(x && ll && hi && ws && planes >= 0 && mode >= 0 && mode <= 5, SONAR_ERR_ARG, "%s: bad argument", what);
@@ -243,6 +150,7 @@ static int dwt2_fwd(const T* x, T* ll, T* hi, int64_t planes, int64_t H, int64_t
     SONAR_REQUIRE(make_taps(tp, dec_lo, dec_hi, flen), SONAR_ERR_ARG, "%s: 1..%d filter taps required", what, kMaxTaps);
     if (planes == 0) return SONAR_OK;
     const int h = (int)dwt_len(H, flen, mode), w = (int)dwt_len(W, flen, mode);
+    if (dwt2_fwd_tiled<T>(x, ll, hi, planes, (int)H, (int)W, h, w, tp, mode, st)) return check_launch(what);  // LDS-staged, one launch
     T* tmp = (T*)ws;
     hipLaunchKernelGGL((dwt_rows_kernel<T>), dim3(grid_for(planes * H * w, kBlock)), dim3(kBlock), 0, st, x, tmp, planes * H, (int)W, w,
                        tp, mode);
@@ -265,6 +173,7 @@ static int dwt2_inv(const T* ll, int64_t ll_h, int64_t ll_w, const T* hi, T* out
                   "%s: requested output %lldx%lld exceeds the reconstruction %lldx%lld", what, (long long)Ho, (long long)Wo,
                   (long long)Hr, (long long)Wr);
     if (planes == 0) return SONAR_OK;
+    if (dwt2_inv_tiled<T>(ll, (int)ll_h, (int)ll_w, hi, out, planes, (int)h, (int)w, (int)Ho, (int)Wo, tp, mode, st)) return check_launch(what);
     T* tmp = (T*)ws;
     hipLaunchKernelGGL((idwt_cols_kernel<T>), dim3(grid_for(planes * Hr * w, kBlock)), dim3(kBlock), 0, st, ll, (int)ll_h, (int)ll_w, hi,
                        tmp, planes, (int)h, (int)w, (int)Hr, tp, mode);
@@ -340,6 +249,32 @@ extern "C" int sonar_wcfg_band_f64(const double* cond, const double* uncond, dou
                                    const double* s_final, int blend_mode, double strength, void* stream) {
     return wcfg_band<double>(cond, uncond, out, n, group_size, groups, s_cond, s_uncond, s_diff, s_final, blend_mode, strength,
                              (hipStream_t)stream, "sonar_wcfg_band_f64");
+}
+extern "C" int64_t sonar_wcfg_fused_ws_bytes(int64_t planes, int64_t H, int64_t W, int levels, int dec_len, int mode_fwd, int rec_len,
+                                             int mode_inv, int elem_size) {
+    WcfgPlan pl;
+    if (planes < 0 || !dims_ok(H, W) || dec_len < 1 || rec_len < 1 || mode_fwd < 0 || mode_fwd > 5 || mode_inv < 0 || mode_inv > 5 ||
+        (elem_size != 4 && elem_size != 8) || !wcfg_plan(pl, planes, H, W, levels, dec_len, mode_fwd, rec_len, mode_inv))
+        return -1;
+    return pl.total * elem_size;
+}
+extern "C" int sonar_wcfg_fused_f32(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H,
+                                    int64_t W, int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd,
+                                    const double* rec_lo, const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales,
+                                    const double* yh_scales, int blend_mode, double strength, int subtract_from_x, void* ws,
+                                    int64_t ws_bytes, void* stream) {
+    return wcfg_fused<float>(cond, uncond, x, out, planes, H, W, levels, dec_lo, dec_hi, dec_len, mode_fwd, rec_lo, rec_hi, rec_len,
+                             mode_inv, yl_scales, yh_scales, blend_mode, strength, subtract_from_x, ws, ws_bytes, (hipStream_t)stream,
+                             "sonar_wcfg_fused_f32");
+}
+extern "C" int sonar_wcfg_fused_f64(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H,
+                                    int64_t W, int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd,
+                                    const double* rec_lo, const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales,
+                                    const double* yh_scales, int blend_mode, double strength, int subtract_from_x, void* ws,
+                                    int64_t ws_bytes, void* stream) {
+    return wcfg_fused<double>(cond, uncond, x, out, planes, H, W, levels, dec_lo, dec_hi, dec_len, mode_fwd, rec_lo, rec_hi, rec_len,
+                              mode_inv, yl_scales, yh_scales, blend_mode, strength, subtract_from_x, ws, ws_bytes, (hipStream_t)stream,
+                              "sonar_wcfg_fused_f64");
 }
 extern "C" int sonar_wcfg_output_f32(const float* x, const void* result, int result_is_f64, float* out, int64_t planes, int64_t H,
                                      int64_t W, int64_t Hr, int64_t Wr, int subtract_from_x, void* stream) {

@@ -1,0 +1,484 @@
+// LDS-staged 2-D DWT / IDWT: one launch per level, for even filter lengths 2..20 (longer / odd filters use the per-pass
+// kernels in dwt.hip).  A workgroup owns a tile of output rows of one plane:
+//   analysis   pass 1 filters along H straight from global memory: one thread per (tensor, column) keeps the 2 TH + F - 2
+//              input rows of its column in registers (every row is loaded once, coalesced across the wave) and slides the
+//              filter down them; the (low, high)-along-H rows go to LDS.  Pass 2 filters along W out of LDS, applies the
+//              WaveletCFG band arithmetic (py/wavelet_cfg.py:765-787) and stores: the intermediate never touches HBM, and
+//              cond / uncond are transformed together so only ONE detail tensor per level is written.
+//   synthesis  pass 1 along H from global, pass 2 along W out of LDS; a thread produces the (even, odd) output pair that
+//              shares one set of coefficients, so there is no per-term parity select or bounds test.
+// Multiply-adds are fused (fma): the reference's transform is a library convolution with no fixed summation order, so
+// the parity bar is the tolerance stated in tests/test_gpu_wavelet.py, not bit equality with the per-pass kernels.
+#pragma once
+#include <cstdlib>
+#include <type_traits>
+
+#include "dwt_common.h"
+
+namespace sonar {
+
+constexpr int kTileThreads = 256;
+constexpr int kFwdRows = 8;    // output rows per analysis tile (register window = 2 * kFwdRows + F - 2 input rows)
+constexpr int kInvRows = 16;   // output rows per synthesis tile (even)
+constexpr size_t kTileLdsLimit = 64 * 1024;
+
+// source index of extended-signal position `pos` (periodization pads odd lengths with a repeat of the last sample)
+__device__ __forceinline__ int src_index(int pos, int n, int ne, int mode) {
+    if (mode == kPeriodization) {
+        int p = pos % ne;
+        if (p < 0) p += ne;
+        return p < n ? p : n - 1;
+    }
+    return ext_index(pos, n, mode);
+}
+
+static inline bool tile_taps_ok(int F) { return F >= 2 && F <= 20 && (F & 1) == 0; }
+
+// analysis LDS: [kFwdRows][2 ceil(W/2) slots][2 tensors' (lowH, highH)] of T, then xmap[2w + F], ymap[2h + F]
+static inline size_t fwd_lds_bytes(int W, int h, int w, int F, size_t elem, int tensors) {
+    return (size_t)tensors * kFwdRows * 2 * (2 * ((W + 1) / 2)) * elem + (size_t)(2 * w + 2 * h + 2 * F) * sizeof(int);
+}
+// synthesis LDS: [kInvRows][lo_w | hi_w][w] of T
+static inline size_t inv_lds_bytes(int w, size_t elem) { return (size_t)kInvRows * 2 * w * elem; }
+
+template <typename T>
+struct BandArgs {
+    BandScales<T> hi;   // per orientation (cH, cV, cD)
+    BandScales<T> ll;   // index 0
+    int combine_ll;     // last level: the approximation band is combined too
+    int blend_mode;
+    T strength;
+};
+
+// PAIR = false: plain DWT of xc -> (llc, hi).  PAIR = true: DWT of xc and xu, hi = band(xc, xu) per orientation;
+// llc / llu separate, or llc = band(ll_c, ll_u) when combine_ll.  ZERO: zero-extension mode (the only mode with "no
+// source" positions; the others never need a select).
+// LDS tile layout: tmp[row][slot(x)][NV] with NV = 2 (lowH, highH) or 4 (cond lowH, cond highH, uncond lowH, uncond highH)
+// and slot(x) = (x & 1) * ceil(W / 2) + x / 2: a tap reads one parity class, so consecutive lanes hit consecutive slots
+// (conflict-free vector reads) and one read fetches every value a tap needs.
+template <typename T, int NV>
+struct alignas(sizeof(T) * NV > 16 ? 16 : sizeof(T) * NV) TileVec {
+    T v[NV];
+};
+
+template <typename T, typename TIn, bool PAIR, int FT, bool ZERO>
+__global__ void __launch_bounds__(kTileThreads) dwt2_tile_kernel(const TIn* __restrict__ xc, const TIn* __restrict__ xu,
+                                                                 T* __restrict__ llc, T* __restrict__ llu, T* __restrict__ hi,
+                                                                 int64_t planes, int H, int W, int h, int w, int tiles, Taps<T> tp,
+                                                                 int mode, BandArgs<T> ba) {
+    extern __shared__ __align__(16) unsigned char tile_smem[];
+    constexpr int TH = kFwdRows, NR = 2 * TH + FT - 2, NT = PAIR ? 2 : 1, NV = 2 * NT;
+    using Vec = TileVec<T, NV>;
+    using Half = TileVec<T, 2>;
+    const int Wh = (W + 1) >> 1, Ws = 2 * Wh;        // slots per row
+    Vec* const tmp = reinterpret_cast<Vec*>(tile_smem);  // [TH][Ws]
+    int* const xmap = reinterpret_cast<int*>(tmp + TH * Ws);
+    int* const ymap = xmap + (2 * w + FT);
+    const int off = mode == kPeriodization ? FT / 2 : 1;
+    {   // extension tables for extended position i + off - (F - 1): xmap = LDS slot (or -1), ymap = source row (or -1)
+        const int He = (mode == kPeriodization && (H & 1)) ? H + 1 : H;
+        const int We = (mode == kPeriodization && (W & 1)) ? W + 1 : W;
+        for (int i = threadIdx.x; i < 2 * w + FT - 2; i += kTileThreads) {
+            const int sx = src_index(i + off - (FT - 1), W, We, mode);
+            xmap[i] = sx < 0 ? -1 : (sx & 1) * Wh + (sx >> 1);
+        }
+        for (int i = threadIdx.x; i < 2 * h + FT - 2; i += kTileThreads) ymap[i] = src_index(i + off - (FT - 1), H, He, mode);
+    }
+    const int hw = h * w;
+    const int dq = kTileThreads / w, dr = kTileThreads - dq * w;  // pass-2 item stride as (rows, columns)
+    const int q0 = threadIdx.x / w, r0 = threadIdx.x - q0 * w;
+    for (int64_t job = blockIdx.x; job < planes * tiles; job += gridDim.x) {
+        const int64_t p = job / tiles;
+        const int y0 = (int)(job - p * tiles) * TH;
+        const int th = min(TH, h - y0);
+        const TIn* const pc = xc + p * (int64_t)H * W;
+        const TIn* const pu = PAIR ? xu + p * (int64_t)H * W : nullptr;
+        __syncthreads();
+        // ---- pass 1: analysis along H, one thread per (tensor, column); window = extended input rows 2 y0 .. 2 y0 + NR - 1
+        for (int it = threadIdx.x; it < NT * W; it += kTileThreads) {
+            const int ten = it >= W ? 1 : 0;
+            const int x = it - ten * W;
+            const TIn* col = (ten ? pu : pc) + x;
+            T v[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                // rows past the tile's need (last tile) re-read a valid row; their outputs are never consumed
+                const int sy = __builtin_amdgcn_readfirstlane(ymap[min(2 * y0 + r, 2 * h + FT - 3)]);
+                if constexpr (ZERO) {
+                    const T g = (T)col[(sy >= 0 ? sy : 0) * W];
+                    v[r] = sy >= 0 ? g : T(0);
+                } else {
+                    v[r] = (T)col[sy * W];
+                }
+            }
+            Half* dst = reinterpret_cast<Half*>(tmp + ((x & 1) * Wh + (x >> 1))) + ten;
+#pragma unroll
+            for (int yl = 0; yl < TH; ++yl) {
+                T lo = T(0), hq = T(0);
+#pragma unroll
+                for (int j = 0; j < FT; ++j) {  // tap j reads window row 2 yl + F - 1 - j
+                    lo = fma_t(tp.lo[j], v[2 * yl + FT - 1 - j], lo);
+                    hq = fma_t(tp.hi[j], v[2 * yl + FT - 1 - j], hq);
+                }
+                Half o2;
+                o2.v[0] = lo;
+                o2.v[1] = hq;
+                dst[yl * Ws * NT] = o2;
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: analysis along W out of LDS, band arithmetic, store
+        T* const ollc = llc + p * (int64_t)hw;
+        T* const ollu = (PAIR && !ba.combine_ll) ? llu + p * (int64_t)hw : nullptr;
+        T* const ohi = hi + p * 3 * (int64_t)hw;
+        for (int yl = q0, xo = r0; yl < th;) {
+            const Vec* row = tmp + yl * Ws;
+            const int* xm = xmap + 2 * xo + (FT - 1);  // tap j reads slot xm[-j]
+            T c_ll = T(0), c_h = T(0), c_v = T(0), c_d = T(0), u_ll = T(0), u_h = T(0), u_v = T(0), u_d = T(0);
+#pragma unroll
+            for (int j = 0; j < FT; ++j) {
+                const int sx = xm[-j];
+                Vec q = row[ZERO ? max(sx, 0) : sx];
+                if constexpr (ZERO) {
+                    if (sx < 0) {
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) q.v[e] = T(0);
+                    }
+                }
+                c_ll = fma_t(tp.lo[j], q.v[0], c_ll);  // low H, low W
+                c_v = fma_t(tp.hi[j], q.v[0], c_v);    // low H, high W  (cV)
+                c_h = fma_t(tp.lo[j], q.v[1], c_h);    // high H, low W  (cH)
+                c_d = fma_t(tp.hi[j], q.v[1], c_d);
+                if constexpr (PAIR) {
+                    u_ll = fma_t(tp.lo[j], q.v[2], u_ll);
+                    u_v = fma_t(tp.hi[j], q.v[2], u_v);
+                    u_h = fma_t(tp.lo[j], q.v[3], u_h);
+                    u_d = fma_t(tp.hi[j], q.v[3], u_d);
+                }
+            }
+            const int o = (y0 + yl) * w + xo;
+            if constexpr (PAIR) {
+                ohi[o] = band_combine<T>(c_h, u_h, ba.hi, 0, ba.blend_mode, ba.strength);
+                ohi[hw + o] = band_combine<T>(c_v, u_v, ba.hi, 1, ba.blend_mode, ba.strength);
+                ohi[2 * hw + o] = band_combine<T>(c_d, u_d, ba.hi, 2, ba.blend_mode, ba.strength);
+                if (ba.combine_ll) {
+                    ollc[o] = band_combine<T>(c_ll, u_ll, ba.ll, 0, ba.blend_mode, ba.strength);
+                } else {
+                    ollc[o] = c_ll;
+                    ollu[o] = u_ll;
+                }
+            } else {
+                ollc[o] = c_ll;
+                ohi[o] = c_h;
+                ohi[hw + o] = c_v;
+                ohi[2 * hw + o] = c_d;
+            }
+            yl += dq;
+            xo += dr;
+            if (xo >= w) {
+                xo -= w;
+                yl += 1;
+            }
+        }
+    }
+}
+
+// The outputs o = 2m and 2m + 1 of a synthesis share their coefficients (K = F / 2 terms each):
+//   non-periodization    x[2m]   = sum_k a[i_k] lo[2k]   + d[i_k] hi[2k],     i_k = m + K - 1 - k   (0 <= i_k < n for valid o)
+//                        x[2m+1] = sum_k a[i_k] lo[2k+1] + d[i_k] hi[2k+1]
+//   periodization, K odd same taps, i_k = (m + (K-1)/2 - k) mod n
+//   periodization, K even x[2m] pairs tap 2k+1 with i = (m + K/2 - 1 - k) mod n, x[2m+1] pairs tap 2k with i = (m + K/2 - k) mod n
+// (from x[o] = sum over 2i + j == o + F - 2, resp. == o + F/2 - 1 mod 2n).  Terms are added with i ascending.
+template <typename T, int FT>
+struct SynthPair {
+    static constexpr int K = FT / 2;
+    template <typename LoadA, typename LoadD>
+    static __device__ __forceinline__ void run(int m, int n, int mode, const Taps<T>& tp, LoadA&& la, LoadD&& ld, T& even, T& odd) {
+        even = T(0);
+        odd = T(0);
+        if (mode != kPeriodization || (K & 1) == 1) {
+            T va[K], vd[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                int i;
+                if (mode != kPeriodization) {
+                    i = m + K - 1 - k;
+                    i = i < n ? i : n - 1;  // only beyond the valid output length (the caller discards those outputs)
+                } else {
+                    i = (m + (K - 1) / 2 - k) % n;
+                    if (i < 0) i += n;
+                }
+                va[k] = la(i);
+                vd[k] = ld(i);
+            }
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                even = fma_t(va[k], tp.lo[2 * k], fma_t(vd[k], tp.hi[2 * k], even));
+                odd = fma_t(va[k], tp.lo[2 * k + 1], fma_t(vd[k], tp.hi[2 * k + 1], odd));
+            }
+        } else {
+            T va[K + 1], vd[K + 1];
+#pragma unroll
+            for (int q = 0; q <= K; ++q) {  // entry q holds i = m + K/2 - q
+                int i = (m + K / 2 - q) % n;
+                if (i < 0) i += n;
+                va[q] = la(i);
+                vd[q] = ld(i);
+            }
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                even = fma_t(va[k + 1], tp.lo[2 * k + 1], fma_t(vd[k + 1], tp.hi[2 * k + 1], even));
+                odd = fma_t(va[k], tp.lo[2 * k], fma_t(vd[k], tp.hi[2 * k], odd));
+            }
+        }
+    }
+};
+
+// FINAL = false: out[planes][Ho][Wo] (type T).  FINAL = true: outf = xsub - (float)rec (or (float)rec), the
+// cast + crop + `x - result` of py/wavelet_cfg.py:729-748 fused into the last synthesis pass.
+template <typename T, bool FINAL, int FT>
+__global__ void __launch_bounds__(kTileThreads) idwt2_tile_kernel(const T* __restrict__ ll, int ll_h, int ll_w,
+                                                                  const T* __restrict__ hi, T* __restrict__ out,
+                                                                  const float* __restrict__ xsub, float* __restrict__ outf,
+                                                                  int64_t planes, int h, int w, int Ho, int Wo, int tiles, Taps<T> tp,
+                                                                  int mode, int subtract) {
+    extern __shared__ __align__(16) unsigned char tile_smem[];
+    constexpr int TH = kInvRows;
+    T* const tmp = reinterpret_cast<T*>(tile_smem);  // [TH][lo_w | hi_w]
+    const int hw = h * w, w2 = 2 * w;
+    const int wp = (Wo + 1) >> 1;                                     // output pairs per row
+    const int dq = kTileThreads / w, dr = kTileThreads - dq * w;     // pass 1 items: (row pair, column)
+    const int q0 = threadIdx.x / w, r0 = threadIdx.x - q0 * w;
+    const int DQ = kTileThreads / wp, DR = kTileThreads - DQ * wp;   // pass 2 items: (row, column pair)
+    const int Q0 = threadIdx.x / wp, R0 = threadIdx.x - Q0 * wp;
+    for (int64_t job = blockIdx.x; job < planes * tiles; job += gridDim.x) {
+        const int64_t p = job / tiles;
+        const int y0 = (int)(job - p * tiles) * TH;  // even
+        const int th = min(TH, Ho - y0);
+        const T* const pll = ll + p * (int64_t)ll_h * ll_w;
+        const T* const phi = hi + p * 3 * (int64_t)hw;
+        __syncthreads();
+        // ---- pass 1: synthesis along H (lanes along x: coalesced); rows (y0 + 2 mp, y0 + 2 mp + 1) -> LDS
+        for (int mp = q0, xo = r0; 2 * mp < th;) {
+            const int m = (y0 >> 1) + mp;
+            T e0, o0, e1, o1;
+            SynthPair<T, FT>::run(m, h, mode, tp, [&](int i) { return pll[i * ll_w + xo]; }, [&](int i) { return phi[i * w + xo]; }, e0, o0);
+            SynthPair<T, FT>::run(m, h, mode, tp, [&](int i) { return phi[hw + i * w + xo]; },
+                                  [&](int i) { return phi[2 * hw + i * w + xo]; }, e1, o1);
+            tmp[(2 * mp) * w2 + xo] = e0;
+            tmp[(2 * mp) * w2 + w + xo] = e1;
+            if (2 * mp + 1 < th) {
+                tmp[(2 * mp + 1) * w2 + xo] = o0;
+                tmp[(2 * mp + 1) * w2 + w + xo] = o1;
+            }
+            mp += dq;
+            xo += dr;
+            if (xo >= w) {
+                xo -= w;
+                mp += 1;
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: synthesis along W out of LDS -> global, two outputs per thread
+        const int64_t obase = (p * Ho + y0) * (int64_t)Wo;
+        for (int yl = Q0, m = R0; yl < th;) {
+            const T* lo_w = tmp + yl * w2;
+            const T* hi_w = lo_w + w;
+            T e, o;
+            SynthPair<T, FT>::run(m, w, mode, tp, [&](int i) { return lo_w[i]; }, [&](int i) { return hi_w[i]; }, e, o);
+            const int64_t at = obase + yl * Wo + 2 * m;
+            const bool has_odd = 2 * m + 1 < Wo;
+            if constexpr (FINAL) {
+                outf[at] = subtract ? xsub[at] - (float)e : (float)e;
+                if (has_odd) outf[at + 1] = subtract ? xsub[at + 1] - (float)o : (float)o;
+            } else {
+                out[at] = e;
+                if (has_odd) out[at + 1] = o;
+            }
+            yl += DQ;
+            m += DR;
+            if (m >= wp) {
+                m -= wp;
+                yl += 1;
+            }
+        }
+    }
+}
+
+// run `body(std::integral_constant<int, FT>)` for the supported filter lengths
+template <typename Body>
+static inline void with_taps(int F, Body&& body) {
+    switch (F) {
+#define SONAR_FT(N) case N: body(std::integral_constant<int, N>{}); break;
+        SONAR_FT(2) SONAR_FT(4) SONAR_FT(6) SONAR_FT(8) SONAR_FT(10) SONAR_FT(12) SONAR_FT(14) SONAR_FT(16) SONAR_FT(18) SONAR_FT(20)
+#undef SONAR_FT
+        default: break;
+    }
+}
+
+static inline int tile_grid(int64_t jobs) { return (int)std::min<int64_t>(jobs, 1 << 20); }
+
+// plain single-level forward through the tile kernel; false if unsupported here (caller falls back to the per-pass kernels)
+template <typename T>
+static bool dwt2_fwd_tiled(const T* x, T* ll, T* hi, int64_t planes, int H, int W, int h, int w, const Taps<T>& tp, int mode,
+                           hipStream_t st) {
+    if (!tile_taps_ok(tp.len)) return false;
+    const size_t lds = fwd_lds_bytes(W, h, w, tp.len, sizeof(T), 1);
+    if (lds > kTileLdsLimit) return false;
+    const int tiles = (h + kFwdRows - 1) / kFwdRows;
+    with_taps(tp.len, [&](auto ft) {
+        constexpr int FT = decltype(ft)::value;
+        if (mode == kZero)
+            hipLaunchKernelGGL((dwt2_tile_kernel<T, T, false, FT, true>), dim3(tile_grid(planes * tiles)), dim3(kTileThreads), lds, st, x,
+                               (const T*)nullptr, ll, (T*)nullptr, hi, planes, H, W, h, w, tiles, tp, mode, BandArgs<T>{});
+        else
+            hipLaunchKernelGGL((dwt2_tile_kernel<T, T, false, FT, false>), dim3(tile_grid(planes * tiles)), dim3(kTileThreads), lds, st, x,
+                               (const T*)nullptr, ll, (T*)nullptr, hi, planes, H, W, h, w, tiles, tp, mode, BandArgs<T>{});
+    });
+    return true;
+}
+
+template <typename T>
+static bool dwt2_inv_tiled(const T* ll, int ll_h, int ll_w, const T* hi, T* out, int64_t planes, int h, int w, int Ho, int Wo,
+                           const Taps<T>& tp, int mode, hipStream_t st) {
+    if (!tile_taps_ok(tp.len)) return false;
+    const size_t lds = inv_lds_bytes(w, sizeof(T));
+    if (lds > kTileLdsLimit) return false;
+    const int tiles = (Ho + kInvRows - 1) / kInvRows;
+    with_taps(tp.len, [&](auto ft) {
+        hipLaunchKernelGGL((idwt2_tile_kernel<T, false, decltype(ft)::value>), dim3(tile_grid(planes * tiles)), dim3(kTileThreads), lds, st,
+                           ll, ll_h, ll_w, hi, out, (const float*)nullptr, (float*)nullptr, planes, h, w, Ho, Wo, tiles, tp, mode, 0);
+    });
+    return true;
+}
+
+// ---- whole WaveletCFG transform-domain step (py/wavelet_cfg.py:750-791 + 729-748), `levels` launches each way
+struct WcfgPlan {
+    int levels;
+    int H[kMaxLevels + 1], W[kMaxLevels + 1];   // [0] = input plane, [j] = coefficient plane of level j
+    int Hr[kMaxLevels + 1], Wr[kMaxLevels + 1]; // reconstruction produced FROM level j (size of level j-1 input, maybe +1)
+    int64_t off_d[kMaxLevels + 1], off_c[kMaxLevels + 1], off_u[kMaxLevels + 1], off_r[kMaxLevels + 1];  // elements
+    int64_t total;  // elements
+};
+
+static inline bool wcfg_plan(WcfgPlan& pl, int64_t planes, int64_t H, int64_t W, int levels, int dec_len, int mode_fwd, int rec_len,
+                             int mode_inv) {
+    if (levels < 1 || levels > kMaxLevels) return false;
+    pl.levels = levels;
+    pl.H[0] = (int)H;
+    pl.W[0] = (int)W;
+    int64_t at = 0;
+    for (int j = 1; j <= levels; ++j) {
+        pl.H[j] = (int)dwt_len(pl.H[j - 1], dec_len, mode_fwd);
+        pl.W[j] = (int)dwt_len(pl.W[j - 1], dec_len, mode_fwd);
+        pl.Hr[j] = mode_inv == kPeriodization ? 2 * pl.H[j] : 2 * pl.H[j] - rec_len + 2;
+        pl.Wr[j] = mode_inv == kPeriodization ? 2 * pl.W[j] : 2 * pl.W[j] - rec_len + 2;
+        if (pl.Hr[j] < pl.H[j - 1] || pl.Wr[j] < pl.W[j - 1]) return false;  // the inverse cannot cover the level below
+        const int64_t n = planes * pl.H[j] * pl.W[j];
+        pl.off_d[j] = at; at += 3 * n;
+        pl.off_c[j] = at; at += n;
+        pl.off_u[j] = at; at += (j < levels ? n : 0);
+        pl.off_r[j] = at; at += (j > 1 ? planes * (int64_t)pl.Hr[j] * pl.Wr[j] : 0);
+    }
+    pl.total = at;
+    return true;
+}
+
+template <typename T>
+static int wcfg_fused(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H, int64_t W,
+                      int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd, const double* rec_lo,
+                      const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,
+                      int blend_mode, double strength, int subtract_from_x, void* ws, int64_t ws_bytes, hipStream_t st,
+                      const char* what) {
+    SONAR_REQUIRE(cond && uncond && out && (x || !subtract_from_x) && ws && yl_scales && yh_scales && planes >= 0 && mode_fwd >= 0 &&
+                      mode_fwd <= 5 && mode_inv >= 0 && mode_inv <= 5 && blend_mode >= 0 && blend_mode <= 2,
+                  SONAR_ERR_ARG, "%s: bad argument", what);
+    SONAR_REQUIRE(dims_ok(H, W), SONAR_ERR_UNSUPPORTED, "%s: bad plane size", what);
+    Taps<T> dec, rec;
+    SONAR_REQUIRE(make_taps(dec, dec_lo, dec_hi, dec_len) && make_taps(rec, rec_lo, rec_hi, rec_len), SONAR_ERR_ARG,
+                  "%s: 1..%d filter taps required", what, kMaxTaps);
+    SONAR_REQUIRE(tile_taps_ok(dec_len) && tile_taps_ok(rec_len), SONAR_ERR_UNSUPPORTED, "%s: even filter lengths 2..20 only", what);
+    WcfgPlan pl;
+    SONAR_REQUIRE(wcfg_plan(pl, planes, H, W, levels, dec_len, mode_fwd, rec_len, mode_inv), SONAR_ERR_UNSUPPORTED,
+                  "%s: 1..%d levels and an inverse filter that covers every level are required", what, kMaxLevels);
+    SONAR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), SONAR_ERR_ARG, "%s: workspace too small (%lld < %lld bytes)", what,
+                  (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
+    if (planes == 0) return SONAR_OK;
+    T* base = (T*)ws;
+    // every level must fit its tile in LDS (checked before the first launch so a refusal has no side effects)
+    for (int j = 1; j <= levels; ++j)
+        SONAR_REQUIRE(fwd_lds_bytes(pl.W[j - 1], pl.H[j], pl.W[j], dec_len, sizeof(T), 2) <= kTileLdsLimit &&
+                          inv_lds_bytes(pl.W[j], sizeof(T)) <= kTileLdsLimit,
+                      SONAR_ERR_UNSUPPORTED, "%s: level %d (%d x %d) does not fit the LDS tile", what, j, pl.H[j], pl.W[j]);
+    auto band_args = [&](int j) {
+        BandArgs<T> ba;
+        for (int g = 0; g < 4; ++g) {
+            const bool in = g < 3;
+            const double* row = yh_scales + (int64_t)(j - 1) * 12;
+            ba.hi.cond[g] = in ? (T)row[0 + g] : T(1);
+            ba.hi.uncond[g] = in ? (T)row[3 + g] : T(1);
+            ba.hi.diff[g] = in ? (T)row[6 + g] : T(1);
+            ba.hi.fin[g] = in ? (T)row[9 + g] : T(1);
+            ba.ll.cond[g] = g == 0 ? (T)yl_scales[0] : T(1);
+            ba.ll.uncond[g] = g == 0 ? (T)yl_scales[1] : T(1);
+            ba.ll.diff[g] = g == 0 ? (T)yl_scales[2] : T(1);
+            ba.ll.fin[g] = g == 0 ? (T)yl_scales[3] : T(1);
+        }
+        ba.combine_ll = j == levels;
+        ba.blend_mode = blend_mode;
+        ba.strength = (T)strength;
+        return ba;
+    };
+    // ---- analysis, finest level first; level 1 reads the fp32 inputs directly (cast in registers)
+    for (int j = 1; j <= levels; ++j) {
+        const int tiles = (pl.H[j] + kFwdRows - 1) / kFwdRows;
+        const size_t lds = fwd_lds_bytes(pl.W[j - 1], pl.H[j], pl.W[j], dec_len, sizeof(T), 2);
+        const dim3 grid(tile_grid(planes * tiles)), blk(kTileThreads);
+        T* d = base + pl.off_d[j];
+        T* c = base + pl.off_c[j];
+        T* u = base + pl.off_u[j];
+        const BandArgs<T> ba = band_args(j);
+        with_taps(dec_len, [&](auto ft) {
+            constexpr int FT = decltype(ft)::value;
+            auto go = [&](auto zero) {
+                constexpr bool Z = decltype(zero)::value;
+                if (j == 1)
+                    hipLaunchKernelGGL((dwt2_tile_kernel<T, float, true, FT, Z>), grid, blk, lds, st, cond, uncond, c, u, d, planes,
+                                       pl.H[0], pl.W[0], pl.H[1], pl.W[1], tiles, dec, mode_fwd, ba);
+                else
+                    hipLaunchKernelGGL((dwt2_tile_kernel<T, T, true, FT, Z>), grid, blk, lds, st, (const T*)(base + pl.off_c[j - 1]),
+                                       (const T*)(base + pl.off_u[j - 1]), c, u, d, planes, pl.H[j - 1], pl.W[j - 1], pl.H[j], pl.W[j],
+                                       tiles, dec, mode_fwd, ba);
+            };
+            if (mode_fwd == kZero) go(std::true_type{}); else go(std::false_type{});
+        });
+    }
+    // ---- synthesis, coarsest level first; the last launch writes x - result (cropped) as fp32
+    const T* ll = base + pl.off_c[levels];
+    int ll_h = pl.H[levels], ll_w = pl.W[levels];
+    for (int j = levels; j >= 1; --j) {
+        const int Ho = j > 1 ? pl.Hr[j] : (int)H, Wo = j > 1 ? pl.Wr[j] : (int)W;
+        const int tiles = (Ho + kInvRows - 1) / kInvRows;
+        const size_t lds = inv_lds_bytes(pl.W[j], sizeof(T));
+        const dim3 grid(tile_grid(planes * tiles)), blk(kTileThreads);
+        const T* d = base + pl.off_d[j];
+        if (j > 1) {
+            T* r = base + pl.off_r[j];
+            with_taps(rec_len, [&](auto ft) {
+                hipLaunchKernelGGL((idwt2_tile_kernel<T, false, decltype(ft)::value>), grid, blk, lds, st, ll, ll_h, ll_w, d, r,
+                                   (const float*)nullptr, (float*)nullptr, planes, pl.H[j], pl.W[j], Ho, Wo, tiles, rec, mode_inv, 0);
+            });
+            ll = r;
+            ll_h = Ho;
+            ll_w = Wo;
+        } else {
+            with_taps(rec_len, [&](auto ft) {
+                hipLaunchKernelGGL((idwt2_tile_kernel<T, true, decltype(ft)::value>), grid, blk, lds, st, ll, ll_h, ll_w, d, (T*)nullptr, x,
+                                   out, planes, pl.H[j], pl.W[j], Ho, Wo, tiles, rec, mode_inv, subtract_from_x);
+            });
+        }
+    }
+    return check_launch(what);
+}
+
+}  // namespace sonar

@@ -21,6 +21,7 @@ INIT_IDS = {"NONE": 0, "SAMPLE": 1, "SAMPLE_NORM": 2}
 RESAMPLE_IDS = {"bilinear": 0, "nearest-exact": 1, "area": 2, "adaptive_avg_pool2d": 2}
 DWT_MODE_IDS = {"zero": 0, "symmetric": 1, "reflect": 2, "periodization": 3, "periodic": 4, "constant": 5, "replicate": 5}
 NPART = 1024
+ERR_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3  # include/sonar_hip.h
 
 
 class SonarHipError(RuntimeError):
@@ -103,6 +104,9 @@ SIGNATURES = {
     "sonar_wcfg_band_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
     "sonar_wcfg_band_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
+    "sonar_wcfg_fused_ws_bytes": (_I64, [_I64, _I64, _I64, _I, _I, _I, _I, _I, _I]),
+    "sonar_wcfg_fused_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _P, _I64, _P]),
+    "sonar_wcfg_fused_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _P, _I64, _P]),
     "sonar_cast_f32_f64": (_I, [_P, _P, _I64, _P]),
 }
 
@@ -689,4 +693,37 @@ def wcfg_output(x: Optional[torch.Tensor], result: torch.Tensor, shape, subtract
     planes = out.numel() // (H * W)
     _check(load().sonar_wcfg_output_f32(_opt(x, "x"), _dev(result, "result", result.dtype), int(result.dtype == torch.float64), _dev(out, "out"),
                                         planes, H, W, Hr, Wr, int(bool(subtract_from_x)), _stream()), "sonar_wcfg_output_f32")
+    return out
+
+
+_WCFG_WS: dict = {}
+
+
+def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], *, levels: int, dec_lo, dec_hi, mode: str, rec_lo, rec_hi,
+               inv_mode: str, yl_scales, yh_scales, blend_mode: str, strength: float, subtract_from_x: bool, high_precision: bool):
+    """WaveletCFG's transform-domain step for fp32 [B, C, H, W] cond / uncond (and x) in 2 * levels launches; returns the
+    fp32 output, or None when a level does not fit the LDS tile (caller uses the per-pass kernels)."""
+    B, Cc, H, W = cond.shape
+    planes = B * Cc
+    lib = load()
+    elem = 8 if high_precision else 4
+    need = lib.sonar_wcfg_fused_ws_bytes(planes, H, W, levels, len(dec_lo), DWT_MODE_IDS[mode], len(rec_lo), DWT_MODE_IDS[inv_mode], elem)
+    if need < 0:
+        return None
+    key = (cond.device, torch.cuda.current_stream().cuda_stream)
+    ws = _WCFG_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WCFG_WS[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=cond.device)  # reused across steps of a sampling run
+    out = torch.empty_like(cond)
+    flat = [float(v) for lvl in yh_scales for name in lvl for v in name]
+    if len(flat) != levels * 12 or len(yl_scales) != 4:
+        raise SonarHipError("wcfg_fused: scale tables must be [levels][4][3] and [4]")
+    fn = lib.sonar_wcfg_fused_f64 if high_precision else lib.sonar_wcfg_fused_f32
+    rc = fn(_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), planes, H, W, levels, _darr(dec_lo), _darr(dec_hi),
+            len(dec_lo), DWT_MODE_IDS[mode], _darr(rec_lo), _darr(rec_hi), len(rec_lo), DWT_MODE_IDS[inv_mode],
+            _darr([float(v) for v in yl_scales]), _darr(flat), BLEND_IDS[blend_mode], float(strength), int(bool(subtract_from_x)),
+            ws.data_ptr(), ws.numel(), _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _check(rc, "sonar_wcfg_fused")
     return out

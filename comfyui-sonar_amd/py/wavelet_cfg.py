@@ -550,6 +550,37 @@ class WaveletCFG:
         return WCFGContext(cond=cond, uncond=uncond, x=x, sigma=sigma, wavelet=wavelet, dtype=eff_dtype, op_kwargs=op_kwargs)
 
     @classmethod
+    def wavelet_cfg_fused(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts) -> Optional[torch.Tensor]:
+        """x - IDWT(band(DWT(cond), DWT(uncond))) through ``sonar_wcfg_fused_*``; None when the shape / dtype is outside its scope."""
+        w = ctx.wavelet
+        if ctx.cond.ndim != 4 or ctx.cond.dtype != torch.float32 or ctx.uncond.dtype != torch.float32 or ctx.dtype not in (torch.float32, torch.float64):
+            return None
+        levels = w.level
+        if levels < 1:
+            return None
+
+        class _Band:  # expand_yh_scales only needs the band count and the orientation count
+            shape = (1, 1, 3, 1, 1)
+
+        fake_yh = [_Band] * levels
+        tabs = {name: rule.scale_table(name, pcts, fake_yh) for name in ("cond", "uncond", "diff", "final")}
+
+        def row(name, j):
+            table = tabs[name][1]
+            if table is None or j >= len(table):
+                return (1.0, 1.0, 1.0)
+            sc = table[j]
+            sc = (float(sc),) * 3 if isinstance(sc, (int, float)) else tuple(float(v) for v in sc)
+            return (sc + (1.0,) * 3)[:3]
+
+        names = ("cond", "uncond", "diff", "final")
+        return hip_lib.wcfg_fused(
+            ctx.cond.contiguous(), ctx.uncond.contiguous(), ctx.x.contiguous(), levels=levels, dec_lo=w.dec_lo, dec_hi=w.dec_hi, mode=w.mode,
+            rec_lo=w.rec_lo, rec_hi=w.rec_hi, inv_mode=w.inv_mode, yl_scales=[tabs[n][0] for n in names],
+            yh_scales=[[row(n, j) for n in names] for j in range(levels)], blend_mode=rule.difference_blend_mode,
+            strength=rule.difference_blend_strength.get_value(pcts), subtract_from_x=True, high_precision=ctx.dtype == torch.float64)
+
+    @classmethod
     def wavelet_cfg_raw(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts) -> torch.Tensor:
         """The transform-domain result in ``ctx.dtype`` at the reconstruction's own size (before cast/crop)."""
         condw = ctx.wavelet.forward(_to_dtype(ctx.cond, ctx.dtype))
@@ -604,7 +635,12 @@ class WaveletCFG:
         plain = rule.blend_mode == "lerp" and wcfg_blend == 1.0
         x = ctx.x
         if plain and rule.target_mode == WCFGTarget.DENOISED and x.ndim == 4 and x.dtype == torch.float32 and self.operation_wavelet_cfg is None:
-            # fast path: cast + crop + (x - result) fused in one kernel straight from the fp64/fp32 reconstruction
+            # fast path 1: the whole transform-domain step in 2 * level LDS-staged launches (cond + uncond analysed together, band
+            # arithmetic before the store, last synthesis pass writes x - result)
+            fused = self.wavelet_cfg_fused(rule=rule, ctx=ctx, pcts=pcts)
+            if fused is not None:
+                return self.maybe_op(fused, self.operation_result, **ctx.op_kwargs).contiguous()
+            # fast path 2: cast + crop + (x - result) fused in one kernel straight from the fp64/fp32 reconstruction
             raw = self.wavelet_cfg_raw(rule=rule, ctx=ctx, pcts=pcts)
             result = hip_lib.wcfg_output(x.contiguous(), raw, x.shape, True)
             return self.maybe_op(result, self.operation_result, **ctx.op_kwargs).contiguous()

@@ -255,6 +255,23 @@ int sonar_wcfg_band_f32(const float* cond, const float* uncond, float* out, int6
 int sonar_wcfg_band_f64(const double* cond, const double* uncond, double* out, int64_t n, int64_t group_size,
                         int64_t groups, const double* s_cond, const double* s_uncond, const double* s_diff,
                         const double* s_final, int blend_mode, double strength, void* stream);
+/* The whole transform-domain step of WaveletCFG in `2 * levels` launches (py/wavelet_cfg.py:750-791,729-748), LDS-staged:
+ * each level's analysis handles cond and uncond together (fp32 inputs cast in registers), applies
+ * blend(u*s_u, (c*s_c - u*s_u)*s_d, strength)*s_f per band before storing; each level's synthesis is one launch; the last
+ * one writes out = x - result (subtract_from_x) or result, cropped to H x W, as fp32.  _f32 / _f64 = arithmetic type
+ * (high_precision_mode).  yl_scales[4] = {cond, uncond, diff, final}; yh_scales[levels][4][3] = the same per level
+ * (finest first) and orientation (cH, cV, cD).  ws: sonar_wcfg_fused_ws_bytes(...) bytes; returns
+ * SONAR_ERR_UNSUPPORTED (nothing launched) when a level does not fit the LDS tile. */
+int64_t sonar_wcfg_fused_ws_bytes(int64_t planes, int64_t H, int64_t W, int levels, int dec_len, int mode_fwd, int rec_len,
+                                  int mode_inv, int elem_size);
+int sonar_wcfg_fused_f32(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H, int64_t W,
+                         int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd, const double* rec_lo,
+                         const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,
+                         int blend_mode, double strength, int subtract_from_x, void* ws, int64_t ws_bytes, void* stream);
+int sonar_wcfg_fused_f64(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H, int64_t W,
+                         int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd, const double* rec_lo,
+                         const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,
+                         int blend_mode, double strength, int subtract_from_x, void* ws, int64_t ws_bytes, void* stream);
 /* process_output, py/wavelet_cfg.py:729-748: out = x - (float)crop(result)  (subtract_from_x = 1, target DENOISED)
  * or out = (float)crop(result); result is [planes][Hr][Wr] (f64 or f32), x/out are [planes][H][W] fp32 */
 int sonar_wcfg_output_f32(const float* x, const void* result, int result_is_f64, float* out, int64_t planes,

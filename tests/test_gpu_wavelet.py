@@ -149,3 +149,39 @@ def test_wavelet_cfg_rule_window_and_blend(api):
     # identity scales: wavelet CFG with all scales 1 and strength s == uncond + s (cond - uncond)
     ident = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(difference=dict(yl_scale=1.0, yh_scales=1.0), difference_blend_strength=5.0))
     torch.testing.assert_close(ident(args), plain, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("high_precision", [True, False])
+@pytest.mark.parametrize("extra", [{}, {"wave": "haar", "level": 3, "padding_mode": "periodization"}, {"wave": "sym5", "level": 2, "padding_mode": "zero"},
+                                   {"wave": "bior2.2", "level": 4, "padding_mode": "reflect", "difference_blend_mode": "lerp", "difference_blend_strength": 0.3,
+                                    "difference": {"yl_scale": 0.5, "yh_scales": [[1.0, 2.0, 3.0], 0.25, "fill"]}}])
+def test_wavelet_cfg_fused_equals_per_pass_path(api, monkeypatch, high_precision, extra):
+    """The LDS-staged 2 * level launch path (fused multiply-adds, H-first analysis) against the per-pass kernels:
+    same transform, different rounding -> fp64 1e-12, fp32 2e-5 on O(1..10) data."""
+    torch.manual_seed(4)
+    shape = (3, 4, 96, 80)  # not a power of two: odd coefficient sizes on the way down
+    cond, uncond, x = (torch.randn(shape, device="cuda") for _ in range(3))
+    params = dict(PLACEHOLDER_RULE, high_precision_mode=high_precision)
+    params.update(extra)
+    args = {"input": x, "cond_scale": 7.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
+            "sigma": torch.full((3,), 7.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+    fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
+    calls = []
+    real = api.hl.wcfg_fused
+    monkeypatch.setattr(api.hl, "wcfg_fused", lambda *a, **k: calls.append(1) or real(*a, **k))
+    fused = fn(args)
+    assert calls, "the fused entry point was not used"
+    monkeypatch.setattr(api.wc.WaveletCFG, "wavelet_cfg_fused", classmethod(lambda cls, **_k: None))
+    per_pass = fn(args)
+    torch.testing.assert_close(fused, per_pass, rtol=1e-5, atol=(1e-11 if high_precision else 4e-5))
+
+
+def test_wavelet_cfg_fused_full_batch_identity(api):
+    """cfg4 size (256 x 4 x 128 x 128): unit scales and strength 1 give x - cond (perfect reconstruction), in 10 launches."""
+    torch.manual_seed(5)
+    shape = (256, 4, 128, 128)
+    cond, uncond, x = (torch.randn(shape, device="cuda") for _ in range(3))
+    args = {"input": x, "cond_scale": 7.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
+            "sigma": torch.full((256,), 7.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+    fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(difference=dict(yl_scale=1.0, yh_scales=1.0), high_precision_mode=False))
+    torch.testing.assert_close(fn(args), x - cond, rtol=0, atol=2e-5)
