@@ -141,34 +141,98 @@ struct PlaneCfg {
     static constexpr size_t kLdsBytes = (size_t)kLdsComplex * sizeof(c32);
 };
 
-// One plane's filtered half-spectrum -> sink(ky, kx, value).  GEN: thread-slot `tid` of plane `gplane` owns the
-// stream (seed, stream_id, tile = gplane, lane = tid); burst step `it` yields the complex pair at linear
-// indices j and j + NC/2 (j = it*NT + tid), so consecutive lanes touch consecutive elements.
-template <int H, int W, bool GEN, int UNROLL = 2, typename Sink>
-__device__ __forceinline__ void fill_plane(const float* __restrict__ z, const float* __restrict__ filter, int64_t plane,
-                                           int64_t gplane, uint64_t seed, uint64_t stream_id, int tid, Sink&& sink) {
+// ---- on-device spectrum draws (generate mode) ---------------------------------------------------------------------
+// Streams are keyed by (seed, stream_id, plane group, thread slot): a group is `group` consecutive global planes (4 when the
+// channel count is a multiple of 4, else 1 -- chosen by the host from C alone, so every shard of a batch agrees) that one
+// workgroup draws back to back, so the Philox seeding cost is paid once per group instead of once per plane.
+// Three streams per slot:  R = radius uniforms and T = angle uniforms of the interior columns 0 < kx < W/2,
+// E = both uniforms of the two edge columns kx = 0, W/2 (slot ky).  The statistics pass (Parseval) needs only R and E:
+// |z|^2 = -ln(u_R) for a unit complex normal, so it skips half of the generator steps and all of sqrt / sin / cos.
+struct SpectrumRng {
+    Xoshiro R, T, E;
+};
+
+template <int H, bool NEED_T>
+__device__ __forceinline__ SpectrumRng spectrum_rng(uint64_t seed, uint64_t stream_id, int64_t ggroup, int tid) {
+    SpectrumRng g;
+    g.R = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 0u, (uint32_t)tid);
+    if constexpr (NEED_T) g.T = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 1u, (uint32_t)tid);
+    else g.T = Xoshiro{0, 0, 0, 1};
+    g.E = Xoshiro{0, 0, 0, 1};
+    if (tid < H) g.E = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 2u, (uint32_t)tid);
+    return g;
+}
+
+// interior element order: q in [0, H (M - 1)): ky = q / (M - 1), kx = 1 + q % (M - 1); slot `tid` draws the pairs
+// (q, q + H (M - 1) / 2) for q = tid, tid + NT, ... (the partner sits H/2 rows below, same column)
+template <int H, int W, typename Edge, typename Inner>
+__device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge, Inner&& inner) {
+    constexpr int NT = kFftThreads, M = W / 2, MI = M - 1, HALF = (H / 2) * MI;
+    if (tid < H) {  // (u_r, u_t) of kx = 0, then of kx = M, row ky = tid (drawn in this order)
+        const uint32_t r0 = g.E.next();
+        const uint32_t t0 = g.E.next();
+        const uint32_t rm = g.E.next();
+        const uint32_t tm = g.E.next();
+        edge(r0, t0, rm, tm);
+    }
+    int ky = tid / MI, kx = 1 + tid - ky * MI;
+    constexpr int DKY = NT / MI, DKX = NT - DKY * MI;
+    for (int q = tid; q < HALF; q += NT) {
+        inner(ky, kx, g);
+        kx += DKX;
+        ky += DKY;
+        if (kx > MI) {
+            kx -= MI;
+            ky += 1;
+        }
+    }
+}
+
+constexpr float kRs = 0.70710678118654752f;  // complex normal: (a + ib) / sqrt(2)
+
+// filtered spectrum of one generated plane -> sink(ky, kx, value)
+template <int H, int W, typename Sink>
+__device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter, SpectrumRng& g, int tid, Sink&& sink) {
+    constexpr int M = W / 2, Wh = M + 1;
+    draw_plane<H, W>(
+        g, tid,
+        [&](uint32_t r0, uint32_t t0, uint32_t rm, uint32_t tm) {
+            float a, b, c, d;
+            box_muller(r0, t0, a, b);
+            box_muller(rm, tm, c, d);
+            const float f0 = filter[tid * Wh], fm = filter[tid * Wh + M];  // (n / sqrt 2) * f: the replay path's rounding
+            sink(tid, 0, make_float2(a * kRs * f0, b * kRs * f0));
+            sink(tid, M, make_float2(c * kRs * fm, d * kRs * fm));
+        },
+        [&](int ky, int kx, SpectrumRng& gg) {
+            const uint32_t ra = gg.R.next();
+            const uint32_t rb = gg.R.next();
+            const uint32_t ta = gg.T.next();
+            const uint32_t tb = gg.T.next();
+            float a, b, c, d;
+            box_muller(ra, ta, a, b);
+            box_muller(rb, tb, c, d);
+            const float fa = filter[ky * Wh + kx], fb = filter[(ky + H / 2) * Wh + kx];
+            sink(ky, kx, make_float2(a * kRs * fa, b * kRs * fa));
+            sink(ky + H / 2, kx, make_float2(c * kRs * fb, d * kRs * fb));
+        });
+}
+
+// One supplied plane's filtered half-spectrum (replay) -> sink(ky, kx, value); thread `tid` handles the complex pair at
+// linear indices j and j + NC/2 (j = it*NT + tid), so consecutive lanes touch consecutive elements.
+template <int H, int W, typename Sink>
+__device__ __forceinline__ void fill_plane(const float* __restrict__ z, const float* __restrict__ filter, int64_t plane, int tid,
+                                           Sink&& sink) {
     constexpr int NT = kFftThreads;
     constexpr int Wh = W / 2 + 1, NC = H * Wh, HALF = NC / 2;
-    Xoshiro rng{0, 0, 0, 0};
-    if constexpr (GEN) rng = rng_stream(seed, stream_id, (uint64_t)gplane, (uint32_t)tid);
     // (ky, kx) of linear index j, advanced incrementally (no per-element division); the partner element
     // j + HALF = j + (H/2) * Wh sits in the same column, H/2 rows below
     int ky = tid / Wh, kx = tid - ky * Wh;
     constexpr int DKY = NT / Wh, DKX = NT - DKY * Wh;
-#pragma unroll UNROLL
+    const c32* zp = reinterpret_cast<const c32*>(z) + plane * NC;
+#pragma unroll 2
     for (int j = tid; j < HALF; j += NT) {
-        c32 za, zb;
-        if constexpr (GEN) {
-            float n[4];
-            rng.normal4(n);
-            constexpr float rs = 0.70710678118654752f;  // complex normal: (a + ib) * sqrt(1/2)
-            za = make_float2(n[0] * rs, n[1] * rs);
-            zb = make_float2(n[2] * rs, n[3] * rs);
-        } else {
-            const c32* zp = reinterpret_cast<const c32*>(z) + plane * NC;
-            za = zp[j];
-            zb = zp[j + HALF];
-        }
+        c32 za = zp[j], zb = zp[j + HALF];
         const float fa = filter[j], fb = filter[j + HALF];
         za.x *= fa; za.y *= fa;
         zb.x *= fb; zb.y *= fb;
@@ -189,7 +253,7 @@ template <int H, int W, int SRC, bool STATS, bool NORM>
 __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_kernel(const float* __restrict__ z,
                                                                        const float* __restrict__ filter, float* out,
                                                                        int64_t planes, uint64_t seed, uint64_t stream_id,
-                                                                       int64_t plane_offset, double* partials, NormArgs na) {
+                                                                       int64_t plane_offset, int group, double* partials, NormArgs na) {
     using C = PlaneCfg<H, W>;
     constexpr int NT = kFftThreads;
     constexpr int M = C::M, S = C::S;
@@ -237,13 +301,18 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
         for (int k1 = 0; k1 < RN1; ++k1) ptw[k1] = c_tw256[((wv * k1) * (256 / M)) & 255];
     }
 
-    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
+    // one workgroup draws the `group` planes of an RNG group back to back (group = 1 unless generating)
+    for (int64_t grp = blockIdx.x; grp * group < planes; grp += gridDim.x) {
+    SpectrumRng rng;
+    if constexpr (GEN) rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + grp, tid);
+    for (int gp = 0; gp < group; ++gp) {
+        const int64_t plane = grp * group + gp;
         __syncthreads();  // previous plane's LDS reads are done (and TW is visible)
         if constexpr (SRC != 2) {
         // ---------------------------------------------------------------- fill: z * filter
-        fill_plane<H, W, GEN>(z, filter, plane, plane_offset + plane, seed, stream_id, tid, [&](int ky, int kx, c32 v) {
-            (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v;
-        });
+        auto sink = [&](int ky, int kx, c32 v) { (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v; };
+        if constexpr (GEN) fill_plane_gen<H, W>(filter, rng, tid, sink);
+        else fill_plane<H, W>(z, filter, plane, tid, sink);
         __syncthreads();
         } else {
         // ---------------------------------------------------------------- forward r2c of a real plane (mirror of the inverse:
@@ -531,6 +600,7 @@ SONAR_UNROLL_ITEMS
             q += (double)pq;
         }
     }
+    }
     if constexpr (STATS) write_partial<NT>(s, q, partials, red);
 }
 
@@ -540,8 +610,9 @@ SONAR_UNROLL_ITEMS
 // (only the Hermitian-symmetric part of the kx = 0 and kx = M columns survives the c2r stage).
 template <int H, int W>
 __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* __restrict__ filter, int64_t planes, uint64_t seed,
-                                                                   uint64_t stream_id, int64_t plane_offset, double* partials) {
-    constexpr int NT = kFftThreads, M = W / 2;
+                                                                   uint64_t stream_id, int64_t plane_offset, int group,
+                                                                   double* partials) {
+    constexpr int NT = kFftThreads, M = W / 2, Wh = M + 1;
     __shared__ c32 EDGE[2][2][H];  // [plane parity][kx = 0 | kx = M][ky]: double-buffered -> one barrier per plane
     __shared__ double red[2 * NT / 64];
     const int tid = threadIdx.x;
@@ -558,39 +629,68 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* _
         }
         q += (double)edge;
     };
-    bool pending = false;
-    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
-        float acc = 0.0f;
-        fill_plane<H, W, true, 4>(nullptr, filter, plane, plane_offset + plane, seed, stream_id, tid, [&](int ky, int kx, c32 v) {
-            if (kx == 0) EDGE[par][0][ky] = v;
-            else if (kx == M) EDGE[par][1][ky] = v;
-            else acc = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, acc));
-        });
-        q += 2.0 * (double)acc;
-        __syncthreads();           // this plane's edge columns are complete; the other buffer's readers finished last iteration
-        edge_terms(par);           // overlaps with the next plane's fill (which writes the other buffer)
-        par ^= 1;
-        pending = true;
+    for (int64_t grp = blockIdx.x; grp * group < planes; grp += gridDim.x) {
+        SpectrumRng rng = spectrum_rng<H, false>(seed, stream_id, plane_offset / group + grp, tid);
+        for (int gp = 0; gp < group; ++gp) {
+            float acc = 0.0f;
+            draw_plane<H, W>(
+                rng, tid,
+                [&](uint32_t r0, uint32_t t0, uint32_t rm, uint32_t tm) {
+                    float a, b, c, d;
+                    box_muller(r0, t0, a, b);
+                    box_muller(rm, tm, c, d);
+                    const float f0 = filter[tid * Wh], fm = filter[tid * Wh + M];
+                    EDGE[par][0][tid] = make_float2(a * kRs * f0, b * kRs * f0);
+                    EDGE[par][1][tid] = make_float2(c * kRs * fm, d * kRs * fm);
+                },
+                [&](int ky, int kx, SpectrumRng& gg) {
+                    // |z f|^2 = f^2 r^2 / 2 = f^2 * (-ln u) with the radius uniform u alone (same u01_open as box_muller)
+                    const uint32_t ra = gg.R.next();
+                    const uint32_t rb = gg.R.next();
+                    const float la = -0.6931471805599453f * __builtin_amdgcn_logf(u01_open(ra));
+                    const float lb = -0.6931471805599453f * __builtin_amdgcn_logf(u01_open(rb));
+                    const float fa = filter[ky * Wh + kx], fb = filter[(ky + H / 2) * Wh + kx];
+                    acc = __builtin_fmaf(fa * fa, la, __builtin_fmaf(fb * fb, lb, acc));
+                });
+            q += 2.0 * (double)acc;
+            __syncthreads();           // this plane's edge columns are complete; the other buffer's readers finished last iteration
+            edge_terms(par);           // overlaps with the next plane's draw (which writes the other buffer)
+            par ^= 1;
+        }
     }
-    (void)pending;
     write_partial<NT>(s, q, partials, red);
 }
 
+// the spectrum draw_plane yields for (seed, stream_id, plane_offset, group), unit filter: zout[planes][H][W/2+1] complex64
 template <int H, int W>
 __global__ void __launch_bounds__(kFftThreads) power_spectrum_kernel(float* zout, int64_t planes, uint64_t seed, uint64_t stream_id,
-                                                                      int64_t plane_offset) {
-    constexpr int Wh = W / 2 + 1, NC = H * Wh;
-    // unit filter: read from a one-element "filter" would need H*Wh ones; inline the draw instead
+                                                                      int64_t plane_offset, int group) {
+    constexpr int M = W / 2, Wh = M + 1, NC = H * Wh;
     const int tid = threadIdx.x;
-    for (int64_t plane = blockIdx.x; plane < planes; plane += gridDim.x) {
-        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)(plane_offset + plane), (uint32_t)tid);
-        c32* zp = reinterpret_cast<c32*>(zout) + plane * NC;
-        for (int j = tid; j < NC / 2; j += kFftThreads) {
-            float n[4];
-            rng.normal4(n);
-            constexpr float rs = 0.70710678118654752f;
-            zp[j] = make_float2(n[0] * rs, n[1] * rs);
-            zp[j + NC / 2] = make_float2(n[2] * rs, n[3] * rs);
+    for (int64_t grp = blockIdx.x; grp * group < planes; grp += gridDim.x) {
+        SpectrumRng rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + grp, tid);
+        for (int gp = 0; gp < group; ++gp) {
+            c32* zp = reinterpret_cast<c32*>(zout) + (grp * group + gp) * NC;
+            draw_plane<H, W>(
+                rng, tid,
+                [&](uint32_t r0, uint32_t t0, uint32_t rm, uint32_t tm) {
+                    float a, b, c, d;
+                    box_muller(r0, t0, a, b);
+                    box_muller(rm, tm, c, d);
+                    zp[tid * Wh] = make_float2(a * kRs, b * kRs);
+                    zp[tid * Wh + M] = make_float2(c * kRs, d * kRs);
+                },
+                [&](int ky, int kx, SpectrumRng& gg) {
+                    const uint32_t ra = gg.R.next();
+                    const uint32_t rb = gg.R.next();
+                    const uint32_t ta = gg.T.next();
+                    const uint32_t tb = gg.T.next();
+                    float a, b, c, d;
+                    box_muller(ra, ta, a, b);
+                    box_muller(rb, tb, c, d);
+                    zp[ky * Wh + kx] = make_float2(a * kRs, b * kRs);
+                    zp[(ky + H / 2) * Wh + kx] = make_float2(c * kRs, d * kRs);
+                });
         }
     }
 }
@@ -608,18 +708,19 @@ static int power_grid(int64_t planes) {
 //       2 = dump the drawn spectrum into `out`, 3 = spectral filter of the real planes `z`
 template <int H, int W>
 static int launch_power(int what, const float* z, const float* filter, float* out, int64_t planes, uint64_t seed,
-                        uint64_t stream_id, int64_t plane_offset, double* partials, NormArgs na, hipStream_t st) {
-    const int g = power_grid<H, W>(planes);
+                        uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st) {
+    const int64_t ngroups = planes / group;
+    const int g = power_grid<H, W>(ngroups);
     const dim3 blk(kFftThreads);
 #define SONAR_PW(G, ST, NM, PART) \
-    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(g), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, PART, na)
+    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(g), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, group, PART, na)
     if (what == 3) {
         if (partials) SONAR_PW(2, true, false, partials); else SONAR_PW(2, false, false, partials);
     } else if (what == 2) {
-        hipLaunchKernelGGL((power_spectrum_kernel<H, W>), dim3(std::min<int64_t>(planes, 2048)), blk, 0, st, out, planes, seed, stream_id, plane_offset);
+        hipLaunchKernelGGL((power_spectrum_kernel<H, W>), dim3(std::min<int64_t>(ngroups, 2048)), blk, 0, st, out, planes, seed, stream_id, plane_offset, group);
     } else if (what == 1) {
-        hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(planes, kNPart)), blk, 0, st, filter, planes, seed, stream_id,
-                           plane_offset, partials);
+        hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(ngroups, kNPart)), blk, 0, st, filter, planes, seed, stream_id,
+                           plane_offset, group, partials);
         SONAR_PW(1, false, true, nullptr);
     } else if (z == nullptr) {
         if (partials) SONAR_PW(1, true, false, partials); else SONAR_PW(1, false, false, partials);
@@ -665,9 +766,15 @@ __global__ void __launch_bounds__(kBlock) channel_mix_kernel(const float* __rest
 using namespace sonar;
 
 static int power_dispatch(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,
-                          uint64_t seed, uint64_t stream_id, int64_t plane_offset, double* partials, NormArgs na, hipStream_t st) {
+                          uint64_t seed, uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na,
+                          hipStream_t st) {
+    const bool gen = what == 1 || what == 2 || (what == 0 && z == nullptr);
+    if (!gen) group = 1;
+    SONAR_REQUIRE(group >= 1 && planes % group == 0 && plane_offset % group == 0, SONAR_ERR_ARG,
+                  "sonar_power_*: planes (%lld) and plane_offset (%lld) must be multiples of the RNG group (%d)", (long long)planes,
+                  (long long)plane_offset, group);
 #define SONAR_CASE(HH, WW) \
-    if (H == HH && W == WW) return launch_power<HH, WW>(what, z, filter, out, planes, seed, stream_id, plane_offset, partials, na, st)
+    if (H == HH && W == WW) return launch_power<HH, WW>(what, z, filter, out, planes, seed, stream_id, plane_offset, group, partials, na, st)
     SONAR_CASE(128, 128);
     SONAR_CASE(64, 64);
     SONAR_CASE(32, 32);
@@ -686,25 +793,25 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
 }
 
 extern "C" int sonar_power_irfft2_f32(const float* z, const float* filter, float* out, int64_t planes, int64_t H,
-                                      int64_t W, uint64_t seed, uint64_t stream_id, int64_t plane_offset,
+                                      int64_t W, uint64_t seed, uint64_t stream_id, int64_t plane_offset, int rng_group,
                                       double* partials, void* stream) {
     SONAR_REQUIRE(filter && out && planes >= 0 && H > 0 && W > 0 && plane_offset >= 0, SONAR_ERR_ARG,
                   "sonar_power_irfft2_f32: bad argument");
     SONAR_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (z == nullptr || (reinterpret_cast<uintptr_t>(z) & 7u) == 0),
                   SONAR_ERR_ARG, "sonar_power_irfft2_f32: misaligned buffer");
     if (planes == 0) return SONAR_OK;
-    return power_dispatch(0, z, filter, out, planes, H, W, seed, stream_id, plane_offset, partials, NormArgs{nullptr, 0, 1.0f, 0.0f},
-                          (hipStream_t)stream);
+    return power_dispatch(0, z, filter, out, planes, H, W, seed, stream_id, plane_offset, rng_group, partials,
+                          NormArgs{nullptr, 0, 1.0f, 0.0f}, (hipStream_t)stream);
 }
 
 extern "C" int sonar_power_noise_f32(const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
-                                     uint64_t stream_id, int64_t plane_offset, float factor, float threshold_std_devs,
-                                     double* partials, void* stream) {
+                                     uint64_t stream_id, int64_t plane_offset, int rng_group, float factor,
+                                     float threshold_std_devs, double* partials, void* stream) {
     SONAR_REQUIRE(filter && out && partials && planes >= 0 && H > 0 && W > 0 && plane_offset >= 0, SONAR_ERR_ARG,
                   "sonar_power_noise_f32: bad argument");
     SONAR_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0, SONAR_ERR_ARG, "sonar_power_noise_f32: misaligned buffer");
     if (planes == 0) return SONAR_OK;
-    return power_dispatch(1, nullptr, filter, out, planes, H, W, seed, stream_id, plane_offset, partials,
+    return power_dispatch(1, nullptr, filter, out, planes, H, W, seed, stream_id, plane_offset, rng_group, partials,
                           NormArgs{partials, planes * H * W, factor, threshold_std_devs}, (hipStream_t)stream);
 }
 
@@ -715,15 +822,15 @@ extern "C" int sonar_spectral_filter_f32(const float* x, const float* filter, fl
     SONAR_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0, SONAR_ERR_ARG,
                   "sonar_spectral_filter_f32: misaligned buffer");
     if (planes == 0) return SONAR_OK;
-    return power_dispatch(3, x, filter, out, planes, H, W, 0, 0, 0, partials, NormArgs{nullptr, 0, 1.0f, 0.0f}, (hipStream_t)stream);
+    return power_dispatch(3, x, filter, out, planes, H, W, 0, 0, 0, 1, partials, NormArgs{nullptr, 0, 1.0f, 0.0f}, (hipStream_t)stream);
 }
 
 extern "C" int sonar_power_spectrum_f32(float* z_out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,
-                                        int64_t plane_offset, void* stream) {
+                                        int64_t plane_offset, int rng_group, void* stream) {
     SONAR_REQUIRE(z_out && planes >= 0 && H > 0 && W > 0 && plane_offset >= 0, SONAR_ERR_ARG, "sonar_power_spectrum_f32: bad argument");
     if (planes == 0) return SONAR_OK;
-    return power_dispatch(2, nullptr, nullptr, z_out, planes, H, W, seed, stream_id, plane_offset, nullptr, NormArgs{nullptr, 0, 1.0f, 0.0f},
-                          (hipStream_t)stream);
+    return power_dispatch(2, nullptr, nullptr, z_out, planes, H, W, seed, stream_id, plane_offset, rng_group, nullptr,
+                          NormArgs{nullptr, 0, 1.0f, 0.0f}, (hipStream_t)stream);
 }
 
 extern "C" int sonar_channel_mix_f32(const float* in, const float* mixer, float* out, int64_t B, int64_t C, int64_t hw,

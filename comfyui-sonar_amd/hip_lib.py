@@ -89,9 +89,9 @@ SIGNATURES = {
     "sonar_resample_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I64, _F, _I, _I, _P, _P]),
     "sonar_pyramid_generate_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _P, _P]),
     "sonar_pyramid_noise_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _F, _F, _P, _P]),
-    "sonar_power_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _F, _F, _P, _P]),
-    "sonar_power_spectrum_f32": (_I, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _P]),
-    "sonar_power_irfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _P, _P]),
+    "sonar_power_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _P]),
+    "sonar_power_spectrum_f32": (_I, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _P]),
+    "sonar_power_irfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _P, _P]),
     "sonar_spectral_filter_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "sonar_std_scale_f32": (_I, [_P, _I64, _F, _P, _I64, _I64, _P]),
     "sonar_channel_mix_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
@@ -521,6 +521,11 @@ def pyramid_noise(shape, device, levels: Sequence, mode: str, seed: int, stream_
     return out
 
 
+def rng_group_for(shape) -> int:
+    """RNG group of the device spectrum draws: a function of the channel count only, so every shard of a batch agrees."""
+    return 4 if len(shape) >= 3 and shape[-3] % 4 == 0 else 1
+
+
 def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: int = 0, stream_id: int = 0, plane_offset: int = 0,
                  partials=None) -> torch.Tensor:
     """out[shape] = irfft2(z * filt, norm='ortho'); z = None draws the spectrum on device."""
@@ -539,7 +544,7 @@ def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: 
     with _Timed("power_irfft2"):
         _check(
             load().sonar_power_irfft2_f32(zp, _dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
-                                          _opt(partials, "partials", torch.float64), _stream()),
+                                          rng_group_for(shape), _opt(partials, "partials", torch.float64), _stream()),
             "sonar_power_irfft2_f32",
         )
     return out
@@ -555,7 +560,7 @@ def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_o
     with _Timed("power_noise"):
         _check(
             load().sonar_power_noise_f32(_dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
-                                         float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
+                                         rng_group_for(shape), float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
             "sonar_power_noise_f32",
         )
     return out
@@ -585,7 +590,7 @@ def power_spectrum(shape, device, *, seed: int, stream_id: int, plane_offset: in
     H, W = shape[-2:]
     z = torch.empty((*shape[:-1], W // 2 + 1), dtype=torch.complex64, device=device)
     planes = z.numel() // (H * (W // 2 + 1))
-    _check(load().sonar_power_spectrum_f32(z.data_ptr(), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset, _stream()),
+    _check(load().sonar_power_spectrum_f32(z.data_ptr(), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset, rng_group_for(shape), _stream()),
            "sonar_power_spectrum_f32")
     return z
 

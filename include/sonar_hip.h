@@ -193,21 +193,26 @@ int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, in
 /* ---------------------------------------------------------------- power-law rFFT noise (row PW) */
 /* py/nodes/powernoise.py:366-377: out = irfft2(z * filter, s=(H,W), norm="ortho").
  *   z      [planes][H][W/2+1] complex64 (interleaved re,im) or NULL -> drawn on device: complex normal
- *          (a+ib)*sqrt(1/2); plane p of this call is global plane plane_offset + p of the logical batch
+ *          (a+ib)*sqrt(1/2); plane p of this call is global plane plane_offset + p of the logical batch.
+ *   rng_group  device draws are keyed per group of `rng_group` consecutive global planes (the Philox seeding of the
+ *          xoshiro bursts is paid once per group); planes and plane_offset must be multiples of it.  It is part of
+ *          the stream definition: every shard of a batch must pass the same value (the host uses 4 when C % 4 == 0,
+ *          else 1).  Ignored when z is supplied.
  *   filter [H][W/2+1] fp32 (broadcast over planes)
  * Supported: H, W powers of two in 16..256 with the half-spectrum LDS-resident (else SONAR_ERR_UNSUPPORTED). */
 int sonar_power_irfft2_f32(const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,
-                           uint64_t seed, uint64_t stream_id, int64_t plane_offset, double* partials /*nullable*/,
-                           void* stream);
+                           uint64_t seed, uint64_t stream_id, int64_t plane_offset, int rng_group,
+                           double* partials /*nullable*/, void* stream);
 /* draw + filter + irfft2 + scale_noise(factor, normalized=True) writing the tensor ONCE: the output statistics are
- * obtained from the spectrum by Parseval's identity in a first RNG-only pass (no FFT, no stores). */
+ * obtained from the spectrum by Parseval's identity in a first RNG-only pass (no FFT, no stores; only the radius
+ * uniforms of the interior columns and the two edge columns are drawn there). */
 int sonar_power_noise_f32(const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
-                          uint64_t stream_id, int64_t plane_offset, float factor, float threshold_std_devs,
+                          uint64_t stream_id, int64_t plane_offset, int rng_group, float factor, float threshold_std_devs,
                           double* partials /*workspace*/, void* stream);
-/* the spectrum the two entry points above draw for (seed, stream_id, plane_offset): z_out[planes][H][W/2+1] complex64
- * (tests / replaying a device draw) */
+/* the spectrum the two entry points above draw for (seed, stream_id, plane_offset, rng_group):
+ * z_out[planes][H][W/2+1] complex64 (tests / replaying a device draw) */
 int sonar_power_spectrum_f32(float* z_out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,
-                             int64_t plane_offset, void* stream);
+                             int64_t plane_offset, int rng_group, void* stream);
 /* spectral filter of real planes: out = irfft2(rfft2(x, norm="ortho") * filter, s=(H,W), norm="ortho") with
  * filter[H][W/2+1] real; forward and inverse FFT both LDS-resident, x read once, out written once (x != out).
  * PowerFilterNoiseItem / time_brownian path (py/nodes/powernoise.py:356-366,471-522) and, with a symmetrised

@@ -381,7 +381,7 @@ def test_power_generate_equals_replay_of_device_draws(hl):
     h, w = shape[-2:]
     filt = dev(torch.rand(h, w // 2 + 1) + 0.25)
     z = hl.power_spectrum(shape, "cuda", seed=77, stream_id=9, plane_offset=12)  # as if three latents preceded this shard
-    assert abs(z.real.std().item() - math.sqrt(0.5)) < 2e-3 and abs(z.imag.mean().item()) < 2e-3
+    assert abs(z.real.std().item() - math.sqrt(0.5)) < 3e-3 and abs(z.imag.mean().item()) < 6e-3  # 166k samples: sigma of the mean = 1.7e-3
     p1 = hl.new_partials("cuda")
     got = hl.power_irfft2(None, filt, shape, seed=77, stream_id=9, plane_offset=12, partials=p1)
     want = hl.power_irfft2(z, filt, shape)
@@ -394,6 +394,15 @@ def test_power_generate_equals_replay_of_device_draws(hl):
     a = hl.power_spectrum((2, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=12)
     b = hl.power_spectrum((3, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=20)
     assert torch.equal(torch.cat((a, b)), z)
+    # channel counts that are not a multiple of 4 use per-plane streams (group 1), still shard-invariant
+    z3 = hl.power_spectrum((4, 3, 32, 32), "cuda", seed=1, stream_id=0, plane_offset=3)
+    a3 = hl.power_spectrum((1, 3, 32, 32), "cuda", seed=1, stream_id=0, plane_offset=3)
+    b3 = hl.power_spectrum((3, 3, 32, 32), "cuda", seed=1, stream_id=0, plane_offset=6)
+    assert torch.equal(torch.cat((a3, b3)), z3)
+    assert abs(z3.real.std().item() - math.sqrt(0.5)) < 1e-2
+    # an offset that splits an RNG group is refused
+    with pytest.raises(hl.SonarHipError):
+        hl.power_spectrum((2, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=2)
 
 
 @pytest.mark.parametrize("hw", [(128, 128), (64, 64), (32, 64)])
@@ -413,7 +422,7 @@ def test_power_noise_fused_normalisation(hl, hw, factor):
     assert abs(fused.std().item() - factor) < 2e-4 * factor + 1e-5
     # the Parseval statistics themselves
     ws = hl.new_partials("cuda")
-    hl._check(hl.load().sonar_power_noise_f32(filt.data_ptr(), fused.data_ptr(), 24, h, w, 5, 2, 8, 1.0, 2.5, ws.data_ptr(),
+    hl._check(hl.load().sonar_power_noise_f32(filt.data_ptr(), fused.data_ptr(), 24, h, w, 5, 2, 8, 4, 1.0, 2.5, ws.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream), "power_noise")
     pars = hl.stats_finalize(ws, fused.numel()).cpu()
     assert abs(pars[1].item() - actual[1].item()) < 2e-5 * actual[1].item()
