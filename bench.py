@@ -80,8 +80,8 @@ def time_calls(fn, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,24 +123,29 @@ def main():
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
-        hl.enable_kernel_timing(("power_noise",))
+        # HIP events on the launch stream (torch's current stream is the stream every sonar_* call launches on) bracket the
+        # timed region: average launch-pair duration = event span / steps.  (Per-call event pairs perturb the pipeline:
+        # they add ~10 us of idle time per step.)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(args.steps):
             step()
+        ev1.record()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        span_ms = ev0.elapsed_time(ev1)
         if distributed:
             dist.barrier()
             t = torch.tensor([elapsed], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = t.item()
-        kt = hl.collect_kernel_timing()
 
         out = None
         if rank == 0:
             value = n_gpus * BATCH * args.steps / elapsed
-            fused_ms = sum(kt["power_noise"]) / max(len(kt["power_noise"]), 1)
+            fused_ms = span_ms / args.steps
             # sonar_power_noise_f32 = statistics pass (re-draw, Parseval, no stores) + final pass (draw, filter, LDS-resident C2R FFT,
             # normalise, ONE write).  Official accounting: normalised generate = 12N bytes per latent
             # (write, read, write of the reference-structured path); this implementation's real traffic is 4N.

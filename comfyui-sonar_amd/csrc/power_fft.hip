@@ -273,11 +273,13 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
     constexpr bool GEN = SRC == 1;
     // norm="ortho" on the inverse; the spectral filter also carries the forward transform's 1/sqrt(HW)
     float scale = SRC == 2 ? 1.0f / ((float)H * (float)W) : 1.0f / sqrtf((float)H * (float)W);
-    NormDecision dec{0.f, 1.f, 0, 0};
-    float inv_std = 1.0f;
+    // normalised output = (v * scale - mean) / std * factor folded into one multiply-add per value: v * nm - nc
+    float nm = scale, nc = 0.0f;
     if constexpr (NORM) {
-        dec = decide_norm<NT>(na.partials, kNPart, na.n_total, na.thr_sd, red, &shd);
-        inv_std = dec.do_div ? 1.0f / dec.stdv : 1.0f;
+        const NormDecision dec = decide_norm<NT>(na.partials, kNPart, na.n_total, na.thr_sd, red, &shd);
+        const float g = (dec.do_div ? 1.0f / dec.stdv : 1.0f) * na.factor;
+        nm = scale * g;
+        nc = dec.do_sub ? dec.mean * g : 0.0f;
     }
     double s = 0.0, q = 0.0;
     for (int j = tid; j < 256; j += NT) TW[j] = c_tw256[j];
@@ -582,11 +584,13 @@ SONAR_UNROLL_ITEMS
             float* orow = oplane + (int64_t)y * W;
 #pragma unroll
             for (int k2 = 0; k2 < RN2; ++k2) {
-                float a = u[k2].x * scale, b = u[k2].y * scale;
+                float a, b;
                 if constexpr (NORM) {
-                    if (dec.do_sub) { a -= dec.mean; b -= dec.mean; }
-                    a = a * inv_std * na.factor;
-                    b = b * inv_std * na.factor;
+                    a = __builtin_fmaf(u[k2].x, nm, -nc);
+                    b = __builtin_fmaf(u[k2].y, nm, -nc);
+                } else {
+                    a = u[k2].x * scale;
+                    b = u[k2].y * scale;
                 }
                 *reinterpret_cast<float2*>(orow + 2 * (k1 + RN1 * k2)) = make_float2(a, b);
                 if constexpr (STATS) {
