@@ -284,7 +284,7 @@ static int launch_perlin_generate(const float* terms, float* out, int64_t B, int
 
 // ------------------------------------------------------------------------------------------------
 // Resampling (F.interpolate semantics, ATen UpSampleKernel index/weight rules).
-struct Lin {
+struct alignas(16) Lin {
     int i0, i1;
     float w0, w1;
 };
@@ -355,15 +355,18 @@ __global__ void __launch_bounds__(kBlock) resample_acc_kernel(float* dst, const 
     if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
 }
 
-// Pyramid, generate mode: out = N(0,1)[stream] + N(0,1)[stream+1]*w0 + sum_l bilerp(level_l)*w_l
+// Pyramid, generate mode: out = N(0,1)[stream] * base_scale + sum_l bilerp(level_l) * w_l.  A level with the latent's own
+// size (the reference's i = 0 level: ratio r^0 = 1) is one more independent N(0,1) per element times w0; the sum of the two
+// independent normals is drawn as ONE normal scaled by sqrt(1 + w0^2) (same distribution, half the generator work).
 constexpr int kMaxLevels = 12;
 struct PyramidLevels {
     const float* ptr[kMaxLevels];
     int h[kMaxLevels], w[kMaxLevels];
     float weight[kMaxLevels];
     int count;       // small-grid levels
-    int fullres;     // number of leading full-resolution levels drawn in-kernel (0 or 1)
+    int fullres;     // number of leading full-resolution levels folded into the base draw (0 or 1)
     float fullres_weight;
+    float base_scale;  // sqrt(1 + fullres_weight^2) when fullres else 1
 };
 
 // MODE as in perlin_generate_kernel (0 raw (+stats), 1 statistics only, 2 normalised final).
@@ -386,16 +389,13 @@ __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, in
     const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
     for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
         Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
-        Xoshiro rng2 = rng_stream(seed, stream_id + 1, (uint64_t)tile, lane);
         const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
         for (int it = 0; it < kTileIters; ++it) {
             float v[4];
             rng.normal4(v);
             if (lv.fullres) {
-                float z[4];
-                rng2.normal4(z);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += lv.fullres_weight != 1.0f ? z[k] * lv.fullres_weight : z[k];
+                for (int k = 0; k < 4; ++k) v[k] *= lv.base_scale;
             }
             const int64_t e = base + it * 256;
             if (e < 0 || e >= n) continue;
@@ -437,10 +437,132 @@ __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, in
     if constexpr (STATS || MODE == 1) write_partial<kBlock>(s, q, partials, red);
 }
 
+// One workgroup per plane, the plane's level grids staged in LDS (they are re-read ~4 H W / (h w) times each by the
+// bilinear gathers); the four waves stride over the plane's RNG tiles.  Same values as the flat kernel above.
+// Requires H * W % kTileElems == 0 and elem_offset % (H * W) == 0 (whole planes, tile-aligned).
+constexpr size_t kPyramidLdsBudget = 48 * 1024;
+
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
+                                                               uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                                               double* partials, int grid_floats) {
+    extern __shared__ __align__(16) float pyr_lds[];
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
+    const int HW = H * W;
+    const int tiles_per_plane = HW / kTileElems;
+    const uint32_t lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int dy = 256 / W, dx = 256 - dy * W;  // one burst step advances 256 elements
+    // bilinear source coordinates depend on (level, x) and (level, y) only: tabulated once per workgroup
+    Lin* const xtab = reinterpret_cast<Lin*>(pyr_lds + grid_floats);  // [level][W]
+    Lin* const ytab = xtab + lv.count * W;                            // [level][H]
+    if (mode == 0) {
+        for (int l = 0; l < lv.count; ++l) {
+            const float sy = (float)lv.h[l] / (float)H, sx = (float)lv.w[l] / (float)W;
+            for (int i = threadIdx.x; i < W; i += kBlock) xtab[l * W + i] = lin_coord(i, sx, lv.w[l]);
+            for (int i = threadIdx.x; i < H; i += kBlock) {
+                Lin ly = lin_coord(i, sy, lv.h[l]);
+                ly.i0 *= lv.w[l];  // row offsets
+                ly.i1 *= lv.w[l];
+                ytab[l * H + i] = ly;
+            }
+        }
+    }
+    for (int64_t p = blockIdx.x; p < planes; p += gridDim.x) {
+        __syncthreads();
+        int off = 0;
+        for (int l = 0; l < lv.count; ++l) {
+            const int n = lv.h[l] * lv.w[l];
+            const float* src = lv.ptr[l] + p * (int64_t)n;
+            for (int i = threadIdx.x; i < n; i += kBlock) pyr_lds[off + i] = src[i];
+            off += n;
+        }
+        __syncthreads();
+        float* const oplane = out + p * (int64_t)HW;
+        const int64_t tile0 = (elem_offset + p * (int64_t)HW) / kTileElems;
+        for (int t = wave; t < tiles_per_plane; t += kBlock / 64) {
+            Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)(tile0 + t), lane);
+            int e = t * kTileElems + (int)lane * 4;  // element index inside the plane
+            int y = e / W, x4 = e - y * W;
+            for (int it = 0; it < kTileIters; ++it) {
+                float v[4];
+                rng.normal4(v);
+                if (lv.fullres) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] *= lv.base_scale;
+                }
+                int lo = 0;
+                for (int l = 0; l < lv.count; ++l) {
+                    const int h = lv.h[l], w = lv.w[l];
+                    const float* plane = pyr_lds + lo;
+                    lo += h * w;
+                    const float wt = lv.weight[l];
+                    if (mode == 0) {
+                        const Lin ly = ytab[l * H + y];
+                        const float* r0 = plane + ly.i0;
+                        const float* r1 = plane + ly.i1;
+                        const Lin* xt = xtab + l * W + x4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const Lin lx = xt[k];
+                            const float t0 = r0[lx.i0] * lx.w0 + r0[lx.i1] * lx.w1;
+                            const float t1 = r1[lx.i0] * lx.w0 + r1[lx.i1] * lx.w1;
+                            v[k] += (t0 * ly.w0 + t1 * ly.w1) * wt;
+                        }
+                    } else if (mode == 1) {
+                        const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+                        const float* row = plane + nearest_exact_idx(y, sy, h) * w;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += row[nearest_exact_idx(x4 + k, sx, w)] * wt;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += area_sample(plane, h, w, H, W, y, x4 + k) * wt;
+                    }
+                }
+                *reinterpret_cast<float4*>(oplane + e) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (STATS) {
+                    const float ps = (v[0] + v[1]) + (v[2] + v[3]);
+                    const float pq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3])));
+                    s += (double)ps;
+                    q += (double)pq;
+                }
+                e += 256;
+                y += dy;
+                x4 += dx;
+                if (x4 >= W) {
+                    x4 -= W;
+                    y += 1;
+                }
+            }
+        }
+    }
+    if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+}
+
+// true if the plane kernel was launched
+static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t W, const PyramidLevels& lv, int mode, uint64_t seed,
+                                 uint64_t stream_id, int64_t elem_offset, double* partials, hipStream_t st) {
+    size_t grid_floats = 0;
+    for (int l = 0; l < lv.count; ++l) grid_floats += (size_t)lv.h[l] * lv.w[l];
+    grid_floats = (grid_floats + 3) & ~(size_t)3;  // the coordinate tables that follow are 16-byte entries
+    const size_t lds = grid_floats * sizeof(float) + (mode == 0 ? (size_t)lv.count * (H + W) * sizeof(Lin) : 0);
+    if ((H * W) % kTileElems != 0 || elem_offset % (H * W) != 0 || lds > kPyramidLdsBudget) return false;
+    const int g = (int)std::min<int64_t>(planes, kNPart);
+    if (partials)
+        hipLaunchKernelGGL((pyramid_plane_kernel<true>), dim3(g), dim3(kBlock), lds, st, out, planes, (int)H, (int)W, lv, mode, seed,
+                           stream_id, elem_offset, partials, (int)grid_floats);
+    else
+        hipLaunchKernelGGL((pyramid_plane_kernel<false>), dim3(g), dim3(kBlock), lds, st, out, planes, (int)H, (int)W, lv, mode, seed,
+                           stream_id, elem_offset, partials, (int)grid_floats);
+    return true;
+}
+
 static int fill_levels(PyramidLevels& lv, int64_t H, int64_t W, int64_t nlevels, const float* const* level_ptrs,
                        const int64_t* level_h, const int64_t* level_w, const float* level_weight, const char* what) {
     lv = PyramidLevels{};
     lv.fullres_weight = 1.0f;
+    lv.base_scale = 1.0f;
     SONAR_REQUIRE(nlevels == 0 || (level_ptrs && level_h && level_w && level_weight), SONAR_ERR_ARG, "%s: level arrays missing", what);
     for (int64_t l = 0; l < nlevels; ++l) {
         if (level_ptrs[l] == nullptr) {
@@ -449,6 +571,7 @@ static int fill_levels(PyramidLevels& lv, int64_t H, int64_t W, int64_t nlevels,
                           "%s: only one in-kernel full-resolution level", what);
             lv.fullres = 1;
             lv.fullres_weight = level_weight[l];
+            lv.base_scale = sqrtf(1.0f + level_weight[l] * level_weight[l]);
             continue;
         }
         SONAR_REQUIRE(lv.count < kMaxLevels, SONAR_ERR_UNSUPPORTED, "%s: too many levels", what);
@@ -558,6 +681,8 @@ extern "C" int sonar_pyramid_generate_f32(float* out, int64_t planes, int64_t H,
     rc = fill_levels(lv, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, "sonar_pyramid_generate_f32");
     if (rc != SONAR_OK) return rc;
     if (planes == 0) return SONAR_OK;
+    if (launch_pyramid_plane(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, (hipStream_t)stream))
+        return check_launch("sonar_pyramid_generate_f32");
     const int g = tile_grid(planes * H * W, elem_offset);
     if (partials)
         hipLaunchKernelGGL((pyramid_generate_kernel<0, true>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes,
@@ -580,6 +705,12 @@ extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, in
     rc = fill_levels(lv, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, "sonar_pyramid_noise_f32");
     if (rc != SONAR_OK) return rc;
     if (planes == 0) return SONAR_OK;
+    // The level gathers make a re-draw cost more than a sweep: generate once (with statistics), then normalise in place
+    if (launch_pyramid_plane(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, (hipStream_t)stream)) {
+        rc = check_launch("sonar_pyramid_noise_f32");
+        if (rc != SONAR_OK) return rc;
+        return sonar_scale_noise_f32(out, planes * H * W, factor, 1, threshold_std_devs, partials, kNPart, planes * H * W, stream);
+    }
     const int g = tile_grid(planes * H * W, elem_offset);
     const NormArgs na{partials, planes * H * W, factor, threshold_std_devs};
     hipLaunchKernelGGL((pyramid_generate_kernel<1, false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes, (int)H,

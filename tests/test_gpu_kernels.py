@@ -293,23 +293,31 @@ def test_pyramid_replay_golden(hl, golden, tag):
     close(noise, g[f"{tag}_out"], rtol=2e-5, atol=5e-6)
 
 
-def test_pyramid_generate_is_sum_of_its_levels(hl):
-    shape = (2, 4, 32, 32)
-    planes = 8
-    sizes = [(32, 32), (9, 9), (2, 2), (1, 1)]
+@pytest.mark.parametrize("shape,mode", [((2, 4, 32, 32), "bilinear"), ((3, 4, 64, 64), "bilinear"), ((2, 4, 128, 128), "bilinear"),
+                                        ((2, 4, 64, 64), "nearest-exact"), ((2, 4, 64, 64), "area"), ((2, 3, 32, 48), "bilinear")])
+def test_pyramid_generate_is_sum_of_its_levels(hl, shape, mode):
+    """Generate mode = base draw * sqrt(1 + w0^2) (the full-resolution level folded in: sum of two independent normals)
+    + sum of the resampled small levels.  32x32 and 32x48 planes use the flat kernel, the others the LDS-staged plane kernel."""
+    planes = shape[0] * shape[1]
+    H, W = shape[-2:]
+    sizes = [(H, W), (H // 3 + 1, W // 3 - 1), (2, 3), (1, 1)]
     weights = [1.0, 0.7, 0.49, 0.343]
     seed = 42
     small = [hl.philox_normal((planes, h, w), "cuda", seed, 10 + i) for i, (h, w) in enumerate(sizes[1:])]
-    levels = [(None, 32, 32, 1.0)] + [(t, h, w, wt) for t, (h, w), wt in zip(small, sizes[1:], weights[1:])]
+    levels = [(None, H, W, weights[0])] + [(t, h, w, wt) for t, (h, w), wt in zip(small, sizes[1:], weights[1:])]
     part = hl.new_partials("cuda")
-    got = hl.pyramid_generate(shape, "cuda", levels, "bilinear", seed, 0, 0, part)
-    want = hl.philox_normal(shape, "cuda", seed, 0)
-    hl.axpby_(want, 1.0, hl.philox_normal(shape, "cuda", seed, 1), 1.0)
+    got = hl.pyramid_generate(shape, "cuda", levels, mode, seed, 0, 0, part)
+    want = hl.philox_normal(shape, "cuda", seed, 0) * math.sqrt(1.0 + weights[0] ** 2)
     for t, wt in zip(small, weights[1:]):
-        hl.resample_acc_(want, t, wt, "bilinear", True)
-    close(got, want, rtol=1e-6, atol=1e-6)
+        hl.resample_acc_(want, t, wt, mode, True)
+    close(got, want, rtol=2e-6, atol=2e-6)
     tot = hl.stats_finalize(part, got.numel()).cpu()
     assert abs(tot[0].item() - got.double().sum().item()) < 1e-7 * got.numel()
+    # shard invariance: the second latent alone (elem_offset = one latent, level grids sliced) reproduces its slice
+    per = shape[1] * H * W
+    lv2 = [(None, H, W, weights[0])] + [(t[shape[1]:2 * shape[1]].contiguous(), h, w, wt) for t, (h, w), wt in zip(small, sizes[1:], weights[1:])]
+    one = hl.pyramid_generate((1, *shape[1:]), "cuda", lv2, mode, seed, 0, per, None)
+    assert torch.equal(one[0], got[1])
 
 
 # ------------------------------------------------------------------------------------------------ power-law rFFT noise
