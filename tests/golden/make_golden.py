@@ -588,6 +588,38 @@ def gen_spectral():
     save("spectral", **cases)
 
 
+# ------------------------------------------------------------------------------------------------ cfg5 in miniature (end to end)
+def gen_cfg5():
+    """BASELINE.json cfg5 at test size, through the REAL reference end to end: scheduled (power-law | gaussian fallback) + Perlin
+    chain, normalised, feeding SonarDPMPPSDE with momentum on a Flux-shaped latent (16 channels).  Inputs, per-step x and the
+    final latent are stored; the GPU test drives the same calls with the latent on the MI355X (replay mode)."""
+    S, N, pn = ref.sonar, ref.noise, ref.powernoise
+    shape = (2, 16, 32, 32)
+    torch.manual_seed(61)
+    x0 = torch.randn(shape) * 10.0
+    sigmas = torch.cat((torch.linspace(10.0, 0.5, 6), torch.zeros(1)))
+
+    def build_chain(mod_noise, mod_pn):
+        inner = mod_noise.CustomNoiseChain()
+        inner.add(mod_pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
+                                        mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1"))
+        fallback = mod_noise.CustomNoiseChain()
+        fallback.add(mod_noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+        chain = mod_noise.CustomNoiseChain()
+        chain.add(mod_noise.ScheduledNoise(0.7, noise=inner, start_sigma=20.0, end_sigma=4.0, normalize=None, fallback_noise=fallback))
+        chain.add(mod_noise.CustomNoiseItem(0.5, noise_type="perlin"))
+        return chain
+
+    chain = build_chain(N, pn)
+    params = dict(momentum=0.9, momentum_hist=0.7, direction=1.0, momentum_mode="NEW", init="SAMPLE_NORM")
+    torch.manual_seed(62)
+    ns = chain.make_noise_sampler(x0, sigmas[sigmas > 0].min(), sigmas.max(), seed=5, cpu=True, normalized=True)
+    trace = []
+    out = S.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas, {"seed": 5}, lambda d: trace.append(d["x"].clone()), True, None,
+                                  dict(params), 0.9, 1.05, ns)
+    save("cfg5", x0=x0, sigmas=sigmas, trace_steps=torch.tensor([1, 3]), trace=torch.stack([trace[1], trace[3]]), out=out)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -604,6 +636,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_powerlaw()
     gen_latent_ops()
     gen_spectral()
+    gen_cfg5()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

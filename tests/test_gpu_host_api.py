@@ -379,3 +379,31 @@ def test_global_normalisation_and_sharded_sampler_single_process(api):
                                  seed=None, cpu=False, normalized=False)
     out = sh(*SIG)
     assert out.shape == (6, 4, 32, 32) and torch.equal(sh.gather(out), out)
+
+
+# ------------------------------------------------------------------------------------------------ cfg5 in miniature, end to end
+def test_cfg5_scheduled_power_perlin_chain_with_dpmpp_momentum(api, golden):
+    """BASELINE.json cfg5 at test size, driven exactly like ComfyUI drives the reference: a chain of ScheduledNoise(power-law
+    noise, gaussian fallback below sigma 4) + Perlin, normalised, as the noise sampler of SonarDPMPPSDE with momentum on a
+    Flux-shaped (16-channel) latent.  Golden: the REAL reference end to end (tests/golden/make_golden.py gen_cfg5).
+    6 sampler steps with 2 noise calls each: tolerance rtol/atol 3e-4 on |x| ~ 10."""
+    g = golden("cfg5")
+    N, S, pn = api.noise, api.sonar, api.powernoise
+    x0, sigmas = g["x0"].cuda(), g["sigmas"]
+    inner = N.CustomNoiseChain()
+    inner.add(pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
+                                mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1"))
+    fallback = N.CustomNoiseChain()
+    fallback.add(N.CustomNoiseItem(1.0, noise_type="gaussian"))
+    chain = N.CustomNoiseChain()
+    chain.add(N.ScheduledNoise(0.7, noise=inner, start_sigma=20.0, end_sigma=4.0, normalize=None, fallback_noise=fallback))
+    chain.add(N.CustomNoiseItem(0.5, noise_type="perlin"))
+    params = dict(momentum=0.9, momentum_hist=0.7, direction=1.0, momentum_mode="NEW", init="SAMPLE_NORM")
+    torch.manual_seed(62)
+    ns = chain.make_noise_sampler(x0, sigmas[sigmas > 0].min(), sigmas.max(), seed=5, cpu=True, normalized=True)
+    trace = []
+    out = S.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas, {"seed": 5}, lambda d: trace.append(d["x"].clone()), True, None,
+                                  dict(params), 0.9, 1.05, ns)
+    for row, step in enumerate(g["trace_steps"].tolist()):
+        close(trace[step], g["trace"][row], rtol=3e-4, atol=3e-4)
+    close(out, g["out"], rtol=3e-4, atol=3e-4)
