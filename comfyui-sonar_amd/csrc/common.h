@@ -97,6 +97,15 @@ struct Xoshiro {
         s3 = __builtin_amdgcn_alignbit(s3, s3, 32 - 11);
         return r;
     }
+    // xoshiro128+ output (two fewer operations): only the HIGH bits are equidistributed well enough to use
+    // (its low 4 bits fail linearity tests) -- for consumers that keep bits 31..9 and drop the rest
+    __device__ __forceinline__ uint32_t next_high() {
+        const uint32_t r = s0 + s3;
+        const uint32_t t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t;
+        s3 = __builtin_amdgcn_alignbit(s3, s3, 32 - 11);
+        return r;
+    }
     __device__ __forceinline__ void normal4(float (&z)[4]) {
         const uint32_t a = next(), b = next(), c = next(), d = next();
         box_muller(a, b, z[0], z[1]);

@@ -145,8 +145,8 @@ struct PlaneCfg {
 // Streams are keyed by (seed, stream_id, plane group, thread slot): a group is `group` consecutive global planes (4 when the
 // channel count is a multiple of 4, else 1 -- chosen by the host from C alone, so every shard of a batch agrees) that one
 // workgroup draws back to back, so the Philox seeding cost is paid once per group instead of once per plane.
-// Three streams per slot:  R = radius uniforms and T = angle uniforms of the interior columns 0 < kx < W/2,
-// E = both uniforms of the two edge columns kx = 0, W/2 (slot ky).  The statistics pass (Parseval) needs only R and E:
+// Three streams per slot:  R = radius words and T = angle words of the interior columns 0 < kx < W/2,
+// E = both for the two edge columns kx = 0, W/2 (slot ky).  The statistics pass (Parseval) needs only R and E:
 // |z|^2 = -ln(u_R) for a unit complex normal, so it skips half of the generator steps and all of sqrt / sin / cos.
 struct SpectrumRng {
     Xoshiro R, T, E;
@@ -164,21 +164,25 @@ __device__ __forceinline__ SpectrumRng spectrum_rng(uint64_t seed, uint64_t stre
 }
 
 // interior element order: q in [0, H (M - 1)): ky = q / (M - 1), kx = 1 + q % (M - 1); slot `tid` draws the pairs
-// (q, q + H (M - 1) / 2) for q = tid, tid + NT, ... (the partner sits H/2 rows below, same column)
-template <int H, int W, typename Edge, typename Inner>
-__device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge, Inner&& inner) {
+// (q, q + H (M - 1) / 2) for q = tid, tid + NT, ... (the partner sits H/2 rows below, same column).  Per pair: two radius
+// words from R, ONE angle word from T (low / high half).  edge(r0, rm, t) and elem(ky, kx, r, t16); t is 0 when !NEED_T.
+template <int H, int W, bool NEED_T, typename Edge, typename Elem>
+__device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge, Elem&& elem) {
     constexpr int NT = kFftThreads, M = W / 2, MI = M - 1, HALF = (H / 2) * MI;
-    if (tid < H) {  // (u_r, u_t) of kx = 0, then of kx = M, row ky = tid (drawn in this order)
-        const uint32_t r0 = g.E.next();
-        const uint32_t t0 = g.E.next();
-        const uint32_t rm = g.E.next();
-        const uint32_t tm = g.E.next();
-        edge(r0, t0, rm, tm);
+    if (tid < H) {  // row ky = tid of the edge columns: radius word of kx = 0, of kx = M, then one angle word for both
+        const uint32_t r0 = g.E.next_high();
+        const uint32_t rm = g.E.next_high();
+        const uint32_t t = g.E.next();
+        edge(r0, rm, t);
     }
     int ky = tid / MI, kx = 1 + tid - ky * MI;
     constexpr int DKY = NT / MI, DKX = NT - DKY * MI;
     for (int q = tid; q < HALF; q += NT) {
-        inner(ky, kx, g);
+        const uint32_t ra = g.R.next_high();  // radius words keep bits 31..9 only
+        const uint32_t rb = g.R.next_high();
+        const uint32_t t = NEED_T ? g.T.next() : 0u;
+        elem(ky, kx, ra, t & 0xFFFFu);
+        elem(ky + H / 2, kx, rb, t >> 16);
         kx += DKX;
         ky += DKY;
         if (kx > MI) {
@@ -188,34 +192,41 @@ __device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge,
     }
 }
 
-constexpr float kRs = 0.70710678118654752f;  // complex normal: (a + ib) / sqrt(2)
+// ---- unit complex normal z = rho e^{i theta}, E|z|^2 = 1, from raw generator bits (about 30 instruction slots) --------------
+// radius: 23 random bits become the mantissa of a float f in [1, 2) in ONE v_alignbit; u = 2 - f is uniform on (0, 1] and
+//   rho^2 = -ln u (the 1/sqrt(2) of "(a + ib) / sqrt 2" folded into the radius), so rho <= sqrt(23 ln 2) = 3.99 (5.65 sigma
+//   per component).
+// angle: 16 random bits -> f in [1, 2) the same way; v_sin / v_cos take revolutions and are periodic, so they are fed f
+//   directly.  One 32-bit draw serves two elements; 65536 directions x a 23-bit radius is far below fp32 output resolution
+//   after the 8192-term FFT sums.
+__device__ __forceinline__ float unit_mantissa(uint32_t hi_bits_in_msb) {  // bits 31..9 -> [1, 2)
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, hi_bits_in_msb, 9));
+}
+__device__ __forceinline__ float neg_ln_u(uint32_t r) {  // -ln(u), u = 2 - f in (0, 1]
+    return -0.6931471805599453f * __builtin_amdgcn_logf(2.0f - unit_mantissa(r));
+}
+__device__ __forceinline__ c32 unit_complex_normal(uint32_t r, uint32_t t16) {
+    const float rho = __builtin_amdgcn_sqrtf(neg_ln_u(r));
+    const float f = __uint_as_float(0x3f800000u | (t16 << 7));
+    return make_float2(rho * __builtin_amdgcn_cosf(f), rho * __builtin_amdgcn_sinf(f));
+}
+// one drawn spectrum element times the filter value (the replay path multiplies the dumped element by f the same way)
+__device__ __forceinline__ c32 drawn_elem(uint32_t r, uint32_t t16, float f) {
+    const c32 z = unit_complex_normal(r, t16);
+    return make_float2(z.x * f, z.y * f);
+}
 
 // filtered spectrum of one generated plane -> sink(ky, kx, value)
 template <int H, int W, typename Sink>
 __device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter, SpectrumRng& g, int tid, Sink&& sink) {
     constexpr int M = W / 2, Wh = M + 1;
-    draw_plane<H, W>(
+    draw_plane<H, W, true>(
         g, tid,
-        [&](uint32_t r0, uint32_t t0, uint32_t rm, uint32_t tm) {
-            float a, b, c, d;
-            box_muller(r0, t0, a, b);
-            box_muller(rm, tm, c, d);
-            const float f0 = filter[tid * Wh], fm = filter[tid * Wh + M];  // (n / sqrt 2) * f: the replay path's rounding
-            sink(tid, 0, make_float2(a * kRs * f0, b * kRs * f0));
-            sink(tid, M, make_float2(c * kRs * fm, d * kRs * fm));
+        [&](uint32_t r0, uint32_t rm, uint32_t t) {
+            sink(tid, 0, drawn_elem(r0, t & 0xFFFFu, filter[tid * Wh]));
+            sink(tid, M, drawn_elem(rm, t >> 16, filter[tid * Wh + M]));
         },
-        [&](int ky, int kx, SpectrumRng& gg) {
-            const uint32_t ra = gg.R.next();
-            const uint32_t rb = gg.R.next();
-            const uint32_t ta = gg.T.next();
-            const uint32_t tb = gg.T.next();
-            float a, b, c, d;
-            box_muller(ra, ta, a, b);
-            box_muller(rb, tb, c, d);
-            const float fa = filter[ky * Wh + kx], fb = filter[(ky + H / 2) * Wh + kx];
-            sink(ky, kx, make_float2(a * kRs * fa, b * kRs * fa));
-            sink(ky + H / 2, kx, make_float2(c * kRs * fb, d * kRs * fb));
-        });
+        [&](int ky, int kx, uint32_t r, uint32_t t16) { sink(ky, kx, drawn_elem(r, t16, filter[ky * Wh + kx])); });
 }
 
 // One supplied plane's filtered half-spectrum (replay) -> sink(ky, kx, value); thread `tid` handles the complex pair at
@@ -637,24 +648,16 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* _
         SpectrumRng rng = spectrum_rng<H, false>(seed, stream_id, plane_offset / group + grp, tid);
         for (int gp = 0; gp < group; ++gp) {
             float acc = 0.0f;
-            draw_plane<H, W>(
+            draw_plane<H, W, false>(
                 rng, tid,
-                [&](uint32_t r0, uint32_t t0, uint32_t rm, uint32_t tm) {
-                    float a, b, c, d;
-                    box_muller(r0, t0, a, b);
-                    box_muller(rm, tm, c, d);
-                    const float f0 = filter[tid * Wh], fm = filter[tid * Wh + M];
-                    EDGE[par][0][tid] = make_float2(a * kRs * f0, b * kRs * f0);
-                    EDGE[par][1][tid] = make_float2(c * kRs * fm, d * kRs * fm);
+                [&](uint32_t r0, uint32_t rm, uint32_t t) {
+                    EDGE[par][0][tid] = drawn_elem(r0, t & 0xFFFFu, filter[tid * Wh]);
+                    EDGE[par][1][tid] = drawn_elem(rm, t >> 16, filter[tid * Wh + M]);
                 },
-                [&](int ky, int kx, SpectrumRng& gg) {
-                    // |z f|^2 = f^2 r^2 / 2 = f^2 * (-ln u) with the radius uniform u alone (same u01_open as box_muller)
-                    const uint32_t ra = gg.R.next();
-                    const uint32_t rb = gg.R.next();
-                    const float la = -0.6931471805599453f * __builtin_amdgcn_logf(u01_open(ra));
-                    const float lb = -0.6931471805599453f * __builtin_amdgcn_logf(u01_open(rb));
-                    const float fa = filter[ky * Wh + kx], fb = filter[(ky + H / 2) * Wh + kx];
-                    acc = __builtin_fmaf(fa * fa, la, __builtin_fmaf(fb * fb, lb, acc));
+                [&](int ky, int kx, uint32_t r, uint32_t) {
+                    // |z f|^2 = f^2 rho^2 = f^2 * (-ln u): the radius word alone
+                    const float f = filter[ky * Wh + kx];
+                    acc = __builtin_fmaf(f * f, neg_ln_u(r), acc);
                 });
             q += 2.0 * (double)acc;
             __syncthreads();           // this plane's edge columns are complete; the other buffer's readers finished last iteration
@@ -675,26 +678,13 @@ __global__ void __launch_bounds__(kFftThreads) power_spectrum_kernel(float* zout
         SpectrumRng rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + grp, tid);
         for (int gp = 0; gp < group; ++gp) {
             c32* zp = reinterpret_cast<c32*>(zout) + (grp * group + gp) * NC;
-            draw_plane<H, W>(
+            draw_plane<H, W, true>(
                 rng, tid,
-                [&](uint32_t r0, uint32_t t0, uint32_t rm, uint32_t tm) {
-                    float a, b, c, d;
-                    box_muller(r0, t0, a, b);
-                    box_muller(rm, tm, c, d);
-                    zp[tid * Wh] = make_float2(a * kRs, b * kRs);
-                    zp[tid * Wh + M] = make_float2(c * kRs, d * kRs);
+                [&](uint32_t r0, uint32_t rm, uint32_t t) {
+                    zp[tid * Wh] = unit_complex_normal(r0, t & 0xFFFFu);
+                    zp[tid * Wh + M] = unit_complex_normal(rm, t >> 16);
                 },
-                [&](int ky, int kx, SpectrumRng& gg) {
-                    const uint32_t ra = gg.R.next();
-                    const uint32_t rb = gg.R.next();
-                    const uint32_t ta = gg.T.next();
-                    const uint32_t tb = gg.T.next();
-                    float a, b, c, d;
-                    box_muller(ra, ta, a, b);
-                    box_muller(rb, tb, c, d);
-                    zp[ky * Wh + kx] = make_float2(a * kRs, b * kRs);
-                    zp[(ky + H / 2) * Wh + kx] = make_float2(c * kRs, d * kRs);
-                });
+                [&](int ky, int kx, uint32_t r, uint32_t t16) { zp[ky * Wh + kx] = unit_complex_normal(r, t16); });
         }
     }
 }

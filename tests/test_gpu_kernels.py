@@ -413,6 +413,32 @@ def test_power_generate_equals_replay_of_device_draws(hl):
         hl.power_spectrum((2, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=2)
 
 
+def test_power_spectrum_draws_are_unit_complex_normals(hl):
+    """Generate-mode spectrum elements z = rho e^{i theta} (23-bit radius word, 16-bit angle word, xoshiro128++ / + bursts
+    seeded by Philox): first moments, E|z|^2 = 1, E|z|^4 = 2, uncorrelated parts, uniform angle, no correlation between
+    neighbouring elements / planes / the two halves of an angle word, and the expected tail."""
+    z = hl.power_spectrum((64, 4, 128, 128), "cuda", seed=2024, stream_id=3).to(torch.complex128)  # 2.1 M elements
+    n = z.numel()
+    re, im = z.real.flatten(), z.imag.flatten()
+    tol = 5.0 / math.sqrt(n)  # 5 sigma of a unit-variance mean
+    assert abs(re.mean().item()) < tol and abs(im.mean().item()) < tol
+    assert abs(re.var().item() - 0.5) < 2 * tol and abs(im.var().item() - 0.5) < 2 * tol
+    assert abs((re * im).mean().item()) < tol
+    a2 = re * re + im * im
+    assert abs(a2.mean().item() - 1.0) < 2 * tol            # exponential(1): mean 1
+    assert abs((a2 * a2).mean().item() - 2.0) < 10 * tol     # second moment 2
+    assert abs(((re ** 4).mean() / re.var() ** 2).item() - 3.0) < 20 * tol  # Gaussian kurtosis of a component
+    ang = torch.atan2(im, re)
+    hist = torch.histc(ang, bins=64, min=-math.pi, max=math.pi) / n * 64
+    assert (hist - 1).abs().max().item() < 6 * math.sqrt(64 / n)
+    for shift in (1, 65, 128 * 65):  # next column, next row, next plane
+        assert abs((re[:-shift] * re[shift:]).mean().item()) < tol and abs((re[:-shift] * im[shift:]).mean().item()) < tol
+    half = z.shape[-2] // 2  # partner rows ky and ky + H/2 share one angle word (low / high half)
+    top, bot = z[..., :half, 1:64], z[..., half:, 1:64]
+    assert abs((top.real * bot.real).mean().item()) < 2 * tol and abs((top.imag * bot.imag).mean().item()) < 2 * tol
+    assert a2.max().item() < 23 * math.log(2) + 1e-6 and a2.max().item() > 11.0  # rho^2 <= 23 ln 2; 2.1 M draws reach ~14.5
+
+
 @pytest.mark.parametrize("hw", [(128, 128), (64, 64), (32, 64)])
 @pytest.mark.parametrize("factor", [1.0, 0.6])
 def test_power_noise_fused_normalisation(hl, hw, factor):
