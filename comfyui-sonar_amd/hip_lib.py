@@ -132,47 +132,6 @@ def load() -> C.CDLL:
     return lib
 
 
-# Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
-_timing: Optional[dict] = None
-
-
-def enable_kernel_timing(names: Sequence[str]) -> None:
-    global _timing
-    _timing = {n: [] for n in names}
-
-
-def collect_kernel_timing() -> dict:
-    """Returns {name: [ms, ...]} (synchronises) and disables timing."""
-    global _timing
-    out = {}
-    if _timing is not None:
-        torch.cuda.synchronize()
-        out = {n: [a.elapsed_time(b) for a, b in evs] for n, evs in _timing.items()}
-    _timing = None
-    return out
-
-
-class _Timed:
-    __slots__ = ("name", "start")
-
-    def __init__(self, name: str):
-        self.name = name
-
-    def __enter__(self):
-        if _timing is not None and self.name in _timing:
-            self.start = torch.cuda.Event(enable_timing=True)
-            self.start.record()
-        else:
-            self.start = None
-
-    def __exit__(self, *exc):
-        if self.start is not None:
-            end = torch.cuda.Event(enable_timing=True)
-            end.record()
-            _timing[self.name].append((self.start, end))
-        return False
-
-
 def _check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().sonar_last_error().decode("utf-8", "replace")
@@ -223,14 +182,13 @@ def stats_finalize(partials: torch.Tensor, n: int, npart: int = NPART) -> torch.
 def scale_noise_(x: torch.Tensor, factor: float, normalized: bool, partials: Optional[torch.Tensor], *,
                  threshold_std_devs: float = 2.5, npart: int = NPART, n_total: Optional[int] = None) -> torch.Tensor:
     n = x.numel()
-    with _Timed("scale_noise"):
-        _check(
-            load().sonar_scale_noise_f32(
-                _dev(x, "x"), n, float(factor), int(bool(normalized)), float(threshold_std_devs),
-                _opt(partials, "partials", torch.float64), npart, n if n_total is None else n_total, _stream(),
-            ),
-            "sonar_scale_noise_f32",
-        )
+    _check(
+        load().sonar_scale_noise_f32(
+            _dev(x, "x"), n, float(factor), int(bool(normalized)), float(threshold_std_devs),
+            _opt(partials, "partials", torch.float64), npart, n if n_total is None else n_total, _stream(),
+        ),
+        "sonar_scale_noise_f32",
+    )
     return x
 
 
@@ -443,12 +401,11 @@ def perlin_generate(shape, terms: torch.Tensor, div_fac: float, seed: int, strea
     out = torch.empty(shape, dtype=torch.float32, device=terms.device)
     b = shape[0]
     chw = out.numel() // max(b, 1)
-    with _Timed("perlin_generate"):
-        _check(
-            load().sonar_perlin_generate_f32(_dev(terms, "terms"), _dev(out, "out"), b, chw, terms.shape[0], float(div_fac),
-                                             seed & (2**64 - 1), stream_id, elem_offset, _opt(partials, "partials", torch.float64), _stream()),
-            "sonar_perlin_generate_f32",
-        )
+    _check(
+        load().sonar_perlin_generate_f32(_dev(terms, "terms"), _dev(out, "out"), b, chw, terms.shape[0], float(div_fac),
+                                         seed & (2**64 - 1), stream_id, elem_offset, _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_perlin_generate_f32",
+    )
     return out
 
 
@@ -459,12 +416,11 @@ def perlin_noise(shape, terms: torch.Tensor, div_fac: float, seed: int, stream_i
     b = shape[0]
     chw = out.numel() // max(b, 1)
     ws = new_partials(terms.device)
-    with _Timed("perlin_noise"):
-        _check(
-            load().sonar_perlin_noise_f32(_dev(terms, "terms"), _dev(out, "out"), b, chw, terms.shape[0], float(div_fac), seed & (2**64 - 1),
-                                          stream_id, elem_offset, float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
-            "sonar_perlin_noise_f32",
-        )
+    _check(
+        load().sonar_perlin_noise_f32(_dev(terms, "terms"), _dev(out, "out"), b, chw, terms.shape[0], float(div_fac), seed & (2**64 - 1),
+                                      stream_id, elem_offset, float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
+        "sonar_perlin_noise_f32",
+    )
     return out
 
 
@@ -541,12 +497,11 @@ def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: 
         zp = z.data_ptr()
     if filt.numel() != H * (W // 2 + 1):
         raise SonarHipError("power_irfft2: filter size mismatch")
-    with _Timed("power_irfft2"):
-        _check(
-            load().sonar_power_irfft2_f32(zp, _dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
-                                          rng_group_for(shape), _opt(partials, "partials", torch.float64), _stream()),
-            "sonar_power_irfft2_f32",
-        )
+    _check(
+        load().sonar_power_irfft2_f32(zp, _dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
+                                      rng_group_for(shape), _opt(partials, "partials", torch.float64), _stream()),
+        "sonar_power_irfft2_f32",
+    )
     return out
 
 
@@ -557,12 +512,11 @@ def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_o
     out = torch.empty(shape, dtype=torch.float32, device=filt.device)
     planes = out.numel() // (H * W)
     ws = new_partials(filt.device)
-    with _Timed("power_noise"):
-        _check(
-            load().sonar_power_noise_f32(_dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
-                                         rng_group_for(shape), float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
-            "sonar_power_noise_f32",
-        )
+    _check(
+        load().sonar_power_noise_f32(_dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
+                                     rng_group_for(shape), float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
+        "sonar_power_noise_f32",
+    )
     return out
 
 
@@ -573,9 +527,8 @@ def spectral_filter(x: torch.Tensor, filt: torch.Tensor, partials: Optional[torc
     if filt.numel() != H * (W // 2 + 1):
         raise SonarHipError("spectral_filter: filter size mismatch")
     out = torch.empty_like(x)
-    with _Timed("spectral_filter"):
-        _check(load().sonar_spectral_filter_f32(_dev(x, "x"), _dev(filt, "filter"), _dev(out, "out"), planes, H, W,
-                                                _opt(partials, "partials", torch.float64), _stream()), "sonar_spectral_filter_f32")
+    _check(load().sonar_spectral_filter_f32(_dev(x, "x"), _dev(filt, "filter"), _dev(out, "out"), planes, H, W,
+                                            _opt(partials, "partials", torch.float64), _stream()), "sonar_spectral_filter_f32")
     return out
 
 
