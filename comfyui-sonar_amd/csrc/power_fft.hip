@@ -192,6 +192,22 @@ __device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge,
     }
 }
 
+// advance the streams past one plane's draws without using them (a workgroup that starts in the middle of an RNG group)
+template <int H, int W, bool NEED_T>
+__device__ __forceinline__ void skip_plane(SpectrumRng& g, int tid) {
+    draw_plane<H, W, NEED_T>(g, tid, [](uint32_t, uint32_t, uint32_t) {}, [](int, int, uint32_t, uint32_t) {});
+}
+
+// A kernel's work units: whole RNG groups (one workgroup draws the group's planes back to back; the seeding is paid once
+// per group), or -- `split`, chosen by the launcher when there are too few groups to fill the chip -- single planes, the
+// workgroup fast-forwarding the group's streams to its plane.  Same values either way.
+struct GroupWalk {
+    int64_t grp;
+    int first, count;
+    __device__ __forceinline__ GroupWalk(int64_t unit, int group, int split)
+        : grp(split ? unit / group : unit), first(split ? (int)(unit % group) : 0), count(split ? 1 : group) {}
+};
+
 // ---- unit complex normal z = rho e^{i theta}, E|z|^2 = 1, from raw generator bits (about 30 instruction slots) --------------
 // radius: 23 random bits become the mantissa of a float f in [1, 2) in ONE v_alignbit; u = 2 - f is uniform on (0, 1] and
 //   rho^2 = -ln u (the 1/sqrt(2) of "(a + ib) / sqrt 2" folded into the radius), so rho <= sqrt(23 ln 2) = 3.99 (5.65 sigma
@@ -264,7 +280,8 @@ template <int H, int W, int SRC, bool STATS, bool NORM>
 __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_kernel(const float* __restrict__ z,
                                                                        const float* __restrict__ filter, float* out,
                                                                        int64_t planes, uint64_t seed, uint64_t stream_id,
-                                                                       int64_t plane_offset, int group, double* partials, NormArgs na) {
+                                                                       int64_t plane_offset, int group, int split, double* partials,
+                                                                       NormArgs na) {
     using C = PlaneCfg<H, W>;
     constexpr int NT = kFftThreads;
     constexpr int M = C::M, S = C::S;
@@ -315,11 +332,15 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
     }
 
     // one workgroup draws the `group` planes of an RNG group back to back (group = 1 unless generating)
-    for (int64_t grp = blockIdx.x; grp * group < planes; grp += gridDim.x) {
+    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+    const GroupWalk gw(unit, group, split);
     SpectrumRng rng;
-    if constexpr (GEN) rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + grp, tid);
-    for (int gp = 0; gp < group; ++gp) {
-        const int64_t plane = grp * group + gp;
+    if constexpr (GEN) {
+        rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + gw.grp, tid);
+        for (int i = 0; i < gw.first; ++i) skip_plane<H, W, true>(rng, tid);
+    }
+    for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
+        const int64_t plane = gw.grp * group + gp;
         __syncthreads();  // previous plane's LDS reads are done (and TW is visible)
         if constexpr (SRC != 2) {
         // ---------------------------------------------------------------- fill: z * filter
@@ -625,7 +646,7 @@ SONAR_UNROLL_ITEMS
 // (only the Hermitian-symmetric part of the kx = 0 and kx = M columns survives the c2r stage).
 template <int H, int W>
 __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* __restrict__ filter, int64_t planes, uint64_t seed,
-                                                                   uint64_t stream_id, int64_t plane_offset, int group,
+                                                                   uint64_t stream_id, int64_t plane_offset, int group, int split,
                                                                    double* partials) {
     constexpr int NT = kFftThreads, M = W / 2, Wh = M + 1;
     __shared__ c32 EDGE[2][2][H];  // [plane parity][kx = 0 | kx = M][ky]: double-buffered -> one barrier per plane
@@ -644,9 +665,11 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* _
         }
         q += (double)edge;
     };
-    for (int64_t grp = blockIdx.x; grp * group < planes; grp += gridDim.x) {
-        SpectrumRng rng = spectrum_rng<H, false>(seed, stream_id, plane_offset / group + grp, tid);
-        for (int gp = 0; gp < group; ++gp) {
+    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+        const GroupWalk gw(unit, group, split);
+        SpectrumRng rng = spectrum_rng<H, false>(seed, stream_id, plane_offset / group + gw.grp, tid);
+        for (int i = 0; i < gw.first; ++i) skip_plane<H, W, false>(rng, tid);
+        for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
             float acc = 0.0f;
             draw_plane<H, W, false>(
                 rng, tid,
@@ -671,13 +694,15 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* _
 // the spectrum draw_plane yields for (seed, stream_id, plane_offset, group), unit filter: zout[planes][H][W/2+1] complex64
 template <int H, int W>
 __global__ void __launch_bounds__(kFftThreads) power_spectrum_kernel(float* zout, int64_t planes, uint64_t seed, uint64_t stream_id,
-                                                                      int64_t plane_offset, int group) {
+                                                                      int64_t plane_offset, int group, int split) {
     constexpr int M = W / 2, Wh = M + 1, NC = H * Wh;
     const int tid = threadIdx.x;
-    for (int64_t grp = blockIdx.x; grp * group < planes; grp += gridDim.x) {
-        SpectrumRng rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + grp, tid);
-        for (int gp = 0; gp < group; ++gp) {
-            c32* zp = reinterpret_cast<c32*>(zout) + (grp * group + gp) * NC;
+    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+        const GroupWalk gw(unit, group, split);
+        SpectrumRng rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + gw.grp, tid);
+        for (int i = 0; i < gw.first; ++i) skip_plane<H, W, true>(rng, tid);
+        for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
+            c32* zp = reinterpret_cast<c32*>(zout) + (gw.grp * group + gp) * NC;
             draw_plane<H, W, true>(
                 rng, tid,
                 [&](uint32_t r0, uint32_t rm, uint32_t t) {
@@ -703,18 +728,20 @@ static int power_grid(int64_t planes) {
 template <int H, int W>
 static int launch_power(int what, const float* z, const float* filter, float* out, int64_t planes, uint64_t seed,
                         uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st) {
-    const int64_t ngroups = planes / group;
+    // too few RNG groups to fill the chip: one workgroup per plane (it fast-forwards the group's streams), same values
+    const int split = group > 1 && planes / group < 2 * 256 ? 1 : 0;
+    const int64_t ngroups = split ? planes : planes / group;  // work units
     const int g = power_grid<H, W>(ngroups);
     const dim3 blk(kFftThreads);
 #define SONAR_PW(G, ST, NM, PART) \
-    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(g), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, group, PART, na)
+    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(g), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, group, split, PART, na)
     if (what == 3) {
         if (partials) SONAR_PW(2, true, false, partials); else SONAR_PW(2, false, false, partials);
     } else if (what == 2) {
-        hipLaunchKernelGGL((power_spectrum_kernel<H, W>), dim3(std::min<int64_t>(ngroups, 2048)), blk, 0, st, out, planes, seed, stream_id, plane_offset, group);
+        hipLaunchKernelGGL((power_spectrum_kernel<H, W>), dim3(std::min<int64_t>(ngroups, 2048)), blk, 0, st, out, planes, seed, stream_id, plane_offset, group, split);
     } else if (what == 1) {
         hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(ngroups, kNPart)), blk, 0, st, filter, planes, seed, stream_id,
-                           plane_offset, group, partials);
+                           plane_offset, group, split, partials);
         SONAR_PW(1, false, true, nullptr);
     } else if (z == nullptr) {
         if (partials) SONAR_PW(1, true, false, partials); else SONAR_PW(1, false, false, partials);

@@ -402,6 +402,11 @@ def test_power_generate_equals_replay_of_device_draws(hl):
     a = hl.power_spectrum((2, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=12)
     b = hl.power_spectrum((3, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=20)
     assert torch.equal(torch.cat((a, b)), z)
+    # 600 latents = 600 RNG groups (> 512): one workgroup per GROUP; its first two latents alone: one workgroup per PLANE
+    # (fast-forwarding the group streams) -- same values
+    big = hl.power_spectrum((600, 4, 32, 32), "cuda", seed=9, stream_id=1)
+    assert torch.equal(hl.power_spectrum((2, 4, 32, 32), "cuda", seed=9, stream_id=1), big[:2])
+    assert torch.equal(hl.power_spectrum((3, 4, 32, 32), "cuda", seed=9, stream_id=1, plane_offset=4 * 597), big[597:])
     # channel counts that are not a multiple of 4 use per-plane streams (group 1), still shard-invariant
     z3 = hl.power_spectrum((4, 3, 32, 32), "cuda", seed=1, stream_id=0, plane_offset=3)
     a3 = hl.power_spectrum((1, 3, 32, 32), "cuda", seed=1, stream_id=0, plane_offset=3)
