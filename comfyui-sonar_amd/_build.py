@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(HERE, "libsonar_hip.so")
 ARCH = "gfx950"
 # -ffp-contract=off: kernels restate the reference's op order; FMAs appear only where written.
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+CXXFLAGS += os.environ.get("SONAR_EXTRA_CXXFLAGS", "").split()  # tuning experiments only (part of the build stamp)
 
 
 def _hipcc() -> str:
