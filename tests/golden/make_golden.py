@@ -620,6 +620,54 @@ def gen_cfg5():
     save("cfg5", x0=x0, sigmas=sigmas, trace_steps=torch.tensor([1, 3]), trace=torch.stack([trace[1], trace[3]]), out=out)
 
 
+# ------------------------------------------------------------------------------------------------ guidance
+GUIDANCE_CASES = {
+    "linear": dict(guidance_type="LINEAR", factor=0.05, start_step=1, end_step=4),
+    "euler": dict(guidance_type="EULER", factor=0.2, start_step=0, end_step=9999),
+    "linear_inject": dict(guidance_type="LINEAR", factor=0.1, start_step=2, end_step=5, guidance_blend_mode="inject"),
+}
+
+
+def gen_guidance():
+    S = ref.sonar
+    cases = {}
+    shape = (2, 4, 8, 8)
+    torch.manual_seed(71)
+    x0 = torch.randn(shape) * 14.6
+    ref_latent = torch.randn(shape) * 0.7 + 0.3
+    sigmas = torch.cat((torch.linspace(14.6, 0.03, 7), torch.zeros(1)))
+    noise_bank = torch.randn(16, *shape)
+    cases.update(x0=x0, ref_latent=ref_latent, sigmas=sigmas, noise_bank=noise_bank)
+
+    def bank_sampler():
+        it = iter(noise_bank)
+        return lambda s, sn: next(it).clone()
+
+    for name, kw in GUIDANCE_CASES.items():
+        kw = dict(kw)
+        blend = kw.pop("guidance_blend_mode", None)
+        gcfg = S.GuidanceConfig(guidance_type=S.GuidanceType[kw.pop("guidance_type")], latent=ref_latent.clone(), **kw)
+        params = {"guidance": gcfg, "momentum": 0.9}
+        if blend:
+            params["guidance_blend_mode"] = blend
+        for kind in ("euler", "ancestral", "dpmpp"):
+            trace = []
+            cb = lambda d: trace.append(d["x"].clone())  # noqa: E731
+            if kind == "euler":
+                S.SonarEuler.sampler(fake_model, x0.clone(), sigmas, {"seed": 0}, cb, True, bank_sampler(), None, dict(params))
+            elif kind == "ancestral":
+                S.SonarEulerAncestral.sampler(fake_model, x0.clone(), sigmas, {"seed": 0}, cb, True, None, dict(params), 0.8, 1.1, bank_sampler())
+            else:
+                S.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas, {"seed": 0}, cb, True, None, dict(params), 0.9, 1.05, bank_sampler())
+            cases[f"{kind}_{name}"] = torch.stack(trace)
+    # the building blocks on their own
+    cases["prepared_ref"] = S.SonarGuidanceMixin.prepare_ref_latent(ref_latent.clone())
+    cases["shift"] = S.SonarGuidanceMixin.guidance_shift(x0, cases["prepared_ref"])
+    cases["euler_step"] = S.SonarGuidanceMixin.guidance_euler(torch.tensor(7.0), torch.tensor(5.0), x0, x0 * 0.5, cases["prepared_ref"], 0.3)
+    cases["linear_step"] = S.SonarGuidanceMixin.guidance_linear(x0, cases["prepared_ref"], 0.3)
+    save("guidance", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -637,6 +685,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_latent_ops()
     gen_spectral()
     gen_cfg5()
+    gen_guidance()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

@@ -407,3 +407,51 @@ def test_cfg5_scheduled_power_perlin_chain_with_dpmpp_momentum(api, golden):
     for row, step in enumerate(g["trace_steps"].tolist()):
         close(trace[step], g["trace"][row], rtol=3e-4, atol=3e-4)
     close(out, g["out"], rtol=3e-4, atol=3e-4)
+
+
+# ------------------------------------------------------------------------------------------------ guidance
+GUIDANCE_CASES = {
+    "linear": dict(guidance_type="LINEAR", factor=0.05, start_step=1, end_step=4),
+    "euler": dict(guidance_type="EULER", factor=0.2, start_step=0, end_step=9999),
+    "linear_inject": dict(guidance_type="LINEAR", factor=0.1, start_step=2, end_step=5, guidance_blend_mode="inject"),
+}
+
+
+def test_guidance_building_blocks(api, golden):
+    g = golden("guidance")
+    S = api.sonar
+    x0, ref = g["x0"].cuda(), g["ref_latent"].cuda()
+    prepared = S.SonarGuidanceMixin.prepare_ref_latent(ref.clone())
+    close(prepared, g["prepared_ref"], rtol=2e-5, atol=2e-5)
+    close(S.SonarGuidanceMixin.guidance_shift(x0, prepared), g["shift"], rtol=2e-5, atol=2e-4)
+    close(S.SonarGuidanceMixin.guidance_euler(torch.tensor(7.0), torch.tensor(5.0), x0, x0 * 0.5, prepared, 0.3), g["euler_step"], rtol=2e-5, atol=2e-4)
+    close(S.SonarGuidanceMixin.guidance_linear(x0, prepared, 0.3), g["linear_step"], rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("kind", ["euler", "ancestral", "dpmpp"])
+@pytest.mark.parametrize("name", list(GUIDANCE_CASES))
+def test_sampler_traces_with_guidance(api, golden, kind, name):
+    """Reference samplers with a guidance latent (py/sonar.py:343-411 inside every step); golden = per-step x of the real reference."""
+    g = golden("guidance")
+    S = api.sonar
+    x0, sigmas, bank = g["x0"].cuda(), g["sigmas"], g["noise_bank"]
+    it = iter(bank)
+    ns = lambda _s, _sn: next(it).cuda()  # noqa: E731
+    kw = dict(GUIDANCE_CASES[name])
+    blend = kw.pop("guidance_blend_mode", None)
+    gcfg = S.GuidanceConfig(guidance_type=S.GuidanceType[kw.pop("guidance_type")], latent=g["ref_latent"].clone(), **kw)
+    params = {"guidance": gcfg, "momentum": 0.9}
+    if blend:
+        params["guidance_blend_mode"] = blend
+    trace = []
+    cb = lambda d: trace.append(d["x"].clone())  # noqa: E731
+    if kind == "euler":
+        S.SonarEuler.sampler(fake_model, x0.clone(), sigmas, {"seed": 0}, cb, True, ns, None, params)
+    elif kind == "ancestral":
+        S.SonarEulerAncestral.sampler(fake_model, x0.clone(), sigmas, {"seed": 0}, cb, True, None, params, 0.8, 1.1, ns)
+    else:
+        S.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas, {"seed": 0}, cb, True, None, params, 0.9, 1.05, ns)
+    want = g[f"{kind}_{name}"]
+    assert len(trace) == want.shape[0]
+    for i, t in enumerate(trace):
+        close(t, want[i], rtol=2e-4, atol=2e-4)
