@@ -668,6 +668,20 @@ def gen_guidance():
     save("guidance", **cases)
 
 
+# ------------------------------------------------------------------------------------------------ 5-D (video) latents
+VIDEO_TYPES = ("gaussian", "perlin", "pyramid", "pyramid_area", "onef_pinkish", "green_test", "velvet")
+
+
+def gen_video():
+    """[B, C, F, H, W] latents: FramesToChannels generators fold frames into channels (py/noise_generation.py:182-209)."""
+    cases = {}
+    shape = (2, 4, 3, 16, 16)
+    for name in VIDEO_TYPES:
+        for normalized in (False, True):
+            cases[f"{name}_{int(normalized)}"] = ref_noise(getattr(NT, name.upper()), shape, 81, normalized)
+    save("video", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -686,6 +700,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_spectral()
     gen_cfg5()
     gen_guidance()
+    gen_video()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

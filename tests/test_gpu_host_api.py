@@ -455,3 +455,15 @@ def test_sampler_traces_with_guidance(api, golden, kind, name):
     assert len(trace) == want.shape[0]
     for i, t in enumerate(trace):
         close(t, want[i], rtol=2e-4, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ 5-D (video) latents
+@pytest.mark.parametrize("name", ["gaussian", "perlin", "pyramid", "pyramid_area", "onef_pinkish", "green_test", "velvet"])
+@pytest.mark.parametrize("normalized", [False, True])
+def test_video_latents(api, golden, name, normalized):
+    """[B, C, F, H, W]: golden from the real reference (frames folded into channels where the generator needs 4-D)."""
+    g = golden("video")
+    want = g[f"{name}_{int(normalized)}"]
+    out = run_type(api, name, tuple(want.shape), 81, normalized)
+    tol = 3e-5 * float(want.abs().max()) if name in ("onef_pinkish", "green_test") else 5e-6
+    close(out, want, rtol=2e-5, atol=tol)
