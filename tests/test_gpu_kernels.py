@@ -505,3 +505,29 @@ def test_channel_mix(hl, golden):
 def test_cpu_tensor_is_rejected(hl):
     with pytest.raises(hl.SonarHipError):
         hl.stats(torch.zeros(16))
+
+
+# ------------------------------------------------------------------------------------------------ C-ABI error behaviour
+def test_c_abi_error_codes_and_messages(hl):
+    """Every entry point returns 0 or a negative SONAR_ERR_* code and leaves a message in sonar_last_error(); nothing is
+    launched on a refused call (the output buffer keeps its contents)."""
+    lib = hl.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.full((64,), 7.0, device="cuda")
+    assert lib.sonar_stats_f32(None, 64, None, st) == hl.ERR_ARG
+    assert b"sonar_stats_f32" in lib.sonar_last_error()
+    filt = torch.ones(24 * 13, device="cuda")
+    out = torch.full((2, 24, 24), 7.0, device="cuda")
+    part = hl.new_partials("cuda")
+    rc = lib.sonar_power_irfft2_f32(None, filt.data_ptr(), out.data_ptr(), 2, 24, 24, 1, 0, 0, 1, part.data_ptr(), st)
+    assert rc == hl.ERR_UNSUPPORTED and b"unsupported plane 24 x 24" in lib.sonar_last_error()
+    rc = lib.sonar_power_irfft2_f32(None, filt.data_ptr(), out.data_ptr(), 6, 32, 32, 1, 0, 2, 4, part.data_ptr(), st)
+    assert rc == hl.ERR_ARG and b"multiples of the RNG group" in lib.sonar_last_error()
+    assert lib.sonar_dwt2_ws_bytes(1, 8, 8, 8, 9, 4, 0) == -1  # mode out of range
+    assert lib.sonar_wcfg_fused_ws_bytes(4, 64, 64, 13, 8, 1, 8, 1, 8) == -1  # more levels than supported
+    torch.cuda.synchronize()
+    assert torch.all(out == 7.0) and torch.all(x == 7.0)
+    with pytest.raises(hl.SonarHipError, match="code -2"):
+        hl.power_irfft2(None, filt, (2, 1, 24, 24))
+    with pytest.raises(hl.SonarHipError):
+        hl.stats(torch.zeros(8))  # host tensor
