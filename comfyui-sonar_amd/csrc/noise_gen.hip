@@ -558,6 +558,54 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Brownian-interval noise (the reference wraps ComfyUI's BrownianTreeNoiseSampler -> torchsde, un-vendored:
+// py/noise_generation.py:262-286, py/nodes/powernoise.py:383-393).  One Brownian path per element over [t_lo, t_hi] is
+// defined by midpoint bisection: W(mid) = (W(a) + W(b)) / 2 + sqrt((b - a) / 4) z(node), with z(node, element) a
+// counter-based N(0,1) (Philox4x32-10, counter = (element group, node id), key = seed), so W(t) is a LINEAR combination of
+// the z's on t's root-to-leaf path.  The host walks the path(s) in fp64 and passes (node id, coefficient) pairs; this
+// kernel evaluates out[e] = sum_k coef[k] * z(node[k], e).  Values depend on (seed, node, global element index) only:
+// repeated / nested / abutting intervals are consistent, batches shard bit-identically.
+constexpr int kMaxBrownianNodes = 96;
+struct BrownianTerms {
+    unsigned long long node[kMaxBrownianNodes];
+    float coef[kMaxBrownianNodes];
+    int count;
+};
+
+__global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
+                                                          uint64_t seed, const unsigned long long* __restrict__ latent_seeds,
+                                                          int64_t latent_elems) {
+    const int64_t groups = (n + 3) / 4;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
+        const int64_t e = g * 4;                       // local element index of the 4-group
+        uint64_t key = seed;
+        uint64_t ctr = (uint64_t)(elem_offset + e) >> 2;  // global 4-group (elem_offset % 4 == 0)
+        if (latent_seeds) {                            // one seed per latent: counters restart inside each latent
+            const int64_t lat = e / latent_elems;
+            key = latent_seeds[lat];
+            ctr = (uint64_t)(e - lat * latent_elems) >> 2;
+        }
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < terms.count; ++k) {
+            const unsigned long long node = terms.node[k];
+            const Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)node, (uint32_t)(node >> 32), (uint32_t)key,
+                                            (uint32_t)(key >> 32));
+            float z[4];
+            box_muller(p.v[0], p.v[1], z[0], z[1]);
+            box_muller(p.v[2], p.v[3], z[2], z[3]);
+            const float c = terms.coef[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(c, z[j], acc[j]);
+        }
+        if (e + 4 <= n && (reinterpret_cast<uintptr_t>(out + e) & 15u) == 0) {
+            *reinterpret_cast<float4*>(out + e) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+            for (int j = 0; j < 4 && e + j < n; ++j) out[e + j] = acc[j];
+        }
+    }
+}
+
 static int fill_levels(PyramidLevels& lv, int64_t H, int64_t W, int64_t nlevels, const float* const* level_ptrs,
                        const int64_t* level_h, const int64_t* level_w, const float* level_weight, const char* what) {
     lv = PyramidLevels{};
@@ -602,6 +650,25 @@ extern "C" int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, ui
     const int active = !(sub == 0.0f && mul == 1.0f && add == 0.0f);
     return launch_fill<Dist::Uniform>(out, n, seed, stream_id, elem_offset, Affine{sub, mul, add, active}, partials,
                                       (hipStream_t)stream, "sonar_philox_uniform_f32");
+}
+
+extern "C" int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, const uint64_t* node_ids, const float* coefs,
+                                  int nnodes, uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems, void* stream) {
+    SONAR_REQUIRE(out && n >= 0 && elem_offset >= 0 && (elem_offset & 3) == 0 && nnodes >= 0 && (nnodes == 0 || (node_ids && coefs)),
+                  SONAR_ERR_ARG, "sonar_brownian_f32: bad argument");
+    SONAR_REQUIRE(nnodes <= kMaxBrownianNodes, SONAR_ERR_UNSUPPORTED, "sonar_brownian_f32: more than %d path nodes", kMaxBrownianNodes);
+    SONAR_REQUIRE(!latent_seeds || (latent_elems > 0 && latent_elems % 4 == 0 && n % latent_elems == 0), SONAR_ERR_ARG,
+                  "sonar_brownian_f32: per-latent seeds need whole latents of a multiple of 4 elements");
+    if (n == 0) return SONAR_OK;
+    BrownianTerms t;
+    t.count = nnodes;
+    for (int k = 0; k < nnodes; ++k) {
+        t.node[k] = node_ids[k];
+        t.coef[k] = coefs[k];
+    }
+    hipLaunchKernelGGL(brownian_kernel, dim3(grid_for((n + 3) / 4, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, n, elem_offset,
+                       t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems);
+    return check_launch("sonar_brownian_f32");
 }
 
 extern "C" int sonar_perlin_terms_f32(const float* angles, float* terms, int64_t iters, int64_t C, int64_t H, int64_t W,

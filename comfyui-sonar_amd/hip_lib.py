@@ -82,6 +82,7 @@ SIGNATURES = {
     "sonar_dpmpp_stage2_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
     "sonar_philox_normal_f32": (_I, [_P, _I64, _U64, _U64, _I64, _P, _P]),
     "sonar_philox_uniform_f32": (_I, [_P, _I64, _U64, _U64, _I64, _F, _F, _F, _P, _P]),
+    "sonar_brownian_f32": (_I, [_P, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_perlin_terms_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "sonar_perlin_apply_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P]),
     "sonar_perlin_generate_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _P, _P]),
@@ -371,6 +372,18 @@ def philox_uniform(shape, device, seed: int, stream_id: int, elem_offset: int = 
                                         float(sub), float(mul), float(add), _opt(partials, "partials", torch.float64), _stream()),
         "sonar_philox_uniform_f32",
     )
+    return out
+
+
+def brownian(shape, device, node_ids, coefs, seed: int, elem_offset: int = 0, latent_seeds: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[e] = sum_k coefs[k] * z(node_ids[k], e): one Brownian-interval increment (host-walked bisection path)."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    n = out.numel()
+    ids = (C.c_uint64 * len(node_ids))(*[int(v) & (2**64 - 1) for v in node_ids])
+    cf = (C.c_float * len(coefs))(*[float(v) for v in coefs])
+    latent_elems = n // shape[0] if latent_seeds is not None else 0
+    _check(load().sonar_brownian_f32(_dev(out, "out"), n, elem_offset, ids, cf, len(node_ids), seed & (2**64 - 1),
+                                     None if latent_seeds is None else latent_seeds.data_ptr(), latent_elems, _stream()), "sonar_brownian_f32")
     return out
 
 

@@ -15,7 +15,7 @@ from torch import Tensor
 
 from ... import hip_lib
 from ..noise import CustomNoiseItemBase
-from ..noise_generation import DeviceRNG, current_batch_offset
+from ..noise_generation import BrownianTreeNoiseSampler, DeviceRNG, current_batch_offset
 from ..utils import attach_stats, pop_stats, scale_noise
 
 
@@ -206,7 +206,11 @@ class PowerNoiseItem(CustomNoiseItemBase):
         shape = x.shape
         filter_rfft = self.make_filter(shape)
         if self.time_brownian:
-            raise NotImplementedError("time_brownian needs ComfyUI's BrownianTreeNoiseSampler (torchsde), which the reference does not vendor")
+            # time-correlated mode (py/nodes/powernoise.py:383-393): a real Brownian-interval field -> rfft2 -> filter -> irfft2
+            if sigma_min is None:
+                raise ValueError("time correlated brownian mode is valid only for stochastic samplers")
+            brownian = BrownianTreeNoiseSampler(x, sigma_min, sigma_max, seed=seed, cpu=cpu)
+            return self.make_noise_sampler_internal(x, brownian, filter_rfft, normalized=normalized)
         if cpu:
             def draw(_s, _sn):  # py/nodes/powernoise.py:396-402
                 return torch.randn((*shape[:-1], shape[-1] // 2 + 1), dtype=torch.complex64, device="cpu")

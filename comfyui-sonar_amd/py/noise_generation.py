@@ -526,7 +526,6 @@ def _off_path(type_name: str):
     return _OffPath
 
 
-BrownianNoiseGenerator = _off_path("brownian")
 StudentTNoiseGenerator = _off_path("studentt")
 LaplacianNoiseGenerator = _off_path("laplacian")
 DistroNoiseGenerator = _off_path("distro")
@@ -698,3 +697,121 @@ class OneFNoiseGenerator(_SpectralGainNoiseGenerator):
     def generate(self, *_args):
         partials = hip_lib.new_partials(self.device)
         return self.fix_output_frames(attach_stats(self.filtered(partials), partials))
+
+
+# --------------------------------------------------------------------------------------------------
+# Brownian-interval noise.  The reference delegates to ComfyUI's k-diffusion BrownianTreeNoiseSampler (torchsde's
+# BrownianTree; un-vendored, not installed, no reference tests at that boundary): "parity unpinned".  Same contract here --
+# W(t) is ONE Brownian path per element and seed, a call returns (W(t1) - W(t0)) / sqrt|t1 - t0| with the reference's sign
+# convention, so every call is N(0,1) and repeated / nested / abutting intervals are mutually consistent -- but the path is
+# this build's own: midpoint bisection with counter-based normals (sonar_brownian_f32), so values differ from torchsde's.
+class BrownianPath:
+    """W(t) on [t_lo, t_hi] as a linear combination of per-node standard normals: host side of sonar_brownian_f32."""
+
+    DEPTH = 20            # dyadic levels below the root; the leaf step is an exact bridge at t, so depth only bounds how close
+    ROOT = 0              # two DISTINCT query times may be before they share a leaf normal (range / 2**20)
+    LEAF = 1 << 40
+    OUTSIDE = 1 << 41
+
+    def __init__(self, t_lo: float, t_hi: float):
+        self.t_lo, self.t_hi = float(t_lo), float(t_hi)
+        if not self.t_hi > self.t_lo:
+            raise ValueError("Brownian noise needs sigma_min < sigma_max")
+
+    def coefficients(self, t: float) -> dict:
+        """{node id: coefficient} with W(t) = sum coefficient * z(node)."""
+        t = float(t)
+        lo, hi = self.t_lo, self.t_hi
+        if t < lo or t > hi:
+            # outside the tree: an independent increment from the nearest end, keyed by the query time itself
+            import struct
+
+            edge = lo if t < lo else hi
+            out = dict(self.coefficients(edge))
+            out[self.OUTSIDE | (struct.unpack("<Q", struct.pack("<d", t))[0] >> 12)] = math.sqrt(abs(t - edge))
+            return out
+        ca, cb = {}, {self.ROOT: math.sqrt(hi - lo)}  # W(lo) = 0, W(hi) ~ N(0, hi - lo)
+        a, b, node = lo, hi, 1
+        for _ in range(self.DEPTH):
+            if t == a:
+                return ca
+            if t == b:
+                return cb
+            mid = 0.5 * (a + b)
+            cm = {k: 0.5 * (ca.get(k, 0.0) + cb.get(k, 0.0)) for k in ca.keys() | cb.keys()}
+            cm[node] = 0.5 * math.sqrt(b - a)  # bridge midpoint: std sqrt((b - a) / 4)
+            if t < mid:
+                b, cb, node = mid, cm, 2 * node
+            else:
+                a, ca, node = mid, cm, 2 * node + 1
+        if t == a:
+            return ca
+        if t == b:
+            return cb
+        lam = (t - a) / (b - a)
+        out = {k: (1.0 - lam) * ca.get(k, 0.0) + lam * cb.get(k, 0.0) for k in ca.keys() | cb.keys()}
+        out[self.LEAF | node] = math.sqrt((t - a) * (b - t) / (b - a))  # exact bridge at t inside the leaf interval
+        return out
+
+    def increment(self, t0: float, t1: float):
+        """(node ids, coefficients) of (W(t_max) - W(t_min)) / sqrt(t_max - t_min)."""
+        ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
+        if ta == tb:
+            raise ValueError("Brownian noise needs two distinct times")
+        ca, cb = self.coefficients(ta), self.coefficients(tb)
+        scale = 1.0 / math.sqrt(tb - ta)
+        terms = {k: (cb.get(k, 0.0) - ca.get(k, 0.0)) * scale for k in ca.keys() | cb.keys()}
+        terms = {k: v for k, v in terms.items() if abs(v) > 1e-9}  # shared ancestors cancel
+        ids = sorted(terms)
+        return ids, [terms[k] for k in ids]
+
+
+class BrownianTreeNoiseSampler:
+    """Interface of k-diffusion's BrownianTreeNoiseSampler (x, sigma_min, sigma_max, seed, transform, cpu) -> (sigma, sigma_next)."""
+
+    def __init__(self, x: Tensor, sigma_min, sigma_max, seed=None, transform=lambda t: t, cpu: bool = False):
+        if not x.is_cuda:
+            raise hip_lib.SonarHipError("Brownian noise: the latent must live on a ROCm device")
+        self.transform = transform
+        t0, t1 = float(transform(torch.as_tensor(sigma_min))), float(transform(torch.as_tensor(sigma_max)))
+        self.sign = 1.0 if t0 <= t1 else -1.0
+        self.path = BrownianPath(min(t0, t1), max(t0, t1))
+        self.shape, self.device = tuple(x.shape), x.device
+        if seed is None:
+            seed = int(torch.randint(0, 2**63 - 1, []).item())
+        self.latent_seeds = None
+        try:
+            seeds = [int(v) for v in seed]
+            if len(seeds) != x.shape[0]:
+                raise ValueError("Brownian noise: one seed per batch item expected")
+            self.seed = 0
+            self.latent_seeds = torch.tensor([v & (2**63 - 1) for v in seeds], dtype=torch.int64, device=self.device)
+        except TypeError:
+            self.seed = int(seed)
+        self.elem_offset = current_batch_offset() * (x.numel() // x.shape[0])  # batch shards draw their own global elements
+
+    def __call__(self, sigma, sigma_next) -> Tensor:
+        t0, t1 = float(self.transform(torch.as_tensor(sigma))), float(self.transform(torch.as_tensor(sigma_next)))
+        sign = self.sign * (1.0 if t0 <= t1 else -1.0)
+        ids, coefs = self.path.increment(t0, t1)
+        return hip_lib.brownian(self.shape, self.device, ids, [c * sign for c in coefs], self.seed, self.elem_offset, self.latent_seeds)
+
+
+class BrownianNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:262-286."""
+
+    name = "brownian"
+
+    def __init__(self, x, *args, **kwargs):
+        super().__init__(x, *args, **kwargs)
+        seed, sigma_min, sigma_max = (self.options.get(k) for k in ("seed", "sigma_min", "sigma_max"))
+        if sigma_min is None or sigma_max is None:
+            raise ValueError("Brownian noise requires sigma_min and sigma_max")
+        self.brownian_tree_ns = BrownianTreeNoiseSampler(x, sigma_min, sigma_max, seed=seed, cpu=self.cpu)
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"normalized": False}
+
+    def generate(self, *args):
+        return self.brownian_tree_ns(*args)

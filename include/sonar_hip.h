@@ -150,6 +150,14 @@ int sonar_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t strea
 int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                              float sub, float mul, float add, double* partials /*nullable*/, void* stream);
 
+/* Brownian-interval noise (the reference wraps ComfyUI's BrownianTreeNoiseSampler -> torchsde, un-vendored:
+ * py/noise_generation.py:262-286, py/nodes/powernoise.py:383-393).  out[e] = sum_k coefs[k] * z(node_ids[k], e) with
+ * z a counter-based N(0,1) keyed by (seed, node id, global element index elem_offset + e).  node_ids / coefs are HOST arrays
+ * (<= 96 entries): the bisection path(s) of the queried interval, walked by the host in fp64.  latent_seeds (device,
+ * nullable): one seed per latent of latent_elems elements (the sampler's batched-seed mode), replacing `seed`. */
+int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, const uint64_t* node_ids, const float* coefs, int nnodes,
+                       uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems, void* stream);
+
 /* ---------------------------------------------------------------- Perlin (row P) */
 /* py/noise_generation.py:465-476,388-405 at the only position generate() uses (grid == output,
  * block 1x1, pos (0.5,0.5)): angles[iters][C][H+1][W+1] -> terms[iters][C][H][W] evaluating the

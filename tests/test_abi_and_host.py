@@ -118,3 +118,29 @@ def test_crop_samples(pkg):
     assert torch.equal(u.crop_samples(t, 4, 2, mode="center", offset_width=10), t[..., 2:4, 4:8])
     with pytest.raises(ValueError):
         u.crop_samples(t, 16, 2)
+
+
+def test_brownian_path_coefficients_are_a_brownian_motion(pkg):
+    """Host side of sonar_brownian_f32: W(t) = sum coef * z(node) must have Var W(t) = t - t_lo and Cov(W(a), W(b)) =
+    min(a, b) - t_lo exactly (any set of i.i.d. N(0,1) node normals then gives ONE consistent Brownian path), and every
+    increment divided by sqrt(dt) must have unit variance."""
+    import importlib
+    import random
+
+    ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
+    bp = ng.BrownianPath(0.03, 14.6)
+    rnd = random.Random(1)
+    var = lambda c: sum(v * v for v in c.values())  # noqa: E731
+    cov = lambda c1, c2: sum(v * c2.get(k, 0.0) for k, v in c1.items())  # noqa: E731
+    for _ in range(300):
+        a, b = sorted(rnd.uniform(0.03, 14.6) for _ in range(2))
+        ca, cb = bp.coefficients(a), bp.coefficients(b)
+        assert abs(var(ca) - (a - 0.03)) < 1e-9 and abs(cov(ca, cb) - (a - 0.03)) < 1e-9
+        ids, co = bp.increment(b, a)  # order does not matter here (the sampler applies the sign)
+        assert abs(sum(c * c for c in co) - 1.0) < 1e-6 and len(ids) <= 96 and ids == sorted(ids)
+    assert bp.coefficients(0.03) == {} and set(bp.coefficients(14.6)) == {bp.ROOT}
+    # outside the tree: independent increment from the nearest end with the right variance
+    out = bp.coefficients(20.0)
+    assert abs(var(out) - (20.0 - 0.03)) < 1e-9
+    with pytest.raises(ValueError):
+        bp.increment(1.0, 1.0)

@@ -6,6 +6,7 @@ Goldens: tests/golden/powerlaw.npz, latent_ops.npz (captured from the real refer
 golden (pytorch_wavelets is not installed anywhere): compared with oracle/dwt_oracle.py (pinned to PyWavelets 1.1.1).
 Tolerances: elementwise rows rtol 2e-5 / atol 5e-6 (powf differs from ATen's pow by <= 2 ulp); WF rtol/atol 3e-5."""
 import importlib
+import math
 import types
 
 import numpy as np
@@ -227,3 +228,50 @@ def test_power_filter_noise_node_device_mode(api):
     # pink: low radial frequencies carry more energy than high ones
     spec = torch.fft.rfft2(out).abs().square().mean(dim=(0, 1))
     assert spec[1:4, 1:4].mean() > 4 * spec[40:60, 40:60].mean()
+
+
+# ------------------------------------------------------------------------------------------------ Brownian-interval noise
+def test_brownian_noise_is_one_consistent_path(api):
+    """NoiseType.BROWNIAN (own counter-based Brownian-interval sampler; the reference's torchsde tree is un-vendored, parity
+    unpinned): every call is N(0,1); increments add up exactly (nested / abutting intervals are one path); disjoint
+    intervals are independent; same seed -> same values, another seed -> independent; batch shards agree."""
+    NG = api.noise_generation
+    x = torch.zeros(4, 4, 64, 64, device="cuda")
+    ns = api.noise.get_noise_sampler("brownian", x, 0.03, 14.6, seed=1234, cpu=False, normalized=False)
+    s = lambda v: torch.tensor(v)  # noqa: E731
+    a = ns(s(10.0), s(6.0))
+    n = a.numel()
+    tol = 5.0 / math.sqrt(n)
+    assert abs(a.mean().item()) < tol and abs(a.var().item() - 1.0) < 3 * tol
+    assert abs(((a.double() ** 4).mean() / a.double().var() ** 2).item() - 3.0) < 30 * tol
+    b = ns(s(6.0), s(2.5))
+    whole = ns(s(10.0), s(2.5))
+    recomposed = (a * math.sqrt(4.0) + b * math.sqrt(3.5)) / math.sqrt(7.5)
+    torch.testing.assert_close(whole, recomposed, rtol=0, atol=2e-5)
+    assert abs((a * b).mean().item()) < tol  # disjoint intervals
+    torch.testing.assert_close(ns(s(6.0), s(10.0)), -a, rtol=0, atol=0)  # direction flips the sign (k-diffusion convention)
+    assert torch.equal(ns(s(10.0), s(6.0)), a)
+    again = api.noise.get_noise_sampler("brownian", x, 0.03, 14.6, seed=1234, cpu=False, normalized=False)(s(10.0), s(6.0))
+    other = api.noise.get_noise_sampler("brownian", x, 0.03, 14.6, seed=1235, cpu=False, normalized=False)(s(10.0), s(6.0))
+    assert torch.equal(again, a) and abs((other * a).mean().item()) < tol
+    with NG.shard_offset(2):
+        part = api.noise.get_noise_sampler("brownian", x[:2], 0.03, 14.6, seed=1234, cpu=False, normalized=False)(s(10.0), s(6.0))
+    assert torch.equal(part, a[2:])
+    with pytest.raises(ValueError):
+        api.noise.get_noise_sampler("brownian", x, None, None, seed=1)
+
+
+def test_brownian_batched_seeds_and_time_brownian_power_noise(api):
+    x = torch.zeros(3, 4, 32, 32, device="cuda")
+    tree = api.noise_generation.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=[5, 6, 5])
+    out = tree(torch.tensor(9.0), torch.tensor(4.0))
+    assert torch.equal(out[0], out[2]) and not torch.equal(out[0], out[1])  # one path per seed, counters restart per latent
+    item = api.powernoise.PowerNoiseItem(1.0, time_brownian=True, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
+                                         mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1")
+    ns = item.make_noise_sampler(x, 0.03, 14.6, seed=11, cpu=False, normalized=True)
+    a, b = ns(torch.tensor(9.0), torch.tensor(4.0)), ns(torch.tensor(9.0), torch.tensor(4.0))
+    for t in (a, b):
+        api.utils.pop_stats(t)
+    assert torch.equal(a, b) and abs(a.std().item() - 1.0) < 5e-3  # time-correlated: the same interval gives the same field
+    with pytest.raises(ValueError):
+        item.make_noise_sampler(x, None, None, seed=11, cpu=False, normalized=True)
