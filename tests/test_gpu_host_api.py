@@ -467,3 +467,31 @@ def test_video_latents(api, golden, name, normalized):
     out = run_type(api, name, tuple(want.shape), 81, normalized)
     tol = 3e-5 * float(want.abs().max()) if name in ("onef_pinkish", "green_test") else 5e-6
     close(out, want, rtol=2e-5, atol=tol)
+
+
+def test_cfg5_generate_mode_with_brownian_on_flux_shape(api):
+    """cfg5 as written (power-law + Perlin + brownian, scheduled / blended, DPM++ SDE with momentum) in generate mode on a
+    Flux-shaped latent: runs entirely on device, finite, and the chain's noise stays unit-variance."""
+    N, S, pn = api.noise, api.sonar, api.powernoise
+    x0 = torch.randn(2, 16, 128, 128, device="cuda") * 10.0
+    sigmas = torch.cat((torch.linspace(10.0, 0.5, 6), torch.zeros(1)))
+
+    def chain_of(item):
+        c = N.CustomNoiseChain()
+        c.add(item)
+        return c
+
+    power = chain_of(pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0,
+                                       pnorm=2.0, mix=1.0, common_mode=0.0, channel_correlation="1"))
+    brown = chain_of(N.CustomNoiseItem(1.0, noise_type="brownian"))
+    chain = N.CustomNoiseChain()
+    chain.add(N.ScheduledNoise(0.6, noise=power, start_sigma=20.0, end_sigma=4.0, normalize=None, fallback_noise=brown))
+    chain.add(N.BlendedNoise(0.4, custom_noise_1=chain_of(N.CustomNoiseItem(1.0, noise_type="perlin")), custom_noise_2=brown,
+                             blend_function=api.utils.BLENDING_MODES["lerp"], noise_2_percent=0.5, normalize=None))
+    ns = chain.make_noise_sampler(x0, 0.5, 10.0, seed=3, cpu=False, normalized=True)
+    sample = ns(torch.tensor(8.0), torch.tensor(6.0))
+    api.utils.pop_stats(sample)
+    assert abs(sample.std().item() - 1.0) < 5e-3 and abs(sample.mean().item()) < 5e-3
+    out = S.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas, {"seed": 3}, None, True, None,
+                                  dict(momentum=0.9, momentum_hist=0.7, direction=1.0), 0.9, 1.05, ns)
+    assert out.shape == x0.shape and bool(torch.isfinite(out).all())
