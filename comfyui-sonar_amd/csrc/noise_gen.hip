@@ -573,6 +573,42 @@ struct BrownianTerms {
     int count;
 };
 
+// Burst variant (latents of a multiple of kTileElems elements, one seed): z(node, .) is a tile-keyed xoshiro stream with
+// stream id `node` (the Gaussian fill's generator, here in sub-tiles of 4 steps x 64 lanes x 4 = 1024 elements), so the
+// Philox seeding is paid once per (node, sub-tile, lane) for 16 values instead of once per 4 values.  A wave owns a
+// sub-tile and keeps its 4 x 4 partial sums in registers over the nodes.
+constexpr int kBrownIters = 4;
+constexpr int kBrownTile = kBrownIters * 256;
+__global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
+                                                                uint64_t seed) {
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int64_t first = elem_offset / kBrownTile, tiles = n / kBrownTile;  // both aligned (launcher)
+    for (int64_t t = wave; t < tiles; t += nwaves) {
+        float acc[kBrownIters][4];
+#pragma unroll
+        for (int it = 0; it < kBrownIters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[it][j] = 0.0f;
+        for (int k = 0; k < terms.count; ++k) {
+            Xoshiro rng = rng_stream(seed, terms.node[k], (uint64_t)(first + t), lane);
+            const float c = terms.coef[k];
+#pragma unroll
+            for (int it = 0; it < kBrownIters; ++it) {
+                float z[4];
+                rng.normal4(z);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_fmaf(c, z[j], acc[it][j]);
+            }
+        }
+        float* dst = out + t * kBrownTile + (int64_t)lane * 4;
+#pragma unroll
+        for (int it = 0; it < kBrownIters; ++it)
+            *reinterpret_cast<float4*>(dst + it * 256) = make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]);
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
                                                           uint64_t seed, const unsigned long long* __restrict__ latent_seeds,
                                                           int64_t latent_elems) {
@@ -659,6 +695,8 @@ extern "C" int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, co
     SONAR_REQUIRE(nnodes <= kMaxBrownianNodes, SONAR_ERR_UNSUPPORTED, "sonar_brownian_f32: more than %d path nodes", kMaxBrownianNodes);
     SONAR_REQUIRE(!latent_seeds || (latent_elems > 0 && latent_elems % 4 == 0 && n % latent_elems == 0), SONAR_ERR_ARG,
                   "sonar_brownian_f32: per-latent seeds need whole latents of a multiple of 4 elements");
+    for (int k = 0; k < nnodes; ++k)
+        SONAR_REQUIRE((node_ids[k] >> 48) == 0, SONAR_ERR_ARG, "sonar_brownian_f32: node ids are 48-bit");
     if (n == 0) return SONAR_OK;
     BrownianTerms t;
     t.count = nnodes;
@@ -666,8 +704,15 @@ extern "C" int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, co
         t.node[k] = node_ids[k];
         t.coef[k] = coefs[k];
     }
-    hipLaunchKernelGGL(brownian_kernel, dim3(grid_for((n + 3) / 4, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, n, elem_offset,
-                       t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems);
+    // the variant is a function of the latent size and the seed kind only, so every shard of a batch picks the same one
+    const bool burst = !latent_seeds && latent_elems > 0 && latent_elems % kTileElems == 0 && n % latent_elems == 0 &&
+                       elem_offset % latent_elems == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    if (burst)
+        hipLaunchKernelGGL(brownian_burst_kernel, dim3(grid_for(n / kBrownTile, 4)), dim3(kBlock), 0, (hipStream_t)stream, out, n,
+                           elem_offset, t, seed);
+    else
+        hipLaunchKernelGGL(brownian_kernel, dim3(grid_for((n + 3) / 4, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, n, elem_offset,
+                           t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems);
     return check_launch("sonar_brownian_f32");
 }
 

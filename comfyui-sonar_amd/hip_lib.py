@@ -381,7 +381,7 @@ def brownian(shape, device, node_ids, coefs, seed: int, elem_offset: int = 0, la
     n = out.numel()
     ids = (C.c_uint64 * len(node_ids))(*[int(v) & (2**64 - 1) for v in node_ids])
     cf = (C.c_float * len(coefs))(*[float(v) for v in coefs])
-    latent_elems = n // shape[0] if latent_seeds is not None else 0
+    latent_elems = n // shape[0]
     _check(load().sonar_brownian_f32(_dev(out, "out"), n, elem_offset, ids, cf, len(node_ids), seed & (2**64 - 1),
                                      None if latent_seeds is None else latent_seeds.data_ptr(), latent_elems, _stream()), "sonar_brownian_f32")
     return out

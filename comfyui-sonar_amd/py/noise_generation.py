@@ -708,19 +708,28 @@ class OneFNoiseGenerator(_SpectralGainNoiseGenerator):
 class BrownianPath:
     """W(t) on [t_lo, t_hi] as a linear combination of per-node standard normals: host side of sonar_brownian_f32."""
 
-    DEPTH = 20            # dyadic levels below the root; the leaf step is an exact bridge at t, so depth only bounds how close
-    ROOT = 0              # two DISTINCT query times may be before they share a leaf normal (range / 2**20)
-    LEAF = 1 << 40
+    DEPTH = 14            # dyadic levels below the root; the leaf step is an exact bridge at t, so depth only bounds how close
+    ROOT = 0              # two DISTINCT query times may be before they share a leaf normal (range / 2**14)
+    LEAF = 1 << 40        # node ids stay below 2**48 (the kernel's stream-id field)
     OUTSIDE = 1 << 41
 
     def __init__(self, t_lo: float, t_hi: float):
         self.t_lo, self.t_hi = float(t_lo), float(t_hi)
         if not self.t_hi > self.t_lo:
             raise ValueError("Brownian noise needs sigma_min < sigma_max")
+        self._cache: dict = {}  # a sampling run queries the same few times over and over (t1 of a step = t0 of the next)
 
     def coefficients(self, t: float) -> dict:
         """{node id: coefficient} with W(t) = sum coefficient * z(node)."""
         t = float(t)
+        hit = self._cache.get(t)
+        if hit is None:
+            if len(self._cache) > 4096:
+                self._cache.clear()
+            hit = self._cache[t] = self._walk(t)
+        return hit
+
+    def _walk(self, t: float) -> dict:
         lo, hi = self.t_lo, self.t_hi
         if t < lo or t > hi:
             # outside the tree: an independent increment from the nearest end, keyed by the query time itself
@@ -728,7 +737,7 @@ class BrownianPath:
 
             edge = lo if t < lo else hi
             out = dict(self.coefficients(edge))
-            out[self.OUTSIDE | (struct.unpack("<Q", struct.pack("<d", t))[0] >> 12)] = math.sqrt(abs(t - edge))
+            out[self.OUTSIDE | ((struct.unpack("<Q", struct.pack("<d", t))[0] >> 23) & ((1 << 40) - 1))] = math.sqrt(abs(t - edge))
             return out
         ca, cb = {}, {self.ROOT: math.sqrt(hi - lo)}  # W(lo) = 0, W(hi) ~ N(0, hi - lo)
         a, b, node = lo, hi, 1

@@ -152,9 +152,11 @@ int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t stre
 
 /* Brownian-interval noise (the reference wraps ComfyUI's BrownianTreeNoiseSampler -> torchsde, un-vendored:
  * py/noise_generation.py:262-286, py/nodes/powernoise.py:383-393).  out[e] = sum_k coefs[k] * z(node_ids[k], e) with
- * z a counter-based N(0,1) keyed by (seed, node id, global element index elem_offset + e).  node_ids / coefs are HOST arrays
- * (<= 96 entries): the bisection path(s) of the queried interval, walked by the host in fp64.  latent_seeds (device,
- * nullable): one seed per latent of latent_elems elements (the sampler's batched-seed mode), replacing `seed`. */
+ * z a counter-based N(0,1) keyed by (seed, node id (48 bits), global element index elem_offset + e).  node_ids / coefs are
+ * HOST arrays (<= 96 entries): the bisection path(s) of the queried interval, walked by the host in fp64.  latent_elems =
+ * elements per latent (0 if unknown): when it is a multiple of 4096 and there is one seed, z(node, .) is the tile-keyed burst
+ * stream of the Gaussian fill with stream id = node (one Philox seeding per 64 values); otherwise one Philox4x32-10 call per
+ * 4 values.  latent_seeds (device, nullable): one seed per latent (the sampler's batched-seed mode), replacing `seed`. */
 int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, const uint64_t* node_ids, const float* coefs, int nnodes,
                        uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems, void* stream);
 
