@@ -259,6 +259,38 @@ def _prep_mask(mask: Tensor, x: Tensor) -> Tensor:
     return m.contiguous()
 
 
+class AdvancedWaveletNoise(AdvancedNoiseBase):
+    """py/noise.py:392-444."""
+
+    ns_factory_arg_keys = ("octave_scale_mode", "octave_rescale_mode", "post_octave_rescale_mode", "initial_amplitude", "persistence",
+                           "octaves", "octave_height_factor", "octave_width_factor", "height_factor", "width_factor", "min_height",
+                           "min_width", "update_blend", "update_blend_function")
+
+    @property
+    def ns_factory(self):
+        return WaveletNoiseGenerator
+
+    def clone_key(self, k):
+        if k == "custom_noise" and getattr(self, "custom_noise", None) is not None:
+            return self.custom_noise.clone()
+        return super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        if x.ndim < 4:
+            raise ValueError("Can only handle 4+ dimensional latents")
+        height, width = x.shape[-2:]
+        result = super().make_noise_sampler(x, *args, normalized=normalized, **kwargs)
+        wavelet_ng = result.noise_sampler
+        max_h = int(max(height, *(od.height for od in wavelet_ng.octave_data))) if wavelet_ng.octave_data else height
+        max_w = int(max(width, *(od.width for od in wavelet_ng.octave_data))) if wavelet_ng.octave_data else width
+        internal = None
+        if getattr(self, "custom_noise", None) is not None:
+            ref_x = x.new_zeros(*x.shape[:-2], max_h, max_w) if (max_w != width or max_h != height) else x
+            internal = self.custom_noise.make_noise_sampler(ref_x, *args, normalized=self.normalize_noise, **kwargs)
+        wavelet_ng.set_internal_noise_sampler(internal)
+        return result
+
+
 class CompositeNoise(CustomNoiseItemBase):
     """py/noise.py:470-533: dst*(1-mask) + src*mask; dst is sampled before src."""
 

@@ -13,7 +13,7 @@ from __future__ import annotations
 import math
 import threading
 from enum import Enum, auto
-from typing import Optional
+from typing import NamedTuple, Optional
 
 import torch
 
@@ -532,7 +532,6 @@ DistroNoiseGenerator = _off_path("distro")
 VoronoiNoiseGenerator = _off_path("voronoi")
 CollatzNoiseGenerator = _off_path("collatz")
 PowerOldNoiseGenerator = _off_path("power_old")
-WaveletNoiseGenerator = _off_path("wavelet")
 ScatternetFilteredNoiseGenerator = _off_path("scatternet_filtered")
 
 
@@ -824,3 +823,88 @@ class BrownianNoiseGenerator(NoiseGenerator):
 
     def generate(self, *args):
         return self.brownian_tree_ns(*args)
+
+
+class WaveletNoiseOctave(NamedTuple):
+    octave: int
+    height: float
+    width: float
+    amplitude: float
+    total_amplitude: float
+
+
+class WaveletNoiseGenerator(FramesToChannelsNoiseGenerator):
+    """py/noise_generation.py:2204-2327: octaves of (noise - lowpass(noise)) at shrinking resolutions, resampled back to the
+    latent size and summed with decaying amplitudes.  The resampling steps (adaptive average pooling down, bilinear up) run on
+    the HIP resampler; the octave arithmetic on the blend / axpby kernels."""
+
+    name = "wavelet"
+    MIN_DIMS = 4
+    MAX_DIMS = 5
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {
+            "octave_scale_mode": "adaptive_avg_pool2d", "octave_rescale_mode": "bilinear", "post_octave_rescale_mode": "bilinear",
+            "initial_amplitude": 1.0, "persistence": 0.5, "octaves": 4, "octave_height_factor": 0.5, "octave_width_factor": 0.5,
+            "height_factor": 2.0, "width_factor": 2.0, "min_height": 4, "min_width": 4, "update_blend": 1.0,
+            "update_blend_function": utils.BLENDING_MODES["lerp"], "noise_sampler": None,
+        }
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.set_octave_data()
+
+    def set_internal_noise_sampler(self, noise_sampler) -> None:
+        self.noise_sampler = noise_sampler
+
+    def set_octave_data(self) -> None:
+        height, width = self.get_adjusted_shape()[-2:]
+        amplitude, total = self.initial_amplitude, 0.0
+        ch, cw = height, width
+        data = []
+        reverse = self.octaves < 0
+        for octave in (reversed(range(abs(self.octaves))) if reverse else range(self.octaves)):
+            ch /= self.height_factor**octave
+            cw /= self.width_factor**octave
+            if (amplitude == 0 or ch < self.min_height or cw < self.min_width or ch * self.octave_height_factor < 1
+                    or cw * self.octave_width_factor < 1):
+                if reverse and not data:
+                    ch, cw = height, width
+                    continue
+                break
+            total += abs(amplitude)
+            data.append(WaveletNoiseOctave(octave, ch, cw, amplitude, total))
+            amplitude *= self.persistence
+        if not data or not total:
+            raise ValueError("Unworkable parameters for wavelet noise")
+        self.octave_data = tuple(data)
+
+    def _generate_octave(self, *args, shape) -> Tensor:
+        height, width = shape[-2:]
+        if self.noise_sampler:
+            noise = self.noise_sampler(*args)
+            utils.pop_stats(noise)
+            noise = noise[..., :height, :width].reshape(shape).contiguous()
+        else:
+            noise = self.rand_like(shape=(*shape[:-2], height, width))
+            utils.pop_stats(noise)
+        sh, sw = int(max(1, height * self.octave_height_factor)), int(max(1, width * self.octave_width_factor))
+        low = utils.scale_samples(utils.scale_samples(noise, sw, sh, mode=self.octave_scale_mode), width=width, height=height,
+                                  mode=self.octave_rescale_mode)
+        detail = hip_lib.blend("subtract_b", noise, low, 1.0)  # noise - lowpass(noise)
+        return self.update_blend_function(noise, detail, self.update_blend)
+
+    def generate(self, *args) -> Tensor:
+        shape = self.get_adjusted_shape()
+        height, width = shape[-2:]
+        result = None
+        for od in self.octave_data:
+            octave = self._generate_octave(*args, shape=(*shape[:-2], int(od.height), int(od.width)))
+            if tuple(octave.shape) != tuple(shape):
+                octave = utils.scale_samples(octave, width, height, mode=self.post_octave_rescale_mode)
+            result = hip_lib.mul_scalar(octave, od.amplitude) if result is None else hip_lib.axpby_(result, 1.0, octave, od.amplitude)
+        total = self.octave_data[-1].total_amplitude
+        if total != 0:
+            result = hip_lib.div_scalar(result, total, out=result)
+        return self.fix_output_frames(result)

@@ -682,6 +682,38 @@ def gen_video():
     save("video", **cases)
 
 
+# ------------------------------------------------------------------------------------------------ wavelet (octave) noise
+WAVELET_ADV = {"deep": dict(octaves=6, persistence=0.7, initial_amplitude=2.0, height_factor=1.5, width_factor=1.5, min_height=2, min_width=2),
+               "reverse": dict(octaves=-3, persistence=0.5, octave_height_factor=0.25, octave_width_factor=0.5, update_blend=0.6),
+               "modes": dict(octaves=3, octave_scale_mode="area", octave_rescale_mode="nearest-exact", post_octave_rescale_mode="bilinear")}
+
+
+def gen_wavelet_noise():
+    cases = {}
+    shape = (2, 4, 48, 32)
+    for normalized in (False, True):
+        cases[f"preset_{int(normalized)}"] = ref_noise(NT.WAVELET, shape, 91, normalized)
+    for name, kw in WAVELET_ADV.items():
+        item = ref.noise.AdvancedWaveletNoise(1.0, custom_noise=None, normalize_noise=False, normalize=None, update_blend_function=torch.lerp,
+                                              **({"octave_scale_mode": "adaptive_avg_pool2d", "octave_rescale_mode": "bilinear",
+                                                  "post_octave_rescale_mode": "bilinear", "initial_amplitude": 1.0, "persistence": 0.5,
+                                                  "octaves": 4, "octave_height_factor": 0.5, "octave_width_factor": 0.5, "height_factor": 2.0,
+                                                  "width_factor": 2.0, "update_blend": 1.0} | kw))
+        torch.manual_seed(91)
+        cases["adv_" + name] = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=91, cpu=True, normalized=False)(
+            torch.tensor(14.6), torch.tensor(10.0))
+    # octaves drawn by another chain (larger than the latent when an octave is): custom_noise
+    chain = ref.noise.CustomNoiseChain()
+    chain.add(ref.noise.CustomNoiseItem(1.0, noise_type="uniform"))
+    item = ref.noise.AdvancedWaveletNoise(1.0, custom_noise=chain, normalize_noise=True, normalize=None, update_blend_function=torch.lerp,
+                                          octave_scale_mode="adaptive_avg_pool2d", octave_rescale_mode="bilinear", post_octave_rescale_mode="bilinear",
+                                          initial_amplitude=1.0, persistence=0.5, octaves=3, octave_height_factor=0.5, octave_width_factor=0.5,
+                                          height_factor=2.0, width_factor=2.0, update_blend=1.0)
+    torch.manual_seed(92)
+    cases["adv_custom"] = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=92, cpu=True, normalized=True)(torch.tensor(14.6), torch.tensor(10.0))
+    save("wavelet_noise", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -701,6 +733,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_cfg5()
     gen_guidance()
     gen_video()
+    gen_wavelet_noise()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

@@ -275,3 +275,48 @@ def test_brownian_batched_seeds_and_time_brownian_power_noise(api):
     assert torch.equal(a, b) and abs(a.std().item() - 1.0) < 5e-3  # time-correlated: the same interval gives the same field
     with pytest.raises(ValueError):
         item.make_noise_sampler(x, None, None, seed=11, cpu=False, normalized=True)
+
+
+# ------------------------------------------------------------------------------------------------ wavelet (octave) noise
+WAVELET_BASE = {"octave_scale_mode": "adaptive_avg_pool2d", "octave_rescale_mode": "bilinear", "post_octave_rescale_mode": "bilinear",
+                "initial_amplitude": 1.0, "persistence": 0.5, "octaves": 4, "octave_height_factor": 0.5, "octave_width_factor": 0.5,
+                "height_factor": 2.0, "width_factor": 2.0, "update_blend": 1.0}
+WAVELET_ADV = {"deep": dict(octaves=6, persistence=0.7, initial_amplitude=2.0, height_factor=1.5, width_factor=1.5, min_height=2, min_width=2),
+               "reverse": dict(octaves=-3, persistence=0.5, octave_height_factor=0.25, octave_width_factor=0.5, update_blend=0.6),
+               "modes": dict(octaves=3, octave_scale_mode="area", octave_rescale_mode="nearest-exact", post_octave_rescale_mode="bilinear")}
+
+
+@pytest.mark.parametrize("normalized", [False, True])
+def test_wavelet_noise_preset(api, golden, normalized):
+    g = golden("wavelet_noise")
+    want = g[f"preset_{int(normalized)}"]
+    x = torch.zeros(tuple(want.shape), device="cuda")
+    torch.manual_seed(91)
+    ns = api.noise.get_noise_sampler("wavelet", x, 0.03, 14.6, seed=91, cpu=True, factor=1.0, normalized=normalized)
+    close(ns(*SIG), want)
+
+
+@pytest.mark.parametrize("name", list(WAVELET_ADV))
+def test_wavelet_noise_advanced(api, golden, name):
+    g = golden("wavelet_noise")
+    want = g["adv_" + name]
+    x = torch.zeros(tuple(want.shape), device="cuda")
+    item = api.noise.AdvancedWaveletNoise(1.0, custom_noise=None, normalize_noise=False, normalize=None,
+                                          update_blend_function=api.utils.BLENDING_MODES["lerp"], **(WAVELET_BASE | WAVELET_ADV[name]))
+    torch.manual_seed(91)
+    close(item.make_noise_sampler(x, 0.03, 14.6, seed=91, cpu=True, normalized=False)(*SIG), want)
+
+
+def test_wavelet_noise_node_with_custom_source(api, golden):
+    g = golden("wavelet_noise")
+    want = g["adv_custom"]
+    x = torch.zeros(tuple(want.shape), device="cuda")
+    chain = api.noise.CustomNoiseChain()
+    chain.add(api.noise.CustomNoiseItem(1.0, noise_type="uniform"))
+    node = api.registry.NODE_CLASS_MAPPINGS["SonarWaveletNoise"]()
+    (out_chain,) = node.go(factor=1.0, rescale=0.0, normalize="default", normalize_noise=True, custom_noise=chain, update_blend_mode="lerp",
+                           **(WAVELET_BASE | {"octaves": 3}))
+    torch.manual_seed(92)
+    close(out_chain.make_noise_sampler(x, 0.03, 14.6, seed=92, cpu=True, normalized=True)(*SIG), want)
+    with pytest.raises(ValueError):
+        node.go(factor=1.0, rescale=0.0, normalize="default", normalize_noise=True, update_blend_mode="lerp", **(WAVELET_BASE | {"octaves": 0}))
