@@ -291,6 +291,53 @@ class AdvancedWaveletNoise(AdvancedNoiseBase):
         return result
 
 
+class GuidedNoise(CustomNoiseItemBase):
+    """py/noise.py:536-623: a noise chain (or zeros) pulled towards a reference latent by the sampler's guidance arithmetic."""
+
+    def __init__(self, factor, *, guidance_factor, ref_latent, method, normalize_noise, normalize_result, noise=None):
+        super().__init__(factor, normalize_noise=normalize_noise, normalize_result=normalize_result, ref_latent=ref_latent.clone(),
+                         noise=noise.clone() if noise is not None else None, method=method, guidance_factor=guidance_factor)
+
+    def clone_key(self, k):
+        if k == "noise" and self.noise is None:
+            return None
+        if k in {"noise", "ref_latent"}:
+            return getattr(self, k).clone()
+        return super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        from .sonar import SonarGuidanceMixin  # sonar imports this module
+
+        factor, guidance_factor = self.factor, self.guidance_factor
+        normalize_noise, normalize_result = (self.get_normalize(f"normalize_{k}", normalized) for k in ("noise", "result"))
+        ns = None if self.noise is None else self.noise.make_noise_sampler(x, *args, normalized=normalize_noise, **kwargs)
+        x_zeros = torch.zeros_like(x) if ns is None else None
+        ref_latent = self.ref_latent.to(x, copy=True)
+        if ref_latent.shape[-2:] != x.shape[-2:]:
+            # one-off setup step on the reference latent (bicubic is outside the HIP resampler's modes)
+            ref_latent = torch.nn.functional.interpolate(ref_latent, size=x.shape[-2:], mode="bicubic", align_corners=True)
+        ref_latent = ref_latent.contiguous()
+
+        def base(s, sn):
+            if ns is None:
+                return x_zeros.clone()
+            out = ns(s, sn)
+            utils.pop_stats(out)
+            return out
+
+        if self.method == "linear":
+            def noise_sampler(s, sn):
+                return scale_noise(SonarGuidanceMixin.guidance_linear(base(s, sn), ref_latent, guidance_factor, do_shift=ns is not None),
+                                   factor, normalized=normalize_result)
+        elif self.method == "euler":
+            def noise_sampler(s, sn):
+                return scale_noise(SonarGuidanceMixin.guidance_euler(s, sn, base(s, sn), x, ref_latent, guidance_factor, do_shift=ns is not None),
+                                   factor, normalized=normalize_result)
+        else:
+            raise ValueError("Bad method")
+        return noise_sampler
+
+
 class CompositeNoise(CustomNoiseItemBase):
     """py/noise.py:470-533: dst*(1-mask) + src*mask; dst is sampled before src."""
 

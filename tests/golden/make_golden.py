@@ -714,6 +714,29 @@ def gen_wavelet_noise():
     save("wavelet_noise", **cases)
 
 
+# ------------------------------------------------------------------------------------------------ guided noise (8f rank 1)
+def gen_guided_noise():
+    cases = {}
+    shape = (2, 4, 16, 16)
+    torch.manual_seed(95)
+    x = torch.randn(shape) * 3.0
+    latent = torch.randn(shape) * 0.8 + 0.2
+    cases["x"], cases["latent"] = x, latent
+    S = ref.sonar
+    ref_lat = ref.utils.scale_noise(S.SonarGuidanceMixin.prepare_ref_latent(latent.clone()), normalized=True)
+    cases["ref_latent"] = ref_lat
+    chain = ref.noise.CustomNoiseChain()
+    chain.add(ref.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    for method in ("linear", "euler"):
+        for with_noise in (True, False):
+            item = ref.noise.GuidedNoise(1.0, guidance_factor=0.4, ref_latent=ref_lat, method=method, normalize_noise=None,
+                                         normalize_result=None, noise=chain if with_noise else None)
+            torch.manual_seed(96)
+            ns = item.make_noise_sampler(x.clone(), 0.03, 14.6, seed=96, cpu=True, normalized=True)
+            cases[f"{method}_{int(with_noise)}"] = ns(torch.tensor(9.0), torch.tensor(6.0))
+    save("guided_noise", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -734,6 +757,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_guidance()
     gen_video()
     gen_wavelet_noise()
+    gen_guided_noise()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

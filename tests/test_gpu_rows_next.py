@@ -320,3 +320,28 @@ def test_wavelet_noise_node_with_custom_source(api, golden):
     close(out_chain.make_noise_sampler(x, 0.03, 14.6, seed=92, cpu=True, normalized=True)(*SIG), want)
     with pytest.raises(ValueError):
         node.go(factor=1.0, rescale=0.0, normalize="default", normalize_noise=True, update_blend_mode="lerp", **(WAVELET_BASE | {"octaves": 0}))
+
+
+# ------------------------------------------------------------------------------------------------ guided noise (8f rank 1)
+@pytest.mark.parametrize("method", ["linear", "euler"])
+@pytest.mark.parametrize("with_noise", [True, False])
+def test_guided_noise(api, golden, method, with_noise):
+    g = golden("guided_noise")
+    x = g["x"].cuda()
+    chain = _gauss_chain(api) if with_noise else None
+    item = api.noise.GuidedNoise(1.0, guidance_factor=0.4, ref_latent=g["ref_latent"].cuda(), method=method, normalize_noise=None,
+                                 normalize_result=None, noise=chain)
+    torch.manual_seed(96)
+    ns = item.make_noise_sampler(x.clone(), 0.03, 14.6, seed=96, cpu=True, normalized=True)
+    close(ns(torch.tensor(9.0), torch.tensor(6.0)), g[f"{method}_{int(with_noise)}"], rtol=2e-5, atol=2e-5)
+
+
+def test_guided_noise_node_prepares_the_reference(api, golden):
+    g = golden("guided_noise")
+    node = api.registry.NODE_CLASS_MAPPINGS["SonarGuidedNoise"]()
+    (chain,) = node.go(factor=1.0, latent={"samples": g["latent"].cuda()}, normalize_noise="default", normalize_result="default",
+                       normalize_ref=True, method="euler", guidance_factor=0.4, sonar_custom_noise=_gauss_chain(api))
+    close(chain.items[0].ref_latent, g["ref_latent"], rtol=2e-5, atol=2e-5)
+    torch.manual_seed(96)
+    out = chain.make_noise_sampler(g["x"].cuda(), 0.03, 14.6, seed=96, cpu=True, normalized=True)(torch.tensor(9.0), torch.tensor(6.0))
+    close(out, g["euler_1"], rtol=2e-5, atol=2e-5)
