@@ -124,6 +124,42 @@ __global__ void __launch_bounds__(kBlock) perlin_terms_kernel(const float* __res
     }
 }
 
+// Generate mode: the lattice angles are drawn where they are used.  angle(iteration, c, gy, gx) = 2 pi u with u a
+// counter-based uniform (Philox4x32-10, counter = (lattice point, iteration group), key = seed; word `it % 4`), so the four
+// corners of a cell are random-access and a neighbouring cell recomputes the same values.  Writes the SUM over iterations
+// of the cell-centre terms: one launch instead of angle fill + terms + pre-add.
+__global__ void __launch_bounds__(kBlock) perlin_lattice_kernel(float* terms_sum, int iters, int64_t C, int H, int W, int blend_mode,
+                                                                uint64_t seed, uint64_t stream_id) {
+    const int64_t total = C * H * W;
+    const int gw = W + 1;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int64_t c = i / ((int64_t)W * H);
+        const int64_t p00 = (c * (H + 1) + y) * gw + x;  // lattice point index of the top-left corner
+        float acc = 0.0f;
+        for (int g = 0; g < iters; g += 4) {
+            auto words = [&](int64_t pt) { return philox4x32_10((uint32_t)pt, (uint32_t)(pt >> 32), (uint32_t)(g >> 2), (uint32_t)stream_id,
+                                                                (uint32_t)seed, (uint32_t)(seed >> 32)); };
+            const Philox4 w00 = words(p00), w01 = words(p00 + 1), w10 = words(p00 + gw), w11 = words(p00 + gw + 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // fully unrolled: the word index must be a compile-time constant (registers, not LDS)
+                if (g + k >= iters) break;
+                // v_sin / v_cos take revolutions: the angle 2 pi u is never formed
+                const float u00 = u01(w00.v[k]), u01_ = u01(w01.v[k]), u10 = u01(w10.v[k]), u11 = u01(w11.v[k]);
+                const float d0 = __builtin_amdgcn_cosf(u00) * 0.5f + __builtin_amdgcn_sinf(u00) * 0.5f;
+                const float d1 = __builtin_amdgcn_cosf(u01_) * -0.5f + __builtin_amdgcn_sinf(u01_) * 0.5f;
+                const float d2 = __builtin_amdgcn_cosf(u10) * 0.5f + __builtin_amdgcn_sinf(u10) * -0.5f;
+                const float d3 = __builtin_amdgcn_cosf(u11) * -0.5f + __builtin_amdgcn_sinf(u11) * -0.5f;
+                const float row0 = blend<float>(blend_mode, d0, d1, 0.5f);
+                const float row1 = blend<float>(blend_mode, d2, d3, 0.5f);
+                acc += blend<float>(blend_mode, row0, row1, 0.5f);
+            }
+        }
+        terms_sum[i] = acc;
+    }
+}
+
 // out[b][i] = base[b][i]/div + terms[0][i] + terms[1][i] + ...   (terms broadcast over batch)
 // replay: base read from memory.  One float4 per lane; chw % 4 == 0 on the vector path.
 template <bool STATS, int V>
@@ -726,6 +762,16 @@ extern "C" int sonar_perlin_terms_f32(const float* angles, float* terms, int64_t
     hipLaunchKernelGGL(perlin_terms_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, angles,
                        terms, iters * C, (int)H, (int)W, blend_mode);
     return check_launch("sonar_perlin_terms_f32");
+}
+
+extern "C" int sonar_perlin_lattice_f32(float* terms_sum, int64_t iters, int64_t C, int64_t H, int64_t W, int blend_mode, uint64_t seed,
+                                        uint64_t stream_id, void* stream) {
+    SONAR_REQUIRE(terms_sum && iters >= 0 && iters < (1 << 20) && C > 0 && H > 0 && W > 0 && blend_mode >= 0 && blend_mode <= 2,
+                  SONAR_ERR_ARG, "sonar_perlin_lattice_f32: bad argument");
+    SONAR_REQUIRE(H < (1 << 20) && W < (1 << 20), SONAR_ERR_UNSUPPORTED, "sonar_perlin_lattice_f32: plane too large");
+    hipLaunchKernelGGL(perlin_lattice_kernel, dim3(grid_for(C * H * W, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, terms_sum,
+                       (int)iters, C, (int)H, (int)W, blend_mode, seed, stream_id);
+    return check_launch("sonar_perlin_lattice_f32");
 }
 
 extern "C" int sonar_perlin_apply_f32(const float* base, const float* terms, float* out, int64_t B, int64_t chw,

@@ -84,6 +84,7 @@ SIGNATURES = {
     "sonar_philox_uniform_f32": (_I, [_P, _I64, _U64, _U64, _I64, _F, _F, _F, _P, _P]),
     "sonar_brownian_f32": (_I, [_P, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_perlin_terms_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
+    "sonar_perlin_lattice_f32": (_I, [_P, _I64, _I64, _I64, _I64, _I, _U64, _U64, _P]),
     "sonar_perlin_apply_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P]),
     "sonar_perlin_generate_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _P, _P]),
     "sonar_perlin_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _F, _F, _P, _P]),
@@ -396,6 +397,14 @@ def perlin_terms(angles: torch.Tensor, blend_mode: str = "lerp") -> torch.Tensor
         "sonar_perlin_terms_f32",
     )
     return terms
+
+
+def perlin_lattice(iters: int, c: int, h: int, w: int, device, blend_mode: str, seed: int, stream_id: int) -> torch.Tensor:
+    """Sum over `iters` of the Perlin cell-centre terms with in-kernel lattice angles: [1, C, H, W]."""
+    out = torch.empty((1, c, h, w), dtype=torch.float32, device=device)
+    _check(load().sonar_perlin_lattice_f32(_dev(out, "terms"), iters, c, h, w, BLEND_IDS[blend_mode], seed & (2**64 - 1), stream_id, _stream()),
+           "sonar_perlin_lattice_f32")
+    return out
 
 
 def perlin_apply(base: torch.Tensor, terms: torch.Tensor, div_fac: float, partials=None) -> torch.Tensor:

@@ -346,17 +346,10 @@ class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):
     def _device_generate(self, partials, fused_factor):
         b, c, h, w = self.get_adjusted_shape()
         seed, stream = self.device_key(2)
-        # the lattice is shared by every latent (and every rank): no batch offset in its counter
-        angles = hip_lib.philox_uniform((max(self.iterations, 0), c, h + 1, w + 1), self.device, seed, stream + 1, 0,
-                                        sub=0.0, mul=2.0 * math.pi, add=0.0)
-        terms = hip_lib.perlin_terms(angles, self.blend_mode)
-        if terms.shape[0] > 1:
-            # device draws have no bit-parity reference: pre-add the lattice terms once ([C,H,W], 256 KiB) so the
-            # streaming kernels read one table instead of `iterations` tables per element
-            total = terms[0].contiguous()
-            for extra in terms[1:]:
-                hip_lib.axpby_(total, 1.0, extra.contiguous(), 1.0)
-            terms = total.unsqueeze(0)
+        # the lattice is shared by every latent (and every rank): no batch offset in its counter.  Device draws have no
+        # bit-parity reference: the angles are drawn inside the terms kernel and the iterations summed there ([C,H,W], 256 KiB),
+        # so the streaming kernels read one table
+        terms = hip_lib.perlin_lattice(max(self.iterations, 0), c, h, w, self.device, self.blend_mode, seed, stream + 1)
         offs = self.latent_elem_offset(c * h * w)
         if fused_factor is None:
             return hip_lib.perlin_generate((b, c, h, w), terms, self.div_fac, seed, stream, offs, partials)

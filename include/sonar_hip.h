@@ -166,6 +166,10 @@ int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, const uint64_
  * reference's blend tree.  blend_mode: SONAR_BLEND_* */
 int sonar_perlin_terms_f32(const float* angles, float* terms, int64_t iters, int64_t C, int64_t H, int64_t W,
                            int blend_mode, void* stream);
+/* generate mode: the same terms with the lattice angles drawn where they are used (counter-based, keyed by seed / stream_id /
+ * lattice point / iteration; shared by every latent and every rank), summed over the iterations: terms_sum[C][H][W] */
+int sonar_perlin_lattice_f32(float* terms_sum, int64_t iters, int64_t C, int64_t H, int64_t W, int blend_mode, uint64_t seed,
+                             uint64_t stream_id, void* stream);
 /* replay mode, py/noise_generation.py:478-493: out = base/div_fac (+ terms[i] broadcast over B, in order) */
 int sonar_perlin_apply_f32(const float* base, const float* terms, float* out, int64_t B, int64_t chw,
                            int64_t iters, float div_fac, double* partials /*nullable*/, void* stream);

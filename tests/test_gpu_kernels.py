@@ -531,3 +531,43 @@ def test_c_abi_error_codes_and_messages(hl):
         hl.power_irfft2(None, filt, (2, 1, 24, 24))
     with pytest.raises(hl.SonarHipError):
         hl.stats(torch.zeros(8))  # host tensor
+
+
+# ------------------------------------------------------------------------------------------------ Perlin lattice drawn in-kernel
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Reference Philox4x32-10 on numpy uint64 lanes (Salmon et al.); returns the four 32-bit words."""
+    import numpy as np
+
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    mask = np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) & mask for v in (c0, c1, c2, c3))
+    for r in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        kk0, kk1 = np.uint64((k0 + r * W0) & 0xFFFFFFFF), np.uint64((k1 + r * W1) & 0xFFFFFFFF)
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ kk0) & mask, lo1, (hi0 ^ c3 ^ kk1) & mask, lo0
+    return c0, c1, c2, c3
+
+
+@pytest.mark.parametrize("blend_mode", ["lerp", "inject"])
+def test_perlin_lattice_kernel_against_a_host_replay_of_its_draws(hl, blend_mode):
+    """sonar_perlin_lattice_f32 draws angle(it, c, gy, gx) = 2 pi u, u = word[it % 4] >> 8 * 2^-24 of
+    Philox4x32-10(counter = (lattice point lo, hi, it // 4, stream), key = seed): replayed here with numpy, then the oracle's term."""
+    import numpy as np
+
+    C, H, W, iters, seed, stream = 2, 5, 7, 6, 0x1234567890ABCDEF, 9
+    got = hl.perlin_lattice(iters, C, H, W, "cuda", blend_mode, seed, stream).cpu()[0]
+    pts = np.arange(C * (H + 1) * (W + 1), dtype=np.uint64)
+    angles = np.zeros((iters, C, H + 1, W + 1), dtype=np.float32)
+    for g in range(0, iters, 4):
+        words = _philox4x32_10(pts & np.uint64(0xFFFFFFFF), pts >> np.uint64(32), np.full_like(pts, g // 4), np.full_like(pts, stream),
+                               seed & 0xFFFFFFFF, seed >> 32)
+        for k in range(4):
+            if g + k < iters:
+                u = (words[k] >> np.uint64(8)).astype(np.float32) * np.float32(2.0**-24)
+                angles[g + k] = (u * np.float32(2 * math.pi)).reshape(C, H + 1, W + 1)
+    want = sum(orc.perlin_term(torch.from_numpy(angles[i]), blend_mode) for i in range(iters))
+    close(got, want, rtol=0, atol=3e-6 * iters)
+    # statistics of a big lattice: the term of one iteration has zero mean
+    big = hl.perlin_lattice(1, 4, 128, 128, "cuda", "lerp", 7, 0)
+    assert abs(big.mean().item()) < 5e-3 and big.std().item() > 0.05
