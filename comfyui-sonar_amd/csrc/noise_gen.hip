@@ -400,6 +400,7 @@ struct PyramidLevels {
     int h[kMaxLevels], w[kMaxLevels];
     float weight[kMaxLevels];
     int count;       // small-grid levels
+    unsigned long long draw_stream[kMaxLevels];  // ptr == nullptr: the level grid is drawn by the plane kernel from this stream id
     int fullres;     // number of leading full-resolution levels folded into the base draw (0 or 1)
     float fullres_weight;
     float base_scale;  // sqrt(1 + fullres_weight^2) when fullres else 1
@@ -510,8 +511,18 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
         int off = 0;
         for (int l = 0; l < lv.count; ++l) {
             const int n = lv.h[l] * lv.w[l];
-            const float* src = lv.ptr[l] + p * (int64_t)n;
-            for (int i = threadIdx.x; i < n; i += kBlock) pyr_lds[off + i] = src[i];
+            if (lv.ptr[l]) {
+                const float* src = lv.ptr[l] + p * (int64_t)n;
+                for (int i = threadIdx.x; i < n; i += kBlock) pyr_lds[off + i] = src[i];
+            } else if ((int)threadIdx.x * 4 < n) {
+                // the grid is drawn here: stream (level stream id, global plane, thread), thread t owns elements 4t.., 4(t + 256)..
+                Xoshiro rng = rng_stream(seed, lv.draw_stream[l], (uint64_t)(elem_offset / HW + p), threadIdx.x);
+                for (int i = threadIdx.x * 4; i < n; i += kBlock * 4) {
+                    float z[4];
+                    rng.normal4(z);
+                    for (int k = 0; k < 4 && i + k < n; ++k) pyr_lds[off + i + k] = z[k];
+                }
+            }
             off += n;
         }
         __syncthreads();
@@ -679,16 +690,17 @@ __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n,
 }
 
 static int fill_levels(PyramidLevels& lv, int64_t H, int64_t W, int64_t nlevels, const float* const* level_ptrs,
-                       const int64_t* level_h, const int64_t* level_w, const float* level_weight, const char* what) {
+                       const int64_t* level_h, const int64_t* level_w, const float* level_weight, uint64_t stream_id, bool* drawn,
+                       const char* what) {
+    *drawn = false;
     lv = PyramidLevels{};
     lv.fullres_weight = 1.0f;
     lv.base_scale = 1.0f;
     SONAR_REQUIRE(nlevels == 0 || (level_ptrs && level_h && level_w && level_weight), SONAR_ERR_ARG, "%s: level arrays missing", what);
     for (int64_t l = 0; l < nlevels; ++l) {
-        if (level_ptrs[l] == nullptr) {
-            // a NULL pointer marks a full-resolution level drawn inside the kernel (stream_id + 1)
-            SONAR_REQUIRE(lv.fullres == 0 && level_h[l] == H && level_w[l] == W, SONAR_ERR_ARG,
-                          "%s: only one in-kernel full-resolution level", what);
+        if (level_ptrs[l] == nullptr && level_h[l] == H && level_w[l] == W) {
+            // a NULL pointer at the latent's own size: the level is folded into the base draw
+            SONAR_REQUIRE(lv.fullres == 0, SONAR_ERR_ARG, "%s: only one in-kernel full-resolution level", what);
             lv.fullres = 1;
             lv.fullres_weight = level_weight[l];
             lv.base_scale = sqrtf(1.0f + level_weight[l] * level_weight[l]);
@@ -696,6 +708,8 @@ static int fill_levels(PyramidLevels& lv, int64_t H, int64_t W, int64_t nlevels,
         }
         SONAR_REQUIRE(lv.count < kMaxLevels, SONAR_ERR_UNSUPPORTED, "%s: too many levels", what);
         lv.ptr[lv.count] = level_ptrs[l];
+        lv.draw_stream[lv.count] = stream_id + 2 + (uint64_t)l;  // used when ptr is NULL: the plane kernel draws the grid
+        if (!level_ptrs[l]) *drawn = true;
         lv.h[lv.count] = (int)level_h[l];
         lv.w[lv.count] = (int)level_w[l];
         lv.weight[lv.count] = level_weight[l];
@@ -836,11 +850,14 @@ extern "C" int sonar_pyramid_generate_f32(float* out, int64_t planes, int64_t H,
     int rc = pyramid_common("sonar_pyramid_generate_f32", out, planes, H, W, mode, elem_offset);
     if (rc != SONAR_OK) return rc;
     PyramidLevels lv;
-    rc = fill_levels(lv, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, "sonar_pyramid_generate_f32");
+    bool drawn = false;
+    rc = fill_levels(lv, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, stream_id, &drawn, "sonar_pyramid_generate_f32");
     if (rc != SONAR_OK) return rc;
     if (planes == 0) return SONAR_OK;
     if (launch_pyramid_plane(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, (hipStream_t)stream))
         return check_launch("sonar_pyramid_generate_f32");
+    SONAR_REQUIRE(!drawn, SONAR_ERR_UNSUPPORTED, "sonar_pyramid_generate_f32: in-kernel level grids need the plane kernel (H*W %% 4096 == 0, "
+                  "whole planes, grids within the LDS budget): pass the grids explicitly");
     const int g = tile_grid(planes * H * W, elem_offset);
     if (partials)
         hipLaunchKernelGGL((pyramid_generate_kernel<0, true>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes,
@@ -860,7 +877,8 @@ extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, in
     if (rc != SONAR_OK) return rc;
     SONAR_REQUIRE(partials, SONAR_ERR_ARG, "sonar_pyramid_noise_f32: partials workspace required");
     PyramidLevels lv;
-    rc = fill_levels(lv, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, "sonar_pyramid_noise_f32");
+    bool drawn = false;
+    rc = fill_levels(lv, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, stream_id, &drawn, "sonar_pyramid_noise_f32");
     if (rc != SONAR_OK) return rc;
     if (planes == 0) return SONAR_OK;
     // The level gathers make a re-draw cost more than a sweep: generate once (with statistics), then normalise in place
@@ -869,6 +887,7 @@ extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, in
         if (rc != SONAR_OK) return rc;
         return sonar_scale_noise_f32(out, planes * H * W, factor, 1, threshold_std_devs, partials, kNPart, planes * H * W, stream);
     }
+    SONAR_REQUIRE(!drawn, SONAR_ERR_UNSUPPORTED, "sonar_pyramid_noise_f32: in-kernel level grids need the plane kernel: pass the grids explicitly");
     const int g = tile_grid(planes * H * W, elem_offset);
     const NormArgs na{partials, planes * H * W, factor, threshold_std_devs};
     hipLaunchKernelGGL((pyramid_generate_kernel<1, false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes, (int)H,

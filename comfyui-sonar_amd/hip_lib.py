@@ -470,17 +470,18 @@ def _pyramid_args(levels):
     return n, ptrs, hs, ws, wts
 
 
-def pyramid_generate(shape, device, levels: Sequence, mode: str, seed: int, stream_id: int, elem_offset: int = 0, partials=None) -> torch.Tensor:
-    """levels: list of (tensor-or-None, h, w, weight); None marks the in-kernel full-resolution level."""
+def pyramid_generate(shape, device, levels: Sequence, mode: str, seed: int, stream_id: int, elem_offset: int = 0, partials=None):
+    """levels: list of (tensor-or-None, h, w, weight); None = drawn on device (see sonar_pyramid_generate_f32).
+    Returns None when a level is to be drawn in-kernel and the plane kernel cannot run this shape."""
     out = torch.empty(shape, dtype=torch.float32, device=device)
     H, W = shape[-2:]
     planes = out.numel() // (H * W)
     n, ptrs, hs, ws, wts = _pyramid_args(levels)
-    _check(
-        load().sonar_pyramid_generate_f32(_dev(out, "out"), planes, H, W, n, ptrs, hs, ws, wts, RESAMPLE_IDS[mode], seed & (2**64 - 1),
-                                          stream_id, elem_offset, _opt(partials, "partials", torch.float64), _stream()),
-        "sonar_pyramid_generate_f32",
-    )
+    rc = load().sonar_pyramid_generate_f32(_dev(out, "out"), planes, H, W, n, ptrs, hs, ws, wts, RESAMPLE_IDS[mode], seed & (2**64 - 1),
+                                           stream_id, elem_offset, _opt(partials, "partials", torch.float64), _stream())
+    if rc == ERR_UNSUPPORTED and any(lv[0] is None and (lv[1], lv[2]) != (H, W) for lv in levels):
+        return None
+    _check(rc, "sonar_pyramid_generate_f32")
     return out
 
 
@@ -491,11 +492,11 @@ def pyramid_noise(shape, device, levels: Sequence, mode: str, seed: int, stream_
     planes = out.numel() // (H * W)
     n, ptrs, hs, ws, wts = _pyramid_args(levels)
     work = new_partials(device)
-    _check(
-        load().sonar_pyramid_noise_f32(_dev(out, "out"), planes, H, W, n, ptrs, hs, ws, wts, RESAMPLE_IDS[mode], seed & (2**64 - 1),
-                                       stream_id, elem_offset, float(factor), float(threshold_std_devs), _dev(work, "ws", torch.float64), _stream()),
-        "sonar_pyramid_noise_f32",
-    )
+    rc = load().sonar_pyramid_noise_f32(_dev(out, "out"), planes, H, W, n, ptrs, hs, ws, wts, RESAMPLE_IDS[mode], seed & (2**64 - 1),
+                                        stream_id, elem_offset, float(factor), float(threshold_std_devs), _dev(work, "ws", torch.float64), _stream())
+    if rc == ERR_UNSUPPORTED and any(lv[0] is None and (lv[1], lv[2]) != (H, W) for lv in levels):
+        return None
+    _check(rc, "sonar_pyramid_noise_f32")
     return out
 
 

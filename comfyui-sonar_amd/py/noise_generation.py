@@ -408,19 +408,31 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
         b, c, h, w = self.get_adjusted_shape()
         seed, stream = self.device_key(2 + self.iterations)
         host = torch.Generator().manual_seed((seed * 0x9E3779B97F4A7C15 + stream) % (2**63))  # shared by all ranks
-        levels = []
+        plan = list(self._plan(h, w, lambda: torch.rand(1, generator=host).item() * 2 + 2))
         plane_offset = current_batch_offset() * c
-        for i, ch, cw in self._plan(h, w, lambda: torch.rand(1, generator=host).item() * 2 + 2):
+        offs = self.latent_elem_offset(c * h * w)
+
+        def run(levels):
+            if fused_factor is not None:
+                return hip_lib.pyramid_noise((b, c, h, w), self.device, levels, mode, seed, stream, offs, fused_factor)
+            out = hip_lib.pyramid_generate((b, c, h, w), self.device, levels, mode, seed, stream, offs, partials)
+            return None if out is None else attach_stats(out, partials)
+
+        if w % 4 == 0:
+            # every level drawn on device: full-resolution levels fold into the base draw, the small grids are drawn by the
+            # plane kernel (no launches, no HBM round trip for them); if that kernel cannot run this shape, explicit grids
+            out = run([(None, ch, cw, self.discount**i) for i, ch, cw in plan])
+            if out is not None:
+                return out
+        levels = []
+        for i, ch, cw in plan:
             if (ch, cw) == (h, w) and not any(lv[0] is None for lv in levels):
-                levels.append((None, h, w, self.discount**i))  # full-resolution level drawn inside the kernel
+                levels.append((None, h, w, self.discount**i))  # full-resolution level folded into the base draw
             else:
                 grid = hip_lib.philox_normal((b * c, ch, cw), self.device, seed, stream + 2 + i, plane_offset * ch * cw)
                 levels.append((grid, ch, cw, self.discount**i))
-        offs = self.latent_elem_offset(c * h * w)
         if w % 4 == 0:
-            if fused_factor is not None:
-                return hip_lib.pyramid_noise((b, c, h, w), self.device, levels, mode, seed, stream, offs, fused_factor)
-            return attach_stats(hip_lib.pyramid_generate((b, c, h, w), self.device, levels, mode, seed, stream, offs, partials), partials)
+            return run(levels)
         # rare odd widths: same values through the unfused kernels
         out = hip_lib.philox_normal((b, c, h, w), self.device, seed, stream, offs)
         for grid, ch, cw, wt in levels:

@@ -191,8 +191,10 @@ int sonar_perlin_noise_f32(const float* terms, float* out, int64_t B, int64_t ch
  * 1 nearest-exact, 2 area (adaptive average, used when downscaling) */
 int sonar_resample_acc_f32(float* dst, const float* src, int64_t planes, int64_t H, int64_t W, int64_t h, int64_t w,
                            float scale, int mode, int accumulate, double* partials /*nullable*/, void* stream);
-/* generate mode: out = N(0,1) + sum_l upsample(levels[l])*weights[l]; levels are device pointers to
- * [planes][h_l][w_l] small grids (level 0 = full-res draws folded in as a second Philox stream) */
+/* generate mode: out = N(0,1) * base_scale + sum_l upsample(levels[l]) * weights[l].  level_ptrs[l]: device pointer to a
+ * [planes][h_l][w_l] grid, or NULL = drawn on device: a NULL level of the latent's own size is folded into the base draw
+ * (sum of two independent normals: base_scale = sqrt(1 + w^2)); a smaller NULL level is drawn by the plane kernel (stream
+ * id stream_id + 2 + l, keyed by global plane) -- SONAR_ERR_UNSUPPORTED if that kernel cannot run this shape. */
 int sonar_pyramid_generate_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels,
                                const float* const* level_ptrs /*host array of device ptrs*/, const int64_t* level_h,
                                const int64_t* level_w, const float* level_weight, int mode, uint64_t seed,

@@ -571,3 +571,23 @@ def test_perlin_lattice_kernel_against_a_host_replay_of_its_draws(hl, blend_mode
     # statistics of a big lattice: the term of one iteration has zero mean
     big = hl.perlin_lattice(1, 4, 128, 128, "cuda", "lerp", 7, 0)
     assert abs(big.mean().item()) < 5e-3 and big.std().item() > 0.05
+
+
+def test_pyramid_in_kernel_level_grids(hl):
+    """Small level grids drawn by the plane kernel (NULL pointer, size below the latent's): deterministic, shard-invariant,
+    right variance; shapes the plane kernel cannot run report 'unsupported' (None) so the host passes explicit grids."""
+    shape = (6, 4, 64, 64)
+    levels = [(None, 64, 64, 1.0), (None, 21, 20, 0.7), (None, 3, 3, 0.49)]
+    a = hl.pyramid_generate(shape, "cuda", levels, "bilinear", 11, 5)
+    assert torch.equal(a, hl.pyramid_generate(shape, "cuda", levels, "bilinear", 11, 5))
+    tail = hl.pyramid_generate((4, 4, 64, 64), "cuda", levels, "bilinear", 11, 5, 2 * 4 * 64 * 64)
+    assert torch.equal(tail, a[2:])
+    other = hl.pyramid_generate(shape, "cuda", levels, "bilinear", 12, 5)
+    assert abs((other * a).mean().item()) < 0.02
+    # variance: 1 + 1 (folded full-resolution level) + the interpolated small levels' share (< their weights squared)
+    v = a.double().var().item()
+    assert 2.0 < v < 2.0 + 0.49 + 0.24 + 0.05
+    # coarse structure really is there: 8x8 block means carry more variance than white noise of variance v would (v / 64)
+    blocks = a.reshape(6, 4, 8, 8, 8, 8).mean(dim=(3, 5))
+    assert blocks.double().var().item() > 3 * v / 64
+    assert hl.pyramid_generate((2, 4, 32, 32), "cuda", [(None, 32, 32, 1.0), (None, 9, 9, 0.7)], "bilinear", 11, 5) is None
