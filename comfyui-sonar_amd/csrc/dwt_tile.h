@@ -50,9 +50,6 @@ struct BandArgs {
     T strength;
 };
 
-// PAIR = false: plain DWT of xc -> (llc, hi).  PAIR = true: DWT of xc and xu, hi = band(xc, xu) per orientation;
-// llc / llu separate, or llc = band(ll_c, ll_u) when combine_ll.  ZERO: zero-extension mode (the only mode with "no
-// source" positions; the others never need a select).
 // LDS tile layout: tmp[row][slot(x)][NV] with NV = 2 (lowH, highH) or 4 (cond lowH, cond highH, uncond lowH, uncond highH)
 // and slot(x) = (x & 1) * ceil(W / 2) + x / 2: a tap reads one parity class, so consecutive lanes hit consecutive slots
 // (conflict-free vector reads) and one read fetches every value a tap needs.
@@ -61,38 +58,52 @@ struct alignas(sizeof(T) * NV > 16 ? 16 : sizeof(T) * NV) TileVec {
     T v[NV];
 };
 
-template <typename T, typename TIn, bool PAIR, int FT, bool ZERO>
-__global__ void __launch_bounds__(kTileThreads) dwt2_tile_kernel(const TIn* __restrict__ xc, const TIn* __restrict__ xu,
-                                                                 T* __restrict__ llc, T* __restrict__ llu, T* __restrict__ hi,
-                                                                 int64_t planes, int H, int W, int h, int w, int tiles, Taps<T> tp,
-                                                                 int mode, BandArgs<T> ba) {
-    extern __shared__ __align__(16) unsigned char tile_smem[];
+// LDS geometry of one analysis tile: tmp[kFwdRows][2 ceil(W/2)] vectors, then xmap[2w + FT], ymap[2h + FT]
+template <typename T, int NV, int FT>
+struct FwdLds {
+    using Vec = TileVec<T, NV>;
+    Vec* tmp;
+    int* xmap;
+    int* ymap;
+    int Wh, Ws;
+    __device__ __forceinline__ FwdLds(unsigned char* smem, int W, int w) {
+        Wh = (W + 1) >> 1;
+        Ws = 2 * Wh;
+        tmp = reinterpret_cast<Vec*>(smem);
+        xmap = reinterpret_cast<int*>(tmp + kFwdRows * Ws);
+        ymap = xmap + (2 * w + FT);
+    }
+};
+
+// extension tables for extended position i + off - (F - 1): xmap = LDS slot (or -1), ymap = source row (or -1)
+template <int FT>
+__device__ __forceinline__ void fwd_build_maps(int* xmap, int* ymap, int H, int W, int h, int w, int Wh, int mode) {
+    const int off = mode == kPeriodization ? FT / 2 : 1;
+    const int He = (mode == kPeriodization && (H & 1)) ? H + 1 : H;
+    const int We = (mode == kPeriodization && (W & 1)) ? W + 1 : W;
+    for (int i = threadIdx.x; i < 2 * w + FT - 2; i += kTileThreads) {
+        const int sx = src_index(i + off - (FT - 1), W, We, mode);
+        xmap[i] = sx < 0 ? -1 : (sx & 1) * Wh + (sx >> 1);
+    }
+    for (int i = threadIdx.x; i < 2 * h + FT - 2; i += kTileThreads) ymap[i] = src_index(i + off - (FT - 1), H, He, mode);
+}
+
+// one analysis tile: output rows [y0, y0 + th) of one plane (pc / pu, ollc / ollu / ohi are plane pointers)
+template <typename T, typename TIn, bool PAIR, int FT, bool ZERO, typename TP>
+__device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const TIn* __restrict__ pu, T* __restrict__ ollc,
+                                             T* __restrict__ ollu, T* __restrict__ ohi, int W, int h, int w, int y0, int th,
+                                             const TP& tp, const BandArgs<T>& ba, const FwdLds<T, PAIR ? 4 : 2, FT>& lds) {
     constexpr int TH = kFwdRows, NR = 2 * TH + FT - 2, NT = PAIR ? 2 : 1, NV = 2 * NT;
     using Vec = TileVec<T, NV>;
     using Half = TileVec<T, 2>;
-    const int Wh = (W + 1) >> 1, Ws = 2 * Wh;        // slots per row
-    Vec* const tmp = reinterpret_cast<Vec*>(tile_smem);  // [TH][Ws]
-    int* const xmap = reinterpret_cast<int*>(tmp + TH * Ws);
-    int* const ymap = xmap + (2 * w + FT);
-    const int off = mode == kPeriodization ? FT / 2 : 1;
-    {   // extension tables for extended position i + off - (F - 1): xmap = LDS slot (or -1), ymap = source row (or -1)
-        const int He = (mode == kPeriodization && (H & 1)) ? H + 1 : H;
-        const int We = (mode == kPeriodization && (W & 1)) ? W + 1 : W;
-        for (int i = threadIdx.x; i < 2 * w + FT - 2; i += kTileThreads) {
-            const int sx = src_index(i + off - (FT - 1), W, We, mode);
-            xmap[i] = sx < 0 ? -1 : (sx & 1) * Wh + (sx >> 1);
-        }
-        for (int i = threadIdx.x; i < 2 * h + FT - 2; i += kTileThreads) ymap[i] = src_index(i + off - (FT - 1), H, He, mode);
-    }
+    Vec* const tmp = lds.tmp;
+    const int* const xmap = lds.xmap;
+    const int* const ymap = lds.ymap;
+    const int Wh = lds.Wh, Ws = lds.Ws;
     const int hw = h * w;
     const int dq = kTileThreads / w, dr = kTileThreads - dq * w;  // pass-2 item stride as (rows, columns)
     const int q0 = threadIdx.x / w, r0 = threadIdx.x - q0 * w;
-    for (int64_t job = blockIdx.x; job < planes * tiles; job += gridDim.x) {
-        const int64_t p = job / tiles;
-        const int y0 = (int)(job - p * tiles) * TH;
-        const int th = min(TH, h - y0);
-        const TIn* const pc = xc + p * (int64_t)H * W;
-        const TIn* const pu = PAIR ? xu + p * (int64_t)H * W : nullptr;
+    {
         __syncthreads();
         // ---- pass 1: analysis along H, one thread per (tensor, column); window = extended input rows 2 y0 .. 2 y0 + NR - 1
         for (int it = threadIdx.x; it < NT * W; it += kTileThreads) {
@@ -128,9 +139,6 @@ __global__ void __launch_bounds__(kTileThreads) dwt2_tile_kernel(const TIn* __re
         }
         __syncthreads();
         // ---- pass 2: analysis along W out of LDS, band arithmetic, store
-        T* const ollc = llc + p * (int64_t)hw;
-        T* const ollu = (PAIR && !ba.combine_ll) ? llu + p * (int64_t)hw : nullptr;
-        T* const ohi = hi + p * 3 * (int64_t)hw;
         for (int yl = q0, xo = r0; yl < th;) {
             const Vec* row = tmp + yl * Ws;
             const int* xm = xmap + 2 * xo + (FT - 1);  // tap j reads slot xm[-j]
@@ -183,6 +191,27 @@ __global__ void __launch_bounds__(kTileThreads) dwt2_tile_kernel(const TIn* __re
     }
 }
 
+// PAIR = false: plain DWT of xc -> (llc, hi).  PAIR = true: DWT of xc and xu, hi = band(xc, xu) per orientation;
+// llc / llu separate, or llc = band(ll_c, ll_u) when combine_ll.  ZERO: zero-extension mode (the only mode with "no
+// source" positions; the others never need a select).
+template <typename T, typename TIn, bool PAIR, int FT, bool ZERO>
+__global__ void __launch_bounds__(kTileThreads) dwt2_tile_kernel(const TIn* __restrict__ xc, const TIn* __restrict__ xu,
+                                                                 T* __restrict__ llc, T* __restrict__ llu, T* __restrict__ hi,
+                                                                 int64_t planes, int H, int W, int h, int w, int tiles, Taps<T> tp,
+                                                                 int mode, BandArgs<T> ba) {
+    extern __shared__ __align__(16) unsigned char tile_smem[];
+    const FwdLds<T, PAIR ? 4 : 2, FT> lds(tile_smem, W, w);
+    fwd_build_maps<FT>(lds.xmap, lds.ymap, H, W, h, w, lds.Wh, mode);
+    const int64_t hw = (int64_t)h * w;
+    for (int64_t job = blockIdx.x; job < planes * tiles; job += gridDim.x) {
+        const int64_t p = job / tiles;
+        const int y0 = (int)(job - p * tiles) * kFwdRows;
+        fwd_tile_job<T, TIn, PAIR, FT, ZERO>(xc + p * (int64_t)H * W, PAIR ? xu + p * (int64_t)H * W : nullptr, llc + p * hw,
+                                             (PAIR && !ba.combine_ll) ? llu + p * hw : nullptr, hi + p * 3 * hw, W, h, w, y0,
+                                             min(kFwdRows, h - y0), tp, ba, lds);
+    }
+}
+
 // The outputs o = 2m and 2m + 1 of a synthesis share their coefficients (K = F / 2 terms each):
 //   non-periodization    x[2m]   = sum_k a[i_k] lo[2k]   + d[i_k] hi[2k],     i_k = m + K - 1 - k   (0 <= i_k < n for valid o)
 //                        x[2m+1] = sum_k a[i_k] lo[2k+1] + d[i_k] hi[2k+1]
@@ -192,8 +221,8 @@ __global__ void __launch_bounds__(kTileThreads) dwt2_tile_kernel(const TIn* __re
 template <typename T, int FT>
 struct SynthPair {
     static constexpr int K = FT / 2;
-    template <typename LoadA, typename LoadD>
-    static __device__ __forceinline__ void run(int m, int n, int mode, const Taps<T>& tp, LoadA&& la, LoadD&& ld, T& even, T& odd) {
+    template <typename TP, typename LoadA, typename LoadD>
+    static __device__ __forceinline__ void run(int m, int n, int mode, const TP& tp, LoadA&& la, LoadD&& ld, T& even, T& odd) {
         even = T(0);
         odd = T(0);
         if (mode != kPeriodization || (K & 1) == 1) {
@@ -234,8 +263,66 @@ struct SynthPair {
     }
 };
 
-// FINAL = false: out[planes][Ho][Wo] (type T).  FINAL = true: outf = xsub - (float)rec (or (float)rec), the
-// cast + crop + `x - result` of py/wavelet_cfg.py:729-748 fused into the last synthesis pass.
+// one synthesis tile: output rows [y0, y0 + th) (y0 even) of one plane.  pll / phi: the plane's approximation (row stride
+// ll_w) and detail bands; out / xsub / outf point at the plane's output.  FINAL = false: out (type T).  FINAL = true:
+// outf = xsub - (float)rec (or (float)rec), the cast + crop + `x - result` of py/wavelet_cfg.py:729-748.
+template <typename T, bool FINAL, int FT, typename TP>
+__device__ __forceinline__ void inv_tile_job(const T* __restrict__ pll, int ll_w, const T* __restrict__ phi, T* __restrict__ out,
+                                             const float* __restrict__ xsub, float* __restrict__ outf, int h, int w, int Wo, int y0,
+                                             int th, const TP& tp, int mode, int subtract, T* tmp) {
+    const int hw = h * w, w2 = 2 * w;
+    const int wp = (Wo + 1) >> 1;                                     // output pairs per row
+    const int dq = kTileThreads / w, dr = kTileThreads - dq * w;     // pass 1 items: (row pair, column)
+    const int q0 = threadIdx.x / w, r0 = threadIdx.x - q0 * w;
+    const int DQ = kTileThreads / wp, DR = kTileThreads - DQ * wp;   // pass 2 items: (row, column pair)
+    const int Q0 = threadIdx.x / wp, R0 = threadIdx.x - Q0 * wp;
+    __syncthreads();
+    // ---- pass 1: synthesis along H (lanes along x: coalesced); rows (y0 + 2 mp, y0 + 2 mp + 1) -> LDS
+    for (int mp = q0, xo = r0; 2 * mp < th;) {
+        const int m = (y0 >> 1) + mp;
+        T e0, o0, e1, o1;
+        SynthPair<T, FT>::run(m, h, mode, tp, [&](int i) { return pll[i * ll_w + xo]; }, [&](int i) { return phi[i * w + xo]; }, e0, o0);
+        SynthPair<T, FT>::run(m, h, mode, tp, [&](int i) { return phi[hw + i * w + xo]; }, [&](int i) { return phi[2 * hw + i * w + xo]; },
+                              e1, o1);
+        tmp[(2 * mp) * w2 + xo] = e0;
+        tmp[(2 * mp) * w2 + w + xo] = e1;
+        if (2 * mp + 1 < th) {
+            tmp[(2 * mp + 1) * w2 + xo] = o0;
+            tmp[(2 * mp + 1) * w2 + w + xo] = o1;
+        }
+        mp += dq;
+        xo += dr;
+        if (xo >= w) {
+            xo -= w;
+            mp += 1;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: synthesis along W out of LDS -> global, two outputs per thread
+    const int obase = y0 * Wo;
+    for (int yl = Q0, m = R0; yl < th;) {
+        const T* lo_w = tmp + yl * w2;
+        const T* hi_w = lo_w + w;
+        T e, o;
+        SynthPair<T, FT>::run(m, w, mode, tp, [&](int i) { return lo_w[i]; }, [&](int i) { return hi_w[i]; }, e, o);
+        const int at = obase + yl * Wo + 2 * m;
+        const bool has_odd = 2 * m + 1 < Wo;
+        if constexpr (FINAL) {
+            outf[at] = subtract ? xsub[at] - (float)e : (float)e;
+            if (has_odd) outf[at + 1] = subtract ? xsub[at + 1] - (float)o : (float)o;
+        } else {
+            out[at] = e;
+            if (has_odd) out[at + 1] = o;
+        }
+        yl += DQ;
+        m += DR;
+        if (m >= wp) {
+            m -= wp;
+            yl += 1;
+        }
+    }
+}
+
 template <typename T, bool FINAL, int FT>
 __global__ void __launch_bounds__(kTileThreads) idwt2_tile_kernel(const T* __restrict__ ll, int ll_h, int ll_w,
                                                                   const T* __restrict__ hi, T* __restrict__ out,
@@ -243,64 +330,94 @@ __global__ void __launch_bounds__(kTileThreads) idwt2_tile_kernel(const T* __res
                                                                   int64_t planes, int h, int w, int Ho, int Wo, int tiles, Taps<T> tp,
                                                                   int mode, int subtract) {
     extern __shared__ __align__(16) unsigned char tile_smem[];
-    constexpr int TH = kInvRows;
-    T* const tmp = reinterpret_cast<T*>(tile_smem);  // [TH][lo_w | hi_w]
-    const int hw = h * w, w2 = 2 * w;
-    const int wp = (Wo + 1) >> 1;                                     // output pairs per row
-    const int dq = kTileThreads / w, dr = kTileThreads - dq * w;     // pass 1 items: (row pair, column)
-    const int q0 = threadIdx.x / w, r0 = threadIdx.x - q0 * w;
-    const int DQ = kTileThreads / wp, DR = kTileThreads - DQ * wp;   // pass 2 items: (row, column pair)
-    const int Q0 = threadIdx.x / wp, R0 = threadIdx.x - Q0 * wp;
+    T* const tmp = reinterpret_cast<T*>(tile_smem);  // [kInvRows][lo_w | hi_w]
+    const int64_t hw = (int64_t)h * w, ohw = (int64_t)Ho * Wo;
     for (int64_t job = blockIdx.x; job < planes * tiles; job += gridDim.x) {
         const int64_t p = job / tiles;
-        const int y0 = (int)(job - p * tiles) * TH;  // even
-        const int th = min(TH, Ho - y0);
-        const T* const pll = ll + p * (int64_t)ll_h * ll_w;
-        const T* const phi = hi + p * 3 * (int64_t)hw;
-        __syncthreads();
-        // ---- pass 1: synthesis along H (lanes along x: coalesced); rows (y0 + 2 mp, y0 + 2 mp + 1) -> LDS
-        for (int mp = q0, xo = r0; 2 * mp < th;) {
-            const int m = (y0 >> 1) + mp;
-            T e0, o0, e1, o1;
-            SynthPair<T, FT>::run(m, h, mode, tp, [&](int i) { return pll[i * ll_w + xo]; }, [&](int i) { return phi[i * w + xo]; }, e0, o0);
-            SynthPair<T, FT>::run(m, h, mode, tp, [&](int i) { return phi[hw + i * w + xo]; },
-                                  [&](int i) { return phi[2 * hw + i * w + xo]; }, e1, o1);
-            tmp[(2 * mp) * w2 + xo] = e0;
-            tmp[(2 * mp) * w2 + w + xo] = e1;
-            if (2 * mp + 1 < th) {
-                tmp[(2 * mp + 1) * w2 + xo] = o0;
-                tmp[(2 * mp + 1) * w2 + w + xo] = o1;
+        const int y0 = (int)(job - p * tiles) * kInvRows;  // even
+        inv_tile_job<T, FINAL, FT>(ll + p * (int64_t)ll_h * ll_w, ll_w, hi + p * 3 * hw, FINAL ? nullptr : out + p * ohw,
+                                   (FINAL && xsub) ? xsub + p * ohw : nullptr, FINAL ? outf + p * ohw : nullptr, h, w, Wo, y0,
+                                   min(kInvRows, Ho - y0), tp, mode, subtract, tmp);
+    }
+}
+
+// ---- levels >= 2 of the WaveletCFG step in ONE launch: a workgroup owns a plane and walks it down (analysis of cond and
+// uncond, band arithmetic) and back up (synthesis) through the same global workspace the per-level launches use; every
+// dependency is inside the workgroup, so a device-scope fence + barrier per level replaces 2 (levels - 1) launches of
+// kernels that are mostly launch latency (a 10 x 10 plane per workgroup).
+constexpr int kDeepMaxLevels = 8;
+constexpr int kDeepTaps = 20;
+template <typename T>
+struct TapsSmall {
+    T lo[kDeepTaps], hi[kDeepTaps];
+};
+template <typename T>
+struct DeepArgs {
+    int64_t planes;
+    int levels;                                        // deep levels k = 1 .. levels
+    int H[kDeepMaxLevels + 1], W[kDeepMaxLevels + 1];    // [0]: the input approximation plane; [k]: coefficient plane of level k
+    int Hr[kDeepMaxLevels + 1], Wr[kDeepMaxLevels + 1];  // reconstruction produced FROM level k
+    int64_t off_in_c, off_in_u;                        // element offsets into the workspace
+    int64_t off_d[kDeepMaxLevels + 1], off_c[kDeepMaxLevels + 1], off_u[kDeepMaxLevels + 1], off_r[kDeepMaxLevels + 1];
+    T hi_scales[kDeepMaxLevels + 1][12];               // per level: cond[3], uncond[3], diff[3], final[3]
+    T ll_scales[4];
+    T strength;
+    int blend_mode, mode_fwd, mode_inv;
+    TapsSmall<T> dec, rec;
+};
+
+template <typename T, int FT>
+__global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char tile_smem[];
+    for (int64_t p = blockIdx.x; p < a.planes; p += gridDim.x) {
+        // ---- analysis, finest deep level first
+        for (int k = 1; k <= a.levels; ++k) {
+            const int H = a.H[k - 1], W = a.W[k - 1], h = a.H[k], w = a.W[k];
+            const FwdLds<T, 4, FT> lds(tile_smem, W, w);
+            __syncthreads();
+            fwd_build_maps<FT>(lds.xmap, lds.ymap, H, W, h, w, lds.Wh, a.mode_fwd);
+            BandArgs<T> ba;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ba.hi.cond[g] = g < 3 ? a.hi_scales[k][g] : T(1);
+                ba.hi.uncond[g] = g < 3 ? a.hi_scales[k][3 + g] : T(1);
+                ba.hi.diff[g] = g < 3 ? a.hi_scales[k][6 + g] : T(1);
+                ba.hi.fin[g] = g < 3 ? a.hi_scales[k][9 + g] : T(1);
+                ba.ll.cond[g] = g == 0 ? a.ll_scales[0] : T(1);
+                ba.ll.uncond[g] = g == 0 ? a.ll_scales[1] : T(1);
+                ba.ll.diff[g] = g == 0 ? a.ll_scales[2] : T(1);
+                ba.ll.fin[g] = g == 0 ? a.ll_scales[3] : T(1);
             }
-            mp += dq;
-            xo += dr;
-            if (xo >= w) {
-                xo -= w;
-                mp += 1;
-            }
+            ba.combine_ll = k == a.levels;
+            ba.blend_mode = a.blend_mode;
+            ba.strength = a.strength;
+            const int64_t in_plane = (int64_t)H * W, hw = (int64_t)h * w;
+            const T* pc = base + (k == 1 ? a.off_in_c : a.off_c[k - 1]) + p * in_plane;
+            const T* pu = base + (k == 1 ? a.off_in_u : a.off_u[k - 1]) + p * in_plane;
+            T* oc = base + a.off_c[k] + p * hw;
+            T* ou = ba.combine_ll ? nullptr : base + a.off_u[k] + p * hw;
+            T* od = base + a.off_d[k] + p * 3 * hw;
+            for (int y0 = 0; y0 < h; y0 += kFwdRows)
+                fwd_tile_job<T, T, true, FT, true>(pc, pu, oc, ou, od, W, h, w, y0, min(kFwdRows, h - y0), a.dec, ba, lds);
+            // the workgroup re-reads what it just stored: workgroup scope is enough (one CU, one L1); a device-scope fence
+            // would write back / invalidate L2 once per level per plane
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __syncthreads();
         }
-        __syncthreads();
-        // ---- pass 2: synthesis along W out of LDS -> global, two outputs per thread
-        const int64_t obase = (p * Ho + y0) * (int64_t)Wo;
-        for (int yl = Q0, m = R0; yl < th;) {
-            const T* lo_w = tmp + yl * w2;
-            const T* hi_w = lo_w + w;
-            T e, o;
-            SynthPair<T, FT>::run(m, w, mode, tp, [&](int i) { return lo_w[i]; }, [&](int i) { return hi_w[i]; }, e, o);
-            const int64_t at = obase + yl * Wo + 2 * m;
-            const bool has_odd = 2 * m + 1 < Wo;
-            if constexpr (FINAL) {
-                outf[at] = subtract ? xsub[at] - (float)e : (float)e;
-                if (has_odd) outf[at + 1] = subtract ? xsub[at + 1] - (float)o : (float)o;
-            } else {
-                out[at] = e;
-                if (has_odd) out[at + 1] = o;
-            }
-            yl += DQ;
-            m += DR;
-            if (m >= wp) {
-                m -= wp;
-                yl += 1;
-            }
+        // ---- synthesis, coarsest level first
+        const T* ll = base + a.off_c[a.levels] + p * (int64_t)a.H[a.levels] * a.W[a.levels];
+        int ll_w = a.W[a.levels];
+        T* const tmp = reinterpret_cast<T*>(tile_smem);
+        for (int k = a.levels; k >= 1; --k) {
+            const int h = a.H[k], w = a.W[k], Ho = a.Hr[k], Wo = a.Wr[k];
+            const T* d = base + a.off_d[k] + p * 3 * (int64_t)h * w;
+            T* r = base + a.off_r[k] + p * (int64_t)Ho * Wo;
+            for (int y0 = 0; y0 < Ho; y0 += kInvRows)
+                inv_tile_job<T, false, FT>(ll, ll_w, d, r, nullptr, nullptr, h, w, Wo, y0, min(kInvRows, Ho - y0), a.rec, a.mode_inv, 0, tmp);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __syncthreads();
+            ll = r;
+            ll_w = Wo;
         }
     }
 }
@@ -429,8 +546,9 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
         ba.strength = (T)strength;
         return ba;
     };
-    // ---- analysis, finest level first; level 1 reads the fp32 inputs directly (cast in registers)
-    for (int j = 1; j <= levels; ++j) {
+    // levels >= 2 in one launch (a workgroup per plane) when the filters have one length and there are enough levels to matter
+    const bool deep = levels >= 3 && dec_len == rec_len && levels - 1 <= kDeepMaxLevels && dec_len <= kDeepTaps;
+    auto launch_fwd = [&](int j) {
         const int tiles = (pl.H[j] + kFwdRows - 1) / kFwdRows;
         const size_t lds = fwd_lds_bytes(pl.W[j - 1], pl.H[j], pl.W[j], dec_len, sizeof(T), 2);
         const dim3 grid(tile_grid(planes * tiles)), blk(kTileThreads);
@@ -452,11 +570,11 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
             };
             if (mode_fwd == kZero) go(std::true_type{}); else go(std::false_type{});
         });
-    }
-    // ---- synthesis, coarsest level first; the last launch writes x - result (cropped) as fp32
+    };
+    // one synthesis level; returns the (pointer, rows, cols) of what it produced for the level above
     const T* ll = base + pl.off_c[levels];
     int ll_h = pl.H[levels], ll_w = pl.W[levels];
-    for (int j = levels; j >= 1; --j) {
+    auto launch_inv = [&](int j) {
         const int Ho = j > 1 ? pl.Hr[j] : (int)H, Wo = j > 1 ? pl.Wr[j] : (int)W;
         const int tiles = (Ho + kInvRows - 1) / kInvRows;
         const size_t lds = inv_lds_bytes(pl.W[j], sizeof(T));
@@ -477,6 +595,59 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
                                    out, planes, pl.H[j], pl.W[j], Ho, Wo, tiles, rec, mode_inv, subtract_from_x);
             });
         }
+    };
+    if (deep) {
+        launch_fwd(1);  // reads the fp32 inputs (cast in registers)
+        DeepArgs<T> a{};
+        a.planes = planes;
+        a.levels = levels - 1;
+        a.off_in_c = pl.off_c[1];
+        a.off_in_u = pl.off_u[1];
+        size_t lds = 0;
+        for (int k = 0; k <= a.levels; ++k) {
+            a.H[k] = pl.H[k + 1];
+            a.W[k] = pl.W[k + 1];
+            if (k == 0) continue;
+            a.Hr[k] = pl.Hr[k + 1];
+            a.Wr[k] = pl.Wr[k + 1];
+            a.off_d[k] = pl.off_d[k + 1];
+            a.off_c[k] = pl.off_c[k + 1];
+            a.off_u[k] = pl.off_u[k + 1];
+            a.off_r[k] = pl.off_r[k + 1];
+            const BandArgs<T> ba = band_args(k + 1);
+            for (int g = 0; g < 3; ++g) {
+                a.hi_scales[k][g] = ba.hi.cond[g];
+                a.hi_scales[k][3 + g] = ba.hi.uncond[g];
+                a.hi_scales[k][6 + g] = ba.hi.diff[g];
+                a.hi_scales[k][9 + g] = ba.hi.fin[g];
+            }
+            lds = std::max(lds, std::max(fwd_lds_bytes(a.W[k - 1], a.H[k], a.W[k], dec_len, sizeof(T), 2), inv_lds_bytes(a.W[k], sizeof(T))));
+        }
+        a.ll_scales[0] = (T)yl_scales[0];
+        a.ll_scales[1] = (T)yl_scales[1];
+        a.ll_scales[2] = (T)yl_scales[2];
+        a.ll_scales[3] = (T)yl_scales[3];
+        a.strength = (T)strength;
+        a.blend_mode = blend_mode;
+        a.mode_fwd = mode_fwd;
+        a.mode_inv = mode_inv;
+        for (int i = 0; i < kDeepTaps; ++i) {
+            a.dec.lo[i] = i < dec_len ? dec.lo[i] : T(0);
+            a.dec.hi[i] = i < dec_len ? dec.hi[i] : T(0);
+            a.rec.lo[i] = i < rec_len ? rec.lo[i] : T(0);
+            a.rec.hi[i] = i < rec_len ? rec.hi[i] : T(0);
+        }
+        with_taps(dec_len, [&](auto ft) {
+            hipLaunchKernelGGL((wcfg_deep_kernel<T, decltype(ft)::value>), dim3((int)std::min<int64_t>(planes, 1 << 20)), dim3(kTileThreads),
+                               lds, st, base, a);
+        });
+        ll = base + pl.off_r[2];  // what the deep kernel reconstructed for level 1
+        ll_h = pl.Hr[2];
+        ll_w = pl.Wr[2];
+        launch_inv(1);
+    } else {
+        for (int j = 1; j <= levels; ++j) launch_fwd(j);
+        for (int j = levels; j >= 1; --j) launch_inv(j);
     }
     return check_launch(what);
 }
