@@ -41,14 +41,27 @@ static inline size_t fwd_lds_bytes(int W, int h, int w, int F, size_t elem, int 
 // synthesis LDS: [kInvRows][lo_w | hi_w][w] of T
 static inline size_t inv_lds_bytes(int w, size_t elem) { return (size_t)kInvRows * 2 * w * elem; }
 
+// compact on purpose: these live in scalar registers next to the filter taps (fp64: 2 SGPRs per value)
 template <typename T>
 struct BandArgs {
-    BandScales<T> hi;   // per orientation (cH, cV, cD)
-    BandScales<T> ll;   // index 0
-    int combine_ll;     // last level: the approximation band is combined too
+    T hc[3], hu[3], hd[3], hf[3];  // cond / uncond / diff / final scale per orientation (cH, cV, cD)
+    T lc, lu, ld, lf;              // the same for the approximation band
+    int combine_ll;                // last level: the approximation band is combined too
     int blend_mode;
     T strength;
 };
+
+// blend(u * s_u, (c * s_c - u * s_u) * s_d, strength) * s_f  (py/wavelet_cfg.py:765-787); scales of 1 are skipped
+template <typename T>
+__device__ __forceinline__ T band_combine4(T c, T u, T sc, T su, T sd, T sf, int blend_mode, T strength) {
+    if (sc != T(1)) c = c * sc;
+    if (su != T(1)) u = u * su;
+    T d = c - u;
+    if (sd != T(1)) d = d * sd;
+    T r = blend<T>(blend_mode, u, d, strength);
+    if (sf != T(1)) r = r * sf;
+    return r;
+}
 
 // LDS tile layout: tmp[row][slot(x)][NV] with NV = 2 (lowH, highH) or 4 (cond lowH, cond highH, uncond lowH, uncond highH)
 // and slot(x) = (x & 1) * ceil(W / 2) + x / 2: a tap reads one parity class, so consecutive lanes hit consecutive slots
@@ -114,7 +127,7 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 // rows past the tile's need (last tile) re-read a valid row; their outputs are never consumed
-                const int sy = __builtin_amdgcn_readfirstlane(ymap[min(2 * y0 + r, 2 * h + FT - 3)]);
+                const int sy = ymap[min(2 * y0 + r, 2 * h + FT - 3)];
                 if constexpr (ZERO) {
                     const T g = (T)col[(sy >= 0 ? sy : 0) * W];
                     v[r] = sy >= 0 ? g : T(0);
@@ -166,11 +179,11 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
             }
             const int o = (y0 + yl) * w + xo;
             if constexpr (PAIR) {
-                ohi[o] = band_combine<T>(c_h, u_h, ba.hi, 0, ba.blend_mode, ba.strength);
-                ohi[hw + o] = band_combine<T>(c_v, u_v, ba.hi, 1, ba.blend_mode, ba.strength);
-                ohi[2 * hw + o] = band_combine<T>(c_d, u_d, ba.hi, 2, ba.blend_mode, ba.strength);
+                ohi[o] = band_combine4<T>(c_h, u_h, ba.hc[0], ba.hu[0], ba.hd[0], ba.hf[0], ba.blend_mode, ba.strength);
+                ohi[hw + o] = band_combine4<T>(c_v, u_v, ba.hc[1], ba.hu[1], ba.hd[1], ba.hf[1], ba.blend_mode, ba.strength);
+                ohi[2 * hw + o] = band_combine4<T>(c_d, u_d, ba.hc[2], ba.hu[2], ba.hd[2], ba.hf[2], ba.blend_mode, ba.strength);
                 if (ba.combine_ll) {
-                    ollc[o] = band_combine<T>(c_ll, u_ll, ba.ll, 0, ba.blend_mode, ba.strength);
+                    ollc[o] = band_combine4<T>(c_ll, u_ll, ba.lc, ba.lu, ba.ld, ba.lf, ba.blend_mode, ba.strength);
                 } else {
                     ollc[o] = c_ll;
                     ollu[o] = u_ll;
@@ -378,16 +391,16 @@ __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepAr
             fwd_build_maps<FT>(lds.xmap, lds.ymap, H, W, h, w, lds.Wh, a.mode_fwd);
             BandArgs<T> ba;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                ba.hi.cond[g] = g < 3 ? a.hi_scales[k][g] : T(1);
-                ba.hi.uncond[g] = g < 3 ? a.hi_scales[k][3 + g] : T(1);
-                ba.hi.diff[g] = g < 3 ? a.hi_scales[k][6 + g] : T(1);
-                ba.hi.fin[g] = g < 3 ? a.hi_scales[k][9 + g] : T(1);
-                ba.ll.cond[g] = g == 0 ? a.ll_scales[0] : T(1);
-                ba.ll.uncond[g] = g == 0 ? a.ll_scales[1] : T(1);
-                ba.ll.diff[g] = g == 0 ? a.ll_scales[2] : T(1);
-                ba.ll.fin[g] = g == 0 ? a.ll_scales[3] : T(1);
+            for (int g = 0; g < 3; ++g) {
+                ba.hc[g] = a.hi_scales[k][g];
+                ba.hu[g] = a.hi_scales[k][3 + g];
+                ba.hd[g] = a.hi_scales[k][6 + g];
+                ba.hf[g] = a.hi_scales[k][9 + g];
             }
+            ba.lc = a.ll_scales[0];
+            ba.lu = a.ll_scales[1];
+            ba.ld = a.ll_scales[2];
+            ba.lf = a.ll_scales[3];
             ba.combine_ll = k == a.levels;
             ba.blend_mode = a.blend_mode;
             ba.strength = a.strength;
@@ -529,18 +542,17 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
                       SONAR_ERR_UNSUPPORTED, "%s: level %d (%d x %d) does not fit the LDS tile", what, j, pl.H[j], pl.W[j]);
     auto band_args = [&](int j) {
         BandArgs<T> ba;
-        for (int g = 0; g < 4; ++g) {
-            const bool in = g < 3;
-            const double* row = yh_scales + (int64_t)(j - 1) * 12;
-            ba.hi.cond[g] = in ? (T)row[0 + g] : T(1);
-            ba.hi.uncond[g] = in ? (T)row[3 + g] : T(1);
-            ba.hi.diff[g] = in ? (T)row[6 + g] : T(1);
-            ba.hi.fin[g] = in ? (T)row[9 + g] : T(1);
-            ba.ll.cond[g] = g == 0 ? (T)yl_scales[0] : T(1);
-            ba.ll.uncond[g] = g == 0 ? (T)yl_scales[1] : T(1);
-            ba.ll.diff[g] = g == 0 ? (T)yl_scales[2] : T(1);
-            ba.ll.fin[g] = g == 0 ? (T)yl_scales[3] : T(1);
+        const double* row = yh_scales + (int64_t)(j - 1) * 12;
+        for (int g = 0; g < 3; ++g) {
+            ba.hc[g] = (T)row[0 + g];
+            ba.hu[g] = (T)row[3 + g];
+            ba.hd[g] = (T)row[6 + g];
+            ba.hf[g] = (T)row[9 + g];
         }
+        ba.lc = (T)yl_scales[0];
+        ba.lu = (T)yl_scales[1];
+        ba.ld = (T)yl_scales[2];
+        ba.lf = (T)yl_scales[3];
         ba.combine_ll = j == levels;
         ba.blend_mode = blend_mode;
         ba.strength = (T)strength;
@@ -616,10 +628,10 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
             a.off_r[k] = pl.off_r[k + 1];
             const BandArgs<T> ba = band_args(k + 1);
             for (int g = 0; g < 3; ++g) {
-                a.hi_scales[k][g] = ba.hi.cond[g];
-                a.hi_scales[k][3 + g] = ba.hi.uncond[g];
-                a.hi_scales[k][6 + g] = ba.hi.diff[g];
-                a.hi_scales[k][9 + g] = ba.hi.fin[g];
+                a.hi_scales[k][g] = ba.hc[g];
+                a.hi_scales[k][3 + g] = ba.hu[g];
+                a.hi_scales[k][6 + g] = ba.hd[g];
+                a.hi_scales[k][9 + g] = ba.hf[g];
             }
             lds = std::max(lds, std::max(fwd_lds_bytes(a.W[k - 1], a.H[k], a.W[k], dec_len, sizeof(T), 2), inv_lds_bytes(a.W[k], sizeof(T))));
         }
