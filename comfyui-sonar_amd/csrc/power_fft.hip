@@ -124,6 +124,9 @@ constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4
 #endif
 #define SONAR_PRAGMA(x) _Pragma(#x)
 #define SONAR_UNROLL_ITEMS SONAR_PRAGMA(unroll SONAR_FFT_UNROLL)
+#ifndef SONAR_DRAW_UNROLL
+#define SONAR_DRAW_UNROLL 1  // the FFT kernel's draw loop (register budget: 128 VGPRs for 4 waves / SIMD)
+#endif
 #ifndef SONAR_FFT_TW_LDS
 #define SONAR_FFT_TW_LDS 0  // measured: constant-memory (scalar) twiddles 78 us vs LDS table 125 us at B=512
 #endif
@@ -163,31 +166,35 @@ __device__ __forceinline__ SpectrumRng spectrum_rng(uint64_t seed, uint64_t stre
     return g;
 }
 
-// interior element order: q in [0, H (M - 1)): ky = q / (M - 1), kx = 1 + q % (M - 1); slot `tid` draws the pairs
-// (q, q + H (M - 1) / 2) for q = tid, tid + NT, ... (the partner sits H/2 rows below, same column).  Per pair: two radius
-// words from R, ONE angle word from T (low / high half).  edge(r0, rm, t) and elem(ky, kx, r, t16); t is 0 when !NEED_T.
-template <int H, int W, bool NEED_T, typename Edge, typename Elem>
-__device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge, Elem&& elem) {
-    constexpr int NT = kFftThreads, M = W / 2, MI = M - 1, HALF = (H / 2) * MI;
+// interior element order: the pairs p in [0, (H/2) M) walk rows of M slots, ky = p / M, kx = 1 + p % M (M a power of two: shifts);
+// slot `tid` draws the pairs p = tid, tid + NT, ... -- element (ky, kx) and its partner H/2 rows below, same column.  Per pair:
+// two radius words from R, ONE angle word from T (low / high half).  The last slot of a row (kx = M) is drawn and DISCARDED
+// (the kx = M column comes from E): 1/M more generator steps buy addresses that are affine in the iteration -- no index
+// arithmetic, LDS / filter offsets become constant strides.  Callbacks: edge(r0, rm, t) and pair(it, p, ra, rb, t) -- radius
+// words of element (ky, kx) and of its partner, `t` = both angles (low half / high half; 0 when !NEED_T).
+template <int W>
+constexpr int draw_shift() { int l = 0; while ((1 << l) < W / 2) ++l; return l; }
+template <int H, int W>
+constexpr int draw_iters() { return ((H / 2) * (W / 2) + kFftThreads - 1) / kFftThreads; }
+
+template <int H, int W, bool NEED_T, int UNROLL = 0, typename Edge, typename Pair>
+__device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge, Pair&& pair) {
+    constexpr int NT = kFftThreads, M = W / 2, LM = draw_shift<W>(), PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
+    constexpr int UNR = UNROLL > 0 ? UNROLL : ITER;  // 0 = full (the statistics pass indexes registers by `it`)
     if (tid < H) {  // row ky = tid of the edge columns: radius word of kx = 0, of kx = M, then one angle word for both
         const uint32_t r0 = g.E.next_high();
         const uint32_t rm = g.E.next_high();
         const uint32_t t = g.E.next();
         edge(r0, rm, t);
     }
-    int ky = tid / MI, kx = 1 + tid - ky * MI;
-    constexpr int DKY = NT / MI, DKX = NT - DKY * MI;
-    for (int q = tid; q < HALF; q += NT) {
-        const uint32_t ra = g.R.next_high();  // radius words keep bits 31..9 only
-        const uint32_t rb = g.R.next_high();
-        const uint32_t t = NEED_T ? g.T.next() : 0u;
-        elem(ky, kx, ra, t & 0xFFFFu);
-        elem(ky + H / 2, kx, rb, t >> 16);
-        kx += DKX;
-        ky += DKY;
-        if (kx > MI) {
-            kx -= MI;
-            ky += 1;
+#pragma unroll UNR
+    for (int it = 0; it < ITER; ++it) {
+        const int p = tid + it * NT;
+        if (PAIRS % NT == 0 || p < PAIRS) {
+            const uint32_t ra = g.R.next_high();  // radius words keep bits 31..9 only
+            const uint32_t rb = g.R.next_high();
+            const uint32_t t = NEED_T ? g.T.next() : 0u;
+            pair(it, p, ra, rb, t);
         }
     }
 }
@@ -195,7 +202,7 @@ __device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge,
 // advance the streams past one plane's draws without using them (a workgroup that starts in the middle of an RNG group)
 template <int H, int W, bool NEED_T>
 __device__ __forceinline__ void skip_plane(SpectrumRng& g, int tid) {
-    draw_plane<H, W, NEED_T>(g, tid, [](uint32_t, uint32_t, uint32_t) {}, [](int, int, uint32_t, uint32_t) {});
+    draw_plane<H, W, NEED_T>(g, tid, [](uint32_t, uint32_t, uint32_t) {}, [](int, int, uint32_t, uint32_t, uint32_t) {});
 }
 
 // A kernel's work units: whole RNG groups (one workgroup draws the group's planes back to back; the seeding is paid once
@@ -232,17 +239,30 @@ __device__ __forceinline__ c32 drawn_elem(uint32_t r, uint32_t t16, float f) {
     return make_float2(z.x * f, z.y * f);
 }
 
-// filtered spectrum of one generated plane -> sink(ky, kx, value)
-template <int H, int W, typename Sink>
-__device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter, SpectrumRng& g, int tid, Sink&& sink) {
-    constexpr int M = W / 2, Wh = M + 1;
-    draw_plane<H, W, true>(
+// filtered spectrum of one generated plane: interior straight into the LDS plane A (row stride S; the discarded kx = M slots
+// land in A's never-read last column), edge columns into the side buffers T0 / TM.  The filter values of pair it + 1 are
+// requested while pair it is drawn (the compiler otherwise issues each load right in front of its use).
+template <int H, int W, int S>
+__device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter, SpectrumRng& g, int tid, c32* A, c32* T0, c32* TM) {
+    constexpr int NT = kFftThreads, M = W / 2, Wh = M + 1, LM = draw_shift<W>(), PAIRS = (H / 2) * M;
+    auto fpos = [&](int p) { return (p >> LM) * Wh + 1 + (p & (M - 1)); };
+    const int p0 = min(tid, PAIRS - 1);
+    float fa = filter[fpos(p0)], fb = filter[fpos(p0) + (H / 2) * Wh];
+    draw_plane<H, W, true, SONAR_DRAW_UNROLL>(
         g, tid,
         [&](uint32_t r0, uint32_t rm, uint32_t t) {
-            sink(tid, 0, drawn_elem(r0, t & 0xFFFFu, filter[tid * Wh]));
-            sink(tid, M, drawn_elem(rm, t >> 16, filter[tid * Wh + M]));
+            T0[tid] = drawn_elem(r0, t & 0xFFFFu, filter[tid * Wh]);
+            TM[tid] = drawn_elem(rm, t >> 16, filter[tid * Wh + M]);
         },
-        [&](int ky, int kx, uint32_t r, uint32_t t16) { sink(ky, kx, drawn_elem(r, t16, filter[ky * Wh + kx])); });
+        [&](int, int p, uint32_t ra, uint32_t rb, uint32_t t) {
+            const int pn = min(p + NT, PAIRS - 1);
+            const float na = filter[fpos(pn)], nb = filter[fpos(pn) + (H / 2) * Wh];
+            c32* const a = A + (p >> LM) * S + 1 + (p & (M - 1));
+            a[0] = drawn_elem(ra, t & 0xFFFFu, fa);
+            a[(H / 2) * S] = drawn_elem(rb, t >> 16, fb);
+            fa = na;
+            fb = nb;
+        });
 }
 
 // One supplied plane's filtered half-spectrum (replay) -> sink(ky, kx, value); thread `tid` handles the complex pair at
@@ -345,7 +365,7 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
         if constexpr (SRC != 2) {
         // ---------------------------------------------------------------- fill: z * filter
         auto sink = [&](int ky, int kx, c32 v) { (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v; };
-        if constexpr (GEN) fill_plane_gen<H, W>(filter, rng, tid, sink);
+        if constexpr (GEN) fill_plane_gen<H, W, S>(filter, rng, tid, A, T0, TM);
         else fill_plane<H, W>(z, filter, plane, tid, sink);
         __syncthreads();
         } else {
@@ -665,6 +685,20 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* _
         }
         q += (double)edge;
     };
+    // A thread meets the same (ky, kx) in every plane: its weights -ln2 f^2 (|z f|^2 = f^2 rho^2 = -ln2 f^2 log2 u, the radius
+    // word alone) live in registers; the discarded kx = M slots weigh 0.
+    constexpr int LM = draw_shift<W>(), PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
+    constexpr float kNegLn2 = -0.6931471805599453f;
+    float wgt[2 * ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int p = tid + it * NT, ky = p >> LM, kx = 1 + (p & (M - 1));
+        const bool live = p < PAIRS && kx < M;
+        const float fa = live ? filter[ky * Wh + kx] : 0.0f, fb = live ? filter[(ky + H / 2) * Wh + kx] : 0.0f;
+        wgt[it] = kNegLn2 * (fa * fa);
+        wgt[it + ITER] = kNegLn2 * (fb * fb);
+    }
+    const float f0 = tid < H ? filter[tid * Wh] : 0.0f, fm = tid < H ? filter[tid * Wh + M] : 0.0f;
     for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
         const GroupWalk gw(unit, group, split);
         SpectrumRng rng = spectrum_rng<H, false>(seed, stream_id, plane_offset / group + gw.grp, tid);
@@ -674,13 +708,12 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* _
             draw_plane<H, W, false>(
                 rng, tid,
                 [&](uint32_t r0, uint32_t rm, uint32_t t) {
-                    EDGE[par][0][tid] = drawn_elem(r0, t & 0xFFFFu, filter[tid * Wh]);
-                    EDGE[par][1][tid] = drawn_elem(rm, t >> 16, filter[tid * Wh + M]);
+                    EDGE[par][0][tid] = drawn_elem(r0, t & 0xFFFFu, f0);
+                    EDGE[par][1][tid] = drawn_elem(rm, t >> 16, fm);
                 },
-                [&](int ky, int kx, uint32_t r, uint32_t) {
-                    // |z f|^2 = f^2 rho^2 = f^2 * (-ln u): the radius word alone
-                    const float f = filter[ky * Wh + kx];
-                    acc = __builtin_fmaf(f * f, neg_ln_u(r), acc);
+                [&](int it, int, uint32_t ra, uint32_t rb, uint32_t) {
+                    acc = __builtin_fmaf(wgt[it], __builtin_amdgcn_logf(2.0f - unit_mantissa(ra)), acc);
+                    acc = __builtin_fmaf(wgt[it + ITER], __builtin_amdgcn_logf(2.0f - unit_mantissa(rb)), acc);
                 });
             q += 2.0 * (double)acc;
             __syncthreads();           // this plane's edge columns are complete; the other buffer's readers finished last iteration
@@ -709,7 +742,13 @@ __global__ void __launch_bounds__(kFftThreads) power_spectrum_kernel(float* zout
                     zp[tid * Wh] = unit_complex_normal(r0, t & 0xFFFFu);
                     zp[tid * Wh + M] = unit_complex_normal(rm, t >> 16);
                 },
-                [&](int ky, int kx, uint32_t r, uint32_t t16) { zp[ky * Wh + kx] = unit_complex_normal(r, t16); });
+                [&](int, int p, uint32_t ra, uint32_t rb, uint32_t t) {
+                    const int ky = p >> draw_shift<W>(), kx = 1 + (p & (M - 1));
+                    if (kx < M) {
+                        zp[ky * Wh + kx] = unit_complex_normal(ra, t & 0xFFFFu);
+                        zp[(ky + H / 2) * Wh + kx] = unit_complex_normal(rb, t >> 16);
+                    }
+                });
         }
     }
 }
