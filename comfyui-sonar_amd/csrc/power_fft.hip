@@ -125,7 +125,7 @@ constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4
 #define SONAR_PRAGMA(x) _Pragma(#x)
 #define SONAR_UNROLL_ITEMS SONAR_PRAGMA(unroll SONAR_FFT_UNROLL)
 #ifndef SONAR_DRAW_UNROLL
-#define SONAR_DRAW_UNROLL 1  // the FFT kernel's draw loop (register budget: 128 VGPRs for 4 waves / SIMD)
+#define SONAR_DRAW_UNROLL 4  // the FFT kernel's draw loop: 1 / 2 / 4 measured 69.8 / 69 / 66.5 us per step at B=512; 8 spills (128-VGPR budget)
 #endif
 #ifndef SONAR_FFT_TW_LDS
 #define SONAR_FFT_TW_LDS 0  // measured: constant-memory (scalar) twiddles 78 us vs LDS table 125 us at B=512
