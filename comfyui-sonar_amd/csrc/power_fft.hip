@@ -335,21 +335,24 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
     auto tw = [&](int idx, int n, bool) -> c32 { return TW[(idx * (256 / n)) & 255]; };
 #else
     // `uni`: the index is wave-uniform (lanes = consecutive columns / rows of one n2) -> scalar load
+    // (a per-lane index reads the LDS copy: vector loads from constant memory cost 64-bit address registers)
     auto tw = [&](int idx, int n, bool uni) -> c32 {
-        return c_tw256[((uni ? __builtin_amdgcn_readfirstlane(idx) : idx) * (256 / n)) & 255];
+        if (uni) return c_tw256[(__builtin_amdgcn_readfirstlane(idx) * (256 / n)) & 255];
+        return TW[(idx * (256 / n)) & 255];
     };
 #endif
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     c32 ctw[CN1], gtw[RN1], ptw[RN1];
-    if constexpr (FAST) {
+    auto load_twiddles = [&](int w) {
 #pragma unroll
-        for (int k1 = 0; k1 < CN1; ++k1) ctw[k1] = c_tw256[((wv * k1) * (256 / H)) & 255];
+        for (int k1 = 0; k1 < CN1; ++k1) ctw[k1] = c_tw256[((w * k1) * (256 / H)) & 255];
 #pragma unroll
-        for (int n1 = 0; n1 < RN1; ++n1) gtw[n1] = c_tw256[((RN2 * n1 + wv) * (256 / W)) & 255];
+        for (int n1 = 0; n1 < RN1; ++n1) gtw[n1] = c_tw256[((RN2 * n1 + w) * (256 / W)) & 255];
 #pragma unroll
-        for (int k1 = 0; k1 < RN1; ++k1) ptw[k1] = c_tw256[((wv * k1) * (256 / M)) & 255];
-    }
+        for (int k1 = 0; k1 < RN1; ++k1) ptw[k1] = c_tw256[((w * k1) * (256 / M)) & 255];
+    };
+    if constexpr (FAST) load_twiddles(wv);
 
     // one workgroup draws the `group` planes of an RNG group back to back (group = 1 unless generating)
     for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
