@@ -141,6 +141,76 @@ __global__ void __launch_bounds__(kBlock) wcfg_output_kernel(const float* __rest
     }
 }
 
+// ---- 1-D transform of flattened latents (py/wavelet_functions.py:56-57 use_1d_dwt; py/wavelet_cfg.py:713-715 flattens to
+// [B, C, H*W]): analysis x[rows][L] -> lo[rows][n], hi[rows][n]; a thread owns one coefficient pair.  Away from the borders
+// (the common case: L is thousands of samples) the taps are read straight, without the extension arithmetic.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) dwt1_fwd_kernel(const T* __restrict__ x, T* __restrict__ lo, T* __restrict__ hi,
+                                                           int64_t rows, int L, int n, Taps<T> tp, int mode) {
+    const int64_t total = rows * n;
+    const int F = tp.len;
+    const int Le = (mode == kPeriodization && (L & 1)) ? L + 1 : L;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int xo = (int)(i % n);
+        const T* row = x + (i / n) * L;
+        const int top = mode == kPeriodization ? 2 * xo + F / 2 : 2 * xo + 1;  // index read by tap 0; tap j reads top - j
+        T a = T(0), d = T(0);
+        if (top < L && top - (F - 1) >= 0) {
+            for (int j = 0; j < F; ++j) {
+                const T v = row[top - j];
+                a += tp.lo[j] * v;
+                d += tp.hi[j] * v;
+            }
+        } else {
+            for (int j = 0; j < F; ++j) {
+                int src;
+                if (mode == kPeriodization) {
+                    int p = (top - j) % Le;
+                    if (p < 0) p += Le;
+                    src = p < L ? p : L - 1;  // the padded sample repeats the last one
+                } else {
+                    src = ext_index(top - j, L, mode);
+                }
+                if (src >= 0) {
+                    const T v = row[src];
+                    a += tp.lo[j] * v;
+                    d += tp.hi[j] * v;
+                }
+            }
+        }
+        lo[i] = a;
+        hi[i] = d;
+    }
+}
+
+// synthesis lo[rows][lo_len] (leading n used), hi[rows][n] -> out[rows][Lo] (cropped); taps walked by parity, so a
+// periodization output costs F / 2 terms like the others (synth() above scans all n coefficients in that mode)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) dwt1_inv_kernel(const T* __restrict__ lo, int lo_len, const T* __restrict__ hi,
+                                                           T* __restrict__ out, int64_t rows, int n, int Lo, Taps<T> tp, int mode) {
+    const int64_t total = rows * Lo;
+    const int F = tp.len;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+        const int o = (int)(idx % Lo);
+        const int64_t r = idx / Lo;
+        const T* a = lo + r * lo_len;
+        const T* d = hi + r * n;
+        const int t = mode == kPeriodization ? o + F / 2 - 1 : o + F - 2;  // 2 i + j == t (mod 2n when periodized)
+        T acc = T(0);
+        for (int j = t & 1; j < F; j += 2) {
+            int i = (t - j) >> 1;  // t - j is even; arithmetic shift = floor
+            if (mode == kPeriodization) {
+                i %= n;
+                if (i < 0) i += n;
+            } else if (i < 0 || i >= n) {
+                continue;
+            }
+            acc += a[i] * tp.lo[j] + d[i] * tp.hi[j];
+        }
+        out[idx] = acc;
+    }
+}
+
 template <typename T>
 static int dwt2_fwd(const T* x, T* ll, T* hi, int64_t planes, int64_t H, int64_t W, const double* dec_lo, const double* dec_hi,
                     int flen, int mode, void* ws, hipStream_t st, const char* what) {
@@ -179,6 +249,35 @@ static int dwt2_inv(const T* ll, int64_t ll_h, int64_t ll_w, const T* hi, T* out
                        tmp, planes, (int)h, (int)w, (int)Hr, tp, mode);
     hipLaunchKernelGGL((idwt_rows_kernel<T>), dim3(grid_for(planes * Ho * Wo, kBlock)), dim3(kBlock), 0, st, tmp, out, planes, (int)w,
                        (int)Hr, (int)Ho, (int)Wo, tp, mode);
+    return check_launch(what);
+}
+
+template <typename T>
+static int dwt1_fwd(const T* x, T* lo, T* hi, int64_t rows, int64_t L, const double* dec_lo, const double* dec_hi, int flen, int mode,
+                    hipStream_t st, const char* what) {
+    SONAR_REQUIRE(x && lo && hi && rows >= 0 && mode >= 0 && mode <= 5, SONAR_ERR_ARG, "%s: bad argument", what);
+    SONAR_REQUIRE(L > 0 && L < (1 << 30), SONAR_ERR_UNSUPPORTED, "%s: bad signal length", what);
+    Taps<T> tp;
+    SONAR_REQUIRE(make_taps(tp, dec_lo, dec_hi, flen), SONAR_ERR_ARG, "%s: 1..%d filter taps required", what, kMaxTaps);
+    if (rows == 0) return SONAR_OK;
+    const int n = (int)dwt_len(L, flen, mode);
+    hipLaunchKernelGGL((dwt1_fwd_kernel<T>), dim3(grid_for(rows * n, kBlock)), dim3(kBlock), 0, st, x, lo, hi, rows, (int)L, n, tp, mode);
+    return check_launch(what);
+}
+
+template <typename T>
+static int dwt1_inv(const T* lo, int64_t lo_len, const T* hi, T* out, int64_t rows, int64_t n, int64_t Lo, const double* rec_lo,
+                    const double* rec_hi, int flen, int mode, hipStream_t st, const char* what) {
+    SONAR_REQUIRE(lo && hi && out && rows >= 0 && mode >= 0 && mode <= 5, SONAR_ERR_ARG, "%s: bad argument", what);
+    SONAR_REQUIRE(n > 0 && n < (1 << 29) && lo_len >= n, SONAR_ERR_ARG, "%s: bad coefficient length", what);
+    Taps<T> tp;
+    SONAR_REQUIRE(make_taps(tp, rec_lo, rec_hi, flen), SONAR_ERR_ARG, "%s: 1..%d filter taps required", what, kMaxTaps);
+    const int64_t Lr = mode == kPeriodization ? 2 * n : 2 * n - flen + 2;
+    SONAR_REQUIRE(Lr > 0 && Lo > 0 && Lo <= Lr, SONAR_ERR_ARG, "%s: requested output %lld exceeds the reconstruction %lld", what,
+                  (long long)Lo, (long long)Lr);
+    if (rows == 0) return SONAR_OK;
+    hipLaunchKernelGGL((dwt1_inv_kernel<T>), dim3(grid_for(rows * Lo, kBlock)), dim3(kBlock), 0, st, lo, (int)lo_len, hi, out, rows, (int)n,
+                       (int)Lo, tp, mode);
     return check_launch(what);
 }
 
@@ -237,6 +336,22 @@ extern "C" int sonar_dwt2_inv_f64(const double* ll, int64_t ll_h, int64_t ll_w, 
                                   int mode, void* ws, void* stream) {
     return dwt2_inv<double>(ll, ll_h, ll_w, hi, out, planes, h, w, Ho, Wo, rec_lo, rec_hi, flen, mode, ws, (hipStream_t)stream,
                             "sonar_dwt2_inv_f64");
+}
+extern "C" int sonar_dwt1_fwd_f32(const float* x, float* lo, float* hi, int64_t rows, int64_t L, const double* dec_lo,
+                                  const double* dec_hi, int flen, int mode, void* stream) {
+    return dwt1_fwd<float>(x, lo, hi, rows, L, dec_lo, dec_hi, flen, mode, (hipStream_t)stream, "sonar_dwt1_fwd_f32");
+}
+extern "C" int sonar_dwt1_fwd_f64(const double* x, double* lo, double* hi, int64_t rows, int64_t L, const double* dec_lo,
+                                  const double* dec_hi, int flen, int mode, void* stream) {
+    return dwt1_fwd<double>(x, lo, hi, rows, L, dec_lo, dec_hi, flen, mode, (hipStream_t)stream, "sonar_dwt1_fwd_f64");
+}
+extern "C" int sonar_dwt1_inv_f32(const float* lo, int64_t lo_len, const float* hi, float* out, int64_t rows, int64_t n, int64_t Lo,
+                                  const double* rec_lo, const double* rec_hi, int flen, int mode, void* stream) {
+    return dwt1_inv<float>(lo, lo_len, hi, out, rows, n, Lo, rec_lo, rec_hi, flen, mode, (hipStream_t)stream, "sonar_dwt1_inv_f32");
+}
+extern "C" int sonar_dwt1_inv_f64(const double* lo, int64_t lo_len, const double* hi, double* out, int64_t rows, int64_t n, int64_t Lo,
+                                  const double* rec_lo, const double* rec_hi, int flen, int mode, void* stream) {
+    return dwt1_inv<double>(lo, lo_len, hi, out, rows, n, Lo, rec_lo, rec_hi, flen, mode, (hipStream_t)stream, "sonar_dwt1_inv_f64");
 }
 extern "C" int sonar_wcfg_band_f32(const float* cond, const float* uncond, float* out, int64_t n, int64_t group_size, int64_t groups,
                                    const double* s_cond, const double* s_uncond, const double* s_diff, const double* s_final,

@@ -103,6 +103,10 @@ SIGNATURES = {
     "sonar_dwt2_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f32": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f64": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
+    "sonar_dwt1_fwd_f32": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _I, _I, _P]),
+    "sonar_dwt1_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _I, _I, _P]),
+    "sonar_dwt1_inv_f32": (_I, [_P, _I64, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
+    "sonar_dwt1_inv_f64": (_I, [_P, _I64, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
     "sonar_wcfg_band_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
     "sonar_wcfg_band_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
@@ -639,6 +643,38 @@ def dwt2_inverse(ll: torch.Tensor, hi: torch.Tensor, rec_lo, rec_hi, mode: str, 
     fn = load().sonar_dwt2_inv_f32 if kind == "f32" else load().sonar_dwt2_inv_f64
     _check(fn(_dev(ll, "ll", hi.dtype), ll_h, ll_w, _dev(hi, "hi", hi.dtype), _dev(out, "out", hi.dtype), planes, h, w, Ho, Wo,
               _darr(rec_lo), _darr(rec_hi), flen, m, ws.data_ptr(), _stream()), f"sonar_dwt2_inv_{kind}")
+    return out
+
+
+def dwt1_forward(x: torch.Tensor, dec_lo, dec_hi, mode: str):
+    """One 1-D analysis level along the last axis: x[..., L] -> (lo[..., n], hi[..., n])."""
+    kind = _wavelet_dtype(x)
+    L = x.shape[-1]
+    rows = x.numel() // max(L, 1)
+    flen, m = len(dec_lo), DWT_MODE_IDS[mode]
+    n = dwt_out_len(L, flen, mode)
+    lo = torch.empty((*x.shape[:-1], n), dtype=x.dtype, device=x.device)
+    hi = torch.empty_like(lo)
+    fn = load().sonar_dwt1_fwd_f32 if kind == "f32" else load().sonar_dwt1_fwd_f64
+    _check(fn(_dev(x, "x", x.dtype), _dev(lo, "lo", x.dtype), _dev(hi, "hi", x.dtype), rows, L, _darr(dec_lo), _darr(dec_hi), flen, m, _stream()),
+           f"sonar_dwt1_fwd_{kind}")
+    return lo, hi
+
+
+def dwt1_inverse(lo: torch.Tensor, hi: torch.Tensor, rec_lo, rec_hi, mode: str, out_len: Optional[int] = None) -> torch.Tensor:
+    """One 1-D synthesis level.  ``lo`` may be one sample longer than the band (its leading samples are used)."""
+    kind = _wavelet_dtype(hi)
+    if lo.dtype != hi.dtype:
+        raise SonarHipError("DWT inverse: lo / hi dtype mismatch")
+    n = hi.shape[-1]
+    rows = hi.numel() // max(n, 1)
+    flen, m = len(rec_lo), DWT_MODE_IDS[mode]
+    full = 2 * n if mode == "periodization" else 2 * n - flen + 2
+    Lo = full if out_len is None else int(out_len)
+    out = torch.empty((*hi.shape[:-1], Lo), dtype=hi.dtype, device=hi.device)
+    fn = load().sonar_dwt1_inv_f32 if kind == "f32" else load().sonar_dwt1_inv_f64
+    _check(fn(_dev(lo, "lo", hi.dtype), lo.shape[-1], _dev(hi, "hi", hi.dtype), _dev(out, "out", hi.dtype), rows, n, Lo, _darr(rec_lo),
+              _darr(rec_hi), flen, m, _stream()), f"sonar_dwt1_inv_{kind}")
     return out
 
 

@@ -597,11 +597,13 @@ class WaveletFilteredNoiseGenerator(FramesToChannelsNoiseGenerator):
         noise = self.rand_like() if self.noise_sampler is None else self.noise_sampler(*args)
         utils.pop_stats(noise)
         noise = noise.reshape(*shape).contiguous()
-        yl, yh = self.wavelet.forward(noise)
+        need_flat = self.use_1d_dwt and noise.ndim > 3  # :1982-1986 -- the 1-D transform runs over the flattened plane
+        flat = (lambda t: t.flatten(start_dim=2)) if need_flat else (lambda t: t)
+        yl, yh = self.wavelet.forward(flat(noise))
         if self.noise_sampler_high is not None:
             high = self.noise_sampler_high(*args)
             utils.pop_stats(high)
-            yl_h, yh_h = self.wavelet.forward(high.reshape(*shape).contiguous())
+            yl_h, yh_h = self.wavelet.forward(flat(high.reshape(*shape).contiguous()))
             if self.preblend_yl_scale_high is not None or self.preblend_yh_scales_high is not None:
                 yl_h, yh_h = wavelet_scaling(yl_h, yh_h, fallback(self.preblend_yl_scale_high, 1.0), fallback(self.preblend_yh_scales_high, 1.0), in_place=True)
             if self.preblend_yl_scale_low is not None or self.preblend_yh_scales_low is not None:
@@ -610,6 +612,8 @@ class WaveletFilteredNoiseGenerator(FramesToChannelsNoiseGenerator):
                                    blend_function=self.yl_blend_function, yh_blend_function=self.yh_blend_function)
         yl, yh = wavelet_scaling(yl, yh, self.yl_scale, self.yh_scales, in_place=True)
         result = self.wavelet.inverse(yl, yh, two_step_inverse=self.two_step_inverse)
+        if need_flat:  # pixel counts the transform cannot return exactly (odd H*W) fail here, like the reference's reshape
+            result = result.reshape(*shape)
         if tuple(result.shape) != tuple(shape):
             result = result[tuple(slice(0, d) for d in shape)].contiguous()
         return self.fix_output_frames(result)

@@ -544,7 +544,10 @@ class WaveletCFG:
         if wavelet is None:
             wavelet = self.wavelet_cache[id(rule)] = rule.make_wavelet()
         wavelet = wavelet.to(device=x.device, dtype=eff_dtype)
-        if x.ndim > 4:
+        if rule.wavelet.use_1d_dwt:
+            cond = cond.flatten(start_dim=2)
+            uncond = uncond.flatten(start_dim=2)
+        elif x.ndim > 4:
             cond = cond.flatten(start_dim=1, end_dim=cond.ndim - 3)
             uncond = uncond.flatten(start_dim=1, end_dim=uncond.ndim - 3)
         return WCFGContext(cond=cond, uncond=uncond, x=x, sigma=sigma, wavelet=wavelet, dtype=eff_dtype, op_kwargs=op_kwargs)
@@ -594,7 +597,8 @@ class WaveletCFG:
             return [None if tabs[name][1] is None else tabs[name][1][j] if j < len(tabs[name][1]) else None for name in ("cond", "uncond", "diff", "final")]
 
         yl = hip_lib.wcfg_band(condw[0], uncondw[0], 1, *[[tabs[n][0]] for n in ("cond", "uncond", "diff", "final")], mode, strength, out=condw[0])
-        out_yh = [hip_lib.wcfg_band(c, u, 3, *band_scales(j), mode, strength, out=c) for j, (c, u) in enumerate(zip(condw[1], uncondw[1]))]
+        norient = 1 if condw[0].ndim == 3 else 3  # 1-D transform: one detail band per level
+        out_yh = [hip_lib.wcfg_band(c, u, norient, *band_scales(j), mode, strength, out=c) for j, (c, u) in enumerate(zip(condw[1], uncondw[1]))]
         return ctx.wavelet.inverse(yl, out_yh)
 
     @classmethod
@@ -605,7 +609,9 @@ class WaveletCFG:
     def process_output(self, *, result: torch.Tensor, rule: WCFGRule, ctx: WCFGContext) -> torch.Tensor:
         """py/wavelet_cfg.py:729-748 (crop to x, DENOISED: x - result; NOISE_NORM: * sigma)."""
         x_shape = ctx.x.shape
-        if ctx.x.ndim > 4:
+        if rule.wavelet.use_1d_dwt:
+            result = result[..., : ctx.cond.shape[2]].reshape(x_shape)
+        elif ctx.x.ndim > 4:
             result = result[..., : x_shape[-2], : x_shape[-1]].reshape(x_shape)
         else:
             result = result[tuple(slice(None, sz) for sz in x_shape)]
@@ -634,7 +640,8 @@ class WaveletCFG:
         ctx = self.get_context(rule=rule, args=args)
         plain = rule.blend_mode == "lerp" and wcfg_blend == 1.0
         x = ctx.x
-        if plain and rule.target_mode == WCFGTarget.DENOISED and x.ndim == 4 and x.dtype == torch.float32 and self.operation_wavelet_cfg is None:
+        if (plain and rule.target_mode == WCFGTarget.DENOISED and x.ndim == 4 and x.dtype == torch.float32 and self.operation_wavelet_cfg is None
+                and not rule.wavelet.use_1d_dwt):
             # fast path 1: the whole transform-domain step in 2 * level LDS-staged launches (cond + uncond analysed together, band
             # arithmetic before the store, last synthesis pass writes x - result)
             fused = self.wavelet_cfg_fused(rule=rule, ctx=ctx, pcts=pcts)

@@ -35,7 +35,9 @@ def _taps(name: str) -> dict:
 
 
 class Wavelet:
-    """py/wavelet_functions.py:23-145 (2-D DWT variant; DTCWT / 1-D DWT are outside this build's hot path)."""
+    """py/wavelet_functions.py:23-145: the 2-D DWT and the 1-D DWT (``use_1d_dwt``, [B, C, L] inputs; yh[j] is then [B, C, l_j]).
+    DTCWT is not built: its biort / qshift filter banks live in the ``dtcwt`` data files of the absent, unpinned
+    ``pytorch_wavelets`` dependency and cannot be restated or pinned here."""
 
     DEFAULT_MODE = "symmetric"
     DEFAULT_LEVEL = 3
@@ -49,8 +51,9 @@ class Wavelet:
                  use_1d_dwt: bool = DEFAULT_USE_1D_DWT, use_dtcwt: bool = DEFAULT_USE_DTCWT, biort: str = DEFAULT_BIORT,
                  qshift: str = DEFAULT_QSHIFT, inv_wave: Optional[str] = None, inv_mode: Optional[str] = None,
                  inv_biort: Optional[str] = None, inv_qshift=None, device=None):
-        if use_dtcwt or use_1d_dwt:
-            raise NotImplementedError("DTCWT and 1-D DWT variants are not on the MI355X hot path of this build (SURVEY.md §8f rank 4)")
+        if use_dtcwt:
+            raise NotImplementedError("the DTCWT variant is not built: its filter banks are unavailable here (SURVEY.md §8c / §8f rank 4)")
+        self.use_1d_dwt = bool(use_1d_dwt)
         if mode not in hip_lib.DWT_MODE_IDS or fallback(inv_mode, mode) not in hip_lib.DWT_MODE_IDS:
             raise ValueError(f"Unknown padding mode {mode!r}; valid: {', '.join(self.modelist())}")
         self.level = int(level)
@@ -66,20 +69,23 @@ class Wavelet:
         """DWTForward(J=level): returns (yl, [yh_0 (finest), ..., yh_{J-1}])."""
         if forward_function is not None:
             return forward_function(t)
-        if t.ndim != 4:
-            raise hip_lib.SonarHipError("Wavelet.forward expects a [B, C, H, W] tensor")
+        one_d = getattr(self, "use_1d_dwt", False)
+        if t.ndim != (3 if one_d else 4):
+            raise hip_lib.SonarHipError("Wavelet.forward expects a [B, C, L] tensor in 1-D mode" if one_d else "Wavelet.forward expects a [B, C, H, W] tensor")
+        step = hip_lib.dwt1_forward if one_d else hip_lib.dwt2_forward
         ll = t.contiguous()
         yh = []
         for _ in range(self.level):
-            ll, hi = hip_lib.dwt2_forward(ll, self.dec_lo, self.dec_hi, self.mode)
+            ll, hi = step(ll, self.dec_lo, self.dec_hi, self.mode)
             yh.append(hi)
         return ll, yh
 
     def _inverse(self, yl: torch.Tensor, yh: Sequence) -> torch.Tensor:
+        step = hip_lib.dwt1_inverse if getattr(self, "use_1d_dwt", False) else hip_lib.dwt2_inverse
         ll = yl.contiguous()
         for hi in reversed(tuple(yh)):
             # a coarser ll may be one row/column larger than the band; the kernel reads only its leading block
-            ll = hip_lib.dwt2_inverse(ll, hi.contiguous(), self.rec_lo, self.rec_hi, self.inv_mode)
+            ll = step(ll, hi.contiguous(), self.rec_lo, self.rec_hi, self.inv_mode)
         return ll
 
     def inverse(self, yl: torch.Tensor, yh: Sequence, *, inverse_function: Optional[Callable] = None,
@@ -158,10 +164,11 @@ def wavelet_scaling(yl: torch.Tensor, yh: Sequence, yl_scale, yh_scales, *, in_p
         hip_lib.band_scale_(yl, [float(yl_scale)])
     table = expand_yh_scales(yh, yh_scales=1.0 if yh_scales is None else yh_scales)
     for scales, band in zip(table, yh):
+        norient = band.shape[2] if band.ndim > 3 else 1  # 1-D transform: [B, C, l] bands, one scale each
         if isinstance(scales, (int, float)):
-            scales = (float(scales),) * band.shape[2]
-        full = tuple(scales) + (1.0,) * (band.shape[2] - len(scales))
-        hip_lib.band_scale_(band, full[: band.shape[2]])
+            scales = (float(scales),) * norient
+        full = tuple(scales) + (1.0,) * (norient - len(scales))
+        hip_lib.band_scale_(band, full[:norient])
     return (yl, yh)
 
 

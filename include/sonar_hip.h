@@ -266,6 +266,20 @@ int sonar_dwt2_inv_f32(const float* ll, int64_t ll_h, int64_t ll_w, const float*
 int sonar_dwt2_inv_f64(const double* ll, int64_t ll_h, int64_t ll_w, const double* hi, double* out, int64_t planes,
                        int64_t h, int64_t w, int64_t Ho, int64_t Wo, const double* rec_lo, const double* rec_hi,
                        int flen, int mode, void* ws, void* stream);
+/* 1-D DWT / IDWT of flattened latents, one level per call (replaces pytorch_wavelets DWT1DForward / DWT1DInverse behind
+ * Wavelet(use_1d_dwt=True), py/wavelet_functions.py:56-57; the callers flatten [B,C,H,W] to [B,C,H*W],
+ * py/wavelet_cfg.py:713-715, py/noise_generation.py:1982-1986).  x[rows][L] -> lo[rows][n], hi[rows][n] with
+ * n = sonar_dwt_out_len(L, flen, mode); the inverse reads the leading n samples of each lo row (row pitch lo_len >= n:
+ * a coarser approximation may be one sample longer than its band) and writes out[rows][Lo], Lo <= 2n - flen + 2
+ * (2n in periodization mode).  Same taps / mode conventions as the 2-D entry points; no workspace. */
+int sonar_dwt1_fwd_f32(const float* x, float* lo, float* hi, int64_t rows, int64_t L, const double* dec_lo,
+                       const double* dec_hi, int flen, int mode, void* stream);
+int sonar_dwt1_fwd_f64(const double* x, double* lo, double* hi, int64_t rows, int64_t L, const double* dec_lo,
+                       const double* dec_hi, int flen, int mode, void* stream);
+int sonar_dwt1_inv_f32(const float* lo, int64_t lo_len, const float* hi, float* out, int64_t rows, int64_t n, int64_t Lo,
+                       const double* rec_lo, const double* rec_hi, int flen, int mode, void* stream);
+int sonar_dwt1_inv_f64(const double* lo, int64_t lo_len, const double* hi, double* out, int64_t rows, int64_t n, int64_t Lo,
+                       const double* rec_lo, const double* rec_hi, int flen, int mode, void* stream);
 /* WaveletCFG band arithmetic, py/wavelet_cfg.py:750-791, for one band tensor of n elements whose element i
  * belongs to orientation group g = (i / group_size) % groups (groups = 3 for yh[B,C,3,h,w], 1 for yl):
  *   c = cond*s_cond[g]; u = uncond*s_uncond[g]; d = (c-u)*s_diff[g]; out = blend(u, d, strength)*s_final[g]

@@ -151,6 +151,43 @@ def waverec2(yl: np.ndarray, yh, wave: str, mode: str):
     return ll
 
 
+def wavedec1(x: np.ndarray, wave: str, mode: str, level: int):
+    """pytorch_wavelets DWT1DForward(J=level) on [..., L] (Wavelet(use_1d_dwt=True), py/wavelet_functions.py:56-57):
+    (yl, [yh_finest, ..., yh_coarsest]); == pywt.wavedec reordered."""
+    dec_lo, dec_hi, _, _ = taps(wave)
+    yh = []
+    lo = x
+    for _ in range(level):
+        lo, hi = dwt_axis(lo, dec_lo, dec_hi, mode, -1)
+        yh.append(hi)
+    return lo, yh
+
+
+def waverec1(yl: np.ndarray, yh, wave: str, mode: str):
+    """pytorch_wavelets DWT1DInverse: coarse to fine; drop the extra sample when the approximation is one longer than the band."""
+    _, _, rec_lo, rec_hi = taps(wave)
+    lo = yl
+    for hi in reversed(yh):
+        if lo.shape[-1] > hi.shape[-1]:
+            lo = lo[..., :-1]
+        lo = idwt_axis(lo, hi, rec_lo, rec_hi, mode, -1)
+    return lo
+
+
+def wavelet_cfg_1d(cond, uncond, wave, mode, level, *, diff_yl=1.0, diff_yh=1.0, strength=1.0):
+    """py/wavelet_cfg.py:713-715,737-738,750-791 in use_1d_dwt mode, `difference` rule, inject blend: the latents are flattened to
+    [B, C, H*W], every level has ONE detail band, the result is cropped to H*W and reshaped."""
+    shape = cond.shape
+    c, u = cond.reshape(*shape[:2], -1), uncond.reshape(*shape[:2], -1)
+    cl, ch = wavedec1(c, wave, mode, level)
+    ul, uh = wavedec1(u, wave, mode, level)
+    yh_scales = expand_yh_scales(level, 1, diff_yh)
+    dl = (cl - ul) * diff_yl
+    dh = [(a - b) * sc[0] for a, b, sc in zip(ch, uh, yh_scales)]
+    out = waverec1(ul + dl * strength, [b + d * strength for b, d in zip(uh, dh)], wave, mode)
+    return out[..., : c.shape[-1]].reshape(shape)
+
+
 # ------------------------------------------------------------------------------------------------ WaveletCFG arithmetic
 def expand_yh_scales(nbands: int, norient: int, yh_scales):
     """py/wavelet_functions.py:148-190 ("fill" repeats the previous entry up to the band count)."""

@@ -40,5 +40,30 @@ for tag, shape, wave, mode, level in specs:
         cases[f"{tag}__yh{j}"] = np.stack([ch, cv, cd], axis=2)
     cases[f"{tag}__rec"] = rec
     cases[f"{tag}__meta"] = np.array([wave, mode, str(level)])
+# 1-D transform (Wavelet(use_1d_dwt=True) -> pytorch_wavelets DWT1DForward / DWT1DInverse == pywt.wavedec / waverec);
+# drawn after the 2-D cases so those keep their values
+specs1d = [
+    ("d1_db4_sym_l5_1024", (1, 2, 1024), "db4", "symmetric", 5),
+    ("d1_haar_per_l3_256", (2, 2, 256), "haar", "periodization", 3),
+    ("d1_db2_per_l3_odd", (1, 3, 37), "db2", "periodization", 3),
+    ("d1_sym5_reflect_l2", (1, 2, 101), "sym5", "reflect", 2),
+    ("d1_db4_zero_l2", (2, 1, 50), "db4", "zero", 2),
+    ("d1_bior22_periodic_l2", (1, 2, 30), "bior2.2", "periodic", 2),
+    ("d1_coif1_constant_l2", (1, 2, 21), "coif1", "constant", 2),
+    ("d1_db4_sym_l1_short", (1, 1, 5), "db4", "symmetric", 1),
+]
+for tag, shape, wave, mode, level in specs1d:
+    x = rng.standard_normal(shape)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        coeffs = pywt.wavedec(x, wave, mode=mode, level=level, axis=-1)
+        rec = pywt.waverec(coeffs, wave, mode=mode, axis=-1)
+    cases[f"{tag}__x"] = x
+    cases[f"{tag}__yl"] = coeffs[0]
+    for j in range(level):
+        cases[f"{tag}__yh{j}"] = coeffs[level - j]
+    cases[f"{tag}__rec"] = rec
+    cases[f"{tag}__meta"] = np.array([wave, mode, str(level)])
 np.savez_compressed(OUT, **cases)
 print(OUT, os.path.getsize(OUT) // 1024, "KiB")

@@ -135,6 +135,21 @@ def test_wavelet_filtered_generator(api, name):
     close(out, torch.from_numpy(want), rtol=3e-5, atol=3e-5)
 
 
+def test_wavelet_filtered_generator_1d_mode(api):
+    """use_1d_dwt (py/noise_generation.py:1982-1986, 2027-2028): the transform runs over the flattened plane."""
+    shape = (2, 4, 16, 24)
+    x = torch.zeros(shape, device="cuda")
+    torch.manual_seed(9)
+    gen = api.noise_generation.WaveletFilteredNoiseGenerator(x, sigma_min=0.03, sigma_max=14.6, seed=9, cpu=True, normalized=False,
+                                                             use_1d_dwt=True, wave="db2", level=2, yl_scale=0.5, yh_scales=[2.0, 1.5])
+    out = gen(*SIG)
+    torch.manual_seed(9)
+    base = torch.randn(shape).numpy().astype(np.float64).reshape(2, 4, -1)
+    yl, yh = dwo.wavedec1(base, "db2", "periodization", 2)
+    want = dwo.waverec1(yl * 0.5, [yh[0] * 2.0, yh[1] * 1.5], "db2", "periodization").reshape(shape)
+    close(out, torch.from_numpy(want), rtol=3e-5, atol=3e-5)
+
+
 def test_wavelet_filtered_item_with_high_noise(api):
     """Low bands from one chain, high bands from another (yl_blend_high = 0, yh_blend_high = 1), then scale_noise."""
     shape = (2, 4, 32, 32)

@@ -34,7 +34,7 @@ def tol(dtype):
 def test_forward_and_inverse_match_pywt(api, tag, dtype):
     wave, mode, level = G[f"{tag}__meta"]
     level = int(level)
-    w = api.wf.Wavelet(wave=str(wave), level=level, mode=str(mode))
+    w = api.wf.Wavelet(wave=str(wave), level=level, mode=str(mode), use_1d_dwt=tag.startswith("d1_"))  # d1_*: pywt.wavedec vectors
     x = torch.from_numpy(G[f"{tag}__x"]).to(dtype).cuda()
     yl, yh = w.forward(x)
     torch.testing.assert_close(yl.cpu().double(), torch.from_numpy(G[f"{tag}__yl"]), **tol(dtype))
@@ -63,6 +63,29 @@ def test_perfect_reconstruction_full_batch(api, wave, mode, level):
     # linearity: DWT(a x) = a DWT(x)
     yl2, _ = w.forward(x * 2)
     torch.testing.assert_close(yl2, yl * 2, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("wave,mode,level", [("db4", "symmetric", 5), ("haar", "periodization", 3), ("sym8", "periodic", 4)])
+def test_1d_transform_full_size(api, wave, mode, level):
+    """use_1d_dwt on flattened SDXL latents ([64, 4, 16384], fp32 and fp64): perfect reconstruction, linearity, band lengths."""
+    torch.manual_seed(0)
+    x = torch.randn(64, 4, 128 * 128, device="cuda")
+    w = api.wf.Wavelet(wave=wave, level=level, mode=mode, use_1d_dwt=True)
+    yl, yh = w.forward(x)
+    n, flen = 128 * 128, len(w.dec_lo)
+    for band in yh:
+        n = api.hl.dwt_out_len(n, flen, mode)
+        assert tuple(band.shape) == (64, 4, n)
+    assert tuple(yl.shape) == (64, 4, n)
+    rec = w.inverse(yl, yh)[..., : 128 * 128]
+    assert (rec - x).abs().max().item() < 5e-5
+    yl2, _ = w.forward(x * 2)
+    torch.testing.assert_close(yl2, yl * 2, rtol=1e-6, atol=1e-6)
+    xd = x[:4].double()
+    rec64 = w.inverse(*w.forward(xd))[..., : 128 * 128]
+    assert (rec64 - xd).abs().max().item() < 1e-11
+    with pytest.raises(api.hl.SonarHipError):
+        w.forward(x.reshape(64, 4, 128, 128))
 
 
 def test_longest_filter_matches_oracle(api):
@@ -128,6 +151,32 @@ def test_wavelet_cfg_matches_oracle(api, high_precision, extra):
                           blend=params.get("difference_blend_mode", "inject"))
     want = x - torch.from_numpy(res[..., :128, :128].astype(np.float32))
     torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=(2e-5 if high_precision else 2e-4))
+
+
+@pytest.mark.parametrize("high_precision", [True, False])
+def test_wavelet_cfg_1d_mode_matches_oracle(api, high_precision):
+    """py/wavelet_cfg.py:713-715,737-738: use_1d_dwt flattens the latents to [B, C, H*W]; one detail band per level."""
+    torch.manual_seed(4)
+    shape = (2, 4, 24, 20)
+    cond, uncond, x = (torch.randn(shape) for _ in range(3))
+    params = dict(difference=dict(yl_scale=2.0, yh_scales=[3.0, 0.5, "fill"]), high_precision_mode=high_precision, use_1d_dwt=True, level=3)
+    rules = api.wc.WCFGRules.build(**params)
+    fn = api.wc.WaveletCFG(existing_cfg=None, rules=rules)
+    args = {"input": x.cuda(), "cond_scale": 7.0, "cond": (x - cond).cuda(), "uncond": (x - uncond).cuda(), "cond_denoised": cond.cuda(),
+            "uncond_denoised": uncond.cuda(), "sigma": torch.full((2,), 7.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+    out = fn(args)
+    assert out.is_contiguous() and out.shape == x.shape and out.dtype == torch.float32
+    ws = rules[0].wavelet
+    dt = np.float64 if high_precision else np.float32
+    res = dwo.wavelet_cfg_1d(cond.numpy().astype(dt), uncond.numpy().astype(dt), ws.wave, ws.padding_mode, ws.level, diff_yl=2.0,
+                             diff_yh=[3.0, 0.5, "fill"])
+    want = x - torch.from_numpy(res.astype(np.float32))
+    torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=(2e-5 if high_precision else 2e-4))
+    # a 3-D latent needs the 1-D mode (py/wavelet_cfg.py:681-682)
+    rules2 = api.wc.WCFGRules.build(difference=dict(yl_scale=2.0))
+    with pytest.raises(RuntimeError):
+        api.wc.WaveletCFG(existing_cfg=None, rules=rules2)({**args, "input": x.cuda().flatten(2), "cond_denoised": cond.cuda().flatten(2),
+                                                            "uncond_denoised": uncond.cuda().flatten(2)})
 
 
 def test_wavelet_cfg_rule_window_and_blend(api):
