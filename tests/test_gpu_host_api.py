@@ -367,6 +367,41 @@ def test_noisy_latent_like_and_noise_adapter_nodes(pkg, api, golden):
     assert torch.count_nonzero(zero) == 0
 
 
+def test_sampler_config_override_node(pkg, api, golden):
+    """SamplerConfigOverride (py/nodes/misc.py:461-619): wraps a SAMPLER; eta / s_noise and the noise source are replaced, parameters
+    the wrapped sampler function does not take are dropped."""
+    g = golden("momentum")
+    M = pkg.NODE_CLASS_MAPPINGS
+    S = api.sonar
+    x0, sigmas = g["x0"].cuda(), g["sigmas"]
+    (inner,) = M["SamplerSonarEulerA"].get_sampler(momentum=0.95, momentum_hist=0.75, momentum_init="ZERO", direction=1.0, rand_init_noise_type="gaussian",
+                                                   noise_type="gaussian", eta=1.0, s_noise=1.0)
+    chain = chain_of(api, item(api, "uniform", 1.0))
+    (wrapped,) = M["SamplerConfigOverride"]().get_sampler(sampler=inner, eta=0.5, s_noise=1.2, s_churn=0.3, r=0.25, sde_solver="heun", cpu_noise=True,
+                                                          noise_type="DEFAULT", custom_noise_opt=chain, normalize=True, yaml_parameters="eta: 0.6")
+    assert wrapped.extra_options == inner.extra_options and wrapped.extra_options is not inner.extra_options
+    torch.manual_seed(11)
+    out = wrapped.sampler_function(fake_model, x0.clone(), sigmas, extra_args={"seed": 3}, callback=None, disable=True, **wrapped.extra_options)
+    torch.manual_seed(11)
+    ns = chain.make_noise_sampler(x0, sigmas[sigmas > 0].min(), sigmas.max(), seed=3, cpu=True, normalized=True)
+    want = S.SonarEulerAncestral.sampler(fake_model, x0.clone(), sigmas, {"seed": 3}, None, True, sonar_config=inner.extra_options["sonar_config"],
+                                         eta=0.6, s_noise=1.2, noise_sampler=ns)
+    close(out, want, rtol=0, atol=0)
+    # a sampler function without a noise_sampler parameter only receives the kwargs it declares
+    seen = {}
+
+    def plain(model, x, sigmas, extra_args=None, s_churn=0.0):
+        seen.update(s_churn=s_churn, extra_args=extra_args)
+        return x
+
+    import types
+    carrier = types.SimpleNamespace(sampler_function=plain, extra_options={}, inpaint_options={})
+    (w2,) = M["SamplerConfigOverride"]().get_sampler(sampler=carrier, eta=0.5, s_noise=1.2, s_churn=0.3, r=0.25, sde_solver="heun", noise_type="perlin")
+    assert w2.sampler_function(None, x0, sigmas) is x0 and seen == {"s_churn": 0.3, "extra_args": {}}
+    with pytest.raises(ValueError):
+        M["SamplerConfigOverride"]().get_sampler(sampler=carrier, eta=0.5, s_noise=1.2, s_churn=0.3, r=0.25, sde_solver="heun", yaml_parameters="[1, 2]")
+
+
 def test_global_normalisation_and_sharded_sampler_single_process(api):
     par = __import__("importlib").import_module("comfyui_sonar_amd.parallel")
     torch.manual_seed(3)
