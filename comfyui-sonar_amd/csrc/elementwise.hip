@@ -397,6 +397,68 @@ __global__ void __launch_bounds__(kBlock) div_mid_kernel(float* x, int64_t outer
     }
 }
 
+// ---- ModulatedNoise (py/noise.py:784-866) ----------------------------------------------------------------------------------
+// unbiased std over the middle axis of x[outer][mid][inner] (torch.std(dim=-3, keepdim=True)); mid == 1 gives NaN like torch
+__global__ void __launch_bounds__(kBlock) std_mid_kernel(const float* __restrict__ x, int64_t outer, int64_t mid, int64_t inner,
+                                                          float* stdv) {
+    const int64_t total = outer * inner;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t o = t / inner, i = t - o * inner;
+        const float* p = x + o * mid * inner + i;
+        double s = 0.0;
+        for (int64_t m = 0; m < mid; ++m) s += (double)p[m * inner];
+        const double mean = s / (double)mid;
+        double q = 0.0;
+        for (int64_t m = 0; m < mid; ++m) {
+            const double d = (double)p[m * inner] - mean;
+            q += d * d;
+        }
+        stdv[t] = (float)sqrt(q / (double)(mid - 1));
+    }
+}
+
+// v = x * k * (1 / (std * |strength| + 1) + 1), std broadcast through (so, sm, si) strides over x's [outer][mid][inner] view
+// (py/noise.py:799-803: noise * scaling + noise).  Optional store; optional partials: slot pair (sum x^2, sum v^2) per block.
+__global__ void __launch_bounds__(kBlock) bcast_gain_kernel(const float* __restrict__ x, const float* __restrict__ stdv, int64_t outer,
+                                                             int64_t mid, int64_t inner, int64_t so, int64_t sm, int64_t si,
+                                                             float abs_strength, float k, float* out, double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    const int64_t total = outer * mid * inner, plane = mid * inner;
+    double sx = 0.0, sv = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t o = t / plane, r = t - o * plane, m = r / inner, i = r - m * inner;
+        const float sd = stdv[o * so + m * sm + i * si];
+        const float gain = 1.0f / (sd * abs_strength + 1.0f);
+        const float xv = x[t];
+        const float plain = xv * k;
+        const float v = plain * gain + plain;
+        if (out) out[t] = v;
+        sx += (double)xv * (double)xv;
+        sv += (double)v * (double)v;
+    }
+    if (partials) write_partial<kBlock>(sx, sv, partials, red);
+}
+
+// out = a * (a_mul * rho) + x * x_mul with rho = sqrt(num_mul * sum(num[2i]) / sum(den[2i+1])) -- the "scale to normal noise
+// strength" ratio of two L2 norms (py/noise.py:805-810), taken from partial slots so the host never reads it back
+__global__ void __launch_bounds__(kBlock) ratio_mix_kernel(const float* __restrict__ a, float a_mul, const float* __restrict__ x,
+                                                            float x_mul, const double* __restrict__ num, double num_mul,
+                                                            const double* __restrict__ den, float* out, int64_t n) {
+    __shared__ double red[2 * kBlock / 64];
+    __shared__ float srho;
+    double sn = 0.0, sd = 0.0;
+    for (int j = threadIdx.x; j < kNPart; j += kBlock) {
+        sn += num[2 * j];
+        sd += den[2 * j + 1];
+    }
+    block_sum2<kBlock>(sn, sd, red);
+    if (threadIdx.x == 0) srho = (float)sqrt(num_mul * sn / sd);
+    __syncthreads();
+    const float am = a_mul * srho;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (int64_t)gridDim.x * kBlock)
+        out[t] = a[t] * am + x[t] * x_mul;
+}
+
 struct PowerLawOp {
     float* x;
     float alpha;
@@ -750,6 +812,36 @@ extern "C" int sonar_div_mid_f32(float* x, int64_t outer, int64_t mid, int64_t i
     hipLaunchKernelGGL(div_mid_kernel, dim3(grid_for(outer * mid * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x,
                        outer, mid, inner, d);
     return check_launch("sonar_div_mid_f32");
+}
+
+extern "C" int sonar_std_mid_f32(const float* x, int64_t outer, int64_t mid, int64_t inner, float* stdv, void* stream) {
+    SONAR_REQUIRE(x && stdv && outer >= 0 && mid > 0 && inner > 0, SONAR_ERR_ARG, "sonar_std_mid_f32: bad argument");
+    if (outer == 0) return SONAR_OK;
+    hipLaunchKernelGGL(std_mid_kernel, dim3(grid_for(outer * inner, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, outer, mid, inner,
+                       stdv);
+    return check_launch("sonar_std_mid_f32");
+}
+
+extern "C" int sonar_bcast_gain_f32(const float* x, const float* stdv, int64_t outer, int64_t mid, int64_t inner, int bcast,
+                                    float abs_strength, float k, float* out, double* partials, void* stream) {
+    SONAR_REQUIRE(x && stdv && (out || partials) && outer >= 0 && mid > 0 && inner > 0 && bcast >= 0 && bcast <= 2, SONAR_ERR_ARG,
+                  "sonar_bcast_gain_f32: bad argument");
+    // bcast 0: std[outer] (dims -3,-2,-1)   1: std[outer][mid] (dims -2,-1)   2: std[outer][inner] (dim -3)
+    const int64_t so = bcast == 0 ? 1 : bcast == 1 ? mid : inner, sm = bcast == 1 ? 1 : 0, si = bcast == 2 ? 1 : 0;
+    const int64_t n = outer * mid * inner;
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>(grid_for(n, kBlock * 4), 1), kNPart);
+    hipLaunchKernelGGL(bcast_gain_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, x, stdv, outer, mid, inner, so, sm, si,
+                       abs_strength, k, out, partials);
+    return check_launch("sonar_bcast_gain_f32");
+}
+
+extern "C" int sonar_ratio_mix_f32(const float* a, float a_mul, const float* x, float x_mul, const double* num_partials,
+                                   double num_mul, const double* den_partials, float* out, int64_t n, void* stream) {
+    SONAR_REQUIRE(a && x && num_partials && den_partials && out && n >= 0, SONAR_ERR_ARG, "sonar_ratio_mix_f32: bad argument");
+    if (n == 0) return SONAR_OK;
+    hipLaunchKernelGGL(ratio_mix_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, (hipStream_t)stream, a, a_mul, x, x_mul,
+                       num_partials, num_mul, den_partials, out, n);
+    return check_launch("sonar_ratio_mix_f32");
 }
 
 extern "C" int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,

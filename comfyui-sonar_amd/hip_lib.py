@@ -103,6 +103,9 @@ SIGNATURES = {
     "sonar_dwt2_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f32": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f64": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
+    "sonar_std_mid_f32": (_I, [_P, _I64, _I64, _I64, _P, _P]),
+    "sonar_bcast_gain_f32": (_I, [_P, _P, _I64, _I64, _I64, _I, _F, _F, _P, _P, _P]),
+    "sonar_ratio_mix_f32": (_I, [_P, _F, _P, _F, _P, _D, _P, _P, _I64, _P]),
     "sonar_dwt1_fwd_f32": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _I, _I, _P]),
     "sonar_dwt1_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _I, _I, _P]),
     "sonar_dwt1_inv_f32": (_I, [_P, _I64, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
@@ -272,6 +275,30 @@ def row_affine(op: int, x: torch.Tensor, rows: int, inner: int, a: torch.Tensor,
     out = torch.empty_like(x)
     _check(load().sonar_row_affine_f32(op, _dev(x, "x"), rows, inner, _dev(a, "a"), _dev(b, "b"), _dev(out, "out"), _stream()),
            "sonar_row_affine_f32")
+    return out
+
+
+def std_mid(x: torch.Tensor, outer: int, mid: int, inner: int) -> torch.Tensor:
+    out = torch.empty(outer * inner, dtype=torch.float32, device=x.device)
+    _check(load().sonar_std_mid_f32(_dev(x, "x"), outer, mid, inner, _dev(out, "stdv"), _stream()), "sonar_std_mid_f32")
+    return out
+
+
+def bcast_gain(x: torch.Tensor, stdv: torch.Tensor, outer: int, mid: int, inner: int, bcast: int, abs_strength: float, k: float, *,
+               store: bool = True, partials: Optional[torch.Tensor] = None):
+    """v = x*k*(1/(std*|strength|+1) + 1); returns (v or None, partials with (sum x^2, sum v^2) per slot)."""
+    out = torch.empty_like(x) if store else None
+    partials = new_partials(x.device) if partials is None else partials
+    _check(load().sonar_bcast_gain_f32(_dev(x, "x"), _dev(stdv, "stdv"), outer, mid, inner, bcast, float(abs_strength), float(k), _opt(out, "out"),
+                                       partials.data_ptr(), _stream()), "sonar_bcast_gain_f32")
+    return out, partials
+
+
+def ratio_mix(a: torch.Tensor, a_mul: float, x: torch.Tensor, x_mul: float, num_partials: torch.Tensor, num_mul: float,
+              den_partials: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(a) if out is None else out
+    _check(load().sonar_ratio_mix_f32(_dev(a, "a"), float(a_mul), _dev(x, "x"), float(x_mul), num_partials.data_ptr(), float(num_mul),
+                                      den_partials.data_ptr(), _dev(out, "out"), a.numel(), _stream()), "sonar_ratio_mix_f32")
     return out
 
 

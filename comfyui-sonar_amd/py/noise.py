@@ -338,6 +338,93 @@ class GuidedNoise(CustomNoiseItemBase):
         return noise_sampler
 
 
+class ModulatedNoise(CustomNoiseItemBase):
+    """py/noise.py:762-1019: noise shaped by the local busyness of a reference latent (or of the sampler's x).  ``intensity`` and
+    ``frequency`` run as HIP kernels (std over the modulation dims -> broadcast gain -> [LDS-resident rfft2 x boost x irfft2] ->
+    L2-norm ratio mix; no scalar is read back).  ``spectral_signum`` (per-sample quantiles of the log-spectrum) is not built."""
+
+    MODULATION_DIMS = (-3, (-2, -1), (-3, -2, -1))
+
+    def __init__(self, factor, *, noise, normalize_result, normalize_noise, normalize_ref, modulation_type="none", modulation_strength=2.0,
+                 modulation_dims=3, ref_latent_opt=None):
+        super().__init__(factor, normalize_result=normalize_result, normalize_noise=normalize_noise, normalize_ref=normalize_ref,
+                         noise=noise.clone(), modulation_dims=modulation_dims, modulation_type=modulation_type,
+                         modulation_strength=modulation_strength, ref_latent_opt=None if ref_latent_opt is None else ref_latent_opt.clone())
+        if modulation_type == "spectral_signum":
+            raise NotImplementedError("ModulatedNoise: the spectral_signum mode is outside this build (SURVEY.md §8f rank 3 covers the fft modes)")
+        if modulation_type in {"intensity", "frequency"} and modulation_dims not in (1, 2, 3):
+            raise ValueError("Bad modulation_dims")
+
+    def clone_key(self, k):
+        if k == "ref_latent_opt":
+            return None if self.ref_latent_opt is None else self.ref_latent_opt.clone()
+        if k == "noise":
+            return self.noise.clone()
+        return super().clone_key(k)
+
+    @staticmethod
+    def _frequency_boost(h: int, w: int, strength: float, device) -> Tensor:
+        """Half-spectrum form of the magnitude boost 1 + (1 - exp(-((ky/h)^2 + (kx/w)^2) b^2)) (:838-848, unshifted index grid)."""
+        from .noise_generation import _half_gain
+
+        ky = (torch.arange(h, dtype=torch.float32)[:, None] / h) ** 2
+        kx = (torch.arange(w, dtype=torch.float32)[None, :] / w) ** 2
+        return _half_gain(2.0 - torch.exp(-(ky + kx) * abs(strength) ** 2)).to(device)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        from .sonar import get_ancestral_step  # sonar imports this module
+
+        factor, strength, mtype = self.factor, float(self.modulation_strength), self.modulation_type
+        normalize_noise, normalize_result, normalize_ref = (self.get_normalize(f"normalize_{k}", normalized) for k in ("noise", "result", "ref"))
+        if mtype not in {"intensity", "frequency"}:
+            ns = self.noise.make_noise_sampler(x, *args, normalized=normalize_result or normalize_noise, **kwargs)
+
+            def plain_sampler(s, sn):
+                return scale_noise(ns(s, sn), factor, normalized=False)
+
+            return plain_sampler
+        ns = self.noise.make_noise_sampler(x, *args, normalized=normalize_noise, **kwargs)
+        ref_latent = None if self.ref_latent_opt is None else self.ref_latent_opt.to(x, copy=True).contiguous()
+        if x.ndim < 3:
+            raise ValueError("ModulatedNoise needs at least 3 dimensions")
+        d3, d2, d1 = x.shape[-3:]
+        outer, mid, inner = x.numel() // (d3 * d2 * d1), d3, d2 * d1
+        which = self.modulation_dims - 1  # 0: dim -3, 1: dims (-2, -1), 2: dims (-3, -2, -1)
+        boost = None
+        if mtype == "frequency":
+            if not hip_lib.power_supported(d2, d1):
+                raise hip_lib.SonarHipError(f"ModulatedNoise frequency mode: plane {d2}x{d1} is not LDS-resident (powers of two, 16..256)")
+            boost = self._frequency_boost(d2, d1, strength, x.device)
+
+        def noise_sampler(s, sn):
+            _down, sigma_up = get_ancestral_step(utils.tensor_item(s), utils.tensor_item(sn), eta=1.0)
+            k = float(sigma_up)  # s_noise = 1
+            # the reference normalises this tensor IN PLACE, sampler's x included (:1005-1008)
+            ref = scale_noise(x if ref_latent is None else ref_latent, normalized=normalize_ref)
+            pop_stats(ref)
+            ref = utils.as_f32(ref).contiguous()
+            # std is shift invariant: the reference's `x - x.mean()` only moves rounding
+            if which == 0:
+                stdv, bcast = hip_lib.std_mid(ref, outer, mid, inner), 2
+            elif which == 1:
+                stdv, bcast = hip_lib.rowstats(ref, outer * mid, inner)[1], 1
+            else:
+                stdv, bcast = hip_lib.rowstats(ref, outer, mid * inner)[1], 0
+            noise = ns(s, sn)
+            pop_stats(noise)
+            noise = noise.contiguous()
+            shaped, parts = hip_lib.bcast_gain(noise, stdv, outer, mid, inner, bcast, abs(strength), k)
+            den = parts
+            if boost is not None:
+                den = hip_lib.new_partials(x.device)
+                shaped = hip_lib.spectral_filter(shaped, boost, den)
+                pop_stats(shaped)
+            out = hip_lib.ratio_mix(shaped, strength, noise, k * (1.0 - strength), parts, k * k, den, out=shaped)
+            return scale_noise(out, factor, normalized=normalize_result)
+
+        return noise_sampler
+
+
 class CompositeNoise(CustomNoiseItemBase):
     """py/noise.py:470-533: dst*(1-mask) + src*mask; dst is sampled before src."""
 

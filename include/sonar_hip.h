@@ -88,6 +88,19 @@ int sonar_rowstats_f32(const float* x, int64_t rows, int64_t inner, float* mean,
 /* op 0: out = (x - a[row]) / b[row]   op 1: out = x * b[row] + a[row]   (same call sites) */
 int sonar_row_affine_f32(int op, const float* x, int64_t rows, int64_t inner, const float* a, const float* b,
                          float* out, void* stream);
+/* ModulatedNoise (py/noise.py:784-866), three steps that never read a scalar back to the host:
+ *  sonar_std_mid_f32   unbiased std over the middle axis of x[outer][mid][inner] -> stdv[outer][inner]
+ *                      (torch.std(dim=-3, keepdim=True), :795-799; the other two modulation_dims use sonar_rowstats_f32)
+ *  sonar_bcast_gain_f32  v = x*k*(1/(std*|strength|+1) + 1) (:800-803), std broadcast by `bcast`: 0 = stdv[outer],
+ *                      1 = stdv[outer][mid], 2 = stdv[outer][inner]; `out` and/or `partials` may be NULL; each partial slot pair
+ *                      holds (sum x^2, sum v^2) of its block (1024 pairs, same layout as the statistics kernels)
+ *  sonar_ratio_mix_f32   out = a*(a_mul*rho) + x*x_mul, rho = sqrt(num_mul * sum num[2i] / sum den[2i+1]): the L2-norm ratio
+ *                      "noise_norm / scaled_noise_norm" (:805-810, :860-866) taken from partial slots */
+int sonar_std_mid_f32(const float* x, int64_t outer, int64_t mid, int64_t inner, float* stdv, void* stream);
+int sonar_bcast_gain_f32(const float* x, const float* stdv, int64_t outer, int64_t mid, int64_t inner, int bcast,
+                         float abs_strength, float k, float* out, double* partials, void* stream);
+int sonar_ratio_mix_f32(const float* a, float a_mul, const float* x, float x_mul, const double* num_partials,
+                        double num_mul, const double* den_partials, float* out, int64_t n, void* stream);
 /* PowerLawNoiseGenerator, py/noise_generation.py:775-779: x = (use_sign ? sign(x) : x) * |x|^alpha, in place */
 int sonar_powerlaw_f32(float* x, float alpha, int use_sign, int64_t n, void* stream);
 /* x viewed as [outer, mid, inner]: amax over `mid` of x (use_abs 0) or |x| (use_abs 1) -> peak[outer, inner]

@@ -554,3 +554,43 @@ def green_test_noise(draw: Tensor, scale_fac: float = 1.0, x_pow=2, y_pow=2, pow
     noise = torch.fft.ifft2(torch.fft.fft2(draw) / torch.sqrt(power))
     noise *= scale / noise.std()
     return torch.real(noise)
+
+
+# ---- ModulatedNoise (py/noise.py:762-1019) ------------------------------------------------------------------
+MODULATION_DIMS = (-3, (-2, -1), (-3, -2, -1))  # py/noise.py:763
+
+
+def _modulation_gain(ref: Tensor, strength: float, dims) -> Tensor:
+    """1 / (std * |strength| + 1) with std over `dims` of the (globally centred) reference, py/noise.py:795-803 and :821-826."""
+    sd = torch.std(ref - ref.mean(), dim=dims, keepdim=True)
+    return 1.0 / (sd * abs(strength) + 1.0)
+
+
+def modulated_intensity(ref: Tensor, noise: Tensor, sigma_up, strength: float, dims, s_noise: float = 1.0) -> Tensor:
+    """py/noise.py:784-810: noise scaled down where the reference is busy, renormalised to the plain noise's L2 norm, then mixed."""
+    plain = noise * s_noise * sigma_up
+    shaped = plain * _modulation_gain(ref, strength, dims) + plain
+    shaped = shaped * (torch.norm(plain) / torch.norm(shaped))
+    return shaped * strength + plain * (1 - strength)
+
+
+def modulated_frequency(ref: Tensor, noise: Tensor, sigma_up, strength: float, dims, s_noise: float = 1.0) -> Tensor:
+    """py/noise.py:812-866: the shaped noise goes through fft2, magnitudes are multiplied by 1 + (1 - exp(-(ky^2/h^2 + kx^2/w^2) b^2))
+    (b = |strength|; unshifted index grid, as the reference writes it), ifft2, real part, same renormalise + mix."""
+    plain = noise * s_noise * sigma_up
+    spec = torch.fft.fft2(plain * _modulation_gain(ref, strength, dims) + plain)
+    h, w = ref.shape[-2:]
+    boost = 2.0 - torch.exp(-((torch.arange(h)[:, None] / h) ** 2 + (torch.arange(w)[None, :] / w) ** 2) * strength**2)
+    shaped = torch.fft.ifft2(spec * boost).real
+    shaped = shaped * (torch.norm(plain) / torch.norm(shaped))
+    return shaped * strength + plain * (1 - strength)
+
+
+def modulated_noise(x_or_ref: Tensor, noise: Tensor, s, sn, *, modulation_type: str, strength: float, modulation_dims: int, factor: float,
+                    normalize_ref: bool, normalize_result: bool) -> Tensor:
+    """ModulatedNoise.make_noise_sampler's closure (py/noise.py:1002-1017): sigma_up from get_ancestral_step(s, sn, eta=1); the
+    reference tensor is passed through scale_noise first (IN PLACE -- it is the sampler's own x when no ref latent is given)."""
+    _, sigma_up = ancestral_step(s, sn, 1.0)
+    fn = {"intensity": modulated_intensity, "frequency": modulated_frequency}[modulation_type]
+    ref = scale_noise(x_or_ref, normalized=normalize_ref)
+    return scale_noise(fn(ref, noise, sigma_up, strength, MODULATION_DIMS[modulation_dims - 1]), factor, normalized=normalize_result)

@@ -16,3 +16,11 @@ for hp in (True, False):
     for _ in range(10): fn(wargs)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     print("fp64" if hp else "fp32", f"{dt*1e6:.1f} us/call", f"{16*65536*b4/dt/1e9:.0f} GB/s at 16N")
+if os.environ.get("WCFG_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(50): fn(wargs)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(35)

@@ -737,6 +737,32 @@ def gen_guided_noise():
     save("guided_noise", **cases)
 
 
+def gen_modulated():
+    """ModulatedNoise (py/noise.py:762-1019): intensity and frequency modes x the three modulation_dims, reference latent given or
+    the sampler's own x; (s, sn) = (9, 6) -> sigma_up via get_ancestral_step(eta=1)."""
+    cases = {}
+    shape = (2, 4, 16, 16)
+    torch.manual_seed(97)
+    x = torch.randn(shape) * 2.0 + 0.3
+    latent = torch.randn(shape) * torch.linspace(0.5, 2.0, 16)[None, None, :, None] + 0.1
+    cases["x"], cases["latent"] = x, latent
+    chain = ref.noise.CustomNoiseChain()
+    chain.add(ref.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    for mtype in ("intensity", "frequency", "none"):
+        for dims in (1, 2, 3):
+            for with_ref in (True, False):
+                item = ref.noise.ModulatedNoise(0.8, noise=chain, normalize_result=None if with_ref else False, normalize_noise=None, normalize_ref=True,
+                                                modulation_type=mtype, modulation_strength=1.5 if with_ref else -0.6, modulation_dims=dims,
+                                                ref_latent_opt=latent if with_ref else None)
+                xin = x.clone()
+                torch.manual_seed(98)
+                ns = item.make_noise_sampler(xin, 0.03, 14.6, seed=98, cpu=True, normalized=True)
+                cases[f"{mtype}_{dims}_{int(with_ref)}"] = ns(torch.tensor(9.0), torch.tensor(6.0))
+                if not with_ref and mtype == "intensity" and dims == 3:
+                    cases["x_after"] = xin  # normalize_ref acts on the sampler's x IN PLACE when no reference latent is given
+    save("modulated", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -758,6 +784,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_video()
     gen_wavelet_noise()
     gen_guided_noise()
+    gen_modulated()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

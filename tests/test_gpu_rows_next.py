@@ -360,3 +360,46 @@ def test_guided_noise_node_prepares_the_reference(api, golden):
     torch.manual_seed(96)
     out = chain.make_noise_sampler(g["x"].cuda(), 0.03, 14.6, seed=96, cpu=True, normalized=True)(torch.tensor(9.0), torch.tensor(6.0))
     close(out, g["euler_1"], rtol=2e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ ModulatedNoise
+@pytest.mark.parametrize("with_ref", [True, False])
+@pytest.mark.parametrize("dims", [1, 2, 3])
+@pytest.mark.parametrize("mtype", ["intensity", "frequency", "none"])
+def test_modulated_noise_matches_reference(api, golden, mtype, dims, with_ref):
+    """py/noise.py:762-1019 against vectors captured from the reference itself (tests/golden/make_golden.py gen_modulated)."""
+    g = golden("modulated")
+    x = g["x"].cuda()
+    item = api.noise.ModulatedNoise(0.8, noise=_gauss_chain(api), normalize_result=None if with_ref else False, normalize_noise=None, normalize_ref=True,
+                                    modulation_type=mtype, modulation_strength=1.5 if with_ref else -0.6, modulation_dims=dims,
+                                    ref_latent_opt=g["latent"] if with_ref else None)
+    torch.manual_seed(98)
+    ns = item.clone().make_noise_sampler(x, 0.03, 14.6, seed=98, cpu=True, normalized=True)
+    out = ns(torch.tensor(9.0), torch.tensor(6.0))
+    assert out.shape == x.shape and out.is_contiguous()
+    close(out, g[f"{mtype}_{dims}_{int(with_ref)}"], rtol=2e-5, atol=2e-5)
+    if not with_ref and mtype != "none":
+        close(x, g["x_after"], rtol=1e-5, atol=1e-5)  # the reference normalises the sampler's x in place
+
+
+def test_modulated_noise_full_size_properties_and_node(api):
+    """SDXL batch: intensity mode with strength 1 keeps the plain noise's L2 norm; frequency mode runs on 128 x 128 planes; the node maps
+    normalize_ref like the reference (a boolean becomes False); spectral_signum is refused."""
+    shape = (16, 4, 128, 128)
+    x = torch.randn(shape, device="cuda")
+    ref = torch.randn(shape, device="cuda") * torch.linspace(0.2, 3.0, 128, device="cuda")[None, None, :, None]
+    for mtype in ("intensity", "frequency"):
+        item = api.noise.ModulatedNoise(1.0, noise=_gauss_chain(api), normalize_result=False, normalize_noise=True, normalize_ref=False,
+                                        modulation_type=mtype, modulation_strength=1.0, modulation_dims=2, ref_latent_opt=ref)
+        out = item.make_noise_sampler(x, 0.03, 14.6, seed=1, cpu=False, normalized=True)(torch.tensor(9.0), torch.tensor(6.0))
+        sigma_up = min(6.0, (36.0 * (81.0 - 36.0) / 81.0) ** 0.5)
+        want_norm = sigma_up * (x.numel() ** 0.5)  # ||unit-variance noise * sigma_up||
+        assert abs(out.norm().item() / want_norm - 1.0) < 5e-3
+        assert torch.isfinite(out).all()
+    node = api.registry.NODE_CLASS_MAPPINGS["SonarModulatedNoise"]()
+    (chain,) = node.go(factor=1.0, sonar_custom_noise=_gauss_chain(api), modulation_type="intensity", dims=3, strength=2.0, normalize_result="default",
+                       normalize_noise="default", normalize_ref=True, ref_latent_opt={"samples": ref.cpu()})
+    assert chain.items[0].normalize_ref is False and chain.items[0].modulation_dims == 3
+    with pytest.raises(NotImplementedError):
+        api.noise.ModulatedNoise(1.0, noise=_gauss_chain(api), normalize_result=None, normalize_noise=None, normalize_ref=True,
+                                 modulation_type="spectral_signum")

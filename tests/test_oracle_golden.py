@@ -265,3 +265,20 @@ def test_onef_is_a_per_plane_filter():
     gain = (1.0 / torch.sqrt(power))[:, :17]
     got = torch.fft.irfft2(torch.fft.rfft2(x) * gain, s=(16, 32))
     close(got, want, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("with_ref", [True, False])
+@pytest.mark.parametrize("dims", [1, 2, 3])
+@pytest.mark.parametrize("mtype", ["intensity", "frequency"])
+def test_modulated_noise(golden, mtype, dims, with_ref):
+    """ModulatedNoise (py/noise.py:762-1019): intensity is the same op sequence (tight); frequency multiplies the spectrum by the real
+    boost directly instead of rebuilding it from magnitude and angle (1e-5)."""
+    g = golden("modulated")
+    torch.manual_seed(98)
+    noise = orc.scale_noise(torch.randn(g["x"].shape), 1.0, normalized=True)  # the gaussian chain item, normalised
+    ref_in = (g["latent"] if with_ref else g["x"]).clone()
+    out = orc.modulated_noise(ref_in, noise, torch.tensor(9.0), torch.tensor(6.0), modulation_type=mtype, strength=1.5 if with_ref else -0.6,
+                              modulation_dims=dims, factor=0.8, normalize_ref=True, normalize_result=with_ref)
+    close(out, g[f"{mtype}_{dims}_{int(with_ref)}"], **({} if mtype == "intensity" else dict(rtol=1e-5, atol=1e-5)))
+    if not with_ref:
+        close(ref_in, g["x_after"])
