@@ -177,6 +177,11 @@ def main():
             if n_gpus == 1:
                 # secondary workloads of the same path (not part of `value`)
                 extra = {}
+                # achievable HBM bandwidth on this box (SURVEY 8d asks for it beside the 8 TB/s spec): device-to-device copy of 1 GiB
+                big_a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device)
+                big_b = torch.empty_like(big_a)
+                extra["hbm_copy_GBps_read_plus_write"] = 2 * big_a.numel() * 4 / time_calls(lambda: big_b.copy_(big_a), 10, 3) / 1e9
+                del big_a, big_b
                 ns_p = nz.get_noise_sampler("perlin", x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
                 extra["perlin_latents_per_s"] = BATCH / time_calls(lambda: ns_p(*sig), 20, 5)
                 x64 = torch.zeros((64, C, H, W), device=device)
