@@ -475,11 +475,14 @@ __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, in
 }
 
 // One workgroup per plane, the plane's level grids staged in LDS (they are re-read ~4 H W / (h w) times each by the
-// bilinear gathers); the four waves stride over the plane's RNG tiles.  Same values as the flat kernel above.
+// bilinear gathers); the four waves stride over the plane's RNG tiles.  Same values as the flat kernel above (to rounding).
 // Requires H * W % kTileElems == 0 and elem_offset % (H * W) == 0 (whole planes, tile-aligned).
-constexpr size_t kPyramidLdsBudget = 48 * 1024;
+// XROWS (bilinear, when it fits): every level grid is first stretched along x to the full width W in LDS (h_l rows of W
+// floats), so an output needs, per level, two conflict-free 16-byte reads and two FMAs per value instead of four gathers, a
+// coordinate-table read and eleven arithmetic instructions; the level weight is folded into the y weights.
+constexpr size_t kPyramidLdsBudget = 64 * 1024;
 
-template <bool STATS>
+template <bool STATS, bool XROWS>
 __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
                                                                uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                                                                double* partials, int grid_floats) {
@@ -494,14 +497,20 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
     // bilinear source coordinates depend on (level, x) and (level, y) only: tabulated once per workgroup
     Lin* const xtab = reinterpret_cast<Lin*>(pyr_lds + grid_floats);  // [level][W]
     Lin* const ytab = xtab + lv.count * W;                            // [level][H]
+    float* const xrows = reinterpret_cast<float*>(ytab + lv.count * H);  // XROWS: [level][h_l][W]
     if (mode == 0) {
         for (int l = 0; l < lv.count; ++l) {
             const float sy = (float)lv.h[l] / (float)H, sx = (float)lv.w[l] / (float)W;
             for (int i = threadIdx.x; i < W; i += kBlock) xtab[l * W + i] = lin_coord(i, sx, lv.w[l]);
             for (int i = threadIdx.x; i < H; i += kBlock) {
                 Lin ly = lin_coord(i, sy, lv.h[l]);
-                ly.i0 *= lv.w[l];  // row offsets
-                ly.i1 *= lv.w[l];
+                const int pitch = XROWS ? W : lv.w[l];
+                ly.i0 *= pitch;  // row offsets
+                ly.i1 *= pitch;
+                if constexpr (XROWS) {
+                    ly.w0 *= lv.weight[l];
+                    ly.w1 *= lv.weight[l];
+                }
                 ytab[l * H + i] = ly;
             }
         }
@@ -526,6 +535,30 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
             off += n;
         }
         __syncthreads();
+        if constexpr (XROWS) {
+            int go = 0, ro = 0;
+            for (int l = 0; l < lv.count; ++l) {
+                const int h = lv.h[l], w = lv.w[l];
+                const float* g = pyr_lds + go;
+                const Lin* xt = xtab + l * W;
+                int yy = (int)threadIdx.x / W, xx = (int)threadIdx.x - yy * W;
+                const int sy = kBlock / W, sx = kBlock - sy * W;
+                for (int i = threadIdx.x; i < h * W; i += kBlock) {
+                    const Lin lx = xt[xx];
+                    const float* row = g + yy * w;
+                    xrows[ro + i] = __builtin_fmaf(row[lx.i1], lx.w1, row[lx.i0] * lx.w0);
+                    yy += sy;
+                    xx += sx;
+                    if (xx >= W) {
+                        xx -= W;
+                        yy += 1;
+                    }
+                }
+                go += h * w;
+                ro += h * W;
+            }
+            __syncthreads();
+        }
         float* const oplane = out + p * (int64_t)HW;
         const int64_t tile0 = (elem_offset + p * (int64_t)HW) / kTileElems;
         for (int t = wave; t < tiles_per_plane; t += kBlock / 64) {
@@ -542,6 +575,17 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
                 int lo = 0;
                 for (int l = 0; l < lv.count; ++l) {
                     const int h = lv.h[l], w = lv.w[l];
+                    if constexpr (XROWS) {
+                        const Lin ly = ytab[l * H + y];
+                        const float4 a = *reinterpret_cast<const float4*>(xrows + lo + ly.i0 + x4);
+                        const float4 b = *reinterpret_cast<const float4*>(xrows + lo + ly.i1 + x4);
+                        lo += h * W;
+                        v[0] = __builtin_fmaf(a.x, ly.w0, __builtin_fmaf(b.x, ly.w1, v[0]));
+                        v[1] = __builtin_fmaf(a.y, ly.w0, __builtin_fmaf(b.y, ly.w1, v[1]));
+                        v[2] = __builtin_fmaf(a.z, ly.w0, __builtin_fmaf(b.z, ly.w1, v[2]));
+                        v[3] = __builtin_fmaf(a.w, ly.w0, __builtin_fmaf(b.w, ly.w1, v[3]));
+                        continue;
+                    }
                     const float* plane = pyr_lds + lo;
                     lo += h * w;
                     const float wt = lv.weight[l];
@@ -590,18 +634,26 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
 // true if the plane kernel was launched
 static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t W, const PyramidLevels& lv, int mode, uint64_t seed,
                                  uint64_t stream_id, int64_t elem_offset, double* partials, hipStream_t st) {
-    size_t grid_floats = 0;
-    for (int l = 0; l < lv.count; ++l) grid_floats += (size_t)lv.h[l] * lv.w[l];
+    size_t grid_floats = 0, rows = 0;
+    for (int l = 0; l < lv.count; ++l) {
+        grid_floats += (size_t)lv.h[l] * lv.w[l];
+        rows += (size_t)lv.h[l];
+    }
     grid_floats = (grid_floats + 3) & ~(size_t)3;  // the coordinate tables that follow are 16-byte entries
     const size_t lds = grid_floats * sizeof(float) + (mode == 0 ? (size_t)lv.count * (H + W) * sizeof(Lin) : 0);
+    const size_t lds_x = lds + rows * W * sizeof(float);
     if ((H * W) % kTileElems != 0 || elem_offset % (H * W) != 0 || lds > kPyramidLdsBudget) return false;
+    const bool xrows = mode == 0 && W % 4 == 0 && lds_x <= kPyramidLdsBudget;
     const int g = (int)std::min<int64_t>(planes, kNPart);
-    if (partials)
-        hipLaunchKernelGGL((pyramid_plane_kernel<true>), dim3(g), dim3(kBlock), lds, st, out, planes, (int)H, (int)W, lv, mode, seed,
-                           stream_id, elem_offset, partials, (int)grid_floats);
-    else
-        hipLaunchKernelGGL((pyramid_plane_kernel<false>), dim3(g), dim3(kBlock), lds, st, out, planes, (int)H, (int)W, lv, mode, seed,
-                           stream_id, elem_offset, partials, (int)grid_floats);
+#define SONAR_PP(ST, XR) \
+    hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR>), dim3(g), dim3(kBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
+                       seed, stream_id, elem_offset, partials, (int)grid_floats)
+    if (partials) {
+        if (xrows) SONAR_PP(true, true); else SONAR_PP(true, false);
+    } else {
+        if (xrows) SONAR_PP(false, true); else SONAR_PP(false, false);
+    }
+#undef SONAR_PP
     return true;
 }
 
