@@ -88,13 +88,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get("SONAR_BENCH_FORCE_DIST"))  # the env knob runs the RCCL path with one rank (self-test)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1", file=sys.stderr)

@@ -147,7 +147,13 @@ def _check(rc: int, what: str) -> None:
         raise SonarHipError(f"{what} failed (code {rc}): {msg}")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # ~1 us; torch.cuda.current_stream() builds a Stream object (~10 us)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream on the current device (every kernel of this library is launched on it)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -754,7 +760,8 @@ def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tenso
     need = lib.sonar_wcfg_fused_ws_bytes(planes, H, W, levels, len(dec_lo), DWT_MODE_IDS[mode], len(rec_lo), DWT_MODE_IDS[inv_mode], elem)
     if need < 0:
         return None
-    key = (cond.device, torch.cuda.current_stream().cuda_stream)
+    stream = _stream()
+    key = (cond.device, stream)
     ws = _WCFG_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = _WCFG_WS[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=cond.device)  # reused across steps of a sampling run
@@ -766,7 +773,7 @@ def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tenso
     rc = fn(_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), planes, H, W, levels, _darr(dec_lo), _darr(dec_hi),
             len(dec_lo), DWT_MODE_IDS[mode], _darr(rec_lo), _darr(rec_hi), len(rec_lo), DWT_MODE_IDS[inv_mode],
             _darr([float(v) for v in yl_scales]), _darr(flat), BLEND_IDS[blend_mode], float(strength), int(bool(subtract_from_x)),
-            ws.data_ptr(), ws.numel(), _stream())
+            ws.data_ptr(), ws.numel(), stream)
     if rc == ERR_UNSUPPORTED:
         return None
     _check(rc, "sonar_wcfg_fused")
