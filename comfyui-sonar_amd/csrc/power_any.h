@@ -1,0 +1,433 @@
+// General-size planes for the power-noise path: any even H x W whose half-spectrum H x (W/2 + 1) (complex64) fits in LDS.
+// The fast kernels in power_fft.hip cover the power-of-two latents (SDXL 1024^2 -> 128 x 128 ...); everything else
+// (832 x 1216 px -> 104 x 152, 768^2 -> 96 x 96 ...) lands here.  Same pipeline, same semantics
+// (torch.fft.irfft2(z * filter, s=(H, W), norm="ortho"), py/nodes/powernoise.py:338-366), written for generality:
+//   * a length-N line DFT is the two-factor Cooley-Tukey split N = N1 x N2 (the host picks the divisor pair with the smallest
+//     N1 + N2; a prime N degenerates to the plain O(N^2) sum) with table twiddles e^{2 pi i j / N} built in LDS per launch;
+//     each pass gathers its outputs in registers, then barrier, then writes -> in place, one plane buffer;
+//   * rows use the half-length complex trick (W real values = W/2 complex) exactly like the fast kernel;
+//   * the kx = 0 and kx = W/2 columns are ordinary columns; c2r takes their real parts after the column transform.
+// Included by power_fft.hip (uses its RNG stream helpers).
+#pragma once
+
+namespace sonar {
+
+constexpr int kAnyThreads = 1024;        // 16 waves; the plane buffer allows one workgroup per CU anyway
+constexpr int kAnySlots = kFftThreads;   // drawing thread slots: streams are keyed by (group, slot) like the fast path
+constexpr int kAnyPer = 4;               // outputs per thread and batch held in registers across a pass's barrier
+constexpr size_t kAnyLdsLimit = 160 * 1024 - 2048;
+
+struct AnyPlan {
+    int H, W, M, S;        // M = W / 2, S = M + 1 = row stride in complex values (odd: M is even for every W = 4 q)
+    int hn1, hn2;          // H = hn1 * hn2
+    int mn1, mn2;          // M = mn1 * mn2
+};
+
+static inline void best_split(int n, int& n1, int& n2) {
+    n1 = 1;
+    n2 = n;
+    for (int a = 1; a * a <= n; ++a)
+        if (n % a == 0) {
+            n1 = a;
+            n2 = n / a;
+        }
+}
+
+// 0 = no, 1 = yes
+static inline int any_plane_ok(int64_t H, int64_t W) {
+    if (H < 2 || W < 2 || (H & 1) || (W & 1) || H > kAnySlots || W > 2 * kAnySlots) return 0;
+    const size_t elems = (size_t)H * (W / 2 + 1);
+    return elems * sizeof(c32) + (size_t)(H + W) * sizeof(c32) <= kAnyLdsLimit ? 1 : 0;
+}
+
+template <bool NEED_T>
+__device__ __forceinline__ SpectrumRng spectrum_rng_dyn(uint64_t seed, uint64_t stream_id, int64_t ggroup, int tid, int H) {
+    SpectrumRng g;
+    g.R = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 0u, (uint32_t)tid);
+    if constexpr (NEED_T) g.T = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 1u, (uint32_t)tid);
+    else g.T = Xoshiro{0, 0, 0, 1};
+    g.E = Xoshiro{0, 0, 0, 1};
+    if (tid < H) g.E = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 2u, (uint32_t)tid);
+    return g;
+}
+
+// draw_plane with run-time sizes (slots tid < kAnySlots): pair p -> ky = p / M, kx = 1 + p % M, partner H/2 rows below;
+// the kx = M slot of a row is drawn and discarded, as in the fast path
+template <bool NEED_T, typename Edge, typename Pair>
+__device__ __forceinline__ void draw_plane_dyn(SpectrumRng& g, int tid, int H, int M, Edge&& edge, Pair&& pair) {
+    if (tid < H) {
+        const uint32_t r0 = g.E.next_high();
+        const uint32_t rm = g.E.next_high();
+        const uint32_t t = g.E.next();
+        edge(r0, rm, t);
+    }
+    const int pairs = (H / 2) * M;
+    for (int p = tid; p < pairs; p += kAnySlots) {
+        const uint32_t ra = g.R.next_high();
+        const uint32_t rb = g.R.next_high();
+        const uint32_t t = NEED_T ? g.T.next() : 0u;
+        pair(p, ra, rb, t);
+    }
+}
+
+// One pass of the two-factor line DFT over `lines` lines of N = N1 * N2 complex values (element stride es, line stride ls),
+// twiddles tw[j] = e^{2 pi i j / TN} with N = TN / ts (FWD: conjugated).  In place: the lines are taken in batches of whole
+// lines (a line's outputs depend on that line only); a batch's outputs -- kAnyPer per thread -- are gathered in registers,
+// barrier, written, barrier.  Threads take consecutive LINES (conflict-free: the plane's row stride is odd).
+//   PASS 0: out[k1 N2 + n2] = w_N^{n2 k1} sum_{n1} in[n1 N2 + n2] w_N1^{n1 k1}
+//   PASS 1: out[k1 + N1 k2] = sum_{n2} in[k1 N2 + n2] w_N2^{n2 k2}
+template <int PASS, bool FWD>
+__device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw, int TN, int ts, int N1, int N2, int lines, int es, int ls,
+                                              int tid) {
+    const int N = N1 * N2;
+    const int per_batch = max(1, (kAnyThreads * kAnyPer) / N);
+#pragma unroll 1
+    for (int l0 = 0; l0 < lines; l0 += per_batch) {
+        const int nl = min(per_batch, lines - l0), total = nl * N;
+        c32 acc[kAnyPer];
+#pragma unroll
+        for (int j = 0; j < kAnyPer; ++j) {
+            const int idx = tid + j * kAnyThreads;
+            float ax = 0.0f, ay = 0.0f;
+            if (idx < total) {
+                const int o = idx / nl, line = l0 + idx - o * nl;
+                int first, stride, count, step, twi = 0;
+                if (PASS == 0) {
+                    const int k1 = o / N2, n2 = o - k1 * N2;
+                    first = n2; stride = N2; count = N1; step = N2 * k1 * ts;   // w_N1^{n1 k1} = w_N^{N2 n1 k1}
+                    twi = n2 * k1 * ts;
+                } else {
+                    const int k2 = o / N1, k1 = o - k2 * N1;
+                    first = k1 * N2; stride = 1; count = N2; step = N1 * k2 * ts;
+                }
+                int t = 0;
+                const c32* src = A + line * ls + first * es;
+                const int sstep = stride * es;
+#pragma unroll 2
+                for (int n = 0; n < count; ++n) {
+                    const c32 v = src[0];
+                    c32 w = tw[t];
+                    if (FWD) w.y = -w.y;
+                    ax = __builtin_fmaf(v.x, w.x, __builtin_fmaf(-v.y, w.y, ax));
+                    ay = __builtin_fmaf(v.x, w.y, __builtin_fmaf(v.y, w.x, ay));
+                    src += sstep;
+                    t += step;
+                    if (t >= TN) t -= TN;
+                }
+                if (PASS == 0) {
+                    c32 w = tw[twi];
+                    if (FWD) w.y = -w.y;
+                    const float bx = ax * w.x - ay * w.y, by = ax * w.y + ay * w.x;
+                    ax = bx;
+                    ay = by;
+                }
+            }
+            acc[j] = make_float2(ax, ay);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kAnyPer; ++j) {
+            const int idx = tid + j * kAnyThreads;
+            if (idx < total) {
+                const int o = idx / nl, line = l0 + idx - o * nl;
+                int dst = o;  // PASS 0: k1 N2 + n2
+                if (PASS == 1) {
+                    const int k2 = o / N1, k1 = o - k2 * N1;
+                    dst = k1 + N1 * k2;
+                }
+                A[line * ls + dst * es] = acc[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool FWD>
+__device__ __forceinline__ void line_dft(c32* A, const c32* tw, int TN, int ts, int N1, int N2, int lines, int es, int ls, int tid) {
+    line_dft_pass<0, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+    line_dft_pass<1, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+}
+
+// SRC as in power_irfft2_kernel: 0 = spectrum supplied, 1 = drawn on device, 2 = real plane in (forward, x filter, inverse)
+template <int SRC, bool STATS, bool NORM>
+__global__ void __launch_bounds__(kAnyThreads) power_irfft2_any_kernel(const float* __restrict__ z, const float* __restrict__ filter,
+                                                                       float* out, int64_t planes, AnyPlan pl, uint64_t seed,
+                                                                       uint64_t stream_id, int64_t plane_offset, int group, int split,
+                                                                       double* partials, NormArgs na) {
+    extern __shared__ __align__(16) unsigned char any_lds[];
+    __shared__ double red[2 * kAnyThreads / 64];
+    __shared__ NormDecision shd;
+    const int H = pl.H, W = pl.W, M = pl.M, S = pl.S, NC = H * S;
+    c32* const A = reinterpret_cast<c32*>(any_lds);
+    c32* const twH = A + NC;   // e^{2 pi i j / H}
+    c32* const twW = twH + H;  // e^{2 pi i j / W}
+    const int tid = threadIdx.x;
+    for (int j = tid; j < H + W; j += kAnyThreads) {
+        const int n = j < H ? H : W, i = j < H ? j : j - H;
+        double sn, cs;
+        sincospi(2.0 * (double)i / (double)n, &sn, &cs);
+        twH[j] = make_float2((float)cs, (float)sn);
+    }
+    float scale = SRC == 2 ? 1.0f / ((float)H * (float)W) : 1.0f / sqrtf((float)H * (float)W);
+    float nm = scale, nc = 0.0f;
+    if constexpr (NORM) {
+        const NormDecision dec = decide_norm<kAnyThreads>(na.partials, kNPart, na.n_total, na.thr_sd, red, &shd);
+        const float g = (dec.do_div ? 1.0f / dec.stdv : 1.0f) * na.factor;
+        nm = scale * g;
+        nc = dec.do_sub ? dec.mean * g : 0.0f;
+    }
+    double s = 0.0, q = 0.0;
+    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+        const GroupWalk gw(unit, group, split);
+        SpectrumRng rng;
+        if constexpr (SRC == 1) {
+            if (tid < kAnySlots) {
+                rng = spectrum_rng_dyn<true>(seed, stream_id, plane_offset / group + gw.grp, tid, H);
+                for (int i = 0; i < gw.first; ++i)
+                    draw_plane_dyn<true>(rng, tid, H, M, [](uint32_t, uint32_t, uint32_t) {}, [](int, uint32_t, uint32_t, uint32_t) {});
+            }
+        }
+        for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
+            const int64_t plane = gw.grp * group + gp;
+            __syncthreads();  // previous plane fully consumed (and the twiddle tables visible)
+            if constexpr (SRC == 1) {
+                if (tid < kAnySlots)
+                    draw_plane_dyn<true>(
+                        rng, tid, H, M,
+                        [&](uint32_t r0, uint32_t rm, uint32_t t) {
+                            A[tid * S] = drawn_elem(r0, t & 0xFFFFu, filter[tid * S]);
+                            A[tid * S + M] = drawn_elem(rm, t >> 16, filter[tid * S + M]);
+                        },
+                        [&](int p, uint32_t ra, uint32_t rb, uint32_t t) {
+                            const int ky = p / M, kx = 1 + p - ky * M;
+                            if (kx < M) {
+                                const int a = ky * S + kx, b = a + (H / 2) * S;
+                                A[a] = drawn_elem(ra, t & 0xFFFFu, filter[a]);
+                                A[b] = drawn_elem(rb, t >> 16, filter[b]);
+                            }
+                        });
+            } else if constexpr (SRC == 0) {
+                const c32* zp = reinterpret_cast<const c32*>(z) + plane * NC;
+                for (int j = tid; j < NC; j += kAnyThreads) {
+                    const c32 v = zp[j];
+                    const float f = filter[j];
+                    A[j] = make_float2(v.x * f, v.y * f);
+                }
+            } else {
+                // ---- forward r2c: rows as W/2 complex values, forward DFT, split into the half-spectrum, forward columns, x filter
+                const float* xin = z + plane * (int64_t)H * W;
+                for (int j = tid; j < H * M; j += kAnyThreads) {
+                    const int r = j / M, m = j - r * M;
+                    A[r * S + m] = *reinterpret_cast<const float2*>(xin + (int64_t)r * W + 2 * m);
+                }
+                __syncthreads();
+                line_dft<true>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, tid);
+                // X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i, w = e^{-2 pi i / W}
+                for (int j = tid; j < H * (M / 2 + 1); j += kAnyThreads) {
+                    const int r = j / (M / 2 + 1), k = j - r * (M / 2 + 1);
+                    c32* row = A + r * S;
+                    if (k == 0) {
+                        const c32 c0 = row[0];
+                        row[0] = make_float2(c0.x + c0.y, 0.0f);
+                        row[M] = make_float2(c0.x - c0.y, 0.0f);
+                    } else {
+                        const int kk = M - k;
+                        const c32 a = row[k], b = row[kk];
+                        const c32 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+                        const c32 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
+                        const c32 w = twW[k];  // conj -> e^{-2 pi i k / W}
+                        const c32 t = make_float2(o.x * w.x + o.y * w.y, o.y * w.x - o.x * w.y);
+                        row[k] = make_float2(e.x + t.x, e.y + t.y);
+                        if (kk != k) row[kk] = make_float2(e.x - t.x, -(e.y - t.y));
+                    }
+                }
+                __syncthreads();
+                line_dft<true>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, tid);
+                for (int j = tid; j < NC; j += kAnyThreads) {
+                    const float f = filter[j];
+                    c32 v = A[j];
+                    v.x *= f;
+                    v.y *= f;
+                    A[j] = v;
+                }
+            }
+            __syncthreads();
+            // ---- inverse columns: every one of the W/2 + 1 columns, length H
+            line_dft<false>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, tid);
+            // ---- c2r pre-twiddle: G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k; X[0], X[M] contribute their real parts
+            for (int j = tid; j < H * (M / 2 + 1); j += kAnyThreads) {
+                const int r = j / (M / 2 + 1), k = j - r * (M / 2 + 1);
+                c32* row = A + r * S;
+                if (k == 0) {
+                    const float x0 = row[0].x, xm = row[M].x;
+                    row[0] = make_float2(x0 + xm, x0 - xm);
+                } else {
+                    const int kk = M - k;
+                    const c32 xa = row[k], xb = row[kk];
+                    {
+                        const c32 e = make_float2(xa.x + xb.x, xa.y - xb.y), d = make_float2(xa.x - xb.x, xa.y + xb.y);
+                        const c32 w = twW[k];
+                        const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+                        row[k] = make_float2(e.x - o.y, e.y + o.x);
+                    }
+                    if (kk != k) {
+                        const c32 e = make_float2(xb.x + xa.x, xb.y - xa.y), d = make_float2(xb.x - xa.x, xb.y + xa.y);
+                        const c32 w = twW[kk];
+                        const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+                        row[kk] = make_float2(e.x - o.y, e.y + o.x);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- rows: length-M complex inverse DFT; value m of a row is (x[2m], x[2m+1])
+            line_dft<false>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, tid);
+            float* const oplane = out + plane * (int64_t)H * W;
+            float ps = 0.0f, pq = 0.0f;
+            for (int j = tid; j < H * M; j += kAnyThreads) {
+                const int r = j / M, m = j - r * M;
+                const c32 g = A[r * S + m];
+                float a, b;
+                if constexpr (NORM) {
+                    a = __builtin_fmaf(g.x, nm, -nc);
+                    b = __builtin_fmaf(g.y, nm, -nc);
+                } else {
+                    a = g.x * scale;
+                    b = g.y * scale;
+                }
+                *reinterpret_cast<float2*>(oplane + (int64_t)r * W + 2 * m) = make_float2(a, b);
+                if constexpr (STATS) {
+                    ps += a + b;
+                    pq = __builtin_fmaf(a, a, __builtin_fmaf(b, b, pq));
+                }
+            }
+            if constexpr (STATS) {
+                s += (double)ps;
+                q += (double)pq;
+            }
+        }
+    }
+    if constexpr (STATS) write_partial<kAnyThreads>(s, q, partials, red);
+}
+
+// Parseval statistics of the drawn, filtered spectrum (see power_stats_kernel), run-time sizes; kAnySlots threads
+__global__ void __launch_bounds__(kFftThreads) power_stats_any_kernel(const float* __restrict__ filter, int64_t planes, AnyPlan pl,
+                                                                      uint64_t seed, uint64_t stream_id, int64_t plane_offset, int group,
+                                                                      int split, double* partials) {
+    extern __shared__ __align__(16) unsigned char any_lds[];
+    __shared__ double red[2 * kFftThreads / 64];
+    const int H = pl.H, M = pl.M, S = pl.S;
+    c32* const EDGE = reinterpret_cast<c32*>(any_lds);  // [parity][column 0 | column M][ky]
+    const int tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    int par = 0;
+    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+        const GroupWalk gw(unit, group, split);
+        SpectrumRng rng = spectrum_rng_dyn<false>(seed, stream_id, plane_offset / group + gw.grp, tid, H);
+        for (int i = 0; i < gw.first; ++i)
+            draw_plane_dyn<false>(rng, tid, H, M, [](uint32_t, uint32_t, uint32_t) {}, [](int, uint32_t, uint32_t, uint32_t) {});
+        for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
+            float acc = 0.0f;
+            c32* const e0 = EDGE + (par * 2 + 0) * H;
+            c32* const em = EDGE + (par * 2 + 1) * H;
+            draw_plane_dyn<false>(
+                rng, tid, H, M,
+                [&](uint32_t r0, uint32_t rm, uint32_t t) {
+                    e0[tid] = drawn_elem(r0, t & 0xFFFFu, filter[tid * S]);
+                    em[tid] = drawn_elem(rm, t >> 16, filter[tid * S + M]);
+                },
+                [&](int p, uint32_t ra, uint32_t rb, uint32_t) {
+                    const int ky = p / M, kx = 1 + p - ky * M;
+                    if (kx < M) {
+                        const float fa = filter[ky * S + kx], fb = filter[(ky + H / 2) * S + kx];
+                        acc = __builtin_fmaf(fa * fa, neg_ln_u(ra), acc);
+                        acc = __builtin_fmaf(fb * fb, neg_ln_u(rb), acc);
+                    }
+                });
+            q += 2.0 * (double)acc;
+            __syncthreads();
+            float edge = 0.0f;
+            for (int ky = tid; ky < H; ky += kFftThreads) {
+                const int kn = ky == 0 ? 0 : H - ky;
+                const c32 a = e0[ky], an = e0[kn], b = em[ky], bn = em[kn];
+                const float ar = 0.5f * (a.x + an.x), ai = 0.5f * (a.y - an.y), br = 0.5f * (b.x + bn.x), bi = 0.5f * (b.y - bn.y);
+                edge += (ar * ar + ai * ai) + (br * br + bi * bi);
+                if (ky == 0) s += (double)(sqrtf((float)H * (float)pl.W) * ar);
+            }
+            q += (double)edge;
+            par ^= 1;
+        }
+    }
+    write_partial<kFftThreads>(s, q, partials, red);
+}
+
+__global__ void __launch_bounds__(kFftThreads) power_spectrum_any_kernel(float* zout, int64_t planes, AnyPlan pl, uint64_t seed,
+                                                                         uint64_t stream_id, int64_t plane_offset, int group, int split) {
+    const int H = pl.H, M = pl.M, S = pl.S, NC = H * S;
+    const int tid = threadIdx.x;
+    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+        const GroupWalk gw(unit, group, split);
+        SpectrumRng rng = spectrum_rng_dyn<true>(seed, stream_id, plane_offset / group + gw.grp, tid, H);
+        for (int i = 0; i < gw.first; ++i)
+            draw_plane_dyn<true>(rng, tid, H, M, [](uint32_t, uint32_t, uint32_t) {}, [](int, uint32_t, uint32_t, uint32_t) {});
+        for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
+            c32* zp = reinterpret_cast<c32*>(zout) + (gw.grp * group + gp) * NC;
+            draw_plane_dyn<true>(
+                rng, tid, H, M,
+                [&](uint32_t r0, uint32_t rm, uint32_t t) {
+                    zp[tid * S] = unit_complex_normal(r0, t & 0xFFFFu);
+                    zp[tid * S + M] = unit_complex_normal(rm, t >> 16);
+                },
+                [&](int p, uint32_t ra, uint32_t rb, uint32_t t) {
+                    const int ky = p / M, kx = 1 + p - ky * M;
+                    if (kx < M) {
+                        zp[ky * S + kx] = unit_complex_normal(ra, t & 0xFFFFu);
+                        zp[(ky + H / 2) * S + kx] = unit_complex_normal(rb, t >> 16);
+                    }
+                });
+        }
+    }
+}
+
+// what: as launch_power
+static int launch_power_any(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
+                            uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st) {
+    AnyPlan pl;
+    pl.H = (int)H;
+    pl.W = (int)W;
+    pl.M = (int)W / 2;
+    pl.S = pl.M + 1;
+    best_split(pl.H, pl.hn1, pl.hn2);
+    best_split(pl.M, pl.mn1, pl.mn2);
+    const size_t lds = ((size_t)H * pl.S + H + W) * sizeof(c32);
+    const size_t lds_stats = (size_t)4 * H * sizeof(c32);
+    const int split = group > 1 && planes / group < 256 ? 1 : 0;
+    const int64_t units = split ? planes : planes / group;
+    const int g = (int)std::min<int64_t>(std::min<int64_t>(units, 256), kNPart);  // one resident workgroup per CU
+#define SONAR_PA(G, ST, NM, PART)                                                                                                          \
+    do {                                                                                                                                   \
+        auto kern = power_irfft2_any_kernel<G, ST, NM>;                                                                                    \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAnyLdsLimit) !=     \
+            hipSuccess)                                                                                                                    \
+            (void)hipGetLastError();                                                                                                       \
+        hipLaunchKernelGGL(kern, dim3(g), dim3(kAnyThreads), lds, st, z, filter, out, planes, pl, seed, stream_id, plane_offset, group,    \
+                           split, PART, na);                                                                                               \
+    } while (0)
+    if (what == 3) {
+        if (partials) SONAR_PA(2, true, false, partials); else SONAR_PA(2, false, false, partials);
+    } else if (what == 2) {
+        hipLaunchKernelGGL(power_spectrum_any_kernel, dim3((int)std::min<int64_t>(units, 2048)), dim3(kFftThreads), 0, st, out, planes, pl, seed,
+                           stream_id, plane_offset, group, split);
+    } else if (what == 1) {
+        hipLaunchKernelGGL(power_stats_any_kernel, dim3((int)std::min<int64_t>(units, kNPart)), dim3(kFftThreads), lds_stats, st, filter, planes,
+                           pl, seed, stream_id, plane_offset, group, split, partials);
+        SONAR_PA(1, false, true, nullptr);
+    } else if (z == nullptr) {
+        if (partials) SONAR_PA(1, true, false, partials); else SONAR_PA(1, false, false, partials);
+    } else {
+        if (partials) SONAR_PA(0, true, false, partials); else SONAR_PA(0, false, false, partials);
+    }
+#undef SONAR_PA
+    return check_launch("sonar_power_* (general-size plane)");
+}
+
+}  // namespace sonar

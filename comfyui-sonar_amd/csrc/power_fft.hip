@@ -826,6 +826,8 @@ __global__ void __launch_bounds__(kBlock) channel_mix_kernel(const float* __rest
 
 }  // namespace sonar
 
+#include "power_any.h"
+
 using namespace sonar;
 
 static int power_dispatch(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,
@@ -851,8 +853,18 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
     SONAR_CASE(256, 64);
     SONAR_CASE(64, 256);
 #undef SONAR_CASE
-    set_error("sonar_power_*: unsupported plane %lld x %lld (powers of two, 16..256, LDS-resident)", (long long)H, (long long)W);
+    if (any_plane_ok(H, W)) return launch_power_any(what, z, filter, out, planes, H, W, seed, stream_id, plane_offset, group, partials, na, st);
+    set_error("sonar_power_*: unsupported plane %lld x %lld (even sizes whose half-spectrum fits in LDS: H <= 512, W <= 1024, about 19k complex values)",
+              (long long)H, (long long)W);
     return SONAR_ERR_UNSUPPORTED;
+}
+
+extern "C" int sonar_power_plane_kind(int64_t H, int64_t W) {
+    static const int fast[][2] = {{128, 128}, {64, 64}, {32, 32}, {16, 16}, {256, 128}, {128, 256}, {128, 64}, {64, 128}, {64, 32}, {32, 64},
+                                  {256, 64}, {64, 256}};
+    for (const auto& f : fast)
+        if (H == f[0] && W == f[1]) return 1;
+    return any_plane_ok(H, W) ? 2 : 0;
 }
 
 extern "C" int sonar_power_irfft2_f32(const float* z, const float* filter, float* out, int64_t planes, int64_t H,

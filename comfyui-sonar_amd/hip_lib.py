@@ -103,6 +103,7 @@ SIGNATURES = {
     "sonar_dwt2_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f32": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f64": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
+    "sonar_power_plane_kind": (_I, [_I64, _I64]),
     "sonar_std_mid_f32": (_I, [_P, _I64, _I64, _I64, _P, _P]),
     "sonar_bcast_gain_f32": (_I, [_P, _P, _I64, _I64, _I64, _I, _F, _F, _P, _P, _P]),
     "sonar_ratio_mix_f32": (_I, [_P, _F, _P, _F, _P, _D, _P, _P, _I64, _P]),
@@ -609,7 +610,8 @@ def power_spectrum(shape, device, *, seed: int, stream_id: int, plane_offset: in
 
 
 def power_supported(H: int, W: int) -> bool:
-    return (H, W) in {(128, 128), (64, 64), (32, 32), (16, 16), (256, 128), (128, 256), (128, 64), (64, 128), (64, 32), (32, 64), (256, 64), (64, 256)}
+    """True when the power-noise kernels take an H x W plane (fixed-size fast kernels or the general-size ones)."""
+    return int(load().sonar_power_plane_kind(int(H), int(W))) != 0
 
 
 def channel_mix(x: torch.Tensor, mixer: torch.Tensor, partials=None) -> torch.Tensor:

@@ -220,6 +220,10 @@ int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, in
                             float factor, float threshold_std_devs, double* partials, void* stream);
 
 /* ---------------------------------------------------------------- power-law rFFT noise (row PW) */
+/* Which kernel family serves an H x W plane of the power-noise path: 1 = the fixed-size LDS FFT kernels (powers of two, 16..256),
+ * 2 = the general-size kernels (any even H <= 512, even W <= 1024 with H*(W/2+1) + H + W <= 20224 complex values: two-factor table-twiddle DFTs in LDS;
+ * e.g. 104 x 152 for 832 x 1216 px), 0 = unsupported (the sonar_power_* / sonar_spectral_filter_f32 calls return -2). */
+int sonar_power_plane_kind(int64_t H, int64_t W);
 /* py/nodes/powernoise.py:366-377: out = irfft2(z * filter, s=(H,W), norm="ortho").
  *   z      [planes][H][W/2+1] complex64 (interleaved re,im) or NULL -> drawn on device: complex normal
  *          (a+ib)*sqrt(1/2); plane p of this call is global plane plane_offset + p of the logical batch.

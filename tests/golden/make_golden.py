@@ -216,6 +216,8 @@ def gen_power_noise():
         ("c", (2, 4, 64, 64), 2, {"alpha": 2.0, "common_mode": 0.25}, True),
         ("d", (3, 4, 32, 64), 3, {"alpha": 1.0, "min_freq": 0.1, "max_freq": 0.4}, False),
         ("e", (1, 2, 16, 16), 4, {"alpha": 0.0, "mix": 0.5}, True),
+        ("np2", (2, 4, 40, 56), 5, {"alpha": 1.0}, True),                       # not powers of two (general-size kernels)
+        ("np2_rot", (1, 4, 52, 76), 6, {"alpha": 1.5, "rotate": 20.0, "stretch": 1.5, "common_mode": 0.1}, True),  # quarter-size 832 x 1216 px
     ):
         item = ref_power_item(**kw)
         x = torch.zeros(shape)

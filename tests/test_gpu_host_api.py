@@ -89,6 +89,8 @@ POWER_KW = {
     "c": {"alpha": 2.0, "common_mode": 0.25},
     "d": {"alpha": 1.0, "min_freq": 0.1, "max_freq": 0.4},
     "e": {"alpha": 0.0, "mix": 0.5},
+    "np2": {"alpha": 1.0},  # 40 x 56 and 52 x 76 planes: the general-size kernels
+    "np2_rot": {"alpha": 1.5, "rotate": 20.0, "stretch": 1.5, "common_mode": 0.1},
 }
 
 

@@ -321,7 +321,7 @@ def test_pyramid_generate_is_sum_of_its_levels(hl, shape, mode):
 
 
 # ------------------------------------------------------------------------------------------------ power-law rFFT noise
-@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e"])
+@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e", "np2", "np2_rot"])
 def test_power_noise_replay_golden(hl, golden, tag):
     g = golden("power_noise")
     z = torch.view_as_complex(g[f"{tag}_z"].contiguous())
@@ -487,9 +487,75 @@ def test_perlin_and_pyramid_fused_normalisation(hl, factor):
     close(one, two, rtol=1e-5, atol=1e-6)
 
 
+GENERAL_PLANES = [(104, 152), (152, 104), (96, 96), (72, 88), (90, 50), (34, 38), (20, 12), (2, 4), (168, 96), (128, 160)]
+
+
+@pytest.mark.parametrize("hw", GENERAL_PLANES)
+def test_power_irfft2_general_size_planes(hl, hw):
+    """Latents that are not powers of two (832 x 1216 px -> 104 x 152 ...): the general-size kernels (two-factor table-twiddle DFTs in
+    LDS; 34 x 38 has the prime factors 17 and 19) against torch.fft on the host -- replay, forward + filter + inverse, unit filter."""
+    torch.manual_seed(23)
+    h, w = hw
+    assert hl.load().sonar_power_plane_kind(h, w) == 2
+    z = torch.randn(3, 2, h, w // 2 + 1, dtype=torch.complex64)
+    filt = torch.rand(h, w // 2 + 1) + 0.5
+    want = torch.fft.irfft2(z * filt, s=(h, w), norm="ortho")
+    part = hl.new_partials("cuda")
+    got = hl.power_irfft2(dev(z), dev(filt), (3, 2, h, w), partials=part)
+    close(got, want, rtol=0, atol=FFT_ATOL)
+    tot = hl.stats_finalize(part, got.numel()).cpu()
+    assert abs(tot[1].item() - (got.double() ** 2).sum().item()) < 1e-5 * tot[1].item() + 1e-9
+    x = torch.randn(3, 2, h, w)
+    close(hl.spectral_filter(dev(x), dev(filt)), orc.spectral_filter(x, filt), rtol=0, atol=FFT_ATOL)
+    close(hl.spectral_filter(dev(x), dev(torch.ones(h, w // 2 + 1))), x, rtol=0, atol=FFT_ATOL)
+
+
+@pytest.mark.parametrize("hw", [(104, 152), (96, 96), (34, 38), (90, 50)])
+def test_power_generate_general_size_planes(hl, hw):
+    """Generate mode on general-size planes: equals the replay of its own dumped spectrum, unit complex normals, shard invariant,
+    fused Parseval normalisation == generate + scale_noise."""
+    h, w = hw
+    shape = (5, 4, h, w)
+    filt = dev(torch.rand(h, w // 2 + 1) + 0.25)
+    z = hl.power_spectrum(shape, "cuda", seed=77, stream_id=9, plane_offset=12)
+    assert abs(z.real.std().item() - math.sqrt(0.5)) < 6e-3 and abs(z.imag.mean().item()) < 1e-2
+    assert abs((z.abs() ** 2).mean().item() - 1.0) < 1.5e-2
+    p1 = hl.new_partials("cuda")
+    got = hl.power_irfft2(None, filt, shape, seed=77, stream_id=9, plane_offset=12, partials=p1)
+    assert torch.equal(got, hl.power_irfft2(z, filt, shape))
+    close(got, torch.fft.irfft2(z.cpu() * filt.cpu(), s=(h, w), norm="ortho"), rtol=0, atol=FFT_ATOL)
+    a = hl.power_spectrum((2, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=12)
+    b = hl.power_spectrum((3, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=20)
+    assert torch.equal(torch.cat((a, b)), z)
+    big = hl.power_spectrum((300, 4, h, w), "cuda", seed=9, stream_id=1) if h * w < 5000 else None  # whole-group units vs per-plane units
+    if big is not None:
+        assert torch.equal(hl.power_spectrum((2, 4, h, w), "cuda", seed=9, stream_id=1), big[:2])
+    for factor in (1.0, 0.6):
+        part = hl.new_partials("cuda")
+        two_pass = hl.power_irfft2(None, filt, shape, seed=5, stream_id=2, plane_offset=8, partials=part)
+        hl.scale_noise_(two_pass, factor, True, part)
+        fused = hl.power_noise(filt, shape, seed=5, stream_id=2, plane_offset=8, factor=factor)
+        close(fused, two_pass, rtol=2e-5, atol=2e-5)
+        assert abs(fused.std().item() - factor) < 3e-4
+
+
+def test_power_general_size_full_batch(hl):
+    """512 SDXL-portrait latents (104 x 152): normalised generation has unit variance, zero mean, flat-filter output is white."""
+    shape = (512, 4, 104, 152)
+    filt = dev(torch.ones(104, 77))
+    out = hl.power_noise(filt, shape, seed=3, stream_id=0, plane_offset=0, factor=1.0)
+    assert abs(out.std().item() - 1.0) < 1e-4 and abs(out.mean().item()) < 1e-3
+    row_corr = (out[:, :, :, 1:] * out[:, :, :, :-1]).mean().item()
+    col_corr = (out[:, :, 1:, :] * out[:, :, :-1, :]).mean().item()
+    assert abs(row_corr) < 2e-3 and abs(col_corr) < 2e-3
+
+
 def test_power_unsupported_shape_raises(hl):
+    assert hl.load().sonar_power_plane_kind(96, 161) == 0 and hl.load().sonar_power_plane_kind(256, 256) == 0
     with pytest.raises(hl.SonarHipError):
-        hl.power_irfft2(None, dev(torch.ones(96, 81)), (1, 4, 96, 160))
+        hl.power_irfft2(None, dev(torch.ones(95, 81)), (1, 4, 95, 160))  # odd height
+    with pytest.raises(hl.SonarHipError):
+        hl.power_irfft2(None, dev(torch.ones(256, 129)), (1, 4, 256, 256))  # half-spectrum larger than LDS
 
 
 def test_channel_mix(hl, golden):
@@ -516,11 +582,11 @@ def test_c_abi_error_codes_and_messages(hl):
     x = torch.full((64,), 7.0, device="cuda")
     assert lib.sonar_stats_f32(None, 64, None, st) == hl.ERR_ARG
     assert b"sonar_stats_f32" in lib.sonar_last_error()
-    filt = torch.ones(24 * 13, device="cuda")
-    out = torch.full((2, 24, 24), 7.0, device="cuda")
+    filt = torch.ones(25 * 13, device="cuda")
+    out = torch.full((2, 25, 24), 7.0, device="cuda")
     part = hl.new_partials("cuda")
-    rc = lib.sonar_power_irfft2_f32(None, filt.data_ptr(), out.data_ptr(), 2, 24, 24, 1, 0, 0, 1, part.data_ptr(), st)
-    assert rc == hl.ERR_UNSUPPORTED and b"unsupported plane 24 x 24" in lib.sonar_last_error()
+    rc = lib.sonar_power_irfft2_f32(None, filt.data_ptr(), out.data_ptr(), 2, 25, 24, 1, 0, 0, 1, part.data_ptr(), st)  # odd height
+    assert rc == hl.ERR_UNSUPPORTED and b"unsupported plane 25 x 24" in lib.sonar_last_error()
     rc = lib.sonar_power_irfft2_f32(None, filt.data_ptr(), out.data_ptr(), 6, 32, 32, 1, 0, 2, 4, part.data_ptr(), st)
     assert rc == hl.ERR_ARG and b"multiples of the RNG group" in lib.sonar_last_error()
     assert lib.sonar_dwt2_ws_bytes(1, 8, 8, 8, 9, 4, 0) == -1  # mode out of range
@@ -528,7 +594,7 @@ def test_c_abi_error_codes_and_messages(hl):
     torch.cuda.synchronize()
     assert torch.all(out == 7.0) and torch.all(x == 7.0)
     with pytest.raises(hl.SonarHipError, match="code -2"):
-        hl.power_irfft2(None, filt, (2, 1, 24, 24))
+        hl.power_irfft2(None, filt, (2, 1, 25, 24))
     with pytest.raises(hl.SonarHipError):
         hl.stats(torch.zeros(8))  # host tensor
 
