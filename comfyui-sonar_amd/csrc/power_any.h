@@ -150,7 +150,7 @@ __device__ __forceinline__ void line_dft(c32* A, const c32* tw, int TN, int ts, 
 
 // SRC as in power_irfft2_kernel: 0 = spectrum supplied, 1 = drawn on device, 2 = real plane in (forward, x filter, inverse)
 template <int SRC, bool STATS, bool NORM>
-__global__ void __launch_bounds__(kAnyThreads) power_irfft2_any_kernel(const float* __restrict__ z, const float* __restrict__ filter,
+__global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const float* __restrict__ z, const float* __restrict__ filter,
                                                                        float* out, int64_t planes, AnyPlan pl, uint64_t seed,
                                                                        uint64_t stream_id, int64_t plane_offset, int group, int split,
                                                                        double* partials, NormArgs na) {
@@ -400,9 +400,11 @@ static int launch_power_any(int what, const float* z, const float* filter, float
     best_split(pl.M, pl.mn1, pl.mn2);
     const size_t lds = ((size_t)H * pl.S + H + W) * sizeof(c32);
     const size_t lds_stats = (size_t)4 * H * sizeof(c32);
-    const int split = group > 1 && planes / group < 256 ? 1 : 0;
+    const int split = group > 1 && planes / group < 512 ? 1 : 0;
     const int64_t units = split ? planes : planes / group;
-    const int g = (int)std::min<int64_t>(std::min<int64_t>(units, 256), kNPart);  // one resident workgroup per CU
+    // resident workgroups: two per CU when two plane buffers fit (the kernel is compiled for <= 64 VGPRs: 2 x 16 waves per CU)
+    const int per_cu = 2 * (lds + 1024) <= 160 * 1024 ? 2 : 1;
+    const int g = (int)std::min<int64_t>(std::min<int64_t>(units, 256 * per_cu), kNPart);
 #define SONAR_PA(G, ST, NM, PART)                                                                                                          \
     do {                                                                                                                                   \
         auto kern = power_irfft2_any_kernel<G, ST, NM>;                                                                                    \
