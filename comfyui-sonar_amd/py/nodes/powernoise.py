@@ -168,8 +168,8 @@ class PowerNoiseItem(CustomNoiseItemBase):
         """``noise_sampler`` returns a complex64 half-spectrum (replay) or None (draw on device)."""
         shape = tuple(x.shape)
         h, w = shape[-2:]
-        if x.ndim != 4:
-            raise hip_lib.SonarHipError("power noise: 4-D latents only")
+        if x.ndim < 4:
+            raise hip_lib.SonarHipError("power noise: [B, C, ..., H, W] latents (4 or more dimensions)")
         if not hip_lib.power_supported(h, w):
             raise _device_irfft2_fallback_error(h, w)
         device = x.device
@@ -177,7 +177,7 @@ class PowerNoiseItem(CustomNoiseItemBase):
         mixer = ChannelMixer(shape[1], self.common_mode, self.channel_correlation)
         identity = mixer.is_identity
         mixer.to(device)
-        planes_per_latent = shape[1]
+        planes_per_latent = math.prod(shape[1:-2])  # 5-D (video) latents: every [H, W] slice is a plane, as in the reference's irfft2
 
         def sampler(sigma, sigma_next):
             z = noise_sampler(sigma, sigma_next)

@@ -532,3 +532,36 @@ def test_cfg5_generate_mode_with_brownian_on_flux_shape(api):
     out = S.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas, {"seed": 3}, None, True, None,
                                   dict(momentum=0.9, momentum_hist=0.7, direction=1.0), 0.9, 1.05, ns)
     assert out.shape == x0.shape and bool(torch.isfinite(out).all())
+
+
+def test_power_noise_item_on_video_latents(api):
+    """5-D [B, C, T, H, W] latents: the reference's irfft2 / channel mixer act on every [H, W] slice (py/nodes/powernoise.py:366-377)."""
+    from oracle import sonar_oracle as orc
+
+    shape = (2, 4, 3, 32, 48)
+    x = torch.zeros(shape, device="cuda")
+    for kw in ({}, {"common_mode": 0.25}):
+        item = power_item(api, **kw)
+        torch.manual_seed(21)
+        out = item.make_noise_sampler(x, None, None, seed=None, cpu=True, normalized=True)(None, None)
+        torch.manual_seed(21)
+        z = orc.draw_power(shape)
+        filt = item.make_filter(shape)
+        noise = torch.fft.irfft2(z * filt, s=shape[-2:], norm="ortho")
+        mixer = orc.channel_mixer(4, kw.get("common_mode", 0.0), torch.ones(6))
+        if mixer is not None and not torch.equal(mixer, torch.eye(4)):
+            noise = (mixer @ noise.swapaxes(0, 1).reshape(4, -1)).reshape(4, 2, *shape[2:]).swapaxes(1, 0)
+        close(out, orc.scale_noise(noise, 1.0, normalized=True), rtol=0, atol=4e-5)
+    # generate mode: two shards of the batch reproduce the whole (plane offsets count C * T planes per latent)
+    ng = api.noise_generation
+    item = power_item(api)
+
+    def gen(xs, offset):
+        torch.manual_seed(33)
+        ng.DeviceRNG._seed, ng.DeviceRNG._next = None, 0  # every "rank" starts its stream counter at 0
+        with ng.shard_offset(offset):
+            return item.make_noise_sampler(xs, None, None, seed=None, cpu=False, normalized=False)(None, None)
+
+    whole = gen(x, 0)
+    assert torch.equal(gen(x[:1], 0), whole[:1]) and torch.equal(gen(x[1:], 1), whole[1:])
+    assert abs(whole.std().item() - 0.9) < 0.1
