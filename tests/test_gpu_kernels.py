@@ -487,7 +487,7 @@ def test_perlin_and_pyramid_fused_normalisation(hl, factor):
     close(one, two, rtol=1e-5, atol=1e-6)
 
 
-GENERAL_PLANES = [(104, 152), (152, 104), (96, 96), (72, 88), (90, 50), (34, 38), (20, 12), (2, 4), (168, 96), (128, 160)]
+GENERAL_PLANES = [(104, 152), (152, 104), (96, 96), (72, 88), (90, 50), (34, 38), (20, 12), (2, 4), (168, 96), (128, 160), (192, 192), (512, 64), (26, 1024)]
 
 
 @pytest.mark.parametrize("hw", GENERAL_PLANES)
