@@ -71,71 +71,82 @@ __device__ __forceinline__ void draw_plane_dyn(SpectrumRng& g, int tid, int H, i
 }
 
 // One pass of the two-factor line DFT over `lines` lines of N = N1 * N2 complex values (element stride es, line stride ls),
-// twiddles tw[j] = e^{2 pi i j / TN} with N = TN / ts (FWD: conjugated).  In place: the lines are taken in batches of whole
-// lines (a line's outputs depend on that line only); a batch's outputs -- kAnyPer per thread -- are gathered in registers,
-// barrier, written, barrier.  Threads take consecutive LINES (conflict-free: the plane's row stride is odd).
-//   PASS 0: out[k1 N2 + n2] = w_N^{n2 k1} sum_{n1} in[n1 N2 + n2] w_N1^{n1 k1}
-//   PASS 1: out[k1 + N1 k2] = sum_{n2} in[k1 N2 + n2] w_N2^{n2 k2}
+// twiddles tw[j] = e^{2 pi i j / TN} with N = TN / ts (FWD: conjugated).
+//   PASS 0: out[k1 N2 + n2] = w_N^{n2 k1} sum_{n1} in[n1 N2 + n2] w_N1^{n1 k1}      (K = N1 terms, G = N2 sums per index)
+//   PASS 1: out[k1 + N1 k2] = sum_{n2} in[k1 N2 + n2] w_N2^{n2 k2}                  (K = N2 terms, G = N1)
+// A work item is the output PAIR (k, K - k) of one sum family: their twiddles are conjugates, so the four real products
+// v.x w.x, v.y w.y, v.x w.y, v.y w.x -- four FMAs per term -- serve both (k = 0 and k = K/2 are single outputs).
+// In place: lines are taken in batches of whole lines (a line's outputs depend on that line only); a batch's items -- kAnyPer
+// per thread -- are gathered in registers, barrier, written, barrier.  Threads take consecutive LINES (conflict-free: odd row
+// stride).
 template <int PASS, bool FWD>
 __device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw, int TN, int ts, int N1, int N2, int lines, int es, int ls,
                                               int tid) {
-    const int N = N1 * N2;
-    const int per_batch = max(1, (kAnyThreads * kAnyPer) / N);
+    const int K = PASS == 0 ? N1 : N2, G = PASS == 0 ? N2 : N1, HK = K / 2 + 1;
+    const int per_line = G * HK;
+    const int per_batch = max(1, (kAnyThreads * kAnyPer) / per_line);
+    const int unit = (PASS == 0 ? N2 : N1) * ts;  // twiddle step of k = 1: w_K = w_N^{N / K}
 #pragma unroll 1
     for (int l0 = 0; l0 < lines; l0 += per_batch) {
-        const int nl = min(per_batch, lines - l0), total = nl * N;
-        c32 acc[kAnyPer];
+        const int nl = min(per_batch, lines - l0), total = nl * per_line;
+        c32 lo[kAnyPer], hi[kAnyPer];
 #pragma unroll
         for (int j = 0; j < kAnyPer; ++j) {
             const int idx = tid + j * kAnyThreads;
-            float ax = 0.0f, ay = 0.0f;
+            float p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, p4 = 0.0f;
+            int k = 0, g = 0;
             if (idx < total) {
-                const int o = idx / nl, line = l0 + idx - o * nl;
-                int first, stride, count, step, twi = 0;
-                if (PASS == 0) {
-                    const int k1 = o / N2, n2 = o - k1 * N2;
-                    first = n2; stride = N2; count = N1; step = N2 * k1 * ts;   // w_N1^{n1 k1} = w_N^{N2 n1 k1}
-                    twi = n2 * k1 * ts;
-                } else {
-                    const int k2 = o / N1, k1 = o - k2 * N1;
-                    first = k1 * N2; stride = 1; count = N2; step = N1 * k2 * ts;
-                }
-                int t = 0;
+                const int it = idx / nl, line = l0 + idx - it * nl;
+                k = it / G;
+                g = it - k * G;
+                const int step = unit * k;  // < TN
+                const int first = PASS == 0 ? g : g * N2, sstep = (PASS == 0 ? N2 : 1) * es;
                 const c32* src = A + line * ls + first * es;
-                const int sstep = stride * es;
+                int t = 0;
 #pragma unroll 2
-                for (int n = 0; n < count; ++n) {
+                for (int n = 0; n < K; ++n) {
                     const c32 v = src[0];
-                    c32 w = tw[t];
-                    if (FWD) w.y = -w.y;
-                    ax = __builtin_fmaf(v.x, w.x, __builtin_fmaf(-v.y, w.y, ax));
-                    ay = __builtin_fmaf(v.x, w.y, __builtin_fmaf(v.y, w.x, ay));
+                    const c32 w = tw[t];
+                    p1 = __builtin_fmaf(v.x, w.x, p1);
+                    p2 = __builtin_fmaf(v.y, w.y, p2);
+                    p3 = __builtin_fmaf(v.x, w.y, p3);
+                    p4 = __builtin_fmaf(v.y, w.x, p4);
                     src += sstep;
                     t += step;
                     if (t >= TN) t -= TN;
                 }
-                if (PASS == 0) {
-                    c32 w = tw[twi];
-                    if (FWD) w.y = -w.y;
-                    const float bx = ax * w.x - ay * w.y, by = ax * w.y + ay * w.x;
-                    ax = bx;
-                    ay = by;
-                }
             }
-            acc[j] = make_float2(ax, ay);
+            // sum v w = (p1 - p2, p3 + p4) belongs to k for the inverse (w) and to K - k for the forward (conj w); sum v conj(w) the other
+            c32 a = make_float2(p1 - p2, p3 + p4), b = make_float2(p1 + p2, p4 - p3);
+            if (FWD) {
+                const c32 sw = a;
+                a = b;
+                b = sw;
+            }
+            if (PASS == 0 && idx < total) {
+                const int kc = k == 0 ? 0 : K - k;
+                c32 wa = tw[g * k * ts], wb = tw[g * kc * ts];
+                if (FWD) {
+                    wa.y = -wa.y;
+                    wb.y = -wb.y;
+                }
+                a = make_float2(a.x * wa.x - a.y * wa.y, a.x * wa.y + a.y * wa.x);
+                b = make_float2(b.x * wb.x - b.y * wb.y, b.x * wb.y + b.y * wb.x);
+            }
+            lo[j] = a;
+            hi[j] = b;
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kAnyPer; ++j) {
             const int idx = tid + j * kAnyThreads;
             if (idx < total) {
-                const int o = idx / nl, line = l0 + idx - o * nl;
-                int dst = o;  // PASS 0: k1 N2 + n2
-                if (PASS == 1) {
-                    const int k2 = o / N1, k1 = o - k2 * N1;
-                    dst = k1 + N1 * k2;
-                }
-                A[line * ls + dst * es] = acc[j];
+                const int it = idx / nl, line = l0 + idx - it * nl;
+                const int k = it / G, g = it - k * G, kc = k == 0 ? 0 : K - k;
+                c32* base = A + line * ls;
+                const int da = PASS == 0 ? k * N2 + g : g + N1 * k, db = PASS == 0 ? kc * N2 + g : g + N1 * kc;
+                base[da * es] = lo[j];
+                if (kc != k) base[db * es] = hi[j];
             }
         }
         __syncthreads();
