@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, in
 
 // One workgroup per plane, the plane's level grids staged in LDS (they are re-read ~4 H W / (h w) times each by the
 // bilinear gathers); the four waves stride over the plane's RNG tiles.  Same values as the flat kernel above (to rounding).
-// Requires H * W % kTileElems == 0 and elem_offset % (H * W) == 0 (whole planes, tile-aligned).
+// Requires W % 4 == 0 and elem_offset % (H * W) == 0 (whole planes; a plane may straddle RNG tiles).
 // XROWS (bilinear, when it fits): every level grid is first stretched along x to the full width W in LDS (h_l rows of W
 // floats), so an output needs, per level, two conflict-free 16-byte reads and two FMAs per value instead of four gathers, a
 // coordinate-table read and eleven arithmetic instructions; the level weight is folded into the y weights.
@@ -490,7 +490,6 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const int HW = H * W;
-    const int tiles_per_plane = HW / kTileElems;
     const uint32_t lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int dy = 256 / W, dx = 256 - dy * W;  // one burst step advances 256 elements
@@ -560,14 +559,19 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
             __syncthreads();
         }
         float* const oplane = out + p * (int64_t)HW;
-        const int64_t tile0 = (elem_offset + p * (int64_t)HW) / kTileElems;
-        for (int t = wave; t < tiles_per_plane; t += kBlock / 64) {
-            Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)(tile0 + t), lane);
-            int e = t * kTileElems + (int)lane * 4;  // element index inside the plane
-            int y = e / W, x4 = e - y * W;
-            for (int it = 0; it < kTileIters; ++it) {
+        // RNG tiles overlapping this plane (a plane need not start or end on a tile boundary: the neighbours' workgroups draw
+        // the shared tile too and each keeps its own part)
+        const int64_t g0 = elem_offset + p * (int64_t)HW;
+        const int64_t tile_first = g0 / kTileElems, tile_last = (g0 + HW - 1) / kTileElems;
+        for (int64_t t = tile_first + wave; t <= tile_last; t += kBlock / 64) {
+            Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)t, lane);
+            int e = (int)(t * kTileElems - g0) + (int)lane * 4;  // element index inside the plane; < 0 or >= HW: not ours
+            int y = e >= 0 ? e / W : -((-e + W - 1) / W);        // floor
+            int x4 = e - y * W;
+            for (int it = 0; it < kTileIters; ++it, e += 256, y += dy, x4 += dx, y += x4 >= W, x4 -= x4 >= W ? W : 0) {
                 float v[4];
                 rng.normal4(v);
+                if (e < 0 || e >= HW) continue;
                 if (lv.fullres) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] *= lv.base_scale;
@@ -618,13 +622,6 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
                     s += (double)ps;
                     q += (double)pq;
                 }
-                e += 256;
-                y += dy;
-                x4 += dx;
-                if (x4 >= W) {
-                    x4 -= W;
-                    y += 1;
-                }
             }
         }
     }
@@ -642,7 +639,7 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     grid_floats = (grid_floats + 3) & ~(size_t)3;  // the coordinate tables that follow are 16-byte entries
     const size_t lds = grid_floats * sizeof(float) + (mode == 0 ? (size_t)lv.count * (H + W) * sizeof(Lin) : 0);
     const size_t lds_x = lds + rows * W * sizeof(float);
-    if ((H * W) % kTileElems != 0 || elem_offset % (H * W) != 0 || lds > kPyramidLdsBudget) return false;
+    if (W % 4 != 0 || elem_offset % (H * W) != 0 || lds > kPyramidLdsBudget) return false;
     const bool xrows = mode == 0 && W % 4 == 0 && lds_x <= kPyramidLdsBudget;
     const int g = (int)std::min<int64_t>(planes, kNPart);
 #define SONAR_PP(ST, XR) \

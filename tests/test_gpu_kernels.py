@@ -297,7 +297,7 @@ def test_pyramid_replay_golden(hl, golden, tag):
                                         ((2, 4, 64, 64), "nearest-exact"), ((2, 4, 64, 64), "area"), ((2, 3, 32, 48), "bilinear")])
 def test_pyramid_generate_is_sum_of_its_levels(hl, shape, mode):
     """Generate mode = base draw * sqrt(1 + w0^2) (the full-resolution level folded in: sum of two independent normals)
-    + sum of the resampled small levels.  32x32 and 32x48 planes use the flat kernel, the others the LDS-staged plane kernel."""
+    + sum of the resampled small levels.  All of them run in the LDS-staged plane kernel (32x32 and 32x48 planes share RNG tiles with their neighbours)."""
     planes = shape[0] * shape[1]
     H, W = shape[-2:]
     sizes = [(H, W), (H // 3 + 1, W // 3 - 1), (2, 3), (1, 1)]
@@ -318,6 +318,23 @@ def test_pyramid_generate_is_sum_of_its_levels(hl, shape, mode):
     lv2 = [(None, H, W, weights[0])] + [(t[shape[1]:2 * shape[1]].contiguous(), h, w, wt) for t, (h, w), wt in zip(small, sizes[1:], weights[1:])]
     one = hl.pyramid_generate((1, *shape[1:]), "cuda", lv2, mode, seed, 0, per, None)
     assert torch.equal(one[0], got[1])
+
+
+def test_pyramid_flat_kernel_for_levels_beyond_lds(hl):
+    """A level grid too large for the plane kernel's LDS budget (126 x 126 floats) takes the flat global-gather kernel: same values."""
+    shape = (2, 4, 128, 128)
+    seed = 9
+    big = hl.philox_normal((8, 126, 126), "cuda", seed, 10)
+    small = hl.philox_normal((8, 5, 7), "cuda", seed, 11)
+    levels = [(None, 128, 128, 1.0), (big, 126, 126, 0.7), (small, 5, 7, 0.49)]
+    part = hl.new_partials("cuda")
+    got = hl.pyramid_generate(shape, "cuda", levels, "bilinear", seed, 0, 0, part)
+    want = hl.philox_normal(shape, "cuda", seed, 0) * math.sqrt(2.0)
+    hl.resample_acc_(want, big, 0.7, "bilinear", True)
+    hl.resample_acc_(want, small, 0.49, "bilinear", True)
+    close(got, want, rtol=2e-6, atol=2e-6)
+    tot = hl.stats_finalize(part, got.numel()).cpu()
+    assert abs(tot[1].item() - (got.double() ** 2).sum().item()) < 1e-6 * tot[1].item()
 
 
 # ------------------------------------------------------------------------------------------------ power-law rFFT noise
@@ -656,4 +673,10 @@ def test_pyramid_in_kernel_level_grids(hl):
     # coarse structure really is there: 8x8 block means carry more variance than white noise of variance v would (v / 64)
     blocks = a.reshape(6, 4, 8, 8, 8, 8).mean(dim=(3, 5))
     assert blocks.double().var().item() > 3 * v / 64
-    assert hl.pyramid_generate((2, 4, 32, 32), "cuda", [(None, 32, 32, 1.0), (None, 9, 9, 0.7)], "bilinear", 11, 5) is None
+    # planes that do not fill an RNG tile (32 x 32) or straddle tiles (104 x 152) run in the plane kernel too, shard-invariant
+    for hh, ww in ((32, 32), (104, 152)):
+        lv = [(None, hh, ww, 1.0), (None, hh // 3, ww // 3, 0.7)]
+        b = hl.pyramid_generate((3, 4, hh, ww), "cuda", lv, "bilinear", 11, 5)
+        assert torch.equal(hl.pyramid_generate((2, 4, hh, ww), "cuda", lv, "bilinear", 11, 5, 4 * hh * ww), b[1:])
+        assert 2.0 < b.double().var().item() < 2.6
+    assert hl.pyramid_generate((2, 4, 32, 30), "cuda", [(None, 32, 30, 1.0), (None, 9, 9, 0.7)], "bilinear", 11, 5) is None  # W % 4 != 0
