@@ -459,6 +459,27 @@ __global__ void __launch_bounds__(kBlock) ratio_mix_kernel(const float* __restri
         out[t] = a[t] * am + x[t] * x_mul;
 }
 
+// LaplacianNoiseGenerator (py/noise_generation.py:789-802): x = x / div_fac + Laplace(loc, scale) with the Laplace variate built
+// from a uniform u in (eps - 1, 1) exactly as torch.distributions.Laplace.rsample does: loc - scale * sign(u) * log1p(-|u|)
+struct LaplaceAddOp {
+    float* x;
+    const float* u;
+    float div_fac, loc, scale;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        Pack<V> p = load<V>(x, i);
+        const Pack<V> pu = load<V>(u, i);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float uu = pu.v[k];
+            const float a = fmaxf(fabsf(uu), 1.17549435e-38f);  // clamp(min=finfo.tiny)
+            const float sgn = uu > 0.0f ? 1.0f : uu < 0.0f ? -1.0f : 0.0f;
+            p.v[k] = p.v[k] / div_fac + (loc - scale * sgn * log1pf(-a));
+        }
+        store<V>(x, i, p);
+    }
+};
+
 struct PowerLawOp {
     float* x;
     float alpha;
@@ -812,6 +833,11 @@ extern "C" int sonar_div_mid_f32(float* x, int64_t outer, int64_t mid, int64_t i
     hipLaunchKernelGGL(div_mid_kernel, dim3(grid_for(outer * mid * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x,
                        outer, mid, inner, d);
     return check_launch("sonar_div_mid_f32");
+}
+
+extern "C" int sonar_laplace_add_f32(float* x, const float* u, float div_fac, float loc, float scale, int64_t n, void* stream) {
+    SONAR_REQUIRE(x && u && n >= 0 && div_fac != 0.0f, SONAR_ERR_ARG, "sonar_laplace_add_f32: bad argument");
+    return launch_ew(LaplaceAddOp{x, u, div_fac, loc, scale}, n, aligned16(x) && aligned16(u), (hipStream_t)stream, "sonar_laplace_add_f32");
 }
 
 extern "C" int sonar_std_mid_f32(const float* x, int64_t outer, int64_t mid, int64_t inner, float* stdv, void* stream) {

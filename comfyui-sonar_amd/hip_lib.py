@@ -103,6 +103,7 @@ SIGNATURES = {
     "sonar_dwt2_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f32": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f64": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
+    "sonar_laplace_add_f32": (_I, [_P, _P, _F, _F, _F, _I64, _P]),
     "sonar_power_plane_kind": (_I, [_I64, _I64]),
     "sonar_std_mid_f32": (_I, [_P, _I64, _I64, _I64, _P, _P]),
     "sonar_bcast_gain_f32": (_I, [_P, _P, _I64, _I64, _I64, _I, _F, _F, _P, _P, _P]),
@@ -307,6 +308,15 @@ def ratio_mix(a: torch.Tensor, a_mul: float, x: torch.Tensor, x_mul: float, num_
     _check(load().sonar_ratio_mix_f32(_dev(a, "a"), float(a_mul), _dev(x, "x"), float(x_mul), num_partials.data_ptr(), float(num_mul),
                                       den_partials.data_ptr(), _dev(out, "out"), a.numel(), _stream()), "sonar_ratio_mix_f32")
     return out
+
+
+def laplace_add_(x: torch.Tensor, u: torch.Tensor, div_fac: float, loc: float, scale: float) -> torch.Tensor:
+    """x = x/div_fac + Laplace(loc, scale) from the uniform u in (eps-1, 1), in place."""
+    if u.numel() != x.numel():
+        raise SonarHipError("laplace_add_: size mismatch")
+    _check(load().sonar_laplace_add_f32(_dev(x, "x"), _dev(u, "u"), float(div_fac), float(loc), float(scale), x.numel(), _stream()),
+           "sonar_laplace_add_f32")
+    return x
 
 
 def powerlaw_(x: torch.Tensor, alpha: float, use_sign: bool) -> torch.Tensor:

@@ -517,6 +517,56 @@ class PyramidOldNoiseGenerator(FramesToChannelsNoiseGenerator):
         return self.fix_output_frames(noise)
 
 
+class LaplacianNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:789-802: randn / div_fac + a Laplace(loc, scale) variate (torch.distributions.Laplace.rsample: a uniform on
+    (eps - 1, 1) from the global generator, then loc - scale * sign(u) * log1p(-|u|))."""
+
+    name = "laplacian"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"loc": 0, "scale": 1.0, "div_fac": 4.0}
+
+    def generate(self, *_args):
+        noise = self.rand_like()
+        utils.pop_stats(noise)
+        eps = float(torch.finfo(torch.float32).eps)
+        if self.cpu:
+            u = tensor_to(torch.empty(tuple(self.shape), dtype=torch.float32).uniform_(eps - 1.0, 1.0), self.device)
+        else:
+            seed, stream = self.device_key()
+            u = hip_lib.philox_uniform(tuple(self.shape), self.device, seed, stream, self.latent_elem_offset(math.prod(self.shape[1:])),
+                                       sub=0.0, mul=2.0 - eps, add=eps - 1.0)
+            utils.pop_stats(u)
+        return hip_lib.laplace_add_(noise.contiguous(), u.contiguous(), self.div_fac, self.loc, self.scale)
+
+
+class PowerOldNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:1259-1287.  The reference draws a normal tensor only to take its batch size, scales a UNIFORM draw by
+    k / (batch index + 1)^alpha per latent and standardises every [H, W] plane ((x - mean) / std, unbiased); same steps here."""
+
+    name = "power_old"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"alpha": 2, "k": 1, "normalized": False}
+
+    def generate(self, *_args):
+        utils.pop_stats(self.rand_like())  # consumed and dropped, like the reference (keeps the generator's call order)
+        noise = self.rand_like(fun=torch.rand)
+        utils.pop_stats(noise)
+        noise = noise.contiguous()
+        b = noise.shape[0]
+        per_latent = noise.numel() // max(b, 1)
+        first = current_batch_offset() + 1  # batch shards keep their global latent index
+        density = (self.k / torch.arange(first, first + b, dtype=torch.float32) ** self.alpha).to(self.device)
+        noise = hip_lib.row_affine(1, noise, b, per_latent, torch.zeros_like(density), density)
+        hw = noise.shape[-1] * noise.shape[-2]
+        rows = noise.numel() // hw
+        mean, std = hip_lib.rowstats(noise, rows, hw)
+        return hip_lib.row_affine(0, noise, rows, hw, mean, std)
+
+
 def _off_path(type_name: str):
     class _OffPath(NoiseGenerator):
         name = type_name
@@ -532,11 +582,9 @@ def _off_path(type_name: str):
 
 
 StudentTNoiseGenerator = _off_path("studentt")
-LaplacianNoiseGenerator = _off_path("laplacian")
 DistroNoiseGenerator = _off_path("distro")
 VoronoiNoiseGenerator = _off_path("voronoi")
 CollatzNoiseGenerator = _off_path("collatz")
-PowerOldNoiseGenerator = _off_path("power_old")
 ScatternetFilteredNoiseGenerator = _off_path("scatternet_filtered")
 
 

@@ -88,6 +88,9 @@ int sonar_rowstats_f32(const float* x, int64_t rows, int64_t inner, float* mean,
 /* op 0: out = (x - a[row]) / b[row]   op 1: out = x * b[row] + a[row]   (same call sites) */
 int sonar_row_affine_f32(int op, const float* x, int64_t rows, int64_t inner, const float* a, const float* b,
                          float* out, void* stream);
+/* LaplacianNoiseGenerator.generate, py/noise_generation.py:796-802: x = x/div_fac + Laplace(loc, scale), the variate built from a
+ * uniform u in (eps-1, 1) the way torch.distributions.Laplace.rsample does: loc - scale*sign(u)*log1p(-max(|u|, tiny)).  In place. */
+int sonar_laplace_add_f32(float* x, const float* u, float div_fac, float loc, float scale, int64_t n, void* stream);
 /* ModulatedNoise (py/noise.py:784-866), three steps that never read a scalar back to the host:
  *  sonar_std_mid_f32   unbiased std over the middle axis of x[outer][mid][inner] -> stdv[outer][inner]
  *                      (torch.std(dim=-3, keepdim=True), :795-799; the other two modulation_dims use sonar_rowstats_f32)

@@ -594,3 +594,20 @@ def modulated_noise(x_or_ref: Tensor, noise: Tensor, s, sn, *, modulation_type: 
     fn = {"intensity": modulated_intensity, "frequency": modulated_frequency}[modulation_type]
     ref = scale_noise(x_or_ref, normalized=normalize_ref)
     return scale_noise(fn(ref, noise, sigma_up, strength, MODULATION_DIMS[modulation_dims - 1]), factor, normalized=normalize_result)
+
+
+# ---- two more registry types (py/noise_generation.py:789-802, 1259-1287) ------------------------------------------------------
+def laplacian_noise(normal_draw: Tensor, uniform_draw: Tensor, loc: float = 0.0, scale: float = 1.0, div_fac: float = 4.0) -> Tensor:
+    """LaplacianNoiseGenerator.generate: randn / div_fac + Laplace(loc, scale).rsample(); `uniform_draw` is the rsample's
+    uniform_(eps - 1, 1) (torch.distributions.Laplace: loc - scale * sign(u) * log1p(-|u|.clamp(min=tiny)))."""
+    tiny = torch.finfo(uniform_draw.dtype).tiny
+    lap = loc - scale * uniform_draw.sign() * torch.log1p(-uniform_draw.abs().clamp(min=tiny))
+    return normal_draw / div_fac + lap
+
+
+def power_old_noise(uniform_draw: Tensor, alpha: float = 2, k: float = 1) -> Tensor:
+    """PowerOldNoiseGenerator.generate: rand * k / (batch index + 1)^alpha, then every [H, W] plane standardised."""
+    b = uniform_draw.shape[0]
+    freq = torch.arange(1, b + 1, dtype=uniform_draw.dtype).reshape((b,) + (1,) * (uniform_draw.dim() - 1))
+    noise = uniform_draw * (k / freq**alpha)
+    return (noise - noise.mean(dim=(-2, -1), keepdim=True)) / noise.std(dim=(-2, -1), keepdim=True)

@@ -147,6 +147,17 @@ def gen_basic_types():
     cases["uniform_draw"] = torch.rand(2, 4, 8, 8)
     must_equal(cases["gaussian_0"], cases["gaussian_draw"], "gaussian")
     must_equal(cases["uniform_0"], orc.uniform_noise(cases["uniform_draw"]), "uniform")
+    # laplacian (randn, then Laplace.rsample's uniform) and power_old (randn dropped, then rand), both on the global generator
+    for name, nt in (("laplacian", NT.LAPLACIAN), ("power_old", NT.POWER_OLD)):
+        for normalized in (False, True):
+            cases[f"{name}_{int(normalized)}"] = ref_noise(nt, (3, 4, 8, 8), 22, normalized)
+    torch.manual_seed(22)
+    n = torch.randn(3, 4, 8, 8)
+    u = torch.empty(3, 4, 8, 8).uniform_(torch.finfo(torch.float32).eps - 1, 1)
+    must_equal(cases["laplacian_0"], orc.laplacian_noise(n, u), "laplacian")
+    torch.manual_seed(22)
+    torch.randn(3, 4, 8, 8)
+    must_equal(cases["power_old_0"], orc.power_old_noise(torch.rand(3, 4, 8, 8)), "power_old")
     save("basic_types", **cases)
 
 

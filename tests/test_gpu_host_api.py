@@ -50,6 +50,23 @@ def test_basic_types(api, golden, name, normalized):
     close(run_type(api, name, (2, 4, 8, 8), 21, normalized), g[f"{name}_{int(normalized)}"])
 
 
+@pytest.mark.parametrize("name", ["laplacian", "power_old"])
+@pytest.mark.parametrize("normalized", [False, True])
+def test_laplacian_and_power_old_types(api, golden, name, normalized):
+    """py/noise_generation.py:789-802 and 1259-1287 against the reference's outputs (replay), plus generate-mode properties."""
+    g = golden("basic_types")
+    close(run_type(api, name, (3, 4, 8, 8), 22, normalized), g[f"{name}_{int(normalized)}"], rtol=2e-5, atol=2e-5)
+    x = torch.zeros(64, 4, 64, 64, device="cuda")
+    out = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=1, cpu=False, normalized=False)(*SIG)
+    if name == "laplacian":  # var = 1/16 + 2 scale^2, excess kurtosis well above a normal's
+        v = out.double().var().item()
+        assert abs(v - (1.0 / 16 + 2.0)) < 0.02 and abs(out.mean().item()) < 5e-3
+        assert (out.double() ** 4).mean().item() / v**2 > 4.5
+    else:  # every plane standardised
+        planes = out.reshape(-1, 64 * 64).double()
+        assert planes.mean(dim=1).abs().max().item() < 1e-5 and (planes.std(dim=1) - 1.0).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_perlin_type(api, golden, tag):
     g = golden("perlin")

@@ -282,3 +282,16 @@ def test_modulated_noise(golden, mtype, dims, with_ref):
     close(out, g[f"{mtype}_{dims}_{int(with_ref)}"], **({} if mtype == "intensity" else dict(rtol=1e-5, atol=1e-5)))
     if not with_ref:
         close(ref_in, g["x_after"])
+
+
+def test_laplacian_and_power_old(golden):
+    g = golden("basic_types")
+    torch.manual_seed(22)
+    n = torch.randn(3, 4, 8, 8)
+    u = torch.empty(3, 4, 8, 8).uniform_(torch.finfo(torch.float32).eps - 1, 1)
+    close(orc.laplacian_noise(n, u), g["laplacian_0"])
+    torch.manual_seed(22)
+    torch.randn(3, 4, 8, 8)
+    raw = orc.power_old_noise(torch.rand(3, 4, 8, 8))
+    close(raw, g["power_old_0"], rtol=1e-5, atol=1e-6)
+    close(orc.scale_noise(raw.clone(), 1.0, normalized=True), g["power_old_1"], rtol=1e-5, atol=1e-6)
