@@ -759,6 +759,19 @@ def wcfg_output(x: Optional[torch.Tensor], result: torch.Tensor, shape, subtract
 
 
 _WCFG_WS: dict = {}
+_WCFG_NEED: dict = {}
+_TAPS: dict = {}
+
+
+def _taps_arr(vals):
+    """ctypes double array of a filter-tap list, built once per distinct list (the taps of a Wavelet never change)."""
+    key = tuple(vals)
+    hit = _TAPS.get(key)
+    if hit is None:
+        if len(_TAPS) > 256:
+            _TAPS.clear()
+        hit = _TAPS[key] = _darr(key)
+    return hit
 
 
 def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], *, levels: int, dec_lo, dec_hi, mode: str, rec_lo, rec_hi,
@@ -769,7 +782,11 @@ def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tenso
     planes = B * Cc
     lib = load()
     elem = 8 if high_precision else 4
-    need = lib.sonar_wcfg_fused_ws_bytes(planes, H, W, levels, len(dec_lo), DWT_MODE_IDS[mode], len(rec_lo), DWT_MODE_IDS[inv_mode], elem)
+    nkey = (planes, H, W, levels, len(dec_lo), mode, len(rec_lo), inv_mode, elem)
+    need = _WCFG_NEED.get(nkey)
+    if need is None:
+        need = _WCFG_NEED[nkey] = lib.sonar_wcfg_fused_ws_bytes(planes, H, W, levels, len(dec_lo), DWT_MODE_IDS[mode], len(rec_lo),
+                                                                DWT_MODE_IDS[inv_mode], elem)
     if need < 0:
         return None
     stream = _stream()
@@ -782,8 +799,8 @@ def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tenso
     if len(flat) != levels * 12 or len(yl_scales) != 4:
         raise SonarHipError("wcfg_fused: scale tables must be [levels][4][3] and [4]")
     fn = lib.sonar_wcfg_fused_f64 if high_precision else lib.sonar_wcfg_fused_f32
-    rc = fn(_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), planes, H, W, levels, _darr(dec_lo), _darr(dec_hi),
-            len(dec_lo), DWT_MODE_IDS[mode], _darr(rec_lo), _darr(rec_hi), len(rec_lo), DWT_MODE_IDS[inv_mode],
+    rc = fn(_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), planes, H, W, levels, _taps_arr(dec_lo), _taps_arr(dec_hi),
+            len(dec_lo), DWT_MODE_IDS[mode], _taps_arr(rec_lo), _taps_arr(rec_hi), len(rec_lo), DWT_MODE_IDS[inv_mode],
             _darr([float(v) for v in yl_scales]), _darr(flat), BLEND_IDS[blend_mode], float(strength), int(bool(subtract_from_x)),
             ws.data_ptr(), ws.numel(), stream)
     if rc == ERR_UNSUPPORTED:

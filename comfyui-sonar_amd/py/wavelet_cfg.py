@@ -124,6 +124,9 @@ def step_from_sigmas(sigma, sigmas: torch.Tensor, *, decimals: Optional[int] = 4
     return round(above + (1.0 - ((sigma - s_lo) / (s_hi - s_lo))), output_decimals)
 
 
+_PCT_CACHE: dict = {}
+
+
 class WCFGPercentages(NamedTuple):
     """py/wavelet_cfg.py:82-212."""
 
@@ -176,7 +179,13 @@ class WCFGPercentages(NamedTuple):
         def pct_of(s):
             return 1.0 - (ms.timestep(torch.tensor(s)) / 999).clamp(0, 1).detach().item()
 
-        pct_start, pct_end, pct_curr = pct_of(start_sigma), pct_of(end_sigma), pct_of(sigma)
+        # a rule's window ends are the same two numbers at every step of a run: their percentages are looked up once per model
+        ends = _PCT_CACHE.get((id(ms), start_sigma, end_sigma))
+        if ends is None or ends[0] is not ms:
+            if len(_PCT_CACHE) > 64:
+                _PCT_CACHE.clear()
+            ends = _PCT_CACHE[(id(ms), start_sigma, end_sigma)] = (ms, pct_of(start_sigma), pct_of(end_sigma))
+        pct_start, pct_end, pct_curr = ends[1], ends[2], pct_of(sigma)
         pct_range_curr = (pct_curr - pct_start) / (pct_end - pct_start)
         pct_sigmas = pct_enabled_sigmas = step = steps = pct_steps = pct_enabled_steps = None
         sigma_first = sigma_last = step_first = step_last = None
@@ -482,6 +491,10 @@ class WCFGContext(NamedTuple):
     op_kwargs: dict
 
 
+class _BandShape:  # expand_yh_scales only needs the band count and the orientation count
+    shape = (1, 1, 3, 1, 1)
+
+
 def _to_dtype(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     if t.dtype == dtype:
         return t.contiguous()
@@ -562,10 +575,7 @@ class WaveletCFG:
         if levels < 1:
             return None
 
-        class _Band:  # expand_yh_scales only needs the band count and the orientation count
-            shape = (1, 1, 3, 1, 1)
-
-        fake_yh = [_Band] * levels
+        fake_yh = [_BandShape] * levels
         tabs = {name: rule.scale_table(name, pcts, fake_yh) for name in ("cond", "uncond", "diff", "final")}
 
         def row(name, j):
