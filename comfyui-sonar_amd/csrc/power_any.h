@@ -86,19 +86,30 @@ __device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw
     const int per_line = G * HK;
     const int per_batch = max(1, (kAnyThreads * kAnyPer) / per_line);
     const int unit = (PASS == 0 ? N2 : N1) * ts;  // twiddle step of k = 1: w_K = w_N^{N / K}
+    const float rG = 1.0f / (float)G;
 #pragma unroll 1
     for (int l0 = 0; l0 < lines; l0 += per_batch) {
         const int nl = min(per_batch, lines - l0), total = nl * per_line;
+        const float rnl = 1.0f / (float)nl;
         c32 lo[kAnyPer], hi[kAnyPer];
+        int where[kAnyPer];  // line | k << 10 | g << 20 of the item (sizes are <= 1023), -1 = none: decoded once, used on both sides of the barrier
 #pragma unroll
         for (int j = 0; j < kAnyPer; ++j) {
             const int idx = tid + j * kAnyThreads;
             float p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, p4 = 0.0f;
             int k = 0, g = 0;
+            where[j] = -1;
             if (idx < total) {
-                const int it = idx / nl, line = l0 + idx - it * nl;
-                k = it / G;
+                // exact small-integer divisions through float reciprocals (idx < 4096 * 4, quotients far below 2^23)
+                int it = (int)(((float)idx + 0.5f) * rnl);
+                it -= it * nl > idx;
+                it += (it + 1) * nl <= idx;
+                const int line = l0 + idx - it * nl;
+                k = (int)(((float)it + 0.5f) * rG);
+                k -= k * G > it;
+                k += (k + 1) * G <= it;
                 g = it - k * G;
+                where[j] = line | (k << 10) | (g << 20);
                 const int step = unit * k;  // < TN
                 const int first = PASS == 0 ? g : g * N2, sstep = (PASS == 0 ? N2 : 1) * es;
                 const c32* src = A + line * ls + first * es;
@@ -139,10 +150,8 @@ __device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kAnyPer; ++j) {
-            const int idx = tid + j * kAnyThreads;
-            if (idx < total) {
-                const int it = idx / nl, line = l0 + idx - it * nl;
-                const int k = it / G, g = it - k * G, kc = k == 0 ? 0 : K - k;
+            if (where[j] >= 0) {
+                const int line = where[j] & 1023, k = (where[j] >> 10) & 1023, g = where[j] >> 20, kc = k == 0 ? 0 : K - k;
                 c32* base = A + line * ls;
                 const int da = PASS == 0 ? k * N2 + g : g + N1 * k, db = PASS == 0 ? kc * N2 + g : g + N1 * kc;
                 base[da * es] = lo[j];
