@@ -16,6 +16,7 @@ constexpr int kAnyThreads = 1024;        // 16 waves; the plane buffer allows on
 constexpr int kAnySlots = kFftThreads;   // drawing thread slots: streams are keyed by (group, slot) like the fast path
 constexpr int kAnyPer = 4;               // outputs per thread and batch held in registers across a pass's barrier
 constexpr size_t kAnyLdsLimit = 160 * 1024 - 2048;
+constexpr int kAnyMaxRadix = 8;           // radix-16 leaves too few (line, n2) families for 1024 threads: measured slower (96 x 96: 176 vs 145 us)
 
 struct AnyPlan {
     int H, W, M, S;        // M = W / 2, S = M + 1 = row stride in complex values (odd: M is even for every W = 4 q)
@@ -23,13 +24,23 @@ struct AnyPlan {
     int mn1, mn2;          // M = mn1 * mn2
 };
 
+// N = n1 * n2: n1 is the first-pass length.  A power-of-two n1 <= kAnyMaxRadix runs as a butterfly codelet (cost ~ 2 terms per value), any
+// other pair costs (n1 + n2) / 2 terms per value (conjugate output pairs share their products); pick the cheapest.
 static inline void best_split(int n, int& n1, int& n2) {
     n1 = 1;
     n2 = n;
+    float best = 0.5f * (1 + n);
     for (int a = 1; a * a <= n; ++a)
-        if (n % a == 0) {
+        if (n % a == 0 && 0.5f * (a + n / a) < best) {
+            best = 0.5f * (a + n / a);
             n1 = a;
             n2 = n / a;
+        }
+    for (int r = 2; r <= kAnyMaxRadix; r *= 2)
+        if (n % r == 0 && 2.0f + 0.5f * (n / r) <= best) {
+            best = 2.0f + 0.5f * (n / r);
+            n1 = r;
+            n2 = n / r;
         }
 }
 
@@ -162,9 +173,43 @@ __device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw
     }
 }
 
+// PASS 0 for N1 = R in {2, 4, 8}: one thread owns a whole sum family (line, n2) -- R loads, the radix-R butterfly codelet of
+// the fixed-size kernels, R - 1 twiddles, R stores to the same slots: no batching, no barrier until the end of the pass.
+template <int R, bool FWD>
+__device__ __forceinline__ void radix_pass0(c32* A, const c32* __restrict__ tw, int ts, int N2, int lines, int es, int ls, int tid) {
+    const int total = lines * N2;
+    const float rl = 1.0f / (float)lines;
+    for (int idx = tid; idx < total; idx += kAnyThreads) {
+        int g = (int)(((float)idx + 0.5f) * rl);
+        g -= g * lines > idx;
+        g += (g + 1) * lines <= idx;
+        const int line = idx - g * lines;
+        c32* base = A + line * ls + g * es;
+        const int stride = N2 * es;
+        c32 v[R];
+#pragma unroll
+        for (int n = 0; n < R; ++n) v[n] = base[n * stride];
+        if (FWD) fdft<R>(v); else idft<R>(v);
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+            c32 w = tw[g * k * ts];
+            if (FWD) w.y = -w.y;
+            v[k] = make_float2(v[k].x * w.x - v[k].y * w.y, v[k].x * w.y + v[k].y * w.x);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) base[k * stride] = v[k];
+    }
+    __syncthreads();
+}
+
 template <bool FWD>
 __device__ __forceinline__ void line_dft(c32* A, const c32* tw, int TN, int ts, int N1, int N2, int lines, int es, int ls, int tid) {
-    line_dft_pass<0, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+    switch (N1) {  // uniform
+        case 8: radix_pass0<8, FWD>(A, tw, ts, N2, lines, es, ls, tid); break;
+        case 4: radix_pass0<4, FWD>(A, tw, ts, N2, lines, es, ls, tid); break;
+        case 2: radix_pass0<2, FWD>(A, tw, ts, N2, lines, es, ls, tid); break;
+        default: line_dft_pass<0, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+    }
     line_dft_pass<1, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
 }
 
