@@ -480,6 +480,112 @@ struct LaplaceAddOp {
     }
 };
 
+// ---- StudentTNoiseGenerator (py/noise_generation.py:652-677) --------------------------------------------------------------------
+// x (a standard normal draw) -> loc + scale * x * rsqrt(max(g / 0.5, tiny) / df), g the torch._standard_gamma(df / 2) draw
+// (torch.distributions.StudentT.rsample / Chi2 / Gamma.rsample)
+struct StudentTOp {
+    float* x;
+    const float* g;
+    float loc, scale, df;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        Pack<V> p = load<V>(x, i);
+        const Pack<V> pg = load<V>(g, i);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float z = fmaxf(pg.v[k] / 0.5f, 1.17549435e-38f);
+            p.v[k] = loc + scale * (p.v[k] * (1.0f / sqrtf(z / df)));
+        }
+        store<V>(x, i, p);
+    }
+};
+
+// q-quantile (torch.quantile, linear interpolation) of |x| over each row of `inner` contiguous values: radix select on the bit
+// patterns (non-negative floats order like unsigned integers), four 8-bit histogram passes in LDS, then one pass for the next
+// order statistic.  One workgroup per row.  rank = lo + frac is computed by the host in fp32 like torch does.
+__global__ void __launch_bounds__(kBlock) abs_quantile_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner, int64_t lo,
+                                                                    float frac, float* out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_prefix, sh_k, sh_cnt, sh_min;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* row = x + r * inner;
+        unsigned prefix = 0, mask = 0, k = (unsigned)lo;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int b = threadIdx.x; b < 256; b += kBlock) hist[b] = 0;
+            __syncthreads();
+            for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
+                const unsigned bits = __float_as_uint(row[i]) & 0x7FFFFFFFu;
+                if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned cum = 0, b = 0;
+                for (; b < 255; ++b) {
+                    if (cum + hist[b] > k) break;
+                    cum += hist[b];
+                }
+                sh_prefix = prefix | (b << shift);
+                sh_k = k - cum;
+            }
+            __syncthreads();
+            prefix = sh_prefix;
+            k = sh_k;
+            mask |= 255u << shift;
+            __syncthreads();
+        }
+        // prefix = bits of the lo-th smallest |x|; the next order statistic is the same value if it repeats, else the smallest larger one
+        if (threadIdx.x == 0) {
+            sh_cnt = 0;
+            sh_min = 0x7FFFFFFFu;
+        }
+        __syncthreads();
+        unsigned cnt = 0, mn = 0x7FFFFFFFu;
+        for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
+            const unsigned bits = __float_as_uint(row[i]) & 0x7FFFFFFFu;
+            cnt += bits <= prefix;
+            if (bits > prefix) mn = min(mn, bits);
+        }
+        atomicAdd(&sh_cnt, cnt);
+        atomicMin(&sh_min, mn);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float vlo = __uint_as_float(prefix);
+            const float vhi = (lo + 1 < (int64_t)sh_cnt || lo + 1 >= inner) ? vlo : __uint_as_float(sh_min);
+            out[r] = blend<float>(SONAR_BLEND_LERP, vlo, vhi, frac);
+        }
+        __syncthreads();
+    }
+}
+
+// x = copysign(|clamp(x, -lim, lim)|^p, x) per row, lim = limit[row] * mul (StudentT: clamp to the quantile, compress the tails)
+__global__ void __launch_bounds__(kBlock) clamp_signpow_rows_kernel(float* x, int64_t rows, int64_t inner, const float* __restrict__ limit,
+                                                                     float mul, float p) {
+    const int64_t total = rows * inner;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const float lim = limit[i / inner] * mul;
+        const float v = fminf(fmaxf(x[i], -lim), lim);
+        const float a = fabsf(v);
+        const float m = p == 0.5f ? sqrtf(a) : p == 1.0f ? a : p == 2.0f ? a * a : powf(a, p);
+        x[i] = copysignf(m, v);
+    }
+}
+
+// acc = (first ? 0 : acc) + mul * z^2: chi-square of an integer df built from squared normals (on-device StudentT draws)
+struct SqAccOp {
+    float* acc;
+    const float* z;
+    float mul;
+    int first;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        Pack<V> a = load<V>(acc, i);
+        const Pack<V> pz = load<V>(z, i);
+#pragma unroll
+        for (int k = 0; k < V; ++k) a.v[k] = (first ? 0.0f : a.v[k]) + mul * (pz.v[k] * pz.v[k]);
+        store<V>(acc, i, a);
+    }
+};
+
 struct PowerLawOp {
     float* x;
     float alpha;
@@ -838,6 +944,34 @@ extern "C" int sonar_div_mid_f32(float* x, int64_t outer, int64_t mid, int64_t i
 extern "C" int sonar_laplace_add_f32(float* x, const float* u, float div_fac, float loc, float scale, int64_t n, void* stream) {
     SONAR_REQUIRE(x && u && n >= 0 && div_fac != 0.0f, SONAR_ERR_ARG, "sonar_laplace_add_f32: bad argument");
     return launch_ew(LaplaceAddOp{x, u, div_fac, loc, scale}, n, aligned16(x) && aligned16(u), (hipStream_t)stream, "sonar_laplace_add_f32");
+}
+
+extern "C" int sonar_studentt_f32(float* x, const float* gamma, float loc, float scale, float df, int64_t n, void* stream) {
+    SONAR_REQUIRE(x && gamma && n >= 0 && df > 0.0f, SONAR_ERR_ARG, "sonar_studentt_f32: bad argument");
+    return launch_ew(StudentTOp{x, gamma, loc, scale, df}, n, aligned16(x) && aligned16(gamma), (hipStream_t)stream, "sonar_studentt_f32");
+}
+
+extern "C" int sonar_abs_quantile_rows_f32(const float* x, int64_t rows, int64_t inner, int64_t rank_lo, float rank_frac, float* out,
+                                           void* stream) {
+    SONAR_REQUIRE(x && out && rows >= 0 && inner > 0 && rank_lo >= 0 && rank_lo < inner && rank_frac >= 0.0f && rank_frac <= 1.0f,
+                  SONAR_ERR_ARG, "sonar_abs_quantile_rows_f32: bad argument");
+    if (rows == 0) return SONAR_OK;
+    hipLaunchKernelGGL(abs_quantile_rows_kernel, dim3(grid_for(rows, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner, rank_lo,
+                       rank_frac, out);
+    return check_launch("sonar_abs_quantile_rows_f32");
+}
+
+extern "C" int sonar_clamp_signpow_rows_f32(float* x, int64_t rows, int64_t inner, const float* limit, float mul, float p, void* stream) {
+    SONAR_REQUIRE(x && limit && rows >= 0 && inner > 0, SONAR_ERR_ARG, "sonar_clamp_signpow_rows_f32: bad argument");
+    if (rows == 0) return SONAR_OK;
+    hipLaunchKernelGGL(clamp_signpow_rows_kernel, dim3(grid_for(rows * inner, kBlock * 4)), dim3(kBlock), 0, (hipStream_t)stream, x, rows,
+                       inner, limit, mul, p);
+    return check_launch("sonar_clamp_signpow_rows_f32");
+}
+
+extern "C" int sonar_sq_acc_f32(float* acc, const float* z, float mul, int first, int64_t n, void* stream) {
+    SONAR_REQUIRE(acc && z && n >= 0, SONAR_ERR_ARG, "sonar_sq_acc_f32: bad argument");
+    return launch_ew(SqAccOp{acc, z, mul, first}, n, aligned16(acc) && aligned16(z), (hipStream_t)stream, "sonar_sq_acc_f32");
 }
 
 extern "C" int sonar_std_mid_f32(const float* x, int64_t outer, int64_t mid, int64_t inner, float* stdv, void* stream) {

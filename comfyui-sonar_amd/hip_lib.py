@@ -103,6 +103,10 @@ SIGNATURES = {
     "sonar_dwt2_fwd_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f32": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
     "sonar_dwt2_inv_f64": (_I, [_P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _PD, _PD, _I, _I, _P, _P]),
+    "sonar_sq_acc_f32": (_I, [_P, _P, _F, _I, _I64, _P]),
+    "sonar_studentt_f32": (_I, [_P, _P, _F, _F, _F, _I64, _P]),
+    "sonar_abs_quantile_rows_f32": (_I, [_P, _I64, _I64, _I64, _F, _P, _P]),
+    "sonar_clamp_signpow_rows_f32": (_I, [_P, _I64, _I64, _P, _F, _F, _P]),
     "sonar_laplace_add_f32": (_I, [_P, _P, _F, _F, _F, _I64, _P]),
     "sonar_power_plane_kind": (_I, [_I64, _I64]),
     "sonar_std_mid_f32": (_I, [_P, _I64, _I64, _I64, _P, _P]),
@@ -308,6 +312,34 @@ def ratio_mix(a: torch.Tensor, a_mul: float, x: torch.Tensor, x_mul: float, num_
     _check(load().sonar_ratio_mix_f32(_dev(a, "a"), float(a_mul), _dev(x, "x"), float(x_mul), num_partials.data_ptr(), float(num_mul),
                                       den_partials.data_ptr(), _dev(out, "out"), a.numel(), _stream()), "sonar_ratio_mix_f32")
     return out
+
+
+def sq_acc_(acc: torch.Tensor, z: torch.Tensor, mul: float, first: bool) -> torch.Tensor:
+    _check(load().sonar_sq_acc_f32(_dev(acc, "acc"), _dev(z, "z"), float(mul), int(bool(first)), acc.numel(), _stream()), "sonar_sq_acc_f32")
+    return acc
+
+
+def studentt_(x: torch.Tensor, gamma: torch.Tensor, loc: float, scale: float, df: float) -> torch.Tensor:
+    _check(load().sonar_studentt_f32(_dev(x, "x"), _dev(gamma, "gamma"), float(loc), float(scale), float(df), x.numel(), _stream()),
+           "sonar_studentt_f32")
+    return x
+
+
+def abs_quantile_rows(x: torch.Tensor, rows: int, inner: int, q: float) -> torch.Tensor:
+    """torch.quantile(|x|.reshape(rows, inner), q, dim=-1) (linear interpolation); the rank is formed in fp32 like torch's."""
+    rank = torch.tensor(q, dtype=torch.float32) * (inner - 1)
+    lo = int(torch.floor(rank).item())
+    frac = float((rank - lo).item())
+    out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _check(load().sonar_abs_quantile_rows_f32(_dev(x, "x"), rows, inner, min(lo, inner - 1), frac, _dev(out, "out"), _stream()),
+           "sonar_abs_quantile_rows_f32")
+    return out
+
+
+def clamp_signpow_rows_(x: torch.Tensor, rows: int, inner: int, limit: torch.Tensor, mul: float, p: float) -> torch.Tensor:
+    _check(load().sonar_clamp_signpow_rows_f32(_dev(x, "x"), rows, inner, _dev(limit, "limit"), float(mul), float(p), _stream()),
+           "sonar_clamp_signpow_rows_f32")
+    return x
 
 
 def laplace_add_(x: torch.Tensor, u: torch.Tensor, div_fac: float, loc: float, scale: float) -> torch.Tensor:

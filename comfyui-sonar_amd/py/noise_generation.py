@@ -567,6 +567,41 @@ class PowerOldNoiseGenerator(NoiseGenerator):
         return hip_lib.row_affine(0, noise, rows, hw, mean, std)
 
 
+class StudentTNoiseGenerator(NoiseGenerator):
+    """py/noise_generation.py:652-677: a Student-t variate (torch.distributions.StudentT.rsample: a normal, then the chi-square through
+    torch._standard_gamma(df / 2)), tails clamped at the per-latent quantile of |noise| and compressed by sign(x) |x|^pow_fac.
+    Replay mode takes both base draws from the host generator in that order; on-device draws build the chi-square of an INTEGER df as
+    a sum of squared normals (other df: replay mode only)."""
+
+    name = "studentt"
+
+    @classmethod
+    def ng_params(cls):
+        return super().ng_params() | {"loc": 0, "scale": 0.2, "df": 1, "quantile_fac": 0.75, "pow_fac": 0.5, "nq_fac": 1.0, "normalized": False}
+
+    def generate(self, *_args):
+        shape = tuple(self.shape)
+        if self.cpu:
+            noise = tensor_to(torch.empty(shape, dtype=torch.float32).normal_(), self.device)
+            gamma = tensor_to(torch._standard_gamma(torch.full(shape, 0.5 * self.df, dtype=torch.float32)), self.device)
+        else:
+            df = int(self.df)
+            if df != self.df or not 1 <= df <= 16:
+                raise NotImplementedError("studentt: on-device draws need an integer df in 1..16 (use cpu noise for other values)")
+            noise = self.rand_like()
+            utils.pop_stats(noise)
+            gamma = torch.empty_like(noise)
+            for i in range(df):  # chi2(df) = sum of df squared normals; gamma(df / 2) = chi2 / 2
+                z = self.rand_like()
+                utils.pop_stats(z)
+                hip_lib.sq_acc_(gamma, z.contiguous(), 0.5, i == 0)
+        noise = hip_lib.studentt_(noise.contiguous(), gamma.contiguous(), self.loc, self.scale, self.df)
+        b = noise.shape[0]
+        inner = noise.numel() // max(b, 1)
+        nq = hip_lib.abs_quantile_rows(noise, b, inner, self.quantile_fac)
+        return hip_lib.clamp_signpow_rows_(noise, b, inner, nq, self.nq_fac, self.pow_fac)
+
+
 def _off_path(type_name: str):
     class _OffPath(NoiseGenerator):
         name = type_name
@@ -581,7 +616,6 @@ def _off_path(type_name: str):
     return _OffPath
 
 
-StudentTNoiseGenerator = _off_path("studentt")
 DistroNoiseGenerator = _off_path("distro")
 VoronoiNoiseGenerator = _off_path("voronoi")
 CollatzNoiseGenerator = _off_path("collatz")

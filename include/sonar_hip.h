@@ -88,6 +88,18 @@ int sonar_rowstats_f32(const float* x, int64_t rows, int64_t inner, float* mean,
 /* op 0: out = (x - a[row]) / b[row]   op 1: out = x * b[row] + a[row]   (same call sites) */
 int sonar_row_affine_f32(int op, const float* x, int64_t rows, int64_t inner, const float* a, const float* b,
                          float* out, void* stream);
+/* StudentTNoiseGenerator.generate, py/noise_generation.py:667-677, in three steps:
+ *  sonar_studentt_f32            x (a standard-normal draw) -> loc + scale * x * rsqrt(max(gamma/0.5, tiny) / df), gamma = the
+ *                                torch._standard_gamma(df/2) draw of torch.distributions.StudentT.rsample (Chi2 = Gamma(df/2, 1/2)); in place
+ *  sonar_abs_quantile_rows_f32   out[row] = torch.quantile(|x[row]|, q) with linear interpolation; the caller passes the fp32 rank
+ *                                q*(inner-1) split into rank_lo + rank_frac (radix select on bit patterns, one workgroup per row)
+ *  sonar_clamp_signpow_rows_f32  x = copysign(|clamp(x, -lim, lim)|^p, x), lim = limit[row] * mul; in place */
+/* acc = (first ? 0 : acc) + mul*z*z -- the chi-square of an integer df as a sum of squared normals (on-device StudentT draws) */
+int sonar_sq_acc_f32(float* acc, const float* z, float mul, int first, int64_t n, void* stream);
+int sonar_studentt_f32(float* x, const float* gamma, float loc, float scale, float df, int64_t n, void* stream);
+int sonar_abs_quantile_rows_f32(const float* x, int64_t rows, int64_t inner, int64_t rank_lo, float rank_frac, float* out,
+                                void* stream);
+int sonar_clamp_signpow_rows_f32(float* x, int64_t rows, int64_t inner, const float* limit, float mul, float p, void* stream);
 /* LaplacianNoiseGenerator.generate, py/noise_generation.py:796-802: x = x/div_fac + Laplace(loc, scale), the variate built from a
  * uniform u in (eps-1, 1) the way torch.distributions.Laplace.rsample does: loc - scale*sign(u)*log1p(-max(|u|, tiny)).  In place. */
 int sonar_laplace_add_f32(float* x, const float* u, float div_fac, float loc, float scale, int64_t n, void* stream);

@@ -611,3 +611,16 @@ def power_old_noise(uniform_draw: Tensor, alpha: float = 2, k: float = 1) -> Ten
     freq = torch.arange(1, b + 1, dtype=uniform_draw.dtype).reshape((b,) + (1,) * (uniform_draw.dim() - 1))
     noise = uniform_draw * (k / freq**alpha)
     return (noise - noise.mean(dim=(-2, -1), keepdim=True)) / noise.std(dim=(-2, -1), keepdim=True)
+
+
+def studentt_noise(normal_draw: Tensor, gamma_draw: Tensor, loc: float = 0.0, scale: float = 0.2, df: float = 1.0, quantile_fac: float = 0.75,
+                   pow_fac: float = 0.5, nq_fac: float = 1.0) -> Tensor:
+    """StudentTNoiseGenerator.generate (py/noise_generation.py:652-677).  torch.distributions.StudentT.rsample draws X = empty.normal_()
+    and the Chi2 through torch._standard_gamma(df / 2) (`gamma_draw`), Z = (gamma / 0.5).clamp(min=tiny), Y = X * rsqrt(Z / df); then the
+    per-latent quantile of |noise| clamps the tails and sign(x) |x|^pow_fac compresses them."""
+    z = (gamma_draw / 0.5).clamp(min=torch.finfo(gamma_draw.dtype).tiny)
+    noise = loc + scale * (normal_draw * torch.rsqrt(z / df))
+    nq = torch.quantile(noise.flatten(start_dim=1).abs(), quantile_fac, dim=-1) * nq_fac
+    nq = nq.reshape(tuple(nq.shape) + (1,) * (noise.ndim - nq.ndim))
+    noise = noise.clamp(-nq, nq)
+    return torch.copysign(torch.pow(torch.abs(noise), pow_fac), noise)

@@ -158,6 +158,19 @@ def gen_basic_types():
     torch.manual_seed(22)
     torch.randn(3, 4, 8, 8)
     must_equal(cases["power_old_0"], orc.power_old_noise(torch.rand(3, 4, 8, 8)), "power_old")
+    # studentt: X = empty.normal_(), then torch._standard_gamma(df / 2), both on the global generator
+    for normalized in (False, True):
+        cases[f"studentt_{int(normalized)}"] = ref_noise(NT.STUDENTT, (3, 4, 8, 8), 23, normalized)
+    cases["studentt_df3"] = ref_noise(NT.STUDENTT, (3, 4, 8, 8), 23, False, df=3, quantile_fac=0.9, pow_fac=0.75, scale=0.5, loc=0.1, nq_fac=0.8)
+    torch.manual_seed(23)
+    xn = torch.empty(3, 4, 8, 8).normal_()
+    gm = torch._standard_gamma(torch.full((3, 4, 8, 8), 0.5))
+    cases["studentt_normal_draw"], cases["studentt_gamma_draw"] = xn, gm
+    must_equal(cases["studentt_0"], orc.studentt_noise(xn, gm), "studentt")
+    torch.manual_seed(23)
+    xn3 = torch.empty(3, 4, 8, 8).normal_()
+    gm3 = torch._standard_gamma(torch.full((3, 4, 8, 8), 1.5))
+    must_equal(cases["studentt_df3"], orc.studentt_noise(xn3, gm3, loc=0.1, scale=0.5, df=3, quantile_fac=0.9, pow_fac=0.75, nq_fac=0.8), "studentt df3")
     save("basic_types", **cases)
 
 

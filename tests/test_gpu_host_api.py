@@ -67,6 +67,32 @@ def test_laplacian_and_power_old_types(api, golden, name, normalized):
         assert planes.mean(dim=1).abs().max().item() < 1e-5 and (planes.std(dim=1) - 1.0).abs().max().item() < 1e-5
 
 
+def test_studentt_type(api, golden):
+    """py/noise_generation.py:652-677 against the reference (replay: normal + torch._standard_gamma base draws, per-latent quantile clamp,
+    sign-preserving power), the quantile kernel against torch.quantile at SDXL size, and the on-device draws' distribution."""
+    g = golden("basic_types")
+    for normalized in (False, True):
+        close(run_type(api, "studentt", (3, 4, 8, 8), 23, normalized), g[f"studentt_{int(normalized)}"], rtol=2e-5, atol=2e-5)
+    close(run_type(api, "studentt", (3, 4, 8, 8), 23, False, df=3, quantile_fac=0.9, pow_fac=0.75, scale=0.5, loc=0.1, nq_fac=0.8),
+          g["studentt_df3"], rtol=2e-5, atol=2e-5)
+    torch.manual_seed(5)
+    x = torch.randn(6, 4 * 128 * 128)
+    x[1, :1000] = 0.25  # repeated values around a rank
+    for q in (0.75, 0.5, 0.999, 0.0, 1.0, 0.123):
+        want = torch.quantile(x.abs(), q, dim=-1)
+        got = api.hl.abs_quantile_rows(x.cuda(), 6, x.shape[1], q)
+        close(got, want, rtol=1e-6, atol=1e-7)
+    xs = torch.zeros(32, 4, 64, 64, device="cuda")
+    out = api.noise.get_noise_sampler("studentt", xs, 0.03, 14.6, seed=1, cpu=False, normalized=False)(*SIG)
+    # |t_1| * 0.2 clamped at its 75 % quantile (0.2 * tan(3 pi / 8) = 0.483), then sqrt: a quarter of the values sit at +-sqrt(0.483)
+    lim = (0.2 * math.tan(3 * math.pi / 8)) ** 0.5
+    assert abs(out.abs().max().item() - lim) < 0.02 * lim
+    at_lim = (out.abs() > 0.999 * out.abs().amax(dim=(1, 2, 3), keepdim=True)).float().mean().item()
+    assert abs(at_lim - 0.25) < 0.01 and abs(out.mean().item()) < 5e-3
+    with pytest.raises(NotImplementedError):
+        api.noise.get_noise_sampler("studentt", xs, 0.03, 14.6, seed=1, cpu=False, normalized=False, df=2.5)(*SIG)
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_perlin_type(api, golden, tag):
     g = golden("perlin")

@@ -295,3 +295,12 @@ def test_laplacian_and_power_old(golden):
     raw = orc.power_old_noise(torch.rand(3, 4, 8, 8))
     close(raw, g["power_old_0"], rtol=1e-5, atol=1e-6)
     close(orc.scale_noise(raw.clone(), 1.0, normalized=True), g["power_old_1"], rtol=1e-5, atol=1e-6)
+
+
+def test_studentt(golden):
+    g = golden("basic_types")
+    close(orc.studentt_noise(g["studentt_normal_draw"], g["studentt_gamma_draw"]), g["studentt_0"])
+    torch.manual_seed(23)
+    xn = torch.empty(3, 4, 8, 8).normal_()
+    gm = torch._standard_gamma(torch.full((3, 4, 8, 8), 0.5))
+    assert torch.equal(xn, g["studentt_normal_draw"]) and torch.equal(gm, g["studentt_gamma_draw"])
