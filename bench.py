@@ -205,7 +205,15 @@ def main():
                 extra["momentum_euler_latent_steps_per_s"] = BATCH / dt
                 extra["momentum_euler_GBps_at_20N"] = 20 * N_LATENT * BATCH / dt / 1e9
                 ns_b = nz.get_noise_sampler("brownian", x64, 0.03, 14.6, seed=7, cpu=False, normalized=False)
-                extra["brownian_b64_latents_per_s"] = 64 / time_calls(lambda: ns_b(torch.tensor(9.0), torch.tensor(7.5)), 10, 3)
+                sched = torch.linspace(14.6, 0.03, 41).tolist()  # like a sampling run: every call ends where the next begins
+                pos = [0]
+
+                def brownian_step():
+                    i = pos[0] % 40
+                    pos[0] += 1
+                    return ns_b(torch.tensor(sched[i]), torch.tensor(sched[i + 1]))
+
+                extra["brownian_b64_latents_per_s"] = 64 / time_calls(brownian_step, 30, 5)
                 filt = torch.rand(H, W // 2 + 1, device=device) + 0.5
                 dt = time_calls(lambda: hl.spectral_filter(xs, filt), 20, 5)
                 extra["spectral_filter_latents_per_s"] = BATCH / dt

@@ -675,8 +675,10 @@ struct BrownianTerms {
 // sub-tile and keeps its 4 x 4 partial sums in registers over the nodes.
 constexpr int kBrownIters = 4;
 constexpr int kBrownTile = kBrownIters * 256;
+// Both kernels: acc = sum_k coef_k z(node_k); out = scale * (acc - prev) (prev may be null), w_out = acc (may be null) -- the
+// second form evaluates ONE path point W(t) and differences it against a cached W(t') (see sonar_brownian_point_f32).
 __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
-                                                                uint64_t seed) {
+                                                                uint64_t seed, const float* __restrict__ prev, float* w_out, float scale) {
     const uint32_t lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
@@ -698,16 +700,25 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
                 for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_fmaf(c, z[j], acc[it][j]);
             }
         }
-        float* dst = out + t * kBrownTile + (int64_t)lane * 4;
+        const int64_t o = t * kBrownTile + (int64_t)lane * 4;
 #pragma unroll
-        for (int it = 0; it < kBrownIters; ++it)
-            *reinterpret_cast<float4*>(dst + it * 256) = make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]);
+        for (int it = 0; it < kBrownIters; ++it) {
+            float4 a = make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]);
+            if (w_out) *reinterpret_cast<float4*>(w_out + o + it * 256) = a;
+            if (out) {
+                if (prev) {
+                    const float4 p = *reinterpret_cast<const float4*>(prev + o + it * 256);
+                    a = make_float4(a.x - p.x, a.y - p.y, a.z - p.z, a.w - p.w);
+                }
+                *reinterpret_cast<float4*>(out + o + it * 256) = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+            }
+        }
     }
 }
 
 __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
                                                           uint64_t seed, const unsigned long long* __restrict__ latent_seeds,
-                                                          int64_t latent_elems) {
+                                                          int64_t latent_elems, const float* __restrict__ prev, float* w_out, float scale) {
     const int64_t groups = (n + 3) / 4;
     for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
         const int64_t e = g * 4;                       // local element index of the 4-group
@@ -730,10 +741,9 @@ __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n,
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(c, z[j], acc[j]);
         }
-        if (e + 4 <= n && (reinterpret_cast<uintptr_t>(out + e) & 15u) == 0) {
-            *reinterpret_cast<float4*>(out + e) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        } else {
-            for (int j = 0; j < 4 && e + j < n; ++j) out[e + j] = acc[j];
+        for (int j = 0; j < 4 && e + j < n; ++j) {
+            if (w_out) w_out[e + j] = acc[j];
+            if (out) out[e + j] = (prev ? acc[j] - prev[e + j] : acc[j]) * scale;
         }
     }
 }
@@ -787,15 +797,15 @@ extern "C" int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, ui
                                       (hipStream_t)stream, "sonar_philox_uniform_f32");
 }
 
-extern "C" int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, const uint64_t* node_ids, const float* coefs,
-                                  int nnodes, uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems, void* stream) {
-    SONAR_REQUIRE(out && n >= 0 && elem_offset >= 0 && (elem_offset & 3) == 0 && nnodes >= 0 && (nnodes == 0 || (node_ids && coefs)),
-                  SONAR_ERR_ARG, "sonar_brownian_f32: bad argument");
-    SONAR_REQUIRE(nnodes <= kMaxBrownianNodes, SONAR_ERR_UNSUPPORTED, "sonar_brownian_f32: more than %d path nodes", kMaxBrownianNodes);
+static int brownian_launch(float* out, float* w_out, const float* prev, float scale, int64_t n, int64_t elem_offset,
+                           const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds,
+                           int64_t latent_elems, void* stream, const char* what) {
+    SONAR_REQUIRE((out || w_out) && n >= 0 && elem_offset >= 0 && (elem_offset & 3) == 0 && nnodes >= 0 && (nnodes == 0 || (node_ids && coefs)),
+                  SONAR_ERR_ARG, "%s: bad argument", what);
+    SONAR_REQUIRE(nnodes <= kMaxBrownianNodes, SONAR_ERR_UNSUPPORTED, "%s: more than %d path nodes", what, kMaxBrownianNodes);
     SONAR_REQUIRE(!latent_seeds || (latent_elems > 0 && latent_elems % 4 == 0 && n % latent_elems == 0), SONAR_ERR_ARG,
-                  "sonar_brownian_f32: per-latent seeds need whole latents of a multiple of 4 elements");
-    for (int k = 0; k < nnodes; ++k)
-        SONAR_REQUIRE((node_ids[k] >> 48) == 0, SONAR_ERR_ARG, "sonar_brownian_f32: node ids are 48-bit");
+                  "%s: per-latent seeds need whole latents of a multiple of 4 elements", what);
+    for (int k = 0; k < nnodes; ++k) SONAR_REQUIRE((node_ids[k] >> 48) == 0, SONAR_ERR_ARG, "%s: node ids are 48-bit", what);
     if (n == 0) return SONAR_OK;
     BrownianTerms t;
     t.count = nnodes;
@@ -803,16 +813,31 @@ extern "C" int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, co
         t.node[k] = node_ids[k];
         t.coef[k] = coefs[k];
     }
+    auto al = [](const void* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     // the variant is a function of the latent size and the seed kind only, so every shard of a batch picks the same one
     const bool burst = !latent_seeds && latent_elems > 0 && latent_elems % kTileElems == 0 && n % latent_elems == 0 &&
-                       elem_offset % latent_elems == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+                       elem_offset % latent_elems == 0 && al(out) && al(w_out) && al(prev);
     if (burst)
         hipLaunchKernelGGL(brownian_burst_kernel, dim3(grid_for(n / kBrownTile, 4)), dim3(kBlock), 0, (hipStream_t)stream, out, n,
-                           elem_offset, t, seed);
+                           elem_offset, t, seed, prev, w_out, scale);
     else
         hipLaunchKernelGGL(brownian_kernel, dim3(grid_for((n + 3) / 4, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, n, elem_offset,
-                           t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems);
-    return check_launch("sonar_brownian_f32");
+                           t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems, prev, w_out, scale);
+    return check_launch(what);
+}
+
+extern "C" int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, const uint64_t* node_ids, const float* coefs,
+                                  int nnodes, uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems, void* stream) {
+    SONAR_REQUIRE(out, SONAR_ERR_ARG, "sonar_brownian_f32: bad argument");
+    return brownian_launch(out, nullptr, nullptr, 1.0f, n, elem_offset, node_ids, coefs, nnodes, seed, latent_seeds, latent_elems, stream,
+                           "sonar_brownian_f32");
+}
+
+extern "C" int sonar_brownian_point_f32(float* out, float* w_out, const float* prev, float scale, int64_t n, int64_t elem_offset,
+                                        const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed,
+                                        const uint64_t* latent_seeds, int64_t latent_elems, void* stream) {
+    return brownian_launch(out, w_out, prev, scale, n, elem_offset, node_ids, coefs, nnodes, seed, latent_seeds, latent_elems, stream,
+                           "sonar_brownian_point_f32");
 }
 
 extern "C" int sonar_perlin_terms_f32(const float* angles, float* terms, int64_t iters, int64_t C, int64_t H, int64_t W,

@@ -7,6 +7,7 @@ There is NO fallback: a missing library, a CPU tensor or a non-zero return code 
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import Optional, Sequence
 
@@ -83,6 +84,7 @@ SIGNATURES = {
     "sonar_philox_normal_f32": (_I, [_P, _I64, _U64, _U64, _I64, _P, _P]),
     "sonar_philox_uniform_f32": (_I, [_P, _I64, _U64, _U64, _I64, _F, _F, _F, _P, _P]),
     "sonar_brownian_f32": (_I, [_P, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
+    "sonar_brownian_point_f32": (_I, [_P, _P, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_perlin_terms_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "sonar_perlin_lattice_f32": (_I, [_P, _I64, _I64, _I64, _I64, _I, _U64, _U64, _P]),
     "sonar_perlin_apply_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P]),
@@ -466,6 +468,20 @@ def brownian(shape, device, node_ids, coefs, seed: int, elem_offset: int = 0, la
     _check(load().sonar_brownian_f32(_dev(out, "out"), n, elem_offset, ids, cf, len(node_ids), seed & (2**64 - 1),
                                      None if latent_seeds is None else latent_seeds.data_ptr(), latent_elems, _stream()), "sonar_brownian_f32")
     return out
+
+
+def brownian_point(shape, device, node_ids, coefs, seed: int, elem_offset: int = 0, latent_seeds: Optional[torch.Tensor] = None, *,
+                   prev: Optional[torch.Tensor] = None, scale: float = 1.0, want_out: bool = True, want_w: bool = True):
+    """W = sum_k coefs[k] z(node_ids[k], e) (ONE path point); returns (scale * (W - prev) or None, W or None)."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device) if want_out else None
+    w = torch.empty(tuple(shape), dtype=torch.float32, device=device) if want_w else None
+    n = math.prod(shape)
+    ids = (C.c_uint64 * len(node_ids))(*[int(v) & (2**64 - 1) for v in node_ids])
+    cf = (C.c_float * len(coefs))(*[float(v) for v in coefs])
+    _check(load().sonar_brownian_point_f32(_opt(out, "out"), _opt(w, "w_out"), _opt(prev, "prev"), float(scale), n, elem_offset, ids, cf,
+                                           len(node_ids), seed & (2**64 - 1), None if latent_seeds is None else latent_seeds.data_ptr(),
+                                           n // shape[0], _stream()), "sonar_brownian_point_f32")
+    return out, w
 
 
 def perlin_terms(angles: torch.Tensor, blend_mode: str = "lerp") -> torch.Tensor:

@@ -889,11 +889,47 @@ class BrownianTreeNoiseSampler:
             self.seed = int(seed)
         self.elem_offset = current_batch_offset() * (x.numel() // x.shape[0])  # batch shards draw their own global elements
 
+    CACHE_POINTS = 3  # W(t) tensors kept (a sampler step ends where the next begins; DPM++ SDE asks (t, s) and (t, t') per step)
+
+    def _point_terms(self, t: float):
+        terms = self.path.coefficients(t)
+        ids = sorted(terms)
+        return ids, [terms[k] for k in ids]
+
     def __call__(self, sigma, sigma_next) -> Tensor:
         t0, t1 = float(self.transform(torch.as_tensor(sigma))), float(self.transform(torch.as_tensor(sigma_next)))
         sign = self.sign * (1.0 if t0 <= t1 else -1.0)
-        ids, coefs = self.path.increment(t0, t1)
-        return hip_lib.brownian(self.shape, self.device, ids, [c * sign for c in coefs], self.seed, self.elem_offset, self.latent_seeds)
+        ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
+        if self.CACHE_POINTS <= 0 or ta == tb:
+            ids, coefs = self.path.increment(t0, t1)
+            return hip_lib.brownian(self.shape, self.device, ids, [c * sign for c in coefs], self.seed, self.elem_offset, self.latent_seeds)
+        # end-point form: out = (W(tb) - W(ta)) / sqrt(tb - ta) with the W(t) tensors of the last few end points kept -- one new
+        # point per call (~16 path nodes) instead of a merged pair of paths (~27)
+        cache = self.__dict__.setdefault("_points", {})
+        scale = sign / math.sqrt(tb - ta)
+        args = (self.shape, self.device)
+        tail = (self.seed, self.elem_offset, self.latent_seeds)
+
+        def remember(t, w):
+            cache.pop(t, None)
+            cache[t] = w
+            while len(cache) > self.CACHE_POINTS:
+                cache.pop(next(iter(cache)))
+
+        wa, wb = cache.get(ta), cache.get(tb)
+        if wa is not None and wb is not None:
+            out = hip_lib.blend("subtract_b", wb, wa, 1.0)
+            return hip_lib.mul_scalar(out, scale, out=out)
+        if wa is None and wb is None:
+            _, wa = hip_lib.brownian_point(*args, *self._point_terms(ta), *tail, want_out=False)
+            remember(ta, wa)
+        if wb is None:
+            out, wb = hip_lib.brownian_point(*args, *self._point_terms(tb), *tail, prev=wa, scale=scale)
+            remember(tb, wb)
+            return out
+        out, wa = hip_lib.brownian_point(*args, *self._point_terms(ta), *tail, prev=wb, scale=-scale)  # scale * (W(tb) - W(ta))
+        remember(ta, wa)
+        return out
 
 
 class BrownianNoiseGenerator(NoiseGenerator):

@@ -187,6 +187,12 @@ int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t stre
  * 4 values.  latent_seeds (device, nullable): one seed per latent (the sampler's batched-seed mode), replacing `seed`. */
 int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, const uint64_t* node_ids, const float* coefs, int nnodes,
                        uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems, void* stream);
+/* One path point instead of an increment: W = sum_k coefs[k] z(node_ids[k], e) with the coefficients of W(t) itself;
+ * w_out = W (nullable) and out = scale * (W - prev) (out, prev nullable; prev = a W(t') kept from an earlier call).  A sampler's
+ * consecutive calls share an end point, so caching the last few W(t) tensors needs ~16 path nodes per call instead of ~27. */
+int sonar_brownian_point_f32(float* out, float* w_out, const float* prev, float scale, int64_t n, int64_t elem_offset,
+                             const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed,
+                             const uint64_t* latent_seeds, int64_t latent_elems, void* stream);
 
 /* ---------------------------------------------------------------- Perlin (row P) */
 /* py/noise_generation.py:465-476,388-405 at the only position generate() uses (grid == output,
