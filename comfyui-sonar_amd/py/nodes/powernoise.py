@@ -198,8 +198,21 @@ class PowerNoiseItem(CustomNoiseItemBase):
                 noise = hip_lib.power_irfft2(z.to(device).contiguous(), filt, shape, partials=partials if identity else None)
             if not identity:
                 noise = mixer(noise, shape, partials=partials)
+            if defer_factor:
+                return noise
             return scale_noise(attach_stats(noise, partials), self.factor, normalized=normalized)
 
+        defer_factor = False
+        if not normalized:
+            def unscaled(sigma, sigma_next):  # a chain folds the factor into its accumulation kernel (CustomNoiseChain)
+                nonlocal defer_factor
+                defer_factor = True
+                try:
+                    return sampler(sigma, sigma_next), float(self.factor)
+                finally:
+                    defer_factor = False
+
+            sampler.unscaled = unscaled
         return sampler
 
     def make_noise_sampler(self, x: Tensor, sigma_min, sigma_max, *, seed, cpu: bool = True, normalized=True):

@@ -147,9 +147,23 @@ class CustomNoiseChain:
         factor = self.factor
 
         def noise_sampler(sigma, sigma_next):
-            total = None
+            # result = sum_i item_i * factor_i (py/noise.py:188-194).  An item that would only multiply by its factor hands back
+            # (raw tensor, factor) instead (`unscaled`), and the multiply rides in the accumulation kernel: y*a + x*b rounds each
+            # product before the add, exactly like mul_ followed by add_, so the sweep is saved without changing a bit.
+            total, first = None, None
             for ns in samplers:
-                total = _accumulate(total, ns(sigma, sigma_next))
+                raw = getattr(ns, "unscaled", None)
+                pair = raw(sigma, sigma_next) if raw is not None else None
+                part, f = pair if pair is not None else (ns(sigma, sigma_next), 1.0)
+                pop_stats(part)
+                if total is None and first is None:
+                    first = (part, f)
+                elif total is None:
+                    total = hip_lib.axpby_(first[0], first[1], part, f)
+                else:
+                    total = hip_lib.axpby_(total, 1.0, part, f)
+            if total is None:
+                total = first[0] if first[1] == 1.0 else scale_noise(first[0], first[1], normalized=False)
             return scale_noise(total, factor, normalized=normalized)
 
         return noise_sampler
@@ -184,6 +198,16 @@ class NoiseSampler:
     @classmethod
     def wrap(cls, f):
         return lambda *args, **kwargs: cls(*args, **kwargs, make_noise_sampler=f)
+
+    def unscaled(self, *args):
+        """(noise before the factor, factor) when this wrapper would only multiply (not normalised); None otherwise."""
+        if self.normalized:
+            return None
+        args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
+        noise = self.noise_sampler(*args)
+        if not hasattr(noise, "to") or noise.dtype != self.dtype or noise.device != self.device or noise.dtype != torch.float32:
+            return scale_noise(noise, self.factor, normalized=False).to(dtype=self.dtype, device=self.device), 1.0
+        return noise, float(self.factor)
 
     def __call__(self, *args, **kwargs):
         args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
