@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kBlock) stats_finalize_kernel(const double* __
 template <int V>
 __global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n, float factor, int normalized,
                                                              float thr_sd, const double* __restrict__ partials,
-                                                             int64_t npart, int64_t n_total) {
+                                                             int64_t npart, int64_t n_total, double* out_partials) {
     __shared__ double red[2 * kBlock / 64];
     __shared__ NormDecision sh;
     NormDecision d{0.f, 1.f, 0, 0};
@@ -128,6 +128,28 @@ __global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n
         d.do_div = 0;
     }
     const bool do_mul = factor != 1.0f;
+    if (out_partials && blockIdx.x == 0) {
+        // statistics of the RESULT, derived from the input's: y = ((x - m) / s) * f  ->  sum y = f (S - n m) / s,
+        // sum y^2 = f^2 (Q - 2 m S + n m^2) / s^2.  A wrapper that normalises this tensor again reads them instead of the tensor.
+        double S = 0.0, Q = 0.0;
+        for (int64_t i = threadIdx.x; i < npart; i += kBlock) {
+            S += partials[2 * i];
+            Q += partials[2 * i + 1];
+        }
+        __syncthreads();
+        block_sum2<kBlock>(S, Q, red);
+        if (threadIdx.x == 0) {
+            const double nt = (double)n_total, m = d.do_sub ? (double)d.mean : 0.0, sd = d.do_div ? (double)d.stdv : 1.0;
+            const double f = do_mul ? (double)factor : 1.0;
+            out_partials[0] = f * (S - nt * m) / sd;
+            out_partials[1] = f * f * (Q - 2.0 * m * S + nt * m * m) / (sd * sd);
+        }
+        for (int j = 1 + threadIdx.x; j < kNPart; j += kBlock) {
+            out_partials[2 * j] = 0.0;
+            out_partials[2 * j + 1] = 0.0;
+        }
+    }
+    if (!d.do_sub && !d.do_div && !do_mul) return;  // nothing to change (every block takes the same decision)
     const int64_t nv = n / V;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     auto f = [&](float v) {
@@ -586,6 +608,37 @@ struct SqAccOp {
     }
 };
 
+// y = y*ymul + x*xmul with the (sum, sumsq) partials of the result: the last accumulation of a noise chain feeds the chain's
+// normalisation without a separate statistics sweep
+__global__ void __launch_bounds__(kBlock) axpby_stats_kernel(float* y, float ymul, const float* __restrict__ x, float xmul, int64_t n,
+                                                              double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
+        Pack<4> py = load<4>(y, i * 4);
+        const Pack<4> px = load<4>(x, i * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float yy = ymul != 1.0f ? py.v[k] * ymul : py.v[k];
+            const float xx = xmul != 1.0f ? px.v[k] * xmul : px.v[k];
+            const float v = yy + xx;
+            py.v[k] = v;
+            s += (double)v;
+            q += (double)v * (double)v;
+        }
+        store<4>(y, i * 4, py);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * 4; i < n; ++i) {
+            const float v = (ymul != 1.0f ? y[i] * ymul : y[i]) + (xmul != 1.0f ? x[i] * xmul : x[i]);
+            y[i] = v;
+            s += (double)v;
+            q += (double)v * (double)v;
+        }
+    write_partial<kBlock>(s, q, partials, red);
+}
+
 struct PowerLawOp {
     float* x;
     float alpha;
@@ -820,21 +873,34 @@ extern "C" int sonar_stats_finalize(const double* partials, int64_t npart, int64
     return check_launch("sonar_stats_finalize");
 }
 
-extern "C" int sonar_scale_noise_f32(float* x, int64_t n, float factor, int normalized, float threshold_std_devs,
-                                     const double* partials, int64_t npart, int64_t n_total, void* stream) {
+static int scale_noise_launch(float* x, int64_t n, float factor, int normalized, float threshold_std_devs, const double* partials,
+                              int64_t npart, int64_t n_total, double* out_partials, void* stream) {
     SONAR_REQUIRE(x && n >= 0, SONAR_ERR_ARG, "sonar_scale_noise_f32: bad argument");
     SONAR_REQUIRE(!normalized || (partials && npart > 0 && n_total > 0), SONAR_ERR_ARG,
                   "sonar_scale_noise_f32: normalized=1 needs partials");
+    SONAR_REQUIRE(!out_partials || (normalized && out_partials != partials), SONAR_ERR_ARG,
+                  "sonar_scale_noise_stats_f32: result statistics need normalized=1 and a separate buffer");
     if (n == 0 || (!normalized && factor == 1.0f)) return SONAR_OK;
     hipStream_t st = (hipStream_t)stream;
     if (aligned16(x)) {
         hipLaunchKernelGGL((scale_noise_kernel<4>), dim3(grid_for(n / 4 + 1, kBlock * 2)), dim3(kBlock), 0, st, x, n,
-                           factor, normalized, threshold_std_devs, partials, npart, n_total);
+                           factor, normalized, threshold_std_devs, partials, npart, n_total, out_partials);
     } else {
         hipLaunchKernelGGL((scale_noise_kernel<1>), dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, st, x, n, factor,
-                           normalized, threshold_std_devs, partials, npart, n_total);
+                           normalized, threshold_std_devs, partials, npart, n_total, out_partials);
     }
     return check_launch("sonar_scale_noise_f32");
+}
+
+extern "C" int sonar_scale_noise_f32(float* x, int64_t n, float factor, int normalized, float threshold_std_devs,
+                                     const double* partials, int64_t npart, int64_t n_total, void* stream) {
+    return scale_noise_launch(x, n, factor, normalized, threshold_std_devs, partials, npart, n_total, nullptr, stream);
+}
+
+extern "C" int sonar_scale_noise_stats_f32(float* x, int64_t n, float factor, float threshold_std_devs, const double* partials,
+                                           int64_t npart, int64_t n_total, double* out_partials, void* stream) {
+    SONAR_REQUIRE(out_partials, SONAR_ERR_ARG, "sonar_scale_noise_stats_f32: bad argument");
+    return scale_noise_launch(x, n, factor, 1, threshold_std_devs, partials, npart, n_total, out_partials, stream);
 }
 
 extern "C" int sonar_std_scale_f32(float* x, int64_t n, float mul, const double* partials, int64_t npart, int64_t n_total,
@@ -844,10 +910,10 @@ extern "C" int sonar_std_scale_f32(float* x, int64_t n, float mul, const double*
     hipStream_t st = (hipStream_t)stream;
     if (aligned16(x))
         hipLaunchKernelGGL((scale_noise_kernel<4>), dim3(grid_for(n / 4 + 1, kBlock * 2)), dim3(kBlock), 0, st, x, n, mul, 2, 0.0f,
-                           partials, npart, n_total);
+                           partials, npart, n_total, (double*)nullptr);
     else
         hipLaunchKernelGGL((scale_noise_kernel<1>), dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, st, x, n, mul, 2, 0.0f, partials,
-                           npart, n_total);
+                           npart, n_total, (double*)nullptr);
     return check_launch("sonar_std_scale_f32");
 }
 
@@ -880,6 +946,14 @@ extern "C" int sonar_blend_tensor_f32(int mode, const float* a, const float* b, 
                   "sonar_blend_tensor_f32: bad argument");
     return launch_ew(BlendTensorOp{mode, a, b, t, tn, out}, n, aligned16(a) && aligned16(b) && aligned16(out),
                      (hipStream_t)stream, "sonar_blend_tensor_f32");
+}
+
+extern "C" int sonar_axpby_stats_f32(float* y, float ymul, const float* x, float xmul, int64_t n, double* partials, void* stream) {
+    SONAR_REQUIRE(x && y && partials && n >= 0 && aligned16(x) && aligned16(y), SONAR_ERR_ARG,
+                  "sonar_axpby_stats_f32: bad argument (16-byte aligned buffers required)");
+    const int g = (int)std::min<int64_t>(kNPart, std::max<int64_t>(1, grid_for(n / 4 + 1, kBlock)));
+    hipLaunchKernelGGL(axpby_stats_kernel, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, y, ymul, x, xmul, n, partials);
+    return check_launch("sonar_axpby_stats_f32");
 }
 
 extern "C" int sonar_axpby_f32(float* y, float ymul, const float* x, float xmul, int64_t n, void* stream) {

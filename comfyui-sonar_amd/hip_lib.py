@@ -65,10 +65,12 @@ SIGNATURES = {
     "sonar_stats_f32": (_I, [_P, _I64, _P, _P]),
     "sonar_stats_finalize": (_I, [_P, _I64, _I64, _P, _P]),
     "sonar_scale_noise_f32": (_I, [_P, _I64, _F, _I, _F, _P, _I64, _I64, _P]),
+    "sonar_scale_noise_stats_f32": (_I, [_P, _I64, _F, _F, _P, _I64, _I64, _P, _P]),
     "sonar_scale_noise_rows_f32": (_I, [_P, _I64, _I64, _F, _P]),
     "sonar_blend_f32": (_I, [_I, _P, _P, _F, _P, _I64, _P]),
     "sonar_blend_tensor_f32": (_I, [_I, _P, _P, _P, _I64, _P, _I64, _P]),
     "sonar_axpby_f32": (_I, [_P, _F, _P, _F, _I64, _P]),
+    "sonar_axpby_stats_f32": (_I, [_P, _F, _P, _F, _I64, _P, _P]),
     "sonar_affine_f32": (_I, [_P, _F, _F, _F, _I64, _P]),
     "sonar_scalar_op_f32": (_I, [_I, _P, _P, _F, _P, _I64, _P]),
     "sonar_rowstats_f32": (_I, [_P, _I64, _I64, _P, _P, _P]),
@@ -165,9 +167,14 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+STATS_ATTR = "_sonar_partials"  # see py/utils.py attach_stats / pop_stats
+
+
 def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
+    if STATS_ATTR in t.__dict__:  # any kernel that touches a tagged tensor drops its statistics tag (producers tag AFTER their launch)
+        del t.__dict__[STATS_ATTR]
     if not t.is_cuda:
         raise SonarHipError(f"{name}: tensor lives on {t.device}; the Sonar HIP path only runs on a ROCm device")
     if t.dtype != dtype:
@@ -215,6 +222,17 @@ def scale_noise_(x: torch.Tensor, factor: float, normalized: bool, partials: Opt
     return x
 
 
+def scale_noise_stats_(x: torch.Tensor, factor: float, partials: torch.Tensor, *, threshold_std_devs: float = 2.5, npart: int = NPART,
+                       n_total: Optional[int] = None):
+    """scale_noise_(normalized=True) that also returns the (sum, sumsq) partials of the result (derived, no extra pass)."""
+    n = x.numel()
+    out_partials = new_partials(x.device)
+    _check(load().sonar_scale_noise_stats_f32(_dev(x, "x"), n, float(factor), float(threshold_std_devs), _dev(partials, "partials", torch.float64),
+                                              npart, n if n_total is None else n_total, out_partials.data_ptr(), _stream()),
+           "sonar_scale_noise_stats_f32")
+    return x, out_partials
+
+
 def scale_noise_rows_(x: torch.Tensor, rows: int, inner: int, factor: float) -> torch.Tensor:
     _check(load().sonar_scale_noise_rows_f32(_dev(x, "x"), rows, inner, float(factor), _stream()), "sonar_scale_noise_rows_f32")
     return x
@@ -252,6 +270,18 @@ def axpby_(y: torch.Tensor, ymul: float, x: torch.Tensor, xmul: float) -> torch.
         raise SonarHipError(f"axpby: shape mismatch {tuple(x.shape)} vs {tuple(y.shape)}")
     _check(load().sonar_axpby_f32(_dev(y, "y"), float(ymul), _dev(x, "x"), float(xmul), y.numel(), _stream()), "sonar_axpby_f32")
     return y
+
+
+def axpby_stats_(y: torch.Tensor, ymul: float, x: torch.Tensor, xmul: float, partials: Optional[torch.Tensor] = None):
+    """axpby_ that also returns the (sum, sumsq) partials of the result; falls back to axpby_ + stats for unaligned views."""
+    if x.shape != y.shape:
+        raise SonarHipError(f"axpby: shape mismatch {tuple(x.shape)} vs {tuple(y.shape)}")
+    partials = new_partials(y.device) if partials is None else partials
+    if (y.data_ptr() | x.data_ptr()) & 15:
+        return axpby_(y, ymul, x, xmul), stats(y, partials)
+    _check(load().sonar_axpby_stats_f32(_dev(y, "y"), float(ymul), _dev(x, "x"), float(xmul), y.numel(), partials.data_ptr(), _stream()),
+           "sonar_axpby_stats_f32")
+    return y, partials
 
 
 def affine_(x: torch.Tensor, sub: float, mul: float, add: float) -> torch.Tensor:

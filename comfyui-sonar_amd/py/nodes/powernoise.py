@@ -185,7 +185,7 @@ class PowerNoiseItem(CustomNoiseItemBase):
             if self.time_brownian:
                 # real noise in: rfft2 -> x filter -> irfft2, forward and inverse both LDS-resident (py/nodes/powernoise.py:356-366)
                 pop_stats(z)
-                noise = hip_lib.spectral_filter(z.to(device).contiguous(), filt, partials if identity else None)
+                noise = hip_lib.spectral_filter(z.to(device).contiguous(), filt, partials if (identity and normalized) else None)
             elif z is None:
                 seed, stream = DeviceRNG.take()
                 offs = current_batch_offset() * planes_per_latent
@@ -193,9 +193,9 @@ class PowerNoiseItem(CustomNoiseItemBase):
                     # draw + filter + FFT + normalise with a single write of the tensor
                     return hip_lib.power_noise(filt, shape, seed=seed, stream_id=stream, plane_offset=offs, factor=self.factor)
                 noise = hip_lib.power_irfft2(None, filt, shape, seed=seed, stream_id=stream, plane_offset=offs,
-                                             partials=partials if identity else None)
+                                             partials=partials if (identity and normalized) else None)
             else:
-                noise = hip_lib.power_irfft2(z.to(device).contiguous(), filt, shape, partials=partials if identity else None)
+                noise = hip_lib.power_irfft2(z.to(device).contiguous(), filt, shape, partials=partials if (identity and normalized) else None)
             if not identity:
                 noise = mixer(noise, shape, partials=partials)
             if defer_factor:

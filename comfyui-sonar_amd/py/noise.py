@@ -151,17 +151,20 @@ class CustomNoiseChain:
             # (raw tensor, factor) instead (`unscaled`), and the multiply rides in the accumulation kernel: y*a + x*b rounds each
             # product before the add, exactly like mul_ followed by add_, so the sweep is saved without changing a bit.
             total, first = None, None
-            for ns in samplers:
+            for idx, ns in enumerate(samplers):
                 raw = getattr(ns, "unscaled", None)
                 pair = raw(sigma, sigma_next) if raw is not None else None
                 part, f = pair if pair is not None else (ns(sigma, sigma_next), 1.0)
                 pop_stats(part)
                 if total is None and first is None:
                     first = (part, f)
-                elif total is None:
-                    total = hip_lib.axpby_(first[0], first[1], part, f)
+                    continue
+                y, ymul = (first if total is None else (total, 1.0))
+                if normalized and idx == len(samplers) - 1:  # the last accumulation also reduces the statistics scale_noise needs
+                    total, partials = hip_lib.axpby_stats_(y, ymul, part, f)
+                    utils.attach_stats(total, partials)
                 else:
-                    total = hip_lib.axpby_(total, 1.0, part, f)
+                    total = hip_lib.axpby_(y, ymul, part, f)
             if total is None:
                 total = first[0] if first[1] == 1.0 else scale_noise(first[0], first[1], normalized=False)
             return scale_noise(total, factor, normalized=normalized)

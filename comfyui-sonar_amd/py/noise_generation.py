@@ -216,6 +216,12 @@ class NoiseGenerator:
 
     def __call__(self, *args, **kwargs):
         self.pre_hook()
+        fused = getattr(self, "generate_normalized", None)
+        if (fused is not None and not kwargs and self.normalized and self.force_normalize in (None, True) and self.normalize_dims is None):
+            # generate + the output hook's scale_noise(normalized=True) as the generator's fused path (device draws: one write)
+            noise = fused(1.0, *args)
+            if noise is not None:
+                return noise
         return self.output_hook(self.generate(*args, **kwargs))
 
     def __str__(self):

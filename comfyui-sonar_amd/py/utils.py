@@ -17,7 +17,7 @@ Tensor = torch.Tensor
 UPSCALE_METHODS = ("bilinear", "nearest-exact", "nearest", "area", "bicubic", "bislerp", "adaptive_avg_pool2d")
 _HIP_RESAMPLE = {"bilinear", "nearest-exact", "area", "adaptive_avg_pool2d"}
 
-_STATS_ATTR = "_sonar_partials"
+_STATS_ATTR = hip_lib.STATS_ATTR
 
 
 def fallback(val, default=None):
@@ -30,15 +30,19 @@ def fallback(val, default=None):
 # re-reading the tensor.  Any in-package op that changes the values must drop the tag first.
 def attach_stats(t: Tensor, partials: Optional[Tensor]) -> Tensor:
     if partials is not None:
-        setattr(t, _STATS_ATTR, partials)
+        setattr(t, _STATS_ATTR, (partials, t._version))
     return t
 
 
 def pop_stats(t: Tensor) -> Optional[Tensor]:
+    """The tag is honoured only if nothing wrote to the tensor since: torch's in-place ops bump ``_version``; every kernel of this
+    library that is handed the tensor drops the tag (hip_lib._dev)."""
     p = getattr(t, _STATS_ATTR, None)
-    if p is not None:
-        delattr(t, _STATS_ATTR)
-    return p
+    if p is None:
+        return None
+    delattr(t, _STATS_ATTR)
+    partials, version = p
+    return partials if version == t._version else None
 
 
 def _require_device(t: Tensor, what: str) -> None:
@@ -110,7 +114,8 @@ def scale_noise(noise: Tensor, factor: float = 1.0, *, normalized: bool = True, 
     partials = pop_stats(noise)
     if partials is None:
         partials = hip_lib.stats(noise)
-    return hip_lib.scale_noise_(noise, factor, True, partials, threshold_std_devs=threshold_std_devs)
+    noise, after = hip_lib.scale_noise_stats_(noise, factor, partials, threshold_std_devs=threshold_std_devs)
+    return attach_stats(noise, after)  # a wrapper that normalises this result again skips its statistics sweep
 
 
 def scale_samples(samples: Tensor, width: int, height: int, *, mode: str = "bicubic") -> Tensor:

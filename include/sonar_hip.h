@@ -63,6 +63,11 @@ int sonar_stats_finalize(const double* partials, int64_t npart, int64_t n, doubl
  * n when the stats were all-reduced over ranks).  In place. */
 int sonar_scale_noise_f32(float* x, int64_t n, float factor, int normalized, float threshold_std_devs,
                           const double* partials, int64_t npart, int64_t n_total, void* stream);
+/* sonar_scale_noise_f32(normalized = 1) that also writes the (sum, sumsq) of the RESULT into out_partials (1024 pairs; derived from the
+ * input statistics and the decision, no extra pass), so a wrapper that normalises the same tensor again (chain -> scheduled -> chain,
+ * py/noise.py:194,676,1405) needs no statistics sweep; when the decision is "leave as is" the kernel returns without touching x. */
+int sonar_scale_noise_stats_f32(float* x, int64_t n, float factor, float threshold_std_devs, const double* partials,
+                                int64_t npart, int64_t n_total, double* out_partials, void* stream);
 /* py/utils.py:96-99 — normalize_dims variant: rows = groups, each of `inner` contiguous elements:
  * y = x/std_row; y -= mean_row(y); y *= factor.  (dims must be trailing & contiguous) */
 int sonar_scale_noise_rows_f32(float* x, int64_t rows, int64_t inner, float factor, void* stream);
@@ -75,6 +80,8 @@ int sonar_blend_tensor_f32(int mode, const float* a, const float* b, const float
                            int64_t n, void* stream);
 /* y = y*ymul + x*xmul  (chain accumulate py/noise.py:192; ancestral noise add py/sonar.py:565) */
 int sonar_axpby_f32(float* y, float ymul, const float* x, float xmul, int64_t n, void* stream);
+/* the same, and the (sum, sumsq) partials of the result (1024 fp64 pairs): the last accumulation of a chain feeds its scale_noise */
+int sonar_axpby_stats_f32(float* y, float ymul, const float* x, float xmul, int64_t n, double* partials, void* stream);
 /* CompositeNoise py/noise.py:524-531: out = dst*(1-mask) + src*mask; mask is [mask_n] broadcast over n/mask_n */
 int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,
                        int64_t n, void* stream);
