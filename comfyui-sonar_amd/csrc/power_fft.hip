@@ -23,12 +23,21 @@ namespace sonar {
 
 using c32 = float2;
 
-__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// complex arithmetic on native 2-vectors: one register pair per complex value, packed adds / multiplies / FMAs, swaps and sign
+// flips as operand modifiers (scalar .x / .y expressions let the vectoriser pair halves of DIFFERENT values and pay for it in moves)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f vv(c32 a) { return v2f{a.x, a.y}; }
+__device__ __forceinline__ c32 cc(v2f a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return cc(vv(a) + vv(b)); }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return cc(vv(a) - vv(b)); }
 __device__ __forceinline__ c32 cmul(c32 a, c32 b) {
-    return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+    const v2f A = vv(a), B = vv(b);
+    return cc(__builtin_elementwise_fma(A.yy, v2f{-B.y, B.x}, A.xx * B));
 }
 __device__ __forceinline__ c32 cmul_i(c32 a) { return make_float2(-a.y, a.x); }  // a * (+i)
+__device__ __forceinline__ c32 cadd_i(c32 a, c32 b) { return cc(vv(a) + v2f{-b.y, b.x}); }   // a + i b
+__device__ __forceinline__ c32 csub_i(c32 a, c32 b) { return cc(vv(a) - v2f{-b.y, b.x}); }   // a - i b
+__device__ __forceinline__ c32 cscale(c32 a, float r) { return cc(vv(a) * r); }
 
 // ---- register codelets: in-place inverse (sign +) DFTs, natural order in and out -------------
 template <int N>
@@ -47,11 +56,11 @@ __device__ __forceinline__ void idft<2>(c32 (&v)[2]) {
 template <>
 __device__ __forceinline__ void idft<4>(c32 (&v)[4]) {
     const c32 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-    const c32 t2 = cadd(v[1], v[3]), t3 = cmul_i(csub(v[1], v[3]));
+    const c32 t2 = cadd(v[1], v[3]), t3 = csub(v[1], v[3]);
     v[0] = cadd(t0, t2);
     v[2] = csub(t0, t2);
-    v[1] = cadd(t1, t3);
-    v[3] = csub(t1, t3);
+    v[1] = cadd_i(t1, t3);
+    v[3] = csub_i(t1, t3);
 }
 
 template <>
@@ -62,12 +71,11 @@ __device__ __forceinline__ void idft<8>(c32 (&v)[8]) {
     idft<4>(e);
     idft<4>(o);
     const c32 t0 = o[0];
-    const c32 t1 = make_float2(r * (o[1].x - o[1].y), r * (o[1].x + o[1].y));   // * e^{i pi/4}
-    const c32 t2 = cmul_i(o[2]);                                                // * i
-    const c32 t3 = make_float2(-r * (o[3].x + o[3].y), r * (o[3].x - o[3].y));  // * e^{3 i pi/4}
+    const c32 t1 = cscale(cadd_i(o[1], o[1]), r);              // * e^{i pi/4}  = r (o + i o)
+    const c32 t3 = cscale(csub(cmul_i(o[3]), o[3]), r);        // * e^{3 i pi/4} = r (i o - o)
     v[0] = cadd(e[0], t0); v[4] = csub(e[0], t0);
     v[1] = cadd(e[1], t1); v[5] = csub(e[1], t1);
-    v[2] = cadd(e[2], t2); v[6] = csub(e[2], t2);
+    v[2] = cadd_i(e[2], o[2]); v[6] = csub_i(e[2], o[2]);      // * i
     v[3] = cadd(e[3], t3); v[7] = csub(e[3], t3);
 }
 
@@ -85,11 +93,11 @@ __device__ __forceinline__ void idft<16>(c32 (&v)[16]) {
     c32 t[8];
     t[0] = o[0];
     t[1] = cmul(o[1], make_float2(c1, s1));
-    t[2] = make_float2(r * (o[2].x - o[2].y), r * (o[2].x + o[2].y));
+    t[2] = cscale(cadd_i(o[2], o[2]), r);
     t[3] = cmul(o[3], make_float2(s1, c1));
     t[4] = cmul_i(o[4]);
     t[5] = cmul(o[5], make_float2(-s1, c1));
-    t[6] = make_float2(-r * (o[6].x + o[6].y), r * (o[6].x - o[6].y));
+    t[6] = cscale(csub(cmul_i(o[6]), o[6]), r);
     t[7] = cmul(o[7], make_float2(-c1, s1));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -520,10 +528,8 @@ __global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_ker
                             xa = row[k];
                             xb = row[M - k];
                         }
-                        const c32 e = make_float2(xa.x + xb.x, xa.y - xb.y);
-                        const c32 d = make_float2(xa.x - xb.x, xa.y + xb.y);
-                        const c32 o = cmul(d, gtw[n1]);
-                        g[it][n1] = make_float2(e.x - o.y, e.y + o.x);
+                        const c32 xc = make_float2(xb.x, -xb.y);  // conj
+                        g[it][n1] = cadd_i(cadd(xa, xc), cmul(csub(xa, xc), gtw[n1]));
                     }
                     idft<RN1>(g[it]);
 #pragma unroll
