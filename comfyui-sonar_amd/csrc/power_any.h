@@ -107,7 +107,7 @@ __device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw
 #pragma unroll
         for (int j = 0; j < kAnyPer; ++j) {
             const int idx = tid + j * kAnyThreads;
-            float p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, p4 = 0.0f;
+            v2f pa = {0.0f, 0.0f}, pb = {0.0f, 0.0f};  // (sum v.x w.x, sum v.x w.y) and (sum v.y w.y, sum v.y w.x): two packed FMAs per term
             int k = 0, g = 0;
             where[j] = -1;
             if (idx < total) {
@@ -127,18 +127,16 @@ __device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw
                 int t = 0;
 #pragma unroll 2
                 for (int n = 0; n < K; ++n) {
-                    const c32 v = src[0];
-                    const c32 w = tw[t];
-                    p1 = __builtin_fmaf(v.x, w.x, p1);
-                    p2 = __builtin_fmaf(v.y, w.y, p2);
-                    p3 = __builtin_fmaf(v.x, w.y, p3);
-                    p4 = __builtin_fmaf(v.y, w.x, p4);
+                    const v2f v = vv(src[0]), w = vv(tw[t]);
+                    pa = __builtin_elementwise_fma(v.xx, w, pa);
+                    pb = __builtin_elementwise_fma(v.yy, w.yx, pb);
                     src += sstep;
                     t += step;
                     if (t >= TN) t -= TN;
                 }
             }
             // sum v w = (p1 - p2, p3 + p4) belongs to k for the inverse (w) and to K - k for the forward (conj w); sum v conj(w) the other
+            const float p1 = pa.x, p3 = pa.y, p2 = pb.x, p4 = pb.y;
             c32 a = make_float2(p1 - p2, p3 + p4), b = make_float2(p1 + p2, p4 - p3);
             if (FWD) {
                 const c32 sw = a;
