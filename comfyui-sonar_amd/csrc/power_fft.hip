@@ -139,6 +139,10 @@ constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4
 #define SONAR_FFT_TW_LDS 0  // measured: constant-memory (scalar) twiddles 78 us vs LDS table 125 us at B=512
 #endif
 constexpr int kFftThreads = SONAR_FFT_THREADS;  // waves per block x two blocks per CU (LDS-bound)
+// threads (= RNG thread slots) of a fixed-size plane's workgroup: 512 from 8192 values up, smaller planes take fewer so that
+// every pass has work for all of them (64 x 64: 256; 32 x 32: 128; 16 x 16: 64) and more workgroups share a CU
+template <int H, int W>
+constexpr int plane_threads() { return H * W >= 8192 ? kFftThreads : H * W >= 2048 ? 256 : H * W >= 1024 ? 128 : 64; }
 
 template <int H, int W>
 struct PlaneCfg {
@@ -183,11 +187,11 @@ __device__ __forceinline__ SpectrumRng spectrum_rng(uint64_t seed, uint64_t stre
 template <int W>
 constexpr int draw_shift() { int l = 0; while ((1 << l) < W / 2) ++l; return l; }
 template <int H, int W>
-constexpr int draw_iters() { return ((H / 2) * (W / 2) + kFftThreads - 1) / kFftThreads; }
+constexpr int draw_iters() { return ((H / 2) * (W / 2) + plane_threads<H, W>() - 1) / plane_threads<H, W>(); }
 
 template <int H, int W, bool NEED_T, int UNROLL = 0, typename Edge, typename Pair>
 __device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge, Pair&& pair) {
-    constexpr int NT = kFftThreads, M = W / 2, LM = draw_shift<W>(), PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
+    constexpr int NT = plane_threads<H, W>(), M = W / 2, LM = draw_shift<W>(), PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
     constexpr int UNR = UNROLL > 0 ? UNROLL : ITER;  // 0 = full (the statistics pass indexes registers by `it`)
     if (tid < H) {  // row ky = tid of the edge columns: radius word of kx = 0, of kx = M, then one angle word for both
         const uint32_t r0 = g.E.next_high();
@@ -252,7 +256,7 @@ __device__ __forceinline__ c32 drawn_elem(uint32_t r, uint32_t t16, float f) {
 // requested while pair it is drawn (the compiler otherwise issues each load right in front of its use).
 template <int H, int W, int S>
 __device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter, SpectrumRng& g, int tid, c32* A, c32* T0, c32* TM) {
-    constexpr int NT = kFftThreads, M = W / 2, Wh = M + 1, LM = draw_shift<W>(), PAIRS = (H / 2) * M;
+    constexpr int NT = plane_threads<H, W>(), M = W / 2, Wh = M + 1, LM = draw_shift<W>(), PAIRS = (H / 2) * M;
     auto fpos = [&](int p) { return (p >> LM) * Wh + 1 + (p & (M - 1)); };
     const int p0 = min(tid, PAIRS - 1);
     float fa = filter[fpos(p0)], fb = filter[fpos(p0) + (H / 2) * Wh];
@@ -278,7 +282,7 @@ __device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter,
 template <int H, int W, typename Sink>
 __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const float* __restrict__ filter, int64_t plane, int tid,
                                            Sink&& sink) {
-    constexpr int NT = kFftThreads;
+    constexpr int NT = plane_threads<H, W>();
     constexpr int Wh = W / 2 + 1, NC = H * Wh, HALF = NC / 2;
     // (ky, kx) of linear index j, advanced incrementally (no per-element division); the partner element
     // j + HALF = j + (H/2) * Wh sits in the same column, H/2 rows below
@@ -305,13 +309,13 @@ __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const fl
 // SRC: 0 = spectrum `z` supplied (replay), 1 = spectrum drawn on device, 2 = `z` is a REAL H x W plane: forward r2c FFT in
 // LDS, x filter, then the same inverse (spectral filter: out = irfft2(rfft2(x) * filter), py/nodes/powernoise.py:356-366)
 template <int H, int W, int SRC, bool STATS, bool NORM>
-__global__ void __launch_bounds__(kFftThreads, SONAR_FFT_WAVES) power_irfft2_kernel(const float* __restrict__ z,
+__global__ void __launch_bounds__((plane_threads<H, W>()), SONAR_FFT_WAVES) power_irfft2_kernel(const float* __restrict__ z,
                                                                        const float* __restrict__ filter, float* out,
                                                                        int64_t planes, uint64_t seed, uint64_t stream_id,
                                                                        int64_t plane_offset, int group, int split, double* partials,
                                                                        NormArgs na) {
     using C = PlaneCfg<H, W>;
-    constexpr int NT = kFftThreads;
+    constexpr int NT = plane_threads<H, W>();
     constexpr int M = C::M, S = C::S;
     constexpr int RN1 = C::RN1, RN2 = C::RN2;
     // FAST shapes (W = 128, H = 64 / 128, 8 waves): every wave owns ONE residue n2 in both twiddled passes, so all
@@ -674,10 +678,10 @@ SONAR_UNROLL_ITEMS
 //   sum x^2  = sum_ky ( |sym(Zf[:,0])[ky]|^2 + |sym(Zf[:,M])[ky]|^2 ) + 2 sum_ky sum_{0<kx<M} |Zf[ky][kx]|^2
 // (only the Hermitian-symmetric part of the kx = 0 and kx = M columns survives the c2r stage).
 template <int H, int W>
-__global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* __restrict__ filter, int64_t planes, uint64_t seed,
+__global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(const float* __restrict__ filter, int64_t planes, uint64_t seed,
                                                                    uint64_t stream_id, int64_t plane_offset, int group, int split,
                                                                    double* partials) {
-    constexpr int NT = kFftThreads, M = W / 2, Wh = M + 1;
+    constexpr int NT = plane_threads<H, W>(), M = W / 2, Wh = M + 1;
     __shared__ c32 EDGE[2][2][H];  // [plane parity][kx = 0 | kx = M][ky]: double-buffered -> one barrier per plane
     __shared__ double red[2 * NT / 64];
     const int tid = threadIdx.x;
@@ -735,7 +739,7 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_kernel(const float* _
 
 // the spectrum draw_plane yields for (seed, stream_id, plane_offset, group), unit filter: zout[planes][H][W/2+1] complex64
 template <int H, int W>
-__global__ void __launch_bounds__(kFftThreads) power_spectrum_kernel(float* zout, int64_t planes, uint64_t seed, uint64_t stream_id,
+__global__ void __launch_bounds__((plane_threads<H, W>())) power_spectrum_kernel(float* zout, int64_t planes, uint64_t seed, uint64_t stream_id,
                                                                       int64_t plane_offset, int group, int split) {
     constexpr int M = W / 2, Wh = M + 1, NC = H * Wh;
     const int tid = threadIdx.x;
@@ -767,7 +771,8 @@ static int power_grid(int64_t planes) {
     using C = PlaneCfg<H, W>;
     static_assert(C::kLdsBytes + 256 <= 160 * 1024, "plane does not fit in LDS");
     // blocks/CU by LDS; persistent grid of resident blocks (<= kNPart so each owns a partial slot)
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (C::kLdsBytes + 256)));
+    // 16 waves per CU at the kernel's 128-VGPR budget
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(1024 / plane_threads<H, W>(), (160 * 1024) / (C::kLdsBytes + 256)));
     return (int)std::min<int64_t>(std::min<int64_t>(planes, (int64_t)256 * per_cu), kNPart);
 }
 
@@ -780,7 +785,7 @@ static int launch_power(int what, const float* z, const float* filter, float* ou
     const int split = group > 1 && planes / group < 2 * 256 ? 1 : 0;
     const int64_t ngroups = split ? planes : planes / group;  // work units
     const int g = power_grid<H, W>(ngroups);
-    const dim3 blk(kFftThreads);
+    const dim3 blk(plane_threads<H, W>());
 #define SONAR_PW(G, ST, NM, PART) \
     hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(g), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, group, split, PART, na)
     if (what == 3) {
