@@ -365,6 +365,145 @@ class GuidedNoise(CustomNoiseItemBase):
         return noise_sampler
 
 
+class RepeatedNoise(CustomNoiseItemBase):
+    """py/noise.py:681-760: a ring of cached noise tensors, re-served flipped / rolled / negated.  Host logic (the u32 draws come
+    from a seeded CPU generator like the reference's); flips and rolls are index permutations done by torch on the device tensor,
+    the arithmetic (negation, normalisation) by the HIP kernels.  Like the reference, a tensor served without a permutation is
+    returned as a plain clone, without the factor."""
+
+    def __init__(self, factor, *, noise, **kwargs):
+        super().__init__(factor, noise=noise.clone(), **kwargs)
+
+    def clone_key(self, k):
+        return self.noise.clone() if k == "noise" else super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        factor, repeat_length, max_recycle, permute = self.factor, self.repeat_length, self.max_recycle, self.permute
+        normalize = self.get_normalize("normalize", normalized)
+        ns = self.noise.make_noise_sampler(x, *args, normalized=False, **kwargs)
+        items: list = []
+        u32_max = 0xFFFF_FFFF
+        seed = kwargs.get("seed")
+        if seed is None:
+            seed = torch.randint(-u32_max, u32_max, (1,), device="cpu", dtype=torch.int64).item()
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(seed)
+        last_idx = -1
+
+        def fresh(s, sn):
+            t = ns(s, sn)
+            pop_stats(t)
+            return t
+
+        def noise_sampler(s, sn):
+            nonlocal last_idx
+            rands = torch.randint(u32_max, (4,), generator=gen, dtype=torch.uint32).tolist()
+            skip_permute = permute == "disabled"
+            if len(items) < repeat_length:
+                idx = len(items)
+                noise = fresh(s, sn)
+                items.append((1, noise))
+                skip_permute = permute != "always"
+            else:
+                idx = rands[0] % repeat_length
+                if idx == last_idx:
+                    idx = (idx + 1) % repeat_length
+                count, noise = items[idx]
+                if count >= max_recycle:
+                    noise = fresh(s, sn)
+                    items[idx] = (1, noise)
+                    skip_permute = permute != "always"
+                else:
+                    items[idx] = (count + 1, noise)
+            last_idx = idx
+            if skip_permute:
+                return noise.clone()
+            dims = noise.ndim
+            if rands[1] % 2 == 0:
+                if rands[2] <= u32_max // 5:
+                    noise = noise.clone()
+                    if rands[2] & 1 == 1:
+                        hip_lib.mul_scalar(noise, -1.0, out=noise)
+                else:
+                    noise = torch.flip(noise, tuple({rands[2] % dims, rands[3] % dims}))
+            else:
+                dim = rands[2] % dims
+                noise = torch.roll(noise, rands[3] % noise.shape[dim], dims=(dim,)).clone()
+            return scale_noise(noise.contiguous(), factor, normalized=normalize)
+
+        return noise_sampler
+
+
+class RandomNoise(CustomNoiseItemBase):
+    """py/noise.py:1022-1073: one (or the sum of ``mix_count`` distinct) randomly chosen item(s) of a chain per call; the choice comes
+    from torch's global CPU generator like the reference's."""
+
+    def __init__(self, factor, *, noise, mix_count, normalize):
+        if len(noise.items) == 0:
+            raise ValueError("RandomNoise requires ta least one noise item")
+        super().__init__(factor, noise=noise.clone(), mix_count=mix_count, normalize=normalize)
+
+    def clone_key(self, k):
+        return self.noise.clone() if k == "noise" else super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        factor = self.factor
+        samplers = tuple(ni.make_noise_sampler(x, *args, normalized=False, **kwargs) for ni in self.noise.items)
+        count = len(samplers)
+        mix_count = min(self.mix_count, count)
+        normalize = self.get_normalize("normalize", normalized or mix_count > 1)
+
+        def noise_sampler(s, sn):
+            if mix_count == 1:
+                return scale_noise(samplers[torch.randint(count, (1,)).item()](s, sn), factor, normalized=normalize)
+            seen = set()
+            while len(seen) < mix_count:
+                seen.add(torch.randint(count, (1,)).item())
+            idxs = tuple(seen)
+            noise = samplers[idxs[0]](s, sn)
+            for i in idxs[1:]:
+                noise = _accumulate(noise, samplers[i](s, sn))
+            return scale_noise(noise, factor, normalized=normalize)
+
+        return noise_sampler
+
+
+class ChannelNoise(CustomNoiseItemBase):
+    """py/noise.py:1076-1131: a different chain item per channel (wrap / repeat / zero when there are fewer items than channels)."""
+
+    def __init__(self, factor, *, noise, insufficient_channels_mode, normalize):
+        if len(noise.items) == 0:
+            raise ValueError("ChannelNoise requires at least one noise item")
+        if insufficient_channels_mode not in {"wrap", "repeat", "zero"}:
+            raise ValueError("Bad insufficient_channels_mode")
+        super().__init__(factor, noise=noise.clone(), insufficient_channels_mode=insufficient_channels_mode, normalize=normalize)
+
+    def clone_key(self, k):
+        return self.noise.clone() if k == "noise" else super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        factor, mode = self.factor, self.insufficient_channels_mode
+        c = x.shape[1]
+        chosen = list(self.noise.items[:c])
+        given = len(chosen)
+        while len(chosen) < c:
+            chosen.append(chosen[len(chosen) % given] if mode == "wrap" else chosen[given - 1] if mode == "repeat" else None)
+        samplers = []
+        for ch, item in enumerate(chosen):
+            xs = x[:, ch:ch + 1, ...].contiguous()
+            if item is None:
+                samplers.append(lambda _s, _sn, xs=xs: torch.zeros_like(xs))
+            else:
+                samplers.append(item.make_noise_sampler(xs, *args, normalized=False, **kwargs))
+        normalize = self.get_normalize("normalize", normalized)
+
+        def noise_sampler(s, sn):
+            noise = torch.cat(tuple(ns(s, sn) for ns in samplers), dim=1)  # channel interleave: a copy, no arithmetic
+            return scale_noise(noise, factor, normalized=normalize)
+
+        return noise_sampler
+
+
 class ModulatedNoise(CustomNoiseItemBase):
     """py/noise.py:762-1019: noise shaped by the local busyness of a reference latent (or of the sampler's x).  ``intensity`` and
     ``frequency`` run as HIP kernels (std over the modulation dims -> broadcast gain -> [LDS-resident rfft2 x boost x irfft2] ->

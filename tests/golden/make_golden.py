@@ -789,6 +789,37 @@ def gen_modulated():
     save("modulated", **cases)
 
 
+def gen_item_wrappers():
+    """RandomNoise / RepeatedNoise / ChannelNoise (py/noise.py:681-760, 1022-1131): sequences of calls on gaussian / uniform items."""
+    cases = {}
+    N = ref.noise
+    shape = (2, 4, 8, 8)
+
+    def chain(*specs):
+        c = N.CustomNoiseChain()
+        for name, f in specs:
+            c.add(N.CustomNoiseItem(f, noise_type=name))
+        return c
+
+    sig = (torch.tensor(9.0), torch.tensor(6.0))
+    for mix in (1, 2):
+        item = N.RandomNoise(0.7, noise=chain(("gaussian", 1.0), ("uniform", 0.5), ("perlin", 0.8)), mix_count=mix, normalize=None)
+        torch.manual_seed(41)
+        ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=41, cpu=True, normalized=True)
+        cases[f"random_mix{mix}"] = torch.stack([ns(*sig) for _ in range(4)])
+    for permute in ("enabled", "always", "disabled"):
+        item = N.RepeatedNoise(0.9, noise=chain(("gaussian", 1.0)), repeat_length=2, max_recycle=3, normalize=None, permute=permute)
+        torch.manual_seed(42)
+        ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=42, cpu=True, normalized=True)
+        cases[f"repeated_{permute}"] = torch.stack([ns(*sig) for _ in range(9)])
+    for mode in ("wrap", "repeat", "zero"):
+        item = N.ChannelNoise(1.1, noise=chain(("gaussian", 1.0), ("uniform", 0.5)), insufficient_channels_mode=mode, normalize=None)
+        torch.manual_seed(43)
+        ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=43, cpu=True, normalized=True)
+        cases[f"channel_{mode}"] = torch.stack([ns(*sig) for _ in range(2)])
+    save("item_wrappers", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -811,6 +842,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_wavelet_noise()
     gen_guided_noise()
     gen_modulated()
+    gen_item_wrappers()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

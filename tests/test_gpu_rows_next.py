@@ -403,3 +403,52 @@ def test_modulated_noise_full_size_properties_and_node(api):
     with pytest.raises(NotImplementedError):
         api.noise.ModulatedNoise(1.0, noise=_gauss_chain(api), normalize_result=None, normalize_noise=None, normalize_ref=True,
                                  modulation_type="spectral_signum")
+
+
+# ------------------------------------------------------------------------------------------------ item wrappers
+def _chain(api, *specs):
+    c = api.noise.CustomNoiseChain()
+    for name, f in specs:
+        c.add(api.noise.CustomNoiseItem(f, noise_type=name))
+    return c
+
+
+def _sequence(ns, n):
+    return torch.stack([ns(torch.tensor(9.0), torch.tensor(6.0)).cpu() for _ in range(n)])
+
+
+@pytest.mark.parametrize("mix", [1, 2])
+def test_random_noise(api, golden, mix):
+    g = golden("item_wrappers")
+    item = api.noise.RandomNoise(0.7, noise=_chain(api, ("gaussian", 1.0), ("uniform", 0.5), ("perlin", 0.8)), mix_count=mix, normalize=None)
+    torch.manual_seed(41)
+    ns = item.clone().make_noise_sampler(torch.zeros(2, 4, 8, 8, device="cuda"), 0.03, 14.6, seed=41, cpu=True, normalized=True)
+    close(_sequence(ns, 4), g[f"random_mix{mix}"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("permute", ["enabled", "always", "disabled"])
+def test_repeated_noise(api, golden, permute):
+    g = golden("item_wrappers")
+    item = api.noise.RepeatedNoise(0.9, noise=_chain(api, ("gaussian", 1.0)), repeat_length=2, max_recycle=3, normalize=None, permute=permute)
+    torch.manual_seed(42)
+    ns = item.clone().make_noise_sampler(torch.zeros(2, 4, 8, 8, device="cuda"), 0.03, 14.6, seed=42, cpu=True, normalized=True)
+    close(_sequence(ns, 9), g[f"repeated_{permute}"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode", ["wrap", "repeat", "zero"])
+def test_channel_noise_and_nodes(api, golden, mode):
+    g = golden("item_wrappers")
+    item = api.noise.ChannelNoise(1.1, noise=_chain(api, ("gaussian", 1.0), ("uniform", 0.5)), insufficient_channels_mode=mode, normalize=None)
+    torch.manual_seed(43)
+    ns = item.clone().make_noise_sampler(torch.zeros(2, 4, 8, 8, device="cuda"), 0.03, 14.6, seed=43, cpu=True, normalized=True)
+    close(_sequence(ns, 2), g[f"channel_{mode}"], rtol=2e-5, atol=2e-5)
+    M = api.registry.NODE_CLASS_MAPPINGS
+    (c1,) = M["SonarChannelNoise"]().go(1.0, sonar_custom_noise=_chain(api, ("gaussian", 1.0)), insufficient_channels_mode=mode, normalize="default")
+    (c2,) = M["SonarRandomNoise"]().go(1.0, _chain(api, ("gaussian", 1.0)), 1, "forced")
+    (c3,) = M["SonarRepeatedNoise"]().go(factor=1.0, sonar_custom_noise=_chain(api, ("gaussian", 1.0)), repeat_length=4, max_recycle=10,
+                                          normalize="disabled", permute="enabled")
+    x = torch.zeros(1, 4, 16, 16, device="cuda")
+    for c in (c1, c2, c3):
+        out = c.make_noise_sampler(x, 0.03, 14.6, seed=1, cpu=False, normalized=True)(torch.tensor(9.0), torch.tensor(6.0))
+        assert out.shape == x.shape and bool(torch.isfinite(out).all())
+    assert c2.items[0].normalize is True and c3.items[0].normalize is False
