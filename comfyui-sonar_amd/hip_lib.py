@@ -175,6 +175,9 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
         raise TypeError(f"{name}: expected a tensor")
     if STATS_ATTR in t.__dict__:  # any kernel that touches a tagged tensor drops its statistics tag (producers tag AFTER their launch)
         del t.__dict__[STATS_ATTR]
+    base = t._base
+    if base is not None and STATS_ATTR in base.__dict__:  # ... also when it is reached through a view of the tagged tensor
+        del base.__dict__[STATS_ATTR]
     if not t.is_cuda:
         raise SonarHipError(f"{name}: tensor lives on {t.device}; the Sonar HIP path only runs on a ROCm device")
     if t.dtype != dtype:

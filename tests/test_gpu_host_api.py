@@ -608,3 +608,20 @@ def test_power_noise_item_on_video_latents(api):
     whole = gen(x, 0)
     assert torch.equal(gen(x[:1], 0), whole[:1]) and torch.equal(gen(x[1:], 1), whole[1:])
     assert abs(whole.std().item() - 0.9) < 0.1
+
+
+def test_statistics_tags_are_dropped_by_any_write(api):
+    """scale_noise tags its result with the result's statistics (so a wrapper that normalises again needs no sweep); the tag must not
+    survive a write: through this library (directly or through a view) or through torch in-place ops."""
+    U, hl = api.utils, api.hl
+    x = torch.randn(4, 4, 32, 32, device="cuda") * 3 + 1
+    y = U.scale_noise(x, 1.0, normalized=True)
+    assert U._STATS_ATTR in y.__dict__
+    again = U.scale_noise(y.clone(), 1.0, normalized=True)
+    tagged = U.scale_noise(y, 1.0, normalized=True)  # uses the tag: decision "leave as is", values untouched
+    assert torch.equal(tagged, again)
+    for write in (lambda t: hl.mul_scalar(t, 2.0, out=t), lambda t: hl.mul_scalar(t.view(-1), 2.0, out=t.view(-1)), lambda t: t.mul_(2.0)):
+        t = U.scale_noise(torch.randn(4, 4, 32, 32, device="cuda"), 1.0, normalized=True)
+        write(t)
+        out = U.scale_noise(t, 1.0, normalized=True)
+        assert abs(out.std().item() - 1.0) < 1e-4  # a stale tag would have left the std at 2
