@@ -504,6 +504,30 @@ class ChannelNoise(CustomNoiseItemBase):
         return noise_sampler
 
 
+class LatentOperationFilteredNoise(CustomNoiseItemBase):
+    """py/noise.py:1665-1698: a chain's noise passed through LATENT_OPERATIONs (each gets ``latent`` and the current ``sigma``)."""
+
+    def clone_key(self, k):
+        if k == "noise" and self.noise is not None:
+            return self.noise.clone()
+        return super().clone_key(k)
+
+    def make_noise_sampler(self, x, sigma_min, sigma_max, *args, normalized=True, **kwargs):
+        factor = self.factor
+        normalize = self.get_normalize("normalize", normalized)
+        ns = self.noise.make_noise_sampler(x, *args, sigma_min=sigma_min, sigma_max=sigma_max, normalized=self.normalize_noise, **kwargs)
+        ops = self.operations
+
+        def noise_sampler(sigma, sigma_next):
+            noise = ns(sigma, sigma_next)
+            for op in ops:
+                pop_stats(noise)  # an operation may change the values in place
+                noise = op(latent=noise, sigma=sigma)
+            return scale_noise(noise.contiguous(), factor, normalized=normalize)
+
+        return noise_sampler
+
+
 class ModulatedNoise(CustomNoiseItemBase):
     """py/noise.py:762-1019: noise shaped by the local busyness of a reference latent (or of the sampler's x).  ``intensity`` and
     ``frequency`` run as HIP kernels (std over the modulation dims -> broadcast gain -> [LDS-resident rfft2 x boost x irfft2] ->

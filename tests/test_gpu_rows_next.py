@@ -452,3 +452,22 @@ def test_channel_noise_and_nodes(api, golden, mode):
         out = c.make_noise_sampler(x, 0.03, 14.6, seed=1, cpu=False, normalized=True)(torch.tensor(9.0), torch.tensor(6.0))
         assert out.shape == x.shape and bool(torch.isfinite(out).all())
     assert c2.items[0].normalize is True and c3.items[0].normalize is False
+
+
+def test_latent_operation_filtered_noise(api):
+    """py/noise.py:1665-1698: chain noise -> LATENT_OPERATIONs (sigma-gated SonarLatentOperation wrappers or plain callables) -> scale_noise."""
+    L = api.latent_ops
+    x = torch.zeros(2, 4, 16, 16, device="cuda")
+    double = lambda latent: api.hl.mul_scalar(latent, 2.0)  # a plain ComfyUI-style latent operation
+    gated = L.SonarLatentOperation(start_sigma=5.0, end_sigma=1.0, op=lambda latent: api.hl.mul_scalar(latent, 10.0))  # outside its window at sigma 9
+    node = api.registry.NODE_CLASS_MAPPINGS["SonarLatentOperationFilteredNoise"]()
+    (chain,) = node.go(factor=0.5, rescale=0.0, normalize="disabled", normalize_noise=False, custom_noise=_chain(api, ("gaussian", 1.0)),
+                       operation_1=double, operation_2=gated)
+    torch.manual_seed(3)
+    out = chain.make_noise_sampler(x, 0.03, 14.6, seed=3, cpu=True, normalized=False)(torch.tensor(9.0), torch.tensor(6.0))
+    torch.manual_seed(3)
+    want = torch.randn(2, 4, 16, 16) * 2.0 * 0.5 * 0.5  # item factor, then the unnormalised chain multiplies by the sum of |factors| again
+    close(out, want, rtol=1e-6, atol=1e-6)
+    torch.manual_seed(3)
+    out = chain.make_noise_sampler(x, 0.03, 14.6, seed=3, cpu=True, normalized=False)(torch.tensor(3.0), torch.tensor(2.0))
+    close(out, want * 10.0, rtol=1e-6, atol=1e-5)
