@@ -100,6 +100,60 @@ static int launch_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
     return check_launch(what);
 }
 
+// Normalised fill without a second sweep: MODE 1 re-draws the values and only reduces their statistics (no stores), MODE 2
+// re-draws them again, normalises with the decision derived from those statistics and stores -- the tensor is written once
+// (GaussianNoiseGenerator / UniformNoiseGenerator followed by scale_noise(normalized=True), py/noise_generation.py:252-260,496-514)
+template <Dist D, bool VEC, int MODE>
+__global__ void __launch_bounds__(kBlock) stream_fill_norm_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
+                                                                  int64_t elem_offset, Affine aff, double* partials, NormArgs na) {
+    __shared__ double red[2 * kBlock / 64];
+    __shared__ NormDecision sh;
+    NormDecision dec{0.f, 1.f, 0, 0};
+    if constexpr (MODE == 2) dec = decide_norm<kBlock>(na.partials, kNPart, na.n_total, na.thr_sd, red, &sh);
+    const NormFast norm(dec, na.factor);
+    double s = 0.0, q = 0.0;
+    for_each_group<D>(n, seed, stream_id, elem_offset, [&](int64_t e, float (&v)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = aff(v[k]);
+        if constexpr (MODE == 1) {
+            if (e >= 0 && e + 4 <= n) {
+                const float ps = (v[0] + v[1]) + (v[2] + v[3]);
+                const float pq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3])));
+                s += (double)ps;
+                q += (double)pq;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e + k >= 0 && e + k < n) {
+                        s += (double)v[k];
+                        q += (double)v[k] * (double)v[k];
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = norm(v[k]);
+            store_group<VEC>(out, n, e, v, s, q, false);
+        }
+    });
+    if constexpr (MODE == 1) write_partial<kBlock>(s, q, partials, red);
+}
+
+template <Dist D>
+static int launch_fill_norm(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset, Affine aff, float factor,
+                            float thr, double* partials, hipStream_t st, const char* what) {
+    if (n == 0) return SONAR_OK;
+    const bool vec = aligned16(out) && (elem_offset & 3) == 0;
+    const int g = tile_grid(n, elem_offset);
+    const NormArgs na{partials, n, factor, thr};
+    hipLaunchKernelGGL((stream_fill_norm_kernel<D, true, 1>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials,
+                       NormArgs{nullptr, 0, 1.0f, 0.0f});
+    if (vec)
+        hipLaunchKernelGGL((stream_fill_norm_kernel<D, true, 2>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials, na);
+    else
+        hipLaunchKernelGGL((stream_fill_norm_kernel<D, false, 2>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials, na);
+    return check_launch(what);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Perlin: lattice term at cell centre (py/noise_generation.py:388-405 with positions == (0.5, 0.5)).
 __global__ void __launch_bounds__(kBlock) perlin_terms_kernel(const float* __restrict__ angles, float* terms,
@@ -795,6 +849,19 @@ extern "C" int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, ui
     const int active = !(sub == 0.0f && mul == 1.0f && add == 0.0f);
     return launch_fill<Dist::Uniform>(out, n, seed, stream_id, elem_offset, Affine{sub, mul, add, active}, partials,
                                       (hipStream_t)stream, "sonar_philox_uniform_f32");
+}
+
+extern "C" int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                      float sub, float mul, float add, float factor, float threshold_std_devs, double* partials,
+                                      void* stream) {
+    SONAR_REQUIRE(out && partials && n >= 0 && elem_offset >= 0, SONAR_ERR_ARG, "sonar_philox_noise_f32: bad argument");
+    const int active = !(sub == 0.0f && mul == 1.0f && add == 0.0f);
+    const Affine aff{sub, mul, add, uniform ? active : 0};
+    if (uniform)
+        return launch_fill_norm<Dist::Uniform>(out, n, seed, stream_id, elem_offset, aff, factor, threshold_std_devs, partials,
+                                               (hipStream_t)stream, "sonar_philox_noise_f32");
+    return launch_fill_norm<Dist::Normal>(out, n, seed, stream_id, elem_offset, aff, factor, threshold_std_devs, partials,
+                                          (hipStream_t)stream, "sonar_philox_noise_f32");
 }
 
 static int brownian_launch(float* out, float* w_out, const float* prev, float scale, int64_t n, int64_t elem_offset,

@@ -85,6 +85,7 @@ SIGNATURES = {
     "sonar_dpmpp_stage2_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
     "sonar_philox_normal_f32": (_I, [_P, _I64, _U64, _U64, _I64, _P, _P]),
     "sonar_philox_uniform_f32": (_I, [_P, _I64, _U64, _U64, _I64, _F, _F, _F, _P, _P]),
+    "sonar_philox_noise_f32": (_I, [_I, _P, _I64, _U64, _U64, _I64, _F, _F, _F, _F, _F, _P, _P]),
     "sonar_brownian_f32": (_I, [_P, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_brownian_point_f32": (_I, [_P, _P, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_perlin_terms_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
@@ -488,6 +489,17 @@ def philox_uniform(shape, device, seed: int, stream_id: int, elem_offset: int = 
                                         float(sub), float(mul), float(add), _opt(partials, "partials", torch.float64), _stream()),
         "sonar_philox_uniform_f32",
     )
+    return out
+
+
+def philox_noise(uniform: bool, shape, device, seed: int, stream_id: int, elem_offset: int, factor: float, *, sub=0.0, mul=1.0, add=0.0,
+                 threshold_std_devs: float = 2.5) -> torch.Tensor:
+    """Normal / affine-uniform draws + scale_noise(factor, normalized=True), the tensor written once."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    ws = new_partials(device)
+    _check(load().sonar_philox_noise_f32(int(bool(uniform)), _dev(out, "out"), out.numel(), seed & (2**64 - 1), stream_id, elem_offset,
+                                         float(sub), float(mul), float(add), float(factor), float(threshold_std_devs), ws.data_ptr(), _stream()),
+           "sonar_philox_noise_f32")
     return out
 
 

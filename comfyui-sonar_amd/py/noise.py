@@ -150,6 +150,11 @@ class CustomNoiseChain:
             # result = sum_i item_i * factor_i (py/noise.py:188-194).  An item that would only multiply by its factor hands back
             # (raw tensor, factor) instead (`unscaled`), and the multiply rides in the accumulation kernel: y*a + x*b rounds each
             # product before the add, exactly like mul_ followed by add_, so the sweep is saved without changing a bit.
+            if normalized and len(samplers) == 1:  # one item, factor 1: draw + normalise with a single write of the tensor
+                fused = getattr(samplers[0], "normalized_call", None)
+                out = fused(factor, sigma, sigma_next) if fused is not None else None
+                if out is not None:
+                    return out
             total, first = None, None
             for idx, ns in enumerate(samplers):
                 raw = getattr(ns, "unscaled", None)
@@ -211,6 +216,20 @@ class NoiseSampler:
         if not hasattr(noise, "to") or noise.dtype != self.dtype or noise.device != self.device or noise.dtype != torch.float32:
             return scale_noise(noise, self.factor, normalized=False).to(dtype=self.dtype, device=self.device), 1.0
         return noise, float(self.factor)
+
+    def normalized_call(self, factor, *args):
+        """This sampler's output (its own factor must be 1, no normalisation of its own) followed by scale_noise(factor,
+        normalized=True), through the generator's fused path; None when that does not apply.  Used by a single-item chain."""
+        if self.normalized or self.factor != 1.0 or self.dtype != torch.float32:
+            return None
+        fused = getattr(self.noise_sampler, "generate_normalized", None)
+        if fused is None:
+            return None
+        gen = self.noise_sampler
+        if getattr(gen, "normalized", False):  # the generator would normalise first, then the chain again: keep that order
+            return None
+        args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
+        return fused(factor, *args)
 
     def __call__(self, *args, **kwargs):
         args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)

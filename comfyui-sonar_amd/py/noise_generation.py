@@ -299,6 +299,14 @@ class GaussianNoiseGenerator(NoiseGenerator):
         partials = hip_lib.new_partials(self.device)
         return attach_stats(self.rand_like(partials=partials), partials)
 
+    def generate_normalized(self, factor, *_args):
+        """generate() + scale_noise(factor, normalized=True), the tensor written once (device draws only)."""
+        if self.cpu or self.normalize_dims is not None:
+            return None
+        seed, stream = self.device_key()
+        shape = tuple(self.shape)
+        return hip_lib.philox_noise(False, shape, self.device, seed, stream, self.latent_elem_offset(math.prod(shape[1:])), factor)
+
 
 class UniformNoiseGenerator(NoiseGenerator):
     """py/noise_generation.py:496-514: (U[0,1) - sub_fac) * mul_fac + mean_fac."""
@@ -318,6 +326,14 @@ class UniformNoiseGenerator(NoiseGenerator):
         out = hip_lib.philox_uniform(tuple(self.shape), self.device, seed, stream, self.latent_elem_offset(per_latent),
                                      sub=self.sub_fac, mul=self.mul_fac, add=self.mean_fac, partials=partials)
         return attach_stats(out, partials)
+
+    def generate_normalized(self, factor, *_args):
+        if self.cpu or self.normalize_dims is not None:
+            return None
+        seed, stream = self.device_key()
+        shape = tuple(self.shape)
+        return hip_lib.philox_noise(True, shape, self.device, seed, stream, self.latent_elem_offset(math.prod(shape[1:])), factor,
+                                    sub=self.sub_fac, mul=self.mul_fac, add=self.mean_fac)
 
 
 class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):

@@ -184,6 +184,12 @@ int sonar_philox_normal_f32(float* out, int64_t n, uint64_t seed, uint64_t strea
 /* out = (u - sub)*mul + add, u~U[0,1)  (py/noise_generation.py:508-514) */
 int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                              float sub, float mul, float add, double* partials /*nullable*/, void* stream);
+/* The same draws followed by scale_noise(factor, normalized = 1) with the tensor written ONCE: a statistics pass re-draws the
+ * values without storing them, the final pass re-draws, normalises and stores (uniform = 0: N(0,1); 1: (U[0,1) - sub)*mul + add).
+ * partials: 1024 fp64 pairs of workspace. */
+int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                           float sub, float mul, float add, float factor, float threshold_std_devs, double* partials,
+                           void* stream);
 
 /* Brownian-interval noise (the reference wraps ComfyUI's BrownianTreeNoiseSampler -> torchsde, un-vendored:
  * py/noise_generation.py:262-286, py/nodes/powernoise.py:383-393).  out[e] = sum_k coefs[k] * z(node_ids[k], e) with

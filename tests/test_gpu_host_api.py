@@ -625,3 +625,28 @@ def test_statistics_tags_are_dropped_by_any_write(api):
         write(t)
         out = U.scale_noise(t, 1.0, normalized=True)
         assert abs(out.std().item() - 1.0) < 1e-4  # a stale tag would have left the std at 2
+
+
+def test_single_item_chain_uses_the_fused_normalised_fill(api):
+    """A chain of ONE factor-1 gaussian / uniform item, normalised, on-device draws: draw + normalise with one write (NoiseSampler.
+    normalized_call -> generate_normalized); same values as the unfused path (generator, then the chain's scale_noise)."""
+    ng = api.noise_generation
+    x = torch.zeros(8, 4, 64, 64, device="cuda")
+    for name in ("gaussian", "uniform"):
+        outs = []
+        for fused in (True, False):
+            chain = chain_of(api, item(api, name, 1.0))
+            torch.manual_seed(77)
+            ng.DeviceRNG._seed, ng.DeviceRNG._next = None, 0
+            ns = chain.make_noise_sampler(x, 0.03, 14.6, seed=1, cpu=False, normalized=True)
+            if not fused:
+                gen_cls = ng.GaussianNoiseGenerator if name == "gaussian" else ng.UniformNoiseGenerator
+                saved = gen_cls.generate_normalized
+                gen_cls.generate_normalized = lambda self, factor, *a: None
+            try:
+                outs.append(ns(*SIG))
+            finally:
+                if not fused:
+                    gen_cls.generate_normalized = saved
+        close(outs[0], outs[1], rtol=1e-5, atol=1e-6)
+        assert abs(outs[0].std().item() - 1.0) < 7e-3  # inside scale_noise's 2.5 / sqrt(n) band nothing is rescaled (uniform: 3.46 / sqrt 12)

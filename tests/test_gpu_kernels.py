@@ -680,3 +680,17 @@ def test_pyramid_in_kernel_level_grids(hl):
         assert torch.equal(hl.pyramid_generate((2, 4, hh, ww), "cuda", lv, "bilinear", 11, 5, 4 * hh * ww), b[1:])
         assert 2.0 < b.double().var().item() < 2.6
     assert hl.pyramid_generate((2, 4, 32, 30), "cuda", [(None, 32, 30, 1.0), (None, 9, 9, 0.7)], "bilinear", 11, 5) is None  # W % 4 != 0
+
+
+@pytest.mark.parametrize("uniform", [False, True])
+@pytest.mark.parametrize("n,offset", [(8 * 4 * 64 * 64, 0), (4096 * 3 + 5, 4096 * 2), (1000, 12)])
+def test_fused_normalised_fill(hl, uniform, n, offset):
+    """sonar_philox_noise_f32 (statistics by re-drawing, one write) == the plain fill followed by stats + scale_noise."""
+    kw = dict(sub=0.5, mul=3.46, add=0.1) if uniform else {}
+    for factor in (1.0, 0.7):
+        part = hl.new_partials("cuda")
+        two = hl.philox_uniform((n,), "cuda", 5, 3, offset, partials=part, **kw) if uniform else hl.philox_normal((n,), "cuda", 5, 3, offset, part)
+        hl.scale_noise_(two, factor, True, part)
+        one = hl.philox_noise(uniform, (n,), "cuda", 5, 3, offset, factor, **kw)
+        close(one, two, rtol=1e-5, atol=1e-6)
+        assert abs(one.std().item() - factor) < (2.5 / math.sqrt(n) + 5e-3) * factor  # inside the band nothing is rescaled
