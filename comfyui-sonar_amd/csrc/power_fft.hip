@@ -191,7 +191,7 @@ constexpr int draw_iters() { return ((H / 2) * (W / 2) + plane_threads<H, W>() -
 
 template <int H, int W, bool NEED_T, int UNROLL = 0, typename Edge, typename Pair>
 __device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge, Pair&& pair) {
-    constexpr int NT = plane_threads<H, W>(), M = W / 2, LM = draw_shift<W>(), PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
+    constexpr int NT = plane_threads<H, W>(), M = W / 2, PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
     constexpr int UNR = UNROLL > 0 ? UNROLL : ITER;  // 0 = full (the statistics pass indexes registers by `it`)
     if (tid < H) {  // row ky = tid of the edge columns: radius word of kx = 0, of kx = M, then one angle word for both
         const uint32_t r0 = g.E.next_high();
@@ -309,7 +309,7 @@ __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const fl
 // SRC: 0 = spectrum `z` supplied (replay), 1 = spectrum drawn on device, 2 = `z` is a REAL H x W plane: forward r2c FFT in
 // LDS, x filter, then the same inverse (spectral filter: out = irfft2(rfft2(x) * filter), py/nodes/powernoise.py:356-366)
 template <int H, int W, int SRC, bool STATS, bool NORM>
-__global__ void __launch_bounds__((plane_threads<H, W>()), SONAR_FFT_WAVES) power_irfft2_kernel(const float* __restrict__ z,
+__global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 : SONAR_FFT_WAVES)) power_irfft2_kernel(const float* __restrict__ z,
                                                                        const float* __restrict__ filter, float* out,
                                                                        int64_t planes, uint64_t seed, uint64_t stream_id,
                                                                        int64_t plane_offset, int group, int split, double* partials,

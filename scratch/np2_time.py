@@ -4,7 +4,7 @@ import torch, sonar_pkg
 pkg = sonar_pkg.load(); hl = pkg.hip_lib; hl.load()
 nz = importlib.import_module("comfyui_sonar_amd.py.noise")
 sig = (torch.tensor(14.6), torch.tensor(10.0))
-for shape in ((512, 4, 104, 152), (512, 4, 96, 96)):
+for shape in ((512, 4, 128, 128), (512, 4, 104, 152), (512, 4, 96, 96)):
     x = torch.zeros(shape, device="cuda")
     for name in ("pyramid", "perlin", "gaussian", "brownian"):
         ns = nz.get_noise_sampler(name, x, 0.03, 14.6, seed=3, cpu=False, normalized=True)
