@@ -102,7 +102,7 @@ __device__ __forceinline__ void fwd_build_maps(int* xmap, int* ymap, int H, int 
 }
 
 // one analysis tile: output rows [y0, y0 + th) of one plane (pc / pu, ollc / ollu / ohi are plane pointers)
-template <typename T, typename TIn, bool PAIR, int FT, bool ZERO, typename TP>
+template <typename T, typename TIn, bool PAIR, int FT, bool ZERO, typename TP, bool SPLIT = false>
 __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const TIn* __restrict__ pu, T* __restrict__ ollc,
                                              T* __restrict__ ollu, T* __restrict__ ohi, int W, int h, int w, int y0, int th,
                                              const TP& tp, const BandArgs<T>& ba, const FwdLds<T, PAIR ? 4 : 2, FT>& lds) {
@@ -118,38 +118,47 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
     const int q0 = threadIdx.x / w, r0 = threadIdx.x - q0 * w;
     {
         __syncthreads();
-        // ---- pass 1: analysis along H, one thread per (tensor, column); window = extended input rows 2 y0 .. 2 y0 + NR - 1
-        for (int it = threadIdx.x; it < NT * W; it += kTileThreads) {
-            const int ten = it >= W ? 1 : 0;
-            const int x = it - ten * W;
-            const TIn* col = (ten ? pu : pc) + x;
-            T v[NR];
+        // ---- pass 1: analysis along H, one thread per (row group, tensor, column); window = extended input rows of the group.
+        // SUB row groups per tile: a narrow level (the deep WaveletCFG levels: 2 x 67, 2 x 37 ... columns) would leave most of
+        // the workgroup idle with one thread per column, so the tile's TH output rows are split over SUB threads per column.
+        auto pass1 = [&](auto sub_c) {
+            constexpr int SUB = decltype(sub_c)::value, THS = TH / SUB, NRS = 2 * THS + FT - 2;
+            for (int it = threadIdx.x; it < SUB * NT * W; it += kTileThreads) {
+                const int sub = it / (NT * W), rest = it - sub * (NT * W);
+                const int ten = rest >= W ? 1 : 0;
+                const int x = rest - ten * W;
+                const TIn* col = (ten ? pu : pc) + x;
+                T v[NRS];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                // rows past the tile's need (last tile) re-read a valid row; their outputs are never consumed
-                const int sy = ymap[min(2 * y0 + r, 2 * h + FT - 3)];
-                if constexpr (ZERO) {
-                    const T g = (T)col[(sy >= 0 ? sy : 0) * W];
-                    v[r] = sy >= 0 ? g : T(0);
-                } else {
-                    v[r] = (T)col[sy * W];
+                for (int r = 0; r < NRS; ++r) {
+                    // rows past the tile's need (last tile) re-read a valid row; their outputs are never consumed
+                    const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h + FT - 3)];
+                    if constexpr (ZERO) {
+                        const T g = (T)col[(sy >= 0 ? sy : 0) * W];
+                        v[r] = sy >= 0 ? g : T(0);
+                    } else {
+                        v[r] = (T)col[sy * W];
+                    }
+                }
+                Half* dst = reinterpret_cast<Half*>(tmp + ((x & 1) * Wh + (x >> 1))) + ten;
+#pragma unroll
+                for (int yl = 0; yl < THS; ++yl) {
+                    T lo = T(0), hq = T(0);
+#pragma unroll
+                    for (int j = 0; j < FT; ++j) {  // tap j reads window row 2 yl + F - 1 - j
+                        lo = fma_t(tp.lo[j], v[2 * yl + FT - 1 - j], lo);
+                        hq = fma_t(tp.hi[j], v[2 * yl + FT - 1 - j], hq);
+                    }
+                    Half o2;
+                    o2.v[0] = lo;
+                    o2.v[1] = hq;
+                    dst[(sub * THS + yl) * Ws * NT] = o2;
                 }
             }
-            Half* dst = reinterpret_cast<Half*>(tmp + ((x & 1) * Wh + (x >> 1))) + ten;
-#pragma unroll
-            for (int yl = 0; yl < TH; ++yl) {
-                T lo = T(0), hq = T(0);
-#pragma unroll
-                for (int j = 0; j < FT; ++j) {  // tap j reads window row 2 yl + F - 1 - j
-                    lo = fma_t(tp.lo[j], v[2 * yl + FT - 1 - j], lo);
-                    hq = fma_t(tp.hi[j], v[2 * yl + FT - 1 - j], hq);
-                }
-                Half o2;
-                o2.v[0] = lo;
-                o2.v[1] = hq;
-                dst[yl * Ws * NT] = o2;
-            }
-        }
+        };
+        if (SPLIT && 4 * NT * W <= kTileThreads) pass1(std::integral_constant<int, 4>{});
+        else if (SPLIT && 2 * NT * W <= kTileThreads) pass1(std::integral_constant<int, 2>{});
+        else pass1(std::integral_constant<int, 1>{});
         __syncthreads();
         // ---- pass 2: analysis along W out of LDS, band arithmetic, store
         for (int yl = q0, xo = r0; yl < th;) {
@@ -411,7 +420,7 @@ __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepAr
             T* ou = ba.combine_ll ? nullptr : base + a.off_u[k] + p * hw;
             T* od = base + a.off_d[k] + p * 3 * hw;
             for (int y0 = 0; y0 < h; y0 += kFwdRows)
-                fwd_tile_job<T, T, true, FT, true>(pc, pu, oc, ou, od, W, h, w, y0, min(kFwdRows, h - y0), a.dec, ba, lds);
+                fwd_tile_job<T, T, true, FT, true, TapsSmall<T>, true>(pc, pu, oc, ou, od, W, h, w, y0, min(kFwdRows, h - y0), a.dec, ba, lds);
             // the workgroup re-reads what it just stored: workgroup scope is enough (one CU, one L1); a device-scope fence
             // would write back / invalidate L2 once per level per plane
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
