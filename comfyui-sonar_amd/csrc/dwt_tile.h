@@ -388,7 +388,7 @@ struct DeepArgs {
     TapsSmall<T> dec, rec;
 };
 
-template <typename T, int FT>
+template <typename T, int FT, bool ZERO>
 __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepArgs<T> a) {
     extern __shared__ __align__(16) unsigned char tile_smem[];
     for (int64_t p = blockIdx.x; p < a.planes; p += gridDim.x) {
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepAr
             T* ou = ba.combine_ll ? nullptr : base + a.off_u[k] + p * hw;
             T* od = base + a.off_d[k] + p * 3 * hw;
             for (int y0 = 0; y0 < h; y0 += kFwdRows)
-                fwd_tile_job<T, T, true, FT, true, TapsSmall<T>, true>(pc, pu, oc, ou, od, W, h, w, y0, min(kFwdRows, h - y0), a.dec, ba, lds);
+                fwd_tile_job<T, T, true, FT, ZERO, TapsSmall<T>, true>(pc, pu, oc, ou, od, W, h, w, y0, min(kFwdRows, h - y0), a.dec, ba, lds);
             // the workgroup re-reads what it just stored: workgroup scope is enough (one CU, one L1); a device-scope fence
             // would write back / invalidate L2 once per level per plane
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -659,8 +659,13 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
             a.rec.hi[i] = i < rec_len ? rec.hi[i] : T(0);
         }
         with_taps(dec_len, [&](auto ft) {
-            hipLaunchKernelGGL((wcfg_deep_kernel<T, decltype(ft)::value>), dim3((int)std::min<int64_t>(planes, 1 << 20)), dim3(kTileThreads),
-                               lds, st, base, a);
+            // zero extension is the only mode with "no source" positions: the others skip its per-tap selects (the kernel is VALU-bound)
+            if (mode_fwd == kZero)
+                hipLaunchKernelGGL((wcfg_deep_kernel<T, decltype(ft)::value, true>), dim3((int)std::min<int64_t>(planes, 1 << 20)),
+                                   dim3(kTileThreads), lds, st, base, a);
+            else
+                hipLaunchKernelGGL((wcfg_deep_kernel<T, decltype(ft)::value, false>), dim3((int)std::min<int64_t>(planes, 1 << 20)),
+                                   dim3(kTileThreads), lds, st, base, a);
         });
         ll = base + pl.off_r[2];  // what the deep kernel reconstructed for level 1
         ll_h = pl.Hr[2];
