@@ -35,11 +35,11 @@ __device__ __forceinline__ int src_index(int pos, int n, int ne, int mode) {
 static inline bool tile_taps_ok(int F) { return F >= 2 && F <= 20 && (F & 1) == 0; }
 
 // analysis LDS: [kFwdRows][2 ceil(W/2) slots][2 tensors' (lowH, highH)] of T, then xmap[2w + F], ymap[2h + F]
-static inline size_t fwd_lds_bytes(int W, int h, int w, int F, size_t elem, int tensors) {
-    return (size_t)tensors * kFwdRows * 2 * (2 * ((W + 1) / 2)) * elem + (size_t)(2 * w + 2 * h + 2 * F) * sizeof(int);
+static inline size_t fwd_lds_bytes(int W, int h, int w, int F, size_t elem, int tensors, int rows = kFwdRows) {
+    return (size_t)tensors * rows * 2 * (2 * ((W + 1) / 2)) * elem + (size_t)(2 * w + 2 * h + 2 * F) * sizeof(int);
 }
 // synthesis LDS: [kInvRows][lo_w | hi_w][w] of T
-static inline size_t inv_lds_bytes(int w, size_t elem) { return (size_t)kInvRows * 2 * w * elem; }
+static inline size_t inv_lds_bytes(int w, size_t elem, int rows = kInvRows) { return (size_t)rows * 2 * w * elem; }
 
 // compact on purpose: these live in scalar registers next to the filter taps (fp64: 2 SGPRs per value)
 template <typename T>
@@ -79,11 +79,11 @@ struct FwdLds {
     int* xmap;
     int* ymap;
     int Wh, Ws;
-    __device__ __forceinline__ FwdLds(unsigned char* smem, int W, int w) {
+    __device__ __forceinline__ FwdLds(unsigned char* smem, int W, int w, int rows = kFwdRows) {
         Wh = (W + 1) >> 1;
         Ws = 2 * Wh;
         tmp = reinterpret_cast<Vec*>(smem);
-        xmap = reinterpret_cast<int*>(tmp + kFwdRows * Ws);
+        xmap = reinterpret_cast<int*>(tmp + rows * Ws);
         ymap = xmap + (2 * w + FT);
     }
 };
@@ -156,9 +156,44 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
                 }
             }
         };
-        if (SPLIT && 4 * NT * W <= kTileThreads) pass1(std::integral_constant<int, 4>{});
-        else if (SPLIT && 2 * NT * W <= kTileThreads) pass1(std::integral_constant<int, 2>{});
-        else pass1(std::integral_constant<int, 1>{});
+        if constexpr (SPLIT) {
+            // a job of `th` (any number of) rows: row groups of TH / 2, items (group, tensor, column) spread over the whole workgroup
+            constexpr int THS = TH / 2, NRS = 2 * THS + FT - 2;
+            const int groups = (th + THS - 1) / THS;
+            for (int it = threadIdx.x; it < groups * NT * W; it += kTileThreads) {
+                const int sub = it / (NT * W), rest = it - sub * (NT * W);
+                const int ten = rest >= W ? 1 : 0;
+                const int x = rest - ten * W;
+                const TIn* col = (ten ? pu : pc) + x;
+                T v[NRS];
+#pragma unroll
+                for (int r = 0; r < NRS; ++r) {
+                    const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h + FT - 3)];
+                    if constexpr (ZERO) {
+                        const T g = (T)col[(sy >= 0 ? sy : 0) * W];
+                        v[r] = sy >= 0 ? g : T(0);
+                    } else {
+                        v[r] = (T)col[sy * W];
+                    }
+                }
+                Half* dst = reinterpret_cast<Half*>(tmp + ((x & 1) * Wh + (x >> 1))) + ten;
+#pragma unroll
+                for (int yl = 0; yl < THS; ++yl) {
+                    T lo = T(0), hq = T(0);
+#pragma unroll
+                    for (int j = 0; j < FT; ++j) {
+                        lo = fma_t(tp.lo[j], v[2 * yl + FT - 1 - j], lo);
+                        hq = fma_t(tp.hi[j], v[2 * yl + FT - 1 - j], hq);
+                    }
+                    Half o2;
+                    o2.v[0] = lo;
+                    o2.v[1] = hq;
+                    if (sub * THS + yl < th) dst[(sub * THS + yl) * Ws * NT] = o2;
+                }
+            }
+        } else {
+            pass1(std::integral_constant<int, 1>{});
+        }
         __syncthreads();
         // ---- pass 2: analysis along W out of LDS, band arithmetic, store
         for (int yl = q0, xo = r0; yl < th;) {
@@ -385,6 +420,7 @@ struct DeepArgs {
     T ll_scales[4];
     T strength;
     int blend_mode, mode_fwd, mode_inv;
+    int fwd_rows[kDeepMaxLevels + 1], inv_rows[kDeepMaxLevels + 1];  // rows per job (multiples of the tile heights; whole levels when LDS allows)
     TapsSmall<T> dec, rec;
 };
 
@@ -395,7 +431,8 @@ __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepAr
         // ---- analysis, finest deep level first
         for (int k = 1; k <= a.levels; ++k) {
             const int H = a.H[k - 1], W = a.W[k - 1], h = a.H[k], w = a.W[k];
-            const FwdLds<T, 4, FT> lds(tile_smem, W, w);
+            const int frows = a.fwd_rows[k];
+            const FwdLds<T, 4, FT> lds(tile_smem, W, w, frows);
             __syncthreads();
             fwd_build_maps<FT>(lds.xmap, lds.ymap, H, W, h, w, lds.Wh, a.mode_fwd);
             BandArgs<T> ba;
@@ -419,8 +456,8 @@ __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepAr
             T* oc = base + a.off_c[k] + p * hw;
             T* ou = ba.combine_ll ? nullptr : base + a.off_u[k] + p * hw;
             T* od = base + a.off_d[k] + p * 3 * hw;
-            for (int y0 = 0; y0 < h; y0 += kFwdRows)
-                fwd_tile_job<T, T, true, FT, ZERO, TapsSmall<T>, true>(pc, pu, oc, ou, od, W, h, w, y0, min(kFwdRows, h - y0), a.dec, ba, lds);
+            for (int y0 = 0; y0 < h; y0 += frows)
+                fwd_tile_job<T, T, true, FT, ZERO, TapsSmall<T>, true>(pc, pu, oc, ou, od, W, h, w, y0, min(frows, h - y0), a.dec, ba, lds);
             // the workgroup re-reads what it just stored: workgroup scope is enough (one CU, one L1); a device-scope fence
             // would write back / invalidate L2 once per level per plane
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -434,8 +471,8 @@ __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepAr
             const int h = a.H[k], w = a.W[k], Ho = a.Hr[k], Wo = a.Wr[k];
             const T* d = base + a.off_d[k] + p * 3 * (int64_t)h * w;
             T* r = base + a.off_r[k] + p * (int64_t)Ho * Wo;
-            for (int y0 = 0; y0 < Ho; y0 += kInvRows)
-                inv_tile_job<T, false, FT>(ll, ll_w, d, r, nullptr, nullptr, h, w, Wo, y0, min(kInvRows, Ho - y0), a.rec, a.mode_inv, 0, tmp);
+            for (int y0 = 0; y0 < Ho; y0 += a.inv_rows[k])
+                inv_tile_job<T, false, FT>(ll, ll_w, d, r, nullptr, nullptr, h, w, Wo, y0, min(a.inv_rows[k], Ho - y0), a.rec, a.mode_inv, 0, tmp);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __syncthreads();
             ll = r;
@@ -642,7 +679,15 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
                 a.hi_scales[k][6 + g] = ba.hd[g];
                 a.hi_scales[k][9 + g] = ba.hf[g];
             }
-            lds = std::max(lds, std::max(fwd_lds_bytes(a.W[k - 1], a.H[k], a.W[k], dec_len, sizeof(T), 2), inv_lds_bytes(a.W[k], sizeof(T))));
+            // rows per job: as many as fit the per-workgroup LDS budget (whole levels for the small ones) -- the kernel is VALU-bound
+            // and a job of 8 x 37 outputs leaves half the lanes of its second sweep idle
+            constexpr size_t kDeepLdsBudget = 39 * 1024;  // four workgroups per CU
+            int fr = kFwdRows, ir = kInvRows;
+            while (fr < a.H[k] && fwd_lds_bytes(a.W[k - 1], a.H[k], a.W[k], dec_len, sizeof(T), 2, fr + kFwdRows) <= kDeepLdsBudget) fr += kFwdRows;
+            while (ir < a.Hr[k] && inv_lds_bytes(a.W[k], sizeof(T), ir + kInvRows) <= kDeepLdsBudget) ir += kInvRows;
+            a.fwd_rows[k] = fr;
+            a.inv_rows[k] = ir;
+            lds = std::max(lds, std::max(fwd_lds_bytes(a.W[k - 1], a.H[k], a.W[k], dec_len, sizeof(T), 2, fr), inv_lds_bytes(a.W[k], sizeof(T), ir)));
         }
         a.ll_scales[0] = (T)yl_scales[0];
         a.ll_scales[1] = (T)yl_scales[1];
