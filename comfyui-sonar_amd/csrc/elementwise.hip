@@ -639,6 +639,18 @@ __global__ void __launch_bounds__(kBlock) axpby_stats_kernel(float* y, float ymu
     write_partial<kBlock>(s, q, partials, red);
 }
 
+// RippleFilteredNoise (py/noise.py:1134-1202): x *= s[(i / inner) % len] with a small periodic table s broadcast over the
+// tensor; with `follow_sign` the result takes the sign of 1 - s (torch.copysign(result, 1 - s))
+__global__ void __launch_bounds__(kBlock) mul_table_kernel(float* x, const float* __restrict__ s, int64_t n, int64_t inner, int64_t len,
+                                                            int follow_sign) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float sv = s[(i / inner) % len];
+        float v = x[i] * sv;
+        if (follow_sign) v = copysignf(v, 1.0f - sv);
+        x[i] = v;
+    }
+}
+
 struct PowerLawOp {
     float* x;
     float alpha;
@@ -1046,6 +1058,14 @@ extern "C" int sonar_clamp_signpow_rows_f32(float* x, int64_t rows, int64_t inne
 extern "C" int sonar_sq_acc_f32(float* acc, const float* z, float mul, int first, int64_t n, void* stream) {
     SONAR_REQUIRE(acc && z && n >= 0, SONAR_ERR_ARG, "sonar_sq_acc_f32: bad argument");
     return launch_ew(SqAccOp{acc, z, mul, first}, n, aligned16(acc) && aligned16(z), (hipStream_t)stream, "sonar_sq_acc_f32");
+}
+
+extern "C" int sonar_mul_table_f32(float* x, const float* table, int64_t n, int64_t inner, int64_t len, int follow_sign, void* stream) {
+    SONAR_REQUIRE(x && table && n >= 0 && inner > 0 && len > 0, SONAR_ERR_ARG, "sonar_mul_table_f32: bad argument");
+    if (n == 0) return SONAR_OK;
+    hipLaunchKernelGGL(mul_table_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, (hipStream_t)stream, x, table, n, inner, len,
+                       follow_sign);
+    return check_launch("sonar_mul_table_f32");
 }
 
 extern "C" int sonar_std_mid_f32(const float* x, int64_t outer, int64_t mid, int64_t inner, float* stdv, void* stream) {

@@ -112,6 +112,7 @@ SIGNATURES = {
     "sonar_studentt_f32": (_I, [_P, _P, _F, _F, _F, _I64, _P]),
     "sonar_abs_quantile_rows_f32": (_I, [_P, _I64, _I64, _I64, _F, _P, _P]),
     "sonar_clamp_signpow_rows_f32": (_I, [_P, _I64, _I64, _P, _F, _F, _P]),
+    "sonar_mul_table_f32": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
     "sonar_laplace_add_f32": (_I, [_P, _P, _F, _F, _F, _I64, _P]),
     "sonar_power_plane_kind": (_I, [_I64, _I64]),
     "sonar_std_mid_f32": (_I, [_P, _I64, _I64, _I64, _P, _P]),
@@ -375,6 +376,13 @@ def abs_quantile_rows(x: torch.Tensor, rows: int, inner: int, q: float) -> torch
 def clamp_signpow_rows_(x: torch.Tensor, rows: int, inner: int, limit: torch.Tensor, mul: float, p: float) -> torch.Tensor:
     _check(load().sonar_clamp_signpow_rows_f32(_dev(x, "x"), rows, inner, _dev(limit, "limit"), float(mul), float(p), _stream()),
            "sonar_clamp_signpow_rows_f32")
+    return x
+
+
+def mul_table_(x: torch.Tensor, table: torch.Tensor, inner: int, follow_sign: bool = False) -> torch.Tensor:
+    """x[i] *= table[(i / inner) % len(table)] in place (optionally copysign(x, 1 - table))."""
+    _check(load().sonar_mul_table_f32(_dev(x, "x"), _dev(table, "table"), x.numel(), int(inner), table.numel(), int(bool(follow_sign)), _stream()),
+           "sonar_mul_table_f32")
     return x
 
 

@@ -8,6 +8,7 @@ order in which sub-samplers are *called* (it fixes the RNG draw order in replay 
 from __future__ import annotations
 
 import abc
+import math
 from functools import partial
 from typing import Callable, Optional
 
@@ -543,6 +544,87 @@ class LatentOperationFilteredNoise(CustomNoiseItemBase):
                 pop_stats(noise)  # an operation may change the values in place
                 noise = op(latent=noise, sigma=sigma)
             return scale_noise(noise.contiguous(), factor, normalized=normalize)
+
+        return noise_sampler
+
+
+class RippleFilteredNoise(CustomNoiseItemBase):
+    """py/noise.py:1134-1202: the chain's noise times a sin / cos gain profile along one dimension (or the flattened trailing ones),
+    rolled a little further every call."""
+
+    def __init__(self, factor, *, noise, **kwargs):
+        super().__init__(factor, noise=noise.clone(), **kwargs)
+
+    def clone_key(self, k):
+        return self.noise.clone() if k == "noise" else super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        factor = self.factor
+        dim = self.dim + x.ndim if self.dim < 0 else self.dim
+        if dim < 0 or dim >= x.ndim:
+            raise ValueError("Dimension out of range")
+        dim_els = math.prod(x.shape[dim:]) if self.flatten else x.shape[dim]
+        inner = 1 if self.flatten else math.prod(x.shape[dim + 1:])
+        mode_fun = torch.sin if self.mode.startswith("sin") else torch.cos
+        follow_sign = self.mode.endswith("_copysign")
+        # setup arithmetic on `dim_els` host values, once per sampler
+        scaler = mode_fun(torch.linspace(self.offset, self.offset + math.pi * self.period, steps=dim_els, dtype=torch.float32))
+        scaler = 1.0 + torch.where(scaler < 0, scaler * self.amplitude_low, scaler * self.amplitude_high)
+        if self.flatten:  # torch's roll(dims=dim) on the broadcast-shaped scaler only moves the axis `dim`
+            scaler = scaler.reshape(x.shape[dim], -1)
+        ns = self.noise.make_noise_sampler(x, *args, normalized=self.normalize_noise, **kwargs)
+        roll = self.roll
+        normalize = self.get_normalize("normalize", normalized)
+        counter = 0
+
+        def noise_sampler(s, sn):
+            nonlocal counter
+            noise = ns(s, sn)
+            to_roll = int(roll * counter)
+            counter += 1
+            table = scaler.roll(to_roll, dims=0).reshape(-1).contiguous().to(noise.device)
+            result = scale_noise(noise, factor, normalized=normalize)
+            return hip_lib.mul_table_(result.contiguous(), table, inner, follow_sign)
+
+        return noise_sampler
+
+
+class PerDimNoise(CustomNoiseItemBase):
+    """py/noise.py:1822-1893: noise assembled along one dimension from separate calls of the chain (slices / concatenation only)."""
+
+    def clone_key(self, k):
+        return self.noise.clone() if k == "noise" else super().clone_key(k)
+
+    def make_noise_sampler(self, x, sigma_min, sigma_max, *args, normalized=True, **kwargs):
+        factor = self.factor
+        normalize = self.get_normalize("normalize", normalized)
+        offset, chunk_size = self.offset, self.chunk_size
+        dim = self.dim + x.ndim if self.dim < 0 else self.dim
+        if dim < 0 or dim >= x.ndim:
+            raise ValueError("Dimension out of range")
+        dim_size = x.shape[dim]
+        if self.shrink_dim:
+            if offset + chunk_size > dim_size:
+                raise ValueError("Offset or chunk size incompatible with tensor")
+            x = x[tuple(slice(offset, offset + chunk_size) if d == dim else slice(None) for d in range(x.ndim))].contiguous()
+        ns = self.noise.make_noise_sampler(x, *args, sigma_min=sigma_min, sigma_max=sigma_max, normalized=self.normalize_noise, **kwargs)
+        trim = tuple(slice(-dim_size, None) if d == dim else slice(None) for d in range(x.ndim))
+        if self.shrink_dim:
+            def noise_sampler(sigma, sigma_next):
+                noise = torch.cat(tuple(ns(sigma, sigma_next) for _ in range(dim_size)), dim=dim)[trim]
+                return scale_noise(noise.contiguous(), factor, normalized=normalize)
+        else:
+            n_chunks = math.ceil(dim_size / chunk_size)
+            temp_shape = list(x.shape)
+            temp_shape[dim] = int(n_chunks * chunk_size)
+
+            def noise_sampler(sigma, sigma_next):
+                result = x.new_zeros(temp_shape)
+                sel = [slice(None)] * x.ndim
+                for idx in range(0, dim_size, chunk_size):
+                    sel[dim] = slice(idx, idx + chunk_size)
+                    result[tuple(sel)] = ns(sigma, sigma_next)[tuple(sel)]
+                return scale_noise(result[trim].contiguous(), factor, normalized=normalize)
 
         return noise_sampler
 

@@ -107,6 +107,9 @@ int sonar_studentt_f32(float* x, const float* gamma, float loc, float scale, flo
 int sonar_abs_quantile_rows_f32(const float* x, int64_t rows, int64_t inner, int64_t rank_lo, float rank_frac, float* out,
                                 void* stream);
 int sonar_clamp_signpow_rows_f32(float* x, int64_t rows, int64_t inner, const float* limit, float mul, float p, void* stream);
+/* RippleFilteredNoise, py/noise.py:1197-1200: x[i] *= table[(i / inner) % len] (a sin / cos gain profile along one dimension, or along
+ * the flattened trailing dimensions with inner = 1); follow_sign: the result takes the sign of 1 - table[..] (torch.copysign). In place. */
+int sonar_mul_table_f32(float* x, const float* table, int64_t n, int64_t inner, int64_t len, int follow_sign, void* stream);
 /* LaplacianNoiseGenerator.generate, py/noise_generation.py:796-802: x = x/div_fac + Laplace(loc, scale), the variate built from a
  * uniform u in (eps-1, 1) the way torch.distributions.Laplace.rsample does: loc - scale*sign(u)*log1p(-max(|u|, tiny)).  In place. */
 int sonar_laplace_add_f32(float* x, const float* u, float div_fac, float loc, float scale, int64_t n, void* stream);

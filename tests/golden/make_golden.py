@@ -817,6 +817,19 @@ def gen_item_wrappers():
         torch.manual_seed(43)
         ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=43, cpu=True, normalized=True)
         cases[f"channel_{mode}"] = torch.stack([ns(*sig) for _ in range(2)])
+    for tag, kw in (("cos_dim-1", dict(mode="cos", dim=-1, flatten=False)), ("sin_copysign_dim1", dict(mode="sin_copysign", dim=1, flatten=False)),
+                    ("cos_flat2", dict(mode="cos", dim=2, flatten=True))):
+        item = N.RippleFilteredNoise(0.8, noise=chain(("gaussian", 1.0)), offset=0.3, roll=1.5, amplitude_high=0.25, amplitude_low=1.6, period=3.0,
+                                     normalize_noise=False, normalize=None, **kw)
+        torch.manual_seed(44)
+        ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=44, cpu=True, normalized=True)
+        cases[f"ripple_{tag}"] = torch.stack([ns(*sig) for _ in range(3)])
+    for tag, kw in (("dim1_chunk1", dict(dim=1, shrink_dim=False, chunk_size=1)), ("dim2_chunk4", dict(dim=2, shrink_dim=False, chunk_size=4)),
+                    ("dim1_shrink", dict(dim=1, shrink_dim=True, chunk_size=1))):
+        item = N.PerDimNoise(0.6, noise=chain(("gaussian", 1.0)), offset=0, normalize_noise=False, normalize=None, **kw)
+        torch.manual_seed(45)
+        ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=45, cpu=True, normalized=True)
+        cases[f"perdim_{tag}"] = torch.stack([ns(*sig) for _ in range(2)])
     save("item_wrappers", **cases)
 
 

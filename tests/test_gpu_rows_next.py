@@ -471,3 +471,24 @@ def test_latent_operation_filtered_noise(api):
     torch.manual_seed(3)
     out = chain.make_noise_sampler(x, 0.03, 14.6, seed=3, cpu=True, normalized=False)(torch.tensor(3.0), torch.tensor(2.0))
     close(out, want * 10.0, rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,kw", [("cos_dim-1", dict(mode="cos", dim=-1, flatten=False)), ("sin_copysign_dim1", dict(mode="sin_copysign", dim=1, flatten=False)),
+                                    ("cos_flat2", dict(mode="cos", dim=2, flatten=True))])
+def test_ripple_filtered_noise(api, golden, tag, kw):
+    g = golden("item_wrappers")
+    item = api.noise.RippleFilteredNoise(0.8, noise=_chain(api, ("gaussian", 1.0)), offset=0.3, roll=1.5, amplitude_high=0.25, amplitude_low=1.6,
+                                         period=3.0, normalize_noise=False, normalize=None, **kw)
+    torch.manual_seed(44)
+    ns = item.clone().make_noise_sampler(torch.zeros(2, 4, 8, 8, device="cuda"), 0.03, 14.6, seed=44, cpu=True, normalized=True)
+    close(_sequence(ns, 3), g[f"ripple_{tag}"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag,kw", [("dim1_chunk1", dict(dim=1, shrink_dim=False, chunk_size=1)), ("dim2_chunk4", dict(dim=2, shrink_dim=False, chunk_size=4)),
+                                    ("dim1_shrink", dict(dim=1, shrink_dim=True, chunk_size=1))])
+def test_per_dim_noise(api, golden, tag, kw):
+    g = golden("item_wrappers")
+    item = api.noise.PerDimNoise(0.6, noise=_chain(api, ("gaussian", 1.0)), offset=0, normalize_noise=False, normalize=None, **kw)
+    torch.manual_seed(45)
+    ns = item.clone().make_noise_sampler(torch.zeros(2, 4, 8, 8, device="cuda"), 0.03, 14.6, seed=45, cpu=True, normalized=True)
+    close(_sequence(ns, 2), g[f"perdim_{tag}"], rtol=2e-5, atol=2e-5)
