@@ -144,10 +144,19 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
 #pragma unroll
                 for (int yl = 0; yl < THS; ++yl) {
                     T lo = T(0), hq = T(0);
+                    if constexpr (std::is_same<T, float>::value) {
+                        typedef float pk2 __attribute__((ext_vector_type(2)));
+                        pk2 acc = {0.0f, 0.0f};
 #pragma unroll
-                    for (int j = 0; j < FT; ++j) {  // tap j reads window row 2 yl + F - 1 - j
-                        lo = fma_t(tp.lo[j], v[2 * yl + FT - 1 - j], lo);
-                        hq = fma_t(tp.hi[j], v[2 * yl + FT - 1 - j], hq);
+                        for (int j = 0; j < FT; ++j) acc = __builtin_elementwise_fma(pk2{tp.lo[j], tp.hi[j]}, pk2{v[2 * yl + FT - 1 - j], v[2 * yl + FT - 1 - j]}, acc);
+                        lo = acc.x;
+                        hq = acc.y;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < FT; ++j) {  // tap j reads window row 2 yl + F - 1 - j
+                            lo = fma_t(tp.lo[j], v[2 * yl + FT - 1 - j], lo);
+                            hq = fma_t(tp.hi[j], v[2 * yl + FT - 1 - j], hq);
+                        }
                     }
                     Half o2;
                     o2.v[0] = lo;
@@ -180,10 +189,19 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
 #pragma unroll
                 for (int yl = 0; yl < THS; ++yl) {
                     T lo = T(0), hq = T(0);
+                    if constexpr (std::is_same<T, float>::value) {
+                        typedef float pk2 __attribute__((ext_vector_type(2)));
+                        pk2 acc = {0.0f, 0.0f};
 #pragma unroll
-                    for (int j = 0; j < FT; ++j) {
-                        lo = fma_t(tp.lo[j], v[2 * yl + FT - 1 - j], lo);
-                        hq = fma_t(tp.hi[j], v[2 * yl + FT - 1 - j], hq);
+                        for (int j = 0; j < FT; ++j) acc = __builtin_elementwise_fma(pk2{tp.lo[j], tp.hi[j]}, pk2{v[2 * yl + FT - 1 - j], v[2 * yl + FT - 1 - j]}, acc);
+                        lo = acc.x;
+                        hq = acc.y;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < FT; ++j) {
+                            lo = fma_t(tp.lo[j], v[2 * yl + FT - 1 - j], lo);
+                            hq = fma_t(tp.hi[j], v[2 * yl + FT - 1 - j], hq);
+                        }
                     }
                     Half o2;
                     o2.v[0] = lo;
@@ -200,6 +218,31 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
             const Vec* row = tmp + yl * Ws;
             const int* xm = xmap + 2 * xo + (FT - 1);  // tap j reads slot xm[-j]
             T c_ll = T(0), c_h = T(0), c_v = T(0), c_d = T(0), u_ll = T(0), u_h = T(0), u_v = T(0), u_d = T(0);
+            if constexpr (std::is_same<T, float>::value) {
+                // fp32: (low W, high W) of one value share a packed FMA -- (lo[j], hi[j]) * q + (acc_lo, acc_hi)
+                typedef float pk2 __attribute__((ext_vector_type(2)));
+                pk2 a0 = {0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+                for (int j = 0; j < FT; ++j) {
+                    const int sx = xm[-j];
+                    Vec q = row[ZERO ? max(sx, 0) : sx];
+                    if constexpr (ZERO) {
+                        if (sx < 0) {
+#pragma unroll
+                            for (int e = 0; e < NV; ++e) q.v[e] = T(0);
+                        }
+                    }
+                    const pk2 t = {tp.lo[j], tp.hi[j]};
+                    a0 = __builtin_elementwise_fma(t, pk2{q.v[0], q.v[0]}, a0);
+                    a1 = __builtin_elementwise_fma(t, pk2{q.v[1], q.v[1]}, a1);
+                    if constexpr (PAIR) {
+                        a2 = __builtin_elementwise_fma(t, pk2{q.v[2], q.v[2]}, a2);
+                        a3 = __builtin_elementwise_fma(t, pk2{q.v[3], q.v[3]}, a3);
+                    }
+                }
+                c_ll = a0.x; c_v = a0.y; c_h = a1.x; c_d = a1.y;
+                u_ll = a2.x; u_v = a2.y; u_h = a3.x; u_d = a3.y;
+            } else {
 #pragma unroll
             for (int j = 0; j < FT; ++j) {
                 const int sx = xm[-j];
@@ -220,6 +263,7 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
                     u_h = fma_t(tp.lo[j], q.v[3], u_h);
                     u_d = fma_t(tp.hi[j], q.v[3], u_d);
                 }
+            }
             }
             const int o = (y0 + yl) * w + xo;
             if constexpr (PAIR) {
