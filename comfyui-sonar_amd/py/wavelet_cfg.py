@@ -187,31 +187,31 @@ class WCFGPercentages(NamedTuple):
             ends = _PCT_CACHE[(id(ms), start_sigma, end_sigma)] = (ms, pct_of(start_sigma), pct_of(end_sigma))
         pct_start, pct_end, pct_curr = ends[1], ends[2], pct_of(sigma)
         pct_range_curr = (pct_curr - pct_start) / (pct_end - pct_start)
-        pct_sigmas = pct_enabled_sigmas = step = steps = pct_steps = pct_enabled_steps = None
-        sigma_first = sigma_last = step_first = step_last = None
-        if sigmas is not None:
-            if sigmas.ndim == 2:
-                sigmas = sigmas.max(dim=0).values
-            elif sigmas.ndim != 1:
-                raise ValueError("Unexpected number of dimensions for sample_sigmas")
-            sigmas = sigmas.detach().cpu()
-            sigma_first, sigma_last = sigmas[0].item(), sigmas[-2].item()
-            if sigma_first <= sigma_last:
-                raise ValueError("Cannot handle non-descending sigmas (possibly Restart or unsampling)")
-            pct_sigmas = (sigma_first - sigma) / (sigma_first - sigma_last)
-            start_sigma, end_sigma = min(start_sigma, sigma_first), max(end_sigma, sigma_last)
-            sigma = min(max(sigma, sigma_last), sigma_first)
-            pct_enabled_sigmas = 1.0 if start_sigma == end_sigma else (start_sigma - sigma) / (start_sigma - end_sigma)
-            steps = len(sigmas) - 1
-            if steps > 1:
-                step = step_from_sigmas(sigma, sigmas)
-                pct_steps = step / (steps - 1) if step is not None else None
-                enabled = torch.arange(len(sigmas), dtype=torch.int32)[(sigmas <= start_sigma) & (sigmas >= end_sigma)]
-                if len(enabled) > 1:
-                    step_first, step_last = enabled[0].item(), enabled[-1].item()
-                    pct_enabled_steps = (step - step_first) / (step_last - step_first)
-            else:
-                step, pct_steps = 0.0, 1.0
+        if sigmas is None:
+            # ComfyUI always passes transformer_options["sample_sigmas"]; without them the reference binds neither step_first nor
+            # step_last (:188-193) and fails while building the tuple.  Same failure here rather than a silently different schedule.
+            raise UnboundLocalError("local variable 'step_first' referenced before assignment")
+        if sigmas.ndim == 2:
+            sigmas = sigmas.max(dim=0).values
+        elif sigmas.ndim != 1:
+            raise ValueError("Unexpected number of dimensions for sample_sigmas")
+        sigmas = sigmas.detach().cpu()
+        sigma_first, sigma_last = sigmas[0].item(), sigmas[-2].item()
+        if sigma_first <= sigma_last:
+            raise ValueError("Cannot handle non-descending sigmas (possibly Restart or unsampling)")
+        pct_sigmas = (sigma_first - sigma) / (sigma_first - sigma_last)
+        start_sigma, end_sigma = min(start_sigma, sigma_first), max(end_sigma, sigma_last)
+        sigma = min(max(sigma, sigma_last), sigma_first)
+        pct_enabled_sigmas = 1.0 if start_sigma == end_sigma else (start_sigma - sigma) / (start_sigma - end_sigma)
+        steps = len(sigmas) - 1  # >= 2 here: a two-entry schedule has sigma_first == sigmas[-2] and was rejected above
+        step = step_from_sigmas(sigma, sigmas)
+        pct_steps = step / (steps - 1) if step is not None else None
+        enabled = torch.arange(len(sigmas), dtype=torch.int32)[(sigmas <= start_sigma) & (sigmas >= end_sigma)]
+        if len(enabled) <= 1:
+            # fewer than two schedule points inside the rule's window: pct_enabled_steps is never bound in the reference (:181-187)
+            raise UnboundLocalError("local variable 'pct_enabled_steps' referenced before assignment")
+        step_first, step_last = enabled[0].item(), enabled[-1].item()
+        pct_enabled_steps = (step - step_first) / (step_last - step_first)  # step None (sigma off the schedule) -> TypeError, as there
         return WCFGPercentages(sigma=sigma, sigma_min=sigma_min, sigma_max=sigma_max, sigma_first=sigma_first, sigma_last=sigma_last,
                                steps=steps, step=step, step_first=step_first, step_last=step_last, pct_sampling=pct_curr,
                                pct_enabled_sampling=pct_range_curr, pct_sigmas=pct_sigmas, pct_enabled_sigmas=pct_enabled_sigmas,

@@ -174,20 +174,6 @@ def waverec1(yl: np.ndarray, yh, wave: str, mode: str):
     return lo
 
 
-def wavelet_cfg_1d(cond, uncond, wave, mode, level, *, diff_yl=1.0, diff_yh=1.0, strength=1.0):
-    """py/wavelet_cfg.py:713-715,737-738,750-791 in use_1d_dwt mode, `difference` rule, inject blend: the latents are flattened to
-    [B, C, H*W], every level has ONE detail band, the result is cropped to H*W and reshaped."""
-    shape = cond.shape
-    c, u = cond.reshape(*shape[:2], -1), uncond.reshape(*shape[:2], -1)
-    cl, ch = wavedec1(c, wave, mode, level)
-    ul, uh = wavedec1(u, wave, mode, level)
-    yh_scales = expand_yh_scales(level, 1, diff_yh)
-    dl = (cl - ul) * diff_yl
-    dh = [(a - b) * sc[0] for a, b, sc in zip(ch, uh, yh_scales)]
-    out = waverec1(ul + dl * strength, [b + d * strength for b, d in zip(uh, dh)], wave, mode)
-    return out[..., : c.shape[-1]].reshape(shape)
-
-
 # ------------------------------------------------------------------------------------------------ WaveletCFG arithmetic
 def expand_yh_scales(nbands: int, norient: int, yh_scales):
     """py/wavelet_functions.py:148-190 ("fill" repeats the previous entry up to the band count)."""
@@ -218,56 +204,140 @@ def expand_yh_scales(nbands: int, norient: int, yh_scales):
 
 
 def wavelet_scaling(yl, yh, yl_scale, yh_scales):
-    """py/wavelet_functions.py:193-216 (out of place)."""
+    """py/wavelet_functions.py:193-216 (out of place).  The reference indexes the scaled slice as ``ht[:, :, lidx]`` for
+    ``lidx < min(ht.shape[2], len(scales))``: axis 2 is the orientation axis of a 2-D band ``[B, C, 3, h, w]``, but for the 1-D
+    transform's bands ``[B, C, l]`` it is the COEFFICIENT axis and the table has one entry per band -- only coefficient 0 of every
+    row is scaled there (pinned by tests/golden/wavelet_scaling.npz, cases ``oned_*``)."""
     yl = yl * yl_scale if yl_scale != 1.0 else yl.copy()
-    scales = expand_yh_scales(len(yh), yh[0].shape[-3], 1.0 if yh_scales is None else yh_scales)
-    out = []
-    for sc, band in zip(scales, yh):
-        band = band.copy()
-        for o in range(min(band.shape[-3], len(sc))):
-            band[..., o, :, :] *= sc[o]
-        out.append(band)
+    norient = yh[0].shape[2] if yh[0].ndim > 3 else 1
+    scales = expand_yh_scales(len(yh), norient, 1.0 if yh_scales is None else yh_scales)
+    out = [band.copy() for band in yh]
+    for sc, band in zip(scales, out):
+        for o in range(min(band.shape[2], len(sc))):
+            band[:, :, o] *= sc[o]
     return yl, out
 
 
-def wavelet_cfg(cond, uncond, wave, mode, level, *, diff_yl=1.0, diff_yh=1.0, strength=1.0, blend="inject"):
-    """py/wavelet_cfg.py:750-791 with a `difference` rule only: result = blend(DWT(u), scale(DWT(c) - DWT(u)), s) -> IDWT."""
-    cl, ch = wavedec2(cond, wave, mode, level)
-    ul, uh = wavedec2(uncond, wave, mode, level)
-    dl, dh = wavelet_scaling(cl - ul, [a - b for a, b in zip(ch, uh)], diff_yl, diff_yh)
+def _lerp(a, b, t):
+    """torch.lerp: a + t (b - a) for |t| < 0.5, else b - (b - a)(1 - t)."""
+    return a + t * (b - a) if abs(t) < 0.5 else b - (b - a) * (1 - t)
 
-    def bl(a, b):
-        if blend == "inject":
-            return a + b * strength
-        if blend == "subtract_b":
-            return a - b * strength
-        return a + strength * (b - a) if abs(strength) < 0.5 else b - (b - a) * (1 - strength)
 
-    return waverec2(bl(ul, dl), [bl(a, b) for a, b in zip(uh, dh)], wave, mode)
+BLENDS = {"lerp": _lerp, "inject": lambda a, b, t: b * t + a, "subtract_b": lambda a, b, t: a - b * t}
+
+
+def wavelet_blend(a, b, *, yl_factor, blend, yh_factor=None, yh_blend=None):
+    """py/wavelet_functions.py:219-238 with named blends (py/utils.py:17-21)."""
+    yh_factor = yl_factor if yh_factor is None else yh_factor
+    fl, fh = BLENDS[blend], BLENDS[blend if yh_blend is None else yh_blend]
+    return fl(a[0], b[0], yl_factor), [fh(x, y, yh_factor) for x, y in zip(a[1], b[1])]
+
+
+def _transform(one_d):
+    return (wavedec1, waverec1) if one_d else (wavedec2, waverec2)
+
+
+def wavelet_cfg(cond, uncond, wave, mode, level, *, cond_scales=None, uncond_scales=None, diff_scales=None, final_scales=None, strength=1.0,
+                blend="inject", inv_wave=None, inv_mode=None, one_d=False):
+    """py/wavelet_cfg.py:750-791: ``IDWT(scale_f(blend(U, scale_d(C - U), s)))`` with ``C = scale_c(DWT cond)``, ``U = scale_u(DWT uncond)``.
+    ``*_scales`` are (yl_scale, yh_scales) pairs or None (rule section absent); returns the reconstruction at its own size."""
+    dec, rec = _transform(one_d)
+    cw, uw = dec(cond, wave, mode, level), dec(uncond, wave, mode, level)
+    if cond_scales is not None:
+        cw = wavelet_scaling(*cw, *cond_scales)
+    if uncond_scales is not None:
+        uw = wavelet_scaling(*uw, *uncond_scales)
+    dw = (cw[0] - uw[0], [a - b for a, b in zip(cw[1], uw[1])])
+    if diff_scales is not None:
+        dw = wavelet_scaling(*dw, *diff_scales)
+    rw = wavelet_blend(uw, dw, yl_factor=strength, blend=blend)
+    if final_scales is not None:
+        rw = wavelet_scaling(*rw, *final_scales)
+    return rec(rw[0], rw[1], inv_wave or wave, inv_mode or mode)
+
+
+def wavelet_cfg_call(args, *, target="denoised", high_precision=True, use_1d=False, wcfg_blend=1.0, blend_mode="lerp", fallback=None, ops=None,
+                     **transform_kw):
+    """py/wavelet_cfg.py:677-748,793-842 for a rule that matched: context (target selection, NOISE_NORM division, operation hooks,
+    flattening), the transform-domain step in fp64 / fp32, the optional blend with the fallback CFG result, crop, ``x - result`` /
+    ``* sigma``.  ``args``: numpy fp32 arrays input / cond / uncond / cond_denoised / uncond_denoised, sigma [B], cond_scale;
+    ``fallback(args)`` / ``ops[...]`` are numpy callables (None: plain CFG / no hook)."""
+    ops = ops or {}
+    x = args["input"]
+    sigma = args["sigma"].reshape(x.shape[0], *((1,) * (x.ndim - 1))).astype(np.float32)
+    if x.ndim == 3 and not use_1d:
+        raise RuntimeError("Enable use_1d_dwt mode for 3D latents.")
+    if x.ndim < 3:
+        raise RuntimeError("Wavelet CFG can't handle latents with 2 or less dimensions.")
+    if target == "denoised":
+        cond, uncond = args["cond_denoised"], args["uncond_denoised"]
+    else:
+        cond, uncond = args["cond"], args["uncond"]
+        if target == "noise_norm":
+            cond, uncond = cond / sigma, uncond / sigma
+    op_kw = dict(sigma=args["sigma"], cond=cond, uncond=uncond, cond_scale=args["cond_scale"])
+
+    def hook(name, t):
+        return ops[name](t, **op_kw) if ops.get(name) is not None else t
+
+    def plain_cfg(a):
+        return a["input"] - ((a["cond_denoised"] - a["uncond_denoised"]) * np.float32(a["cond_scale"]) + a["uncond_denoised"])
+
+    fallback = plain_cfg if fallback is None else fallback
+    cond, uncond = hook("operation_cond", cond), hook("operation_uncond", uncond)
+    if use_1d:
+        cond, uncond = cond.reshape(*cond.shape[:2], -1), uncond.reshape(*uncond.shape[:2], -1)
+    elif x.ndim > 4:
+        cond, uncond = cond.reshape(cond.shape[0], -1, *cond.shape[-2:]), uncond.reshape(uncond.shape[0], -1, *uncond.shape[-2:])
+    dt = np.float64 if high_precision else np.float32
+    result = wavelet_cfg(cond.astype(dt), uncond.astype(dt), one_d=use_1d, **transform_kw).astype(np.float32)
+    if blend_mode != "lerp" or wcfg_blend != 1.0:
+        normal = hook("operation_fallback_cfg", fallback(args))
+        if target == "denoised":
+            normal = x - normal
+        elif target == "noise_norm":
+            normal = normal / sigma
+        result = BLENDS[blend_mode](normal, result, np.float32(wcfg_blend)).astype(np.float32)
+    if use_1d:
+        result = result[..., : cond.shape[2]].reshape(x.shape)
+    elif x.ndim > 4:
+        result = result[..., : x.shape[-2], : x.shape[-1]].reshape(x.shape)
+    else:
+        result = result[tuple(slice(None, n) for n in x.shape)]
+    if target == "denoised":
+        result = x - result
+    elif target == "noise_norm":
+        result = result * sigma
+    return hook("operation_result", hook("operation_wavelet_cfg", result))
 
 
 def wavelet_filtered_noise(noise, *, wave="haar", mode="periodization", level=3, yl_scale=1.0, yh_scales=1.0, noise_high=None,
-                           yl_blend_high=0.0, yh_blend_high=1.0, blend="lerp", two_step_inverse=False, preblend_low=None,
-                           preblend_high=None):
-    """py/noise_generation.py:1980-2032 (WaveletFilteredNoiseGenerator.generate), 2-D DWT variant.
-    preblend_* = (yl_scale, yh_scales) pairs applied to the low / high decompositions before blending."""
-
-    def bl(a, b, t):
-        if blend == "inject":
-            return a + b * t
-        return a + t * (b - a) if abs(t) < 0.5 else b - (b - a) * (1 - t)
-
-    yl, yh = wavedec2(noise, wave, mode, level)
+                           yl_blend_high=0.0, yh_blend_high=1.0, yl_blend="lerp", yh_blend="lerp", two_step_inverse=False,
+                           preblend_low=None, preblend_high=None, inv_wave=None, inv_mode=None, use_1d_dwt=False):
+    """py/noise_generation.py:1968-2032 (WaveletFilteredNoiseGenerator.generate).  ``noise`` / ``noise_high``: the base draws,
+    [B, C, H, W] or [B, C, T, H, W] (frames fold into channels, :186-200); preblend_* = (yl_scale, yh_scales) pairs applied to the
+    low / high decompositions before blending (either member None -> 1.0, whole pair None -> step skipped)."""
+    shape = noise.shape
+    fold = (lambda t: t.reshape(t.shape[0], -1, *t.shape[-2:])) if noise.ndim == 5 else (lambda t: t)
+    noise = fold(noise)
+    work_shape = noise.shape
+    flat = (lambda t: t.reshape(*t.shape[:2], -1)) if use_1d_dwt else (lambda t: t)
+    dec, rec = _transform(use_1d_dwt)
+    inv_wave, inv_mode = inv_wave or wave, inv_mode or mode
+    yl, yh = dec(flat(noise), wave, mode, level)
     if noise_high is not None:
-        hl, hh = wavedec2(noise_high, wave, mode, level)
+        hl, hh = dec(flat(fold(noise_high)), wave, mode, level)
         if preblend_high is not None:
-            hl, hh = wavelet_scaling(hl, hh, *preblend_high)
+            hl, hh = wavelet_scaling(hl, hh, *(1.0 if v is None else v for v in preblend_high))
         if preblend_low is not None:
-            yl, yh = wavelet_scaling(yl, yh, *preblend_low)
-        yl, yh = bl(yl, hl, yl_blend_high), [bl(a, b, yh_blend_high) for a, b in zip(yh, hh)]
+            yl, yh = wavelet_scaling(yl, yh, *(1.0 if v is None else v for v in preblend_low))
+        yl, yh = wavelet_blend((yl, yh), (hl, hh), yl_factor=yl_blend_high, yh_factor=yh_blend_high, blend=yl_blend, yh_blend=yh_blend)
     yl, yh = wavelet_scaling(yl, yh, yl_scale, yh_scales)
     if two_step_inverse:
-        out = waverec2(np.zeros_like(yl), yh, wave, mode) + waverec2(yl, [np.zeros_like(b) for b in yh], wave, mode)
+        out = rec(np.zeros_like(yl), yh, inv_wave, inv_mode) + rec(yl, [np.zeros_like(b) for b in yh], inv_wave, inv_mode)
     else:
-        out = waverec2(yl, yh, wave, mode)
-    return out[tuple(slice(0, d) for d in noise.shape)]
+        out = rec(yl, yh, inv_wave, inv_mode)
+    if use_1d_dwt:
+        out = out.reshape(work_shape)
+    out = out[tuple(slice(0, d) for d in work_shape)]
+    return out.reshape(shape)
