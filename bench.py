@@ -228,7 +228,8 @@ def main():
                     999 * (1 - (sg.log() - math.log(0.03)) / (math.log(14.6) - math.log(0.03)))).clamp(0, 999))
                 cond, uncond, xin = (torch.randn(b4, C, H, W, device=device) for _ in range(3))
                 wargs = {"cond_denoised": cond, "uncond_denoised": uncond, "cond": xin - cond, "uncond": xin - uncond, "input": xin, "cond_scale": 7.0,
-                         "sigma": torch.full((b4,), 7.0, device=device), "model": types.SimpleNamespace(model_sampling=ms), "model_options": {}}
+                         "sigma": torch.full((b4,), 7.0, device=device), "model": types.SimpleNamespace(model_sampling=ms),
+                         "model_options": {"transformer_options": {"sample_sigmas": torch.cat([torch.linspace(14.6, 0.03, 20), torch.zeros(1)])}}}
                 for tag, hp in (("fp64", True), ("fp32", False)):  # the node's placeholder rule: db4, level 5, symmetric, difference scales 5 / 3
                     cfg_fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0), high_precision_mode=hp))
                     try:

@@ -118,11 +118,13 @@ __global__ void __launch_bounds__(kBlock) idwt_rows_kernel(const T* __restrict__
     }
 }
 
-template <typename T>
+// HEAD: the reference's band scaling on 1-D bands [B, C, l] (py/wavelet_functions.py:212-215 indexes axis 2, the coefficient axis
+// there): group 0 = the first coefficient of every row of group_size elements, group 1 (unit scales) = the rest.
+template <typename T, bool HEAD>
 __global__ void __launch_bounds__(kBlock) wcfg_band_kernel(const T* cond, const T* uncond, T* out /* may alias cond / uncond */, int64_t n, int64_t group_size, int groups,
                                                             BandScales<T> sc, int blend_mode, T strength) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const int g = groups > 1 ? (int)((i / group_size) % groups) : 0;
+        const int g = HEAD ? (int)(i % group_size != 0) : groups > 1 ? (int)((i / group_size) % groups) : 0;
         out[i] = band_combine<T>(cond[i], uncond[i], sc, g, blend_mode, strength);
     }
 }
@@ -281,7 +283,7 @@ static int dwt1_inv(const T* lo, int64_t lo_len, const T* hi, T* out, int64_t ro
     return check_launch(what);
 }
 
-template <typename T>
+template <typename T, bool HEAD = false>
 static int wcfg_band(const T* cond, const T* uncond, T* out, int64_t n, int64_t group_size, int64_t groups, const double* s_cond,
                      const double* s_uncond, const double* s_diff, const double* s_final, int blend_mode, double strength,
                      hipStream_t st, const char* what) {
@@ -289,14 +291,14 @@ static int wcfg_band(const T* cond, const T* uncond, T* out, int64_t n, int64_t 
                   SONAR_ERR_ARG, "%s: bad argument", what);
     BandScales<T> sc;
     for (int g = 0; g < 4; ++g) {
-        const bool in = g < groups;
+        const bool in = g < (HEAD ? 1 : groups);
         sc.cond[g] = in && s_cond ? (T)s_cond[g] : T(1);
         sc.uncond[g] = in && s_uncond ? (T)s_uncond[g] : T(1);
         sc.diff[g] = in && s_diff ? (T)s_diff[g] : T(1);
         sc.fin[g] = in && s_final ? (T)s_final[g] : T(1);
     }
     if (n == 0) return SONAR_OK;
-    hipLaunchKernelGGL((wcfg_band_kernel<T>), dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, st, cond, uncond, out, n, group_size,
+    hipLaunchKernelGGL((wcfg_band_kernel<T, HEAD>), dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, st, cond, uncond, out, n, group_size,
                        (int)groups, sc, blend_mode, (T)strength);
     return check_launch(what);
 }
@@ -364,6 +366,18 @@ extern "C" int sonar_wcfg_band_f64(const double* cond, const double* uncond, dou
                                    const double* s_final, int blend_mode, double strength, void* stream) {
     return wcfg_band<double>(cond, uncond, out, n, group_size, groups, s_cond, s_uncond, s_diff, s_final, blend_mode, strength,
                              (hipStream_t)stream, "sonar_wcfg_band_f64");
+}
+extern "C" int sonar_wcfg_band_head_f32(const float* cond, const float* uncond, float* out, int64_t n, int64_t row_len, const double* s_cond,
+                                        const double* s_uncond, const double* s_diff, const double* s_final, int blend_mode,
+                                        double strength, void* stream) {
+    return wcfg_band<float, true>(cond, uncond, out, n, row_len, 2, s_cond, s_uncond, s_diff, s_final, blend_mode, strength,
+                                  (hipStream_t)stream, "sonar_wcfg_band_head_f32");
+}
+extern "C" int sonar_wcfg_band_head_f64(const double* cond, const double* uncond, double* out, int64_t n, int64_t row_len,
+                                        const double* s_cond, const double* s_uncond, const double* s_diff, const double* s_final,
+                                        int blend_mode, double strength, void* stream) {
+    return wcfg_band<double, true>(cond, uncond, out, n, row_len, 2, s_cond, s_uncond, s_diff, s_final, blend_mode, strength,
+                                   (hipStream_t)stream, "sonar_wcfg_band_head_f64");
 }
 extern "C" int64_t sonar_wcfg_fused_ws_bytes(int64_t planes, int64_t H, int64_t W, int levels, int dec_len, int mode_fwd, int rec_len,
                                              int mode_inv, int elem_size) {

@@ -138,6 +138,9 @@ constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4
 #ifndef SONAR_FFT_TW_LDS
 #define SONAR_FFT_TW_LDS 0  // measured: constant-memory (scalar) twiddles 78 us vs LDS table 125 us at B=512
 #endif
+#ifndef SONAR_PW_SKIP
+#define SONAR_PW_SKIP 0  // profiling builds only (scratch/pw_passes.py): 1 draw, 2 column passes, 4 rows pass a, 8 rows pass b arithmetic, 16 global stores
+#endif
 constexpr int kFftThreads = SONAR_FFT_THREADS;  // waves per block x two blocks per CU (LDS-bound)
 // threads (= RNG thread slots) of a fixed-size plane's workgroup: 512 from 8192 values up, smaller planes take fewer so that
 // every pass has work for all of them (64 x 64: 256; 32 x 32: 128; 16 x 16: 64) and more workgroups share a CU
@@ -380,8 +383,9 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         if constexpr (SRC != 2) {
         // ---------------------------------------------------------------- fill: z * filter
         auto sink = [&](int ky, int kx, c32 v) { (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v; };
-        if constexpr (GEN) fill_plane_gen<H, W, S>(filter, rng, tid, A, T0, TM);
-        else fill_plane<H, W>(z, filter, plane, tid, sink);
+        if constexpr (GEN) {
+            if constexpr (!(SONAR_PW_SKIP & 1)) fill_plane_gen<H, W, S>(filter, rng, tid, A, T0, TM);
+        } else fill_plane<H, W>(z, filter, plane, tid, sink);
         __syncthreads();
         } else {
         // ---------------------------------------------------------------- forward r2c of a real plane (mirror of the inverse:
@@ -488,7 +492,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             }
             __syncthreads();
             // ------------------------------------------------------------ columns, pass a: radix CN1, one item per thread
-            {
+            if constexpr (!(SONAR_PW_SKIP & 2)) {
                 const int c = lane, n2 = wv;
                 c32 v[CN1];
 #pragma unroll
@@ -502,7 +506,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             __syncthreads();
             // ------------------------------------------------------------ columns, pass b: radix 8, rows 8 k1 .. 8 k1 + 7
 #pragma unroll
-            for (int it = 0; it < CN1 / 8; ++it) {
+            for (int it = 0; it < ((SONAR_PW_SKIP & 2) ? 0 : CN1 / 8); ++it) {
                 const int c = lane, k1 = wv + 8 * it;
                 c32 u[CN2];
 #pragma unroll
@@ -513,7 +517,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             }
             __syncthreads();
             // ------------------------------------------------------------ rows, pass a: n2 = wave, rows lane + 64 it
-            {
+            if constexpr (!(SONAR_PW_SKIP & 4)) {
                 constexpr int ITEMS = H / 64;
                 const int n2 = wv;
                 c32 g[ITEMS][RN1];
@@ -644,8 +648,8 @@ SONAR_UNROLL_ITEMS
             const int y = (r / CN2) + CN1 * (r % CN2);
             c32 u[RN2];
 #pragma unroll
-            for (int n2 = 0; n2 < RN2; ++n2) u[n2] = A[r * S + RN2 * k1 + n2];
-            idft<RN2>(u);
+            for (int n2 = 0; n2 < RN2; ++n2) u[n2] = (SONAR_PW_SKIP & 8) ? make_float2((float)(item + n2), 1.0f) : A[r * S + RN2 * k1 + n2];
+            if constexpr (!(SONAR_PW_SKIP & 8)) idft<RN2>(u);
             float* orow = oplane + (int64_t)y * W;
 #pragma unroll
             for (int k2 = 0; k2 < RN2; ++k2) {
@@ -657,7 +661,8 @@ SONAR_UNROLL_ITEMS
                     a = u[k2].x * scale;
                     b = u[k2].y * scale;
                 }
-                *reinterpret_cast<float2*>(orow + 2 * (k1 + RN1 * k2)) = make_float2(a, b);
+                if constexpr (!(SONAR_PW_SKIP & 16)) *reinterpret_cast<float2*>(orow + 2 * (k1 + RN1 * k2)) = make_float2(a, b);
+                else if (a == 123.456f && b == 654.321f) *reinterpret_cast<float2*>(orow) = make_float2(a, b);  // keeps the arithmetic alive
                 if constexpr (STATS) {
                     ps += a + b;
                     pq = __builtin_fmaf(a, a, __builtin_fmaf(b, b, pq));

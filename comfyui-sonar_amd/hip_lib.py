@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import weakref
 from typing import Optional, Sequence
 
 import torch  # noqa: F401  (must be imported before the .so so both share one HIP runtime)
@@ -124,6 +125,8 @@ SIGNATURES = {
     "sonar_dwt1_inv_f64": (_I, [_P, _I64, _P, _P, _I64, _I64, _I64, _PD, _PD, _I, _I, _P]),
     "sonar_wcfg_band_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
     "sonar_wcfg_band_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
+    "sonar_wcfg_band_head_f32": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
+    "sonar_wcfg_band_head_f64": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
     "sonar_wcfg_fused_ws_bytes": (_I64, [_I64, _I64, _I64, _I, _I, _I, _I, _I, _I]),
     "sonar_wcfg_fused_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _P, _I64, _P]),
@@ -160,32 +163,53 @@ def _check(rc: int, what: str) -> None:
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # ~1 us; torch.cuda.current_stream() builds a Stream object (~10 us)
+_last_device = -1  # device index of the tensor most recently checked by _dev (arguments are evaluated before _stream())
 
 
 def _stream() -> int:
-    """hipStream_t of torch's current stream on the current device (every kernel of this library is launched on it)."""
+    """hipStream_t of torch's current stream on the current device (every kernel of this library is launched on it).  The tensors
+    of the call must live on that device: a launch on another device's memory from this device's stream is never what was meant."""
+    cur = torch.cuda.current_device()
+    if _last_device >= 0 and _last_device != cur:
+        raise SonarHipError(f"tensor on cuda:{_last_device} but the current device is cuda:{cur}: select it (torch.cuda.device / set_device) first")
     if _RAW_STREAM is not None:
-        return _RAW_STREAM(torch.cuda.current_device())
+        return _RAW_STREAM(cur)
     return torch.cuda.current_stream().cuda_stream
 
 
 STATS_ATTR = "_sonar_partials"  # see py/utils.py attach_stats / pop_stats
+# storage address -> weak reference to the tensor that carries a statistics tag for it.  Raw-pointer kernels do not bump torch's
+# version counter, so a write through ANY view of a tagged tensor's storage (sibling views, views of views) must drop the tag:
+# keyed by storage, not by tensor object.  Tags live from a producer kernel to the next scale_noise, so this is almost always empty.
+TAGGED: dict = {}
+
+
+def tag_register(t: torch.Tensor) -> None:
+    key = t.untyped_storage().data_ptr()
+    TAGGED[key] = weakref.ref(t, lambda _r, k=key: TAGGED.pop(k, None))
+
+
+def tag_forget(t: torch.Tensor) -> None:
+    if TAGGED:
+        TAGGED.pop(t.untyped_storage().data_ptr(), None)
 
 
 def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
+    global _last_device
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
-    if STATS_ATTR in t.__dict__:  # any kernel that touches a tagged tensor drops its statistics tag (producers tag AFTER their launch)
-        del t.__dict__[STATS_ATTR]
-    base = t._base
-    if base is not None and STATS_ATTR in base.__dict__:  # ... also when it is reached through a view of the tagged tensor
-        del base.__dict__[STATS_ATTR]
+    if TAGGED:  # any kernel that touches the storage of a tagged tensor drops its statistics tag (producers tag AFTER their launch)
+        ref = TAGGED.pop(t.untyped_storage().data_ptr(), None)
+        owner = None if ref is None else ref()
+        if owner is not None:
+            owner.__dict__.pop(STATS_ATTR, None)
     if not t.is_cuda:
         raise SonarHipError(f"{name}: tensor lives on {t.device}; the Sonar HIP path only runs on a ROCm device")
     if t.dtype != dtype:
         raise SonarHipError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise SonarHipError(f"{name}: tensor must be contiguous")
+    _last_device = t.device.index
     return t.data_ptr()
 
 
@@ -837,6 +861,30 @@ def wcfg_band(cond: torch.Tensor, uncond: torch.Tensor, groups: int, s_cond, s_u
     _check(fn(_dev(cond, "cond", cond.dtype), _dev(uncond, "uncond", cond.dtype), _dev(out, "out", cond.dtype), cond.numel(), group_size, groups,
               arr(s_cond), arr(s_uncond), arr(s_diff), arr(s_final), BLEND_IDS[blend_mode], float(strength), _stream()), f"sonar_wcfg_band_{kind}")
     return out
+
+
+def wcfg_band_head(cond: torch.Tensor, uncond: torch.Tensor, s_cond, s_uncond, s_diff, s_final, blend_mode: str, strength: float,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The band arithmetic on a 1-D band [B, C, l]: the four scales (floats or None) act on coefficient 0 of each row only, as the
+    reference's ``ht[:, :, lidx]`` does there (py/wavelet_functions.py:212-215); the blend acts on every coefficient."""
+    kind = _wavelet_dtype(cond)
+    out = torch.empty_like(cond) if out is None else out
+    fn = load().sonar_wcfg_band_head_f32 if kind == "f32" else load().sonar_wcfg_band_head_f64
+
+    def arr(v):
+        return None if v is None else _darr([float(v)])
+
+    _check(fn(_dev(cond, "cond", cond.dtype), _dev(uncond, "uncond", cond.dtype), _dev(out, "out", cond.dtype), cond.numel(), cond.shape[-1],
+              arr(s_cond), arr(s_uncond), arr(s_diff), arr(s_final), BLEND_IDS[blend_mode], float(strength), _stream()), f"sonar_wcfg_band_head_{kind}")
+    return out
+
+
+def band_scale_head_(band: torch.Tensor, scale: float) -> torch.Tensor:
+    """band[:, :, 0] *= scale in place for a 1-D band [B, C, l] (see wcfg_band_head): the band rides in the uncond slot, whose scale
+    reaches coefficient 0 only, and an inject blend of strength 0 returns it (u + d * 0)."""
+    if float(scale) == 1.0:
+        return band
+    return wcfg_band_head(band, band, None, float(scale), None, None, "inject", 0.0, out=band)
 
 
 def band_scale_(band: torch.Tensor, scales) -> torch.Tensor:

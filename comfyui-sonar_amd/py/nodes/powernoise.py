@@ -200,7 +200,10 @@ class PowerNoiseItem(CustomNoiseItemBase):
                 noise = mixer(noise, shape, partials=partials)
             if defer_factor:
                 return noise
-            return scale_noise(attach_stats(noise, partials), self.factor, normalized=normalized)
+            # the statistics were written by the FFT kernel (identity mixer, normalising call) or by the mixer; otherwise the
+            # workspace is untouched memory and must not ride along
+            have_stats = (identity and normalized) or not identity
+            return scale_noise(attach_stats(noise, partials if have_stats else None), self.factor, normalized=normalized)
 
         defer_factor = False
         if not normalized:

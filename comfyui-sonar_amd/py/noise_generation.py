@@ -85,23 +85,21 @@ class NoiseError(Exception):
 # --------------------------------------------------------------------------------------------------
 # on-device RNG bookkeeping (generate mode)
 class DeviceRNG:
-    """Hands out Philox stream ids.  The key is torch's current global seed, so ``torch.manual_seed(s)``
-    makes device-generated noise reproducible exactly like it does for the reference's draws; the
-    stream counter restarts whenever the seed changes."""
+    """Hands out Philox stream ids from the state of torch's default generator of the current ROCm device -- the generator the
+    reference's ``cpu=False`` draws consume.  (seed, stream) = (its seed, its Philox offset / 4); taking ``count`` streams advances
+    the offset like a draw would, without launching anything.  So ``torch.manual_seed(s)`` (every call of it, same value or not),
+    ``torch.cuda.set_rng_state`` and ``torch.cuda.manual_seed`` rewind device-generated noise exactly as they rewind the
+    reference's, and ranks that seed alike stay in step (shard invariance)."""
 
     _lock = threading.Lock()
-    _seed: Optional[int] = None
-    _next = 0
 
     @classmethod
     def take(cls, count: int = 1) -> tuple[int, int]:
+        gen = torch.cuda.default_generators[torch.cuda.current_device()]
         with cls._lock:
-            seed = torch.initial_seed()
-            if seed != cls._seed:
-                cls._seed, cls._next = seed, 0
-            first = cls._next
-            cls._next += count
-            return seed, first
+            offset = gen.get_offset()
+            gen.set_offset(offset + 4 * int(count))  # Philox offsets move in units of 4
+        return gen.initial_seed(), offset // 4
 
 
 class _Shard(threading.local):

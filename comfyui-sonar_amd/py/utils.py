@@ -31,16 +31,18 @@ def fallback(val, default=None):
 def attach_stats(t: Tensor, partials: Optional[Tensor]) -> Tensor:
     if partials is not None:
         setattr(t, _STATS_ATTR, (partials, t._version))
+        hip_lib.tag_register(t)
     return t
 
 
 def pop_stats(t: Tensor) -> Optional[Tensor]:
-    """The tag is honoured only if nothing wrote to the tensor since: torch's in-place ops bump ``_version``; every kernel of this
-    library that is handed the tensor drops the tag (hip_lib._dev)."""
+    """The tag is honoured only if nothing wrote to the tensor since: torch's in-place ops bump ``_version`` (shared by all views of
+    a storage); every kernel of this library that is handed ANY view of the tensor's storage drops the tag (hip_lib._dev)."""
     p = getattr(t, _STATS_ATTR, None)
     if p is None:
         return None
     delattr(t, _STATS_ATTR)
+    hip_lib.tag_forget(t)
     partials, version = p
     return partials if version == t._version else None
 
@@ -94,9 +96,9 @@ def scale_noise(noise: Tensor, factor: float = 1.0, *, normalized: bool = True, 
     attached the statistics, in which case only the apply kernel runs."""
     n = noise.numel()
     if not normalized or n == 0:
+        pop_stats(noise)  # a tag that outlives this call would be picked up by a later normalisation of other contents
         if factor == 1:
             return noise
-        pop_stats(noise)
         _require_device(noise, "scale_noise")
         return hip_lib.scale_noise_(noise, factor, False, None)
     _require_device(noise, "scale_noise")

@@ -503,6 +503,18 @@ def _to_dtype(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t.to(dtype).contiguous()
 
 
+def _per_latent(t: torch.Tensor, sigma: torch.Tensor, *, divide: bool) -> torch.Tensor:
+    """``t / sigma`` or ``t * sigma`` with one sigma per latent (``sigma`` shaped [B, 1, ...], py/wavelet_cfg.py:697-699,746-747,832-833)
+    through the row kernel: (t - 0) / s and t * s + 0 are the reference's quotient / product exactly."""
+    rows = t.shape[0]
+    s = utils.as_f32(sigma.reshape(-1)).to(t.device)
+    if s.numel() == 1 and rows > 1:
+        s = s.expand(rows)
+    s = s.contiguous()
+    zero = torch.zeros_like(s)
+    return hip_lib.row_affine(0 if divide else 1, utils.as_f32(t).contiguous(), rows, t.numel() // max(rows, 1), zero, s)
+
+
 class WaveletCFG:
     """py/wavelet_cfg.py:626-842 — a ComfyUI ``sampler_cfg_function``."""
 
@@ -544,7 +556,7 @@ class WaveletCFG:
         if rule.target_mode in {WCFGTarget.NOISE, WCFGTarget.NOISE_NORM}:
             cond, uncond = args["cond"], args["uncond"]
             if rule.target_mode == WCFGTarget.NOISE_NORM:
-                cond, uncond = cond / sigma, uncond / sigma
+                cond, uncond = _per_latent(cond, sigma, divide=True), _per_latent(uncond, sigma, divide=True)
         elif rule.target_mode == WCFGTarget.DENOISED:
             cond, uncond = args["cond_denoised"], args["uncond_denoised"]
         else:
@@ -607,8 +619,16 @@ class WaveletCFG:
             return [None if tabs[name][1] is None else tabs[name][1][j] if j < len(tabs[name][1]) else None for name in ("cond", "uncond", "diff", "final")]
 
         yl = hip_lib.wcfg_band(condw[0], uncondw[0], 1, *[[tabs[n][0]] for n in ("cond", "uncond", "diff", "final")], mode, strength, out=condw[0])
-        norient = 1 if condw[0].ndim == 3 else 3  # 1-D transform: one detail band per level
-        out_yh = [hip_lib.wcfg_band(c, u, norient, *band_scales(j), mode, strength, out=c) for j, (c, u) in enumerate(zip(condw[1], uncondw[1]))]
+        if condw[0].ndim == 3:
+            # 1-D transform: one detail band [B, C, l] per level; the reference's band scaling reaches only coefficient 0 of each row
+            # there (wavelet_functions.wavelet_scaling), the blend every coefficient
+            def head(s):
+                return None if s is None else float(s[0] if isinstance(s, (tuple, list)) else s)
+
+            out_yh = [hip_lib.wcfg_band_head(c, u, *[head(s) for s in band_scales(j)], mode, strength, out=c)
+                      for j, (c, u) in enumerate(zip(condw[1], uncondw[1]))]
+        else:
+            out_yh = [hip_lib.wcfg_band(c, u, 3, *band_scales(j), mode, strength, out=c) for j, (c, u) in enumerate(zip(condw[1], uncondw[1]))]
         return ctx.wavelet.inverse(yl, out_yh)
 
     @classmethod
@@ -628,7 +648,7 @@ class WaveletCFG:
         if rule.target_mode == WCFGTarget.DENOISED:
             result = hip_lib.blend("subtract_b", utils.as_f32(ctx.x), utils.as_f32(result), 1.0)
         elif rule.target_mode == WCFGTarget.NOISE_NORM:
-            result = result * ctx.sigma
+            result = _per_latent(result, ctx.sigma, divide=False)
         return self.maybe_op(result, self.operation_wavelet_cfg, **ctx.op_kwargs)
 
     def __call__(self, args: dict) -> torch.Tensor:
@@ -667,7 +687,7 @@ class WaveletCFG:
             if rule.target_mode == WCFGTarget.DENOISED:
                 normal = hip_lib.blend("subtract_b", utils.as_f32(ctx.x), utils.as_f32(normal), 1.0)
             elif rule.target_mode == WCFGTarget.NOISE_NORM:
-                normal = normal / ctx.sigma
+                normal = _per_latent(normal, ctx.sigma, divide=True)
             crop = tuple(slice(None, sz) for sz in normal.shape)
             result = utils.BLENDING_MODES[rule.blend_mode](normal, result[crop].contiguous(), wcfg_blend)
         result = self.process_output(result=result, ctx=ctx, rule=rule)

@@ -164,9 +164,14 @@ def wavelet_scaling(yl: torch.Tensor, yh: Sequence, yl_scale, yh_scales, *, in_p
         hip_lib.band_scale_(yl, [float(yl_scale)])
     table = expand_yh_scales(yh, yh_scales=1.0 if yh_scales is None else yh_scales)
     for scales, band in zip(table, yh):
-        norient = band.shape[2] if band.ndim > 3 else 1  # 1-D transform: [B, C, l] bands, one scale each
         if isinstance(scales, (int, float)):
-            scales = (float(scales),) * norient
+            scales = (float(scales),)
+        if band.ndim <= 3:
+            # 1-D transform, bands [B, C, l]: the reference's ``ht[:, :, lidx] *= scales[lidx]`` walks axis 2 -- the coefficient axis
+            # here -- for lidx < len(scales) == 1, so only the first coefficient of every row is scaled (:212-215; golden `oned_*`)
+            hip_lib.band_scale_head_(band, scales[0])
+            continue
+        norient = band.shape[2]
         full = tuple(scales) + (1.0,) * (norient - len(scales))
         hip_lib.band_scale_(band, full[:norient])
     return (yl, yh)

@@ -344,6 +344,16 @@ int sonar_wcfg_band_f32(const float* cond, const float* uncond, float* out, int6
 int sonar_wcfg_band_f64(const double* cond, const double* uncond, double* out, int64_t n, int64_t group_size,
                         int64_t groups, const double* s_cond, const double* s_uncond, const double* s_diff,
                         const double* s_final, int blend_mode, double strength, void* stream);
+/* The same arithmetic on a band of the 1-D transform ([B, C, l] rows of row_len coefficients, use_1d_dwt).  The reference's
+ * wavelet_scaling (py/wavelet_functions.py:208-215) indexes axis 2 of every band: the orientation axis of a 2-D band, but the
+ * COEFFICIENT axis of a 1-D band, whose scale table has one entry -- so only the first coefficient of each row is scaled.
+ * s_* are HOST pointers to ONE double each (NULL = 1): applied where i % row_len == 0; every other element uses unit scales. */
+int sonar_wcfg_band_head_f32(const float* cond, const float* uncond, float* out, int64_t n, int64_t row_len,
+                             const double* s_cond, const double* s_uncond, const double* s_diff, const double* s_final,
+                             int blend_mode, double strength, void* stream);
+int sonar_wcfg_band_head_f64(const double* cond, const double* uncond, double* out, int64_t n, int64_t row_len,
+                             const double* s_cond, const double* s_uncond, const double* s_diff, const double* s_final,
+                             int blend_mode, double strength, void* stream);
 /* The whole transform-domain step of WaveletCFG in `2 * levels` launches (py/wavelet_cfg.py:750-791,729-748), LDS-staged:
  * each level's analysis handles cond and uncond together (fp32 inputs cast in registers), applies
  * blend(u*s_u, (c*s_c - u*s_u)*s_d, strength)*s_f per band before storing; each level's synthesis is one launch; the last

@@ -833,6 +833,32 @@ def gen_item_wrappers():
     save("item_wrappers", **cases)
 
 
+def gen_power_wrapped():
+    """RandomNoise / ChannelNoise over PowerNoiseItems with factor 1 and the identity channel mixer (py/noise.py:1022-1131 calling
+    py/nodes/powernoise.py:338-408 with normalized=False, then scale_noise(normalized=True) on the result)."""
+    cases = {}
+    N = ref.noise
+    shape = (2, 4, 16, 16)
+    sig = (torch.tensor(9.0), torch.tensor(6.0))
+
+    def chain(*items):
+        c = N.CustomNoiseChain()
+        for it in items:
+            c.add(it)
+        return c
+
+    item = N.RandomNoise(1.0, noise=chain(ref_power_item(), ref_power_item(alpha=2.0)), mix_count=1, normalize=None)
+    torch.manual_seed(46)
+    ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=46, cpu=True, normalized=True)
+    cases["random_power"] = torch.stack([ns(*sig) for _ in range(4)])
+    item = N.ChannelNoise(1.0, noise=chain(ref_power_item(), N.CustomNoiseItem(1.0, noise_type="gaussian")), insufficient_channels_mode="wrap",
+                          normalize=None)
+    torch.manual_seed(47)
+    ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=47, cpu=True, normalized=True)
+    cases["channel_power"] = torch.stack([ns(*sig) for _ in range(2)])
+    save("power_wrapped", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -856,6 +882,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_guided_noise()
     gen_modulated()
     gen_item_wrappers()
+    gen_power_wrapped()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

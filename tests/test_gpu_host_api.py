@@ -181,17 +181,14 @@ def test_power_noise_device_mode_statistics_and_shards(api):
     filt = item.make_filter(shape)[0, 0]
     ratio = (spec[1:40, 1:40] / filt[1:40, 1:40].square()).mean().item()
     assert abs(ratio - 1.0) < 0.1  # E|Z f|^2 = f^2 for unit complex normal Z
-    torch.manual_seed(123)
     parts = []
     for b0 in (0, 4):
         with api.noise_generation.shard_offset(b0):
             xs = torch.zeros((4, *shape[1:]), device="cuda")
             ns = item.make_noise_sampler(xs, None, None, seed=None, cpu=False, normalized=False)
-            api.noise_generation.DeviceRNG._next = 0  # same stream id for both "ranks"
+            torch.manual_seed(123)  # every "rank" seeds alike -> same stream ids
             parts.append(ns(None, None))
     torch.manual_seed(123)
-    api.noise_generation.DeviceRNG._next = 0
-    api.noise_generation.DeviceRNG._seed = None
     whole = item.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=False)(None, None)
     assert torch.equal(torch.cat(parts), whole)
     normed = item.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)(None, None)
@@ -369,7 +366,6 @@ def test_device_mode_distribution_and_shard_invariance(api, name):
 
     def gen(b0, b):
         torch.manual_seed(77)
-        NG.DeviceRNG._seed = None
         with NG.shard_offset(b0):
             x = torch.zeros((b, *shape[1:]), device="cuda")
             ns = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, factor=1.0, normalized=False)
@@ -378,7 +374,6 @@ def test_device_mode_distribution_and_shard_invariance(api, name):
     whole = gen(0, 8)
     assert torch.equal(torch.cat([gen(0, 3), gen(3, 5)]), whole)
     torch.manual_seed(77)
-    NG.DeviceRNG._seed = None
     x = torch.zeros(shape, device="cuda")
     normed = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, factor=1.0, normalized=True)(*SIG)
     thr = 2.5 / math.sqrt(normed.numel())  # scale_noise leaves statistics inside the threshold untouched
@@ -601,7 +596,6 @@ def test_power_noise_item_on_video_latents(api):
 
     def gen(xs, offset):
         torch.manual_seed(33)
-        ng.DeviceRNG._seed, ng.DeviceRNG._next = None, 0  # every "rank" starts its stream counter at 0
         with ng.shard_offset(offset):
             return item.make_noise_sampler(xs, None, None, seed=None, cpu=False, normalized=False)(None, None)
 
@@ -637,7 +631,6 @@ def test_single_item_chain_uses_the_fused_normalised_fill(api):
         for fused in (True, False):
             chain = chain_of(api, item(api, name, 1.0))
             torch.manual_seed(77)
-            ng.DeviceRNG._seed, ng.DeviceRNG._next = None, 0
             ns = chain.make_noise_sampler(x, 0.03, 14.6, seed=1, cpu=False, normalized=True)
             if not fused:
                 gen_cls = ng.GaussianNoiseGenerator if name == "gaussian" else ng.UniformNoiseGenerator
@@ -650,3 +643,21 @@ def test_single_item_chain_uses_the_fused_normalised_fill(api):
                     gen_cls.generate_normalized = saved
         close(outs[0], outs[1], rtol=1e-5, atol=1e-6)
         assert abs(outs[0].std().item() - 1.0) < 7e-3  # inside scale_noise's 2.5 / sqrt(n) band nothing is rescaled (uniform: 3.46 / sqrt 12)
+
+
+@pytest.mark.parametrize("name", ["gaussian", "perlin", "pyramid"])
+def test_reseeding_with_the_same_value_rewinds_device_noise(api, name):
+    """ComfyUI seeds before every run, usually with the same number: two runs in one process must draw the same device noise."""
+    x = torch.zeros(4, 4, 32, 32, device="cuda")
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(1234)
+        ns = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, factor=1.0, normalized=True)
+        runs.append(torch.stack([ns(*SIG) for _ in range(3)]))
+    assert torch.equal(runs[0], runs[1])
+    assert not torch.equal(runs[0][0], runs[0][1])  # consecutive calls within a run differ
+    state = torch.cuda.get_rng_state()
+    a = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, factor=1.0, normalized=True)(*SIG)
+    torch.cuda.set_rng_state(state)
+    b = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, factor=1.0, normalized=True)(*SIG)
+    assert torch.equal(a, b)

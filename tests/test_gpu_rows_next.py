@@ -2,8 +2,9 @@
 AdvancedPowerLawNoise), wavelet-filtered noise (WF) and the sigma-gated latent operations (L) — through the
 reference's plugin API with latents on the MI355X.
 
-Goldens: tests/golden/powerlaw.npz, latent_ops.npz (captured from the real reference).  WF has no reference-run
-golden (pytorch_wavelets is not installed anywhere): compared with oracle/dwt_oracle.py (pinned to PyWavelets 1.1.1).
+Goldens: tests/golden/powerlaw.npz, latent_ops.npz (captured from the real reference).  WF here: against
+oracle/dwt_oracle.py (pinned to the reference's own WF outputs by tests/test_wavelet_oracle_cpu.py); the reference-run WF
+fixtures themselves are compared in tests/test_gpu_wavelet_golden.py.
 Tolerances: elementwise rows rtol 2e-5 / atol 5e-6 (powf differs from ATen's pow by <= 2 ulp); WF rtol/atol 3e-5."""
 import importlib
 import math
@@ -145,8 +146,7 @@ def test_wavelet_filtered_generator_1d_mode(api):
     out = gen(*SIG)
     torch.manual_seed(9)
     base = torch.randn(shape).numpy().astype(np.float64).reshape(2, 4, -1)
-    yl, yh = dwo.wavedec1(base, "db2", "periodization", 2)
-    want = dwo.waverec1(yl * 0.5, [yh[0] * 2.0, yh[1] * 1.5], "db2", "periodization").reshape(shape)
+    want = dwo.wavelet_filtered_noise(base.reshape(shape), use_1d_dwt=True, wave="db2", level=2, yl_scale=0.5, yh_scales=[2.0, 1.5])
     close(out, torch.from_numpy(want), rtol=3e-5, atol=3e-5)
 
 
@@ -161,7 +161,7 @@ def test_wavelet_filtered_item_with_high_noise(api):
     torch.manual_seed(12)
     low, high = torch.randn(shape), torch.randn(shape)
     raw = dwo.wavelet_filtered_noise(low.numpy().astype(np.float64), noise_high=high.numpy().astype(np.float64), wave="db2", level=2,
-                                     mode="periodization", yh_scales=[1.0, 0.5], preblend_high=(2.0, 1.0))
+                                     mode="periodization", yh_scales=[1.0, 0.5], preblend_high=(2.0, None))
     from oracle import sonar_oracle as orc
 
     want = orc.scale_noise(torch.from_numpy(raw).float(), 1.0, normalized=True)
@@ -492,3 +492,31 @@ def test_per_dim_noise(api, golden, tag, kw):
     torch.manual_seed(45)
     ns = item.clone().make_noise_sampler(torch.zeros(2, 4, 8, 8, device="cuda"), 0.03, 14.6, seed=45, cpu=True, normalized=True)
     close(_sequence(ns, 2), g[f"perdim_{tag}"], rtol=2e-5, atol=2e-5)
+
+
+def _power_item(api, **kw):
+    args = dict(time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0, common_mode=0.0,
+                channel_correlation="1,1,1,1,1,1")
+    args.update(kw)
+    return api.powernoise.PowerNoiseItem(1.0, **args)
+
+
+def test_wrappers_over_power_items(api, golden):
+    """RandomNoise / ChannelNoise call their items with normalized=False and normalise the result themselves: a PowerNoiseItem with
+    factor 1 and the identity mixer returns early from its own scale_noise and must not hand on a statistics tag it never filled."""
+    g = golden("power_wrapped")
+    x = torch.zeros(2, 4, 16, 16, device="cuda")
+    chain = api.noise.CustomNoiseChain()
+    chain.add(_power_item(api))
+    chain.add(_power_item(api, alpha=2.0))
+    item = api.noise.RandomNoise(1.0, noise=chain, mix_count=1, normalize=None)
+    torch.manual_seed(46)
+    ns = item.make_noise_sampler(x, 0.03, 14.6, seed=46, cpu=True, normalized=True)
+    near(_sequence(ns, 4), g["random_power"])
+    chain = api.noise.CustomNoiseChain()
+    chain.add(_power_item(api))
+    chain.add(api.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    item = api.noise.ChannelNoise(1.0, noise=chain, insufficient_channels_mode="wrap", normalize=None)
+    torch.manual_seed(47)
+    ns = item.make_noise_sampler(x, 0.03, 14.6, seed=47, cpu=True, normalized=True)
+    near(_sequence(ns, 2), g["channel_power"])

@@ -1,7 +1,11 @@
-"""-m gpu: 2-D DWT / IDWT kernels and WaveletCFG against PyWavelets 1.1.1 golden vectors and the numpy oracle.
+"""-m gpu: 2-D DWT / IDWT kernels against PyWavelets 1.1.1 golden vectors, and WaveletCFG at SDXL sizes against the numpy oracle
+(oracle/dwt_oracle.py, itself pinned to the reference's own outputs by tests/test_wavelet_oracle_cpu.py; the reference-run
+fixtures proper are compared in tests/test_gpu_wavelet_golden.py).
 
 Tolerance: fp64 path 1e-11 (same arithmetic, different summation order); fp32 path rtol 2e-5 / atol 2e-5 on
-O(1) data (taps rounded to fp32, 8-tap dot products over up to 5 levels)."""
+O(1) data (taps rounded to fp32, 8-tap dot products over up to 5 levels).  WaveletCFG outputs: absolute, relative to the
+output's peak (the placeholder rule scales the approximation band by 5 and the detail bands by 3, so outputs reach O(20) and
+the fp32 transform's 2e-5-class error grows with them): 2e-6 x peak for fp64 rules, 5e-5 x peak for fp32 rules."""
 import importlib
 import types
 
@@ -110,17 +114,15 @@ def test_wavelist_and_errors(api):
         api.wf.Wavelet(use_dtcwt=True)
 
 
-class FakeSampling:
-    sigma_min = torch.tensor(0.03)
-    sigma_max = torch.tensor(14.6)
+from tests.golden.wavelet_cases import SAMPLE_SIGMAS, FakeModel  # noqa: E402
 
-    @staticmethod
-    def timestep(sigma):
-        return (999 * (1 - (sigma.log() - np.log(0.03)) / (np.log(14.6) - np.log(0.03)))).clamp(0, 999)
+# ComfyUI hands the sampler's sigma schedule to every cfg function; the reference cannot build its percentages without it
+MODEL_OPTIONS = {"transformer_options": {"sample_sigmas": SAMPLE_SIGMAS["karras12"]}}
 
 
-class FakeModel:
-    model_sampling = FakeSampling()
+def wcfg_close(out, want, high_precision):
+    want = want.float() if isinstance(want, torch.Tensor) else torch.from_numpy(np.asarray(want, dtype=np.float32))
+    torch.testing.assert_close(out.cpu(), want, rtol=0, atol=(2e-6 if high_precision else 5e-5) * max(1.0, float(want.abs().max())))
 
 
 PLACEHOLDER_RULE = dict(difference=dict(yl_scale=5.0, yh_scales=3.0))  # the node's placeholder YAML (py/nodes/misc.py)
@@ -139,18 +141,18 @@ def test_wavelet_cfg_matches_oracle(api, high_precision, extra):
     rules = api.wc.WCFGRules.build(**params)
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=rules)
     args = {"input": x.cuda(), "cond_scale": 7.0, "cond": (x - cond).cuda(), "uncond": (x - uncond).cuda(), "cond_denoised": cond.cuda(),
-            "uncond_denoised": uncond.cuda(), "sigma": torch.full((2,), 7.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+            "uncond_denoised": uncond.cuda(), "sigma": torch.full((2,), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
     out = fn(args)
     assert out.is_contiguous() and out.shape == x.shape and out.dtype == torch.float32
     rule = rules[0]
     ws = rule.wavelet
     diff = params["difference"]
     dt = np.float64 if high_precision else np.float32
-    res = dwo.wavelet_cfg(cond.numpy().astype(dt), uncond.numpy().astype(dt), ws.wave, ws.padding_mode, ws.level, diff_yl=diff["yl_scale"],
-                          diff_yh=diff["yh_scales"], strength=params.get("difference_blend_strength", 1.0),
+    res = dwo.wavelet_cfg(cond.numpy().astype(dt), uncond.numpy().astype(dt), ws.wave, ws.padding_mode, ws.level,
+                          diff_scales=(diff["yl_scale"], diff["yh_scales"]), strength=params.get("difference_blend_strength", 1.0),
                           blend=params.get("difference_blend_mode", "inject"))
     want = x - torch.from_numpy(res[..., :128, :128].astype(np.float32))
-    torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=(2e-5 if high_precision else 2e-4))
+    wcfg_close(out, want, high_precision)
 
 
 @pytest.mark.parametrize("high_precision", [True, False])
@@ -163,15 +165,15 @@ def test_wavelet_cfg_1d_mode_matches_oracle(api, high_precision):
     rules = api.wc.WCFGRules.build(**params)
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=rules)
     args = {"input": x.cuda(), "cond_scale": 7.0, "cond": (x - cond).cuda(), "uncond": (x - uncond).cuda(), "cond_denoised": cond.cuda(),
-            "uncond_denoised": uncond.cuda(), "sigma": torch.full((2,), 7.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+            "uncond_denoised": uncond.cuda(), "sigma": torch.full((2,), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
     out = fn(args)
     assert out.is_contiguous() and out.shape == x.shape and out.dtype == torch.float32
     ws = rules[0].wavelet
     dt = np.float64 if high_precision else np.float32
-    res = dwo.wavelet_cfg_1d(cond.numpy().astype(dt), uncond.numpy().astype(dt), ws.wave, ws.padding_mode, ws.level, diff_yl=2.0,
-                             diff_yh=[3.0, 0.5, "fill"])
-    want = x - torch.from_numpy(res.astype(np.float32))
-    torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=(2e-5 if high_precision else 2e-4))
+    flat = lambda t: t.numpy().astype(dt).reshape(2, 4, -1)  # noqa: E731
+    res = dwo.wavelet_cfg(flat(cond), flat(uncond), ws.wave, ws.padding_mode, ws.level, diff_scales=(2.0, [3.0, 0.5, "fill"]), one_d=True)
+    want = x - torch.from_numpy(res[..., : 24 * 20].reshape(shape).astype(np.float32))
+    wcfg_close(out, want, high_precision)
     # a 3-D latent needs the 1-D mode (py/wavelet_cfg.py:681-682)
     rules2 = api.wc.WCFGRules.build(difference=dict(yl_scale=2.0))
     with pytest.raises(RuntimeError):
@@ -184,7 +186,7 @@ def test_wavelet_cfg_rule_window_and_blend(api):
     shape = (1, 4, 64, 64)
     cond, uncond, x = (torch.randn(shape, device="cuda") for _ in range(3))
     args = {"input": x, "cond_scale": 5.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
-            "sigma": torch.full((1,), 3.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+            "sigma": torch.full((1,), 3.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
     plain = x - (uncond + (cond - uncond) * 5.0)
     # outside the rule's sigma window -> plain CFG
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(start_sigma=14.0, end_sigma=5.0, **PLACEHOLDER_RULE))
@@ -213,7 +215,7 @@ def test_wavelet_cfg_fused_equals_per_pass_path(api, monkeypatch, high_precision
     params = dict(PLACEHOLDER_RULE, high_precision_mode=high_precision)
     params.update(extra)
     args = {"input": x, "cond_scale": 7.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
-            "sigma": torch.full((3,), 7.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+            "sigma": torch.full((3,), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
     calls = []
     real = api.hl.wcfg_fused
@@ -231,6 +233,6 @@ def test_wavelet_cfg_fused_full_batch_identity(api):
     shape = (256, 4, 128, 128)
     cond, uncond, x = (torch.randn(shape, device="cuda") for _ in range(3))
     args = {"input": x, "cond_scale": 7.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
-            "sigma": torch.full((256,), 7.0, device="cuda"), "model": FakeModel(), "model_options": {}}
+            "sigma": torch.full((256,), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(difference=dict(yl_scale=1.0, yh_scales=1.0), high_precision_mode=False))
     torch.testing.assert_close(fn(args), x - cond, rtol=0, atol=2e-5)
