@@ -141,6 +141,12 @@ constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4
 #ifndef SONAR_PW_SKIP
 #define SONAR_PW_SKIP 0  // profiling builds only (scratch/pw_passes.py): 1 draw, 2 column passes, 4 rows pass a, 8 rows pass b arithmetic, 16 global stores
 #endif
+#ifdef SONAR_PW_TRACE  // profiling builds: per-phase s_memtime stamps of wave 0 of every workgroup (scratch/pw_trace.py)
+__device__ unsigned long long g_pw_trace[1024 * 8 * 12];
+#define SONAR_STAMP(slot) do { if (tid == 0 && pidx < 8) g_pw_trace[(blockIdx.x * 8 + pidx) * 12 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SONAR_STAMP(slot) do { } while (0)
+#endif
 constexpr int kFftThreads = SONAR_FFT_THREADS;  // waves per block x two blocks per CU (LDS-bound)
 // threads (= RNG thread slots) of a fixed-size plane's workgroup: 512 from 8192 values up, smaller planes take fewer so that
 // every pass has work for all of them (64 x 64: 256; 32 x 32: 128; 16 x 16: 64) and more workgroups share a CU
@@ -154,6 +160,17 @@ struct PlaneCfg {
     static constexpr int S = M + 1;       // LDS row stride (complex): odd -> rows hit distinct banks
     static constexpr int CN1 = split_n1(H), CN2 = H / CN1;
     static constexpr int RN1 = split_n1(M), RN2 = M / RN1;
+    // Column of element (k1, n2) of a row BETWEEN the two row passes (inverse: written by pass a, read by pass b; forward: written by
+    // pass b', read by pass a').  The natural k = RN2 k1 + n2 puts the RN1 lanes of a row that pass b runs side by side (k1 = lane %
+    // RN1) RN2 complex values = 16 dwords apart: with S = 1 mod 16 the 16 lanes of an LDS access group (ds_read2_b64 / ds_write2_b64:
+    // 16 contiguous lanes, 32 banks) fall on 2 * 16 / RN1 bank pairs -- a 4-way conflict at M = 64.  Spreading k1 with stride
+    // G = 16 / RN1 (the rows of a group fill the gaps: bank pair = row + G k1 + n2 % G) makes the access conflict-free; lanes = rows
+    // accesses (the other pass) only see a different constant offset.
+    static constexpr bool kRowSwizzle = RN1 <= 16 && 16 % RN1 == 0 && RN2 % (16 / RN1) == 0 && S % 16 == 1;
+    static __host__ __device__ constexpr int rpos(int k1, int n2) {
+        constexpr int G = kRowSwizzle ? 16 / RN1 : 1;
+        return kRowSwizzle ? G * k1 + (n2 % G) + 16 * (n2 / G) : RN2 * k1 + n2;
+    }
     // plane + raw columns 0 and M (side buffers) + twiddle table
     static constexpr int kLdsComplex = H * S + 2 * H + 256;
     static constexpr size_t kLdsBytes = (size_t)kLdsComplex * sizeof(c32);
@@ -369,6 +386,11 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
     };
     if constexpr (FAST) load_twiddles(wv);
 
+#ifdef SONAR_PW_DESYNC  // profiling builds: the second resident workgroup of every CU starts late (out of phase with the first)
+    if (blockIdx.x >= gridDim.x / 2)
+        for (int i = 0; i < SONAR_PW_DESYNC; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
+    [[maybe_unused]] int pidx = 0;  // planes this workgroup has started (trace builds)
     // one workgroup draws the `group` planes of an RNG group back to back (group = 1 unless generating)
     for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
     const GroupWalk gw(unit, group, split);
@@ -380,13 +402,16 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
     for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
         const int64_t plane = gw.grp * group + gp;
         __syncthreads();  // previous plane's LDS reads are done (and TW is visible)
+        SONAR_STAMP(0);
         if constexpr (SRC != 2) {
         // ---------------------------------------------------------------- fill: z * filter
         auto sink = [&](int ky, int kx, c32 v) { (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v; };
         if constexpr (GEN) {
             if constexpr (!(SONAR_PW_SKIP & 1)) fill_plane_gen<H, W, S>(filter, rng, tid, A, T0, TM);
         } else fill_plane<H, W>(z, filter, plane, tid, sink);
+        SONAR_STAMP(1);
         __syncthreads();
+        SONAR_STAMP(2);
         } else {
         // ---------------------------------------------------------------- forward r2c of a real plane (mirror of the inverse:
         // the same four-step splits run backwards, so the spectrum lands in natural (ky, kx) order where the inverse reads it)
@@ -405,18 +430,34 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
 #pragma unroll
             for (int n2 = 1; n2 < RN2; ++n2) u[n2] = cmulc(u[n2], tw(n2 * k1, M, false));
 #pragma unroll
-            for (int n2 = 0; n2 < RN2; ++n2) A[r * S + RN2 * k1 + n2] = u[n2];
+            for (int n2 = 0; n2 < RN2; ++n2) A[r * S + C::rpos(k1, n2)] = u[n2];
         }
         __syncthreads();
-        // rows, pass a': DFT over k1 -> n1: C[k = RN2 n1 + n2], in place
-        for (int item = tid; item < RN2 * H; item += NT) {
-            const int r = item % H, n2 = item / H;
-            c32 v[RN1];
+        // rows, pass a': DFT over k1 -> n1: C[k = RN2 n1 + n2]; reads the swizzled columns, writes the natural ones (what the split
+        // and the column passes index), so every read of the pass is done before the first write
+        {
+            constexpr int ITEMS = (RN2 * H + NT - 1) / NT;
+            c32 v[ITEMS][RN1];
 #pragma unroll
-            for (int k1 = 0; k1 < RN1; ++k1) v[k1] = A[r * S + RN2 * k1 + n2];
-            fdft<RN1>(v);
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * NT;
+                if (item < RN2 * H) {
+                    const int r = item % H, n2 = item / H;
 #pragma unroll
-            for (int n1 = 0; n1 < RN1; ++n1) A[r * S + RN2 * n1 + n2] = v[n1];
+                    for (int k1 = 0; k1 < RN1; ++k1) v[it][k1] = A[r * S + C::rpos(k1, n2)];
+                    fdft<RN1>(v[it]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * NT;
+                if (item < RN2 * H) {
+                    const int r = item % H, n2 = item / H;
+#pragma unroll
+                    for (int n1 = 0; n1 < RN1; ++n1) A[r * S + RN2 * n1 + n2] = v[it][n1];
+                }
+            }
         }
         __syncthreads();
         // r2c split: X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i,
@@ -491,6 +532,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
                 A[ky * S] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
             }
             __syncthreads();
+            SONAR_STAMP(3);
             // ------------------------------------------------------------ columns, pass a: radix CN1, one item per thread
             if constexpr (!(SONAR_PW_SKIP & 2)) {
                 const int c = lane, n2 = wv;
@@ -503,7 +545,9 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
 #pragma unroll
                 for (int k1 = 0; k1 < CN1; ++k1) A[(CN2 * k1 + n2) * S + c] = v[k1];
             }
+            SONAR_STAMP(4);
             __syncthreads();
+            SONAR_STAMP(5);
             // ------------------------------------------------------------ columns, pass b: radix 8, rows 8 k1 .. 8 k1 + 7
 #pragma unroll
             for (int it = 0; it < ((SONAR_PW_SKIP & 2) ? 0 : CN1 / 8); ++it) {
@@ -515,7 +559,9 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
 #pragma unroll
                 for (int k2 = 0; k2 < CN2; ++k2) A[(CN2 * k1 + k2) * S + c] = u[k2];
             }
+            SONAR_STAMP(6);
             __syncthreads();
+            SONAR_STAMP(7);
             // ------------------------------------------------------------ rows, pass a: n2 = wave, rows lane + 64 it
             if constexpr (!(SONAR_PW_SKIP & 4)) {
                 constexpr int ITEMS = H / 64;
@@ -543,14 +589,17 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
 #pragma unroll
                     for (int k1 = 1; k1 < RN1; ++k1) g[it][k1] = cmul(g[it][k1], ptw[k1]);
                 }
+                SONAR_STAMP(8);
                 __syncthreads();  // every mirrored read is done before anyone overwrites
 #pragma unroll
                 for (int it = 0; it < ITEMS; ++it) {
 #pragma unroll
-                    for (int k1 = 0; k1 < RN1; ++k1) A[(lane + 64 * it) * S + RN2 * k1 + n2] = g[it][k1];
+                    for (int k1 = 0; k1 < RN1; ++k1) A[(lane + 64 * it) * S + C::rpos(k1, n2)] = g[it][k1];
                 }
             }
+            SONAR_STAMP(9);
             __syncthreads();
+            SONAR_STAMP(10);
         } else {
         // ---------------------------------------------------------------- columns, pass a
         // Column 0 is built on the fly from the raw kx = 0 / kx = M columns:
@@ -633,7 +682,7 @@ SONAR_UNROLL_ITEMS
                     const int r = item % H;
                     const int n2 = item / H;
 #pragma unroll
-                    for (int k1 = 0; k1 < RN1; ++k1) A[r * S + RN2 * k1 + n2] = g[it][k1];
+                    for (int k1 = 0; k1 < RN1; ++k1) A[r * S + C::rpos(k1, n2)] = g[it][k1];
                 }
             }
         }
@@ -648,7 +697,7 @@ SONAR_UNROLL_ITEMS
             const int y = (r / CN2) + CN1 * (r % CN2);
             c32 u[RN2];
 #pragma unroll
-            for (int n2 = 0; n2 < RN2; ++n2) u[n2] = (SONAR_PW_SKIP & 8) ? make_float2((float)(item + n2), 1.0f) : A[r * S + RN2 * k1 + n2];
+            for (int n2 = 0; n2 < RN2; ++n2) u[n2] = (SONAR_PW_SKIP & 8) ? make_float2((float)(item + n2), 1.0f) : A[r * S + C::rpos(k1, n2)];
             if constexpr (!(SONAR_PW_SKIP & 8)) idft<RN2>(u);
             float* orow = oplane + (int64_t)y * W;
 #pragma unroll
@@ -673,6 +722,8 @@ SONAR_UNROLL_ITEMS
             s += (double)ps;
             q += (double)pq;
         }
+        SONAR_STAMP(11);
+        ++pidx;
     }
     }
     if constexpr (STATS) write_partial<NT>(s, q, partials, red);
@@ -874,6 +925,12 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
               (long long)H, (long long)W);
     return SONAR_ERR_UNSUPPORTED;
 }
+
+#ifdef SONAR_PW_TRACE
+extern "C" int sonar_debug_pw_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sonar::g_pw_trace), sizeof(sonar::g_pw_trace));
+}
+#endif
 
 extern "C" int sonar_power_plane_kind(int64_t H, int64_t W) {
     static const int fast[][2] = {{128, 128}, {64, 64}, {32, 32}, {16, 16}, {256, 128}, {128, 256}, {128, 64}, {64, 128}, {64, 32}, {32, 64},

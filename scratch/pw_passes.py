@@ -35,4 +35,8 @@ for name in names:
                                            C.c_int, C.c_void_p, C.c_void_p]
     pair = timed(lambda: lib.sonar_power_noise_f32(filt.data_ptr(), out.data_ptr(), planes, H, W, 1, 2, 0, 4, 1.0, 2.5, partials.data_ptr(), stream))
     final = timed(lambda: lib.sonar_power_irfft2_f32(None, filt.data_ptr(), out.data_ptr(), planes, H, W, 1, 2, 0, 4, None, stream))
+    lib.sonar_spectral_filter_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    xin = torch.randn(planes, H, W, device=dev)
+    sf = timed(lambda: lib.sonar_spectral_filter_f32(xin.data_ptr(), filt.data_ptr(), out.data_ptr(), planes, H, W, None, stream), 50)
+    print(f"{name:24s} spectral filter {sf:7.1f} us", flush=True)
     print(f"{name:24s} pair {pair:7.1f} us   final pass alone {final:7.1f} us   std {out.std().item():.4f}", flush=True)
