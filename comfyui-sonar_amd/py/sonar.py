@@ -189,11 +189,22 @@ class SonarBase:
             hip_lib.scale_noise_(hist, cfg.rand_init_noise_multiplier, False, None)
         return hist
 
+    def _rand_init_due(self, step: int) -> bool:
+        return self.history_d is None and self.cfg.init == HistoryType.RAND and self.check_step(step, is_history=True)
+
+    def prefetch_rand_history(self, x: Tensor, step: int) -> None:
+        """Draws the RAND history now if this step will create it.  The reference draws it inside momentum_step, i.e. BEFORE the
+        step's ancestral noise (py/sonar.py:262-320, 541-573); a sampler that fetches its noise first (to fuse the add into the step
+        kernel) calls this ahead of the fetch so that the global generator is consumed in the reference's order."""
+        if self._rand_init_due(step) and getattr(self, "_rand_pre", None) is None:
+            self._rand_pre = self._rand_history(x)
+
     def _history_for_kernel(self, x: Tensor, step: int, kc: hip_lib.MomentumCfg) -> Optional[Tensor]:
         """RAND init creates the history inside the step, after the denoised mix read 'no history'."""
-        if self.history_d is None and self.cfg.init == HistoryType.RAND and self.check_step(step, is_history=True):
+        if self._rand_init_due(step):
             kc.h_in_fresh = 1
-            return self._rand_history(x)
+            pre, self._rand_pre = getattr(self, "_rand_pre", None), None
+            return pre if pre is not None else self._rand_history(x)
         return self.history_d
 
     # ---- reference-signature building blocks (unfused; the samplers below use the fused kernels)
@@ -407,6 +418,7 @@ class SonarEulerAncestral(SonarSampler):
         add_noise = h_next > 0
         if add_noise and not self.guidance_active(step_index):
             # the noise add rides in the step kernel: x' = md*dt + x + noise*(s_noise*sigma_up)
+            self.prefetch_rand_history(sample, step_index)
             nz = utils.as_f32(self.noise_sampler(sigma, self.sigmas[step_index + 1]))
             utils.pop_stats(nz)
             scale = float(torch.as_tensor(self.s_noise * sigma_up, dtype=torch.float32))

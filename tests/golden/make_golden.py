@@ -9,6 +9,7 @@ not reproduce the reference (bit-exact where the op sequence is identical).
 """
 from __future__ import annotations
 
+import importlib
 import math
 import os
 import sys
@@ -859,6 +860,89 @@ def gen_power_wrapped():
     save("power_wrapped", **cases)
 
 
+# ------------------------------------------------------------------------------------------------ round 2: remaining section-8 rows
+PYRAMID_VARIANTS = ("highres_pyramid", "highres_pyramid_area", "pyramid_old", "pyramid_old_area", "pyramid_mix", "pyramid_mix_area")
+
+
+def gen_pyramid_variants():
+    """HighresPyramid / PyramidOld / pyramid_mix presets (py/noise_generation.py:517-606, py/noise.py:2345-2418), replay mode."""
+    cases = {}
+    shape = (2, 4, 16, 16)
+    for name in PYRAMID_VARIANTS:
+        for normalized in (False, True):
+            cases[f"{name}_{int(normalized)}"] = ref_noise(getattr(NT, name.upper()), shape, 61, normalized)
+    cases["video_highres"] = ref_noise(NT.HIGHRES_PYRAMID, (1, 4, 2, 8, 8), 62, True)
+    save("pyramid_variants", **cases)
+
+
+def gen_ffilter():
+    """FreeU-Extreme's ffilter (py/nodes/freeu_extreme.py:10-29): irfft2(rfft2(x) * normalised power filter), with its filter cache."""
+    fx = importlib.import_module("sonar_ref.nodes.freeu_extreme")
+    PF = ref.powernoise.PowerFilter
+    cases = {}
+    g = torch.Generator().manual_seed(71)
+    specs = {"a": ((2, 8, 32, 32), dict(alpha=1.0, max_freq=0.7071), 1.0), "b": ((1, 6, 16, 64), dict(alpha=-0.5, min_freq=0.05, max_freq=0.5), 0.7),
+             "c": ((1, 3, 40, 56), dict(alpha=2.0, max_freq=0.7071, stretch=1.5, rotate=20.0), 1.0)}
+    cache = {}
+    for tag, (shape, fkw, nf) in specs.items():
+        x = torch.randn(shape, generator=g)
+        cases[f"{tag}_x"] = x
+        cases[f"{tag}_out"] = fx.ffilter(x, PF(**fkw), normalization_factor=nf, cfg_idx=tag, filter_cache=cache)
+    # same cache key, another filter: the cached one wins (:13-16)
+    cases["a_cached_out"] = fx.ffilter(cases["a_x"], PF(alpha=3.0), cfg_idx="a", filter_cache=cache)
+    assert torch.equal(cases["a_cached_out"], cases["a_out"])
+    # half precision in, half precision out (:22,29)
+    cases["a_half_out"] = fx.ffilter(cases["a_x"].half(), PF(alpha=1.0, max_freq=0.7071), cfg_idx=0, filter_cache={}).float()
+    for kw in (dict(), dict(cfg_idx=1), dict(filter_cache={})):  # no cache key: the reference never binds filter_rfft
+        try:
+            fx.ffilter(cases["a_x"], PF(alpha=1.0), **kw)
+            raise SystemExit("expected an error")
+        except UnboundLocalError:
+            pass
+    save("ffilter", **cases)
+
+
+def gen_cfg_exact():
+    """BASELINE cfg1 exactly as SURVEY.md 8d states it, cfg3 in replay mode at SDXL size, and the RAND history initialisation."""
+    S = ref.sonar
+    cases = {}
+    torch.manual_seed(3)
+    x0 = torch.randn(1, 4, 64, 64) * 14.6
+    sigmas = torch.cat((torch.linspace(14.6, 0.03, 20), torch.zeros(1)))
+    trace = []
+    out = S.SonarEuler.sampler(lambda x, sigma, **_k: x * 0.5, x0.clone(), sigmas, {"seed": 0}, lambda d: trace.append(d["x"].clone()), True, None, None,
+                               dict(momentum=0.95))
+    mine = orc.sonar_euler(lambda x, sigma, **_k: x * 0.5, x0.clone(), sigmas, orc.MomentumCfg(momentum=0.95))
+    must_equal(out, mine, "cfg1")
+    cases["cfg1_x0"], cases["cfg1_sigmas"], cases["cfg1_out"], cases["cfg1_trace"] = x0, sigmas, out, torch.stack(trace)
+    # gaussian noise on the same latent, as the config names it (not consumed by the non-ancestral sampler)
+    cases["cfg1_noise"] = ref_noise(NT.GAUSSIAN, (1, 4, 64, 64), 3, True)
+    shape = (2, 4, 128, 128)
+    for name in ("perlin", "pyramid"):
+        cases[f"cfg3_{name}"] = ref_noise(getattr(NT, name.upper()), shape, 0, True)
+    # init = RAND draws its history from the global generator inside the first momentum step, BEFORE that step's noise (py/sonar.py:169-206)
+    shape = (2, 4, 8, 8)
+    torch.manual_seed(5)
+    x1 = torch.randn(shape) * 14.6
+    sig7 = torch.cat((torch.linspace(14.6, 0.03, 7), torch.zeros(1)))
+    cases["rand_x0"], cases["rand_sigmas"] = x1, sig7
+    for kind in ("euler", "ancestral", "dpmpp"):
+        trace = []
+        cb = lambda d: trace.append(d["x"].clone())  # noqa: E731
+        torch.manual_seed(17)
+        x = torch.zeros(shape)
+        ns = ref.noise.get_noise_sampler(NT.GAUSSIAN, x, 0.03, 14.6, seed=17, cpu=True, factor=1.0, normalized=True)
+        kw = dict(init="RAND", momentum=0.9)
+        if kind == "euler":
+            S.SonarEuler.sampler(fake_model, x1.clone(), sig7, {"seed": 0}, cb, True, None, None, dict(kw))
+        elif kind == "ancestral":
+            S.SonarEulerAncestral.sampler(fake_model, x1.clone(), sig7, {"seed": 0}, cb, True, None, dict(kw), 0.8, 1.1, ns)
+        else:
+            S.SonarDPMPPSDE.sampler(fake_model, x1.clone(), sig7, {"seed": 0}, cb, True, None, dict(kw), 0.9, 1.05, ns)
+        cases[f"rand_{kind}"] = torch.stack(trace)
+    save("cfg_exact", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -883,6 +967,9 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_modulated()
     gen_item_wrappers()
     gen_power_wrapped()
+    gen_pyramid_variants()
+    gen_ffilter()
+    gen_cfg_exact()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

@@ -1,0 +1,291 @@
+"""-m gpu: rows finished in round 2 against goldens captured from the real reference (tests/golden/make_golden.py:
+gen_pyramid_variants, gen_ffilter, gen_cfg_exact), and every BASELINE.json configuration at its FULL size.
+
+Tolerances: replay-mode elementwise / resampling rows rtol 2e-5 atol 2e-5 (HighresPyramid / PyramidOld sum levels drawn at up to
+32x the latent resolution and averaged down: accumulation order differs from ATen's); FFT rows 2e-5 of the output peak; sampler
+traces rtol / atol 1e-4 on |x| ~ 10 (20 steps for cfg1: 3e-4)."""
+import importlib
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SIG = (torch.tensor(14.6), torch.tensor(10.0))
+PYRAMID_VARIANTS = ("highres_pyramid", "highres_pyramid_area", "pyramid_old", "pyramid_old_area", "pyramid_mix", "pyramid_mix_area")
+
+
+@pytest.fixture(scope="module")
+def api(pkg):
+    pkg.hip_lib.load()
+    mods = {m: importlib.import_module(f"comfyui_sonar_amd.py.{m}") for m in ("utils", "noise_generation", "noise", "sonar", "wavelet_cfg")}
+    mods["powernoise"] = importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise")
+    mods["freeu"] = importlib.import_module("comfyui_sonar_amd.py.nodes.freeu_extreme")
+    return types.SimpleNamespace(**mods, hl=pkg.hip_lib)
+
+
+def close(a, b, rtol=2e-5, atol=2e-5):
+    torch.testing.assert_close(a.detach().cpu().float(), b.detach().cpu().float(), rtol=rtol, atol=atol)
+
+
+def near(a, b, rel=2e-5):
+    b = b.detach().cpu().float()
+    torch.testing.assert_close(a.detach().cpu().float(), b, rtol=0, atol=rel * float(b.abs().max()))
+
+
+def replay(api, name, shape, seed, normalized):
+    x = torch.zeros(shape, device="cuda")
+    torch.manual_seed(seed)
+    ns = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=seed, cpu=True, factor=1.0, normalized=normalized)
+    return ns(*SIG)
+
+
+# ------------------------------------------------------------------------------------------------ row Y: pyramid variants
+@pytest.mark.parametrize("normalized", [False, True])
+@pytest.mark.parametrize("name", PYRAMID_VARIANTS)
+def test_pyramid_variants_replay(api, golden, name, normalized):
+    g = golden("pyramid_variants")
+    want = g[f"{name}_{int(normalized)}"]
+    close(replay(api, name, tuple(want.shape), 61, normalized), want)
+
+
+def test_highres_pyramid_video_latent(api, golden):
+    want = golden("pyramid_variants")["video_highres"]
+    close(replay(api, "highres_pyramid", tuple(want.shape), 62, True), want)
+
+
+@pytest.mark.parametrize("name", ["highres_pyramid", "pyramid_old", "pyramid_mix"])
+def test_pyramid_variants_generate_mode(api, name):
+    """Device draws: unit statistics after normalisation, shard invariance (two halves of a batch == the whole)."""
+    ng = api.noise_generation
+    shape = (4, 4, 32, 32)
+
+    def gen(b0, b, normalized=False):
+        torch.manual_seed(9)
+        with ng.shard_offset(b0):
+            x = torch.zeros((b, *shape[1:]), device="cuda")
+            return api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, factor=1.0, normalized=normalized)(*SIG)
+
+    whole = gen(0, 4)
+    assert bool(torch.isfinite(whole).all())
+    if name == "pyramid_old":  # the other two normalise parts per call tensor (uniform base / each mixed generator): shards differ by design
+        assert torch.equal(torch.cat([gen(0, 2), gen(2, 2)]), whole)
+    normed = gen(0, 4, True)
+    thr = 2.5 / math.sqrt(normed.numel())
+    assert abs(normed.std().item() - 1.0) < thr + 1e-4 and abs(normed.mean().item()) < thr + 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ 8f-2: FreeU-Extreme ffilter
+def test_ffilter_matches_reference(api, golden):
+    g = golden("ffilter")
+    PF = api.powernoise.PowerFilter
+    specs = {"a": (dict(alpha=1.0, max_freq=0.7071), 1.0), "b": (dict(alpha=-0.5, min_freq=0.05, max_freq=0.5), 0.7),
+             "c": (dict(alpha=2.0, max_freq=0.7071, stretch=1.5, rotate=20.0), 1.0)}
+    cache = {}
+    for tag, (fkw, nf) in specs.items():
+        x = g[f"{tag}_x"].cuda()
+        out = api.freeu.ffilter(x, PF(**fkw), normalization_factor=nf, cfg_idx=tag, filter_cache=cache)
+        assert out.dtype == x.dtype and out.shape == x.shape
+        near(out, g[f"{tag}_out"])
+    assert set(cache) == {("a", torch.Size([32, 32])), ("b", torch.Size([16, 64])), ("c", torch.Size([40, 56]))}
+    assert all(v.is_cuda for v in cache.values())
+    # a cache hit wins over the filter argument (py/nodes/freeu_extreme.py:13-16)
+    near(api.freeu.ffilter(g["a_x"].cuda(), PF(alpha=3.0), cfg_idx="a", filter_cache=cache), g["a_cached_out"])
+    half = api.freeu.ffilter(g["a_x"].cuda().half(), PF(alpha=1.0, max_freq=0.7071), cfg_idx=0, filter_cache={})
+    assert half.dtype == torch.float16
+    near(half, g["a_half_out"], rel=2e-3)  # fp16 input and output rounding
+    for kw in (dict(), dict(cfg_idx=1), dict(filter_cache={})):  # the reference fails without a cache key
+        with pytest.raises(UnboundLocalError):
+            api.freeu.ffilter(g["a_x"].cuda(), PF(alpha=1.0), **kw)
+    with pytest.raises(api.hl.SonarHipError):
+        api.freeu.ffilter(g["a_x"], PF(alpha=1.0), cfg_idx=0, filter_cache={})
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE cfg1, exactly
+def test_cfg1_exact(api, golden):
+    """x0 = randn(1,4,64,64, seed 3) * 14.6, linspace(14.6, 0.03, 20) + [0], den = 0.5 x, SonarEuler(momentum = 0.95)."""
+    g = golden("cfg_exact")
+    torch.manual_seed(3)
+    x0 = torch.randn(1, 4, 64, 64) * 14.6
+    assert torch.equal(x0, g["cfg1_x0"])
+    trace = []
+    out = api.sonar.SonarEuler.sampler(lambda x, sigma, **_k: x * 0.5, x0.cuda(), g["cfg1_sigmas"], {"seed": 0}, lambda d: trace.append(d["x"].clone()), True,
+                                       None, None, dict(momentum=0.95))
+    assert len(trace) == 20
+    for i, t in enumerate(trace):
+        close(t, g["cfg1_trace"][i], rtol=3e-4, atol=3e-4)
+    close(out, g["cfg1_out"], rtol=3e-4, atol=3e-4)
+    close(replay(api, "gaussian", (1, 4, 64, 64), 3, True), g["cfg1_noise"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["euler", "ancestral", "dpmpp"])
+def test_rand_history_init_keeps_the_reference_draw_order(api, golden, kind):
+    """init = RAND draws the history from the global generator inside the first momentum step, before that step's noise."""
+    g = golden("cfg_exact")
+    S = api.sonar
+    x1, sig7 = g["rand_x0"].cuda(), g["rand_sigmas"]
+
+    def fake_model(x, sigma, **_kw):
+        s = sigma.reshape(-1, *([1] * (x.ndim - 1)))
+        return x * 0.5 + torch.tanh(x) * (0.1 * s / (1.0 + s))
+
+    trace = []
+    cb = lambda d: trace.append(d["x"].clone())  # noqa: E731
+    torch.manual_seed(17)
+    ns = api.noise.get_noise_sampler("gaussian", torch.zeros_like(x1), 0.03, 14.6, seed=17, cpu=True, factor=1.0, normalized=True)
+    kw = dict(init="RAND", momentum=0.9)
+    if kind == "euler":
+        S.SonarEuler.sampler(fake_model, x1.clone(), sig7, {"seed": 0}, cb, True, None, None, kw)
+    elif kind == "ancestral":
+        S.SonarEulerAncestral.sampler(fake_model, x1.clone(), sig7, {"seed": 0}, cb, True, None, kw, 0.8, 1.1, ns)
+    else:
+        S.SonarDPMPPSDE.sampler(fake_model, x1.clone(), sig7, {"seed": 0}, cb, True, None, kw, 0.9, 1.05, ns)
+    want = g[f"rand_{kind}"]
+    assert len(trace) == want.shape[0]
+    for i, t in enumerate(trace):
+        close(t, want[i], rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE cfg2 at full size
+def power_item(api):
+    return api.powernoise.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                                         common_mode=0.0, channel_correlation="1,1,1,1,1,1")
+
+
+def test_cfg2_headline_full_size(api):
+    """512 x 4 x 128 x 128 through sonar_power_noise_f32 (the benchmarked call): unit statistics, 8 sampled planes equal
+    irfft2(dumped spectrum x filter) normalised with the tensor's own statistics, and the two 256-latent shards equal the whole."""
+    ng, hl = api.noise_generation, api.hl
+    item = power_item(api)
+    shape = (512, 4, 128, 128)
+    x = torch.zeros(shape, device="cuda")
+    torch.manual_seed(2024)
+    state = torch.cuda.get_rng_state()
+    whole = item.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)(None, None)
+    assert whole.shape == shape and bool(torch.isfinite(whole).all())
+    assert abs(whole.std().item() - 1.0) < 1e-4 and abs(whole.mean().item()) < 1e-4
+    # the same draws, un-normalised, and the spectrum behind them
+    torch.cuda.set_rng_state(state)
+    raw = item.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=False)(None, None)
+    torch.cuda.set_rng_state(state)
+    seed, stream = ng.DeviceRNG.take()
+    filt = item.make_filter(shape).to("cuda")[0, 0]
+    planes = [0, 1, 777, 1024, 1500, 2045, 2046, 2047]
+    for p in planes:
+        b, c = divmod(p, 4)
+        # dump the RNG group (4 planes) that holds plane p
+        z = hl.power_spectrum((1, 4, 128, 128), x.device, seed=seed, stream_id=stream, plane_offset=b * 4)
+        want = torch.fft.irfft2(z[0, c] * filt, s=(128, 128), norm="ortho")
+        torch.testing.assert_close(raw[b, c], want, rtol=0, atol=2e-5 * float(want.abs().max()))
+    mean, std = raw.mean().item(), raw.std().item()
+    torch.testing.assert_close(whole[300], (raw[300] - (mean if abs(mean) > 2.5 / math.sqrt(raw.numel()) else 0.0)) / std, rtol=1e-5, atol=1e-5)
+    # shards: ranks 0 and 1 of a 2-GPU job draw latents [0, 256) and [256, 512) of the same logical batch
+    parts = []
+    for b0 in (0, 256):
+        torch.cuda.set_rng_state(state)
+        with ng.shard_offset(b0):
+            parts.append(item.make_noise_sampler(x[:256], None, None, seed=None, cpu=False, normalized=False)(None, None))
+    assert torch.equal(torch.cat(parts), raw)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE cfg3 at full size
+@pytest.mark.parametrize("name", ["perlin", "pyramid"])
+def test_cfg3_replay_at_sdxl_size(api, golden, name):
+    want = golden("cfg_exact")[f"cfg3_{name}"]
+    close(replay(api, name, (2, 4, 128, 128), 0, True), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["perlin", "pyramid"])
+def test_cfg3_generate_full_batch(api, name):
+    """64 x 4 x 128 x 128 drawn on device: unit statistics, two 32-latent shards == the whole, the Perlin lattice term is shared."""
+    ng = api.noise_generation
+    shape = (64, 4, 128, 128)
+
+    def gen(b0, b, normalized):
+        torch.manual_seed(31)
+        with ng.shard_offset(b0):
+            x = torch.zeros((b, *shape[1:]), device="cuda")
+            return api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, factor=1.0, normalized=normalized)(*SIG)
+
+    raw = gen(0, 64, False)
+    assert torch.equal(torch.cat([gen(0, 32, False), gen(32, 32, False)]), raw)
+    normed = gen(0, 64, True)
+    assert bool(torch.isfinite(normed).all())
+    thr = 2.5 / math.sqrt(normed.numel())
+    assert abs(normed.std().item() - 1.0) < thr + 1e-4 and abs(normed.mean().item()) < thr + 1e-4
+    if name == "perlin":  # two latents differ only by their uniform base / div_fac: |diff| <= 0.5
+        assert float((raw[0] - raw[1]).abs().max()) <= 0.5 + 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE cfg4 at full size
+def test_cfg4_full_batch_matches_small_batch(api):
+    """256 x 4 x 128 x 128 WaveletCFG (placeholder rule, fp64 and fp32): per-plane arithmetic, so the first 2 latents of the full batch
+    equal a 2-latent call (the 2 x 4 x 128 x 128 case is pinned to the reference in tests/test_gpu_wavelet_golden.py)."""
+    from tests.golden.wavelet_cases import SAMPLE_SIGMAS, FakeModel
+
+    torch.manual_seed(12)
+    cond, uncond, x = (torch.randn(256, 4, 128, 128, device="cuda") for _ in range(3))
+    opts = {"transformer_options": {"sample_sigmas": SAMPLE_SIGMAS["karras12"]}}
+
+    def args(n):
+        return {"input": x[:n], "cond_scale": 7.0, "cond": x[:n] - cond[:n], "uncond": x[:n] - uncond[:n], "cond_denoised": cond[:n],
+                "uncond_denoised": uncond[:n], "sigma": torch.full((n,), 7.0, device="cuda"), "model": FakeModel(), "model_options": opts}
+
+    for hp in (True, False):
+        fn = api.wavelet_cfg.WaveletCFG(existing_cfg=None, rules=api.wavelet_cfg.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0),
+                                                                                                 high_precision_mode=hp))
+        full, small = fn(args(256)), fn(args(2))
+        assert full.shape == x.shape and bool(torch.isfinite(full).all())
+        assert torch.equal(full[:2], small)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE cfg5: one rank's shard
+def test_cfg5_full_shard_one_dpmpp_step(api):
+    """128 x 16 x 128 x 128 (one GPU's share of the 1024-latent Flux batch): scheduled power-law + Perlin + Brownian chain in generate
+    mode, one SonarDPMPPSDE step with momentum: finite, the chain's noise is unit-variance, and two 64-latent shards equal the whole."""
+    N, S, ng, pn = api.noise, api.sonar, api.noise_generation, api.powernoise
+
+    def chain_of(*items):
+        c = N.CustomNoiseChain()
+        for it in items:
+            c.add(it)
+        return c
+
+    def build():
+        power = pn.PowerNoiseItem(0.5, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                                  common_mode=0.0, channel_correlation="1")
+        inner = chain_of(power, N.CustomNoiseItem(0.3, noise_type="perlin"), N.CustomNoiseItem(0.2, noise_type="brownian"))
+        fallback = chain_of(N.CustomNoiseItem(1.0, noise_type="gaussian"))
+        return chain_of(N.ScheduledNoise(1.0, noise=inner, start_sigma=20.0, end_sigma=0.0, normalize=None, fallback_noise=fallback))
+
+    sigmas = torch.tensor([10.0, 7.0, 0.0])
+    torch.manual_seed(1)
+    x0 = torch.randn(128, 16, 128, 128, device="cuda") * 10.0
+
+    def run(xs, b0):
+        torch.manual_seed(8)
+        with ng.shard_offset(b0):
+            ns = build().make_noise_sampler(xs, 0.5, 10.0, seed=3, cpu=False, normalized=True)
+            sample = ns(torch.tensor(8.0), torch.tensor(6.0)).clone()
+            out = S.SonarDPMPPSDE.sampler(lambda x, sigma, **_k: x * 0.5, xs.clone(), sigmas, {"seed": 3}, None, True, None,
+                                          dict(momentum=0.95), 1.0, 1.0, ns)
+        return sample, out
+
+    sample, out = run(x0, 0)
+    assert out.shape == x0.shape and bool(torch.isfinite(out).all())
+    assert abs(sample.std().item() - 1.0) < 2e-3 and abs(sample.mean().item()) < 2e-3
+    # each shard normalises its own call tensor (== the reference called with B/2), so compare un-normalised parts:
+    # the Perlin lattice, the Brownian paths and the power spectra are keyed by global latent index
+    parts = []
+    for b0 in (0, 64):
+        torch.manual_seed(8)
+        with ng.shard_offset(b0):
+            item = pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                                     common_mode=0.0, channel_correlation="1")
+            parts.append(item.make_noise_sampler(x0[b0:b0 + 64], None, None, seed=None, cpu=False, normalized=False)(None, None))
+    torch.manual_seed(8)
+    item = pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                             common_mode=0.0, channel_correlation="1")
+    assert torch.equal(torch.cat(parts), item.make_noise_sampler(x0, None, None, seed=None, cpu=False, normalized=False)(None, None))
