@@ -8,6 +8,7 @@
 // coalesced along W.  Taps travel as kernel arguments (wave-uniform index -> scalar loads).
 #include "dwt_common.h"
 #include "dwt_tile.h"
+#include "dwt_lowpass.h"
 
 namespace sonar {
 
@@ -404,6 +405,31 @@ extern "C" int sonar_wcfg_fused_f64(const float* cond, const float* uncond, cons
     return wcfg_fused<double>(cond, uncond, x, out, planes, H, W, levels, dec_lo, dec_hi, dec_len, mode_fwd, rec_lo, rec_hi, rec_len,
                               mode_inv, yl_scales, yh_scales, blend_mode, strength, subtract_from_x, ws, ws_bytes, (hipStream_t)stream,
                               "sonar_wcfg_fused_f64");
+}
+extern "C" int64_t sonar_wcfg_lowpass_lds_bytes(int64_t H, int64_t W, int levels, int flen, int mode_fwd, int mode_inv, int elem_size) {
+    size_t lds = 0;
+    if (mode_fwd < 0 || mode_fwd > 5 || mode_inv < 0 || mode_inv > 5) return -1;
+    if (elem_size == 8) {
+        LowArgs<double> a{};
+        return lowpass_plan(a, lds, H, W, levels, flen, mode_fwd, mode_inv) ? (int64_t)lds : -1;
+    }
+    if (elem_size == 4) {
+        LowArgs<float> a{};
+        return lowpass_plan(a, lds, H, W, levels, flen, mode_fwd, mode_inv) ? (int64_t)lds : -1;
+    }
+    return -1;
+}
+extern "C" int sonar_wcfg_lowpass_f32(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H, int64_t W,
+                                      int levels, const double* dec_lo, const double* rec_lo, int flen, int mode_fwd, int mode_inv,
+                                      const double* g, double ku, double kt, int subtract_from_x, void* stream) {
+    return wcfg_lowpass<float>(cond, uncond, x, out, planes, H, W, levels, dec_lo, rec_lo, flen, mode_fwd, mode_inv, g, ku, kt, subtract_from_x,
+                               (hipStream_t)stream, "sonar_wcfg_lowpass_f32");
+}
+extern "C" int sonar_wcfg_lowpass_f64(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H, int64_t W,
+                                      int levels, const double* dec_lo, const double* rec_lo, int flen, int mode_fwd, int mode_inv,
+                                      const double* g, double ku, double kt, int subtract_from_x, void* stream) {
+    return wcfg_lowpass<double>(cond, uncond, x, out, planes, H, W, levels, dec_lo, rec_lo, flen, mode_fwd, mode_inv, g, ku, kt, subtract_from_x,
+                                (hipStream_t)stream, "sonar_wcfg_lowpass_f64");
 }
 extern "C" int sonar_wcfg_output_f32(const float* x, const void* result, int result_is_f64, float* out, int64_t planes, int64_t H,
                                      int64_t W, int64_t Hr, int64_t Wr, int subtract_from_x, void* stream) {

@@ -1,0 +1,370 @@
+// WaveletCFG for rules that only scale the DIFFERENCE bands, with one scale per level (py/wavelet_cfg.py:750-791 with `cond`,
+// `uncond`, `final` absent or unit and `difference.yh_scales` scalar per level -- the node's placeholder rule, BASELINE cfg4).
+//
+// The transform-domain step is linear:  IDWT(blend(U, D (C - U), t)) = k_u u + k_t IDWT(D DWT(c - u)), U = DWT(u), C = DWT(c),
+// because IDWT(DWT(u)) = u (perfect reconstruction, same wavelet both ways).  With ONE scale d_j for the three detail bands of level
+// j and l for the approximation, the band-scaled reconstruction telescopes through the same identity, level by level
+// (details_j = LL_{j-1} - Up_j(LL_j)):
+//     IDWT(D DWT(v)) = d_1 v + Up_1( (d_2 - d_1) LL_1 + Up_2( (d_3 - d_2) LL_2 + ... Up_J( (l - d_J) LL_J ) ) )
+// LL_j = low-pass analysis chain of v, Up_j = synthesis of level j with zero detail bands.  No detail band is ever formed: a
+// workgroup owns a plane, keeps the LL pyramid (67^2 + 37^2 + ... values for a 128 x 128 plane) in LDS, and the tensors cross HBM
+// once: read cond, uncond, x, write out = x - result (16N bytes per latent, the figure SURVEY.md 8d prices).  fp64 (the reference's
+// high_precision_mode default) or fp32 arithmetic; results agree with the band-by-band path to rounding (tests compare both with
+// the reference-run fixtures).
+#pragma once
+#include "dwt_tile.h"
+
+namespace sonar {
+
+constexpr int kLowThreads = 512;   // 8 waves per plane: the phases are short and latency-bound, more waves hide more of it
+constexpr int kLowRows = 16;       // output rows per level-1 analysis tile / final synthesis tile
+constexpr int kLowMaxLevels = 8;
+
+template <typename T>
+struct LowArgs {
+    int64_t planes;
+    int levels;
+    int H[kLowMaxLevels + 1], W[kLowMaxLevels + 1];  // [0]: the latent plane; [j]: LL plane of level j
+    int off_ll[kLowMaxLevels + 1];                    // LDS offsets (elements of T) of LL_1 .. LL_J
+    int off_tmp;                                      // LDS scratch (elements of T)
+    int off_tmp1, rows1;                              // level-1 analysis scratch (overlays LL_2 .. and the scratch) and its tile height
+    int rows_out;                                     // output rows per tile of the final synthesis
+    int off_maps;                                     // LDS byte offset of the extension tables
+    int map_h[kLowMaxLevels + 1], map_w[kLowMaxLevels + 1];  // table offsets (ints) per level, rows / columns
+    T g[kLowMaxLevels + 1];                           // g[0] = d_1; g[j] = d_{j+1} - d_j; g[J] = l - d_J
+    T ku, kt;                                         // result = ku u + kt (g[0] v + Up_1(...))
+    int subtract_from_x, mode_fwd, mode_inv;
+    T dlo[kDeepTaps], rlo[kDeepTaps];
+};
+
+// items (row, col) of a rows x cols grid dealt to the workgroup's threads in flat order, without a division per item
+struct Walk2 {
+    int r, c, dr, dc;
+    __device__ __forceinline__ Walk2(int tid, int cols) : r(tid / cols), c(tid - (tid / cols) * cols), dr(kLowThreads / cols), dc(kLowThreads - (kLowThreads / cols) * cols) {}
+    __device__ __forceinline__ void next(int cols) {
+        r += dr;
+        c += dc;
+        if (c >= cols) {
+            c -= cols;
+            r += 1;
+        }
+    }
+};
+
+// low-pass synthesis of the output pair (2m, 2m + 1) from one coefficient sequence (SynthPair of dwt_tile.h without the detail terms)
+template <typename T, int FT, typename Load>
+__device__ __forceinline__ void synth_low_pair(int m, int n, int mode, const T* __restrict__ rlo, Load&& la, T& even, T& odd) {
+    constexpr int K = FT / 2;
+    even = T(0);
+    odd = T(0);
+    if (mode != kPeriodization || (K & 1) == 1) {
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            int i;
+            if (mode != kPeriodization) {
+                i = m + K - 1 - k;
+                i = i < n ? i : n - 1;  // only beyond the valid output length (never consumed)
+            } else {
+                i = (m + (K - 1) / 2 - k) % n;
+                if (i < 0) i += n;
+            }
+            const T a = la(i);
+            even = fma_t(a, rlo[2 * k], even);
+            odd = fma_t(a, rlo[2 * k + 1], odd);
+        }
+    } else {
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            int ie = (m + K / 2 - (k + 1)) % n, io = (m + K / 2 - k) % n;
+            if (ie < 0) ie += n;
+            if (io < 0) io += n;
+            even = fma_t(la(ie), rlo[2 * k + 1], even);
+            odd = fma_t(la(io), rlo[2 * k], odd);
+        }
+    }
+}
+
+template <typename T, int FT>
+__global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* __restrict__ cond, const float* __restrict__ uncond,
+                                                                    const float* __restrict__ xin, float* __restrict__ out, LowArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char low_smem[];
+    T* const lds = reinterpret_cast<T*>(low_smem);
+    int* const maps = reinterpret_cast<int*>(low_smem + a.off_maps);
+    T* const tmp = lds + a.off_tmp;
+    const int tid = threadIdx.x;
+    const int J = a.levels;
+    // extension tables, the same for every plane: tap j of output i reads table[2 i + F - 1 - j] (source index, -1 = implicit zero)
+    for (int j = 1; j <= J; ++j) {
+        const int off = a.mode_fwd == kPeriodization ? FT / 2 : 1;
+        const int Hp = a.H[j - 1], Wp = a.W[j - 1];
+        const int He = (a.mode_fwd == kPeriodization && (Hp & 1)) ? Hp + 1 : Hp, We = (a.mode_fwd == kPeriodization && (Wp & 1)) ? Wp + 1 : Wp;
+        for (int i = tid; i < 2 * a.H[j] + FT - 2; i += kLowThreads) maps[a.map_h[j] + i] = src_index(i + off - (FT - 1), Hp, He, a.mode_fwd);
+        for (int i = tid; i < 2 * a.W[j] + FT - 2; i += kLowThreads) {
+            const int sx = src_index(i + off - (FT - 1), Wp, We, a.mode_fwd);
+            // level 1 reads its scratch rows in the parity-split layout: the table holds the slot
+            maps[a.map_w[j] + i] = (j == 1 && sx >= 0) ? (sx & 1) * ((Wp + 1) >> 1) + (sx >> 1) : sx;
+        }
+    }
+#ifdef SONAR_LOW_STAGGER  // profiling builds: the k-th resident workgroup of a CU starts k * SONAR_LOW_STAGGER (x 0.85 us) late
+    for (int i = 0; i < (int)(blockIdx.x / 256) * SONAR_LOW_STAGGER; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
+    const int H = a.H[0], W = a.W[0], h1 = a.H[1], w1 = a.W[1];
+    const int Wh = (W + 1) >> 1, Ws = 2 * Wh;  // parity-split row of the level-1 scratch: slot(x) = (x & 1) Wh + x / 2
+    for (int64_t p = blockIdx.x; p < a.planes; p += gridDim.x) {
+        const float* pc = cond + p * (int64_t)H * W;
+        const float* pu = uncond + p * (int64_t)H * W;
+        __syncthreads();  // tables are built; the previous plane's readers are done
+        // ---------------------------------------------------------------- level 1: low-pass analysis of v = cond - uncond (from global)
+        {
+            T* const ll1 = lds + a.off_ll[1];
+            const int* const ymap = maps + a.map_h[1];
+            const int* const xmap = maps + a.map_w[1];
+            constexpr int THS = 4, NRS = 2 * THS + FT - 2;
+            T* const tmp1 = lds + a.off_tmp1;
+#ifdef SONAR_LOW_NOANALYSIS
+            if (false)
+#endif
+            for (int y0 = 0; y0 < h1; y0 += a.rows1) {
+                const int th = min(a.rows1, h1 - y0);
+                // along H: one thread per (row group of 4, column); each input row of the group's window is read once
+                for (Walk2 wk(tid, W); wk.r * THS < th; wk.next(W)) {
+                    const int sub = wk.r, x = wk.c;
+                    {
+                        T v[NRS];
+#pragma unroll
+                        for (int r = 0; r < NRS; ++r) {
+                            const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h1 + FT - 3)];
+                            const int at = max(sy, 0) * W + x;
+                            const T d = (T)pc[at] - (T)pu[at];
+                            v[r] = sy >= 0 ? d : T(0);
+                        }
+                        T* dst = tmp1 + (x & 1) * Wh + (x >> 1);
+#pragma unroll
+                        for (int yl = 0; yl < THS; ++yl) {
+                            T lo = T(0);
+#pragma unroll
+                            for (int j = 0; j < FT; ++j) lo = fma_t(a.dlo[j], v[2 * yl + FT - 1 - j], lo);
+                            if (sub * THS + yl < th) dst[(sub * THS + yl) * Ws] = lo;
+                        }
+                    }
+                }
+                __syncthreads();
+                // along W out of LDS
+                for (Walk2 wk(tid, w1); wk.r < th; wk.next(w1)) {
+                    const int yl = wk.r, xo = wk.c;
+                    const T* row = tmp1 + yl * Ws;
+                    const int* xm = xmap + 2 * xo + (FT - 1);
+                    T acc = T(0);
+#pragma unroll
+                    for (int j = 0; j < FT; ++j) {
+                        const int slot = xm[-j];
+                        const T q = row[max(slot, 0)];
+                        acc = fma_t(a.dlo[j], slot >= 0 ? q : T(0), acc);
+                    }
+                    ll1[(y0 + yl) * w1 + xo] = acc;
+                }
+                __syncthreads();
+            }
+        }
+        // ---------------------------------------------------------------- deeper levels: LL_j from LL_{j-1}, all in LDS
+#ifdef SONAR_LOW_NODEEP
+        if (false)
+#endif
+        for (int j = 2; j <= J; ++j) {
+            const int Hp = a.H[j - 1], Wp = a.W[j - 1], h = a.H[j], w = a.W[j];
+            const T* const src = lds + a.off_ll[j - 1];
+            T* const dst = lds + a.off_ll[j];
+            const int* const ymap = maps + a.map_h[j];
+            const int* const xmap = maps + a.map_w[j];
+            for (Walk2 wk(tid, Wp); wk.r < h; wk.next(Wp)) {   // along H
+                const int yo = wk.r, x = wk.c;
+                const int* ym = ymap + 2 * yo + (FT - 1);
+                T acc = T(0);
+#pragma unroll
+                for (int t = 0; t < FT; ++t) {
+                    const int sy = ym[-t];
+                    const T q = src[max(sy, 0) * Wp + x];
+                    acc = fma_t(a.dlo[t], sy >= 0 ? q : T(0), acc);
+                }
+                tmp[yo * Wp + x] = acc;
+            }
+            __syncthreads();
+            for (Walk2 wk(tid, w); wk.r < h; wk.next(w)) {    // along W
+                const int yo = wk.r, xo = wk.c;
+                const int* xm = xmap + 2 * xo + (FT - 1);
+                const T* row = tmp + yo * Wp;
+                T acc = T(0);
+#pragma unroll
+                for (int t = 0; t < FT; ++t) {
+                    const int sx = xm[-t];
+                    const T q = row[max(sx, 0)];
+                    acc = fma_t(a.dlo[t], sx >= 0 ? q : T(0), acc);
+                }
+                dst[yo * w + xo] = acc;
+            }
+            __syncthreads();
+        }
+        // ---------------------------------------------------------------- back up: B_J = g_J LL_J; B_{j-1} = g_{j-1} LL_{j-1} + Up_j(B_j)
+        {
+            T* const top = lds + a.off_ll[J];
+            const T gJ = a.g[J];
+            for (int it = tid; it < a.H[J] * a.W[J]; it += kLowThreads) top[it] *= gJ;
+            __syncthreads();
+        }
+#ifdef SONAR_LOW_NODEEP
+        if (false)
+#endif
+        for (int j = J; j >= 2; --j) {
+            const int h = a.H[j], w = a.W[j], Ho = a.H[j - 1], Wo = a.W[j - 1];  // only the rows / columns the level below keeps
+            const T* const B = lds + a.off_ll[j];
+            T* const dst = lds + a.off_ll[j - 1];
+            const int hp = (Ho + 1) >> 1, wp = (Wo + 1) >> 1;
+            for (Walk2 wk(tid, w); wk.r < hp; wk.next(w)) {   // along H: rows (2m, 2m + 1) of column xo
+                const int m = wk.r, xo = wk.c;
+                T e, o;
+                synth_low_pair<T, FT>(m, h, a.mode_inv, a.rlo, [&](int i) { return B[i * w + xo]; }, e, o);
+                tmp[(2 * m) * w + xo] = e;
+                if (2 * m + 1 < Ho) tmp[(2 * m + 1) * w + xo] = o;
+            }
+            __syncthreads();
+            const T gp = a.g[j - 1];
+            for (Walk2 wk(tid, wp); wk.r < Ho; wk.next(wp)) {  // along W, accumulate into g_{j-1} LL_{j-1}
+                const int y = wk.r, m = wk.c;
+                const T* row = tmp + y * w;
+                T e, o;
+                synth_low_pair<T, FT>(m, w, a.mode_inv, a.rlo, [&](int i) { return row[i]; }, e, o);
+                T* d = dst + y * Wo + 2 * m;
+                d[0] = fma_t(gp, d[0], e);
+                if (2 * m + 1 < Wo) d[1] = fma_t(gp, d[1], o);
+            }
+            __syncthreads();
+        }
+        // ---------------------------------------------------------------- level 1 synthesis + the elementwise tail, straight to global
+        {
+            const T* const B = lds + a.off_ll[1];
+            const float* px = a.subtract_from_x ? xin + p * (int64_t)H * W : nullptr;
+            float* po = out + p * (int64_t)H * W;
+            const int wp = (W + 1) >> 1;
+            const T g0 = a.g[0];
+            for (int y0 = 0; y0 < H; y0 += a.rows_out) {
+                const int th = min(a.rows_out, H - y0);
+                for (Walk2 wk(tid, w1); wk.r < ((th + 1) >> 1); wk.next(w1)) {
+                    const int mp = wk.r, xo = wk.c;
+                    T e, o;
+                    synth_low_pair<T, FT>((y0 >> 1) + mp, h1, a.mode_inv, a.rlo, [&](int i) { return B[i * w1 + xo]; }, e, o);
+                    tmp[(2 * mp) * w1 + xo] = e;
+                    if (2 * mp + 1 < th) tmp[(2 * mp + 1) * w1 + xo] = o;
+                }
+                __syncthreads();
+                for (Walk2 wk(tid, wp); wk.r < th; wk.next(wp)) {
+                    const int yl = wk.r, m = wk.c;
+                    const T* row = tmp + yl * w1;
+                    T e, o;
+                    synth_low_pair<T, FT>(m, w1, a.mode_inv, a.rlo, [&](int i) { return row[i]; }, e, o);
+                    const int at = (y0 + yl) * W + 2 * m;
+                    const bool pair = 2 * m + 1 < W;
+                    if (pair && (W & 1) == 0) {  // rows are 8-byte aligned: one vector access per tensor
+#ifdef SONAR_LOW_NOREREAD  // profiling builds: what the second read of cond / uncond costs
+                        const float2 c2 = make_float2((float)e, 1.0f), u2 = make_float2(2.0f, (float)o);
+#else
+                        const float2 c2 = *reinterpret_cast<const float2*>(pc + at), u2 = *reinterpret_cast<const float2*>(pu + at);
+#endif
+                        const T r0 = fma_t(a.ku, (T)u2.x, a.kt * fma_t(g0, (T)c2.x - (T)u2.x, e));
+                        const T r1 = fma_t(a.ku, (T)u2.y, a.kt * fma_t(g0, (T)c2.y - (T)u2.y, o));
+                        float2 res = make_float2((float)r0, (float)r1);
+                        if (px) {
+                            const float2 x2 = *reinterpret_cast<const float2*>(px + at);
+                            res = make_float2(x2.x - res.x, x2.y - res.y);
+                        }
+                        *reinterpret_cast<float2*>(po + at) = res;
+                    } else {
+                        const T r0 = fma_t(a.ku, (T)pu[at], a.kt * fma_t(g0, (T)pc[at] - (T)pu[at], e));
+                        po[at] = px ? px[at] - (float)r0 : (float)r0;
+                        if (pair) {
+                            const T r1 = fma_t(a.ku, (T)pu[at + 1], a.kt * fma_t(g0, (T)pc[at + 1] - (T)pu[at + 1], o));
+                            po[at + 1] = px ? px[at + 1] - (float)r1 : (float)r1;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// LDS plan; false when the plane's LL pyramid does not fit one workgroup's share (the caller takes the band-by-band path)
+template <typename T>
+static bool lowpass_plan(LowArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W, int levels, int flen, int mode_fwd, int mode_inv) {
+    if (levels < 1 || levels > kLowMaxLevels || !tile_taps_ok(flen) || flen > kDeepTaps || !dims_ok(H, W) || H > 4096 || W > 4096) return false;
+    a.levels = levels;
+    a.H[0] = (int)H;
+    a.W[0] = (int)W;
+    int at = 0;
+    int tmp = kLowRows * 2 * (((int)W + 1) / 2);  // level-1 analysis tile (parity-split rows)
+    int ints = 0;
+    for (int j = 1; j <= levels; ++j) {
+        a.H[j] = (int)dwt_len(a.H[j - 1], flen, mode_fwd);
+        a.W[j] = (int)dwt_len(a.W[j - 1], flen, mode_fwd);
+        const int Hr = mode_inv == kPeriodization ? 2 * a.H[j] : 2 * a.H[j] - flen + 2;
+        const int Wr = mode_inv == kPeriodization ? 2 * a.W[j] : 2 * a.W[j] - flen + 2;
+        if (Hr < a.H[j - 1] || Wr < a.W[j - 1]) return false;  // the inverse cannot cover the level below
+        a.off_ll[j] = at;
+        at += a.H[j] * a.W[j];
+        if (j >= 2) tmp = std::max(tmp, std::max(a.H[j] * a.W[j - 1], (a.H[j - 1] + 1) * a.W[j]));
+        a.map_h[j] = ints;
+        ints += 2 * a.H[j] + flen;
+        a.map_w[j] = ints;
+        ints += 2 * a.W[j] + flen;
+    }
+    tmp = std::max(tmp, (kLowRows + 1) * a.W[1]);  // final synthesis tile
+    a.off_tmp = at;
+    at += tmp;
+    // level 1 runs before the deeper LL planes exist: its scratch may lie over them -> taller tiles, fewer barrier-separated phases
+    a.off_tmp1 = levels >= 2 ? a.off_ll[2] : a.off_tmp;
+    const int ws1 = 2 * (((int)W + 1) / 2);
+    a.rows1 = std::max(kLowRows, std::min((a.H[1] + 3) / 4 * 4, (at - a.off_tmp1) / ws1 / 4 * 4));
+    a.rows_out = std::max(kLowRows, std::min(((int)H + 1) / 2 * 2, (tmp / a.W[1] - 1) / 2 * 2));
+    a.off_maps = (int)(((size_t)at * sizeof(T) + 15) / 16 * 16);
+    lds_bytes = (size_t)a.off_maps + (size_t)ints * sizeof(int);
+    return lds_bytes <= 80 * 1024;  // two workgroups per CU
+}
+
+template <typename T>
+static int wcfg_lowpass(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H, int64_t W, int levels,
+                        const double* dec_lo, const double* rec_lo, int flen, int mode_fwd, int mode_inv, const double* g, double ku, double kt,
+                        int subtract_from_x, hipStream_t st, const char* what) {
+    SONAR_REQUIRE(cond && uncond && out && (x || !subtract_from_x) && dec_lo && rec_lo && g && planes >= 0 && mode_fwd >= 0 && mode_fwd <= 5 &&
+                      mode_inv >= 0 && mode_inv <= 5,
+                  SONAR_ERR_ARG, "%s: bad argument", what);
+    LowArgs<T> a{};
+    size_t lds = 0;
+    SONAR_REQUIRE(lowpass_plan(a, lds, H, W, levels, flen, mode_fwd, mode_inv), SONAR_ERR_UNSUPPORTED,
+                  "%s: the plane's low-pass pyramid does not fit in LDS (or unsupported filter length / level count)", what);
+    if (planes == 0) return SONAR_OK;
+    a.planes = planes;
+    for (int j = 0; j <= levels; ++j) a.g[j] = (T)g[j];
+    a.ku = (T)ku;
+    a.kt = (T)kt;
+    a.subtract_from_x = subtract_from_x;
+    a.mode_fwd = mode_fwd;
+    a.mode_inv = mode_inv;
+    for (int i = 0; i < kDeepTaps; ++i) {
+        a.dlo[i] = i < flen ? (T)dec_lo[i] : T(0);
+        a.rlo[i] = i < flen ? (T)rec_lo[i] : T(0);
+    }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
+    const int grid = (int)std::min<int64_t>(planes, (int64_t)256 * per_cu);
+    with_taps(flen, [&](auto ft) {
+        constexpr int FT = decltype(ft)::value;
+        auto kern = wcfg_lowpass_kernel<T, FT>;
+        static bool raised = false;  // per instantiation: dynamic LDS above the 64 KB default needs the attribute once
+        if (lds > 64 * 1024 && !raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kLowThreads), lds, st, cond, uncond, x, out, a);
+    });
+    return check_launch(what);
+}
+
+}  // namespace sonar

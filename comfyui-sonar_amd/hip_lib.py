@@ -127,6 +127,9 @@ SIGNATURES = {
     "sonar_wcfg_band_f64": (_I, [_P, _P, _P, _I64, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
     "sonar_wcfg_band_head_f32": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
     "sonar_wcfg_band_head_f64": (_I, [_P, _P, _P, _I64, _I64, _PD, _PD, _PD, _PD, _I, _D, _P]),
+    "sonar_wcfg_lowpass_lds_bytes": (_I64, [_I64, _I64, _I, _I, _I, _I, _I]),
+    "sonar_wcfg_lowpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
+    "sonar_wcfg_lowpass_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
     "sonar_wcfg_fused_ws_bytes": (_I64, [_I64, _I64, _I64, _I, _I, _I, _I, _I, _I]),
     "sonar_wcfg_fused_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _P, _I64, _P]),
@@ -904,6 +907,33 @@ def wcfg_output(x: Optional[torch.Tensor], result: torch.Tensor, shape, subtract
     planes = out.numel() // (H * W)
     _check(load().sonar_wcfg_output_f32(_opt(x, "x"), _dev(result, "result", result.dtype), int(result.dtype == torch.float64), _dev(out, "out"),
                                         planes, H, W, Hr, Wr, int(bool(subtract_from_x)), _stream()), "sonar_wcfg_output_f32")
+    return out
+
+
+_LOW_OK: dict = {}
+
+
+def wcfg_lowpass(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], *, levels: int, dec_lo, rec_lo, mode: str, inv_mode: str, g,
+                 ku: float, kt: float, subtract_from_x: bool, high_precision: bool) -> Optional[torch.Tensor]:
+    """WaveletCFG for difference-only rules with one detail scale per level, ONE launch (``sonar_wcfg_lowpass_*``: low-pass pyramid in
+    LDS, 16N bytes of HBM traffic per latent); None when the plane's pyramid does not fit in LDS (caller: ``wcfg_fused``)."""
+    B, Cc, H, W = cond.shape
+    lib = load()
+    elem = 8 if high_precision else 4
+    key = (H, W, levels, len(dec_lo), mode, inv_mode, elem)
+    ok = _LOW_OK.get(key)
+    if ok is None:
+        ok = _LOW_OK[key] = len(dec_lo) == len(rec_lo) and lib.sonar_wcfg_lowpass_lds_bytes(H, W, levels, len(dec_lo), DWT_MODE_IDS[mode],
+                                                                                            DWT_MODE_IDS[inv_mode], elem) >= 0
+    if not ok:
+        return None
+    if len(g) != levels + 1:
+        raise SonarHipError("wcfg_lowpass: g must hold levels + 1 weights")
+    out = torch.empty_like(cond)
+    fn = lib.sonar_wcfg_lowpass_f64 if high_precision else lib.sonar_wcfg_lowpass_f32
+    _check(fn(_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), B * Cc, H, W, levels, _taps_arr(dec_lo), _taps_arr(rec_lo),
+              len(dec_lo), DWT_MODE_IDS[mode], DWT_MODE_IDS[inv_mode], _darr([float(v) for v in g]), float(ku), float(kt), int(bool(subtract_from_x)),
+              _stream()), "sonar_wcfg_lowpass")
     return out
 
 

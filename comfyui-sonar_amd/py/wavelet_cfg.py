@@ -12,6 +12,7 @@ import math
 from enum import Enum, auto
 from typing import Callable, NamedTuple, Optional, Sequence
 
+import numpy as _np
 import torch
 
 from .. import hip_lib
@@ -99,32 +100,86 @@ def step_from_sigmas(sigma, sigmas: torch.Tensor, *, decimals: Optional[int] = 4
         sigmas = sigmas.max(dim=0).values
     elif sigmas.ndim != 1:
         raise ValueError(f"Unexpected number of dimensions in sigmas, should be 1 or 2 but got shape {sigmas.shape}")
-    sigmas = sigmas[:-1]
-    if not len(sigmas) or torch.any(sigmas <= 0):
-        return None
-    if decimals is not None:
-        sigmas = sigmas.round(decimals=decimals)
-        sigma = round(sigma, decimals)
-    lo, hi = sigmas.aminmax()
-    if not lo <= sigma <= hi:
-        return None
-    last = len(sigmas) - 1
-    idx = int(utils.tensor_item((sigmas - sigma).abs().argmin()))
-    at = utils.tensor_item(sigmas[idx])
-    if decimals is not None:
-        at = round(at, decimals)
-    if sigma == at:
-        return float(idx)
-    below, above = (idx, idx - 1) if sigma > at else (idx + 1, idx)
-    if min(below, above) < 0 or max(below, above) > last:
-        return None
-    s_lo, s_hi = utils.tensor_item(sigmas[below]), utils.tensor_item(sigmas[above])
-    if s_hi == s_lo:
-        return float(idx)
-    return round(above + (1.0 - ((sigma - s_lo) / (s_hi - s_lo))), output_decimals)
+    return _StepTable(sigmas, decimals).step(sigma, output_decimals)
+
+
+class _StepTable:
+    """Everything ``step_from_sigmas`` derives from the schedule alone (the rounded sigmas, their range), kept as host numbers: a
+    sampling run asks once per model evaluation with the same schedule.  The fp32 semantics of the reference's tensor expressions are
+    kept (a Python scalar meets an fp32 tensor as an fp32 value)."""
+
+    def __init__(self, sigmas_1d_cpu: torch.Tensor, decimals: Optional[int] = 4):
+        import numpy as np
+
+        self.np = np
+        sig = sigmas_1d_cpu[:-1]
+        self.decimals = decimals
+        self.valid = bool(len(sig)) and not bool(torch.any(sig <= 0))
+        if not self.valid:
+            return
+        if decimals is not None:
+            sig = sig.round(decimals=decimals)
+        self.sig = sig.to(torch.float32).numpy().copy() if sig.dtype == torch.float32 else None
+        self.sig_t = sig
+        self.vals = sig.tolist()
+        lo, hi = sig.aminmax()
+        self.lo, self.hi = lo.item(), hi.item()
+        self.last = len(sig) - 1
+
+    def step(self, sigma: float, output_decimals: int = 2):
+        if not self.valid:
+            return None
+        if self.decimals is not None:
+            sigma = round(sigma, self.decimals)
+        if self.sig is not None:
+            s32 = self.np.float32(sigma)
+            if not self.lo <= float(s32) <= self.hi:
+                return None
+            idx = int(self.np.abs(self.sig - s32).argmin())
+        else:  # unusual dtypes: the tensor expressions themselves
+            if not self.lo <= sigma <= self.hi:
+                return None
+            idx = int((self.sig_t - sigma).abs().argmin())
+        at = self.vals[idx]
+        if self.decimals is not None:
+            at = round(at, self.decimals)
+        if sigma == at:
+            return float(idx)
+        below, above = (idx, idx - 1) if sigma > at else (idx + 1, idx)
+        if min(below, above) < 0 or max(below, above) > self.last:
+            return None
+        s_lo, s_hi = self.vals[below], self.vals[above]
+        if s_hi == s_lo:
+            return float(idx)
+        return round(above + (1.0 - ((sigma - s_lo) / (s_hi - s_lo))), output_decimals)
+
+
+class _Schedule:
+    """What ``WCFGPercentages.build`` derives from (sample_sigmas, rule window) alone -- including which of the reference's failures
+    the pair leads to -- computed once per schedule tensor and window."""
+
+    def __init__(self, sigmas: torch.Tensor, start_sigma: float, end_sigma: float):
+        self.keep = sigmas  # the key holds id(sigmas): keep the tensor alive while the entry lives
+        self.error = None
+        if sigmas.ndim == 2:
+            sigmas = sigmas.max(dim=0).values
+        elif sigmas.ndim != 1:
+            self.error = ValueError("Unexpected number of dimensions for sample_sigmas")
+            return
+        sigmas = sigmas.detach().cpu()
+        self.sigma_first, self.sigma_last = sigmas[0].item(), sigmas[-2].item()
+        if self.sigma_first <= self.sigma_last:
+            self.error = ValueError("Cannot handle non-descending sigmas (possibly Restart or unsampling)")
+            return
+        self.start, self.end = min(start_sigma, self.sigma_first), max(end_sigma, self.sigma_last)
+        self.steps = len(sigmas) - 1  # >= 2 here: a two-entry schedule has sigma_first == sigmas[-2] and was rejected above
+        self.table = _StepTable(sigmas)
+        enabled = torch.arange(len(sigmas), dtype=torch.int32)[(sigmas <= self.start) & (sigmas >= self.end)]
+        self.enabled = None if len(enabled) <= 1 else (enabled[0].item(), enabled[-1].item())
 
 
 _PCT_CACHE: dict = {}
+_SCHED_CACHE: dict = {}
 
 
 class WCFGPercentages(NamedTuple):
@@ -171,51 +226,59 @@ class WCFGPercentages(NamedTuple):
     def build(cls, *, ms, start_sigma: float, end_sigma: float, sigma: float, sigmas: Optional[torch.Tensor], **_kw) -> "WCFGPercentages":
         if start_sigma < end_sigma:
             raise ValueError("start/end sigmas out of order")
-        sigma_max, sigma_min = ms.sigma_max.detach().item(), ms.sigma_min.detach().item()
-        start_sigma = min(sigma_max, start_sigma)
-        end_sigma = min(max(sigma_min, end_sigma), sigma_max)
-        sigma = min(max(sigma, sigma_min), sigma_max)
-
-        def pct_of(s):
-            return 1.0 - (ms.timestep(torch.tensor(s)) / 999).clamp(0, 1).detach().item()
-
-        # a rule's window ends are the same two numbers at every step of a run: their percentages are looked up once per model
+        # the model's sigma range and the percentages of the rule window's ends are the same numbers at every step of a run
         ends = _PCT_CACHE.get((id(ms), start_sigma, end_sigma))
         if ends is None or ends[0] is not ms:
             if len(_PCT_CACHE) > 64:
                 _PCT_CACHE.clear()
-            ends = _PCT_CACHE[(id(ms), start_sigma, end_sigma)] = (ms, pct_of(start_sigma), pct_of(end_sigma))
-        pct_start, pct_end, pct_curr = ends[1], ends[2], pct_of(sigma)
+            sigma_max, sigma_min = ms.sigma_max.detach().item(), ms.sigma_min.detach().item()
+            s0, s1 = min(sigma_max, start_sigma), min(max(sigma_min, end_sigma), sigma_max)
+            ends = _PCT_CACHE[(id(ms), start_sigma, end_sigma)] = (ms, sigma_max, sigma_min, s0, s1, cls._pct_of(ms, s0), cls._pct_of(ms, s1))
+        _ms, sigma_max, sigma_min, start_sigma, end_sigma, pct_start, pct_end = ends
+        sigma = min(max(sigma, sigma_min), sigma_max)
+        pct_curr = cls._pct_of(ms, sigma)
         pct_range_curr = (pct_curr - pct_start) / (pct_end - pct_start)
         if sigmas is None:
             # ComfyUI always passes transformer_options["sample_sigmas"]; without them the reference binds neither step_first nor
             # step_last (:188-193) and fails while building the tuple.  Same failure here rather than a silently different schedule.
             raise UnboundLocalError("local variable 'step_first' referenced before assignment")
-        if sigmas.ndim == 2:
-            sigmas = sigmas.max(dim=0).values
-        elif sigmas.ndim != 1:
-            raise ValueError("Unexpected number of dimensions for sample_sigmas")
-        sigmas = sigmas.detach().cpu()
-        sigma_first, sigma_last = sigmas[0].item(), sigmas[-2].item()
-        if sigma_first <= sigma_last:
-            raise ValueError("Cannot handle non-descending sigmas (possibly Restart or unsampling)")
+        key = (id(sigmas), sigmas._version, start_sigma, end_sigma)
+        sched = _SCHED_CACHE.get(key)
+        if sched is None or sched.keep is not sigmas:
+            if len(_SCHED_CACHE) > 64:
+                _SCHED_CACHE.clear()
+            sched = _SCHED_CACHE[key] = _Schedule(sigmas, start_sigma, end_sigma)
+        if sched.error is not None:
+            raise type(sched.error)(*sched.error.args)
+        sigma_first, sigma_last, start_sigma, end_sigma = sched.sigma_first, sched.sigma_last, sched.start, sched.end
         pct_sigmas = (sigma_first - sigma) / (sigma_first - sigma_last)
-        start_sigma, end_sigma = min(start_sigma, sigma_first), max(end_sigma, sigma_last)
         sigma = min(max(sigma, sigma_last), sigma_first)
         pct_enabled_sigmas = 1.0 if start_sigma == end_sigma else (start_sigma - sigma) / (start_sigma - end_sigma)
-        steps = len(sigmas) - 1  # >= 2 here: a two-entry schedule has sigma_first == sigmas[-2] and was rejected above
-        step = step_from_sigmas(sigma, sigmas)
+        steps = sched.steps
+        step = sched.table.step(sigma)
         pct_steps = step / (steps - 1) if step is not None else None
-        enabled = torch.arange(len(sigmas), dtype=torch.int32)[(sigmas <= start_sigma) & (sigmas >= end_sigma)]
-        if len(enabled) <= 1:
+        if sched.enabled is None:
             # fewer than two schedule points inside the rule's window: pct_enabled_steps is never bound in the reference (:181-187)
             raise UnboundLocalError("local variable 'pct_enabled_steps' referenced before assignment")
-        step_first, step_last = enabled[0].item(), enabled[-1].item()
+        step_first, step_last = sched.enabled
         pct_enabled_steps = (step - step_first) / (step_last - step_first)  # step None (sigma off the schedule) -> TypeError, as there
         return WCFGPercentages(sigma=sigma, sigma_min=sigma_min, sigma_max=sigma_max, sigma_first=sigma_first, sigma_last=sigma_last,
                                steps=steps, step=step, step_first=step_first, step_last=step_last, pct_sampling=pct_curr,
                                pct_enabled_sampling=pct_range_curr, pct_sigmas=pct_sigmas, pct_enabled_sigmas=pct_enabled_sigmas,
                                pct_steps=pct_steps, pct_enabled_steps=pct_enabled_steps)
+
+    @staticmethod
+    def _pct_of(ms, s: float) -> float:
+        """``1.0 - (ms.timestep(tensor(s)) / 999).clamp(0, 1).item()`` (:148-153): the model's ``timestep`` is the one tensor call; the
+        quotient of its 0-d result by 999 is formed as torch forms it (fp32 for integer and fp32 timesteps), on a host scalar."""
+        t = ms.timestep(torch.tensor(s))
+        if t.dtype in (torch.float64,):
+            q = t.item() / 999
+        elif t.dtype in (torch.float32, torch.int64, torch.int32):
+            q = float(_np.float32(t.item()) / _np.float32(999.0))
+        else:
+            return 1.0 - (t / 999).clamp(0, 1).detach().item()
+        return 1.0 - min(max(q, 0.0), 1.0)
 
 
 class WCFGScales(NamedTuple):
@@ -503,6 +566,18 @@ def _to_dtype(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t.to(dtype).contiguous()
 
 
+_LOWPASS_ARGS: dict = {}
+
+
+def _rule_is_static(rule: "WCFGRule") -> bool:
+    """True when nothing in the rule is scheduled: its scale tables and strengths are the same numbers at every step."""
+    for spec in (rule.diff, rule.cond, rule.uncond, rule.final):
+        if spec is not None and not isinstance(spec, WCFGScales):
+            return False
+    return all(isinstance(v.value_start, (int, float)) and (v.value_end is None or v.scheduler is None)
+               for v in (rule.blend_strength, rule.difference_blend_strength))
+
+
 def _per_latent(t: torch.Tensor, sigma: torch.Tensor, *, divide: bool) -> torch.Tensor:
     """``t / sigma`` or ``t * sigma`` with one sigma per latent (``sigma`` shaped [B, 1, ...], py/wavelet_cfg.py:697-699,746-747,832-833)
     through the row kernel: (t - 0) / s and t * s + 0 are the reference's quotient / product exactly."""
@@ -606,6 +681,62 @@ class WaveletCFG:
             strength=rule.difference_blend_strength.get_value(pcts), subtract_from_x=True, high_precision=ctx.dtype == torch.float64)
 
     @classmethod
+    def wavelet_cfg_lowpass(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts) -> Optional[torch.Tensor]:
+        """x - result in ONE launch for rules that only scale the difference bands with one scale per level (the node's placeholder
+        rule): by linearity and perfect reconstruction the step collapses to a low-pass pyramid of cond - uncond kept in LDS
+        (``sonar_wcfg_lowpass_*``, csrc/dwt_lowpass.h).  None when the rule / wavelet / shape is outside that scope."""
+        w = ctx.wavelet
+        if ctx.cond.ndim != 4 or ctx.cond.dtype != torch.float32 or ctx.uncond.dtype != torch.float32 or ctx.dtype not in (torch.float32, torch.float64):
+            return None
+        levels = w.level
+        if levels < 1 or getattr(w, "wave", None) is None or w.wave != w.inv_wave or w.wave == "dmey" or len(w.dec_lo) != len(w.rec_lo):
+            return None  # perfect reconstruction needs the analysis and synthesis banks of one wavelet
+        static = _rule_is_static(rule)
+        hit = _LOWPASS_ARGS.get(id(rule)) if static else None
+        if hit is not None and hit[0] is rule:
+            plan = hit[1]
+        else:
+            plan = cls._lowpass_plan(rule, pcts, levels)
+            if static:
+                if len(_LOWPASS_ARGS) > 64:
+                    _LOWPASS_ARGS.clear()
+                _LOWPASS_ARGS[id(rule)] = (rule, plan)
+        if plan is None:
+            return None
+        g, ku, kt = plan
+        return hip_lib.wcfg_lowpass(ctx.cond.contiguous(), ctx.uncond.contiguous(), ctx.x.contiguous(), levels=levels, dec_lo=w.dec_lo, rec_lo=w.rec_lo,
+                                    mode=w.mode, inv_mode=w.inv_mode, g=g, ku=ku, kt=kt, subtract_from_x=True, high_precision=ctx.dtype == torch.float64)
+
+    @staticmethod
+    def _lowpass_plan(rule: WCFGRule, pcts, levels: int):
+        """(g, ku, kt) of ``sonar_wcfg_lowpass_*`` for this rule at these percentages, or None when the rule needs the bands."""
+        fake_yh = [_BandShape] * levels
+        for name in ("cond", "uncond", "final"):
+            yl, table = rule.scale_table(name, pcts, fake_yh)
+            if yl != 1.0 or (table is not None and any(float(v) != 1.0 for row in table for v in (row if isinstance(row, (tuple, list)) else (row,)))):
+                return None
+        yl, table = rule.scale_table("diff", pcts, fake_yh)
+        d = []
+        for j in range(levels):
+            row = (1.0,) if table is None or j >= len(table) else table[j]
+            row = tuple(float(v) for v in row) if isinstance(row, (tuple, list)) else (float(row),)
+            if any(v != row[0] for v in row[:3]):
+                return None  # per-orientation scales need the bands themselves
+            d.append(row[0])
+        g = [d[0], *(d[j] - d[j - 1] for j in range(1, levels)), float(yl) - d[-1]]
+        t = float(rule.difference_blend_strength.get_value(pcts))
+        mode = rule.difference_blend_mode
+        if mode == "inject":
+            ku, kt = 1.0, t
+        elif mode == "lerp":
+            ku, kt = 1.0 - t, t
+        elif mode == "subtract_b":
+            ku, kt = 1.0, -t
+        else:
+            return None
+        return g, ku, kt
+
+    @classmethod
     def wavelet_cfg_raw(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts) -> torch.Tensor:
         """The transform-domain result in ``ctx.dtype`` at the reconstruction's own size (before cast/crop)."""
         condw = ctx.wavelet.forward(_to_dtype(ctx.cond, ctx.dtype))
@@ -672,6 +803,10 @@ class WaveletCFG:
         x = ctx.x
         if (plain and rule.target_mode == WCFGTarget.DENOISED and x.ndim == 4 and x.dtype == torch.float32 and self.operation_wavelet_cfg is None
                 and not rule.wavelet.use_1d_dwt):
+            # fast path 0: difference-only rule with one scale per level -> low-pass pyramid in LDS, one launch, 16N bytes of traffic
+            low = self.wavelet_cfg_lowpass(rule=rule, ctx=ctx, pcts=pcts)
+            if low is not None:
+                return self.maybe_op(low, self.operation_result, **ctx.op_kwargs).contiguous()
             # fast path 1: the whole transform-domain step in 2 * level LDS-staged launches (cond + uncond analysed together, band
             # arithmetic before the store, last synthesis pass writes x - result)
             fused = self.wavelet_cfg_fused(rule=rule, ctx=ctx, pcts=pcts)

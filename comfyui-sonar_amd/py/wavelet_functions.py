@@ -59,6 +59,7 @@ class Wavelet:
         self.level = int(level)
         self.mode = mode
         self.inv_mode = fallback(inv_mode, mode)
+        self.wave, self.inv_wave = wave, fallback(inv_wave, wave)
         fwd, inv = _taps(wave), _taps(fallback(inv_wave, wave))
         self.dec_lo, self.dec_hi = fwd["dec_lo"], fwd["dec_hi"]
         self.rec_lo, self.rec_hi = inv["rec_lo"], inv["rec_hi"]

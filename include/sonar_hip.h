@@ -371,6 +371,22 @@ int sonar_wcfg_fused_f64(const float* cond, const float* uncond, const float* x,
                          int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd, const double* rec_lo,
                          const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,
                          int blend_mode, double strength, int subtract_from_x, void* ws, int64_t ws_bytes, void* stream);
+/* WaveletCFG for difference-only rules with ONE detail scale per level (py/wavelet_cfg.py:750-791 with `cond` / `uncond` / `final`
+ * absent; the node's placeholder rule, BASELINE cfg4).  By linearity and perfect reconstruction
+ *   IDWT(blend(DWT u, D (DWT c - DWT u), t)) = ku u + kt (g[0] v + Up_1(g[1] LL_1 + Up_2(... g[J] LL_J))),  v = c - u,
+ * LL_j = low-pass analysis chain of v, Up_j = level-j synthesis with zero details, g[0] = d_1, g[j] = d_{j+1} - d_j, g[J] = l - d_J
+ * (d_j: the detail scale of level j, l: the approximation scale; (ku, kt) = (1, t) inject, (1 - t, t) lerp, (1, -t) subtract_b).
+ * One launch, a workgroup per plane, the LL pyramid stays in LDS: out = x - result (subtract_from_x) or result; fp32 tensors,
+ * _f32 / _f64 = arithmetic type.  dec_lo / rec_lo: the `flen` (even, <= 20) low-pass taps of ONE wavelet (perfect-reconstruction
+ * pair); g: HOST array of levels + 1 doubles.  SONAR_ERR_UNSUPPORTED when the pyramid does not fit in LDS
+ * (sonar_wcfg_lowpass_lds_bytes < 0): callers use sonar_wcfg_fused_* then. */
+int64_t sonar_wcfg_lowpass_lds_bytes(int64_t H, int64_t W, int levels, int flen, int mode_fwd, int mode_inv, int elem_size);
+int sonar_wcfg_lowpass_f32(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H,
+                           int64_t W, int levels, const double* dec_lo, const double* rec_lo, int flen, int mode_fwd,
+                           int mode_inv, const double* g, double ku, double kt, int subtract_from_x, void* stream);
+int sonar_wcfg_lowpass_f64(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H,
+                           int64_t W, int levels, const double* dec_lo, const double* rec_lo, int flen, int mode_fwd,
+                           int mode_inv, const double* g, double ku, double kt, int subtract_from_x, void* stream);
 /* process_output, py/wavelet_cfg.py:729-748: out = x - (float)crop(result)  (subtract_from_x = 1, target DENOISED)
  * or out = (float)crop(result); result is [planes][Hr][Wr] (f64 or f32), x/out are [planes][H][W] fp32 */
 int sonar_wcfg_output_f32(const float* x, const void* result, int result_is_f64, float* out, int64_t planes,

@@ -217,6 +217,7 @@ def test_wavelet_cfg_fused_equals_per_pass_path(api, monkeypatch, high_precision
     args = {"input": x, "cond_scale": 7.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
             "sigma": torch.full((3,), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
+    monkeypatch.setattr(api.wc.WaveletCFG, "wavelet_cfg_lowpass", classmethod(lambda cls, **_k: None))  # this test is about the band kernels
     calls = []
     real = api.hl.wcfg_fused
     monkeypatch.setattr(api.hl, "wcfg_fused", lambda *a, **k: calls.append(1) or real(*a, **k))

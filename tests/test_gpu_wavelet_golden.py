@@ -96,9 +96,41 @@ def test_wavelet_cfg_matches_reference(api, name):
     np.testing.assert_allclose(fn(args).cpu().numpy(), want, rtol=0, atol=_wcfg_tol(case, want))
 
 
-@pytest.mark.parametrize("name", [n for n, c in wc.WCFG_CASES.items() if len(c["shape"]) == 4 and not c["params"].get("use_1d_dwt")])
+FOUR_D = [n for n, c in wc.WCFG_CASES.items() if len(c["shape"]) == 4 and not c["params"].get("use_1d_dwt")]
+
+
+def test_lowpass_path_is_taken_where_it_applies(api, monkeypatch):
+    """Difference-only rules with one scale per level run as ONE launch (sonar_wcfg_lowpass_*); the others do not."""
+    calls = []
+    real = api.hl.wcfg_lowpass
+    monkeypatch.setattr(api.hl, "wcfg_lowpass", lambda *a, **k: calls.append(1) or real(*a, **k))
+    used = {}
+    for name in FOUR_D:
+        case = wc.WCFG_CASES[name]
+        calls.clear()
+        wh.build_wcfg(api.wavelet_cfg, case)(wh.wcfg_args(case, name, wc.FakeModel(), device="cuda"))
+        used[name] = bool(calls)
+    for name in ("placeholder", "placeholder_f32", "placeholder_128", "identity_scales", "haar_per", "lerp_diff_small_t", "subtract_diff",
+                 "two_levels_inv_wave", "second_rule"):
+        assert used[name], name
+    for name in ("odd_sizes", "lerp_diff", "all_scales", "all_scales_f32", "target_noise", "blend_half", "outside_window", "scheduled_scales"):
+        assert not used[name], name
+
+
+@pytest.mark.parametrize("name", FOUR_D)
+def test_wavelet_cfg_band_path_matches_reference(api, name, monkeypatch):
+    """The same cases with the low-pass shortcut disabled: cond and uncond analysed band by band (sonar_wcfg_fused_*, 3 launches)."""
+    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "wavelet_cfg_lowpass", classmethod(lambda cls, **_k: None))
+    case = wc.WCFG_CASES[name]
+    args = wh.wcfg_args(case, name, wc.FakeModel(), device="cuda")
+    want = WCFG[f"{name}__out"]
+    np.testing.assert_allclose(wh.build_wcfg(api.wavelet_cfg, case)(args).cpu().numpy(), want, rtol=0, atol=_wcfg_tol(case, want))
+
+
+@pytest.mark.parametrize("name", FOUR_D)
 def test_wavelet_cfg_per_pass_path_matches_reference(api, name, monkeypatch):
-    """The same cases with the fused 3-launch entry point disabled: the per-level kernels behind Wavelet.forward / inverse."""
+    """The same cases with both fast entry points disabled: the per-level kernels behind Wavelet.forward / inverse."""
+    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "wavelet_cfg_lowpass", classmethod(lambda cls, **_k: None))
     monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "wavelet_cfg_fused", classmethod(lambda cls, **_k: None))
     case = wc.WCFG_CASES[name]
     args = wh.wcfg_args(case, name, wc.FakeModel(), device="cuda")
