@@ -4,29 +4,34 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): noise-latents/sec on SDXL 4x128x128 latents.  One "step" = one call of the
-normalised power-law (pink, alpha = 1) rFFT noise sampler for a batch of 512 latents per GPU (cfg2 of
-BASELINE.json at the north_star's batch), through the reference's plugin API
-(PowerNoiseItem.make_noise_sampler -> ns(sigma, sigma_next)), generate mode (cpu=False: spectrum drawn by
-the in-kernel Philox RNG, nothing read from HBM but the 33 KB filter).  N > 1: one process per GPU,
-every rank generates its own 512-latent shard of one logical N*512 batch (weak scaling, no data-path
-collective; shard-invariant counters) — the only collectives are the timing barrier / max.
+Metric (BASELINE.json): noise-latents/sec on SDXL 4x128x128 latents.  One "step" = one call of the normalised power-law (pink,
+alpha = 1) rFFT noise sampler for a batch of 512 latents per GPU (cfg2 of BASELINE.json at the north_star's batch), through the
+reference's plugin API (PowerNoiseItem.make_noise_sampler -> ns(sigma, sigma_next)), generate mode (cpu=False: spectrum drawn
+in-kernel, nothing read from HBM but the 33 KB filter).  N > 1: one process per GPU, every rank generates its own 512-latent
+shard of one logical N*512 batch (weak scaling, no data-path collective; shard-invariant counters) — the only collectives are the
+timing barrier / max, and, outside `value`, the optional final gather (RCCL all-gather vs direct peer copies).
 
-Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernels = the launch pair of one C-ABI call,
-HIP-event timed on the launch stream inside the timed region; `achieved` uses SURVEY.md §8d's official
-12N bytes/latent for normalised generation, `achieved_single_write` the 4N this implementation really moves;
-`traffic` = HBM bytes per launch from the rocprofv3 PMC passes recorded in profiles/r01_traffic.json),
-`cpu_baseline` (oracle on host cores, bounded sample, N = 1 only), `extra` (other rows of the path, outside
-the timed region).
+Prints ONE JSON line (rank 0).  Keys beyond the contract:
+  roofline      the dominant launch pair (statistics pass + final pass of one C-ABI call), HIP-event timed on the launch stream
+                inside the timed region.  `achieved` / `frac` are at the bytes the kernels REALLY move (4N per latent: one write;
+                `traffic` = the rocprofv3 PMC figure from profiles/r02_traffic.json); `frac_contract_12N` is the same time priced
+                at SURVEY.md 8d's 12N (the reference-structured write + read + write).  `bound` = what the counters and the
+                per-pass timings in profiles/ show limits the pair (vector-ALU issue + LDS latency), `peak` stays the HBM peak the
+                fraction is taken against.  `kernels` = the other rows of the path, each event-timed here, with its own bytes.
+  cpu_baseline  oracle/sonar_oracle.py (PyTorch-CPU restatement pinned to the reference) on the host cores: all cores and one
+                thread, bounded samples, CPU model string (N = 1 only).
+  extra         other configurations of BASELINE.json (cfg3 / cfg4 / cfg5) event-timed outside the timed region.
 """
 from __future__ import annotations
 
 import argparse
 import importlib
 import json
+import math
 import os
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -34,47 +39,184 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 BATCH = 512
 C, H, W = 4, 128, 128
 N_LATENT = C * H * W
 
 
-def power_item(pn):
-    return pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
-                             mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1")
+def power_item(pn, factor=1.0, channels="1,1,1,1,1,1"):
+    return pn.PowerNoiseItem(factor, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
+                             mix=1.0, common_mode=0.0, channel_correlation=channels)
 
 
-def cpu_baseline(target_s: float = 12.0):
-    """Oracle (PyTorch-CPU restatement of the reference, `port`) on the host cores: same workload at a bounded batch."""
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(target_s: float = 8.0):
+    """Oracle (PyTorch-CPU restatement of the reference, `port`) on the host cores: the same workload at a bounded batch, with every
+    host core and with one thread."""
     from oracle import sonar_oracle as orc
 
     shape = (64, C, H, W)
     filt = orc.power_filter_normalize(orc.power_filter_build(shape, alpha=1.0, max_freq=0.7071), shape)
-    torch.manual_seed(0)
-    orc.power_noise(orc.draw_power(shape), filt, shape, None, 1.0, True)  # warm
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        z = orc.draw_power(shape)
-        orc.power_noise(z, filt, shape, None, 1.0, True)
-        reps += 1
-        if time.perf_counter() - t0 >= target_s or reps >= 400:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": reps * shape[0] / dt, "unit": "latents/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} x power-law normalised noise calls at batch {shape[0]} (SDXL 4x128x128), {dt:.1f} s, oracle/sonar_oracle.py"}
+
+    def run(seconds):
+        torch.manual_seed(0)
+        orc.power_noise(orc.draw_power(shape), filt, shape, None, 1.0, True)  # warm
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            orc.power_noise(orc.draw_power(shape), filt, shape, None, 1.0, True)
+            reps += 1
+            if time.perf_counter() - t0 >= seconds or reps >= 400:
+                break
+        return reps, time.perf_counter() - t0
+
+    cores = torch.get_num_threads()
+    reps, dt = run(target_s)
+    torch.set_num_threads(1)
+    reps1, dt1 = run(target_s * 0.5)
+    torch.set_num_threads(cores)
+    return {"value": reps * shape[0] / dt, "unit": "latents/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "all_cores": {"value": reps * shape[0] / dt, "threads": cores}, "one_thread": {"value": reps1 * shape[0] / dt1, "threads": 1},
+            "sample": f"{reps} (all cores, {dt:.1f} s) + {reps1} (one thread, {dt1:.1f} s) normalised power-law noise calls at batch {shape[0]} "
+                      "(SDXL 4x128x128), oracle/sonar_oracle.py"}
 
 
-def time_calls(fn, steps, warmup):
+def event_us(fn, steps=20, warmup=5):
+    """Average GPU time of fn() in microseconds: HIP events on torch's current stream (the stream every sonar_* call launches on)."""
     for _ in range(warmup):
         fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    e0.record()
     for _ in range(steps):
         fn()
+    e1.record()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    return e0.elapsed_time(e1) / steps * 1e3
+
+
+def traffic_table() -> dict:
+    if os.path.exists(TRAFFIC_FILE):
+        with open(TRAFFIC_FILE) as fh:
+            return json.load(fh)
+    return {}
+
+
+def kernel_entry(name, us, bytes_per_launch, traffic, note=None):
+    gbps = bytes_per_launch / (us * 1e-6) / 1e9
+    e = {"kernel": name, "avg_launch_us": us, "bytes_per_launch": bytes_per_launch, "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic}
+    if note:
+        e["note"] = note
+    return e
+
+
+def secondary_rows(device, hl, pn, ng, nz, x, sig):
+    """Other rows of the path and the other BASELINE configurations, event-timed (N = 1 only, outside `value`)."""
+    tr = traffic_table()
+    kernels, extra = [], {}
+    # achievable HBM bandwidth on this box (SURVEY 8d asks for it beside the 8 TB/s spec): device-to-device copy of 1 GiB
+    big_a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device)
+    big_b = torch.empty_like(big_a)
+    extra["hbm_copy_GBps_read_plus_write"] = 2 * big_a.numel() * 4 / (event_us(lambda: big_b.copy_(big_a), 10, 3) * 1e-6) / 1e9
+    del big_a, big_b
+    # cfg3: Perlin and pyramid, normalised, generate mode, at the north_star batch (512) and at the configured batch (64)
+    x64 = torch.zeros((64, C, H, W), device=device)
+    for name in ("perlin", "pyramid"):
+        for tag, xb in (("b512", x), ("b64", x64)):
+            ns = nz.get_noise_sampler(name, xb, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+            us = event_us(lambda: ns(*sig))
+            b = xb.shape[0]
+            extra[f"{name}_{tag}_latents_per_s"] = b / (us * 1e-6)
+            real = (4 if name == "perlin" else 12) * N_LATENT * b  # Perlin is written once; pyramid generates, then scales in place
+            kernels.append(kernel_entry(f"{name} normalised generate, batch {b}", us, real, tr.get(f"{name}_{tag}", {}).get("hbm_bytes_per_launch"),
+                                        "4N real (12N contract)" if name == "perlin" else "12N real = contract"))
+    # momentum step (row M): 3 reads + 2 writes
+    sonar = importlib.import_module("comfyui_sonar_amd.py.sonar")
+    sb = sonar.SonarBase(sonar.SonarBase.get_config(None, {}))
+    den, xs = torch.randn_like(x), torch.randn_like(x)
+    sb.momentum_step(0, xs, den, torch.tensor(10.0), torch.tensor(8.0))
+    us = event_us(lambda: sb.momentum_step(1, xs, den, torch.tensor(8.0), torch.tensor(6.0)))
+    extra["momentum_euler_latent_steps_per_s"] = BATCH / (us * 1e-6)
+    kernels.append(kernel_entry("ew_kernel<EulerOp> fused momentum step, batch 512", us, 20 * N_LATENT * BATCH,
+                                tr.get("momentum_euler_b512", {}).get("hbm_bytes_per_launch")))
+    # spectral filter (PowerFilterNoiseItem / ffilter): one read, one write
+    filt = torch.rand(H, W // 2 + 1, device=device) + 0.5
+    us = event_us(lambda: hl.spectral_filter(xs, filt))
+    extra["spectral_filter_latents_per_s"] = BATCH / (us * 1e-6)
+    kernels.append(kernel_entry("power_irfft2_kernel<SRC=2> spectral filter, batch 512", us, 8 * N_LATENT * BATCH,
+                                tr.get("spectral_filter_b512", {}).get("hbm_bytes_per_launch")))
+    # brownian (cfg5's third source), one new path point per call
+    ns_b = nz.get_noise_sampler("brownian", x64, 0.03, 14.6, seed=7, cpu=False, normalized=False)
+    sched = torch.linspace(14.6, 0.03, 41).tolist()
+    pos = [0]
+
+    def brownian_step():
+        i = pos[0] % 40
+        pos[0] += 1
+        return ns_b(torch.tensor(sched[i]), torch.tensor(sched[i + 1]))
+
+    extra["brownian_b64_latents_per_s"] = 64 / (event_us(brownian_step, 30, 5) * 1e-6)
+    # cfg4: WaveletCFG db4 / level 5 / symmetric, fp32 I/O, 256 latents (cond, uncond, x -> out: 16N bytes per latent)
+    wc = importlib.import_module("comfyui_sonar_amd.py.wavelet_cfg")
+    b4 = 256
+    ms = types.SimpleNamespace(sigma_min=torch.tensor(0.03), sigma_max=torch.tensor(14.6), timestep=lambda sg: (
+        999 * (1 - (sg.log() - math.log(0.03)) / (math.log(14.6) - math.log(0.03)))).clamp(0, 999))
+    cond, uncond, xin = (torch.randn(b4, C, H, W, device=device) for _ in range(3))
+    wargs = {"cond_denoised": cond, "uncond_denoised": uncond, "cond": xin - cond, "uncond": xin - uncond, "input": xin, "cond_scale": 7.0,
+             "sigma": torch.full((b4,), 7.0, device=device), "model": types.SimpleNamespace(model_sampling=ms),
+             "model_options": {"transformer_options": {"sample_sigmas": torch.cat([torch.linspace(14.6, 0.03, 20), torch.zeros(1)])}}}
+    for tag, hp in (("fp64", True), ("fp32", False)):  # the node's placeholder rule: db4, level 5, symmetric, difference scales 5 / 3
+        cfg_fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0), high_precision_mode=hp))
+        try:
+            us = event_us(lambda: cfg_fn(wargs), 10, 3)
+            extra[f"wavelet_cfg_{tag}_end_to_end_us"] = us
+            extra[f"wavelet_cfg_{tag}_latents_per_s"] = b4 / (us * 1e-6)
+            w = cfg_fn.rules[0].make_wavelet()
+            kus = event_us(lambda: hl.wcfg_lowpass(cond, uncond, xin, levels=5, dec_lo=w.dec_lo, rec_lo=w.rec_lo, mode="symmetric", inv_mode="symmetric",
+                                                   g=[3.0, 0.0, 0.0, 0.0, 0.0, 2.0], ku=1.0, kt=1.0, subtract_from_x=True, high_precision=hp), 10, 3)
+            extra[f"wavelet_cfg_{tag}_kernel_us"] = kus
+            kernels.append(kernel_entry(f"wcfg_lowpass_kernel<{'double' if hp else 'float'}, 8> WaveletCFG placeholder rule, batch 256", kus,
+                                        16 * N_LATENT * b4, tr.get(f"wcfg_lowpass_{tag}_b256", {}).get("hbm_bytes_per_launch"),
+                                        "end to end adds the reference's sigma.max().item() sync and the host rule logic"))
+        except Exception as exc:  # secondary figure only; the headline must still print
+            extra[f"wavelet_cfg_{tag}_error"] = repr(exc)[:200]
+    # cfg5: one rank's shard (128 Flux latents), scheduled power + Perlin + Brownian chain, SonarDPMPPSDE with momentum, per step
+    try:
+        xf = torch.randn(128, 16, H, W, device=device) * 10.0
+        inner = nz.CustomNoiseChain()
+        inner.add(power_item(pn, 0.5, "1"))
+        inner.add(nz.CustomNoiseItem(0.3, noise_type="perlin"))
+        inner.add(nz.CustomNoiseItem(0.2, noise_type="brownian"))
+        fallback = nz.CustomNoiseChain()
+        fallback.add(nz.CustomNoiseItem(1.0, noise_type="gaussian"))
+        chain = nz.CustomNoiseChain()
+        chain.add(nz.ScheduledNoise(1.0, noise=inner, start_sigma=20.0, end_sigma=0.0, normalize=None, fallback_noise=fallback))
+        sigmas = torch.cat([torch.linspace(14.6, 0.5, 11), torch.zeros(1)])
+        ns5 = chain.make_noise_sampler(xf, 0.5, 14.6, seed=3, cpu=False, normalized=True)
+
+        def run5():
+            return sonar.SonarDPMPPSDE.sampler(lambda t, sigma, **_k: hl.mul_scalar(t, 0.5), xf, sigmas[:6], {"seed": 3}, None, True, None, dict(momentum=0.95),
+                                               1.0, 1.0, ns5)
+
+        us = event_us(run5, 3, 1)
+        extra["cfg5_step_ms"] = us / 5 / 1e3  # 5 sampler steps per run (10 noise calls, 10 fake-model scalings)
+        extra["cfg5_latent_steps_per_s"] = 128 * 5 / (us * 1e-6)
+        del xf
+    except Exception as exc:
+        extra["cfg5_error"] = repr(exc)[:200]
+    return kernels, extra
 
 
 def main():
@@ -83,6 +225,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,21 +264,25 @@ def main():
     torch.manual_seed(0)
     x = torch.zeros((BATCH, C, H, W), device=device)
     sig = (torch.tensor(14.6), torch.tensor(10.0))
+    out = None
     with ng.shard_offset(rank * BATCH):  # this rank's slice of the logical N*512 batch
         ns = power_item(pn).make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)
 
         def step():
             return ns(*sig)
 
+        # HIP events on the launch stream (torch's current stream is the stream every sonar_* call launches on) bracket the
+        # timed region: average launch-pair duration = event span / steps.  (Per-call event pairs perturb the pipeline:
+        # they add ~10 us of idle time per step.)  The events are created and recorded once before the region: the first
+        # record of an event allocates it.
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        ev1.record()
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
-        # HIP events on the launch stream (torch's current stream is the stream every sonar_* call launches on) bracket the
-        # timed region: average launch-pair duration = event span / steps.  (Per-call event pairs perturb the pipeline:
-        # they add ~10 us of idle time per step.)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record()
@@ -151,20 +298,37 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = t.item()
 
-        out = None
+        gather = None
+        if distributed:
+            # optional final gather, outside `value`: RCCL all-gather vs direct peer-to-peer copies over xGMI
+            par = importlib.import_module("comfyui_sonar_amd.parallel")
+            shard = step()
+            gather = {}
+            for tag, direct in (("rccl_all_gather", False), ("direct_peer_copies", True)):
+                try:
+                    par.gather_batch(shard, BATCH * world, direct=direct)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    g0 = time.perf_counter()
+                    for _ in range(5):
+                        par.gather_batch(shard, BATCH * world, direct=direct)
+                    torch.cuda.synchronize()
+                    gt = torch.tensor([(time.perf_counter() - g0) / 5], device=device, dtype=torch.float64)
+                    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+                    gather[tag + "_ms"] = gt.item() * 1e3
+                    gather[tag + "_GBps_per_rank_in"] = shard.numel() * 4 * (world - 1) / gt.item() / 1e9
+                except Exception as exc:
+                    gather[tag + "_error"] = repr(exc)[:200]
+
         if rank == 0:
             value = n_gpus * BATCH * args.steps / elapsed
-            fused_ms = span_ms / args.steps
-            # sonar_power_noise_f32 = statistics pass (re-draw, Parseval, no stores) + final pass (draw, filter, LDS-resident C2R FFT,
-            # normalise, ONE write).  Official accounting: normalised generate = 12N bytes per latent
-            # (write, read, write of the reference-structured path); this implementation's real traffic is 4N.
-            official_bytes = 12 * N_LATENT * BATCH
+            pair_us = span_ms / args.steps * 1e3
+            # sonar_power_noise_f32 = statistics pass (re-draw of the radius words, Parseval, no stores) + final pass (draw, filter,
+            # LDS-resident C2R FFT, normalise, ONE write): 4N bytes per latent really cross HBM (profiles/r02_traffic.json).
             real_bytes = 4 * N_LATENT * BATCH
-            achieved = official_bytes / (fused_ms * 1e-3) / 1e9
-            traffic = None
-            if os.path.exists(TRAFFIC_FILE):
-                with open(TRAFFIC_FILE) as fh:
-                    traffic = json.load(fh).get("power_noise_b512", {}).get("hbm_bytes_per_launch")
+            contract_bytes = 12 * N_LATENT * BATCH
+            achieved = real_bytes / (pair_us * 1e-6) / 1e9
+            tr = traffic_table()
             step_s = elapsed / args.steps
             out = {
                 "metric": "noise-latents/sec (SDXL 4x128x128)", "value": value, "unit": "latents/s", "n_gpus": n_gpus,
@@ -173,72 +337,25 @@ def main():
                 "config": {"workload": "cfg2: power-law (pink, alpha=1) rFFT noise, normalised, SDXL 4x128x128, batch 512 per GPU, "
                                        "generate mode (in-kernel Philox-seeded xoshiro128++)", "batch_per_gpu": BATCH, "global_batch": BATCH * n_gpus,
                            "parallelism": f"batch-shard x{n_gpus}"},
-                "roofline": {"bound": "hbm", "kernel": "power_stats_kernel<128,128> + power_irfft2_kernel<128,128,GEN,NORM> (one C-ABI call)",
-                             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                             "bytes_per_launch": official_bytes, "avg_launch_us": fused_ms * 1e3,
-                             "achieved_single_write": real_bytes / (fused_ms * 1e-3) / 1e9,
-                             "note": "bytes_per_launch = 12N x 512 latents (SURVEY 8d official figure for normalised generation); the kernels write "
-                                     "the tensor once (4N, see traffic): statistics come from the spectrum by Parseval, so the launch pair is "
-                                     "bound by RNG ALU + LDS FFT, not by HBM"},
-                "path": {"step_GBps_at_12N": official_bytes / step_s / 1e9, "step_frac_of_hbm_peak_at_12N": official_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
-                         "step_GBps_real_4N": real_bytes / step_s / 1e9},
+                "roofline": {"bound": "valu", "limiter": "vector-ALU issue + LDS / barrier latency (per-pass timings and counters: profiles/r02_power_kernel.md); "
+                                                         "HBM moves 4N per latent and would allow ~21 us per launch",
+                             "kernel": "power_stats_kernel<128,128> + power_irfft2_kernel<128,128,GEN,NORM> (one C-ABI call)",
+                             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                             "traffic": tr.get("power_noise_b512", {}).get("hbm_bytes_per_launch"), "bytes_per_launch": real_bytes,
+                             "avg_launch_us": pair_us, "achieved_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9,
+                             "frac_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                             "note": "achieved / frac: the 4N bytes the launch pair really moves (one write of the tensor; statistics come from "
+                                     "the spectrum by Parseval); *_contract_12N: the same time at SURVEY 8d's 12N for the reference-structured "
+                                     "write + read + write"},
+                "path": {"step_GBps_real_4N": real_bytes / step_s / 1e9, "step_GBps_at_12N": contract_bytes / step_s / 1e9,
+                         "host_us_per_step_beyond_gpu": max(0.0, step_s * 1e6 - pair_us)},
             }
-            if n_gpus == 1:
-                # secondary workloads of the same path (not part of `value`)
-                extra = {}
-                # achievable HBM bandwidth on this box (SURVEY 8d asks for it beside the 8 TB/s spec): device-to-device copy of 1 GiB
-                big_a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device)
-                big_b = torch.empty_like(big_a)
-                extra["hbm_copy_GBps_read_plus_write"] = 2 * big_a.numel() * 4 / time_calls(lambda: big_b.copy_(big_a), 10, 3) / 1e9
-                del big_a, big_b
-                ns_p = nz.get_noise_sampler("perlin", x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
-                extra["perlin_latents_per_s"] = BATCH / time_calls(lambda: ns_p(*sig), 20, 5)
-                x64 = torch.zeros((64, C, H, W), device=device)
-                ns_y = nz.get_noise_sampler("pyramid", x64, 0.03, 14.6, seed=None, cpu=False, normalized=True)
-                extra["pyramid_b64_latents_per_s"] = 64 / time_calls(lambda: ns_y(*sig), 20, 5)
-                sonar = importlib.import_module("comfyui_sonar_amd.py.sonar")
-                sb = sonar.SonarBase(sonar.SonarBase.get_config(None, {}))
-                den = torch.randn_like(x)
-                xs = torch.randn_like(x)
-                sb.momentum_step(0, xs, den, torch.tensor(10.0), torch.tensor(8.0))
-                dt = time_calls(lambda: sb.momentum_step(1, xs, den, torch.tensor(8.0), torch.tensor(6.0)), 20, 5)
-                extra["momentum_euler_latent_steps_per_s"] = BATCH / dt
-                extra["momentum_euler_GBps_at_20N"] = 20 * N_LATENT * BATCH / dt / 1e9
-                ns_b = nz.get_noise_sampler("brownian", x64, 0.03, 14.6, seed=7, cpu=False, normalized=False)
-                sched = torch.linspace(14.6, 0.03, 41).tolist()  # like a sampling run: every call ends where the next begins
-                pos = [0]
-
-                def brownian_step():
-                    i = pos[0] % 40
-                    pos[0] += 1
-                    return ns_b(torch.tensor(sched[i]), torch.tensor(sched[i + 1]))
-
-                extra["brownian_b64_latents_per_s"] = 64 / time_calls(brownian_step, 30, 5)
-                filt = torch.rand(H, W // 2 + 1, device=device) + 0.5
-                dt = time_calls(lambda: hl.spectral_filter(xs, filt), 20, 5)
-                extra["spectral_filter_latents_per_s"] = BATCH / dt
-                extra["spectral_filter_GBps_at_8N"] = 8 * N_LATENT * BATCH / dt / 1e9
-                # cfg4: WaveletCFG db4 / level 5 / symmetric, fp32 I/O, 256 latents (cond, uncond, x -> out: 16N bytes per latent)
-                wc = importlib.import_module("comfyui_sonar_amd.py.wavelet_cfg")
-                b4 = 256
-                import math
-                import types
-
-                ms = types.SimpleNamespace(sigma_min=torch.tensor(0.03), sigma_max=torch.tensor(14.6), timestep=lambda sg: (
-                    999 * (1 - (sg.log() - math.log(0.03)) / (math.log(14.6) - math.log(0.03)))).clamp(0, 999))
-                cond, uncond, xin = (torch.randn(b4, C, H, W, device=device) for _ in range(3))
-                wargs = {"cond_denoised": cond, "uncond_denoised": uncond, "cond": xin - cond, "uncond": xin - uncond, "input": xin, "cond_scale": 7.0,
-                         "sigma": torch.full((b4,), 7.0, device=device), "model": types.SimpleNamespace(model_sampling=ms),
-                         "model_options": {"transformer_options": {"sample_sigmas": torch.cat([torch.linspace(14.6, 0.03, 20), torch.zeros(1)])}}}
-                for tag, hp in (("fp64", True), ("fp32", False)):  # the node's placeholder rule: db4, level 5, symmetric, difference scales 5 / 3
-                    cfg_fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0), high_precision_mode=hp))
-                    try:
-                        dt = time_calls(lambda: cfg_fn(wargs), 10, 3)
-                        extra[f"wavelet_cfg_{tag}_latents_per_s"] = b4 / dt
-                        extra[f"wavelet_cfg_{tag}_GBps_at_16N"] = 16 * N_LATENT * b4 / dt / 1e9
-                    except Exception as exc:  # secondary figure only; the headline must still print
-                        extra[f"wavelet_cfg_{tag}_error"] = repr(exc)[:200]
-                out["extra"] = extra
+            if gather:
+                out["gather"] = gather
+    if rank == 0 and n_gpus == 1 and not args.no_extra:
+        kernels, extra = secondary_rows(device, hl, pn, ng, nz, x, sig)
+        out["roofline"]["kernels"] = kernels
+        out["extra"] = extra
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

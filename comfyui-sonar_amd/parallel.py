@@ -56,8 +56,8 @@ class ShardedNoiseSampler:
         with noise_generation.shard_offset(self.start):
             return self.sampler(sigma, sigma_next)
 
-    def gather(self, local: torch.Tensor) -> torch.Tensor:
-        return gather_batch(local, self.global_shape[0], group=self.group)
+    def gather(self, local: torch.Tensor, *, direct: bool = False) -> torch.Tensor:
+        return gather_batch(local, self.global_shape[0], group=self.group, direct=direct)
 
 
 def allreduce_stats(local: torch.Tensor, group=None) -> torch.Tensor:
@@ -79,14 +79,38 @@ def normalise_global_(x: torch.Tensor, factor: float = 1.0, *, threshold_std_dev
     return hip_lib.scale_noise_(x, factor, True, partials, threshold_std_devs=threshold_std_devs, n_total=n_total)
 
 
-def gather_batch(local: torch.Tensor, global_batch: int, group=None) -> torch.Tensor:
-    """All-gather the shards along dim 0 into [global_batch, ...] on every rank (uneven shards are padded to the largest).
-    On MI355X the 7 xGMI links are point-to-point: RCCL's all-gather of 128 MiB shards is per-link bound (~0.9 ms for
-    cfg5); it is outside the timed hot path unless the consumer needs the full batch on one device."""
+def gather_batch(local: torch.Tensor, global_batch: int, group=None, *, direct: bool = False) -> torch.Tensor:
+    """All-gather the shards along dim 0 into [global_batch, ...] on every rank.
+
+    ``direct=False``: one RCCL ``all_gather_into_tensor`` (uneven shards are padded to the largest).  On MI355X the xGMI fabric is
+    point-to-point (7 links x ~153 GB/s per GPU), so a ring all-gather is bound by ONE link per hop.
+    ``direct=True``: every rank posts world - 1 sends of its shard and world - 1 receives straight into the slices
+    of the output, all at once (``batch_isend_irecv`` -> RCCL point-to-point): every link carries one shard concurrently, nothing
+    is forwarded, uneven shards need no padding.  Either way the gather is outside the timed hot path unless the consumer needs the
+    full batch on one device."""
     rank, world = rank_world(group)
     if world == 1:
         return local
-    counts = [shard_range(global_batch, r, world)[1] for r in range(world)]
+    spans = [shard_range(global_batch, r, world) for r in range(world)]
+    counts = [c for _s, c in spans]
+    if local.shape[0] != counts[rank]:
+        raise ValueError(f"gather_batch: rank {rank} holds {local.shape[0]} latents, its shard of {global_batch} is {counts[rank]}")
+    local = local.contiguous()
+    if direct:
+        out = torch.empty((global_batch, *local.shape[1:]), dtype=local.dtype, device=local.device)
+        start, count = spans[rank]
+        out[start:start + count].copy_(local)
+        ops = []
+        for step in range(1, world):  # peer order rotated by rank: at every step each link pair is used once
+            dst, src = (rank + step) % world, (rank - step) % world
+            if count:
+                ops.append(dist.P2POp(dist.isend, local, dst if group is None else dist.get_global_rank(group, dst), group))
+            s0, c0 = spans[src]
+            if c0:
+                ops.append(dist.P2POp(dist.irecv, out[s0:s0 + c0], src if group is None else dist.get_global_rank(group, src), group))
+        for req in dist.batch_isend_irecv(ops) if ops else ():
+            req.wait()
+        return out
     biggest = max(counts)
     send = local
     if local.shape[0] < biggest:

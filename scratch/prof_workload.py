@@ -1,0 +1,50 @@
+"""Workload for the round-2 PMC passes: every kernel whose HBM traffic profiles/r02_traffic.json reports, a few launches each, at the
+sizes bench.py times them, plus three calibration kernels with known byte counts (see scratch/calib.py)."""
+import importlib, os, sys, types, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, sonar_pkg
+pkg = sonar_pkg.load(); hl = pkg.hip_lib; hl.load()
+pn = importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise")
+nz = importlib.import_module("comfyui_sonar_amd.py.noise")
+sonar = importlib.import_module("comfyui_sonar_amd.py.sonar")
+wc = importlib.import_module("comfyui_sonar_amd.py.wavelet_cfg")
+dev = "cuda"
+sig = (torch.tensor(14.6), torch.tensor(10.0))
+REPS = int(os.environ.get("PROF_REPS", "4"))
+x = torch.zeros((512, 4, 128, 128), device=dev)
+x64 = torch.zeros((64, 4, 128, 128), device=dev)
+# calibration: known bytes (134 217 728 B per tensor)
+for i in range(REPS):
+    t = hl.philox_normal(tuple(x.shape), dev, 1, i)
+    p = hl.stats(t)
+    hl.scale_noise_(t, 0.5, True, p)
+item = pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0, common_mode=0.0,
+                         channel_correlation="1,1,1,1,1,1")
+ns = item.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)
+for _ in range(REPS): ns(*sig)
+for name in ("perlin", "pyramid"):
+    for xb in (x, x64):
+        s = nz.get_noise_sampler(name, xb, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+        for _ in range(REPS): s(*sig)
+        torch.cuda.synchronize()
+sb = sonar.SonarBase(sonar.SonarBase.get_config(None, {}))
+den, xs = torch.randn_like(x), torch.randn_like(x)
+sb.momentum_step(0, xs, den, torch.tensor(10.0), torch.tensor(8.0))
+for _ in range(REPS): sb.momentum_step(1, xs, den, torch.tensor(8.0), torch.tensor(6.0))
+filt = torch.rand(128, 65, device=dev) + 0.5
+for _ in range(REPS): hl.spectral_filter(xs, filt)
+b4 = 256
+ms = types.SimpleNamespace(sigma_min=torch.tensor(0.03), sigma_max=torch.tensor(14.6), timestep=lambda sg: (999 * (1 - (sg.log() - math.log(0.03)) / (math.log(14.6) - math.log(0.03)))).clamp(0, 999))
+cond, uncond, xin = (torch.randn(b4, 4, 128, 128, device=dev) for _ in range(3))
+wargs = {"cond_denoised": cond, "uncond_denoised": uncond, "cond": xin - cond, "uncond": xin - uncond, "input": xin, "cond_scale": 7.0,
+         "sigma": torch.full((b4,), 7.0, device=dev), "model": types.SimpleNamespace(model_sampling=ms),
+         "model_options": {"transformer_options": {"sample_sigmas": torch.cat([torch.linspace(14.6, 0.03, 20), torch.zeros(1)])}}}
+real_low = wc.WaveletCFG.wavelet_cfg_lowpass
+for hp in (True, False):
+    fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0), high_precision_mode=hp))
+    for _ in range(REPS): fn(wargs)                       # low-pass path (one launch)
+    wc.WaveletCFG.wavelet_cfg_lowpass = classmethod(lambda cls, **_k: None)
+    for _ in range(REPS): fn(wargs)                       # band path: dwt2_tile_kernel, wcfg_deep_kernel, idwt2_tile_kernel
+    wc.WaveletCFG.wavelet_cfg_lowpass = real_low
+torch.cuda.synchronize()
+print("workload done")

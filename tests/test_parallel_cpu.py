@@ -51,6 +51,7 @@ def _worker(rank, world, port, global_batch, out_dir):
         torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
         gathered = par.gather_batch(local, global_batch)
         assert torch.equal(gathered, full)
+        assert torch.equal(par.gather_batch(local, global_batch, direct=True), full)  # world - 1 concurrent point-to-point copies
         torch.save(torch.tensor([start, count]), os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
