@@ -186,14 +186,9 @@ struct NormDecision {
     int do_sub, do_div;
 };
 
+// the decision from this thread's share (s, q) of the (sum, sumsq) partials; every thread of the block takes part
 template <int BLOCK>
-__device__ __forceinline__ NormDecision decide_norm(const double* __restrict__ partials, int64_t npart, int64_t n_total,
-                                                    float thr_sd, double* red, NormDecision* sh) {
-    double s = 0.0, q = 0.0;
-    for (int64_t i = threadIdx.x; i < npart; i += BLOCK) {
-        s += partials[2 * i];
-        q += partials[2 * i + 1];
-    }
+__device__ __forceinline__ NormDecision decide_from_sums(double s, double q, int64_t n_total, float thr_sd, double* red, NormDecision* sh) {
     block_sum2<BLOCK>(s, q, red);
     if (threadIdx.x == 0) {
         const double nt = (double)n_total;
@@ -211,6 +206,17 @@ __device__ __forceinline__ NormDecision decide_norm(const double* __restrict__ p
     }
     __syncthreads();
     return *sh;
+}
+
+template <int BLOCK>
+__device__ __forceinline__ NormDecision decide_norm(const double* __restrict__ partials, int64_t npart, int64_t n_total,
+                                                    float thr_sd, double* red, NormDecision* sh) {
+    double s = 0.0, q = 0.0;
+    for (int64_t i = threadIdx.x; i < npart; i += BLOCK) {
+        s += partials[2 * i];
+        q += partials[2 * i + 1];
+    }
+    return decide_from_sums<BLOCK>(s, q, n_total, thr_sd, red, sh);
 }
 
 // arguments of the kernels that normalise inside the generating pass

@@ -275,7 +275,8 @@ __device__ __forceinline__ c32 drawn_elem(uint32_t r, uint32_t t16, float f) {
 // land in A's never-read last column), edge columns into the side buffers T0 / TM.  The filter values of pair it + 1 are
 // requested while pair it is drawn (the compiler otherwise issues each load right in front of its use).
 template <int H, int W, int S>
-__device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter, SpectrumRng& g, int tid, c32* A, c32* T0, c32* TM) {
+__device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter, SpectrumRng& g, int tid, c32* A, c32* T0, c32* TM,
+                                               int* edge_seq = nullptr) {
     constexpr int NT = plane_threads<H, W>(), M = W / 2, Wh = M + 1, LM = draw_shift<W>(), PAIRS = (H / 2) * M;
     auto fpos = [&](int p) { return (p >> LM) * Wh + 1 + (p & (M - 1)); };
     const int p0 = min(tid, PAIRS - 1);
@@ -285,6 +286,10 @@ __device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter,
         [&](uint32_t r0, uint32_t rm, uint32_t t) {
             T0[tid] = drawn_elem(r0, t & 0xFFFFu, filter[tid * Wh]);
             TM[tid] = drawn_elem(rm, t >> 16, filter[tid * Wh + M]);
+            if (edge_seq) {  // whole waves take this branch (H is a multiple of 64): publish "this wave's edge rows are in LDS"
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if ((tid & 63) == 0) __hip_atomic_fetch_add(edge_seq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         },
         [&](int, int p, uint32_t ra, uint32_t rb, uint32_t t) {
             const int pn = min(p + NT, PAIRS - 1);
@@ -349,17 +354,32 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
     c32* const TW = TM + H;         // e^{2 pi i j / 256}
     __shared__ double red[2 * NT / 64];
     __shared__ NormDecision shd;
+    __shared__ int edge_seq;  // FAST generate path: edge-column waves drawn so far (two per plane), see the fill
     const int tid = threadIdx.x;
     constexpr bool GEN = SRC == 1;
     // norm="ortho" on the inverse; the spectral filter also carries the forward transform's 1/sqrt(HW)
     float scale = SRC == 2 ? 1.0f / ((float)H * (float)W) : 1.0f / sqrtf((float)H * (float)W);
     // normalised output = (v * scale - mean) / std * factor folded into one multiply-add per value: v * nm - nc
     float nm = scale, nc = 0.0f;
+    // The normalisation decision needs the statistics pass's partials: they are requested here and first USED right before the first
+    // plane's stores, so their latency (every workgroup reads all kNPart pairs) hides behind that plane's draw and transforms.
+    constexpr int NPRE = (NORM && kNPart % NT == 0) ? kNPart / NT : 0;
+    [[maybe_unused]] double pre_s[NPRE > 0 ? NPRE : 1], pre_q[NPRE > 0 ? NPRE : 1];
+    [[maybe_unused]] bool norm_pending = NORM;
     if constexpr (NORM) {
-        const NormDecision dec = decide_norm<NT>(na.partials, kNPart, na.n_total, na.thr_sd, red, &shd);
-        const float g = (dec.do_div ? 1.0f / dec.stdv : 1.0f) * na.factor;
-        nm = scale * g;
-        nc = dec.do_sub ? dec.mean * g : 0.0f;
+        if constexpr (NPRE > 0) {
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                pre_s[i] = na.partials[2 * (tid + i * NT)];
+                pre_q[i] = na.partials[2 * (tid + i * NT) + 1];
+            }
+        } else {
+            const NormDecision dec = decide_norm<NT>(na.partials, kNPart, na.n_total, na.thr_sd, red, &shd);
+            const float g = (dec.do_div ? 1.0f / dec.stdv : 1.0f) * na.factor;
+            nm = scale * g;
+            nc = dec.do_sub ? dec.mean * g : 0.0f;
+            norm_pending = false;
+        }
     }
     double s = 0.0, q = 0.0;
     for (int j = tid; j < 256; j += NT) TW[j] = c_tw256[j];
@@ -391,6 +411,8 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         for (int i = 0; i < SONAR_PW_DESYNC; ++i) __builtin_amdgcn_s_sleep(32);
 #endif
     [[maybe_unused]] int pidx = 0;  // planes this workgroup has started (trace builds)
+    [[maybe_unused]] int edge_want = 0;
+    if (tid == 0) edge_seq = 0;  // visible after the first plane's top-of-loop barrier
     // one workgroup draws the `group` planes of an RNG group back to back (group = 1 unless generating)
     for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
     const GroupWalk gw(unit, group, split);
@@ -406,9 +428,26 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         if constexpr (SRC != 2) {
         // ---------------------------------------------------------------- fill: z * filter
         auto sink = [&](int ky, int kx, c32 v) { (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v; };
+        // the draw is one long vector-ALU stream, the transform passes are short bursts between LDS round trips and barriers: with the
+        // passes at a higher issue priority the co-resident workgroup's draw fills their gaps instead of delaying them (-2.7 us per launch)
+        __builtin_amdgcn_s_setprio(0);
         if constexpr (GEN) {
-            if constexpr (!(SONAR_PW_SKIP & 1)) fill_plane_gen<H, W, S>(filter, rng, tid, A, T0, TM);
+            if constexpr (!(SONAR_PW_SKIP & 1)) fill_plane_gen<H, W, S>(filter, rng, tid, A, T0, TM, (FAST && H == 2 * 64) ? &edge_seq : nullptr);
+            if constexpr (FAST && H == 2 * 64 && !(SONAR_PW_SKIP & 1)) {
+                // The edge columns were drawn first, by waves 0-1, which then announced themselves in edge_seq; the LAST two waves build
+                // the packed column 0 from them at the end of their own draws (Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky]): no separate
+                // fix-up phase and barrier, and the edge work is not stacked on the waves that already drew it.
+                edge_want += 2;
+                if (tid >= NT - H) {
+                    while (__hip_atomic_load(&edge_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < edge_want) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const int ky = tid - (NT - H), kn = (H - ky) & (H - 1);
+                    const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
+                    A[ky * S] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
+                }
+            }
         } else fill_plane<H, W>(z, filter, plane, tid, sink);
+        __builtin_amdgcn_s_setprio(3);
         SONAR_STAMP(1);
         __syncthreads();
         SONAR_STAMP(2);
@@ -525,13 +564,15 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         __syncthreads();
         }
         if constexpr (FAST) {
-            // fix-up: Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky] -> column 0 of the plane
-            if (tid < H) {
-                const int ky = tid, kn = (H - ky) & (H - 1);
-                const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
-                A[ky * S] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
+            if constexpr (!(GEN && H == 2 * 64) || (SONAR_PW_SKIP & 1)) {
+                // fix-up: Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky] -> column 0 of the plane (the 128-row generate path did it inside the fill)
+                if (tid < H) {
+                    const int ky = tid, kn = (H - ky) & (H - 1);
+                    const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
+                    A[ky * S] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
+                }
+                __syncthreads();
             }
-            __syncthreads();
             SONAR_STAMP(3);
             // ------------------------------------------------------------ columns, pass a: radix CN1, one item per thread
             if constexpr (!(SONAR_PW_SKIP & 2)) {
@@ -688,6 +729,21 @@ SONAR_UNROLL_ITEMS
         }
         __syncthreads();
         }  // !FAST
+        if constexpr (NPRE > 0) {
+            if (norm_pending) {  // uniform: the first plane of every workgroup
+                double ps0 = 0.0, pq0 = 0.0;
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    ps0 += pre_s[i];
+                    pq0 += pre_q[i];
+                }
+                const NormDecision dec = decide_from_sums<NT>(ps0, pq0, na.n_total, na.thr_sd, red, &shd);
+                const float g = (dec.do_div ? 1.0f / dec.stdv : 1.0f) * na.factor;
+                nm = scale * g;
+                nc = dec.do_sub ? dec.mean * g : 0.0f;
+                norm_pending = false;
+            }
+        }
         // ---------------------------------------------------------------- rows, pass b -> global
         float* const oplane = out + plane * (int64_t)H * W;
         float ps = 0.0f, pq = 0.0f;  // per-plane fp32 partials (<= 64 values per thread), folded into fp64 below
