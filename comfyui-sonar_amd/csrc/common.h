@@ -129,15 +129,38 @@ constexpr int kTileIters = 16;
 constexpr int kTileElems = kTileIters * 256;
 
 // ---- reductions -----------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+// Wave-wide sums on the DPP data path (no LDS crossbar traffic, unlike __shfl / ds_bpermute): butterfly inside each quad
+// (quad_perm), rotate-and-add inside each row of 16 lanes (row_ror:4, row_ror:8), then the row totals travel down the wave with
+// row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3); lane 63 holds the total, returned to every lane through v_readlane.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum_dpp(T v) {
+    v += dpp_move<0xB1>(v);         // quad_perm:[1,0,3,2]
+    v += dpp_move<0x4E>(v);         // quad_perm:[2,3,0,1]
+    v += dpp_move<0x124>(v);        // row_ror:4
+    v += dpp_move<0x128>(v);        // row_ror:8  -> every lane holds its row's sum
+    v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 = wave total
     return v;
 }
+__device__ __forceinline__ double wave_sum(double v) {
+    v = wave_sum_dpp(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_dpp(v)), 63));
 }
 
 // Block-wide (sum, sumsq) in fp64; result valid in thread 0.  `red` = 2*kBlock/64 doubles of LDS.

@@ -861,6 +861,101 @@ struct CastOp {
     }
 };
 
+// ---- ModulatedNoise spectral_signum (py/noise.py:938-1015) --------------------------------------------------------------------
+// DFT along the middle axis of complex z[outer][C][inner] (the channel axis of fftn over dims (-3) or (-3, -2, -1)); out of place.
+// inverse: e^{+...}, no 1/C (the caller folds it into the mask gain).  real_in: the input is a real float array (imaginary part 0);
+// real_out: only the real part is written, to a float array.  C <= 64: every output sums C terms read through L1 / L2.
+__global__ void __launch_bounds__(kBlock) cdft_mid_kernel(const float* __restrict__ zin, float* __restrict__ zout, int64_t outer, int C,
+                                                          int64_t inner, int inverse, int real_in, int real_out) {
+    const int64_t total = outer * C * inner;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = t % inner;
+        const int k = (int)((t / inner) % C);
+        const int64_t o = t / (inner * C);
+        float re = 0.0f, im = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const int64_t at = (o * C + c) * inner + i;
+            float xr, xi;
+            if (real_in) {
+                xr = zin[at];
+                xi = 0.0f;
+            } else {
+                const float2 v = reinterpret_cast<const float2*>(zin)[at];
+                xr = v.x;
+                xi = v.y;
+            }
+            float sn, cs;
+            sincospif(2.0f * (float)((c * k) % C) / (float)C, &sn, &cs);
+            if (!inverse) sn = -sn;
+            re += xr * cs - xi * sn;
+            im += xr * sn + xi * cs;
+        }
+        if (real_out) zout[t] = re;
+        else reinterpret_cast<float2*>(zout)[t] = make_float2(re, im);
+    }
+}
+
+// la = log(sqrt(re^2 + im^2)) of a spectrum z[planes][H][Wz] (Wz = W/2 + 1 columns of an rfft2 half-spectrum, or Wz = W for a full
+// one) and the multiset of |la| over the FULL spectrum: full[planes][H][W]; the columns an rfft2 drops come from their Hermitian
+// partners ((C - c) % C, (H - ky) % H, W - kx) -- C > 1 when a channel DFT was applied on top (fftn over (-3, -2, -1)).
+__global__ void __launch_bounds__(kBlock) spectral_logamp_kernel(const float2* __restrict__ z, float* __restrict__ la, float* __restrict__ full,
+                                                                 int64_t planes, int C, int H, int W, int Wz) {
+    const int64_t nz = planes * H * Wz;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < nz; t += (int64_t)gridDim.x * kBlock) {
+        const float2 v = z[t];
+        la[t] = logf(sqrtf(v.x * v.x + v.y * v.y));
+    }
+    (void)full;
+}
+__global__ void __launch_bounds__(kBlock) spectral_full_kernel(const float* __restrict__ la, float* __restrict__ full, int64_t planes, int C,
+                                                               int H, int W, int Wz) {
+    const int64_t nf = planes * H * W;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < nf; t += (int64_t)gridDim.x * kBlock) {
+        const int kx = (int)(t % W), ky = (int)((t / W) % H);
+        const int64_t p = t / ((int64_t)W * H);
+        int64_t src;
+        if (kx < Wz) {
+            src = (p * H + ky) * Wz + kx;
+        } else {
+            const int64_t b = p / C;
+            const int c = (int)(p % C);
+            src = ((b * C + (C - c) % C) * H + (H - ky) % H) * Wz + (W - kx);
+        }
+        full[t] = fabsf(la[src]);
+    }
+}
+
+// z *= gain * (mult_low * mult_high) ^ intensity with, per bin (:975-1003),
+//   mult_high = la > q_high ? 1 - min((la - q_high) / (q_max - q_high), 0.5) : 1,  mult_low = la < q_low ? 1 + min(1 - la / q_low, 0.5) : 1
+// q[nq][3] = (low, high, max) quantiles of |la| per SAMPLE; the reference expands that [B] vector against [B, C, H, W] as [B, 1, 1],
+// so the row used for a bin of plane p is 0 when nq == 1 and the bin's CHANNEL index p % C when nq == C.
+// channel_sym (a channel DFT was applied and nq == C): the Hermitian partner of a bin sits at channel frequency (C - c) % C and meets
+// ANOTHER quantile row, so the reference's mask is not Hermitian and it keeps the real part of a complex inverse; that real part equals
+// the inverse of the spectrum times the symmetrised mask (m(k) + m(-k)) / 2 (|z| is symmetric), which a half-spectrum inverse can take.
+__device__ __forceinline__ float signum_mult(float a, const float* __restrict__ qq, float intensity) {
+    const float ql = qq[0], qh = qq[1], qm = qq[2];
+    const float hi = a > qh ? 1.0f - fminf((a - qh) / (qm - qh), 0.5f) : 1.0f;
+    const float lo = a < ql ? 1.0f + fminf(1.0f - a / ql, 0.5f) : 1.0f;
+    return powf(lo * hi, intensity);
+}
+__global__ void __launch_bounds__(kBlock) spectral_signum_mask_kernel(float2* z, const float* __restrict__ la, const float* __restrict__ q, int nq,
+                                                                      int64_t planes, int C, int64_t plane_elems, float intensity, float gain,
+                                                                      int channel_sym) {
+    const int64_t n = planes * plane_elems;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (int64_t)gridDim.x * kBlock) {
+        const int64_t p = t / plane_elems;
+        const int c = (int)(p % C);
+        const float a = la[t];
+        float m = signum_mult(a, q + 3 * (nq == 1 ? 0 : c), intensity);
+        if (channel_sym && nq != 1) m = 0.5f * (m + signum_mult(a, q + 3 * ((C - c) % C), intensity));
+        m *= gain;
+        float2 v = z[t];
+        v.x *= m;
+        v.y *= m;
+        z[t] = v;
+    }
+}
+
 }  // namespace sonar
 
 using namespace sonar;
@@ -1096,6 +1191,38 @@ extern "C" int sonar_ratio_mix_f32(const float* a, float a_mul, const float* x, 
     hipLaunchKernelGGL(ratio_mix_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, (hipStream_t)stream, a, a_mul, x, x_mul,
                        num_partials, num_mul, den_partials, out, n);
     return check_launch("sonar_ratio_mix_f32");
+}
+
+extern "C" int sonar_cdft_mid_f32(const float* z_in, float* z_out, int64_t outer, int64_t C, int64_t inner, int inverse, int real_in,
+                                  int real_out, void* stream) {
+    SONAR_REQUIRE(z_in && z_out && z_in != z_out && outer >= 0 && C >= 1 && C <= 64 && inner > 0, SONAR_ERR_ARG,
+                  "sonar_cdft_mid_f32: bad argument (1..64 channels, out of place)");
+    if (outer == 0) return SONAR_OK;
+    hipLaunchKernelGGL(cdft_mid_kernel, dim3(grid_for(outer * C * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, z_in, z_out, outer,
+                       (int)C, inner, inverse, real_in, real_out);
+    return check_launch("sonar_cdft_mid_f32");
+}
+
+extern "C" int sonar_spectral_logamp_f32(const float* z, float* la, float* full, int64_t planes, int64_t C, int64_t H, int64_t W,
+                                         int64_t Wz, void* stream) {
+    SONAR_REQUIRE(z && la && full && planes >= 0 && C >= 1 && planes % C == 0 && H > 0 && W > 0 && (Wz == W || Wz == W / 2 + 1), SONAR_ERR_ARG,
+                  "sonar_spectral_logamp_f32: bad argument");
+    if (planes == 0) return SONAR_OK;
+    hipLaunchKernelGGL(spectral_logamp_kernel, dim3(grid_for(planes * H * Wz, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float2*>(z), la, full, planes, (int)C, (int)H, (int)W, (int)Wz);
+    hipLaunchKernelGGL(spectral_full_kernel, dim3(grid_for(planes * H * W, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, la, full, planes,
+                       (int)C, (int)H, (int)W, (int)Wz);
+    return check_launch("sonar_spectral_logamp_f32");
+}
+
+extern "C" int sonar_spectral_signum_mask_f32(float* z, const float* la, const float* q, int64_t nq, int64_t planes, int64_t C,
+                                              int64_t plane_elems, float intensity, float gain, int channel_sym, void* stream) {
+    SONAR_REQUIRE(z && la && q && planes >= 0 && C >= 1 && plane_elems > 0 && (nq == 1 || nq == C), SONAR_ERR_ARG,
+                  "sonar_spectral_signum_mask_f32: bad argument (one quantile row, or one per channel)");
+    if (planes == 0) return SONAR_OK;
+    hipLaunchKernelGGL(spectral_signum_mask_kernel, dim3(grid_for(planes * plane_elems, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream,
+                       reinterpret_cast<float2*>(z), la, q, (int)nq, planes, (int)C, plane_elems, intensity, gain, channel_sym);
+    return check_launch("sonar_spectral_signum_mask_f32");
 }
 
 extern "C" int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,

@@ -425,7 +425,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         const int64_t plane = gw.grp * group + gp;
         __syncthreads();  // previous plane's LDS reads are done (and TW is visible)
         SONAR_STAMP(0);
-        if constexpr (SRC != 2) {
+        if constexpr (SRC < 2) {
         // ---------------------------------------------------------------- fill: z * filter
         auto sink = [&](int ky, int kx, c32 v) { (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v; };
         // the draw is one long vector-ALU stream, the transform passes are short bursts between LDS round trips and barriers: with the
@@ -548,10 +548,11 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         for (int ky = tid; ky < H; ky += NT) {
             const int kn = (H - ky) & (H - 1);
             const c32 p = A[ky * S], pn = A[kn * S];
-            const float f0 = filter[ky * Wh], fm = filter[ky * Wh + M];
+            const float f0 = SRC == 3 ? 1.0f : filter[ky * Wh], fm = SRC == 3 ? 1.0f : filter[ky * Wh + M];
             T0[ky] = make_float2(0.5f * (p.x + pn.x) * f0, 0.5f * (p.y - pn.y) * f0);
             TM[ky] = make_float2(0.5f * (p.y + pn.y) * fm, -0.5f * (p.x - pn.x) * fm);
         }
+        if constexpr (SRC != 3) {
         for (int j = tid; j < H * M; j += NT) {
             const int ky = j / M, c = j - ky * M;
             if (c != 0) {
@@ -561,7 +562,17 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
                 A[ky * S + c] = v;
             }
         }
+        }
         __syncthreads();
+        if constexpr (SRC == 3) {
+            // forward only: the unscaled half-spectrum rfft2(x)[ky][kx], kx = 0 .. W/2, to global (complex64) and on to the next plane
+            c32* const zp = reinterpret_cast<c32*>(out) + plane * (int64_t)H * Wh;
+            for (int j = tid; j < H * Wh; j += NT) {
+                const int ky = j / Wh, kx = j - ky * Wh;
+                zp[j] = kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx];
+            }
+            continue;
+        }
         }
         if constexpr (FAST) {
             if constexpr (!(GEN && H == 2 * 64) || (SONAR_PW_SKIP & 1)) {
@@ -889,7 +900,7 @@ static int power_grid(int64_t planes) {
 }
 
 // what: 0 = irfft2 (z given or drawn; optional statistics), 1 = normalised generate (stats pass + final pass),
-//       2 = dump the drawn spectrum into `out`, 3 = spectral filter of the real planes `z`
+//       2 = dump the drawn spectrum into `out`, 3 = spectral filter of the real planes `z`, 4 = forward rfft2 of the real planes `z` into `out`
 template <int H, int W>
 static int launch_power(int what, const float* z, const float* filter, float* out, int64_t planes, uint64_t seed,
                         uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st) {
@@ -900,7 +911,9 @@ static int launch_power(int what, const float* z, const float* filter, float* ou
     const dim3 blk(plane_threads<H, W>());
 #define SONAR_PW(G, ST, NM, PART) \
     hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(g), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, group, split, PART, na)
-    if (what == 3) {
+    if (what == 4) {
+        SONAR_PW(3, false, false, nullptr);
+    } else if (what == 3) {
         if (partials) SONAR_PW(2, true, false, partials); else SONAR_PW(2, false, false, partials);
     } else if (what == 2) {
         hipLaunchKernelGGL((power_spectrum_kernel<H, W>), dim3(std::min<int64_t>(ngroups, 2048)), blk, 0, st, out, planes, seed, stream_id, plane_offset, group, split);
@@ -976,6 +989,10 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
     SONAR_CASE(256, 64);
     SONAR_CASE(64, 256);
 #undef SONAR_CASE
+    if (what == 4) {
+        set_error("sonar_rfft2_f32: power-of-two planes from 16 x 16 to 256 x 128 only (got %lld x %lld)", (long long)H, (long long)W);
+        return SONAR_ERR_UNSUPPORTED;
+    }
     if (any_plane_ok(H, W)) return launch_power_any(what, z, filter, out, planes, H, W, seed, stream_id, plane_offset, group, partials, na, st);
     set_error("sonar_power_*: unsupported plane %lld x %lld (even sizes whose half-spectrum fits in LDS: H <= 512, W <= 1024, about 19k complex values)",
               (long long)H, (long long)W);
@@ -1027,6 +1044,14 @@ extern "C" int sonar_spectral_filter_f32(const float* x, const float* filter, fl
                   "sonar_spectral_filter_f32: misaligned buffer");
     if (planes == 0) return SONAR_OK;
     return power_dispatch(3, x, filter, out, planes, H, W, 0, 0, 0, 1, partials, NormArgs{nullptr, 0, 1.0f, 0.0f}, (hipStream_t)stream);
+}
+
+extern "C" int sonar_rfft2_f32(const float* x, float* z_out, int64_t planes, int64_t H, int64_t W, void* stream) {
+    SONAR_REQUIRE(x && z_out && planes >= 0 && H > 0 && W > 0, SONAR_ERR_ARG, "sonar_rfft2_f32: bad argument");
+    SONAR_REQUIRE((reinterpret_cast<uintptr_t>(z_out) & 7u) == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0, SONAR_ERR_ARG,
+                  "sonar_rfft2_f32: misaligned buffer");
+    if (planes == 0) return SONAR_OK;
+    return power_dispatch(4, x, nullptr, z_out, planes, H, W, 0, 0, 0, 1, nullptr, NormArgs{nullptr, 0, 1.0f, 0.0f}, (hipStream_t)stream);
 }
 
 extern "C" int sonar_power_spectrum_f32(float* z_out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,

@@ -116,6 +116,10 @@ SIGNATURES = {
     "sonar_mul_table_f32": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
     "sonar_laplace_add_f32": (_I, [_P, _P, _F, _F, _F, _I64, _P]),
     "sonar_power_plane_kind": (_I, [_I64, _I64]),
+    "sonar_rfft2_f32": (_I, [_P, _P, _I64, _I64, _I64, _P]),
+    "sonar_cdft_mid_f32": (_I, [_P, _P, _I64, _I64, _I64, _I, _I, _I, _P]),
+    "sonar_spectral_logamp_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
+    "sonar_spectral_signum_mask_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _I, _P]),
     "sonar_std_mid_f32": (_I, [_P, _I64, _I64, _I64, _P, _P]),
     "sonar_bcast_gain_f32": (_I, [_P, _P, _I64, _I64, _I64, _I, _F, _F, _P, _P, _P]),
     "sonar_ratio_mix_f32": (_I, [_P, _F, _P, _F, _P, _D, _P, _P, _I64, _P]),
@@ -729,6 +733,44 @@ def spectral_filter(x: torch.Tensor, filt: torch.Tensor, partials: Optional[torc
     _check(load().sonar_spectral_filter_f32(_dev(x, "x"), _dev(filt, "filter"), _dev(out, "out"), planes, H, W,
                                             _opt(partials, "partials", torch.float64), _stream()), "sonar_spectral_filter_f32")
     return out
+
+
+def rfft2(x: torch.Tensor) -> torch.Tensor:
+    """torch.fft.rfft2(x) (unscaled) over the last two dims as a complex64 tensor [..., H, W/2+1]; LDS-resident, power-of-two planes."""
+    H, W = int(x.shape[-2]), int(x.shape[-1])
+    z = torch.empty((*x.shape[:-1], W // 2 + 1), dtype=torch.complex64, device=x.device)
+    _dev(x, "x")
+    _check(load().sonar_rfft2_f32(x.data_ptr(), z.data_ptr(), x.numel() // (H * W), H, W, _stream()), "sonar_rfft2_f32")
+    return z
+
+
+def cdft_mid(z: torch.Tensor, outer: int, C: int, inner: int, *, inverse: bool, real_out: bool = False) -> torch.Tensor:
+    """DFT along the middle axis of z viewed as [outer][C][inner]; ``z`` complex64 or (real input) float32.  Inverse: no 1/C."""
+    real_in = z.dtype == torch.float32
+    if not real_in and z.dtype != torch.complex64:
+        raise SonarHipError("cdft_mid: float32 or complex64 input")
+    if not z.is_cuda or not z.is_contiguous():
+        raise SonarHipError("cdft_mid: contiguous device tensor required")
+    out = torch.empty(z.shape, dtype=torch.float32 if real_out else torch.complex64, device=z.device)
+    _check(load().sonar_cdft_mid_f32(z.data_ptr(), out.data_ptr(), outer, C, inner, int(bool(inverse)), int(real_in), int(bool(real_out)), _stream()),
+           "sonar_cdft_mid_f32")
+    return out
+
+
+def spectral_logamp(z: torch.Tensor, planes: int, C: int, H: int, W: int):
+    """(la, full): log amplitude of the complex64 spectrum z [planes, H, Wz] and |la| over the full H x W spectrum (see the header)."""
+    Wz = int(z.shape[-1])
+    la = torch.empty(z.shape, dtype=torch.float32, device=z.device)
+    full = torch.empty((planes, H, W), dtype=torch.float32, device=z.device)
+    _check(load().sonar_spectral_logamp_f32(z.data_ptr(), _dev(la, "la"), _dev(full, "full"), planes, C, H, W, Wz, _stream()), "sonar_spectral_logamp_f32")
+    return la, full
+
+
+def spectral_signum_mask_(z: torch.Tensor, la: torch.Tensor, q: torch.Tensor, planes: int, C: int, plane_elems: int, intensity: float, gain: float,
+                          channel_sym: bool = False):
+    _check(load().sonar_spectral_signum_mask_f32(z.data_ptr(), _dev(la, "la"), _dev(q, "q"), q.shape[0], planes, C, plane_elems, float(intensity),
+                                                 float(gain), int(bool(channel_sym)), _stream()), "sonar_spectral_signum_mask_f32")
+    return z
 
 
 def std_scale_(x: torch.Tensor, mul: float, partials: torch.Tensor) -> torch.Tensor:

@@ -632,7 +632,8 @@ class PerDimNoise(CustomNoiseItemBase):
 class ModulatedNoise(CustomNoiseItemBase):
     """py/noise.py:762-1019: noise shaped by the local busyness of a reference latent (or of the sampler's x).  ``intensity`` and
     ``frequency`` run as HIP kernels (std over the modulation dims -> broadcast gain -> [LDS-resident rfft2 x boost x irfft2] ->
-    L2-norm ratio mix; no scalar is read back).  ``spectral_signum`` (per-sample quantiles of the log-spectrum) is not built."""
+    L2-norm ratio mix; no scalar is read back).  ``spectral_signum``: forward transform over the modulation dims (LDS-resident rfft2
+    and / or a channel DFT), log amplitude, per-sample quantiles by radix select, soft clamp of the outlying bins, inverse."""
 
     MODULATION_DIMS = (-3, (-2, -1), (-3, -2, -1))
 
@@ -641,9 +642,7 @@ class ModulatedNoise(CustomNoiseItemBase):
         super().__init__(factor, normalize_result=normalize_result, normalize_noise=normalize_noise, normalize_ref=normalize_ref,
                          noise=noise.clone(), modulation_dims=modulation_dims, modulation_type=modulation_type,
                          modulation_strength=modulation_strength, ref_latent_opt=None if ref_latent_opt is None else ref_latent_opt.clone())
-        if modulation_type == "spectral_signum":
-            raise NotImplementedError("ModulatedNoise: the spectral_signum mode is outside this build (SURVEY.md §8f rank 3 covers the fft modes)")
-        if modulation_type in {"intensity", "frequency"} and modulation_dims not in (1, 2, 3):
+        if modulation_type in {"intensity", "frequency", "spectral_signum"} and modulation_dims not in (1, 2, 3):
             raise ValueError("Bad modulation_dims")
 
     def clone_key(self, k):
@@ -652,6 +651,24 @@ class ModulatedNoise(CustomNoiseItemBase):
         if k == "noise":
             return self.noise.clone()
         return super().clone_key(k)
+
+    def _spectral_signum_sampler(self, x, args, kwargs, factor, strength, normalize_noise, normalize_result, normalize_ref):
+        from .sonar import get_ancestral_step
+
+        ns = self.noise.make_noise_sampler(x, *args, normalized=normalize_noise, **kwargs)
+        ref_latent = None if self.ref_latent_opt is None else self.ref_latent_opt.to(x, copy=True).contiguous()
+        which = self.modulation_dims - 1
+
+        def noise_sampler(s, sn):
+            _down, sigma_up = get_ancestral_step(utils.tensor_item(s), utils.tensor_item(sn), eta=1.0)
+            # the reference still normalises the (unused) first argument in place, sampler's x included (:1005-1008)
+            pop_stats(scale_noise(x if ref_latent is None else ref_latent, normalized=normalize_ref))
+            noise = ns(s, sn)
+            pop_stats(noise)
+            out = _spectral_signum(utils.as_f32(noise), float(sigma_up), strength, which)
+            return scale_noise(out, factor, normalized=normalize_result)
+
+        return noise_sampler
 
     @staticmethod
     def _frequency_boost(h: int, w: int, strength: float, device) -> Tensor:
@@ -667,6 +684,8 @@ class ModulatedNoise(CustomNoiseItemBase):
 
         factor, strength, mtype = self.factor, float(self.modulation_strength), self.modulation_type
         normalize_noise, normalize_result, normalize_ref = (self.get_normalize(f"normalize_{k}", normalized) for k in ("noise", "result", "ref"))
+        if mtype == "spectral_signum":
+            return self._spectral_signum_sampler(x, args, kwargs, factor, strength, normalize_noise, normalize_result, normalize_ref)
         if mtype not in {"intensity", "frequency"}:
             ns = self.noise.make_noise_sampler(x, *args, normalized=normalize_result or normalize_noise, **kwargs)
 
@@ -714,6 +733,43 @@ class ModulatedNoise(CustomNoiseItemBase):
             return scale_noise(out, factor, normalized=normalize_result)
 
         return noise_sampler
+
+
+def _spectral_signum(noise: Tensor, k: float, intensity: float, which: int, percentile: float = 5.0) -> Tensor:
+    """py/noise.py:938-1015 (spectral_modulate_noise) on device.  ``which``: 0 = fftn over dim -3 (a channel DFT), 1 = over (-2, -1)
+    (rfft2 per plane), 2 = over (-3, -2, -1) (rfft2, then the channel DFT on the half-spectrum).  The per-sample quantiles of
+    |log amplitude| run over the FULL spectrum (the half-spectrum's dropped columns come back through their Hermitian partners)."""
+    if noise.ndim != 4:
+        raise hip_lib.SonarHipError("ModulatedNoise spectral_signum: [B, C, H, W] latents on the HIP path")
+    b, c, h, w = noise.shape
+    add = hip_lib.mul_scalar(noise.contiguous(), k)  # additive_noise = noise * s_noise * sigma_up
+    if which == 0:
+        z = hip_lib.cdft_mid(add, b, c, h * w, inverse=False)          # complex [B, C, H, W]
+        la, full = hip_lib.spectral_logamp(z.reshape(b * c, h, w), b * c, 1, h, w)
+        gain, plane_elems = 1.0 / c, h * w
+    else:
+        if not (hip_lib.power_supported(h, w) and int(hip_lib.load().sonar_power_plane_kind(h, w)) == 1):
+            raise hip_lib.SonarHipError(f"ModulatedNoise spectral_signum: plane {h}x{w} is not LDS-resident (powers of two, 16..256)")
+        z = hip_lib.rfft2(add)                                          # complex [B, C, H, W/2+1]
+        wz = w // 2 + 1
+        if which == 2:
+            z = hip_lib.cdft_mid(z, b, c, h * wz, inverse=False)
+        la, full = hip_lib.spectral_logamp(z.reshape(b * c, h, wz), b * c, c if which == 2 else 1, h, w)
+        # torch's ifftn divides by the transformed element count; the inverse kernel below is ortho (1 / sqrt(H W))
+        gain, plane_elems = 1.0 / math.sqrt(h * w) / (c if which == 2 else 1), h * wz
+    # torch.quantile(|log_amp|.flatten(1), q, dim=1): one row per SAMPLE
+    q = torch.stack([hip_lib.abs_quantile_rows(full, b, c * h * w, qq) for qq in (percentile * 0.01, 1 - percentile * 0.01, 1.0)], dim=1).contiguous()
+    if b != 1 and b != c:
+        # the reference expands the [B] quantile vector as [B, 1, 1] against [B, C, H, W]: it only lines up for B = 1 or B = C
+        raise RuntimeError(f"The expanded size of the tensor ({c}) must match the existing size ({b}) at non-singleton dimension 1.  "
+                           f"Target sizes: [{b}, {c}, {h}, {w}].  Tensor sizes: [{b}, 1, 1]")
+    hip_lib.spectral_signum_mask_(z, la, q[:1].contiguous() if b == 1 else q, b * c, c, plane_elems, intensity, gain, channel_sym=which == 2)
+    if which == 0:
+        return hip_lib.cdft_mid(z, b, c, h * w, inverse=True, real_out=True)
+    if which == 2:
+        z = hip_lib.cdft_mid(z, b, c, h * (w // 2 + 1), inverse=True)
+    ones = torch.ones(h, w // 2 + 1, dtype=torch.float32, device=noise.device)
+    return hip_lib.power_irfft2(z, ones, (b, c, h, w))
 
 
 class CompositeNoise(CustomNoiseItemBase):

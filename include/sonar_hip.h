@@ -82,6 +82,24 @@ int sonar_blend_tensor_f32(int mode, const float* a, const float* b, const float
 int sonar_axpby_f32(float* y, float ymul, const float* x, float xmul, int64_t n, void* stream);
 /* the same, and the (sum, sumsq) partials of the result (1024 fp64 pairs): the last accumulation of a chain feeds its scale_noise */
 int sonar_axpby_stats_f32(float* y, float ymul, const float* x, float xmul, int64_t n, double* partials, void* stream);
+/* ModulatedNoise spectral_signum (py/noise.py:938-1015): fftn over the modulation dims -> log amplitude -> per-sample quantiles of its
+ * absolute value (sonar_abs_quantile_rows_f32 on `full`) -> soft clamp of the bins outside the 5 % / 95 % quantiles -> inverse.
+ *  sonar_rfft2_f32                 z_out[planes][H][W/2+1] (complex64) = rfft2(x) unscaled, LDS-resident (power-of-two planes)
+ *  sonar_cdft_mid_f32              DFT along the middle axis of complex z[outer][C][inner] (the channel axis), out of place; real_in:
+ *                                  float input; real_out: real part only, float output; inverse without the 1/C
+ *  sonar_spectral_logamp_f32       la = log(sqrt(re^2 + im^2)); full[planes][H][W] = |la| over the whole spectrum (dropped rfft2 columns
+ *                                  from their Hermitian partners; C = channels when a channel DFT was applied, else 1)
+ *  sonar_spectral_signum_mask_f32  z *= gain * (mult_low * mult_high)^intensity, q[nq][3] = (low, high, max) quantile rows: row 0 when
+ *                                  nq == 1, the bin's CHANNEL index when nq == C (how the reference's expand() lines the vector up);
+ *                                  channel_sym: z is a HALF spectrum under a channel DFT -> the mask is averaged with its Hermitian
+ *                                  partner's (row (C - c) % C), which is what the real part of the reference's complex inverse keeps */
+int sonar_rfft2_f32(const float* x, float* z_out, int64_t planes, int64_t H, int64_t W, void* stream);
+int sonar_cdft_mid_f32(const float* z_in, float* z_out, int64_t outer, int64_t C, int64_t inner, int inverse, int real_in,
+                       int real_out, void* stream);
+int sonar_spectral_logamp_f32(const float* z, float* la, float* full, int64_t planes, int64_t C, int64_t H, int64_t W, int64_t Wz,
+                              void* stream);
+int sonar_spectral_signum_mask_f32(float* z, const float* la, const float* q, int64_t nq, int64_t planes, int64_t C,
+                                   int64_t plane_elems, float intensity, float gain, int channel_sym, void* stream);
 /* CompositeNoise py/noise.py:524-531: out = dst*(1-mask) + src*mask; mask is [mask_n] broadcast over n/mask_n */
 int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,
                        int64_t n, void* stream);

@@ -790,6 +790,30 @@ def gen_modulated():
     save("modulated", **cases)
 
 
+def gen_spectral_signum():
+    """ModulatedNoise spectral_signum (py/noise.py:938-1015): fftn over the modulation dims, per-sample quantiles of |log amplitude|,
+    soft clamp of the bins outside the 5 % / 95 % quantiles, inverse.  The reference expands the per-sample quantile vector [B] as
+    [B, 1, 1] against [B, C, H, W], which only works for B = 1 (broadcast) or B = C (the vector then runs along the CHANNEL axis)."""
+    cases = {}
+    chain = ref.noise.CustomNoiseChain()
+    chain.add(ref.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    for tag, shape in (("b1", (1, 4, 32, 32)), ("b4", (4, 4, 16, 16))):
+        for dims in (1, 2, 3):
+            for strength in (2.0, -0.7):
+                item = ref.noise.ModulatedNoise(0.9, noise=chain, normalize_result=None, normalize_noise=None, normalize_ref=False,
+                                                modulation_type="spectral_signum", modulation_strength=strength, modulation_dims=dims)
+                torch.manual_seed(99)
+                ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=99, cpu=True, normalized=True)
+                cases[f"{tag}_{dims}_{strength}"] = ns(torch.tensor(9.0), torch.tensor(6.0))
+    item = ref.noise.ModulatedNoise(1.0, noise=chain, normalize_result=None, normalize_noise=None, normalize_ref=False, modulation_type="spectral_signum")
+    try:
+        item.make_noise_sampler(torch.zeros(2, 4, 16, 16), 0.03, 14.6, seed=99, cpu=True, normalized=True)(torch.tensor(9.0), torch.tensor(6.0))
+        raise SystemExit("expected an error")
+    except RuntimeError as exc:
+        cases["b2_error"] = np.array(str(exc)[:60])
+    save("spectral_signum", **cases)
+
+
 def gen_item_wrappers():
     """RandomNoise / RepeatedNoise / ChannelNoise (py/noise.py:681-760, 1022-1131): sequences of calls on gaussian / uniform items."""
     cases = {}
@@ -965,6 +989,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_wavelet_noise()
     gen_guided_noise()
     gen_modulated()
+    gen_spectral_signum()
     gen_item_wrappers()
     gen_power_wrapped()
     gen_pyramid_variants()

@@ -384,7 +384,7 @@ def test_modulated_noise_matches_reference(api, golden, mtype, dims, with_ref):
 
 def test_modulated_noise_full_size_properties_and_node(api):
     """SDXL batch: intensity mode with strength 1 keeps the plain noise's L2 norm; frequency mode runs on 128 x 128 planes; the node maps
-    normalize_ref like the reference (a boolean becomes False); spectral_signum is refused."""
+    normalize_ref like the reference (a boolean becomes False)."""
     shape = (16, 4, 128, 128)
     x = torch.randn(shape, device="cuda")
     ref = torch.randn(shape, device="cuda") * torch.linspace(0.2, 3.0, 128, device="cuda")[None, None, :, None]
@@ -400,9 +400,30 @@ def test_modulated_noise_full_size_properties_and_node(api):
     (chain,) = node.go(factor=1.0, sonar_custom_noise=_gauss_chain(api), modulation_type="intensity", dims=3, strength=2.0, normalize_result="default",
                        normalize_noise="default", normalize_ref=True, ref_latent_opt={"samples": ref.cpu()})
     assert chain.items[0].normalize_ref is False and chain.items[0].modulation_dims == 3
-    with pytest.raises(NotImplementedError):
-        api.noise.ModulatedNoise(1.0, noise=_gauss_chain(api), normalize_result=None, normalize_noise=None, normalize_ref=True,
-                                 modulation_type="spectral_signum")
+
+
+@pytest.mark.parametrize("strength", [2.0, -0.7])
+@pytest.mark.parametrize("dims", [1, 2, 3])
+@pytest.mark.parametrize("tag,shape", [("b1", (1, 4, 32, 32)), ("b4", (4, 4, 16, 16))])
+def test_modulated_noise_spectral_signum(api, golden, tag, shape, dims, strength):
+    """py/noise.py:938-1015 against the reference's own outputs.  FFT rows: 2e-5 of the output peak; a bin whose log amplitude sits
+    within rounding of a quantile threshold may land on the other side of it, but the clamp is continuous there."""
+    g = golden("spectral_signum")
+    item = api.noise.ModulatedNoise(0.9, noise=_gauss_chain(api), normalize_result=None, normalize_noise=None, normalize_ref=False,
+                                    modulation_type="spectral_signum", modulation_strength=strength, modulation_dims=dims)
+    torch.manual_seed(99)
+    ns = item.make_noise_sampler(torch.zeros(shape, device="cuda"), 0.03, 14.6, seed=99, cpu=True, normalized=True)
+    near(ns(torch.tensor(9.0), torch.tensor(6.0)), g[f"{tag}_{dims}_{strength}"], rel=3e-5)
+
+
+def test_modulated_noise_spectral_signum_batch_quirk(api, golden):
+    """The reference's quantile broadcast only lines up for B = 1 or B = C; any other batch fails there, and here."""
+    item = api.noise.ModulatedNoise(1.0, noise=_gauss_chain(api), normalize_result=None, normalize_noise=None, normalize_ref=False,
+                                    modulation_type="spectral_signum")
+    ns = item.make_noise_sampler(torch.zeros(2, 4, 16, 16, device="cuda"), 0.03, 14.6, seed=99, cpu=True, normalized=True)
+    with pytest.raises(RuntimeError) as exc:
+        ns(torch.tensor(9.0), torch.tensor(6.0))
+    assert str(exc.value).startswith(str(golden("spectral_signum")["b2_error"])[:40])
 
 
 # ------------------------------------------------------------------------------------------------ item wrappers
