@@ -334,8 +334,10 @@ class SonarGuidanceMixin:
             return cls.guidance_linear(x, ref_latent, factor=factor, do_shift=do_shift)
         shifted = cls.guidance_shift(denoised, ref_latent) if do_shift else ref_latent
         d = to_d(x, sigma, shifted)
-        dt = (float(sigma_next) - float(sigma)) * factor
-        return hip_lib.axpby_(d, float(torch.as_tensor(dt, dtype=torch.float32)), utils.as_f32(x), 1.0)
+        # the reference forms dt on fp32 0-d tensors: the difference rounds to fp32, then the product with the (fp32-cast) factor does
+        f32 = torch.float32
+        dt = (torch.as_tensor(float(sigma_next), dtype=f32) - torch.as_tensor(float(sigma), dtype=f32)) * torch.as_tensor(factor, dtype=f32)
+        return hip_lib.axpby_(d, float(dt), utils.as_f32(x), 1.0)
 
     @classmethod
     def guidance_linear(cls, x, ref_latent, factor: float = 0.2, *, blend=None, do_shift: bool = True) -> Tensor:
