@@ -237,3 +237,33 @@ def test_wavelet_cfg_fused_full_batch_identity(api):
             "sigma": torch.full((256,), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(difference=dict(yl_scale=1.0, yh_scales=1.0), high_precision_mode=False))
     torch.testing.assert_close(fn(args), x - cond, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("high_precision", [True, False])
+@pytest.mark.parametrize("wave,mode,level,shape", [
+    ("haar", "zero", 3, (2, 3, 40, 56)), ("db2", "symmetric", 4, (1, 4, 37, 50)), ("db4", "reflect", 3, (2, 2, 64, 48)),
+    ("sym5", "periodization", 2, (1, 4, 50, 38)), ("coif2", "periodic", 2, (1, 2, 72, 64)), ("db8", "constant", 2, (1, 2, 96, 80)),
+    ("bior2.2", "symmetric", 3, (1, 4, 33, 47)), ("db10", "symmetric", 1, (1, 2, 64, 64)), ("db4", "symmetric", 5, (2, 4, 128, 128))])
+def test_lowpass_path_equals_band_path(api, monkeypatch, wave, mode, level, shape, high_precision):
+    """The one-launch low-pass pyramid (sonar_wcfg_lowpass_*) against the band-by-band kernels (sonar_wcfg_fused_*) on rules with one
+    scale per level: every padding mode, odd sizes, filter lengths 2..20, lerp / inject / subtract blends.  Same transform, different
+    algebra: fp64 arithmetic 3e-7 of the output peak (the outputs are fp32 tensors: a last-bit difference of the final rounding), fp32 5e-5."""
+    torch.manual_seed(7)
+    cond, uncond, x = (torch.randn(shape, device="cuda") for _ in range(3))
+    args = {"input": x, "cond_scale": 7.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
+            "sigma": torch.full((shape[0],), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
+    for blend, strength in (("inject", 1.0), ("lerp", 0.35), ("lerp", 0.8), ("subtract_b", 0.6)):
+        params = dict(difference=dict(yl_scale=2.5, yh_scales=[3.0, 0.5, "fill", 1.5][: level + 1]), wave=wave, level=level, padding_mode=mode,
+                      high_precision_mode=high_precision, difference_blend_mode=blend, difference_blend_strength=strength)
+        fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
+        calls = []
+        real = api.hl.wcfg_lowpass
+        with monkeypatch.context() as m:
+            m.setattr(api.hl, "wcfg_lowpass", lambda *a, **k: calls.append(1) or real(*a, **k))
+            low = fn(args)
+        assert calls, "the low-pass entry point was not used"
+        with monkeypatch.context() as m:
+            m.setattr(api.wc.WaveletCFG, "wavelet_cfg_lowpass", classmethod(lambda cls, **_k: None))
+            bands = fn(args)
+        peak = float(bands.abs().max())
+        torch.testing.assert_close(low, bands, rtol=0, atol=(3e-7 if high_precision else 5e-5) * max(1.0, peak))
