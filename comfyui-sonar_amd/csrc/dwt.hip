@@ -391,20 +391,20 @@ extern "C" int64_t sonar_wcfg_fused_ws_bytes(int64_t planes, int64_t H, int64_t 
 extern "C" int sonar_wcfg_fused_f32(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H,
                                     int64_t W, int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd,
                                     const double* rec_lo, const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales,
-                                    const double* yh_scales, int blend_mode, double strength, int subtract_from_x, void* ws,
-                                    int64_t ws_bytes, void* stream) {
+                                    const double* yh_scales, int blend_mode, double strength, int subtract_from_x,
+                                    int perfect_reconstruction, void* ws, int64_t ws_bytes, void* stream) {
     return wcfg_fused<float>(cond, uncond, x, out, planes, H, W, levels, dec_lo, dec_hi, dec_len, mode_fwd, rec_lo, rec_hi, rec_len,
                              mode_inv, yl_scales, yh_scales, blend_mode, strength, subtract_from_x, ws, ws_bytes, (hipStream_t)stream,
-                             "sonar_wcfg_fused_f32");
+                             "sonar_wcfg_fused_f32", perfect_reconstruction != 0);
 }
 extern "C" int sonar_wcfg_fused_f64(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H,
                                     int64_t W, int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd,
                                     const double* rec_lo, const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales,
-                                    const double* yh_scales, int blend_mode, double strength, int subtract_from_x, void* ws,
-                                    int64_t ws_bytes, void* stream) {
+                                    const double* yh_scales, int blend_mode, double strength, int subtract_from_x,
+                                    int perfect_reconstruction, void* ws, int64_t ws_bytes, void* stream) {
     return wcfg_fused<double>(cond, uncond, x, out, planes, H, W, levels, dec_lo, dec_hi, dec_len, mode_fwd, rec_lo, rec_hi, rec_len,
                               mode_inv, yl_scales, yh_scales, blend_mode, strength, subtract_from_x, ws, ws_bytes, (hipStream_t)stream,
-                              "sonar_wcfg_fused_f64");
+                              "sonar_wcfg_fused_f64", perfect_reconstruction != 0);
 }
 extern "C" int64_t sonar_wcfg_lowpass_lds_bytes(int64_t H, int64_t W, int levels, int flen, int mode_fwd, int mode_inv, int elem_size) {
     size_t lds = 0;

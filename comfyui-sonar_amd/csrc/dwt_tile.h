@@ -51,6 +51,14 @@ struct BandArgs {
     T strength;
 };
 
+// How a forward tile gets its input and what it does before storing:
+//   kFwdPlain  one tensor, coefficients stored as they are                      (Wavelet.forward)
+//   kFwdPair   cond and uncond side by side, band arithmetic before the store   (any WaveletCFG rule)
+//   kFwdDiff   ONE tensor v = cond - uncond formed on load, bands scaled by the difference scales on store -- difference-only rules:
+//              IDWT(blend(U, D (C - U), t)) = ku u + kt IDWT(D DWT(c - u)), so uncond's transform is never computed
+//   kFwdScale  one tensor (a deeper level of kFwdDiff), bands scaled on store
+enum FwdMode { kFwdPlain = 0, kFwdPair = 1, kFwdDiff = 2, kFwdScale = 3 };
+
 // blend(u * s_u, (c * s_c - u * s_u) * s_d, strength) * s_f  (py/wavelet_cfg.py:765-787); scales of 1 are skipped
 template <typename T>
 __device__ __forceinline__ T band_combine4(T c, T u, T sc, T su, T sd, T sf, int blend_mode, T strength) {
@@ -102,10 +110,11 @@ __device__ __forceinline__ void fwd_build_maps(int* xmap, int* ymap, int H, int 
 }
 
 // one analysis tile: output rows [y0, y0 + th) of one plane (pc / pu, ollc / ollu / ohi are plane pointers)
-template <typename T, typename TIn, bool PAIR, int FT, bool ZERO, typename TP, bool SPLIT = false>
+template <typename T, typename TIn, int MODE, int FT, bool ZERO, typename TP, bool SPLIT = false>
 __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const TIn* __restrict__ pu, T* __restrict__ ollc,
                                              T* __restrict__ ollu, T* __restrict__ ohi, int W, int h, int w, int y0, int th,
-                                             const TP& tp, const BandArgs<T>& ba, const FwdLds<T, PAIR ? 4 : 2, FT>& lds) {
+                                             const TP& tp, const BandArgs<T>& ba, const FwdLds<T, MODE == kFwdPair ? 4 : 2, FT>& lds) {
+    constexpr bool PAIR = MODE == kFwdPair, DIFF = MODE == kFwdDiff, SCALE = MODE == kFwdDiff || MODE == kFwdScale;
     constexpr int TH = kFwdRows, NR = 2 * TH + FT - 2, NT = PAIR ? 2 : 1, NV = 2 * NT;
     using Vec = TileVec<T, NV>;
     using Half = TileVec<T, 2>;
@@ -134,10 +143,12 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
                     // rows past the tile's need (last tile) re-read a valid row; their outputs are never consumed
                     const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h + FT - 3)];
                     if constexpr (ZERO) {
-                        const T g = (T)col[(sy >= 0 ? sy : 0) * W];
+                        T g = (T)col[(sy >= 0 ? sy : 0) * W];
+                        if constexpr (DIFF) g -= (T)pu[(sy >= 0 ? sy : 0) * W + x];
                         v[r] = sy >= 0 ? g : T(0);
                     } else {
                         v[r] = (T)col[sy * W];
+                        if constexpr (DIFF) v[r] -= (T)pu[sy * W + x];
                     }
                 }
                 Half* dst = reinterpret_cast<Half*>(tmp + ((x & 1) * Wh + (x >> 1))) + ten;
@@ -179,10 +190,12 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
                 for (int r = 0; r < NRS; ++r) {
                     const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h + FT - 3)];
                     if constexpr (ZERO) {
-                        const T g = (T)col[(sy >= 0 ? sy : 0) * W];
+                        T g = (T)col[(sy >= 0 ? sy : 0) * W];
+                        if constexpr (DIFF) g -= (T)pu[(sy >= 0 ? sy : 0) * W + x];
                         v[r] = sy >= 0 ? g : T(0);
                     } else {
                         v[r] = (T)col[sy * W];
+                        if constexpr (DIFF) v[r] -= (T)pu[sy * W + x];
                     }
                 }
                 Half* dst = reinterpret_cast<Half*>(tmp + ((x & 1) * Wh + (x >> 1))) + ten;
@@ -276,6 +289,11 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
                     ollc[o] = c_ll;
                     ollu[o] = u_ll;
                 }
+            } else if constexpr (SCALE) {
+                ollc[o] = ba.combine_ll ? c_ll * ba.ld : c_ll;
+                ohi[o] = c_h * ba.hd[0];
+                ohi[hw + o] = c_v * ba.hd[1];
+                ohi[2 * hw + o] = c_d * ba.hd[2];
             } else {
                 ollc[o] = c_ll;
                 ohi[o] = c_h;
@@ -295,19 +313,20 @@ __device__ __forceinline__ void fwd_tile_job(const TIn* __restrict__ pc, const T
 // PAIR = false: plain DWT of xc -> (llc, hi).  PAIR = true: DWT of xc and xu, hi = band(xc, xu) per orientation;
 // llc / llu separate, or llc = band(ll_c, ll_u) when combine_ll.  ZERO: zero-extension mode (the only mode with "no
 // source" positions; the others never need a select).
-template <typename T, typename TIn, bool PAIR, int FT, bool ZERO>
+template <typename T, typename TIn, int MODE, int FT, bool ZERO>
 __global__ void __launch_bounds__(kTileThreads) dwt2_tile_kernel(const TIn* __restrict__ xc, const TIn* __restrict__ xu,
                                                                  T* __restrict__ llc, T* __restrict__ llu, T* __restrict__ hi,
                                                                  int64_t planes, int H, int W, int h, int w, int tiles, Taps<T> tp,
                                                                  int mode, BandArgs<T> ba) {
     extern __shared__ __align__(16) unsigned char tile_smem[];
+    constexpr bool PAIR = MODE == kFwdPair, TWO = PAIR || MODE == kFwdDiff;
     const FwdLds<T, PAIR ? 4 : 2, FT> lds(tile_smem, W, w);
     fwd_build_maps<FT>(lds.xmap, lds.ymap, H, W, h, w, lds.Wh, mode);
     const int64_t hw = (int64_t)h * w;
     for (int64_t job = blockIdx.x; job < planes * tiles; job += gridDim.x) {
         const int64_t p = job / tiles;
         const int y0 = (int)(job - p * tiles) * kFwdRows;
-        fwd_tile_job<T, TIn, PAIR, FT, ZERO>(xc + p * (int64_t)H * W, PAIR ? xu + p * (int64_t)H * W : nullptr, llc + p * hw,
+        fwd_tile_job<T, TIn, MODE, FT, ZERO>(xc + p * (int64_t)H * W, TWO ? xu + p * (int64_t)H * W : nullptr, llc + p * hw,
                                              (PAIR && !ba.combine_ll) ? llu + p * hw : nullptr, hi + p * 3 * hw, W, h, w, y0,
                                              min(kFwdRows, h - y0), tp, ba, lds);
     }
@@ -366,11 +385,16 @@ struct SynthPair {
 
 // one synthesis tile: output rows [y0, y0 + th) (y0 even) of one plane.  pll / phi: the plane's approximation (row stride
 // ll_w) and detail bands; out / xsub / outf point at the plane's output.  FINAL = false: out (type T).  FINAL = true:
-// outf = xsub - (float)rec (or (float)rec), the cast + crop + `x - result` of py/wavelet_cfg.py:729-748.
-template <typename T, bool FINAL, int FT, typename TP>
+// outf = xsub - (float)rec (or (float)rec), the cast + crop + `x - result` of py/wavelet_cfg.py:729-748.  FINAL = 2 (difference-only
+// rules, kFwdDiff): rec is the synthesis of the scaled bands of cond - uncond and the result is ku * uncond + kt * rec.
+struct FinalMix {
+    const float* usub = nullptr;
+    double ku = 0.0, kt = 1.0;
+};
+template <typename T, int FINAL, int FT, typename TP>
 __device__ __forceinline__ void inv_tile_job(const T* __restrict__ pll, int ll_w, const T* __restrict__ phi, T* __restrict__ out,
                                              const float* __restrict__ xsub, float* __restrict__ outf, int h, int w, int Wo, int y0,
-                                             int th, const TP& tp, int mode, int subtract, T* tmp) {
+                                             int th, const TP& tp, int mode, int subtract, T* tmp, const FinalMix& mix = FinalMix{}) {
     const int hw = h * w, w2 = 2 * w;
     const int wp = (Wo + 1) >> 1;                                     // output pairs per row
     const int dq = kTileThreads / w, dr = kTileThreads - dq * w;     // pass 1 items: (row pair, column)
@@ -408,7 +432,11 @@ __device__ __forceinline__ void inv_tile_job(const T* __restrict__ pll, int ll_w
         SynthPair<T, FT>::run(m, w, mode, tp, [&](int i) { return lo_w[i]; }, [&](int i) { return hi_w[i]; }, e, o);
         const int at = obase + yl * Wo + 2 * m;
         const bool has_odd = 2 * m + 1 < Wo;
-        if constexpr (FINAL) {
+        if constexpr (FINAL != 0) {
+            if constexpr (FINAL == 2) {
+                e = fma_t((T)mix.ku, (T)mix.usub[at], (T)mix.kt * e);
+                if (has_odd) o = fma_t((T)mix.ku, (T)mix.usub[at + 1], (T)mix.kt * o);
+            }
             outf[at] = subtract ? xsub[at] - (float)e : (float)e;
             if (has_odd) outf[at + 1] = subtract ? xsub[at + 1] - (float)o : (float)o;
         } else {
@@ -424,21 +452,23 @@ __device__ __forceinline__ void inv_tile_job(const T* __restrict__ pll, int ll_w
     }
 }
 
-template <typename T, bool FINAL, int FT>
+template <typename T, int FINAL, int FT>
 __global__ void __launch_bounds__(kTileThreads) idwt2_tile_kernel(const T* __restrict__ ll, int ll_h, int ll_w,
                                                                   const T* __restrict__ hi, T* __restrict__ out,
                                                                   const float* __restrict__ xsub, float* __restrict__ outf,
                                                                   int64_t planes, int h, int w, int Ho, int Wo, int tiles, Taps<T> tp,
-                                                                  int mode, int subtract) {
+                                                                  int mode, int subtract, FinalMix mix) {
     extern __shared__ __align__(16) unsigned char tile_smem[];
     T* const tmp = reinterpret_cast<T*>(tile_smem);  // [kInvRows][lo_w | hi_w]
     const int64_t hw = (int64_t)h * w, ohw = (int64_t)Ho * Wo;
     for (int64_t job = blockIdx.x; job < planes * tiles; job += gridDim.x) {
         const int64_t p = job / tiles;
         const int y0 = (int)(job - p * tiles) * kInvRows;  // even
+        FinalMix m = mix;
+        if constexpr (FINAL == 2) m.usub += p * ohw;
         inv_tile_job<T, FINAL, FT>(ll + p * (int64_t)ll_h * ll_w, ll_w, hi + p * 3 * hw, FINAL ? nullptr : out + p * ohw,
                                    (FINAL && xsub) ? xsub + p * ohw : nullptr, FINAL ? outf + p * ohw : nullptr, h, w, Wo, y0,
-                                   min(kInvRows, Ho - y0), tp, mode, subtract, tmp);
+                                   min(kInvRows, Ho - y0), tp, mode, subtract, tmp, m);
     }
 }
 
@@ -468,7 +498,7 @@ struct DeepArgs {
     TapsSmall<T> dec, rec;
 };
 
-template <typename T, int FT, bool ZERO>
+template <typename T, int FT, bool ZERO, bool DIFF>
 __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepArgs<T> a) {
     extern __shared__ __align__(16) unsigned char tile_smem[];
     for (int64_t p = blockIdx.x; p < a.planes; p += gridDim.x) {
@@ -476,7 +506,7 @@ __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepAr
         for (int k = 1; k <= a.levels; ++k) {
             const int H = a.H[k - 1], W = a.W[k - 1], h = a.H[k], w = a.W[k];
             const int frows = a.fwd_rows[k];
-            const FwdLds<T, 4, FT> lds(tile_smem, W, w, frows);
+            const FwdLds<T, DIFF ? 2 : 4, FT> lds(tile_smem, W, w, frows);
             __syncthreads();
             fwd_build_maps<FT>(lds.xmap, lds.ymap, H, W, h, w, lds.Wh, a.mode_fwd);
             BandArgs<T> ba;
@@ -496,12 +526,12 @@ __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepAr
             ba.strength = a.strength;
             const int64_t in_plane = (int64_t)H * W, hw = (int64_t)h * w;
             const T* pc = base + (k == 1 ? a.off_in_c : a.off_c[k - 1]) + p * in_plane;
-            const T* pu = base + (k == 1 ? a.off_in_u : a.off_u[k - 1]) + p * in_plane;
+            const T* pu = DIFF ? nullptr : base + (k == 1 ? a.off_in_u : a.off_u[k - 1]) + p * in_plane;
             T* oc = base + a.off_c[k] + p * hw;
-            T* ou = ba.combine_ll ? nullptr : base + a.off_u[k] + p * hw;
+            T* ou = (DIFF || ba.combine_ll) ? nullptr : base + a.off_u[k] + p * hw;
             T* od = base + a.off_d[k] + p * 3 * hw;
             for (int y0 = 0; y0 < h; y0 += frows)
-                fwd_tile_job<T, T, true, FT, ZERO, TapsSmall<T>, true>(pc, pu, oc, ou, od, W, h, w, y0, min(frows, h - y0), a.dec, ba, lds);
+                fwd_tile_job<T, T, DIFF ? kFwdScale : kFwdPair, FT, ZERO, TapsSmall<T>, true>(pc, pu, oc, ou, od, W, h, w, y0, min(frows, h - y0), a.dec, ba, lds);
             // the workgroup re-reads what it just stored: workgroup scope is enough (one CU, one L1); a device-scope fence
             // would write back / invalidate L2 once per level per plane
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -516,7 +546,7 @@ __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepAr
             const T* d = base + a.off_d[k] + p * 3 * (int64_t)h * w;
             T* r = base + a.off_r[k] + p * (int64_t)Ho * Wo;
             for (int y0 = 0; y0 < Ho; y0 += a.inv_rows[k])
-                inv_tile_job<T, false, FT>(ll, ll_w, d, r, nullptr, nullptr, h, w, Wo, y0, min(a.inv_rows[k], Ho - y0), a.rec, a.mode_inv, 0, tmp);
+                inv_tile_job<T, 0, FT>(ll, ll_w, d, r, nullptr, nullptr, h, w, Wo, y0, min(a.inv_rows[k], Ho - y0), a.rec, a.mode_inv, 0, tmp);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __syncthreads();
             ll = r;
@@ -549,10 +579,10 @@ static bool dwt2_fwd_tiled(const T* x, T* ll, T* hi, int64_t planes, int H, int 
     with_taps(tp.len, [&](auto ft) {
         constexpr int FT = decltype(ft)::value;
         if (mode == kZero)
-            hipLaunchKernelGGL((dwt2_tile_kernel<T, T, false, FT, true>), dim3(tile_grid(planes * tiles)), dim3(kTileThreads), lds, st, x,
+            hipLaunchKernelGGL((dwt2_tile_kernel<T, T, kFwdPlain, FT, true>), dim3(tile_grid(planes * tiles)), dim3(kTileThreads), lds, st, x,
                                (const T*)nullptr, ll, (T*)nullptr, hi, planes, H, W, h, w, tiles, tp, mode, BandArgs<T>{});
         else
-            hipLaunchKernelGGL((dwt2_tile_kernel<T, T, false, FT, false>), dim3(tile_grid(planes * tiles)), dim3(kTileThreads), lds, st, x,
+            hipLaunchKernelGGL((dwt2_tile_kernel<T, T, kFwdPlain, FT, false>), dim3(tile_grid(planes * tiles)), dim3(kTileThreads), lds, st, x,
                                (const T*)nullptr, ll, (T*)nullptr, hi, planes, H, W, h, w, tiles, tp, mode, BandArgs<T>{});
     });
     return true;
@@ -566,8 +596,8 @@ static bool dwt2_inv_tiled(const T* ll, int ll_h, int ll_w, const T* hi, T* out,
     if (lds > kTileLdsLimit) return false;
     const int tiles = (Ho + kInvRows - 1) / kInvRows;
     with_taps(tp.len, [&](auto ft) {
-        hipLaunchKernelGGL((idwt2_tile_kernel<T, false, decltype(ft)::value>), dim3(tile_grid(planes * tiles)), dim3(kTileThreads), lds, st,
-                           ll, ll_h, ll_w, hi, out, (const float*)nullptr, (float*)nullptr, planes, h, w, Ho, Wo, tiles, tp, mode, 0);
+        hipLaunchKernelGGL((idwt2_tile_kernel<T, 0, decltype(ft)::value>), dim3(tile_grid(planes * tiles)), dim3(kTileThreads), lds, st,
+                           ll, ll_h, ll_w, hi, out, (const float*)nullptr, (float*)nullptr, planes, h, w, Ho, Wo, tiles, tp, mode, 0, FinalMix{});
     });
     return true;
 }
@@ -582,7 +612,7 @@ struct WcfgPlan {
 };
 
 static inline bool wcfg_plan(WcfgPlan& pl, int64_t planes, int64_t H, int64_t W, int levels, int dec_len, int mode_fwd, int rec_len,
-                             int mode_inv) {
+                             int mode_inv, bool diff_only = false) {
     if (levels < 1 || levels > kMaxLevels) return false;
     pl.levels = levels;
     pl.H[0] = (int)H;
@@ -597,7 +627,7 @@ static inline bool wcfg_plan(WcfgPlan& pl, int64_t planes, int64_t H, int64_t W,
         const int64_t n = planes * pl.H[j] * pl.W[j];
         pl.off_d[j] = at; at += 3 * n;
         pl.off_c[j] = at; at += n;
-        pl.off_u[j] = at; at += (j < levels ? n : 0);
+        pl.off_u[j] = at; at += (j < levels && !diff_only ? n : 0);
         pl.off_r[j] = at; at += (j > 1 ? planes * (int64_t)pl.Hr[j] * pl.Wr[j] : 0);
     }
     pl.total = at;
@@ -609,7 +639,7 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
                       int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd, const double* rec_lo,
                       const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,
                       int blend_mode, double strength, int subtract_from_x, void* ws, int64_t ws_bytes, hipStream_t st,
-                      const char* what) {
+                      const char* what, bool perfect_reconstruction = false) {
     SONAR_REQUIRE(cond && uncond && out && (x || !subtract_from_x) && ws && yl_scales && yh_scales && planes >= 0 && mode_fwd >= 0 &&
                       mode_fwd <= 5 && mode_inv >= 0 && mode_inv <= 5 && blend_mode >= 0 && blend_mode <= 2,
                   SONAR_ERR_ARG, "%s: bad argument", what);
@@ -618,8 +648,24 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
     SONAR_REQUIRE(make_taps(dec, dec_lo, dec_hi, dec_len) && make_taps(rec, rec_lo, rec_hi, rec_len), SONAR_ERR_ARG,
                   "%s: 1..%d filter taps required", what, kMaxTaps);
     SONAR_REQUIRE(tile_taps_ok(dec_len) && tile_taps_ok(rec_len), SONAR_ERR_UNSUPPORTED, "%s: even filter lengths 2..20 only", what);
+    // difference-only rule over a perfect-reconstruction pair (the caller vouches for the pair: one wavelet both ways): every cond /
+    // uncond / final scale is 1, the blend is linear in (uncond band, difference band), so
+    //   IDWT(blend(U, D (C - U), t)) = ku u + kt IDWT(D DWT(c - u))
+    // and ONE tensor is transformed instead of two (py/wavelet_cfg.py:765-787 with the identities of csrc/dwt_lowpass.h)
+    bool diff_only = perfect_reconstruction && levels >= 1;
+    for (int i = 0; diff_only && i < 4; ++i)
+        if (i != 2 && yl_scales[i] != 1.0) diff_only = false;
+    for (int j = 0; diff_only && j < levels; ++j)
+        for (int i = 0; i < 12; ++i)
+            if (i / 3 != 2 && yh_scales[(int64_t)j * 12 + i] != 1.0) diff_only = false;
+    FinalMix mix;
+    if (diff_only) {
+        mix.usub = uncond;
+        mix.ku = blend_mode == SONAR_BLEND_LERP ? 1.0 - strength : 1.0;
+        mix.kt = blend_mode == SONAR_BLEND_SUBTRACT_B ? -strength : strength;
+    }
     WcfgPlan pl;
-    SONAR_REQUIRE(wcfg_plan(pl, planes, H, W, levels, dec_len, mode_fwd, rec_len, mode_inv), SONAR_ERR_UNSUPPORTED,
+    SONAR_REQUIRE(wcfg_plan(pl, planes, H, W, levels, dec_len, mode_fwd, rec_len, mode_inv, diff_only), SONAR_ERR_UNSUPPORTED,
                   "%s: 1..%d levels and an inverse filter that covers every level are required", what, kMaxLevels);
     SONAR_REQUIRE(ws_bytes >= pl.total * (int64_t)sizeof(T), SONAR_ERR_ARG, "%s: workspace too small (%lld < %lld bytes)", what,
                   (long long)ws_bytes, (long long)(pl.total * (int64_t)sizeof(T)));
@@ -627,7 +673,7 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
     T* base = (T*)ws;
     // every level must fit its tile in LDS (checked before the first launch so a refusal has no side effects)
     for (int j = 1; j <= levels; ++j)
-        SONAR_REQUIRE(fwd_lds_bytes(pl.W[j - 1], pl.H[j], pl.W[j], dec_len, sizeof(T), 2) <= kTileLdsLimit &&
+        SONAR_REQUIRE(fwd_lds_bytes(pl.W[j - 1], pl.H[j], pl.W[j], dec_len, sizeof(T), diff_only ? 1 : 2) <= kTileLdsLimit &&
                           inv_lds_bytes(pl.W[j], sizeof(T)) <= kTileLdsLimit,
                       SONAR_ERR_UNSUPPORTED, "%s: level %d (%d x %d) does not fit the LDS tile", what, j, pl.H[j], pl.W[j]);
     auto band_args = [&](int j) {
@@ -652,7 +698,8 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
     const bool deep = levels >= 3 && dec_len == rec_len && levels - 1 <= kDeepMaxLevels && dec_len <= kDeepTaps;
     auto launch_fwd = [&](int j) {
         const int tiles = (pl.H[j] + kFwdRows - 1) / kFwdRows;
-        const size_t lds = fwd_lds_bytes(pl.W[j - 1], pl.H[j], pl.W[j], dec_len, sizeof(T), 2);
+        const int nten = diff_only ? 1 : 2;
+        const size_t lds = fwd_lds_bytes(pl.W[j - 1], pl.H[j], pl.W[j], dec_len, sizeof(T), nten);
         const dim3 grid(tile_grid(planes * tiles)), blk(kTileThreads);
         T* d = base + pl.off_d[j];
         T* c = base + pl.off_c[j];
@@ -662,11 +709,18 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
             constexpr int FT = decltype(ft)::value;
             auto go = [&](auto zero) {
                 constexpr bool Z = decltype(zero)::value;
-                if (j == 1)
-                    hipLaunchKernelGGL((dwt2_tile_kernel<T, float, true, FT, Z>), grid, blk, lds, st, cond, uncond, c, u, d, planes,
+                if (diff_only && j == 1)
+                    hipLaunchKernelGGL((dwt2_tile_kernel<T, float, kFwdDiff, FT, Z>), grid, blk, lds, st, cond, uncond, c, (T*)nullptr, d,
+                                       planes, pl.H[0], pl.W[0], pl.H[1], pl.W[1], tiles, dec, mode_fwd, ba);
+                else if (diff_only)
+                    hipLaunchKernelGGL((dwt2_tile_kernel<T, T, kFwdScale, FT, Z>), grid, blk, lds, st, (const T*)(base + pl.off_c[j - 1]),
+                                       (const T*)nullptr, c, (T*)nullptr, d, planes, pl.H[j - 1], pl.W[j - 1], pl.H[j], pl.W[j], tiles, dec,
+                                       mode_fwd, ba);
+                else if (j == 1)
+                    hipLaunchKernelGGL((dwt2_tile_kernel<T, float, kFwdPair, FT, Z>), grid, blk, lds, st, cond, uncond, c, u, d, planes,
                                        pl.H[0], pl.W[0], pl.H[1], pl.W[1], tiles, dec, mode_fwd, ba);
                 else
-                    hipLaunchKernelGGL((dwt2_tile_kernel<T, T, true, FT, Z>), grid, blk, lds, st, (const T*)(base + pl.off_c[j - 1]),
+                    hipLaunchKernelGGL((dwt2_tile_kernel<T, T, kFwdPair, FT, Z>), grid, blk, lds, st, (const T*)(base + pl.off_c[j - 1]),
                                        (const T*)(base + pl.off_u[j - 1]), c, u, d, planes, pl.H[j - 1], pl.W[j - 1], pl.H[j], pl.W[j],
                                        tiles, dec, mode_fwd, ba);
             };
@@ -685,16 +739,20 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
         if (j > 1) {
             T* r = base + pl.off_r[j];
             with_taps(rec_len, [&](auto ft) {
-                hipLaunchKernelGGL((idwt2_tile_kernel<T, false, decltype(ft)::value>), grid, blk, lds, st, ll, ll_h, ll_w, d, r,
-                                   (const float*)nullptr, (float*)nullptr, planes, pl.H[j], pl.W[j], Ho, Wo, tiles, rec, mode_inv, 0);
+                hipLaunchKernelGGL((idwt2_tile_kernel<T, 0, decltype(ft)::value>), grid, blk, lds, st, ll, ll_h, ll_w, d, r,
+                                   (const float*)nullptr, (float*)nullptr, planes, pl.H[j], pl.W[j], Ho, Wo, tiles, rec, mode_inv, 0, FinalMix{});
             });
             ll = r;
             ll_h = Ho;
             ll_w = Wo;
         } else {
             with_taps(rec_len, [&](auto ft) {
-                hipLaunchKernelGGL((idwt2_tile_kernel<T, true, decltype(ft)::value>), grid, blk, lds, st, ll, ll_h, ll_w, d, (T*)nullptr, x,
-                                   out, planes, pl.H[j], pl.W[j], Ho, Wo, tiles, rec, mode_inv, subtract_from_x);
+                if (diff_only)
+                    hipLaunchKernelGGL((idwt2_tile_kernel<T, 2, decltype(ft)::value>), grid, blk, lds, st, ll, ll_h, ll_w, d, (T*)nullptr, x,
+                                       out, planes, pl.H[j], pl.W[j], Ho, Wo, tiles, rec, mode_inv, subtract_from_x, mix);
+                else
+                    hipLaunchKernelGGL((idwt2_tile_kernel<T, 1, decltype(ft)::value>), grid, blk, lds, st, ll, ll_h, ll_w, d, (T*)nullptr, x,
+                                       out, planes, pl.H[j], pl.W[j], Ho, Wo, tiles, rec, mode_inv, subtract_from_x, FinalMix{});
             });
         }
     };
@@ -727,11 +785,11 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
             // and a job of 8 x 37 outputs leaves half the lanes of its second sweep idle
             constexpr size_t kDeepLdsBudget = 39 * 1024;  // four workgroups per CU
             int fr = kFwdRows, ir = kInvRows;
-            while (fr < a.H[k] && fwd_lds_bytes(a.W[k - 1], a.H[k], a.W[k], dec_len, sizeof(T), 2, fr + kFwdRows) <= kDeepLdsBudget) fr += kFwdRows;
+            while (fr < a.H[k] && fwd_lds_bytes(a.W[k - 1], a.H[k], a.W[k], dec_len, sizeof(T), diff_only ? 1 : 2, fr + kFwdRows) <= kDeepLdsBudget) fr += kFwdRows;
             while (ir < a.Hr[k] && inv_lds_bytes(a.W[k], sizeof(T), ir + kInvRows) <= kDeepLdsBudget) ir += kInvRows;
             a.fwd_rows[k] = fr;
             a.inv_rows[k] = ir;
-            lds = std::max(lds, std::max(fwd_lds_bytes(a.W[k - 1], a.H[k], a.W[k], dec_len, sizeof(T), 2, fr), inv_lds_bytes(a.W[k], sizeof(T), ir)));
+            lds = std::max(lds, std::max(fwd_lds_bytes(a.W[k - 1], a.H[k], a.W[k], dec_len, sizeof(T), diff_only ? 1 : 2, fr), inv_lds_bytes(a.W[k], sizeof(T), ir)));
         }
         a.ll_scales[0] = (T)yl_scales[0];
         a.ll_scales[1] = (T)yl_scales[1];
@@ -749,12 +807,16 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
         }
         with_taps(dec_len, [&](auto ft) {
             // zero extension is the only mode with "no source" positions: the others skip its per-tap selects (the kernel is VALU-bound)
-            if (mode_fwd == kZero)
-                hipLaunchKernelGGL((wcfg_deep_kernel<T, decltype(ft)::value, true>), dim3((int)std::min<int64_t>(planes, 1 << 20)),
-                                   dim3(kTileThreads), lds, st, base, a);
+            constexpr int FT = decltype(ft)::value;
+            const dim3 grid((int)std::min<int64_t>(planes, 1 << 20)), blk(kTileThreads);
+            if (mode_fwd == kZero && diff_only)
+                hipLaunchKernelGGL((wcfg_deep_kernel<T, FT, true, true>), grid, blk, lds, st, base, a);
+            else if (mode_fwd == kZero)
+                hipLaunchKernelGGL((wcfg_deep_kernel<T, FT, true, false>), grid, blk, lds, st, base, a);
+            else if (diff_only)
+                hipLaunchKernelGGL((wcfg_deep_kernel<T, FT, false, true>), grid, blk, lds, st, base, a);
             else
-                hipLaunchKernelGGL((wcfg_deep_kernel<T, decltype(ft)::value, false>), dim3((int)std::min<int64_t>(planes, 1 << 20)),
-                                   dim3(kTileThreads), lds, st, base, a);
+                hipLaunchKernelGGL((wcfg_deep_kernel<T, FT, false, false>), grid, blk, lds, st, base, a);
         });
         ll = base + pl.off_r[2];  // what the deep kernel reconstructed for level 1
         ll_h = pl.Hr[2];

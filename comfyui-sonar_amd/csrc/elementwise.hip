@@ -1225,6 +1225,54 @@ extern "C" int sonar_spectral_signum_mask_f32(float* z, const float* la, const f
     return check_launch("sonar_spectral_signum_mask_f32");
 }
 
+// torch.max semantics (a NaN anywhere gives NaN) over a small vector, written straight into host-visible pinned memory: one launch +
+// one stream wait replaces torch's reduce kernel, device-to-host copy and wait for WaveletCFG's `sigma.max().item()`
+// (py/wavelet_cfg.py:795-796).
+__global__ void __launch_bounds__(kBlock) max_to_host_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ host_out) {
+    __shared__ float part[kBlock / 64];
+    __shared__ int nan_part[kBlock / 64];
+    float m = -INFINITY;
+    int bad = 0;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+        const float v = x[i];
+        bad |= v != v;
+        m = fmaxf(m, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off));
+        bad |= __shfl_xor(bad, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6] = m;
+        nan_part[threadIdx.x >> 6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            m = fmaxf(m, part[w]);
+            bad |= nan_part[w];
+        }
+        *host_out = bad ? NAN : m;
+        __threadfence_system();
+    }
+}
+
+extern "C" int sonar_max_to_host_f32(const float* x, int64_t n, float* result, void* stream) {
+    SONAR_REQUIRE(x && result && n >= 1, SONAR_ERR_ARG, "sonar_max_to_host_f32: bad argument (a non-empty device vector is required)");
+    static thread_local float* slot[64] = {};
+    int dev = 0;
+    SONAR_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, SONAR_ERR_HIP, "sonar_max_to_host_f32: no current device");
+    if (!slot[dev])
+        SONAR_REQUIRE(hipHostMalloc((void**)&slot[dev], 64, hipHostMallocMapped) == hipSuccess, SONAR_ERR_HIP,
+                      "sonar_max_to_host_f32: pinned allocation failed");
+    hipLaunchKernelGGL(max_to_host_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, x, n, slot[dev]);
+    const int rc = check_launch("sonar_max_to_host_f32");
+    if (rc != SONAR_OK) return rc;
+    SONAR_REQUIRE(hipStreamSynchronize((hipStream_t)stream) == hipSuccess, SONAR_ERR_HIP, "sonar_max_to_host_f32: stream wait failed");
+    *result = *(volatile float*)slot[dev];
+    return SONAR_OK;
+}
+
 extern "C" int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,
                                   int64_t n, void* stream) {
     SONAR_REQUIRE(dst && src && mask && out && n >= 0 && mask_n > 0, SONAR_ERR_ARG, "sonar_mask_mix_f32: bad argument");

@@ -135,9 +135,10 @@ SIGNATURES = {
     "sonar_wcfg_lowpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_lowpass_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
+    "sonar_max_to_host_f32": (_I, [_P, _I64, C.POINTER(C.c_float), _P]),
     "sonar_wcfg_fused_ws_bytes": (_I64, [_I64, _I64, _I64, _I, _I, _I, _I, _I, _I]),
-    "sonar_wcfg_fused_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _P, _I64, _P]),
-    "sonar_wcfg_fused_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _P, _I64, _P]),
+    "sonar_wcfg_fused_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _I, _P, _I64, _P]),
+    "sonar_wcfg_fused_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _I, _P, _I64, _P]),
     "sonar_cast_f32_f64": (_I, [_P, _P, _I64, _P]),
 }
 
@@ -995,10 +996,22 @@ def _taps_arr(vals):
     return hit
 
 
+_MAX_SLOT = C.c_float()
+
+
+def max_to_host(x: torch.Tensor) -> float:
+    """``x.max().item()`` for a non-empty fp32 device tensor (NaN if any element is NaN) in one launch and one stream wait."""
+    x = x.contiguous()
+    _check(load().sonar_max_to_host_f32(_dev(x, "x"), x.numel(), C.byref(_MAX_SLOT), _stream()), "sonar_max_to_host_f32")
+    return _MAX_SLOT.value
+
+
 def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], *, levels: int, dec_lo, dec_hi, mode: str, rec_lo, rec_hi,
-               inv_mode: str, yl_scales, yh_scales, blend_mode: str, strength: float, subtract_from_x: bool, high_precision: bool):
+               inv_mode: str, yl_scales, yh_scales, blend_mode: str, strength: float, subtract_from_x: bool, high_precision: bool,
+               perfect_reconstruction: bool = False):
     """WaveletCFG's transform-domain step for fp32 [B, C, H, W] cond / uncond (and x) in 2 * levels launches; returns the
-    fp32 output, or None when a level does not fit the LDS tile (caller uses the per-pass kernels)."""
+    fp32 output, or None when a level does not fit the LDS tile (caller uses the per-pass kernels).  ``perfect_reconstruction``:
+    the analysis / synthesis pair is one wavelet both ways, which lets difference-only rules transform cond - uncond alone."""
     B, Cc, H, W = cond.shape
     planes = B * Cc
     lib = load()
@@ -1023,7 +1036,7 @@ def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tenso
     rc = fn(_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), planes, H, W, levels, _taps_arr(dec_lo), _taps_arr(dec_hi),
             len(dec_lo), DWT_MODE_IDS[mode], _taps_arr(rec_lo), _taps_arr(rec_hi), len(rec_lo), DWT_MODE_IDS[inv_mode],
             _darr([float(v) for v in yl_scales]), _darr(flat), BLEND_IDS[blend_mode], float(strength), int(bool(subtract_from_x)),
-            ws.data_ptr(), ws.numel(), stream)
+            int(bool(perfect_reconstruction)), ws.data_ptr(), ws.numel(), stream)
     if rc == ERR_UNSUPPORTED:
         return None
     _check(rc, "sonar_wcfg_fused")

@@ -590,6 +590,12 @@ def _per_latent(t: torch.Tensor, sigma: torch.Tensor, *, divide: bool) -> torch.
     return hip_lib.row_affine(0 if divide else 1, utils.as_f32(t).contiguous(), rows, t.numel() // max(rows, 1), zero, s)
 
 
+def _reconstructs(w) -> bool:
+    """IDWT(DWT(t)) == t needs the analysis and synthesis banks of ONE wavelet (dmey is only approximately a wavelet); every pywt
+    extension mode reconstructs, also with a different mode on the way back (the valid region never sees the extension)."""
+    return getattr(w, "wave", None) is not None and w.wave == w.inv_wave and w.wave != "dmey" and len(w.dec_lo) == len(w.rec_lo)
+
+
 class WaveletCFG:
     """py/wavelet_cfg.py:626-842 — a ComfyUI ``sampler_cfg_function``."""
 
@@ -678,7 +684,8 @@ class WaveletCFG:
             ctx.cond.contiguous(), ctx.uncond.contiguous(), ctx.x.contiguous(), levels=levels, dec_lo=w.dec_lo, dec_hi=w.dec_hi, mode=w.mode,
             rec_lo=w.rec_lo, rec_hi=w.rec_hi, inv_mode=w.inv_mode, yl_scales=[tabs[n][0] for n in names],
             yh_scales=[[row(n, j) for n in names] for j in range(levels)], blend_mode=rule.difference_blend_mode,
-            strength=rule.difference_blend_strength.get_value(pcts), subtract_from_x=True, high_precision=ctx.dtype == torch.float64)
+            strength=rule.difference_blend_strength.get_value(pcts), subtract_from_x=True, high_precision=ctx.dtype == torch.float64,
+            perfect_reconstruction=_reconstructs(w))
 
     @classmethod
     def wavelet_cfg_lowpass(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts) -> Optional[torch.Tensor]:
@@ -689,8 +696,8 @@ class WaveletCFG:
         if ctx.cond.ndim != 4 or ctx.cond.dtype != torch.float32 or ctx.uncond.dtype != torch.float32 or ctx.dtype not in (torch.float32, torch.float64):
             return None
         levels = w.level
-        if levels < 1 or getattr(w, "wave", None) is None or w.wave != w.inv_wave or w.wave == "dmey" or len(w.dec_lo) != len(w.rec_lo):
-            return None  # perfect reconstruction needs the analysis and synthesis banks of one wavelet
+        if levels < 1 or not _reconstructs(w):
+            return None
         static = _rule_is_static(rule)
         hit = _LOWPASS_ARGS.get(id(rule)) if static else None
         if hit is not None and hit[0] is rule:
@@ -785,7 +792,8 @@ class WaveletCFG:
     def __call__(self, args: dict) -> torch.Tensor:
         """py/wavelet_cfg.py:793-842."""
         sigma = args["sigma"]
-        sigma_f = sigma.max().item()
+        # `sigma.max().item()`: one launch into pinned memory when sigma is an fp32 device tensor (the sampler's case)
+        sigma_f = hip_lib.max_to_host(sigma) if sigma.is_cuda and sigma.dtype == torch.float32 and sigma.numel() > 0 else sigma.max().item()
         rule = self.rules.get_rule(sigma_f)
         if rule is None:
             return self.fallback_cfg_function(args)

@@ -378,17 +378,27 @@ int sonar_wcfg_band_head_f64(const double* cond, const double* uncond, double* o
  * one writes out = x - result (subtract_from_x) or result, cropped to H x W, as fp32.  _f32 / _f64 = arithmetic type
  * (high_precision_mode).  yl_scales[4] = {cond, uncond, diff, final}; yh_scales[levels][4][3] = the same per level
  * (finest first) and orientation (cH, cV, cD).  ws: sonar_wcfg_fused_ws_bytes(...) bytes; returns
- * SONAR_ERR_UNSUPPORTED (nothing launched) when a level does not fit the LDS tile. */
+ * SONAR_ERR_UNSUPPORTED (nothing launched) when a level does not fit the LDS tile.
+ * perfect_reconstruction != 0: the caller vouches that (dec, mode_fwd) / (rec, mode_inv) reconstruct exactly (one wavelet both
+ * ways).  Rules that then only scale the difference bands (every cond / uncond / final scale 1, any per-level, per-orientation
+ * diff scales) take the single-tensor route: IDWT(blend(U, D (C - U), t)) = ku u + kt IDWT(D DWT(c - u)) -- c - u is formed on
+ * load, ONE transform runs instead of two, and the last synthesis adds ku * uncond. */
 int64_t sonar_wcfg_fused_ws_bytes(int64_t planes, int64_t H, int64_t W, int levels, int dec_len, int mode_fwd, int rec_len,
                                   int mode_inv, int elem_size);
 int sonar_wcfg_fused_f32(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H, int64_t W,
                          int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd, const double* rec_lo,
                          const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,
-                         int blend_mode, double strength, int subtract_from_x, void* ws, int64_t ws_bytes, void* stream);
+                         int blend_mode, double strength, int subtract_from_x, int perfect_reconstruction, void* ws, int64_t ws_bytes,
+                         void* stream);
 int sonar_wcfg_fused_f64(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H, int64_t W,
                          int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd, const double* rec_lo,
                          const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,
-                         int blend_mode, double strength, int subtract_from_x, void* ws, int64_t ws_bytes, void* stream);
+                         int blend_mode, double strength, int subtract_from_x, int perfect_reconstruction, void* ws, int64_t ws_bytes,
+                         void* stream);
+/* max over a non-empty device vector with torch.max's NaN rule, returned to the host: WaveletCFG's `sigma.max().item()`
+ * (py/wavelet_cfg.py:795-796) as one launch that writes into pinned host memory + one stream wait.  BLOCKS until the stream drains
+ * (as `.item()` does). */
+int sonar_max_to_host_f32(const float* x, int64_t n, float* result, void* stream);
 /* WaveletCFG for difference-only rules with ONE detail scale per level (py/wavelet_cfg.py:750-791 with `cond` / `uncond` / `final`
  * absent; the node's placeholder rule, BASELINE cfg4).  By linearity and perfect reconstruction
  *   IDWT(blend(DWT u, D (DWT c - DWT u), t)) = ku u + kt (g[0] v + Up_1(g[1] LL_1 + Up_2(... g[J] LL_J))),  v = c - u,

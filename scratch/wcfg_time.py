@@ -21,21 +21,17 @@ def timed(fn, n=30):
 real_low = wc.WaveletCFG.wavelet_cfg_lowpass
 for hp in (True, False):
     fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0), high_precision_mode=hp))
-    for path in ("lowpass", "bands"):
+    real_pr = wc._reconstructs
+    for path in ("lowpass", "diff", "pair"):
         wc.WaveletCFG.wavelet_cfg_lowpass = real_low if path == "lowpass" else classmethod(lambda cls, **_k: None)
+        wc._reconstructs = (lambda w: False) if path == "pair" else real_pr
         wall, ev = timed(lambda: fn(args))
         print(f"{'fp64' if hp else 'fp32'} {path:8s} wall {wall:7.1f} us  events {ev:7.1f} us  -> {16 * 4 * 128 * 128 * b / ev / 1e3:7.1f} GB/s at 16N", flush=True)
     wc.WaveletCFG.wavelet_cfg_lowpass = real_low
+    wc._reconstructs = real_pr
     w = fn.rules[0].make_wavelet()
     g = [3.0, 0, 0, 0, 0, 2.0]
     wall, ev = timed(lambda: hl.wcfg_lowpass(cond, uncond, x, levels=5, dec_lo=w.dec_lo, rec_lo=w.rec_lo, mode="symmetric", inv_mode="symmetric", g=g, ku=1.0, kt=1.0,
                                              subtract_from_x=True, high_precision=hp))
     print(f"{'fp64' if hp else 'fp32'} kernel   wall {wall:7.1f} us  events {ev:7.1f} us", flush=True)
 
-import cProfile, pstats
-fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0)))
-for _ in range(5): fn(args)
-pr = cProfile.Profile(); pr.enable()
-for _ in range(100): fn(args)
-pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)

@@ -6,6 +6,7 @@ Tolerance: fp64 path 1e-11 (same arithmetic, different summation order); fp32 pa
 O(1) data (taps rounded to fp32, 8-tap dot products over up to 5 levels).  WaveletCFG outputs: absolute, relative to the
 output's peak (the placeholder rule scales the approximation band by 5 and the detail bands by 3, so outputs reach O(20) and
 the fp32 transform's 2e-5-class error grows with them): 2e-6 x peak for fp64 rules, 5e-5 x peak for fp32 rules."""
+import math
 import importlib
 import types
 
@@ -264,6 +265,56 @@ def test_lowpass_path_equals_band_path(api, monkeypatch, wave, mode, level, shap
         assert calls, "the low-pass entry point was not used"
         with monkeypatch.context() as m:
             m.setattr(api.wc.WaveletCFG, "wavelet_cfg_lowpass", classmethod(lambda cls, **_k: None))
+            m.setattr(api.wc, "_reconstructs", lambda w: False)  # cond and uncond both transformed (the general route)
             bands = fn(args)
         peak = float(bands.abs().max())
         torch.testing.assert_close(low, bands, rtol=0, atol=(3e-7 if high_precision else 5e-5) * max(1.0, peak))
+
+
+@pytest.mark.parametrize("high_precision", [True, False])
+@pytest.mark.parametrize("wave,mode,level,shape", [
+    ("haar", "zero", 3, (2, 3, 40, 56)), ("db2", "symmetric", 4, (1, 4, 37, 50)), ("db4", "reflect", 3, (2, 2, 64, 48)),
+    ("sym5", "periodization", 2, (1, 4, 50, 38)), ("coif2", "periodic", 2, (1, 2, 72, 64)), ("db8", "constant", 2, (1, 2, 96, 80)),
+    ("bior2.2", "symmetric", 3, (1, 4, 33, 47)), ("db10", "symmetric", 1, (1, 2, 64, 64)), ("db4", "symmetric", 5, (2, 4, 128, 128)),
+    ("db4", "zero", 5, (1, 4, 128, 128))])
+def test_difference_route_equals_pair_route(api, monkeypatch, wave, mode, level, shape, high_precision):
+    """Difference-only rules with per-orientation scales: ``sonar_wcfg_fused_*`` transforms cond - uncond alone when the wavelet pair
+    reconstructs (perfect_reconstruction = 1) and must agree with the route that transforms cond and uncond side by side."""
+    torch.manual_seed(11)
+    cond, uncond, x = (torch.randn(shape, device="cuda") for _ in range(3))
+    args = {"input": x, "cond_scale": 7.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
+            "sigma": torch.full((shape[0],), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
+    for blend, strength in (("inject", 1.0), ("lerp", 0.35), ("subtract_b", 0.6)):
+        params = dict(difference=dict(yl_scale=0.75, yh_scales=[[3.0, 1.0, 0.5], 0.5, "fill", [1.5, 2.0, 0.25]][: level + 1]), wave=wave, level=level,
+                      padding_mode=mode, high_precision_mode=high_precision, difference_blend_mode=blend, difference_blend_strength=strength)
+        fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
+        seen = []
+        real = api.hl.wcfg_fused
+        with monkeypatch.context() as m:
+            m.setattr(api.hl, "wcfg_fused", lambda *a, **k: seen.append(k.get("perfect_reconstruction")) or real(*a, **k))
+            single = fn(args)
+        assert seen == [True], "the fused entry point was not used with the reconstruction flag"
+        with monkeypatch.context() as m:
+            m.setattr(api.wc, "_reconstructs", lambda w: False)
+            pair = fn(args)
+        peak = float(pair.abs().max())
+        torch.testing.assert_close(single, pair, rtol=0, atol=(3e-7 if high_precision else 5e-5) * max(1.0, peak))
+
+
+def test_max_to_host_matches_torch(api):
+    """``sonar_max_to_host_f32`` == ``sigma.max().item()`` (py/wavelet_cfg.py:795-796), NaN rule included, on a side stream too."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n in (1, 2, 63, 64, 65, 256, 1000, 70001):
+        t = torch.randn(n, device="cuda", generator=g) * 50
+        assert api.hl.max_to_host(t) == t.max().item()
+    t = torch.randn(4, 1, 1, 1, device="cuda", generator=g)
+    assert api.hl.max_to_host(t) == t.max().item()
+    t = torch.full((300,), -float("inf"), device="cuda")
+    assert api.hl.max_to_host(t) == -float("inf")
+    t = torch.randn(500, device="cuda", generator=g)
+    t[321] = float("nan")
+    assert math.isnan(api.hl.max_to_host(t)) and math.isnan(t.max().item())
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        t = torch.arange(1000, device="cuda", dtype=torch.float32)
+        assert api.hl.max_to_host(t) == 999.0
