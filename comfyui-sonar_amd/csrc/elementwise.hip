@@ -355,6 +355,22 @@ __global__ void __launch_bounds__(kBlock) row_affine_kernel(int op, const float*
     }
 }
 
+// normalize_to_scale's tail (py/utils.py:462-469): ((x - lo) / ((hi - lo) + eps)) * (tmax - tmin) + tmin, clamped; each step rounded
+// on its own as the reference's in-place tensor ops are
+__global__ void __launch_bounds__(kBlock) minmax_rescale_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
+                                                                 const float* __restrict__ lo, const float* __restrict__ hi, float eps,
+                                                                 float tmin, float tmax, float* out) {
+    const int64_t total = rows * inner;
+    const float span = __fsub_rn(tmax, tmin);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / inner;
+        const float denom = __fadd_rn(__fsub_rn(hi[r], lo[r]), eps);
+        float v = __fsub_rn(x[i], lo[r]) / denom;
+        v = __fadd_rn(__fmul_rn(v, span), tmin);
+        out[i] = v != v ? v : fminf(fmaxf(v, tmin), tmax);  // clamp_ keeps NaN
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) amax_mid_kernel(const float* __restrict__ x, int64_t outer, int64_t mid,
                                                            int64_t inner, int use_abs, float* peak) {
     const int64_t total = outer * inner;
@@ -1094,6 +1110,15 @@ extern "C" int sonar_row_affine_f32(int op, const float* x, int64_t rows, int64_
     hipLaunchKernelGGL(row_affine_kernel, dim3(grid_for(rows * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, op, x,
                        rows, inner, a, b, out);
     return check_launch("sonar_row_affine_f32");
+}
+
+extern "C" int sonar_minmax_rescale_f32(const float* x, int64_t rows, int64_t inner, const float* lo, const float* hi, float eps,
+                                        float target_min, float target_max, float* out, void* stream) {
+    SONAR_REQUIRE(x && lo && hi && out && rows >= 0 && inner > 0, SONAR_ERR_ARG, "sonar_minmax_rescale_f32: bad argument");
+    if (rows == 0) return SONAR_OK;
+    hipLaunchKernelGGL(minmax_rescale_kernel, dim3(grid_for(rows * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x, rows,
+                       inner, lo, hi, eps, target_min, target_max, out);
+    return check_launch("sonar_minmax_rescale_f32");
 }
 
 extern "C" int sonar_powerlaw_f32(float* x, float alpha, int use_sign, int64_t n, void* stream) {

@@ -403,6 +403,53 @@ __device__ __forceinline__ int nearest_exact_idx(int dst, float scale, int in_si
     const int i = (int)floorf(((float)dst + 0.5f) * scale);
     return i < in_size - 1 ? i : in_size - 1;
 }
+__device__ __forceinline__ int nearest_idx(int dst, float scale, int in_size) {  // legacy "nearest": floor(dst * scale)
+    const int i = (int)floorf((float)dst * scale);
+    return i < in_size - 1 ? i : in_size - 1;
+}
+// align_corners=True bilinear: src = dst * (in - 1) / (out - 1)
+__device__ __forceinline__ Lin lin_coord_aligned(int dst, float scale, int in_size) {
+    const float src = scale * (float)dst;
+    int i0 = (int)src;
+    i0 = i0 < in_size - 1 ? i0 : in_size - 1;
+    const float l1 = src - (float)i0;
+    Lin r;
+    r.i0 = i0;
+    r.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    r.w0 = 1.0f - l1;
+    r.w1 = l1;
+    return r;
+}
+// bicubic (A = -0.75, ATen UpSampleBicubic2d): taps at floor(src) - 1 .. + 2 with clamped indices; weights from t = src - floor(src)
+struct Cubic {
+    int i[4];
+    float c[4];
+};
+__device__ __forceinline__ Cubic cubic_coord(int dst, float scale, int in_size, bool aligned) {
+    const float A = -0.75f;
+    const float src = aligned ? scale * (float)dst : scale * ((float)dst + 0.5f) - 0.5f;
+    const float fl = floorf(src);
+    const int i0 = (int)fl;
+    const float t = src - fl, u = 1.0f - t;
+    Cubic r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.i[k] = min(max(i0 - 1 + k, 0), in_size - 1);
+    const float t1 = t + 1.0f, u1 = u + 1.0f;
+    r.c[0] = ((A * t1 - 5.0f * A) * t1 + 8.0f * A) * t1 - 4.0f * A;
+    r.c[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+    r.c[2] = ((A + 2.0f) * u - (A + 3.0f)) * u * u + 1.0f;
+    r.c[3] = ((A * u1 - 5.0f * A) * u1 + 8.0f * A) * u1 - 4.0f * A;
+    return r;
+}
+__device__ __forceinline__ float bicubic(const float* __restrict__ plane, int w, const Cubic& cy, const Cubic& cx) {
+    float rows[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* r = plane + (int64_t)cy.i[k] * w;
+        rows[k] = r[cx.i[0]] * cx.c[0] + r[cx.i[1]] * cx.c[1] + r[cx.i[2]] * cx.c[2] + r[cx.i[3]] * cx.c[3];
+    }
+    return rows[0] * cy.c[0] + rows[1] * cy.c[1] + rows[2] * cy.c[2] + rows[3] * cy.c[3];
+}
 __device__ __forceinline__ float area_sample(const float* __restrict__ plane, int h, int w, int H, int W, int y, int x) {
     // adaptive average pooling window: [floor(i*in/out), ceil((i+1)*in/out))
     const int y0 = (int)(((int64_t)y * h) / H), y1 = (int)((((int64_t)y + 1) * h + H - 1) / H);
@@ -420,7 +467,9 @@ __global__ void __launch_bounds__(kBlock) resample_acc_kernel(float* dst, const 
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const int64_t total = planes * H * W;
-    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const bool aligned = mode == 5 || mode == 6;  // align_corners=True: (in - 1) / (out - 1), 0 for a single output
+    const float sy = aligned ? (H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.0f) : (float)h / (float)H;
+    const float sx = aligned ? (W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.0f) : (float)w / (float)W;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int x = (int)(i % W);
         const int y = (int)((i / W) % H);
@@ -431,8 +480,16 @@ __global__ void __launch_bounds__(kBlock) resample_acc_kernel(float* dst, const 
             v = bilerp(plane, w, lin_coord(y, sy, h), lin_coord(x, sx, w));
         } else if (mode == 1) {
             v = plane[(int64_t)nearest_exact_idx(y, sy, h) * w + nearest_exact_idx(x, sx, w)];
-        } else {
+        } else if (mode == 2) {
             v = area_sample(plane, h, w, H, W, y, x);
+        } else if (mode == 3) {
+            v = plane[(int64_t)nearest_idx(y, sy, h) * w + nearest_idx(x, sx, w)];
+        } else if (mode == 6) {
+            v = bilerp(plane, w, lin_coord_aligned(y, sy, h), lin_coord_aligned(x, sx, w));
+        } else if (H == h && W == w) {
+            v = plane[(int64_t)y * w + x];  // same size: ATen copies
+        } else {
+            v = bicubic(plane, w, cubic_coord(y, sy, h, aligned), cubic_coord(x, sx, w, aligned));
         }
         if (scale != 1.0f) v = v * scale;
         if (accumulate) v = dst[i] + v;
@@ -961,7 +1018,7 @@ extern "C" int sonar_perlin_noise_f32(const float* terms, float* out, int64_t B,
 
 extern "C" int sonar_resample_acc_f32(float* dst, const float* src, int64_t planes, int64_t H, int64_t W, int64_t h,
                                       int64_t w, float scale, int mode, int accumulate, double* partials, void* stream) {
-    SONAR_REQUIRE(dst && src && planes >= 0 && H > 0 && W > 0 && h > 0 && w > 0 && mode >= 0 && mode <= 2, SONAR_ERR_ARG,
+    SONAR_REQUIRE(dst && src && planes >= 0 && H > 0 && W > 0 && h > 0 && w > 0 && mode >= 0 && mode <= 6, SONAR_ERR_ARG,
                   "sonar_resample_acc_f32: bad argument");
     SONAR_REQUIRE(H < (1 << 24) && W < (1 << 24) && h < (1 << 24) && w < (1 << 24), SONAR_ERR_UNSUPPORTED,
                   "sonar_resample_acc_f32: plane too large");

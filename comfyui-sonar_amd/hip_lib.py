@@ -20,7 +20,10 @@ LIB_PATH = os.path.join(_HERE, "libsonar_hip.so")
 BLEND_IDS = {"lerp": 0, "inject": 1, "subtract_b": 2}
 MODE_IDS = {"CLASSIC": 0, "NEW": 1, "DENOISED": 2}
 INIT_IDS = {"NONE": 0, "SAMPLE": 1, "SAMPLE_NORM": 2}
-RESAMPLE_IDS = {"bilinear": 0, "nearest-exact": 1, "area": 2, "adaptive_avg_pool2d": 2}
+RESAMPLE_IDS = {"bilinear": 0, "nearest-exact": 1, "area": 2, "adaptive_avg_pool2d": 2, "nearest": 3, "bicubic": 4, "bicubic_aligned": 5,
+                "bilinear_aligned": 6}
+UPSCALE_MODES = ("bilinear", "nearest-exact", "area", "adaptive_avg_pool2d", "nearest", "bicubic")  # F.interpolate modes of `scale_samples`
+PYRAMID_FUSED_MODES = ("bilinear", "nearest-exact", "area", "adaptive_avg_pool2d")                  # modes the fused pyramid kernels carry
 DWT_MODE_IDS = {"zero": 0, "symmetric": 1, "reflect": 2, "periodization": 3, "periodic": 4, "constant": 5, "replicate": 5}
 NPART = 1024
 ERR_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3  # include/sonar_hip.h
@@ -135,6 +138,7 @@ SIGNATURES = {
     "sonar_wcfg_lowpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_lowpass_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
+    "sonar_minmax_rescale_f32": (_I, [_P, _I64, _I64, _P, _P, _F, _F, _F, _P, _P]),
     "sonar_max_to_host_f32": (_I, [_P, _I64, C.POINTER(C.c_float), _P]),
     "sonar_wcfg_fused_ws_bytes": (_I64, [_I64, _I64, _I64, _I, _I, _I, _I, _I, _I]),
     "sonar_wcfg_fused_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _I, _P, _I64, _P]),
@@ -994,6 +998,14 @@ def _taps_arr(vals):
             _TAPS.clear()
         hit = _TAPS[key] = _darr(key)
     return hit
+
+
+def minmax_rescale(x: torch.Tensor, rows: int, inner: int, lo: torch.Tensor, hi: torch.Tensor, eps: float, target_min: float,
+                   target_max: float) -> torch.Tensor:
+    out = torch.empty_like(x)
+    _check(load().sonar_minmax_rescale_f32(_dev(x, "x"), rows, inner, _dev(lo, "lo"), _dev(hi, "hi"), float(eps), float(target_min),
+                                           float(target_max), _dev(out, "out"), _stream()), "sonar_minmax_rescale_f32")
+    return out
 
 
 _MAX_SLOT = C.c_float()

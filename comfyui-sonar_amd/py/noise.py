@@ -361,8 +361,10 @@ class GuidedNoise(CustomNoiseItemBase):
         x_zeros = torch.zeros_like(x) if ns is None else None
         ref_latent = self.ref_latent.to(x, copy=True)
         if ref_latent.shape[-2:] != x.shape[-2:]:
-            # one-off setup step on the reference latent (bicubic is outside the HIP resampler's modes)
-            ref_latent = torch.nn.functional.interpolate(ref_latent, size=x.shape[-2:], mode="bicubic", align_corners=True)
+            # F.interpolate(ref_latent, size=..., mode="bicubic", align_corners=True)  (py/noise.py:583-588)
+            src = utils.as_f32(ref_latent).contiguous()
+            sized = torch.empty((*src.shape[:-2], *x.shape[-2:]), dtype=torch.float32, device=src.device)
+            ref_latent = hip_lib.resample_acc_(sized, src, 1.0, "bicubic_aligned", accumulate=False).to(ref_latent.dtype)
         ref_latent = ref_latent.contiguous()
 
         def base(s, sn):

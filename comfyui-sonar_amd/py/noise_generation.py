@@ -404,7 +404,7 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
 
     def generate(self, *_args):
         mode = self.upscale_mode
-        if mode not in hip_lib.RESAMPLE_IDS:
+        if mode not in hip_lib.UPSCALE_MODES:
             raise NotImplementedError(f"pyramid upscale_mode {mode!r} is not on the HIP path")
         b, c, h, w = self.get_adjusted_shape()
         partials = hip_lib.new_partials(self.device)
@@ -438,7 +438,8 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
             out = hip_lib.pyramid_generate((b, c, h, w), self.device, levels, mode, seed, stream, offs, partials)
             return None if out is None else attach_stats(out, partials)
 
-        if w % 4 == 0:
+        fusable = w % 4 == 0 and mode in hip_lib.PYRAMID_FUSED_MODES  # nearest / bicubic: the unfused kernels below
+        if fusable:
             # every level drawn on device: full-resolution levels fold into the base draw, the small grids are drawn by the
             # plane kernel (no launches, no HBM round trip for them); if that kernel cannot run this shape, explicit grids
             out = run([(None, ch, cw, self.discount**i) for i, ch, cw in plan])
@@ -451,9 +452,9 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
             else:
                 grid = hip_lib.philox_normal((b * c, ch, cw), self.device, seed, stream + 2 + i, plane_offset * ch * cw)
                 levels.append((grid, ch, cw, self.discount**i))
-        if w % 4 == 0:
+        if fusable:
             return run(levels)
-        # rare odd widths: same values through the unfused kernels
+        # rare odd widths / modes: same values through the unfused kernels
         out = hip_lib.philox_normal((b, c, h, w), self.device, seed, stream, offs)
         for grid, ch, cw, wt in levels:
             if grid is None:
@@ -464,7 +465,7 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
         return attach_stats(out, hip_lib.stats(out, partials))
 
     def generate_normalized(self, factor, *_args):
-        if self.cpu or self.normalize_dims is not None or self.upscale_mode not in hip_lib.RESAMPLE_IDS:
+        if self.cpu or self.normalize_dims is not None or self.upscale_mode not in hip_lib.UPSCALE_MODES:
             return None
         return self.fix_output_frames(self._device_generate(None, factor))
 
@@ -487,7 +488,7 @@ class HighresPyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
 
     def generate(self, s, sn):
         mode = self.upscale_mode
-        if mode not in hip_lib.RESAMPLE_IDS:
+        if mode not in hip_lib.UPSCALE_MODES:
             raise NotImplementedError(f"highres_pyramid upscale_mode {mode!r} is not on the HIP path")
         b, c, h, w = self.get_adjusted_shape()
         noise = self.noise_generator(s, sn).reshape(b, c, h, w)
@@ -519,7 +520,7 @@ class PyramidOldNoiseGenerator(FramesToChannelsNoiseGenerator):
 
     def generate(self, *_args):
         mode = self.upscale_mode
-        if mode not in hip_lib.RESAMPLE_IDS:
+        if mode not in hip_lib.UPSCALE_MODES:
             raise NotImplementedError(f"pyramid_old upscale_mode {mode!r} is not on the HIP path")
         b, c, h, w = self.get_adjusted_shape()
         noise = torch.zeros((b, c, h, w), dtype=torch.float32, device=self.device)

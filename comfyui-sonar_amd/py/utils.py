@@ -15,7 +15,6 @@ from .. import hip_lib
 Tensor = torch.Tensor
 
 UPSCALE_METHODS = ("bilinear", "nearest-exact", "nearest", "area", "bicubic", "bislerp", "adaptive_avg_pool2d")
-_HIP_RESAMPLE = {"bilinear", "nearest-exact", "area", "adaptive_avg_pool2d"}
 
 _STATS_ATTR = hip_lib.STATS_ATTR
 
@@ -121,21 +120,19 @@ def scale_noise(noise: Tensor, factor: float = 1.0, *, normalized: bool = True, 
 
 
 def scale_samples(samples: Tensor, width: int, height: int, *, mode: str = "bicubic") -> Tensor:
-    """py/utils.py:58-67.  bilinear / nearest-exact / area / adaptive_avg_pool2d run on the HIP resampler."""
+    """py/utils.py:58-67: ``F.interpolate(samples, size=(height, width), mode=mode)`` on the HIP resampler (bilinear / nearest /
+    nearest-exact / bicubic / area / adaptive_avg_pool2d)."""
     _require_device(samples, "scale_samples")
-    if mode in _HIP_RESAMPLE:
+    if mode in hip_lib.UPSCALE_MODES:
         src = as_f32(samples)
         out = torch.empty((*src.shape[:-2], height, width), dtype=torch.float32, device=src.device)
         hip_lib.resample_acc_(out, src, 1.0, mode, accumulate=False)
         return out if samples.dtype == torch.float32 else out.to(samples.dtype)
-    if mode in {"nearest", "bicubic"}:
-        # outside the HIP hot path (SURVEY.md §8a lists bilinear/nearest-exact/area): device-side library op
-        return torch.nn.functional.interpolate(samples, size=(height, width), mode=mode)
     raise NotImplementedError(f"upscale mode {mode!r} needs ComfyUI's bislerp, which the reference does not vendor")
 
 
 def normalize_to_scale(latent: Tensor, target_min: float, target_max: float, *, dim=(-3, -2, -1), eps: float = 1e-07) -> Tensor:
-    """py/utils.py:452-470: per-group min/max (HIP reduction) then rescale + clamp."""
+    """py/utils.py:452-470: per-group min / max (HIP reduction), then rescale + clamp in one kernel."""
     _require_device(latent, "normalize_to_scale")
     x = as_f32(latent)
     dims = sorted(d % x.ndim for d in dim) if len(dim) else list(range(x.ndim))
@@ -145,12 +142,9 @@ def normalize_to_scale(latent: Tensor, target_min: float, target_max: float, *, 
     for d in dims:
         inner *= x.shape[d]
     rows = x.numel() // inner
+    x = x.contiguous()
     lo, hi = hip_lib.minmax_rows(x, rows, inner)
-    shape = (*x.shape[: x.ndim - len(dims)], *([1] * len(dims)))
-    lo, hi = lo.reshape(shape), hi.reshape(shape)
-    out = x - lo
-    out /= (hi - lo).add_(eps)
-    return out.mul_(target_max - target_min).add_(target_min).clamp_(target_min, target_max)
+    return hip_lib.minmax_rescale(x, rows, inner, lo, hi, eps, target_min, target_max)
 
 
 def tensor_to(tensor: Tensor, dest) -> Tensor:

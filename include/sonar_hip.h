@@ -153,6 +153,10 @@ int sonar_amax_mid_f32(const float* x, int64_t outer, int64_t mid, int64_t inner
 int sonar_div_mid_f32(float* x, int64_t outer, int64_t mid, int64_t inner, const float* d, void* stream);
 /* py/utils.py:452-470 normalize_to_scale: per row min/max rescale to [lo,hi] */
 int sonar_minmax_rows_f32(const float* x, int64_t rows, int64_t inner, float* out_min, float* out_max, void* stream);
+/* the rest of normalize_to_scale (py/utils.py:462-469): out = clamp(((x - lo[r]) / ((hi[r] - lo[r]) + eps)) * (target_max - target_min)
+ * + target_min, target_min, target_max), one (lo, hi) per row, every step rounded separately as the reference's tensor ops are */
+int sonar_minmax_rescale_f32(const float* x, int64_t rows, int64_t inner, const float* lo, const float* hi, float eps,
+                             float target_min, float target_max, float* out, void* stream);
 
 /* ---------------------------------------------------------------- momentum step (rows M, M2) */
 typedef struct sonar_momentum_cfg {
@@ -256,7 +260,9 @@ int sonar_perlin_noise_f32(const float* terms, float* out, int64_t B, int64_t ch
 /* ---------------------------------------------------------------- Pyramid (row Y) */
 /* dst[B*C][H][W] += bilinear_upsample(src[B*C][h][w]) * scale   (F.interpolate(mode="bilinear",
  * align_corners=False), py/utils.py:58-67 <- py/noise_generation.py:629-646).  mode: 0 bilinear,
- * 1 nearest-exact, 2 area (adaptive average, used when downscaling) */
+ * 1 nearest-exact, 2 area (adaptive average, used when downscaling), 3 nearest (legacy floor(dst * in / out)), 4 bicubic
+ * (A = -0.75, clamped taps), 5 bicubic with align_corners=True (py/noise.py:583-588, GuidedNoise's reference latent),
+ * 6 bilinear with align_corners=True (py/nodes/powernoise.py:133, the filter's gain curve) */
 int sonar_resample_acc_f32(float* dst, const float* src, int64_t planes, int64_t H, int64_t W, int64_t h, int64_t w,
                            float scale, int mode, int accumulate, double* partials /*nullable*/, void* stream);
 /* generate mode: out = N(0,1) * base_scale + sum_l upsample(levels[l]) * weights[l].  level_ptrs[l]: device pointer to a

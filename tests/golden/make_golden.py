@@ -967,6 +967,42 @@ def gen_cfg_exact():
     save("cfg_exact", **cases)
 
 
+def gen_resample_modes():
+    """scale_samples (py/utils.py:58-67 -> F.interpolate) in every mode the reference lists except bislerp, enlarging, shrinking and
+    at non-integer ratios; the pyramid generators with bicubic / nearest levels (py/noise_generation.py:608-680,517-606); GuidedNoise
+    with a reference latent of another size (bicubic, align_corners=True, py/noise.py:581-588)."""
+    cases = {}
+    g = torch.Generator().manual_seed(131)
+    src = {"a": torch.randn(2, 3, 8, 12, generator=g), "b": torch.randn(1, 4, 33, 17, generator=g), "c": torch.randn(1, 2, 5, 5, generator=g)}
+    sizes = {"a": [(16, 24), (13, 31), (4, 6), (8, 12)], "b": [(64, 64), (16, 9), (40, 17)], "c": [(1, 1), (5, 11)]}
+    for tag, x in src.items():
+        cases[f"src_{tag}"] = x
+        for (h, w) in sizes[tag]:
+            for mode in ("bilinear", "nearest-exact", "nearest", "area", "bicubic", "adaptive_avg_pool2d"):
+                cases[f"scale_{tag}_{h}x{w}_{mode}"] = ref.utils.scale_samples(x, w, h, mode=mode)
+    shape = (2, 4, 16, 16)
+    for mode in ("bicubic", "nearest"):
+        cases[f"pyramid_{mode}"] = ref_noise(NT.PYRAMID, shape, 63, True, upscale_mode=mode)
+        cases[f"pyramid_old_{mode}"] = ref_noise(NT.PYRAMID_OLD, shape, 64, False, upscale_mode=mode)
+        cases[f"highres_pyramid_{mode}"] = ref_noise(NT.HIGHRES_PYRAMID, shape, 65, True, upscale_mode=mode)
+    torch.manual_seed(132)
+    x = torch.randn(shape) * 3.0
+    small = ref.utils.scale_noise(torch.randn(2, 4, 6, 10) * 0.8 + 0.2, normalized=True)
+    cases["guided_x"], cases["guided_ref"] = x, small
+    for method in ("linear", "euler"):
+        item = ref.noise.GuidedNoise(1.0, guidance_factor=0.4, ref_latent=small, method=method, normalize_noise=None, normalize_result=None, noise=None)
+        ns = item.make_noise_sampler(x.clone(), 0.03, 14.6, seed=96, cpu=True, normalized=True)
+        cases[f"guided_{method}"] = ns(torch.tensor(9.0), torch.tensor(6.0))
+    # normalize_to_scale (py/utils.py:450-469): default dims, the last two, everything; a constant group (hi == lo -> eps only)
+    t = torch.randn(3, 4, 9, 7, generator=g) * 2.0 + 0.5
+    t[1, 2] = 0.75
+    cases["nts_in"] = t
+    cases["nts_default"] = ref.utils.normalize_to_scale(t.clone(), 0.0, 1.0)
+    cases["nts_hw"] = ref.utils.normalize_to_scale(t.clone(), -1.5, 2.0, dim=(-2, -1))
+    cases["nts_all"] = ref.utils.normalize_to_scale(t.clone(), 0.25, 0.5, dim=(-4, -3, -2, -1), eps=1e-3)
+    save("resample_modes", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -995,6 +1031,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_pyramid_variants()
     gen_ffilter()
     gen_cfg_exact()
+    gen_resample_modes()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

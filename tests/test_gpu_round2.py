@@ -35,11 +35,61 @@ def near(a, b, rel=2e-5):
     torch.testing.assert_close(a.detach().cpu().float(), b, rtol=0, atol=rel * float(b.abs().max()))
 
 
-def replay(api, name, shape, seed, normalized):
+def replay(api, name, shape, seed, normalized, **kw):
     x = torch.zeros(shape, device="cuda")
     torch.manual_seed(seed)
-    ns = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=seed, cpu=True, factor=1.0, normalized=normalized)
+    ns = api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=seed, cpu=True, factor=1.0, normalized=normalized, **kw)
     return ns(*SIG)
+
+
+# ------------------------------------------------------------------------------------------------ row U: every F.interpolate mode of scale_samples
+def test_scale_samples_every_mode(api, golden):
+    """py/utils.py:58-67 against the reference's outputs: bilinear, nearest-exact, nearest, area, bicubic, adaptive_avg_pool2d; enlarging,
+    shrinking, non-integer ratios, same size, down to one pixel.  fp32 resampling weights: 2e-6 of the output peak + 2e-6."""
+    g = golden("resample_modes")
+    seen = 0
+    for key in g:
+        if not key.startswith("scale_"):
+            continue
+        _, tag, size, mode = key.split("_", 3)
+        h, w = (int(v) for v in size.split("x"))
+        want = g[key]
+        got = api.utils.scale_samples(g[f"src_{tag}"].cuda(), w, h, mode=mode)
+        assert got.is_cuda and tuple(got.shape) == tuple(want.shape)
+        torch.testing.assert_close(got.cpu(), want, rtol=0, atol=2e-6 * float(want.abs().max()) + 2e-6, msg=lambda m, key=key: f"{key}: {m}")
+        seen += 1
+    assert seen == 9 * 6
+    with pytest.raises(NotImplementedError):
+        api.utils.scale_samples(g["src_a"].cuda(), 8, 8, mode="bislerp")
+
+
+@pytest.mark.parametrize("mode", ["bicubic", "nearest"])
+@pytest.mark.parametrize("name,seed,normalized", [("pyramid", 63, True), ("pyramid_old", 64, False), ("highres_pyramid", 65, True)])
+def test_pyramid_levels_through_bicubic_and_nearest(api, golden, name, seed, normalized, mode):
+    want = golden("resample_modes")[f"{name}_{mode}"]
+    close(replay(api, name, tuple(want.shape), seed, normalized, upscale_mode=mode), want)
+    if name == "pyramid":  # device draws with these modes: the unfused kernels, shard-invariant like the fused ones
+        ng = api.noise_generation
+
+        def gen(b0, b):
+            torch.manual_seed(9)
+            with ng.shard_offset(b0):
+                x = torch.zeros((b, 4, 32, 32), device="cuda")
+                return api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, factor=1.0, normalized=False, upscale_mode=mode)(*SIG)
+
+        whole = gen(0, 4)
+        assert bool(torch.isfinite(whole).all()) and 0.8 < float(whole.std()) < 3.0
+        assert torch.equal(torch.cat([gen(0, 2), gen(2, 2)]), whole)
+
+
+@pytest.mark.parametrize("method", ["linear", "euler"])
+def test_guided_noise_resizes_its_reference(api, golden, method):
+    """py/noise.py:581-588: a reference latent of another size goes through bicubic, align_corners=True."""
+    g = golden("resample_modes")
+    item = api.noise.GuidedNoise(1.0, guidance_factor=0.4, ref_latent=g["guided_ref"].cuda(), method=method, normalize_noise=None,
+                                 normalize_result=None, noise=None)
+    ns = item.make_noise_sampler(g["guided_x"].cuda(), 0.03, 14.6, seed=96, cpu=True, normalized=True)
+    close(ns(torch.tensor(9.0), torch.tensor(6.0)), g[f"guided_{method}"])
 
 
 # ------------------------------------------------------------------------------------------------ row Y: pyramid variants
@@ -289,3 +339,13 @@ def test_cfg5_full_shard_one_dpmpp_step(api):
     item = pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
                              common_mode=0.0, channel_correlation="1")
     assert torch.equal(torch.cat(parts), item.make_noise_sampler(x0, None, None, seed=None, cpu=False, normalized=False)(None, None))
+
+
+def test_normalize_to_scale(api, golden):
+    """py/utils.py:450-469 against the reference: min / max reduction + the rescale kernel, each step rounded as the reference's tensor ops
+    are -- bit-exact, including a constant group (denominator eps only)."""
+    g = golden("resample_modes")
+    x = g["nts_in"].cuda()
+    assert torch.equal(api.utils.normalize_to_scale(x.clone(), 0.0, 1.0).cpu(), g["nts_default"])
+    assert torch.equal(api.utils.normalize_to_scale(x.clone(), -1.5, 2.0, dim=(-2, -1)).cpu(), g["nts_hw"])
+    assert torch.equal(api.utils.normalize_to_scale(x.clone(), 0.25, 0.5, dim=(-4, -3, -2, -1), eps=1e-3).cpu(), g["nts_all"])
