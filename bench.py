@@ -157,7 +157,7 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
     extra["spectral_filter_latents_per_s"] = BATCH / (us * 1e-6)
     kernels.append(kernel_entry("power_irfft2_kernel<SRC=2> spectral filter, batch 512", us, 8 * N_LATENT * BATCH,
                                 tr.get("spectral_filter_b512", {}).get("hbm_bytes_per_launch")))
-    # brownian (cfg5's third source), one new path point per call
+    # brownian (cfg5's third source): one new path point per call, bridged between the kept tensors of its neighbours
     ns_b = nz.get_noise_sampler("brownian", x64, 0.03, 14.6, seed=7, cpu=False, normalized=False)
     sched = torch.linspace(14.6, 0.03, 41).tolist()
     pos = [0]

@@ -767,12 +767,15 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
 
 // ------------------------------------------------------------------------------------------------
 // Brownian-interval noise (the reference wraps ComfyUI's BrownianTreeNoiseSampler -> torchsde, un-vendored:
-// py/noise_generation.py:262-286, py/nodes/powernoise.py:383-393).  One Brownian path per element over [t_lo, t_hi] is
-// defined by midpoint bisection: W(mid) = (W(a) + W(b)) / 2 + sqrt((b - a) / 4) z(node), with z(node, element) a
-// counter-based N(0,1) (Philox4x32-10, counter = (element group, node id), key = seed), so W(t) is a LINEAR combination of
-// the z's on t's root-to-leaf path.  The host walks the path(s) in fp64 and passes (node id, coefficient) pairs; this
-// kernel evaluates out[e] = sum_k coef[k] * z(node[k], e).  Values depend on (seed, node, global element index) only:
-// repeated / nested / abutting intervals are consistent, batches shard bit-identically.
+// py/noise_generation.py:262-286, py/nodes/powernoise.py:383-393).  One Brownian path per element over [t_lo, t_hi], defined
+// point by point as the sampler asks for times (torchsde's BrownianInterval grows its tree the same way): a new time t between
+// the nearest known times a < t < b is the Brownian bridge
+//   W(t) = ((b - t) W(a) + (t - a) W(b)) / (b - a) + sqrt((t - a)(b - t) / (b - a)) z(node_t),
+// z(node, element) a counter-based N(0,1) keyed by (seed, node id, global element index).  So every W(t) is a LINEAR combination
+// of node normals (the host keeps the coefficients in fp64) and can be evaluated two ways with the same value up to fp32
+// rounding: from the cached tensors W(a), W(b) plus ONE fresh normal per element (`base_a` / `base_b` below: the sampler's
+// case, a step starts where the last one ended), or from its expansion out[e] = sum_k coef[k] * z(node[k], e).  Values depend on
+// (seed, node, global element index) only: repeated / nested / abutting intervals are consistent, batches shard bit-identically.
 constexpr int kMaxBrownianNodes = 96;
 struct BrownianTerms {
     unsigned long long node[kMaxBrownianNodes];
@@ -786,20 +789,38 @@ struct BrownianTerms {
 // sub-tile and keeps its 4 x 4 partial sums in registers over the nodes.
 constexpr int kBrownIters = 4;
 constexpr int kBrownTile = kBrownIters * 256;
-// Both kernels: acc = sum_k coef_k z(node_k); out = scale * (acc - prev) (prev may be null), w_out = acc (may be null) -- the
-// second form evaluates ONE path point W(t) and differences it against a cached W(t') (see sonar_brownian_point_f32).
+// Both kernels: acc = fa base_a + fb base_b + sum_k coef_k z(node_k) (either base may be null); out = scale * (acc - prev) (prev
+// may be null), w_out = acc (may be null) -- ONE path point W(t), differenced against a cached W(t') (sonar_brownian_point_f32 /
+// sonar_brownian_bridge_f32).  No __restrict__ on the inputs: prev is usually one of the bases.
+struct BrownianBase {
+    const float* a;
+    const float* b;
+    float fa, fb;
+};
 __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
-                                                                uint64_t seed, const float* __restrict__ prev, float* w_out, float scale) {
+                                                                uint64_t seed, const float* prev, float* w_out, float scale,
+                                                                BrownianBase base) {
     const uint32_t lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
     const int64_t first = elem_offset / kBrownTile, tiles = n / kBrownTile;  // both aligned (launcher)
     for (int64_t t = wave; t < tiles; t += nwaves) {
         float acc[kBrownIters][4];
+        const int64_t o = t * kBrownTile + (int64_t)lane * 4;
 #pragma unroll
-        for (int it = 0; it < kBrownIters; ++it)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[it][j] = 0.0f;
+        for (int it = 0; it < kBrownIters; ++it) {
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (base.a) {
+                const float4 p = *reinterpret_cast<const float4*>(base.a + o + it * 256);
+                v = make_float4(base.fa * p.x, base.fa * p.y, base.fa * p.z, base.fa * p.w);
+            }
+            if (base.b) {
+                const float4 p = *reinterpret_cast<const float4*>(base.b + o + it * 256);
+                v = make_float4(__builtin_fmaf(base.fb, p.x, v.x), __builtin_fmaf(base.fb, p.y, v.y), __builtin_fmaf(base.fb, p.z, v.z),
+                                __builtin_fmaf(base.fb, p.w, v.w));
+            }
+            acc[it][0] = v.x; acc[it][1] = v.y; acc[it][2] = v.z; acc[it][3] = v.w;
+        }
         for (int k = 0; k < terms.count; ++k) {
             Xoshiro rng = rng_stream(seed, terms.node[k], (uint64_t)(first + t), lane);
             const float c = terms.coef[k];
@@ -811,7 +832,6 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
                 for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_fmaf(c, z[j], acc[it][j]);
             }
         }
-        const int64_t o = t * kBrownTile + (int64_t)lane * 4;
 #pragma unroll
         for (int it = 0; it < kBrownIters; ++it) {
             float4 a = make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]);
@@ -829,7 +849,8 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
 
 __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
                                                           uint64_t seed, const unsigned long long* __restrict__ latent_seeds,
-                                                          int64_t latent_elems, const float* __restrict__ prev, float* w_out, float scale) {
+                                                          int64_t latent_elems, const float* prev, float* w_out, float scale,
+                                                          BrownianBase base) {
     const int64_t groups = (n + 3) / 4;
     for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
         const int64_t e = g * 4;                       // local element index of the 4-group
@@ -841,6 +862,10 @@ __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n,
             ctr = (uint64_t)(e - lat * latent_elems) >> 2;
         }
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < 4 && e + j < n; ++j) {
+            if (base.a) acc[j] = base.fa * base.a[e + j];
+            if (base.b) acc[j] = __builtin_fmaf(base.fb, base.b[e + j], acc[j]);
+        }
         for (int k = 0; k < terms.count; ++k) {
             const unsigned long long node = terms.node[k];
             const Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)node, (uint32_t)(node >> 32), (uint32_t)key,
@@ -923,7 +948,7 @@ extern "C" int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64
 
 static int brownian_launch(float* out, float* w_out, const float* prev, float scale, int64_t n, int64_t elem_offset,
                            const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds,
-                           int64_t latent_elems, void* stream, const char* what) {
+                           int64_t latent_elems, void* stream, const char* what, BrownianBase base = BrownianBase{nullptr, nullptr, 0.0f, 0.0f}) {
     SONAR_REQUIRE((out || w_out) && n >= 0 && elem_offset >= 0 && (elem_offset & 3) == 0 && nnodes >= 0 && (nnodes == 0 || (node_ids && coefs)),
                   SONAR_ERR_ARG, "%s: bad argument", what);
     SONAR_REQUIRE(nnodes <= kMaxBrownianNodes, SONAR_ERR_UNSUPPORTED, "%s: more than %d path nodes", what, kMaxBrownianNodes);
@@ -940,13 +965,13 @@ static int brownian_launch(float* out, float* w_out, const float* prev, float sc
     auto al = [](const void* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     // the variant is a function of the latent size and the seed kind only, so every shard of a batch picks the same one
     const bool burst = !latent_seeds && latent_elems > 0 && latent_elems % kTileElems == 0 && n % latent_elems == 0 &&
-                       elem_offset % latent_elems == 0 && al(out) && al(w_out) && al(prev);
+                       elem_offset % latent_elems == 0 && al(out) && al(w_out) && al(prev) && al(base.a) && al(base.b);
     if (burst)
         hipLaunchKernelGGL(brownian_burst_kernel, dim3(grid_for(n / kBrownTile, 4)), dim3(kBlock), 0, (hipStream_t)stream, out, n,
-                           elem_offset, t, seed, prev, w_out, scale);
+                           elem_offset, t, seed, prev, w_out, scale, base);
     else
         hipLaunchKernelGGL(brownian_kernel, dim3(grid_for((n + 3) / 4, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, n, elem_offset,
-                           t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems, prev, w_out, scale);
+                           t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems, prev, w_out, scale, base);
     return check_launch(what);
 }
 
@@ -962,6 +987,14 @@ extern "C" int sonar_brownian_point_f32(float* out, float* w_out, const float* p
                                         const uint64_t* latent_seeds, int64_t latent_elems, void* stream) {
     return brownian_launch(out, w_out, prev, scale, n, elem_offset, node_ids, coefs, nnodes, seed, latent_seeds, latent_elems, stream,
                            "sonar_brownian_point_f32");
+}
+
+extern "C" int sonar_brownian_bridge_f32(float* out, float* w_out, const float* prev, float scale, const float* base_a, float fa,
+                                         const float* base_b, float fb, int64_t n, int64_t elem_offset, const uint64_t* node_ids,
+                                         const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds,
+                                         int64_t latent_elems, void* stream) {
+    return brownian_launch(out, w_out, prev, scale, n, elem_offset, node_ids, coefs, nnodes, seed, latent_seeds, latent_elems, stream,
+                           "sonar_brownian_bridge_f32", BrownianBase{base_a, base_b, fa, fb});
 }
 
 extern "C" int sonar_perlin_terms_f32(const float* angles, float* terms, int64_t iters, int64_t C, int64_t H, int64_t W,

@@ -26,6 +26,7 @@ UPSCALE_MODES = ("bilinear", "nearest-exact", "area", "adaptive_avg_pool2d", "ne
 PYRAMID_FUSED_MODES = ("bilinear", "nearest-exact", "area", "adaptive_avg_pool2d")                  # modes the fused pyramid kernels carry
 DWT_MODE_IDS = {"zero": 0, "symmetric": 1, "reflect": 2, "periodization": 3, "periodic": 4, "constant": 5, "replicate": 5}
 NPART = 1024
+BROWNIAN_MAX_TERMS = 96  # kMaxBrownianNodes (csrc/noise_gen.hip)
 ERR_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3  # include/sonar_hip.h
 
 
@@ -91,6 +92,7 @@ SIGNATURES = {
     "sonar_philox_uniform_f32": (_I, [_P, _I64, _U64, _U64, _I64, _F, _F, _F, _P, _P]),
     "sonar_philox_noise_f32": (_I, [_I, _P, _I64, _U64, _U64, _I64, _F, _F, _F, _F, _F, _P, _P]),
     "sonar_brownian_f32": (_I, [_P, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
+    "sonar_brownian_bridge_f32": (_I, [_P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_brownian_point_f32": (_I, [_P, _P, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_perlin_terms_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "sonar_perlin_lattice_f32": (_I, [_P, _I64, _I64, _I64, _I64, _I, _U64, _U64, _P]),
@@ -571,6 +573,30 @@ def brownian_point(shape, device, node_ids, coefs, seed: int, elem_offset: int =
                                            len(node_ids), seed & (2**64 - 1), None if latent_seeds is None else latent_seeds.data_ptr(),
                                            n // shape[0], _stream()), "sonar_brownian_point_f32")
     return out, w
+
+
+def brownian_bridge(shape, device, node_ids, coefs, seed: int, elem_offset: int = 0, latent_seeds: Optional[torch.Tensor] = None, *,
+                    base_a: Optional[torch.Tensor] = None, fa: float = 0.0, base_b: Optional[torch.Tensor] = None, fb: float = 0.0,
+                    prev: Optional[torch.Tensor] = None, scale: float = 1.0, want_out: bool = True, want_w: bool = True):
+    """W = fa * base_a + fb * base_b + sum_k coefs[k] z(node_ids[k], e); returns (scale * (W - prev) or None, W or None).  More than 96
+    terms are accumulated in chunks through ``base_a``."""
+    node_ids, coefs = list(node_ids), list(coefs)
+    n = math.prod(shape)
+    lib = load()
+    while True:
+        last = len(node_ids) <= BROWNIAN_MAX_TERMS
+        ids, cf = node_ids[:BROWNIAN_MAX_TERMS], coefs[:BROWNIAN_MAX_TERMS]
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=device) if want_out and last else None
+        w = torch.empty(tuple(shape), dtype=torch.float32, device=device) if want_w or not last else None
+        _check(lib.sonar_brownian_bridge_f32(_opt(out, "out"), _opt(w, "w_out"), _opt(prev, "prev") if last else None, float(scale),
+                                             _opt(base_a, "base_a"), float(fa), _opt(base_b, "base_b"), float(fb), n, elem_offset,
+                                             (C.c_uint64 * len(ids))(*[int(v) & (2**64 - 1) for v in ids]), (C.c_float * len(cf))(*[float(v) for v in cf]),
+                                             len(ids), seed & (2**64 - 1), None if latent_seeds is None else latent_seeds.data_ptr(),
+                                             n // shape[0], _stream()), "sonar_brownian_bridge_f32")
+        if last:
+            return out, w
+        node_ids, coefs = node_ids[BROWNIAN_MAX_TERMS:], coefs[BROWNIAN_MAX_TERMS:]
+        base_a, fa, base_b, fb = w, 1.0, None, 0.0
 
 
 def perlin_terms(angles: torch.Tensor, blend_mode: str = "lerp") -> torch.Tensor:

@@ -817,71 +817,65 @@ class OneFNoiseGenerator(_SpectralGainNoiseGenerator):
 # convention, so every call is N(0,1) and repeated / nested / abutting intervals are mutually consistent -- but the path is
 # this build's own: midpoint bisection with counter-based normals (sonar_brownian_f32), so values differ from torchsde's.
 class BrownianPath:
-    """W(t) on [t_lo, t_hi] as a linear combination of per-node standard normals: host side of sonar_brownian_f32."""
+    """W(t) on [t_lo, t_hi] as a linear combination of per-node standard normals: host side of sonar_brownian_*_f32.
 
-    DEPTH = 14            # dyadic levels below the root; the leaf step is an exact bridge at t, so depth only bounds how close
-    ROOT = 0              # two DISTINCT query times may be before they share a leaf normal (range / 2**14)
-    LEAF = 1 << 40        # node ids stay below 2**48 (the kernel's stream-id field)
-    OUTSIDE = 1 << 41
+    The path is defined point by point, in the order times are asked for (torchsde's BrownianInterval grows its tree the same way): a new
+    time t between the nearest known times a < t < b is the Brownian bridge W(t) = ((b - t) W(a) + (t - a) W(b)) / (b - a) +
+    sqrt((t - a)(b - t) / (b - a)) z(node), node = the point's creation number.  By the Markov property the joint law of all known points
+    is exactly a Brownian motion's.  ``terms[t]`` is the expansion of W(t) over the node normals (fp64); ``bridge[t]`` how it was made."""
+
+    ROOT = 0              # node ids are creation numbers; they stay below 2**40 (the kernel's stream-id field has 48 bits)
 
     def __init__(self, t_lo: float, t_hi: float):
         self.t_lo, self.t_hi = float(t_lo), float(t_hi)
         if not self.t_hi > self.t_lo:
             raise ValueError("Brownian noise needs sigma_min < sigma_max")
-        self._cache: dict = {}  # a sampling run queries the same few times over and over (t1 of a step = t0 of the next)
+        self.times = [self.t_lo, self.t_hi]  # sorted; W(lo) = 0, W(hi) ~ N(0, hi - lo)
+        self.terms = {self.t_lo: {}, self.t_hi: {self.ROOT: math.sqrt(self.t_hi - self.t_lo)}}
+        self.bridge: dict = {}  # t -> (a, b, fa, fb, s, node)
+        self._next = 1
 
     def coefficients(self, t: float) -> dict:
-        """{node id: coefficient} with W(t) = sum coefficient * z(node)."""
+        """{node id: coefficient} with W(t) = sum coefficient * z(node); defines the point if it is new."""
         t = float(t)
-        hit = self._cache.get(t)
-        if hit is None:
-            if len(self._cache) > 4096:
-                self._cache.clear()
-            hit = self._cache[t] = self._walk(t)
-        return hit
+        hit = self.terms.get(t)
+        if hit is not None:
+            return hit
+        import bisect
 
-    def _walk(self, t: float) -> dict:
-        lo, hi = self.t_lo, self.t_hi
-        if t < lo or t > hi:
-            # outside the tree: an independent increment from the nearest end, keyed by the query time itself
-            import struct
-
-            edge = lo if t < lo else hi
-            out = dict(self.coefficients(edge))
-            out[self.OUTSIDE | ((struct.unpack("<Q", struct.pack("<d", t))[0] >> 23) & ((1 << 40) - 1))] = math.sqrt(abs(t - edge))
-            return out
-        ca, cb = {}, {self.ROOT: math.sqrt(hi - lo)}  # W(lo) = 0, W(hi) ~ N(0, hi - lo)
-        a, b, node = lo, hi, 1
-        for _ in range(self.DEPTH):
-            if t == a:
-                return ca
-            if t == b:
-                return cb
-            mid = 0.5 * (a + b)
-            cm = {k: 0.5 * (ca.get(k, 0.0) + cb.get(k, 0.0)) for k in ca.keys() | cb.keys()}
-            cm[node] = 0.5 * math.sqrt(b - a)  # bridge midpoint: std sqrt((b - a) / 4)
-            if t < mid:
-                b, cb, node = mid, cm, 2 * node
-            else:
-                a, ca, node = mid, cm, 2 * node + 1
-        if t == a:
-            return ca
-        if t == b:
-            return cb
-        lam = (t - a) / (b - a)
-        out = {k: (1.0 - lam) * ca.get(k, 0.0) + lam * cb.get(k, 0.0) for k in ca.keys() | cb.keys()}
-        out[self.LEAF | node] = math.sqrt((t - a) * (b - t) / (b - a))  # exact bridge at t inside the leaf interval
+        i = bisect.bisect_left(self.times, t)
+        node = self._next
+        if node >= (1 << 40):
+            raise RuntimeError("Brownian noise: out of node ids")
+        self._next += 1
+        if 0 < i < len(self.times):
+            a, b = self.times[i - 1], self.times[i]
+            fb = (t - a) / (b - a)
+            fa = 1.0 - fb
+            sd = math.sqrt((t - a) * (b - t) / (b - a))
+            ca, cb = self.terms[a], self.terms[b]
+            out = {k: fa * ca.get(k, 0.0) + fb * cb.get(k, 0.0) for k in ca.keys() | cb.keys()}
+        else:
+            # beyond every known time (a query outside [t_lo, t_hi]): an independent increment from the outermost known time -- the
+            # two-sided motion continues; later times between two such points are bridges like any other
+            a, b = (self.times[-1], None) if i else (self.times[0], None)
+            fa, fb, sd = 1.0, 0.0, math.sqrt(abs(t - a))
+            out = dict(self.terms[a])
+        out[node] = sd
+        self.times.insert(i, t)
+        self.terms[t] = out
+        self.bridge[t] = (a, b, fa, fb, sd, node)
         return out
 
     def increment(self, t0: float, t1: float):
-        """(node ids, coefficients) of (W(t_max) - W(t_min)) / sqrt(t_max - t_min)."""
+        """(node ids, coefficients) of (W(t_max) - W(t_min)) / sqrt(t_max - t_min); the smaller time is defined first."""
         ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
         if ta == tb:
             raise ValueError("Brownian noise needs two distinct times")
         ca, cb = self.coefficients(ta), self.coefficients(tb)
         scale = 1.0 / math.sqrt(tb - ta)
         terms = {k: (cb.get(k, 0.0) - ca.get(k, 0.0)) * scale for k in ca.keys() | cb.keys()}
-        terms = {k: v for k, v in terms.items() if abs(v) > 1e-9}  # shared ancestors cancel
+        terms = {k: v for k, v in terms.items() if abs(v) > 1e-12}
         ids = sorted(terms)
         return ids, [terms[k] for k in ids]
 
@@ -909,13 +903,47 @@ class BrownianTreeNoiseSampler:
         except TypeError:
             self.seed = int(seed)
         self.elem_offset = current_batch_offset() * (x.numel() // x.shape[0])  # batch shards draw their own global elements
+        self._points: dict = {}  # t -> W(t) tensor, least recently used first
 
-    CACHE_POINTS = 3  # W(t) tensors kept (a sampler step ends where the next begins; DPM++ SDE asks (t, s) and (t, t') per step)
+    # W(t) tensors kept: a sampler step ends where the next begins and DPM++ SDE asks (t, s) and (t, t') per step, so the two times a
+    # new one is bridged between are the previous step's and the interval's end -- ONE fresh normal per element per call
+    CACHE_POINTS = 4
 
-    def _point_terms(self, t: float):
-        terms = self.path.coefficients(t)
-        ids = sorted(terms)
-        return ids, [terms[k] for k in ids]
+    def _remember(self, t: float, w: Tensor) -> None:
+        self._points.pop(t, None)
+        self._points[t] = w
+        while len(self._points) > self.CACHE_POINTS:
+            self._points.pop(next(iter(self._points)))
+
+    def _cached(self, t: float, *, cheap: bool = False) -> Optional[Tensor]:
+        """The kept W(t); with ``cheap`` also a point whose expansion is a single normal (the interval's end) is evaluated and kept."""
+        w = self._points.get(t)
+        if w is not None:
+            self._remember(t, w)
+        elif cheap and len(self.path.terms.get(t, ())) == 1:
+            (node, coef), = self.path.terms[t].items()
+            _, w = hip_lib.brownian_bridge(self.shape, self.device, [node], [coef], self.seed, self.elem_offset, self.latent_seeds, want_out=False)
+            self._remember(t, w)
+        return w
+
+    def _point(self, t: float, *, prev: Optional[Tensor] = None, scale: float = 1.0, want_out: bool = True):
+        """(scale * (W(t) - prev) or None, W(t)) for a time that is not kept: the bridge between its two kept neighbours, else its expansion."""
+        tail = (self.seed, self.elem_offset, self.latent_seeds)
+        made = self.path.bridge.get(t)
+        out = w = None
+        if made is not None and self.CACHE_POINTS > 0:
+            a, b, fa, fb, sd, node = made
+            wa = None if a == self.path.t_lo else self._cached(a, cheap=True)  # W(t_lo) = 0
+            wb = None if b is None else self._cached(b, cheap=True)            # b is None: an extension beyond the known times
+            if (wb is not None or b is None) and (wa is not None or a == self.path.t_lo):
+                out, w = hip_lib.brownian_bridge(self.shape, self.device, [node], [sd], *tail, base_a=wa, fa=fa, base_b=wb, fb=fb, prev=prev,
+                                                 scale=scale, want_out=want_out)
+        if w is None:
+            terms = self.path.coefficients(t)
+            ids = sorted(terms)
+            out, w = hip_lib.brownian_bridge(self.shape, self.device, ids, [terms[k] for k in ids], *tail, prev=prev, scale=scale, want_out=want_out)
+        self._remember(t, w)
+        return out, w
 
     def __call__(self, sigma, sigma_next) -> Tensor:
         t0, t1 = float(self.transform(torch.as_tensor(sigma))), float(self.transform(torch.as_tensor(sigma_next)))
@@ -923,33 +951,26 @@ class BrownianTreeNoiseSampler:
         ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
         if self.CACHE_POINTS <= 0 or ta == tb:
             ids, coefs = self.path.increment(t0, t1)
-            return hip_lib.brownian(self.shape, self.device, ids, [c * sign for c in coefs], self.seed, self.elem_offset, self.latent_seeds)
-        # end-point form: out = (W(tb) - W(ta)) / sqrt(tb - ta) with the W(t) tensors of the last few end points kept -- one new
-        # point per call (~16 path nodes) instead of a merged pair of paths (~27)
-        cache = self.__dict__.setdefault("_points", {})
+            out, _ = hip_lib.brownian_bridge(self.shape, self.device, ids, [c * sign for c in coefs], self.seed, self.elem_offset, self.latent_seeds,
+                                             want_w=False)
+            return out
+        # out = (W(tb) - W(ta)) / sqrt(tb - ta); both times are defined here, the smaller first, whatever is kept
+        self.path.coefficients(ta)
+        self.path.coefficients(tb)
         scale = sign / math.sqrt(tb - ta)
-        args = (self.shape, self.device)
-        tail = (self.seed, self.elem_offset, self.latent_seeds)
-
-        def remember(t, w):
-            cache.pop(t, None)
-            cache[t] = w
-            while len(cache) > self.CACHE_POINTS:
-                cache.pop(next(iter(cache)))
-
-        wa, wb = cache.get(ta), cache.get(tb)
+        wa, wb = self._cached(ta), self._cached(tb)
         if wa is not None and wb is not None:
             out = hip_lib.blend("subtract_b", wb, wa, 1.0)
             return hip_lib.mul_scalar(out, scale, out=out)
         if wa is None and wb is None:
-            _, wa = hip_lib.brownian_point(*args, *self._point_terms(ta), *tail, want_out=False)
-            remember(ta, wa)
+            if ta == self.path.t_lo:  # W(t_lo) = 0
+                out, _ = self._point(tb, scale=scale)
+                return out
+            _, wa = self._point(ta, want_out=False)
         if wb is None:
-            out, wb = hip_lib.brownian_point(*args, *self._point_terms(tb), *tail, prev=wa, scale=scale)
-            remember(tb, wb)
+            out, _ = self._point(tb, prev=wa, scale=scale)
             return out
-        out, wa = hip_lib.brownian_point(*args, *self._point_terms(ta), *tail, prev=wb, scale=-scale)  # scale * (W(tb) - W(ta))
-        remember(ta, wa)
+        out, _ = self._point(ta, prev=wb, scale=-scale)  # scale * (W(tb) - W(ta))
         return out
 
 

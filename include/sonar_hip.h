@@ -219,18 +219,25 @@ int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64_t seed, ui
 /* Brownian-interval noise (the reference wraps ComfyUI's BrownianTreeNoiseSampler -> torchsde, un-vendored:
  * py/noise_generation.py:262-286, py/nodes/powernoise.py:383-393).  out[e] = sum_k coefs[k] * z(node_ids[k], e) with
  * z a counter-based N(0,1) keyed by (seed, node id (48 bits), global element index elem_offset + e).  node_ids / coefs are
- * HOST arrays (<= 96 entries): the bisection path(s) of the queried interval, walked by the host in fp64.  latent_elems =
+ * HOST arrays (<= 96 entries): the expansion of the queried increment / point over the node normals, kept by the host in fp64
+ * (each queried time is a Brownian bridge between the nearest times known before it).  latent_elems =
  * elements per latent (0 if unknown): when it is a multiple of 4096 and there is one seed, z(node, .) is the tile-keyed burst
  * stream of the Gaussian fill with stream id = node (one Philox seeding per 64 values); otherwise one Philox4x32-10 call per
  * 4 values.  latent_seeds (device, nullable): one seed per latent (the sampler's batched-seed mode), replacing `seed`. */
 int sonar_brownian_f32(float* out, int64_t n, int64_t elem_offset, const uint64_t* node_ids, const float* coefs, int nnodes,
                        uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems, void* stream);
 /* One path point instead of an increment: W = sum_k coefs[k] z(node_ids[k], e) with the coefficients of W(t) itself;
- * w_out = W (nullable) and out = scale * (W - prev) (out, prev nullable; prev = a W(t') kept from an earlier call).  A sampler's
- * consecutive calls share an end point, so caching the last few W(t) tensors needs ~16 path nodes per call instead of ~27. */
+ * w_out = W (nullable) and out = scale * (W - prev) (out, prev nullable; prev = a W(t') kept from an earlier call). */
 int sonar_brownian_point_f32(float* out, float* w_out, const float* prev, float scale, int64_t n, int64_t elem_offset,
                              const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed,
                              const uint64_t* latent_seeds, int64_t latent_elems, void* stream);
+/* The bridge form of a path point: W = fa * base_a + fb * base_b + sum_k coefs[k] z(node_ids[k], e), base_a / base_b (nullable) =
+ * the cached W tensors of the two times the new one was bridged between -- ONE fresh normal per element instead of the point's
+ * whole expansion.  Also accumulates an expansion longer than 96 terms in chunks (base_a = the partial sum, fa = 1). */
+int sonar_brownian_bridge_f32(float* out, float* w_out, const float* prev, float scale, const float* base_a, float fa,
+                              const float* base_b, float fb, int64_t n, int64_t elem_offset, const uint64_t* node_ids,
+                              const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems,
+                              void* stream);
 
 /* ---------------------------------------------------------------- Perlin (row P) */
 /* py/noise_generation.py:465-476,388-405 at the only position generate() uses (grid == output,

@@ -139,8 +139,25 @@ def test_brownian_path_coefficients_are_a_brownian_motion(pkg):
         ids, co = bp.increment(b, a)  # order does not matter here (the sampler applies the sign)
         assert abs(sum(c * c for c in co) - 1.0) < 1e-6 and len(ids) <= 96 and ids == sorted(ids)
     assert bp.coefficients(0.03) == {} and set(bp.coefficients(14.6)) == {bp.ROOT}
-    # outside the tree: independent increment from the nearest end with the right variance
+    # outside [t_lo, t_hi] the two-sided motion continues: independent increments from the outermost known time, bridges in between
     out = bp.coefficients(20.0)
-    assert abs(var(out) - (20.0 - 0.03)) < 1e-9
+    far = bp.coefficients(25.0)
+    mid = bp.coefficients(22.0)
+    assert abs(var(out) - (20.0 - 0.03)) < 1e-9 and abs(cov(out, far) - (20.0 - 0.03)) < 1e-9 and abs(cov(mid, far) - (22.0 - 0.03)) < 1e-9
+    below, lower = bp.coefficients(0.02), bp.coefficients(0.005)
+    assert abs(var(below) - 0.01) < 1e-12 and abs(cov(below, lower) - 0.01) < 1e-12 and abs(var(lower) - 0.025) < 1e-12
+    assert abs(cov(below, out)) < 1e-12  # increments on either side of t_lo are independent
     with pytest.raises(ValueError):
         bp.increment(1.0, 1.0)
+    # a sampler's pattern -- times walking down from the top, two queries per step -- keeps every new point a bridge between the previous
+    # one and an end of the interval; its expansion then holds every earlier normal (the device evaluates it from the kept neighbours)
+    bp = ng.BrownianPath(0.03, 14.6)
+    ts = [14.6 * 0.97**k for k in range(1, 150)]
+    for k, t in enumerate(ts):
+        c = bp.coefficients(t)
+        a, b, fa, fb, sd, node = bp.bridge[t]
+        assert (a, b) == (0.03, ts[k - 1] if k else 14.6) and abs(fa + fb - 1.0) < 1e-15 and c[node] == sd and len(c) == k + 2
+        assert abs(var(c) - (t - 0.03)) < 1e-9
+        if k:
+            assert abs(cov(c, bp.coefficients(ts[k - 1])) - (t - 0.03)) < 1e-9
+    assert bp.coefficients(ts[40]) is bp.coefficients(ts[40])  # a known time is never redefined

@@ -276,6 +276,37 @@ def test_brownian_noise_is_one_consistent_path(api):
         api.noise.get_noise_sampler("brownian", x, None, None, seed=1)
 
 
+@pytest.mark.parametrize("seeds", [None, [5, 6, 7]])
+def test_brownian_bridge_route_equals_expansion_route(api, seeds):
+    """A new time is evaluated from the kept W tensors of the two times it was bridged between (one fresh normal per element); without kept
+    tensors (CACHE_POINTS = 0) from its whole expansion over the node normals, in chunks of 96 terms.  Same linear combination, fp32
+    rounding apart.  The walk is a DPM++ SDE run's: (t, s) and (t, t') per step, 60 steps -> expansions of up to ~120 terms; the last steps run below sigma_min,
+    where the path continues as independent increments from the outermost known time."""
+    NG = api.noise_generation
+    x = torch.zeros(3, 4, 64, 64, device="cuda")
+    seed = 77 if seeds is None else seeds
+    kept = NG.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=seed)
+    bare = NG.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=seed)
+    bare.CACHE_POINTS = 0
+    sig = [14.6 * 0.9**k for k in range(61)]
+    worst = 0.0
+    for k in range(60):
+        mid = math.sqrt(sig[k] * sig[k + 1])
+        for pair in ((sig[k], mid), (sig[k], sig[k + 1])):
+            a = kept(torch.tensor(pair[0]), torch.tensor(pair[1]))
+            b = bare(torch.tensor(pair[0]), torch.tensor(pair[1]))
+            worst = max(worst, float((a - b).abs().max()))
+            if k in (0, 30, 59):
+                n = a.numel()
+                assert abs(a.mean().item()) < 5 / math.sqrt(n) and abs(a.var().item() - 1.0) < 15 / math.sqrt(n)
+    assert len(kept._points) <= kept.CACHE_POINTS and max(len(c) for c in bare.path.terms.values()) > 100
+    assert worst < 2e-5, worst
+    # the whole run is one path: the first and the last step's increments, recomposed from the end points, agree with a direct query
+    whole = kept(torch.tensor(sig[0]), torch.tensor(sig[60]))
+    direct = bare(torch.tensor(sig[0]), torch.tensor(sig[60]))
+    torch.testing.assert_close(whole, direct, rtol=0, atol=2e-5)
+
+
 def test_brownian_batched_seeds_and_time_brownian_power_noise(api):
     x = torch.zeros(3, 4, 32, 32, device="cuda")
     tree = api.noise_generation.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=[5, 6, 5])
