@@ -58,6 +58,36 @@ __device__ __forceinline__ void store_group(float* out, int64_t n, int64_t e, co
     }
 }
 
+// Accumulating epilogue of the generators: instead of writing a fresh tensor that a chain then folds into its running sum with
+// sonar_axpby_f32 (read 8N, write 4N), the generator reads the sum and writes it back: v <- y * ya + v * f with the products
+// rounded on their own and skipped when the multiplier is exactly 1, as AxpbyOp does (elementwise.hip), so the chain's value does
+// not change by a bit.  y == nullptr: plain store.  y may be the output itself (in place).
+struct Accum {
+    const float* y;
+    float ya, f;
+    __device__ __forceinline__ float operator()(float yv, float v) const {
+        const float yy = ya != 1.0f ? yv * ya : yv;
+        const float xx = f != 1.0f ? v * f : v;
+        return yy + xx;
+    }
+};
+template <bool VEC>
+__device__ __forceinline__ void accumulate_group(const Accum& acc, int64_t n, int64_t e, float (&v)[4]) {
+    if (!acc.y) return;
+    if (VEC && e >= 0 && e + 4 <= n) {
+        const float4 y = *reinterpret_cast<const float4*>(acc.y + e);
+        v[0] = acc(y.x, v[0]);
+        v[1] = acc(y.y, v[1]);
+        v[2] = acc(y.z, v[2]);
+        v[3] = acc(y.w, v[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e + k >= 0 && e + k < n) v[k] = acc(acc.y[e + k], v[k]);
+    }
+}
+static constexpr Accum kNoAccum{nullptr, 1.0f, 1.0f};
+
 struct Affine {
     float sub, mul, add;
     int active;
@@ -67,12 +97,13 @@ struct Affine {
 // VEC: out 16-B aligned and elem_offset % 4 == 0 -> dwordx4 stores
 template <Dist D, bool VEC, bool STATS>
 __global__ void __launch_bounds__(kBlock) stream_fill_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
-                                                             int64_t elem_offset, Affine aff, double* partials) {
+                                                             int64_t elem_offset, Affine aff, double* partials, Accum acc) {
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     for_each_group<D>(n, seed, stream_id, elem_offset, [&](int64_t e, float (&v)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = aff(v[k]);
+        accumulate_group<VEC>(acc, n, e, v);
         store_group<VEC>(out, n, e, v, s, q, STATS);
     });
     if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
@@ -85,12 +116,12 @@ static inline int tile_grid(int64_t n, int64_t elem_offset) {
 
 template <Dist D>
 static int launch_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset, Affine aff,
-                       double* partials, hipStream_t st, const char* what) {
+                       double* partials, hipStream_t st, const char* what, Accum acc = kNoAccum) {
     if (n == 0) return SONAR_OK;
-    const bool vec = aligned16(out) && (elem_offset & 3) == 0;
+    const bool vec = aligned16(out) && aligned16(acc.y) && (elem_offset & 3) == 0;
     const int g = tile_grid(n, elem_offset);
 #define SONAR_FILL(A, S) \
-    hipLaunchKernelGGL((stream_fill_kernel<D, A, S>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials)
+    hipLaunchKernelGGL((stream_fill_kernel<D, A, S>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials, acc)
     if (vec) {
         if (partials) SONAR_FILL(true, true); else SONAR_FILL(true, false);
     } else {
@@ -270,7 +301,7 @@ template <int MODE, bool VEC, bool STATS>
 __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __restrict__ terms, float* out, int64_t B,
                                                                   int64_t chw, int iters, float div_fac, uint64_t seed,
                                                                   uint64_t stream_id, int64_t elem_offset, double* partials,
-                                                                  NormArgs na) {
+                                                                  NormArgs na, Accum acc) {
     __shared__ double red[2 * kBlock / 64];
     __shared__ NormDecision sh;
     NormDecision dec{0.f, 1.f, 0, 0};
@@ -329,6 +360,7 @@ __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __
                         }
                 }
             } else {
+                if constexpr (MODE == 0) accumulate_group<VEC>(acc, n, e, v);
                 store_group<VEC>(out, n, e, v, s, q, STATS);
             }
         }
@@ -356,13 +388,14 @@ static int launch_perlin_apply(const float* base, const float* terms, float* out
 template <int MODE>
 static int launch_perlin_generate(const float* terms, float* out, int64_t B, int64_t chw, int64_t iters, float div_fac,
                                   uint64_t seed, uint64_t stream_id, int64_t elem_offset, double* partials, NormArgs na,
-                                  hipStream_t st, const char* what) {
+                                  hipStream_t st, const char* what, Accum acc = kNoAccum) {
     const int64_t n = B * chw;
     if (n == 0) return SONAR_OK;
-    const bool vec = (chw % 4 == 0) && (MODE == 1 || aligned16(out)) && (iters == 0 || aligned16(terms)) && (elem_offset % 4 == 0);
+    const bool vec = (chw % 4 == 0) && (MODE == 1 || aligned16(out)) && (iters == 0 || aligned16(terms)) && (elem_offset % 4 == 0) &&
+                     aligned16(acc.y);
     const int g = tile_grid(n, elem_offset);
 #define SONAR_PG(V, S) \
-    hipLaunchKernelGGL((perlin_generate_kernel<MODE, V, S>), dim3(g), dim3(kBlock), 0, st, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials, na)
+    hipLaunchKernelGGL((perlin_generate_kernel<MODE, V, S>), dim3(g), dim3(kBlock), 0, st, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials, na, acc)
     if (vec) {
         if (partials && MODE == 0) SONAR_PG(true, true); else SONAR_PG(true, false);
     } else {
@@ -799,7 +832,9 @@ struct BrownianBase {
 };
 __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
                                                                 uint64_t seed, const float* prev, float* w_out, float scale,
-                                                                BrownianBase base) {
+                                                                BrownianBase base, Accum fold, double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
     const uint32_t lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
@@ -841,16 +876,21 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
                     const float4 p = *reinterpret_cast<const float4*>(prev + o + it * 256);
                     a = make_float4(a.x - p.x, a.y - p.y, a.z - p.z, a.w - p.w);
                 }
-                *reinterpret_cast<float4*>(out + o + it * 256) = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+                float v[4] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale};
+                accumulate_group<true>(fold, n, o + it * 256, v);
+                store_group<true>(out, n, o + it * 256, v, s, q, partials != nullptr);
             }
         }
     }
+    if (partials) write_partial<kBlock>(s, q, partials, red);  // uniform branch (kernel argument)
 }
 
 __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
                                                           uint64_t seed, const unsigned long long* __restrict__ latent_seeds,
                                                           int64_t latent_elems, const float* prev, float* w_out, float scale,
-                                                          BrownianBase base) {
+                                                          BrownianBase base, Accum fold, double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
     const int64_t groups = (n + 3) / 4;
     for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
         const int64_t e = g * 4;                       // local element index of the 4-group
@@ -879,9 +919,16 @@ __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n,
         }
         for (int j = 0; j < 4 && e + j < n; ++j) {
             if (w_out) w_out[e + j] = acc[j];
-            if (out) out[e + j] = (prev ? acc[j] - prev[e + j] : acc[j]) * scale;
+            if (out) {
+                float v = (prev ? acc[j] - prev[e + j] : acc[j]) * scale;
+                if (fold.y) v = fold(fold.y[e + j], v);
+                out[e + j] = v;
+                s += (double)v;
+                q += (double)v * (double)v;
+            }
         }
     }
+    if (partials) write_partial<kBlock>(s, q, partials, red);
 }
 
 static int fill_levels(PyramidLevels& lv, int64_t H, int64_t W, int64_t nlevels, const float* const* level_ptrs,
@@ -948,7 +995,8 @@ extern "C" int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64
 
 static int brownian_launch(float* out, float* w_out, const float* prev, float scale, int64_t n, int64_t elem_offset,
                            const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds,
-                           int64_t latent_elems, void* stream, const char* what, BrownianBase base = BrownianBase{nullptr, nullptr, 0.0f, 0.0f}) {
+                           int64_t latent_elems, void* stream, const char* what, BrownianBase base = BrownianBase{nullptr, nullptr, 0.0f, 0.0f},
+                           Accum acc = kNoAccum, double* partials = nullptr) {
     SONAR_REQUIRE((out || w_out) && n >= 0 && elem_offset >= 0 && (elem_offset & 3) == 0 && nnodes >= 0 && (nnodes == 0 || (node_ids && coefs)),
                   SONAR_ERR_ARG, "%s: bad argument", what);
     SONAR_REQUIRE(nnodes <= kMaxBrownianNodes, SONAR_ERR_UNSUPPORTED, "%s: more than %d path nodes", what, kMaxBrownianNodes);
@@ -965,13 +1013,17 @@ static int brownian_launch(float* out, float* w_out, const float* prev, float sc
     auto al = [](const void* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     // the variant is a function of the latent size and the seed kind only, so every shard of a batch picks the same one
     const bool burst = !latent_seeds && latent_elems > 0 && latent_elems % kTileElems == 0 && n % latent_elems == 0 &&
-                       elem_offset % latent_elems == 0 && al(out) && al(w_out) && al(prev) && al(base.a) && al(base.b);
+                       elem_offset % latent_elems == 0 && al(out) && al(w_out) && al(prev) && al(base.a) && al(base.b) && al(acc.y);
+    SONAR_REQUIRE(!partials || out, SONAR_ERR_ARG, "%s: statistics need an output tensor", what);
+    // statistics: one (sum, sumsq) pair per block, at most kNPart blocks
+    const int cap = partials ? kNPart : kMaxGrid;
     if (burst)
-        hipLaunchKernelGGL(brownian_burst_kernel, dim3(grid_for(n / kBrownTile, 4)), dim3(kBlock), 0, (hipStream_t)stream, out, n,
-                           elem_offset, t, seed, prev, w_out, scale, base);
+        hipLaunchKernelGGL(brownian_burst_kernel, dim3(std::min(cap, grid_for(n / kBrownTile, 4))), dim3(kBlock), 0, (hipStream_t)stream, out,
+                           n, elem_offset, t, seed, prev, w_out, scale, base, acc, partials);
     else
-        hipLaunchKernelGGL(brownian_kernel, dim3(grid_for((n + 3) / 4, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, out, n, elem_offset,
-                           t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems, prev, w_out, scale, base);
+        hipLaunchKernelGGL(brownian_kernel, dim3(std::min(cap, grid_for((n + 3) / 4, kBlock))), dim3(kBlock), 0, (hipStream_t)stream, out, n,
+                           elem_offset, t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems, prev, w_out, scale,
+                           base, acc, partials);
     return check_launch(what);
 }
 
@@ -995,6 +1047,34 @@ extern "C" int sonar_brownian_bridge_f32(float* out, float* w_out, const float* 
                                          int64_t latent_elems, void* stream) {
     return brownian_launch(out, w_out, prev, scale, n, elem_offset, node_ids, coefs, nnodes, seed, latent_seeds, latent_elems, stream,
                            "sonar_brownian_bridge_f32", BrownianBase{base_a, base_b, fa, fb});
+}
+
+// accumulating forms: y <- y * y_mul + x * x_mul with x the generator's values (never stored), partials (nullable) <- statistics of y
+static bool accum_ok(const sonar_accumulate* a) { return a && a->y; }
+
+extern "C" int sonar_brownian_bridge_acc_f32(const sonar_accumulate* acc, float* w_out, const float* prev, float scale, const float* base_a,
+                                             float fa, const float* base_b, float fb, int64_t n, int64_t elem_offset,
+                                             const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed,
+                                             const uint64_t* latent_seeds, int64_t latent_elems, void* stream) {
+    SONAR_REQUIRE(accum_ok(acc), SONAR_ERR_ARG, "sonar_brownian_bridge_acc_f32: bad argument");
+    return brownian_launch(acc->y, w_out, prev, scale, n, elem_offset, node_ids, coefs, nnodes, seed, latent_seeds, latent_elems, stream,
+                           "sonar_brownian_bridge_acc_f32", BrownianBase{base_a, base_b, fa, fb}, Accum{acc->y, acc->y_mul, acc->x_mul},
+                           acc->partials);
+}
+
+extern "C" int sonar_philox_normal_acc_f32(const sonar_accumulate* acc, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                           void* stream) {
+    SONAR_REQUIRE(accum_ok(acc) && n >= 0 && elem_offset >= 0, SONAR_ERR_ARG, "sonar_philox_normal_acc_f32: bad argument");
+    return launch_fill<Dist::Normal>(acc->y, n, seed, stream_id, elem_offset, Affine{0.f, 1.f, 0.f, 0}, acc->partials, (hipStream_t)stream,
+                                     "sonar_philox_normal_acc_f32", Accum{acc->y, acc->y_mul, acc->x_mul});
+}
+
+extern "C" int sonar_perlin_generate_acc_f32(const sonar_accumulate* acc, const float* terms, int64_t B, int64_t chw, int64_t iters,
+                                             float div_fac, uint64_t seed, uint64_t stream_id, int64_t elem_offset, void* stream) {
+    SONAR_REQUIRE(accum_ok(acc) && (terms || iters == 0) && B >= 0 && chw > 0 && chw < (1LL << 31) && iters >= 0 && elem_offset >= 0,
+                  SONAR_ERR_ARG, "sonar_perlin_generate_acc_f32: bad argument");
+    return launch_perlin_generate<0>(terms, acc->y, B, chw, iters, div_fac, seed, stream_id, elem_offset, acc->partials, NormArgs{},
+                                     (hipStream_t)stream, "sonar_perlin_generate_acc_f32", Accum{acc->y, acc->y_mul, acc->x_mul});
 }
 
 extern "C" int sonar_perlin_terms_f32(const float* angles, float* terms, int64_t iters, int64_t C, int64_t H, int64_t W,

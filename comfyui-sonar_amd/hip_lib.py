@@ -92,6 +92,9 @@ SIGNATURES = {
     "sonar_philox_uniform_f32": (_I, [_P, _I64, _U64, _U64, _I64, _F, _F, _F, _P, _P]),
     "sonar_philox_noise_f32": (_I, [_I, _P, _I64, _U64, _U64, _I64, _F, _F, _F, _F, _F, _P, _P]),
     "sonar_brownian_f32": (_I, [_P, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
+    "sonar_brownian_bridge_acc_f32": (_I, [_P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
+    "sonar_philox_normal_acc_f32": (_I, [_P, _I64, _U64, _U64, _I64, _P]),
+    "sonar_perlin_generate_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _P]),
     "sonar_brownian_bridge_f32": (_I, [_P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_brownian_point_f32": (_I, [_P, _P, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_perlin_terms_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
@@ -573,6 +576,53 @@ def brownian_point(shape, device, node_ids, coefs, seed: int, elem_offset: int =
                                            len(node_ids), seed & (2**64 - 1), None if latent_seeds is None else latent_seeds.data_ptr(),
                                            n // shape[0], _stream()), "sonar_brownian_point_f32")
     return out, w
+
+
+class Accumulate(C.Structure):
+    """``sonar_accumulate`` (include/sonar_hip.h): y <- y * y_mul + x * x_mul, partials <- statistics of the new y."""
+
+    _fields_ = [("y", C.c_void_p), ("y_mul", C.c_float), ("x_mul", C.c_float), ("partials", C.c_void_p)]
+
+
+def accumulate_arg(y: torch.Tensor, y_mul: float, x_mul: float, partials: Optional[torch.Tensor]):
+    if y.dtype != torch.float32 or not y.is_contiguous():
+        raise SonarHipError("accumulate: the running sum must be a contiguous float32 tensor")
+    return C.byref(Accumulate(_dev(y, "y"), float(y_mul), float(x_mul), _opt(partials, "partials", torch.float64)))
+
+
+def philox_normal_acc_(y: torch.Tensor, y_mul: float, x_mul: float, seed: int, stream_id: int, elem_offset: int = 0, partials=None) -> torch.Tensor:
+    """y <- y * y_mul + N(0,1) * x_mul (the draw of ``philox_normal``), in place."""
+    _check(load().sonar_philox_normal_acc_f32(accumulate_arg(y, y_mul, x_mul, partials), y.numel(), seed & (2**64 - 1), stream_id, elem_offset,
+                                              _stream()), "sonar_philox_normal_acc_f32")
+    return y
+
+
+def perlin_generate_acc_(y: torch.Tensor, y_mul: float, x_mul: float, terms: torch.Tensor, div_fac: float, seed: int, stream_id: int,
+                         elem_offset: int = 0, partials=None) -> torch.Tensor:
+    """y <- y * y_mul + perlin * x_mul (the values of ``perlin_generate``), in place."""
+    b = y.shape[0]
+    _check(load().sonar_perlin_generate_acc_f32(accumulate_arg(y, y_mul, x_mul, partials), _dev(terms, "terms"), b, y.numel() // max(b, 1),
+                                                terms.shape[0], float(div_fac), seed & (2**64 - 1), stream_id, elem_offset, _stream()),
+           "sonar_perlin_generate_acc_f32")
+    return y
+
+
+def brownian_bridge_acc_(y: torch.Tensor, y_mul: float, x_mul: float, node_ids, coefs, seed: int, elem_offset: int = 0,
+                         latent_seeds: Optional[torch.Tensor] = None, *, base_a=None, fa: float = 0.0, base_b=None, fb: float = 0.0, prev=None,
+                         scale: float = 1.0, partials=None, want_w: bool = True):
+    """The increment of ``brownian_bridge`` folded into y (y <- y * y_mul + scale * (W - prev) * x_mul); returns W (or None).  At most 96
+    terms; none at all is fine (W = fa * base_a + fb * base_b)."""
+    if len(node_ids) > BROWNIAN_MAX_TERMS:
+        raise SonarHipError("brownian_bridge_acc_: expansion too long for one launch")
+    w = torch.empty_like(y) if want_w else None
+    n = y.numel()
+    _check(load().sonar_brownian_bridge_acc_f32(accumulate_arg(y, y_mul, x_mul, partials), _opt(w, "w_out"), _opt(prev, "prev"), float(scale),
+                                                _opt(base_a, "base_a"), float(fa), _opt(base_b, "base_b"), float(fb), n, elem_offset,
+                                                (C.c_uint64 * len(node_ids))(*[int(v) & (2**64 - 1) for v in node_ids]),
+                                                (C.c_float * len(coefs))(*[float(v) for v in coefs]), len(node_ids), seed & (2**64 - 1),
+                                                None if latent_seeds is None else latent_seeds.data_ptr(), n // y.shape[0], _stream()),
+           "sonar_brownian_bridge_acc_f32")
+    return w
 
 
 def brownian_bridge(shape, device, node_ids, coefs, seed: int, elem_offset: int = 0, latent_seeds: Optional[torch.Tensor] = None, *,

@@ -158,21 +158,36 @@ class CustomNoiseChain:
                     return out
             total, first = None, None
             for idx, ns in enumerate(samplers):
+                fold = getattr(ns, "accumulate", None) if idx else None
+                if fold is not None:
+                    # a generator that can fold its values into the running sum does so (read + write of the sum) instead of writing a
+                    # tensor for the accumulation kernel to read back; same arithmetic, same bits
+                    y, ymul = first if total is None else (total, 1.0)
+                    partials = hip_lib.new_partials(y.device) if idx == len(samplers) - 1 else None
+                    if fold(y, ymul, partials, sigma, sigma_next):
+                        total = y
+                        if partials is not None:
+                            utils.attach_stats(total, partials)
+                        continue
                 raw = getattr(ns, "unscaled", None)
                 pair = raw(sigma, sigma_next) if raw is not None else None
                 part, f = pair if pair is not None else (ns(sigma, sigma_next), 1.0)
-                pop_stats(part)
+                tag = pop_stats(part)
                 if total is None and first is None:
                     first = (part, f)
+                    if len(samplers) == 1 and f == 1.0 and tag is not None:
+                        utils.attach_stats(part, tag)  # the only item, used as it is: its statistics still describe it
                     continue
                 y, ymul = (first if total is None else (total, 1.0))
-                if normalized and idx == len(samplers) - 1:  # the last accumulation also reduces the statistics scale_noise needs
+                if idx == len(samplers) - 1:  # the last accumulation also reduces the statistics a normalisation (here or a layer up) needs
                     total, partials = hip_lib.axpby_stats_(y, ymul, part, f)
                     utils.attach_stats(total, partials)
                 else:
                     total = hip_lib.axpby_(y, ymul, part, f)
             if total is None:
                 total = first[0] if first[1] == 1.0 else scale_noise(first[0], first[1], normalized=False)
+            if not normalized and factor == 1:
+                return total  # nothing to do; the statistics tag of the sum (if any) stays valid for a normalising layer above
             return scale_noise(total, factor, normalized=normalized)
 
         return noise_sampler
@@ -217,6 +232,17 @@ class NoiseSampler:
         if not hasattr(noise, "to") or noise.dtype != self.dtype or noise.device != self.device or noise.dtype != torch.float32:
             return scale_noise(noise, self.factor, normalized=False).to(dtype=self.dtype, device=self.device), 1.0
         return noise, float(self.factor)
+
+    def accumulate(self, y, y_mul, partials, *args) -> bool:
+        """y <- y * y_mul + noise * factor in place, the noise never written out, when this wrapper would only multiply and its generator can
+        fold (``generate_into``); ``partials`` (nullable) receives the statistics of the new y.  False: the caller takes the ordinary route."""
+        if self.normalized or self.dtype != torch.float32 or y.dtype != torch.float32 or y.device != self.device or not y.is_contiguous():
+            return False
+        into = getattr(self.noise_sampler, "generate_into", None)
+        if into is None:
+            return False
+        args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
+        return bool(into(y, float(y_mul), float(self.factor), partials, *args))
 
     def normalized_call(self, factor, *args):
         """This sampler's output (its own factor must be 1, no normalisation of its own) followed by scale_noise(factor,

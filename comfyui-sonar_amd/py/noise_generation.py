@@ -212,6 +212,11 @@ class NoiseGenerator:
     def generate(self, *args):
         raise NotImplementedError
 
+    def _plain_output(self) -> bool:
+        """True when ``__call__`` hands back ``generate``'s device draw untouched (no normalisation in the output hook), so a generator
+        may fold its values straight into a chain's running sum (``generate_into``: y <- y * y_mul + generate() * x_mul)."""
+        return not self.cpu and not (self.normalized and self.force_normalize in (None, True)) and self.normalize_dims is None
+
     def __call__(self, *args, **kwargs):
         self.pre_hook()
         fused = getattr(self, "generate_normalized", None)
@@ -305,6 +310,14 @@ class GaussianNoiseGenerator(NoiseGenerator):
         shape = tuple(self.shape)
         return hip_lib.philox_noise(False, shape, self.device, seed, stream, self.latent_elem_offset(math.prod(shape[1:])), factor)
 
+    def generate_into(self, y, y_mul, x_mul, partials, *_args):
+        if not self._plain_output() or tuple(y.shape) != tuple(self.shape):
+            return False
+        self.pre_hook()
+        seed, stream = self.device_key()
+        hip_lib.philox_normal_acc_(y, y_mul, x_mul, seed, stream, self.latent_elem_offset(math.prod(self.shape[1:])), partials)
+        return True
+
 
 class UniformNoiseGenerator(NoiseGenerator):
     """py/noise_generation.py:496-514: (U[0,1) - sub_fac) * mul_fac + mean_fac."""
@@ -380,6 +393,16 @@ class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):
         if self.cpu or self.normalize_dims is not None or self.blend_mode not in hip_lib.BLEND_IDS:
             return None
         return self.fix_output_frames(self._device_generate(None, factor))
+
+    def generate_into(self, y, y_mul, x_mul, partials, *_args):
+        if not self._plain_output() or tuple(y.shape) != tuple(self.shape) or self.blend_mode not in hip_lib.BLEND_IDS:
+            return False
+        self.pre_hook()
+        b, c, h, w = self.get_adjusted_shape()
+        seed, stream = self.device_key(2)  # the same keys, in the same order, as _device_generate
+        terms = hip_lib.perlin_lattice(max(self.iterations, 0), c, h, w, self.device, self.blend_mode, seed, stream + 1)
+        hip_lib.perlin_generate_acc_(y.view(b, c, h, w), y_mul, x_mul, terms, self.div_fac, seed, stream, self.latent_elem_offset(c * h * w), partials)
+        return True
 
 
 class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
@@ -926,9 +949,24 @@ class BrownianTreeNoiseSampler:
             self._remember(t, w)
         return w
 
-    def _point(self, t: float, *, prev: Optional[Tensor] = None, scale: float = 1.0, want_out: bool = True):
-        """(scale * (W(t) - prev) or None, W(t)) for a time that is not kept: the bridge between its two kept neighbours, else its expansion."""
+    def _emit(self, ids, coefs, *, base_a=None, fa=0.0, base_b=None, fb=0.0, prev=None, scale=1.0, want_out=True, want_w=True, fold=None):
+        """One evaluation W = fa base_a + fb base_b + sum coef z(node): (scale * (W - prev) or None, W or None).  With ``fold`` = (y, y_mul,
+        x_mul, partials) the increment is folded into the chain's running sum y instead of being written out (``accumulate``)."""
         tail = (self.seed, self.elem_offset, self.latent_seeds)
+        bases = dict(base_a=base_a, fa=fa, base_b=base_b, fb=fb)
+        if fold is None:
+            return hip_lib.brownian_bridge(self.shape, self.device, ids, coefs, *tail, **bases, prev=prev, scale=scale, want_out=want_out, want_w=want_w)
+        y, y_mul, x_mul, partials = fold
+        w = None
+        if len(ids) > hip_lib.BROWNIAN_MAX_TERMS:  # a long expansion: W first (in chunks), then the fold with no terms left
+            _, w = hip_lib.brownian_bridge(self.shape, self.device, ids, coefs, *tail, **bases, want_out=False)
+            ids, coefs, bases = [], [], dict(base_b=w, fb=1.0)
+            want_w = False
+        made = hip_lib.brownian_bridge_acc_(y, y_mul, x_mul, ids, coefs, *tail, **bases, prev=prev, scale=scale, partials=partials, want_w=want_w)
+        return y, (made if w is None else w)
+
+    def _point(self, t: float, *, prev: Optional[Tensor] = None, scale: float = 1.0, want_out: bool = True, fold=None):
+        """(scale * (W(t) - prev) or None, W(t)) for a time that is not kept: the bridge between its two kept neighbours, else its expansion."""
         made = self.path.bridge.get(t)
         out = w = None
         if made is not None and self.CACHE_POINTS > 0:
@@ -936,23 +974,28 @@ class BrownianTreeNoiseSampler:
             wa = None if a == self.path.t_lo else self._cached(a, cheap=True)  # W(t_lo) = 0
             wb = None if b is None else self._cached(b, cheap=True)            # b is None: an extension beyond the known times
             if (wb is not None or b is None) and (wa is not None or a == self.path.t_lo):
-                out, w = hip_lib.brownian_bridge(self.shape, self.device, [node], [sd], *tail, base_a=wa, fa=fa, base_b=wb, fb=fb, prev=prev,
-                                                 scale=scale, want_out=want_out)
+                out, w = self._emit([node], [sd], base_a=wa, fa=fa, base_b=wb, fb=fb, prev=prev, scale=scale, want_out=want_out, fold=fold)
         if w is None:
             terms = self.path.coefficients(t)
             ids = sorted(terms)
-            out, w = hip_lib.brownian_bridge(self.shape, self.device, ids, [terms[k] for k in ids], *tail, prev=prev, scale=scale, want_out=want_out)
+            out, w = self._emit(ids, [terms[k] for k in ids], prev=prev, scale=scale, want_out=want_out, fold=fold)
         self._remember(t, w)
         return out, w
 
-    def __call__(self, sigma, sigma_next) -> Tensor:
+    def accumulate(self, y: Tensor, y_mul: float, x_mul: float, partials, sigma, sigma_next) -> bool:
+        """y <- y * y_mul + self(sigma, sigma_next) * x_mul without writing the increment out (a noise chain's running sum)."""
+        if tuple(y.shape) != self.shape or y.device != self.device or y.dtype != torch.float32 or not y.is_contiguous():
+            return False
+        self(sigma, sigma_next, fold=(y, y_mul, x_mul, partials))
+        return True
+
+    def __call__(self, sigma, sigma_next, *, fold=None) -> Tensor:
         t0, t1 = float(self.transform(torch.as_tensor(sigma))), float(self.transform(torch.as_tensor(sigma_next)))
         sign = self.sign * (1.0 if t0 <= t1 else -1.0)
         ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
         if self.CACHE_POINTS <= 0 or ta == tb:
             ids, coefs = self.path.increment(t0, t1)
-            out, _ = hip_lib.brownian_bridge(self.shape, self.device, ids, [c * sign for c in coefs], self.seed, self.elem_offset, self.latent_seeds,
-                                             want_w=False)
+            out, _ = self._emit(ids, [c * sign for c in coefs], want_w=False, fold=fold)
             return out
         # out = (W(tb) - W(ta)) / sqrt(tb - ta); both times are defined here, the smaller first, whatever is kept
         self.path.coefficients(ta)
@@ -960,17 +1003,17 @@ class BrownianTreeNoiseSampler:
         scale = sign / math.sqrt(tb - ta)
         wa, wb = self._cached(ta), self._cached(tb)
         if wa is not None and wb is not None:
-            out = hip_lib.blend("subtract_b", wb, wa, 1.0)
-            return hip_lib.mul_scalar(out, scale, out=out)
+            out, _ = self._emit([], [], base_b=wb, fb=1.0, prev=wa, scale=scale, want_w=False, fold=fold)
+            return out
         if wa is None and wb is None:
             if ta == self.path.t_lo:  # W(t_lo) = 0
-                out, _ = self._point(tb, scale=scale)
+                out, _ = self._point(tb, scale=scale, fold=fold)
                 return out
             _, wa = self._point(ta, want_out=False)
         if wb is None:
-            out, _ = self._point(tb, prev=wa, scale=scale)
+            out, _ = self._point(tb, prev=wa, scale=scale, fold=fold)
             return out
-        out, _ = self._point(ta, prev=wb, scale=-scale)  # scale * (W(tb) - W(ta))
+        out, _ = self._point(ta, prev=wb, scale=-scale, fold=fold)  # scale * (W(tb) - W(ta))
         return out
 
 
@@ -992,6 +1035,11 @@ class BrownianNoiseGenerator(NoiseGenerator):
 
     def generate(self, *args):
         return self.brownian_tree_ns(*args)
+
+    def generate_into(self, y, y_mul, x_mul, partials, *args):
+        if not self._plain_output():
+            return False
+        return self.brownian_tree_ns.accumulate(y, y_mul, x_mul, partials, *args)
 
 
 class WaveletNoiseOctave(NamedTuple):

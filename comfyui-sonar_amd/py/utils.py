@@ -95,9 +95,9 @@ def scale_noise(noise: Tensor, factor: float = 1.0, *, normalized: bool = True, 
     attached the statistics, in which case only the apply kernel runs."""
     n = noise.numel()
     if not normalized or n == 0:
-        pop_stats(noise)  # a tag that outlives this call would be picked up by a later normalisation of other contents
         if factor == 1:
-            return noise
+            return noise  # untouched: a statistics tag (written by the producing kernel, checked against storage + version) still describes it
+        pop_stats(noise)  # the values change below: the tag would describe other contents
         _require_device(noise, "scale_noise")
         return hip_lib.scale_noise_(noise, factor, False, None)
     _require_device(noise, "scale_noise")

@@ -239,6 +239,26 @@ int sonar_brownian_bridge_f32(float* out, float* w_out, const float* prev, float
                               const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems,
                               void* stream);
 
+/* Accumulating forms of the generators (noise chains: result = sum_i item_i * factor_i, py/noise.py:188-194).  Instead of writing
+ * a fresh tensor that sonar_axpby_f32 then folds into the running sum (read 8N + write 4N more), the generator reads the sum and
+ * writes it back: y <- y * y_mul + x * x_mul with x the values the plain form would have stored (products rounded separately and
+ * skipped for a multiplier of exactly 1: bit-identical to plain form + sonar_axpby_f32).  partials (nullable, SONAR_NPART pairs)
+ * receives (sum, sumsq) of the new y, which is what a following scale_noise needs. */
+typedef struct sonar_accumulate {
+    float* y;         /* running sum, updated in place */
+    float y_mul;
+    float x_mul;
+    double* partials; /* nullable */
+} sonar_accumulate;
+int sonar_philox_normal_acc_f32(const sonar_accumulate* acc, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                void* stream);
+int sonar_perlin_generate_acc_f32(const sonar_accumulate* acc, const float* terms, int64_t B, int64_t chw, int64_t iters, float div_fac,
+                                  uint64_t seed, uint64_t stream_id, int64_t elem_offset, void* stream);
+int sonar_brownian_bridge_acc_f32(const sonar_accumulate* acc, float* w_out, const float* prev, float scale, const float* base_a, float fa,
+                                  const float* base_b, float fb, int64_t n, int64_t elem_offset, const uint64_t* node_ids,
+                                  const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems,
+                                  void* stream);
+
 /* ---------------------------------------------------------------- Perlin (row P) */
 /* py/noise_generation.py:465-476,388-405 at the only position generate() uses (grid == output,
  * block 1x1, pos (0.5,0.5)): angles[iters][C][H+1][W+1] -> terms[iters][C][H][W] evaluating the

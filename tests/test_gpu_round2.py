@@ -349,3 +349,85 @@ def test_normalize_to_scale(api, golden):
     assert torch.equal(api.utils.normalize_to_scale(x.clone(), 0.0, 1.0).cpu(), g["nts_default"])
     assert torch.equal(api.utils.normalize_to_scale(x.clone(), -1.5, 2.0, dim=(-2, -1)).cpu(), g["nts_hw"])
     assert torch.equal(api.utils.normalize_to_scale(x.clone(), 0.25, 0.5, dim=(-4, -3, -2, -1), eps=1e-3).cpu(), g["nts_all"])
+
+
+# ------------------------------------------------------------------------------------------------ chains: generators that fold into the running sum
+@pytest.mark.parametrize("n_shape", [(3, 4, 64, 64), (2, 3, 5, 7)])
+def test_accumulating_generators_match_generate_then_axpby(api, n_shape):
+    """sonar_{philox_normal,perlin_generate,brownian_bridge}_acc_f32: y <- y * a + x * b with x the values the plain entry point would
+    have written -- bit-identical to plain + sonar_axpby_f32 (products rounded separately, a multiplier of 1 skipped), statistics of
+    the new y included.  Shapes with and without the vector path."""
+    hl = api.hl
+    g = torch.Generator(device="cuda").manual_seed(4)
+    y0 = torch.randn(n_shape, device="cuda", generator=g)
+    n = y0.numel()
+    per = n // n_shape[0]
+    offs = 8 * per  # a shard that starts at latent 8
+    for a, b in ((1.0, 1.0), (0.5, 0.3), (1.0, 0.2), (-1.25, 1.0)):
+        # Gaussian
+        x = hl.philox_normal(n_shape, "cuda", 1234, 7, offs)
+        want = hl.axpby_(y0.clone(), a, x, b)
+        part = hl.new_partials("cuda")
+        got = hl.philox_normal_acc_(y0.clone(), a, b, 1234, 7, offs, part)
+        assert torch.equal(got, want)
+        s = part.view(-1, 2).sum(0)
+        assert abs(s[0].item() - want.double().sum().item()) < 1e-6 * n and abs(s[1].item() - (want.double() ** 2).sum().item()) < 1e-6 * n
+        # Perlin
+        c, h, w = n_shape[1:]
+        terms = hl.perlin_lattice(2, c, h, w, "cuda", "lerp", 99, 3)
+        x = hl.perlin_generate(n_shape, terms, 2.0, 99, 2, offs, None)
+        want = hl.axpby_(y0.clone(), a, x, b)
+        part = hl.new_partials("cuda")
+        got = hl.perlin_generate_acc_(y0.clone(), a, b, terms, 2.0, 99, 2, offs, part)
+        assert torch.equal(got, want)
+        s = part.view(-1, 2).sum(0)
+        assert abs(s[0].item() - want.double().sum().item()) < 1e-6 * n
+        # Brownian bridge between two kept tensors, differenced against one of them
+        wa, wb = torch.randn(n_shape, device="cuda", generator=g), torch.randn(n_shape, device="cuda", generator=g)
+        kw = dict(base_a=wa, fa=0.3, base_b=wb, fb=0.7, prev=wa, scale=1.7)
+        x, w = hl.brownian_bridge(n_shape, "cuda", [5], [0.4], 77, offs, None, **kw)
+        want = hl.axpby_(y0.clone(), a, x, b)
+        part = hl.new_partials("cuda")
+        yy = y0.clone()
+        w2 = hl.brownian_bridge_acc_(yy, a, b, [5], [0.4], 77, offs, None, **kw, partials=part)
+        assert torch.equal(yy, want) and torch.equal(w2, w)
+        s = part.view(-1, 2).sum(0)
+        assert abs(s[1].item() - (want.double() ** 2).sum().item()) < 1e-6 * n
+        # no terms at all: the increment between two kept tensors
+        x, _ = hl.brownian_bridge(n_shape, "cuda", [], [], 77, offs, None, base_b=wb, fb=1.0, prev=wa, scale=-0.5, want_w=False)
+        assert torch.equal(x, (wb - wa) * -0.5)
+
+
+def test_chain_of_folding_generators_equals_the_unfused_chain(api, monkeypatch):
+    """A chain of power-law + Perlin + Brownian + Gaussian items (cfg5's mix): items after the first fold into the running sum.  Same seeds,
+    folding switched off -> the same tensor, bit for bit, normalised or not."""
+    N, pn = api.noise, api.powernoise
+
+    def build():
+        chain = N.CustomNoiseChain()
+        chain.add(pn.PowerNoiseItem(0.5, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                                    common_mode=0.0, channel_correlation="1"))
+        chain.add(N.CustomNoiseItem(0.3, noise_type="perlin"))
+        chain.add(N.CustomNoiseItem(0.2, noise_type="brownian"))
+        chain.add(N.CustomNoiseItem(0.1, noise_type="gaussian"))
+        return chain
+
+    x = torch.zeros(4, 4, 64, 64, device="cuda")
+    steps = [(10.0, 7.0), (7.0, 4.0), (7.0, 5.5), (4.0, 1.0)]
+    for normalized in (True, False):
+        runs = []
+        for fold in (True, False):
+            with monkeypatch.context() as m:
+                if not fold:
+                    m.delattr(N.NoiseSampler, "accumulate")
+                torch.manual_seed(21)
+                ns = build().make_noise_sampler(x, 0.03, 14.6, seed=5, cpu=False, normalized=normalized)
+                outs = []
+                for s, sn in steps:
+                    out = ns(torch.tensor(s), torch.tensor(sn))
+                    outs.append((out.clone(), api.utils.pop_stats(out) is not None))
+                runs.append(outs)
+        for (a, tag_a), (b, _tag_b) in zip(*runs):
+            assert torch.equal(a, b)
+            assert bool(torch.isfinite(a).all()) and (not normalized or abs(a.std().item() - 1.1) < 3e-3)  # scale_noise(factor = sum |factor_i|)
+            assert tag_a or not normalized  # the normalised result carries its statistics (derived from the sum's, no sweep)
