@@ -844,26 +844,28 @@ class BrownianPath:
 
     The path is defined point by point, in the order times are asked for (torchsde's BrownianInterval grows its tree the same way): a new
     time t between the nearest known times a < t < b is the Brownian bridge W(t) = ((b - t) W(a) + (t - a) W(b)) / (b - a) +
-    sqrt((t - a)(b - t) / (b - a)) z(node), node = the point's creation number.  By the Markov property the joint law of all known points
-    is exactly a Brownian motion's.  ``terms[t]`` is the expansion of W(t) over the node normals (fp64); ``bridge[t]`` how it was made."""
+    sqrt((t - a)(b - t) / (b - a)) z(node), node = the point's creation number; beyond every known time it is an independent increment
+    from the outermost one (the two-sided motion continues outside [t_lo, t_hi]).  By the Markov property the joint law of all known
+    points is exactly a Brownian motion's.  ``bridge[t]`` = (a, b, fa, fb, sd, node) is how a point was made -- all a sampler run needs,
+    O(1) per point; ``coefficients(t)`` expands W(t) over the node normals (fp64) on demand, for the evaluation without kept tensors."""
 
     ROOT = 0              # node ids are creation numbers; they stay below 2**40 (the kernel's stream-id field has 48 bits)
+    MEMO = 512            # expansions remembered (each can hold every earlier node: a run of n monotone queries makes them O(n) long)
 
     def __init__(self, t_lo: float, t_hi: float):
         self.t_lo, self.t_hi = float(t_lo), float(t_hi)
         if not self.t_hi > self.t_lo:
             raise ValueError("Brownian noise needs sigma_min < sigma_max")
         self.times = [self.t_lo, self.t_hi]  # sorted; W(lo) = 0, W(hi) ~ N(0, hi - lo)
-        self.terms = {self.t_lo: {}, self.t_hi: {self.ROOT: math.sqrt(self.t_hi - self.t_lo)}}
-        self.bridge: dict = {}  # t -> (a, b, fa, fb, s, node)
+        self.bridge: dict = {}               # t -> (a, b or None, fa, fb, sd, node)
         self._next = 1
+        self._memo: dict = {}
 
-    def coefficients(self, t: float) -> dict:
-        """{node id: coefficient} with W(t) = sum coefficient * z(node); defines the point if it is new."""
+    def define(self, t: float) -> None:
+        """Make t a point of the path (a bridge between its neighbours, or an extension beyond the outermost known time)."""
         t = float(t)
-        hit = self.terms.get(t)
-        if hit is not None:
-            return hit
+        if t in self.bridge or t == self.t_lo or t == self.t_hi:
+            return
         import bisect
 
         i = bisect.bisect_left(self.times, t)
@@ -874,28 +876,49 @@ class BrownianPath:
         if 0 < i < len(self.times):
             a, b = self.times[i - 1], self.times[i]
             fb = (t - a) / (b - a)
-            fa = 1.0 - fb
-            sd = math.sqrt((t - a) * (b - t) / (b - a))
-            ca, cb = self.terms[a], self.terms[b]
-            out = {k: fa * ca.get(k, 0.0) + fb * cb.get(k, 0.0) for k in ca.keys() | cb.keys()}
+            made = (a, b, 1.0 - fb, fb, math.sqrt((t - a) * (b - t) / (b - a)), node)
         else:
-            # beyond every known time (a query outside [t_lo, t_hi]): an independent increment from the outermost known time -- the
-            # two-sided motion continues; later times between two such points are bridges like any other
-            a, b = (self.times[-1], None) if i else (self.times[0], None)
-            fa, fb, sd = 1.0, 0.0, math.sqrt(abs(t - a))
-            out = dict(self.terms[a])
-        out[node] = sd
+            a = self.times[-1] if i else self.times[0]
+            made = (a, None, 1.0, 0.0, math.sqrt(abs(t - a)), node)
         self.times.insert(i, t)
-        self.terms[t] = out
-        self.bridge[t] = (a, b, fa, fb, sd, node)
-        return out
+        self.bridge[t] = made
+
+    def coefficients(self, t: float) -> dict:
+        """{node id: coefficient} with W(t) = sum coefficient * z(node); defines the point if it is new."""
+        t = float(t)
+        self.define(t)
+        memo = self._memo
+        if len(memo) > self.MEMO:
+            memo.clear()
+        base = {self.t_lo: {}, self.t_hi: {self.ROOT: math.sqrt(self.t_hi - self.t_lo)}}
+        stack = [t]
+        while stack:  # iterative: a monotone run nests its points n deep
+            u = stack[-1]
+            if u in memo or u in base:
+                stack.pop()
+                continue
+            a, b, fa, fb, sd, node = self.bridge[u]
+            need = [p for p in (a, b) if p is not None and p not in memo and p not in base]
+            if need:
+                stack.extend(need)
+                continue
+            ca = memo.get(a, base.get(a))
+            cb = {} if b is None else memo.get(b, base.get(b))
+            out = {k: fa * ca.get(k, 0.0) + fb * cb.get(k, 0.0) for k in ca.keys() | cb.keys()}
+            out[node] = sd
+            memo[u] = out
+            stack.pop()
+        return memo[t] if t in memo else base[t]
 
     def increment(self, t0: float, t1: float):
         """(node ids, coefficients) of (W(t_max) - W(t_min)) / sqrt(t_max - t_min); the smaller time is defined first."""
         ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
         if ta == tb:
             raise ValueError("Brownian noise needs two distinct times")
-        ca, cb = self.coefficients(ta), self.coefficients(tb)
+        self.define(ta)
+        self.define(tb)
+        ca = dict(self.coefficients(ta))  # a copy: the memo may be cleared by the second expansion
+        cb = self.coefficients(tb)
         scale = 1.0 / math.sqrt(tb - ta)
         terms = {k: (cb.get(k, 0.0) - ca.get(k, 0.0)) * scale for k in ca.keys() | cb.keys()}
         terms = {k: v for k, v in terms.items() if abs(v) > 1e-12}
@@ -939,13 +962,13 @@ class BrownianTreeNoiseSampler:
             self._points.pop(next(iter(self._points)))
 
     def _cached(self, t: float, *, cheap: bool = False) -> Optional[Tensor]:
-        """The kept W(t); with ``cheap`` also a point whose expansion is a single normal (the interval's end) is evaluated and kept."""
+        """The kept W(t); with ``cheap`` the interval's end, whose expansion is a single normal, is evaluated and kept when it is not."""
         w = self._points.get(t)
         if w is not None:
             self._remember(t, w)
-        elif cheap and len(self.path.terms.get(t, ())) == 1:
-            (node, coef), = self.path.terms[t].items()
-            _, w = hip_lib.brownian_bridge(self.shape, self.device, [node], [coef], self.seed, self.elem_offset, self.latent_seeds, want_out=False)
+        elif cheap and t == self.path.t_hi:
+            _, w = hip_lib.brownian_bridge(self.shape, self.device, [self.path.ROOT], [math.sqrt(self.path.t_hi - self.path.t_lo)], self.seed,
+                                           self.elem_offset, self.latent_seeds, want_out=False)
             self._remember(t, w)
         return w
 
@@ -998,8 +1021,8 @@ class BrownianTreeNoiseSampler:
             out, _ = self._emit(ids, [c * sign for c in coefs], want_w=False, fold=fold)
             return out
         # out = (W(tb) - W(ta)) / sqrt(tb - ta); both times are defined here, the smaller first, whatever is kept
-        self.path.coefficients(ta)
-        self.path.coefficients(tb)
+        self.path.define(ta)
+        self.path.define(tb)
         scale = sign / math.sqrt(tb - ta)
         wa, wb = self._cached(ta), self._cached(tb)
         if wa is not None and wb is not None:

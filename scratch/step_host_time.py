@@ -18,8 +18,11 @@ for b in (512, 64):
         t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
         print(f"B={b:4d} {name:9s} host {(t1 - t0) / 200 * 1e6:6.1f} us/call   total {(t2 - t0) / 200 * 1e6:6.1f} us/call", flush=True)
 x = torch.zeros(64, 4, 128, 128, device="cuda")
-ns = nz.get_noise_sampler("perlin", x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
-pr = cProfile.Profile(); pr.enable()
-for _ in range(200): ns(*sig)
-pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+for name in sys.argv[1:] or ["perlin"]:
+    ns = item.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True) if name == "power" else nz.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+    for _ in range(20): ns(*sig)
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(200): ns(*sig)
+    pr.disable(); torch.cuda.synchronize()
+    print("=====", name)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(16)

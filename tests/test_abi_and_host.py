@@ -160,4 +160,10 @@ def test_brownian_path_coefficients_are_a_brownian_motion(pkg):
         assert abs(var(c) - (t - 0.03)) < 1e-9
         if k:
             assert abs(cov(c, bp.coefficients(ts[k - 1])) - (t - 0.03)) < 1e-9
-    assert bp.coefficients(ts[40]) is bp.coefficients(ts[40])  # a known time is never redefined
+    assert bp.coefficients(ts[40]) == bp.coefficients(ts[40]) and bp.bridge[ts[40]][5] == 41  # a known time is never redefined
+    # points cost O(1) to define; expansions are made on demand and only a bounded number is remembered
+    long = ng.BrownianPath(0.0, 1.0)
+    for k in range(1, 3000):
+        long.define(1.0 - k / 3001.0)
+    c = long.coefficients(1.0 - 2999 / 3001.0)
+    assert len(c) == 3000 and abs(var(c) - (1.0 - 2999 / 3001.0)) < 1e-9 and len(long._memo) <= long.MEMO + 3000

@@ -299,7 +299,7 @@ def test_brownian_bridge_route_equals_expansion_route(api, seeds):
             if k in (0, 30, 59):
                 n = a.numel()
                 assert abs(a.mean().item()) < 5 / math.sqrt(n) and abs(a.var().item() - 1.0) < 15 / math.sqrt(n)
-    assert len(kept._points) <= kept.CACHE_POINTS and max(len(c) for c in bare.path.terms.values()) > 100
+    assert len(kept._points) <= kept.CACHE_POINTS and len(bare.path.coefficients(float(torch.tensor(sig[55])))) > 100
     assert worst < 2e-5, worst
     # the whole run is one path: the first and the last step's increments, recomposed from the end points, agree with a direct query
     whole = kept(torch.tensor(sig[0]), torch.tensor(sig[60]))
