@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""profiles/rNN_traffic.json from tools/rocpd_traffic.py's per-kernel table (scratch/prof_r02.sh writes it as traffic_raw.json):
+    python tools/make_traffic_json.py gpurun_out/r02/traffic_raw.json > profiles/r02_traffic.json
+Kernels are picked by name fragments; batch-512 and batch-64 launches of one kernel (same name) are split in proportion to the batch."""
+import json
+import sys
+
+N = 4 * 128 * 128 * 4  # bytes of one fp32 SDXL latent
+
+
+def pick(raw, *frags, exclude=()):
+    hits = {k: v for k, v in raw.items() if all(f in k for f in frags) and not any(e in k for e in exclude)}
+    if len(hits) != 1:
+        raise SystemExit(f"{frags}: {len(hits)} kernels match: {sorted(hits)}")
+    return next(iter(hits.values()))
+
+
+def total(*rows):
+    return int(sum(r["hbm_bytes_per_launch"] for r in rows))
+
+
+def main(path):
+    raw = json.load(open(path))
+    out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over scratch/prof_workload.py (scratch/prof_r02.sh, "
+                   "tools/rocpd_traffic.py, tools/make_traffic_json.py); raw counters are KiB per dispatch.  hbm_bytes_per_launch = 2 x FETCH_SIZE + "
+                   "WRITE_SIZE: the gfx950 correction of MI355X_MICROARCH.md, confirmed in the same run by the calibration kernels below "
+                   "(one 134 217 728-byte tensor written / read / read + written)."}
+    out["calibration"] = {k: raw[k] for k in raw if k.startswith(("stream_fill_kernel<", "stats_kernel<", "scale_noise_kernel<"))}
+    scale = pick(raw, "scale_noise_kernel<")
+    st, fin = pick(raw, "power_stats_kernel"), pick(raw, "power_irfft2_kernel<128, 128, 1, false, true>")
+    out["power_noise_b512"] = {"kernels": {"power_stats_kernel<128,128>": st, "power_irfft2_kernel<128,128,GEN,NORM>": fin},
+                               "hbm_bytes_per_launch": total(st, fin), "algorithmic_bytes_4N": 512 * N, "contract_bytes_12N": 3 * 512 * N}
+    sf = pick(raw, "power_irfft2_kernel<128, 128, 2,")
+    out["spectral_filter_b512"] = dict(sf, algorithmic_bytes_8N=2 * 512 * N)
+    # Perlin: lattice + statistics pass + final pass, run equally often at batch 512 and 64 (same kernel names)
+    per = [pick(raw, "perlin_lattice_kernel"), pick(raw, "perlin_generate_kernel<1,"), pick(raw, "perlin_generate_kernel<2,")]
+    both = 2 * total(*per)
+    out["perlin_b512"] = {"hbm_bytes_per_launch": int(both * 512 / 576), "algorithmic_bytes_4N": 512 * N, "contract_bytes_12N": 3 * 512 * N,
+                          "note": "lattice + statistics pass (no stores) + final pass; the workload ran batch 512 and batch 64 equally often, bytes split in proportion to the batch"}
+    out["perlin_b64"] = {"hbm_bytes_per_launch": int(both * 64 / 576), "algorithmic_bytes_4N": 64 * N, "contract_bytes_12N": 3 * 64 * N}
+    pyr = pick(raw, "pyramid_plane_kernel<true, true>")
+    both = 2 * pyr["hbm_bytes_per_launch"]
+    out["pyramid_b512"] = {"hbm_bytes_per_launch": int(both * 512 / 576) + 2 * 512 * N,
+                           "kernels": {"pyramid_plane_kernel": int(both * 512 / 576), "scale_noise_kernel (in place, read + write)": 2 * 512 * N},
+                           "algorithmic_bytes_12N": 3 * 512 * N,
+                           "note": "generate pass with statistics (one write) + in-place scale_noise (calibrated read + write above); plane kernel bytes split by batch"}
+    out["pyramid_b64"] = {"hbm_bytes_per_launch": int(both * 64 / 576) + 2 * 64 * N, "algorithmic_bytes_12N": 3 * 64 * N}
+    mom = pick(raw, "EulerOp")
+    out["momentum_euler_b512"] = dict(mom, algorithmic_bytes_20N=5 * 512 * N, note="x, denoised, history in; x', history' out")
+    for tag, T in (("fp64", "double"), ("fp32", "float")):
+        low = pick(raw, f"wcfg_lowpass_kernel<{T},")
+        out[f"wcfg_lowpass_{tag}_b256"] = dict(low, algorithmic_bytes_16N=4 * 256 * N, ratio_to_16N=round(low["hbm_bytes_per_launch"] / (4 * 256 * N), 2),
+                                               note="cond and uncond are read twice (analysis, then the output phase); the second read mostly comes out of the "
+                                                    "256 MB memory-side cache: removing it (profiling build) saves 8-10 us of the kernel's 97 / 112 us")
+        for route, mode, deep in (("bands_difference", "2", "true"), ("bands_pair", "1", "false")):
+            ks = {"dwt2_tile_kernel (level 1 analysis)": pick(raw, f"dwt2_tile_kernel<{T}, float, {mode},"),
+                  "wcfg_deep_kernel (levels 2..5)": pick(raw, f"wcfg_deep_kernel<{T},", f", {deep}>"),
+                  "idwt2_tile_kernel (level 1 synthesis + output)": pick(raw, f"idwt2_tile_kernel<{T}, {mode},")}
+            tot = total(*ks.values())
+            out[f"wcfg_{route}_{tag}_b256"] = {"kernels": ks, "hbm_bytes_per_launch": tot, "algorithmic_bytes_16N": 4 * 256 * N,
+                                               "ratio_to_16N": round(tot / (4 * 256 * N), 2)}
+    br = pick(raw, "brownian_burst_kernel")
+    out["brownian_bridge_cfg5_shard"] = dict(br, tensor_bytes=128 * 16 * 128 * 128 * 4,
+                                             note="128 x 16 x 128 x 128: reads the kept neighbour tensor(s), writes W(t) and the increment (or reads and "
+                                                  "writes the chain's running sum): 3-4 tensors per call")
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
