@@ -25,6 +25,7 @@ Prints ONE JSON line (rank 0).  Keys beyond the contract:
 from __future__ import annotations
 
 import argparse
+import datetime
 import importlib
 import json
 import math
@@ -266,7 +267,8 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # a collective that hangs ends the process after two minutes instead of holding the node
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=120))
             dist.barrier()
         finally:
             os.dup2(saved_stdout, 1)
@@ -322,28 +324,6 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = t.item()
 
-        gather = None
-        if distributed:
-            # optional final gather, outside `value`: RCCL all-gather vs direct peer-to-peer copies over xGMI
-            par = importlib.import_module("comfyui_sonar_amd.parallel")
-            shard = step()
-            gather = {}
-            for tag, direct in (("rccl_all_gather", False), ("direct_peer_copies", True)):
-                try:
-                    par.gather_batch(shard, BATCH * world, direct=direct)
-                    torch.cuda.synchronize()
-                    dist.barrier()
-                    g0 = time.perf_counter()
-                    for _ in range(5):
-                        par.gather_batch(shard, BATCH * world, direct=direct)
-                    torch.cuda.synchronize()
-                    gt = torch.tensor([(time.perf_counter() - g0) / 5], device=device, dtype=torch.float64)
-                    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-                    gather[tag + "_ms"] = gt.item() * 1e3
-                    gather[tag + "_GBps_per_rank_in"] = shard.numel() * 4 * (world - 1) / gt.item() / 1e9
-                except Exception as exc:
-                    gather[tag + "_error"] = repr(exc)[:200]
-
         if rank == 0:
             value = n_gpus * BATCH * args.steps / elapsed
             pair_us = span_ms / args.steps * 1e3
@@ -374,8 +354,6 @@ def main():
                 "path": {"step_GBps_real_4N": real_bytes / step_s / 1e9, "step_GBps_at_12N": contract_bytes / step_s / 1e9,
                          "host_us_per_step_beyond_gpu": max(0.0, step_s * 1e6 - pair_us)},
             }
-            if gather:
-                out["gather"] = gather
     if rank == 0 and n_gpus == 1 and not args.no_extra:
         kernels, extra = secondary_rows(device, hl, pn, ng, nz, x, sig)
         out["roofline"]["kernels"] = kernels
@@ -383,8 +361,37 @@ def main():
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
+        # optional final gather, outside `value` and AFTER the result line is out (reported on stderr): RCCL all-gather
+        # vs direct peer-to-peer copies over xGMI.  Every rank learns whether all ranks succeeded before the next collective.
+        par = importlib.import_module("comfyui_sonar_amd.parallel")
+        with ng.shard_offset(rank * BATCH):
+            shard = ns(*sig)
+        gather = {}
+        for tag, direct in (("rccl_all_gather", False), ("direct_peer_copies", True)):
+            ok, secs = 1.0, 0.0
+            try:
+                par.gather_batch(shard, BATCH * world, direct=direct)
+                torch.cuda.synchronize()
+                g0 = time.perf_counter()
+                for _ in range(5):
+                    par.gather_batch(shard, BATCH * world, direct=direct)
+                torch.cuda.synchronize()
+                secs = (time.perf_counter() - g0) / 5
+            except Exception as exc:
+                ok = 0.0
+                gather[tag + "_error"] = repr(exc)[:200]
+            gt = torch.tensor([secs, -ok], device=device, dtype=torch.float64)
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)  # slowest rank; -ok is 0 if any rank failed
+            if gt[1].item() == -1.0:
+                gather[tag + "_ms"] = gt[0].item() * 1e3
+                gather[tag + "_GBps_per_rank_in"] = shard.numel() * 4 * (world - 1) / gt[0].item() / 1e9
+            else:
+                gather.setdefault(tag + "_error", "failed on another rank")
+                break
+        if rank == 0:
+            print("[bench] gather (outside value): " + json.dumps(gather), file=sys.stderr, flush=True)
         dist.barrier()
         dist.destroy_process_group()
 
