@@ -11,6 +11,10 @@ in-kernel, nothing read from HBM but the 33 KB filter).  N > 1: one process per 
 shard of one logical N*512 batch (weak scaling, no data-path collective; shard-invariant counters) — the only collectives are the
 timing barrier / max, and, outside `value`, the optional final gather (RCCL all-gather vs direct peer copies).
 
+Before the W warm-up steps the contract asks for, `--prewarm` (default 1000) untimed steps bring the GPU to its sustained clocks:
+the step time falls from ~67 us in the first milliseconds of a process to 60.5 us after ~30 ms of work and stays there
+(scratch/warm_curve.py); `config.prewarm_steps` records it.  `--prewarm 0` measures the cold figure.
+
 Prints ONE JSON line (rank 0).  Keys beyond the contract:
   roofline      the dominant launch pair (statistics pass + final pass of one C-ABI call), HIP-event timed on the launch stream
                 inside the timed region.  `achieved` / `frac` are at the bytes the kernels REALLY move (4N per latent: one write;
@@ -249,6 +253,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--prewarm", type=int, default=1000,
+                    help="untimed steps before the W warm-up steps: the GPU reaches its sustained clocks after ~30 ms of work "
+                         "(scratch/warm_curve.py: 67 us per step cold, 60.5 us from step ~400 on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -304,6 +311,9 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         ev1.record()
+        for _ in range(max(args.prewarm, 0)):  # clock ramp, outside the W + K steps of the contract
+            step()
+        torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -339,7 +349,7 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "cfg2: power-law (pink, alpha=1) rFFT noise, normalised, SDXL 4x128x128, batch 512 per GPU, "
-                                       "generate mode (in-kernel Philox-seeded xoshiro128++)", "batch_per_gpu": BATCH, "global_batch": BATCH * n_gpus,
+                                       "generate mode (in-kernel Philox-seeded xoshiro128++)", "batch_per_gpu": BATCH, "global_batch": BATCH * n_gpus, "prewarm_steps": max(args.prewarm, 0),
                            "parallelism": f"batch-shard x{n_gpus}"},
                 "roofline": {"bound": "valu", "limiter": "vector-ALU issue + LDS / barrier latency (per-pass timings and counters: profiles/r02_power_kernel.md); "
                                                          "HBM moves 4N per latent and would allow ~21 us per launch",
