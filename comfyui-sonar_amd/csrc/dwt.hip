@@ -288,10 +288,10 @@ template <typename T, bool HEAD = false>
 static int wcfg_band(const T* cond, const T* uncond, T* out, int64_t n, int64_t group_size, int64_t groups, const double* s_cond,
                      const double* s_uncond, const double* s_diff, const double* s_final, int blend_mode, double strength,
                      hipStream_t st, const char* what) {
-    SONAR_REQUIRE(cond && uncond && out && n >= 0 && groups >= 1 && groups <= 4 && group_size > 0 && blend_mode >= 0 && blend_mode <= 2,
+    SONAR_REQUIRE(cond && uncond && out && n >= 0 && groups >= 1 && groups <= kMaxBandGroups && group_size > 0 && blend_mode >= 0 && blend_mode <= 2,
                   SONAR_ERR_ARG, "%s: bad argument", what);
     BandScales<T> sc;
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < kMaxBandGroups; ++g) {
         const bool in = g < (HEAD ? 1 : groups);
         sc.cond[g] = in && s_cond ? (T)s_cond[g] : T(1);
         sc.uncond[g] = in && s_uncond ? (T)s_uncond[g] : T(1);

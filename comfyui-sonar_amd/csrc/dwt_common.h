@@ -75,9 +75,10 @@ __device__ __forceinline__ T synth(const T* __restrict__ a, int64_t sa, const T*
 }
 
 // ---- WaveletCFG band arithmetic
+constexpr int kMaxBandGroups = 8;  // orientations per band: 3 (DWT), 6 (dual-tree complex transform)
 template <typename T>
 struct BandScales {
-    T cond[4], uncond[4], diff[4], fin[4];
+    T cond[kMaxBandGroups], uncond[kMaxBandGroups], diff[kMaxBandGroups], fin[kMaxBandGroups];
 };
 
 // blend(u * s_u, (c * s_c - u * s_u) * s_d, strength) * s_f  (py/wavelet_cfg.py:765-787), scales of 1 are skipped like the reference's `!= 1.0` tests

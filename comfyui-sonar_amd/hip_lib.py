@@ -144,6 +144,12 @@ SIGNATURES = {
     "sonar_wcfg_lowpass_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
     "sonar_minmax_rescale_f32": (_I, [_P, _I64, _I64, _P, _P, _F, _F, _F, _P, _P]),
+    "sonar_axis_taps_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _I, _I, _P]),
+    "sonar_axis_taps_f64": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _I, _I, _P]),
+    "sonar_dtcwt_q2c_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "sonar_dtcwt_c2q_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "sonar_dtcwt_q2c_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "sonar_dtcwt_c2q_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_max_to_host_f32": (_I, [_P, _I64, C.POINTER(C.c_float), _P]),
     "sonar_wcfg_fused_ws_bytes": (_I64, [_I64, _I64, _I64, _I, _I, _I, _I, _I, _I]),
     "sonar_wcfg_fused_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _I, _P, _I64, _P]),
@@ -978,7 +984,8 @@ def wcfg_band(cond: torch.Tensor, uncond: torch.Tensor, groups: int, s_cond, s_u
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     kind = _wavelet_dtype(cond)
     out = torch.empty_like(cond) if out is None else out
-    group_size = cond.shape[-1] * cond.shape[-2]
+    # elements that share a scale: h * w of a [B, C, groups, h, w] band (h * w * 2 of a DTCWT band [B, C, 6, h, w, 2])
+    group_size = math.prod(cond.shape[3:]) if cond.ndim >= 5 else cond.shape[-1] * cond.shape[-2]
     fn = load().sonar_wcfg_band_f32 if kind == "f32" else load().sonar_wcfg_band_f64
 
     def arr(v):
@@ -1074,6 +1081,51 @@ def _taps_arr(vals):
             _TAPS.clear()
         hit = _TAPS[key] = _darr(key)
     return hit
+
+
+def axis_taps(x: torch.Tensor, idx: torch.Tensor, coef: torch.Tensor, axis: int, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """out[..., j, ...] (+)= sum_k coef[j, k] * x[..., idx[j, k], ...] along ``axis`` (-2 or -1) of a contiguous fp32 / fp64 tensor."""
+    kind = _wavelet_dtype(x)
+    if axis not in (-1, -2) or x.ndim < 2 or not x.is_contiguous() or coef.dtype != x.dtype or idx.dtype != torch.int32:
+        raise SonarHipError("axis_taps: a contiguous tensor, axis -1 / -2 and tables of matching type are required")
+    n_out, taps = idx.shape
+    n_in = x.shape[axis]
+    inner = x.shape[-1] if axis == -2 else 1
+    outer = x.numel() // (n_in * inner)
+    shape = list(x.shape)
+    shape[axis] = n_out
+    if out is None:
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    elif list(out.shape) != shape or not out.is_contiguous() or out.dtype != x.dtype:
+        raise SonarHipError("axis_taps: output shape mismatch")
+    fn = load().sonar_axis_taps_f32 if kind == "f32" else load().sonar_axis_taps_f64
+    _check(fn(_dev(x, "x", x.dtype), _dev(out, "out", x.dtype), outer, n_in, n_out, inner, idx.data_ptr(), _dev(coef, "coef", x.dtype), taps,
+              int(bool(accumulate)), _stream()), f"sonar_axis_taps_{kind}")
+    return out
+
+
+def dtcwt_q2c(lh: torch.Tensor, hh: torch.Tensor, hl: torch.Tensor) -> torch.Tensor:
+    """Three [B, C, 2h, 2w] planes -> [B, C, 6, h, w, 2] complex bands (orientation order 15 .. 165 degrees)."""
+    kind = _wavelet_dtype(lh)
+    B, Cc, H2, W2 = lh.shape
+    out = torch.empty((B, Cc, 6, H2 // 2, W2 // 2, 2), dtype=lh.dtype, device=lh.device)
+    fn = load().sonar_dtcwt_q2c_f32 if kind == "f32" else load().sonar_dtcwt_q2c_f64
+    _check(fn(_dev(lh, "lh", lh.dtype), _dev(hh, "hh", lh.dtype), _dev(hl, "hl", lh.dtype), _dev(out, "bands", lh.dtype), B * Cc, H2 // 2, W2 // 2,
+              _stream()), f"sonar_dtcwt_q2c_{kind}")
+    return out
+
+
+def dtcwt_c2q(bands: torch.Tensor):
+    """[B, C, 6, h, w, 2] -> (lh, hh, hl), each [B, C, 2h, 2w]."""
+    kind = _wavelet_dtype(bands)
+    B, Cc, six, h, w, two = bands.shape
+    if six != 6 or two != 2:
+        raise SonarHipError("dtcwt_c2q: bands must be [B, C, 6, h, w, 2]")
+    bands = bands.contiguous()
+    outs = [torch.empty((B, Cc, 2 * h, 2 * w), dtype=bands.dtype, device=bands.device) for _ in range(3)]
+    fn = load().sonar_dtcwt_c2q_f32 if kind == "f32" else load().sonar_dtcwt_c2q_f64
+    _check(fn(_dev(bands, "bands", bands.dtype), *[_dev(o, "plane", bands.dtype) for o in outs], B * Cc, h, w, _stream()), f"sonar_dtcwt_c2q_{kind}")
+    return tuple(outs)
 
 
 def minmax_rescale(x: torch.Tensor, rows: int, inner: int, lo: torch.Tensor, hi: torch.Tensor, eps: float, target_min: float,

@@ -665,8 +665,8 @@ class WaveletCFG:
         if ctx.cond.ndim != 4 or ctx.cond.dtype != torch.float32 or ctx.uncond.dtype != torch.float32 or ctx.dtype not in (torch.float32, torch.float64):
             return None
         levels = w.level
-        if levels < 1:
-            return None
+        if levels < 1 or getattr(w, "use_dtcwt", False):
+            return None  # the dual-tree transform goes band by band (wavelet_cfg_raw)
 
         fake_yh = [_BandShape] * levels
         tabs = {name: rule.scale_table(name, pcts, fake_yh) for name in ("cond", "uncond", "diff", "final")}
@@ -766,7 +766,8 @@ class WaveletCFG:
             out_yh = [hip_lib.wcfg_band_head(c, u, *[head(s) for s in band_scales(j)], mode, strength, out=c)
                       for j, (c, u) in enumerate(zip(condw[1], uncondw[1]))]
         else:
-            out_yh = [hip_lib.wcfg_band(c, u, 3, *band_scales(j), mode, strength, out=c) for j, (c, u) in enumerate(zip(condw[1], uncondw[1]))]
+            # groups = orientations per band: 3 for the DWT's [B, C, 3, h, w], 6 for the dual-tree transform's [B, C, 6, h, w, 2]
+            out_yh = [hip_lib.wcfg_band(c, u, c.shape[2], *band_scales(j), mode, strength, out=c) for j, (c, u) in enumerate(zip(condw[1], uncondw[1]))]
         return ctx.wavelet.inverse(yl, out_yh)
 
     @classmethod

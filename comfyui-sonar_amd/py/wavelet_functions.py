@@ -35,9 +35,10 @@ def _taps(name: str) -> dict:
 
 
 class Wavelet:
-    """py/wavelet_functions.py:23-145: the 2-D DWT and the 1-D DWT (``use_1d_dwt``, [B, C, L] inputs; yh[j] is then [B, C, l_j]).
-    DTCWT is not built: its biort / qshift filter banks live in the ``dtcwt`` data files of the absent, unpinned
-    ``pytorch_wavelets`` dependency and cannot be restated or pinned here."""
+    """py/wavelet_functions.py:23-145: the 2-D DWT, the 1-D DWT (``use_1d_dwt``, [B, C, L] inputs; yh[j] is then [B, C, l_j]) and the
+    dual-tree complex transform (``use_dtcwt``: ``py/dtcwt.py``, yh[j] [B, C, 6, h_j, w_j, 2]; the published algorithm with the
+    `near_sym_a` / `legall` and `qshift_a` filter banks -- the other banks are data files of the absent ``pytorch_wavelets`` / ``dtcwt``
+    packages and raise; parity unpinned)."""
 
     DEFAULT_MODE = "symmetric"
     DEFAULT_LEVEL = 3
@@ -51,9 +52,18 @@ class Wavelet:
                  use_1d_dwt: bool = DEFAULT_USE_1D_DWT, use_dtcwt: bool = DEFAULT_USE_DTCWT, biort: str = DEFAULT_BIORT,
                  qshift: str = DEFAULT_QSHIFT, inv_wave: Optional[str] = None, inv_mode: Optional[str] = None,
                  inv_biort: Optional[str] = None, inv_qshift=None, device=None):
-        if use_dtcwt:
-            raise NotImplementedError("the DTCWT variant is not built: its filter banks are unavailable here (SURVEY.md §8c / §8f rank 4)")
-        self.use_1d_dwt = bool(use_1d_dwt)
+        self.use_dtcwt = bool(use_dtcwt)
+        self.use_1d_dwt = bool(use_1d_dwt) and not self.use_dtcwt  # the reference tests use_dtcwt first (:56-61)
+        if self.use_dtcwt:
+            from .dtcwt import DTCWT
+
+            if mode != "symmetric" or fallback(inv_mode, mode) != "symmetric":
+                raise NotImplementedError("DTCWT: symmetric extension only (pytorch_wavelets' default)")
+            self.level, self.mode, self.inv_mode = int(level), mode, fallback(inv_mode, mode)
+            self.wave = self.inv_wave = None  # no (dec, rec) tap pair: the DWT fast paths of WaveletCFG do not apply
+            self._dt = DTCWT(level=self.level, biort=biort, qshift=qshift, inv_biort=inv_biort, inv_qshift=inv_qshift)
+            self.device, self.dtype = device, None
+            return
         if mode not in hip_lib.DWT_MODE_IDS or fallback(inv_mode, mode) not in hip_lib.DWT_MODE_IDS:
             raise ValueError(f"Unknown padding mode {mode!r}; valid: {', '.join(self.modelist())}")
         self.level = int(level)
@@ -70,6 +80,8 @@ class Wavelet:
         """DWTForward(J=level): returns (yl, [yh_0 (finest), ..., yh_{J-1}])."""
         if forward_function is not None:
             return forward_function(t)
+        if getattr(self, "use_dtcwt", False):
+            return self._dt.forward(t)
         one_d = getattr(self, "use_1d_dwt", False)
         if t.ndim != (3 if one_d else 4):
             raise hip_lib.SonarHipError("Wavelet.forward expects a [B, C, L] tensor in 1-D mode" if one_d else "Wavelet.forward expects a [B, C, H, W] tensor")
@@ -82,6 +94,8 @@ class Wavelet:
         return ll, yh
 
     def _inverse(self, yl: torch.Tensor, yh: Sequence) -> torch.Tensor:
+        if getattr(self, "use_dtcwt", False):
+            return self._dt.inverse((yl, tuple(yh)))
         step = hip_lib.dwt1_inverse if getattr(self, "use_1d_dwt", False) else hip_lib.dwt2_inverse
         ll = yl.contiguous()
         for hi in reversed(tuple(yh)):

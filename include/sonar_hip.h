@@ -386,9 +386,9 @@ int sonar_dwt1_inv_f32(const float* lo, int64_t lo_len, const float* hi, float* 
 int sonar_dwt1_inv_f64(const double* lo, int64_t lo_len, const double* hi, double* out, int64_t rows, int64_t n, int64_t Lo,
                        const double* rec_lo, const double* rec_hi, int flen, int mode, void* stream);
 /* WaveletCFG band arithmetic, py/wavelet_cfg.py:750-791, for one band tensor of n elements whose element i
- * belongs to orientation group g = (i / group_size) % groups (groups = 3 for yh[B,C,3,h,w], 1 for yl):
+ * belongs to orientation group g = (i / group_size) % groups (groups = 3 for yh[B,C,3,h,w], 6 for the dual-tree transform's [B,C,6,h,w,2] with group_size = 2 h w, 1 for yl):
  *   c = cond*s_cond[g]; u = uncond*s_uncond[g]; d = (c-u)*s_diff[g]; out = blend(u, d, strength)*s_final[g]
- * s_* are HOST arrays of `groups` (<= 4) doubles; multiplications by exactly 1 are skipped like the reference. */
+ * s_* are HOST arrays of `groups` (<= 8) doubles; multiplications by exactly 1 are skipped like the reference. */
 int sonar_wcfg_band_f32(const float* cond, const float* uncond, float* out, int64_t n, int64_t group_size,
                         int64_t groups, const double* s_cond, const double* s_uncond, const double* s_diff,
                         const double* s_final, int blend_mode, double strength, void* stream);
@@ -428,6 +428,23 @@ int sonar_wcfg_fused_f64(const float* cond, const float* uncond, const float* x,
                          const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,
                          int blend_mode, double strength, int subtract_from_x, int perfect_reconstruction, void* ws, int64_t ws_bytes,
                          void* stream);
+/* ---------------------------------------------------------------- DTCWT (row 8f-4)
+ * The dual-tree complex wavelet transform the reference reaches through pytorch_wavelets' DTCWTForward / DTCWTInverse
+ * (py/wavelet_functions.py:56-73; Kingsbury's dtwavexfm2 / dtwaveifm2).  Each of its stages (odd-length filters with symmetric
+ * extension, decimating / interpolating dual-tree filters) is a sparse linear map along one axis with `taps` terms per output row:
+ *   out[o][j][i] (+)= sum_k coef[j][k] * x[o][idx[j][k]][i],  o < outer, j < n_out, i < inner
+ * idx [n_out][taps] (int32) / coef [n_out][taps]: DEVICE tables built once per length by the host (py/dtcwt.py).  x != out. */
+int sonar_axis_taps_f32(const float* x, float* out, int64_t outer, int64_t n_in, int64_t n_out, int64_t inner, const int* idx,
+                        const float* coef, int taps, int accumulate, void* stream);
+int sonar_axis_taps_f64(const double* x, double* out, int64_t outer, int64_t n_in, int64_t n_out, int64_t inner, const int* idx,
+                        const double* coef, int taps, int accumulate, void* stream);
+/* q2c / c2q: three real planes lh, hh, hl [planes][2h][2w] <-> bands [planes][6][h][w][2] (orientations 15, 45, 75, 105, 135, 165
+ * degrees, last axis re / im): quad (a b / c d) <-> ((a - d) + i (b + c)) / sqrt 2 and ((a + d) + i (b - c)) / sqrt 2; lh feeds
+ * orientations (0, 5), hh (1, 4), hl (2, 3). */
+int sonar_dtcwt_q2c_f32(const float* lh, const float* hh, const float* hl, float* bands, int64_t planes, int64_t h, int64_t w, void* stream);
+int sonar_dtcwt_c2q_f32(const float* bands, float* lh, float* hh, float* hl, int64_t planes, int64_t h, int64_t w, void* stream);
+int sonar_dtcwt_q2c_f64(const double* lh, const double* hh, const double* hl, double* bands, int64_t planes, int64_t h, int64_t w, void* stream);
+int sonar_dtcwt_c2q_f64(const double* bands, double* lh, double* hh, double* hl, int64_t planes, int64_t h, int64_t w, void* stream);
 /* max over a non-empty device vector with torch.max's NaN rule, returned to the host: WaveletCFG's `sigma.max().item()`
  * (py/wavelet_cfg.py:795-796) as one launch that writes into pinned host memory + one stream wait.  BLOCKS until the stream drains
  * (as `.item()` does). */
