@@ -4,8 +4,8 @@
 pytorch_wavelets and its filter-bank data files are not part of the reference (un-vendored, absent): **parity unpinned**.  The
 algorithm and the filter banks are the published ones -- `near_sym_a` (5 / 7 taps) and `legall` (5 / 3) in closed form, `qshift_a`
 (10 taps) from the published coefficients -- and are tested by their defining properties: perfect reconstruction, orthonormal shifts /
-half-band products of the filters, orientation selectivity of the six subbands, agreement with the numpy restatement in
-``oracle/dtcwt_oracle.py``.  Layout as pytorch_wavelets documents it: ``yl [B, C, H / 2**(J-1), W / 2**(J-1)]`` and
+half-band products of the filters, orientation selectivity of the six subbands, agreement with a plain numpy restatement kept with
+the tests.  Layout as pytorch_wavelets documents it: ``yl [B, C, H / 2**(J-1), W / 2**(J-1)]`` and
 ``yh[j] [B, C, 6, h_j, w_j, 2]`` (orientations 15, 45, 75, 105, 135, 165 degrees; last axis real / imaginary), finest level first.
 
 Every stage is a sparse linear map along one axis; the host builds its (source index, coefficient) table for a given length once (numpy,
