@@ -1136,14 +1136,12 @@ def minmax_rescale(x: torch.Tensor, rows: int, inner: int, lo: torch.Tensor, hi:
     return out
 
 
-_MAX_SLOT = C.c_float()
-
-
 def max_to_host(x: torch.Tensor) -> float:
     """``x.max().item()`` for a non-empty fp32 device tensor (NaN if any element is NaN) in one launch and one stream wait."""
     x = x.contiguous()
-    _check(load().sonar_max_to_host_f32(_dev(x, "x"), x.numel(), C.byref(_MAX_SLOT), _stream()), "sonar_max_to_host_f32")
-    return _MAX_SLOT.value
+    slot = C.c_float()  # per call: the sampler thread and a preview thread may both be in here
+    _check(load().sonar_max_to_host_f32(_dev(x, "x"), x.numel(), C.byref(slot), _stream()), "sonar_max_to_host_f32")
+    return slot.value
 
 
 def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], *, levels: int, dec_lo, dec_hi, mode: str, rec_lo, rec_hi,

@@ -13,7 +13,6 @@ below) and ``sonar_axis_taps_*`` applies it on the device.  The quad <-> complex
 """
 from __future__ import annotations
 
-import math
 from typing import Sequence
 
 import numpy as np
