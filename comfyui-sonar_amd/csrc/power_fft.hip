@@ -839,8 +839,24 @@ __global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(co
         const GroupWalk gw(unit, group, split);
         SpectrumRng rng = spectrum_rng<H, false>(seed, stream_id, plane_offset / group + gw.grp, tid);
         for (int i = 0; i < gw.first; ++i) skip_plane<H, W, false>(rng, tid);
-        for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
+        // The planes of a group meet the same weight at the same slot, so sum_planes w log2 u = w log2(prod_planes u): ONE logarithm per
+        // slot and group instead of one per plane (a group has at most 4 planes: the product of four u in [2^-23, 1] stays a normal float,
+        // and its rounding error, 3 x 2^-24 relative, is below the logarithm's own).
+        float prod[2 * ITER];
+#pragma unroll
+        for (int it = 0; it < 2 * ITER; ++it) prod[it] = 1.0f;
+        int in_prod = 0;
+        auto flush = [&]() {
             float acc = 0.0f;
+#pragma unroll
+            for (int it = 0; it < 2 * ITER; ++it) {
+                acc = __builtin_fmaf(wgt[it], __builtin_amdgcn_logf(prod[it]), acc);
+                prod[it] = 1.0f;
+            }
+            q += 2.0 * (double)acc;
+            in_prod = 0;
+        };
+        for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
             draw_plane<H, W, false>(
                 rng, tid,
                 [&](uint32_t r0, uint32_t rm, uint32_t t) {
@@ -848,14 +864,15 @@ __global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(co
                     EDGE[par][1][tid] = drawn_elem(rm, t >> 16, fm);
                 },
                 [&](int it, int, uint32_t ra, uint32_t rb, uint32_t) {
-                    acc = __builtin_fmaf(wgt[it], __builtin_amdgcn_logf(2.0f - unit_mantissa(ra)), acc);
-                    acc = __builtin_fmaf(wgt[it + ITER], __builtin_amdgcn_logf(2.0f - unit_mantissa(rb)), acc);
+                    prod[it] *= 2.0f - unit_mantissa(ra);
+                    prod[it + ITER] *= 2.0f - unit_mantissa(rb);
                 });
-            q += 2.0 * (double)acc;
+            if (++in_prod == 4) flush();
             __syncthreads();           // this plane's edge columns are complete; the other buffer's readers finished last iteration
             edge_terms(par);           // overlaps with the next plane's draw (which writes the other buffer)
             par ^= 1;
         }
+        if (in_prod) flush();
     }
     write_partial<NT>(s, q, partials, red);
 }
