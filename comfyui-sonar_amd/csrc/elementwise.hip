@@ -752,10 +752,70 @@ __device__ __forceinline__ float momentum_d(const sonar_momentum_cfg& c, HistSta
     return c.use_momentum ? md : d;
 }
 
+// A noise tensor whose global normalisation (py/utils.py:100-105) is still pending: the decision -- taken on the device from the
+// tensor's (sum, sumsq) partials by sonar_norm_decision_f32 -- rides along and the step kernel that consumes the noise applies it on
+// the fly, with scale_noise_kernel's own operation sequence (subtract, divide, multiply: same bits), instead of a separate read +
+// write of the tensor.
+// The quotient v / std without the ten-instruction IEEE division sequence per element: std is the same for every element, so its
+// correctly rounded reciprocal is taken once (sonar_norm_decision_f32) and one residual step q' = q + (v - std q) / std on q = v / std
+// gives the correctly rounded quotient (Markstein: exact remainder by fma, correctly rounded reciprocal) for every v in the normal
+// range -- the same bits as scale_noise_kernel's `v / std`, at three instructions.
+struct PendingNorm {  // one thread's copy of the decision (read once per item, not once per element)
+    float mean, stdv, inv_std, factor;
+    bool sub, div, mul;
+    __device__ __forceinline__ explicit PendingNorm(const sonar_noise_norm* __restrict__ nn) {
+        if (nn) {
+            mean = nn->mean; stdv = nn->stdv; inv_std = nn->inv_std; factor = nn->factor;
+            sub = nn->do_sub != 0; div = nn->do_div != 0; mul = factor != 1.0f;
+        } else {
+            mean = 0.0f; stdv = inv_std = factor = 1.0f;
+            sub = div = mul = false;
+        }
+    }
+    __device__ __forceinline__ float operator()(float v) const {
+        if (sub) v = v - mean;
+        if (div) {
+            const float q = v * inv_std;
+            v = __builtin_fmaf(__builtin_fmaf(-stdv, q, v), inv_std, q);
+        }
+        if (mul) v = v * factor;
+        return v;
+    }
+};
+
+__global__ void __launch_bounds__(kBlock) norm_decision_kernel(const double* __restrict__ partials, int64_t npart, int64_t n_total, float factor,
+                                                                float thr_sd, sonar_noise_norm* out) {
+    __shared__ double red[2 * kBlock / 64];
+    __shared__ NormDecision sh;
+    const NormDecision d = decide_norm<kBlock>(partials, npart, n_total, thr_sd, red, &sh);
+    if (threadIdx.x == 0) {
+        out->mean = d.mean;
+        out->stdv = d.stdv;
+        out->inv_std = 1.0f / d.stdv;  // correctly rounded (IEEE division), once
+        out->factor = factor;
+        out->do_sub = d.do_sub;
+        out->do_div = d.do_div;
+    }
+}
+
+struct ApplyNormOp {
+    float* x;
+    const sonar_noise_norm* nn;
+    template <int V>
+    __device__ __forceinline__ void run(int64_t i) const {
+        Pack<V> p = load<V>(x, i);
+        const PendingNorm pending(nn);
+#pragma unroll
+        for (int k = 0; k < V; ++k) p.v[k] = pending(p.v[k]);
+        store<V>(x, i, p);
+    }
+};
+
 struct EulerOp {
     const float *x, *den, *h_in;
     float *x_out, *h_out;
     const float* noise;
+    const sonar_noise_norm* noise_norm;
     float noise_scale, sigma, dt;
     sonar_momentum_cfg c;
     template <int V>
@@ -765,6 +825,7 @@ struct EulerOp {
         if (h_in) ph = load<V>(h_in, i);
         if (noise) pn = load<V>(noise, i);
         const bool early = c.momentum == 1.0f || c.mode == SONAR_MODE_DENOISED;
+        const PendingNorm pending(noise_norm);
         bool present = false;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -773,7 +834,7 @@ struct EulerOp {
             const float d = (px.v[k] - den_m) / sigma;  // to_d
             const float md = momentum_d(c, hs, early, px.v[k], den_m, sigma, d);
             float xn = md * dt + px.v[k];
-            if (noise) xn = xn + pn.v[k] * noise_scale;
+            if (noise) xn = xn + pending(pn.v[k]) * noise_scale;
             rx.v[k] = xn;
             rh.v[k] = hs.h;
             present = hs.present;
@@ -787,6 +848,7 @@ struct Dpmpp1Op {
     const float *x, *den, *h_in;
     float *x2_out, *md1_out, *h_out;
     const float* noise;
+    const sonar_noise_norm* noise_norm;
     float noise_scale, sigma, expm1_a, ratio_a;
     int adj_is_one;
     sonar_momentum_cfg c;
@@ -797,6 +859,7 @@ struct Dpmpp1Op {
         if (h_in) ph = load<V>(h_in, i);
         if (noise) pn = load<V>(noise, i);
         const bool early = adj_is_one || c.mode == SONAR_MODE_DENOISED;
+        const PendingNorm pending(noise_norm);
         bool present = false;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -805,7 +868,7 @@ struct Dpmpp1Op {
             const float diff2 = expm1_a * md1;
             const float m_d = momentum_d(c, hs, early, px.v[k], md1, sigma, diff2);
             float x2 = ratio_a * px.v[k] - m_d;
-            if (noise) x2 = x2 + pn.v[k] * noise_scale;
+            if (noise) x2 = x2 + pending(pn.v[k]) * noise_scale;
             rx.v[k] = x2;
             rm.v[k] = md1;
             rh.v[k] = hs.h;
@@ -821,6 +884,7 @@ struct Dpmpp2Op {
     const float *x, *den2, *md1, *h_in;
     float *x_out, *dd_out, *h_out;
     const float* noise;
+    const sonar_noise_norm* noise_norm;
     float noise_scale, sigma_s, expm1_b, ratio_b, fac;
     int adj_is_one;
     sonar_momentum_cfg c;
@@ -832,6 +896,7 @@ struct Dpmpp2Op {
         if (noise) pn = load<V>(noise, i);
         const bool early = adj_is_one || c.mode == SONAR_MODE_DENOISED;
         const float one_minus_fac = 1.0f - fac;
+        const PendingNorm pending(noise_norm);
         bool present = false;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -841,7 +906,7 @@ struct Dpmpp2Op {
             const float diff1 = expm1_b * dd;
             const float m_d = momentum_d(c, hs, early, px.v[k], md2, sigma_s, diff1);
             float xn = ratio_b * px.v[k] - m_d;
-            if (noise) xn = xn + pn.v[k] * noise_scale;
+            if (noise) xn = xn + pending(pn.v[k]) * noise_scale;
             rx.v[k] = xn;
             rd.v[k] = dd;
             rh.v[k] = hs.h;
@@ -1312,21 +1377,22 @@ static bool cfg_ok(const sonar_momentum_cfg* c) {
 
 extern "C" int sonar_momentum_euler_f32(const float* x, const float* denoised, const float* h_in, float* x_out,
                                         float* h_out, const float* noise, float noise_scale, float sigma, float dt,
-                                        const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, void* stream) {
+                                        const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present,
+                                        const sonar_noise_norm* noise_norm, void* stream) {
     SONAR_REQUIRE(x && denoised && x_out && n >= 0 && cfg_ok(cfg), SONAR_ERR_ARG, "sonar_momentum_euler_f32: bad argument");
     const int present = hist_present_after(*cfg, h_in != nullptr, true);
     SONAR_REQUIRE(!present || h_out, SONAR_ERR_ARG, "sonar_momentum_euler_f32: h_out required (history is produced)");
     if (h_out_present) *h_out_present = present;
     const bool v = aligned16(x) && aligned16(denoised) && aligned16(x_out) && (!h_in || aligned16(h_in)) &&
                    (!h_out || aligned16(h_out)) && (!noise || aligned16(noise));
-    return launch_ew(EulerOp{x, denoised, h_in, x_out, h_out, noise, noise_scale, sigma, dt, *cfg}, n, v,
+    return launch_ew(EulerOp{x, denoised, h_in, x_out, h_out, noise, noise ? noise_norm : nullptr, noise_scale, sigma, dt, *cfg}, n, v,
                      (hipStream_t)stream, "sonar_momentum_euler_f32");
 }
 
 extern "C" int sonar_dpmpp_stage1_f32(const float* x, const float* denoised, const float* h_in, float* x2_out,
                                       float* md1_out, float* h_out, const float* noise, float noise_scale, float sigma,
                                       float expm1_a, float ratio_a, int adj_is_one, const sonar_momentum_cfg* cfg,
-                                      int64_t n, int* h_out_present, void* stream) {
+                                      int64_t n, int* h_out_present, const sonar_noise_norm* noise_norm, void* stream) {
     SONAR_REQUIRE(x && denoised && x2_out && md1_out && n >= 0 && cfg_ok(cfg), SONAR_ERR_ARG,
                   "sonar_dpmpp_stage1_f32: bad argument");
     const int present = hist_present_after(*cfg, h_in != nullptr, true);
@@ -1334,7 +1400,7 @@ extern "C" int sonar_dpmpp_stage1_f32(const float* x, const float* denoised, con
     if (h_out_present) *h_out_present = present;
     const bool v = aligned16(x) && aligned16(denoised) && aligned16(x2_out) && aligned16(md1_out) &&
                    (!h_in || aligned16(h_in)) && (!h_out || aligned16(h_out)) && (!noise || aligned16(noise));
-    return launch_ew(Dpmpp1Op{x, denoised, h_in, x2_out, md1_out, h_out, noise, noise_scale, sigma, expm1_a, ratio_a,
+    return launch_ew(Dpmpp1Op{x, denoised, h_in, x2_out, md1_out, h_out, noise, noise ? noise_norm : nullptr, noise_scale, sigma, expm1_a, ratio_a,
                               adj_is_one, *cfg},
                      n, v, (hipStream_t)stream, "sonar_dpmpp_stage1_f32");
 }
@@ -1342,7 +1408,8 @@ extern "C" int sonar_dpmpp_stage1_f32(const float* x, const float* denoised, con
 extern "C" int sonar_dpmpp_stage2_f32(const float* x, const float* denoised2, const float* md1, const float* h_in,
                                       float* x_out, float* dd_out, float* h_out, const float* noise, float noise_scale,
                                       float sigma_s, float expm1_b, float ratio_b, float fac, int adj_is_one,
-                                      const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, void* stream) {
+                                      const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present,
+                                      const sonar_noise_norm* noise_norm, void* stream) {
     SONAR_REQUIRE(x && denoised2 && md1 && x_out && n >= 0 && cfg_ok(cfg), SONAR_ERR_ARG,
                   "sonar_dpmpp_stage2_f32: bad argument");
     const int present = hist_present_after(*cfg, h_in != nullptr, true);
@@ -1351,9 +1418,22 @@ extern "C" int sonar_dpmpp_stage2_f32(const float* x, const float* denoised2, co
     const bool v = aligned16(x) && aligned16(denoised2) && aligned16(md1) && aligned16(x_out) &&
                    (!dd_out || aligned16(dd_out)) && (!h_in || aligned16(h_in)) && (!h_out || aligned16(h_out)) &&
                    (!noise || aligned16(noise));
-    return launch_ew(Dpmpp2Op{x, denoised2, md1, h_in, x_out, dd_out, h_out, noise, noise_scale, sigma_s, expm1_b,
+    return launch_ew(Dpmpp2Op{x, denoised2, md1, h_in, x_out, dd_out, h_out, noise, noise ? noise_norm : nullptr, noise_scale, sigma_s, expm1_b,
                               ratio_b, fac, adj_is_one, *cfg},
                      n, v, (hipStream_t)stream, "sonar_dpmpp_stage2_f32");
+}
+
+extern "C" int sonar_norm_decision_f32(const double* partials, int64_t npart, int64_t n_total, float factor, float threshold_std_devs,
+                                       sonar_noise_norm* out, void* stream) {
+    SONAR_REQUIRE(partials && out && npart > 0 && n_total > 1, SONAR_ERR_ARG, "sonar_norm_decision_f32: bad argument");
+    hipLaunchKernelGGL(norm_decision_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, partials, npart, n_total, factor, threshold_std_devs,
+                       out);
+    return check_launch("sonar_norm_decision_f32");
+}
+
+extern "C" int sonar_apply_norm_f32(float* x, int64_t n, const sonar_noise_norm* norm, void* stream) {
+    SONAR_REQUIRE(x && norm && n >= 0, SONAR_ERR_ARG, "sonar_apply_norm_f32: bad argument");
+    return launch_ew(ApplyNormOp{x, norm}, n, aligned16(x), (hipStream_t)stream, "sonar_apply_norm_f32");
 }
 
 extern "C" int sonar_cast_f32_f64(const float* in, double* out, int64_t n, void* stream) {

@@ -85,9 +85,11 @@ SIGNATURES = {
     "sonar_div_mid_f32": (_I, [_P, _I64, _I64, _I64, _P, _P]),
     "sonar_mask_mix_f32": (_I, [_P, _P, _P, _I64, _P, _I64, _P]),
     "sonar_minmax_rows_f32": (_I, [_P, _I64, _I64, _P, _P, _P]),
-    "sonar_momentum_euler_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
-    "sonar_dpmpp_stage1_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
-    "sonar_dpmpp_stage2_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P]),
+    "sonar_momentum_euler_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _F, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P, _P]),
+    "sonar_dpmpp_stage1_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P, _P]),
+    "sonar_dpmpp_stage2_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, C.POINTER(MomentumCfg), _I64, C.POINTER(C.c_int), _P, _P]),
+    "sonar_norm_decision_f32": (_I, [_P, _I64, _I64, _F, _F, _P, _P]),
+    "sonar_apply_norm_f32": (_I, [_P, _I64, _P, _P]),
     "sonar_philox_normal_f32": (_I, [_P, _I64, _U64, _U64, _I64, _P, _P]),
     "sonar_philox_uniform_f32": (_I, [_P, _I64, _U64, _U64, _I64, _F, _F, _F, _P, _P]),
     "sonar_philox_noise_f32": (_I, [_I, _P, _I64, _U64, _U64, _I64, _F, _F, _F, _F, _F, _P, _P]),
@@ -476,15 +478,31 @@ def cast_f32_f64(x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ momentum
+def norm_decision(partials: torch.Tensor, n_total: int, factor: float, threshold_std_devs: float = 2.5) -> torch.Tensor:
+    """The decision ``scale_noise(factor, normalized=True)`` would take for a tensor with these (sum, sumsq) partials, left on the device
+    (``sonar_noise_norm``, 24 bytes) for the kernel that consumes the tensor; see ``apply_norm_`` and the ``noise_norm`` arguments."""
+    out = torch.empty(6, dtype=torch.float32, device=partials.device)
+    _check(load().sonar_norm_decision_f32(_dev(partials, "partials", torch.float64), NPART, int(n_total), float(factor), float(threshold_std_devs),
+                                          out.data_ptr(), _stream()), "sonar_norm_decision_f32")
+    return out
+
+
+def apply_norm_(x: torch.Tensor, norm: torch.Tensor) -> torch.Tensor:
+    """Materialise a pending normalisation in place (what the step kernels do on the fly)."""
+    _check(load().sonar_apply_norm_f32(_dev(x, "x"), x.numel(), _dev(norm, "norm"), _stream()), "sonar_apply_norm_f32")
+    return x
+
+
 def momentum_euler(x, denoised, h_in, cfg: MomentumCfg, sigma: float, dt: float, *, noise=None, noise_scale: float = 0.0,
-                   x_out=None, h_out=None):
+                   x_out=None, h_out=None, noise_norm=None):
     x_out = torch.empty_like(x) if x_out is None else x_out
     h_out = torch.empty_like(x) if h_out is None else h_out
     present = C.c_int(0)
     _check(
         load().sonar_momentum_euler_f32(
             _dev(x, "x"), _dev(denoised, "denoised"), _opt(h_in, "h_in"), _dev(x_out, "x_out"), _dev(h_out, "h_out"),
-            _opt(noise, "noise"), float(noise_scale), float(sigma), float(dt), C.byref(cfg), x.numel(), C.byref(present), _stream(),
+            _opt(noise, "noise"), float(noise_scale), float(sigma), float(dt), C.byref(cfg), x.numel(), C.byref(present),
+            _opt(noise_norm, "noise_norm"), _stream(),
         ),
         "sonar_momentum_euler_f32",
     )
@@ -492,7 +510,7 @@ def momentum_euler(x, denoised, h_in, cfg: MomentumCfg, sigma: float, dt: float,
 
 
 def dpmpp_stage1(x, denoised, h_in, cfg: MomentumCfg, sigma: float, expm1_a: float, ratio_a: float, adj_is_one: bool, *,
-                 noise=None, noise_scale: float = 0.0):
+                 noise=None, noise_scale: float = 0.0, noise_norm=None):
     x2 = torch.empty_like(x)
     md1 = torch.empty_like(x)
     h_out = torch.empty_like(x)
@@ -501,7 +519,7 @@ def dpmpp_stage1(x, denoised, h_in, cfg: MomentumCfg, sigma: float, expm1_a: flo
         load().sonar_dpmpp_stage1_f32(
             _dev(x, "x"), _dev(denoised, "denoised"), _opt(h_in, "h_in"), _dev(x2, "x2"), _dev(md1, "md1"), _dev(h_out, "h_out"),
             _opt(noise, "noise"), float(noise_scale), float(sigma), float(expm1_a), float(ratio_a), int(bool(adj_is_one)),
-            C.byref(cfg), x.numel(), C.byref(present), _stream(),
+            C.byref(cfg), x.numel(), C.byref(present), _opt(noise_norm, "noise_norm"), _stream(),
         ),
         "sonar_dpmpp_stage1_f32",
     )
@@ -509,7 +527,7 @@ def dpmpp_stage1(x, denoised, h_in, cfg: MomentumCfg, sigma: float, expm1_a: flo
 
 
 def dpmpp_stage2(x, denoised2, md1, h_in, cfg: MomentumCfg, sigma_s: float, expm1_b: float, ratio_b: float, fac: float,
-                 adj_is_one: bool, *, noise=None, noise_scale: float = 0.0, want_dd: bool = False):
+                 adj_is_one: bool, *, noise=None, noise_scale: float = 0.0, want_dd: bool = False, noise_norm=None):
     x_out = torch.empty_like(x)
     dd = torch.empty_like(x) if want_dd else None
     h_out = torch.empty_like(x)
@@ -518,7 +536,7 @@ def dpmpp_stage2(x, denoised2, md1, h_in, cfg: MomentumCfg, sigma_s: float, expm
         load().sonar_dpmpp_stage2_f32(
             _dev(x, "x"), _dev(denoised2, "denoised2"), _dev(md1, "md1"), _opt(h_in, "h_in"), _dev(x_out, "x_out"), _opt(dd, "dd"),
             _dev(h_out, "h_out"), _opt(noise, "noise"), float(noise_scale), float(sigma_s), float(expm1_b), float(ratio_b),
-            float(fac), int(bool(adj_is_one)), C.byref(cfg), x.numel(), C.byref(present), _stream(),
+            float(fac), int(bool(adj_is_one)), C.byref(cfg), x.numel(), C.byref(present), _opt(noise_norm, "noise_norm"), _stream(),
         ),
         "sonar_dpmpp_stage2_f32",
     )

@@ -147,7 +147,8 @@ class CustomNoiseChain:
             raise ValueError("Failed to get noise sampler")
         factor = self.factor
 
-        def noise_sampler(sigma, sigma_next):
+        def summed(sigma, sigma_next):
+            """(tensor, final): final = True -> already scaled / normalised (the one-item fused path); else the chain's plain sum."""
             # result = sum_i item_i * factor_i (py/noise.py:188-194).  An item that would only multiply by its factor hands back
             # (raw tensor, factor) instead (`unscaled`), and the multiply rides in the accumulation kernel: y*a + x*b rounds each
             # product before the add, exactly like mul_ followed by add_, so the sweep is saved without changing a bit.
@@ -155,7 +156,7 @@ class CustomNoiseChain:
                 fused = getattr(samplers[0], "normalized_call", None)
                 out = fused(factor, sigma, sigma_next) if fused is not None else None
                 if out is not None:
-                    return out
+                    return out, True
             total, first = None, None
             for idx, ns in enumerate(samplers):
                 fold = getattr(ns, "accumulate", None) if idx else None
@@ -186,10 +187,30 @@ class CustomNoiseChain:
                     total = hip_lib.axpby_(y, ymul, part, f)
             if total is None:
                 total = first[0] if first[1] == 1.0 else scale_noise(first[0], first[1], normalized=False)
-            if not normalized and factor == 1:
-                return total  # nothing to do; the statistics tag of the sum (if any) stays valid for a normalising layer above
+            return total, False
+
+        def noise_sampler(sigma, sigma_next):
+            total, final = summed(sigma, sigma_next)
+            if final or (not normalized and factor == 1):
+                return total  # nothing left to do; a statistics tag of the sum (if any) stays valid for a normalising layer above
             return scale_noise(total, factor, normalized=normalized)
 
+        def deferred(sigma, sigma_next):
+            """(tensor, norm) for a consumer that can apply the final normalisation while it reads the noise (the Sonar sampler steps,
+            ``noise_norm`` of sonar_momentum_euler_f32 / sonar_dpmpp_stage*_f32): the sum with its statistics already reduced comes
+            back as it is and ``norm`` holds the decision on the device (``hip_lib.norm_decision``) -- the read + write of
+            ``scale_noise`` is saved.  ``norm`` None: the tensor is final (every other case)."""
+            total, final = summed(sigma, sigma_next)
+            if final or (not normalized and factor == 1):
+                return total, None
+            partials = utils.pop_stats(total) if normalized else None
+            if partials is None or total.dtype != torch.float32 or not total.is_contiguous():
+                if partials is not None:
+                    utils.attach_stats(total, partials)
+                return scale_noise(total, factor, normalized=normalized), None
+            return total, hip_lib.norm_decision(partials, total.numel(), factor)
+
+        noise_sampler.deferred = deferred
         return noise_sampler
 
 

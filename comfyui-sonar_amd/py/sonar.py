@@ -149,6 +149,18 @@ class SonarBase:
         self.noise_sampler = noise_sampler
         return noise_sampler
 
+    def draw_noise(self, sigma, sigma_next, *, defer: bool = True):
+        """(noise as fp32, norm): ``self.noise_sampler(sigma, sigma_next)``.  A sampler built by this package's noise chains can hand the
+        sum back with its final normalisation still pending (``deferred``; ``norm`` = the decision on the device) for the step kernels to
+        apply while they read the noise; ``defer=False`` (or any other sampler) gives the finished tensor and ``norm`` None."""
+        lazy = getattr(self.noise_sampler, "deferred", None) if defer else None
+        nz, norm = lazy(sigma, sigma_next) if lazy is not None else (self.noise_sampler(sigma, sigma_next), None)
+        if norm is not None and nz.dtype != torch.float32:
+            nz, norm = hip_lib.apply_norm_(utils.as_f32(nz), norm), None
+        nz = utils.as_f32(nz)
+        utils.pop_stats(nz)
+        return nz, norm
+
     # ---- scalar bookkeeping
     @property
     def history_ratios(self):
@@ -265,14 +277,14 @@ class SonarBase:
 
     # ---- fused step
     def momentum_step(self, step: int, x: Tensor, denoised: Tensor, sigma, sigma_down, *, noise_add: Optional[Tensor] = None,
-                      noise_scale: float = 0.0) -> Tensor:
+                      noise_scale: float = 0.0, noise_norm: Optional[Tensor] = None) -> Tensor:
         """py/sonar.py:309-320 as ONE kernel launch; optional fused ancestral noise add (:563-566)."""
         sigma_t, down_t = torch.as_tensor(sigma, dtype=torch.float32), torch.as_tensor(sigma_down, dtype=torch.float32)
         dt = (down_t.cpu() - sigma_t.cpu()).item()  # fp32 subtraction, like the reference's 0-d tensors
         kc = self.kernel_cfg(step)
         h_in = self._history_for_kernel(x, step, kc)
         x32, den32 = utils.as_f32(x), utils.as_f32(denoised)
-        x_out, h_out = hip_lib.momentum_euler(x32, den32, h_in, kc, float(sigma_t), dt, noise=noise_add, noise_scale=noise_scale)
+        x_out, h_out = hip_lib.momentum_euler(x32, den32, h_in, kc, float(sigma_t), dt, noise=noise_add, noise_scale=noise_scale, noise_norm=noise_norm)
         self.history_d = h_out
         return x_out
 
@@ -421,16 +433,14 @@ class SonarEulerAncestral(SonarSampler):
         if add_noise and not self.guidance_active(step_index):
             # the noise add rides in the step kernel: x' = md*dt + x + noise*(s_noise*sigma_up)
             self.prefetch_rand_history(sample, step_index)
-            nz = utils.as_f32(self.noise_sampler(sigma, self.sigmas[step_index + 1]))
-            utils.pop_stats(nz)
+            nz, norm = self.draw_noise(sigma, self.sigmas[step_index + 1])
             scale = float(torch.as_tensor(self.s_noise * sigma_up, dtype=torch.float32))
-            result = self.momentum_step(step_index, sample, denoised, h_sigma, sigma_down, noise_add=nz, noise_scale=scale)
+            result = self.momentum_step(step_index, sample, denoised, h_sigma, sigma_down, noise_add=nz, noise_scale=scale, noise_norm=norm)
         else:
             result = self.momentum_step(step_index, sample, denoised, h_sigma, sigma_down)
             if add_noise:
                 result = self.guidance_step(step_index, result, denoised)
-                nz = utils.as_f32(self.noise_sampler(sigma, self.sigmas[step_index + 1]))
-                utils.pop_stats(nz)
+                nz, _ = self.draw_noise(sigma, self.sigmas[step_index + 1], defer=False)
                 result = hip_lib.axpby_(nz, float(torch.as_tensor(self.s_noise * sigma_up, dtype=torch.float32)), result, 1.0)
         return result, sigma, sigma, denoised
 
@@ -480,12 +490,11 @@ class SonarDPMPPSDE(SonarSampler):
         # ---- stage 1
         kc = self.kernel_cfg(step_index)
         h_in = self._history_for_kernel(x, step_index, kc)
-        nz = utils.as_f32(self.noise_sampler(s_t, s_s))
-        utils.pop_stats(nz)
+        nz, norm = self.draw_noise(s_t, s_s)
         x32 = utils.as_f32(x)
         x_2, md1, hist = hip_lib.dpmpp_stage1(
             x32, utils.as_f32(denoised), h_in, kc, f32(sigma), f32((t - s_).expm1()), f32(self.sigma_fn(s_) / s_t), adjusted == 1,
-            noise=nz, noise_scale=f32(self.s_noise * su),
+            noise=nz, noise_scale=f32(self.s_noise * su), noise_norm=norm,
         )
         self.history_d = hist
         denoised_2 = self.call_model(x_2, s_s)
@@ -495,18 +504,16 @@ class SonarDPMPPSDE(SonarSampler):
         t_down = self.t_fn(sd)
         kc2 = self.kernel_cfg(step_index)
         fuse_noise = not self.guidance_active(step_index)
-        nz2 = utils.as_f32(self.noise_sampler(s_t, s_t_next)) if fuse_noise else None
-        if nz2 is not None:
-            utils.pop_stats(nz2)
+        nz2, norm2 = self.draw_noise(s_t, s_t_next) if fuse_noise else (None, None)
         x_out, dd, hist = hip_lib.dpmpp_stage2(
             x32, utils.as_f32(denoised_2), md1, self.history_d, kc2, f32(s_s), f32((t - t_down).expm1()),
             f32(self.sigma_fn(t_down) / s_t), fac, adjusted == 1, noise=nz2, noise_scale=f32(self.s_noise * su), want_dd=not fuse_noise,
+            noise_norm=norm2,
         )
         self.history_d = hist
         if not fuse_noise:
             x_out = self.guidance_step(step_index, x_out, dd)
-            nz2 = utils.as_f32(self.noise_sampler(s_t, s_t_next))
-            utils.pop_stats(nz2)
+            nz2, _ = self.draw_noise(s_t, s_t_next, defer=False)
             x_out = hip_lib.axpby_(nz2, f32(self.s_noise * su), x_out, 1.0)
         return x_out
 

@@ -158,6 +158,19 @@ int sonar_minmax_rows_f32(const float* x, int64_t rows, int64_t inner, float* ou
 int sonar_minmax_rescale_f32(const float* x, int64_t rows, int64_t inner, const float* lo, const float* hi, float eps,
                              float target_min, float target_max, float* out, void* stream);
 
+/* A pending global normalisation of a noise tensor (py/utils.py:100-105): the decision scale_noise(normalized=True) would take,
+ * computed ON THE DEVICE from the tensor's (sum, sumsq) partials and left in device memory, so that the kernel that consumes the
+ * noise (the sampler-step kernels below take it as `noise_norm`, nullable) applies `((v - mean) / std) * factor` -- only the parts
+ * the thresholds ask for, in scale_noise's own order: same bits -- while it reads the noise, instead of a separate read + write of
+ * the tensor.  sonar_apply_norm_f32 materialises it in place for any other consumer. */
+typedef struct sonar_noise_norm {
+    float mean, stdv, inv_std /* correctly rounded 1 / stdv */, factor;
+    int32_t do_sub, do_div;
+} sonar_noise_norm;
+int sonar_norm_decision_f32(const double* partials, int64_t npart, int64_t n_total, float factor, float threshold_std_devs,
+                            sonar_noise_norm* out /* device */, void* stream);
+int sonar_apply_norm_f32(float* x, int64_t n, const sonar_noise_norm* norm /* device */, void* stream);
+
 /* ---------------------------------------------------------------- momentum step (rows M, M2) */
 typedef struct sonar_momentum_cfg {
     float momentum;      /* SonarConfig.momentum             py/sonar.py:47 */
@@ -182,7 +195,8 @@ typedef struct sonar_momentum_cfg {
  * x_out may alias x; h_out may alias h_in. */
 int sonar_momentum_euler_f32(const float* x, const float* denoised, const float* h_in, float* x_out,
                              float* h_out, const float* noise, float noise_scale, float sigma, float dt,
-                             const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, void* stream);
+                             const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, const sonar_noise_norm* noise_norm,
+                             void* stream);
 
 /* DPM-Solver++(SDE) half steps, py/sonar.py:649-735.  Stage 1:
  *   md1 = MD(den, sigma); m_d = D(expm1_a * md1); x2 = ratio_a*x - m_d + noise*noise_scale
@@ -194,11 +208,12 @@ int sonar_momentum_euler_f32(const float* x, const float* denoised, const float*
 int sonar_dpmpp_stage1_f32(const float* x, const float* denoised, const float* h_in, float* x2_out, float* md1_out,
                            float* h_out, const float* noise, float noise_scale, float sigma, float expm1_a,
                            float ratio_a, int adj_is_one, const sonar_momentum_cfg* cfg, int64_t n,
-                           int* h_out_present, void* stream);
+                           int* h_out_present, const sonar_noise_norm* noise_norm, void* stream);
 int sonar_dpmpp_stage2_f32(const float* x, const float* denoised2, const float* md1, const float* h_in,
                            float* x_out, float* dd_out, float* h_out, const float* noise, float noise_scale,
                            float sigma_s, float expm1_b, float ratio_b, float fac, int adj_is_one,
-                           const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, void* stream);
+                           const sonar_momentum_cfg* cfg, int64_t n, int* h_out_present, const sonar_noise_norm* noise_norm,
+                           void* stream);
 
 /* ---------------------------------------------------------------- base generators (rows G1, G2) */
 /* On-device counter RNG.  Philox4x32-10 (key = seed) seeds one xoshiro128++ burst per (stream id, tile, lane);

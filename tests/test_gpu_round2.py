@@ -431,3 +431,68 @@ def test_chain_of_folding_generators_equals_the_unfused_chain(api, monkeypatch):
             assert torch.equal(a, b)
             assert bool(torch.isfinite(a).all()) and (not normalized or abs(a.std().item() - 1.1) < 3e-3)  # scale_noise(factor = sum |factor_i|)
             assert tag_a or not normalized  # the normalised result carries its statistics (derived from the sum's, no sweep)
+
+
+# ------------------------------------------------------------------------------------------------ noise whose normalisation rides in the step kernel
+@pytest.mark.parametrize("case", ["shift_and_scale", "scale_only", "as_is"])
+def test_step_kernels_apply_a_pending_normalisation_like_scale_noise(api, case):
+    """sonar_norm_decision_f32 + the `noise_norm` argument of the three sampler-step kernels == scale_noise(normalized=True) first, then the
+    plain kernels: bit for bit (same decision, same subtract / divide / multiply sequence).  Also sonar_apply_norm_f32."""
+    hl = api.hl
+    g = torch.Generator(device="cuda").manual_seed(12)
+    shape = (4, 4, 64, 64)
+    noise = torch.randn(shape, device="cuda", generator=g)
+    if case == "shift_and_scale":
+        noise = noise * 1.7 + 0.4
+    elif case == "scale_only":
+        noise = noise * 0.6
+    else:
+        noise = (noise - noise.mean()) / noise.std()
+    factor = 1.0 if case == "as_is" else 1.3
+    x, den, md1 = (torch.randn(shape, device="cuda", generator=g) for _ in range(3))
+    n = noise.numel()
+    want_noise = hl.scale_noise_(noise.clone(), factor, True, hl.stats(noise))
+    norm = hl.norm_decision(hl.stats(noise), n, factor)
+    assert torch.equal(hl.apply_norm_(noise.clone(), norm), want_noise)
+    cfg = hl.MomentumCfg()
+    cfg.momentum, cfg.hist_ratio, cfg.hist_scale, cfg.md_scale = 0.95, 0.75, 1.0, 1.0
+    cfg.mode, cfg.use_momentum, cfg.update_hist, cfg.init_kind = 0, 1, 1, 0
+    h = torch.randn(shape, device="cuda", generator=g)
+    a = hl.momentum_euler(x, den, h, cfg, 3.0, -0.5, noise=noise, noise_scale=0.7, noise_norm=norm)
+    b = hl.momentum_euler(x, den, h, cfg, 3.0, -0.5, noise=want_noise, noise_scale=0.7)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a = hl.dpmpp_stage1(x, den, h, cfg, 3.0, -0.3, 0.8, False, noise=noise, noise_scale=0.7, noise_norm=norm)
+    b = hl.dpmpp_stage1(x, den, h, cfg, 3.0, -0.3, 0.8, False, noise=want_noise, noise_scale=0.7)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    a = hl.dpmpp_stage2(x, den, md1, h, cfg, 2.0, -0.4, 0.6, 1.0, False, noise=noise, noise_scale=0.7, noise_norm=norm)
+    b = hl.dpmpp_stage2(x, den, md1, h, cfg, 2.0, -0.4, 0.6, 1.0, False, noise=want_noise, noise_scale=0.7)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("sampler", ["dpmpp_sde", "euler_ancestral"])
+def test_samplers_with_deferred_normalisation_equal_the_plain_run(api, sampler, monkeypatch):
+    """A chain's noise handed to the step kernels with its normalisation pending (`deferred`) gives the same trajectory as the chain
+    normalising first: cfg5's mix (power-law + Perlin + Brownian), 6 steps."""
+    N, pn, S = api.noise, api.powernoise, api.sonar
+
+    def run(defer):
+        chain = N.CustomNoiseChain()
+        chain.add(pn.PowerNoiseItem(0.5, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                                    common_mode=0.0, channel_correlation="1"))
+        chain.add(N.CustomNoiseItem(0.3, noise_type="perlin"))
+        chain.add(N.CustomNoiseItem(0.2, noise_type="brownian"))
+        torch.manual_seed(31)
+        x = torch.randn(2, 4, 64, 64, device="cuda") * 10
+        sigmas = torch.cat([torch.linspace(14.6, 0.5, 7), torch.zeros(1)])
+        ns = chain.make_noise_sampler(x, 0.5, 14.6, seed=3, cpu=False, normalized=True)
+        assert hasattr(ns, "deferred")
+        if not defer:
+            plain = ns
+            ns = lambda s, sn: plain(s, sn)  # noqa: E731  (no `deferred` attribute: the sampler takes the finished tensor)
+        model = lambda t, sigma, **_k: api.hl.mul_scalar(t, 0.5)  # noqa: E731
+        if sampler == "dpmpp_sde":
+            return S.SonarDPMPPSDE.sampler(model, x, sigmas, {"seed": 3}, None, True, None, dict(momentum=0.95), 1.0, 1.0, ns)
+        return S.SonarEulerAncestral.sampler(model, x, sigmas, {"seed": 3}, None, True, None, dict(momentum=0.95), 1.0, 1.0, ns)
+
+    a, b = run(True), run(False)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
