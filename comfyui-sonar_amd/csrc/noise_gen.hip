@@ -297,7 +297,11 @@ __global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __res
 // raw values (+ optional statistics), MODE 1 only reduces the statistics (no stores), MODE 2 re-draws the
 // same values, normalises them with the decision derived from `norm_partials` and writes the final tensor.
 // generate: base u ~ U[0,1) drawn on device.  VEC: chw % 4 == 0, aligned pointers, elem_offset % 4 == 0.
-template <int MODE, bool VEC, bool STATS>
+// FAST (the shape every device-drawn call has: ONE summed term table, latents and shard offsets that are whole RNG tiles): a tile
+// lies inside one latent, so its 16 term vectors sit at fixed strides -- they are requested four iterations ahead of their use (the
+// general loop below waits for each load right where it issues it: at 4 waves per SIMD that wait, not the arithmetic, set the
+// kernel's time) and there is no position bookkeeping, range test or tail path.
+template <int MODE, bool VEC, bool STATS, bool FAST = false>
 __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __restrict__ terms, float* out, int64_t B,
                                                                   int64_t chw, int iters, float div_fac, uint64_t seed,
                                                                   uint64_t stream_id, int64_t elem_offset, double* partials,
@@ -315,6 +319,55 @@ __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
     const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
     const int ichw = (int)chw;  // launcher guarantees chw < 2^31
+    if constexpr (FAST) {
+        static_assert(VEC, "the fast path is a vector path");
+        for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+            Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+            const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
+            const float4* trow = reinterpret_cast<const float4*>(terms + (base % chw));  // + it * 64 vectors
+            float4 cur[4], nxt[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = trow[j * 64];
+            float ts = 0.0f, tq = 0.0f;  // the tile's 64 values per lane in fp32, folded into the fp64 sums once per tile
+#pragma unroll
+            for (int g = 0; g < kTileIters / 4; ++g) {
+                if (g + 1 < kTileIters / 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nxt[j] = trow[(4 * (g + 1) + j) * 64];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4];
+                    rng.uniform4(v);
+                    const int64_t e = base + (4 * g + j) * 256;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = divide(v[k]);
+                    v[0] += cur[j].x; v[1] += cur[j].y; v[2] += cur[j].z; v[3] += cur[j].w;
+                    if constexpr (MODE == 2) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = norm(v[k]);
+                    }
+                    if constexpr (MODE != 1) {
+                        if constexpr (MODE == 0) accumulate_group<true>(acc, n, e, v);
+                        double unused_s = 0.0, unused_q = 0.0;
+                        store_group<true>(out, n, e, v, unused_s, unused_q, false);
+                    }
+                    if constexpr (STATS || MODE == 1) {
+                        ts += (v[0] + v[1]) + (v[2] + v[3]);
+                        tq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[3], v[3], tq))));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+            }
+            if constexpr (STATS || MODE == 1) {
+                s += (double)ts;
+                q += (double)tq;
+            }
+        }
+        if constexpr (STATS || MODE == 1) write_partial<kBlock>(s, q, partials, red);
+        return;
+    }
     for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
         Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
         const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
@@ -394,14 +447,20 @@ static int launch_perlin_generate(const float* terms, float* out, int64_t B, int
     const bool vec = (chw % 4 == 0) && (MODE == 1 || aligned16(out)) && (iters == 0 || aligned16(terms)) && (elem_offset % 4 == 0) &&
                      aligned16(acc.y);
     const int g = tile_grid(n, elem_offset);
+    const bool fast = vec && iters == 1 && chw % kTileElems == 0 && elem_offset % kTileElems == 0;
 #define SONAR_PG(V, S) \
     hipLaunchKernelGGL((perlin_generate_kernel<MODE, V, S>), dim3(g), dim3(kBlock), 0, st, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials, na, acc)
-    if (vec) {
+#define SONAR_PGF(S) \
+    hipLaunchKernelGGL((perlin_generate_kernel<MODE, true, S, true>), dim3(g), dim3(kBlock), 0, st, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials, na, acc)
+    if (fast) {
+        if (partials && MODE == 0) SONAR_PGF(true); else SONAR_PGF(false);
+    } else if (vec) {
         if (partials && MODE == 0) SONAR_PG(true, true); else SONAR_PG(true, false);
     } else {
         if (partials && MODE == 0) SONAR_PG(false, true); else SONAR_PG(false, false);
     }
 #undef SONAR_PG
+#undef SONAR_PGF
     return check_launch(what);
 }
 

@@ -496,3 +496,23 @@ def test_samplers_with_deferred_normalisation_equal_the_plain_run(api, sampler, 
 
     a, b = run(True), run(False)
     assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+def test_perlin_fast_path_equals_the_general_kernel(api):
+    """perlin_generate_kernel's fast path (one summed term table, tile-aligned latents: term vectors requested four iterations ahead)
+    against the general loop, reached with a second, all-zero term table: raw values + statistics, the statistics-only pass and the
+    normalising pass, and the folding form."""
+    hl = api.hl
+    shape = (6, 4, 64, 64)
+    terms = hl.perlin_lattice(2, 4, 64, 64, "cuda", "lerp", 99, 3)
+    two = torch.cat([terms, torch.zeros_like(terms)]).contiguous()
+    offs = 4 * 4 * 64 * 64
+    pa, pb = hl.new_partials("cuda"), hl.new_partials("cuda")
+    a = hl.perlin_generate(shape, terms, 2.0, 7, 5, offs, pa)
+    b = hl.perlin_generate(shape, two, 2.0, 7, 5, offs, pb)
+    # values bit-equal; the fast path sums a tile's 64 values per lane in fp32 before its fp64 partials: statistics agree to ~1e-7
+    assert torch.equal(a, b)
+    torch.testing.assert_close(pa.view(-1, 2).sum(0), pb.view(-1, 2).sum(0), rtol=2e-6, atol=0)
+    torch.testing.assert_close(hl.perlin_noise(shape, terms, 2.0, 7, 5, offs, 1.25), hl.perlin_noise(shape, two, 2.0, 7, 5, offs, 1.25), rtol=1e-6, atol=1e-6)
+    y = torch.randn(shape, device="cuda")
+    assert torch.equal(hl.perlin_generate_acc_(y.clone(), 0.5, 0.3, terms, 2.0, 7, 5, offs), hl.perlin_generate_acc_(y.clone(), 0.5, 0.3, two, 2.0, 7, 5, offs))
