@@ -259,23 +259,30 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
                 for (Walk2 wk(tid, wp); wk.r < th; wk.next(wp)) {
                     const int yl = wk.r, m = wk.c;
                     const T* row = tmp + yl * w1;
-                    T e, o;
-                    synth_low_pair<T, FT>(m, w1, a.mode_inv, a.rlo, [&](int i) { return row[i]; }, e, o);
                     const int at = (y0 + yl) * W + 2 * m;
                     const bool pair = 2 * m + 1 < W;
-                    if (pair && (W & 1) == 0) {  // rows are 8-byte aligned: one vector access per tensor
+                    const bool vec = pair && (W & 1) == 0;  // rows are 8-byte aligned: one vector access per tensor
+                    // the three global reads are requested BEFORE the synthesis out of LDS, not after it: the compiler keeps source order
+                    // here and otherwise waits for them with nothing left to overlap (-2..3 % on the kernel; requesting them a whole
+                    // item ahead measured the same for fp32 and slower for fp64)
+                    float2 c2 = make_float2(0.0f, 0.0f), u2 = c2, x2 = c2;
+                    if (vec) {
 #ifdef SONAR_LOW_NOREREAD  // profiling builds: what the second read of cond / uncond costs
-                        const float2 c2 = make_float2((float)e, 1.0f), u2 = make_float2(2.0f, (float)o);
+                        c2 = make_float2(1.0f, 1.0f);
+                        u2 = make_float2(2.0f, 2.0f);
 #else
-                        const float2 c2 = *reinterpret_cast<const float2*>(pc + at), u2 = *reinterpret_cast<const float2*>(pu + at);
+                        c2 = *reinterpret_cast<const float2*>(pc + at);
+                        u2 = *reinterpret_cast<const float2*>(pu + at);
 #endif
+                        if (px) x2 = *reinterpret_cast<const float2*>(px + at);
+                    }
+                    T e, o;
+                    synth_low_pair<T, FT>(m, w1, a.mode_inv, a.rlo, [&](int i) { return row[i]; }, e, o);
+                    if (vec) {
                         const T r0 = fma_t(a.ku, (T)u2.x, a.kt * fma_t(g0, (T)c2.x - (T)u2.x, e));
                         const T r1 = fma_t(a.ku, (T)u2.y, a.kt * fma_t(g0, (T)c2.y - (T)u2.y, o));
                         float2 res = make_float2((float)r0, (float)r1);
-                        if (px) {
-                            const float2 x2 = *reinterpret_cast<const float2*>(px + at);
-                            res = make_float2(x2.x - res.x, x2.y - res.y);
-                        }
+                        if (px) res = make_float2(x2.x - res.x, x2.y - res.y);
                         *reinterpret_cast<float2*>(po + at) = res;
                     } else {
                         const T r0 = fma_t(a.ku, (T)pu[at], a.kt * fma_t(g0, (T)pc[at] - (T)pu[at], e));
