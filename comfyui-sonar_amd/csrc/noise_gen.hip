@@ -1048,6 +1048,15 @@ extern "C" int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64
     if (uniform)
         return launch_fill_norm<Dist::Uniform>(out, n, seed, stream_id, elem_offset, aff, factor, threshold_std_devs, partials,
                                                (hipStream_t)stream, "sonar_philox_noise_f32");
+    if (factor == 1.0f) {
+        // N(0,1) draws with factor 1 almost never need the normalisation: the thresholds sit at 2.5 standard errors of the mean and
+        // 3.5 of the standard deviation (98.7 % of tensors pass both).  So: ONE pass that stores the draws and reduces their
+        // statistics, then scale_noise's own kernel, which takes the decision on the device and returns at once when there is
+        // nothing to do -- instead of drawing everything twice (statistics pass + final pass: 26 + 32 us per 512 SDXL latents).
+        const int rc = launch_fill<Dist::Normal>(out, n, seed, stream_id, elem_offset, aff, partials, (hipStream_t)stream, "sonar_philox_noise_f32");
+        if (rc != SONAR_OK || n == 0) return rc;
+        return sonar_scale_noise_f32(out, n, 1.0f, 1, threshold_std_devs, partials, kNPart, n, stream);
+    }
     return launch_fill_norm<Dist::Normal>(out, n, seed, stream_id, elem_offset, aff, factor, threshold_std_devs, partials,
                                           (hipStream_t)stream, "sonar_philox_noise_f32");
 }

@@ -516,3 +516,21 @@ def test_perlin_fast_path_equals_the_general_kernel(api):
     torch.testing.assert_close(hl.perlin_noise(shape, terms, 2.0, 7, 5, offs, 1.25), hl.perlin_noise(shape, two, 2.0, 7, 5, offs, 1.25), rtol=1e-6, atol=1e-6)
     y = torch.randn(shape, device="cuda")
     assert torch.equal(hl.perlin_generate_acc_(y.clone(), 0.5, 0.3, terms, 2.0, 7, 5, offs), hl.perlin_generate_acc_(y.clone(), 0.5, 0.3, two, 2.0, 7, 5, offs))
+
+
+def test_gaussian_normalised_single_pass(api):
+    """sonar_philox_noise_f32 for N(0,1) with factor 1: one pass stores the draws and their statistics, scale_noise's kernel decides on
+    the device.  Same values as draw + scale_noise; with the default thresholds the draws of a large tensor come back untouched, with
+    zero thresholds they are shifted and scaled to mean 0 / std 1; other factors keep the two-pass (draw twice, write once) route."""
+    hl = api.hl
+    shape = (64, 4, 128, 128)
+    offs = 3 * 4 * 128 * 128
+    raw = hl.philox_normal(shape, "cuda", 11, 5, offs)
+    for thr in (2.5, 0.0):
+        got = hl.philox_noise(False, shape, "cuda", 11, 5, offs, 1.0, threshold_std_devs=thr)
+        want = hl.scale_noise_(raw.clone(), 1.0, True, hl.stats(raw), threshold_std_devs=thr)
+        torch.testing.assert_close(got, want, rtol=0, atol=1e-6)
+        if thr == 0.0:
+            assert abs(got.mean().item()) < 1e-6 and abs(got.std().item() - 1.0) < 1e-6 and not torch.equal(got, raw)
+    two_pass = hl.philox_noise(False, shape, "cuda", 11, 5, offs, 1.5, threshold_std_devs=0.0)
+    torch.testing.assert_close(two_pass, hl.scale_noise_(raw.clone(), 1.5, True, hl.stats(raw), threshold_std_devs=0.0), rtol=1e-6, atol=1e-6)
