@@ -458,6 +458,8 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         const float* const xin = z + plane * (int64_t)H * W;
         // rows, pass b': spatial row y sits in LDS row r with y = r / CN2 + CN1 * (r % CN2) (what the column passes expect);
         // complex element m = k1 + RN1 * k2 is (x[2m], x[2m+1]); DFT over k2 -> n2, twiddle
+        // two items per trip: the second item's eight row loads are in flight while the first is transformed
+#pragma unroll 2
         for (int item = tid; item < RN1 * H; item += NT) {
             const int k1 = item % RN1, r = item / RN1;
             const int y = (r / CN2) + CN1 * (r % CN2);
@@ -553,6 +555,8 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             TM[ky] = make_float2(0.5f * (p.y + pn.y) * fm, -0.5f * (p.x - pn.x) * fm);
         }
         if constexpr (SRC != 3) {
+        // unrolled: the filter values are global loads (L2 hits) -- eight in flight instead of a wait per element
+#pragma unroll 8
         for (int j = tid; j < H * M; j += NT) {
             const int ky = j / M, c = j - ky * M;
             if (c != 0) {
