@@ -297,11 +297,10 @@ __global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __res
 // raw values (+ optional statistics), MODE 1 only reduces the statistics (no stores), MODE 2 re-draws the
 // same values, normalises them with the decision derived from `norm_partials` and writes the final tensor.
 // generate: base u ~ U[0,1) drawn on device.  VEC: chw % 4 == 0, aligned pointers, elem_offset % 4 == 0.
-// FAST (the shape every device-drawn call has: ONE summed term table, latents and shard offsets that are whole RNG tiles): a tile
-// lies inside one latent, so its 16 term vectors sit at fixed strides -- they are requested four iterations ahead of their use (the
-// general loop below waits for each load right where it issues it: at 4 waves per SIMD that wait, not the arithmetic, set the
-// kernel's time) and there is no position bookkeeping, range test or tail path.
-template <int MODE, bool VEC, bool STATS, bool FAST = false>
+// FAST (what every device-drawn call has: ONE summed term table, vector-aligned latents): the tile's 16 term vectors are requested
+// four iterations ahead of their use by a cursor of their own (the general loop below waits for each load right where it issues it:
+// at 4 waves per SIMD that wait, not the arithmetic, set the kernel's time), and there is no per-element tail path.
+template <int MODE, bool VEC, bool STATS, bool FAST = false, bool ALIGNED = false>
 __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __restrict__ terms, float* out, int64_t B,
                                                                   int64_t chw, int iters, float div_fac, uint64_t seed,
                                                                   uint64_t stream_id, int64_t elem_offset, double* partials,
@@ -324,22 +323,36 @@ __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __
         for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
             Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
             const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
-            const float4* trow = reinterpret_cast<const float4*>(terms + (base % chw));  // + it * 64 vectors
+            // position of the tile's first vector inside the latent; the prefetch cursor walks on in steps of 256 elements and wraps
+            // at the latent's end (a tile may straddle two latents when chw is not a multiple of the tile)
+            int rp = (int)(((base % chw) + chw) % chw);
+            const float4* const trow = reinterpret_cast<const float4*>(terms + rp);  // ALIGNED: the tile's vectors sit at trow[it * 64]
+            int fetched = 0;
+            auto next_terms = [&]() {
+                if constexpr (ALIGNED) return trow[64 * fetched++];  // unrolled callers: constant offsets in the load instructions
+                const float4 t = *reinterpret_cast<const float4*>(terms + rp);
+                rp += 256;
+                rp -= rp >= ichw ? ichw : 0;  // chw >= 256 (launcher)
+                return t;
+            };
             float4 cur[4], nxt[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cur[j] = trow[j * 64];
+            for (int j = 0; j < 4; ++j) cur[j] = next_terms();
             float ts = 0.0f, tq = 0.0f;  // the tile's 64 values per lane in fp32, folded into the fp64 sums once per tile
 #pragma unroll
             for (int g = 0; g < kTileIters / 4; ++g) {
                 if (g + 1 < kTileIters / 4) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) nxt[j] = trow[(4 * (g + 1) + j) * 64];
+                    for (int j = 0; j < 4; ++j) nxt[j] = next_terms();
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v[4];
                     rng.uniform4(v);
                     const int64_t e = base + (4 * g + j) * 256;
+                    if constexpr (!ALIGNED) {
+                        if (e < 0 || e >= n) continue;  // the two ends of a shard that does not start / end on a tile (whole groups of 4)
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = divide(v[k]);
                     v[0] += cur[j].x; v[1] += cur[j].y; v[2] += cur[j].z; v[3] += cur[j].w;
@@ -447,13 +460,16 @@ static int launch_perlin_generate(const float* terms, float* out, int64_t B, int
     const bool vec = (chw % 4 == 0) && (MODE == 1 || aligned16(out)) && (iters == 0 || aligned16(terms)) && (elem_offset % 4 == 0) &&
                      aligned16(acc.y);
     const int g = tile_grid(n, elem_offset);
-    const bool fast = vec && iters == 1 && chw % kTileElems == 0 && elem_offset % kTileElems == 0;
+    const bool fast = vec && iters == 1 && chw >= 256;
+    const bool aligned = fast && chw % kTileElems == 0 && elem_offset % kTileElems == 0;  // every tile inside one latent and inside the shard
 #define SONAR_PG(V, S) \
     hipLaunchKernelGGL((perlin_generate_kernel<MODE, V, S>), dim3(g), dim3(kBlock), 0, st, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials, na, acc)
-#define SONAR_PGF(S) \
-    hipLaunchKernelGGL((perlin_generate_kernel<MODE, true, S, true>), dim3(g), dim3(kBlock), 0, st, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials, na, acc)
-    if (fast) {
-        if (partials && MODE == 0) SONAR_PGF(true); else SONAR_PGF(false);
+#define SONAR_PGF(S, AL) \
+    hipLaunchKernelGGL((perlin_generate_kernel<MODE, true, S, true, AL>), dim3(g), dim3(kBlock), 0, st, terms, out, B, chw, (int)iters, div_fac, seed, stream_id, elem_offset, partials, na, acc)
+    if (aligned) {
+        if (partials && MODE == 0) SONAR_PGF(true, true); else SONAR_PGF(false, true);
+    } else if (fast) {
+        if (partials && MODE == 0) SONAR_PGF(true, false); else SONAR_PGF(false, false);
     } else if (vec) {
         if (partials && MODE == 0) SONAR_PG(true, true); else SONAR_PG(true, false);
     } else {

@@ -503,10 +503,16 @@ def test_perlin_fast_path_equals_the_general_kernel(api):
     against the general loop, reached with a second, all-zero term table: raw values + statistics, the statistics-only pass and the
     normalising pass, and the folding form."""
     hl = api.hl
-    shape = (6, 4, 64, 64)
-    terms = hl.perlin_lattice(2, 4, 64, 64, "cuda", "lerp", 99, 3)
+    _perlin_fast_vs_general(hl, (6, 4, 64, 64), 4)      # latents of whole RNG tiles
+    _perlin_fast_vs_general(hl, (5, 4, 104, 152), 3)    # 63232 elements per latent: tiles straddle latents, the shard ends inside a tile
+    _perlin_fast_vs_general(hl, (3, 2, 8, 8), 1)        # latents smaller than one 256-element step
+
+
+def _perlin_fast_vs_general(hl, shape, first_latent):
+    c, h, w = shape[1:]
+    terms = hl.perlin_lattice(2, c, h, w, "cuda", "lerp", 99, 3)
     two = torch.cat([terms, torch.zeros_like(terms)]).contiguous()
-    offs = 4 * 4 * 64 * 64
+    offs = first_latent * c * h * w
     pa, pb = hl.new_partials("cuda"), hl.new_partials("cuda")
     a = hl.perlin_generate(shape, terms, 2.0, 7, 5, offs, pa)
     b = hl.perlin_generate(shape, two, 2.0, 7, 5, offs, pb)
