@@ -2,7 +2,7 @@
 (py/wavelet_functions.py:56-73), i.e. N. G. Kingsbury's dtwavexfm2 / dtwaveifm2.
 
 pytorch_wavelets and its filter-bank data files are not part of the reference (un-vendored, absent): **parity unpinned**.  The
-algorithm and the filter banks are the published ones -- `near_sym_a` (5 / 7 taps) and `legall` (5 / 3) in closed form, `qshift_a`
+algorithm and the filter banks are the published ones -- `near_sym_a` (5 / 7 taps), `legall` (5 / 3) and `antonini` (9 / 7) in closed form, `qshift_a`
 (10 taps) from the published coefficients -- and are tested by their defining properties: perfect reconstruction, orthonormal shifts /
 half-band products of the filters, orientation selectivity of the six subbands, agreement with a plain numpy restatement kept with
 the tests.  Layout as pytorch_wavelets documents it: ``yl [B, C, H / 2**(J-1), W / 2**(J-1)]`` and
@@ -24,6 +24,12 @@ _BIORT = {
     # analysis / synthesis low-pass (odd lengths, unit DC gain); the high-pass pair is their alternating-sign mirror
     "near_sym_a": ([-1 / 20, 5 / 20, 12 / 20, 5 / 20, -1 / 20], [-3 / 280, -15 / 280, 73 / 280, 170 / 280, 73 / 280, -15 / 280, -3 / 280]),
     "legall": ([-1 / 8, 2 / 8, 6 / 8, 2 / 8, -1 / 8], [1 / 4, 2 / 4, 1 / 4]),
+    # CDF 9 / 7: the factors of the eighth-order maximally flat half-band filter (four zeros at -1 each; h0o takes the complex root pair
+    # of 1 + 4y + 10y^2 + 20y^3, g0o the real root), unit DC gain; agrees with the published 12-digit table
+    "antonini": ([0.02674875741081003, -0.01686411844287496, -0.07822326652899003, 0.2668641184428749, 0.60294901823636,
+                  0.2668641184428749, -0.07822326652899003, -0.01686411844287496, 0.02674875741081003],
+                 [-0.04563588155712507, -0.02877176311425014, 0.29563588155712506, 0.5575435262285002, 0.29563588155712506,
+                  -0.02877176311425014, -0.04563588155712507]),
 }
 _QSHIFT = {
     "qshift_a": [0.0511304052838317, -0.0139753702468888, -0.109836051665971, 0.263839561058938, 0.766628467793037, 0.563655710127052,

@@ -8,7 +8,7 @@ signals", ACHA 2001; "Design of Q-shift complex wavelets for image processing us
 colifilt / q2c / c2q), with pytorch_wavelets' tensor layout: ``yl [B, C, H / 2**(J-1), W / 2**(J-1)]``, ``yh[j] [B, C, 6, h_j, w_j, 2]``
 (orientations 15, 45, 75, 105, 135, 165 degrees; last axis real / imaginary).
 
-Filter banks: `near_sym_a` (5 / 7 taps) and `legall` (5 / 3) in closed form, `qshift_a` (10 taps) from the published coefficients; they
+Filter banks: `near_sym_a` (5 / 7 taps), `legall` (5 / 3) and `antonini` (9 / 7) in closed form, `qshift_a` (10 taps) from the published coefficients; they
 are checked by their defining properties (tests/test_dtcwt_cpu.py: half-band product, orthonormal shifts), and the transform by perfect
 reconstruction, by its 4:1 redundancy layout and by the orientation selectivity of its six subbands.
 """
@@ -20,6 +20,11 @@ BIORT = {
     # (h0o, g0o): analysis / synthesis low-pass, odd lengths, unit DC gain; the high-pass pair is their alternating-sign mirror
     "near_sym_a": (np.array([-1, 5, 12, 5, -1]) / 20.0, np.array([-3, -15, 73, 170, 73, -15, -3]) / 280.0),
     "legall": (np.array([-1, 2, 6, 2, -1]) / 8.0, np.array([1, 2, 1]) / 4.0),
+    # CDF 9 / 7 (factors of the 8th-order maximally flat half-band filter; the published 12-digit table to full precision)
+    "antonini": (np.array([0.02674875741081003, -0.01686411844287496, -0.07822326652899003, 0.2668641184428749, 0.60294901823636,
+                           0.2668641184428749, -0.07822326652899003, -0.01686411844287496, 0.02674875741081003]),
+                 np.array([-0.04563588155712507, -0.02877176311425014, 0.29563588155712506, 0.5575435262285002, 0.29563588155712506,
+                           -0.02877176311425014, -0.04563588155712507])),
 }
 QSHIFT = {
     "qshift_a": np.array([0.0511304052838317, -0.0139753702468888, -0.109836051665971, 0.263839561058938, 0.766628467793037,

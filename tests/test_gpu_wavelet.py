@@ -112,7 +112,7 @@ def test_wavelist_and_errors(api):
     with pytest.raises(ValueError):
         api.wf.Wavelet(wave="nope")
     with pytest.raises(NotImplementedError):
-        api.wf.Wavelet(use_dtcwt=True, biort="antonini")  # only near_sym_a / legall / qshift_a are built in (tests/test_gpu_dtcwt.py)
+        api.wf.Wavelet(use_dtcwt=True, biort="near_sym_b")  # near_sym_a / legall / antonini / qshift_a are built in (tests/test_gpu_dtcwt.py)
 
 
 from tests.golden.wavelet_cases import SAMPLE_SIGMAS, FakeModel  # noqa: E402
