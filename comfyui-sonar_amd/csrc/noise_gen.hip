@@ -1128,9 +1128,9 @@ extern "C" int sonar_brownian_point_f32(float* out, float* w_out, const float* p
 extern "C" int sonar_brownian_bridge_f32(float* out, float* w_out, const float* prev, float scale, const float* base_a, float fa,
                                          const float* base_b, float fb, int64_t n, int64_t elem_offset, const uint64_t* node_ids,
                                          const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds,
-                                         int64_t latent_elems, void* stream) {
+                                         int64_t latent_elems, double* partials, void* stream) {
     return brownian_launch(out, w_out, prev, scale, n, elem_offset, node_ids, coefs, nnodes, seed, latent_seeds, latent_elems, stream,
-                           "sonar_brownian_bridge_f32", BrownianBase{base_a, base_b, fa, fb});
+                           "sonar_brownian_bridge_f32", BrownianBase{base_a, base_b, fa, fb}, kNoAccum, partials);
 }
 
 // accumulating forms: y <- y * y_mul + x * x_mul with x the generator's values (never stored), partials (nullable) <- statistics of y

@@ -97,7 +97,7 @@ SIGNATURES = {
     "sonar_brownian_bridge_acc_f32": (_I, [_P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_philox_normal_acc_f32": (_I, [_P, _I64, _U64, _U64, _I64, _P]),
     "sonar_perlin_generate_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _P]),
-    "sonar_brownian_bridge_f32": (_I, [_P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
+    "sonar_brownian_bridge_f32": (_I, [_P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P, _P]),
     "sonar_brownian_point_f32": (_I, [_P, _P, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_perlin_terms_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I, _P]),
     "sonar_perlin_lattice_f32": (_I, [_P, _I64, _I64, _I64, _I64, _I, _U64, _U64, _P]),
@@ -651,9 +651,9 @@ def brownian_bridge_acc_(y: torch.Tensor, y_mul: float, x_mul: float, node_ids, 
 
 def brownian_bridge(shape, device, node_ids, coefs, seed: int, elem_offset: int = 0, latent_seeds: Optional[torch.Tensor] = None, *,
                     base_a: Optional[torch.Tensor] = None, fa: float = 0.0, base_b: Optional[torch.Tensor] = None, fb: float = 0.0,
-                    prev: Optional[torch.Tensor] = None, scale: float = 1.0, want_out: bool = True, want_w: bool = True):
+                    prev: Optional[torch.Tensor] = None, scale: float = 1.0, want_out: bool = True, want_w: bool = True, partials=None):
     """W = fa * base_a + fb * base_b + sum_k coefs[k] z(node_ids[k], e); returns (scale * (W - prev) or None, W or None).  More than 96
-    terms are accumulated in chunks through ``base_a``."""
+    terms are accumulated in chunks through ``base_a``.  ``partials``: receives the (sum, sumsq) statistics of the increment."""
     node_ids, coefs = list(node_ids), list(coefs)
     n = math.prod(shape)
     lib = load()
@@ -666,7 +666,8 @@ def brownian_bridge(shape, device, node_ids, coefs, seed: int, elem_offset: int 
                                              _opt(base_a, "base_a"), float(fa), _opt(base_b, "base_b"), float(fb), n, elem_offset,
                                              (C.c_uint64 * len(ids))(*[int(v) & (2**64 - 1) for v in ids]), (C.c_float * len(cf))(*[float(v) for v in cf]),
                                              len(ids), seed & (2**64 - 1), None if latent_seeds is None else latent_seeds.data_ptr(),
-                                             n // shape[0], _stream()), "sonar_brownian_bridge_f32")
+                                             n // shape[0], _opt(partials, "partials", torch.float64) if last and out is not None else None, _stream()),
+               "sonar_brownian_bridge_f32")
         if last:
             return out, w
         node_ids, coefs = node_ids[BROWNIAN_MAX_TERMS:], coefs[BROWNIAN_MAX_TERMS:]

@@ -972,13 +972,15 @@ class BrownianTreeNoiseSampler:
             self._remember(t, w)
         return w
 
-    def _emit(self, ids, coefs, *, base_a=None, fa=0.0, base_b=None, fb=0.0, prev=None, scale=1.0, want_out=True, want_w=True, fold=None):
+    def _emit(self, ids, coefs, *, base_a=None, fa=0.0, base_b=None, fb=0.0, prev=None, scale=1.0, want_out=True, want_w=True, fold=None,
+              partials=None):
         """One evaluation W = fa base_a + fb base_b + sum coef z(node): (scale * (W - prev) or None, W or None).  With ``fold`` = (y, y_mul,
         x_mul, partials) the increment is folded into the chain's running sum y instead of being written out (``accumulate``)."""
         tail = (self.seed, self.elem_offset, self.latent_seeds)
         bases = dict(base_a=base_a, fa=fa, base_b=base_b, fb=fb)
         if fold is None:
-            return hip_lib.brownian_bridge(self.shape, self.device, ids, coefs, *tail, **bases, prev=prev, scale=scale, want_out=want_out, want_w=want_w)
+            return hip_lib.brownian_bridge(self.shape, self.device, ids, coefs, *tail, **bases, prev=prev, scale=scale, want_out=want_out, want_w=want_w,
+                                           partials=partials)
         y, y_mul, x_mul, partials = fold
         w = None
         if len(ids) > hip_lib.BROWNIAN_MAX_TERMS:  # a long expansion: W first (in chunks), then the fold with no terms left
@@ -988,7 +990,7 @@ class BrownianTreeNoiseSampler:
         made = hip_lib.brownian_bridge_acc_(y, y_mul, x_mul, ids, coefs, *tail, **bases, prev=prev, scale=scale, partials=partials, want_w=want_w)
         return y, (made if w is None else w)
 
-    def _point(self, t: float, *, prev: Optional[Tensor] = None, scale: float = 1.0, want_out: bool = True, fold=None):
+    def _point(self, t: float, *, prev: Optional[Tensor] = None, scale: float = 1.0, want_out: bool = True, fold=None, partials=None):
         """(scale * (W(t) - prev) or None, W(t)) for a time that is not kept: the bridge between its two kept neighbours, else its expansion."""
         made = self.path.bridge.get(t)
         out = w = None
@@ -997,11 +999,12 @@ class BrownianTreeNoiseSampler:
             wa = None if a == self.path.t_lo else self._cached(a, cheap=True)  # W(t_lo) = 0
             wb = None if b is None else self._cached(b, cheap=True)            # b is None: an extension beyond the known times
             if (wb is not None or b is None) and (wa is not None or a == self.path.t_lo):
-                out, w = self._emit([node], [sd], base_a=wa, fa=fa, base_b=wb, fb=fb, prev=prev, scale=scale, want_out=want_out, fold=fold)
+                out, w = self._emit([node], [sd], base_a=wa, fa=fa, base_b=wb, fb=fb, prev=prev, scale=scale, want_out=want_out, fold=fold,
+                                    partials=partials)
         if w is None:
             terms = self.path.coefficients(t)
             ids = sorted(terms)
-            out, w = self._emit(ids, [terms[k] for k in ids], prev=prev, scale=scale, want_out=want_out, fold=fold)
+            out, w = self._emit(ids, [terms[k] for k in ids], prev=prev, scale=scale, want_out=want_out, fold=fold, partials=partials)
         self._remember(t, w)
         return out, w
 
@@ -1012,13 +1015,14 @@ class BrownianTreeNoiseSampler:
         self(sigma, sigma_next, fold=(y, y_mul, x_mul, partials))
         return True
 
-    def __call__(self, sigma, sigma_next, *, fold=None) -> Tensor:
+    def __call__(self, sigma, sigma_next, *, fold=None, partials=None) -> Tensor:
+        """The increment; ``partials`` (optional workspace) receives its (sum, sumsq) statistics from the same pass."""
         t0, t1 = float(self.transform(torch.as_tensor(sigma))), float(self.transform(torch.as_tensor(sigma_next)))
         sign = self.sign * (1.0 if t0 <= t1 else -1.0)
         ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
         if self.CACHE_POINTS <= 0 or ta == tb:
             ids, coefs = self.path.increment(t0, t1)
-            out, _ = self._emit(ids, [c * sign for c in coefs], want_w=False, fold=fold)
+            out, _ = self._emit(ids, [c * sign for c in coefs], want_w=False, fold=fold, partials=partials)
             return out
         # out = (W(tb) - W(ta)) / sqrt(tb - ta); both times are defined here, the smaller first, whatever is kept
         self.path.define(ta)
@@ -1026,17 +1030,17 @@ class BrownianTreeNoiseSampler:
         scale = sign / math.sqrt(tb - ta)
         wa, wb = self._cached(ta), self._cached(tb)
         if wa is not None and wb is not None:
-            out, _ = self._emit([], [], base_b=wb, fb=1.0, prev=wa, scale=scale, want_w=False, fold=fold)
+            out, _ = self._emit([], [], base_b=wb, fb=1.0, prev=wa, scale=scale, want_w=False, fold=fold, partials=partials)
             return out
         if wa is None and wb is None:
             if ta == self.path.t_lo:  # W(t_lo) = 0
-                out, _ = self._point(tb, scale=scale, fold=fold)
+                out, _ = self._point(tb, scale=scale, fold=fold, partials=partials)
                 return out
             _, wa = self._point(ta, want_out=False)
         if wb is None:
-            out, _ = self._point(tb, prev=wa, scale=scale, fold=fold)
+            out, _ = self._point(tb, prev=wa, scale=scale, fold=fold, partials=partials)
             return out
-        out, _ = self._point(ta, prev=wb, scale=-scale, fold=fold)  # scale * (W(tb) - W(ta))
+        out, _ = self._point(ta, prev=wb, scale=-scale, fold=fold, partials=partials)  # scale * (W(tb) - W(ta))
         return out
 
 
@@ -1057,7 +1061,9 @@ class BrownianNoiseGenerator(NoiseGenerator):
         return super().ng_params() | {"normalized": False}
 
     def generate(self, *args):
-        return self.brownian_tree_ns(*args)
+        # the increment's statistics come out of the same pass: the normalisation that usually follows (py/noise.py:245) needs no sweep
+        partials = hip_lib.new_partials(self.device)
+        return attach_stats(self.brownian_tree_ns(*args, partials=partials), partials)
 
     def generate_into(self, y, y_mul, x_mul, partials, *args):
         if not self._plain_output():

@@ -254,7 +254,7 @@ int sonar_brownian_point_f32(float* out, float* w_out, const float* prev, float 
 int sonar_brownian_bridge_f32(float* out, float* w_out, const float* prev, float scale, const float* base_a, float fa,
                               const float* base_b, float fb, int64_t n, int64_t elem_offset, const uint64_t* node_ids,
                               const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems,
-                              void* stream);
+                              double* partials /* nullable: (sum, sumsq) of `out`, SONAR_NPART pairs */, void* stream);
 
 /* Accumulating forms of the generators (noise chains: result = sum_i item_i * factor_i, py/noise.py:188-194).  Instead of writing
  * a fresh tensor that sonar_axpby_f32 then folds into the running sum (read 8N + write 4N more), the generator reads the sum and

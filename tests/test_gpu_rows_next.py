@@ -256,6 +256,10 @@ def test_brownian_noise_is_one_consistent_path(api):
     s = lambda v: torch.tensor(v)  # noqa: E731
     a = ns(s(10.0), s(6.0))
     n = a.numel()
+    part = api.utils.pop_stats(a)  # the increment's statistics come out of the generating pass
+    assert part is not None
+    sums = part.view(-1, 2).sum(0)
+    assert abs(sums[0].item() - a.double().sum().item()) < 1e-6 * n and abs(sums[1].item() - (a.double() ** 2).sum().item()) < 1e-6 * n
     tol = 5.0 / math.sqrt(n)
     assert abs(a.mean().item()) < tol and abs(a.var().item() - 1.0) < 3 * tol
     assert abs(((a.double() ** 4).mean() / a.double().var() ** 2).item() - 3.0) < 30 * tol
