@@ -279,6 +279,20 @@ class NoiseSampler:
         args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
         return fused(factor, *args)
 
+    def deferred(self, *args):
+        """(noise, norm) like ``CustomNoiseChain``'s ``deferred``: for a generator whose normalised form costs a separate pass over the
+        tensor (pyramid), the raw draw comes back with the decision on the device and the consuming sampler step applies it while it reads
+        the noise.  ``norm`` None: the tensor is final (every other generator)."""
+        raw = getattr(self.noise_sampler, "generate_raw_stats", None) if self.normalized and self.dtype == torch.float32 else None
+        if raw is not None:
+            gen = self.noise_sampler
+            gen.pre_hook()
+            got = raw(*(self.transform(torch.as_tensor(s)) if s is not None else s for s in args))
+            if got is not None and got[0].dtype == torch.float32 and got[0].device == self.device:
+                noise, partials = got
+                return noise, hip_lib.norm_decision(partials, noise.numel(), self.factor)
+        return self(*args), None
+
     def __call__(self, *args, **kwargs):
         args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
         fused = getattr(self.noise_sampler, "generate_normalized", None) if self.normalized and not kwargs else None

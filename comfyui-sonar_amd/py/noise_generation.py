@@ -492,6 +492,16 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
             return None
         return self.fix_output_frames(self._device_generate(None, factor))
 
+    def generate_raw_stats(self, *_args):
+        """(raw noise, its statistics partials) -- what ``generate_normalized`` computes before its in-place normalisation pass, for a
+        consumer that applies the normalisation itself while reading the noise (``NoiseSampler.deferred``); None when not applicable."""
+        if self.cpu or self.normalize_dims is not None or self.upscale_mode not in hip_lib.UPSCALE_MODES:
+            return None
+        partials = hip_lib.new_partials(self.device)
+        out = self._device_generate(partials, None)
+        part = utils.pop_stats(out)
+        return None if part is None else (self.fix_output_frames(out), part)
+
 
 class HighresPyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
     """py/noise_generation.py:517-564: uniform base plus Gaussian levels drawn at up to 15x the

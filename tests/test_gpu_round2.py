@@ -540,3 +540,30 @@ def test_gaussian_normalised_single_pass(api):
             assert abs(got.mean().item()) < 1e-6 and abs(got.std().item() - 1.0) < 1e-6 and not torch.equal(got, raw)
     two_pass = hl.philox_noise(False, shape, "cuda", 11, 5, offs, 1.5, threshold_std_devs=0.0)
     torch.testing.assert_close(two_pass, hl.scale_noise_(raw.clone(), 1.5, True, hl.stats(raw), threshold_std_devs=0.0), rtol=1e-6, atol=1e-6)
+
+
+def test_euler_ancestral_with_pyramid_noise_deferred_equals_plain(api):
+    """A single pyramid generator behind ``get_noise_sampler(normalized=True)``: the sampler step applies the normalisation its fused
+    path would have spent a pass on; same trajectory."""
+    N, S = api.noise, api.sonar
+
+    def run(defer):
+        torch.manual_seed(41)
+        x = torch.randn(4, 4, 64, 64, device="cuda") * 10
+        sigmas = torch.cat([torch.linspace(14.6, 0.5, 6), torch.zeros(1)])
+        ns = N.get_noise_sampler("pyramid", x, 0.5, 14.6, seed=3, cpu=False, normalized=True)
+        assert hasattr(ns, "deferred")
+        if defer:
+            _noise, norm = ns.deferred(torch.tensor(14.6), torch.tensor(10.0))
+            assert norm is not None  # the pyramid path really defers
+            torch.manual_seed(41)
+            x = torch.randn(4, 4, 64, 64, device="cuda") * 10
+            ns = N.get_noise_sampler("pyramid", x, 0.5, 14.6, seed=3, cpu=False, normalized=True)
+        else:
+            inner = ns
+            ns = lambda s, sn: inner(s, sn)  # noqa: E731
+        return S.SonarEulerAncestral.sampler(lambda t, sigma, **_k: api.hl.mul_scalar(t, 0.5), x, sigmas, {"seed": 3}, None, True, None,
+                                             dict(momentum=0.95), 1.0, 1.0, ns)
+
+    a, b = run(True), run(False)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
