@@ -577,7 +577,7 @@ def philox_noise(uniform: bool, shape, device, seed: int, stream_id: int, elem_o
 
 
 def brownian(shape, device, node_ids, coefs, seed: int, elem_offset: int = 0, latent_seeds: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[e] = sum_k coefs[k] * z(node_ids[k], e): one Brownian-interval increment (host-walked bisection path)."""
+    """out[e] = sum_k coefs[k] * z(node_ids[k], e): one Brownian-interval increment from its expansion over the node normals."""
     out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
     n = out.numel()
     ids = (C.c_uint64 * len(node_ids))(*[int(v) & (2**64 - 1) for v in node_ids])

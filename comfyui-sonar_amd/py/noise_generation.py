@@ -848,7 +848,8 @@ class OneFNoiseGenerator(_SpectralGainNoiseGenerator):
 # BrownianTree; un-vendored, not installed, no reference tests at that boundary): "parity unpinned".  Same contract here --
 # W(t) is ONE Brownian path per element and seed, a call returns (W(t1) - W(t0)) / sqrt|t1 - t0| with the reference's sign
 # convention, so every call is N(0,1) and repeated / nested / abutting intervals are mutually consistent -- but the path is
-# this build's own: midpoint bisection with counter-based normals (sonar_brownian_f32), so values differ from torchsde's.
+# this build's own: Brownian bridges between the times asked for, with counter-based normals (sonar_brownian_bridge_f32), so values
+# differ from torchsde's.
 class BrownianPath:
     """W(t) on [t_lo, t_hi] as a linear combination of per-node standard normals: host side of sonar_brownian_*_f32.
 
