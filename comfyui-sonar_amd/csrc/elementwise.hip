@@ -2,6 +2,7 @@
 // chain accumulation, mask mix, and the fused Sonar momentum steps.  All HBM-bound: 16 B/lane
 // coalesced accesses, grid-stride over <= kMaxGrid blocks of 256 threads, fp64 block reductions.
 #include <math.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -1316,9 +1317,11 @@ extern "C" int sonar_spectral_signum_mask_f32(float* z, const float* la, const f
 }
 
 // torch.max semantics (a NaN anywhere gives NaN) over a small vector, written straight into host-visible pinned memory: one launch +
-// one stream wait replaces torch's reduce kernel, device-to-host copy and wait for WaveletCFG's `sigma.max().item()`
-// (py/wavelet_cfg.py:795-796).
-__global__ void __launch_bounds__(kBlock) max_to_host_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ host_out) {
+// one wait replaces torch's reduce kernel, device-to-host copy and wait for WaveletCFG's `sigma.max().item()`
+// (py/wavelet_cfg.py:795-796).  The result and the ticket of the request leave as ONE 8-byte store, so a host that sees the ticket
+// sees the value.
+__global__ void __launch_bounds__(kBlock) max_to_host_kernel(const float* __restrict__ x, int64_t n, unsigned long long* __restrict__ host_out,
+                                                             unsigned ticket) {
     __shared__ float part[kBlock / 64];
     __shared__ int nan_part[kBlock / 64];
     float m = -INFINITY;
@@ -1342,25 +1345,67 @@ __global__ void __launch_bounds__(kBlock) max_to_host_kernel(const float* __rest
             m = fmaxf(m, part[w]);
             bad |= nan_part[w];
         }
-        *host_out = bad ? NAN : m;
-        __threadfence_system();
+        const unsigned long long word = ((unsigned long long)ticket << 32) | __float_as_uint(bad ? NAN : m);
+        __hip_atomic_store(host_out, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-extern "C" int sonar_max_to_host_f32(const float* x, int64_t n, float* result, void* stream) {
-    SONAR_REQUIRE(x && result && n >= 1, SONAR_ERR_ARG, "sonar_max_to_host_f32: bad argument (a non-empty device vector is required)");
-    static thread_local float* slot[64] = {};
+namespace {
+// one request in flight per host thread and device: the pinned word it lands in and the ticket it carries
+struct MaxSlot {
+    unsigned long long* word = nullptr;
+    unsigned ticket = 0;
+    bool pending = false;
+};
+thread_local MaxSlot g_max_slot[64];
+}  // namespace
+
+extern "C" int sonar_max_to_host_begin_f32(const float* x, int64_t n, void* stream) {
+    SONAR_REQUIRE(x && n >= 1, SONAR_ERR_ARG, "sonar_max_to_host_begin_f32: bad argument (a non-empty device vector is required)");
     int dev = 0;
-    SONAR_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, SONAR_ERR_HIP, "sonar_max_to_host_f32: no current device");
-    if (!slot[dev])
-        SONAR_REQUIRE(hipHostMalloc((void**)&slot[dev], 64, hipHostMallocMapped) == hipSuccess, SONAR_ERR_HIP,
-                      "sonar_max_to_host_f32: pinned allocation failed");
-    hipLaunchKernelGGL(max_to_host_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, x, n, slot[dev]);
-    const int rc = check_launch("sonar_max_to_host_f32");
-    if (rc != SONAR_OK) return rc;
-    SONAR_REQUIRE(hipStreamSynchronize((hipStream_t)stream) == hipSuccess, SONAR_ERR_HIP, "sonar_max_to_host_f32: stream wait failed");
-    *result = *(volatile float*)slot[dev];
+    SONAR_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, SONAR_ERR_HIP, "sonar_max_to_host_begin_f32: no current device");
+    MaxSlot& s = g_max_slot[dev];
+    SONAR_REQUIRE(!s.pending, SONAR_ERR_ARG, "sonar_max_to_host_begin_f32: the previous request of this thread was not collected");
+    if (!s.word) {
+        SONAR_REQUIRE(hipHostMalloc((void**)&s.word, 64, hipHostMallocMapped) == hipSuccess, SONAR_ERR_HIP,
+                      "sonar_max_to_host_begin_f32: pinned allocation failed");
+        *s.word = 0;
+    }
+    s.ticket = s.ticket + 1 ? s.ticket + 1 : 1;  // never 0: the word starts as 0
+    hipLaunchKernelGGL(max_to_host_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, x, n, s.word, s.ticket);
+    const int rc = check_launch("sonar_max_to_host_begin_f32");
+    s.pending = rc == SONAR_OK;
+    return rc;
+}
+
+extern "C" int sonar_max_to_host_end_f32(float* result, void* stream) {
+    SONAR_REQUIRE(result, SONAR_ERR_ARG, "sonar_max_to_host_end_f32: bad argument");
+    int dev = 0;
+    SONAR_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, SONAR_ERR_HIP, "sonar_max_to_host_end_f32: no current device");
+    MaxSlot& s = g_max_slot[dev];
+    SONAR_REQUIRE(s.pending, SONAR_ERR_ARG, "sonar_max_to_host_end_f32: no request in flight on this thread");
+    s.pending = false;
+    // the word usually lands within microseconds: look at it for a short while before handing the wait to the runtime
+    unsigned long long word = 0;
+    bool seen = false;
+    for (int spin = 0; spin < 16384 && !seen; ++spin) {
+        word = __atomic_load_n(s.word, __ATOMIC_ACQUIRE);
+        seen = (unsigned)(word >> 32) == s.ticket;
+    }
+    if (!seen) {
+        SONAR_REQUIRE(hipStreamSynchronize((hipStream_t)stream) == hipSuccess, SONAR_ERR_HIP, "sonar_max_to_host_end_f32: stream wait failed");
+        word = __atomic_load_n(s.word, __ATOMIC_ACQUIRE);
+        SONAR_REQUIRE((unsigned)(word >> 32) == s.ticket, SONAR_ERR_HIP, "sonar_max_to_host_end_f32: the result never arrived");
+    }
+    const unsigned bits = (unsigned)word;
+    memcpy(result, &bits, sizeof(float));
     return SONAR_OK;
+}
+
+extern "C" int sonar_max_to_host_f32(const float* x, int64_t n, float* result, void* stream) {
+    SONAR_REQUIRE(result, SONAR_ERR_ARG, "sonar_max_to_host_f32: bad argument (a non-empty device vector is required)");
+    const int rc = sonar_max_to_host_begin_f32(x, n, stream);
+    return rc != SONAR_OK ? rc : sonar_max_to_host_end_f32(result, stream);
 }
 
 extern "C" int sonar_mask_mix_f32(const float* dst, const float* src, const float* mask, int64_t mask_n, float* out,

@@ -153,6 +153,8 @@ SIGNATURES = {
     "sonar_dtcwt_q2c_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_dtcwt_c2q_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_max_to_host_f32": (_I, [_P, _I64, C.POINTER(C.c_float), _P]),
+    "sonar_max_to_host_begin_f32": (_I, [_P, _I64, _P]),
+    "sonar_max_to_host_end_f32": (_I, [C.POINTER(C.c_float), _P]),
     "sonar_wcfg_fused_ws_bytes": (_I64, [_I64, _I64, _I64, _I, _I, _I, _I, _I, _I]),
     "sonar_wcfg_fused_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _I, _P, _I64, _P]),
     "sonar_wcfg_fused_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _I, _P, _I64, _P]),
@@ -1062,10 +1064,10 @@ def wcfg_output(x: Optional[torch.Tensor], result: torch.Tensor, shape, subtract
 _LOW_OK: dict = {}
 
 
-def wcfg_lowpass(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], *, levels: int, dec_lo, rec_lo, mode: str, inv_mode: str, g,
-                 ku: float, kt: float, subtract_from_x: bool, high_precision: bool) -> Optional[torch.Tensor]:
-    """WaveletCFG for difference-only rules with one detail scale per level, ONE launch (``sonar_wcfg_lowpass_*``: low-pass pyramid in
-    LDS, 16N bytes of HBM traffic per latent); None when the plane's pyramid does not fit in LDS (caller: ``wcfg_fused``)."""
+def wcfg_lowpass_plan(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], *, levels: int, dec_lo, rec_lo, mode: str, inv_mode: str, g,
+                      ku: float, kt: float, subtract_from_x: bool, high_precision: bool):
+    """Everything of ``wcfg_lowpass`` but the launch: a zero-argument callable that launches and returns the output tensor, or None
+    when the plane's pyramid does not fit in LDS.  WaveletCFG builds it while its sigma read is in flight."""
     B, Cc, H, W = cond.shape
     lib = load()
     elem = 8 if high_precision else 4
@@ -1080,10 +1082,26 @@ def wcfg_lowpass(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Ten
         raise SonarHipError("wcfg_lowpass: g must hold levels + 1 weights")
     out = torch.empty_like(cond)
     fn = lib.sonar_wcfg_lowpass_f64 if high_precision else lib.sonar_wcfg_lowpass_f32
-    _check(fn(_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), B * Cc, H, W, levels, _taps_arr(dec_lo), _taps_arr(rec_lo),
-              len(dec_lo), DWT_MODE_IDS[mode], DWT_MODE_IDS[inv_mode], _darr([float(v) for v in g]), float(ku), float(kt), int(bool(subtract_from_x)),
-              _stream()), "sonar_wcfg_lowpass")
-    return out
+    call = (_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), B * Cc, H, W, levels, _taps_arr(dec_lo), _taps_arr(rec_lo),
+            len(dec_lo), DWT_MODE_IDS[mode], DWT_MODE_IDS[inv_mode], _darr([float(v) for v in g]), float(ku), float(kt), int(bool(subtract_from_x)),
+            _stream())
+    keep = (cond, uncond, x)
+
+    def launch():
+        _check(fn(*call), "sonar_wcfg_lowpass")
+        return out
+
+    launch.keep = keep
+    return launch
+
+
+def wcfg_lowpass(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], *, levels: int, dec_lo, rec_lo, mode: str, inv_mode: str, g,
+                 ku: float, kt: float, subtract_from_x: bool, high_precision: bool) -> Optional[torch.Tensor]:
+    """WaveletCFG for difference-only rules with one detail scale per level, ONE launch (``sonar_wcfg_lowpass_*``: low-pass pyramid in
+    LDS, 16N bytes of HBM traffic per latent); None when the plane's pyramid does not fit in LDS (caller: ``wcfg_fused``)."""
+    launch = wcfg_lowpass_plan(cond, uncond, x, levels=levels, dec_lo=dec_lo, rec_lo=rec_lo, mode=mode, inv_mode=inv_mode, g=g, ku=ku, kt=kt,
+                               subtract_from_x=subtract_from_x, high_precision=high_precision)
+    return None if launch is None else launch()
 
 
 _WCFG_WS: dict = {}
@@ -1160,6 +1178,21 @@ def max_to_host(x: torch.Tensor) -> float:
     x = x.contiguous()
     slot = C.c_float()  # per call: the sampler thread and a preview thread may both be in here
     _check(load().sonar_max_to_host_f32(_dev(x, "x"), x.numel(), C.byref(slot), _stream()), "sonar_max_to_host_f32")
+    return slot.value
+
+
+def max_to_host_begin(x: torch.Tensor):
+    """Launch half of ``max_to_host``: returns the token ``max_to_host_end`` takes.  The caller does whatever does not need the value
+    in between (one request per thread at a time; always collect it, also on an error path)."""
+    x = x.contiguous()
+    stream = _stream()
+    _check(load().sonar_max_to_host_begin_f32(_dev(x, "x"), x.numel(), stream), "sonar_max_to_host_begin_f32")
+    return (stream, x)  # x: keeps the vector alive until the value has been read
+
+
+def max_to_host_end(token) -> float:
+    slot = C.c_float()
+    _check(load().sonar_max_to_host_end_f32(C.byref(slot), token[0]), "sonar_max_to_host_end_f32")
     return slot.value
 
 

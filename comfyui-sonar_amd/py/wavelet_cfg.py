@@ -609,6 +609,7 @@ class WaveletCFG:
         self.operation_fallback_cfg = operation_fallback_cfg
         self.operation_wavelet_cfg = operation_wavelet_cfg
         self.operation_result = operation_result
+        self._likely_rule = rules[0] if rules else None  # the rule the next call is prepared for before its sigma is known
 
     @staticmethod
     def basic_cfg_function(args: dict) -> torch.Tensor:
@@ -692,6 +693,12 @@ class WaveletCFG:
         """x - result in ONE launch for rules that only scale the difference bands with one scale per level (the node's placeholder
         rule): by linearity and perfect reconstruction the step collapses to a low-pass pyramid of cond - uncond kept in LDS
         (``sonar_wcfg_lowpass_*``, csrc/dwt_lowpass.h).  None when the rule / wavelet / shape is outside that scope."""
+        launch = cls._lowpass_launch(rule=rule, ctx=ctx, pcts=pcts)
+        return None if launch is None else launch()
+
+    @classmethod
+    def _lowpass_launch(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts):
+        """``wavelet_cfg_lowpass`` up to the launch (``pcts`` is only read when the rule is scheduled)."""
         w = ctx.wavelet
         if ctx.cond.ndim != 4 or ctx.cond.dtype != torch.float32 or ctx.uncond.dtype != torch.float32 or ctx.dtype not in (torch.float32, torch.float64):
             return None
@@ -711,8 +718,27 @@ class WaveletCFG:
         if plan is None:
             return None
         g, ku, kt = plan
-        return hip_lib.wcfg_lowpass(ctx.cond.contiguous(), ctx.uncond.contiguous(), ctx.x.contiguous(), levels=levels, dec_lo=w.dec_lo, rec_lo=w.rec_lo,
-                                    mode=w.mode, inv_mode=w.inv_mode, g=g, ku=ku, kt=kt, subtract_from_x=True, high_precision=ctx.dtype == torch.float64)
+        return hip_lib.wcfg_lowpass_plan(ctx.cond.contiguous(), ctx.uncond.contiguous(), ctx.x.contiguous(), levels=levels, dec_lo=w.dec_lo,
+                                         rec_lo=w.rec_lo, mode=w.mode, inv_mode=w.inv_mode, g=g, ku=ku, kt=kt, subtract_from_x=True,
+                                         high_precision=ctx.dtype == torch.float64)
+
+    def _speculate(self, args: dict):
+        """While the sigma read is in flight: (rule, context, launch) of the one-launch path for the rule the previous call matched,
+        when that rule is unscheduled and nothing in its preparation depends on sigma's VALUE or runs user operations.  None otherwise
+        (and on any error: the ordinary path raises it where the reference does)."""
+        rule = self._likely_rule
+        if rule is None or self.operation_cond is not None or self.operation_uncond is not None or self.operation_wavelet_cfg is not None:
+            return None
+        x = args.get("input")
+        if (not torch.is_tensor(x) or x.ndim != 4 or x.dtype != torch.float32 or rule.target_mode != WCFGTarget.DENOISED or rule.wavelet.use_1d_dwt
+                or rule.blend_mode != "lerp" or not _rule_is_static(rule) or rule.blend_strength.get_value(None) != 1.0):
+            return None
+        try:
+            ctx = self.get_context(rule=rule, args=args)
+            launch = self._lowpass_launch(rule=rule, ctx=ctx, pcts=None)
+        except Exception:  # noqa: BLE001 -- reported by the ordinary path, in the reference's order
+            return None
+        return None if launch is None else (rule, ctx, launch)
 
     @staticmethod
     def _lowpass_plan(rule: WCFGRule, pcts, levels: int):
@@ -793,13 +819,28 @@ class WaveletCFG:
     def __call__(self, args: dict) -> torch.Tensor:
         """py/wavelet_cfg.py:793-842."""
         sigma = args["sigma"]
-        # `sigma.max().item()`: one launch into pinned memory when sigma is an fp32 device tensor (the sampler's case)
-        sigma_f = hip_lib.max_to_host(sigma) if sigma.is_cuda and sigma.dtype == torch.float32 and sigma.numel() > 0 else sigma.max().item()
+        ready = None
+        if sigma.is_cuda and sigma.dtype == torch.float32 and sigma.numel() > 0:
+            # `sigma.max().item()`: one launch into pinned memory; what does not need the value is prepared while it is in flight
+            token = hip_lib.max_to_host_begin(sigma)
+            try:
+                ready = self._speculate(args)
+            finally:
+                sigma_f = hip_lib.max_to_host_end(token)
+        else:
+            sigma_f = sigma.max().item()
         rule = self.rules.get_rule(sigma_f)
         if rule is None:
             return self.fallback_cfg_function(args)
+        self._likely_rule = rule
         if rule.verbose:
             _say(f"\nWCFG: Rule matched, sigma={sigma_f:.4f}, rule={rule.pretty_non_default()}")
+        if ready is not None and ready[0] is rule:
+            # launch first; the percentages (whose errors are the reference's errors, py/wavelet_cfg.py:155-222) are checked under the kernel
+            low = ready[2]()
+            WCFGPercentages.build(ms=args["model"].model_sampling, start_sigma=rule.start_sigma, end_sigma=rule.end_sigma, sigma=sigma_f,
+                                  sigmas=args.get("model_options", {}).get("transformer_options", {}).get("sample_sigmas"))
+            return self.maybe_op(low, self.operation_result, **ready[1].op_kwargs).contiguous()
         model = args["model"]
         pcts = WCFGPercentages.build(ms=model.model_sampling, start_sigma=rule.start_sigma, end_sigma=rule.end_sigma, sigma=sigma_f,
                                      sigmas=args.get("model_options", {}).get("transformer_options", {}).get("sample_sigmas"))

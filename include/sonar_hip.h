@@ -463,8 +463,11 @@ int sonar_dtcwt_c2q_f32(const float* bands, float* lh, float* hh, float* hl, int
 int sonar_dtcwt_q2c_f64(const double* lh, const double* hh, const double* hl, double* bands, int64_t planes, int64_t h, int64_t w, void* stream);
 int sonar_dtcwt_c2q_f64(const double* bands, double* lh, double* hh, double* hl, int64_t planes, int64_t h, int64_t w, void* stream);
 /* max over a non-empty device vector with torch.max's NaN rule, returned to the host: WaveletCFG's `sigma.max().item()`
- * (py/wavelet_cfg.py:795-796) as one launch that writes into pinned host memory + one stream wait.  BLOCKS until the stream drains
- * (as `.item()` does). */
+ * (py/wavelet_cfg.py:795-796) as one launch that writes into pinned host memory + one wait.  `begin` only launches; `end` BLOCKS
+ * until the value has landed (as `.item()` does) -- the host prepares everything that does not depend on the value in between.
+ * One request per host thread and device at a time (`begin` twice without `end`: SONAR_ERR_ARG).  `sonar_max_to_host_f32` = both. */
+int sonar_max_to_host_begin_f32(const float* x, int64_t n, void* stream);
+int sonar_max_to_host_end_f32(float* result, void* stream);
 int sonar_max_to_host_f32(const float* x, int64_t n, float* result, void* stream);
 /* WaveletCFG for difference-only rules with ONE detail scale per level (py/wavelet_cfg.py:750-791 with `cond` / `uncond` / `final`
  * absent; the node's placeholder rule, BASELINE cfg4).  By linearity and perfect reconstruction

@@ -39,15 +39,15 @@ cond, uncond, xin = (torch.randn(b4, 4, 128, 128, device=dev) for _ in range(3))
 wargs = {"cond_denoised": cond, "uncond_denoised": uncond, "cond": xin - cond, "uncond": xin - uncond, "input": xin, "cond_scale": 7.0,
          "sigma": torch.full((b4,), 7.0, device=dev), "model": types.SimpleNamespace(model_sampling=ms),
          "model_options": {"transformer_options": {"sample_sigmas": torch.cat([torch.linspace(14.6, 0.03, 20), torch.zeros(1)])}}}
-real_low, real_pr = wc.WaveletCFG.wavelet_cfg_lowpass, wc._reconstructs
+real_low, real_pr = wc.WaveletCFG._lowpass_launch, wc._reconstructs
 for hp in (True, False):
     fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0), high_precision_mode=hp))
     for _ in range(REPS): fn(wargs)                       # low-pass path (one launch)
-    wc.WaveletCFG.wavelet_cfg_lowpass = classmethod(lambda cls, **_k: None)
+    wc.WaveletCFG._lowpass_launch = classmethod(lambda cls, **_k: None)
     for _ in range(REPS): fn(wargs)                       # band path, one tensor (cond - uncond): dwt2_tile_kernel<.., 2, ..>, wcfg_deep_kernel<.., true>, idwt2_tile_kernel<.., 2, ..>
     wc._reconstructs = lambda w: False
     for _ in range(REPS): fn(wargs)                       # band path, cond and uncond side by side (any rule): <.., 1, ..>, <.., false>, <.., 1, ..>
-    wc.WaveletCFG.wavelet_cfg_lowpass, wc._reconstructs = real_low, real_pr
+    wc.WaveletCFG._lowpass_launch, wc._reconstructs = real_low, real_pr
 del cond, uncond, xin, wargs
 # cfg5's Brownian source on one rank's shard (128 Flux latents): one new path point per call, bridged between kept tensors; then the
 # same folded into a running sum (the chain form)

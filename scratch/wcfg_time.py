@@ -18,16 +18,16 @@ def timed(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e6, e0.elapsed_time(e1) / n * 1e3
 
-real_low = wc.WaveletCFG.wavelet_cfg_lowpass
+real_low = wc.WaveletCFG._lowpass_launch
 for hp in (True, False):
     fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0), high_precision_mode=hp))
     real_pr = wc._reconstructs
     for path in ("lowpass", "diff", "pair"):
-        wc.WaveletCFG.wavelet_cfg_lowpass = real_low if path == "lowpass" else classmethod(lambda cls, **_k: None)
+        wc.WaveletCFG._lowpass_launch = real_low if path == "lowpass" else classmethod(lambda cls, **_k: None)
         wc._reconstructs = (lambda w: False) if path == "pair" else real_pr
         wall, ev = timed(lambda: fn(args))
         print(f"{'fp64' if hp else 'fp32'} {path:8s} wall {wall:7.1f} us  events {ev:7.1f} us  -> {16 * 4 * 128 * 128 * b / ev / 1e3:7.1f} GB/s at 16N", flush=True)
-    wc.WaveletCFG.wavelet_cfg_lowpass = real_low
+    wc.WaveletCFG._lowpass_launch = real_low
     wc._reconstructs = real_pr
     w = fn.rules[0].make_wavelet()
     g = [3.0, 0, 0, 0, 0, 2.0]

@@ -16,6 +16,7 @@ import torch
 
 from oracle import dwt_oracle as dwo
 from tests.conftest import GOLDEN
+from tests import wavelet_helpers as wh
 
 pytestmark = pytest.mark.gpu
 
@@ -218,7 +219,7 @@ def test_wavelet_cfg_fused_equals_per_pass_path(api, monkeypatch, high_precision
     args = {"input": x, "cond_scale": 7.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,
             "sigma": torch.full((3,), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
-    monkeypatch.setattr(api.wc.WaveletCFG, "wavelet_cfg_lowpass", classmethod(lambda cls, **_k: None))  # this test is about the band kernels
+    monkeypatch.setattr(api.wc.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))  # this test is about the band kernels
     calls = []
     real = api.hl.wcfg_fused
     monkeypatch.setattr(api.hl, "wcfg_fused", lambda *a, **k: calls.append(1) or real(*a, **k))
@@ -258,13 +259,13 @@ def test_lowpass_path_equals_band_path(api, monkeypatch, wave, mode, level, shap
                       high_precision_mode=high_precision, difference_blend_mode=blend, difference_blend_strength=strength)
         fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
         calls = []
-        real = api.hl.wcfg_lowpass
+        real = api.hl.wcfg_lowpass_plan
         with monkeypatch.context() as m:
-            m.setattr(api.hl, "wcfg_lowpass", lambda *a, **k: calls.append(1) or real(*a, **k))
+            m.setattr(api.hl, "wcfg_lowpass_plan", lambda *a, **k: wh.counted_launch(real(*a, **k), calls))
             low = fn(args)
         assert calls, "the low-pass entry point was not used"
         with monkeypatch.context() as m:
-            m.setattr(api.wc.WaveletCFG, "wavelet_cfg_lowpass", classmethod(lambda cls, **_k: None))
+            m.setattr(api.wc.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))
             m.setattr(api.wc, "_reconstructs", lambda w: False)  # cond and uncond both transformed (the general route)
             bands = fn(args)
         peak = float(bands.abs().max())
@@ -318,3 +319,23 @@ def test_max_to_host_matches_torch(api):
     with torch.cuda.stream(side):
         t = torch.arange(1000, device="cuda", dtype=torch.float32)
         assert api.hl.max_to_host(t) == 999.0
+
+
+def test_max_to_host_split(api):
+    """``sonar_max_to_host_begin_f32`` / ``_end_f32``: the launch and the wait as two calls; one request per thread at a time."""
+    t = torch.randn(777, device="cuda")
+    tok = api.hl.max_to_host_begin(t)
+    other = torch.randn(1 << 20, device="cuda").square_().sum()  # unrelated work queued behind the request
+    assert api.hl.max_to_host_end(tok) == t.max().item()
+    assert math.isfinite(other.item())
+    tok = api.hl.max_to_host_begin(t)
+    with pytest.raises(api.hl.SonarHipError):
+        api.hl.max_to_host_begin(t)
+    assert api.hl.max_to_host_end(tok) == t.max().item()
+    with pytest.raises(api.hl.SonarHipError):
+        api.hl.max_to_host_end(tok)
+    for k in range(200):  # tickets: every request returns ITS value
+        v = torch.full((65,), float(k), device="cuda")
+        assert api.hl.max_to_host(v) == float(k)
+    t[5] = float("nan")
+    assert math.isnan(api.hl.max_to_host_end(api.hl.max_to_host_begin(t)))

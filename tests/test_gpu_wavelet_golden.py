@@ -102,8 +102,8 @@ FOUR_D = [n for n, c in wc.WCFG_CASES.items() if len(c["shape"]) == 4 and not c[
 def test_lowpass_path_is_taken_where_it_applies(api, monkeypatch):
     """Difference-only rules with one scale per level run as ONE launch (sonar_wcfg_lowpass_*); the others do not."""
     calls = []
-    real = api.hl.wcfg_lowpass
-    monkeypatch.setattr(api.hl, "wcfg_lowpass", lambda *a, **k: calls.append(1) or real(*a, **k))
+    real = api.hl.wcfg_lowpass_plan
+    monkeypatch.setattr(api.hl, "wcfg_lowpass_plan", lambda *a, **k: wh.counted_launch(real(*a, **k), calls))  # launches, not preparations
     used = {}
     for name in FOUR_D:
         case = wc.WCFG_CASES[name]
@@ -120,7 +120,7 @@ def test_lowpass_path_is_taken_where_it_applies(api, monkeypatch):
 @pytest.mark.parametrize("name", FOUR_D)
 def test_wavelet_cfg_band_path_matches_reference(api, name, monkeypatch):
     """The same cases with the low-pass shortcut disabled: cond and uncond analysed band by band (sonar_wcfg_fused_*, 3 launches)."""
-    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "wavelet_cfg_lowpass", classmethod(lambda cls, **_k: None))
+    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))
     case = wc.WCFG_CASES[name]
     args = wh.wcfg_args(case, name, wc.FakeModel(), device="cuda")
     want = WCFG[f"{name}__out"]
@@ -130,12 +130,45 @@ def test_wavelet_cfg_band_path_matches_reference(api, name, monkeypatch):
 @pytest.mark.parametrize("name", FOUR_D)
 def test_wavelet_cfg_per_pass_path_matches_reference(api, name, monkeypatch):
     """The same cases with both fast entry points disabled: the per-level kernels behind Wavelet.forward / inverse."""
-    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "wavelet_cfg_lowpass", classmethod(lambda cls, **_k: None))
+    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))
     monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "wavelet_cfg_fused", classmethod(lambda cls, **_k: None))
     case = wc.WCFG_CASES[name]
     args = wh.wcfg_args(case, name, wc.FakeModel(), device="cuda")
     want = WCFG[f"{name}__out"]
     np.testing.assert_allclose(wh.build_wcfg(api.wavelet_cfg, case)(args).cpu().numpy(), want, rtol=0, atol=_wcfg_tol(case, want))
+
+
+def test_prepared_launch_equals_ordinary_path(api):
+    """While the sigma read is in flight the call prepares the one-launch path for the rule the previous call matched
+    (WaveletCFG._speculate).  Same bits as the ordinary order, across a change of rule, and the prepared launch is really used."""
+    case = wc.WCFG_CASES["second_rule"]
+    fn = wh.build_wcfg(api.wavelet_cfg, case)
+    plain = wh.build_wcfg(api.wavelet_cfg, case)
+    seen = []
+    real = fn._speculate
+    fn._speculate = lambda a: seen.append(real(a)) or seen[-1]
+    plain._speculate = lambda a: None
+    base = wh.wcfg_args(case, "second_rule", wc.FakeModel(), device="cuda")
+    for k, sigma in enumerate((3.0, 3.0, 9.0, 9.0, 3.0, 20.0, 3.0)):
+        args = dict(base, sigma=torch.full_like(base["sigma"], sigma))
+        got, want = fn(args), plain(args)
+        assert torch.equal(got, want), (k, sigma)
+        rule = fn.rules.get_rule(sigma)
+        # prepared for the rule of the previous call: used when this call matches the same rule
+        assert seen[-1] is not None and (seen[-1][0] is rule) == (k in (1, 3, 6)), (k, sigma)
+    np.testing.assert_allclose(fn(base).cpu().numpy(), WCFG["second_rule__out"], rtol=0, atol=_wcfg_tol(case, WCFG["second_rule__out"]))
+    # the percentages are still built (under the kernel), so their errors still surface: no sample_sigmas -> the reference's error
+    bad = dict(base, model_options={"transformer_options": {}})
+    fn(base)
+    with pytest.raises(UnboundLocalError):
+        fn(bad)
+    with pytest.raises(UnboundLocalError):
+        plain(bad)
+    # user operations on cond / uncond run inside get_context: nothing is prepared then
+    op = wh.build_wcfg(api.wavelet_cfg, case)
+    op.operation_cond = lambda latent, **_k: latent
+    assert op._speculate(base) is None
+    torch.testing.assert_close(op(base), plain(base), rtol=0, atol=0)
 
 
 def test_wavelet_cfg_errors(api):

@@ -71,3 +71,11 @@ def numpy_ops(ops):
             return fn(latent=torch.from_numpy(np.ascontiguousarray(t)), **kw).numpy()
         return call
     return {k: wrap(v) for k, v in ops.items()}
+
+
+def counted_launch(launch, calls):
+    """Wrap what ``hip_lib.wcfg_lowpass_plan`` returned so that ``calls`` records every LAUNCH (a prepared launch that is dropped because
+    another rule matched does not count)."""
+    if launch is None:
+        return None
+    return lambda: calls.append(1) or launch()
