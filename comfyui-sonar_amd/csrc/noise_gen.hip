@@ -905,55 +905,102 @@ struct BrownianBase {
     const float* b;
     float fa, fb;
 };
+// A tile-keyed generator's fold y <- y * ya + x * f riding in this kernel's pass over y (sonar_fold_prefix): the chain's previous item
+// (Gaussian draw or Perlin) is evaluated on the fly and applied BEFORE the increment's own fold, so its read + write of the running sum
+// disappears.  Same stream keys, same operations in the same order as its own kernel -> the same bits.
+struct Prefix {
+    float ya, f, div_fac;
+    uint64_t seed, stream_id;
+    const float* terms;
+    int chw;
+};
+// PRE: 0 none, 1 Gaussian draw, 2 Perlin (summed lattice, tile-aligned latents).  With a prefix a wave walks the kBrownPerTile
+// consecutive Brownian tiles of one generator tile, carrying the prefix's generator state across them.
+constexpr int kBrownPerTile = kTileElems / (4 * 256);
+template <int PRE>
 __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
                                                                 uint64_t seed, const float* prev, float* w_out, float scale,
-                                                                BrownianBase base, Accum fold, double* partials) {
+                                                                BrownianBase base, Accum fold, double* partials, Prefix pre) {
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const uint32_t lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
     const int64_t first = elem_offset / kBrownTile, tiles = n / kBrownTile;  // both aligned (launcher)
-    for (int64_t t = wave; t < tiles; t += nwaves) {
-        float acc[kBrownIters][4];
-        const int64_t o = t * kBrownTile + (int64_t)lane * 4;
-#pragma unroll
-        for (int it = 0; it < kBrownIters; ++it) {
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (base.a) {
-                const float4 p = *reinterpret_cast<const float4*>(base.a + o + it * 256);
-                v = make_float4(base.fa * p.x, base.fa * p.y, base.fa * p.z, base.fa * p.w);
-            }
-            if (base.b) {
-                const float4 p = *reinterpret_cast<const float4*>(base.b + o + it * 256);
-                v = make_float4(__builtin_fmaf(base.fb, p.x, v.x), __builtin_fmaf(base.fb, p.y, v.y), __builtin_fmaf(base.fb, p.z, v.z),
-                                __builtin_fmaf(base.fb, p.w, v.w));
-            }
-            acc[it][0] = v.x; acc[it][1] = v.y; acc[it][2] = v.z; acc[it][3] = v.w;
+    constexpr int SUB = PRE ? kBrownPerTile : 1;
+    const Accum pfold{fold.y, pre.ya, pre.f};
+    const Divider pdiv(PRE == 2 ? pre.div_fac : 1.0f);
+    for (int64_t T = wave; T < tiles / SUB; T += nwaves) {
+        Xoshiro prng;
+        const float4* trow = nullptr;
+        if constexpr (PRE != 0) {
+            prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)(elem_offset / kTileElems + T), lane);
+            // shards start on a latent boundary and latents are whole tiles (launcher): the tile's vectors sit at trow[64 * iteration]
+            if constexpr (PRE == 2) trow = reinterpret_cast<const float4*>(pre.terms + (int)((T * kTileElems + (int64_t)lane * 4) % pre.chw));
         }
-        for (int k = 0; k < terms.count; ++k) {
-            Xoshiro rng = rng_stream(seed, terms.node[k], (uint64_t)(first + t), lane);
-            const float c = terms.coef[k];
+#pragma unroll 1
+        for (int sub = 0; sub < SUB; ++sub) {
+            const int64_t t = T * SUB + sub;
+            float acc[kBrownIters][4];
+            const int64_t o = t * kBrownTile + (int64_t)lane * 4;
 #pragma unroll
             for (int it = 0; it < kBrownIters; ++it) {
-                float z[4];
-                rng.normal4(z);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_fmaf(c, z[j], acc[it][j]);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < kBrownIters; ++it) {
-            float4 a = make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]);
-            if (w_out) *reinterpret_cast<float4*>(w_out + o + it * 256) = a;
-            if (out) {
-                if (prev) {
-                    const float4 p = *reinterpret_cast<const float4*>(prev + o + it * 256);
-                    a = make_float4(a.x - p.x, a.y - p.y, a.z - p.z, a.w - p.w);
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (base.a) {
+                    const float4 p = *reinterpret_cast<const float4*>(base.a + o + it * 256);
+                    v = make_float4(base.fa * p.x, base.fa * p.y, base.fa * p.z, base.fa * p.w);
                 }
-                float v[4] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale};
-                accumulate_group<true>(fold, n, o + it * 256, v);
-                store_group<true>(out, n, o + it * 256, v, s, q, partials != nullptr);
+                if (base.b) {
+                    const float4 p = *reinterpret_cast<const float4*>(base.b + o + it * 256);
+                    v = make_float4(__builtin_fmaf(base.fb, p.x, v.x), __builtin_fmaf(base.fb, p.y, v.y), __builtin_fmaf(base.fb, p.z, v.z),
+                                    __builtin_fmaf(base.fb, p.w, v.w));
+                }
+                acc[it][0] = v.x; acc[it][1] = v.y; acc[it][2] = v.z; acc[it][3] = v.w;
+            }
+            for (int k = 0; k < terms.count; ++k) {
+                Xoshiro rng = rng_stream(seed, terms.node[k], (uint64_t)(first + t), lane);
+                const float c = terms.coef[k];
+#pragma unroll
+                for (int it = 0; it < kBrownIters; ++it) {
+                    float z[4];
+                    rng.normal4(z);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_fmaf(c, z[j], acc[it][j]);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < kBrownIters; ++it) {
+                float4 a = make_float4(acc[it][0], acc[it][1], acc[it][2], acc[it][3]);
+                if (w_out) *reinterpret_cast<float4*>(w_out + o + it * 256) = a;
+                if (out) {
+                    if (prev) {
+                        const float4 p = *reinterpret_cast<const float4*>(prev + o + it * 256);
+                        a = make_float4(a.x - p.x, a.y - p.y, a.z - p.z, a.w - p.w);
+                    }
+                    float v[4] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale};
+                    if constexpr (PRE != 0) {
+                        // the previous item's values for these four elements, folded into y first: y1 = y * ya + x * f (its own kernel's
+                        // arithmetic), then this item's fold on y1
+                        float x[4];
+                        if constexpr (PRE == 1) {
+                            prng.normal4(x);
+                        } else {
+                            prng.uniform4(x);
+                            const float4 tv = trow[64 * (sub * kBrownIters + it)];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) x[k] = pdiv(x[k]);
+                            x[0] += tv.x; x[1] += tv.y; x[2] += tv.z; x[3] += tv.w;
+                        }
+                        const float4 y = *reinterpret_cast<const float4*>(fold.y + o + it * 256);
+                        v[0] = fold(pfold(y.x, x[0]), v[0]);
+                        v[1] = fold(pfold(y.y, x[1]), v[1]);
+                        v[2] = fold(pfold(y.z, x[2]), v[2]);
+                        v[3] = fold(pfold(y.w, x[3]), v[3]);
+                    } else {
+                        accumulate_group<true>(fold, n, o + it * 256, v);
+                    }
+                    store_group<true>(out, n, o + it * 256, v, s, q, partials != nullptr);
+                }
             }
         }
     }
@@ -1080,7 +1127,7 @@ extern "C" int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64
 static int brownian_launch(float* out, float* w_out, const float* prev, float scale, int64_t n, int64_t elem_offset,
                            const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds,
                            int64_t latent_elems, void* stream, const char* what, BrownianBase base = BrownianBase{nullptr, nullptr, 0.0f, 0.0f},
-                           Accum acc = kNoAccum, double* partials = nullptr) {
+                           Accum acc = kNoAccum, double* partials = nullptr, const sonar_fold_prefix* pre = nullptr) {
     SONAR_REQUIRE((out || w_out) && n >= 0 && elem_offset >= 0 && (elem_offset & 3) == 0 && nnodes >= 0 && (nnodes == 0 || (node_ids && coefs)),
                   SONAR_ERR_ARG, "%s: bad argument", what);
     SONAR_REQUIRE(nnodes <= kMaxBrownianNodes, SONAR_ERR_UNSUPPORTED, "%s: more than %d path nodes", what, kMaxBrownianNodes);
@@ -1101,9 +1148,26 @@ static int brownian_launch(float* out, float* w_out, const float* prev, float sc
     SONAR_REQUIRE(!partials || out, SONAR_ERR_ARG, "%s: statistics need an output tensor", what);
     // statistics: one (sum, sumsq) pair per block, at most kNPart blocks
     const int cap = partials ? kNPart : kMaxGrid;
-    if (burst)
-        hipLaunchKernelGGL(brownian_burst_kernel, dim3(std::min(cap, grid_for(n / kBrownTile, 4))), dim3(kBlock), 0, (hipStream_t)stream, out,
-                           n, elem_offset, t, seed, prev, w_out, scale, base, acc, partials);
+    Prefix px{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1};
+    if (pre) {
+        // the previous chain item rides along only in the tile kernel, on the same running sum, with whole generator tiles per latent
+        SONAR_REQUIRE(pre->kind == SONAR_PREFIX_NORMAL || pre->kind == SONAR_PREFIX_PERLIN, SONAR_ERR_ARG, "%s: unknown prefix kind", what);
+        const bool perlin = pre->kind == SONAR_PREFIX_PERLIN;
+        SONAR_REQUIRE(burst && acc.y && out == acc.y &&
+                          (!perlin || (pre->terms && al(pre->terms) && pre->chw == latent_elems && pre->chw < (1LL << 31))),
+                      SONAR_ERR_UNSUPPORTED, "%s: this shape cannot host a fold prefix (apply it with its own entry point)", what);
+        px = Prefix{pre->y_mul, pre->x_mul, perlin ? pre->div_fac : 1.0f, pre->seed, pre->stream_id, pre->terms, perlin ? (int)pre->chw : 1};
+    }
+#define SONAR_BB(P) \
+    hipLaunchKernelGGL((brownian_burst_kernel<P>), dim3(std::min(cap, grid_for(n / (kBrownTile * (P ? kBrownPerTile : 1)), 4))), dim3(kBlock), 0, \
+                       (hipStream_t)stream, out, n, elem_offset, t, seed, prev, w_out, scale, base, acc, partials, px)
+    if (burst && pre && pre->kind == SONAR_PREFIX_NORMAL)
+        SONAR_BB(1);
+    else if (burst && pre)
+        SONAR_BB(2);
+    else if (burst)
+        SONAR_BB(0);
+#undef SONAR_BB
     else
         hipLaunchKernelGGL(brownian_kernel, dim3(std::min(cap, grid_for((n + 3) / 4, kBlock))), dim3(kBlock), 0, (hipStream_t)stream, out, n,
                            elem_offset, t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems, prev, w_out, scale,
@@ -1144,6 +1208,16 @@ extern "C" int sonar_brownian_bridge_acc_f32(const sonar_accumulate* acc, float*
     return brownian_launch(acc->y, w_out, prev, scale, n, elem_offset, node_ids, coefs, nnodes, seed, latent_seeds, latent_elems, stream,
                            "sonar_brownian_bridge_acc_f32", BrownianBase{base_a, base_b, fa, fb}, Accum{acc->y, acc->y_mul, acc->x_mul},
                            acc->partials);
+}
+
+extern "C" int sonar_brownian_bridge_chain_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, float* w_out, const float* prev,
+                                               float scale, const float* base_a, float fa, const float* base_b, float fb, int64_t n,
+                                               int64_t elem_offset, const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed,
+                                               int64_t latent_elems, void* stream) {
+    SONAR_REQUIRE(accum_ok(acc) && pre, SONAR_ERR_ARG, "sonar_brownian_bridge_chain_f32: bad argument");
+    return brownian_launch(acc->y, w_out, prev, scale, n, elem_offset, node_ids, coefs, nnodes, seed, nullptr, latent_elems, stream,
+                           "sonar_brownian_bridge_chain_f32", BrownianBase{base_a, base_b, fa, fb}, Accum{acc->y, acc->y_mul, acc->x_mul},
+                           acc->partials, pre);
 }
 
 extern "C" int sonar_philox_normal_acc_f32(const sonar_accumulate* acc, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,

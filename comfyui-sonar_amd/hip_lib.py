@@ -152,6 +152,7 @@ SIGNATURES = {
     "sonar_dtcwt_c2q_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_dtcwt_q2c_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_dtcwt_c2q_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "sonar_brownian_bridge_chain_f32": (_I, [_P, _P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _I64, _P]),
     "sonar_max_to_host_f32": (_I, [_P, _I64, C.POINTER(C.c_float), _P]),
     "sonar_max_to_host_begin_f32": (_I, [_P, _I64, _P]),
     "sonar_max_to_host_end_f32": (_I, [C.POINTER(C.c_float), _P]),
@@ -633,19 +634,77 @@ def perlin_generate_acc_(y: torch.Tensor, y_mul: float, x_mul: float, terms: tor
     return y
 
 
+class FoldPrefixArg(C.Structure):
+    """``sonar_fold_prefix`` (include/sonar_hip.h)."""
+
+    _fields_ = [("kind", C.c_int32), ("y_mul", C.c_float), ("x_mul", C.c_float), ("div_fac", C.c_float), ("seed", C.c_uint64),
+                ("stream_id", C.c_uint64), ("terms", C.c_void_p), ("chw", C.c_int64)]
+
+
+PREFIX_NORMAL, PREFIX_PERLIN = 1, 2
+_TILE_ELEMS = 4096
+
+
+class FoldPrefix:
+    """The fold y <- y * y_mul + x * x_mul of a tile-keyed generator (Gaussian draw / Perlin), captured with its keys already taken so
+    that the NEXT chain item's kernel can evaluate it during its own pass over y (``sonar_brownian_bridge_chain_f32``).  Whoever holds
+    one must end with ``apply()``: a no-op once a kernel has hosted it, the item's own accumulating launch otherwise."""
+
+    def __init__(self, kind: int, y: torch.Tensor, y_mul: float, x_mul: float, seed: int, stream_id: int, elem_offset: int,
+                 terms: Optional[torch.Tensor] = None, div_fac: float = 1.0):
+        self.kind, self.y, self.y_mul, self.x_mul = kind, y, float(y_mul), float(x_mul)
+        self.seed, self.stream_id, self.elem_offset, self.terms, self.div_fac = seed, stream_id, elem_offset, terms, float(div_fac)
+        self.consumed = False
+
+    def apply(self) -> None:
+        if self.consumed:
+            return
+        self.consumed = True
+        if self.kind == PREFIX_NORMAL:
+            philox_normal_acc_(self.y, self.y_mul, self.x_mul, self.seed, self.stream_id, self.elem_offset)
+        else:
+            perlin_generate_acc_(self.y, self.y_mul, self.x_mul, self.terms, self.div_fac, self.seed, self.stream_id, self.elem_offset)
+
+    def hosted(self, y: torch.Tensor, elem_offset: int, tensors) -> bool:
+        """Can a tile kernel working on ``y`` at ``elem_offset`` carry this fold?  (Mirrors the checks of the entry point.)"""
+        latent = y.numel() // max(y.shape[0], 1)
+        if (self.consumed or y.data_ptr() != self.y.data_ptr() or y.numel() != self.y.numel() or elem_offset != self.elem_offset
+                or y.shape[0] == 0 or latent % _TILE_ELEMS or any(t is not None and t.data_ptr() % 16 for t in (y, *tensors))):
+            return False
+        if self.kind == PREFIX_PERLIN:
+            return self.terms is not None and self.terms.numel() == latent and self.terms.data_ptr() % 16 == 0
+        return self.kind == PREFIX_NORMAL
+
+    def arg(self):
+        return C.byref(FoldPrefixArg(self.kind, self.y_mul, self.x_mul, self.div_fac, self.seed & (2**64 - 1), self.stream_id,
+                                     None if self.terms is None else _dev(self.terms, "terms"),
+                                     0 if self.terms is None else self.terms.numel()))
+
+
 def brownian_bridge_acc_(y: torch.Tensor, y_mul: float, x_mul: float, node_ids, coefs, seed: int, elem_offset: int = 0,
                          latent_seeds: Optional[torch.Tensor] = None, *, base_a=None, fa: float = 0.0, base_b=None, fb: float = 0.0, prev=None,
-                         scale: float = 1.0, partials=None, want_w: bool = True):
+                         scale: float = 1.0, partials=None, want_w: bool = True, pre: Optional[FoldPrefix] = None):
     """The increment of ``brownian_bridge`` folded into y (y <- y * y_mul + scale * (W - prev) * x_mul); returns W (or None).  At most 96
-    terms; none at all is fine (W = fa * base_a + fb * base_b)."""
+    terms; none at all is fine (W = fa * base_a + fb * base_b).  ``pre``: the previous chain item's fold, applied to y first -- inside
+    this launch when the tile kernel can host it, by its own launch before this one otherwise."""
     if len(node_ids) > BROWNIAN_MAX_TERMS:
         raise SonarHipError("brownian_bridge_acc_: expansion too long for one launch")
     w = torch.empty_like(y) if want_w else None
     n = y.numel()
+    ids = (C.c_uint64 * len(node_ids))(*[int(v) & (2**64 - 1) for v in node_ids])
+    cfs = (C.c_float * len(coefs))(*[float(v) for v in coefs])
+    if pre is not None and latent_seeds is None and pre.hosted(y, elem_offset, (w, prev, base_a, base_b)):
+        pre.consumed = True
+        _check(load().sonar_brownian_bridge_chain_f32(accumulate_arg(y, y_mul, x_mul, partials), pre.arg(), _opt(w, "w_out"), _opt(prev, "prev"),
+                                                      float(scale), _opt(base_a, "base_a"), float(fa), _opt(base_b, "base_b"), float(fb), n,
+                                                      elem_offset, ids, cfs, len(node_ids), seed & (2**64 - 1), n // y.shape[0], _stream()),
+               "sonar_brownian_bridge_chain_f32")
+        return w
+    if pre is not None:
+        pre.apply()
     _check(load().sonar_brownian_bridge_acc_f32(accumulate_arg(y, y_mul, x_mul, partials), _opt(w, "w_out"), _opt(prev, "prev"), float(scale),
-                                                _opt(base_a, "base_a"), float(fa), _opt(base_b, "base_b"), float(fb), n, elem_offset,
-                                                (C.c_uint64 * len(node_ids))(*[int(v) & (2**64 - 1) for v in node_ids]),
-                                                (C.c_float * len(coefs))(*[float(v) for v in coefs]), len(node_ids), seed & (2**64 - 1),
+                                                _opt(base_a, "base_a"), float(fa), _opt(base_b, "base_b"), float(fb), n, elem_offset, ids, cfs,
+                                                len(node_ids), seed & (2**64 - 1),
                                                 None if latent_seeds is None else latent_seeds.data_ptr(), n // y.shape[0], _stream()),
            "sonar_brownian_bridge_acc_f32")
     return w

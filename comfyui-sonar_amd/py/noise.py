@@ -158,18 +158,34 @@ class CustomNoiseChain:
                 if out is not None:
                     return out, True
             total, first = None, None
+            pending = None  # the previous item's fold, captured for this item's kernel (hip_lib.FoldPrefix)
             for idx, ns in enumerate(samplers):
                 fold = getattr(ns, "accumulate", None) if idx else None
                 if fold is not None:
                     # a generator that can fold its values into the running sum does so (read + write of the sum) instead of writing a
                     # tensor for the accumulation kernel to read back; same arithmetic, same bits
                     y, ymul = first if total is None else (total, 1.0)
-                    partials = hip_lib.new_partials(y.device) if idx == len(samplers) - 1 else None
-                    if fold(y, ymul, partials, sigma, sigma_next):
+                    last = idx == len(samplers) - 1
+                    if pending is None and not last and getattr(samplers[idx + 1], "accepts_prefix", False):
+                        # ... and when the NEXT item's kernel can evaluate this one on the fly, not even that: one pass for both
+                        capture = getattr(ns, "fold_prefix", None)
+                        pending = capture(y, ymul, sigma, sigma_next) if capture is not None else None
+                        if pending is not None:
+                            total = y
+                            continue
+                    partials = hip_lib.new_partials(y.device) if last else None
+                    done = fold(y, ymul, partials, sigma, sigma_next, **({} if pending is None else {"pre": pending}))
+                    if pending is not None:
+                        pending.apply()  # nothing to do when the kernel hosted it
+                        pending = None
+                    if done:
                         total = y
                         if partials is not None:
                             utils.attach_stats(total, partials)
                         continue
+                elif pending is not None:
+                    pending.apply()
+                    pending = None
                 raw = getattr(ns, "unscaled", None)
                 pair = raw(sigma, sigma_next) if raw is not None else None
                 part, f = pair if pair is not None else (ns(sigma, sigma_next), 1.0)
@@ -254,16 +270,34 @@ class NoiseSampler:
             return scale_noise(noise, self.factor, normalized=False).to(dtype=self.dtype, device=self.device), 1.0
         return noise, float(self.factor)
 
-    def accumulate(self, y, y_mul, partials, *args) -> bool:
+    def accumulate(self, y, y_mul, partials, *args, pre=None) -> bool:
         """y <- y * y_mul + noise * factor in place, the noise never written out, when this wrapper would only multiply and its generator can
-        fold (``generate_into``); ``partials`` (nullable) receives the statistics of the new y.  False: the caller takes the ordinary route."""
+        fold (``generate_into``); ``partials`` (nullable) receives the statistics of the new y.  False: the caller takes the ordinary route
+        (and ``pre``, the previous item's captured fold, is still the caller's to apply)."""
         if self.normalized or self.dtype != torch.float32 or y.dtype != torch.float32 or y.device != self.device or not y.is_contiguous():
             return False
         into = getattr(self.noise_sampler, "generate_into", None)
         if into is None:
             return False
         args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
-        return bool(into(y, float(y_mul), float(self.factor), partials, *args))
+        return bool(into(y, float(y_mul), float(self.factor), partials, *args, **({} if pre is None else {"pre": pre})))
+
+    @property
+    def accepts_prefix(self) -> bool:
+        """True when ``accumulate`` takes ``pre=`` (the previous chain item's fold, ``hip_lib.FoldPrefix``) and applies it in its own pass."""
+        return (not self.normalized and self.dtype == torch.float32 and bool(getattr(self.noise_sampler, "accepts_prefix", False))
+                and getattr(self.noise_sampler, "generate_into", None) is not None)
+
+    def fold_prefix(self, y, y_mul, *args):
+        """``accumulate`` captured instead of launched: the descriptor of y <- y * y_mul + noise * factor for the next item's kernel (the
+        generator's keys are taken now, in chain order); None when this sampler cannot fold that way."""
+        if self.normalized or self.dtype != torch.float32 or y.dtype != torch.float32 or y.device != self.device or not y.is_contiguous():
+            return None
+        make = getattr(self.noise_sampler, "fold_prefix", None)
+        if make is None:
+            return None
+        args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
+        return make(y, float(y_mul), float(self.factor), *args)
 
     def normalized_call(self, factor, *args):
         """This sampler's output (its own factor must be 1, no normalisation of its own) followed by scale_noise(factor,

@@ -318,6 +318,14 @@ class GaussianNoiseGenerator(NoiseGenerator):
         hip_lib.philox_normal_acc_(y, y_mul, x_mul, seed, stream, self.latent_elem_offset(math.prod(self.shape[1:])), partials)
         return True
 
+    def fold_prefix(self, y, y_mul, x_mul, *_args):
+        """``generate_into`` captured instead of launched (``hip_lib.FoldPrefix``): the next chain item's kernel applies it in its own pass."""
+        if not self._plain_output() or tuple(y.shape) != tuple(self.shape):
+            return None
+        self.pre_hook()
+        seed, stream = self.device_key()
+        return hip_lib.FoldPrefix(hip_lib.PREFIX_NORMAL, y, y_mul, x_mul, seed, stream, self.latent_elem_offset(math.prod(self.shape[1:])))
+
 
 class UniformNoiseGenerator(NoiseGenerator):
     """py/noise_generation.py:496-514: (U[0,1) - sub_fac) * mul_fac + mean_fac."""
@@ -403,6 +411,17 @@ class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):
         terms = hip_lib.perlin_lattice(max(self.iterations, 0), c, h, w, self.device, self.blend_mode, seed, stream + 1)
         hip_lib.perlin_generate_acc_(y.view(b, c, h, w), y_mul, x_mul, terms, self.div_fac, seed, stream, self.latent_elem_offset(c * h * w), partials)
         return True
+
+    def fold_prefix(self, y, y_mul, x_mul, *_args):
+        """``generate_into`` with the lattice built and the keys taken, the fold itself left to the next chain item's kernel."""
+        if not self._plain_output() or tuple(y.shape) != tuple(self.shape) or self.blend_mode not in hip_lib.BLEND_IDS:
+            return None
+        self.pre_hook()
+        b, c, h, w = self.get_adjusted_shape()
+        seed, stream = self.device_key(2)
+        terms = hip_lib.perlin_lattice(max(self.iterations, 0), c, h, w, self.device, self.blend_mode, seed, stream + 1)
+        return hip_lib.FoldPrefix(hip_lib.PREFIX_PERLIN, y.view(b, c, h, w), y_mul, x_mul, seed, stream, self.latent_elem_offset(c * h * w),
+                                  terms=terms, div_fac=self.div_fac)
 
 
 class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
@@ -992,13 +1011,14 @@ class BrownianTreeNoiseSampler:
         if fold is None:
             return hip_lib.brownian_bridge(self.shape, self.device, ids, coefs, *tail, **bases, prev=prev, scale=scale, want_out=want_out, want_w=want_w,
                                            partials=partials)
-        y, y_mul, x_mul, partials = fold
+        y, y_mul, x_mul, partials, pre = fold
         w = None
         if len(ids) > hip_lib.BROWNIAN_MAX_TERMS:  # a long expansion: W first (in chunks), then the fold with no terms left
             _, w = hip_lib.brownian_bridge(self.shape, self.device, ids, coefs, *tail, **bases, want_out=False)
             ids, coefs, bases = [], [], dict(base_b=w, fb=1.0)
             want_w = False
-        made = hip_lib.brownian_bridge_acc_(y, y_mul, x_mul, ids, coefs, *tail, **bases, prev=prev, scale=scale, partials=partials, want_w=want_w)
+        made = hip_lib.brownian_bridge_acc_(y, y_mul, x_mul, ids, coefs, *tail, **bases, prev=prev, scale=scale, partials=partials, want_w=want_w,
+                                            pre=pre)
         return y, (made if w is None else w)
 
     def _point(self, t: float, *, prev: Optional[Tensor] = None, scale: float = 1.0, want_out: bool = True, fold=None, partials=None):
@@ -1019,11 +1039,13 @@ class BrownianTreeNoiseSampler:
         self._remember(t, w)
         return out, w
 
-    def accumulate(self, y: Tensor, y_mul: float, x_mul: float, partials, sigma, sigma_next) -> bool:
-        """y <- y * y_mul + self(sigma, sigma_next) * x_mul without writing the increment out (a noise chain's running sum)."""
+    def accumulate(self, y: Tensor, y_mul: float, x_mul: float, partials, sigma, sigma_next, pre=None) -> bool:
+        """y <- y * y_mul + self(sigma, sigma_next) * x_mul without writing the increment out (a noise chain's running sum).  ``pre``
+        (``hip_lib.FoldPrefix``): the previous item's fold, applied to y first by the same launch when it can be (else by its own).
+        False: nothing was done to y, ``pre`` included."""
         if tuple(y.shape) != self.shape or y.device != self.device or y.dtype != torch.float32 or not y.is_contiguous():
             return False
-        self(sigma, sigma_next, fold=(y, y_mul, x_mul, partials))
+        self(sigma, sigma_next, fold=(y, y_mul, x_mul, partials, pre))
         return True
 
     def __call__(self, sigma, sigma_next, *, fold=None, partials=None) -> Tensor:
@@ -1076,10 +1098,12 @@ class BrownianNoiseGenerator(NoiseGenerator):
         partials = hip_lib.new_partials(self.device)
         return attach_stats(self.brownian_tree_ns(*args, partials=partials), partials)
 
-    def generate_into(self, y, y_mul, x_mul, partials, *args):
+    accepts_prefix = True  # generate_into(..., pre=): the previous chain item's fold rides in this generator's kernel
+
+    def generate_into(self, y, y_mul, x_mul, partials, *args, pre=None):
         if not self._plain_output():
             return False
-        return self.brownian_tree_ns.accumulate(y, y_mul, x_mul, partials, *args)
+        return self.brownian_tree_ns.accumulate(y, y_mul, x_mul, partials, *args, pre=pre)
 
 
 class WaveletNoiseOctave(NamedTuple):

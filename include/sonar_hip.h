@@ -275,6 +275,29 @@ int sonar_brownian_bridge_acc_f32(const sonar_accumulate* acc, float* w_out, con
                                   const float* base_b, float fb, int64_t n, int64_t elem_offset, const uint64_t* node_ids,
                                   const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds, int64_t latent_elems,
                                   void* stream);
+/* Two chain items in ONE pass over the running sum (py/noise.py:188-194 with a Gaussian or Perlin item followed by a Brownian one):
+ * `pre` describes the fold the PREVIOUS item would have made with its own entry point (kind NORMAL: sonar_philox_normal_acc_f32 with
+ * that seed / stream_id; kind PERLIN: sonar_perlin_generate_acc_f32 with iters == 1, that summed lattice, chw == latent_elems); the
+ * Brownian kernel evaluates it per element, applies y1 = y * pre.y_mul + x * pre.x_mul and then its own fold on y1 -- the same
+ * operations as the two launches, so the same bits, with one read + write of the sum instead of two.  Requires the tile route of the
+ * Brownian kernel (one seed, latents of whole 4096-element tiles, 16-byte aligned tensors; the two items share elem_offset):
+ * SONAR_ERR_UNSUPPORTED otherwise, and the caller applies `pre` with its own entry point first. */
+#define SONAR_PREFIX_NORMAL 1
+#define SONAR_PREFIX_PERLIN 2
+typedef struct sonar_fold_prefix {
+    int32_t kind;
+    float y_mul;      /* y1 = y * y_mul + x * x_mul */
+    float x_mul;
+    float div_fac;    /* PERLIN */
+    uint64_t seed;
+    uint64_t stream_id;
+    const float* terms; /* PERLIN: the summed lattice [chw] */
+    int64_t chw;        /* PERLIN */
+} sonar_fold_prefix;
+int sonar_brownian_bridge_chain_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, float* w_out, const float* prev, float scale,
+                                    const float* base_a, float fa, const float* base_b, float fb, int64_t n, int64_t elem_offset,
+                                    const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed, int64_t latent_elems,
+                                    void* stream);
 
 /* ---------------------------------------------------------------- Perlin (row P) */
 /* py/noise_generation.py:465-476,388-405 at the only position generate() uses (grid == output,

@@ -433,6 +433,107 @@ def test_chain_of_folding_generators_equals_the_unfused_chain(api, monkeypatch):
             assert tag_a or not normalized  # the normalised result carries its statistics (derived from the sum's, no sweep)
 
 
+@pytest.mark.parametrize("n_shape", [(3, 4, 64, 64), (2, 16, 128, 128), (2, 3, 5, 7), (2, 4, 40, 56)])
+def test_brownian_kernel_hosts_the_previous_items_fold(api, n_shape):
+    """sonar_brownian_bridge_chain_f32: the previous chain item's fold (Gaussian draw or Perlin, ``hip_lib.FoldPrefix``) evaluated inside
+    the Brownian kernel's pass over the running sum == that item's own accumulating launch followed by the Brownian one, bit for bit
+    (y and W), statistics of the final y included.  Latents that are not whole generator tiles: the prefix is applied by its own launch."""
+    hl = api.hl
+    g = torch.Generator(device="cuda").manual_seed(8)
+    y0 = torch.randn(n_shape, device="cuda", generator=g)
+    n, per = y0.numel(), y0.numel() // n_shape[0]
+    offs = 8 * per
+    c, h, w = n_shape[1:]
+    terms = hl.perlin_lattice(3, c, h, w, "cuda", "lerp", 99, 3)
+    wa, wb = torch.randn(n_shape, device="cuda", generator=g), torch.randn(n_shape, device="cuda", generator=g)
+    routes = [dict(ids=[5], coefs=[0.4], base_a=wa, fa=0.3, base_b=wb, fb=0.7, prev=wa, scale=1.7),   # bridge between two kept tensors
+              dict(ids=[], coefs=[], base_b=wb, fb=1.0, prev=wa, scale=-0.5),                          # both ends kept
+              dict(ids=[3, 9, 11], coefs=[0.2, -0.7, 1.1], scale=0.9)]                                # a short expansion, W(t_lo) = 0
+    hostable = per % 4096 == 0
+    for kind in ("normal", "perlin"):
+        for (a1, b1), b2, route in zip(((0.5, 0.3), (1.0, 1.0), (-1.25, 0.2)), (0.2, 1.0, 0.6), routes):
+            def prefix(y):
+                if kind == "normal":
+                    return hl.FoldPrefix(hl.PREFIX_NORMAL, y, a1, b1, 1234, 7, offs)
+                return hl.FoldPrefix(hl.PREFIX_PERLIN, y, a1, b1, 99, 2, offs, terms=terms, div_fac=2.0)
+
+            kw = {k: v for k, v in route.items() if k not in ("ids", "coefs")}
+            want = y0.clone()
+            prefix(want).apply()
+            if kind == "normal":
+                assert torch.equal(want, hl.philox_normal_acc_(y0.clone(), a1, b1, 1234, 7, offs))
+            part_w = hl.new_partials("cuda")
+            w_want = hl.brownian_bridge_acc_(want, 1.0, b2, route["ids"], route["coefs"], 77, offs, None, **kw, partials=part_w)
+            got = y0.clone()
+            pre = prefix(got)
+            assert pre.hosted(got, offs, (wa, wb)) == hostable
+            part_g = hl.new_partials("cuda")
+            w_got = hl.brownian_bridge_acc_(got, 1.0, b2, route["ids"], route["coefs"], 77, offs, None, **kw, partials=part_g, pre=pre)
+            assert pre.consumed
+            pre.apply()  # must be a no-op now
+            assert torch.equal(got, want), (kind, route["ids"])
+            assert torch.equal(w_got, w_want)
+            sw, sg = part_w.view(-1, 2).sum(0), part_g.view(-1, 2).sum(0)
+            torch.testing.assert_close(sg, sw, rtol=1e-12, atol=1e-9 * n)
+    # per-latent seeds have no tile route: the prefix goes first, by its own launch
+    if per % 4:
+        return  # (that route needs latents of whole 4-element groups)
+    seeds = torch.arange(1, n_shape[0] + 1, dtype=torch.int64, device="cuda")
+    want = y0.clone()
+    hl.philox_normal_acc_(want, 0.5, 0.3, 1234, 7, offs)
+    hl.brownian_bridge_acc_(want, 1.0, 0.2, [5], [0.4], 0, offs, seeds, want_w=False)
+    got = y0.clone()
+    hl.brownian_bridge_acc_(got, 1.0, 0.2, [5], [0.4], 0, offs, seeds, want_w=False, pre=hl.FoldPrefix(hl.PREFIX_NORMAL, got, 0.5, 0.3, 1234, 7, offs))
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("items", [("gaussian", "perlin", "brownian"), ("gaussian", "gaussian", "brownian"), ("power", "perlin", "brownian", "perlin", "brownian"),
+                                   ("gaussian", "perlin", "gaussian", "brownian", "gaussian")])
+def test_chain_with_hosted_folds_equals_the_plain_chain(api, monkeypatch, items):
+    """Chains whose Brownian item follows a Gaussian / Perlin item: that item is not launched at all, the Brownian kernel applies it.  Same
+    seeds with the hosting switched off (every item folds by itself) and with folding switched off -> the same tensors."""
+    N, pn = api.noise, api.powernoise
+
+    def build():
+        chain = N.CustomNoiseChain()
+        for k, name in enumerate(items):
+            f = (0.5, 0.3, 0.2, 0.15, 0.1)[k]
+            if name == "power":
+                chain.add(pn.PowerNoiseItem(f, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
+                                            mix=1.0, common_mode=0.0, channel_correlation="1"))
+            else:
+                chain.add(N.CustomNoiseItem(f, noise_type=name))
+        return chain
+
+    x = torch.zeros(4, 4, 64, 64, device="cuda")
+    steps = [(10.0, 7.0), (7.0, 4.0), (7.0, 5.5), (4.0, 1.0)]
+    hosted = []
+    real = api.hl.FoldPrefix.hosted
+    for normalized in (True, False):
+        runs = []
+        for variant in ("hosted", "folded", "plain"):
+            with monkeypatch.context() as m:
+                if variant == "hosted":
+                    m.setattr(api.hl.FoldPrefix, "hosted", lambda self, *a: hosted.append(real(self, *a)) or hosted[-1])
+                elif variant == "folded":
+                    m.setattr(N.NoiseSampler, "accepts_prefix", property(lambda self: False))
+                else:
+                    m.delattr(N.NoiseSampler, "accumulate")
+                torch.manual_seed(21)
+                ns = build().make_noise_sampler(x, 0.03, 14.6, seed=5, cpu=False, normalized=normalized)
+                runs.append([ns(torch.tensor(s), torch.tensor(sn)).clone() for s, sn in steps])
+        for a, b, c in zip(*runs):
+            assert bool(torch.isfinite(a).all())
+            if normalized and items[-1] == "brownian":
+                # the last kernel also reduces the statistics; with a hosted fold its waves walk the tiles in another order, so the
+                # fp64 sums (and with them the normalisation's mean / std) may differ in their last bits
+                torch.testing.assert_close(a, b, rtol=0, atol=2e-6)
+            else:
+                assert torch.equal(a, b)
+            assert torch.equal(b, c)
+    assert hosted and all(hosted)
+
+
 # ------------------------------------------------------------------------------------------------ noise whose normalisation rides in the step kernel
 @pytest.mark.parametrize("case", ["shift_and_scale", "scale_only", "as_is"])
 def test_step_kernels_apply_a_pending_normalisation_like_scale_noise(api, case):
