@@ -150,6 +150,14 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
             real = (4 if name == "perlin" else 12) * N_LATENT * b  # Perlin is written once; pyramid generates, then scales in place
             kernels.append(kernel_entry(f"{name} normalised generate, batch {b}", us, real, tr.get(f"{name}_{tag}", {}).get("hbm_bytes_per_launch"),
                                         "4N real (12N contract)" if name == "perlin" else "12N real = contract"))
+    # cfg3 as a chain: Perlin + pyramid items of one CustomNoiseChain, normalised (the Perlin item is evaluated inside the pyramid
+    # kernel: lattice + ONE generating launch + the normalisation pass)
+    for tag, xb in (("b512", x), ("b64", x64)):
+        chain3 = nz.CustomNoiseChain()
+        chain3.add(nz.CustomNoiseItem(0.5, noise_type="perlin"))
+        chain3.add(nz.CustomNoiseItem(0.5, noise_type="pyramid"))
+        ns3 = chain3.make_noise_sampler(xb, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+        extra[f"cfg3_chain_{tag}_latents_per_s"] = xb.shape[0] / (event_us(lambda: ns3(*sig), 30, 10) * 1e-6)
     # momentum step (row M): 3 reads + 2 writes
     sonar = importlib.import_module("comfyui_sonar_amd.py.sonar")
     sb = sonar.SonarBase(sonar.SonarBase.get_config(None, {}))

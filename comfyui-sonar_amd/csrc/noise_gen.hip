@@ -88,6 +88,54 @@ __device__ __forceinline__ void accumulate_group(const Accum& acc, int64_t n, in
 }
 static constexpr Accum kNoAccum{nullptr, 1.0f, 1.0f};
 
+// A tile-keyed generator's fold y <- y * ya + x * f riding in ANOTHER generator's pass over y (sonar_fold_prefix): the chain's previous
+// item (Gaussian draw or Perlin) is evaluated on the fly and applied BEFORE the hosting kernel's own fold, so its read + write of the
+// running sum disappears.  Same stream keys, same operations in the same order as its own kernel -> the same bits.  fresh: that item
+// is the chain's first, the sum holds nothing yet: y1 = x, no read at all.
+struct Prefix {
+    float ya, f, div_fac;
+    uint64_t seed, stream_id;
+    const float* terms;
+    int chw;
+    int fresh;
+};
+// kind: 0 none, 1 Gaussian draw, 2 Perlin (summed lattice).  One group of four values: x drawn by the caller's copy of the prefix's
+// generator (`rng`, advanced here), `term` the lattice vector of these four elements (Perlin).
+template <int PRE>
+__device__ __forceinline__ void prefix_draw(Xoshiro& rng, const Divider& div, const float4& term, float (&x)[4]) {
+    if constexpr (PRE == 1) {
+        rng.normal4(x);
+    } else {
+        rng.uniform4(x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = div(x[k]);
+        x[0] += term.x; x[1] += term.y; x[2] += term.z; x[3] += term.w;
+    }
+}
+// v <- fold(y1, v) with y1 = x (fresh) or y * ya + x * f, y read from the running sum
+__device__ __forceinline__ void prefix_fold(const Prefix& pre, const Accum& pfold, const Accum& fold, int64_t e, const float (&x)[4], float (&v)[4]) {
+    if (pre.fresh) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fold(x[k], v[k]);
+    } else {
+        const float4 y = *reinterpret_cast<const float4*>(fold.y + e);
+        v[0] = fold(pfold(y.x, x[0]), v[0]);
+        v[1] = fold(pfold(y.y, x[1]), v[1]);
+        v[2] = fold(pfold(y.z, x[2]), v[2]);
+        v[3] = fold(pfold(y.w, x[3]), v[3]);
+    }
+}
+static int make_prefix(const sonar_fold_prefix* pre, Prefix& px, const char* what) {
+    SONAR_REQUIRE(pre->kind == SONAR_PREFIX_NORMAL || pre->kind == SONAR_PREFIX_PERLIN, SONAR_ERR_ARG, "%s: unknown prefix kind", what);
+    const bool perlin = pre->kind == SONAR_PREFIX_PERLIN;
+    SONAR_REQUIRE(!perlin || (pre->terms && pre->chw > 0 && pre->chw < (1LL << 31) && (reinterpret_cast<uintptr_t>(pre->terms) & 15u) == 0),
+                  SONAR_ERR_ARG, "%s: a Perlin prefix needs its 16-byte aligned lattice", what);
+    SONAR_REQUIRE(!pre->fresh || pre->x_mul == 1.0f, SONAR_ERR_ARG, "%s: a fresh prefix is the first item's raw values (x_mul 1)", what);
+    px = Prefix{pre->y_mul, pre->x_mul, perlin ? pre->div_fac : 1.0f, pre->seed, pre->stream_id, pre->terms, perlin ? (int)pre->chw : 1,
+                pre->fresh ? 1 : 0};
+    return SONAR_OK;
+}
+
 struct Affine {
     float sub, mul, add;
     int active;
@@ -701,10 +749,13 @@ __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, in
 // coordinate-table read and eleven arithmetic instructions; the level weight is folded into the y weights.
 constexpr size_t kPyramidLdsBudget = 64 * 1024;
 
-template <bool STATS, bool XROWS>
+// fold (nullable y): the values are folded into a chain's running sum, out == fold.y (sonar_pyramid_generate_acc_f32); PRE != 0: the
+// chain's previous item rides along (Prefix above) -- its generator shares this kernel's tile keying, so its state simply walks the
+// same (tile, iteration) sequence.
+template <bool STATS, bool XROWS, int PRE = 0>
 __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
                                                                uint64_t seed, uint64_t stream_id, int64_t elem_offset,
-                                                               double* partials, int grid_floats) {
+                                                               double* partials, int grid_floats, Accum fold, Prefix pre) {
     extern __shared__ __align__(16) float pyr_lds[];
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
@@ -778,18 +829,30 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
             __syncthreads();
         }
         float* const oplane = out + p * (int64_t)HW;
+        const Accum pfold{fold.y, pre.ya, pre.f};
+        const Divider pdiv(PRE == 2 ? pre.div_fac : 1.0f);
+        // Perlin prefix: the plane's lattice vectors (the lattice repeats per latent of pre.chw = channels * H * W elements)
+        const float* const tplane = PRE == 2 ? pre.terms + (int)(p % (pre.chw / HW)) * HW : nullptr;
         // RNG tiles overlapping this plane (a plane need not start or end on a tile boundary: the neighbours' workgroups draw
         // the shared tile too and each keeps its own part)
         const int64_t g0 = elem_offset + p * (int64_t)HW;
         const int64_t tile_first = g0 / kTileElems, tile_last = (g0 + HW - 1) / kTileElems;
         for (int64_t t = tile_first + wave; t <= tile_last; t += kBlock / 64) {
             Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)t, lane);
+            Xoshiro prng;
+            if constexpr (PRE != 0) prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)t, lane);
             int e = (int)(t * kTileElems - g0) + (int)lane * 4;  // element index inside the plane; < 0 or >= HW: not ours
             int y = e >= 0 ? e / W : -((-e + W - 1) / W);        // floor
             int x4 = e - y * W;
             for (int it = 0; it < kTileIters; ++it, e += 256, y += dy, x4 += dx, y += x4 >= W, x4 -= x4 >= W ? W : 0) {
                 float v[4];
                 rng.normal4(v);
+                float px[4];
+                if constexpr (PRE != 0) {  // the prefix's generator walks every iteration of the tile, ours or not
+                    const bool ours = e >= 0 && e < HW;
+                    const float4 tv = PRE == 2 && ours ? *reinterpret_cast<const float4*>(tplane + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    prefix_draw<PRE>(prng, pdiv, tv, px);
+                }
                 if (e < 0 || e >= HW) continue;
                 if (lv.fullres) {
 #pragma unroll
@@ -834,6 +897,12 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
                         for (int k = 0; k < 4; ++k) v[k] += area_sample(plane, h, w, H, W, y, x4 + k) * wt;
                     }
                 }
+                if constexpr (PRE != 0) {
+                    prefix_fold(pre, pfold, fold, p * (int64_t)HW + e, px, v);
+                } else if (fold.y) {
+                    const float4 yv = *reinterpret_cast<const float4*>(fold.y + p * (int64_t)HW + e);
+                    v[0] = fold(yv.x, v[0]); v[1] = fold(yv.y, v[1]); v[2] = fold(yv.z, v[2]); v[3] = fold(yv.w, v[3]);
+                }
                 *reinterpret_cast<float4*>(oplane + e) = make_float4(v[0], v[1], v[2], v[3]);
                 if constexpr (STATS) {
                     const float ps = (v[0] + v[1]) + (v[2] + v[3]);
@@ -849,7 +918,8 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
 
 // true if the plane kernel was launched
 static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t W, const PyramidLevels& lv, int mode, uint64_t seed,
-                                 uint64_t stream_id, int64_t elem_offset, double* partials, hipStream_t st) {
+                                 uint64_t stream_id, int64_t elem_offset, double* partials, hipStream_t st, Accum fold = kNoAccum,
+                                 int pre_kind = 0, Prefix pre = Prefix{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1, 0}) {
     size_t grid_floats = 0, rows = 0;
     for (int l = 0; l < lv.count; ++l) {
         grid_floats += (size_t)lv.h[l] * lv.w[l];
@@ -861,14 +931,21 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     if (W % 4 != 0 || elem_offset % (H * W) != 0 || lds > kPyramidLdsBudget) return false;
     const bool xrows = mode == 0 && W % 4 == 0 && lds_x <= kPyramidLdsBudget;
     const int g = (int)std::min<int64_t>(planes, kNPart);
-#define SONAR_PP(ST, XR) \
-    hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR>), dim3(g), dim3(kBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
-                       seed, stream_id, elem_offset, partials, (int)grid_floats)
+#define SONAR_PP(ST, XR, P) \
+    hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P>), dim3(g), dim3(kBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
+                       seed, stream_id, elem_offset, partials, (int)grid_floats, fold, pre)
+#define SONAR_PPK(ST, XR) \
+    do { \
+        if (pre_kind == SONAR_PREFIX_NORMAL) SONAR_PP(ST, XR, 1); \
+        else if (pre_kind == SONAR_PREFIX_PERLIN) SONAR_PP(ST, XR, 2); \
+        else SONAR_PP(ST, XR, 0); \
+    } while (0)
     if (partials) {
-        if (xrows) SONAR_PP(true, true); else SONAR_PP(true, false);
+        if (xrows) SONAR_PPK(true, true); else SONAR_PPK(true, false);
     } else {
-        if (xrows) SONAR_PP(false, true); else SONAR_PP(false, false);
+        if (xrows) SONAR_PPK(false, true); else SONAR_PPK(false, false);
     }
+#undef SONAR_PPK
 #undef SONAR_PP
     return true;
 }
@@ -904,15 +981,6 @@ struct BrownianBase {
     const float* a;
     const float* b;
     float fa, fb;
-};
-// A tile-keyed generator's fold y <- y * ya + x * f riding in this kernel's pass over y (sonar_fold_prefix): the chain's previous item
-// (Gaussian draw or Perlin) is evaluated on the fly and applied BEFORE the increment's own fold, so its read + write of the running sum
-// disappears.  Same stream keys, same operations in the same order as its own kernel -> the same bits.
-struct Prefix {
-    float ya, f, div_fac;
-    uint64_t seed, stream_id;
-    const float* terms;
-    int chw;
 };
 // PRE: 0 none, 1 Gaussian draw, 2 Perlin (summed lattice, tile-aligned latents).  With a prefix a wave walks the kBrownPerTile
 // consecutive Brownian tiles of one generator tile, carrying the prefix's generator state across them.
@@ -982,20 +1050,10 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
                         // the previous item's values for these four elements, folded into y first: y1 = y * ya + x * f (its own kernel's
                         // arithmetic), then this item's fold on y1
                         float x[4];
-                        if constexpr (PRE == 1) {
-                            prng.normal4(x);
-                        } else {
-                            prng.uniform4(x);
-                            const float4 tv = trow[64 * (sub * kBrownIters + it)];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) x[k] = pdiv(x[k]);
-                            x[0] += tv.x; x[1] += tv.y; x[2] += tv.z; x[3] += tv.w;
-                        }
-                        const float4 y = *reinterpret_cast<const float4*>(fold.y + o + it * 256);
-                        v[0] = fold(pfold(y.x, x[0]), v[0]);
-                        v[1] = fold(pfold(y.y, x[1]), v[1]);
-                        v[2] = fold(pfold(y.z, x[2]), v[2]);
-                        v[3] = fold(pfold(y.w, x[3]), v[3]);
+                        float4 tv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if constexpr (PRE == 2) tv = trow[64 * (sub * kBrownIters + it)];
+                        prefix_draw<PRE>(prng, pdiv, tv, x);
+                        prefix_fold(pre, pfold, fold, o + it * 256, x, v);
                     } else {
                         accumulate_group<true>(fold, n, o + it * 256, v);
                     }
@@ -1148,15 +1206,13 @@ static int brownian_launch(float* out, float* w_out, const float* prev, float sc
     SONAR_REQUIRE(!partials || out, SONAR_ERR_ARG, "%s: statistics need an output tensor", what);
     // statistics: one (sum, sumsq) pair per block, at most kNPart blocks
     const int cap = partials ? kNPart : kMaxGrid;
-    Prefix px{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1};
+    Prefix px{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1, 0};
     if (pre) {
         // the previous chain item rides along only in the tile kernel, on the same running sum, with whole generator tiles per latent
-        SONAR_REQUIRE(pre->kind == SONAR_PREFIX_NORMAL || pre->kind == SONAR_PREFIX_PERLIN, SONAR_ERR_ARG, "%s: unknown prefix kind", what);
-        const bool perlin = pre->kind == SONAR_PREFIX_PERLIN;
-        SONAR_REQUIRE(burst && acc.y && out == acc.y &&
-                          (!perlin || (pre->terms && al(pre->terms) && pre->chw == latent_elems && pre->chw < (1LL << 31))),
-                      SONAR_ERR_UNSUPPORTED, "%s: this shape cannot host a fold prefix (apply it with its own entry point)", what);
-        px = Prefix{pre->y_mul, pre->x_mul, perlin ? pre->div_fac : 1.0f, pre->seed, pre->stream_id, pre->terms, perlin ? (int)pre->chw : 1};
+        const int prc = make_prefix(pre, px, what);
+        if (prc != SONAR_OK) return prc;
+        SONAR_REQUIRE(burst && acc.y && out == acc.y && (pre->kind != SONAR_PREFIX_PERLIN || pre->chw == latent_elems), SONAR_ERR_UNSUPPORTED,
+                      "%s: this shape cannot host a fold prefix (apply it with its own entry point)", what);
     }
 #define SONAR_BB(P) \
     hipLaunchKernelGGL((brownian_burst_kernel<P>), dim3(std::min(cap, grid_for(n / (kBrownTile * (P ? kBrownPerTile : 1)), 4))), dim3(kBlock), 0, \
@@ -1335,6 +1391,34 @@ extern "C" int sonar_pyramid_generate_f32(float* out, int64_t planes, int64_t H,
         hipLaunchKernelGGL((pyramid_generate_kernel<0, false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes,
                            (int)H, (int)W, lv, mode, seed, stream_id, elem_offset, partials, NormArgs{});
     return check_launch("sonar_pyramid_generate_f32");
+}
+
+// The same values folded into a chain's running sum (y <- y * y_mul + pyramid * x_mul, sonar_accumulate), optionally with the chain's
+// previous item riding along (sonar_fold_prefix).  Plane kernel only: SONAR_ERR_UNSUPPORTED when it cannot run this shape.
+extern "C" int sonar_pyramid_generate_acc_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, int64_t planes, int64_t H, int64_t W,
+                                              int64_t nlevels, const float* const* level_ptrs, const int64_t* level_h,
+                                              const int64_t* level_w, const float* level_weight, int mode, uint64_t seed,
+                                              uint64_t stream_id, int64_t elem_offset, void* stream) {
+    const char* what = "sonar_pyramid_generate_acc_f32";
+    SONAR_REQUIRE(acc && acc->y, SONAR_ERR_ARG, "%s: bad argument", what);
+    int rc = pyramid_common(what, acc->y, planes, H, W, mode, elem_offset);
+    if (rc != SONAR_OK) return rc;
+    PyramidLevels lv;
+    bool drawn = false;
+    rc = fill_levels(lv, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, stream_id, &drawn, what);
+    if (rc != SONAR_OK) return rc;
+    Prefix px{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1, 0};
+    if (pre) {
+        rc = make_prefix(pre, px, what);
+        if (rc != SONAR_OK) return rc;
+        SONAR_REQUIRE(pre->kind != SONAR_PREFIX_PERLIN || pre->chw % (H * W) == 0, SONAR_ERR_UNSUPPORTED,
+                      "%s: the Perlin prefix's latent is not a whole number of planes", what);
+    }
+    if (planes == 0) return SONAR_OK;
+    SONAR_REQUIRE(launch_pyramid_plane(acc->y, planes, H, W, lv, mode, seed, stream_id, elem_offset, acc->partials, (hipStream_t)stream,
+                                       Accum{acc->y, acc->y_mul, acc->x_mul}, pre ? pre->kind : 0, px),
+                  SONAR_ERR_UNSUPPORTED, "%s: the plane kernel cannot run this shape (whole planes, grids within the LDS budget)", what);
+    return check_launch(what);
 }
 
 extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels,

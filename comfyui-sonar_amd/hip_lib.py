@@ -152,6 +152,7 @@ SIGNATURES = {
     "sonar_dtcwt_c2q_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_dtcwt_q2c_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_dtcwt_c2q_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "sonar_pyramid_generate_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I, _U64, _U64, _I64, _P]),
     "sonar_brownian_bridge_chain_f32": (_I, [_P, _P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _I64, _P]),
     "sonar_max_to_host_f32": (_I, [_P, _I64, C.POINTER(C.c_float), _P]),
     "sonar_max_to_host_begin_f32": (_I, [_P, _I64, _P]),
@@ -638,7 +639,7 @@ class FoldPrefixArg(C.Structure):
     """``sonar_fold_prefix`` (include/sonar_hip.h)."""
 
     _fields_ = [("kind", C.c_int32), ("y_mul", C.c_float), ("x_mul", C.c_float), ("div_fac", C.c_float), ("seed", C.c_uint64),
-                ("stream_id", C.c_uint64), ("terms", C.c_void_p), ("chw", C.c_int64)]
+                ("stream_id", C.c_uint64), ("terms", C.c_void_p), ("chw", C.c_int64), ("fresh", C.c_int32)]
 
 
 PREFIX_NORMAL, PREFIX_PERLIN = 1, 2
@@ -647,38 +648,51 @@ _TILE_ELEMS = 4096
 
 class FoldPrefix:
     """The fold y <- y * y_mul + x * x_mul of a tile-keyed generator (Gaussian draw / Perlin), captured with its keys already taken so
-    that the NEXT chain item's kernel can evaluate it during its own pass over y (``sonar_brownian_bridge_chain_f32``).  Whoever holds
-    one must end with ``apply()``: a no-op once a kernel has hosted it, the item's own accumulating launch otherwise."""
+    that the NEXT chain item's kernel can evaluate it during its own pass over y (``sonar_brownian_bridge_chain_f32``,
+    ``sonar_pyramid_generate_acc_f32``).  ``fresh``: the item is the chain's first -- y is a new tensor that holds nothing yet, y <- x.
+    Whoever holds one must end with ``apply()``: a no-op once a kernel has hosted it, the item's own launch otherwise."""
 
     def __init__(self, kind: int, y: torch.Tensor, y_mul: float, x_mul: float, seed: int, stream_id: int, elem_offset: int,
-                 terms: Optional[torch.Tensor] = None, div_fac: float = 1.0):
+                 terms: Optional[torch.Tensor] = None, div_fac: float = 1.0, fresh: bool = False, view=None):
         self.kind, self.y, self.y_mul, self.x_mul = kind, y, float(y_mul), float(x_mul)
         self.seed, self.stream_id, self.elem_offset, self.terms, self.div_fac = seed, stream_id, elem_offset, terms, float(div_fac)
+        self.fresh = bool(fresh)
+        self.view = tuple(view) if view is not None else tuple(y.shape)  # the [B, C, H, W] the generator works on (y may be 5-D)
+        self.first_factor = 1.0  # fresh: the factor the chain multiplies the first item by (set by NoiseSampler.fold_prefix)
         self.consumed = False
+        if self.fresh and self.x_mul != 1.0:
+            raise SonarHipError("FoldPrefix: a fresh prefix carries the first item's raw values")
 
     def apply(self) -> None:
         if self.consumed:
             return
         self.consumed = True
-        if self.kind == PREFIX_NORMAL:
-            philox_normal_acc_(self.y, self.y_mul, self.x_mul, self.seed, self.stream_id, self.elem_offset)
+        y = self.y.view(self.view)
+        if self.fresh:
+            if self.kind == PREFIX_NORMAL:
+                philox_normal(self.view, y.device, self.seed, self.stream_id, self.elem_offset, out=y)
+            else:
+                perlin_generate(self.view, self.terms, self.div_fac, self.seed, self.stream_id, self.elem_offset, out=y)
+        elif self.kind == PREFIX_NORMAL:
+            philox_normal_acc_(y, self.y_mul, self.x_mul, self.seed, self.stream_id, self.elem_offset)
         else:
-            perlin_generate_acc_(self.y, self.y_mul, self.x_mul, self.terms, self.div_fac, self.seed, self.stream_id, self.elem_offset)
+            perlin_generate_acc_(y, self.y_mul, self.x_mul, self.terms, self.div_fac, self.seed, self.stream_id, self.elem_offset)
 
-    def hosted(self, y: torch.Tensor, elem_offset: int, tensors) -> bool:
-        """Can a tile kernel working on ``y`` at ``elem_offset`` carry this fold?  (Mirrors the checks of the entry point.)"""
-        latent = y.numel() // max(y.shape[0], 1)
+    def hosted(self, y: torch.Tensor, elem_offset: int, tensors=()) -> bool:
+        """Can a kernel working on ``y`` at ``elem_offset`` carry this fold?  (Mirrors the checks of the entry points; the hosting
+        kernel adds its own shape conditions.)"""
         if (self.consumed or y.data_ptr() != self.y.data_ptr() or y.numel() != self.y.numel() or elem_offset != self.elem_offset
-                or y.shape[0] == 0 or latent % _TILE_ELEMS or any(t is not None and t.data_ptr() % 16 for t in (y, *tensors))):
+                or y.shape[0] == 0 or any(t is not None and t.data_ptr() % 16 for t in (y, *tensors))):
             return False
         if self.kind == PREFIX_PERLIN:
+            latent = y.numel() // y.shape[0]
             return self.terms is not None and self.terms.numel() == latent and self.terms.data_ptr() % 16 == 0
         return self.kind == PREFIX_NORMAL
 
     def arg(self):
         return C.byref(FoldPrefixArg(self.kind, self.y_mul, self.x_mul, self.div_fac, self.seed & (2**64 - 1), self.stream_id,
                                      None if self.terms is None else _dev(self.terms, "terms"),
-                                     0 if self.terms is None else self.terms.numel()))
+                                     0 if self.terms is None else self.terms.numel(), int(self.fresh)))
 
 
 def brownian_bridge_acc_(y: torch.Tensor, y_mul: float, x_mul: float, node_ids, coefs, seed: int, elem_offset: int = 0,
@@ -693,7 +707,8 @@ def brownian_bridge_acc_(y: torch.Tensor, y_mul: float, x_mul: float, node_ids, 
     n = y.numel()
     ids = (C.c_uint64 * len(node_ids))(*[int(v) & (2**64 - 1) for v in node_ids])
     cfs = (C.c_float * len(coefs))(*[float(v) for v in coefs])
-    if pre is not None and latent_seeds is None and pre.hosted(y, elem_offset, (w, prev, base_a, base_b)):
+    if (pre is not None and latent_seeds is None and (n // max(y.shape[0], 1)) % _TILE_ELEMS == 0
+            and pre.hosted(y, elem_offset, (w, prev, base_a, base_b))):
         pre.consumed = True
         _check(load().sonar_brownian_bridge_chain_f32(accumulate_arg(y, y_mul, x_mul, partials), pre.arg(), _opt(w, "w_out"), _opt(prev, "prev"),
                                                       float(scale), _opt(base_a, "base_a"), float(fa), _opt(base_b, "base_b"), float(fb), n,
@@ -766,8 +781,9 @@ def perlin_apply(base: torch.Tensor, terms: torch.Tensor, div_fac: float, partia
     return out
 
 
-def perlin_generate(shape, terms: torch.Tensor, div_fac: float, seed: int, stream_id: int, elem_offset: int = 0, partials=None) -> torch.Tensor:
-    out = torch.empty(shape, dtype=torch.float32, device=terms.device)
+def perlin_generate(shape, terms: torch.Tensor, div_fac: float, seed: int, stream_id: int, elem_offset: int = 0, partials=None,
+                    out=None) -> torch.Tensor:
+    out = torch.empty(shape, dtype=torch.float32, device=terms.device) if out is None else out
     b = shape[0]
     chw = out.numel() // max(b, 1)
     _check(
@@ -830,6 +846,27 @@ def pyramid_generate(shape, device, levels: Sequence, mode: str, seed: int, stre
         return None
     _check(rc, "sonar_pyramid_generate_f32")
     return out
+
+
+def pyramid_generate_acc_(y: torch.Tensor, y_mul: float, x_mul: float, levels: Sequence, mode: str, seed: int, stream_id: int,
+                          elem_offset: int = 0, partials=None, pre: Optional[FoldPrefix] = None) -> bool:
+    """y[B, C, H, W] <- y * y_mul + pyramid * x_mul (the values of ``pyramid_generate``) in place; ``pre``: the previous chain item's fold,
+    applied to y first (inside the same launch when it can be).  False when the plane kernel cannot run the shape: the pyramid values
+    were not folded (a ``pre`` that is still unconsumed is the caller's to apply first)."""
+    H, W = y.shape[-2:]
+    planes = y.numel() // (H * W)
+    n, ptrs, hs, ws, wts = _pyramid_args(levels)
+    host = pre is not None and pre.hosted(y, elem_offset, [lv[0] for lv in levels])
+    if pre is not None and not host:
+        pre.apply()
+    rc = load().sonar_pyramid_generate_acc_f32(accumulate_arg(y, y_mul, x_mul, partials), pre.arg() if host else None, planes, H, W, n, ptrs, hs,
+                                               ws, wts, RESAMPLE_IDS[mode], seed & (2**64 - 1), stream_id, elem_offset, _stream())
+    if rc == ERR_UNSUPPORTED:
+        return False
+    _check(rc, "sonar_pyramid_generate_acc_f32")
+    if host:
+        pre.consumed = True
+    return True
 
 
 def pyramid_noise(shape, device, levels: Sequence, mode: str, seed: int, stream_id: int, elem_offset: int, factor: float,

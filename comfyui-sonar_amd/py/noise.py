@@ -161,6 +161,13 @@ class CustomNoiseChain:
             pending = None  # the previous item's fold, captured for this item's kernel (hip_lib.FoldPrefix)
             for idx, ns in enumerate(samplers):
                 fold = getattr(ns, "accumulate", None) if idx else None
+                if idx == 0 and len(samplers) > 1 and getattr(samplers[1], "accepts_prefix", False):
+                    # the first item too can be evaluated by the second item's kernel: the sum is then written once, by that kernel
+                    capture = getattr(ns, "fold_prefix", None)
+                    pending = capture(None, 1.0, sigma, sigma_next) if capture is not None else None
+                    if pending is not None:
+                        first = (pending.y, pending.first_factor)
+                        continue
                 if fold is not None:
                     # a generator that can fold its values into the running sum does so (read + write of the sum) instead of writing a
                     # tensor for the accumulation kernel to read back; same arithmetic, same bits
@@ -290,13 +297,23 @@ class NoiseSampler:
 
     def fold_prefix(self, y, y_mul, *args):
         """``accumulate`` captured instead of launched: the descriptor of y <- y * y_mul + noise * factor for the next item's kernel (the
-        generator's keys are taken now, in chain order); None when this sampler cannot fold that way."""
-        if self.normalized or self.dtype != torch.float32 or y.dtype != torch.float32 or y.device != self.device or not y.is_contiguous():
+        generator's keys are taken now, in chain order); None when this sampler cannot fold that way.  ``y`` None: this is the chain's
+        first item -- the descriptor allocates the running sum (``pre.y``), which starts as the raw values (``pre.first_factor``: the
+        multiplier the next fold applies to it)."""
+        if self.normalized or self.dtype != torch.float32:
+            return None
+        if y is not None and (y.dtype != torch.float32 or y.device != self.device or not y.is_contiguous()):
             return None
         make = getattr(self.noise_sampler, "fold_prefix", None)
         if make is None:
             return None
         args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
+        if y is None:
+            # the chain's first item: the sum starts as its RAW values and the next fold multiplies them by the factor (``unscaled``)
+            pre = make(None, 1.0, 1.0, *args)
+            if pre is not None:
+                pre.first_factor = float(self.factor)
+            return pre
         return make(y, float(y_mul), float(self.factor), *args)
 
     def normalized_call(self, factor, *args):

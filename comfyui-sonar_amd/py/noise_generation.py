@@ -319,12 +319,17 @@ class GaussianNoiseGenerator(NoiseGenerator):
         return True
 
     def fold_prefix(self, y, y_mul, x_mul, *_args):
-        """``generate_into`` captured instead of launched (``hip_lib.FoldPrefix``): the next chain item's kernel applies it in its own pass."""
-        if not self._plain_output() or tuple(y.shape) != tuple(self.shape):
+        """``generate_into`` captured instead of launched (``hip_lib.FoldPrefix``): the next chain item's kernel applies it in its own pass.
+        ``y`` None: this item is the chain's first -- the running sum is allocated here and starts as this generator's raw values."""
+        fresh = y is None
+        if not self._plain_output() or (not fresh and tuple(y.shape) != tuple(self.shape)):
             return None
+        if fresh:
+            y = torch.empty(tuple(self.shape), dtype=torch.float32, device=self.device)
         self.pre_hook()
         seed, stream = self.device_key()
-        return hip_lib.FoldPrefix(hip_lib.PREFIX_NORMAL, y, y_mul, x_mul, seed, stream, self.latent_elem_offset(math.prod(self.shape[1:])))
+        return hip_lib.FoldPrefix(hip_lib.PREFIX_NORMAL, y, y_mul, x_mul, seed, stream, self.latent_elem_offset(math.prod(self.shape[1:])),
+                                  fresh=fresh)
 
 
 class UniformNoiseGenerator(NoiseGenerator):
@@ -413,15 +418,19 @@ class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):
         return True
 
     def fold_prefix(self, y, y_mul, x_mul, *_args):
-        """``generate_into`` with the lattice built and the keys taken, the fold itself left to the next chain item's kernel."""
-        if not self._plain_output() or tuple(y.shape) != tuple(self.shape) or self.blend_mode not in hip_lib.BLEND_IDS:
+        """``generate_into`` with the lattice built and the keys taken, the fold itself left to the next chain item's kernel (``y`` None:
+        the chain's first item, see ``GaussianNoiseGenerator.fold_prefix``)."""
+        fresh = y is None
+        if not self._plain_output() or (not fresh and tuple(y.shape) != tuple(self.shape)) or self.blend_mode not in hip_lib.BLEND_IDS:
             return None
+        if fresh:
+            y = torch.empty(tuple(self.shape), dtype=torch.float32, device=self.device)
         self.pre_hook()
         b, c, h, w = self.get_adjusted_shape()
         seed, stream = self.device_key(2)
         terms = hip_lib.perlin_lattice(max(self.iterations, 0), c, h, w, self.device, self.blend_mode, seed, stream + 1)
-        return hip_lib.FoldPrefix(hip_lib.PREFIX_PERLIN, y.view(b, c, h, w), y_mul, x_mul, seed, stream, self.latent_elem_offset(c * h * w),
-                                  terms=terms, div_fac=self.div_fac)
+        return hip_lib.FoldPrefix(hip_lib.PREFIX_PERLIN, y, y_mul, x_mul, seed, stream, self.latent_elem_offset(c * h * w),
+                                  terms=terms, div_fac=self.div_fac, fresh=fresh, view=(b, c, h, w))
 
 
 class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
@@ -465,10 +474,38 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
             return self.fix_output_frames(attach_stats(noise, partials))
         return self.fix_output_frames(self._device_generate(partials, None))
 
-    def _device_generate(self, partials, fused_factor):
+    accepts_prefix = True  # generate_into(..., pre=): the previous chain item's fold rides in the plane kernel
+
+    def generate_into(self, y, y_mul, x_mul, partials, *_args, pre=None):
+        """y <- y * y_mul + generate() * x_mul in the plane kernel's own pass (``sonar_pyramid_generate_acc_f32``); a shape that kernel
+        cannot run gets the same values, from the same keys, through generate + the accumulation kernel."""
+        mode = self.upscale_mode
+        if (not self._plain_output() or tuple(y.shape) != tuple(self.shape) or mode not in hip_lib.UPSCALE_MODES
+                or y.dtype != torch.float32 or not y.is_contiguous()):
+            return False
+        self.pre_hook()
+        b, c, h, w = self.get_adjusted_shape()
+        keys = self.device_key(2 + self.iterations)
+        seed, stream = keys
+        if w % 4 == 0 and mode in hip_lib.PYRAMID_FUSED_MODES:
+            host = torch.Generator().manual_seed((seed * 0x9E3779B97F4A7C15 + stream) % (2**63))
+            plan = list(self._plan(h, w, lambda: torch.rand(1, generator=host).item() * 2 + 2))
+            if hip_lib.pyramid_generate_acc_(y.view(b, c, h, w), y_mul, x_mul, [(None, ch, cw, self.discount**i) for i, ch, cw in plan], mode,
+                                             seed, stream, self.latent_elem_offset(c * h * w), partials, pre=pre):
+                return True
+        if pre is not None:
+            pre.apply()
+        part = self._device_generate(None, None, keys=keys)
+        utils.pop_stats(part)
+        hip_lib.axpby_(y, y_mul, part.view(y.shape), x_mul)
+        if partials is not None:
+            hip_lib.stats(y, partials)
+        return True
+
+    def _device_generate(self, partials, fused_factor, keys=None):
         mode = self.upscale_mode
         b, c, h, w = self.get_adjusted_shape()
-        seed, stream = self.device_key(2 + self.iterations)
+        seed, stream = self.device_key(2 + self.iterations) if keys is None else keys
         host = torch.Generator().manual_seed((seed * 0x9E3779B97F4A7C15 + stream) % (2**63))  # shared by all ranks
         plan = list(self._plan(h, w, lambda: torch.rand(1, generator=host).item() * 2 + 2))
         plane_offset = current_batch_offset() * c

@@ -293,11 +293,20 @@ typedef struct sonar_fold_prefix {
     uint64_t stream_id;
     const float* terms; /* PERLIN: the summed lattice [chw] */
     int64_t chw;        /* PERLIN */
+    int32_t fresh;      /* 1: the item is the chain's FIRST -- the sum holds nothing yet, y1 = x (y is not read; x_mul must be 1 and the
+                           hosting fold's y_mul carries the item's factor, as sonar_axpby_f32 would) */
 } sonar_fold_prefix;
 int sonar_brownian_bridge_chain_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, float* w_out, const float* prev, float scale,
                                     const float* base_a, float fa, const float* base_b, float fb, int64_t n, int64_t elem_offset,
                                     const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed, int64_t latent_elems,
                                     void* stream);
+/* Pyramid noise (sonar_pyramid_generate_f32's values, levels drawn in the kernel or passed in) folded into the running sum, `pre`
+ * (nullable) as above: the plane kernel's generator shares the tile keying of the Gaussian / Perlin generators, so any whole-plane
+ * shape it can run can host them.  SONAR_ERR_UNSUPPORTED when the plane kernel cannot run the shape (nothing was done). */
+int sonar_pyramid_generate_acc_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, int64_t planes, int64_t H, int64_t W,
+                                   int64_t nlevels, const float* const* level_ptrs, const int64_t* level_h, const int64_t* level_w,
+                                   const float* level_weight, int mode, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                   void* stream);
 
 /* ---------------------------------------------------------------- Perlin (row P) */
 /* py/noise_generation.py:465-476,388-405 at the only position generate() uses (grid == output,

@@ -449,7 +449,6 @@ def test_brownian_kernel_hosts_the_previous_items_fold(api, n_shape):
     routes = [dict(ids=[5], coefs=[0.4], base_a=wa, fa=0.3, base_b=wb, fb=0.7, prev=wa, scale=1.7),   # bridge between two kept tensors
               dict(ids=[], coefs=[], base_b=wb, fb=1.0, prev=wa, scale=-0.5),                          # both ends kept
               dict(ids=[3, 9, 11], coefs=[0.2, -0.7, 1.1], scale=0.9)]                                # a short expansion, W(t_lo) = 0
-    hostable = per % 4096 == 0
     for kind in ("normal", "perlin"):
         for (a1, b1), b2, route in zip(((0.5, 0.3), (1.0, 1.0), (-1.25, 0.2)), (0.2, 1.0, 0.6), routes):
             def prefix(y):
@@ -466,7 +465,7 @@ def test_brownian_kernel_hosts_the_previous_items_fold(api, n_shape):
             w_want = hl.brownian_bridge_acc_(want, 1.0, b2, route["ids"], route["coefs"], 77, offs, None, **kw, partials=part_w)
             got = y0.clone()
             pre = prefix(got)
-            assert pre.hosted(got, offs, (wa, wb)) == hostable
+            assert pre.hosted(got, offs, (wa, wb))  # (the Brownian wrapper adds its own condition: latents of whole generator tiles)
             part_g = hl.new_partials("cuda")
             w_got = hl.brownian_bridge_acc_(got, 1.0, b2, route["ids"], route["coefs"], 77, offs, None, **kw, partials=part_g, pre=pre)
             assert pre.consumed
@@ -487,8 +486,64 @@ def test_brownian_kernel_hosts_the_previous_items_fold(api, n_shape):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("n_shape", [(3, 4, 64, 64), (2, 16, 128, 128), (2, 4, 40, 56), (3, 3, 20, 12)])
+def test_pyramid_kernel_folds_and_hosts_the_previous_items_fold(api, n_shape):
+    """sonar_pyramid_generate_acc_f32: y <- y * a + pyramid * b == sonar_pyramid_generate_f32 + sonar_axpby_f32, and with a Gaussian / Perlin
+    prefix (also a FRESH one: the chain's first item, y not read at all) == that item's own launch first.  Bit for bit; planes that
+    straddle generator tiles included."""
+    hl = api.hl
+    g = torch.Generator(device="cuda").manual_seed(9)
+    y0 = torch.randn(n_shape, device="cuda", generator=g)
+    b, c, h, w = n_shape
+    per = c * h * w
+    offs = 8 * per
+    levels = [(None, h, w, 1.0), (None, max(1, h // 3), max(1, w // 3), 0.7), (None, max(1, h // 11), max(1, w // 11), 0.49)]
+    terms = hl.perlin_lattice(3, c, h, w, "cuda", "lerp", 99, 3)
+    x = hl.pyramid_generate(n_shape, "cuda", levels, "bilinear", 4321, 11, offs)
+    assert x is not None
+    for a, bb in ((1.0, 1.0), (0.5, 0.3), (-1.25, 0.2)):
+        want = hl.axpby_(y0.clone(), a, x, bb)
+        part = hl.new_partials("cuda")
+        got = y0.clone()
+        assert hl.pyramid_generate_acc_(got, a, bb, levels, "bilinear", 4321, 11, offs, part)
+        assert torch.equal(got, want)
+        # (groups of four are summed in fp32 before they enter the fp64 sums, in each kernel's own grouping)
+        torch.testing.assert_close(part.view(-1, 2).sum(0), hl.stats(want).view(-1, 2).sum(0), rtol=1e-7, atol=1e-7 * y0.numel())
+    for kind in ("normal", "perlin"):
+        for fresh in (False, True):
+            a1, b1, b2 = (1.0, 1.0, 0.7) if fresh else (0.5, 0.3, 0.2)
+
+            def prefix(y):
+                if kind == "normal":
+                    return hl.FoldPrefix(hl.PREFIX_NORMAL, y, a1, b1, 1234, 7, offs, fresh=fresh)
+                return hl.FoldPrefix(hl.PREFIX_PERLIN, y, a1, b1, 99, 2, offs, terms=terms, div_fac=2.0, fresh=fresh)
+
+            want = torch.full(n_shape, float("nan"), device="cuda") if fresh else y0.clone()
+            prefix(want).apply()
+            if fresh:
+                raw = hl.philox_normal(n_shape, "cuda", 1234, 7, offs) if kind == "normal" else hl.perlin_generate(n_shape, terms, 2.0, 99, 2, offs)
+                assert torch.equal(want, raw)
+            ymul = 0.6 if fresh else 1.0  # fresh: the first item's factor rides in the hosting fold
+            hl.pyramid_generate_acc_(want, ymul, b2, levels, "bilinear", 4321, 11, offs)
+            got = torch.full(n_shape, float("nan"), device="cuda") if fresh else y0.clone()
+            pre = prefix(got)
+            assert pre.hosted(got, offs)
+            assert hl.pyramid_generate_acc_(got, ymul, b2, levels, "bilinear", 4321, 11, offs, pre=pre) and pre.consumed
+            assert torch.equal(got, want), (kind, fresh)
+    # a fresh prefix in the Brownian kernel
+    if per % 4096 == 0:
+        wa = torch.randn(n_shape, device="cuda", generator=g)
+        want = hl.perlin_generate(n_shape, terms, 2.0, 99, 2, offs)
+        hl.brownian_bridge_acc_(want, 0.6, 0.2, [5], [0.4], 77, offs, None, base_a=wa, fa=0.3, prev=wa, scale=1.7, want_w=False)
+        got = torch.full(n_shape, float("nan"), device="cuda")
+        pre = hl.FoldPrefix(hl.PREFIX_PERLIN, got, 1.0, 1.0, 99, 2, offs, terms=terms, div_fac=2.0, fresh=True)
+        hl.brownian_bridge_acc_(got, 0.6, 0.2, [5], [0.4], 77, offs, None, base_a=wa, fa=0.3, prev=wa, scale=1.7, want_w=False, pre=pre)
+        assert pre.consumed and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("items", [("gaussian", "perlin", "brownian"), ("gaussian", "gaussian", "brownian"), ("power", "perlin", "brownian", "perlin", "brownian"),
-                                   ("gaussian", "perlin", "gaussian", "brownian", "gaussian")])
+                                   ("gaussian", "perlin", "gaussian", "brownian", "gaussian"), ("perlin", "pyramid"), ("pyramid", "perlin"),
+                                   ("perlin", "brownian"), ("gaussian", "pyramid", "perlin", "pyramid", "gaussian"), ("power", "gaussian", "pyramid")])
 def test_chain_with_hosted_folds_equals_the_plain_chain(api, monkeypatch, items):
     """Chains whose Brownian item follows a Gaussian / Perlin item: that item is not launched at all, the Brownian kernel applies it.  Same
     seeds with the hosting switched off (every item folds by itself) and with folding switched off -> the same tensors."""
@@ -514,7 +569,7 @@ def test_chain_with_hosted_folds_equals_the_plain_chain(api, monkeypatch, items)
         for variant in ("hosted", "folded", "plain"):
             with monkeypatch.context() as m:
                 if variant == "hosted":
-                    m.setattr(api.hl.FoldPrefix, "hosted", lambda self, *a: hosted.append(real(self, *a)) or hosted[-1])
+                    m.setattr(api.hl.FoldPrefix, "hosted", lambda self, *a, **k: hosted.append(real(self, *a, **k)) or hosted[-1])
                 elif variant == "folded":
                     m.setattr(N.NoiseSampler, "accepts_prefix", property(lambda self: False))
                 else:
@@ -531,7 +586,7 @@ def test_chain_with_hosted_folds_equals_the_plain_chain(api, monkeypatch, items)
             else:
                 assert torch.equal(a, b)
             assert torch.equal(b, c)
-    assert hosted and all(hosted)
+    assert (hosted and all(hosted)) or items == ("pyramid", "perlin")  # (nothing in that chain can host)
 
 
 # ------------------------------------------------------------------------------------------------ noise whose normalisation rides in the step kernel
