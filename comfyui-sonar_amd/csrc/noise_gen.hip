@@ -179,6 +179,75 @@ static int launch_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
     return check_launch(what);
 }
 
+// Two tile-keyed generators in one pass over a chain's running sum: the HOST item (1 Gaussian draw, 2 Perlin) folds its values as its
+// own accumulating kernel would, after the previous item (PRE, same kinds; `pre.fresh`: the chain's first) has been applied on the
+// fly.  Whole groups of four only (n, elem_offset multiples of 4, 16-byte aligned tensors, Perlin latents of a multiple of 4).
+template <int HOST, int PRE, bool STATS>
+__global__ void __launch_bounds__(kBlock) pair_fold_kernel(Accum fold, int64_t n, int64_t elem_offset, Prefix host, Prefix pre, double* partials) {
+    __shared__ double red[2 * kBlock / 64];
+    double s = 0.0, q = 0.0;
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
+    const Accum pfold{fold.y, pre.ya, pre.f};
+    const Divider hdiv(HOST == 2 ? host.div_fac : 1.0f), pdiv(PRE == 2 ? pre.div_fac : 1.0f);
+    for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+        Xoshiro hrng = rng_stream(host.seed, host.stream_id, (uint64_t)tile, lane);
+        Xoshiro prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)tile, lane);
+        const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
+        // positions inside the latent (the lattices repeat per latent; shards start on a latent boundary), kept incrementally
+        int rh = HOST == 2 ? (int)(((base % host.chw) + host.chw) % host.chw) : 0;
+        int rp = PRE == 2 ? (int)(((base % pre.chw) + pre.chw) % pre.chw) : 0;
+#pragma unroll 4
+        for (int it = 0; it < kTileIters; ++it) {
+            const int64_t e = base + it * 256;
+            const bool ours = e >= 0 && e < n;
+            float4 th = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tp = th;
+            if constexpr (HOST == 2) {
+                if (ours) th = *reinterpret_cast<const float4*>(host.terms + rh);
+                rh += 256;
+                while (rh >= host.chw) rh -= host.chw;
+            }
+            if constexpr (PRE == 2) {
+                if (ours) tp = *reinterpret_cast<const float4*>(pre.terms + rp);
+                rp += 256;
+                while (rp >= pre.chw) rp -= pre.chw;
+            }
+            float v[4], x[4];
+            prefix_draw<HOST>(hrng, hdiv, th, v);
+            prefix_draw<PRE>(prng, pdiv, tp, x);
+            if (!ours) continue;
+            prefix_fold(pre, pfold, fold, e, x, v);
+            store_group<true>(const_cast<float*>(fold.y), n, e, v, s, q, STATS);
+        }
+    }
+    if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+}
+
+static int launch_pair_fold(const sonar_accumulate* acc, const sonar_fold_prefix* pre, int host_kind, const Prefix& host, int64_t n,
+                            int64_t elem_offset, hipStream_t st, const char* what) {
+    SONAR_REQUIRE(acc && acc->y && pre && n >= 0 && elem_offset >= 0, SONAR_ERR_ARG, "%s: bad argument", what);
+    Prefix px;
+    const int rc = make_prefix(pre, px, what);
+    if (rc != SONAR_OK) return rc;
+    SONAR_REQUIRE(n % 4 == 0 && elem_offset % 4 == 0 && aligned16(acc->y) && (host_kind != SONAR_PREFIX_PERLIN || host.chw % 4 == 0) &&
+                      (pre->kind != SONAR_PREFIX_PERLIN || pre->chw % 4 == 0),
+                  SONAR_ERR_UNSUPPORTED, "%s: hosting a fold prefix needs whole 4-element groups and 16-byte aligned tensors", what);
+    if (n == 0) return SONAR_OK;
+    const Accum fold{acc->y, acc->y_mul, acc->x_mul};
+    const int g = tile_grid(n, elem_offset);
+#define SONAR_PF(H, P) \
+    do { \
+        if (acc->partials) hipLaunchKernelGGL((pair_fold_kernel<H, P, true>), dim3(g), dim3(kBlock), 0, st, fold, n, elem_offset, host, px, acc->partials); \
+        else hipLaunchKernelGGL((pair_fold_kernel<H, P, false>), dim3(g), dim3(kBlock), 0, st, fold, n, elem_offset, host, px, acc->partials); \
+    } while (0)
+    const bool hp = host_kind == SONAR_PREFIX_PERLIN, pp = pre->kind == SONAR_PREFIX_PERLIN;
+    if (hp && pp) SONAR_PF(2, 2); else if (hp) SONAR_PF(2, 1); else if (pp) SONAR_PF(1, 2); else SONAR_PF(1, 1);
+#undef SONAR_PF
+    return check_launch(what);
+}
+
 // Normalised fill without a second sweep: MODE 1 re-draws the values and only reduces their statistics (no stores), MODE 2
 // re-draws them again, normalises with the decision derived from those statistics and stores -- the tensor is written once
 // (GaussianNoiseGenerator / UniformNoiseGenerator followed by scale_noise(normalized=True), py/noise_generation.py:252-260,496-514)
@@ -1289,6 +1358,22 @@ extern "C" int sonar_perlin_generate_acc_f32(const sonar_accumulate* acc, const 
                   SONAR_ERR_ARG, "sonar_perlin_generate_acc_f32: bad argument");
     return launch_perlin_generate<0>(terms, acc->y, B, chw, iters, div_fac, seed, stream_id, elem_offset, acc->partials, NormArgs{},
                                      (hipStream_t)stream, "sonar_perlin_generate_acc_f32", Accum{acc->y, acc->y_mul, acc->x_mul});
+}
+
+// the accumulating forms with the chain's previous item riding along (sonar_fold_prefix, see sonar_hip.h)
+extern "C" int sonar_philox_normal_chain_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, int64_t n, uint64_t seed,
+                                             uint64_t stream_id, int64_t elem_offset, void* stream) {
+    return launch_pair_fold(acc, pre, SONAR_PREFIX_NORMAL, Prefix{1.0f, 1.0f, 1.0f, seed, stream_id, nullptr, 1, 0}, n, elem_offset,
+                            (hipStream_t)stream, "sonar_philox_normal_chain_f32");
+}
+
+extern "C" int sonar_perlin_generate_chain_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, const float* terms, int64_t B,
+                                               int64_t chw, float div_fac, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                               void* stream) {
+    SONAR_REQUIRE(terms && aligned16(terms) && B >= 0 && chw > 0 && chw < (1LL << 31), SONAR_ERR_ARG,
+                  "sonar_perlin_generate_chain_f32: bad argument (the summed, 16-byte aligned lattice is required)");
+    return launch_pair_fold(acc, pre, SONAR_PREFIX_PERLIN, Prefix{1.0f, 1.0f, div_fac, seed, stream_id, terms, (int)chw, 0}, B * chw, elem_offset,
+                            (hipStream_t)stream, "sonar_perlin_generate_chain_f32");
 }
 
 extern "C" int sonar_perlin_terms_f32(const float* angles, float* terms, int64_t iters, int64_t C, int64_t H, int64_t W,

@@ -152,6 +152,8 @@ SIGNATURES = {
     "sonar_dtcwt_c2q_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_dtcwt_q2c_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
     "sonar_dtcwt_c2q_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
+    "sonar_philox_normal_chain_f32": (_I, [_P, _P, _I64, _U64, _U64, _I64, _P]),
+    "sonar_perlin_generate_chain_f32": (_I, [_P, _P, _P, _I64, _I64, _F, _U64, _U64, _I64, _P]),
     "sonar_pyramid_generate_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I, _U64, _U64, _I64, _P]),
     "sonar_brownian_bridge_chain_f32": (_I, [_P, _P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _I64, _P]),
     "sonar_max_to_host_f32": (_I, [_P, _I64, C.POINTER(C.c_float), _P]),
@@ -618,18 +620,42 @@ def accumulate_arg(y: torch.Tensor, y_mul: float, x_mul: float, partials: Option
     return C.byref(Accumulate(_dev(y, "y"), float(y_mul), float(x_mul), _opt(partials, "partials", torch.float64)))
 
 
-def philox_normal_acc_(y: torch.Tensor, y_mul: float, x_mul: float, seed: int, stream_id: int, elem_offset: int = 0, partials=None) -> torch.Tensor:
-    """y <- y * y_mul + N(0,1) * x_mul (the draw of ``philox_normal``), in place."""
+def _hosts_pair(y: torch.Tensor, elem_offset: int, pre, chw: int = 4) -> bool:
+    """The pair kernel's conditions (sonar_*_chain_f32): whole 4-element groups, aligned tensors, a hostable ``pre``."""
+    return (pre is not None and y.numel() % 4 == 0 and elem_offset % 4 == 0 and chw % 4 == 0 and pre.hosted(y, elem_offset)
+            and (pre.terms is None or pre.terms.numel() % 4 == 0))
+
+
+def philox_normal_acc_(y: torch.Tensor, y_mul: float, x_mul: float, seed: int, stream_id: int, elem_offset: int = 0, partials=None,
+                       pre=None) -> torch.Tensor:
+    """y <- y * y_mul + N(0,1) * x_mul (the draw of ``philox_normal``), in place.  ``pre`` (``FoldPrefix``): the previous chain item's fold,
+    applied to y first -- in this launch when the pair kernel can take it, by its own launch otherwise."""
+    if _hosts_pair(y, elem_offset, pre):
+        pre.consumed = True
+        _check(load().sonar_philox_normal_chain_f32(accumulate_arg(y, y_mul, x_mul, partials), pre.arg(), y.numel(), seed & (2**64 - 1), stream_id,
+                                                    elem_offset, _stream()), "sonar_philox_normal_chain_f32")
+        return y
+    if pre is not None:
+        pre.apply()
     _check(load().sonar_philox_normal_acc_f32(accumulate_arg(y, y_mul, x_mul, partials), y.numel(), seed & (2**64 - 1), stream_id, elem_offset,
                                               _stream()), "sonar_philox_normal_acc_f32")
     return y
 
 
 def perlin_generate_acc_(y: torch.Tensor, y_mul: float, x_mul: float, terms: torch.Tensor, div_fac: float, seed: int, stream_id: int,
-                         elem_offset: int = 0, partials=None) -> torch.Tensor:
-    """y <- y * y_mul + perlin * x_mul (the values of ``perlin_generate``), in place."""
+                         elem_offset: int = 0, partials=None, pre=None) -> torch.Tensor:
+    """y <- y * y_mul + perlin * x_mul (the values of ``perlin_generate``), in place; ``pre`` as in ``philox_normal_acc_``."""
     b = y.shape[0]
-    _check(load().sonar_perlin_generate_acc_f32(accumulate_arg(y, y_mul, x_mul, partials), _dev(terms, "terms"), b, y.numel() // max(b, 1),
+    chw = y.numel() // max(b, 1)
+    if terms.shape[0] == 1 and terms.data_ptr() % 16 == 0 and _hosts_pair(y, elem_offset, pre, chw):
+        pre.consumed = True
+        _check(load().sonar_perlin_generate_chain_f32(accumulate_arg(y, y_mul, x_mul, partials), pre.arg(), _dev(terms, "terms"), b, chw,
+                                                      float(div_fac), seed & (2**64 - 1), stream_id, elem_offset, _stream()),
+               "sonar_perlin_generate_chain_f32")
+        return y
+    if pre is not None:
+        pre.apply()
+    _check(load().sonar_perlin_generate_acc_f32(accumulate_arg(y, y_mul, x_mul, partials), _dev(terms, "terms"), b, chw,
                                                 terms.shape[0], float(div_fac), seed & (2**64 - 1), stream_id, elem_offset, _stream()),
            "sonar_perlin_generate_acc_f32")
     return y

@@ -310,12 +310,14 @@ class GaussianNoiseGenerator(NoiseGenerator):
         shape = tuple(self.shape)
         return hip_lib.philox_noise(False, shape, self.device, seed, stream, self.latent_elem_offset(math.prod(shape[1:])), factor)
 
-    def generate_into(self, y, y_mul, x_mul, partials, *_args):
+    accepts_prefix = True  # generate_into(..., pre=): the previous chain item's fold rides in this generator's kernel
+
+    def generate_into(self, y, y_mul, x_mul, partials, *_args, pre=None):
         if not self._plain_output() or tuple(y.shape) != tuple(self.shape):
             return False
         self.pre_hook()
         seed, stream = self.device_key()
-        hip_lib.philox_normal_acc_(y, y_mul, x_mul, seed, stream, self.latent_elem_offset(math.prod(self.shape[1:])), partials)
+        hip_lib.philox_normal_acc_(y, y_mul, x_mul, seed, stream, self.latent_elem_offset(math.prod(self.shape[1:])), partials, pre=pre)
         return True
 
     def fold_prefix(self, y, y_mul, x_mul, *_args):
@@ -407,14 +409,17 @@ class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):
             return None
         return self.fix_output_frames(self._device_generate(None, factor))
 
-    def generate_into(self, y, y_mul, x_mul, partials, *_args):
+    accepts_prefix = True
+
+    def generate_into(self, y, y_mul, x_mul, partials, *_args, pre=None):
         if not self._plain_output() or tuple(y.shape) != tuple(self.shape) or self.blend_mode not in hip_lib.BLEND_IDS:
             return False
         self.pre_hook()
         b, c, h, w = self.get_adjusted_shape()
         seed, stream = self.device_key(2)  # the same keys, in the same order, as _device_generate
         terms = hip_lib.perlin_lattice(max(self.iterations, 0), c, h, w, self.device, self.blend_mode, seed, stream + 1)
-        hip_lib.perlin_generate_acc_(y.view(b, c, h, w), y_mul, x_mul, terms, self.div_fac, seed, stream, self.latent_elem_offset(c * h * w), partials)
+        hip_lib.perlin_generate_acc_(y.view(b, c, h, w), y_mul, x_mul, terms, self.div_fac, seed, stream, self.latent_elem_offset(c * h * w), partials,
+                                     pre=pre)
         return True
 
     def fold_prefix(self, y, y_mul, x_mul, *_args):

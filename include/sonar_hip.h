@@ -300,6 +300,12 @@ int sonar_brownian_bridge_chain_f32(const sonar_accumulate* acc, const sonar_fol
                                     const float* base_a, float fa, const float* base_b, float fb, int64_t n, int64_t elem_offset,
                                     const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed, int64_t latent_elems,
                                     void* stream);
+/* sonar_philox_normal_acc_f32 / sonar_perlin_generate_acc_f32 (iters == 1: `terms` is the summed lattice) with `pre` riding along.
+ * Whole 4-element groups only (n, elem_offset, chw multiples of 4; 16-byte aligned tensors): SONAR_ERR_UNSUPPORTED otherwise. */
+int sonar_philox_normal_chain_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, int64_t n, uint64_t seed, uint64_t stream_id,
+                                  int64_t elem_offset, void* stream);
+int sonar_perlin_generate_chain_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, const float* terms, int64_t B, int64_t chw,
+                                    float div_fac, uint64_t seed, uint64_t stream_id, int64_t elem_offset, void* stream);
 /* Pyramid noise (sonar_pyramid_generate_f32's values, levels drawn in the kernel or passed in) folded into the running sum, `pre`
  * (nullable) as above: the plane kernel's generator shares the tile keying of the Gaussian / Perlin generators, so any whole-plane
  * shape it can run can host them.  SONAR_ERR_UNSUPPORTED when the plane kernel cannot run the shape (nothing was done). */
