@@ -38,7 +38,7 @@ def main(path):
     out["perlin_b512"] = {"hbm_bytes_per_launch": int(both * 512 / 576), "algorithmic_bytes_4N": 512 * N, "contract_bytes_12N": 3 * 512 * N,
                           "note": "lattice + statistics pass (no stores) + final pass; the workload ran batch 512 and batch 64 equally often, bytes split in proportion to the batch"}
     out["perlin_b64"] = {"hbm_bytes_per_launch": int(both * 64 / 576), "algorithmic_bytes_4N": 64 * N, "contract_bytes_12N": 3 * 64 * N}
-    pyr = pick(raw, "pyramid_plane_kernel<true, true>")
+    pyr = pick(raw, "pyramid_plane_kernel<true, true, 0>")
     both = 2 * pyr["hbm_bytes_per_launch"]
     out["pyramid_b512"] = {"hbm_bytes_per_launch": int(both * 512 / 576) + 2 * 512 * N,
                            "kernels": {"pyramid_plane_kernel": int(both * 512 / 576), "scale_noise_kernel (in place, read + write)": 2 * 512 * N},
@@ -59,7 +59,7 @@ def main(path):
             tot = total(*ks.values())
             out[f"wcfg_{route}_{tag}_b256"] = {"kernels": ks, "hbm_bytes_per_launch": tot, "algorithmic_bytes_16N": 4 * 256 * N,
                                                "ratio_to_16N": round(tot / (4 * 256 * N), 2)}
-    br = pick(raw, "brownian_burst_kernel")
+    br = pick(raw, "brownian_burst_kernel<0>")
     out["brownian_bridge_cfg5_shard"] = dict(br, tensor_bytes=128 * 16 * 128 * 128 * 4,
                                              note="128 x 16 x 128 x 128: reads the kept neighbour tensor(s), writes W(t) and the increment (or reads and "
                                                   "writes the chain's running sum): 3-4 tensors per call")
