@@ -634,6 +634,32 @@ def test_chain_with_hosted_folds_equals_the_plain_chain(api, monkeypatch, items)
     assert (hosted and all(hosted)) or items == ("pyramid", "perlin")  # (nothing in that chain can host)
 
 
+@pytest.mark.parametrize("items", [("perlin", "pyramid"), ("power", "perlin", "brownian"), ("gaussian", "perlin", "gaussian")])
+def test_hosted_chains_shard_like_their_items(api, items):
+    """cfg3 / cfg5 chains at SDXL size, drawn on device: the batch 16 chain == its two 8-latent shards (global element keys in the
+    hosting kernels too: ``elem_offset`` of the prefix and of the host are the shard's), over several sampler steps."""
+    N, pn, ng = api.noise, api.powernoise, api.noise_generation
+
+    def run(b0, b):
+        chain = N.CustomNoiseChain()
+        for k, name in enumerate(items):
+            f = (0.5, 0.3, 0.2)[k]
+            if name == "power":
+                chain.add(pn.PowerNoiseItem(f, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
+                                            mix=1.0, common_mode=0.0, channel_correlation="1"))
+            else:
+                chain.add(N.CustomNoiseItem(f, noise_type=name))
+        torch.manual_seed(77)
+        with ng.shard_offset(b0):
+            x = torch.zeros(b, 4, 128, 128, device="cuda")
+            ns = chain.make_noise_sampler(x, 0.03, 14.6, seed=9, cpu=False, normalized=False)
+            return [ns(torch.tensor(s), torch.tensor(sn)).clone() for s, sn in ((10.0, 7.0), (7.0, 4.0), (7.0, 5.5))]
+
+    whole = run(0, 16)
+    for step, (lo, hi) in enumerate(zip(run(0, 8), run(8, 8))):
+        assert torch.equal(torch.cat([lo, hi]), whole[step]), step
+
+
 # ------------------------------------------------------------------------------------------------ noise whose normalisation rides in the step kernel
 @pytest.mark.parametrize("case", ["shift_and_scale", "scale_only", "as_is"])
 def test_step_kernels_apply_a_pending_normalisation_like_scale_noise(api, case):
