@@ -1140,18 +1140,22 @@ __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n,
                                                           BrownianBase base, Accum fold, double* partials) {
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
-    const int64_t groups = (n + 3) / 4;
+    // a thread owns one GLOBAL group of four elements (the counter of its draws): a shard whose first element is not a multiple of
+    // four (odd latent sizes) starts and ends inside a group and keeps its part of it
+    const int shift = latent_seeds ? 0 : (int)(elem_offset & 3);
+    const int64_t groups = (n + shift + 3) / 4;
     for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
-        const int64_t e = g * 4;                       // local element index of the 4-group
+        const int64_t e = g * 4 - shift;               // local element index of the group's first element (< 0: before the shard)
         uint64_t key = seed;
-        uint64_t ctr = (uint64_t)(elem_offset + e) >> 2;  // global 4-group (elem_offset % 4 == 0)
+        uint64_t ctr = (uint64_t)(elem_offset + e) >> 2;  // global 4-group
         if (latent_seeds) {                            // one seed per latent: counters restart inside each latent
             const int64_t lat = e / latent_elems;
             key = latent_seeds[lat];
             ctr = (uint64_t)(e - lat * latent_elems) >> 2;
         }
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int j = 0; j < 4 && e + j < n; ++j) {
+        for (int j = 0; j < 4; ++j) {
+            if (e + j < 0 || e + j >= n) continue;
             if (base.a) acc[j] = base.fa * base.a[e + j];
             if (base.b) acc[j] = __builtin_fmaf(base.fb, base.b[e + j], acc[j]);
         }
@@ -1166,7 +1170,8 @@ __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n,
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(c, z[j], acc[j]);
         }
-        for (int j = 0; j < 4 && e + j < n; ++j) {
+        for (int j = 0; j < 4; ++j) {
+            if (e + j < 0 || e + j >= n) continue;
             if (w_out) w_out[e + j] = acc[j];
             if (out) {
                 float v = (prev ? acc[j] - prev[e + j] : acc[j]) * scale;
@@ -1255,8 +1260,9 @@ static int brownian_launch(float* out, float* w_out, const float* prev, float sc
                            const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds,
                            int64_t latent_elems, void* stream, const char* what, BrownianBase base = BrownianBase{nullptr, nullptr, 0.0f, 0.0f},
                            Accum acc = kNoAccum, double* partials = nullptr, const sonar_fold_prefix* pre = nullptr) {
-    SONAR_REQUIRE((out || w_out) && n >= 0 && elem_offset >= 0 && (elem_offset & 3) == 0 && nnodes >= 0 && (nnodes == 0 || (node_ids && coefs)),
-                  SONAR_ERR_ARG, "%s: bad argument", what);
+    SONAR_REQUIRE((out || w_out) && n >= 0 && elem_offset >= 0 && nnodes >= 0 && (nnodes == 0 || (node_ids && coefs)), SONAR_ERR_ARG,
+                  "%s: bad argument", what);
+    SONAR_REQUIRE(!latent_seeds || (elem_offset & 3) == 0, SONAR_ERR_ARG, "%s: per-latent seeds need an element offset of whole 4-element groups", what);
     SONAR_REQUIRE(nnodes <= kMaxBrownianNodes, SONAR_ERR_UNSUPPORTED, "%s: more than %d path nodes", what, kMaxBrownianNodes);
     SONAR_REQUIRE(!latent_seeds || (latent_elems > 0 && latent_elems % 4 == 0 && n % latent_elems == 0), SONAR_ERR_ARG,
                   "%s: per-latent seeds need whole latents of a multiple of 4 elements", what);
@@ -1294,7 +1300,7 @@ static int brownian_launch(float* out, float* w_out, const float* prev, float sc
         SONAR_BB(0);
 #undef SONAR_BB
     else
-        hipLaunchKernelGGL(brownian_kernel, dim3(std::min(cap, grid_for((n + 3) / 4, kBlock))), dim3(kBlock), 0, (hipStream_t)stream, out, n,
+        hipLaunchKernelGGL(brownian_kernel, dim3(std::min(cap, grid_for((n + 6) / 4, kBlock))), dim3(kBlock), 0, (hipStream_t)stream, out, n,
                            elem_offset, t, seed, reinterpret_cast<const unsigned long long*>(latent_seeds), latent_elems, prev, w_out, scale,
                            base, acc, partials);
     return check_launch(what);

@@ -660,6 +660,68 @@ def test_hosted_chains_shard_like_their_items(api, items):
         assert torch.equal(torch.cat([lo, hi]), whole[step]), step
 
 
+def test_chain_routes_agree_on_random_shapes(api, monkeypatch):
+    """Randomised differential run (fixed seed): random latent shapes -- odd sizes, 5-D video latents, tiny planes, shard offsets that
+    are not multiples of four elements -- and random item lists; hosted, folded and plain routes give the same unnormalised sum, bit
+    for bit.  (`scratch/fuzz_chains.py` is the long-running form.)"""
+    import random
+
+    N, pn, ng = api.noise, api.powernoise, api.noise_generation
+    rnd = random.Random(7)
+    kinds = ["gaussian", "perlin", "pyramid", "brownian", "uniform", "power", "laplacian"]
+    for it in range(60):
+        b, c = rnd.randint(1, 4), rnd.choice([1, 3, 4, 16])
+        h, w = rnd.choice([(8, 8), (16, 24), (32, 32), (64, 64), (20, 12), (18, 30), (7, 9), (40, 56), (33, 17), (4, 4)])
+        frames = rnd.choice([0, 0, 0, 3])
+        shape = (b, c, frames, h, w) if frames else (b, c, h, w)
+        items = [rnd.choice(kinds) for _ in range(rnd.randint(2, 4))]
+        if h % 2 or w % 2 or frames:
+            items = [k if k != "power" else "gaussian" for k in items]
+        factors = [rnd.choice([1.0, 0.5, 0.3, -0.7, 0.25]) for _ in items]
+        offset = rnd.choice([0, 0, 2, 5])
+
+        def build():
+            chain = N.CustomNoiseChain()
+            for f, name in zip(factors, items):
+                if name == "power":
+                    chain.add(pn.PowerNoiseItem(f, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0,
+                                                pnorm=2.0, mix=1.0, common_mode=0.0, channel_correlation="1"))
+                else:
+                    chain.add(N.CustomNoiseItem(f, noise_type=name))
+            return chain
+
+        x = torch.zeros(shape, device="cuda")
+        runs = []
+        for variant in ("hosted", "folded", "plain"):
+            with monkeypatch.context() as m:
+                if variant == "folded":
+                    m.setattr(N.NoiseSampler, "accepts_prefix", property(lambda self: False))
+                elif variant == "plain":
+                    m.delattr(N.NoiseSampler, "accumulate")
+                torch.manual_seed(1000 + it)
+                with ng.shard_offset(offset):
+                    ns = build().make_noise_sampler(x, 0.03, 14.6, seed=5 + it, cpu=False, normalized=False)
+                    runs.append([ns(torch.tensor(s), torch.tensor(sn)).clone() for s, sn in ((10.0, 7.0), (7.0, 4.0))])
+        for a, b_, c_ in zip(*runs):
+            assert bool(torch.isfinite(a).all()) and torch.equal(a, b_) and torch.equal(b_, c_), (it, shape, items, factors, offset)
+
+
+def test_brownian_shards_with_odd_latents(api):
+    """Latents of 3 x 33 x 17 elements: a shard's first element need not be a multiple of four; the general Brownian kernel owns GLOBAL
+    groups of four, so the shards of a batch still add up to the whole."""
+    ng = api.noise_generation
+
+    def run(b0, b):
+        with ng.shard_offset(b0):
+            x = torch.zeros(b, 3, 33, 17, device="cuda")
+            ns = api.noise.get_noise_sampler("brownian", x, 0.03, 14.6, seed=11, cpu=False, normalized=False)
+            return [ns(torch.tensor(s), torch.tensor(sn)).clone() for s, sn in ((10.0, 7.0), (7.0, 4.0), (7.0, 5.5))]
+
+    whole = run(0, 5)
+    for step, parts in enumerate(zip(run(0, 1), run(1, 2), run(3, 2))):
+        assert torch.equal(torch.cat(parts), whole[step]), step
+
+
 # ------------------------------------------------------------------------------------------------ noise whose normalisation rides in the step kernel
 @pytest.mark.parametrize("case", ["shift_and_scale", "scale_only", "as_is"])
 def test_step_kernels_apply_a_pending_normalisation_like_scale_noise(api, case):
