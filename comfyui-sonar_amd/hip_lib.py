@@ -156,6 +156,9 @@ SIGNATURES = {
     "sonar_perlin_generate_chain_f32": (_I, [_P, _P, _P, _I64, _I64, _F, _U64, _U64, _I64, _P]),
     "sonar_pyramid_generate_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I, _U64, _U64, _I64, _P]),
     "sonar_brownian_bridge_chain_f32": (_I, [_P, _P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _I64, _P]),
+    "sonar_dft_rows_r2c_f32": (_I, [_P, _P, _I64, _I64, _P]),
+    "sonar_dft_cols_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P]),
+    "sonar_dft_rows_c2r_f32": (_I, [_P, _P, _I64, _I64, _F, _P, _P]),
     "sonar_max_to_host_f32": (_I, [_P, _I64, C.POINTER(C.c_float), _P]),
     "sonar_max_to_host_begin_f32": (_I, [_P, _I64, _P]),
     "sonar_max_to_host_end_f32": (_I, [C.POINTER(C.c_float), _P]),
@@ -930,6 +933,12 @@ def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: 
         zp = z.data_ptr()
     if filt.numel() != H * (W // 2 + 1):
         raise SonarHipError("power_irfft2: filter size mismatch")
+    if power_plane_kind(H, W) == 3:
+        if z is None:
+            # the reference's own route: white noise, rfft2, x filter, irfft2 (py/nodes/powernoise.py:356-366); global element keys
+            white = philox_normal(tuple(shape), filt.device, seed, stream_id, plane_offset * H * W)
+            return _direct_spectral_filter(white, filt, partials)
+        return _direct_inverse(z, filt, out, 1.0 / math.sqrt(H * W), partials)
     _check(
         load().sonar_power_irfft2_f32(zp, _dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
                                       rng_group_for(shape), _opt(partials, "partials", torch.float64), _stream()),
@@ -945,6 +954,9 @@ def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_o
     out = torch.empty(shape, dtype=torch.float32, device=filt.device)
     planes = out.numel() // (H * W)
     ws = new_partials(filt.device)
+    if power_plane_kind(H, W) == 3:
+        white = philox_normal(tuple(shape), filt.device, seed, stream_id, plane_offset * H * W)
+        return scale_noise_(_direct_spectral_filter(white, filt, ws), factor, True, ws, threshold_std_devs=threshold_std_devs)
     _check(
         load().sonar_power_noise_f32(_dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
                                      rng_group_for(shape), float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
@@ -959,6 +971,8 @@ def spectral_filter(x: torch.Tensor, filt: torch.Tensor, partials: Optional[torc
     planes = x.numel() // (H * W)
     if filt.numel() != H * (W // 2 + 1):
         raise SonarHipError("spectral_filter: filter size mismatch")
+    if power_plane_kind(H, W) == 3:
+        return _direct_spectral_filter(x, filt, partials)
     out = torch.empty_like(x)
     _check(load().sonar_spectral_filter_f32(_dev(x, "x"), _dev(filt, "filter"), _dev(out, "out"), planes, H, W,
                                             _opt(partials, "partials", torch.float64), _stream()), "sonar_spectral_filter_f32")
@@ -1019,9 +1033,46 @@ def power_spectrum(shape, device, *, seed: int, stream_id: int, plane_offset: in
     return z
 
 
+DIRECT_DFT_MAX = 2048
+
+
+def power_plane_kind(H: int, W: int) -> int:
+    """1: fixed-size LDS kernels, 2: general-size LDS kernels (even sizes that fit), 3: direct DFT passes (any size up to 2048), 0: none."""
+    kind = int(load().sonar_power_plane_kind(int(H), int(W)))
+    if kind == 0 and 1 <= H <= DIRECT_DFT_MAX and 1 <= W <= DIRECT_DFT_MAX:
+        return 3
+    return kind
+
+
 def power_supported(H: int, W: int) -> bool:
-    """True when the power-noise kernels take an H x W plane (fixed-size fast kernels or the general-size ones)."""
-    return int(load().sonar_power_plane_kind(int(H), int(W))) != 0
+    """True when the spectral kernels take an H x W plane: LDS-resident FFTs, or the direct DFT passes for the rest."""
+    return power_plane_kind(H, W) != 0
+
+
+def _direct_inverse(z: torch.Tensor, filt: Optional[torch.Tensor], out: torch.Tensor, scale: float, partials) -> torch.Tensor:
+    """out = scale * irfft2-unnormalised(z * filt) for complex64 z [planes, H, W/2+1] through the direct passes."""
+    H, W = out.shape[-2:]
+    K = W // 2 + 1
+    planes = out.numel() // (H * W)
+    lib = load()
+    ws = torch.empty((planes, H, K), dtype=torch.complex64, device=out.device)
+    _check(lib.sonar_dft_cols_f32(z.data_ptr(), None if filt is None else _dev(filt, "filter"), ws.data_ptr(), planes, H, K, 1, _stream()),
+           "sonar_dft_cols_f32")
+    _check(lib.sonar_dft_rows_c2r_f32(ws.data_ptr(), _dev(out, "out"), planes * H, W, float(scale), _opt(partials, "partials", torch.float64),
+                                      _stream()), "sonar_dft_rows_c2r_f32")
+    return out
+
+
+def _direct_spectral_filter(x: torch.Tensor, filt: torch.Tensor, partials) -> torch.Tensor:
+    H, W = int(x.shape[-2]), int(x.shape[-1])
+    K = W // 2 + 1
+    planes = x.numel() // (H * W)
+    lib = load()
+    a = torch.empty((planes, H, K), dtype=torch.complex64, device=x.device)
+    b = torch.empty_like(a)
+    _check(lib.sonar_dft_rows_r2c_f32(_dev(x, "x"), a.data_ptr(), planes * H, W, _stream()), "sonar_dft_rows_r2c_f32")
+    _check(lib.sonar_dft_cols_f32(a.data_ptr(), None, b.data_ptr(), planes, H, K, 0, _stream()), "sonar_dft_cols_f32")
+    return _direct_inverse(b, filt, torch.empty_like(x), 1.0 / (H * W), partials)
 
 
 def channel_mix(x: torch.Tensor, mixer: torch.Tensor, partials=None) -> torch.Tensor:

@@ -31,7 +31,7 @@ def ffilter(x: torch.Tensor, pfilter: PowerFilter, normalization_factor: float =
     filter_cache[cache_key] = filter_rfft
     h, w = x.shape[-2:]
     if not hip_lib.power_supported(h, w):
-        raise hip_lib.SonarHipError(f"ffilter: plane {h}x{w} is not LDS-resident (even sizes whose half-spectrum fits in LDS)")
+        raise hip_lib.SonarHipError(f"ffilter: plane {h}x{w} is beyond the spectral kernels (sides of at most 2048)")
     x32 = x if x.dtype == torch.float32 else x.to(torch.float32)
     out = hip_lib.spectral_filter(x32.contiguous(), filter_rfft.reshape(h, w // 2 + 1).contiguous())
     return out if x.dtype == torch.float32 else out.to(x.dtype)

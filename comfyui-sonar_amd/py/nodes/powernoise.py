@@ -143,7 +143,7 @@ class PowerFilter:
 
 def _device_irfft2_fallback_error(h, w):
     return hip_lib.SonarHipError(
-        f"power noise: plane {h}x{w} is not supported by the LDS-resident FFT kernel (powers of two, 16..256); "
+        f"power noise: plane {h}x{w} is beyond the spectral kernels (LDS-resident FFTs, direct passes up to 2048 x 2048); "
         "there is no CPU fallback"
     )
 

@@ -817,7 +817,7 @@ class ModulatedNoise(CustomNoiseItemBase):
         boost = None
         if mtype == "frequency":
             if not hip_lib.power_supported(d2, d1):
-                raise hip_lib.SonarHipError(f"ModulatedNoise frequency mode: plane {d2}x{d1} is not LDS-resident (powers of two, 16..256)")
+                raise hip_lib.SonarHipError(f"ModulatedNoise frequency mode: plane {d2}x{d1} is beyond the spectral kernels (sides of at most 2048)")
             boost = self._frequency_boost(d2, d1, strength, x.device)
 
         def noise_sampler(s, sn):

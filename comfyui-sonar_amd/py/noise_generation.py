@@ -850,7 +850,7 @@ class _SpectralGainNoiseGenerator(FramesToChannelsNoiseGenerator):
         noise = self.rand_like()
         utils.pop_stats(noise)
         if not hip_lib.power_supported(self.height, self.width):
-            raise hip_lib.SonarHipError(f"{self.name}: plane {self.height}x{self.width} is not LDS-resident (powers of two, 16..256)")
+            raise hip_lib.SonarHipError(f"{self.name}: plane {self.height}x{self.width} is beyond the spectral kernels (sides of at most 2048)")
         gain = _half_gain(self.spectral_gain().to(torch.float32)).to(self.device)
         return hip_lib.spectral_filter(noise.contiguous(), gain, partials)
 

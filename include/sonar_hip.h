@@ -500,6 +500,16 @@ int sonar_dtcwt_q2c_f32(const float* lh, const float* hh, const float* hl, float
 int sonar_dtcwt_c2q_f32(const float* bands, float* lh, float* hh, float* hl, int64_t planes, int64_t h, int64_t w, void* stream);
 int sonar_dtcwt_q2c_f64(const double* lh, const double* hh, const double* hl, double* bands, int64_t planes, int64_t h, int64_t w, void* stream);
 int sonar_dtcwt_c2q_f64(const double* bands, double* lh, double* hh, double* hl, int64_t planes, int64_t h, int64_t w, void* stream);
+/* Direct real 2-D DFT passes for planes the LDS-resident FFT kernels do not take (odd heights / widths -- 1080-line video gives
+ * 135-row latents -- or planes beyond the LDS budget): torch.fft.rfft2 / irfft2 (py/nodes/powernoise.py:338-408,
+ * py/noise_generation.py:680-759, py/nodes/freeu_extreme.py:10-29) as rows r2c -> columns (optionally x a real filter [H][K] on the
+ * way in; inverse: e^{+}) -> rows c2r (x scale; the imaginary parts of the DC / Nyquist columns are ignored, as irfft does), through a
+ * caller-owned complex64 workspace [planes][H][W/2+1].  O(N) per output, lines of at most 2048; unscaled except for `scale`.
+ * partials (nullable): (sum, sumsq) of the real output. */
+int sonar_dft_rows_r2c_f32(const float* x, float* y, int64_t rows, int64_t W, void* stream);
+int sonar_dft_cols_f32(const float* in, const float* filter /*nullable*/, float* out, int64_t planes, int64_t H, int64_t K, int inverse,
+                       void* stream);
+int sonar_dft_rows_c2r_f32(const float* y, float* out, int64_t rows, int64_t W, float scale, double* partials /*nullable*/, void* stream);
 /* max over a non-empty device vector with torch.max's NaN rule, returned to the host: WaveletCFG's `sigma.max().item()`
  * (py/wavelet_cfg.py:795-796) as one launch that writes into pinned host memory + one wait.  `begin` only launches; `end` BLOCKS
  * until the value has landed (as `.item()` does) -- the host prepares everything that does not depend on the value in between.

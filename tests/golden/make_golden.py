@@ -243,6 +243,7 @@ def gen_power_noise():
         ("e", (1, 2, 16, 16), 4, {"alpha": 0.0, "mix": 0.5}, True),
         ("np2", (2, 4, 40, 56), 5, {"alpha": 1.0}, True),                       # not powers of two (general-size kernels)
         ("np2_rot", (1, 4, 52, 76), 6, {"alpha": 1.5, "rotate": 20.0, "stretch": 1.5, "common_mode": 0.1}, True),  # quarter-size 832 x 1216 px
+        ("odd", (2, 4, 27, 35), 7, {"alpha": 1.0, "common_mode": 0.1}, True),   # odd height and width (1080 lines -> 135 rows): direct DFT passes
     ):
         item = ref_power_item(**kw)
         x = torch.zeros(shape)
@@ -1003,6 +1004,40 @@ def gen_resample_modes():
     save("resample_modes", **cases)
 
 
+# ------------------------------------------------------------------------------------------------ every registry type on odd shapes
+SWEEP_SHAPES = [(1, 3, 10, 14), (2, 4, 12, 20), (1, 16, 8, 8), (3, 1, 18, 6), (2, 4, 9, 7), (1, 4, 2, 12, 8), (2, 2, 16, 16), (1, 5, 24, 4)]
+SWEEP_SKIP = {"BROWNIAN",  # torchsde, un-vendored
+              "COLLATZ", "DISTRO", "VORONOI_FUZZ", "VORONOI_MIX",  # outside the path
+              "PYRAMID_BISLERP", "HIGHRES_PYRAMID_BISLERP", "PYRAMID_MIX_BISLERP", "PYRAMID_OLD_BISLERP"}  # comfy.utils.bislerp: not in the image
+
+
+def gen_shape_sweep():
+    """Every NoiseType of the registry (py/noise.py:2244-2457) that the path covers, in replay mode on shapes the other fixtures do not
+    have: channel counts 1 / 3 / 5 / 16, H != W, odd sizes, a 5-D video latent.  What the reference RAISES on a shape is a result too
+    (its type is recorded and the product must raise the same)."""
+    import json
+    import random
+
+    rnd = random.Random(20260)
+    cases, meta = {}, {}
+    for nt in NT:
+        if nt.name in SWEEP_SKIP:
+            continue
+        for k, shape in enumerate(rnd.sample(SWEEP_SHAPES, 3)):
+            seed, normalized = 300 + 7 * k + len(nt.name), bool(k % 2)
+            key = f"{nt.name.lower()}__{k}"
+            try:
+                out = ref_noise(nt, shape, seed, normalized)
+                cases[key] = out
+                meta[key] = dict(type=nt.name.lower(), shape=list(shape), seed=seed, normalized=normalized, error=None)
+            except Exception as exc:  # noqa: BLE001 -- the reference's refusal is the expected behaviour
+                meta[key] = dict(type=nt.name.lower(), shape=list(shape), seed=seed, normalized=normalized, error=type(exc).__name__,
+                                 message=str(exc)[:200])
+    ok = sum(1 for m in meta.values() if m["error"] is None)
+    print(f"shape sweep: {ok} outputs, {len(meta) - ok} refusals")
+    save("shape_sweep", meta_json=json.dumps(meta), **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -1032,6 +1067,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_ffilter()
     gen_cfg_exact()
     gen_resample_modes()
+    gen_shape_sweep()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

@@ -134,6 +134,7 @@ POWER_KW = {
     "e": {"alpha": 0.0, "mix": 0.5},
     "np2": {"alpha": 1.0},  # 40 x 56 and 52 x 76 planes: the general-size kernels
     "np2_rot": {"alpha": 1.5, "rotate": 20.0, "stretch": 1.5, "common_mode": 0.1},
+    "odd": {"alpha": 1.0, "common_mode": 0.1},  # 27 x 35: the direct DFT passes
 }
 
 

@@ -338,11 +338,11 @@ def test_pyramid_flat_kernel_for_levels_beyond_lds(hl):
 
 
 # ------------------------------------------------------------------------------------------------ power-law rFFT noise
-@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e", "np2", "np2_rot"])
+@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e", "np2", "np2_rot", "odd"])
 def test_power_noise_replay_golden(hl, golden, tag):
     g = golden("power_noise")
     z = torch.view_as_complex(g[f"{tag}_z"].contiguous())
-    shape = tuple(z.shape[:-1]) + ((z.shape[-1] - 1) * 2,)
+    shape = tuple(g[f"{tag}_out"].shape)
     filt = g[f"{tag}_filter"]
     mixer = g[f"{tag}_mixer"]
     identity = torch.equal(mixer, torch.eye(mixer.shape[0]))
@@ -567,12 +567,21 @@ def test_power_general_size_full_batch(hl):
     assert abs(row_corr) < 2e-3 and abs(col_corr) < 2e-3
 
 
-def test_power_unsupported_shape_raises(hl):
+def test_planes_beyond_the_lds_kernels_take_the_direct_passes(hl):
+    """Odd sizes and half-spectra larger than LDS are not the LDS kernels' (kind 0 at the C ABI); the host routes them through the
+    direct DFT passes (kind 3), up to 2048 x 2048; beyond that it raises."""
     assert hl.load().sonar_power_plane_kind(96, 161) == 0 and hl.load().sonar_power_plane_kind(256, 256) == 0
+    assert hl.power_plane_kind(95, 160) == 3 and hl.power_plane_kind(256, 256) == 3 and hl.power_plane_kind(128, 128) == 1
+    assert hl.power_plane_kind(4096, 64) == 0 and not hl.power_supported(64, 4096)
+    out = hl.power_irfft2(None, dev(torch.ones(95, 81)), (1, 4, 95, 160), seed=3, stream_id=1)  # odd height
+    assert tuple(out.shape) == (1, 4, 95, 160) and bool(torch.isfinite(out).all()) and abs(out.std().item() - 1.0) < 0.02
+    z = torch.randn(2, 256, 129, dtype=torch.complex64, device="cuda")
+    filt = torch.rand(256, 129, device="cuda") + 0.5
+    got = hl.power_irfft2(z, filt, (2, 1, 256, 256)).reshape(2, 256, 256)  # half-spectrum larger than LDS
+    want = torch.fft.irfft2(z * filt, s=(256, 256), norm="ortho")
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-5 * float(want.abs().max()))
     with pytest.raises(hl.SonarHipError):
-        hl.power_irfft2(None, dev(torch.ones(95, 81)), (1, 4, 95, 160))  # odd height
-    with pytest.raises(hl.SonarHipError):
-        hl.power_irfft2(None, dev(torch.ones(256, 129)), (1, 4, 256, 256))  # half-spectrum larger than LDS
+        hl.power_irfft2(None, dev(torch.ones(4096, 33)), (1, 1, 4096, 64))
 
 
 def test_channel_mix(hl, golden):
@@ -611,7 +620,7 @@ def test_c_abi_error_codes_and_messages(hl):
     torch.cuda.synchronize()
     assert torch.all(out == 7.0) and torch.all(x == 7.0)
     with pytest.raises(hl.SonarHipError, match="code -2"):
-        hl.power_irfft2(None, filt, (2, 1, 25, 24))
+        hl.power_irfft2(None, torch.ones(4096, 13, device="cuda"), (2, 1, 4096, 24))  # beyond the direct passes too (lines of at most 2048)
     with pytest.raises(hl.SonarHipError):
         hl.stats(torch.zeros(8))  # host tensor
 
@@ -694,3 +703,57 @@ def test_fused_normalised_fill(hl, uniform, n, offset):
         one = hl.philox_noise(uniform, (n,), "cuda", 5, 3, offset, factor, **kw)
         close(one, two, rtol=1e-5, atol=1e-6)
         assert abs(one.std().item() - factor) < (2.5 / math.sqrt(n) + 5e-3) * factor  # inside the band nothing is rescaled
+
+
+@pytest.mark.parametrize("shape", [(3, 9, 7), (2, 135, 30), (5, 16, 21), (2, 33, 64), (1, 1, 5), (2, 6, 1), (1, 250, 250)])
+def test_direct_dft_passes_match_torch_fft(hl, shape):
+    """sonar_dft_rows_r2c / cols / rows_c2r (the route of planes the LDS FFT kernels do not take: odd sizes, big planes) against
+    torch.fft: rfft2, irfft2 of a filtered spectrum (norm='ortho', imaginary parts of the DC / Nyquist columns ignored), and the
+    spectral filter irfft2(rfft2(x) * f).  fp32 direct sums: 2e-5 of the result's peak."""
+    planes, H, W = shape
+    K = W // 2 + 1
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(planes, H, W, device="cuda", generator=g)
+    filt = torch.rand(H, K, device="cuda", generator=g) + 0.5
+    assert hl.power_plane_kind(H, W) == 3
+    lib = hl.load()
+    a = torch.empty(planes, H, K, dtype=torch.complex64, device="cuda")
+    b = torch.empty_like(a)
+    assert lib.sonar_dft_rows_r2c_f32(x.data_ptr(), a.data_ptr(), planes * H, W, None) == 0
+    assert lib.sonar_dft_cols_f32(a.data_ptr(), None, b.data_ptr(), planes, H, K, 0, None) == 0
+    want = torch.fft.rfft2(x)
+    torch.testing.assert_close(b, want, rtol=0, atol=2e-5 * float(want.abs().max()))
+    z = torch.randn(planes, H, K, dtype=torch.complex64, device="cuda", generator=g)
+    part = hl.new_partials("cuda")
+    got = hl.power_irfft2(z, filt, (planes, 1, H, W), partials=part).reshape(planes, H, W)
+    want = torch.fft.irfft2(z * filt, s=(H, W), norm="ortho")
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-5 * max(1.0, float(want.abs().max())))
+    sums = part.view(-1, 2).sum(0)
+    torch.testing.assert_close(sums, torch.stack([got.double().sum(), (got.double() ** 2).sum()]), rtol=1e-9, atol=1e-6)
+    got = hl.spectral_filter(x, filt)
+    want = torch.fft.irfft2(torch.fft.rfft2(x, norm="ortho") * filt, s=(H, W), norm="ortho")
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-5 * max(1.0, float(want.abs().max())))
+
+
+def test_power_noise_on_an_odd_plane(pkg, hl):
+    """1080-line video: 135 x 240 latents.  Generate mode takes the direct passes (white noise -> rfft2 x filter -> irfft2, the
+    reference's own route): unit statistics after normalisation, two shards == the whole."""
+    import importlib
+
+    pn = importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise")
+    ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
+    item = pn.PowerNoiseItem(1.0, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                             common_mode=0.0, channel_correlation="1")
+
+    def run(b0, b, normalized):
+        torch.manual_seed(4)
+        with ng.shard_offset(b0):
+            x = torch.zeros(b, 4, 135, 240, device="cuda")
+            return item.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=normalized)(None, None)
+
+    whole = run(0, 4, False)
+    assert torch.equal(torch.cat([run(0, 2, False), run(2, 2, False)]), whole)
+    normed = run(0, 4, True)
+    assert bool(torch.isfinite(normed).all()) and abs(normed.std().item() - 1.0) < 1e-3 and abs(normed.mean().item()) < 5e-3
+    # pink: neighbouring pixels correlate
+    assert float((whole[..., 1:] * whole[..., :-1]).mean() / whole.var()) > 0.2

@@ -42,6 +42,30 @@ def replay(api, name, shape, seed, normalized, **kw):
     return ns(*SIG)
 
 
+# ------------------------------------------------------------------------------------------------ every registry type on odd shapes
+def _sweep_cases():
+    import json
+    import numpy as np
+    from tests.conftest import GOLDEN
+
+    g = np.load(f"{GOLDEN}/shape_sweep.npz", allow_pickle=False)
+    return g, json.loads(str(g["meta_json"]))
+
+
+@pytest.mark.parametrize("key", sorted(_sweep_cases()[1]))
+def test_registry_types_on_odd_shapes(api, key):
+    """Every NoiseType the path covers, replay mode, against the reference's own output on shapes the other fixtures do not have
+    (1 / 3 / 5 / 16 channels, H != W, odd sizes, a 5-D video latent; tests/golden/make_golden.py gen_shape_sweep).  fp32 op sequences
+    through FFTs and resamplers: 2e-5 of the output's peak."""
+    g, meta = _sweep_cases()
+    m = meta[key]
+    assert m["error"] is None
+    want = torch.from_numpy(g[key])
+    got = replay(api, m["type"], tuple(m["shape"]), m["seed"], m["normalized"])
+    assert got.is_cuda and tuple(got.shape) == tuple(want.shape) and got.dtype == torch.float32
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5 * max(1.0, float(want.abs().max())))
+
+
 # ------------------------------------------------------------------------------------------------ row U: every F.interpolate mode of scale_samples
 def test_scale_samples_every_mode(api, golden):
     """py/utils.py:58-67 against the reference's outputs: bilinear, nearest-exact, nearest, area, bicubic, adaptive_avg_pool2d; enlarging,
