@@ -1038,6 +1038,20 @@ def gen_shape_sweep():
     save("shape_sweep", meta_json=json.dumps(meta), **cases)
 
 
+def gen_wrapper_sweep():
+    """Noise-item wrappers (py/noise.py: Random / Repeated / Channel / RippleFiltered / PerDim / Scheduled / Blended) over inner chains,
+    on odd shapes and a 5-D video latent, several calls each: tests/golden/sweep_cases.py holds the specs both sides build from."""
+    from tests.golden import sweep_cases as sc
+
+    cases = {}
+    for name in sc.WRAPPERS:
+        item, shape, seed, calls = sc.build(ref.noise, ref.utils, name)
+        torch.manual_seed(seed)
+        ns = item.make_noise_sampler(torch.zeros(shape), 0.03, 14.6, seed=seed, cpu=True, normalized=True)
+        cases[name] = torch.stack([ns(torch.tensor(sc.SIGMAS[k % len(sc.SIGMAS)][0]), torch.tensor(sc.SIGMAS[k % len(sc.SIGMAS)][1])) for k in range(calls)])
+    save("wrapper_sweep", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -1068,6 +1082,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_cfg_exact()
     gen_resample_modes()
     gen_shape_sweep()
+    gen_wrapper_sweep()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

@@ -66,6 +66,25 @@ def test_registry_types_on_odd_shapes(api, key):
     torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5 * max(1.0, float(want.abs().max())))
 
 
+from tests.golden import sweep_cases as _sc  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(_sc.WRAPPERS))
+def test_item_wrappers_on_odd_shapes(api, golden, name):
+    """Random / Repeated / Channel / RippleFiltered / PerDim / Scheduled / Blended wrappers (py/noise.py) over inner chains, several calls
+    each, on odd shapes and a 5-D video latent, against the reference's outputs (tests/golden/make_golden.py gen_wrapper_sweep)."""
+    want = golden("wrapper_sweep")[name]
+    item, shape, seed, calls = _sc.build(api.noise, api.utils, name)
+    x = torch.zeros(shape, device="cuda")
+    torch.manual_seed(seed)
+    ns = item.make_noise_sampler(x, 0.03, 14.6, seed=seed, cpu=True, normalized=True)
+    for k in range(calls):
+        s, sn = _sc.SIGMAS[k % len(_sc.SIGMAS)]
+        got = ns(torch.tensor(s), torch.tensor(sn))
+        assert got.is_cuda and tuple(got.shape) == tuple(want[k].shape)
+        torch.testing.assert_close(got.cpu(), want[k], rtol=2e-5, atol=2e-5 * max(1.0, float(want[k].abs().max())), equal_nan=True)
+
+
 # ------------------------------------------------------------------------------------------------ row U: every F.interpolate mode of scale_samples
 def test_scale_samples_every_mode(api, golden):
     """py/utils.py:58-67 against the reference's outputs: bilinear, nearest-exact, nearest, area, bicubic, adaptive_avg_pool2d; enlarging,
