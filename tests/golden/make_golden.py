@@ -1052,6 +1052,17 @@ def gen_wrapper_sweep():
     save("wrapper_sweep", **cases)
 
 
+def gen_sampler_sweep():
+    """The three Sonar samplers end to end (py/sonar.py:452-820) with registry noise in replay mode on odd shapes, 16 / 5 / 1 channels
+    and a 5-D video latent: per-step x of the reference (tests/golden/sweep_cases.py SAMPLERS)."""
+    from tests.golden import sweep_cases as sc
+
+    cases = {}
+    for name in sc.SAMPLERS:
+        cases[name] = torch.stack(sc.run_sampler(ref.sonar, ref.noise, name, "cpu"))
+    save("sampler_sweep", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -1083,6 +1094,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_resample_modes()
     gen_shape_sweep()
     gen_wrapper_sweep()
+    gen_sampler_sweep()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

@@ -44,3 +44,46 @@ def build(noise_mod, utils_mod, name):
             chain.add(noise_mod.CustomNoiseItem(f, noise_type=noise_type))
         kw[key] = chain
     return getattr(noise_mod, cls)(factor, **kw), SHAPES[shape_idx], seed, calls
+
+
+# sampler sweep: name -> (sampler kind, config overrides, noise type, shape index, seed); 5 steps from sigma 14.6 down to 0, noise drawn by
+# the registry sampler in replay mode (cpu=True) on the global generator, exactly as ComfyUI would run it
+SAMPLERS = {
+    "euler_odd": ("euler", dict(), "gaussian", 0, 171),
+    "euler_video_denoised": ("euler", dict(momentum_mode="DENOISED", init="SAMPLE"), "gaussian", 2, 172),
+    "ancestral_odd_perlin": ("ancestral", dict(momentum=0.8, momentum_hist=0.5), "perlin", 1, 173),
+    "ancestral_video_pyramid": ("ancestral", dict(momentum_mode="CLASSIC"), "pyramid", 2, 174),
+    "ancestral_16ch_uniform": ("ancestral", dict(direction=-0.5), "uniform", 4, 175),
+    "dpmpp_odd_gaussian": ("dpmpp", dict(), "gaussian", 3, 176),
+    "dpmpp_video_perlin": ("dpmpp", dict(momentum=0.7, init="SAMPLE_NORM"), "perlin", 2, 177),
+    "dpmpp_5ch_laplacian": ("dpmpp", dict(blend_mode="inject", momentum=0.3, momentum_hist=0.4), "laplacian", 5, 178),
+}
+
+
+def fake_model(x, sigma, **_kw):
+    import torch
+
+    s = sigma.reshape(-1, *([1] * (x.ndim - 1)))
+    return x * 0.5 + torch.tanh(x) * (0.1 * s / (1.0 + s))
+
+
+def run_sampler(sonar_mod, noise_mod, name, device):
+    """Per-step x of the named case (list of tensors) with ``sonar_mod`` / ``noise_mod`` the reference's or the product's modules."""
+    import torch
+
+    kind, cfg, noise_type, shape_idx, seed = SAMPLERS[name]
+    shape = SHAPES[shape_idx]
+    torch.manual_seed(seed)
+    x0 = (torch.randn(shape) * 14.6).to(device)
+    sigmas = torch.cat((torch.linspace(14.6, 0.03, 5), torch.zeros(1)))
+    ns = noise_mod.get_noise_sampler(noise_type, x0, 0.03, 14.6, seed=seed, cpu=True, normalized=True)
+    trace = []
+    cb = lambda d: trace.append(d["x"].clone())  # noqa: E731
+    extra = {"seed": seed}
+    if kind == "euler":
+        sonar_mod.SonarEuler.sampler(fake_model, x0.clone(), sigmas, extra, cb, True, ns, None, dict(cfg))
+    elif kind == "ancestral":
+        sonar_mod.SonarEulerAncestral.sampler(fake_model, x0.clone(), sigmas, extra, cb, True, None, dict(cfg), 0.8, 1.1, ns)
+    else:
+        sonar_mod.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas, extra, cb, True, None, dict(cfg), 0.9, 1.05, ns)
+    return trace

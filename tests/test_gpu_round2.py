@@ -85,6 +85,18 @@ def test_item_wrappers_on_odd_shapes(api, golden, name):
         torch.testing.assert_close(got.cpu(), want[k], rtol=2e-5, atol=2e-5 * max(1.0, float(want[k].abs().max())), equal_nan=True)
 
 
+@pytest.mark.parametrize("name", sorted(_sc.SAMPLERS))
+def test_samplers_on_odd_shapes(api, golden, name):
+    """SonarEuler / SonarEulerAncestral / SonarDPMPPSDE end to end with registry noise (replay mode) on odd shapes, other channel counts
+    and a 5-D video latent: every step's x against the reference's run (tests/golden/make_golden.py gen_sampler_sweep)."""
+    want = golden("sampler_sweep")[name]
+    trace = _sc.run_sampler(api.sonar, api.noise, name, "cuda")
+    assert len(trace) == want.shape[0]
+    for i, t in enumerate(trace):
+        assert t.is_cuda
+        torch.testing.assert_close(t.cpu(), want[i], rtol=2e-4, atol=2e-4)
+
+
 # ------------------------------------------------------------------------------------------------ row U: every F.interpolate mode of scale_samples
 def test_scale_samples_every_mode(api, golden):
     """py/utils.py:58-67 against the reference's outputs: bilinear, nearest-exact, nearest, area, bicubic, adaptive_avg_pool2d; enlarging,
