@@ -1063,6 +1063,18 @@ def gen_sampler_sweep():
     save("sampler_sweep", **cases)
 
 
+def gen_advanced_sweep():
+    """ModulatedNoise, GuidedNoise, AdvancedWaveletNoise, PowerFilterNoiseItem and PowerNoiseItem (py/noise.py, py/nodes/powernoise.py) on odd
+    planes and non-integer resize ratios: tests/golden/sweep_cases.py ADVANCED."""
+    from tests.golden import sweep_cases as sc
+
+    pn = importlib.import_module("sonar_ref.nodes.powernoise")
+    cases = {}
+    for name in sc.ADVANCED:
+        cases[name] = torch.stack(sc.run_advanced(ref.noise, pn, ref.utils, name, "cpu"))
+    save("advanced_sweep", **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -1095,6 +1107,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_shape_sweep()
     gen_wrapper_sweep()
     gen_sampler_sweep()
+    gen_advanced_sweep()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

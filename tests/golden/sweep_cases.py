@@ -87,3 +87,68 @@ def run_sampler(sonar_mod, noise_mod, name, device):
     else:
         sonar_mod.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas, extra, cb, True, None, dict(cfg), 0.9, 1.05, ns)
     return trace
+
+
+# advanced items: name -> builder(noise_mod, powernoise_mod, utils_mod, torch, device) returning (item, x tensor on CPU); odd planes send the
+# spectral ones through the direct DFT passes, the resamplers through non-integer ratios
+def _chain(noise_mod, *specs):
+    chain = noise_mod.CustomNoiseChain()
+    for noise_type, f in specs:
+        chain.add(noise_mod.CustomNoiseItem(f, noise_type=noise_type))
+    return chain
+
+
+def _latent(torch, shape, seed, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale + shift
+
+
+WAVELET_KW = dict(octave_scale_mode="adaptive_avg_pool2d", octave_rescale_mode="bilinear", post_octave_rescale_mode="bilinear", initial_amplitude=1.0,
+                  persistence=0.5, octaves=3, octave_height_factor=0.5, octave_width_factor=0.5, height_factor=2.0, width_factor=2.0, update_blend=1.0)
+
+ADVANCED = {
+    "modulated_intensity_odd": lambda N, P, U, t, dev: (N.ModulatedNoise(0.8, noise=_chain(N, ("gaussian", 1.0)), normalize_result=None, normalize_noise=None,
+                                                                   normalize_ref=True, modulation_type="intensity", modulation_strength=1.5, modulation_dims=2,
+                                                                   ref_latent_opt=_latent(t, (2, 4, 9, 7), 1, 1.3, 0.1)), _latent(t, (2, 4, 9, 7), 2, 2.0, 0.3)),
+    "modulated_frequency_odd": lambda N, P, U, t, dev: (N.ModulatedNoise(1.0, noise=_chain(N, ("gaussian", 1.0)), normalize_result=None, normalize_noise=None,
+                                                                   normalize_ref=True, modulation_type="frequency", modulation_strength=1.2, modulation_dims=3,
+                                                                   ref_latent_opt=_latent(t, (1, 3, 15, 21), 3, 1.0, 0.0)), _latent(t, (1, 3, 15, 21), 4, 2.0, 0.0)),
+    "modulated_frequency_self": lambda N, P, U, t, dev: (N.ModulatedNoise(0.9, noise=_chain(N, ("perlin", 1.0)), normalize_result=False, normalize_noise=None,
+                                                                    normalize_ref=True, modulation_type="frequency", modulation_strength=-0.6, modulation_dims=1,
+                                                                    ref_latent_opt=None), _latent(t, (2, 5, 12, 20), 5, 2.0, 0.3)),
+    "guided_linear_odd": lambda N, P, U, t, dev: (N.GuidedNoise(1.0, guidance_factor=0.4, ref_latent=U.scale_noise(_latent(t, (1, 4, 11, 9), 6, 0.8, 0.2).to(dev), normalized=True),
+                                                           method="linear", normalize_noise=None, normalize_result=None, noise=_chain(N, ("gaussian", 1.0))),
+                                             _latent(t, (2, 4, 13, 17), 7, 3.0)),
+    "guided_euler_odd": lambda N, P, U, t, dev: (N.GuidedNoise(0.7, guidance_factor=-0.3, ref_latent=U.scale_noise(_latent(t, (2, 3, 20, 12), 8, 0.8, 0.2).to(dev), normalized=True),
+                                                          method="euler", normalize_noise=None, normalize_result=None, noise=None), _latent(t, (2, 3, 10, 14), 9, 3.0)),
+    "wavelet_noise_odd": lambda N, P, U, t, dev: (N.AdvancedWaveletNoise(1.0, custom_noise=None, normalize_noise=False, normalize=None, update_blend_function=t.lerp,
+                                                                   **WAVELET_KW), t.zeros(1, 3, 30, 22)),
+    "wavelet_noise_custom": lambda N, P, U, t, dev: (N.AdvancedWaveletNoise(1.0, custom_noise=_chain(N, ("uniform", 1.0)), normalize_noise=True, normalize=None,
+                                                                      update_blend_function=t.lerp, **WAVELET_KW), t.zeros(2, 4, 18, 26)),
+    "power_filter_noise_odd": lambda N, P, U, t, dev: (P.PowerFilterNoiseItem(1.0, noise=_chain(N, ("gaussian", 1.0)), normalize_noise=None, normalize_result=None,
+                                                                        time_brownian=True, power_filter=P.PowerFilter(alpha=1.0, max_freq=0.5),
+                                                                        filter_norm_factor=1.0, mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1"),
+                                                  t.zeros(2, 4, 15, 21)),
+    "power_filter_noise_mixed": lambda N, P, U, t, dev: (P.PowerFilterNoiseItem(0.8, noise=_chain(N, ("uniform", 1.0), ("perlin", 0.5)), normalize_noise=None,
+                                                                          normalize_result=None, time_brownian=True,
+                                                                          power_filter=P.PowerFilter(alpha=-0.5, min_freq=0.1, max_freq=0.7071, rotate=20.0, stretch=1.5),
+                                                                          filter_norm_factor=1.0, mix=0.7, common_mode=0.25, channel_correlation="1,0.5,0.2,1,0.3,0.1"),
+                                                    t.zeros(1, 4, 24, 40)),
+    "power_noise_odd": lambda N, P, U, t, dev: (P.PowerNoiseItem(1.0, time_brownian=False, alpha=1.5, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
+                                                            mix=1.0, common_mode=0.0, channel_correlation="1,1,1,1,1,1"), t.zeros(2, 4, 17, 33)),
+}
+ADVANCED_SEEDS = {name: 200 + k for k, name in enumerate(sorted(ADVANCED))}
+
+
+def run_advanced(noise_mod, powernoise_mod, utils_mod, name, device):
+    import torch
+
+    item, x = ADVANCED[name](noise_mod, powernoise_mod, utils_mod, torch, device)
+    seed = ADVANCED_SEEDS[name]
+    for attr in ("ref_latent", "ref_latent_opt"):  # reference latents travel with the item
+        v = getattr(item, attr, None)
+        if torch.is_tensor(v):
+            setattr(item, attr, v.to(device))
+    torch.manual_seed(seed)
+    ns = item.make_noise_sampler(x.to(device), 0.03, 14.6, seed=seed, cpu=True, normalized=True)
+    return [ns(torch.tensor(s), torch.tensor(sn)) for s, sn in SIGMAS[:2]]

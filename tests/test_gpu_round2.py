@@ -97,6 +97,19 @@ def test_samplers_on_odd_shapes(api, golden, name):
         torch.testing.assert_close(t.cpu(), want[i], rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("name", sorted(_sc.ADVANCED))
+def test_advanced_items_on_odd_shapes(api, golden, name):
+    """ModulatedNoise (intensity / frequency), GuidedNoise (reference latent resized by non-integer ratios), AdvancedWaveletNoise,
+    PowerFilterNoiseItem and PowerNoiseItem on odd planes (spectral work through the direct DFT passes) against the reference's outputs
+    (tests/golden/make_golden.py gen_advanced_sweep).  FFT / resampler chains in fp32: 4e-5 of the output's peak."""
+    want = golden("advanced_sweep")[name]
+    outs = _sc.run_advanced(api.noise, api.powernoise, api.utils, name, "cuda")
+    assert len(outs) == want.shape[0]
+    for got, w in zip(outs, want):
+        assert got.is_cuda and tuple(got.shape) == tuple(w.shape)
+        torch.testing.assert_close(got.cpu(), w, rtol=4e-5, atol=4e-5 * max(1.0, float(w.abs().max())))
+
+
 # ------------------------------------------------------------------------------------------------ row U: every F.interpolate mode of scale_samples
 def test_scale_samples_every_mode(api, golden):
     """py/utils.py:58-67 against the reference's outputs: bilinear, nearest-exact, nearest, area, bicubic, adaptive_avg_pool2d; enlarging,
