@@ -590,6 +590,17 @@ def _per_latent(t: torch.Tensor, sigma: torch.Tensor, *, divide: bool) -> torch.
     return hip_lib.row_affine(0 if divide else 1, utils.as_f32(t).contiguous(), rows, t.numel() // max(rows, 1), zero, s)
 
 
+def _check_broadcast(a: tuple, b: tuple) -> None:
+    """torch's refusal to broadcast two shapes, with its message (the first mismatch counted from the trailing dimension)."""
+    n = max(len(a), len(b))
+    pa, pb = (1,) * (n - len(a)) + a, (1,) * (n - len(b)) + b
+    for d in range(n - 1, -1, -1):
+        if pa[d] != pb[d] and pa[d] != 1 and pb[d] != 1:
+            raise RuntimeError(f"The size of tensor a ({pa[d]}) must match the size of tensor b ({pb[d]}) at non-singleton dimension {d}")
+    if pa != pb:
+        raise hip_lib.SonarHipError(f"WaveletCFG: blending {a} with {b} needs broadcasting, which the HIP blend kernels do not do")
+
+
 def _reconstructs(w) -> bool:
     """IDWT(DWT(t)) == t needs the analysis and synthesis banks of ONE wavelet (dmey is only approximately a wavelet); every pywt
     extension mode reconstructs, also with a different mode on the way back (the valid region never sees the extension)."""
@@ -873,7 +884,9 @@ class WaveletCFG:
                 normal = hip_lib.blend("subtract_b", utils.as_f32(ctx.x), utils.as_f32(normal), 1.0)
             elif rule.target_mode == WCFGTarget.NOISE_NORM:
                 normal = _per_latent(normal, ctx.sigma, divide=True)
-            crop = tuple(slice(None, sz) for sz in normal.shape)
-            result = utils.BLENDING_MODES[rule.blend_mode](normal, result[crop].contiguous(), wcfg_blend)
+            # the reference blends BEFORE it crops (:825-836): a reconstruction larger than the latent (odd sizes) or of another rank
+            # (flattened video / 1-D latents) does not broadcast against the fallback result, and torch says so
+            _check_broadcast(tuple(normal.shape), tuple(result.shape))
+            result = utils.BLENDING_MODES[rule.blend_mode](normal, result.contiguous(), wcfg_blend)
         result = self.process_output(result=result, ctx=ctx, rule=rule)
         return self.maybe_op(result, self.operation_result, **ctx.op_kwargs).contiguous()

@@ -297,6 +297,12 @@ def wavelet_cfg_call(args, *, target="denoised", high_precision=True, use_1d=Fal
             normal = x - normal
         elif target == "noise_norm":
             normal = normal / sigma
+        # blended before the crop (:825-836): torch refuses shapes that do not broadcast, first mismatch counted from the trailing dimension
+        n = max(normal.ndim, result.ndim)
+        pa, pb = (1,) * (n - normal.ndim) + normal.shape, (1,) * (n - result.ndim) + result.shape
+        for d in range(n - 1, -1, -1):
+            if pa[d] != pb[d] and pa[d] != 1 and pb[d] != 1:
+                raise RuntimeError(f"The size of tensor a ({pa[d]}) must match the size of tensor b ({pb[d]}) at non-singleton dimension {d}")
         result = BLENDS[blend_mode](normal, result, np.float32(wcfg_blend)).astype(np.float32)
     if use_1d:
         result = result[..., : cond.shape[2]].reshape(x.shape)

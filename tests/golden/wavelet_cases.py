@@ -217,6 +217,9 @@ WCFG_ERRORS = {
     "three_d_needs_1d": dict(shape=(2, 4, 480), sigma=7.0, params=PLACEHOLDER),
     "two_d": dict(shape=(4, 480), sigma=7.0, params=PLACEHOLDER),
     "no_sample_sigmas": dict(shape=(1, 4, 16, 16), sigma=7.0, params=PLACEHOLDER, sample_sigmas=None),
+    # odd latent sizes reconstruct one sample larger (17 x 23 -> 18 x 24); the plain path crops in process_output, but a blend with the
+    # fallback CFG (py/wavelet_cfg.py:825-836) meets the uncropped reconstruction first and torch refuses to broadcast
+    "odd_size_blend": dict(shape=(2, 4, 17, 23), sigma=7.0, params=dict(PLACEHOLDER, blend_strength=0.5)),
 }
 
 
