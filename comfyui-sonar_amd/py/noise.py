@@ -113,6 +113,23 @@ class CustomNoiseItem(CustomNoiseItemBase):
         return lambda sigma, sigma_next: ns(fallback(o_sigma, sigma), fallback(o_sigma_next, sigma_next))
 
 
+def _for_latent_dtype(x: Tensor, build: Callable) -> Callable:
+    """The reference draws noise in the latent's dtype (``torch.randn(..., dtype=x.dtype)``); the kernels here compute in fp32.  A half /
+    bfloat16 latent gets a sampler built for its fp32 image whose output is rounded to the latent's dtype once, at the end -- every value is
+    the fp32 value correctly rounded, where the reference rounds after every operation."""
+    if not torch.is_tensor(x) or x.dtype not in (torch.float16, torch.bfloat16):
+        return build(x)
+    inner = build(x.to(torch.float32))
+    dtype = x.dtype
+
+    def noise_sampler(sigma, sigma_next):
+        out = inner(sigma, sigma_next)
+        utils.pop_stats(out)
+        return out.to(dtype)
+
+    return noise_sampler
+
+
 class CustomNoiseChain:
     """py/noise.py:137-196."""
 
@@ -142,6 +159,8 @@ class CustomNoiseChain:
 
     @torch.no_grad()
     def make_noise_sampler(self, x: Tensor, sigma_min=None, sigma_max=None, seed=None, cpu=True, normalized=True) -> Callable:
+        if torch.is_tensor(x) and x.dtype in (torch.float16, torch.bfloat16):
+            return _for_latent_dtype(x, lambda x32: self.make_noise_sampler(x32, sigma_min, sigma_max, seed=seed, cpu=cpu, normalized=normalized))
         samplers = tuple(i.make_noise_sampler(x, sigma_min, sigma_max, seed=seed, cpu=cpu, normalized=False) for i in self.items)
         if not samplers or not all(samplers):
             raise ValueError("Failed to get noise sampler")
@@ -1100,4 +1119,4 @@ def get_noise_sampler(noise_type, x: Tensor, sigma_min, sigma_max, seed=None, cp
     factory = NOISE_SAMPLERS.get(noise_type)
     if factory is None:
         raise ValueError("Unknown noise sampler")
-    return factory(x, sigma_min, sigma_max, seed=seed, cpu=cpu, factor=factor, normalized=normalized, **kwargs)
+    return _for_latent_dtype(x, lambda x32: factory(x32, sigma_min, sigma_max, seed=seed, cpu=cpu, factor=factor, normalized=normalized, **kwargs))

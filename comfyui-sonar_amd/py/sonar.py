@@ -386,11 +386,12 @@ class SonarSampler(SonarWithGuidance):
 
     @classmethod
     def _run(cls, sonar, x, sigmas, callback, disable):
+        dtype = x.dtype  # a half / bfloat16 latent is carried in fp32 between the steps and handed back in its own dtype
         for i in trange(len(sigmas) - 1, disable=disable):
             x, sigma, sigma_hat, denoised = sonar.step(i, x)
             if callback is not None:
                 callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigma_hat, "denoised": denoised})
-        return x
+        return x if x.dtype == dtype else x.to(dtype)
 
 
 class SonarEuler(SonarSampler):

@@ -110,6 +110,54 @@ def test_advanced_items_on_odd_shapes(api, golden, name):
         torch.testing.assert_close(got.cpu(), w, rtol=4e-5, atol=4e-5 * max(1.0, float(w.abs().max())))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_precision_and_strided_latents(api, dtype):
+    """The reference draws and steps in the latent's dtype and takes any strides.  Here a half / bfloat16 latent gets fp32 noise rounded once
+    (chains, registry samplers, generate and replay mode) and samplers that carry fp32 between the steps and return the latent's dtype;
+    channels-last, transposed and sliced latents give the result of their contiguous copies."""
+    N, S = api.noise, api.sonar
+    g = torch.Generator().manual_seed(1)
+    x32 = (torch.randn(2, 4, 16, 24, generator=g) * 10).cuda()
+    big = torch.zeros(2, 4, 32, 27, device="cuda", dtype=dtype)
+    big[:, :, ::2, 1:-2] = x32.to(dtype)
+    layouts = {"contiguous": x32.to(dtype), "channels_last": x32.to(dtype).contiguous(memory_format=torch.channels_last),
+               "transposed": x32.to(dtype).transpose(2, 3).contiguous().transpose(2, 3), "sliced": big[:, :, ::2, 1:-2]}
+    sigmas = torch.cat((torch.linspace(14.6, 0.03, 5), torch.zeros(1)))
+    model = lambda x, sigma, **_k: x * 0.5  # noqa: E731
+    for name in ("gaussian", "perlin", "brownian", "onef_pinkish"):
+        for cpu in (True, False):
+            if name == "brownian" and cpu:
+                continue
+            torch.manual_seed(5)
+            want = N.get_noise_sampler(name, x32, 0.03, 14.6, seed=5, cpu=cpu, normalized=True)(torch.tensor(10.0), torch.tensor(7.0))
+            for tag, xv in layouts.items():
+                torch.manual_seed(5)
+                got = N.get_noise_sampler(name, xv, 0.03, 14.6, seed=5, cpu=cpu, normalized=True)(torch.tensor(10.0), torch.tensor(7.0))
+                assert got.dtype == dtype and tuple(got.shape) == tuple(xv.shape)
+                assert torch.equal(got, want.to(dtype)), (name, cpu, tag)
+    chain = N.CustomNoiseChain()
+    chain.add(N.CustomNoiseItem(0.5, noise_type="perlin"))
+    chain.add(N.CustomNoiseItem(0.5, noise_type="pyramid"))
+    torch.manual_seed(6)
+    want = chain.make_noise_sampler(x32, 0.03, 14.6, seed=6, cpu=False, normalized=True)(torch.tensor(10.0), torch.tensor(7.0))
+    torch.manual_seed(6)
+    got = chain.make_noise_sampler(layouts["sliced"], 0.03, 14.6, seed=6, cpu=False, normalized=True)(torch.tensor(10.0), torch.tensor(7.0))
+    assert got.dtype == dtype and torch.equal(got, want.to(dtype))
+    for kind in ("euler", "ancestral", "dpmpp"):
+        outs = {}
+        for tag, xv in layouts.items():
+            torch.manual_seed(3)
+            ns = N.get_noise_sampler("gaussian", xv, 0.03, 14.6, seed=3, cpu=True, normalized=True)
+            if kind == "euler":
+                outs[tag] = S.SonarEuler.sampler(model, xv, sigmas, {"seed": 3}, None, True, ns, None, {})
+            elif kind == "ancestral":
+                outs[tag] = S.SonarEulerAncestral.sampler(model, xv, sigmas, {"seed": 3}, None, True, None, {}, 0.8, 1.1, ns)
+            else:
+                outs[tag] = S.SonarDPMPPSDE.sampler(model, xv, sigmas, {"seed": 3}, None, True, None, {}, 0.9, 1.05, ns)
+            assert outs[tag].dtype == dtype and bool(torch.isfinite(outs[tag]).all())
+            assert torch.equal(outs[tag], outs["contiguous"]), (kind, tag)
+
+
 # ------------------------------------------------------------------------------------------------ row U: every F.interpolate mode of scale_samples
 def test_scale_samples_every_mode(api, golden):
     """py/utils.py:58-67 against the reference's outputs: bilinear, nearest-exact, nearest, area, bicubic, adaptive_avg_pool2d; enlarging,
