@@ -1094,7 +1094,7 @@ extern "C" int sonar_scale_noise_stats_f32(float* x, int64_t n, float factor, fl
 
 extern "C" int sonar_std_scale_f32(float* x, int64_t n, float mul, const double* partials, int64_t npart, int64_t n_total,
                                    void* stream) {
-    SONAR_REQUIRE(x && partials && n >= 0 && npart > 0 && n_total > 1, SONAR_ERR_ARG, "sonar_std_scale_f32: bad argument");
+    SONAR_REQUIRE(x && partials && n >= 0 && npart > 0 && n_total >= 1, SONAR_ERR_ARG, "sonar_std_scale_f32: bad argument");  // one element: its std is NaN, as in torch
     if (n == 0) return SONAR_OK;
     hipStream_t st = (hipStream_t)stream;
     if (aligned16(x))

@@ -1038,6 +1038,33 @@ def gen_shape_sweep():
     save("shape_sweep", meta_json=json.dumps(meta), **cases)
 
 
+TINY_SHAPES = [(1, 1, 1, 1), (1, 4, 2, 2), (2, 3, 1, 5), (2, 4, 3, 3), (1, 4, 1, 2, 2)]
+
+
+def gen_tiny_sweep():
+    """The same registry types on degenerate latents: single pixels, 1-pixel rows, 2 x 2 and 3 x 3 planes.  Outputs where the reference
+    produces one, its error type where it refuses.  (Empty batches are not part of the path: ComfyUI never samples one.)"""
+    import json
+
+    cases, meta = {}, {}
+    for nt in NT:
+        if nt.name in SWEEP_SKIP:
+            continue
+        for k, shape in enumerate(TINY_SHAPES):
+            key = f"{nt.name.lower()}__{k}"
+            seed, normalized = 500 + k, bool(k % 2)
+            try:
+                out = ref_noise(nt, shape, seed, normalized)
+                cases[key] = out
+                meta[key] = dict(type=nt.name.lower(), shape=list(shape), seed=seed, normalized=normalized, error=None)
+            except Exception as exc:  # noqa: BLE001
+                meta[key] = dict(type=nt.name.lower(), shape=list(shape), seed=seed, normalized=normalized, error=type(exc).__name__,
+                                 message=str(exc)[:160])
+    ok = sum(1 for m in meta.values() if m["error"] is None)
+    print(f"tiny sweep: {ok} outputs, {len(meta) - ok} refusals")
+    save("tiny_sweep", meta_json=json.dumps(meta), **cases)
+
+
 def gen_wrapper_sweep():
     """Noise-item wrappers (py/noise.py: Random / Repeated / Channel / RippleFiltered / PerDim / Scheduled / Blended) over inner chains,
     on odd shapes and a 5-D video latent, several calls each: tests/golden/sweep_cases.py holds the specs both sides build from."""
@@ -1105,6 +1132,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_cfg_exact()
     gen_resample_modes()
     gen_shape_sweep()
+    gen_tiny_sweep()
     gen_wrapper_sweep()
     gen_sampler_sweep()
     gen_advanced_sweep()

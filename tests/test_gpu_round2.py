@@ -158,6 +158,34 @@ def test_half_precision_and_strided_latents(api, dtype):
             assert torch.equal(outs[tag], outs["contiguous"]), (kind, tag)
 
 
+def _tiny_cases():
+    import json
+    import numpy as np
+    from tests.conftest import GOLDEN
+
+    g = np.load(f"{GOLDEN}/tiny_sweep.npz", allow_pickle=False)
+    return g, json.loads(str(g["meta_json"]))
+
+
+@pytest.mark.parametrize("key", sorted(_tiny_cases()[1]))
+def test_registry_types_on_degenerate_latents(api, key):
+    """Single pixels, 1-pixel rows and 2 x 2 / 3 x 3 planes through every registry type, replay mode: the reference's
+    output where it has one (NaN where a one-element std is NaN), the reference's refusal where it refuses (same exception type)."""
+    g, meta = _tiny_cases()
+    m = meta[key]
+    shape = tuple(m["shape"])
+    if m["error"] is not None:
+        with pytest.raises(Exception) as exc:
+            replay(api, m["type"], shape, m["seed"], m["normalized"])
+        assert type(exc.value).__name__ == m["error"], (exc.value, m["message"])
+        return
+    want = torch.from_numpy(g[key])
+    got = replay(api, m["type"], shape, m["seed"], m["normalized"])
+    assert got.is_cuda and tuple(got.shape) == tuple(want.shape)
+    peak = float(want[torch.isfinite(want)].abs().max()) if bool(torch.isfinite(want).any()) else 1.0
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-5, atol=2e-5 * max(1.0, peak), equal_nan=True)
+
+
 # ------------------------------------------------------------------------------------------------ row U: every F.interpolate mode of scale_samples
 def test_scale_samples_every_mode(api, golden):
     """py/utils.py:58-67 against the reference's outputs: bilinear, nearest-exact, nearest, area, bicubic, adaptive_avg_pool2d; enlarging,
