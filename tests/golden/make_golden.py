@@ -1102,6 +1102,32 @@ def gen_advanced_sweep():
     save("advanced_sweep", **cases)
 
 
+def gen_node_sweep():
+    """Every node of the registry that returns a noise chain, run with the defaults of its own sockets (node_abi.json) over a gaussian base
+    chain and sampled on an odd latent: tests/golden/sweep_cases.py run_node.  Nodes whose construction or sampling the reference refuses
+    with these inputs are recorded with the exception type."""
+    import json
+    from tests.golden import sweep_cases as sc
+
+    abi = json.load(open(os.path.join(OUT, "node_abi.json")))
+    M = ref.nodes.NODE_CLASS_MAPPINGS
+    cases, meta = {}, {}
+    for key, entry in abi.items():
+        if not entry["returns"] or entry["returns"][0] != "SONAR_CUSTOM_NOISE" or key in sc.NODE_SKIP:
+            continue
+        try:
+            outs = sc.run_node(M, abi, key, "cpu")
+        except Exception as exc:  # noqa: BLE001
+            meta[key] = dict(error=type(exc).__name__, message=str(exc)[:160])
+            continue
+        if outs is None:
+            continue
+        cases[key.replace(" ", "_")] = torch.stack(outs)
+        meta[key] = dict(error=None)
+    print("node sweep:", sum(1 for m in meta.values() if m["error"] is None), "chains,", sum(1 for m in meta.values() if m["error"]), "refusals")
+    save("node_sweep", meta_json=json.dumps(meta), **cases)
+
+
 if __name__ == "__main__" and "--only" in sys.argv:
     globals()["gen_" + sys.argv[sys.argv.index("--only") + 1]]()
     sys.exit(0)
@@ -1136,6 +1162,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_wrapper_sweep()
     gen_sampler_sweep()
     gen_advanced_sweep()
+    gen_node_sweep()
     globals()["gen_node_abi"]()
     gen_entry_nodes()
     print("golden vectors written to", OUT)

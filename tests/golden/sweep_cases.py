@@ -152,3 +152,65 @@ def run_advanced(noise_mod, powernoise_mod, utils_mod, name, device):
     torch.manual_seed(seed)
     ns = item.make_noise_sampler(x.to(device), 0.03, 14.6, seed=seed, cpu=True, normalized=True)
     return [ns(torch.tensor(s), torch.tensor(sn)) for s, sn in SIGMAS[:2]]
+
+
+# node sweep: every node that returns a SONAR_CUSTOM_NOISE chain, built with the defaults of its sockets (tests/golden/node_abi.json, captured from
+# the reference) over a gaussian base chain, then sampled twice in replay mode on an odd latent
+NODE_SHAPE = (2, 4, 10, 14)
+NODE_SKIP = {"SonarBlehOpsNoise", "SonarBlendFilterNoise"}  # integrations with other custom-node packs (not in the image)
+
+
+def node_defaults(abi_entry, provide):
+    kw = {}
+    for name, spec in abi_entry["inputs"].items():
+        t = spec["type"]
+        if isinstance(t, list):
+            kw[name] = spec.get("default", t[0])
+        elif t in ("FLOAT", "INT", "BOOLEAN", "STRING"):
+            if "default" not in spec and t != "STRING":
+                return None
+            kw[name] = spec.get("default", "")  # (yaml_parameters sockets have no default: empty text)
+        elif spec["section"] == "optional":
+            continue
+        elif t in provide:
+            kw[name] = provide[t]()
+        elif t == "*" and "custom_noise" in name:
+            kw[name] = provide["SONAR_CUSTOM_NOISE"]()
+        else:
+            return None
+    return kw
+
+
+def run_node(mappings, abi, key, device):
+    """Outputs of two sampler calls through the chain node ``key`` builds from its default sockets; None when a required socket has no default
+    and no provider here."""
+    import torch
+
+    def base_chain():
+        node = mappings["SonarCustomNoise"]()
+        return getattr(node, abi["SonarCustomNoise"]["function"])(factor=1.0, rescale=0.0, noise_type="gaussian")[0]
+
+    def power_filter():
+        node = mappings["SonarPowerFilter"]()
+        kw = node_defaults(abi["SonarPowerFilter"], {})
+        return getattr(node, abi["SonarPowerFilter"]["function"])(**kw)[0]
+
+    def latent():
+        g = torch.Generator().manual_seed(31)
+        return {"samples": (torch.randn(NODE_SHAPE, generator=g) * 0.8 + 0.2).to(device)}
+
+    def mask():
+        g = torch.Generator().manual_seed(32)
+        return (torch.rand(1, NODE_SHAPE[-2], NODE_SHAPE[-1], generator=g) > 0.5).float()
+
+    provide = {"SONAR_CUSTOM_NOISE": base_chain, "SONAR_POWER_FILTER": power_filter, "LATENT": latent, "MASK": mask}
+    kw = node_defaults(abi[key], provide)
+    if kw is None:
+        return None
+    node = mappings[key]()
+    chain = getattr(node, abi[key]["function"])(**kw)[0]
+    x = torch.zeros(NODE_SHAPE, device=device)
+    seed = 900 + sum(key.encode()) % 97
+    torch.manual_seed(seed)
+    ns = chain.make_noise_sampler(x, 0.03, 14.6, seed=seed, cpu=True, normalized=True)
+    return [ns(torch.tensor(s), torch.tensor(sn)) for s, sn in SIGMAS[:2]]
