@@ -57,14 +57,17 @@ __global__ void __launch_bounds__(kBlock) dft_cols_kernel(const float2* __restri
     build_table(tw, H, inverse ? 1 : -1);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ktiles = (K + 63) / 64;
-    const int64_t units = planes * ktiles;
+    constexpr int kWaves = kBlock / 64;
+    const int ktiles = (K + 63) / 64, nchunks = (H + kWaves - 1) / kWaves;
+    const int64_t units = planes * ktiles * nchunks;  // a workgroup: 64 columns x kWaves output rows of one plane (one row per wave)
     for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
-        const int64_t p = u / ktiles;
-        const int k = (int)(u % ktiles) * 64 + lane;
-        if (k >= K) continue;
+        const int64_t p = u / ((int64_t)ktiles * nchunks);
+        const int rem = (int)(u % ((int64_t)ktiles * nchunks));
+        const int k = (rem / nchunks) * 64 + lane;
+        const int n = (rem % nchunks) * kWaves + wave;
+        if (k >= K || n >= H) continue;
         const float2* src = in + p * (int64_t)H * K + k;
-        for (int n = wave; n < H; n += kBlock / 64) {
+        {
             float re = 0.0f, im = 0.0f;
             int idx = 0;
             for (int m = 0; m < H; ++m) {
@@ -141,8 +144,8 @@ extern "C" int sonar_dft_cols_f32(const float* in, const float* filter, float* o
     SONAR_REQUIRE(in && out && in != out && planes >= 0 && H >= 1 && H <= kDirectMax && K >= 1 && K <= kDirectMax, SONAR_ERR_ARG,
                   "sonar_dft_cols_f32: bad argument (out of place, lines of at most %d)", kDirectMax);
     if (planes == 0) return SONAR_OK;
-    const int64_t units = planes * ((K + 63) / 64);
-    hipLaunchKernelGGL(dft_cols_kernel, dim3((int)std::min<int64_t>(units, 4096)), dim3(kBlock), (size_t)H * sizeof(float2), (hipStream_t)stream,
+    const int64_t units = planes * ((K + 63) / 64) * ((H + kBlock / 64 - 1) / (kBlock / 64));
+    hipLaunchKernelGGL(dft_cols_kernel, dim3((int)std::min<int64_t>(units, 1 << 16)), dim3(kBlock), (size_t)H * sizeof(float2), (hipStream_t)stream,
                        reinterpret_cast<const float2*>(in), filter, reinterpret_cast<float2*>(out), planes, (int)H, (int)K, inverse);
     return check_launch("sonar_dft_cols_f32");
 }
