@@ -10,7 +10,7 @@ pn = importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise")
 ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-KINDS = ["gaussian", "perlin", "pyramid", "brownian", "uniform", "power", "laplacian"]
+KINDS = ["gaussian", "perlin", "pyramid", "brownian", "uniform", "power", "laplacian", "studentt", "onef_pinkish", "pyramid_area", "highres_pyramid", "velvet"]
 bad = 0
 for it in range(iters):
     b, c = rnd.randint(1, 4), rnd.choice([1, 3, 4, 16])
