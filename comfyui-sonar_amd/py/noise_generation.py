@@ -438,6 +438,23 @@ class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):
                                   terms=terms, div_fac=self.div_fac, fresh=fresh, view=(b, c, h, w))
 
 
+def _level_ratios(seed: int, stream: int):
+    """The pyramid levels' shrink ratios r in [2, 4) of a device-mode draw (py/noise_generation.py:628: ``torch.rand(1) * 2 + 2`` per level): a
+    host-side splitmix64 sequence keyed by the call's (seed, stream) -- the same on every rank, no tensor work for a handful of scalars."""
+    state = (seed * 0x9E3779B97F4A7C15 + stream) & 0xFFFFFFFFFFFFFFFF
+
+    def draw() -> float:
+        nonlocal state
+        state = (state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        return (z >> 11) * (2.0 / 9007199254740992.0) + 2.0
+
+    return draw
+
+
 class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
     """py/noise_generation.py:609-649: Gaussian base plus bilinearly upsampled Gaussian levels whose
     sizes shrink by a random ratio r in [2,4) per level (cumulative), weighted discount**i."""
@@ -493,8 +510,7 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
         keys = self.device_key(2 + self.iterations)
         seed, stream = keys
         if w % 4 == 0 and mode in hip_lib.PYRAMID_FUSED_MODES:
-            host = torch.Generator().manual_seed((seed * 0x9E3779B97F4A7C15 + stream) % (2**63))
-            plan = list(self._plan(h, w, lambda: torch.rand(1, generator=host).item() * 2 + 2))
+            plan = list(self._plan(h, w, _level_ratios(seed, stream)))
             if hip_lib.pyramid_generate_acc_(y.view(b, c, h, w), y_mul, x_mul, [(None, ch, cw, self.discount**i) for i, ch, cw in plan], mode,
                                              seed, stream, self.latent_elem_offset(c * h * w), partials, pre=pre):
                 return True
@@ -511,8 +527,7 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
         mode = self.upscale_mode
         b, c, h, w = self.get_adjusted_shape()
         seed, stream = self.device_key(2 + self.iterations) if keys is None else keys
-        host = torch.Generator().manual_seed((seed * 0x9E3779B97F4A7C15 + stream) % (2**63))  # shared by all ranks
-        plan = list(self._plan(h, w, lambda: torch.rand(1, generator=host).item() * 2 + 2))
+        plan = list(self._plan(h, w, _level_ratios(seed, stream)))  # shared by all ranks
         plane_offset = current_batch_offset() * c
         offs = self.latent_elem_offset(c * h * w)
 
