@@ -9,7 +9,10 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 SKIP = {"COLLATZ", "DISTRO", "VORONOI_FUZZ", "VORONOI_MIX", "PYRAMID_BISLERP", "HIGHRES_PYRAMID_BISLERP", "PYRAMID_MIX_BISLERP", "PYRAMID_OLD_BISLERP"}
 types = [t for t in ng.NoiseType if t.name not in SKIP]
-bad = 0
+# normalise INSIDE the generator over the whole batch tensor (py/noise_generation.py:212-249, :680-704): a shard uses its own statistics
+BATCH_NORMALISED = {"ONEF_GREENISH_MIX", "ONEF_PINKISH_MIX", "ONEF_PINKISHGREENISH", "RAINBOW_INTENSE", "RAINBOW_MILD", "PYRAMID_MIX", "PYRAMID_MIX_AREA",
+                    "GREEN_TEST"}
+bad = expected = 0
 for it in range(iters):
     t = rnd.choice(types)
     b = rnd.randint(2, 5)
@@ -40,6 +43,9 @@ for it in range(iters):
         if not bool(torch.isfinite(whole[k]).all()):
             print(f"[{it}] {t.name} {(b, *tail)}: non-finite output", flush=True); bad += 1; break
         if not torch.equal(torch.cat([lo[k], hi[k]]), whole[k]):
+            if t.name in BATCH_NORMALISED:
+                expected += 1
+                break
             d = float((torch.cat([lo[k], hi[k]]) - whole[k]).abs().max())
             print(f"[{it}] {t.name} {(b, *tail)} cut {cut} call {k}: shards != whole, max diff {d:.3e}", flush=True); bad += 1; break
-print(f"{iters} draws, {bad} problems")
+print(f"{iters} draws, {bad} problems ({expected} shard differences of the types that normalise inside the generator over the batch)")

@@ -45,7 +45,10 @@ for it in range(iters):
         if rnd.random() < 0.25 and not one_d:
             params[name] = dict(yl_scale=rnd.choice([1.0, 1.2]), yh_scales=scales(level))
     if rnd.random() < 0.2:
-        params["inv_padding_mode"] = rnd.choice(MODES)
+        # (periodization and the other modes produce bands of different lengths: mixing them between analysis and synthesis has no defined
+        # result -- the numpy checker refuses, pytorch_wavelets is not here to say what the reference does)
+        per = params["padding_mode"] == "periodization"
+        params["inv_padding_mode"] = rnd.choice([m for m in MODES if (m == "periodization") == per])
     if rnd.random() < 0.2:
         params.update(start_sigma=rnd.choice([14.0, 8.0]), end_sigma=rnd.choice([5.0, 1.0]))
     sigma = rnd.choice([7.0, 3.0, 9.5, [6.0, 2.0, 4.0][: shape[0]]])
