@@ -372,6 +372,81 @@ __global__ void __launch_bounds__(kBlock) minmax_rescale_kernel(const float* __r
     }
 }
 
+// normalize_to_scale_adv (py/utils.py:473-510): the negative and the positive values of a row are rescaled separately, each between its
+// own extremes.  Pass 1: per row (min, max) over the negatives and over the positives (+-inf where a sign has no value).
+__global__ void __launch_bounds__(kBlock) signed_minmax_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner, float4* __restrict__ out) {
+    __shared__ float red[4][kBlock / 64];
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        float nlo = INFINITY, nhi = -INFINITY, plo = INFINITY, phi = -INFINITY;
+        const float* row = x + r * inner;
+        for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
+            const float v = row[i];
+            if (v < 0.0f) {
+                nlo = fminf(nlo, v);
+                nhi = fmaxf(nhi, v);
+            } else if (v > 0.0f) {
+                plo = fminf(plo, v);
+                phi = fmaxf(phi, v);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            nlo = fminf(nlo, __shfl_xor(nlo, off));
+            nhi = fmaxf(nhi, __shfl_xor(nhi, off));
+            plo = fminf(plo, __shfl_xor(plo, off));
+            phi = fmaxf(phi, __shfl_xor(phi, off));
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            red[0][w] = nlo; red[1][w] = nhi; red[2][w] = plo; red[3][w] = phi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kBlock / 64; ++w) {
+                nlo = fminf(nlo, red[0][w]);
+                nhi = fmaxf(nhi, red[1][w]);
+                plo = fminf(plo, red[2][w]);
+                phi = fmaxf(phi, red[3][w]);
+            }
+            out[r] = make_float4(nlo, nhi, plo, phi);
+        }
+    }
+}
+
+// Pass 2: x < 0 -> normalize_to_scale over the negatives to [min_neg, max_neg] (max_neg >= 0: the row's own largest negative), x > 0 ->
+// over the positives to [min_pos, max_pos] (min_pos < 0: the row's own smallest positive), 0 stays 0; a skipped sign is copied.  Each
+// step rounded on its own, as the reference's in-place tensor ops are (the same sequence as minmax_rescale_kernel).
+__global__ void __launch_bounds__(kBlock) signed_rescale_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
+                                                                 const float4* __restrict__ stats, double min_neg, double max_neg, double min_pos,
+                                                                 double max_pos, int skip_neg, int skip_pos, float eps, float* __restrict__ out) {
+    const int64_t total = rows * inner;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const float4 st = stats[i / inner];
+        const float v = x[i];
+        float res = 0.0f;
+        if (v < 0.0f || v > 0.0f) {
+            const bool neg = v < 0.0f;
+            if (neg ? skip_neg : skip_pos) {
+                res = v;
+            } else {
+                const float lo = neg ? st.x : st.z, hi = neg ? st.y : st.w;
+                // the targets are Python floats in the reference (the data-derived ones `.item()` of an fp32 value): their difference is
+                // formed in double and meets the fp32 tensor as one rounded scalar; add_ / clamp_ round each bound on its own
+                const double tmin_d = neg ? min_neg : (min_pos < 0.0 ? (double)st.z : min_pos);
+                const double tmax_d = neg ? (max_neg >= 0.0 ? (double)st.y : max_neg) : max_pos;
+                const float span = (float)(tmax_d - tmin_d), tmin = (float)tmin_d, tmax = (float)tmax_d;
+                const float denom = __fadd_rn(__fsub_rn(hi, lo), eps);
+                float q = __fsub_rn(v, lo) / denom;
+                q = __fadd_rn(__fmul_rn(q, span), tmin);
+                res = q != q ? q : fminf(fmaxf(q, tmin), tmax);
+            }
+        } else if (v != v) {
+            res = 0.0f;  // NaN is neither < 0 nor > 0: the reference's masks leave the zero of zeros_like
+        }
+        out[i] = res;
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) amax_mid_kernel(const float* __restrict__ x, int64_t outer, int64_t mid,
                                                            int64_t inner, int use_abs, float* peak) {
     const int64_t total = outer * inner;
@@ -1185,6 +1260,20 @@ extern "C" int sonar_minmax_rescale_f32(const float* x, int64_t rows, int64_t in
     hipLaunchKernelGGL(minmax_rescale_kernel, dim3(grid_for(rows * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x, rows,
                        inner, lo, hi, eps, target_min, target_max, out);
     return check_launch("sonar_minmax_rescale_f32");
+}
+
+extern "C" int sonar_signed_rescale_f32(const float* x, int64_t rows, int64_t inner, double min_neg, double max_neg, double min_pos, double max_pos,
+                                        float eps, float* stats_ws, float* out, void* stream) {
+    SONAR_REQUIRE(x && out && stats_ws && rows >= 0 && inner > 0 && (reinterpret_cast<uintptr_t>(stats_ws) & 15u) == 0, SONAR_ERR_ARG,
+                  "sonar_signed_rescale_f32: bad argument (a 16-byte aligned workspace of 4 floats per row is required)");
+    if (rows == 0) return SONAR_OK;
+    // py/utils.py:482-483
+    const int skip_pos = max_pos <= 0.0 || min_pos >= max_pos, skip_neg = min_neg >= 0.0 || min_neg >= max_neg;
+    float4* st = reinterpret_cast<float4*>(stats_ws);
+    hipLaunchKernelGGL(signed_minmax_rows_kernel, dim3((int)std::min<int64_t>(rows, 4096)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner, st);
+    hipLaunchKernelGGL(signed_rescale_kernel, dim3(grid_for(rows * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner, st,
+                       min_neg, max_neg, min_pos, max_pos, skip_neg, skip_pos, eps, out);
+    return check_launch("sonar_signed_rescale_f32");
 }
 
 extern "C" int sonar_powerlaw_f32(float* x, float alpha, int use_sign, int64_t n, void* stream) {

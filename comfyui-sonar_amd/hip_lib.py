@@ -156,6 +156,7 @@ SIGNATURES = {
     "sonar_perlin_generate_chain_f32": (_I, [_P, _P, _P, _I64, _I64, _F, _U64, _U64, _I64, _P]),
     "sonar_pyramid_generate_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I, _U64, _U64, _I64, _P]),
     "sonar_brownian_bridge_chain_f32": (_I, [_P, _P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _I64, _P]),
+    "sonar_signed_rescale_f32": (_I, [_P, _I64, _I64, _D, _D, _D, _D, _F, _P, _P, _P]),
     "sonar_dft_rows_r2c_f32": (_I, [_P, _P, _I64, _I64, _P]),
     "sonar_dft_cols_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P]),
     "sonar_dft_rows_c2r_f32": (_I, [_P, _P, _I64, _I64, _F, _P, _P]),
@@ -1343,6 +1344,15 @@ def minmax_rescale(x: torch.Tensor, rows: int, inner: int, lo: torch.Tensor, hi:
     out = torch.empty_like(x)
     _check(load().sonar_minmax_rescale_f32(_dev(x, "x"), rows, inner, _dev(lo, "lo"), _dev(hi, "hi"), float(eps), float(target_min),
                                            float(target_max), _dev(out, "out"), _stream()), "sonar_minmax_rescale_f32")
+    return out
+
+
+def signed_rescale(x: torch.Tensor, rows: int, inner: int, min_neg: float, max_neg: float, min_pos: float, max_pos: float, eps: float = 1e-07) -> torch.Tensor:
+    """normalize_to_scale_adv per row of ``inner`` elements (``sonar_signed_rescale_f32``)."""
+    out = torch.empty_like(x)
+    ws = torch.empty(max(rows, 1) * 4, dtype=torch.float32, device=x.device)
+    _check(load().sonar_signed_rescale_f32(_dev(x, "x"), rows, inner, float(min_neg), float(max_neg), float(min_pos), float(max_pos), float(eps),
+                                           _dev(ws, "stats_ws"), _dev(out, "out"), _stream()), "sonar_signed_rescale_f32")
     return out
 
 

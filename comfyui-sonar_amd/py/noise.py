@@ -722,6 +722,71 @@ class RippleFilteredNoise(CustomNoiseItemBase):
         return noise_sampler
 
 
+class NormalizeToScaleNoise(CustomNoiseItemBase):
+    """py/noise.py:1205-1300: the chain's noise rescaled into a value range (simple: min / max over ``dims``; advanced: negatives and
+    positives separately, over the whole tensor or per batch item), then the mean / std adjustments, then the usual scaling."""
+
+    def __init__(self, factor, *, noise, min_negative_value: float, max_negative_value: float, min_positive_value: float, max_positive_value: float,
+                 mode: str, **kwargs):
+        if mode == "simple":
+            if min_negative_value >= max_positive_value:
+                raise ValueError("In simple mode, min_negative_value can't be greater or equal to max_positive_value")
+        elif mode == "advanced":
+            if min_negative_value >= max_negative_value:
+                raise ValueError("In advanced mode, min_negative_value can't be greater or equal to max_negative value")
+            if min_positive_value >= max_positive_value:
+                raise ValueError("In advanced mode, min_positive_value can't be greater or equal to max_positive value")
+        else:
+            raise ValueError("Bad mode")
+        super().__init__(factor, noise=noise.clone(), min_negative_value=min_negative_value, max_negative_value=max_negative_value,
+                         min_positive_value=min_positive_value, max_positive_value=max_positive_value, mode=mode, **kwargs)
+
+    def clone_key(self, k):
+        return self.noise.clone() if k == "noise" else super().clone_key(k)
+
+    @staticmethod
+    def _trailing(noise: Tensor, dims, what: str):
+        """(rows, inner) of a reduction over ``dims``, which must be the trailing dimensions (the node's '-3, -2, -1' and its suffixes)."""
+        nd = noise.ndim
+        want = sorted(d % nd for d in dims) if len(dims) else list(range(nd))
+        if want != list(range(nd - len(want), nd)):
+            raise hip_lib.SonarHipError(f"NormalizeToScaleNoise: {what} must be the trailing dimensions on the HIP path (got {tuple(dims)})")
+        inner = math.prod(noise.shape[nd - len(want):])
+        return noise.numel() // max(inner, 1), inner
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        std_dims, std_multiplier = self.std_dims, self.std_multiplier
+        mean_dims, mean_multiplier = self.mean_dims, self.mean_multiplier
+        factor, mode = self.factor, self.mode
+        ns = self.noise.make_noise_sampler(x, *args, normalized=self.normalize_noise, **kwargs)
+        normalize = self.get_normalize("normalize", normalized)
+
+        def noise_sampler(s, sn):
+            noise = ns(s, sn)
+            pop_stats(noise)
+            noise = utils.as_f32(noise).contiguous()
+            if mode == "simple":
+                noise = utils.normalize_to_scale(noise, self.min_negative_value, self.max_positive_value, dim=self.dims)
+            else:
+                # whole tensor (no dims, or fewer than two dimensions) or one batch item at a time (:1282-1286): rows of the same kernel
+                rows = 1 if (noise.ndim < 2 or not self.dims) else noise.shape[0]
+                noise = hip_lib.signed_rescale(noise, rows, noise.numel() // max(rows, 1), self.min_negative_value, self.max_negative_value,
+                                               self.min_positive_value, self.max_positive_value)
+            if mean_multiplier != 0:
+                rows, inner = self._trailing(noise, mean_dims, "mean_dims")
+                mean, _ = hip_lib.rowstats(noise, rows, inner)
+                noise = hip_lib.row_affine(0, noise, rows, inner, mean * mean_multiplier, torch.ones_like(mean))  # (x - m k) / 1
+            if std_multiplier != 0:
+                rows, inner = self._trailing(noise, std_dims, "std_dims")
+                _, std = hip_lib.rowstats(noise, rows, inner)
+                adj = (std - 1.0) * std_multiplier + 1.0
+                adj = torch.where(adj == 0, torch.full_like(adj, 1e-07), adj)
+                noise = hip_lib.row_affine(0, noise, rows, inner, torch.zeros_like(adj), adj)
+            return scale_noise(noise, factor, normalized=normalize)
+
+        return noise_sampler
+
+
 class PerDimNoise(CustomNoiseItemBase):
     """py/noise.py:1822-1893: noise assembled along one dimension from separate calls of the chain (slices / concatenation only)."""
 

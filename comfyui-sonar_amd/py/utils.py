@@ -147,6 +147,14 @@ def normalize_to_scale(latent: Tensor, target_min: float, target_max: float, *, 
     return hip_lib.minmax_rescale(x, rows, inner, lo, hi, eps, target_min, target_max)
 
 
+def normalize_to_scale_adv(t: Tensor, *, min_pos: float, max_pos: float, min_neg: float, max_neg: float, dim=(-3, -2, -1)) -> Tensor:
+    """py/utils.py:473-510: negatives and positives rescaled separately between their own extremes.  The reference selects the values of a sign
+    into a 1-D tensor first, so whatever ``dim`` says the extremes are those of the WHOLE tensor passed in: one row."""
+    _require_device(t, "normalize_to_scale_adv")
+    x = as_f32(t).contiguous()
+    return hip_lib.signed_rescale(x, 1, x.numel(), min_neg, max_neg, min_pos, max_pos)
+
+
 def tensor_to(tensor: Tensor, dest) -> Tensor:
     """py/utils.py:112-121."""
     device = dest.device if isinstance(dest, Tensor) else dest

@@ -500,6 +500,12 @@ int sonar_dtcwt_q2c_f32(const float* lh, const float* hh, const float* hl, float
 int sonar_dtcwt_c2q_f32(const float* bands, float* lh, float* hh, float* hl, int64_t planes, int64_t h, int64_t w, void* stream);
 int sonar_dtcwt_q2c_f64(const double* lh, const double* hh, const double* hl, double* bands, int64_t planes, int64_t h, int64_t w, void* stream);
 int sonar_dtcwt_c2q_f64(const double* bands, double* lh, double* hh, double* hl, int64_t planes, int64_t h, int64_t w, void* stream);
+/* normalize_to_scale_adv (py/utils.py:473-510; NormalizeToScaleNoise's advanced mode, py/noise.py:1262-1286): per row of `inner` elements the
+ * negative values are rescaled between their own extremes to [min_neg, max_neg] (max_neg >= 0: the row's largest negative value) and the
+ * positive ones to [min_pos, max_pos] (min_pos < 0: the row's smallest positive value); zeros stay, a sign whose range is degenerate
+ * (:482-483) is copied.  stats_ws: 4 floats per row, 16-byte aligned.  Two launches. */
+int sonar_signed_rescale_f32(const float* x, int64_t rows, int64_t inner, double min_neg, double max_neg, double min_pos, double max_pos, float eps,
+                             float* stats_ws, float* out, void* stream);
 /* Direct real 2-D DFT passes for planes the LDS-resident FFT kernels do not take (odd heights / widths -- 1080-line video gives
  * 135-row latents -- or planes beyond the LDS budget): torch.fft.rfft2 / irfft2 (py/nodes/powernoise.py:338-408,
  * py/noise_generation.py:680-759, py/nodes/freeu_extreme.py:10-29) as rows r2c -> columns (optionally x a real filter [H][K] on the

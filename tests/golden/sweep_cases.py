@@ -21,6 +21,24 @@ WRAPPERS = {
     "perdim_dim1": ("PerDimNoise", 0.6, dict(dim=1, shrink_dim=False, chunk_size=1, offset=0, normalize_noise=False, normalize=None), dict(noise=[("gaussian", 1.0)]), 5, 150, 2),
     "perdim_dim2_chunk": ("PerDimNoise", 1.0, dict(dim=2, shrink_dim=False, chunk_size=4, offset=1, normalize_noise=False, normalize=True), dict(noise=[("uniform", 1.0)]), 1, 151, 2),
     "perdim_shrink": ("PerDimNoise", 1.0, dict(dim=1, shrink_dim=True, chunk_size=2, offset=0, normalize_noise=True, normalize=None), dict(noise=[("gaussian", 1.0)]), 4, 152, 2),
+    "to_scale_simple": ("NormalizeToScaleNoise", 1.0, dict(min_negative_value=-4.5, max_negative_value=0.0, min_positive_value=0.0, max_positive_value=4.5,
+                                                          mode="simple", dims=(-3, -2, -1), std_dims=(-3, -2, -1), std_multiplier=1.0, mean_dims=(-3, -2, -1),
+                                                          mean_multiplier=1.0, normalize_noise=False, normalize=None), dict(noise=[("gaussian", 1.0)]), 0, 157, 2),
+    "to_scale_simple_hw": ("NormalizeToScaleNoise", 0.8, dict(min_negative_value=-1.5, max_negative_value=0.0, min_positive_value=0.0, max_positive_value=2.0,
+                                                             mode="simple", dims=(-2, -1), std_dims=(-2, -1), std_multiplier=0.5, mean_dims=(-1,),
+                                                             mean_multiplier=0.25, normalize_noise=True, normalize=True), dict(noise=[("perlin", 1.0)]), 5, 158, 2),
+    "to_scale_simple_plain": ("NormalizeToScaleNoise", 1.0, dict(min_negative_value=0.25, max_negative_value=0.0, min_positive_value=0.0, max_positive_value=0.75,
+                                                                mode="simple", dims=(), std_dims=(), std_multiplier=0.0, mean_dims=(), mean_multiplier=0.0,
+                                                                normalize_noise=False, normalize=False), dict(noise=[("uniform", 1.0)]), 2, 159, 2),
+    "to_scale_adv_global": ("NormalizeToScaleNoise", 1.0, dict(min_negative_value=-3.0, max_negative_value=-0.5, min_positive_value=0.25, max_positive_value=2.0,
+                                                              mode="advanced", dims=(), std_dims=(), std_multiplier=0.0, mean_dims=(), mean_multiplier=0.0,
+                                                              normalize_noise=False, normalize=False), dict(noise=[("gaussian", 1.0)]), 1, 160, 2),
+    "to_scale_adv_auto": ("NormalizeToScaleNoise", 1.0, dict(min_negative_value=-4.3, max_negative_value=0.0, min_positive_value=-1.0, max_positive_value=3.7,
+                                                            mode="advanced", dims=(-3, -2, -1), std_dims=(-3, -2, -1), std_multiplier=1.0, mean_dims=(-3, -2, -1),
+                                                            mean_multiplier=1.0, normalize_noise=False, normalize=None), dict(noise=[("gaussian", 1.0)]), 5, 161, 2),
+    "to_scale_adv_skip_neg": ("NormalizeToScaleNoise", 0.9, dict(min_negative_value=0.5, max_negative_value=1.0, min_positive_value=0.1, max_positive_value=1.2,
+                                                                mode="advanced", dims=(-3, -2, -1), std_dims=(), std_multiplier=0.0, mean_dims=(), mean_multiplier=0.0,
+                                                                normalize_noise=False, normalize=None), dict(noise=[("laplacian", 1.0)]), 0, 162, 2),
     "scheduled": ("ScheduledNoise", 1.0, dict(start_sigma=10.0, end_sigma=5.0, normalize=True),
                   dict(noise=[("perlin", 1.0), ("gaussian", 0.5)], fallback_noise=[("uniform", 1.0)]), 0, 153, 3),
     "scheduled_video": ("ScheduledNoise", 0.8, dict(start_sigma=20.0, end_sigma=4.0, normalize=None),
