@@ -722,6 +722,75 @@ class RippleFilteredNoise(CustomNoiseItemBase):
         return noise_sampler
 
 
+class ResizedNoise(CustomNoiseItemBase):
+    """py/noise.py:1410-1519: the inner chain runs at another latent size (a crop or a rescaled copy of x as its reference) and its noise is
+    cropped / rescaled back -- ``scale_samples`` (the HIP resampler) and window indexing only."""
+
+    def __init__(self, factor, *, custom_noise, **kwargs):
+        if len(custom_noise.items) == 0:
+            raise ValueError("ResizedNoise requires at least one noise item")
+        super().__init__(factor, custom_noise=custom_noise.clone(), **kwargs)
+
+    def clone_key(self, k):
+        return self.custom_noise.clone() if k == "custom_noise" else super().clone_key(k)
+
+    def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
+        if x.ndim < 3:
+            raise ValueError("ResizedNoise can only handle 3+ dimensional latents")
+        factor = self.factor
+        normalize = self.get_normalize("normalize", normalized)
+        spatial_compression, spatial_mode = self.spatial_compression, self.spatial_mode
+        width, height = self.width, self.height
+        xh, xw = x.shape[-2:]
+        if spatial_mode != "percentage":
+            height //= spatial_compression
+            width //= spatial_compression
+        if spatial_mode == "absolute":
+            nh, nw = int(height), int(width)
+        elif spatial_mode == "relative":
+            nh, nw = int(xh + height), int(xw + width)
+        elif spatial_mode == "percentage":
+            nh, nw = max(1, int(xh * height)), max(1, int(xw * width))
+        else:
+            raise ValueError("Bad spatial_mode")
+        offsh = self.crop_offset_vertical // spatial_compression
+        offsw = self.crop_offset_horizontal // spatial_compression
+        if xh == nh and xw == nw:
+            ns = self.custom_noise.make_noise_sampler(x, *args, normalized=normalize, **kwargs)
+
+            def same_size(*a, **k):
+                return scale_noise(ns(*a, **k), factor, normalized=False)  # .mul_(factor)
+
+            return same_size
+        upscale_mode, downscale_mode, crop_mode = self.upscale_mode, self.downscale_mode, self.crop_mode
+        x_all_bigger = xh >= nh and xw >= nw
+        x_any_bigger = xh >= nh or xw >= nw
+        crop_back = partial(utils.crop_samples, width=xw, height=xh, mode=crop_mode, offset_width=offsw, offset_height=offsh)
+        if x_all_bigger:
+            if self.initial_reference == "prefer_crop":
+                x = utils.crop_samples(x, nw, nh, mode=crop_mode, offset_width=offsw, offset_height=offsh).contiguous()
+            else:
+                x = utils.scale_samples(x, nw, nh, mode=downscale_mode)
+            output = partial(utils.scale_samples, width=xw, height=xh, mode=upscale_mode)
+        else:
+            x = utils.scale_samples(x, nw, nh, mode=upscale_mode)
+            if x_any_bigger:
+                output = partial(utils.scale_samples, width=xw, height=xh, mode=upscale_mode)
+            elif self.downscale_strategy == "scale":
+                output = partial(utils.scale_samples, width=xw, height=xh, mode=downscale_mode)
+            else:
+                output = lambda t: crop_back(t).contiguous()  # noqa: E731
+        ns = self.custom_noise.make_noise_sampler(x, *args, normalized=False, **kwargs)
+        del x
+
+        def noise_sampler(*a, **k):
+            noise = scale_noise(ns(*a, **k), factor, normalized=normalize)
+            pop_stats(noise)
+            return output(noise.contiguous())
+
+        return noise_sampler
+
+
 class NormalizeToScaleNoise(CustomNoiseItemBase):
     """py/noise.py:1205-1300: the chain's noise rescaled into a value range (simple: min / max over ``dims``; advanced: negatives and
     positives separately, over the whole tensor or per batch item), then the mean / std adjustments, then the usual scaling."""

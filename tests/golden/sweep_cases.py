@@ -39,6 +39,27 @@ WRAPPERS = {
     "to_scale_adv_skip_neg": ("NormalizeToScaleNoise", 0.9, dict(min_negative_value=0.5, max_negative_value=1.0, min_positive_value=0.1, max_positive_value=1.2,
                                                                 mode="advanced", dims=(-3, -2, -1), std_dims=(), std_multiplier=0.0, mean_dims=(), mean_multiplier=0.0,
                                                                 normalize_noise=False, normalize=None), dict(noise=[("laplacian", 1.0)]), 0, 162, 2),
+    "resized_up_crop": ("ResizedNoise", 1.0, dict(width=192.0, height=160.0, spatial_compression=8, spatial_mode="absolute", downscale_strategy="crop",
+                                                  initial_reference="prefer_crop", crop_offset_horizontal=16, crop_offset_vertical=-8, crop_mode="top_left",
+                                                  upscale_mode="bilinear", downscale_mode="area", normalize=None), dict(custom_noise=[("gaussian", 1.0)]), 0, 163, 2),
+    "resized_up_scale": ("ResizedNoise", 0.8, dict(width=176.0, height=144.0, spatial_compression=8, spatial_mode="absolute", downscale_strategy="scale",
+                                                   initial_reference="prefer_crop", crop_offset_horizontal=0, crop_offset_vertical=0, crop_mode="center",
+                                                   upscale_mode="nearest-exact", downscale_mode="area", normalize="default"), dict(custom_noise=[("perlin", 1.0)]), 5, 164, 2),
+    "resized_down_crop": ("ResizedNoise", 1.0, dict(width=64.0, height=48.0, spatial_compression=8, spatial_mode="absolute", downscale_strategy="crop",
+                                                    initial_reference="prefer_crop", crop_offset_horizontal=8, crop_offset_vertical=8, crop_mode="bottom_right",
+                                                    upscale_mode="bicubic", downscale_mode="bilinear", normalize=True), dict(custom_noise=[("gaussian", 1.0)]), 5, 165, 2),
+    "resized_down_scale": ("ResizedNoise", 1.0, dict(width=64.0, height=48.0, spatial_compression=8, spatial_mode="absolute", downscale_strategy="scale",
+                                                     initial_reference="prefer_scale", crop_offset_horizontal=0, crop_offset_vertical=0, crop_mode="center",
+                                                     upscale_mode="bilinear", downscale_mode="bilinear", normalize=False), dict(custom_noise=[("uniform", 1.0)]), 5, 166, 2),
+    "resized_mixed": ("ResizedNoise", 1.0, dict(width=-32.0, height=24.0, spatial_compression=8, spatial_mode="relative", downscale_strategy="crop",
+                                                      initial_reference="prefer_crop", crop_offset_horizontal=0, crop_offset_vertical=0, crop_mode="center",
+                                                      upscale_mode="nearest", downscale_mode="nearest-exact", normalize=None), dict(custom_noise=[("gaussian", 1.0)]), 3, 167, 2),
+    "resized_percentage": ("ResizedNoise", 1.0, dict(width=1.5, height=2.25, spatial_compression=8, spatial_mode="percentage", downscale_strategy="crop",
+                                                     initial_reference="prefer_crop", crop_offset_horizontal=24, crop_offset_vertical=0, crop_mode="center_left",
+                                                     upscale_mode="area", downscale_mode="area", normalize=None), dict(custom_noise=[("pyramid", 1.0)]), 1, 168, 2),
+    "resized_same": ("ResizedNoise", 0.6, dict(width=112.0, height=80.0, spatial_compression=8, spatial_mode="absolute", downscale_strategy="crop",
+                                               initial_reference="prefer_crop", crop_offset_horizontal=0, crop_offset_vertical=0, crop_mode="center",
+                                               upscale_mode="bilinear", downscale_mode="bilinear", normalize=None), dict(custom_noise=[("gaussian", 1.0)]), 0, 169, 2),
     "scheduled": ("ScheduledNoise", 1.0, dict(start_sigma=10.0, end_sigma=5.0, normalize=True),
                   dict(noise=[("perlin", 1.0), ("gaussian", 0.5)], fallback_noise=[("uniform", 1.0)]), 0, 153, 3),
     "scheduled_video": ("ScheduledNoise", 0.8, dict(start_sigma=20.0, end_sigma=4.0, normalize=None),
