@@ -34,7 +34,10 @@ import importlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 import types
 
@@ -256,6 +259,39 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
     return kernels, extra
 
 
+def _free_port() -> int:
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes (torch.distributed.run, one per GPU)
+    and relay rank 0's JSON line and the launcher's exit code.  This process never touches the GPU (no HIP call, no library load:
+    `torch.cuda.device_count()` only counts), so starting other programs from it is safe on this pool."""
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("SONAR_BENCH_BACKEND", "nccl") == "nccl":
+        print(f"[bench] --gpus {n} needs {n} GPUs on this node, {have} visible: not measuring fewer GPUs under that label",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in res.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if res.returncode == 0 and line is None:
+        print("[bench] the ranks exited cleanly but printed no result line", file=sys.stderr, flush=True)
+        sys.exit(3)
+    sys.exit(res.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,30 +304,47 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)  # does not return
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SONAR_BENCH_BACKEND", "nccl")  # "gloo": self-test of the N > 1 path with ranks sharing a GPU
+    share_gpu = backend == "gloo" and torch.cuda.device_count() < world
+    device_index = 0 if share_gpu else local_rank
     distributed = world > 1 or bool(os.environ.get("SONAR_BENCH_FORCE_DIST"))  # the env knob runs the RCCL path with one rank (self-test)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device_index)
         # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the one JSON line
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
             # a collective that hangs ends the process after two minutes instead of holding the node
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=120))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=120))
+            else:
+                dist.init_process_group(backend, timeout=datetime.timedelta(seconds=120))
             dist.barrier()
         finally:
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
-    n_gpus = world if distributed else 1
-    if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1", file=sys.stderr)
-    device = torch.device("cuda", local_rank)
+    # the number of GPUs reported is the number of ranks the process group really has, never the flag
+    n_gpus = dist.get_world_size() if distributed else 1
+    if args.gpus != n_gpus:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but the process group has {n_gpus} rank(s): refusing to report a mislabelled figure",
+                  file=sys.stderr, flush=True)
+        if distributed:
+            dist.destroy_process_group()
+        sys.exit(2)
+    device = torch.device("cuda", device_index)
 
     import sonar_pkg
 
@@ -336,19 +389,28 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         span_ms = ev0.elapsed_time(ev1)
+        pair_us_local = span_ms / args.steps * 1e3
+        ranks = None
         if distributed:
             dist.barrier()
-            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = t.item()
+            coll_dev = device if backend == "nccl" else "cpu"
+            t = torch.tensor([elapsed, pair_us_local], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank's wall clock and launch-pair time
+            elapsed, pair_us_max = t[0].item(), t[1].item()
+            ranks = [None] * n_gpus
+            dist.all_gather_object(ranks, {"rank": rank, "device": f"cuda:{device_index}", "device_name": torch.cuda.get_device_name(device_index),
+                                           "shard_start": rank * BATCH, "shard_count": BATCH, "pair_us": pair_us_local})
+        else:
+            pair_us_max = pair_us_local
 
         if rank == 0:
             value = n_gpus * BATCH * args.steps / elapsed
-            pair_us = span_ms / args.steps * 1e3
+            pair_us = pair_us_max  # N > 1: the slowest rank's launch pair; every rank runs the same pair on its own shard
+            peak = HBM_PEAK_GBPS * n_gpus  # the job's roofline: N x 8 TB/s
             # sonar_power_noise_f32 = statistics pass (re-draw of the radius words, Parseval, no stores) + final pass (draw, filter,
             # LDS-resident C2R FFT, normalise, ONE write): 4N bytes per latent really cross HBM (profiles/r02_traffic.json).
-            real_bytes = 4 * N_LATENT * BATCH
-            contract_bytes = 12 * N_LATENT * BATCH
+            real_bytes = 4 * N_LATENT * BATCH * n_gpus  # all ranks' launches together
+            contract_bytes = 12 * N_LATENT * BATCH * n_gpus
             achieved = real_bytes / (pair_us * 1e-6) / 1e9
             tr = traffic_table()
             step_s = elapsed / args.steps
@@ -362,10 +424,10 @@ def main():
                 "roofline": {"bound": "valu", "limiter": "vector-ALU issue + LDS / barrier latency (per-pass timings and counters: profiles/r02_power_kernel.md); "
                                                          "HBM moves 4N per latent and would allow ~21 us per launch",
                              "kernel": "power_stats_kernel<128,128> + power_irfft2_kernel<128,128,GEN,NORM> (one C-ABI call)",
-                             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                             "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                              "traffic": tr.get("power_noise_b512", {}).get("hbm_bytes_per_launch"), "bytes_per_launch": real_bytes,
                              "avg_launch_us": pair_us, "achieved_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9,
-                             "frac_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                             "frac_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9 / peak,
                              "note": "achieved / frac: the 4N bytes the launch pair really moves (one write of the tensor; statistics come from "
                                      "the spectrum by Parseval); *_contract_12N: the same time at SURVEY 8d's 12N for the reference-structured "
                                      "write + read + write"},
@@ -376,22 +438,44 @@ def main():
         kernels, extra = secondary_rows(device, hl, pn, ng, nz, x, sig)
         out["roofline"]["kernels"] = kernels
         out["extra"] = extra
-    if rank == 0:
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and ranks is not None:
+        out["ranks"] = ranks
     if distributed:
-        # optional final gather, outside `value` and AFTER the result line is out (reported on stderr): RCCL all-gather
-        # vs direct peer-to-peer copies over xGMI.  Every rank learns whether all ranks succeeded before the next collective.
+        # optional final gather, outside `value`: RCCL all-gather vs direct peer-to-peer copies over xGMI, reported
+        # under extra.gather.  Every rank learns whether all ranks succeeded before the next collective.  The result line waits for
+        # it, so a watchdog on rank 0 prints the line without the gather figures if a collective hangs (the process group's own
+        # two-minute timeout then ends the ranks).
+        printed = threading.Event()
+        lock = threading.Lock()
+
+        def emit(gather_result):
+            with lock:
+                if printed.is_set():
+                    return
+                out.setdefault("extra", {})["gather"] = gather_result
+                print(json.dumps(out), flush=True)
+                printed.set()
+
+        watchdog = None
+        if rank == 0:
+            watchdog = threading.Timer(90.0, emit, args=({"error": "no answer from the gather collectives within 90 s"},))
+            watchdog.daemon = True
+            watchdog.start()
         par = importlib.import_module("comfyui_sonar_amd.parallel")
+        coll_dev = device if backend == "nccl" else "cpu"
         with ng.shard_offset(rank * BATCH):
             shard = ns(*sig)
-        gather = {}
+        gather = {"backend": dist.get_backend(), "bytes_per_shard": shard.numel() * 4}
         for tag, direct in (("rccl_all_gather", False), ("direct_peer_copies", True)):
             ok, secs = 1.0, 0.0
             try:
-                par.gather_batch(shard, BATCH * world, direct=direct)
+                full = par.gather_batch(shard, BATCH * world, direct=direct)
                 torch.cuda.synchronize()
+                if tuple(full.shape) != (BATCH * world, C, H, W) or not torch.equal(full[rank * BATCH:(rank + 1) * BATCH], shard):
+                    raise RuntimeError("gathered batch does not hold this rank's shard at its place")
+                del full
                 g0 = time.perf_counter()
                 for _ in range(5):
                     par.gather_batch(shard, BATCH * world, direct=direct)
@@ -400,18 +484,21 @@ def main():
             except Exception as exc:
                 ok = 0.0
                 gather[tag + "_error"] = repr(exc)[:200]
-            gt = torch.tensor([secs, -ok], device=device, dtype=torch.float64)
+            gt = torch.tensor([secs, -ok], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(gt, op=dist.ReduceOp.MAX)  # slowest rank; -ok is 0 if any rank failed
             if gt[1].item() == -1.0:
                 gather[tag + "_ms"] = gt[0].item() * 1e3
-                gather[tag + "_GBps_per_rank_in"] = shard.numel() * 4 * (world - 1) / gt[0].item() / 1e9
+                gather[tag + "_GBps_per_rank_in"] = shard.numel() * 4 * (world - 1) / max(gt[0].item(), 1e-12) / 1e9
             else:
                 gather.setdefault(tag + "_error", "failed on another rank")
                 break
         if rank == 0:
-            print("[bench] gather (outside value): " + json.dumps(gather), file=sys.stderr, flush=True)
+            watchdog.cancel()
+            emit(gather)
         dist.barrier()
         dist.destroy_process_group()
+    elif rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

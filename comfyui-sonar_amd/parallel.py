@@ -60,12 +60,22 @@ class ShardedNoiseSampler:
         return gather_batch(local, self.global_shape[0], group=self.group, direct=direct)
 
 
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """A gloo process group (ranks sharing one GPU in a self-test, no RCCL) moves device tensors through the host."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def allreduce_stats(local: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the (sum, sumsq, n) fp64 triple over ranks (24 bytes: latency only)."""
     if local.dtype != torch.float64 or local.numel() != 3:
         raise ValueError("allreduce_stats expects a float64 tensor of 3 elements")
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)
+        if _host_staged(local, group):
+            host = local.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            local.copy_(host)
+        else:
+            dist.all_reduce(local, op=dist.ReduceOp.SUM, group=group)
     return local
 
 
@@ -96,6 +106,8 @@ def gather_batch(local: torch.Tensor, global_batch: int, group=None, *, direct: 
     if local.shape[0] != counts[rank]:
         raise ValueError(f"gather_batch: rank {rank} holds {local.shape[0]} latents, its shard of {global_batch} is {counts[rank]}")
     local = local.contiguous()
+    if _host_staged(local, group):
+        return gather_batch(local.cpu(), global_batch, group, direct=direct).to(local.device)
     if direct:
         out = torch.empty((global_batch, *local.shape[1:]), dtype=local.dtype, device=local.device)
         start, count = spans[rank]

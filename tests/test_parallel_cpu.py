@@ -77,3 +77,18 @@ def test_shard_range_partitions_every_batch(pkg):
     assert par.shard_range(1024, 3, 8) == (384, 128)  # cfg5: 128 Flux latents per GPU
     with pytest.raises(ValueError):
         par.shard_range(8, 2, 2)
+
+
+def test_bench_refuses_to_mislabel_the_gpu_count():
+    """`python bench.py --gpus 2` on a node with fewer GPUs ends with a non-zero code and no result line (it used to measure one GPU
+    and print n_gpus: 1); the launcher role touches no GPU, so this runs anywhere."""
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SONAR_BENCH_BACKEND")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and '"metric"' not in res.stdout and "needs 2 GPUs" in res.stderr
