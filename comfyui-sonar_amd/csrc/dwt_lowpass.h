@@ -303,6 +303,9 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
 template <typename T>
 static bool lowpass_plan(LowArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W, int levels, int flen, int mode_fwd, int mode_inv) {
     if (levels < 1 || levels > kLowMaxLevels || !tile_taps_ok(flen) || flen > kDeepTaps || !dims_ok(H, W) || H > 4096 || W > 4096) return false;
+    // a periodised transform paired with any other extension reconstructs a plane shifted by flen / 2 - 1 samples: not the identity
+    // this path is built on (py/wavelet_functions.py:81-105 runs both transforms for real; the band-by-band path does the same)
+    if (flen > 2 && (mode_fwd == kPeriodization) != (mode_inv == kPeriodization)) return false;
     a.levels = levels;
     a.H[0] = (int)H;
     a.W[0] = (int)W;

@@ -652,7 +652,7 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
     // uncond / final scale is 1, the blend is linear in (uncond band, difference band), so
     //   IDWT(blend(U, D (C - U), t)) = ku u + kt IDWT(D DWT(c - u))
     // and ONE tensor is transformed instead of two (py/wavelet_cfg.py:765-787 with the identities of csrc/dwt_lowpass.h)
-    bool diff_only = perfect_reconstruction && levels >= 1;
+    bool diff_only = perfect_reconstruction && levels >= 1 && (dec_len == 2 || (mode_fwd == kPeriodization) == (mode_inv == kPeriodization));
     for (int i = 0; diff_only && i < 4; ++i)
         if (i != 2 && yl_scales[i] != 1.0) diff_only = false;
     for (int j = 0; diff_only && j < levels; ++j)

@@ -357,12 +357,12 @@ __global__ void __launch_bounds__(kBlock) row_affine_kernel(int op, const float*
 }
 
 // normalize_to_scale's tail (py/utils.py:462-469): ((x - lo) / ((hi - lo) + eps)) * (tmax - tmin) + tmin, clamped; each step rounded
-// on its own as the reference's in-place tensor ops are
+// on its own as the reference's in-place tensor ops are.  The targets are Python floats there: their difference is formed in double
+// and rounded to fp32 ONCE (`span`; 0.3 - 0.1 is 0.2, not 0.20000002)
 __global__ void __launch_bounds__(kBlock) minmax_rescale_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
                                                                  const float* __restrict__ lo, const float* __restrict__ hi, float eps,
-                                                                 float tmin, float tmax, float* out) {
+                                                                 float tmin, float tmax, float span, float* out) {
     const int64_t total = rows * inner;
-    const float span = __fsub_rn(tmax, tmin);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / inner;
         const float denom = __fadd_rn(__fsub_rn(hi[r], lo[r]), eps);
@@ -1254,11 +1254,11 @@ extern "C" int sonar_row_affine_f32(int op, const float* x, int64_t rows, int64_
 }
 
 extern "C" int sonar_minmax_rescale_f32(const float* x, int64_t rows, int64_t inner, const float* lo, const float* hi, float eps,
-                                        float target_min, float target_max, float* out, void* stream) {
+                                        double target_min, double target_max, float* out, void* stream) {
     SONAR_REQUIRE(x && lo && hi && out && rows >= 0 && inner > 0, SONAR_ERR_ARG, "sonar_minmax_rescale_f32: bad argument");
     if (rows == 0) return SONAR_OK;
     hipLaunchKernelGGL(minmax_rescale_kernel, dim3(grid_for(rows * inner, kBlock * 2)), dim3(kBlock), 0, (hipStream_t)stream, x, rows,
-                       inner, lo, hi, eps, target_min, target_max, out);
+                       inner, lo, hi, eps, (float)target_min, (float)target_max, (float)(target_max - target_min), out);
     return check_launch("sonar_minmax_rescale_f32");
 }
 

@@ -145,7 +145,7 @@ SIGNATURES = {
     "sonar_wcfg_lowpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_lowpass_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
-    "sonar_minmax_rescale_f32": (_I, [_P, _I64, _I64, _P, _P, _F, _F, _F, _P, _P]),
+    "sonar_minmax_rescale_f32": (_I, [_P, _I64, _I64, _P, _P, _F, _D, _D, _P, _P]),
     "sonar_axis_taps_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _I, _I, _P]),
     "sonar_axis_taps_f64": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _I, _I, _P]),
     "sonar_dtcwt_q2c_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _P]),
@@ -216,17 +216,31 @@ STATS_ATTR = "_sonar_partials"  # see py/utils.py attach_stats / pop_stats
 # storage address -> weak reference to the tensor that carries a statistics tag for it.  Raw-pointer kernels do not bump torch's
 # version counter, so a write through ANY view of a tagged tensor's storage (sibling views, views of views) must drop the tag:
 # keyed by storage, not by tensor object.  Tags live from a producer kernel to the next scale_noise, so this is almost always empty.
-TAGGED: dict = {}
+TAGGED: dict = {}  # storage address -> list of weak references (several views of one storage may each carry a tag)
+
+
+def _tag_drop_dead(key: int, ref) -> None:
+    refs = TAGGED.get(key)
+    if refs is not None:
+        refs[:] = [r for r in refs if r is not ref and r() is not None]
+        if not refs:
+            TAGGED.pop(key, None)
 
 
 def tag_register(t: torch.Tensor) -> None:
     key = t.untyped_storage().data_ptr()
-    TAGGED[key] = weakref.ref(t, lambda _r, k=key: TAGGED.pop(k, None))
+    TAGGED.setdefault(key, []).append(weakref.ref(t, lambda r, k=key: _tag_drop_dead(k, r)))
 
 
 def tag_forget(t: torch.Tensor) -> None:
+    """The tensor gave its tag up itself (pop_stats): other views of the storage keep theirs."""
     if TAGGED:
-        TAGGED.pop(t.untyped_storage().data_ptr(), None)
+        key = t.untyped_storage().data_ptr()
+        refs = TAGGED.get(key)
+        if refs is not None:
+            refs[:] = [r for r in refs if r() is not None and r() is not t]
+            if not refs:
+                TAGGED.pop(key, None)
 
 
 def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
@@ -234,10 +248,10 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
     if TAGGED:  # any kernel that touches the storage of a tagged tensor drops its statistics tag (producers tag AFTER their launch)
-        ref = TAGGED.pop(t.untyped_storage().data_ptr(), None)
-        owner = None if ref is None else ref()
-        if owner is not None:
-            owner.__dict__.pop(STATS_ATTR, None)
+        for ref in TAGGED.pop(t.untyped_storage().data_ptr(), ()):
+            owner = ref()
+            if owner is not None:
+                owner.__dict__.pop(STATS_ATTR, None)
     if not t.is_cuda:
         raise SonarHipError(f"{name}: tensor lives on {t.device}; the Sonar HIP path only runs on a ROCm device")
     if t.dtype != dtype:

@@ -734,59 +734,50 @@ class ResizedNoise(CustomNoiseItemBase):
     def clone_key(self, k):
         return self.custom_noise.clone() if k == "custom_noise" else super().clone_key(k)
 
+    def working_size(self, xh: int, xw: int):
+        """(rows, columns) the inner chain runs at, plus the crop offsets in latent cells.  `absolute` / `relative` sizes and the
+        offsets are given in pixels (floor-divided by the compression), `percentage` sizes as fractions of the latent."""
+        comp = self.spatial_compression
+        if self.spatial_mode == "percentage":
+            size = (max(1, int(xh * self.height)), max(1, int(xw * self.width)))
+        elif self.spatial_mode in ("absolute", "relative"):
+            base = (xh, xw) if self.spatial_mode == "relative" else (0, 0)
+            size = (int(base[0] + self.height // comp), int(base[1] + self.width // comp))
+        else:
+            raise ValueError("Bad spatial_mode")
+        return size, (self.crop_offset_vertical // comp, self.crop_offset_horizontal // comp)
+
     def make_noise_sampler(self, x, *args, normalized=True, **kwargs):
         if x.ndim < 3:
             raise ValueError("ResizedNoise can only handle 3+ dimensional latents")
-        factor = self.factor
-        normalize = self.get_normalize("normalize", normalized)
-        spatial_compression, spatial_mode = self.spatial_compression, self.spatial_mode
-        width, height = self.width, self.height
+        factor, normalize = self.factor, self.get_normalize("normalize", normalized)
         xh, xw = x.shape[-2:]
-        if spatial_mode != "percentage":
-            height //= spatial_compression
-            width //= spatial_compression
-        if spatial_mode == "absolute":
-            nh, nw = int(height), int(width)
-        elif spatial_mode == "relative":
-            nh, nw = int(xh + height), int(xw + width)
-        elif spatial_mode == "percentage":
-            nh, nw = max(1, int(xh * height)), max(1, int(xw * width))
-        else:
-            raise ValueError("Bad spatial_mode")
-        offsh = self.crop_offset_vertical // spatial_compression
-        offsw = self.crop_offset_horizontal // spatial_compression
-        if xh == nh and xw == nw:
-            ns = self.custom_noise.make_noise_sampler(x, *args, normalized=normalize, **kwargs)
+        (nh, nw), (off_y, off_x) = self.working_size(xh, xw)
+        if (nh, nw) == (xh, xw):  # nothing to resize: the inner chain normalises, this item only multiplies
+            inner = self.custom_noise.make_noise_sampler(x, *args, normalized=normalize, **kwargs)
+            return lambda *a, **k: scale_noise(inner(*a, **k), factor, normalized=False)
 
-            def same_size(*a, **k):
-                return scale_noise(ns(*a, **k), factor, normalized=False)  # .mul_(factor)
+        def window(t, rows, cols):
+            return utils.crop_samples(t, cols, rows, mode=self.crop_mode, offset_width=off_x, offset_height=off_y).contiguous()
 
-            return same_size
-        upscale_mode, downscale_mode, crop_mode = self.upscale_mode, self.downscale_mode, self.crop_mode
-        x_all_bigger = xh >= nh and xw >= nw
-        x_any_bigger = xh >= nh or xw >= nw
-        crop_back = partial(utils.crop_samples, width=xw, height=xh, mode=crop_mode, offset_width=offsw, offset_height=offsh)
-        if x_all_bigger:
-            if self.initial_reference == "prefer_crop":
-                x = utils.crop_samples(x, nw, nh, mode=crop_mode, offset_width=offsw, offset_height=offsh).contiguous()
-            else:
-                x = utils.scale_samples(x, nw, nh, mode=downscale_mode)
-            output = partial(utils.scale_samples, width=xw, height=xh, mode=upscale_mode)
+        def resample(mode):
+            return lambda t, rows, cols: utils.scale_samples(t, cols, rows, mode=mode)
+
+        up, down = resample(self.upscale_mode), resample(self.downscale_mode)
+        # route = (how the reference latent reaches the working size, how the noise comes back), chosen by which of the two is larger
+        covers = (xh >= nh) + (xw >= nw)  # in how many axes the latent is at least the working size
+        if covers == 2:
+            to_work, back = (window if self.initial_reference == "prefer_crop" else down), up
+        elif covers == 1:
+            to_work, back = up, up
         else:
-            x = utils.scale_samples(x, nw, nh, mode=upscale_mode)
-            if x_any_bigger:
-                output = partial(utils.scale_samples, width=xw, height=xh, mode=upscale_mode)
-            elif self.downscale_strategy == "scale":
-                output = partial(utils.scale_samples, width=xw, height=xh, mode=downscale_mode)
-            else:
-                output = lambda t: crop_back(t).contiguous()  # noqa: E731
-        ns = self.custom_noise.make_noise_sampler(x, *args, normalized=False, **kwargs)
-        del x
+            to_work, back = up, (down if self.downscale_strategy == "scale" else window)
+        inner = self.custom_noise.make_noise_sampler(to_work(x, nh, nw), *args, normalized=False, **kwargs)
 
         def noise_sampler(*a, **k):
-            noise = scale_noise(ns(*a, **k), factor, normalized=normalize)
+            noise = scale_noise(inner(*a, **k), factor, normalized=normalize)
             pop_stats(noise)
-            return output(noise.contiguous())
+            return back(noise.contiguous(), xh, xw)
 
         return noise_sampler
 

@@ -147,57 +147,6 @@ def normalize_to_scale(latent: Tensor, target_min: float, target_max: float, *, 
     return hip_lib.minmax_rescale(x, rows, inner, lo, hi, eps, target_min, target_max)
 
 
-def adjust_slice(s: slice, size: int, offset: int) -> slice:
-    """py/utils.py:513-523: a slice moved by ``offset`` as far as the bounds allow."""
-    if offset == 0:
-        return s
-    start = s.start if s.start is not None else 0
-    stop = s.stop if s.stop is not None else size
-    if offset < 0:
-        adj = min(start, abs(offset))
-        return slice(start - adj, stop - adj)
-    adj = min(size - stop, offset)
-    return slice(start + adj, stop + adj)
-
-
-def crop_samples(tensor: Tensor, width: int, height: int, *, mode="center", offset_width: int = 0, offset_height: int = 0) -> Tensor:
-    """py/utils.py:526-568: a (height, width) window of the last two dimensions (a view; indexing only)."""
-    if tensor.ndim < 3:
-        raise ValueError("Can only handle >= 3 dimensional tensors")
-    th, tw = tensor.shape[-2:]
-    if (tw, th) == (width, height):
-        return tensor
-    if tw < width or th < height:
-        raise ValueError("Can't crop sample smaller than requested width or height")
-    if mode == "center":
-        hmode = wmode = "center"
-    else:
-        hmode, wmode, *splitextra = mode.split("_")
-        if splitextra:
-            raise ValueError("Bad composite mode")
-    if hmode == "top":
-        hslice = slice(0, height)
-    elif hmode == "center":
-        hoffs = (th - height) // 2
-        hslice = slice(hoffs, hoffs + height)
-    elif hmode == "bottom":
-        hslice = slice(th - height, th)
-    else:
-        raise ValueError("Bad height mode in composite mode")
-    if wmode == "left":
-        wslice = slice(0, width)
-    elif wmode == "center":
-        woffs = (tw - width) // 2
-        wslice = slice(woffs, woffs + width)
-    elif wmode == "right":
-        wslice = slice(tw - width, tw)
-    else:
-        raise ValueError("Bad width mode in composite mode")
-    wslice = adjust_slice(wslice, tw, offset_width)
-    hslice = adjust_slice(hslice, th, offset_height)
-    return tensor[..., hslice, wslice]
-
-
 def normalize_to_scale_adv(t: Tensor, *, min_pos: float, max_pos: float, min_neg: float, max_neg: float, dim=(-3, -2, -1)) -> Tensor:
     """py/utils.py:473-510: negatives and positives rescaled separately between their own extremes.  The reference selects the values of a sign
     into a 1-D tensor first, so whatever ``dim`` says the extremes are those of the WHOLE tensor passed in: one row."""
@@ -213,7 +162,8 @@ def tensor_to(tensor: Tensor, dest) -> Tensor:
 
 
 def crop_samples(tensor: Tensor, width: int, height: int, *, mode: str = "center", offset_width: int = 0, offset_height: int = 0) -> Tensor:
-    """py/utils.py:526-570 (pure indexing)."""
+    """py/utils.py:513-570 (pure indexing): a (height, width) window of the last two dimensions, anchored per axis at an edge or the
+    centre (`center`, or `<top|center|bottom>_<left|center|right>`) and then moved by the offsets as far as the tensor allows."""
     if tensor.ndim < 3:
         raise ValueError("Can only handle >= 3 dimensional tensors")
     th, tw = tensor.shape[-2:]

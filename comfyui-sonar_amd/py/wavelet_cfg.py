@@ -585,6 +585,8 @@ def _per_latent(t: torch.Tensor, sigma: torch.Tensor, *, divide: bool) -> torch.
     s = utils.as_f32(sigma.reshape(-1)).to(t.device)
     if s.numel() == 1 and rows > 1:
         s = s.expand(rows)
+    elif s.numel() != rows:  # the kernel reads one value per row: refuse what torch's broadcast refuses, with its words
+        raise RuntimeError(f"The size of tensor a ({rows}) must match the size of tensor b ({s.numel()}) at non-singleton dimension 0")
     s = s.contiguous()
     zero = torch.zeros_like(s)
     return hip_lib.row_affine(0 if divide else 1, utils.as_f32(t).contiguous(), rows, t.numel() // max(rows, 1), zero, s)
@@ -602,9 +604,14 @@ def _check_broadcast(a: tuple, b: tuple) -> None:
 
 
 def _reconstructs(w) -> bool:
-    """IDWT(DWT(t)) == t needs the analysis and synthesis banks of ONE wavelet (dmey is only approximately a wavelet); every pywt
-    extension mode reconstructs, also with a different mode on the way back (the valid region never sees the extension)."""
-    return getattr(w, "wave", None) is not None and w.wave == w.inv_wave and w.wave != "dmey" and len(w.dec_lo) == len(w.rec_lo)
+    """IDWT(DWT(t)) == t (after the crop) needs the analysis and synthesis banks of ONE wavelet (dmey is only approximately a wavelet)
+    and extension modes that agree on the coefficient grid: pywt's non-periodised modes are interchangeable (the valid region never
+    sees the extension), but a periodised transform keeps H/2 coefficients on a grid shifted by L/2 - 1 samples, so pairing it with
+    any other mode returns a SHIFTED reconstruction for filters longer than two taps -- the reference computes exactly that, and such
+    rules take the band-by-band path."""
+    if getattr(w, "wave", None) is None or w.wave != w.inv_wave or w.wave == "dmey" or len(w.dec_lo) != len(w.rec_lo):
+        return False
+    return len(w.dec_lo) == 2 or (w.mode == "periodization") == (w.inv_mode == "periodization")
 
 
 class WaveletCFG:

@@ -154,9 +154,10 @@ int sonar_div_mid_f32(float* x, int64_t outer, int64_t mid, int64_t inner, const
 /* py/utils.py:452-470 normalize_to_scale: per row min/max rescale to [lo,hi] */
 int sonar_minmax_rows_f32(const float* x, int64_t rows, int64_t inner, float* out_min, float* out_max, void* stream);
 /* the rest of normalize_to_scale (py/utils.py:462-469): out = clamp(((x - lo[r]) / ((hi[r] - lo[r]) + eps)) * (target_max - target_min)
- * + target_min, target_min, target_max), one (lo, hi) per row, every step rounded separately as the reference's tensor ops are */
+ * + target_min, target_min, target_max), one (lo, hi) per row, every step rounded separately as the reference's tensor ops are; the
+ * targets arrive as doubles (Python floats in the reference): their difference is rounded to fp32 once */
 int sonar_minmax_rescale_f32(const float* x, int64_t rows, int64_t inner, const float* lo, const float* hi, float eps,
-                             float target_min, float target_max, float* out, void* stream);
+                             double target_min, double target_max, float* out, void* stream);
 
 /* A pending global normalisation of a noise tensor (py/utils.py:100-105): the decision scale_noise(normalized=True) would take,
  * computed ON THE DEVICE from the tensor's (sum, sumsq) partials and left in device memory, so that the kernel that consumes the

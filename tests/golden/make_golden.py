@@ -1001,6 +1001,7 @@ def gen_resample_modes():
     cases["nts_default"] = ref.utils.normalize_to_scale(t.clone(), 0.0, 1.0)
     cases["nts_hw"] = ref.utils.normalize_to_scale(t.clone(), -1.5, 2.0, dim=(-2, -1))
     cases["nts_all"] = ref.utils.normalize_to_scale(t.clone(), 0.25, 0.5, dim=(-4, -3, -2, -1), eps=1e-3)
+    cases["nts_inexact"] = ref.utils.normalize_to_scale(t.clone(), 0.1, 0.3)  # targets that are not fp32 numbers: span = fp32(0.3 - 0.1)
     save("resample_modes", **cases)
 
 

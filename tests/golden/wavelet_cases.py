@@ -211,6 +211,12 @@ WCFG_CASES = {
     "oned_f32": dict(shape=(2, 4, 24, 20), sigma=7.0, params=dict(difference=dict(yl_scale=2.0, yh_scales=[3.0, 0.5, "fill"]), use_1d_dwt=True, level=3,
                                                                   high_precision_mode=False)),
 }
+# a periodised inverse after a symmetric forward transform (and the other way round) does NOT reconstruct: the reference's result
+# carries the shift of the mismatched pair, so these rules must take the band-by-band path (no linearity shortcut)
+WCFG_CASES["mixed_modes"] = dict(shape=(2, 4, 32, 32), sigma=7.0, params=dict(PLACEHOLDER, wave="db2", level=1, padding_mode="symmetric",
+                                                                              inv_padding_mode="periodization"))
+WCFG_CASES["mixed_modes_zero_f32"] = dict(shape=(1, 4, 32, 32), sigma=7.0, params=dict(PLACEHOLDER, wave="db4", level=1, padding_mode="zero",
+                                                                                       inv_padding_mode="periodization", high_precision_mode=False))
 WCFG_CASES["with_ops"] = dict(shape=(2, 4, 32, 32), sigma=5.0, params=dict(PLACEHOLDER, level=2, blend_strength=0.5), ops=True)
 WCFG_CASES["with_ops_plain"] = dict(shape=(2, 4, 32, 32), sigma=5.0, params=dict(PLACEHOLDER, level=2), ops=True)
 WCFG_ERRORS = {

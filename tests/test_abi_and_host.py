@@ -167,3 +167,35 @@ def test_brownian_path_coefficients_are_a_brownian_motion(pkg):
         long.define(1.0 - k / 3001.0)
     c = long.coefficients(1.0 - 2999 / 3001.0)
     assert len(c) == 3000 and abs(var(c) - (1.0 - 2999 / 3001.0)) < 1e-9 and len(long._memo) <= long.MEMO + 3000
+
+
+def test_every_tagged_view_of_a_storage_loses_its_tag(pkg):
+    """Two tensors on one storage may each carry a statistics tag; a kernel handed either of them (or any third view) must drop BOTH:
+    raw-pointer kernels do not bump torch's version counter, so a surviving tag would normalise with statistics of other contents."""
+    import importlib
+
+    hl = pkg.hip_lib
+    utils = importlib.import_module("comfyui_sonar_amd.py.utils")
+    base = torch.zeros(4, 8)
+    a, b = base[:2], base[2:]
+    utils.attach_stats(a, torch.zeros(4, dtype=torch.float64))
+    utils.attach_stats(b, torch.ones(4, dtype=torch.float64))
+    assert len(hl.TAGGED[base.untyped_storage().data_ptr()]) == 2
+    with pytest.raises(hl.SonarHipError):  # a CPU tensor is refused -- after the tags of its storage are gone
+        hl._dev(base.view(-1), "x")
+    assert utils.pop_stats(a) is None and utils.pop_stats(b) is None and not hl.TAGGED
+    # a tensor that gives up its own tag leaves its sibling's alone; dead tensors leave the table
+    utils.attach_stats(a, torch.zeros(4, dtype=torch.float64))
+    utils.attach_stats(b, torch.ones(4, dtype=torch.float64))
+    assert utils.pop_stats(a) is not None and utils.pop_stats(b) is not None and not hl.TAGGED
+    utils.attach_stats(a, torch.zeros(4, dtype=torch.float64))
+    del a
+    assert not hl.TAGGED
+
+
+def test_per_latent_sigma_must_have_one_value_or_one_per_latent(pkg):
+    import importlib
+
+    wc = importlib.import_module("comfyui_sonar_amd.py.wavelet_cfg")
+    with pytest.raises(RuntimeError, match=r"size of tensor a \(4\) must match the size of tensor b \(3\)"):
+        wc._per_latent(torch.zeros(4, 2, 8, 8), torch.ones(3), divide=True)

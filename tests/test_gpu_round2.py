@@ -533,6 +533,7 @@ def test_normalize_to_scale(api, golden):
     assert torch.equal(api.utils.normalize_to_scale(x.clone(), 0.0, 1.0).cpu(), g["nts_default"])
     assert torch.equal(api.utils.normalize_to_scale(x.clone(), -1.5, 2.0, dim=(-2, -1)).cpu(), g["nts_hw"])
     assert torch.equal(api.utils.normalize_to_scale(x.clone(), 0.25, 0.5, dim=(-4, -3, -2, -1), eps=1e-3).cpu(), g["nts_all"])
+    assert torch.equal(api.utils.normalize_to_scale(x.clone(), 0.1, 0.3).cpu(), g["nts_inexact"])  # the span is rounded once, from double
 
 
 # ------------------------------------------------------------------------------------------------ chains: generators that fold into the running sum
