@@ -53,13 +53,7 @@ static inline int any_plane_ok(int64_t H, int64_t W) {
 
 template <bool NEED_T>
 __device__ __forceinline__ SpectrumRng spectrum_rng_dyn(uint64_t seed, uint64_t stream_id, int64_t ggroup, int tid, int H) {
-    SpectrumRng g;
-    g.R = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 0u, (uint32_t)tid);
-    if constexpr (NEED_T) g.T = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 1u, (uint32_t)tid);
-    else g.T = Xoshiro{0, 0, 0, 1};
-    g.E = Xoshiro{0, 0, 0, 1};
-    if (tid < H) g.E = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 2u, (uint32_t)tid);
-    return g;
+    return spectrum_seed<NEED_T>(seed, stream_id, ggroup, tid, tid < H);  // one Philox block read at three depths (power_fft.hip)
 }
 
 // draw_plane with run-time sizes (slots tid < kAnySlots): pair p -> ky = p / M, kx = 1 + p % M, partner H/2 rows below;

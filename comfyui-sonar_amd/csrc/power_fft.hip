@@ -15,6 +15,7 @@
 //            straight to global as float2 (x[2m], x[2m+1]) in 64-B runs.
 // The normaliser's (sum, sumsq) partials are accumulated from the stored values.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "twiddles256.h"
@@ -34,9 +35,12 @@ __device__ __forceinline__ c32 cmul(c32 a, c32 b) {
     const v2f A = vv(a), B = vv(b);
     return cc(__builtin_elementwise_fma(A.yy, v2f{-B.y, B.x}, A.xx * B));
 }
-__device__ __forceinline__ c32 cmul_i(c32 a) { return make_float2(-a.y, a.x); }  // a * (+i)
-__device__ __forceinline__ c32 cadd_i(c32 a, c32 b) { return cc(vv(a) + v2f{-b.y, b.x}); }   // a + i b
-__device__ __forceinline__ c32 csub_i(c32 a, c32 b) { return cc(vv(a) - v2f{-b.y, b.x}); }   // a - i b
+// a +- i b as ONE packed FMA: swap(b) * (-+1, +-1) + a (the swap is an operand modifier, the sign pair a scalar register pair; exact, so
+// the same bits as the add).  Written as `a + {-b.y, b.x}` the compiler builds the rotated vector with a v_xor and a v_mov first:
+// three instructions for every multiply-by-i butterfly, 128 extra vector instructions per plane and thread in the transforms.
+__device__ __forceinline__ c32 cadd_i(c32 a, c32 b) { return cc(__builtin_elementwise_fma(vv(b).yx, v2f{-1.0f, 1.0f}, vv(a))); }   // a + i b
+__device__ __forceinline__ c32 csub_i(c32 a, c32 b) { return cc(__builtin_elementwise_fma(vv(b).yx, v2f{1.0f, -1.0f}, vv(a))); }   // a - i b
+__device__ __forceinline__ c32 cmul_i(c32 a) { return cc(vv(a).yx * v2f{-1.0f, 1.0f}); }  // a * (+i)
 __device__ __forceinline__ c32 cscale(c32 a, float r) { return cc(vv(a) * r); }
 
 // ---- register codelets: in-place inverse (sign +) DFTs, natural order in and out -------------
@@ -72,7 +76,7 @@ __device__ __forceinline__ void idft<8>(c32 (&v)[8]) {
     idft<4>(o);
     const c32 t0 = o[0];
     const c32 t1 = cscale(cadd_i(o[1], o[1]), r);              // * e^{i pi/4}  = r (o + i o)
-    const c32 t3 = cscale(csub(cmul_i(o[3]), o[3]), r);        // * e^{3 i pi/4} = r (i o - o)
+    const c32 t3 = cscale(csub_i(o[3], o[3]), -r);             // * e^{3 i pi/4} = r (i o - o) = -r (o - i o)
     v[0] = cadd(e[0], t0); v[4] = csub(e[0], t0);
     v[1] = cadd(e[1], t1); v[5] = csub(e[1], t1);
     v[2] = cadd_i(e[2], o[2]); v[6] = csub_i(e[2], o[2]);      // * i
@@ -95,14 +99,18 @@ __device__ __forceinline__ void idft<16>(c32 (&v)[16]) {
     t[1] = cmul(o[1], make_float2(c1, s1));
     t[2] = cscale(cadd_i(o[2], o[2]), r);
     t[3] = cmul(o[3], make_float2(s1, c1));
-    t[4] = cmul_i(o[4]);
     t[5] = cmul(o[5], make_float2(-s1, c1));
-    t[6] = cscale(csub(cmul_i(o[6]), o[6]), r);
+    t[6] = cscale(csub_i(o[6], o[6]), -r);
     t[7] = cmul(o[7], make_float2(-c1, s1));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        v[i] = cadd(e[i], t[i]);
-        v[i + 8] = csub(e[i], t[i]);
+        if (i == 4) {  // * i: folded into the butterfly
+            v[4] = cadd_i(e[4], o[4]);
+            v[12] = csub_i(e[4], o[4]);
+        } else {
+            v[i] = cadd(e[i], t[i]);
+            v[i + 8] = csub(e[i], t[i]);
+        }
     }
 }
 
@@ -187,15 +195,55 @@ struct SpectrumRng {
     Xoshiro R, T, E;
 };
 
+// The three streams of a (group, thread slot) start from ONE Philox4x32 counter block, read at three depths: R after the standard
+// 10 rounds (the same state as rng_stream of tile 4 * group), E after 12, T after 14.  Each extra pair of rounds is a keyed
+// multiplicative bijection of an already mixed block, so the states are unrelated as far as the GF(2)-linear xoshiro recurrences are
+// concerned, and seeding costs 14 rounds per slot instead of 30 (12 instead of 20 in the statistics pass, which never draws T).
+// 32-bit multiplies are the slow instructions here (v_mad_u64_u32, about a sixth of the plain rate): seeding was 3.7 us of the
+// statistics pass's 9.7 us and 5.5 us of vector-ALU time in the final pass (512 SDXL latents).
+struct PhiloxBlock {
+    uint32_t c0, c1, c2, c3, k0, k1;
+    template <int ROUNDS>
+    __device__ __forceinline__ void rounds() {
+        constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint64_t p0 = (uint64_t)M0 * (uint64_t)c0;
+            const uint64_t p1 = (uint64_t)M1 * (uint64_t)c2;
+            const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+            const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+            const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+            c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+            k0 += W0; k1 += W1;
+        }
+    }
+    __device__ __forceinline__ Xoshiro state() const { return Xoshiro{c0, c1, c2, c3 | 1u}; }  // never the all-zero state
+};
+
+template <bool NEED_T>
+__device__ __forceinline__ SpectrumRng spectrum_seed(uint64_t seed, uint64_t stream_id, int64_t ggroup, int tid, bool edge_slot) {
+    const uint64_t tile = (uint64_t)ggroup << 2;
+    PhiloxBlock b{(uint32_t)tile, (uint32_t)(tile >> 32), (uint32_t)stream_id, (uint32_t)((stream_id >> 32) << 16) ^ (uint32_t)tid,
+                  (uint32_t)seed, (uint32_t)(seed >> 32)};
+    SpectrumRng g;
+    b.rounds<10>();
+    g.R = b.state();
+    g.E = Xoshiro{0, 0, 0, 1};
+    g.T = Xoshiro{0, 0, 0, 1};
+    if (NEED_T || edge_slot) {  // whole waves: the edge slots are the first H threads, H a multiple of 64 on every fixed-size plane
+        b.rounds<2>();
+        g.E = b.state();
+    }
+    if constexpr (NEED_T) {
+        b.rounds<2>();
+        g.T = b.state();
+    }
+    return g;
+}
+
 template <int H, bool NEED_T>
 __device__ __forceinline__ SpectrumRng spectrum_rng(uint64_t seed, uint64_t stream_id, int64_t ggroup, int tid) {
-    SpectrumRng g;
-    g.R = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 0u, (uint32_t)tid);
-    if constexpr (NEED_T) g.T = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 1u, (uint32_t)tid);
-    else g.T = Xoshiro{0, 0, 0, 1};
-    g.E = Xoshiro{0, 0, 0, 1};
-    if (tid < H) g.E = rng_stream(seed, stream_id, ((uint64_t)ggroup << 2) | 2u, (uint32_t)tid);
-    return g;
+    return spectrum_seed<NEED_T>(seed, stream_id, ggroup, tid, tid < H);
 }
 
 // interior element order: the pairs p in [0, (H/2) M) walk rows of M slots, ky = p / M, kx = 1 + p % M (M a power of two: shifts);
@@ -800,6 +848,380 @@ SONAR_UNROLL_ITEMS
     if constexpr (STATS) write_partial<NT>(s, q, partials, red);
 }
 
+// ---- pipelined generate path ---------------------------------------------------------------------------------------------------
+// power_irfft2_kernel runs draw -> columns -> rows -> store as barrier-separated phases of ONE 8-wave team; with two such workgroups
+// per CU the vector ALUs idle whenever both sit in a latency-bound transform phase (profiles/r02_power_kernel.md: 27 us of issue in
+// a 50 us pass, 37 % of a wave's time at barriers).  Here ONE 16-wave workgroup per CU runs two teams over two plane buffers:
+//   drawing team (waves 8-15)   draws plane j -- thread slot (wave n2, lane) draws rows n2, n2 + 8, ... of ONE column, which are
+//                               exactly the 16 inputs of its radix-16 item of column pass a -- keeps them in registers, transforms
+//                               them and writes pass a's OUTPUT to LDS: the spectrum itself never goes through LDS
+//   transforming team (0-7)     meanwhile runs column pass b, the row passes and the stores of plane j - 1
+// so every SIMD holds two drawing and two transforming waves at all times and the draw fills the transform's LDS round trips.
+// While the drawing team works in registers the buffer of plane j is free: the transforming team ping-pongs between the buffers
+// (pass b: X -> Y, row pass a: Y -> X, no read-before-write barrier inside row pass a), and the drawing team writes plane j into Y in
+// the last phase, when nothing reads Y any more.  The hardware barrier counts all 16 waves: both teams run the SAME three barriers
+// per plane; the draw is cut into chunks of whole pair iterations that follow the transform phases' durations (SONAR_PIPE_CHUNKS =
+// iterations in phases 1 and 2; the rest, with column pass a, in phase 3).  Thread slot = thread within the drawing team: streams,
+// draw order and arithmetic -- therefore every output bit -- are those of power_irfft2_kernel<H, W, 1, ...>.
+#ifndef SONAR_PIPE_CHUNKS
+#define SONAR_PIPE_CHUNKS 3, 5
+#endif
+#ifndef SONAR_PIPE_PRIO_DRAW
+#define SONAR_PIPE_PRIO_DRAW 0
+#endif
+#ifndef SONAR_PIPE_PRIO_FFT
+#define SONAR_PIPE_PRIO_FFT 3
+#endif
+#ifndef SONAR_PIPE_SKIP
+#define SONAR_PIPE_SKIP 0  // profiling builds only: 1 no global stores, 2 no draw arithmetic (zeros), 4 no row pass b arithmetic, 8 no row pass a, 16 no column pass b
+#endif
+#ifdef SONAR_PW_TRACE
+__device__ unsigned long long g_pipe_trace[256 * 16 * 10 * 4];
+#define SONAR_PIPE_STAMP(slot) do { if (lane == 0 && j < 10 && blockIdx.x < 256) g_pipe_trace[((blockIdx.x * 16 + wv_all) * 10 + j) * 4 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SONAR_PIPE_STAMP(slot) do { } while (0)
+#endif
+
+// iterations [IT0, IT1) of one thread slot's draw, kept in registers: iteration `it` is element (ky = n2 + 8 it, kx) and its partner
+// 64 rows below = inputs n1 = it and n1 = it + H / 16 of the slot's column-pass-a item
+template <int H, int W, int IT0, int IT1>
+__device__ __forceinline__ void draw_chunk_regs(const float* __restrict__ filter, SpectrumRng& g, int tid, c32 (&v)[H / 8], float& fa, float& fb) {
+    constexpr int NT = plane_threads<H, W>(), M = W / 2, Wh = M + 1, LM = draw_shift<W>(), PAIRS = (H / 2) * M;
+    static_assert(PAIRS % NT == 0 && IT0 <= IT1 && IT1 <= PAIRS / NT && NT == 8 * M && PAIRS / NT == H / 16, "slot = (wave n2, column)");
+    auto fpos = [&](int p) { return (p >> LM) * Wh + 1 + (p & (M - 1)); };
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
+        const int p = tid + it * NT;
+        const uint32_t ra = g.R.next_high();
+        const uint32_t rb = g.R.next_high();
+        const uint32_t t = g.T.next();
+        const int pn = (p + NT) & (PAIRS - 1);  // the last iteration requests the next plane's first pair
+        const float na = filter[fpos(pn)], nb = filter[fpos(pn) + (H / 2) * Wh];
+        if constexpr (SONAR_PIPE_SKIP & 2) {
+            v[it] = make_float2(fa + (float)ra, fb);
+            v[it + H / 16] = make_float2(fb + (float)t, fa + (float)rb);
+        } else {
+        v[it] = drawn_elem(ra, t & 0xFFFFu, fa);
+        v[it + H / 16] = drawn_elem(rb, t >> 16, fb);
+        }
+        fa = na;
+        fb = nb;
+    }
+}
+
+// ---- the transforming team's passes.  NW waves share a pass (8 in the steady state; all 16 on the workgroup's last plane, when the
+// drawing team has nothing left to draw); `w` = this wave's index among them.  Every pass requests ALL of its LDS operands before the
+// first butterfly: scheduled item by item the loads come in batches of four with a wait behind each, and a team of two waves per SIMD
+// has little else to run meanwhile.
+// columns, pass b: radix 8 over rows 8 k1 .. 8 k1 + 7 of column `lane`, X -> Y
+template <int H, int W, int NW>
+__device__ __forceinline__ void pipe_col_b(const c32* X, c32* Y, int w, int lane) {
+    constexpr int S = PlaneCfg<H, W>::S, CN1 = H / 8, CN2 = 8, ITEMS = CN1 / NW;
+    static_assert(CN1 % NW == 0, "whole items per wave");
+    c32 u[ITEMS][CN2];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+#pragma unroll
+        for (int n2 = 0; n2 < CN2; ++n2) u[it][n2] = X[(CN2 * (w + NW * it) + n2) * S + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        idft<CN2>(u[it]);
+#pragma unroll
+        for (int k2 = 0; k2 < CN2; ++k2) Y[(CN2 * (w + NW * it) + k2) * S + lane] = u[it][k2];
+    }
+}
+
+// rows, pass a (c2r pre-twiddle fused): residue n2 = w % 8 (its twiddles are wave-uniform: scalar registers), rows lane + 64 it; Y -> X,
+// element (k1, n2) of a row lands at column 8 n2 + k1
+template <int H, int W, int NW>
+__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane, const c32 (&gtw)[8], const c32 (&ptw)[8]) {
+    using C = PlaneCfg<H, W>;
+    constexpr int M = C::M, S = C::S, RN1 = C::RN1, RN2 = C::RN2, ROWS = H / 64, ITEMS = ROWS * 8 / NW;
+    static_assert(RN1 == 8 && RN2 == 8 && (NW == 8 || NW == 8 * ROWS), "one residue per wave");
+    const int n2 = w & 7, it0 = NW == 8 ? 0 : w >> 3;
+    c32 xa[ITEMS][RN1], xb[ITEMS][RN1];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const c32* row = Y + (lane + 64 * (it0 + it)) * S;
+#pragma unroll
+        for (int n1 = 0; n1 < RN1; ++n1) {
+            const int k = RN2 * n1 + n2;
+            if (k == 0) {  // uniform: residue 0, n1 = 0 -- the packed column holds Re = column 0, Im = column M
+                const c32 p = row[0];
+                xa[it][n1] = make_float2(p.x, 0.0f);
+                xb[it][n1] = make_float2(p.y, 0.0f);
+            } else {
+                xa[it][n1] = row[k];
+                xb[it][n1] = row[M - k];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        c32 g[RN1];
+#pragma unroll
+        for (int n1 = 0; n1 < RN1; ++n1) {
+            const c32 xc = make_float2(xb[it][n1].x, -xb[it][n1].y);  // conj
+            g[n1] = cadd_i(cadd(xa[it][n1], xc), cmul(csub(xa[it][n1], xc), gtw[n1]));
+        }
+        idft<RN1>(g);
+#pragma unroll
+        for (int k1 = 1; k1 < RN1; ++k1) g[k1] = cmul(g[k1], ptw[k1]);
+#pragma unroll
+        for (int k1 = 0; k1 < RN1; ++k1) X[(lane + 64 * (it0 + it)) * S + RN1 * n2 + k1] = g[k1];
+    }
+}
+
+// rows, pass b -> global.  A thread owns LDS row r and the output residues k1 = 2a, 2a + 1 (NW = 8): its two radix-8 items yield the
+// complex outputs m = k1 + 8 k2, FOUR consecutive floats per k2 -> eight 16-byte stores (64-byte runs from the four lanes of a row)
+// instead of sixteen 8-byte ones: the store phase is bound by store instructions, not bytes.  Pass a left element (k1, n2) at column
+// 8 n2 + k1, so the thread's two inputs of an n2 sit side by side (one ds_read2_b64).  Lane -> row: a read2's access groups are 16
+// consecutive lanes over 32 banks; they hold rows r0 + {0, 1, 8, 9} x a < 4, whose 2-dword windows start at 2 r + 4 a (mod 32) =
+// {0, 2, 16, 18} + 4 a with the odd row stride -- all different.  NW = 16 (last plane): the second eight waves take k1 = 2a + 1.
+template <int H, int W, int NW, bool STATS, bool NORM>
+__device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, int lane, float scale, float nm, float nc, double& s, double& q) {
+    using C = PlaneCfg<H, W>;
+    constexpr int S = C::S, RN1 = C::RN1, RN2 = C::RN2, CN1 = H / 8, CN2 = 8, NK = NW == 8 ? 2 : 1;
+    static_assert(H == 128 && RN1 == 8 && RN2 == 8 && (NW == 8 || NW == 16), "16 rows x 4 residue pairs per wave");
+    const int a = lane & 3, w8 = w & 7, k0 = 2 * a + (NW == 8 ? 0 : w >> 3);
+    const int r = 16 * w8 + 2 * (lane >> 4) + 8 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
+    const int y = (r / CN2) + CN1 * (r % CN2);
+    c32 u[NK][RN2];
+#pragma unroll
+    for (int n2 = 0; n2 < RN2; ++n2) {
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            if constexpr (SONAR_PIPE_SKIP & 4) u[i][n2] = make_float2((float)(lane + n2), 1.0f + i);
+            else u[i][n2] = X[r * S + RN1 * n2 + k0 + i];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(SONAR_PIPE_SKIP & 4)) {
+#pragma unroll
+        for (int i = 0; i < NK; ++i) idft<RN2>(u[i]);
+    }
+    float* const orow = oplane + (int64_t)y * W + 2 * k0;
+    float ps = 0.0f, pq = 0.0f;
+#pragma unroll
+    for (int k2 = 0; k2 < RN2; ++k2) {
+        float o[2 * NK];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            if constexpr (NORM) {
+                o[2 * i] = __builtin_fmaf(u[i][k2].x, nm, -nc);
+                o[2 * i + 1] = __builtin_fmaf(u[i][k2].y, nm, -nc);
+            } else {
+                o[2 * i] = u[i][k2].x * scale;
+                o[2 * i + 1] = u[i][k2].y * scale;
+            }
+            if constexpr (STATS) {
+                ps += o[2 * i] + o[2 * i + 1];
+                pq = __builtin_fmaf(o[2 * i], o[2 * i], __builtin_fmaf(o[2 * i + 1], o[2 * i + 1], pq));
+            }
+        }
+        float* const dst = orow + 2 * RN1 * k2;
+        if constexpr (SONAR_PIPE_SKIP & 1) {
+            if (o[0] == 123.456f && o[1] == 654.321f) *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);  // keeps the arithmetic alive
+        } else if constexpr (NK == 2) {
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+        }
+    }
+    if constexpr (STATS) {
+        s += (double)ps;
+        q += (double)pq;
+    }
+}
+
+// The draw only touches registers, so nothing orders it against a barrier: the optimiser sinks every chunk to its first use, right in
+// front of column pass a (phase 3), and the first two phases of the drawing team run empty.  An empty volatile asm that takes the
+// chunk's results as read-write operands makes them opaque at that point: they must exist before it, and it stays before the barrier.
+template <int IT0, int IT1, int N>
+__device__ __forceinline__ void pin_chunk(c32 (&v)[N]) {
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
+        asm volatile("" : "+v"(v[it].x), "+v"(v[it].y), "+v"(v[it + N / 2].x), "+v"(v[it + N / 2].y));
+    }
+}
+
+template <int H, int W, bool STATS, bool NORM>
+__global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restrict__ filter, float* out, int64_t planes, uint64_t seed,
+                                                          uint64_t stream_id, int64_t plane_offset, int group, int split, double* partials,
+                                                          NormArgs na) {
+    using C = PlaneCfg<H, W>;
+    constexpr int NT = 512, NALL = 1024;
+    static_assert(plane_threads<H, W>() == NT && W == 128 && H == 128, "one 8-wave team per plane, slot = one radix-16 column item");
+    constexpr int M = C::M, S = C::S, Wh = M + 1, RN1 = C::RN1, RN2 = C::RN2, CN1 = H / 8, CN2 = 8, ITER = draw_iters<H, W>();
+    constexpr int LM = draw_shift<W>();
+    constexpr int kChunk[2] = {SONAR_PIPE_CHUNKS};
+    constexpr int E0 = kChunk[0], E1 = E0 + kChunk[1];
+    static_assert(E1 <= ITER && ITER == CN1 / 2, "chunks of whole pair iterations");
+    constexpr int BUF = H * S;
+    __shared__ c32 PLANES[2 * BUF];
+    __shared__ c32 EDGE[3 * H];  // raw columns kx = 0 and kx = M of the plane being drawn, and the packed column built from them
+    // stream states of this workgroup's SECOND unit, seeded by the transforming team while it waits for the first plane (the draw team
+    // would spend ~0.8 us on the Philox rounds at the unit switch: 32-bit multiplies at a sixth of the plain rate)
+    __shared__ uint4 SEED_RT[2 * NT];
+    __shared__ uint4 SEED_E[H];
+    __shared__ double red[2 * NALL / 64];
+    __shared__ NormDecision shd;
+    const int wv_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool drawer = wv_all >= NT / 64;
+    const int tid = threadIdx.x & (NT - 1), lane = threadIdx.x & 63, wv = wv_all & (NT / 64 - 1);
+    // this workgroup's plane sequence: units blockIdx.x, blockIdx.x + gridDim.x, ...; `per_unit` planes each
+    const int64_t nunits = split ? planes : planes / group;
+    const int per_unit = split ? 1 : group;
+    const int64_t my_units = (int64_t)blockIdx.x < nunits ? (nunits - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int n = (int)(my_units * per_unit);
+    const float scale = 1.0f / sqrtf((float)H * (float)W);
+    float nm = scale, nc = 0.0f;
+    // the statistics pass's partials: requested now, reduced by all 16 waves when the first plane has been drawn (one pair per thread)
+    static_assert(!NORM || kNPart == NALL, "one partial pair per thread");
+    [[maybe_unused]] double pre_s = 0.0, pre_q = 0.0;
+    if constexpr (NORM) {
+        pre_s = na.partials[2 * threadIdx.x];
+        pre_q = na.partials[2 * threadIdx.x + 1];
+    }
+    auto decide = [&]() {
+        if constexpr (NORM) {
+            const NormDecision dec = decide_from_sums<NALL>(pre_s, pre_q, na.n_total, na.thr_sd, red, &shd);
+            const float g = (dec.do_div ? 1.0f / dec.stdv : 1.0f) * na.factor;
+            nm = scale * g;
+            nc = dec.do_sub ? dec.mean * g : 0.0f;
+        }
+    };
+    double s = 0.0, q = 0.0;
+    if (drawer) {
+        // ------------------------------------------------------------------------------------------------ drawing team
+        __builtin_amdgcn_s_setprio(SONAR_PIPE_PRIO_DRAW);
+        c32* const T0 = EDGE;
+        c32* const TM = EDGE + H;
+        c32* const Q = EDGE + 2 * H;
+        SpectrumRng rng;
+        auto fpos = [&](int p) { return (p >> LM) * Wh + 1 + (p & (M - 1)); };
+        float fa = filter[fpos(tid)], fb = filter[fpos(tid) + (H / 2) * Wh];
+        const float f0 = tid < H ? filter[tid * Wh] : 0.0f, fm = tid < H ? filter[tid * Wh + M] : 0.0f;
+        c32 ctw[CN1];  // e^{2 pi i n2 k1 / H}: wave-uniform, loop-invariant
+#pragma unroll
+        for (int k1 = 0; k1 < CN1; ++k1) ctw[k1] = c_tw256[((wv * k1) * (256 / H)) & 255];
+        // lane L holds column kx = L + 1; the slot of kx = M (lane 63) is drawn and discarded, that lane transforms the packed column 0
+        const int col = (lane + 1) & (M - 1);
+        int64_t unit = blockIdx.x;
+        int gp = 0;
+        for (int j = 0; j < n; ++j) {
+            if (j == 1) decide();
+            c32* const A = PLANES + (j & 1) * BUF;
+            c32 v[CN1];
+            SONAR_PIPE_STAMP(0);
+            if (gp == 0) {
+                const GroupWalk gw(unit, group, split);
+                if (j == per_unit) {  // the second unit: states left in LDS by the transforming team (visible: barriers since)
+                    const uint4 r = SEED_RT[tid], t = SEED_RT[NT + tid];
+                    rng.R = Xoshiro{r.x, r.y, r.z, r.w};
+                    rng.T = Xoshiro{t.x, t.y, t.z, t.w};
+                    if (tid < H) {
+                        const uint4 e = SEED_E[tid];
+                        rng.E = Xoshiro{e.x, e.y, e.z, e.w};
+                    }
+                } else {
+                    rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + gw.grp, tid);
+                }
+                for (int i = 0; i < gw.first; ++i) skip_plane<H, W, true>(rng, tid);
+            }
+            if (tid < H) {  // row ky = tid of the edge columns (waves 0-1 of the team)
+                const uint32_t r0 = rng.E.next_high();
+                const uint32_t rm = rng.E.next_high();
+                const uint32_t t = rng.E.next();
+                T0[tid] = drawn_elem(r0, t & 0xFFFFu, f0);
+                TM[tid] = drawn_elem(rm, t >> 16, fm);
+            }
+            draw_chunk_regs<H, W, 0, E0>(filter, rng, tid, v, fa, fb);
+            pin_chunk<0, E0>(v);
+            SONAR_PIPE_STAMP(1);
+            __syncthreads();
+            if (tid >= NT - H) {  // packed column 0 (Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky]) from the edge rows, by the team's last waves
+                const int ky = tid - (NT - H), kn = (H - ky) & (H - 1);
+                const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
+                Q[ky] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
+            }
+            draw_chunk_regs<H, W, E0, E1>(filter, rng, tid, v, fa, fb);
+            pin_chunk<E0, E1>(v);
+            SONAR_PIPE_STAMP(2);
+            __syncthreads();
+            draw_chunk_regs<H, W, E1, ITER>(filter, rng, tid, v, fa, fb);
+            if (lane == M - 1) {
+#pragma unroll
+                for (int n1 = 0; n1 < CN1; ++n1) v[n1] = Q[CN2 * n1 + wv];
+            }
+            // -------------------------------------------------------- columns, pass a: radix CN1 on the drawn registers (n2 = wave)
+            idft<CN1>(v);
+#pragma unroll
+            for (int k1 = 1; k1 < CN1; ++k1) v[k1] = cmul(v[k1], ctw[k1]);
+#pragma unroll
+            for (int k1 = 0; k1 < CN1; ++k1) A[(CN2 * k1 + wv) * S + col] = v[k1];
+            if (++gp == per_unit) {
+                gp = 0;
+                unit += gridDim.x;
+            }
+            SONAR_PIPE_STAMP(3);
+            __syncthreads();
+        }
+        // nothing left to draw while the other team transforms the last plane: the same three barriers
+        if (n == 1) decide();
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+    } else {
+        // ------------------------------------------------------------------------------------------------ transforming team
+        // wave wv owns residue n2 = wv in the twiddled row pass: every twiddle is wave-uniform and loop-invariant (scalar registers)
+        __builtin_amdgcn_s_setprio(SONAR_PIPE_PRIO_FFT);
+        c32 gtw[RN1], ptw[RN1];
+#pragma unroll
+        for (int n1 = 0; n1 < RN1; ++n1) gtw[n1] = c_tw256[((RN2 * n1 + wv) * (256 / W)) & 255];
+#pragma unroll
+        for (int k1 = 0; k1 < RN1; ++k1) ptw[k1] = c_tw256[((wv * k1) * (256 / M)) & 255];
+        int64_t unit = blockIdx.x;
+        int gp = 0;
+        if (n > per_unit) {  // nothing to transform yet: seed the second unit's streams for the drawing team
+            const GroupWalk gw(unit + gridDim.x, group, split);
+            const SpectrumRng g2 = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + gw.grp, tid);
+            SEED_RT[tid] = make_uint4(g2.R.s0, g2.R.s1, g2.R.s2, g2.R.s3);
+            SEED_RT[NT + tid] = make_uint4(g2.T.s0, g2.T.s1, g2.T.s2, g2.T.s3);
+            if (tid < H) SEED_E[tid] = make_uint4(g2.E.s0, g2.E.s1, g2.E.s2, g2.E.s3);
+        }
+        for (int j = 0; j <= n; ++j) {  // iteration j transforms plane j - 1
+            constexpr int NW = 8;
+            if (j == 1) decide();
+            const bool work = j >= 1;
+            c32* const X = PLANES + ((j + 1) & 1) * BUF;  // plane j - 1 (pass a's output)
+            c32* const Y = PLANES + (j & 1) * BUF;        // free until the drawing team writes plane j in phase 3
+            SONAR_PIPE_STAMP(0);
+            if (work && !(SONAR_PIPE_SKIP & 16)) pipe_col_b<H, W, NW>(X, Y, wv, lane);
+            SONAR_PIPE_STAMP(1);
+            __syncthreads();
+            if (work && !(SONAR_PIPE_SKIP & 8)) pipe_row_a<H, W, NW>(Y, X, wv, lane, gtw, ptw);
+            SONAR_PIPE_STAMP(2);
+            __syncthreads();
+            if (work) {
+                const GroupWalk gw(unit, group, split);
+                float* const oplane = out + (gw.grp * group + gw.first + gp) * (int64_t)H * W;
+                pipe_row_b<H, W, NW, STATS, NORM>(X, oplane, wv, lane, scale, nm, nc, s, q);
+                if (++gp == per_unit) {
+                    gp = 0;
+                    unit += gridDim.x;
+                }
+            }
+            SONAR_PIPE_STAMP(3);
+            __syncthreads();
+        }
+    }
+    if constexpr (STATS) write_partial<NALL>(s, q, partials, red);
+}
+
 // Statistics of the output WITHOUT computing it (Parseval, ortho-normalised transform):
 //   sum   x  = sqrt(H W) * Re(Zf[0][0])
 //   sum x^2  = sum_ky ( |sym(Zf[:,0])[ky]|^2 + |sym(Zf[:,M])[ky]|^2 ) + 2 sum_ky sum_{0<kx<M} |Zf[ky][kx]|^2
@@ -925,6 +1347,29 @@ static int power_grid(int64_t planes) {
 template <int H, int W>
 static int launch_power(int what, const float* z, const float* filter, float* out, int64_t planes, uint64_t seed,
                         uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st) {
+    // Generated 128 x 128 planes, more than one per CU: the pipelined kernel (one 16-wave workgroup per CU, the draw of plane j + 1
+    // under the transforms of plane j; same streams, same bits).  SONAR_POWER_PIPE=0 keeps the phase-serial kernel (A/B timing).
+    if constexpr (H == 128 && W == 128) {
+        static const bool pipe_on = [] { const char* e = getenv("SONAR_POWER_PIPE"); return !(e && e[0] == '0'); }();
+        if (pipe_on && z == nullptr && (what == 0 || what == 1) && planes > 256) {
+            const int psplit = group > 1 && planes / group < 256 ? 1 : 0;  // fewer RNG groups than CUs: single planes as units
+            const int64_t units = psplit ? planes : planes / group;
+            const int pg = (int)std::min<int64_t>(units, 256);
+            if (what == 1) {
+                hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(units, kNPart)), dim3(plane_threads<H, W>()), 0, st, filter,
+                                   planes, seed, stream_id, plane_offset, group, psplit, partials);
+                hipLaunchKernelGGL((power_pipe_kernel<H, W, false, true>), dim3(pg), dim3(1024), 0, st, filter, out, planes, seed, stream_id,
+                                   plane_offset, group, psplit, (double*)nullptr, na);
+            } else if (partials) {
+                hipLaunchKernelGGL((power_pipe_kernel<H, W, true, false>), dim3(pg), dim3(1024), 0, st, filter, out, planes, seed, stream_id,
+                                   plane_offset, group, psplit, partials, na);
+            } else {
+                hipLaunchKernelGGL((power_pipe_kernel<H, W, false, false>), dim3(pg), dim3(1024), 0, st, filter, out, planes, seed, stream_id,
+                                   plane_offset, group, psplit, partials, na);
+            }
+            return check_launch("sonar_power_*");
+        }
+    }
     // too few RNG groups to fill the chip: one workgroup per plane (it fast-forwards the group's streams), same values
     const int split = group > 1 && planes / group < 2 * 256 ? 1 : 0;
     const int64_t ngroups = split ? planes : planes / group;  // work units
@@ -1023,6 +1468,9 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
 #ifdef SONAR_PW_TRACE
 extern "C" int sonar_debug_pw_trace(unsigned long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sonar::g_pw_trace), sizeof(sonar::g_pw_trace));
+}
+extern "C" int sonar_debug_pipe_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sonar::g_pipe_trace), sizeof(sonar::g_pipe_trace));
 }
 #endif
 
