@@ -866,6 +866,19 @@ SONAR_UNROLL_ITEMS
 #ifndef SONAR_PIPE_CHUNKS
 #define SONAR_PIPE_CHUNKS 3, 5
 #endif
+// look-ahead statistics (TeamStats): planes of the unit whose radius words are drawn in the first / by the end of the second of the
+// three phases; A, B drawing team (while the last plane is transformed), C, D transforming team (while the first plane is drawn)
+#ifndef SONAR_AHEAD_SPLIT_A
+#define SONAR_AHEAD_SPLIT_A 1
+#define SONAR_AHEAD_SPLIT_B 3
+#endif
+#ifndef SONAR_AHEAD_SPLIT_C
+#define SONAR_AHEAD_SPLIT_C 2
+#define SONAR_AHEAD_SPLIT_D 3
+#endif
+#ifndef SONAR_AHEAD_PRIO
+#define SONAR_AHEAD_PRIO 0  // the transforming team's issue priority while it computes look-ahead statistics beside the first draw
+#endif
 #ifndef SONAR_PIPE_PRIO_DRAW
 #define SONAR_PIPE_PRIO_DRAW 0
 #endif
@@ -1037,6 +1050,108 @@ __device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, i
     }
 }
 
+// ---- statistics of the NEXT call, computed in the pipelined kernel's idle corners -------------------------------------------------
+// A normalised call needs the Parseval statistics of all of its planes before its first store: power_stats_kernel, 10 us in front of
+// a 41 us final pass.  A sampler calls the same generator step after step with consecutive stream ids, and the pipelined kernel has
+// two idle corners per launch -- the transforming team while the first plane is drawn, the drawing team while the last plane is
+// transformed -- so each team there computes the statistics of ONE unit of the call that follows (same seed, `next_stream`) and leaves
+// them as that call's partials: its host wrapper then skips the statistics launch when the prediction held, and runs it when not.
+// The work is the statistics kernel's, per unit, in the same order (same bits); it is spread over three barrier-separated steps
+// because the workgroup barrier counts both teams.
+template <int H, int W>
+struct TeamStats {
+    static constexpr int NT = plane_threads<H, W>(), M = W / 2, Wh = M + 1, LM = draw_shift<W>(), PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
+    float wgt[2 * ITER], prod[2 * ITER];
+    float f0, fm;
+    SpectrumRng rng;
+    double s, q;
+    int planes_in_unit;
+
+    // weights, stream states, and the unit's edge columns (all planes: the E stream is its own) into `edge` [plane][2][H]
+    __device__ __forceinline__ void begin(const float* __restrict__ filter, uint64_t seed, uint64_t stream_id, int64_t plane_offset, int group,
+                                          const GroupWalk& gw, int tid, c32* edge) {
+        constexpr float kNegLn2 = -0.6931471805599453f;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int p = tid + it * NT, ky = p >> LM, kx = 1 + (p & (M - 1));
+            const bool live = p < PAIRS && kx < M;
+            const float fa = live ? filter[ky * Wh + kx] : 0.0f, fb = live ? filter[(ky + H / 2) * Wh + kx] : 0.0f;
+            wgt[it] = kNegLn2 * (fa * fa);
+            wgt[it + ITER] = kNegLn2 * (fb * fb);
+            prod[it] = 1.0f;
+            prod[it + ITER] = 1.0f;
+        }
+        f0 = tid < H ? filter[tid * Wh] : 0.0f;
+        fm = tid < H ? filter[tid * Wh + M] : 0.0f;
+        s = 0.0;
+        q = 0.0;
+        planes_in_unit = gw.count;
+        rng = spectrum_rng<H, false>(seed, stream_id, plane_offset / group + gw.grp, tid);
+        for (int i = 0; i < gw.first; ++i) skip_plane<H, W, false>(rng, tid);
+        if (tid < H) {
+            for (int b = 0; b < gw.count; ++b) {
+                const uint32_t r0 = rng.E.next_high();
+                const uint32_t rm = rng.E.next_high();
+                const uint32_t t = rng.E.next();
+                edge[(2 * b) * H + tid] = drawn_elem(r0, t & 0xFFFFu, f0);
+                edge[(2 * b + 1) * H + tid] = drawn_elem(rm, t >> 16, fm);
+            }
+        }
+    }
+    // radius words of planes [b0, b1) of the unit
+    __device__ __forceinline__ void radii(int b0, int b1, int tid) {
+        for (int b = b0; b < min(b1, planes_in_unit); ++b) {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const uint32_t ra = rng.R.next_high();
+                const uint32_t rb = rng.R.next_high();
+                prod[it] *= 2.0f - unit_mantissa(ra);
+                prod[it + ITER] *= 2.0f - unit_mantissa(rb);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 2 * ITER; ++it) asm volatile("" : "+v"(prod[it]));  // stays in this phase (registers only: see pin_chunk)
+    }
+    __device__ __forceinline__ void products() {
+        float acc = 0.0f;
+#pragma unroll
+        for (int it = 0; it < 2 * ITER; ++it) acc = __builtin_fmaf(wgt[it], __builtin_amdgcn_logf(prod[it]), acc);
+        q += 2.0 * (double)acc;
+    }
+    // the edge columns' terms (after a barrier behind begin()), then this wave's sums into `sred` [2][8]
+    __device__ __forceinline__ void edges_and_wave_sums(const c32* edge, int tid, double* sred) {
+        for (int b = 0; b < planes_in_unit; ++b) {
+            float e = 0.0f;
+            if (tid < H) {
+                const int ky = tid, kn = (H - ky) & (H - 1);
+                const c32 a = edge[(2 * b) * H + ky], an = edge[(2 * b) * H + kn], c = edge[(2 * b + 1) * H + ky], cn = edge[(2 * b + 1) * H + kn];
+                const float ar = 0.5f * (a.x + an.x), ai = 0.5f * (a.y - an.y), br = 0.5f * (c.x + cn.x), bi = 0.5f * (c.y - cn.y);
+                e += (ar * ar + ai * ai) + (br * br + bi * bi);
+                if (ky == 0) s += (double)(sqrtf((float)H * (float)W) * ar);
+            }
+            q += (double)e;
+        }
+        const double ws = wave_sum(s), wq = wave_sum(q);
+        if ((tid & 63) == 0) {
+            sred[tid >> 6] = ws;
+            sred[NT / 64 + (tid >> 6)] = wq;
+        }
+    }
+    // (after a barrier) the unit's pair, summed over the team's waves in the statistics kernel's order
+    static __device__ __forceinline__ void store(const double* sred, int tid, double* partials_next, int64_t slot) {
+        if (tid == 0) {
+            double ss = 0.0, qq = 0.0;
+#pragma unroll
+            for (int i = 0; i < NT / 64; ++i) {
+                ss += sred[i];
+                qq += sred[NT / 64 + i];
+            }
+            partials_next[2 * slot] = ss;
+            partials_next[2 * slot + 1] = qq;
+        }
+    }
+};
+
 // The draw only touches registers, so nothing orders it against a barrier: the optimiser sinks every chunk to its first use, right in
 // front of column pass a (phase 3), and the first two phases of the drawing team run empty.  An empty volatile asm that takes the
 // chunk's results as read-write operands makes them opaque at that point: they must exist before it, and it stays before the barrier.
@@ -1051,7 +1166,7 @@ __device__ __forceinline__ void pin_chunk(c32 (&v)[N]) {
 template <int H, int W, bool STATS, bool NORM>
 __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restrict__ filter, float* out, int64_t planes, uint64_t seed,
                                                           uint64_t stream_id, int64_t plane_offset, int group, int split, double* partials,
-                                                          NormArgs na) {
+                                                          NormArgs na, uint64_t next_stream, double* partials_next) {
     using C = PlaneCfg<H, W>;
     constexpr int NT = 512, NALL = 1024;
     static_assert(plane_threads<H, W>() == NT && W == 128 && H == 128, "one 8-wave team per plane, slot = one radix-16 column item");
@@ -1067,6 +1182,7 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
     // would spend ~0.8 us on the Philox rounds at the unit switch: 32-bit multiplies at a sixth of the plain rate)
     __shared__ uint4 SEED_RT[2 * NT];
     __shared__ uint4 SEED_E[H];
+    __shared__ double sred[2 * NT / 64];  // wave sums of a team's look-ahead statistics (TeamStats)
     __shared__ double red[2 * NALL / 64];
     __shared__ NormDecision shd;
     const int wv_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -1077,6 +1193,8 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
     const int per_unit = split ? 1 : group;
     const int64_t my_units = (int64_t)blockIdx.x < nunits ? (nunits - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int n = (int)(my_units * per_unit);
+    // statistics of the call that follows (TeamStats): one unit per team, so only for workgroups with at most two units
+    const bool ahead = partials_next != nullptr && nunits <= 2 * (int64_t)gridDim.x;
     const float scale = 1.0f / sqrtf((float)H * (float)W);
     float nm = scale, nc = 0.0f;
     // the statistics pass's partials: requested now, reduced by all 16 waves when the first plane has been drawn (one pair per thread)
@@ -1170,11 +1288,27 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             SONAR_PIPE_STAMP(3);
             __syncthreads();
         }
-        // nothing left to draw while the other team transforms the last plane: the same three barriers
+        // nothing left to draw while the other team transforms the last plane (the same three barriers): the next call's statistics of
+        // this workgroup's second unit; its edge columns wait in the seed area, which nobody reads any more
         if (n == 1) decide();
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
+        if (ahead && my_units == 2) {
+            TeamStats<H, W> ts;
+            c32* const edge = reinterpret_cast<c32*>(SEED_RT);
+            const GroupWalk gw((int64_t)blockIdx.x + gridDim.x, group, split);
+            ts.begin(filter, seed, next_stream, plane_offset, group, gw, tid, edge);
+            ts.radii(0, SONAR_AHEAD_SPLIT_A, tid);
+            __syncthreads();
+            ts.radii(SONAR_AHEAD_SPLIT_A, SONAR_AHEAD_SPLIT_B, tid);
+            __syncthreads();
+            ts.radii(SONAR_AHEAD_SPLIT_B, 4, tid);
+            ts.products();
+            ts.edges_and_wave_sums(edge, tid, sred);
+            __syncthreads();
+        } else {
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+        }
     } else {
         // ------------------------------------------------------------------------------------------------ transforming team
         // wave wv owns residue n2 = wv in the twiddled row pass: every twiddle is wave-uniform and loop-invariant (scalar registers)
@@ -1193,7 +1327,35 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             SEED_RT[NT + tid] = make_uint4(g2.T.s0, g2.T.s1, g2.T.s2, g2.T.s3);
             if (tid < H) SEED_E[tid] = make_uint4(g2.E.s0, g2.E.s1, g2.E.s2, g2.E.s3);
         }
-        for (int j = 0; j <= n; ++j) {  // iteration j transforms plane j - 1
+        // iteration 0: the first plane is being drawn.  The next call's statistics of this workgroup's first unit (edge columns in the
+        // second plane buffer, untouched until iteration 1), over the iteration's three barriers
+        if (ahead && my_units >= 1) {
+            TeamStats<H, W> ts;
+            c32* const edge = PLANES + BUF;
+            const GroupWalk gw(unit, group, split);
+            if (blockIdx.x == 0)
+                for (int64_t slot = nunits + tid; slot < kNPart; slot += NT) {
+                    partials_next[2 * slot] = 0.0;
+                    partials_next[2 * slot + 1] = 0.0;
+                }
+            __builtin_amdgcn_s_setprio(SONAR_AHEAD_PRIO);
+            ts.begin(filter, seed, next_stream, plane_offset, group, gw, tid, edge);
+            ts.radii(0, SONAR_AHEAD_SPLIT_C, tid);
+            __syncthreads();
+            ts.radii(SONAR_AHEAD_SPLIT_C, SONAR_AHEAD_SPLIT_D, tid);
+            __syncthreads();
+            ts.radii(SONAR_AHEAD_SPLIT_D, 4, tid);
+            ts.products();
+            ts.edges_and_wave_sums(edge, tid, sred);
+            __syncthreads();
+            TeamStats<H, W>::store(sred, tid, partials_next, unit);
+            __builtin_amdgcn_s_setprio(SONAR_PIPE_PRIO_FFT);
+        } else {
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+        }
+        for (int j = 1; j <= n; ++j) {  // iteration j transforms plane j - 1
             constexpr int NW = 8;
             if (j == 1) decide();
             const bool work = j >= 1;
@@ -1219,6 +1381,10 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             __syncthreads();
         }
     }
+    if (ahead) {
+        __syncthreads();  // the drawing team's wave sums are in LDS
+        if (drawer && my_units == 2) TeamStats<H, W>::store(sred, tid, partials_next, (int64_t)blockIdx.x + gridDim.x);
+    }
     if constexpr (STATS) write_partial<NALL>(s, q, partials, red);
 }
 
@@ -1231,11 +1397,12 @@ __global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(co
                                                                    uint64_t stream_id, int64_t plane_offset, int group, int split,
                                                                    double* partials) {
     constexpr int NT = plane_threads<H, W>(), M = W / 2, Wh = M + 1;
-    __shared__ c32 EDGE[2][2][H];  // [plane parity][kx = 0 | kx = M][ky]: double-buffered -> one barrier per plane
+    constexpr int NB = 4;  // planes per batch: their edge columns wait in LDS for ONE barrier (a barrier per plane made the eight
+                           // waves of a group wait for each other four times per group)
+    __shared__ c32 EDGE[NB][2][H];  // [plane of the batch][kx = 0 | kx = M][ky]
     __shared__ double red[2 * NT / 64];
     const int tid = threadIdx.x;
     double s = 0.0, q = 0.0;
-    int par = 0;
     auto edge_terms = [&](int p) {
         float edge = 0.0f;
         for (int ky = tid; ky < H; ky += NT) {
@@ -1265,40 +1432,34 @@ __global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(co
         const GroupWalk gw(unit, group, split);
         SpectrumRng rng = spectrum_rng<H, false>(seed, stream_id, plane_offset / group + gw.grp, tid);
         for (int i = 0; i < gw.first; ++i) skip_plane<H, W, false>(rng, tid);
-        // The planes of a group meet the same weight at the same slot, so sum_planes w log2 u = w log2(prod_planes u): ONE logarithm per
-        // slot and group instead of one per plane (a group has at most 4 planes: the product of four u in [2^-23, 1] stays a normal float,
-        // and its rounding error, 3 x 2^-24 relative, is below the logarithm's own).
-        float prod[2 * ITER];
+        for (int g0 = 0; g0 < gw.count; g0 += NB) {
+            const int nb = min(NB, gw.count - g0);
+            // The planes of a batch meet the same weight at the same slot, so sum_planes w log2 u = w log2(prod_planes u): ONE logarithm
+            // per slot and batch instead of one per plane (the product of four u in [2^-23, 1] stays a normal float, and its rounding
+            // error, 3 x 2^-24 relative, is below the logarithm's own).
+            float prod[2 * ITER];
 #pragma unroll
-        for (int it = 0; it < 2 * ITER; ++it) prod[it] = 1.0f;
-        int in_prod = 0;
-        auto flush = [&]() {
+            for (int it = 0; it < 2 * ITER; ++it) prod[it] = 1.0f;
+            for (int b = 0; b < nb; ++b) {
+                draw_plane<H, W, false>(
+                    rng, tid,
+                    [&](uint32_t r0, uint32_t rm, uint32_t t) {
+                        EDGE[b][0][tid] = drawn_elem(r0, t & 0xFFFFu, f0);
+                        EDGE[b][1][tid] = drawn_elem(rm, t >> 16, fm);
+                    },
+                    [&](int it, int, uint32_t ra, uint32_t rb, uint32_t) {
+                        prod[it] *= 2.0f - unit_mantissa(ra);
+                        prod[it + ITER] *= 2.0f - unit_mantissa(rb);
+                    });
+            }
             float acc = 0.0f;
 #pragma unroll
-            for (int it = 0; it < 2 * ITER; ++it) {
-                acc = __builtin_fmaf(wgt[it], __builtin_amdgcn_logf(prod[it]), acc);
-                prod[it] = 1.0f;
-            }
+            for (int it = 0; it < 2 * ITER; ++it) acc = __builtin_fmaf(wgt[it], __builtin_amdgcn_logf(prod[it]), acc);
             q += 2.0 * (double)acc;
-            in_prod = 0;
-        };
-        for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
-            draw_plane<H, W, false>(
-                rng, tid,
-                [&](uint32_t r0, uint32_t rm, uint32_t t) {
-                    EDGE[par][0][tid] = drawn_elem(r0, t & 0xFFFFu, f0);
-                    EDGE[par][1][tid] = drawn_elem(rm, t >> 16, fm);
-                },
-                [&](int it, int, uint32_t ra, uint32_t rb, uint32_t) {
-                    prod[it] *= 2.0f - unit_mantissa(ra);
-                    prod[it + ITER] *= 2.0f - unit_mantissa(rb);
-                });
-            if (++in_prod == 4) flush();
-            __syncthreads();           // this plane's edge columns are complete; the other buffer's readers finished last iteration
-            edge_terms(par);           // overlaps with the next plane's draw (which writes the other buffer)
-            par ^= 1;
+            __syncthreads();  // the batch's edge columns are complete
+            for (int b = 0; b < nb; ++b) edge_terms(b);
+            __syncthreads();  // ... and read, before the next batch overwrites them
         }
-        if (in_prod) flush();
     }
     write_partial<NT>(s, q, partials, red);
 }
@@ -1344,28 +1505,47 @@ static int power_grid(int64_t planes) {
 
 // what: 0 = irfft2 (z given or drawn; optional statistics), 1 = normalised generate (stats pass + final pass),
 //       2 = dump the drawn spectrum into `out`, 3 = spectral filter of the real planes `z`, 4 = forward rfft2 of the real planes `z` into `out`
+// look-ahead of a normalised generate call (sonar_power_noise_ahead_f32): `have_stats` -- the partials already hold this call's
+// statistics (left by the previous call's look-ahead), `next` -- where to leave those of the call with stream id `next_stream`
+struct Ahead {
+    int have_stats = 0;
+    uint64_t next_stream = 0;
+    double* next = nullptr;
+};
+
+static bool pipe_enabled() {
+    static const bool on = [] { const char* e = getenv("SONAR_POWER_PIPE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// the pipelined kernel's work units for `planes` planes in RNG groups of `group`
+static int64_t pipe_units(int64_t planes, int group, int* psplit) {
+    *psplit = group > 1 && planes / group < 256 ? 1 : 0;  // fewer RNG groups than CUs: single planes as units
+    return *psplit ? planes : planes / group;
+}
+
 template <int H, int W>
 static int launch_power(int what, const float* z, const float* filter, float* out, int64_t planes, uint64_t seed,
-                        uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st) {
+                        uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st,
+                        Ahead ah = Ahead()) {
     // Generated 128 x 128 planes, more than one per CU: the pipelined kernel (one 16-wave workgroup per CU, the draw of plane j + 1
     // under the transforms of plane j; same streams, same bits).  SONAR_POWER_PIPE=0 keeps the phase-serial kernel (A/B timing).
     if constexpr (H == 128 && W == 128) {
-        static const bool pipe_on = [] { const char* e = getenv("SONAR_POWER_PIPE"); return !(e && e[0] == '0'); }();
-        if (pipe_on && z == nullptr && (what == 0 || what == 1) && planes > 256) {
-            const int psplit = group > 1 && planes / group < 256 ? 1 : 0;  // fewer RNG groups than CUs: single planes as units
-            const int64_t units = psplit ? planes : planes / group;
+        if (pipe_enabled() && z == nullptr && (what == 0 || what == 1) && planes > 256) {
+            int psplit;
+            const int64_t units = pipe_units(planes, group, &psplit);
             const int pg = (int)std::min<int64_t>(units, 256);
             if (what == 1) {
-                hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(units, kNPart)), dim3(plane_threads<H, W>()), 0, st, filter,
-                                   planes, seed, stream_id, plane_offset, group, psplit, partials);
+                if (!ah.have_stats)
+                    hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(units, kNPart)), dim3(plane_threads<H, W>()), 0, st, filter,
+                                       planes, seed, stream_id, plane_offset, group, psplit, partials);
                 hipLaunchKernelGGL((power_pipe_kernel<H, W, false, true>), dim3(pg), dim3(1024), 0, st, filter, out, planes, seed, stream_id,
-                                   plane_offset, group, psplit, (double*)nullptr, na);
+                                   plane_offset, group, psplit, (double*)nullptr, na, ah.next_stream, ah.next);
             } else if (partials) {
                 hipLaunchKernelGGL((power_pipe_kernel<H, W, true, false>), dim3(pg), dim3(1024), 0, st, filter, out, planes, seed, stream_id,
-                                   plane_offset, group, psplit, partials, na);
+                                   plane_offset, group, psplit, partials, na, (uint64_t)0, (double*)nullptr);
             } else {
                 hipLaunchKernelGGL((power_pipe_kernel<H, W, false, false>), dim3(pg), dim3(1024), 0, st, filter, out, planes, seed, stream_id,
-                                   plane_offset, group, psplit, partials, na);
+                                   plane_offset, group, psplit, partials, na, (uint64_t)0, (double*)nullptr);
             }
             return check_launch("sonar_power_*");
         }
@@ -1434,7 +1614,7 @@ using namespace sonar;
 
 static int power_dispatch(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,
                           uint64_t seed, uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na,
-                          hipStream_t st) {
+                          hipStream_t st, Ahead ah = Ahead()) {
     const bool gen = what == 1 || what == 2 || (what == 0 && z == nullptr);
     if (!gen) group = 1;
     SONAR_REQUIRE(group >= 1 && planes % group == 0 && plane_offset % group == 0, SONAR_ERR_ARG,
@@ -1442,7 +1622,7 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
                   (long long)plane_offset, group);
 #define SONAR_CASE(HH, WW) \
     if (H == HH && W == WW) return launch_power<HH, WW>(what, z, filter, out, planes, seed, stream_id, plane_offset, group, partials, na, st)
-    SONAR_CASE(128, 128);
+    if (H == 128 && W == 128) return launch_power<128, 128>(what, z, filter, out, planes, seed, stream_id, plane_offset, group, partials, na, st, ah);
     SONAR_CASE(64, 64);
     SONAR_CASE(32, 32);
     SONAR_CASE(16, 16);
@@ -1503,6 +1683,31 @@ extern "C" int sonar_power_noise_f32(const float* filter, float* out, int64_t pl
     if (planes == 0) return SONAR_OK;
     return power_dispatch(1, nullptr, filter, out, planes, H, W, seed, stream_id, plane_offset, rng_group, partials,
                           NormArgs{partials, planes * H * W, factor, threshold_std_devs}, (hipStream_t)stream);
+}
+
+extern "C" int sonar_power_noise_ahead_ok(int64_t planes, int64_t H, int64_t W, int rng_group) {
+    if (H != 128 || W != 128 || !pipe_enabled() || planes <= 256 || rng_group < 1 || planes % rng_group) return 0;
+    int psplit;
+    return pipe_units(planes, rng_group, &psplit) <= 2 * 256 ? 1 : 0;  // one look-ahead unit per team: at most two units per workgroup
+}
+
+extern "C" int sonar_power_noise_ahead_f32(const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
+                                           uint64_t stream_id, int64_t plane_offset, int rng_group, float factor,
+                                           float threshold_std_devs, double* partials, int have_stats, uint64_t next_stream_id,
+                                           double* partials_next, void* stream) {
+    SONAR_REQUIRE(filter && out && partials && planes >= 0 && H > 0 && W > 0 && plane_offset >= 0, SONAR_ERR_ARG,
+                  "sonar_power_noise_ahead_f32: bad argument");
+    SONAR_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7u) == 0 && partials_next != partials, SONAR_ERR_ARG,
+                  "sonar_power_noise_ahead_f32: misaligned buffer, or the same workspace for both calls' statistics");
+    SONAR_REQUIRE(sonar_power_noise_ahead_ok(planes, H, W, rng_group), SONAR_ERR_UNSUPPORTED,
+                  "sonar_power_noise_ahead_f32: no look-ahead for %lld planes of %lld x %lld (ask sonar_power_noise_ahead_ok first)", (long long)planes,
+                  (long long)H, (long long)W);
+    Ahead ah;
+    ah.have_stats = have_stats != 0;
+    ah.next_stream = next_stream_id;
+    ah.next = partials_next;
+    return power_dispatch(1, nullptr, filter, out, planes, H, W, seed, stream_id, plane_offset, rng_group, partials,
+                          NormArgs{partials, planes * H * W, factor, threshold_std_devs}, (hipStream_t)stream, ah);
 }
 
 extern "C" int sonar_spectral_filter_f32(const float* x, const float* filter, float* out, int64_t planes, int64_t H, int64_t W,

@@ -108,6 +108,8 @@ SIGNATURES = {
     "sonar_pyramid_generate_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _P, _P]),
     "sonar_pyramid_noise_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _F, _F, _P, _P]),
     "sonar_power_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _P]),
+    "sonar_power_noise_ahead_ok": (_I, [_I64, _I64, _I64, _I]),
+    "sonar_power_noise_ahead_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _I, _U64, _P, _P]),
     "sonar_power_spectrum_f32": (_I, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _P]),
     "sonar_power_irfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _P, _P]),
     "sonar_spectral_filter_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _P, _P]),
@@ -962,19 +964,66 @@ def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: 
     return out
 
 
+class PowerLookahead:
+    """What one power-noise sampler remembers between calls (``power_noise(lookahead=...)``): the statistics the previous call's
+    final pass computed for the stream id it expected next, and the key (filter, shape, seed, stream, offset, group) they belong to.
+    A sampler's calls take consecutive stream ids (one ``DeviceRNG.take`` per call; a constant step when other generators draw in
+    between), so the expectation is the last stream id plus the last step."""
+
+    __slots__ = ("key", "partials", "last_stream", "last_delta", "step", "hits", "misses")
+
+    def __init__(self):
+        self.key = None
+        self.partials = None
+        self.last_stream = None
+        self.last_delta = None
+        self.step = 1
+        self.hits = 0
+        self.misses = 0
+
+
 def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_offset: int, factor: float,
-                threshold_std_devs: float = 2.5) -> torch.Tensor:
-    """draw + filter + irfft2 + scale_noise(factor, normalized=True); the tensor is written once."""
+                threshold_std_devs: float = 2.5, lookahead: Optional[PowerLookahead] = None) -> torch.Tensor:
+    """draw + filter + irfft2 + scale_noise(factor, normalized=True); the tensor is written once.  ``lookahead``: on the pipelined path
+    the call also leaves the statistics of the call expected next (idle waves of its final pass), and skips its own statistics launch
+    when the previous call left them -- same output bits with or without."""
     H, W = shape[-2:]
     out = torch.empty(shape, dtype=torch.float32, device=filt.device)
     planes = out.numel() // (H * W)
-    ws = new_partials(filt.device)
     if power_plane_kind(H, W) == 3:
+        ws = new_partials(filt.device)
         white = philox_normal(tuple(shape), filt.device, seed, stream_id, plane_offset * H * W)
         return scale_noise_(_direct_spectral_filter(white, filt, ws), factor, True, ws, threshold_std_devs=threshold_std_devs)
+    group = rng_group_for(shape)
+    lib = load()
+    seed &= 2**64 - 1
+    if lookahead is not None and lib.sonar_power_noise_ahead_ok(planes, H, W, group):
+        def key_for(stream):
+            return (filt.data_ptr(), filt._version, tuple(shape), seed, stream, plane_offset, group, filt.device)
+
+        have = lookahead.key is not None and lookahead.key == key_for(stream_id)
+        ws = lookahead.partials if have else new_partials(filt.device)
+        if lookahead.last_stream is not None and stream_id > lookahead.last_stream:
+            delta = stream_id - lookahead.last_stream
+            if lookahead.last_delta is None or delta == lookahead.last_delta:
+                lookahead.step = delta  # a step seen twice in a row (or the first one seen); a one-off shift is not adopted
+            lookahead.last_delta = delta
+        nxt = (stream_id + lookahead.step) & (2**64 - 1)
+        nws = new_partials(filt.device)
+        _check(
+            lib.sonar_power_noise_ahead_f32(_dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed, stream_id, plane_offset, group,
+                                            float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), int(have), nxt,
+                                            _dev(nws, "ws_next", torch.float64), _stream()),
+            "sonar_power_noise_ahead_f32",
+        )
+        lookahead.hits += int(have)
+        lookahead.misses += int(not have)
+        lookahead.key, lookahead.partials, lookahead.last_stream = key_for(nxt), nws, stream_id
+        return out
+    ws = new_partials(filt.device)
     _check(
-        load().sonar_power_noise_f32(_dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
-                                     rng_group_for(shape), float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
+        lib.sonar_power_noise_f32(_dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed, stream_id, plane_offset,
+                                  group, float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
         "sonar_power_noise_f32",
     )
     return out

@@ -178,6 +178,7 @@ class PowerNoiseItem(CustomNoiseItemBase):
         identity = mixer.is_identity
         mixer.to(device)
         planes_per_latent = math.prod(shape[1:-2])  # 5-D (video) latents: every [H, W] slice is a plane, as in the reference's irfft2
+        lookahead = hip_lib.PowerLookahead()  # a sampler's calls take consecutive stream ids: each leaves the next one's statistics
 
         def sampler(sigma, sigma_next):
             z = noise_sampler(sigma, sigma_next)
@@ -191,7 +192,8 @@ class PowerNoiseItem(CustomNoiseItemBase):
                 offs = current_batch_offset() * planes_per_latent
                 if identity and normalized:
                     # draw + filter + FFT + normalise with a single write of the tensor
-                    return hip_lib.power_noise(filt, shape, seed=seed, stream_id=stream, plane_offset=offs, factor=self.factor)
+                    return hip_lib.power_noise(filt, shape, seed=seed, stream_id=stream, plane_offset=offs, factor=self.factor,
+                                               lookahead=lookahead)
                 noise = hip_lib.power_irfft2(None, filt, shape, seed=seed, stream_id=stream, plane_offset=offs,
                                              partials=partials if (identity and normalized) else None)
             else:

@@ -386,6 +386,18 @@ int sonar_power_irfft2_f32(const float* z, const float* filter, float* out, int6
 int sonar_power_noise_f32(const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
                           uint64_t stream_id, int64_t plane_offset, int rng_group, float factor, float threshold_std_devs,
                           double* partials /*workspace*/, void* stream);
+
+/* sonar_power_noise_f32 with a look-ahead for samplers that call the same generator step after step (consecutive stream ids).
+ * have_stats != 0: `partials` already holds THIS call's statistics (what an earlier call left in its partials_next for exactly this
+ * filter / shape / seed / stream_id / plane_offset / rng_group): the statistics launch is skipped.  partials_next (may be NULL):
+ * receives the statistics of the same call with stream id next_stream_id, computed by the final pass's otherwise idle waves -- pass it
+ * as `partials` with have_stats = 1 if the next call turns out to be that one, ignore it otherwise.  Output bits are those of
+ * sonar_power_noise_f32 either way.  Only where sonar_power_noise_ahead_ok() says 1 (pipelined 128 x 128 path, at most 512 work
+ * units); SONAR_ERR_UNSUPPORTED elsewhere.  Same call site: py/nodes/powernoise.py:338-408 followed by py/utils.py:85-106. */
+int sonar_power_noise_ahead_ok(int64_t planes, int64_t H, int64_t W, int rng_group);
+int sonar_power_noise_ahead_f32(const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
+                                uint64_t stream_id, int64_t plane_offset, int rng_group, float factor, float threshold_std_devs,
+                                double* partials, int have_stats, uint64_t next_stream_id, double* partials_next, void* stream);
 /* the spectrum the two entry points above draw for (seed, stream_id, plane_offset, rng_group):
  * z_out[planes][H][W/2+1] complex64 (tests / replaying a device draw) */
 int sonar_power_spectrum_f32(float* z_out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,

@@ -13,8 +13,14 @@ filt = (torch.rand(H, W // 2 + 1, device=dev) + 0.5).contiguous()
 out = torch.empty(planes, H, W, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
 lib.sonar_power_irfft2_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+lib.sonar_power_noise_ahead_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
+AHEAD = os.environ.get("SONAR_TRACE_AHEAD", "0") == "1"  # the normalised call with the look-ahead statistics in the idle corners
+ws = [torch.zeros(2048, dtype=torch.float64, device=dev) for _ in range(2)]
 def launch():
-    assert lib.sonar_power_irfft2_f32(None, filt.data_ptr(), out.data_ptr(), planes, H, W, 1, 2, 0, 4, None, stream) == 0
+    if AHEAD:
+        assert lib.sonar_power_noise_ahead_f32(filt.data_ptr(), out.data_ptr(), planes, H, W, 1, 2, 0, 4, 1.0, 2.5, ws[0].data_ptr(), 0, 3, ws[1].data_ptr(), stream) == 0
+    else:
+        assert lib.sonar_power_irfft2_f32(None, filt.data_ptr(), out.data_ptr(), planes, H, W, 1, 2, 0, 4, None, stream) == 0
 for _ in range(300):
     launch()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,0 +1,114 @@
+"""-m gpu, round 3: the pipelined power-noise kernel and its look-ahead statistics."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(pkg):
+    import types
+
+    pkg.hip_lib.load()
+    return types.SimpleNamespace(hl=pkg.hip_lib, powernoise=importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise"),
+                                 noise=importlib.import_module("comfyui_sonar_amd.py.noise"),
+                                 noise_generation=importlib.import_module("comfyui_sonar_amd.py.noise_generation"),
+                                 utils=importlib.import_module("comfyui_sonar_amd.py.utils"))
+
+
+def _item(pn, factor=1.0, channels="1,1,1,1,1,1"):
+    return pn.PowerNoiseItem(factor, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                             common_mode=0.0, channel_correlation=channels)
+
+
+def _filter(api, shape):
+    return _item(api.powernoise).make_filter(shape).to("cuda", torch.float32).reshape(shape[-2], shape[-1] // 2 + 1).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(512, 4, 128, 128), (96, 4, 128, 128), (171, 3, 128, 128), (65, 4, 128, 128), (300, 4, 128, 128)])
+def test_pipelined_power_kernel_equals_the_phase_serial_kernel(api, shape, monkeypatch):
+    """The pipelined generate kernel (drawing team / transforming team, planes > 256) against the spectrum the same streams dump and
+    torch's irfft2 (sampled planes), and normalised == (raw - mean) / std of the raw call: what the phase-serial kernel is tested on."""
+    hl = api.hl
+    filt = _filter(api, shape)
+    planes = shape[0] * shape[1]
+    raw = hl.power_irfft2(None, filt, shape, seed=11, stream_id=5, plane_offset=0)
+    spec = hl.power_spectrum(shape, "cuda", seed=11, stream_id=5)
+    for pl in (0, 1, 255, 256, planes // 2 + 3, planes - 1):
+        z = spec.reshape(planes, 128, 65)[pl] * filt
+        want = torch.fft.irfft2(z, s=(128, 128), norm="ortho")
+        got = raw.reshape(planes, 128, 128)[pl]
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item(), pl
+    norm = hl.power_noise(filt, shape, seed=11, stream_id=5, plane_offset=0, factor=0.75)
+    d = raw.double()
+    want = ((d - d.mean()) / d.std()).float() * 0.75
+    torch.testing.assert_close(norm, want, rtol=2e-5, atol=2e-6)
+    # two shards of the batch are the batch (stream keys are global plane groups; only for latent counts a shard cut can halve)
+    if shape[0] % 2 == 0:
+        half = shape[0] // 2
+        a = hl.power_irfft2(None, filt, (half, *shape[1:]), seed=11, stream_id=5, plane_offset=0)
+        b = hl.power_irfft2(None, filt, (half, *shape[1:]), seed=11, stream_id=5, plane_offset=half * shape[1])
+        assert torch.equal(torch.cat([a, b]), raw)
+
+
+@pytest.mark.parametrize("shape", [(512, 4, 128, 128), (128, 4, 128, 128), (100, 3, 128, 128)])
+def test_lookahead_statistics_are_the_statistics_kernels(api, shape):
+    """The statistics a call leaves for the next stream id == what the statistics launch of that call computes (same pairs, bit for bit:
+    one unit per slot, the same order of additions), and a call that uses them writes the same tensor."""
+    hl = api.hl
+    lib = hl.load()
+    filt = _filter(api, shape)
+    planes = shape[0] * shape[1]
+    group = hl.rng_group_for(shape)
+    assert lib.sonar_power_noise_ahead_ok(planes, 128, 128, group) == 1
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call(stream_id, ws, have, nxt, nws):
+        out = torch.empty(shape, device="cuda")
+        rc = lib.sonar_power_noise_ahead_f32(filt.data_ptr(), out.data_ptr(), planes, 128, 128, 3, stream_id, 0, group, 1.0, 2.5, ws.data_ptr(), int(have),
+                                             nxt, 0 if nws is None else nws.data_ptr(), st)
+        assert rc == 0, lib.sonar_last_error()
+        return out
+
+    ws7, ws8, ws8b = (torch.full((2 * hl.NPART,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3))
+    out7 = call(7, ws7, False, 8, ws8)           # statistics launch for stream 7, look-ahead for stream 8
+    out8_plain = call(8, ws8b, False, 9, None)    # statistics launch for stream 8
+    assert torch.equal(ws8, ws8b) and not bool(torch.isnan(ws8).any())
+    out8_ahead = call(8, ws8, True, 9, None)      # no statistics launch: the look-ahead's pairs
+    assert torch.equal(out8_ahead, out8_plain)
+    assert torch.equal(out7, hl.power_noise(filt, shape, seed=3, stream_id=7, plane_offset=0, factor=1.0))
+
+
+def test_lookahead_in_the_sampler_hits_and_misses(api):
+    """A sampler called step after step predicts its next stream id (hit: no statistics launch); another device draw in between shifts
+    the stream ids once (one miss; a one-off step is not adopted).  Every call equals the call without look-ahead."""
+    pn, hl, ng = api.powernoise, api.hl, api.noise_generation
+    x = torch.zeros(96, 4, 128, 128, device="cuda")
+    sig = (torch.tensor(14.6), torch.tensor(10.0))
+    states = []
+    real = hl.PowerLookahead
+
+    class Spy(real):
+        def __init__(self):
+            super().__init__()
+            states.append(self)
+
+    hl.PowerLookahead = Spy
+    try:
+        torch.manual_seed(21)
+        ns = _item(pn).make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)
+        got = [ns(*sig).clone() for _ in range(3)]
+        ng.DeviceRNG.take()                      # somebody else draws: the stream ids shift by one
+        got += [ns(*sig).clone() for _ in range(2)]
+    finally:
+        hl.PowerLookahead = real
+    look = states[-1]
+    assert (look.hits, look.misses) == (3, 2)   # calls 2, 3 and 5 hit; call 1 (nothing known) and call 4 (shifted) miss
+    torch.manual_seed(21)
+    filt = _filter(api, tuple(x.shape))
+    seed, first = ng.DeviceRNG.take(0)
+    streams = [first, first + 1, first + 2, first + 4, first + 5]
+    for g, stream in zip(got, streams):
+        assert torch.equal(g, hl.power_noise(filt, tuple(x.shape), seed=seed, stream_id=stream, plane_offset=0, factor=1.0))
