@@ -7,7 +7,11 @@
 Metric (BASELINE.json): noise-latents/sec on SDXL 4x128x128 latents.  One "step" = one call of the normalised power-law (pink,
 alpha = 1) rFFT noise sampler for a batch of 512 latents per GPU (cfg2 of BASELINE.json at the north_star's batch), through the
 reference's plugin API (PowerNoiseItem.make_noise_sampler -> ns(sigma, sigma_next)), generate mode (cpu=False: spectrum drawn
-in-kernel, nothing read from HBM but the 33 KB filter).  N > 1: one process per GPU, every rank generates its own 512-latent
+in-kernel, nothing read from HBM but the 33 KB filter).  A step's launches: the pipelined final pass (draw, filter, LDS-resident C2R
+FFT, normalise, ONE write), which also computes the Parseval statistics of the call the sampler expects next in its idle waves; the
+statistics launch of a call only runs when that expectation failed (the first call of a sampler).  Every step therefore does one
+statistics computation and one final pass, as before -- the statistics of step k are computed during step k - 1.  `--no-lookahead`
+times the two-launch form (statistics launch + final pass per call); `extra.power_noise_two_launch_us` reports it either way.  N > 1: one process per GPU, every rank generates its own 512-latent
 shard of one logical N*512 batch (weak scaling, no data-path collective; shard-invariant counters) — the only collectives are the
 timing barrier / max, and, outside `value`, the optional final gather (RCCL all-gather vs direct peer copies).
 
@@ -47,7 +51,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+if not os.path.exists(TRAFFIC_FILE):
+    TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 BATCH = 512
 C, H, W = 4, 128, 128
 N_LATENT = C * H * W
@@ -300,6 +306,8 @@ def main():
     ap.add_argument("--prewarm", type=int, default=1000,
                     help="untimed steps before the W warm-up steps: the GPU reaches its sustained clocks after ~30 ms of work "
                          "(scratch/warm_curve.py: 67 us per step cold, 60.5 us from step ~400 on)")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="every call launches its own statistics pass (the sampler is given no PowerLookahead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -360,7 +368,12 @@ def main():
     sig = (torch.tensor(14.6), torch.tensor(10.0))
     out = None
     with ng.shard_offset(rank * BATCH):  # this rank's slice of the logical N*512 batch
-        ns = power_item(pn).make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)
+        def make_sampler(lookahead):
+            item = power_item(pn)
+            item.stats_lookahead = lookahead
+            return item.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)
+
+        ns = make_sampler(not args.no_lookahead)
 
         def step():
             return ns(*sig)
@@ -407,8 +420,9 @@ def main():
             value = n_gpus * BATCH * args.steps / elapsed
             pair_us = pair_us_max  # N > 1: the slowest rank's launch pair; every rank runs the same pair on its own shard
             peak = HBM_PEAK_GBPS * n_gpus  # the job's roofline: N x 8 TB/s
-            # sonar_power_noise_f32 = statistics pass (re-draw of the radius words, Parseval, no stores) + final pass (draw, filter,
-            # LDS-resident C2R FFT, normalise, ONE write): 4N bytes per latent really cross HBM (profiles/r02_traffic.json).
+            # one call = the final pass (draw, filter, LDS-resident C2R FFT, normalise, ONE write) + one statistics computation (re-draw
+            # of the radius words, Parseval, no stores: in the final pass's idle waves, or its own launch): 4N bytes per latent really
+            # cross HBM (profiles/r03_traffic.json)
             real_bytes = 4 * N_LATENT * BATCH * n_gpus  # all ranks' launches together
             contract_bytes = 12 * N_LATENT * BATCH * n_gpus
             achieved = real_bytes / (pair_us * 1e-6) / 1e9
@@ -420,10 +434,12 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "cfg2: power-law (pink, alpha=1) rFFT noise, normalised, SDXL 4x128x128, batch 512 per GPU, "
                                        "generate mode (in-kernel Philox-seeded xoshiro128++)", "batch_per_gpu": BATCH, "global_batch": BATCH * n_gpus, "prewarm_steps": max(args.prewarm, 0),
+                           "stats_lookahead": not args.no_lookahead,
                            "parallelism": f"batch-shard x{n_gpus}"},
-                "roofline": {"bound": "valu", "limiter": "vector-ALU issue + LDS / barrier latency (per-pass timings and counters: profiles/r02_power_kernel.md); "
-                                                         "HBM moves 4N per latent and would allow ~21 us per launch",
-                             "kernel": "power_stats_kernel<128,128> + power_irfft2_kernel<128,128,GEN,NORM> (one C-ABI call)",
+                "roofline": {"bound": "valu", "limiter": "vector-ALU issue + LDS / barrier latency of two 8-wave teams per CU (phase timeline and counters: "
+                                                         "profiles/r03_power_kernel.md); HBM moves 4N per latent and would allow ~21 us per launch",
+                             "kernel": "power_pipe_kernel<128,128,NORM> with the next call's statistics in its idle waves (one C-ABI call, "
+                                       "sonar_power_noise_ahead_f32); --no-lookahead: power_stats_kernel<128,128> + power_pipe_kernel",
                              "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                              "traffic": tr.get("power_noise_b512", {}).get("hbm_bytes_per_launch"), "bytes_per_launch": real_bytes,
                              "avg_launch_us": pair_us, "achieved_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9,
@@ -436,6 +452,10 @@ def main():
             }
     if rank == 0 and n_gpus == 1 and not args.no_extra:
         kernels, extra = secondary_rows(device, hl, pn, ng, nz, x, sig)
+        ns_two = make_sampler(False)
+        extra["power_noise_two_launch_us"] = event_us(lambda: ns_two(*sig), 100, 300)
+        ns_one = make_sampler(True)
+        extra["power_noise_lookahead_us"] = event_us(lambda: ns_one(*sig), 100, 300)
         out["roofline"]["kernels"] = kernels
         out["extra"] = extra
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

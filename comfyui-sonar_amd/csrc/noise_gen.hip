@@ -817,6 +817,13 @@ __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, in
 // floats), so an output needs, per level, two conflict-free 16-byte reads and two FMAs per value instead of four gathers, a
 // coordinate-table read and eleven arithmetic instructions; the level weight is folded into the y weights.
 constexpr size_t kPyramidLdsBudget = 64 * 1024;
+#ifndef SONAR_PYR_UNROLL_N
+#define SONAR_PYR_UNROLL_N 1
+#endif
+#define SONAR_PYR_PRAGMA(x) _Pragma(#x)
+#define SONAR_PYR_UNROLL_(n) SONAR_PYR_PRAGMA(unroll n)
+#define SONAR_PYR_UNROLL_X(n) SONAR_PYR_UNROLL_(n)
+#define SONAR_PYR_UNROLL SONAR_PYR_UNROLL_X(SONAR_PYR_UNROLL_N)
 
 // fold (nullable y): the values are folded into a chain's running sum, out == fold.y (sonar_pyramid_generate_acc_f32); PRE != 0: the
 // chain's previous item rides along (Prefix above) -- its generator shares this kernel's tile keying, so its state simply walks the
@@ -906,6 +913,9 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
         // the shared tile too and each keeps its own part)
         const int64_t g0 = elem_offset + p * (int64_t)HW;
         const int64_t tile_first = g0 / kTileElems, tile_last = (g0 + HW - 1) / kTileElems;
+#ifdef SONAR_PYR_SETUP_ONLY  // profiling builds: what the per-plane setup (grids, tables, stretched rows) costs
+        if (oplane != nullptr) continue;
+#endif
         for (int64_t t = tile_first + wave; t <= tile_last; t += kBlock / 64) {
             Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)t, lane);
             Xoshiro prng;
@@ -913,6 +923,7 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
             int e = (int)(t * kTileElems - g0) + (int)lane * 4;  // element index inside the plane; < 0 or >= HW: not ours
             int y = e >= 0 ? e / W : -((-e + W - 1) / W);        // floor
             int x4 = e - y * W;
+SONAR_PYR_UNROLL
             for (int it = 0; it < kTileIters; ++it, e += 256, y += dy, x4 += dx, y += x4 >= W, x4 -= x4 >= W ? W : 0) {
                 float v[4];
                 rng.normal4(v);

@@ -184,7 +184,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950). There is no non-HIP implementation of this path."
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(os.environ.get("SONAR_HIP_LIB") or LIB_PATH)  # the override is for A/B timing of profiling builds (scratch/)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.restype = restype

@@ -151,6 +151,8 @@ def _device_irfft2_fallback_error(h, w):
 class PowerNoiseItem(CustomNoiseItemBase):
     """py/nodes/powernoise.py:297-408."""
 
+    stats_lookahead = True  # device-drawn, normalised calls: see hip_lib.power_noise(lookahead=...)
+
     def __init__(self, factor, *, channel_correlation, power_filter=None, **kwargs):
         if isinstance(channel_correlation, str):
             vals = tuple(float(v) for v in (v.strip() for v in channel_correlation.split(",")) if v)
@@ -178,7 +180,9 @@ class PowerNoiseItem(CustomNoiseItemBase):
         identity = mixer.is_identity
         mixer.to(device)
         planes_per_latent = math.prod(shape[1:-2])  # 5-D (video) latents: every [H, W] slice is a plane, as in the reference's irfft2
-        lookahead = hip_lib.PowerLookahead()  # a sampler's calls take consecutive stream ids: each leaves the next one's statistics
+        # a sampler's calls take consecutive stream ids: each call leaves the next one's statistics (`stats_lookahead = False` on the item
+        # or the class: every call launches its own statistics pass)
+        lookahead = hip_lib.PowerLookahead() if self.stats_lookahead else None
 
         def sampler(sigma, sigma_next):
             z = noise_sampler(sigma, sigma_next)

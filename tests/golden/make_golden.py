@@ -648,6 +648,47 @@ def gen_cfg5():
     save("cfg5", x0=x0, sigmas=sigmas, trace_steps=torch.tensor([1, 3]), trace=torch.stack([trace[1], trace[3]]), out=out)
 
 
+def cfg5_full_chain(mod_noise, mod_pn):
+    """BASELINE.json cfg5's noise at the Flux latent's real size: ScheduledNoise over a power-law + Perlin + third-source chain with a
+    Gaussian fallback, normalised.  The third source is Gaussian here (the configured Brownian one delegates to torchsde, which the
+    image lacks): the chain arithmetic, the scheduling and the normalisation around it are the configured ones."""
+    inner = mod_noise.CustomNoiseChain()
+    inner.add(mod_pn.PowerNoiseItem(0.5, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0,
+                                    mix=1.0, common_mode=0.0, channel_correlation="1"))
+    inner.add(mod_noise.CustomNoiseItem(0.3, noise_type="perlin"))
+    inner.add(mod_noise.CustomNoiseItem(0.2, noise_type="gaussian"))
+    fallback = mod_noise.CustomNoiseChain()
+    fallback.add(mod_noise.CustomNoiseItem(1.0, noise_type="gaussian"))
+    chain = mod_noise.CustomNoiseChain()
+    chain.add(mod_noise.ScheduledNoise(1.0, noise=inner, start_sigma=20.0, end_sigma=0.0, normalize=None, fallback_noise=fallback))
+    return chain
+
+
+def gen_cfg5_full():
+    """cfg5 at 2 x 16 x 128 x 128 through the REAL reference: two SonarDPMPPSDE steps with momentum 0.95 (four noise calls).  The latent
+    is re-created from its seed by the test; stored: every fourth pixel of the result and of one noise call, and fp64 plane sums of
+    both (whole-tensor evidence in 300 KB)."""
+    S, N, pn = ref.sonar, ref.noise, ref.powernoise
+    shape = (2, 16, 128, 128)
+    torch.manual_seed(71)
+    x0 = torch.randn(shape) * 10.0
+    sigmas = torch.tensor([10.0, 7.0, 4.0, 0.0])
+    torch.manual_seed(72)
+    ns = cfg5_full_chain(N, pn).make_noise_sampler(x0, sigmas[sigmas > 0].min(), sigmas.max(), seed=5, cpu=True, normalized=True)
+    calls = []
+
+    def spy(s, sn):
+        out = ns(s, sn)
+        calls.append(out.clone())
+        return out
+
+    out = S.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas[:3], {"seed": 5}, None, True, None, dict(momentum=0.95), 1.0, 1.0, spy)
+    assert len(calls) == 4
+    save("cfg5_full", sigmas=sigmas, out_sub=out[..., ::4, ::4].contiguous(), out_plane_sums=out.double().sum(dim=(-2, -1)),
+         out_plane_sq=(out.double() ** 2).sum(dim=(-2, -1)), noise_sub=calls[1][..., ::4, ::4].contiguous(),
+         noise_plane_sums=calls[1].double().sum(dim=(-2, -1)), noise_plane_sq=(calls[1].double() ** 2).sum(dim=(-2, -1)))
+
+
 # ------------------------------------------------------------------------------------------------ guidance (SURVEY 8f rank 1)
 GUIDANCE_CASES = {
     "linear": dict(guidance_type="LINEAR", factor=0.05, start_step=1, end_step=4),
@@ -1146,6 +1187,7 @@ if __name__ == "__main__" and "--nodes-only" not in sys.argv:
     gen_latent_ops()
     gen_spectral()
     gen_cfg5()
+    gen_cfg5_full()
     gen_guidance()
     gen_video()
     gen_wavelet_noise()

@@ -112,3 +112,46 @@ def test_lookahead_in_the_sampler_hits_and_misses(api):
     streams = [first, first + 1, first + 2, first + 4, first + 5]
     for g, stream in zip(got, streams):
         assert torch.equal(g, hl.power_noise(filt, tuple(x.shape), seed=seed, stream_id=stream, plane_offset=0, factor=1.0))
+
+
+def test_cfg5_at_the_flux_latents_size_against_the_reference(api, golden):
+    """BASELINE.json cfg5 at 2 x 16 x 128 x 128 against the REAL reference (tests/golden/make_golden.py gen_cfg5_full): the scheduled
+    power-law + Perlin + third-source chain, normalised, through two SonarDPMPPSDE steps with momentum (four noise calls), replay mode.
+    The third source is Gaussian (the configured Brownian one needs torchsde, absent from the image): chain arithmetic, scheduling and
+    normalisation at the full size are pinned here, not only in the 32 x 32 miniature.  Compared: every fourth pixel of the result and
+    of one noise call, and the fp64 plane sums / sums of squares of the whole tensors."""
+    g = golden("cfg5_full")
+    N, pn = api.noise, api.powernoise
+    S = importlib.import_module("comfyui_sonar_amd.py.sonar")
+
+    def fake_model(x, sigma, **_kw):  # tests/golden/make_golden.py fake_model
+        s = sigma.reshape(-1, *([1] * (x.ndim - 1)))
+        return x * 0.5 + torch.tanh(x) * (0.1 * s / (1.0 + s))
+
+    inner = N.CustomNoiseChain()
+    inner.add(_item(pn, 0.5, "1"))
+    inner.add(N.CustomNoiseItem(0.3, noise_type="perlin"))
+    inner.add(N.CustomNoiseItem(0.2, noise_type="gaussian"))
+    fallback = N.CustomNoiseChain()
+    fallback.add(N.CustomNoiseItem(1.0, noise_type="gaussian"))
+    chain = N.CustomNoiseChain()
+    chain.add(N.ScheduledNoise(1.0, noise=inner, start_sigma=20.0, end_sigma=0.0, normalize=None, fallback_noise=fallback))
+    torch.manual_seed(71)
+    x0 = (torch.randn(2, 16, 128, 128) * 10.0).cuda()
+    sigmas = g["sigmas"]
+    torch.manual_seed(72)
+    ns = chain.make_noise_sampler(x0, sigmas[sigmas > 0].min(), sigmas.max(), seed=5, cpu=True, normalized=True)
+    calls = []
+
+    def spy(s, sn):
+        out = ns(s, sn)
+        calls.append(out.clone())
+        return out
+
+    out = S.SonarDPMPPSDE.sampler(fake_model, x0.clone(), sigmas[:3], {"seed": 5}, None, True, None, dict(momentum=0.95), 1.0, 1.0, spy)
+    assert len(calls) == 4
+    for got, tag, tol in ((calls[1], "noise", 5e-5), (out, "out", 3e-4)):
+        torch.testing.assert_close(got[..., ::4, ::4].cpu(), g[f"{tag}_sub"], rtol=tol, atol=tol)
+        d = got.double()
+        torch.testing.assert_close(d.sum(dim=(-2, -1)).cpu(), g[f"{tag}_plane_sums"], rtol=0, atol=128 * 128 * tol * 0.05)
+        torch.testing.assert_close((d * d).sum(dim=(-2, -1)).cpu(), g[f"{tag}_plane_sq"], rtol=2 * tol, atol=0)
