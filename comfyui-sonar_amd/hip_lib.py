@@ -1044,11 +1044,20 @@ def spectral_filter(x: torch.Tensor, filt: torch.Tensor, partials: Optional[torc
 
 
 def rfft2(x: torch.Tensor) -> torch.Tensor:
-    """torch.fft.rfft2(x) (unscaled) over the last two dims as a complex64 tensor [..., H, W/2+1]; LDS-resident, power-of-two planes."""
+    """torch.fft.rfft2(x) (unscaled) over the last two dims as a complex64 tensor [..., H, W/2+1]: LDS-resident for the power-of-two
+    planes, two direct passes (rows r2c, columns) for every other size (lines of at most 2048)."""
     H, W = int(x.shape[-2]), int(x.shape[-1])
-    z = torch.empty((*x.shape[:-1], W // 2 + 1), dtype=torch.complex64, device=x.device)
+    K = W // 2 + 1
+    z = torch.empty((*x.shape[:-1], K), dtype=torch.complex64, device=x.device)
     _dev(x, "x")
-    _check(load().sonar_rfft2_f32(x.data_ptr(), z.data_ptr(), x.numel() // (H * W), H, W, _stream()), "sonar_rfft2_f32")
+    planes = x.numel() // (H * W)
+    lib = load()
+    if int(lib.sonar_power_plane_kind(H, W)) == 1:
+        _check(lib.sonar_rfft2_f32(x.data_ptr(), z.data_ptr(), planes, H, W, _stream()), "sonar_rfft2_f32")
+        return z
+    rows = torch.empty_like(z)
+    _check(lib.sonar_dft_rows_r2c_f32(x.data_ptr(), rows.data_ptr(), planes * H, W, _stream()), "sonar_dft_rows_r2c_f32")
+    _check(lib.sonar_dft_cols_f32(rows.data_ptr(), None, z.data_ptr(), planes, H, K, 0, _stream()), "sonar_dft_cols_f32")
     return z
 
 

@@ -1006,9 +1006,9 @@ def _spectral_signum(noise: Tensor, k: float, intensity: float, which: int, perc
         la, full = hip_lib.spectral_logamp(z.reshape(b * c, h, w), b * c, 1, h, w)
         gain, plane_elems = 1.0 / c, h * w
     else:
-        if not (hip_lib.power_supported(h, w) and int(hip_lib.load().sonar_power_plane_kind(h, w)) == 1):
-            raise hip_lib.SonarHipError(f"ModulatedNoise spectral_signum: plane {h}x{w} is not LDS-resident (powers of two, 16..256)")
-        z = hip_lib.rfft2(add)                                          # complex [B, C, H, W/2+1]
+        if not hip_lib.power_supported(h, w):
+            raise hip_lib.SonarHipError(f"ModulatedNoise spectral_signum: plane {h}x{w} is beyond the transform kernels (lines of at most 2048)")
+        z = hip_lib.rfft2(add)                                          # complex [B, C, H, W/2+1]; any plane size
         wz = w // 2 + 1
         if which == 2:
             z = hip_lib.cdft_mid(z, b, c, h * wz, inverse=False)

@@ -910,9 +910,12 @@ class OneFNoiseGenerator(_SpectralGainNoiseGenerator):
         if self.k != 0:
             power = self.k / power
         power[0, 0] = self.base_power
-        if bool((power < 0).any()):
-            raise hip_lib.SonarHipError("onef: negative spectral power (complex gain) is not supported on the HIP path")
-        return 1.0 / (torch.sqrt(power) if self.use_sqrt else power)
+        if not self.use_sqrt:
+            return 1.0 / power
+        # the reference divides the spectrum by sqrt(power) in COMPLEX arithmetic (py/noise_generation.py:752-757): where the power is
+        # negative the divisor is imaginary, the (Hermitian) spectrum of the real noise turns anti-Hermitian there, and those frequencies
+        # vanish from the real part it returns -- a gain of zero
+        return torch.where(power < 0, torch.zeros_like(power), 1.0 / torch.sqrt(power.clamp_min(0.0)))
 
     def generate(self, *_args):
         partials = hip_lib.new_partials(self.device)

@@ -326,19 +326,18 @@ class SonarGuidanceMixin:
     def guidance_shift(cls, t: Tensor, ref_latent: Tensor, *, dim=None) -> Tensor:
         if dim is None:
             dim = tuple(range(-(t.ndim - 1), 0))
-        dims = sorted(d % t.ndim for d in dim)
-        if dims != list(range(t.ndim - len(dims), t.ndim)):
-            raise hip_lib.SonarHipError("guidance_shift: dim must be the trailing dimensions on the HIP path")
+        dims = sorted({d % t.ndim for d in dim})
+        t32, inverse = utils.dims_last(utils.as_f32(t), dims)  # any dim tuple: the statistics of a transposed copy
         inner = 1
-        for d in dims:
-            inner *= t.shape[d]
-        t32 = utils.as_f32(t)
+        for d in range(t32.ndim - len(dims), t32.ndim):
+            inner *= t32.shape[d]
         rows = t32.numel() // inner
         avg, std = hip_lib.rowstats(t32, rows, inner)
         ref = utils.as_f32(ref_latent.to(t.device))
-        if ref.shape != t32.shape:
-            ref = ref.expand_as(t32).contiguous()
-        return hip_lib.row_affine(1, ref, rows, inner, avg, std)
+        if ref.shape != t.shape:
+            ref = ref.expand(t.shape)
+        ref, _ = utils.dims_last(ref, dims)
+        return utils.dims_restore(hip_lib.row_affine(1, ref, rows, inner, avg, std), inverse)
 
     @classmethod
     def guidance_euler(cls, sigma, sigma_next, x, denoised, ref_latent, factor: float = 0.2, *, do_shift: bool = True) -> Tensor:

@@ -105,18 +105,32 @@ def scale_noise(noise: Tensor, factor: float = 1.0, *, normalized: bool = True, 
         raise hip_lib.SonarHipError("scale_noise: expects a contiguous float32 tensor")
     if normalize_dims is not None:
         pop_stats(noise)
-        dims = sorted(d % noise.ndim for d in normalize_dims)
-        if dims != list(range(noise.ndim - len(dims), noise.ndim)):
-            raise hip_lib.SonarHipError("scale_noise: normalize_dims must be the trailing dimensions on the HIP path")
+        rows_last, inverse = dims_last(noise, normalize_dims)
         inner = 1
-        for d in dims:
-            inner *= noise.shape[d]
-        return hip_lib.scale_noise_rows_(noise, n // inner, inner, factor)
+        for d in range(noise.ndim - len({d % noise.ndim for d in normalize_dims}), noise.ndim):
+            inner *= rows_last.shape[d]
+        return dims_restore(hip_lib.scale_noise_rows_(rows_last, n // inner, inner, factor), inverse)
     partials = pop_stats(noise)
     if partials is None:
         partials = hip_lib.stats(noise)
     noise, after = hip_lib.scale_noise_stats_(noise, factor, partials, threshold_std_devs=threshold_std_devs)
     return attach_stats(noise, after)  # a wrapper that normalises this result again skips its statistics sweep
+
+
+def dims_last(t: Tensor, dims):
+    """(tensor with the dimensions ``dims`` moved to the end and made contiguous, permutation that undoes the move or None).  The row
+    kernels reduce over trailing dimensions; any other choice (the reference takes any ``dim`` tuple: py/utils.py:97-99,452-470,
+    py/sonar.py:372-377) is the same reduction on a transposed copy -- a layout change, no arithmetic."""
+    nd = t.ndim
+    dims = sorted({d % nd for d in dims})
+    if dims == list(range(nd - len(dims), nd)):
+        return t.contiguous(), None
+    perm = [d for d in range(nd) if d not in dims] + dims
+    return t.permute(perm).contiguous(), [perm.index(d) for d in range(nd)]
+
+
+def dims_restore(t: Tensor, inverse) -> Tensor:
+    return t if inverse is None else t.permute(inverse).contiguous()
 
 
 def scale_samples(samples: Tensor, width: int, height: int, *, mode: str = "bicubic") -> Tensor:
@@ -135,16 +149,14 @@ def normalize_to_scale(latent: Tensor, target_min: float, target_max: float, *, 
     """py/utils.py:452-470: per-group min / max (HIP reduction), then rescale + clamp in one kernel."""
     _require_device(latent, "normalize_to_scale")
     x = as_f32(latent)
-    dims = sorted(d % x.ndim for d in dim) if len(dim) else list(range(x.ndim))
-    if dims != list(range(x.ndim - len(dims), x.ndim)):
-        raise hip_lib.SonarHipError("normalize_to_scale: dim must be the trailing dimensions on the HIP path")
+    dims = sorted({d % x.ndim for d in dim}) if len(dim) else list(range(x.ndim))
+    x, inverse = dims_last(x, dims)
     inner = 1
-    for d in dims:
+    for d in range(x.ndim - len(dims), x.ndim):
         inner *= x.shape[d]
     rows = x.numel() // inner
-    x = x.contiguous()
     lo, hi = hip_lib.minmax_rows(x, rows, inner)
-    return hip_lib.minmax_rescale(x, rows, inner, lo, hi, eps, target_min, target_max)
+    return dims_restore(hip_lib.minmax_rescale(x, rows, inner, lo, hi, eps, target_min, target_max), inverse)
 
 
 def normalize_to_scale_adv(t: Tensor, *, min_pos: float, max_pos: float, min_neg: float, max_neg: float, dim=(-3, -2, -1)) -> Tensor:

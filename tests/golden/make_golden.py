@@ -571,7 +571,12 @@ def gen_latent_ops():
 SPECTRAL_TYPES = ("onef_pinkish", "onef_greenish", "onef_pinkishgreenish", "onef_pinkish_mix", "onef_greenish_mix", "green_test",
                   "rainbow_mild", "rainbow_intense", "pink_old")
 ONEF_ADV = {"sqrt": dict(alpha=0.25, k=2.0, hfac=2.0, wfac=0.5, use_sqrt=True), "nosqrt": dict(alpha=1.0, k=0.5, hfac=1.0, wfac=1.0, use_sqrt=False),
-            "k0": dict(alpha=-1.0, k=0.0, hfac=1.0, wfac=1.0, use_sqrt=True)}
+            "k0": dict(alpha=-1.0, k=0.0, hfac=1.0, wfac=1.0, use_sqrt=True),
+            # negative spectral power: its complex square root is imaginary, those frequencies drop out of the real part (use_sqrt), or
+            # the gain is simply negative (no square root)
+            "neg_k": dict(alpha=1.0, k=-1.5, hfac=1.0, wfac=1.0, use_sqrt=True),
+            "neg_base": dict(alpha=0.5, k=1.0, hfac=1.0, wfac=1.0, base_power=-2.0, use_sqrt=True),
+            "neg_k_nosqrt": dict(alpha=1.0, k=-0.75, hfac=1.0, wfac=1.0, base_power=-1.5, use_sqrt=False)}
 
 
 def gen_spectral():
@@ -832,6 +837,10 @@ def gen_modulated():
     save("modulated", **cases)
 
 
+# b1 / b4: LDS-resident power-of-two planes; g1: a general-size plane (SDXL 832 x 1216 px in miniature); o1: an odd plane (direct passes)
+SIGNUM_SHAPES = (("b1", (1, 4, 32, 32)), ("b4", (4, 4, 16, 16)), ("g1", (1, 4, 26, 38)), ("o1", (1, 3, 9, 15)))
+
+
 def gen_spectral_signum():
     """ModulatedNoise spectral_signum (py/noise.py:938-1015): fftn over the modulation dims, per-sample quantiles of |log amplitude|,
     soft clamp of the bins outside the 5 % / 95 % quantiles, inverse.  The reference expands the per-sample quantile vector [B] as
@@ -839,7 +848,7 @@ def gen_spectral_signum():
     cases = {}
     chain = ref.noise.CustomNoiseChain()
     chain.add(ref.noise.CustomNoiseItem(1.0, noise_type="gaussian"))
-    for tag, shape in (("b1", (1, 4, 32, 32)), ("b4", (4, 4, 16, 16))):
+    for tag, shape in SIGNUM_SHAPES:
         for dims in (1, 2, 3):
             for strength in (2.0, -0.7):
                 item = ref.noise.ModulatedNoise(0.9, noise=chain, normalize_result=None, normalize_noise=None, normalize_ref=False,
@@ -1044,6 +1053,19 @@ def gen_resample_modes():
     cases["nts_all"] = ref.utils.normalize_to_scale(t.clone(), 0.25, 0.5, dim=(-4, -3, -2, -1), eps=1e-3)
     cases["nts_inexact"] = ref.utils.normalize_to_scale(t.clone(), 0.1, 0.3)  # targets that are not fp32 numbers: span = fp32(0.3 - 0.1)
     save("resample_modes", **cases)
+    # reductions over dimensions that are not the trailing ones (py/utils.py:97-99,452-470, py/sonar.py:372-377)
+    nt = {"t": t}
+    nt["nts_c"] = ref.utils.normalize_to_scale(t.clone(), -1.0, 1.0, dim=(1,))
+    nt["nts_bh"] = ref.utils.normalize_to_scale(t.clone(), 0.0, 2.0, dim=(0, 2))
+    tn = torch.randn(3, 4, 9, 7, generator=g) * 1.7 + 0.3
+    nt["sn_in"] = tn
+    nt["sn_c"] = ref.utils.scale_noise(tn.clone(), 0.8, normalize_dims=(1,))
+    nt["sn_bw"] = ref.utils.scale_noise(tn.clone(), 1.25, normalize_dims=(0, 3))
+    rl = torch.randn(3, 4, 9, 7, generator=g)
+    nt["gs_ref"] = rl
+    nt["gs_c"] = ref.sonar.SonarGuidanceMixin.guidance_shift(tn.clone(), rl.clone(), dim=(1,))
+    nt["gs_bhw"] = ref.sonar.SonarGuidanceMixin.guidance_shift(tn.clone(), rl.clone(), dim=(0, 2, 3))
+    save("nontrailing", **nt)
 
 
 # ------------------------------------------------------------------------------------------------ every registry type on odd shapes

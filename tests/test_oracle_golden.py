@@ -228,7 +228,10 @@ def test_latent_ops(golden):
 SPECTRAL_TYPES = ("onef_pinkish", "onef_greenish", "onef_pinkishgreenish", "onef_pinkish_mix", "onef_greenish_mix", "green_test",
                   "rainbow_mild", "rainbow_intense", "pink_old")
 ONEF_ADV = {"sqrt": dict(alpha=0.25, k=2.0, hfac=2.0, wfac=0.5, use_sqrt=True), "nosqrt": dict(alpha=1.0, k=0.5, hfac=1.0, wfac=1.0, use_sqrt=False),
-            "k0": dict(alpha=-1.0, k=0.0, hfac=1.0, wfac=1.0, use_sqrt=True)}
+            "k0": dict(alpha=-1.0, k=0.0, hfac=1.0, wfac=1.0, use_sqrt=True),
+            "neg_k": dict(alpha=1.0, k=-1.5, hfac=1.0, wfac=1.0, use_sqrt=True),
+            "neg_base": dict(alpha=0.5, k=1.0, hfac=1.0, wfac=1.0, base_power=-2.0, use_sqrt=True),
+            "neg_k_nosqrt": dict(alpha=1.0, k=-0.75, hfac=1.0, wfac=1.0, base_power=-1.5, use_sqrt=False)}
 
 
 def test_spectral_gain_generators(golden):
