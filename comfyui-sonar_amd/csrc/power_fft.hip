@@ -379,6 +379,14 @@ __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const fl
     }
 }
 
+// the 8-wave passes of the pipelined kernel below, shared with the 128-row fast path here (defined with power_pipe_kernel)
+template <int H, int W, int NW>
+__device__ __forceinline__ void pipe_col_b(const c32* X, c32* Y, int w, int lane);
+template <int H, int W, int NW, bool INPLACE = false>
+__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane, const c32 (&gtw)[8], const c32 (&ptw)[8]);
+template <int H, int W, int NW, bool STATS, bool NORM>
+__device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, int lane, float scale, float nm, float nc, double& s, double& q);
+
 // SRC: 0 = spectrum `z` supplied (replay), 1 = spectrum drawn on device, 2 = `z` is a REAL H x W plane: forward r2c FFT in
 // LDS, x filter, then the same inverse (spectral filter: out = irfft2(rfft2(x) * filter), py/nodes/powernoise.py:356-366)
 template <int H, int W, int SRC, bool STATS, bool NORM>
@@ -396,6 +404,8 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
     // (no s_load / lgkmcnt(0) stall inside the passes); the column split is H = (H/8) x 8 instead of 8 x (H/8).
     constexpr bool FAST = (W == 128) && (H == 128 || H == 64) && (NT == 512) && !SONAR_FFT_TW_LDS;
     constexpr int CN1 = FAST ? H / 8 : C::CN1, CN2 = FAST ? 8 : C::CN2;
+    // (Measured dead end, round 3: fusing the spectral filter's last forward column pass, the filter and the inverse's first column pass
+    // in registers -- the same 16 rows of a column per thread -- spills at the 128-register cap: 107 us instead of 94 per 512 latents.)
     __shared__ c32 A[C::kLdsComplex];
     c32* const T0 = A + H * S;      // raw column kx = 0
     c32* const TM = T0 + H;         // raw column kx = M
@@ -652,6 +662,14 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             SONAR_STAMP(4);
             __syncthreads();
             SONAR_STAMP(5);
+            if constexpr (H == 128) {
+            // ------------------------------------------------------------ the pipelined kernel's passes: all LDS operands requested up
+            // front, row pass a leaves element (k1, n2) at column 8 n2 + k1 for the 16-byte stores of pass b
+            if constexpr (!(SONAR_PW_SKIP & 2)) pipe_col_b<H, W, 8>(A, A, wv, lane);  // in place: an item reads and writes the same 8 rows of its column
+            __syncthreads();
+            if constexpr (!(SONAR_PW_SKIP & 4)) pipe_row_a<H, W, 8, true>(A, A, wv, lane, gtw, ptw);
+            __syncthreads();
+            } else {
             // ------------------------------------------------------------ columns, pass b: radix 8, rows 8 k1 .. 8 k1 + 7
 #pragma unroll
             for (int it = 0; it < ((SONAR_PW_SKIP & 2) ? 0 : CN1 / 8); ++it) {
@@ -704,6 +722,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             SONAR_STAMP(9);
             __syncthreads();
             SONAR_STAMP(10);
+            }  // H != 128
         } else {
         // ---------------------------------------------------------------- columns, pass a
         // Column 0 is built on the fly from the raw kx = 0 / kx = M columns:
@@ -809,6 +828,12 @@ SONAR_UNROLL_ITEMS
         }
         // ---------------------------------------------------------------- rows, pass b -> global
         float* const oplane = out + plane * (int64_t)H * W;
+        if constexpr (FAST && H == 128) {
+            pipe_row_b<H, W, 8, STATS, NORM>(A, oplane, wv, lane, scale, nm, nc, s, q);
+            SONAR_STAMP(11);
+            ++pidx;
+            continue;
+        }
         float ps = 0.0f, pq = 0.0f;  // per-plane fp32 partials (<= 64 values per thread), folded into fp64 below
 SONAR_UNROLL_ITEMS
         for (int item = tid; item < RN1 * H; item += NT) {
@@ -947,44 +972,68 @@ __device__ __forceinline__ void pipe_col_b(const c32* X, c32* Y, int w, int lane
 }
 
 // rows, pass a (c2r pre-twiddle fused): residue n2 = w % 8 (its twiddles are wave-uniform: scalar registers), rows lane + 64 it; Y -> X,
-// element (k1, n2) of a row lands at column 8 n2 + k1
-template <int H, int W, int NW>
+// element (k1, n2) of a row lands at column 8 n2 + k1.  INPLACE (one plane buffer, X == Y: the phase-serial kernel): a workgroup barrier
+// between the loads and the stores
+template <int H, int W, int NW, bool INPLACE>
 __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane, const c32 (&gtw)[8], const c32 (&ptw)[8]) {
     using C = PlaneCfg<H, W>;
     constexpr int M = C::M, S = C::S, RN1 = C::RN1, RN2 = C::RN2, ROWS = H / 64, ITEMS = ROWS * 8 / NW;
     static_assert(RN1 == 8 && RN2 == 8 && (NW == 8 || NW == 8 * ROWS), "one residue per wave");
     const int n2 = w & 7, it0 = NW == 8 ? 0 : w >> 3;
-    c32 xa[ITEMS][RN1], xb[ITEMS][RN1];
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
+    auto load = [&](int it, c32 (&xa)[RN1], c32 (&xb)[RN1]) {
         const c32* row = Y + (lane + 64 * (it0 + it)) * S;
 #pragma unroll
         for (int n1 = 0; n1 < RN1; ++n1) {
             const int k = RN2 * n1 + n2;
             if (k == 0) {  // uniform: residue 0, n1 = 0 -- the packed column holds Re = column 0, Im = column M
                 const c32 p = row[0];
-                xa[it][n1] = make_float2(p.x, 0.0f);
-                xb[it][n1] = make_float2(p.y, 0.0f);
+                xa[n1] = make_float2(p.x, 0.0f);
+                xb[n1] = make_float2(p.y, 0.0f);
             } else {
-                xa[it][n1] = row[k];
-                xb[it][n1] = row[M - k];
+                xa[n1] = row[k];
+                xb[n1] = row[M - k];
             }
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        c32 g[RN1];
+    };
+    auto transform = [&](const c32 (&xa)[RN1], const c32 (&xb)[RN1], c32 (&g)[RN1]) {
 #pragma unroll
         for (int n1 = 0; n1 < RN1; ++n1) {
-            const c32 xc = make_float2(xb[it][n1].x, -xb[it][n1].y);  // conj
-            g[n1] = cadd_i(cadd(xa[it][n1], xc), cmul(csub(xa[it][n1], xc), gtw[n1]));
+            const c32 xc = make_float2(xb[n1].x, -xb[n1].y);  // conj
+            g[n1] = cadd_i(cadd(xa[n1], xc), cmul(csub(xa[n1], xc), gtw[n1]));
         }
         idft<RN1>(g);
 #pragma unroll
         for (int k1 = 1; k1 < RN1; ++k1) g[k1] = cmul(g[k1], ptw[k1]);
+    };
+    auto store = [&](int it, const c32 (&g)[RN1]) {
 #pragma unroll
         for (int k1 = 0; k1 < RN1; ++k1) X[(lane + 64 * (it0 + it)) * S + RN1 * n2 + k1] = g[k1];
+    };
+    if constexpr (INPLACE) {
+        // one plane buffer: only the ITEMS x 8 results cross the barrier (the operands of both items would: 64 registers beside the
+        // phase-serial kernel's draw state)
+        c32 g[ITEMS][RN1];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            c32 xa[RN1], xb[RN1];
+            load(it, xa, xb);
+            __builtin_amdgcn_sched_barrier(0);
+            transform(xa, xb, g[it]);
+        }
+        __syncthreads();  // every wave holds its results: the (mirrored) operands of all rows have been read
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) store(it, g[it]);
+    } else {
+        c32 xa[ITEMS][RN1], xb[ITEMS][RN1];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) load(it, xa[it], xb[it]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            c32 g[RN1];
+            transform(xa[it], xb[it], g);
+            store(it, g);
+        }
     }
 }
 
