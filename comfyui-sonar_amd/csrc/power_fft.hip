@@ -146,6 +146,9 @@ constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4
 #ifndef SONAR_FFT_TW_LDS
 #define SONAR_FFT_TW_LDS 0  // measured: constant-memory (scalar) twiddles 78 us vs LDS table 125 us at B=512
 #endif
+#ifndef SONAR_FWD_UNI
+#define SONAR_FWD_UNI 1  // forward passes: wave-uniform twiddles through scalar loads (1) or as broadcast reads of the LDS table (0)
+#endif
 #ifndef SONAR_PW_SKIP
 #define SONAR_PW_SKIP 0  // profiling builds only (scratch/pw_passes.py): 1 draw, 2 column passes, 4 rows pass a, 8 rows pass b arithmetic, 16 global stores
 #endif
@@ -574,7 +577,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
                 const c32 a = row[k], b = row[M - k];
                 const c32 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
                 const c32 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
-                const c32 t = cmulc(o, tw(k, W, H % 64 == 0));
+                const c32 t = cmulc(o, tw(k, W, SONAR_FWD_UNI && H % 64 == 0));
                 row[k] = make_float2(e.x + t.x, e.y + t.y);
                 row[M - k] = make_float2(e.x - t.x, -(e.y - t.y));
             }
@@ -588,7 +591,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             for (int k2 = 0; k2 < CN2; ++k2) u[k2] = A[(CN2 * k1 + k2) * S + c];
             fdft<CN2>(u);
 #pragma unroll
-            for (int n2 = 1; n2 < CN2; ++n2) u[n2] = cmulc(u[n2], tw(n2 * k1, H, M % 64 == 0));
+            for (int n2 = 1; n2 < CN2; ++n2) u[n2] = cmulc(u[n2], tw(n2 * k1, H, SONAR_FWD_UNI && M % 64 == 0));
 #pragma unroll
             for (int n2 = 0; n2 < CN2; ++n2) A[(CN2 * k1 + n2) * S + c] = u[n2];
         }
@@ -1340,22 +1343,30 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         // nothing left to draw while the other team transforms the last plane (the same three barriers): the next call's statistics of
         // this workgroup's second unit; its edge columns wait in the seed area, which nobody reads any more
         if (n == 1) decide();
+        [[maybe_unused]] const int j = n;  // (trace builds)
+        SONAR_PIPE_STAMP(0);
         if (ahead && my_units == 2) {
             TeamStats<H, W> ts;
             c32* const edge = reinterpret_cast<c32*>(SEED_RT);
             const GroupWalk gw((int64_t)blockIdx.x + gridDim.x, group, split);
             ts.begin(filter, seed, next_stream, plane_offset, group, gw, tid, edge);
             ts.radii(0, SONAR_AHEAD_SPLIT_A, tid);
+            SONAR_PIPE_STAMP(1);
             __syncthreads();
             ts.radii(SONAR_AHEAD_SPLIT_A, SONAR_AHEAD_SPLIT_B, tid);
+            SONAR_PIPE_STAMP(2);
             __syncthreads();
             ts.radii(SONAR_AHEAD_SPLIT_B, 4, tid);
             ts.products();
             ts.edges_and_wave_sums(edge, tid, sred);
+            SONAR_PIPE_STAMP(3);
             __syncthreads();
         } else {
+            SONAR_PIPE_STAMP(1);
             __syncthreads();
+            SONAR_PIPE_STAMP(2);
             __syncthreads();
+            SONAR_PIPE_STAMP(3);
             __syncthreads();
         }
     } else {
@@ -1378,6 +1389,8 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         }
         // iteration 0: the first plane is being drawn.  The next call's statistics of this workgroup's first unit (edge columns in the
         // second plane buffer, untouched until iteration 1), over the iteration's three barriers
+        [[maybe_unused]] const int j = 0;  // (trace builds; shadowed by the loop below)
+        SONAR_PIPE_STAMP(0);
         if (ahead && my_units >= 1) {
             TeamStats<H, W> ts;
             c32* const edge = PLANES + BUF;
@@ -1390,18 +1403,24 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             __builtin_amdgcn_s_setprio(SONAR_AHEAD_PRIO);
             ts.begin(filter, seed, next_stream, plane_offset, group, gw, tid, edge);
             ts.radii(0, SONAR_AHEAD_SPLIT_C, tid);
+            SONAR_PIPE_STAMP(1);
             __syncthreads();
             ts.radii(SONAR_AHEAD_SPLIT_C, SONAR_AHEAD_SPLIT_D, tid);
+            SONAR_PIPE_STAMP(2);
             __syncthreads();
             ts.radii(SONAR_AHEAD_SPLIT_D, 4, tid);
             ts.products();
             ts.edges_and_wave_sums(edge, tid, sred);
+            SONAR_PIPE_STAMP(3);
             __syncthreads();
             TeamStats<H, W>::store(sred, tid, partials_next, unit);
             __builtin_amdgcn_s_setprio(SONAR_PIPE_PRIO_FFT);
         } else {
+            SONAR_PIPE_STAMP(1);
             __syncthreads();
+            SONAR_PIPE_STAMP(2);
             __syncthreads();
+            SONAR_PIPE_STAMP(3);
             __syncthreads();
         }
         for (int j = 1; j <= n; ++j) {  // iteration j transforms plane j - 1

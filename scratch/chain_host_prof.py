@@ -1,25 +1,28 @@
-"""Host time of one chain call (cfg3: Perlin + pyramid, 64 latents): cProfile of 400 calls, GPU idle most of the time."""
+"""cfg3 chain (Perlin + pyramid, normalised) at batch 64: wall time per call against GPU time per call, and the host profile."""
 import cProfile, importlib, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sonar_pkg
-pkg = sonar_pkg.load(); pkg.hip_lib.load()
+pkg = sonar_pkg.load(); hl = pkg.hip_lib; hl.load()
 nz = importlib.import_module("comfyui_sonar_amd.py.noise")
+x = torch.zeros((64, 4, 128, 128), device="cuda")
 sig = (torch.tensor(14.6), torch.tensor(10.0))
 chain = nz.CustomNoiseChain()
 chain.add(nz.CustomNoiseItem(0.5, noise_type="perlin"))
 chain.add(nz.CustomNoiseItem(0.5, noise_type="pyramid"))
-x = torch.zeros(64, 4, 128, 128, device="cuda")
-ns = chain.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)
+ns = chain.make_noise_sampler(x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
 for _ in range(300): ns(*sig)
 torch.cuda.synchronize()
-n = 400
 t0 = time.perf_counter()
-for _ in range(n): ns(*sig)
-t1 = time.perf_counter()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(500): ns(*sig)
+host = (time.perf_counter() - t0) / 500 * 1e6
+e1.record(); torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / 500 * 1e6
+print(f"host issue time {host:.1f} us per call, wall {wall:.1f} us, GPU span {e0.elapsed_time(e1) * 2:.1f} us per call")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(500): ns(*sig)
+pr.disable()
 torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"host per call {(t1 - t0) / n * 1e6:.1f} us; with the final sync {(t2 - t0) / n * 1e6:.1f} us")
-pr = cProfile.Profile(); pr.enable()
-for _ in range(n): ns(*sig)
-pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(35)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(22)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/rNN_traffic.json from tools/rocpd_traffic.py's per-kernel table (scratch/prof_r02.sh writes it as traffic_raw.json):
-    python tools/make_traffic_json.py gpurun_out/r02/traffic_raw.json > profiles/r02_traffic.json
+"""profiles/rNN_traffic.json from tools/rocpd_traffic.py's per-kernel table (scratch/prof_r03.sh writes it as traffic_raw.json):
+    python tools/make_traffic_json.py gpurun_out/r03/traffic_raw.json > profiles/r03_traffic.json
 Kernels are picked by name fragments; batch-512 and batch-64 launches of one kernel (same name) are split in proportion to the batch."""
 import json
 import sys
@@ -21,15 +21,20 @@ def total(*rows):
 
 def main(path):
     raw = json.load(open(path))
-    out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over scratch/prof_workload.py (scratch/prof_r02.sh, "
+    out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over scratch/prof_workload.py (scratch/prof_r03.sh, "
                    "tools/rocpd_traffic.py, tools/make_traffic_json.py); raw counters are KiB per dispatch.  hbm_bytes_per_launch = 2 x FETCH_SIZE + "
                    "WRITE_SIZE: the gfx950 correction of MI355X_MICROARCH.md, confirmed in the same run by the calibration kernels below "
                    "(one 134 217 728-byte tensor written / read / read + written)."}
     out["calibration"] = {k: raw[k] for k in raw if k.startswith(("stream_fill_kernel<", "stats_kernel<", "scale_noise_kernel<"))}
     scale = pick(raw, "scale_noise_kernel<")
-    st, fin = pick(raw, "power_stats_kernel"), pick(raw, "power_irfft2_kernel<128, 128, 1, false, true>")
-    out["power_noise_b512"] = {"kernels": {"power_stats_kernel<128,128>": st, "power_irfft2_kernel<128,128,GEN,NORM>": fin},
-                               "hbm_bytes_per_launch": total(st, fin), "algorithmic_bytes_4N": 512 * N, "contract_bytes_12N": 3 * 512 * N}
+    fin = pick(raw, "power_pipe_kernel<128, 128, false, true>")
+    out["power_noise_b512"] = {"kernels": {"power_pipe_kernel<128,128,NORM> (final pass + the next call's statistics in its idle waves)": fin},
+                               "hbm_bytes_per_launch": total(fin), "algorithmic_bytes_4N": 512 * N, "contract_bytes_12N": 3 * 512 * N,
+                               "note": "a sampler's steady state: one launch per call; the first call of a sampler also runs power_stats_kernel "
+                                       "(no stores: a few KiB)"}
+    stats = [v for k, v in raw.items() if "power_stats_kernel" in k]
+    if stats:
+        out["power_noise_b512"]["kernels"]["power_stats_kernel<128,128> (first call only)"] = stats[0]
     sf = pick(raw, "power_irfft2_kernel<128, 128, 2,")
     out["spectral_filter_b512"] = dict(sf, algorithmic_bytes_8N=2 * 512 * N)
     # Perlin: lattice + statistics pass + final pass, run equally often at batch 512 and 64 (same kernel names)
