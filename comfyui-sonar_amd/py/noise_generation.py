@@ -937,7 +937,14 @@ class BrownianPath:
     sqrt((t - a)(b - t) / (b - a)) z(node), node = the point's creation number; beyond every known time it is an independent increment
     from the outermost one (the two-sided motion continues outside [t_lo, t_hi]).  By the Markov property the joint law of all known
     points is exactly a Brownian motion's.  ``bridge[t]`` = (a, b, fa, fb, sd, node) is how a point was made -- all a sampler run needs,
-    O(1) per point; ``coefficients(t)`` expands W(t) over the node normals (fp64) on demand, for the evaluation without kept tensors."""
+    O(1) per point; ``coefficients(t)`` expands W(t) over the node normals (fp64) on demand, for the evaluation without kept tensors.
+
+    ORDER DEPENDENCE (unlike ComfyUI's BrownianTree, whose dyadic tree makes W(t) a fixed function of the seed up to its tolerance):
+    a point's value depends on which points were known when it was first asked for, i.e. on the HISTORY of queries of this instance,
+    not only on (seed, t).  One sampler run is self-consistent (every increment it sees comes from one path), and two runs that ask for
+    the same times in the same order see the same path; two runs over the same range with different step counts, or a resumed run
+    that re-creates the sampler, see different (equally valid) paths at the times they share -- as they do with torchsde's
+    BrownianInterval without its dyadic pre-tree.  ``tests/test_abi_and_host.py::test_brownian_path_depends_on_the_query_order``."""
 
     ROOT = 0              # node ids are creation numbers; they stay below 2**40 (the kernel's stream-id field has 48 bits)
     MEMO = 512            # expansions remembered (each can hold every earlier node: a run of n monotone queries makes them O(n) long)

@@ -199,3 +199,24 @@ def test_per_latent_sigma_must_have_one_value_or_one_per_latent(pkg):
     wc = importlib.import_module("comfyui_sonar_amd.py.wavelet_cfg")
     with pytest.raises(RuntimeError, match=r"size of tensor a \(4\) must match the size of tensor b \(3\)"):
         wc._per_latent(torch.zeros(4, 2, 8, 8), torch.ones(3), divide=True)
+
+
+def test_brownian_path_depends_on_the_query_order(pkg):
+    """The Brownian path is built point by point in query order (BrownianPath's docstring): the same times in the same order give the
+    same expansion, another order gives another -- equally a Brownian motion (the variance / covariance test above holds for every
+    order) -- so W(t) is a function of (seed, history), not of (seed, t) alone.  Pinned here so that a change of that contract is a
+    decision, not an accident."""
+    import importlib
+
+    ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
+    times = [10.0, 7.0, 4.0, 8.5]
+    a, b, c = ng.BrownianPath(0.03, 14.6), ng.BrownianPath(0.03, 14.6), ng.BrownianPath(0.03, 14.6)
+    for t in times:
+        a.coefficients(t)
+        b.coefficients(t)
+    for t in reversed(times):
+        c.coefficients(t)
+    assert all(a.coefficients(t) == b.coefficients(t) for t in times)          # same history: the same path
+    assert any(a.coefficients(t) != c.coefficients(t) for t in times)          # another history: another path ...
+    var = lambda co: sum(v * v for v in co.values())  # noqa: E731
+    assert all(abs(var(p.coefficients(t)) - (t - 0.03)) < 1e-9 for p in (a, c) for t in times)  # ... of the same law
