@@ -817,6 +817,15 @@ __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, in
 // floats), so an output needs, per level, two conflict-free 16-byte reads and two FMAs per value instead of four gathers, a
 // coordinate-table read and eleven arithmetic instructions; the level weight is folded into the y weights.
 constexpr size_t kPyramidLdsBudget = 64 * 1024;
+// The grids and the stretched rows of a plane take up to 64 KB of LDS, so two workgroups fit a CU: with 256 threads that is two
+// waves per SIMD (one at batch 64, where there is a plane per CU) and the tile loop runs at the latency of its dependent chains.
+// kPyrParts 256-thread parts share one plane's LDS instead.
+#ifndef SONAR_PYR_PARTS
+#define SONAR_PYR_PARTS 2
+#endif
+constexpr int kPyrParts = SONAR_PYR_PARTS;
+constexpr int kPyrBlock = kPyrParts * kBlock;
+static_assert((kPyrParts & (kPyrParts - 1)) == 0 && kTileIters % kPyrParts == 0, "parts split a tile's burst evenly");
 #ifndef SONAR_PYR_UNROLL_N
 #define SONAR_PYR_UNROLL_N 1
 #endif
@@ -829,15 +838,16 @@ constexpr size_t kPyramidLdsBudget = 64 * 1024;
 // chain's previous item rides along (Prefix above) -- its generator shares this kernel's tile keying, so its state simply walks the
 // same (tile, iteration) sequence.
 template <bool STATS, bool XROWS, int PRE = 0>
-__global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
+__global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
                                                                uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                                                                double* partials, int grid_floats, Accum fold, Prefix pre) {
     extern __shared__ __align__(16) float pyr_lds[];
-    __shared__ double red[2 * kBlock / 64];
+    __shared__ double red[2 * kPyrBlock / 64];
     double s = 0.0, q = 0.0;
     const int HW = H * W;
     const uint32_t lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int part = threadIdx.x / kBlock, slot = threadIdx.x % kBlock;  // 256-thread parts of the workgroup
     const int dy = 256 / W, dx = 256 - dy * W;  // one burst step advances 256 elements
     // bilinear source coordinates depend on (level, x) and (level, y) only: tabulated once per workgroup
     Lin* const xtab = reinterpret_cast<Lin*>(pyr_lds + grid_floats);  // [level][W]
@@ -846,8 +856,8 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
     if (mode == 0) {
         for (int l = 0; l < lv.count; ++l) {
             const float sy = (float)lv.h[l] / (float)H, sx = (float)lv.w[l] / (float)W;
-            for (int i = threadIdx.x; i < W; i += kBlock) xtab[l * W + i] = lin_coord(i, sx, lv.w[l]);
-            for (int i = threadIdx.x; i < H; i += kBlock) {
+            for (int i = threadIdx.x; i < W; i += kPyrBlock) xtab[l * W + i] = lin_coord(i, sx, lv.w[l]);
+            for (int i = threadIdx.x; i < H; i += kPyrBlock) {
                 Lin ly = lin_coord(i, sy, lv.h[l]);
                 const int pitch = XROWS ? W : lv.w[l];
                 ly.i0 *= pitch;  // row offsets
@@ -867,11 +877,12 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
             const int n = lv.h[l] * lv.w[l];
             if (lv.ptr[l]) {
                 const float* src = lv.ptr[l] + p * (int64_t)n;
-                for (int i = threadIdx.x; i < n; i += kBlock) pyr_lds[off + i] = src[i];
-            } else if ((int)threadIdx.x * 4 < n) {
-                // the grid is drawn here: stream (level stream id, global plane, thread), thread t owns elements 4t.., 4(t + 256)..
-                Xoshiro rng = rng_stream(seed, lv.draw_stream[l], (uint64_t)(elem_offset / HW + p), threadIdx.x);
-                for (int i = threadIdx.x * 4; i < n; i += kBlock * 4) {
+                for (int i = threadIdx.x; i < n; i += kPyrBlock) pyr_lds[off + i] = src[i];
+            } else if ((l & (kPyrParts - 1)) == part && slot * 4 < n) {
+                // the grid is drawn here: stream (level stream id, global plane, slot), slot t of 256 owns elements 4t.., 4(t + 256)..;
+                // the levels alternate between the workgroup's 256-thread parts
+                Xoshiro rng = rng_stream(seed, lv.draw_stream[l], (uint64_t)(elem_offset / HW + p), slot);
+                for (int i = slot * 4; i < n; i += kBlock * 4) {
                     float z[4];
                     rng.normal4(z);
                     for (int k = 0; k < 4 && i + k < n; ++k) pyr_lds[off + i + k] = z[k];
@@ -887,8 +898,8 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
                 const float* g = pyr_lds + go;
                 const Lin* xt = xtab + l * W;
                 int yy = (int)threadIdx.x / W, xx = (int)threadIdx.x - yy * W;
-                const int sy = kBlock / W, sx = kBlock - sy * W;
-                for (int i = threadIdx.x; i < h * W; i += kBlock) {
+                const int sy = kPyrBlock / W, sx = kPyrBlock - sy * W;
+                for (int i = threadIdx.x; i < h * W; i += kPyrBlock) {
                     const Lin lx = xt[xx];
                     const float* row = g + yy * w;
                     xrows[ro + i] = __builtin_fmaf(row[lx.i1], lx.w1, row[lx.i0] * lx.w0);
@@ -916,15 +927,23 @@ __global__ void __launch_bounds__(kBlock) pyramid_plane_kernel(float* out, int64
 #ifdef SONAR_PYR_SETUP_ONLY  // profiling builds: what the per-plane setup (grids, tables, stretched rows) costs
         if (oplane != nullptr) continue;
 #endif
-        for (int64_t t = tile_first + wave; t <= tile_last; t += kBlock / 64) {
+        // a tile's burst is split between the parts: part k runs iterations [k, k + 1) * kTileIters / kPyrParts after stepping its
+        // generators over the iterations before them (8 plain instructions per word instead of a Box-Muller pair)
+        constexpr int kIters = kTileIters / kPyrParts;
+        for (int64_t t = tile_first + wave % (kBlock / 64); t <= tile_last; t += kBlock / 64) {
             Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)t, lane);
             Xoshiro prng;
             if constexpr (PRE != 0) prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)t, lane);
-            int e = (int)(t * kTileElems - g0) + (int)lane * 4;  // element index inside the plane; < 0 or >= HW: not ours
+            for (int k = 0; k < part * kIters * 4; ++k) {
+                rng.next();
+                if constexpr (PRE != 0) prng.next();
+            }
+            // element index inside the plane; < 0 or >= HW: not ours
+            int e = (int)(t * kTileElems - g0) + (int)lane * 4 + part * kIters * 256;
             int y = e >= 0 ? e / W : -((-e + W - 1) / W);        // floor
             int x4 = e - y * W;
 SONAR_PYR_UNROLL
-            for (int it = 0; it < kTileIters; ++it, e += 256, y += dy, x4 += dx, y += x4 >= W, x4 -= x4 >= W ? W : 0) {
+            for (int it = 0; it < kIters; ++it, e += 256, y += dy, x4 += dx, y += x4 >= W, x4 -= x4 >= W ? W : 0) {
                 float v[4];
                 rng.normal4(v);
                 float px[4];
@@ -993,7 +1012,7 @@ SONAR_PYR_UNROLL
             }
         }
     }
-    if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
+    if constexpr (STATS) write_partial<kPyrBlock>(s, q, partials, red);
 }
 
 // true if the plane kernel was launched
@@ -1012,7 +1031,7 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     const bool xrows = mode == 0 && W % 4 == 0 && lds_x <= kPyramidLdsBudget;
     const int g = (int)std::min<int64_t>(planes, kNPart);
 #define SONAR_PP(ST, XR, P) \
-    hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P>), dim3(g), dim3(kBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
+    hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P>), dim3(g), dim3(kPyrBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
                        seed, stream_id, elem_offset, partials, (int)grid_floats, fold, pre)
 #define SONAR_PPK(ST, XR) \
     do { \
