@@ -181,18 +181,54 @@ __global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n
         for (int64_t j = nv * V + threadIdx.x; j < n; j += kBlock) x[j] = f(x[j]);
 }
 
+// Kernels with ONE workgroup per row (a row is usually a whole latent or plane, and there are few of them) run at the latency of that
+// workgroup's loads, not at any throughput: kRowThreads threads, and row_visit keeps four independent 16-byte loads per thread in
+// flight (amax over four rows of 65536 values: 63 -> 6 us).  f sees every element once, in no particular order.
+// Short rows (there are then usually many) keep 256-thread workgroups.
+constexpr int kRowThreads = 1024;
+constexpr int64_t kLongRow = 8192;
+template <int THREADS, typename F>
+__device__ __forceinline__ void row_visit(const float* __restrict__ row, int64_t n, F&& f) {
+    if ((reinterpret_cast<uintptr_t>(row) & 15u) == 0 && (n & 3) == 0) {
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        const int64_t n4 = n >> 2;
+        int64_t i = threadIdx.x;
+        for (; i + 3 * THREADS < n4; i += 4 * THREADS) {
+            const float4 a = row4[i], b = row4[i + THREADS], c = row4[i + 2 * THREADS], d = row4[i + 3 * THREADS];
+            f(a.x); f(a.y); f(a.z); f(a.w);
+            f(b.x); f(b.y); f(b.z); f(b.w);
+            f(c.x); f(c.y); f(c.z); f(c.w);
+            f(d.x); f(d.y); f(d.z); f(d.w);
+        }
+        for (; i < n4; i += THREADS) {
+            const float4 a = row4[i];
+            f(a.x); f(a.y); f(a.z); f(a.w);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += THREADS) f(row[i]);
+    }
+}
+
+// one workgroup per row: 1024 threads for long rows, 256 for short ones
+#define SONAR_ROW_LAUNCH(kernel, row_len, nrows, lds, st, ...) \
+    do { \
+        if ((row_len) >= kLongRow) hipLaunchKernelGGL(kernel<kRowThreads>, dim3(grid_for(nrows, 1)), dim3(kRowThreads), lds, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel<kBlock>, dim3(grid_for(nrows, 1)), dim3(kBlock), lds, st, __VA_ARGS__); \
+    } while (0)
+
 // normalize_dims variant (py/utils.py:96-99): one block per row of `inner` contiguous elements
-__global__ void __launch_bounds__(kBlock) scale_rows_kernel(float* x, int64_t rows, int64_t inner, float factor) {
-    __shared__ double red[2 * kBlock / 64];
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) scale_rows_kernel(float* x, int64_t rows, int64_t inner, float factor) {
+    __shared__ double red[2 * THREADS / 64];
     __shared__ float sh_val;
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         float* row = x + r * inner;
         double s = 0.0, q = 0.0;
-        for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
-            const double v = row[i];
+        row_visit<THREADS>(row, inner, [&](float f) {
+            const double v = f;
             s += v; q += v * v;
-        }
-        block_sum2<kBlock>(s, q, red);
+        });
+        block_sum2<THREADS>(s, q, red);
         if (threadIdx.x == 0) {
             const double nt = (double)inner;
             const double var = (q - s * (s / nt)) / (nt - 1.0);
@@ -201,28 +237,38 @@ __global__ void __launch_bounds__(kBlock) scale_rows_kernel(float* x, int64_t ro
         __syncthreads();
         const float sd = sh_val;
         double s2 = 0.0, q2 = 0.0;
-        for (int64_t i = threadIdx.x; i < inner; i += kBlock) s2 += (double)(row[i] / sd);
+        row_visit<THREADS>(row, inner, [&](float f) { s2 += (double)(f / sd); });
         __syncthreads();
-        block_sum2<kBlock>(s2, q2, red);
+        block_sum2<THREADS>(s2, q2, red);
         if (threadIdx.x == 0) sh_val = (float)(s2 / (double)inner);
         __syncthreads();
         const float mean = sh_val;
-        for (int64_t i = threadIdx.x; i < inner; i += kBlock) row[i] = (row[i] / sd - mean) * factor;
+        if ((reinterpret_cast<uintptr_t>(row) & 15u) == 0 && (inner & 3) == 0) {
+            float4* row4 = reinterpret_cast<float4*>(row);
+            for (int64_t i = threadIdx.x; i < (inner >> 2); i += THREADS) {
+                float4 v = row4[i];
+                v.x = (v.x / sd - mean) * factor; v.y = (v.y / sd - mean) * factor;
+                v.z = (v.z / sd - mean) * factor; v.w = (v.w / sd - mean) * factor;
+                row4[i] = v;
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < inner; i += THREADS) row[i] = (row[i] / sd - mean) * factor;
+        }
         __syncthreads();
     }
 }
 
-__global__ void __launch_bounds__(kBlock) minmax_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) minmax_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
                                                               float* out_min, float* out_max) {
-    __shared__ float smin[kBlock / 64], smax[kBlock / 64];
+    __shared__ float smin[THREADS / 64], smax[THREADS / 64];
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float* row = x + r * inner;
         float lo = INFINITY, hi = -INFINITY;
-        for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
-            const float v = row[i];
+        row_visit<THREADS>(row, inner, [&](float v) {
             lo = fminf(lo, v);
             hi = fmaxf(hi, v);
-        }
+        });
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             lo = fminf(lo, __shfl_down(lo, off, 64));
@@ -234,7 +280,7 @@ __global__ void __launch_bounds__(kBlock) minmax_rows_kernel(const float* __rest
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int w = 1; w < kBlock / 64; ++w) {
+            for (int w = 1; w < THREADS / 64; ++w) {
                 lo = fminf(lo, smin[w]);
                 hi = fmaxf(hi, smax[w]);
             }
@@ -325,17 +371,18 @@ struct ScalarOp {
     }
 };
 
-__global__ void __launch_bounds__(kBlock) rowstats_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) rowstats_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
                                                            float* mean, float* stdv) {
-    __shared__ double red[2 * kBlock / 64];
+    __shared__ double red[2 * THREADS / 64];
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float* row = x + r * inner;
         double s = 0.0, q = 0.0;
-        for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
-            const double v = row[i];
+        row_visit<THREADS>(row, inner, [&](float f) {
+            const double v = f;
             s += v; q += v * v;
-        }
-        block_sum2<kBlock>(s, q, red);
+        });
+        block_sum2<THREADS>(s, q, red);
         if (threadIdx.x == 0) {
             const double nt = (double)inner, m = s / nt;
             const double var = (q - s * m) / (nt - 1.0);
@@ -466,20 +513,19 @@ __global__ void __launch_bounds__(kBlock) amax_mid_kernel(const float* __restric
 }
 
 // inner == 1: one workgroup per row of `mid` contiguous elements
-__global__ void __launch_bounds__(kBlock) amax_row_kernel(const float* __restrict__ x, int64_t rows, int64_t len, int use_abs,
-                                                           float* peak) {
-    __shared__ float smax[kBlock / 64];
-    __shared__ int snan[kBlock / 64];
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) amax_row_kernel(const float* __restrict__ x, int64_t rows, int64_t len, int use_abs,
+                                                                float* peak) {
+    __shared__ float smax[THREADS / 64];
+    __shared__ int snan[THREADS / 64];
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-        const float* row = x + r * len;
         float hi = -INFINITY;
         int nan = 0;
-        for (int64_t i = threadIdx.x; i < len; i += kBlock) {
-            float v = row[i];
+        row_visit<THREADS>(x + r * len, len, [&](float v) {
             if (use_abs) v = fabsf(v);
             nan |= v != v;
             hi = fmaxf(hi, v);
-        }
+        });
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             hi = fmaxf(hi, __shfl_down(hi, off, 64));
@@ -491,7 +537,7 @@ __global__ void __launch_bounds__(kBlock) amax_row_kernel(const float* __restric
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int w = 1; w < kBlock / 64; ++w) {
+            for (int w = 1; w < THREADS / 64; ++w) {
                 hi = fmaxf(hi, smax[w]);
                 nan |= snan[w];
             }
@@ -617,29 +663,66 @@ struct StudentTOp {
 // q-quantile (torch.quantile, linear interpolation) of |x| over each row of `inner` contiguous values: radix select on the bit
 // patterns (non-negative floats order like unsigned integers), four 8-bit histogram passes in LDS, then one pass for the next
 // order statistic.  One workgroup per row.  rank = lo + frac is computed by the host in fp32 like torch does.
-__global__ void __launch_bounds__(kBlock) abs_quantile_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner, int64_t lo,
-                                                                    float frac, float* out) {
-    __shared__ unsigned hist[256];
+// The first pass sees the exponent byte -- two or three bins take every value -- so each bin is kept in kQuantReplicas copies (lane
+// mod 32 picks one, copies of a bin in distinct banks): same-address LDS atomics serialise, 226 -> 20 us for four rows of 65536.
+constexpr int kQuantReplicas = 32;
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) abs_quantile_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner, int64_t lo,
+                                                                        float frac, float* out) {
+    __shared__ unsigned hist[256 * kQuantReplicas];
+    __shared__ unsigned total[256];
     __shared__ unsigned sh_prefix, sh_k, sh_cnt, sh_min;
+    const unsigned rep = threadIdx.x & (kQuantReplicas - 1);
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float* row = x + r * inner;
+        const bool vec = (reinterpret_cast<uintptr_t>(row) & 15u) == 0 && (inner & 3) == 0;
+        const float4* row4 = reinterpret_cast<const float4*>(row);
         unsigned prefix = 0, mask = 0, k = (unsigned)lo;
         for (int shift = 24; shift >= 0; shift -= 8) {
-            for (int b = threadIdx.x; b < 256; b += kBlock) hist[b] = 0;
+            for (int b = threadIdx.x; b < 256 * kQuantReplicas; b += THREADS) hist[b] = 0;
             __syncthreads();
-            for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
-                const unsigned bits = __float_as_uint(row[i]) & 0x7FFFFFFFu;
-                if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> shift) & 255u], 1u);
+            auto tally = [&](float v) {
+                const unsigned bits = __float_as_uint(v) & 0x7FFFFFFFu;
+                if ((bits & mask) == prefix) atomicAdd(&hist[((bits >> shift) & 255u) * kQuantReplicas + rep], 1u);
+            };
+            if (vec) {
+                for (int64_t i = threadIdx.x; i < (inner >> 2); i += THREADS) {
+                    const float4 v = row4[i];
+                    tally(v.x); tally(v.y); tally(v.z); tally(v.w);
+                }
+            } else {
+                for (int64_t i = threadIdx.x; i < inner; i += THREADS) tally(row[i]);
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned cum = 0, b = 0;
-                for (; b < 255; ++b) {
-                    if (cum + hist[b] > k) break;
-                    cum += hist[b];
+            if (threadIdx.x < 256) {
+                unsigned sum = 0;
+                for (int j = 0; j < kQuantReplicas; ++j) sum += hist[threadIdx.x * kQuantReplicas + ((j + threadIdx.x) & (kQuantReplicas - 1))];
+                total[threadIdx.x] = sum;
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                // the first bin b with (bins 0..b) > k, 255 if there is none: lane l owns bins 4l..4l+3
+                const unsigned a0 = total[4 * threadIdx.x], a1 = total[4 * threadIdx.x + 1], a2 = total[4 * threadIdx.x + 2], a3 = total[4 * threadIdx.x + 3];
+                const unsigned own = a0 + a1 + a2 + a3;
+                unsigned incl = own;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned up = __shfl_up(incl, off, 64);
+                    if ((int)threadIdx.x >= off) incl += up;
                 }
-                sh_prefix = prefix | (b << shift);
-                sh_k = k - cum;
+                const unsigned excl = incl - own;
+                if ((excl <= k && k < incl) || (threadIdx.x == 63 && k >= incl)) {
+                    unsigned cum = excl, b = 4 * threadIdx.x;
+                    if (cum + a0 <= k) {
+                        cum += a0; ++b;
+                        if (cum + a1 <= k) {
+                            cum += a1; ++b;
+                            if (cum + a2 <= k) { cum += a2; ++b; }
+                        }
+                    }
+                    sh_prefix = prefix | (b << shift);
+                    sh_k = k - cum;
+                }
             }
             __syncthreads();
             prefix = sh_prefix;
@@ -654,10 +737,18 @@ __global__ void __launch_bounds__(kBlock) abs_quantile_rows_kernel(const float* 
         }
         __syncthreads();
         unsigned cnt = 0, mn = 0x7FFFFFFFu;
-        for (int64_t i = threadIdx.x; i < inner; i += kBlock) {
-            const unsigned bits = __float_as_uint(row[i]) & 0x7FFFFFFFu;
+        auto look = [&](float v) {
+            const unsigned bits = __float_as_uint(v) & 0x7FFFFFFFu;
             cnt += bits <= prefix;
             if (bits > prefix) mn = min(mn, bits);
+        };
+        if (vec) {
+            for (int64_t i = threadIdx.x; i < (inner >> 2); i += THREADS) {
+                const float4 v = row4[i];
+                look(v.x); look(v.y); look(v.z); look(v.w);
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < inner; i += THREADS) look(row[i]);
         }
         atomicAdd(&sh_cnt, cnt);
         atomicMin(&sh_min, mn);
@@ -1184,7 +1275,7 @@ extern "C" int sonar_std_scale_f32(float* x, int64_t n, float mul, const double*
 extern "C" int sonar_scale_noise_rows_f32(float* x, int64_t rows, int64_t inner, float factor, void* stream) {
     SONAR_REQUIRE(x && rows >= 0 && inner > 0, SONAR_ERR_ARG, "sonar_scale_noise_rows_f32: bad argument");
     if (rows == 0) return SONAR_OK;
-    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(rows, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner,
+    SONAR_ROW_LAUNCH(scale_rows_kernel, inner, rows, 0, (hipStream_t)stream, x, rows, inner,
                        factor);
     return check_launch("sonar_scale_noise_rows_f32");
 }
@@ -1193,7 +1284,7 @@ extern "C" int sonar_minmax_rows_f32(const float* x, int64_t rows, int64_t inner
                                      void* stream) {
     SONAR_REQUIRE(x && out_min && out_max && rows >= 0 && inner > 0, SONAR_ERR_ARG, "sonar_minmax_rows_f32: bad argument");
     if (rows == 0) return SONAR_OK;
-    hipLaunchKernelGGL(minmax_rows_kernel, dim3(grid_for(rows, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner,
+    SONAR_ROW_LAUNCH(minmax_rows_kernel, inner, rows, 0, (hipStream_t)stream, x, rows, inner,
                        out_min, out_max);
     return check_launch("sonar_minmax_rows_f32");
 }
@@ -1239,7 +1330,7 @@ extern "C" int sonar_scalar_op_f32(int op, const float* a, const float* b, float
 extern "C" int sonar_rowstats_f32(const float* x, int64_t rows, int64_t inner, float* mean, float* stdv, void* stream) {
     SONAR_REQUIRE(x && mean && stdv && rows >= 0 && inner > 0, SONAR_ERR_ARG, "sonar_rowstats_f32: bad argument");
     if (rows == 0) return SONAR_OK;
-    hipLaunchKernelGGL(rowstats_kernel, dim3(grid_for(rows, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner, mean, stdv);
+    SONAR_ROW_LAUNCH(rowstats_kernel, inner, rows, 0, (hipStream_t)stream, x, rows, inner, mean, stdv);
     return check_launch("sonar_rowstats_f32");
 }
 
@@ -1286,8 +1377,7 @@ extern "C" int sonar_amax_mid_f32(const float* x, int64_t outer, int64_t mid, in
     SONAR_REQUIRE(x && peak && outer >= 0 && mid > 0 && inner > 0, SONAR_ERR_ARG, "sonar_amax_mid_f32: bad argument");
     if (outer == 0) return SONAR_OK;
     if (inner == 1)
-        hipLaunchKernelGGL(amax_row_kernel, dim3(grid_for(outer, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, outer, mid, use_abs,
-                           peak);
+        SONAR_ROW_LAUNCH(amax_row_kernel, mid, outer, 0, (hipStream_t)stream, x, outer, mid, use_abs, peak);
     else
         hipLaunchKernelGGL(amax_mid_kernel, dim3(grid_for(outer * inner, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, x, outer,
                            mid, inner, use_abs, peak);
@@ -1317,7 +1407,7 @@ extern "C" int sonar_abs_quantile_rows_f32(const float* x, int64_t rows, int64_t
     SONAR_REQUIRE(x && out && rows >= 0 && inner > 0 && rank_lo >= 0 && rank_lo < inner && rank_frac >= 0.0f && rank_frac <= 1.0f,
                   SONAR_ERR_ARG, "sonar_abs_quantile_rows_f32: bad argument");
     if (rows == 0) return SONAR_OK;
-    hipLaunchKernelGGL(abs_quantile_rows_kernel, dim3(grid_for(rows, 1)), dim3(kBlock), 0, (hipStream_t)stream, x, rows, inner, rank_lo,
+    SONAR_ROW_LAUNCH(abs_quantile_rows_kernel, inner, rows, 0, (hipStream_t)stream, x, rows, inner, rank_lo,
                        rank_frac, out);
     return check_launch("sonar_abs_quantile_rows_f32");
 }

@@ -183,3 +183,44 @@ def test_rfft2_on_any_plane_size(api):
         want = torch.fft.rfft2(x)
         got = api.hl.rfft2(x)
         assert (got - want).abs().max().item() <= 3e-5 * want.abs().max().item(), shape
+
+
+def test_the_spectral_gain_is_uploaded_once_and_follows_its_parameters(api):
+    """OneF / GreenTest build their gain with host arithmetic and a blocking upload: kept per generator, rebuilt when a parameter it
+    depends on changes (the values of a call do not depend on whether the gain was cached)."""
+    ng = api.noise_generation
+    x = torch.zeros((2, 4, 64, 64), device="cuda")
+    gen = ng.OneFNoiseGenerator(x, cpu=False, alpha=-0.5)
+    g0 = gen.device_gain()
+    assert gen.device_gain() is g0
+    fresh = ng._half_gain(gen.spectral_gain().to(torch.float32)).to("cuda")
+    assert torch.equal(g0, fresh)
+    torch.manual_seed(5)
+    first = gen.generate()  # cached gain
+    torch.manual_seed(5)
+    again = ng.OneFNoiseGenerator(x, cpu=False, alpha=-0.5).generate()  # fresh gain
+    assert torch.equal(first, again)
+    gen.alpha = 0.5
+    g1 = gen.device_gain()
+    assert g1 is not g0 and not torch.equal(g1, g0)
+    assert torch.equal(g1, ng._half_gain(gen.spectral_gain().to(torch.float32)).to("cuda"))
+    gen.update_x(torch.zeros((2, 4, 32, 64), device="cuda"))
+    assert gen.device_gain().shape == (32, 33)
+
+
+@pytest.mark.parametrize("rows,inner", [(4, 65536), (3, 8192), (5, 8190), (7, 1000), (2, 65537), (64, 16384)])
+def test_row_kernels_on_long_and_short_rows(api, rows, inner):
+    """One workgroup per row: 1024 threads and 16-byte loads for long aligned rows, the scalar walk otherwise -- same results."""
+    hl = api.hl
+    g = torch.Generator(device="cpu").manual_seed(rows * 131 + inner)
+    x = torch.randn(rows, inner, generator=g).cuda()
+    mean, std = hl.rowstats(x, rows, inner)
+    torch.testing.assert_close(mean.cpu(), x.double().mean(1).float().cpu(), rtol=0, atol=1e-7)
+    torch.testing.assert_close(std.cpu(), x.double().std(1).float().cpu(), rtol=2e-7, atol=0)
+    lo, hi = hl.minmax_rows(x, rows, inner)
+    assert torch.equal(lo, x.amin(1)) and torch.equal(hi, x.amax(1))
+    peak = hl.amax_mid(x.reshape(rows, inner, 1), rows, inner, 1, True)
+    assert torch.equal(peak.reshape(-1), x.abs().amax(1))
+    q = hl.abs_quantile_rows(x, rows, inner, 0.75)
+    want = torch.quantile(x.abs().cpu(), 0.75, dim=1)
+    torch.testing.assert_close(q.cpu().reshape(-1), want, rtol=1e-6, atol=0)
