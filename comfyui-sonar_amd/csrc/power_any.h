@@ -12,11 +12,123 @@
 
 namespace sonar {
 
-constexpr int kAnyThreads = 1024;        // 16 waves; the plane buffer allows one workgroup per CU anyway
+constexpr int kAnyThreads = 1024;        // one workgroup per CU (16 waves) when only one plane buffer fits; two of kAnySlots threads otherwise
 constexpr int kAnySlots = kFftThreads;   // drawing thread slots: streams are keyed by (group, slot) like the fast path
 constexpr int kAnyPer = 4;               // outputs per thread and batch held in registers across a pass's barrier
 constexpr size_t kAnyLdsLimit = 160 * 1024 - 2048;
-constexpr int kAnyMaxRadix = 8;           // radix-16 leaves too few (line, n2) families for 1024 threads: measured slower (96 x 96: 176 vs 145 us)
+
+// ---- register codelets of any length up to kAnyCodelet ---------------------------------------------------------------------------
+// idft_any<N>: in-place inverse (sign +) DFT, natural order in and out.  Powers of two are the fixed-size kernels' codelets; an odd
+// prime P is the symmetric form X[k], X[P - k] = (v0 + sum_j cos(2 pi j k / P) (v[j] + v[P - j])) +- i sum_j sin(2 pi j k / P) (v[j] -
+// v[P - j]) -- (P - 1)^2 / 2 packed FMAs; a composite N = A x B is Cooley-Tukey in registers (B transforms of length A, constant
+// twiddles, A transforms of length B).  Every coefficient is a compile-time constant (static_for hands the loop indices to the
+// lambdas as types), so a codelet is straight-line packed arithmetic on register pairs.
+constexpr int kAnyCodelet = 16;
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr double ct_series(double x, bool cosine) {  // |x| <= pi
+    double term = cosine ? 1.0 : x, sum = term;
+    for (int k = 1; k < 20; ++k) {
+        const double a = cosine ? 2.0 * k - 1.0 : 2.0 * k, b = a + 1.0;
+        term *= -x * x / (a * b);
+        sum += term;
+    }
+    return sum;
+}
+// cos / sin of 2 pi m / n, exact on the axes
+constexpr double ct_cos2pi(int m, int n) {
+    m = ((m % n) + n) % n;
+    if (4 * m % n == 0) return 4 * m / n == 0 ? 1.0 : 4 * m / n == 2 ? -1.0 : 0.0;
+    double x = 6.283185307179586476925286766559 * m / n;
+    if (x > 3.14159265358979323846) x -= 6.283185307179586476925286766559;
+    return ct_series(x, true);
+}
+constexpr double ct_sin2pi(int m, int n) {
+    m = ((m % n) + n) % n;
+    if (4 * m % n == 0) return 4 * m / n == 1 ? 1.0 : 4 * m / n == 3 ? -1.0 : 0.0;
+    double x = 6.283185307179586476925286766559 * m / n;
+    if (x > 3.14159265358979323846) x -= 6.283185307179586476925286766559;
+    return ct_series(x, false);
+}
+constexpr int ct_first_factor(int n) {  // the first-pass length of a composite codelet: 4 when it divides, else the smallest prime
+    if (n % 4 == 0) return 4;
+    for (int a = 2; a * a <= n; ++a)
+        if (n % a == 0) return a;
+    return n;
+}
+constexpr bool ct_pow2(int n) { return (n & (n - 1)) == 0; }
+
+template <int N>
+__device__ __forceinline__ void idft_any(c32 (&v)[N]) {
+    if constexpr (ct_pow2(N)) {
+        idft<N>(v);
+    } else if constexpr (ct_first_factor(N) == N) {
+        constexpr int h = (N - 1) / 2;
+        c32 a[h + 1], b[h + 1];
+        const c32 v0 = v[0];
+        c32 sum = v0;
+        static_for<1, h + 1>([&](auto jc) {
+            constexpr int j = jc;
+            a[j] = cadd(v[j], v[N - j]);
+            b[j] = csub(v[j], v[N - j]);
+            sum = cadd(sum, a[j]);
+        });
+        static_for<1, h + 1>([&](auto kc) {
+            constexpr int k = kc;
+            v2f cs = vv(v0), sn = {0.0f, 0.0f};
+            static_for<1, h + 1>([&](auto jc) {
+                constexpr int j = jc;
+                constexpr float c = (float)ct_cos2pi(j * k, N), t = (float)ct_sin2pi(j * k, N);
+                cs = __builtin_elementwise_fma(vv(a[j]), v2f{c, c}, cs);
+                sn = __builtin_elementwise_fma(vv(b[j]), v2f{t, t}, sn);
+            });
+            v[k] = cadd_i(cc(cs), cc(sn));
+            v[N - k] = csub_i(cc(cs), cc(sn));
+        });
+        v[0] = sum;
+    } else {
+        constexpr int A = ct_first_factor(N), B = N / A;
+        c32 t[N];
+        static_for<0, B>([&](auto n2c) {
+            constexpr int n2 = n2c;
+            c32 u[A];
+            static_for<0, A>([&](auto n1c) { constexpr int n1 = n1c; u[n1] = v[n1 * B + n2]; });
+            idft_any<A>(u);
+            static_for<0, A>([&](auto k1c) {
+                constexpr int k1 = k1c;
+                if constexpr (k1 * n2 == 0) {
+                    t[k1 * B + n2] = u[k1];
+                } else {
+                    constexpr float c = (float)ct_cos2pi(k1 * n2, N), sgn = (float)ct_sin2pi(k1 * n2, N);
+                    t[k1 * B + n2] = cmul(u[k1], make_float2(c, sgn));
+                }
+            });
+        });
+        static_for<0, A>([&](auto k1c) {
+            constexpr int k1 = k1c;
+            c32 u[B];
+            static_for<0, B>([&](auto n2c) { constexpr int n2 = n2c; u[n2] = t[k1 * B + n2]; });
+            idft_any<B>(u);
+            static_for<0, B>([&](auto k2c) { constexpr int k2 = k2c; v[k1 + A * k2] = u[k2]; });
+        });
+    }
+}
+// forward (sign -) through the inverse codelet, as fdft
+template <int N>
+__device__ __forceinline__ void fdft_any(c32 (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = make_float2(v[i].y, v[i].x);
+    idft_any<N>(v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = make_float2(v[i].y, v[i].x);
+}
 
 struct AnyPlan {
     int H, W, M, S;        // M = W / 2, S = M + 1 = row stride in complex values (odd: M is even for every W = 4 q)
@@ -24,9 +136,24 @@ struct AnyPlan {
     int mn1, mn2;          // M = mn1 * mn2
 };
 
-// N = n1 * n2: n1 is the first-pass length.  A power-of-two n1 <= kAnyMaxRadix runs as a butterfly codelet (cost ~ 2 terms per value), any
-// other pair costs (n1 + n2) / 2 terms per value (conjugate output pairs share their products); pick the cheapest.
+// N = n1 * n2: n1 is the first-pass length.  Both factors <= kAnyCodelet: two register-codelet passes (the most balanced pair, the
+// larger factor first: pass 0 needs no batching); n <= kAnyCodelet: one pass.  Otherwise (a prime factor above 16, or N > 256): a
+// first pass of length n1 <= kAnyCodelet runs as a codelet (cost ~ 2 terms per value), any other pair costs (n1 + n2) / 2 terms per value as
+// direct sums (conjugate output pairs share their products); pick the cheapest.
 static inline void best_split(int n, int& n1, int& n2) {
+    if (n <= kAnyCodelet) {
+        n1 = n;
+        n2 = 1;
+        return;
+    }
+    int best_pair = 0;
+    for (int a = 2; a <= kAnyCodelet; ++a)
+        if (n % a == 0 && n / a <= kAnyCodelet && n / a <= a && (best_pair == 0 || a < best_pair)) best_pair = a;
+    if (best_pair) {
+        n1 = best_pair;
+        n2 = n / best_pair;
+        return;
+    }
     n1 = 1;
     n2 = n;
     float best = 0.5f * (1 + n);
@@ -36,7 +163,7 @@ static inline void best_split(int n, int& n1, int& n2) {
             n1 = a;
             n2 = n / a;
         }
-    for (int r = 2; r <= kAnyMaxRadix; r *= 2)
+    for (int r = 2; r <= kAnyCodelet; ++r)
         if (n % r == 0 && 2.0f + 0.5f * (n / r) <= best) {
             best = 2.0f + 0.5f * (n / r);
             n1 = r;
@@ -56,7 +183,7 @@ __device__ __forceinline__ SpectrumRng spectrum_rng_dyn(uint64_t seed, uint64_t 
     return spectrum_seed<NEED_T>(seed, stream_id, ggroup, tid, tid < H);  // one Philox block read at three depths (power_fft.hip)
 }
 
-// draw_plane with run-time sizes (slots tid < kAnySlots): pair p -> ky = p / M, kx = 1 + p % M, partner H/2 rows below;
+// draw_plane with run-time sizes (slots tid < kAnySlots): pair p -> ky = p / M, kx = 1 + p % M (handed to `pair`), partner H/2 rows below;
 // the kx = M slot of a row is drawn and discarded, as in the fast path
 template <bool NEED_T, typename Edge, typename Pair>
 __device__ __forceinline__ void draw_plane_dyn(SpectrumRng& g, int tid, int H, int M, Edge&& edge, Pair&& pair) {
@@ -66,12 +193,20 @@ __device__ __forceinline__ void draw_plane_dyn(SpectrumRng& g, int tid, int H, i
         const uint32_t t = g.E.next();
         edge(r0, rm, t);
     }
-    const int pairs = (H / 2) * M;
+    // (ky, kx) of pair p walk along with it: one division per plane instead of one per pair
+    const int pairs = (H / 2) * M, dky = kAnySlots / M, dkx = kAnySlots - dky * M;
+    int ky = tid / M, kx = 1 + tid - ky * M;
     for (int p = tid; p < pairs; p += kAnySlots) {
         const uint32_t ra = g.R.next_high();
         const uint32_t rb = g.R.next_high();
         const uint32_t t = NEED_T ? g.T.next() : 0u;
-        pair(p, ra, rb, t);
+        pair(ky, kx, ra, rb, t);
+        ky += dky;
+        kx += dkx;
+        if (kx > M) {
+            kx -= M;
+            ++ky;
+        }
     }
 }
 
@@ -84,12 +219,12 @@ __device__ __forceinline__ void draw_plane_dyn(SpectrumRng& g, int tid, int H, i
 // In place: lines are taken in batches of whole lines (a line's outputs depend on that line only); a batch's items -- kAnyPer
 // per thread -- are gathered in registers, barrier, written, barrier.  Threads take consecutive LINES (conflict-free: odd row
 // stride).
-template <int PASS, bool FWD>
+template <int NT, int PASS, bool FWD>
 __device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw, int TN, int ts, int N1, int N2, int lines, int es, int ls,
                                               int tid) {
     const int K = PASS == 0 ? N1 : N2, G = PASS == 0 ? N2 : N1, HK = K / 2 + 1;
     const int per_line = G * HK;
-    const int per_batch = max(1, (kAnyThreads * kAnyPer) / per_line);
+    const int per_batch = max(1, (NT * kAnyPer) / per_line);
     const int unit = (PASS == 0 ? N2 : N1) * ts;  // twiddle step of k = 1: w_K = w_N^{N / K}
     const float rG = 1.0f / (float)G;
 #pragma unroll 1
@@ -100,7 +235,7 @@ __device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw
         int where[kAnyPer];  // line | k << 10 | g << 20 of the item (sizes are <= 1023), -1 = none: decoded once, used on both sides of the barrier
 #pragma unroll
         for (int j = 0; j < kAnyPer; ++j) {
-            const int idx = tid + j * kAnyThreads;
+            const int idx = tid + j * NT;
             v2f pa = {0.0f, 0.0f}, pb = {0.0f, 0.0f};  // (sum v.x w.x, sum v.x w.y) and (sum v.y w.y, sum v.y w.x): two packed FMAs per term
             int k = 0, g = 0;
             where[j] = -1;
@@ -165,13 +300,13 @@ __device__ __forceinline__ void line_dft_pass(c32* A, const c32* __restrict__ tw
     }
 }
 
-// PASS 0 for N1 = R in {2, 4, 8}: one thread owns a whole sum family (line, n2) -- R loads, the radix-R butterfly codelet of
-// the fixed-size kernels, R - 1 twiddles, R stores to the same slots: no batching, no barrier until the end of the pass.
-template <int R, bool FWD>
+// PASS 0 for N1 = R <= kAnyCodelet: one thread owns a whole sum family (line, n2) -- R loads, the length-R register codelet,
+// R - 1 twiddles, R stores to the same slots: no batching, no barrier until the end of the pass.
+template <int NT, int R, bool FWD>
 __device__ __forceinline__ void radix_pass0(c32* A, const c32* __restrict__ tw, int ts, int N2, int lines, int es, int ls, int tid) {
     const int total = lines * N2;
     const float rl = 1.0f / (float)lines;
-    for (int idx = tid; idx < total; idx += kAnyThreads) {
+    for (int idx = tid; idx < total; idx += NT) {
         int g = (int)(((float)idx + 0.5f) * rl);
         g -= g * lines > idx;
         g += (g + 1) * lines <= idx;
@@ -181,7 +316,7 @@ __device__ __forceinline__ void radix_pass0(c32* A, const c32* __restrict__ tw, 
         c32 v[R];
 #pragma unroll
         for (int n = 0; n < R; ++n) v[n] = base[n * stride];
-        if (FWD) fdft<R>(v); else idft<R>(v);
+        if (FWD) fdft_any<R>(v); else idft_any<R>(v);
 #pragma unroll
         for (int k = 1; k < R; ++k) {
             c32 w = tw[g * k * ts];
@@ -194,32 +329,71 @@ __device__ __forceinline__ void radix_pass0(c32* A, const c32* __restrict__ tw, 
     __syncthreads();
 }
 
-template <bool FWD>
-__device__ __forceinline__ void line_dft(c32* A, const c32* tw, int TN, int ts, int N1, int N2, int lines, int es, int ls, int tid) {
-    switch (N1) {  // uniform
-        case 8: radix_pass0<8, FWD>(A, tw, ts, N2, lines, es, ls, tid); break;
-        case 4: radix_pass0<4, FWD>(A, tw, ts, N2, lines, es, ls, tid); break;
-        case 2: radix_pass0<2, FWD>(A, tw, ts, N2, lines, es, ls, tid); break;
-        default: line_dft_pass<0, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+// PASS 1 for N2 = R <= kAnyCodelet: one thread owns the family (line, k1) -- R loads from in[k1 R + n2], the codelet, R stores to
+// out[k1 + N1 k2].  Outputs land on other families' inputs of the SAME line, so lines are taken in batches of whole lines (all loads,
+// barrier, all stores, barrier); lanes take consecutive lines (odd row stride: conflict-free).
+template <int NT, int R, bool FWD>
+__device__ __forceinline__ void codelet_pass1(c32* A, int N1, int lines, int es, int ls, int tid) {
+    const int per_batch = max(1, NT / N1);
+#pragma unroll 1
+    for (int l0 = 0; l0 < lines; l0 += per_batch) {
+        const int nl = min(per_batch, lines - l0), total = nl * N1;
+        c32 v[R];
+        c32* base = nullptr;
+        if (tid < total) {
+            int k1 = (int)(((float)tid + 0.5f) / (float)nl);
+            k1 -= k1 * nl > tid;
+            k1 += (k1 + 1) * nl <= tid;
+            base = A + (l0 + tid - k1 * nl) * ls + k1 * es;
+            const c32* src = base + k1 * (R - 1) * es;  // element k1 R of the line
+#pragma unroll
+            for (int n = 0; n < R; ++n) v[n] = src[n * es];
+            if (FWD) fdft_any<R>(v); else idft_any<R>(v);
+        }
+        __syncthreads();
+        if (tid < total) {
+            const int stride = N1 * es;
+#pragma unroll
+            for (int k = 0; k < R; ++k) base[k * stride] = v[k];
+        }
+        __syncthreads();
     }
-    line_dft_pass<1, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+}
+
+#define SONAR_ANY_RADICES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+// not inlined: four call sites per kernel, fifteen codelets per pass
+template <int NT, bool FWD>
+__device__ __noinline__ void line_dft(c32* A, const c32* tw, int TN, int ts, int N1, int N2, int lines, int es, int ls, int tid) {
+    switch (N1) {  // uniform
+#define SONAR_ANY_CASE(R) case R: radix_pass0<NT, R, FWD>(A, tw, ts, N2, lines, es, ls, tid); break;
+        SONAR_ANY_RADICES(SONAR_ANY_CASE)
+#undef SONAR_ANY_CASE
+        default: line_dft_pass<NT, 0, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+    }
+    switch (N2) {
+        case 1: break;  // pass 0 was the whole transform
+#define SONAR_ANY_CASE(R) case R: codelet_pass1<NT, R, FWD>(A, N1, lines, es, ls, tid); break;
+        SONAR_ANY_RADICES(SONAR_ANY_CASE)
+#undef SONAR_ANY_CASE
+        default: line_dft_pass<NT, 1, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+    }
 }
 
 // SRC as in power_irfft2_kernel: 0 = spectrum supplied, 1 = drawn on device, 2 = real plane in (forward, x filter, inverse)
-template <int SRC, bool STATS, bool NORM>
-__global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const float* __restrict__ z, const float* __restrict__ filter,
+template <int NT, int SRC, bool STATS, bool NORM>
+__global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __restrict__ z, const float* __restrict__ filter,
                                                                        float* out, int64_t planes, AnyPlan pl, uint64_t seed,
                                                                        uint64_t stream_id, int64_t plane_offset, int group, int split,
                                                                        double* partials, NormArgs na) {
     extern __shared__ __align__(16) unsigned char any_lds[];
-    __shared__ double red[2 * kAnyThreads / 64];
+    __shared__ double red[2 * NT / 64];
     __shared__ NormDecision shd;
     const int H = pl.H, W = pl.W, M = pl.M, S = pl.S, NC = H * S;
     c32* const A = reinterpret_cast<c32*>(any_lds);
     c32* const twH = A + NC;   // e^{2 pi i j / H}
     c32* const twW = twH + H;  // e^{2 pi i j / W}
     const int tid = threadIdx.x;
-    for (int j = tid; j < H + W; j += kAnyThreads) {
+    for (int j = tid; j < H + W; j += NT) {
         const int n = j < H ? H : W, i = j < H ? j : j - H;
         double sn, cs;
         sincospi(2.0 * (double)i / (double)n, &sn, &cs);
@@ -228,7 +402,7 @@ __global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const 
     float scale = SRC == 2 ? 1.0f / ((float)H * (float)W) : 1.0f / sqrtf((float)H * (float)W);
     float nm = scale, nc = 0.0f;
     if constexpr (NORM) {
-        const NormDecision dec = decide_norm<kAnyThreads>(na.partials, kNPart, na.n_total, na.thr_sd, red, &shd);
+        const NormDecision dec = decide_norm<NT>(na.partials, kNPart, na.n_total, na.thr_sd, red, &shd);
         const float g = (dec.do_div ? 1.0f / dec.stdv : 1.0f) * na.factor;
         nm = scale * g;
         nc = dec.do_sub ? dec.mean * g : 0.0f;
@@ -241,7 +415,7 @@ __global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const 
             if (tid < kAnySlots) {
                 rng = spectrum_rng_dyn<true>(seed, stream_id, plane_offset / group + gw.grp, tid, H);
                 for (int i = 0; i < gw.first; ++i)
-                    draw_plane_dyn<true>(rng, tid, H, M, [](uint32_t, uint32_t, uint32_t) {}, [](int, uint32_t, uint32_t, uint32_t) {});
+                    draw_plane_dyn<true>(rng, tid, H, M, [](uint32_t, uint32_t, uint32_t) {}, [](int, int, uint32_t, uint32_t, uint32_t) {});
             }
         }
         for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
@@ -255,8 +429,7 @@ __global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const 
                             A[tid * S] = drawn_elem(r0, t & 0xFFFFu, filter[tid * S]);
                             A[tid * S + M] = drawn_elem(rm, t >> 16, filter[tid * S + M]);
                         },
-                        [&](int p, uint32_t ra, uint32_t rb, uint32_t t) {
-                            const int ky = p / M, kx = 1 + p - ky * M;
+                        [&](int ky, int kx, uint32_t ra, uint32_t rb, uint32_t t) {
                             if (kx < M) {
                                 const int a = ky * S + kx, b = a + (H / 2) * S;
                                 A[a] = drawn_elem(ra, t & 0xFFFFu, filter[a]);
@@ -265,7 +438,7 @@ __global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const 
                         });
             } else if constexpr (SRC == 0) {
                 const c32* zp = reinterpret_cast<const c32*>(z) + plane * NC;
-                for (int j = tid; j < NC; j += kAnyThreads) {
+                for (int j = tid; j < NC; j += NT) {
                     const c32 v = zp[j];
                     const float f = filter[j];
                     A[j] = make_float2(v.x * f, v.y * f);
@@ -273,14 +446,14 @@ __global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const 
             } else {
                 // ---- forward r2c: rows as W/2 complex values, forward DFT, split into the half-spectrum, forward columns, x filter
                 const float* xin = z + plane * (int64_t)H * W;
-                for (int j = tid; j < H * M; j += kAnyThreads) {
+                for (int j = tid; j < H * M; j += NT) {
                     const int r = j / M, m = j - r * M;
                     A[r * S + m] = *reinterpret_cast<const float2*>(xin + (int64_t)r * W + 2 * m);
                 }
                 __syncthreads();
-                line_dft<true>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, tid);
+                line_dft<NT, true>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, tid);
                 // X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i, w = e^{-2 pi i / W}
-                for (int j = tid; j < H * (M / 2 + 1); j += kAnyThreads) {
+                for (int j = tid; j < H * (M / 2 + 1); j += NT) {
                     const int r = j / (M / 2 + 1), k = j - r * (M / 2 + 1);
                     c32* row = A + r * S;
                     if (k == 0) {
@@ -299,8 +472,8 @@ __global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const 
                     }
                 }
                 __syncthreads();
-                line_dft<true>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, tid);
-                for (int j = tid; j < NC; j += kAnyThreads) {
+                line_dft<NT, true>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, tid);
+                for (int j = tid; j < NC; j += NT) {
                     const float f = filter[j];
                     c32 v = A[j];
                     v.x *= f;
@@ -310,10 +483,18 @@ __global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const 
             }
             __syncthreads();
             // ---- inverse columns: every one of the W/2 + 1 columns, length H
-            line_dft<false>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, tid);
+            line_dft<NT, false>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, tid);
             // ---- c2r pre-twiddle: G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k; X[0], X[M] contribute their real parts
-            for (int j = tid; j < H * (M / 2 + 1); j += kAnyThreads) {
-                const int r = j / (M / 2 + 1), k = j - r * (M / 2 + 1);
+            const int Q = M / 2 + 1, qdr = NT / Q, qdk = NT - qdr * Q;  // (row, k) of item j walk along with it
+            int qr = tid / Q, qk = tid - qr * Q;
+            for (int j = tid; j < H * Q; j += NT) {
+                const int r = qr, k = qk;
+                qr += qdr;
+                qk += qdk;
+                if (qk >= Q) {
+                    qk -= Q;
+                    ++qr;
+                }
                 c32* row = A + r * S;
                 if (k == 0) {
                     const float x0 = row[0].x, xm = row[M].x;
@@ -337,11 +518,19 @@ __global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const 
             }
             __syncthreads();
             // ---- rows: length-M complex inverse DFT; value m of a row is (x[2m], x[2m+1])
-            line_dft<false>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, tid);
+            line_dft<NT, false>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, tid);
             float* const oplane = out + plane * (int64_t)H * W;
             float ps = 0.0f, pq = 0.0f;
-            for (int j = tid; j < H * M; j += kAnyThreads) {
-                const int r = j / M, m = j - r * M;
+            const int sdr = NT / M, sdm = NT - sdr * M;
+            int sr = tid / M, sm = tid - sr * M;
+            for (int j = tid; j < H * M; j += NT) {
+                const int r = sr, m = sm;
+                sr += sdr;
+                sm += sdm;
+                if (sm >= M) {
+                    sm -= M;
+                    ++sr;
+                }
                 const c32 g = A[r * S + m];
                 float a, b;
                 if constexpr (NORM) {
@@ -363,7 +552,7 @@ __global__ void __launch_bounds__(kAnyThreads, 8) power_irfft2_any_kernel(const 
             }
         }
     }
-    if constexpr (STATS) write_partial<kAnyThreads>(s, q, partials, red);
+    if constexpr (STATS) write_partial<NT>(s, q, partials, red);
 }
 
 // Parseval statistics of the drawn, filtered spectrum (see power_stats_kernel), run-time sizes; kAnySlots threads
@@ -381,7 +570,7 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_any_kernel(const floa
         const GroupWalk gw(unit, group, split);
         SpectrumRng rng = spectrum_rng_dyn<false>(seed, stream_id, plane_offset / group + gw.grp, tid, H);
         for (int i = 0; i < gw.first; ++i)
-            draw_plane_dyn<false>(rng, tid, H, M, [](uint32_t, uint32_t, uint32_t) {}, [](int, uint32_t, uint32_t, uint32_t) {});
+            draw_plane_dyn<false>(rng, tid, H, M, [](uint32_t, uint32_t, uint32_t) {}, [](int, int, uint32_t, uint32_t, uint32_t) {});
         for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
             float acc = 0.0f;
             c32* const e0 = EDGE + (par * 2 + 0) * H;
@@ -392,8 +581,7 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_any_kernel(const floa
                     e0[tid] = drawn_elem(r0, t & 0xFFFFu, filter[tid * S]);
                     em[tid] = drawn_elem(rm, t >> 16, filter[tid * S + M]);
                 },
-                [&](int p, uint32_t ra, uint32_t rb, uint32_t) {
-                    const int ky = p / M, kx = 1 + p - ky * M;
+                [&](int ky, int kx, uint32_t ra, uint32_t rb, uint32_t) {
                     if (kx < M) {
                         const float fa = filter[ky * S + kx], fb = filter[(ky + H / 2) * S + kx];
                         acc = __builtin_fmaf(fa * fa, neg_ln_u(ra), acc);
@@ -425,7 +613,7 @@ __global__ void __launch_bounds__(kFftThreads) power_spectrum_any_kernel(float* 
         const GroupWalk gw(unit, group, split);
         SpectrumRng rng = spectrum_rng_dyn<true>(seed, stream_id, plane_offset / group + gw.grp, tid, H);
         for (int i = 0; i < gw.first; ++i)
-            draw_plane_dyn<true>(rng, tid, H, M, [](uint32_t, uint32_t, uint32_t) {}, [](int, uint32_t, uint32_t, uint32_t) {});
+            draw_plane_dyn<true>(rng, tid, H, M, [](uint32_t, uint32_t, uint32_t) {}, [](int, int, uint32_t, uint32_t, uint32_t) {});
         for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
             c32* zp = reinterpret_cast<c32*>(zout) + (gw.grp * group + gp) * NC;
             draw_plane_dyn<true>(
@@ -434,8 +622,7 @@ __global__ void __launch_bounds__(kFftThreads) power_spectrum_any_kernel(float* 
                     zp[tid * S] = unit_complex_normal(r0, t & 0xFFFFu);
                     zp[tid * S + M] = unit_complex_normal(rm, t >> 16);
                 },
-                [&](int p, uint32_t ra, uint32_t rb, uint32_t t) {
-                    const int ky = p / M, kx = 1 + p - ky * M;
+                [&](int ky, int kx, uint32_t ra, uint32_t rb, uint32_t t) {
                     if (kx < M) {
                         zp[ky * S + kx] = unit_complex_normal(ra, t & 0xFFFFu);
                         zp[(ky + H / 2) * S + kx] = unit_complex_normal(rb, t >> 16);
@@ -459,17 +646,23 @@ static int launch_power_any(int what, const float* z, const float* filter, float
     const size_t lds_stats = (size_t)4 * H * sizeof(c32);
     const int split = group > 1 && planes / group < 512 ? 1 : 0;
     const int64_t units = split ? planes : planes / group;
-    // resident workgroups: two per CU when two plane buffers fit (the kernel is compiled for <= 64 VGPRs: 2 x 16 waves per CU)
+    // resident workgroups: 16 waves per CU at the codelets' 128-register budget -- two 512-thread workgroups when two plane buffers fit
+    // (two planes in flight per CU: one's barriers under the other's passes), else one of 1024 threads
     const int per_cu = 2 * (lds + 1024) <= 160 * 1024 ? 2 : 1;
     const int g = (int)std::min<int64_t>(std::min<int64_t>(units, 256 * per_cu), kNPart);
-#define SONAR_PA(G, ST, NM, PART)                                                                                                          \
+#define SONAR_PA_NT(NT, G, ST, NM, PART)                                                                                                   \
     do {                                                                                                                                   \
-        auto kern = power_irfft2_any_kernel<G, ST, NM>;                                                                                    \
+        auto kern = power_irfft2_any_kernel<NT, G, ST, NM>;                                                                                \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAnyLdsLimit) !=     \
             hipSuccess)                                                                                                                    \
             (void)hipGetLastError();                                                                                                       \
-        hipLaunchKernelGGL(kern, dim3(g), dim3(kAnyThreads), lds, st, z, filter, out, planes, pl, seed, stream_id, plane_offset, group,    \
-                           split, PART, na);                                                                                               \
+        hipLaunchKernelGGL(kern, dim3(g), dim3(NT), lds, st, z, filter, out, planes, pl, seed, stream_id, plane_offset, group, split,      \
+                           PART, na);                                                                                                      \
+    } while (0)
+#define SONAR_PA(G, ST, NM, PART)                                                                                                          \
+    do {                                                                                                                                   \
+        if (per_cu == 2) SONAR_PA_NT(kAnySlots, G, ST, NM, PART);                                                                          \
+        else SONAR_PA_NT(kAnyThreads, G, ST, NM, PART);                                                                                    \
     } while (0)
     if (what == 3) {
         if (partials) SONAR_PA(2, true, false, partials); else SONAR_PA(2, false, false, partials);
@@ -486,6 +679,7 @@ static int launch_power_any(int what, const float* z, const float* filter, float
         if (partials) SONAR_PA(0, true, false, partials); else SONAR_PA(0, false, false, partials);
     }
 #undef SONAR_PA
+#undef SONAR_PA_NT
     return check_launch("sonar_power_* (general-size plane)");
 }
 

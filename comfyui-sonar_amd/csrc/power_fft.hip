@@ -17,6 +17,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "twiddles256.h"
 
@@ -1562,13 +1564,16 @@ __global__ void __launch_bounds__((plane_threads<H, W>())) power_spectrum_kernel
 }
 
 template <int H, int W>
-static int power_grid(int64_t planes) {
+static int power_grid(int64_t planes, bool owns_partials = true) {
     using C = PlaneCfg<H, W>;
     static_assert(C::kLdsBytes + 256 <= 160 * 1024, "plane does not fit in LDS");
-    // blocks/CU by LDS; persistent grid of resident blocks (<= kNPart so each owns a partial slot)
-    // 16 waves per CU at the kernel's 128-VGPR budget
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(1024 / plane_threads<H, W>(), (160 * 1024) / (C::kLdsBytes + 256)));
-    return (int)std::min<int64_t>(std::min<int64_t>(planes, (int64_t)256 * per_cu), kNPart);
+    // blocks/CU by LDS; persistent grid of resident blocks (<= kNPart when each owns a partial slot)
+    // 16 waves per CU at the 128-row kernels' 128-VGPR budget; the smaller planes' kernels take 64 registers: 32 waves
+    static const int waves = [] { const char* e = getenv("SONAR_POWER_WAVES"); return e ? atoi(e) : 0; }();
+    const int threads_cu = waves > 0 ? waves * 64 : (H >= 128 ? 1024 : 2048);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(threads_cu / plane_threads<H, W>(), (160 * 1024) / (C::kLdsBytes + 256)));
+    const int64_t g = std::min<int64_t>(planes, (int64_t)256 * per_cu);
+    return (int)(owns_partials ? std::min<int64_t>(g, kNPart) : g);
 }
 
 // what: 0 = irfft2 (z given or drawn; optional statistics), 1 = normalised generate (stats pass + final pass),
@@ -1621,10 +1626,9 @@ static int launch_power(int what, const float* z, const float* filter, float* ou
     // too few RNG groups to fill the chip: one workgroup per plane (it fast-forwards the group's streams), same values
     const int split = group > 1 && planes / group < 2 * 256 ? 1 : 0;
     const int64_t ngroups = split ? planes : planes / group;  // work units
-    const int g = power_grid<H, W>(ngroups);
     const dim3 blk(plane_threads<H, W>());
 #define SONAR_PW(G, ST, NM, PART) \
-    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(g), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, group, split, PART, na)
+    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(power_grid<H, W>(ngroups, ST)), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, group, split, PART, na)
     if (what == 4) {
         SONAR_PW(3, false, false, nullptr);
     } else if (what == 3) {

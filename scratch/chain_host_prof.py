@@ -25,4 +25,4 @@ pr.enable()
 for _ in range(500): ns(*sig)
 pr.disable()
 torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(22)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(22); st.sort_stats("cumulative").print_stats(60)

@@ -504,7 +504,10 @@ def test_perlin_and_pyramid_fused_normalisation(hl, factor):
     close(one, two, rtol=1e-5, atol=1e-6)
 
 
-GENERAL_PLANES = [(104, 152), (152, 104), (96, 96), (72, 88), (90, 50), (34, 38), (20, 12), (2, 4), (168, 96), (128, 160), (192, 192), (512, 64), (26, 1024)]
+GENERAL_PLANES = [(104, 152), (152, 104), (96, 96), (72, 88), (90, 50), (34, 38), (20, 12), (2, 4), (168, 96), (128, 160), (192, 192), (512, 64), (26, 1024),
+                  # register codelets of every length 2..16 in either pass (round 3): 11 x 2 / 13 x 2, 15 x 2 / 14, 9 x 2 / 10, 12 x 2 / 9 x 2,
+                  # 12 x 12 / 8 x 7, 12 x 10 / 10 x 8, 11 x 8 / 13 x 4, 16 x 11 / 8 x 5, 14 x 9 / 9 x 5, one-pass lengths, 16 x 15 / 15 x 2
+                  (22, 26), (30, 28), (18, 20), (24, 36), (144, 112), (120, 160), (88, 104), (176, 80), (126, 90), (14, 10), (6, 12), (240, 60)]
 
 
 @pytest.mark.parametrize("hw", GENERAL_PLANES)
