@@ -24,6 +24,9 @@ constexpr size_t kAnyLdsLimit = 160 * 1024 - 2048;
 // twiddles, A transforms of length B).  Every coefficient is a compile-time constant (static_for hands the loop indices to the
 // lambdas as types), so a codelet is straight-line packed arithmetic on register pairs.
 constexpr int kAnyCodelet = 16;
+#ifndef SONAR_ANY_PRIMES  // codelets for 17 and 19 too (136 = 8 x 17 and 152 = 8 x 19 are SDXL sides): 104 x 152 216 -> 152 us, the other sizes +3 %
+#define SONAR_ANY_PRIMES 1
+#endif
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -140,15 +143,16 @@ struct AnyPlan {
 // larger factor first: pass 0 needs no batching); n <= kAnyCodelet: one pass.  Otherwise (a prime factor above 16, or N > 256): a
 // first pass of length n1 <= kAnyCodelet runs as a codelet (cost ~ 2 terms per value), any other pair costs (n1 + n2) / 2 terms per value as
 // direct sums (conjugate output pairs share their products); pick the cheapest.
+static inline bool codelet_len(int n) { return n <= kAnyCodelet || (SONAR_ANY_PRIMES && (n == 17 || n == 19)); }
 static inline void best_split(int n, int& n1, int& n2) {
-    if (n <= kAnyCodelet) {
+    if (codelet_len(n)) {
         n1 = n;
         n2 = 1;
         return;
     }
     int best_pair = 0;
-    for (int a = 2; a <= kAnyCodelet; ++a)
-        if (n % a == 0 && n / a <= kAnyCodelet && n / a <= a && (best_pair == 0 || a < best_pair)) best_pair = a;
+    for (int a = 2; a <= 19; ++a)
+        if (n % a == 0 && codelet_len(a) && codelet_len(n / a) && n / a <= a && (best_pair == 0 || a < best_pair)) best_pair = a;
     if (best_pair) {
         n1 = best_pair;
         n2 = n / best_pair;
@@ -163,8 +167,8 @@ static inline void best_split(int n, int& n1, int& n2) {
             n1 = a;
             n2 = n / a;
         }
-    for (int r = 2; r <= kAnyCodelet; ++r)
-        if (n % r == 0 && 2.0f + 0.5f * (n / r) <= best) {
+    for (int r = 2; r <= 19; ++r)
+        if (n % r == 0 && codelet_len(r) && 2.0f + 0.5f * (n / r) <= best) {
             best = 2.0f + 0.5f * (n / r);
             n1 = r;
             n2 = n / r;
@@ -360,10 +364,22 @@ __device__ __forceinline__ void codelet_pass1(c32* A, int N1, int lines, int es,
     }
 }
 
+#if SONAR_ANY_PRIMES
+#define SONAR_ANY_RADICES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(19)
+#else
 #define SONAR_ANY_RADICES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#endif
 // not inlined: four call sites per kernel, fifteen codelets per pass
+#ifndef SONAR_ANY_INLINE
+#define SONAR_ANY_INLINE 1
+#endif
+#if SONAR_ANY_INLINE
+#define SONAR_ANY_LINKAGE __forceinline__
+#else
+#define SONAR_ANY_LINKAGE __noinline__
+#endif
 template <int NT, bool FWD>
-__device__ __noinline__ void line_dft(c32* A, const c32* tw, int TN, int ts, int N1, int N2, int lines, int es, int ls, int tid) {
+__device__ SONAR_ANY_LINKAGE void line_dft(c32* A, const c32* tw, int TN, int ts, int N1, int N2, int lines, int es, int ls, int tid) {
     switch (N1) {  // uniform
 #define SONAR_ANY_CASE(R) case R: radix_pass0<NT, R, FWD>(A, tw, ts, N2, lines, es, ls, tid); break;
         SONAR_ANY_RADICES(SONAR_ANY_CASE)
