@@ -131,6 +131,9 @@ __device__ __forceinline__ c32 cmulc(c32 a, c32 b) {  // a * conj(b)
 
 constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4 : n == 16 ? 2 : 1; }
 
+#ifndef SONAR_ROW32_SPLIT8
+#define SONAR_ROW32_SPLIT8 1
+#endif
 #ifndef SONAR_FFT_THREADS
 #define SONAR_FFT_THREADS 512
 #endif
@@ -172,7 +175,9 @@ struct PlaneCfg {
     static constexpr int Wh = M + 1;      // half-spectrum width
     static constexpr int S = M + 1;       // LDS row stride (complex): odd -> rows hit distinct banks
     static constexpr int CN1 = split_n1(H), CN2 = H / CN1;
-    static constexpr int RN1 = split_n1(M), RN2 = M / RN1;
+    // 64 x 64: rows of 32 complex values split 8 x 4, not 4 x 8 -- row pass b's RN1 lanes of a row store side by side, 64-byte runs
+    // instead of 32 (79 -> 77.5 us generated, 95 -> 92 us filtered per 33.5 M values; the other heights with W = 64 do not gain)
+    static constexpr int RN1 = (H == 64 && M == 32 && SONAR_ROW32_SPLIT8) ? 8 : split_n1(M), RN2 = M / RN1;
     // Column of element (k1, n2) of a row BETWEEN the two row passes (inverse: written by pass a, read by pass b; forward: written by
     // pass b', read by pass a').  The natural k = RN2 k1 + n2 puts the RN1 lanes of a row that pass b runs side by side (k1 = lane %
     // RN1) RN2 complex values = 16 dwords apart: with S = 1 mod 16 the 16 lanes of an LDS access group (ds_read2_b64 / ds_write2_b64:
@@ -488,6 +493,12 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         const int64_t plane = gw.grp * group + gp;
         __syncthreads();  // previous plane's LDS reads are done (and TW is visible)
         SONAR_STAMP(0);
+        // The general passes index by item = thread + k * NT: every LDS address of a plane is loop-invariant, the optimiser hoists them all
+        // out of the plane loop (the 64 x 64 kernel then wants 184 registers, spills 47 at its 128 and reloads them plane after plane).
+        // An opaque copy of the thread index per plane keeps the address arithmetic -- a few integer operations -- inside the loop
+        // (64 x 64: 106 -> 78 us per 33.5 M values, 256 x 64: 185 -> 91; the planes below 4096 values fit their budget as they are).
+        int ptid = tid;
+        if constexpr (!FAST && H * W >= 4096) asm volatile("" : "+v"(ptid));
         if constexpr (SRC < 2) {
         // ---------------------------------------------------------------- fill: z * filter
         auto sink = [&](int ky, int kx, c32 v) { (kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx]) = v; };
@@ -523,7 +534,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         // complex element m = k1 + RN1 * k2 is (x[2m], x[2m+1]); DFT over k2 -> n2, twiddle
         // two items per trip: the second item's eight row loads are in flight while the first is transformed
 #pragma unroll 2
-        for (int item = tid; item < RN1 * H; item += NT) {
+        for (int item = ptid; item < RN1 * H; item += NT) {
             const int k1 = item % RN1, r = item / RN1;
             const int y = (r / CN2) + CN1 * (r % CN2);
             const float* xrow = xin + (int64_t)y * W;
@@ -544,7 +555,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             c32 v[ITEMS][RN1];
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * NT;
+                const int item = ptid + it * NT;
                 if (item < RN2 * H) {
                     const int r = item % H, n2 = item / H;
 #pragma unroll
@@ -555,7 +566,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * NT;
+                const int item = ptid + it * NT;
                 if (item < RN2 * H) {
                     const int r = item % H, n2 = item / H;
 #pragma unroll
@@ -566,7 +577,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         __syncthreads();
         // r2c split: X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i,
         // w = e^{-2 pi i / W}; the two real columns X[0], X[M] are packed into column 0 as X[0] + i X[M]
-        for (int item = tid; item < (M / 2 + 1) * H; item += NT) {
+        for (int item = ptid; item < (M / 2 + 1) * H; item += NT) {
             const int r = item % H, k = item / H;
             c32* row = A + r * S;
             if (k == 0) {
@@ -586,7 +597,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         }
         __syncthreads();
         // columns, pass b': DFT over k2 -> n2 for fixed k1 (rows CN2 k1 + .), twiddle
-        for (int item = tid; item < CN1 * M; item += NT) {
+        for (int item = ptid; item < CN1 * M; item += NT) {
             const int c = item % M, k1 = item / M;
             c32 u[CN2];
 #pragma unroll
@@ -599,7 +610,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         }
         __syncthreads();
         // columns, pass a': DFT over k1 -> n1: Z[ky = CN2 n1 + n2][c], in place
-        for (int item = tid; item < CN2 * M; item += NT) {
+        for (int item = ptid; item < CN2 * M; item += NT) {
             const int c = item % M, n2 = item / M;
             c32 v[CN1];
 #pragma unroll
@@ -610,7 +621,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         }
         __syncthreads();
         // unpack column 0 (P = DFT(X0 + i XM): Z0 = (P[ky] + conj P[-ky]) / 2, ZM = (P[ky] - conj P[-ky]) / 2i), x filter
-        for (int ky = tid; ky < H; ky += NT) {
+        for (int ky = ptid; ky < H; ky += NT) {
             const int kn = (H - ky) & (H - 1);
             const c32 p = A[ky * S], pn = A[kn * S];
             const float f0 = SRC == 3 ? 1.0f : filter[ky * Wh], fm = SRC == 3 ? 1.0f : filter[ky * Wh + M];
@@ -620,7 +631,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         if constexpr (SRC != 3) {
         // unrolled: the filter values are global loads (L2 hits) -- eight in flight instead of a wait per element
 #pragma unroll 8
-        for (int j = tid; j < H * M; j += NT) {
+        for (int j = ptid; j < H * M; j += NT) {
             const int ky = j / M, c = j - ky * M;
             if (c != 0) {
                 const float f = filter[ky * Wh + c];
@@ -634,7 +645,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         if constexpr (SRC == 3) {
             // forward only: the unscaled half-spectrum rfft2(x)[ky][kx], kx = 0 .. W/2, to global (complex64) and on to the next plane
             c32* const zp = reinterpret_cast<c32*>(out) + plane * (int64_t)H * Wh;
-            for (int j = tid; j < H * Wh; j += NT) {
+            for (int j = ptid; j < H * Wh; j += NT) {
                 const int ky = j / Wh, kx = j - ky * Wh;
                 zp[j] = kx == 0 ? T0[ky] : kx == M ? TM[ky] : A[ky * S + kx];
             }
@@ -733,7 +744,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         // Column 0 is built on the fly from the raw kx = 0 / kx = M columns:
         //   Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky],  sym(Z)[ky] = (Z[ky] + conj Z[-ky]) / 2
 SONAR_UNROLL_ITEMS
-        for (int item = tid; item < CN2 * M; item += NT) {
+        for (int item = ptid; item < CN2 * M; item += NT) {
             const int c = item % M;
             const int n2 = item / M;
             c32 v[CN1];
@@ -758,7 +769,7 @@ SONAR_UNROLL_ITEMS
         // ---------------------------------------------------------------- columns, pass b
         // LDS row r = CN2*k1 + k2 afterwards holds spatial row y = k1 + CN1*k2
 SONAR_UNROLL_ITEMS
-        for (int item = tid; item < CN1 * M; item += NT) {
+        for (int item = ptid; item < CN1 * M; item += NT) {
             const int c = item % M, k1 = item / M;
             c32 u[CN2];
 #pragma unroll
@@ -774,7 +785,7 @@ SONAR_UNROLL_ITEMS
             c32 g[ITEMS][RN1];
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * NT;
+                const int item = ptid + it * NT;
                 if (item < RN2 * H) {
                     const int r = item % H;
                     const int n2 = item / H;
@@ -805,7 +816,7 @@ SONAR_UNROLL_ITEMS
             __syncthreads();  // every mirrored read is done before anyone overwrites
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * NT;
+                const int item = ptid + it * NT;
                 if (item < RN2 * H) {
                     const int r = item % H;
                     const int n2 = item / H;
@@ -841,7 +852,7 @@ SONAR_UNROLL_ITEMS
         }
         float ps = 0.0f, pq = 0.0f;  // per-plane fp32 partials (<= 64 values per thread), folded into fp64 below
 SONAR_UNROLL_ITEMS
-        for (int item = tid; item < RN1 * H; item += NT) {
+        for (int item = ptid; item < RN1 * H; item += NT) {
             const int k1 = item % RN1, r = item / RN1;
             const int y = (r / CN2) + CN1 * (r % CN2);
             c32 u[RN2];
