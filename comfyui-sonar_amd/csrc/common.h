@@ -299,3 +299,9 @@ __device__ __forceinline__ T blend(int mode, T a, T b, T t) {
 }
 
 }  // namespace sonar
+
+// power_fft.hip (power_any.h): the LDS line transforms as passes through a complex workspace, for the planes beyond LDS; false = not
+// taken (odd width, misaligned buffer, line too long): dft_direct.hip then runs its direct sums
+bool sonar_lines_rows_r2c(const float* x, float* y, int64_t rows, int64_t W, hipStream_t st);
+bool sonar_lines_cols(const float* in, const float* filter, float* out, int64_t planes, int64_t H, int64_t K, int inverse, hipStream_t st);
+bool sonar_lines_rows_c2r(const float* y, float* out, int64_t rows, int64_t W, float scale, double* partials, hipStream_t st);

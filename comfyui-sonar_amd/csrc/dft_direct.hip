@@ -134,6 +134,7 @@ using namespace sonar;
 extern "C" int sonar_dft_rows_r2c_f32(const float* x, float* y, int64_t rows, int64_t W, void* stream) {
     SONAR_REQUIRE(x && y && rows >= 0 && W >= 1 && W <= kDirectMax, SONAR_ERR_ARG, "sonar_dft_rows_r2c_f32: bad argument (1 <= W <= %d)", kDirectMax);
     if (rows == 0) return SONAR_OK;
+    if ((reinterpret_cast<uintptr_t>(y) & 7u) == 0 && sonar_lines_rows_r2c(x, y, rows, W, (hipStream_t)stream)) return check_launch("sonar_dft_rows_r2c_f32");
     hipLaunchKernelGGL(dft_rows_r2c_kernel, dim3((int)std::min<int64_t>(rows, 4096)), dim3(kBlock), (size_t)W * (sizeof(float2) + sizeof(float)),
                        (hipStream_t)stream, x, reinterpret_cast<float2*>(y), rows, (int)W);
     return check_launch("sonar_dft_rows_r2c_f32");
@@ -144,6 +145,9 @@ extern "C" int sonar_dft_cols_f32(const float* in, const float* filter, float* o
     SONAR_REQUIRE(in && out && in != out && planes >= 0 && H >= 1 && H <= kDirectMax && K >= 1 && K <= kDirectMax, SONAR_ERR_ARG,
                   "sonar_dft_cols_f32: bad argument (out of place, lines of at most %d)", kDirectMax);
     if (planes == 0) return SONAR_OK;
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7u) == 0 &&
+        sonar_lines_cols(in, filter, out, planes, H, K, inverse, (hipStream_t)stream))
+        return check_launch("sonar_dft_cols_f32");
     const int64_t units = planes * ((K + 63) / 64) * ((H + kBlock / 64 - 1) / (kBlock / 64));
     hipLaunchKernelGGL(dft_cols_kernel, dim3((int)std::min<int64_t>(units, 1 << 16)), dim3(kBlock), (size_t)H * sizeof(float2), (hipStream_t)stream,
                        reinterpret_cast<const float2*>(in), filter, reinterpret_cast<float2*>(out), planes, (int)H, (int)K, inverse);
@@ -152,6 +156,8 @@ extern "C" int sonar_dft_cols_f32(const float* in, const float* filter, float* o
 
 extern "C" int sonar_dft_rows_c2r_f32(const float* y, float* out, int64_t rows, int64_t W, float scale, double* partials, void* stream) {
     SONAR_REQUIRE(y && out && rows >= 0 && W >= 1 && W <= kDirectMax, SONAR_ERR_ARG, "sonar_dft_rows_c2r_f32: bad argument (1 <= W <= %d)", kDirectMax);
+    if (rows > 0 && (reinterpret_cast<uintptr_t>(y) & 7u) == 0 && sonar_lines_rows_c2r(y, out, rows, W, scale, partials, (hipStream_t)stream))
+        return check_launch("sonar_dft_rows_c2r_f32");
     const size_t lds = (size_t)W * sizeof(float2) + (size_t)(W / 2 + 1) * sizeof(float2);
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>(rows, kNPart));
     if (partials)

@@ -699,4 +699,234 @@ static int launch_power_any(int what, const float* z, const float* filter, float
     return check_launch("sonar_power_* (general-size plane)");
 }
 
+// ---- planes beyond LDS: the same line transforms, a pass per launch through a complex workspace ---------------------------------
+// (sonar_dft_rows_r2c_f32 / sonar_dft_cols_f32 / sonar_dft_rows_c2r_f32 for even widths: dft_direct.hip keeps the odd ones.)  A
+// workgroup stages a batch of lines in LDS -- rows as W/2 complex values with the half-length trick, columns as a block of adjacent
+// columns of one plane -- runs line_dft over them and writes the result; lengths up to kLinesMax, any factorisation (a factor the
+// codelets do not cover costs that pass its direct sums: 512 = 16 x 32 is sixteen terms per value, not 512).
+constexpr int kLinesThreads = 512;
+constexpr int kLinesMax = 2048;
+constexpr size_t kLinesLds = 64 * 1024;  // two workgroups per CU
+
+__device__ __forceinline__ void lines_table(c32* tw, int N, int tid) {  // e^{2 pi i j / N}
+    for (int j = tid; j < N; j += kLinesThreads) {
+        double sn, cs;
+        sincospi(2.0 * (double)j / (double)N, &sn, &cs);
+        tw[j] = make_float2((float)cs, (float)sn);
+    }
+}
+
+// y[row][k] = sum_x x[row][x] e^{-2 pi i k x / W}, k = 0 .. W/2; `per` rows per batch
+__global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_kernel(const float* __restrict__ x, c32* __restrict__ y, int64_t rows, int W, int n1,
+                                                                     int n2, int per) {
+    extern __shared__ __align__(16) unsigned char any_lds[];
+    const int M = W / 2, S = M + 1, tid = threadIdx.x;
+    c32* const A = reinterpret_cast<c32*>(any_lds);
+    c32* const tw = A + per * S;
+    lines_table(tw, W, tid);
+    for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
+        const int nr = (int)min<int64_t>(per, rows - r0);
+        __syncthreads();
+        for (int j = tid; j < nr * M; j += kLinesThreads) {
+            const int r = j / M, m = j - r * M;
+            A[r * S + m] = *reinterpret_cast<const float2*>(x + (r0 + r) * W + 2 * m);
+        }
+        __syncthreads();
+        line_dft<kLinesThreads, true>(A, tw, W, 2, n1, n2, nr, 1, S, tid);
+        // X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i, w = e^{-2 pi i / W}
+        for (int j = tid; j < nr * (M / 2 + 1); j += kLinesThreads) {
+            const int r = j / (M / 2 + 1), k = j - r * (M / 2 + 1);
+            c32* row = A + r * S;
+            if (k == 0) {
+                const c32 c0 = row[0];
+                row[0] = make_float2(c0.x + c0.y, 0.0f);
+                row[M] = make_float2(c0.x - c0.y, 0.0f);
+            } else {
+                const int kk = M - k;
+                const c32 a = row[k], b = row[kk];
+                const c32 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+                const c32 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
+                const c32 w = tw[k];
+                const c32 t = make_float2(o.x * w.x + o.y * w.y, o.y * w.x - o.x * w.y);
+                row[k] = make_float2(e.x + t.x, e.y + t.y);
+                if (kk != k) row[kk] = make_float2(e.x - t.x, -(e.y - t.y));
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < nr * S; j += kLinesThreads) {
+            const int r = j / S, k = j - r * S;
+            y[(r0 + r) * S + k] = A[r * S + k];
+        }
+    }
+}
+
+// out[p][n][k] = sum_m in[p][m][k] (* filter[m][k]) e^{-+ 2 pi i m n / H}: a workgroup owns `cols` adjacent columns of one plane
+template <bool INV>
+__global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32* __restrict__ in, const float* __restrict__ filter,
+                                                                      c32* __restrict__ out, int64_t planes, int H, int K, int n1, int n2,
+                                                                      int cols) {
+    extern __shared__ __align__(16) unsigned char any_lds[];
+    const int S = cols | 1, tid = threadIdx.x;  // odd row stride
+    c32* const A = reinterpret_cast<c32*>(any_lds);
+    c32* const tw = A + (size_t)H * S;
+    lines_table(tw, H, tid);
+    const int blocks = (K + cols - 1) / cols;
+    for (int64_t u = blockIdx.x; u < planes * blocks; u += gridDim.x) {
+        const int64_t p = u / blocks;
+        const int k0 = (int)(u - p * blocks) * cols, nc = min(cols, K - k0);
+        const c32* src = in + p * (int64_t)H * K + k0;
+        __syncthreads();
+        for (int j = tid; j < H * nc; j += kLinesThreads) {
+            const int m = j / nc, c = j - m * nc;
+            c32 v = src[(int64_t)m * K + c];
+            if (filter) {
+                const float f = filter[(int64_t)m * K + k0 + c];
+                v.x *= f;
+                v.y *= f;
+            }
+            A[m * S + c] = v;
+        }
+        __syncthreads();
+        line_dft<kLinesThreads, !INV>(A, tw, H, 1, n1, n2, nc, S, 1, tid);
+        c32* dst = out + p * (int64_t)H * K + k0;
+        for (int j = tid; j < H * nc; j += kLinesThreads) {
+            const int m = j / nc, c = j - m * nc;
+            dst[(int64_t)m * K + c] = A[m * S + c];
+        }
+    }
+}
+
+// out[row][x] = scale * (Re y0 + sum_{k >= 1} w_k Re(y_k e^{+2 pi i k x / W})), w_k = 2 (1 for the Nyquist column)
+template <bool STATS>
+__global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* __restrict__ y, float* __restrict__ out, int64_t rows, int W, int n1,
+                                                                     int n2, int per, float scale, double* partials) {
+    extern __shared__ __align__(16) unsigned char any_lds[];
+    __shared__ double red[2 * kLinesThreads / 64];
+    const int M = W / 2, S = M + 1, tid = threadIdx.x;
+    c32* const A = reinterpret_cast<c32*>(any_lds);
+    c32* const tw = A + per * S;
+    lines_table(tw, W, tid);
+    double s = 0.0, q = 0.0;
+    for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
+        const int nr = (int)min<int64_t>(per, rows - r0);
+        __syncthreads();
+        for (int j = tid; j < nr * S; j += kLinesThreads) {
+            const int r = j / S, k = j - r * S;
+            A[r * S + k] = y[(r0 + r) * S + k];
+        }
+        __syncthreads();
+        // G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k; X[0], X[M] contribute their real parts
+        for (int j = tid; j < nr * (M / 2 + 1); j += kLinesThreads) {
+            const int r = j / (M / 2 + 1), k = j - r * (M / 2 + 1);
+            c32* row = A + r * S;
+            if (k == 0) {
+                const float x0 = row[0].x, xm = row[M].x;
+                row[0] = make_float2(x0 + xm, x0 - xm);
+            } else {
+                const int kk = M - k;
+                const c32 xa = row[k], xb = row[kk];
+                {
+                    const c32 e = make_float2(xa.x + xb.x, xa.y - xb.y), d = make_float2(xa.x - xb.x, xa.y + xb.y);
+                    const c32 w = tw[k];
+                    const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+                    row[k] = make_float2(e.x - o.y, e.y + o.x);
+                }
+                if (kk != k) {
+                    const c32 e = make_float2(xb.x + xa.x, xb.y - xa.y), d = make_float2(xb.x - xa.x, xb.y + xa.y);
+                    const c32 w = tw[kk];
+                    const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+                    row[kk] = make_float2(e.x - o.y, e.y + o.x);
+                }
+            }
+        }
+        __syncthreads();
+        line_dft<kLinesThreads, false>(A, tw, W, 2, n1, n2, nr, 1, S, tid);
+        for (int j = tid; j < nr * M; j += kLinesThreads) {
+            const int r = j / M, m = j - r * M;
+            const c32 g = A[r * S + m];
+            const float a = g.x * scale, b = g.y * scale;
+            *reinterpret_cast<float2*>(out + (r0 + r) * W + 2 * m) = make_float2(a, b);
+            if constexpr (STATS) {  // fp64 per value, like the direct pass (its callers compare the sums with the tensor's)
+                const double da = a, db = b;
+                s += da + db;
+                q += da * da + db * db;
+            }
+        }
+    }
+    if constexpr (STATS) write_partial<kLinesThreads>(s, q, partials, red);
+}
+
+// rows per batch / columns per block that fit kLinesLds beside the twiddle table
+static inline int lines_per(size_t line_bytes, size_t table_bytes, int want) {
+    const size_t room = kLinesLds > table_bytes ? kLinesLds - table_bytes : 0;
+    return (int)std::max<size_t>(1, std::min<size_t>(want, room / line_bytes));
+}
+
+template <typename K>
+static void lines_lds_attr(K kern) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAnyLdsLimit) != hipSuccess)
+        (void)hipGetLastError();
+}
+
 }  // namespace sonar
+
+// even widths / any height up to kLinesMax; false: not taken (the direct passes of dft_direct.hip run)
+bool sonar_lines_rows_r2c(const float* x, float* y, int64_t rows, int64_t W, hipStream_t st) {
+    using namespace sonar;
+    if (W < 4 || (W & 1) || W > 2 * kLinesMax || (reinterpret_cast<uintptr_t>(x) & 7u)) return false;
+    const int M = (int)W / 2;
+    int n1, n2;
+    best_split(M, n1, n2);
+    const size_t line = (size_t)(M + 1) * sizeof(c32), table = (size_t)W * sizeof(c32);
+    const int per = lines_per(line, table, 512);
+    lines_lds_attr(lines_r2c_kernel);
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>((rows + per - 1) / per, 1024));
+    hipLaunchKernelGGL(lines_r2c_kernel, dim3(g), dim3(kLinesThreads), per * line + table, st, x, reinterpret_cast<c32*>(y), rows, (int)W, n1, n2, per);
+    return true;
+}
+
+bool sonar_lines_cols(const float* in, const float* filter, float* out, int64_t planes, int64_t H, int64_t K, int inverse, hipStream_t st) {
+    using namespace sonar;
+    if (H < 2 || H > kLinesMax) return false;
+    int n1, n2;
+    best_split((int)H, n1, n2);
+    const size_t table = (size_t)H * sizeof(c32);
+    int cols = lines_per((size_t)H * sizeof(c32), table, 64);
+    if (((cols | 1) * (size_t)H) * sizeof(c32) + table > kAnyLdsLimit) cols = std::max(1, cols - 1);
+    cols = (int)std::min<int64_t>(cols, K);
+    const size_t lds = (size_t)H * (cols | 1) * sizeof(c32) + table;
+    if (lds > kAnyLdsLimit) return false;
+    const int64_t units = planes * ((K + cols - 1) / cols);
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(units, 4096));
+    if (inverse) {
+        lines_lds_attr(lines_cols_kernel<true>);
+        hipLaunchKernelGGL(lines_cols_kernel<true>, dim3(g), dim3(kLinesThreads), lds, st, reinterpret_cast<const c32*>(in), filter,
+                           reinterpret_cast<c32*>(out), planes, (int)H, (int)K, n1, n2, cols);
+    } else {
+        lines_lds_attr(lines_cols_kernel<false>);
+        hipLaunchKernelGGL(lines_cols_kernel<false>, dim3(g), dim3(kLinesThreads), lds, st, reinterpret_cast<const c32*>(in), filter,
+                           reinterpret_cast<c32*>(out), planes, (int)H, (int)K, n1, n2, cols);
+    }
+    return true;
+}
+
+bool sonar_lines_rows_c2r(const float* y, float* out, int64_t rows, int64_t W, float scale, double* partials, hipStream_t st) {
+    using namespace sonar;
+    if (W < 4 || (W & 1) || W > 2 * kLinesMax || (reinterpret_cast<uintptr_t>(out) & 7u)) return false;
+    const int M = (int)W / 2;
+    int n1, n2;
+    best_split(M, n1, n2);
+    const size_t line = (size_t)(M + 1) * sizeof(c32), table = (size_t)W * sizeof(c32);
+    const int per = lines_per(line, table, 512);
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>((rows + per - 1) / per, kNPart));
+    if (partials) {
+        lines_lds_attr(lines_c2r_kernel<true>);
+        hipLaunchKernelGGL(lines_c2r_kernel<true>, dim3(g), dim3(kLinesThreads), per * line + table, st, reinterpret_cast<const c32*>(y), out, rows, (int)W,
+                           n1, n2, per, scale, partials);
+    } else {
+        lines_lds_attr(lines_c2r_kernel<false>);
+        hipLaunchKernelGGL(lines_c2r_kernel<false>, dim3(g), dim3(kLinesThreads), per * line + table, st, reinterpret_cast<const c32*>(y), out, rows, (int)W,
+                           n1, n2, per, scale, partials);
+    }
+    return true;
+}

@@ -708,11 +708,14 @@ def test_fused_normalised_fill(hl, uniform, n, offset):
         assert abs(one.std().item() - factor) < (2.5 / math.sqrt(n) + 5e-3) * factor  # inside the band nothing is rescaled
 
 
-@pytest.mark.parametrize("shape", [(3, 9, 7), (2, 135, 30), (5, 16, 21), (2, 33, 64), (1, 1, 5), (2, 6, 1), (1, 250, 250)])
+@pytest.mark.parametrize("shape", [(3, 9, 7), (2, 135, 30), (5, 16, 21), (2, 33, 64), (1, 1, 5), (2, 6, 1), (1, 250, 250),
+                                   # even widths run the LDS line transforms pass by pass (round 3): 16 x 16 codelets, a direct second pass (512 = 16 x
+                                   # 32), the longest lines either way, a length with the factors 13 and 20
+                                   (1, 256, 256), (2, 384, 512), (1, 2048, 40), (1, 34, 2048), (1, 300, 520)])
 def test_direct_dft_passes_match_torch_fft(hl, shape):
     """sonar_dft_rows_r2c / cols / rows_c2r (the route of planes the LDS FFT kernels do not take: odd sizes, big planes) against
     torch.fft: rfft2, irfft2 of a filtered spectrum (norm='ortho', imaginary parts of the DC / Nyquist columns ignored), and the
-    spectral filter irfft2(rfft2(x) * f).  fp32 direct sums: 2e-5 of the result's peak."""
+    spectral filter irfft2(rfft2(x) * f).  fp32 sums: 2e-5 of the result's peak."""
     planes, H, W = shape
     K = W // 2 + 1
     g = torch.Generator(device="cuda").manual_seed(3)
