@@ -144,10 +144,13 @@ extern "C" int sonar_dft_cols_f32(const float* in, const float* filter, float* o
                                   void* stream) {
     SONAR_REQUIRE(in && out && in != out && planes >= 0 && H >= 1 && H <= kDirectMax && K >= 1 && K <= kDirectMax, SONAR_ERR_ARG,
                   "sonar_dft_cols_f32: bad argument (out of place, lines of at most %d)", kDirectMax);
+    SONAR_REQUIRE(inverse >= 0 && inverse <= 2 && (inverse != 2 || filter), SONAR_ERR_ARG, "sonar_dft_cols_f32: inverse is 0, 1 or 2 (2 needs the filter)");
     if (planes == 0) return SONAR_OK;
     if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7u) == 0 &&
         sonar_lines_cols(in, filter, out, planes, H, K, inverse, (hipStream_t)stream))
         return check_launch("sonar_dft_cols_f32");
+    // the round trip (forward, x filter, inverse) only exists with the columns in LDS: the caller runs the two passes instead
+    SONAR_REQUIRE(inverse != 2, SONAR_ERR_UNSUPPORTED, "sonar_dft_cols_f32: the fused round trip does not take these buffers");
     const int64_t units = planes * ((K + 63) / 64) * ((H + kBlock / 64 - 1) / (kBlock / 64));
     hipLaunchKernelGGL(dft_cols_kernel, dim3((int)std::min<int64_t>(units, 1 << 16)), dim3(kBlock), (size_t)H * sizeof(float2), (hipStream_t)stream,
                        reinterpret_cast<const float2*>(in), filter, reinterpret_cast<float2*>(out), planes, (int)H, (int)K, inverse);

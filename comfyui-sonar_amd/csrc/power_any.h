@@ -760,8 +760,10 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_kernel(const float
     }
 }
 
-// out[p][n][k] = sum_m in[p][m][k] (* filter[m][k]) e^{-+ 2 pi i m n / H}: a workgroup owns `cols` adjacent columns of one plane
-template <bool INV>
+// MODE 0 / 1: out[p][n][k] = sum_m in[p][m][k] (* filter[m][k]) e^{-+ 2 pi i m n / H}; MODE 2: the spectral filter's middle -- forward
+// columns, x filter[ky][k], inverse columns -- with the columns staying in LDS (one pass over the workspace instead of two).  A
+// workgroup owns `cols` adjacent columns of one plane.
+template <int MODE>
 __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32* __restrict__ in, const float* __restrict__ filter,
                                                                       c32* __restrict__ out, int64_t planes, int H, int K, int n1, int n2,
                                                                       int cols) {
@@ -779,7 +781,7 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32*
         for (int j = tid; j < H * nc; j += kLinesThreads) {
             const int m = j / nc, c = j - m * nc;
             c32 v = src[(int64_t)m * K + c];
-            if (filter) {
+            if (MODE == 1 && filter) {
                 const float f = filter[(int64_t)m * K + k0 + c];
                 v.x *= f;
                 v.y *= f;
@@ -787,7 +789,19 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32*
             A[m * S + c] = v;
         }
         __syncthreads();
-        line_dft<kLinesThreads, !INV>(A, tw, H, 1, n1, n2, nc, S, 1, tid);
+        line_dft<kLinesThreads, MODE != 1>(A, tw, H, 1, n1, n2, nc, S, 1, tid);
+        if constexpr (MODE == 2) {
+            for (int j = tid; j < H * nc; j += kLinesThreads) {
+                const int m = j / nc, c = j - m * nc;
+                const float f = filter[(int64_t)m * K + k0 + c];
+                c32 v = A[m * S + c];
+                v.x *= f;
+                v.y *= f;
+                A[m * S + c] = v;
+            }
+            __syncthreads();
+            line_dft<kLinesThreads, false>(A, tw, H, 1, n1, n2, nc, S, 1, tid);
+        }
         c32* dst = out + p * (int64_t)H * K + k0;
         for (int j = tid; j < H * nc; j += kLinesThreads) {
             const int m = j / nc, c = j - m * nc;
@@ -898,15 +912,14 @@ bool sonar_lines_cols(const float* in, const float* filter, float* out, int64_t 
     if (lds > kAnyLdsLimit) return false;
     const int64_t units = planes * ((K + cols - 1) / cols);
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>(units, 4096));
-    if (inverse) {
-        lines_lds_attr(lines_cols_kernel<true>);
-        hipLaunchKernelGGL(lines_cols_kernel<true>, dim3(g), dim3(kLinesThreads), lds, st, reinterpret_cast<const c32*>(in), filter,
-                           reinterpret_cast<c32*>(out), planes, (int)H, (int)K, n1, n2, cols);
-    } else {
-        lines_lds_attr(lines_cols_kernel<false>);
-        hipLaunchKernelGGL(lines_cols_kernel<false>, dim3(g), dim3(kLinesThreads), lds, st, reinterpret_cast<const c32*>(in), filter,
-                           reinterpret_cast<c32*>(out), planes, (int)H, (int)K, n1, n2, cols);
-    }
+#define SONAR_LINES_COLS(MODE)                                                                                                            \
+    do {                                                                                                                                   \
+        lines_lds_attr(lines_cols_kernel<MODE>);                                                                                           \
+        hipLaunchKernelGGL(lines_cols_kernel<MODE>, dim3(g), dim3(kLinesThreads), lds, st, reinterpret_cast<const c32*>(in), filter,       \
+                           reinterpret_cast<c32*>(out), planes, (int)H, (int)K, n1, n2, cols);                                             \
+    } while (0)
+    if (inverse == 2) SONAR_LINES_COLS(2); else if (inverse) SONAR_LINES_COLS(1); else SONAR_LINES_COLS(0);
+#undef SONAR_LINES_COLS
     return true;
 }
 

@@ -1144,6 +1144,12 @@ def _direct_spectral_filter(x: torch.Tensor, filt: torch.Tensor, partials) -> to
     a = torch.empty((planes, H, K), dtype=torch.complex64, device=x.device)
     b = torch.empty_like(a)
     _check(lib.sonar_dft_rows_r2c_f32(_dev(x, "x"), a.data_ptr(), planes * H, W, _stream()), "sonar_dft_rows_r2c_f32")
+    # forward columns, x filter, inverse columns in one pass over the workspace when the columns go through LDS (mode 2)
+    if lib.sonar_dft_cols_f32(a.data_ptr(), _dev(filt, "filter"), b.data_ptr(), planes, H, K, 2, _stream()) == 0:
+        out = torch.empty_like(x)
+        _check(lib.sonar_dft_rows_c2r_f32(b.data_ptr(), _dev(out, "out"), planes * H, W, 1.0 / (H * W), _opt(partials, "partials", torch.float64),
+                                          _stream()), "sonar_dft_rows_c2r_f32")
+        return out
     _check(lib.sonar_dft_cols_f32(a.data_ptr(), None, b.data_ptr(), planes, H, K, 0, _stream()), "sonar_dft_cols_f32")
     return _direct_inverse(b, filt, torch.empty_like(x), 1.0 / (H * W), partials)
 
