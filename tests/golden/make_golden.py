@@ -244,6 +244,7 @@ def gen_power_noise():
         ("np2", (2, 4, 40, 56), 5, {"alpha": 1.0}, True),                       # not powers of two (general-size kernels)
         ("np2_rot", (1, 4, 52, 76), 6, {"alpha": 1.5, "rotate": 20.0, "stretch": 1.5, "common_mode": 0.1}, True),  # quarter-size 832 x 1216 px
         ("odd", (2, 4, 27, 35), 7, {"alpha": 1.0, "common_mode": 0.1}, True),   # odd height and width (1080 lines -> 135 rows): direct DFT passes
+        ("sdxl_portrait", (1, 4, 104, 152), 8, {"alpha": 1.0}, True),           # 832 x 1216 px at full size: codelets 13 x 8 and 19 x 4
     ):
         item = ref_power_item(**kw)
         x = torch.zeros(shape)

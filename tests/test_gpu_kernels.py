@@ -338,7 +338,7 @@ def test_pyramid_flat_kernel_for_levels_beyond_lds(hl):
 
 
 # ------------------------------------------------------------------------------------------------ power-law rFFT noise
-@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e", "np2", "np2_rot", "odd"])
+@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e", "np2", "np2_rot", "odd", "sdxl_portrait"])
 def test_power_noise_replay_golden(hl, golden, tag):
     g = golden("power_noise")
     z = torch.view_as_complex(g[f"{tag}_z"].contiguous())

@@ -97,7 +97,7 @@ def test_power_filter_and_mixer(golden):
     close(orc.channel_mixer(4, 0.4, torch.tensor([0.5, -0.3, 0.8])), g["mixer_partial"])
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e", "np2", "np2_rot", "odd"])
+@pytest.mark.parametrize("tag", ["cfg2", "b", "c", "d", "e", "np2", "np2_rot", "odd", "sdxl_portrait"])
 def test_power_noise(golden, tag):
     g = golden("power_noise")
     z = torch.view_as_complex(g[f"{tag}_z"].contiguous())
