@@ -137,6 +137,7 @@ struct AnyPlan {
     int H, W, M, S;        // M = W / 2, S = M + 1 = row stride in complex values (odd: M is even for every W = 4 q)
     int hn1, hn2;          // H = hn1 * hn2
     int mn1, mn2;          // M = mn1 * mn2
+    int c2r_fuse;          // the rows' first pass forms the c2r pre-twiddle as it loads (c2r_pass0): pays when its batches of whole rows are few and full
 };
 
 // N = n1 * n2: n1 is the first-pass length.  Both factors <= kAnyCodelet: two register-codelet passes (the most balanced pair, the
@@ -379,6 +380,16 @@ __device__ __forceinline__ void codelet_pass1(c32* A, int N1, int lines, int es,
 #define SONAR_ANY_LINKAGE __noinline__
 #endif
 template <int NT, bool FWD>
+__device__ SONAR_ANY_LINKAGE void line_pass1(c32* A, const c32* tw, int TN, int ts, int N1, int N2, int lines, int es, int ls, int tid) {
+    switch (N2) {  // uniform
+        case 1: break;  // pass 0 was the whole transform
+#define SONAR_ANY_CASE(R) case R: codelet_pass1<NT, R, FWD>(A, N1, lines, es, ls, tid); break;
+        SONAR_ANY_RADICES(SONAR_ANY_CASE)
+#undef SONAR_ANY_CASE
+        default: line_dft_pass<NT, 1, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+    }
+}
+template <int NT, bool FWD>
 __device__ SONAR_ANY_LINKAGE void line_dft(c32* A, const c32* tw, int TN, int ts, int N1, int N2, int lines, int es, int ls, int tid) {
     switch (N1) {  // uniform
 #define SONAR_ANY_CASE(R) case R: radix_pass0<NT, R, FWD>(A, tw, ts, N2, lines, es, ls, tid); break;
@@ -386,13 +397,115 @@ __device__ SONAR_ANY_LINKAGE void line_dft(c32* A, const c32* tw, int TN, int ts
 #undef SONAR_ANY_CASE
         default: line_dft_pass<NT, 0, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
     }
-    switch (N2) {
-        case 1: break;  // pass 0 was the whole transform
-#define SONAR_ANY_CASE(R) case R: codelet_pass1<NT, R, FWD>(A, N1, lines, es, ls, tid); break;
+    line_pass1<NT, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+}
+
+// The c2r pre-twiddle G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k (X[0], X[M] contribute their real parts) as a pass over
+// the plane of its own: every row's (k, M - k) pairs read, combined and written back.
+template <int NT>
+__device__ __forceinline__ void c2r_pretwiddle(c32* A, const c32* __restrict__ twW, int H, int M, int S, int tid) {
+    const int Q = M / 2 + 1, qdr = NT / Q, qdk = NT - qdr * Q;  // (row, k) of item j walk along with it
+    int qr = tid / Q, qk = tid - qr * Q;
+    for (int j = tid; j < H * Q; j += NT) {
+        const int r = qr, k = qk;
+        qr += qdr;
+        qk += qdk;
+        if (qk >= Q) {
+            qk -= Q;
+            ++qr;
+        }
+        c32* row = A + r * S;
+        if (k == 0) {
+            const float x0 = row[0].x, xm = row[M].x;
+            row[0] = make_float2(x0 + xm, x0 - xm);
+        } else {
+            const int kk = M - k;
+            const c32 xa = row[k], xb = row[kk];
+            {
+                const c32 e = make_float2(xa.x + xb.x, xa.y - xb.y), d = make_float2(xa.x - xb.x, xa.y + xb.y);
+                const c32 w = twW[k];
+                const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+                row[k] = make_float2(e.x - o.y, e.y + o.x);
+            }
+            if (kk != k) {
+                const c32 e = make_float2(xb.x + xa.x, xb.y - xa.y), d = make_float2(xb.x - xa.x, xb.y + xa.y);
+                const c32 w = twW[kk];
+                const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+                row[kk] = make_float2(e.x - o.y, e.y + o.x);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ... or folded into the rows' first pass when that is a codelet: the thread that owns family (row, n2) forms G[n1 N2 + n2] from
+// X[k] and X[M - k] as it loads (one more LDS read and the w^k table read per value; the pass of its own costs both reads, both
+// writes and the item indexing).  The mirrored values belong to another family of the SAME row, so rows are taken in batches of
+// whole rows: all loads, barrier, all stores, barrier.
+template <int NT, int R>
+__device__ __forceinline__ void c2r_pass0(c32* A, const c32* __restrict__ twW, int N2, int H, int M, int S, int tid) {
+    // rows per batch: as many as the threads take, spread evenly over the batches (96 rows of 6 families: 48 + 48, not 85 + 11)
+    const int most = max(1, NT / N2), batches = (H + most - 1) / most, per_batch = (H + batches - 1) / batches;
+#pragma unroll 1
+    for (int l0 = 0; l0 < H; l0 += per_batch) {
+        const int nl = min(per_batch, H - l0), total = nl * N2;
+        c32 v[R];
+        c32* row = nullptr;
+        int n2 = 0;
+        if (tid < total) {
+            n2 = (int)(((float)tid + 0.5f) / (float)nl);
+            n2 -= n2 * nl > tid;
+            n2 += (n2 + 1) * nl <= tid;
+            row = A + (l0 + tid - n2 * nl) * S;
+#pragma unroll
+            for (int n1 = 0; n1 < R; ++n1) {
+                const int k = n1 * N2 + n2;
+                if (n1 == 0 && n2 == 0) {  // k = 0
+                    const float x0 = row[0].x, xm = row[M].x;
+                    v[n1] = make_float2(x0 + xm, x0 - xm);
+                } else {
+                    const c32 xa = row[k], xb = row[M - k], w = twW[k];
+                    const c32 e = make_float2(xa.x + xb.x, xa.y - xb.y), d = make_float2(xa.x - xb.x, xa.y + xb.y);
+                    const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+                    v[n1] = make_float2(e.x - o.y, e.y + o.x);
+                }
+            }
+            idft_any<R>(v);
+#pragma unroll
+            for (int k1 = 1; k1 < R; ++k1) {
+                const c32 w = twW[2 * n2 * k1];  // e^{2 pi i n2 k1 / M}
+                v[k1] = make_float2(v[k1].x * w.x - v[k1].y * w.y, v[k1].x * w.y + v[k1].y * w.x);
+            }
+        }
+        __syncthreads();
+        if (tid < total) {
+#pragma unroll
+            for (int k1 = 0; k1 < R; ++k1) row[k1 * N2 + n2] = v[k1];
+        }
+        __syncthreads();
+    }
+}
+
+// rows of the inverse: pre-twiddle + length-M complex inverse DFT (value m of a row is then (x[2m], x[2m+1]))
+#ifndef SONAR_ANY_FUSE_C2R
+#define SONAR_ANY_FUSE_C2R 1
+#endif
+template <int NT>
+__device__ SONAR_ANY_LINKAGE void c2r_rows(c32* A, const c32* twW, int W, int N1, int N2, int H, int M, int S, int fuse, int tid) {
+    if (!SONAR_ANY_FUSE_C2R || !fuse) {  // uniform
+        c2r_pretwiddle<NT>(A, twW, H, M, S, tid);
+        line_dft<NT, false>(A, twW, W, 2, N1, N2, H, 1, S, tid);
+        return;
+    }
+    switch (N1) {  // uniform
+#define SONAR_ANY_CASE(R) case R: c2r_pass0<NT, R>(A, twW, N2, H, M, S, tid); break;
         SONAR_ANY_RADICES(SONAR_ANY_CASE)
 #undef SONAR_ANY_CASE
-        default: line_dft_pass<NT, 1, FWD>(A, tw, TN, ts, N1, N2, lines, es, ls, tid);
+        default:
+            c2r_pretwiddle<NT>(A, twW, H, M, S, tid);
+            line_dft_pass<NT, 0, false>(A, twW, W, 2, N1, N2, H, 1, S, tid);
     }
+    line_pass1<NT, false>(A, twW, W, 2, N1, N2, H, 1, S, tid);
 }
 
 // SRC as in power_irfft2_kernel: 0 = spectrum supplied, 1 = drawn on device, 2 = real plane in (forward, x filter, inverse)
@@ -500,41 +613,8 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
             __syncthreads();
             // ---- inverse columns: every one of the W/2 + 1 columns, length H
             line_dft<NT, false>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, tid);
-            // ---- c2r pre-twiddle: G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k; X[0], X[M] contribute their real parts
-            const int Q = M / 2 + 1, qdr = NT / Q, qdk = NT - qdr * Q;  // (row, k) of item j walk along with it
-            int qr = tid / Q, qk = tid - qr * Q;
-            for (int j = tid; j < H * Q; j += NT) {
-                const int r = qr, k = qk;
-                qr += qdr;
-                qk += qdk;
-                if (qk >= Q) {
-                    qk -= Q;
-                    ++qr;
-                }
-                c32* row = A + r * S;
-                if (k == 0) {
-                    const float x0 = row[0].x, xm = row[M].x;
-                    row[0] = make_float2(x0 + xm, x0 - xm);
-                } else {
-                    const int kk = M - k;
-                    const c32 xa = row[k], xb = row[kk];
-                    {
-                        const c32 e = make_float2(xa.x + xb.x, xa.y - xb.y), d = make_float2(xa.x - xb.x, xa.y + xb.y);
-                        const c32 w = twW[k];
-                        const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
-                        row[k] = make_float2(e.x - o.y, e.y + o.x);
-                    }
-                    if (kk != k) {
-                        const c32 e = make_float2(xb.x + xa.x, xb.y - xa.y), d = make_float2(xb.x - xa.x, xb.y + xa.y);
-                        const c32 w = twW[kk];
-                        const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
-                        row[kk] = make_float2(e.x - o.y, e.y + o.x);
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- rows: length-M complex inverse DFT; value m of a row is (x[2m], x[2m+1])
-            line_dft<NT, false>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, tid);
+            // ---- rows: c2r pre-twiddle + length-M complex inverse DFT; value m of a row is (x[2m], x[2m+1])
+            c2r_rows<NT>(A, twW, W, pl.mn1, pl.mn2, H, M, S, pl.c2r_fuse, tid);
             float* const oplane = out + plane * (int64_t)H * W;
             float ps = 0.0f, pq = 0.0f;
             const int sdr = NT / M, sdm = NT - sdr * M;
@@ -659,6 +739,13 @@ static int launch_power_any(int what, const float* z, const float* filter, float
     best_split(pl.H, pl.hn1, pl.hn2);
     best_split(pl.M, pl.mn1, pl.mn2);
     const size_t lds = ((size_t)H * pl.S + H + W) * sizeof(c32);
+    {
+        // measured (scratch/size_sweep.py, fused against the pre-twiddle pass of its own): 104 x 152 (416 families, one batch) 155 ->
+        // 143 us, 144 x 112 (2 x 511) 142 -> 139; 96 x 96 (2 x 288) 137 -> 140, 192 x 192 and 160 x 160 (three batches) +6 %
+        const int nt = 2 * (lds + 1024) <= 160 * 1024 ? kAnySlots : kAnyThreads;
+        const int families = pl.H * pl.mn2, batches = (pl.H + std::max(1, nt / pl.mn2) - 1) / std::max(1, nt / pl.mn2);
+        pl.c2r_fuse = codelet_len(pl.mn1) && batches <= 2 && 5 * families >= 4 * batches * nt ? 1 : 0;
+    }
     const size_t lds_stats = (size_t)4 * H * sizeof(c32);
     const int split = group > 1 && planes / group < 512 ? 1 : 0;
     const int64_t units = split ? planes : planes / group;
