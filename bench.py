@@ -182,6 +182,23 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
     extra["spectral_filter_latents_per_s"] = BATCH / (us * 1e-6)
     kernels.append(kernel_entry("power_irfft2_kernel<SRC=2> spectral filter, batch 512", us, 8 * N_LATENT * BATCH,
                                 tr.get("spectral_filter_b512", {}).get("hbm_bytes_per_launch")))
+    # the same call on planes off the 128 x 128 path, 33.5 M values each: SD 1.5 latents (the fixed-size kernels' general passes), an
+    # SDXL portrait bucket (general-size kernels: codelets 13 x 8 and 19 x 4), 2048 px (beyond LDS: line transforms pass by pass)
+    for tag, (hh, ww, nb) in {"64x64": (64, 64, 2048), "104x152": (104, 152, 530), "256x256": (256, 256, 128)}.items():
+        try:
+            fz = torch.rand(hh, ww // 2 + 1, device=device) + 0.5
+            shp, ctr = (nb, C, hh, ww), [0]
+
+            def sized_call():
+                ctr[0] += 1
+                return hl.power_noise(fz, shp, seed=11, stream_id=ctr[0], plane_offset=0, factor=1.0)
+
+            us = event_us(sized_call, 20, 5)
+            extra[f"power_noise_{tag}_us"] = us
+            kernels.append(kernel_entry(f"power noise, normalised generate, {nb} latents of {C} x {hh} x {ww}", us, 4 * nb * C * hh * ww, None,
+                                        "two launches (statistics + final pass; five passes for 256 x 256); bytes = the tensor written once"))
+        except Exception as exc:  # secondary figure only
+            extra[f"power_noise_{tag}_error"] = repr(exc)[:200]
     # brownian (cfg5's third source): one new path point per call, bridged between the kept tensors of its neighbours
     ns_b = nz.get_noise_sampler("brownian", x64, 0.03, 14.6, seed=7, cpu=False, normalized=False)
     sched = torch.linspace(14.6, 0.03, 41).tolist()
