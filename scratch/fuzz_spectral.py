@@ -1,0 +1,59 @@
+"""Randomised differential runs of the spectral kernels over plane sizes (every route: fixed-size, general-size with codelets, line
+transforms pass by pass, direct sums for odd widths): irfft2 of a supplied spectrum and the spectral filter against torch.fft on the
+device, generate mode against the replay of its own dumped spectrum (LDS-resident routes), statistics partials against the tensor.
+python scratch/fuzz_spectral.py [iterations] [seed]"""
+import os, random, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, sonar_pkg
+pkg = sonar_pkg.load(); hl = pkg.hip_lib; hl.load()
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+kinds = {}
+for it in range(iters):
+    style = rnd.random()
+    if style < 0.45:   # latent-like: multiples of 8
+        H, W = 8 * rnd.randint(1, 40), 8 * rnd.randint(1, 40)
+    elif style < 0.8:  # any even
+        H, W = 2 * rnd.randint(1, 150), 2 * rnd.randint(1, 150)
+    elif style < 0.9:  # odd somewhere
+        H, W = rnd.randint(1, 200), rnd.randint(1, 200)
+    else:              # long lines
+        H, W = rnd.choice([2, 4, 6, 10, 34]) * rnd.randint(1, 4), 2 * rnd.randint(300, 1024)
+        if rnd.random() < 0.5: H, W = W, H
+    kind = hl.power_plane_kind(H, W)
+    if kind == 0: continue
+    kinds[kind] = kinds.get(kind, 0) + 1
+    planes = rnd.choice([1, 2, 3, 5, 8])
+    K = W // 2 + 1
+    g = torch.Generator(device="cuda").manual_seed(it)
+    z = torch.randn(planes, H, K, dtype=torch.complex64, device="cuda", generator=g)
+    filt = torch.rand(H, K, device="cuda", generator=g) + 0.5
+    shape = (planes, 1, H, W)
+    tag = f"it {it}: {planes} x {H} x {W} kind {kind}"
+    try:
+        part = hl.new_partials("cuda")
+        got = hl.power_irfft2(z, filt, shape, partials=part).reshape(planes, H, W)
+        want = torch.fft.irfft2(z * filt, s=(H, W), norm="ortho")
+        err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+        sums = part.view(-1, 2).sum(0)
+        serr = abs(sums[1].item() - (got.double() ** 2).sum().item()) / max(1e-30, (got.double() ** 2).sum().item())
+        x = torch.randn(planes, H, W, device="cuda", generator=g)
+        f2 = hl.spectral_filter(x, filt)
+        w2 = torch.fft.irfft2(torch.fft.rfft2(x, norm="ortho") * filt, s=(H, W), norm="ortho")
+        err2 = (f2 - w2).abs().max().item() / max(1.0, w2.abs().max().item())
+        err3 = 0.0
+        if kind in (1, 2):
+            sh4 = (planes, 4, H, W)
+            zz = hl.power_spectrum(sh4, "cuda", seed=it, stream_id=3, plane_offset=4)
+            a = hl.power_irfft2(None, filt, sh4, seed=it, stream_id=3, plane_offset=4)
+            b = hl.power_irfft2(zz, filt, sh4)
+            err3 = 0.0 if torch.equal(a, b) else (a - b).abs().max().item() + 1.0
+        if not (err < 3e-5 and err2 < 3e-5 and serr < 1e-5 and err3 == 0.0):
+            bad += 1
+            print(f"MISMATCH {tag}: irfft2 {err:.2e} filter {err2:.2e} sumsq {serr:.2e} generate-vs-replay {err3:.2e}")
+    except Exception as exc:
+        bad += 1
+        print(f"ERROR {tag}: {type(exc).__name__}: {str(exc)[:160]}")
+print(f"{iters} iterations, routes {kinds}, {bad} bad")
+sys.exit(1 if bad else 0)
