@@ -131,6 +131,9 @@ __device__ __forceinline__ c32 cmulc(c32 a, c32 b) {  // a * conj(b)
 
 constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4 : n == 16 ? 2 : 1; }
 
+#ifndef SONAR_FILTER_IN_PASS
+#define SONAR_FILTER_IN_PASS 1  // FAST spectral filter: multiply by the filter in the inverse column pass a
+#endif
 #ifndef SONAR_ROW32_SPLIT8
 #define SONAR_ROW32_SPLIT8 1
 #endif
@@ -533,6 +536,8 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         // rows, pass b': spatial row y sits in LDS row r with y = r / CN2 + CN1 * (r % CN2) (what the column passes expect);
         // complex element m = k1 + RN1 * k2 is (x[2m], x[2m+1]); DFT over k2 -> n2, twiddle
         // two items per trip: the second item's eight row loads are in flight while the first is transformed
+        // (two adjacent k1 per item with 16-byte loads, half the memory instructions: 89 us instead of 85 per 512 latents -- the second set
+        // of eight values costs the pass its overlap)
 #pragma unroll 2
         for (int item = ptid; item < RN1 * H; item += NT) {
             const int k1 = item % RN1, r = item / RN1;
@@ -628,7 +633,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             T0[ky] = make_float2(0.5f * (p.x + pn.x) * f0, 0.5f * (p.y - pn.y) * f0);
             TM[ky] = make_float2(0.5f * (p.y + pn.y) * fm, -0.5f * (p.x - pn.x) * fm);
         }
-        if constexpr (SRC != 3) {
+        if constexpr (SRC != 3 && !(FAST && SONAR_FILTER_IN_PASS)) {
         // unrolled: the filter values are global loads (L2 hits) -- eight in flight instead of a wait per element
 #pragma unroll 8
         for (int j = ptid; j < H * M; j += NT) {
@@ -667,8 +672,23 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             if constexpr (!(SONAR_PW_SKIP & 2)) {
                 const int c = lane, n2 = wv;
                 c32 v[CN1];
+                if constexpr (SRC == 2 && SONAR_FILTER_IN_PASS) {
+                    // the spectral filter's multiply rides on this pass's loads instead of being a pass over the plane of its own (column 0
+                    // is the packed edge pair, filtered when it was unpacked).  The filter values are the same for every plane: an opaque
+                    // lane index keeps their loads (L1 hits) in the plane loop -- hoisted they would hold CN1 registers the passes need.
+                    int fl = lane;
+                    asm volatile("" : "+v"(fl));
+                    float f[CN1];
+#pragma unroll
+                    for (int n1 = 0; n1 < CN1; ++n1) f[n1] = filter[(CN2 * n1 + n2) * (M + 1) + fl];
+#pragma unroll
+                    for (int n1 = 0; n1 < CN1; ++n1) v[n1] = A[(CN2 * n1 + n2) * S + c];
+#pragma unroll
+                    for (int n1 = 0; n1 < CN1; ++n1) v[n1] = cscale(v[n1], c == 0 ? 1.0f : f[n1]);
+                } else {
 #pragma unroll
                 for (int n1 = 0; n1 < CN1; ++n1) v[n1] = A[(CN2 * n1 + n2) * S + c];
+                }
                 idft<CN1>(v);
 #pragma unroll
                 for (int k1 = 1; k1 < CN1; ++k1) v[k1] = cmul(v[k1], ctw[k1]);
