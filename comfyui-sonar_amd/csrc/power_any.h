@@ -992,8 +992,15 @@ bool sonar_lines_cols(const float* in, const float* filter, float* out, int64_t 
     int n1, n2;
     best_split((int)H, n1, n2);
     const size_t table = (size_t)H * sizeof(c32);
-    int cols = lines_per((size_t)H * sizeof(c32), table, 64);
-    if (((cols | 1) * (size_t)H) * sizeof(c32) + table > kAnyLdsLimit) cols = std::max(1, cols - 1);
+    // a block of columns is a run of cols x 8 bytes in every row of the workspace: whole 128-byte lines when the budget allows (two
+    // workgroups per CU: 74 KB each with the odd LDS row stride)
+    const size_t room = 74 * 1024 - table;
+    int cols = (int)std::max<size_t>(1, std::min<size_t>(64, room / ((size_t)H * sizeof(c32)) - 1));
+    for (int unit = 16; unit >= 2; unit /= 2)
+        if (cols >= unit) {
+            cols -= cols % unit;
+            break;
+        }
     cols = (int)std::min<int64_t>(cols, K);
     const size_t lds = (size_t)H * (cols | 1) * sizeof(c32) + table;
     if (lds > kAnyLdsLimit) return false;
