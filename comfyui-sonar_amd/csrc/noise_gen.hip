@@ -1050,6 +1050,79 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// PyramidOld (py/noise_generation.py:567-606): noise = sum_i discount^i * interpolate(normal(std = 0.5^i) at (2^(i+1) H) x (2^(i+1) W),
+// size = (H, W)).  The reference (and the replay path here) materialises every level -- the last of five is 32 x 32 times the latent:
+// 1 GiB for four SDXL latents -- to keep, with the default nearest-exact mode, ONE value of each 2^(i+1) x 2^(i+1) block.  On-device
+// draws need no such tensor: the level value at (plane, ys, xs) is a counter-based normal keyed by its global element index
+// (Philox4x32-10 of group e / 4, Box-Muller, slot e % 4), so the kernel draws exactly the taps the shrinking interpolation reads --
+// nearest-exact / nearest 1, bilinear 2 x 2, bicubic 4 x 4 per level and output (the ratio is an exact power of two: the source
+// coordinate sits half way between two samples, the weights are constants).  sonar_pyramid_old_level_f32 writes a whole level from
+// the same keys: the definition the sampled kernel is tested against.  Area mode averages whole blocks of independent normals: the
+// block mean IS a normal of std 0.5^i / 2^(i+1), drawn directly (same joint distribution as drawing the level and pooling it).
+__device__ __forceinline__ float level_normal(uint64_t seed, uint64_t stream, int64_t e) {
+    float z[4];
+    philox_normal4(seed, stream, (uint64_t)(e >> 2), z);
+    const int slot = (int)(e & 3);
+    return slot == 0 ? z[0] : slot == 1 ? z[1] : slot == 2 ? z[2] : z[3];
+}
+
+// MODE: RESAMPLE ids 0 bilinear, 1 nearest-exact, 2 area, 3 nearest, 4 bicubic
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) pyramid_old_sampled_kernel(float* out, int64_t planes, int H, int W, int levels, float discount,
+                                                                      uint64_t seed, uint64_t stream0, int64_t plane_offset) {
+    const int64_t total = planes * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t p = idx / ((int64_t)H * W);
+        const int rem = (int)(idx - p * H * W), y = rem / W, x = rem - y * W;
+        float acc = 0.0f, wt = 1.0f, sd = 1.0f;
+        for (int i = 0; i < levels; ++i, wt *= discount, sd *= 0.5f) {
+            const int r = 2 << i;
+            const int64_t Hs = (int64_t)H * r, Ws = (int64_t)W * r;
+            const int64_t base = (plane_offset + p) * Hs * Ws;
+            const uint64_t stream = stream0 + (uint64_t)i;
+            float v;
+            if constexpr (MODE == 2) {
+                // area = the mean of an r x r block of independent N(0, sd^2) values: exactly one N(0, (sd / r)^2) value, independent
+                // from block to block -- drawn as such, keyed by the OUTPUT element (no level value is ever defined for this mode)
+                v = level_normal(seed, stream, (plane_offset + p) * (int64_t)H * W + rem) * (1.0f / (float)r);
+            } else if constexpr (MODE == 1 || MODE == 3) {
+                const int64_t ys = (int64_t)y * r + (MODE == 1 ? r / 2 : 0), xs = (int64_t)x * r + (MODE == 1 ? r / 2 : 0);
+                v = level_normal(seed, stream, base + ys * Ws + xs);
+            } else if constexpr (MODE == 0) {
+                const int64_t y0 = (int64_t)y * r + r / 2 - 1, x0 = (int64_t)x * r + r / 2 - 1;  // the coordinate is y0 + 0.5
+                const float a = level_normal(seed, stream, base + y0 * Ws + x0), b = level_normal(seed, stream, base + y0 * Ws + x0 + 1);
+                const float c = level_normal(seed, stream, base + (y0 + 1) * Ws + x0), d = level_normal(seed, stream, base + (y0 + 1) * Ws + x0 + 1);
+                v = 0.5f * (0.5f * a + 0.5f * b) + 0.5f * (0.5f * c + 0.5f * d);
+            } else {
+                // cubic convolution, A = -0.75, t = 0.5: taps -1 .. 2 around y0, clamped at the borders
+                constexpr float w4[4] = {-0.09375f, 0.59375f, 0.59375f, -0.09375f};
+                const int64_t y0 = (int64_t)y * r + r / 2 - 1, x0 = (int64_t)x * r + r / 2 - 1;
+                v = 0.0f;
+#pragma unroll
+                for (int dy = 0; dy < 4; ++dy) {
+                    const int64_t ys = min(max(y0 - 1 + dy, (int64_t)0), Hs - 1);
+                    float row = 0.0f;
+#pragma unroll
+                    for (int dx = 0; dx < 4; ++dx) {
+                        const int64_t xs = min(max(x0 - 1 + dx, (int64_t)0), Ws - 1);
+                        row = __builtin_fmaf(w4[dx], level_normal(seed, stream, base + ys * Ws + xs), row);
+                    }
+                    v = __builtin_fmaf(w4[dy], row, v);
+                }
+            }
+            acc = __builtin_fmaf(v * sd, wt, acc);
+        }
+        out[idx] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) pyramid_old_level_kernel(float* level, int64_t n, float sd, uint64_t seed, uint64_t stream,
+                                                                    int64_t elem_offset) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        level[i] = level_normal(seed, stream, elem_offset + i) * sd;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Brownian-interval noise (the reference wraps ComfyUI's BrownianTreeNoiseSampler -> torchsde, un-vendored:
 // py/noise_generation.py:262-286, py/nodes/powernoise.py:383-393).  One Brownian path per element over [t_lo, t_hi], defined
 // point by point as the sampler asks for times (torchsde's BrownianInterval grows its tree the same way): a new time t between
@@ -1540,6 +1613,33 @@ extern "C" int sonar_pyramid_generate_acc_f32(const sonar_accumulate* acc, const
                                        Accum{acc->y, acc->y_mul, acc->x_mul}, pre ? pre->kind : 0, px),
                   SONAR_ERR_UNSUPPORTED, "%s: the plane kernel cannot run this shape (whole planes, grids within the LDS budget)", what);
     return check_launch(what);
+}
+
+extern "C" int sonar_pyramid_old_sampled_f32(float* out, int64_t planes, int64_t H, int64_t W, int levels, float discount, int mode,
+                                             uint64_t seed, uint64_t stream_id, int64_t plane_offset, void* stream) {
+    SONAR_REQUIRE(out && planes >= 0 && H > 0 && W > 0 && levels >= 0 && levels <= 16 && plane_offset >= 0, SONAR_ERR_ARG,
+                  "sonar_pyramid_old_sampled_f32: bad argument");
+    SONAR_REQUIRE(mode >= 0 && mode <= 4, SONAR_ERR_UNSUPPORTED, "sonar_pyramid_old_sampled_f32: mode %d", mode);
+    SONAR_REQUIRE((double)(plane_offset + planes) * (double)H * (double)W * 4.0 * (double)(1ll << (2 * levels)) < 9.0e18, SONAR_ERR_UNSUPPORTED,
+                  "sonar_pyramid_old_sampled_f32: level element indices beyond 2^63");
+    if (planes == 0) return SONAR_OK;
+    const int g = grid_for(planes * H * W, kBlock);
+    hipStream_t st = (hipStream_t)stream;
+#define SONAR_PO(M) hipLaunchKernelGGL(pyramid_old_sampled_kernel<M>, dim3(g), dim3(kBlock), 0, st, out, planes, (int)H, (int)W, levels, discount, seed, stream_id, plane_offset)
+    if (mode == 0) SONAR_PO(0); else if (mode == 1) SONAR_PO(1); else if (mode == 2) SONAR_PO(2); else if (mode == 3) SONAR_PO(3); else SONAR_PO(4);
+#undef SONAR_PO
+    return check_launch("sonar_pyramid_old_sampled_f32");
+}
+
+extern "C" int sonar_pyramid_old_level_f32(float* level, int64_t planes, int64_t H, int64_t W, int level_index, uint64_t seed,
+                                           uint64_t stream_id, int64_t plane_offset, void* stream) {
+    SONAR_REQUIRE(level && planes >= 0 && H > 0 && W > 0 && level_index >= 0 && level_index < 16 && plane_offset >= 0, SONAR_ERR_ARG,
+                  "sonar_pyramid_old_level_f32: bad argument");
+    const int64_t r = 2ll << level_index, per = H * r * W * r, n = planes * per;
+    if (n == 0) return SONAR_OK;
+    hipLaunchKernelGGL(pyramid_old_level_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, (hipStream_t)stream, level, n,
+                       ldexpf(1.0f, -level_index), seed, stream_id + (uint64_t)level_index, plane_offset * per);
+    return check_launch("sonar_pyramid_old_level_f32");
 }
 
 extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels,

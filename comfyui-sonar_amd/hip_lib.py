@@ -107,6 +107,8 @@ SIGNATURES = {
     "sonar_resample_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I64, _F, _I, _I, _P, _P]),
     "sonar_pyramid_generate_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _P, _P]),
     "sonar_pyramid_noise_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _F, _F, _P, _P]),
+    "sonar_pyramid_old_sampled_f32": (_I, [_P, _I64, _I64, _I64, _I, _F, _I, _U64, _U64, _I64, _P]),
+    "sonar_pyramid_old_level_f32": (_I, [_P, _I64, _I64, _I64, _I, _U64, _U64, _I64, _P]),
     "sonar_power_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _P]),
     "sonar_power_noise_ahead_ok": (_I, [_I64, _I64, _I64, _I]),
     "sonar_power_noise_ahead_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _I, _U64, _P, _P]),
@@ -852,6 +854,29 @@ def perlin_noise(shape, terms: torch.Tensor, div_fac: float, seed: int, stream_i
                                       stream_id, elem_offset, float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), _stream()),
         "sonar_perlin_noise_f32",
     )
+    return out
+
+
+def pyramid_old_sampled(shape, device, levels: int, discount: float, mode: str, seed: int, stream_id: int, plane_offset: int = 0):
+    """PyramidOld's sum of shrunk levels with only the taps drawn (``sonar_pyramid_old_sampled_f32``; area: the block means drawn
+    directly); None for a mode the kernel does not carry."""
+    b, c, h, w = shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=device)
+    rc = load().sonar_pyramid_old_sampled_f32(_dev(out, "out"), b * c, h, w, int(levels), float(discount), RESAMPLE_IDS[mode], seed & (2**64 - 1),
+                                              stream_id, plane_offset, _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _check(rc, "sonar_pyramid_old_sampled_f32")
+    return out
+
+
+def pyramid_old_level(shape, device, level_index: int, seed: int, stream_id: int, plane_offset: int = 0) -> torch.Tensor:
+    """Level ``level_index`` of the sampled PyramidOld, whole ([b, c, 2^(i+1) h, 2^(i+1) w], std 0.5^i): the same keys."""
+    b, c, h, w = shape
+    r = 2 << level_index
+    out = torch.empty((b, c, h * r, w * r), dtype=torch.float32, device=device)
+    _check(load().sonar_pyramid_old_level_f32(_dev(out, "level"), b * c, h, w, int(level_index), seed & (2**64 - 1), stream_id, plane_offset,
+                                              _stream()), "sonar_pyramid_old_level_f32")
     return out
 
 

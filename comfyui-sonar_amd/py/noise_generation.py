@@ -632,17 +632,25 @@ class PyramidOldNoiseGenerator(FramesToChannelsNoiseGenerator):
         if mode not in hip_lib.UPSCALE_MODES:
             raise NotImplementedError(f"pyramid_old upscale_mode {mode!r} is not on the HIP path")
         b, c, h, w = self.get_adjusted_shape()
+        if not self.cpu:
+            # on-device draws: a level value is a counter-based normal keyed by its global element index, so only the taps the shrinking
+            # interpolation reads are drawn (the levels are up to 32 x 32 times the latent: 1 GiB for four SDXL latents); area modes
+            # average whole blocks of independent normals -- the block mean is drawn directly, as one normal of the mean's variance
+            seed, stream = self.device_key(max(self.iterations, 1))
+            plane_offset = current_batch_offset() * c
+            out = hip_lib.pyramid_old_sampled((b, c, h, w), self.device, self.iterations, self.discount, mode, seed, stream, plane_offset)
+            if out is None:
+                out = torch.zeros((b, c, h, w), dtype=torch.float32, device=self.device)
+                for i in range(self.iterations):
+                    level = hip_lib.pyramid_old_level((b, c, h, w), self.device, i, seed, stream, plane_offset)
+                    hip_lib.resample_acc_(out, level, self.discount**i, mode, True)
+                    del level
+            return self.fix_output_frames(out)
         noise = torch.zeros((b, c, h, w), dtype=torch.float32, device=self.device)
         r = 1
         for i in range(self.iterations):
             r *= 2
-            if self.cpu:
-                level = tensor_to(torch.normal(mean=0, std=0.5**i, size=(b, c, h * r, w * r), dtype=torch.float32, generator=self.generator), self.device)
-            else:
-                seed, stream = self.device_key()
-                level = hip_lib.philox_normal((b, c, h * r, w * r), self.device, seed, stream, current_batch_offset() * c * h * r * w * r)
-                if i:
-                    hip_lib.scale_noise_(level, 0.5**i, False, None)
+            level = tensor_to(torch.normal(mean=0, std=0.5**i, size=(b, c, h * r, w * r), dtype=torch.float32, generator=self.generator), self.device)
             hip_lib.resample_acc_(noise, level, self.discount**i, mode, True)
         return self.fix_output_frames(noise)
 

@@ -363,6 +363,19 @@ int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, in
                             const float* level_weight, int mode, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                             float factor, float threshold_std_devs, double* partials, void* stream);
 
+/* PyramidOld with on-device draws (py/noise_generation.py:567-606: noise = sum_i discount^i * F.interpolate(normal(std = 0.5^i) at
+ * (2^(i+1) H) x (2^(i+1) W), size = (H, W), mode)): the levels are never materialised.  Level i's value at (global plane, ys, xs) is a
+ * counter-based normal keyed by its global element index (stream stream_id + i), and the kernel draws exactly the taps the shrinking
+ * interpolation reads: mode 1 nearest-exact / 3 nearest one, 0 bilinear 2 x 2, 4 bicubic 4 x 4 per level and output (ids as
+ * sonar_resample_acc_f32).  Mode 2 (area) averages r x r blocks of independent normals: the block mean is itself a normal of std
+ * 0.5^i / r, independent from block to block, and is drawn as such (keyed by the output element; same joint distribution as drawing
+ * the level and pooling it, no level values defined).  out[planes][H][W] is overwritten.  sonar_pyramid_old_level_f32 writes level `level_index` ([planes][2^(i+1) H][2^(i+1) W], already x 0.5^i) from the same
+ * keys: resampling those levels with sonar_resample_acc_f32 gives the sampled kernel's values (the tests do). */
+int sonar_pyramid_old_sampled_f32(float* out, int64_t planes, int64_t H, int64_t W, int levels, float discount, int mode, uint64_t seed,
+                                  uint64_t stream_id, int64_t plane_offset, void* stream);
+int sonar_pyramid_old_level_f32(float* level, int64_t planes, int64_t H, int64_t W, int level_index, uint64_t seed, uint64_t stream_id,
+                                int64_t plane_offset, void* stream);
+
 /* ---------------------------------------------------------------- power-law rFFT noise (row PW) */
 /* Which kernel family serves an H x W plane of the power-noise path: 1 = the fixed-size LDS FFT kernels (powers of two, 16..256),
  * 2 = the general-size kernels (any even H <= 512, even W <= 1024 with H*(W/2+1) + H + W <= 20224 complex values: two-factor table-twiddle DFTs in LDS;

@@ -224,3 +224,47 @@ def test_row_kernels_on_long_and_short_rows(api, rows, inner):
     q = hl.abs_quantile_rows(x, rows, inner, 0.75)
     want = torch.quantile(x.abs().cpu(), 0.75, dim=1)
     torch.testing.assert_close(q.cpu().reshape(-1), want, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("mode", ["nearest-exact", "nearest", "bilinear", "bicubic"])
+def test_pyramid_old_draws_only_the_taps_it_reads(api, mode):
+    """sonar_pyramid_old_sampled_f32 against its definition: the levels written out whole from the same keys (sonar_pyramid_old_level_f32),
+    shrunk by the resampler and summed -- the reference's loop (py/noise_generation.py:567-606).  Shards of a batch add up."""
+    hl = api.hl
+    shape, levels, discount = (3, 4, 24, 40), 4, 0.8
+    got = hl.pyramid_old_sampled(shape, "cuda", levels, discount, mode, 77, 5, plane_offset=8)
+    want = torch.zeros(shape, device="cuda")
+    for i in range(levels):
+        level = hl.pyramid_old_level(shape, "cuda", i, 77, 5, plane_offset=8)
+        assert tuple(level.shape) == (3, 4, 24 * (2 << i), 40 * (2 << i)) and abs(level.std().item() - 0.5**i) < 0.02 * 0.5**i
+        hl.resample_acc_(want, level, discount**i, mode, True)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-6)
+    a = hl.pyramid_old_sampled((1, 4, 24, 40), "cuda", levels, discount, mode, 77, 5, plane_offset=8)
+    b = hl.pyramid_old_sampled((2, 4, 24, 40), "cuda", levels, discount, mode, 77, 5, plane_offset=12)
+    assert torch.equal(torch.cat([a, b]), got)
+    # area: the mean of a block of independent normals, drawn as one normal of the mean's variance -- same distribution as pooling the levels
+    area = hl.pyramid_old_sampled((8, 4, 64, 64), "cuda", levels, discount, "area", 77, 5)
+    pooled = torch.zeros((8, 4, 64, 64), device="cuda")
+    for i in range(levels):
+        hl.resample_acc_(pooled, hl.pyramid_old_level((8, 4, 64, 64), "cuda", i, 77, 5), discount**i, "area", True)
+    want_sd = sum((discount**i * 0.5**i / (2 << i)) ** 2 for i in range(levels)) ** 0.5
+    assert abs(area.std().item() / want_sd - 1.0) < 0.01 and abs(pooled.std().item() / want_sd - 1.0) < 0.01 and abs(area.mean().item()) < 0.01 * want_sd
+    lag = (area[..., 1:] * area[..., :-1]).mean().item() / want_sd**2
+    assert abs(lag) < 0.01  # neighbours are independent
+
+
+def test_pyramid_old_sampler_on_device(api):
+    """The registry type end to end: finite, shard invariant, the area variant through whole levels from the same keys."""
+    ng = api.noise_generation
+    SIG = (torch.tensor(14.6), torch.tensor(10.0))
+
+    def gen(name, b0, b):
+        torch.manual_seed(9)
+        with ng.shard_offset(b0):
+            x = torch.zeros((b, 4, 32, 32), device="cuda")
+            return api.noise.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, factor=1.0, normalized=False)(*SIG)
+
+    for name in ("pyramid_old", "pyramid_old_area"):
+        whole = gen(name, 0, 4)
+        assert bool(torch.isfinite(whole).all()) and 0.5 < float(whole.std()) < 3.0
+        assert torch.equal(torch.cat([gen(name, 0, 2), gen(name, 2, 2)]), whole)
