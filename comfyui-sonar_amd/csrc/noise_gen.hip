@@ -676,9 +676,16 @@ __device__ __forceinline__ float bicubic(const float* __restrict__ plane, int w,
     return rows[0] * cy.c[0] + rows[1] * cy.c[1] + rows[2] * cy.c[2] + rows[3] * cy.c[3];
 }
 __device__ __forceinline__ float area_sample(const float* __restrict__ plane, int h, int w, int H, int W, int y, int x) {
-    // adaptive average pooling window: [floor(i*in/out), ceil((i+1)*in/out))
-    const int y0 = (int)(((int64_t)y * h) / H), y1 = (int)((((int64_t)y + 1) * h + H - 1) / H);
-    const int x0 = (int)(((int64_t)x * w) / W), x1 = (int)((((int64_t)x + 1) * w + W - 1) / W);
+    // adaptive average pooling window: [floor(i*in/out), ceil((i+1)*in/out)); 32-bit quotients whenever the products fit (a 64-bit
+    // division is ~80 instructions, four of them per value were this mode's cost)
+    int y0, y1, x0, x1;
+    if ((int64_t)(H + 1) * h < (1ll << 31) && (int64_t)(W + 1) * w < (1ll << 31)) {
+        y0 = (int)(((unsigned)y * (unsigned)h) / (unsigned)H), y1 = (int)((((unsigned)y + 1u) * (unsigned)h + (unsigned)H - 1u) / (unsigned)H);
+        x0 = (int)(((unsigned)x * (unsigned)w) / (unsigned)W), x1 = (int)((((unsigned)x + 1u) * (unsigned)w + (unsigned)W - 1u) / (unsigned)W);
+    } else {
+        y0 = (int)(((int64_t)y * h) / H), y1 = (int)((((int64_t)y + 1) * h + H - 1) / H);
+        x0 = (int)(((int64_t)x * w) / W), x1 = (int)((((int64_t)x + 1) * w + W - 1) / W);
+    }
     float acc = 0.0f;
     for (int yy = y0; yy < y1; ++yy)
         for (int xx = x0; xx < x1; ++xx) acc += plane[(int64_t)yy * w + xx];
@@ -853,6 +860,22 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     Lin* const xtab = reinterpret_cast<Lin*>(pyr_lds + grid_floats);  // [level][W]
     Lin* const ytab = xtab + lv.count * W;                            // [level][H]
     float* const xrows = reinterpret_cast<float*>(ytab + lv.count * H);  // XROWS: [level][h_l][W]
+    if (mode == 2) {
+        // area: the adaptive-average window [floor(i in / out), ceil((i + 1) in / out)) of every (level, x) and (level, y), tabulated once
+        // per workgroup (i0 = start, i1 = end): the tile loop otherwise divides four times per value and level
+        for (int l = 0; l < lv.count; ++l) {
+            for (int i = threadIdx.x; i < W + H; i += kPyrBlock) {
+                const bool isx = i < W;
+                const int64_t d = isx ? i : i - W, in = isx ? lv.w[l] : lv.h[l], on = isx ? W : H;
+                Lin a;
+                a.i0 = (int)((d * in) / on);
+                a.i1 = (int)(((d + 1) * in + on - 1) / on);
+                a.w0 = (float)(a.i1 - a.i0);
+                a.w1 = 0.0f;
+                (isx ? xtab[l * W + d] : ytab[l * H + d]) = a;
+            }
+        }
+    }
     if (mode == 0) {
         for (int l = 0; l < lv.count; ++l) {
             const float sy = (float)lv.h[l] / (float)H, sx = (float)lv.w[l] / (float)W;
@@ -992,8 +1015,15 @@ SONAR_PYR_UNROLL
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] += row[nearest_exact_idx(x4 + k, sx, w)] * wt;
                     } else {
+                        const Lin ly = ytab[l * H + y];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] += area_sample(plane, h, w, H, W, y, x4 + k) * wt;
+                        for (int k = 0; k < 4; ++k) {
+                            const Lin lx = xtab[l * W + x4 + k];
+                            float acc = 0.0f;  // same order and rounding as area_sample
+                            for (int yy = ly.i0; yy < ly.i1; ++yy)
+                                for (int xx = lx.i0; xx < lx.i1; ++xx) acc += plane[yy * w + xx];
+                            v[k] += acc / (ly.w0 * lx.w0) * wt;
+                        }
                     }
                 }
                 if constexpr (PRE != 0) {
@@ -1025,7 +1055,7 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
         rows += (size_t)lv.h[l];
     }
     grid_floats = (grid_floats + 3) & ~(size_t)3;  // the coordinate tables that follow are 16-byte entries
-    const size_t lds = grid_floats * sizeof(float) + (mode == 0 ? (size_t)lv.count * (H + W) * sizeof(Lin) : 0);
+    const size_t lds = grid_floats * sizeof(float) + (mode == 0 || mode == 2 ? (size_t)lv.count * (H + W) * sizeof(Lin) : 0);
     const size_t lds_x = lds + rows * W * sizeof(float);
     if (W % 4 != 0 || elem_offset % (H * W) != 0 || lds > kPyramidLdsBudget) return false;
     const bool xrows = mode == 0 && W % 4 == 0 && lds_x <= kPyramidLdsBudget;
