@@ -1171,6 +1171,7 @@ def _scaled(f: float):
     def fn(t):
         pop_stats(t)
         return hip_lib.scale_noise_(t, f, False, None)
+    fn.scale_factor = f  # a pure multiply: MixedNoiseGenerator folds it into its accumulation kernel
     return fn
 
 

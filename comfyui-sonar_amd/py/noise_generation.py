@@ -277,13 +277,38 @@ class MixedNoiseGenerator(NoiseGenerator):
         self.ng_list = [(klass(x, **klass_kwargs, **passed), transform) for klass, klass_kwargs, transform in self.noise_mix]
 
     def generate(self, *args):
-        total = None
+        # total = sum_i transform_i(part_i), then output_fun.  A transform that only multiplies (``scale_factor``: the presets' _scaled)
+        # rides in the accumulation kernel -- y * a + x * b rounds each product before the add, exactly like the multiply pass followed
+        # by the add -- and so does an output multiply by a power of two (it commutes with every rounding); the last accumulation also
+        # leaves the statistics the caller's normalisation would otherwise sweep the tensor for.  Same bits, three to four passes less.
+        parts = []
         for gen, transform in self.ng_list:
             part = gen(*args)
             utils.pop_stats(part)
-            if transform is not None:
-                part = transform(part)
-            total = part if total is None else hip_lib.axpby_(total, 1.0, part, 1.0)
+            factor = getattr(transform, "scale_factor", None) if transform is not None else 1.0
+            if factor is None:
+                part, factor = transform(part), 1.0
+                utils.pop_stats(part)
+            parts.append((part, float(factor)))
+        out_factor = getattr(self.output_fun, "scale_factor", None) if self.output_fun is not None else 1.0
+        fold_out = out_factor is not None and out_factor != 0.0 and math.frexp(out_factor)[0] in (0.5, -0.5)
+        g = out_factor if fold_out else 1.0
+        total, f0 = parts[0]
+        fusable = (len(parts) > 1 and all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() and p.shape == total.shape for p, _ in parts))
+        if not fusable:
+            total = None
+            for (part, factor), (_, transform) in zip(parts, self.ng_list):
+                if factor != 1.0:
+                    part = hip_lib.scale_noise_(part, factor, False, None)
+                total = part if total is None else hip_lib.axpby_(total, 1.0, part, 1.0)
+            return self.output_fun(total) if self.output_fun is not None else total
+        for idx in range(1, len(parts)):
+            part, factor = parts[idx]
+            ymul = f0 * g if idx == 1 else 1.0
+            if idx == len(parts) - 1 and (fold_out or self.output_fun is None):
+                total, partials = hip_lib.axpby_stats_(total, ymul, part, factor * g)
+                return attach_stats(total, partials)
+            hip_lib.axpby_(total, ymul, part, factor * g)
         return self.output_fun(total) if self.output_fun is not None else total
 
 
