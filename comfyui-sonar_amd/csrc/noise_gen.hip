@@ -1080,14 +1080,14 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// PyramidOld (py/noise_generation.py:567-606): noise = sum_i discount^i * interpolate(normal(std = 0.5^i) at (2^(i+1) H) x (2^(i+1) W),
-// size = (H, W)).  The reference (and the replay path here) materialises every level -- the last of five is 32 x 32 times the latent:
+// Levels that are drawn only to be shrunk.  PyramidOld (py/noise_generation.py:567-606): noise = sum_i discount^i * interpolate(normal(std =
+// 0.5^i) at (2^(i+1) H) x (2^(i+1) W), size = (H, W)); HighresPyramid (:517-564): levels of up to 15 x the latent's sides.  The reference (and the replay path here) materialises every level -- the last of five is 32 x 32 times the latent:
 // 1 GiB for four SDXL latents -- to keep, with the default nearest-exact mode, ONE value of each 2^(i+1) x 2^(i+1) block.  On-device
 // draws need no such tensor: the level value at (plane, ys, xs) is a counter-based normal keyed by its global element index
 // (Philox4x32-10 of group e / 4, Box-Muller, slot e % 4), so the kernel draws exactly the taps the shrinking interpolation reads --
 // nearest-exact / nearest 1, bilinear 2 x 2, bicubic 4 x 4 per level and output (the ratio is an exact power of two: the source
-// coordinate sits half way between two samples, the weights are constants).  sonar_pyramid_old_level_f32 writes a whole level from
-// the same keys: the definition the sampled kernel is tested against.  Area mode averages whole blocks of independent normals: the
+// coordinate sits half way between two samples), any ratio through the resampler's own index rules.  sonar_level_normal_f32 writes a
+// whole level from the same keys: the definition the sampled kernel is tested against.  Area mode averages whole blocks of independent normals: the
 // block mean IS a normal of std 0.5^i / 2^(i+1), drawn directly (same joint distribution as drawing the level and pooling it).
 __device__ __forceinline__ float level_normal(uint64_t seed, uint64_t stream, int64_t e) {
     float z[4];
@@ -1096,60 +1096,72 @@ __device__ __forceinline__ float level_normal(uint64_t seed, uint64_t stream, in
     return slot == 0 ? z[0] : slot == 1 ? z[1] : slot == 2 ? z[2] : z[3];
 }
 
-// MODE: RESAMPLE ids 0 bilinear, 1 nearest-exact, 2 area, 3 nearest, 4 bicubic
+// MODE: RESAMPLE ids 0 bilinear, 1 nearest-exact, 2 area (whole-block windows only), 3 nearest, 4 bicubic -- the resampler's own index and
+// weight rules (lin_coord / nearest_*_idx / cubic_coord above) with the plane read replaced by the keyed draw.
+constexpr int kMaxSampledLevels = 16;
+struct SampledLevels {
+    int count;
+    int h[kMaxSampledLevels], w[kMaxSampledLevels];
+    float weight[kMaxSampledLevels], sd[kMaxSampledLevels];
+};
+
 template <int MODE>
-__global__ void __launch_bounds__(kBlock) pyramid_old_sampled_kernel(float* out, int64_t planes, int H, int W, int levels, float discount,
-                                                                      uint64_t seed, uint64_t stream0, int64_t plane_offset) {
+__global__ void __launch_bounds__(kBlock) levels_sampled_kernel(float* out, int64_t planes, int H, int W, SampledLevels lv, uint64_t seed,
+                                                                 uint64_t stream0, int64_t plane_offset, int accumulate) {
     const int64_t total = planes * H * W;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
         const int64_t p = idx / ((int64_t)H * W);
         const int rem = (int)(idx - p * H * W), y = rem / W, x = rem - y * W;
-        float acc = 0.0f, wt = 1.0f, sd = 1.0f;
-        for (int i = 0; i < levels; ++i, wt *= discount, sd *= 0.5f) {
-            const int r = 2 << i;
-            const int64_t Hs = (int64_t)H * r, Ws = (int64_t)W * r;
-            const int64_t base = (plane_offset + p) * Hs * Ws;
-            const uint64_t stream = stream0 + (uint64_t)i;
+        float acc = accumulate ? out[idx] : 0.0f;
+        for (int l = 0; l < lv.count; ++l) {
+            const int h = lv.h[l], w = lv.w[l];
+            const float sd = lv.sd[l];
+            const int64_t base = (plane_offset + p) * (int64_t)h * w;
+            const uint64_t stream = stream0 + (uint64_t)l;
+            auto at = [&](int yy, int xx) { return level_normal(seed, stream, base + (int64_t)yy * w + xx) * sd; };
+            const float sy = (float)h / (float)H, sx = (float)w / (float)W;
             float v;
             if constexpr (MODE == 2) {
-                // area = the mean of an r x r block of independent N(0, sd^2) values: exactly one N(0, (sd / r)^2) value, independent
-                // from block to block -- drawn as such, keyed by the OUTPUT element (no level value is ever defined for this mode)
-                v = level_normal(seed, stream, (plane_offset + p) * (int64_t)H * W + rem) * (1.0f / (float)r);
-            } else if constexpr (MODE == 1 || MODE == 3) {
-                const int64_t ys = (int64_t)y * r + (MODE == 1 ? r / 2 : 0), xs = (int64_t)x * r + (MODE == 1 ? r / 2 : 0);
-                v = level_normal(seed, stream, base + ys * Ws + xs);
+                // area over whole r x r blocks of independent N(0, sd^2) values: the block mean is exactly one N(0, (sd / r)^2) value,
+                // independent from block to block -- drawn as such, keyed by the OUTPUT element (no level value is defined for this mode)
+                v = level_normal(seed, stream, (plane_offset + p) * (int64_t)H * W + rem) * (sd / sqrtf((float)(h / H) * (float)(w / W)));
+            } else if constexpr (MODE == 1) {
+                v = at(nearest_exact_idx(y, sy, h), nearest_exact_idx(x, sx, w));
+            } else if constexpr (MODE == 3) {
+                v = at(nearest_idx(y, sy, h), nearest_idx(x, sx, w));
             } else if constexpr (MODE == 0) {
-                const int64_t y0 = (int64_t)y * r + r / 2 - 1, x0 = (int64_t)x * r + r / 2 - 1;  // the coordinate is y0 + 0.5
-                const float a = level_normal(seed, stream, base + y0 * Ws + x0), b = level_normal(seed, stream, base + y0 * Ws + x0 + 1);
-                const float c = level_normal(seed, stream, base + (y0 + 1) * Ws + x0), d = level_normal(seed, stream, base + (y0 + 1) * Ws + x0 + 1);
-                v = 0.5f * (0.5f * a + 0.5f * b) + 0.5f * (0.5f * c + 0.5f * d);
+                const Lin ly = lin_coord(y, sy, h), lx = lin_coord(x, sx, w);
+                const float t0 = at(ly.i0, lx.i0) * lx.w0 + at(ly.i0, lx.i1) * lx.w1;
+                const float t1 = at(ly.i1, lx.i0) * lx.w0 + at(ly.i1, lx.i1) * lx.w1;
+                v = t0 * ly.w0 + t1 * ly.w1;
             } else {
-                // cubic convolution, A = -0.75, t = 0.5: taps -1 .. 2 around y0, clamped at the borders
-                constexpr float w4[4] = {-0.09375f, 0.59375f, 0.59375f, -0.09375f};
-                const int64_t y0 = (int64_t)y * r + r / 2 - 1, x0 = (int64_t)x * r + r / 2 - 1;
-                v = 0.0f;
+                const Cubic cy = cubic_coord(y, sy, h, false), cx = cubic_coord(x, sx, w, false);
+                float rows[4];
 #pragma unroll
-                for (int dy = 0; dy < 4; ++dy) {
-                    const int64_t ys = min(max(y0 - 1 + dy, (int64_t)0), Hs - 1);
-                    float row = 0.0f;
-#pragma unroll
-                    for (int dx = 0; dx < 4; ++dx) {
-                        const int64_t xs = min(max(x0 - 1 + dx, (int64_t)0), Ws - 1);
-                        row = __builtin_fmaf(w4[dx], level_normal(seed, stream, base + ys * Ws + xs), row);
-                    }
-                    v = __builtin_fmaf(w4[dy], row, v);
-                }
+                for (int k = 0; k < 4; ++k)
+                    rows[k] = at(cy.i[k], cx.i[0]) * cx.c[0] + at(cy.i[k], cx.i[1]) * cx.c[1] + at(cy.i[k], cx.i[2]) * cx.c[2] + at(cy.i[k], cx.i[3]) * cx.c[3];
+                v = rows[0] * cy.c[0] + rows[1] * cy.c[1] + rows[2] * cy.c[2] + rows[3] * cy.c[3];
             }
-            acc = __builtin_fmaf(v * sd, wt, acc);
+            v = v * lv.weight[l];  // the resampler's order: scale, then add to the running sum
+            acc = acc + v;
         }
         out[idx] = acc;
     }
 }
 
-__global__ void __launch_bounds__(kBlock) pyramid_old_level_kernel(float* level, int64_t n, float sd, uint64_t seed, uint64_t stream,
-                                                                    int64_t elem_offset) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        level[i] = level_normal(seed, stream, elem_offset + i) * sd;
+__global__ void __launch_bounds__(kBlock) level_normal_kernel(float* level, int64_t n, float sd, uint64_t seed, uint64_t stream,
+                                                               int64_t elem_offset) {
+    // a thread per Philox group of four consecutive elements (the ends of the range may cut a group)
+    const int64_t g0 = elem_offset >> 2, g1 = (elem_offset + n + 3) >> 2;
+    for (int64_t g = g0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; g < g1; g += (int64_t)gridDim.x * kBlock) {
+        float z[4];
+        philox_normal4(seed, stream, (uint64_t)g, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = 4 * g + k - elem_offset;
+            if (i >= 0 && i < n) level[i] = z[k] * sd;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1645,31 +1657,44 @@ extern "C" int sonar_pyramid_generate_acc_f32(const sonar_accumulate* acc, const
     return check_launch(what);
 }
 
-extern "C" int sonar_pyramid_old_sampled_f32(float* out, int64_t planes, int64_t H, int64_t W, int levels, float discount, int mode,
-                                             uint64_t seed, uint64_t stream_id, int64_t plane_offset, void* stream) {
-    SONAR_REQUIRE(out && planes >= 0 && H > 0 && W > 0 && levels >= 0 && levels <= 16 && plane_offset >= 0, SONAR_ERR_ARG,
-                  "sonar_pyramid_old_sampled_f32: bad argument");
-    SONAR_REQUIRE(mode >= 0 && mode <= 4, SONAR_ERR_UNSUPPORTED, "sonar_pyramid_old_sampled_f32: mode %d", mode);
-    SONAR_REQUIRE((double)(plane_offset + planes) * (double)H * (double)W * 4.0 * (double)(1ll << (2 * levels)) < 9.0e18, SONAR_ERR_UNSUPPORTED,
-                  "sonar_pyramid_old_sampled_f32: level element indices beyond 2^63");
+extern "C" int sonar_levels_sampled_f32(float* out, int64_t planes, int64_t H, int64_t W, int nlevels, const int64_t* level_h,
+                                       const int64_t* level_w, const float* level_weight, const float* level_sd, int mode, uint64_t seed,
+                                       uint64_t stream_id, int64_t plane_offset, int accumulate, void* stream) {
+    SONAR_REQUIRE(out && planes >= 0 && H > 0 && W > 0 && nlevels >= 0 && nlevels <= kMaxSampledLevels && plane_offset >= 0 &&
+                      (nlevels == 0 || (level_h && level_w && level_weight && level_sd)),
+                  SONAR_ERR_ARG, "sonar_levels_sampled_f32: bad argument (at most %d levels)", kMaxSampledLevels);
+    SONAR_REQUIRE(mode >= 0 && mode <= 4, SONAR_ERR_UNSUPPORTED, "sonar_levels_sampled_f32: mode %d", mode);
+    SampledLevels lv;
+    lv.count = nlevels;
+    for (int l = 0; l < nlevels; ++l) {
+        SONAR_REQUIRE(level_h[l] > 0 && level_w[l] > 0 && level_h[l] < (1ll << 30) && level_w[l] < (1ll << 30) &&
+                          (double)(plane_offset + planes) * (double)level_h[l] * (double)level_w[l] < 9.0e18,
+                      SONAR_ERR_UNSUPPORTED, "sonar_levels_sampled_f32: level %d is too large for its element keys", l);
+        // area: only whole blocks average independent values (any other ratio's windows overlap: draw the level and pool it)
+        SONAR_REQUIRE(mode != 2 || (level_h[l] % H == 0 && level_w[l] % W == 0), SONAR_ERR_UNSUPPORTED,
+                      "sonar_levels_sampled_f32: area mode needs levels of whole multiples of the output size");
+        lv.h[l] = (int)level_h[l];
+        lv.w[l] = (int)level_w[l];
+        lv.weight[l] = level_weight[l];
+        lv.sd[l] = level_sd[l];
+    }
     if (planes == 0) return SONAR_OK;
     const int g = grid_for(planes * H * W, kBlock);
     hipStream_t st = (hipStream_t)stream;
-#define SONAR_PO(M) hipLaunchKernelGGL(pyramid_old_sampled_kernel<M>, dim3(g), dim3(kBlock), 0, st, out, planes, (int)H, (int)W, levels, discount, seed, stream_id, plane_offset)
-    if (mode == 0) SONAR_PO(0); else if (mode == 1) SONAR_PO(1); else if (mode == 2) SONAR_PO(2); else if (mode == 3) SONAR_PO(3); else SONAR_PO(4);
-#undef SONAR_PO
-    return check_launch("sonar_pyramid_old_sampled_f32");
+#define SONAR_LS(M) hipLaunchKernelGGL(levels_sampled_kernel<M>, dim3(g), dim3(kBlock), 0, st, out, planes, (int)H, (int)W, lv, seed, stream_id, plane_offset, accumulate)
+    if (mode == 0) SONAR_LS(0); else if (mode == 1) SONAR_LS(1); else if (mode == 2) SONAR_LS(2); else if (mode == 3) SONAR_LS(3); else SONAR_LS(4);
+#undef SONAR_LS
+    return check_launch("sonar_levels_sampled_f32");
 }
 
-extern "C" int sonar_pyramid_old_level_f32(float* level, int64_t planes, int64_t H, int64_t W, int level_index, uint64_t seed,
-                                           uint64_t stream_id, int64_t plane_offset, void* stream) {
-    SONAR_REQUIRE(level && planes >= 0 && H > 0 && W > 0 && level_index >= 0 && level_index < 16 && plane_offset >= 0, SONAR_ERR_ARG,
-                  "sonar_pyramid_old_level_f32: bad argument");
-    const int64_t r = 2ll << level_index, per = H * r * W * r, n = planes * per;
+extern "C" int sonar_level_normal_f32(float* level, int64_t planes, int64_t h, int64_t w, float sd, uint64_t seed, uint64_t stream_id,
+                                      int64_t plane_offset, void* stream) {
+    SONAR_REQUIRE(level && planes >= 0 && h > 0 && w > 0 && plane_offset >= 0, SONAR_ERR_ARG, "sonar_level_normal_f32: bad argument");
+    const int64_t n = planes * h * w;
     if (n == 0) return SONAR_OK;
-    hipLaunchKernelGGL(pyramid_old_level_kernel, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, (hipStream_t)stream, level, n,
-                       ldexpf(1.0f, -level_index), seed, stream_id + (uint64_t)level_index, plane_offset * per);
-    return check_launch("sonar_pyramid_old_level_f32");
+    hipLaunchKernelGGL(level_normal_kernel, dim3(grid_for(n / 4 + 2, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, level, n, sd, seed, stream_id,
+                       plane_offset * h * w);
+    return check_launch("sonar_level_normal_f32");
 }
 
 extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels,

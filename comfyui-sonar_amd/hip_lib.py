@@ -107,8 +107,8 @@ SIGNATURES = {
     "sonar_resample_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I64, _F, _I, _I, _P, _P]),
     "sonar_pyramid_generate_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _P, _P]),
     "sonar_pyramid_noise_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _F, _F, _P, _P]),
-    "sonar_pyramid_old_sampled_f32": (_I, [_P, _I64, _I64, _I64, _I, _F, _I, _U64, _U64, _I64, _P]),
-    "sonar_pyramid_old_level_f32": (_I, [_P, _I64, _I64, _I64, _I, _U64, _U64, _I64, _P]),
+    "sonar_levels_sampled_f32": (_I, [_P, _I64, _I64, _I64, _I, _PI64, _PI64, _PF, _PF, _I, _U64, _U64, _I64, _I, _P]),
+    "sonar_level_normal_f32": (_I, [_P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _P]),
     "sonar_power_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _P]),
     "sonar_power_noise_ahead_ok": (_I, [_I64, _I64, _I64, _I]),
     "sonar_power_noise_ahead_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _I, _U64, _P, _P]),
@@ -857,26 +857,35 @@ def perlin_noise(shape, terms: torch.Tensor, div_fac: float, seed: int, stream_i
     return out
 
 
-def pyramid_old_sampled(shape, device, levels: int, discount: float, mode: str, seed: int, stream_id: int, plane_offset: int = 0):
-    """PyramidOld's sum of shrunk levels with only the taps drawn (``sonar_pyramid_old_sampled_f32``; area: the block means drawn
-    directly); None for a mode the kernel does not carry."""
+def levels_sampled(shape, device, levels, mode: str, seed: int, stream_id: int, plane_offset: int = 0, out: Optional[torch.Tensor] = None):
+    """sum_l weight_l * interpolate(level_l, size = shape[-2:], mode) with only the interpolation's taps drawn (``sonar_levels_sampled_f32``):
+    ``levels`` = [(h, w, weight, sd), ...], level l a normal field of std sd keyed by (stream_id + l, global element index).  ``out``: added
+    to instead of overwritten.  None when the kernel does not carry the request (area mode off whole multiples, more than 16 levels)."""
     b, c, h, w = shape
-    out = torch.empty((b, c, h, w), dtype=torch.float32, device=device)
-    rc = load().sonar_pyramid_old_sampled_f32(_dev(out, "out"), b * c, h, w, int(levels), float(discount), RESAMPLE_IDS[mode], seed & (2**64 - 1),
-                                              stream_id, plane_offset, _stream())
+    n = len(levels)
+    if n > 16:
+        return None
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((b, c, h, w), dtype=torch.float32, device=device)
+    hs = (C.c_int64 * max(n, 1))(*[int(lv[0]) for lv in levels])
+    ws = (C.c_int64 * max(n, 1))(*[int(lv[1]) for lv in levels])
+    wts = (C.c_float * max(n, 1))(*[float(lv[2]) for lv in levels])
+    sds = (C.c_float * max(n, 1))(*[float(lv[3]) for lv in levels])
+    rc = load().sonar_levels_sampled_f32(_dev(out, "out"), b * c, h, w, n, hs, ws, wts, sds, RESAMPLE_IDS[mode], seed & (2**64 - 1), stream_id,
+                                         plane_offset, int(accumulate), _stream())
     if rc == ERR_UNSUPPORTED:
         return None
-    _check(rc, "sonar_pyramid_old_sampled_f32")
+    _check(rc, "sonar_levels_sampled_f32")
     return out
 
 
-def pyramid_old_level(shape, device, level_index: int, seed: int, stream_id: int, plane_offset: int = 0) -> torch.Tensor:
-    """Level ``level_index`` of the sampled PyramidOld, whole ([b, c, 2^(i+1) h, 2^(i+1) w], std 0.5^i): the same keys."""
+def level_normal(shape, device, sd: float, seed: int, stream_id: int, plane_offset: int = 0) -> torch.Tensor:
+    """One whole level [b, c, h, w] of ``levels_sampled`` (std ``sd``): the same keys."""
     b, c, h, w = shape
-    r = 2 << level_index
-    out = torch.empty((b, c, h * r, w * r), dtype=torch.float32, device=device)
-    _check(load().sonar_pyramid_old_level_f32(_dev(out, "level"), b * c, h, w, int(level_index), seed & (2**64 - 1), stream_id, plane_offset,
-                                              _stream()), "sonar_pyramid_old_level_f32")
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=device)
+    _check(load().sonar_level_normal_f32(_dev(out, "level"), b * c, h, w, float(sd), seed & (2**64 - 1), stream_id, plane_offset, _stream()),
+           "sonar_level_normal_f32")
     return out
 
 

@@ -629,17 +629,33 @@ class HighresPyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
         utils.pop_stats(noise)
         rs = torch.rand(self.iterations, dtype=torch.float32, generator=self.generator).cpu() * 2 + 2
         ch, cw = h, w
+        sizes = []
         for i in range(self.iterations):
             r = rs[i].item()
             ch, cw = min(h * 15, int(ch * (r**i))), min(w * 15, int(cw * (r**i)))
-            if self.cpu:
-                level = tensor_to(torch.randn(b, c, ch, cw, generator=self.generator), self.device)
-            else:
-                seed, stream = self.device_key()
-                level = hip_lib.philox_normal((b, c, ch, cw), self.device, seed, stream, current_batch_offset() * c * ch * cw)
-            hip_lib.resample_acc_(noise, level, self.discount**i, mode, True)
+            sizes.append((ch, cw, self.discount**i))
             if ch >= h * 15 or cw >= w * 15:
                 break
+        if not self.cpu and noise.dtype == torch.float32 and noise.is_contiguous():
+            # on-device draws: the levels (up to 225 x the latent's elements each) are never built -- a level value is a counter-based
+            # normal keyed by its global element index and only the taps the shrinking interpolation reads are drawn
+            seed, stream = self.device_key(max(len(sizes), 1))
+            plane_offset = current_batch_offset() * c
+            if hip_lib.levels_sampled((b, c, h, w), self.device, [(lh, lw, wt, 1.0) for lh, lw, wt in sizes], mode, seed, stream, plane_offset,
+                                      out=noise) is None:
+                for i, (lh, lw, wt) in enumerate(sizes):  # area off whole multiples: the windows overlap, the level is drawn (tile streams:
+                    # the cheaper generator when every value is needed) and pooled
+                    level = hip_lib.philox_normal((b, c, lh, lw), self.device, seed, stream + i, plane_offset * lh * lw)
+                    hip_lib.resample_acc_(noise, level, wt, mode, True)
+                    del level
+            return self.fix_output_frames(noise)
+        for lh, lw, wt in sizes:
+            if self.cpu:
+                level = tensor_to(torch.randn(b, c, lh, lw, generator=self.generator), self.device)
+            else:
+                seed, stream = self.device_key()
+                level = hip_lib.philox_normal((b, c, lh, lw), self.device, seed, stream, current_batch_offset() * c * lh * lw)
+            hip_lib.resample_acc_(noise, level, wt, mode, True)
         return self.fix_output_frames(noise)
 
 
@@ -663,12 +679,13 @@ class PyramidOldNoiseGenerator(FramesToChannelsNoiseGenerator):
             # average whole blocks of independent normals -- the block mean is drawn directly, as one normal of the mean's variance
             seed, stream = self.device_key(max(self.iterations, 1))
             plane_offset = current_batch_offset() * c
-            out = hip_lib.pyramid_old_sampled((b, c, h, w), self.device, self.iterations, self.discount, mode, seed, stream, plane_offset)
+            levels = [(h * (2 << i), w * (2 << i), self.discount**i, 0.5**i) for i in range(self.iterations)]
+            out = hip_lib.levels_sampled((b, c, h, w), self.device, levels, mode, seed, stream, plane_offset)
             if out is None:
                 out = torch.zeros((b, c, h, w), dtype=torch.float32, device=self.device)
-                for i in range(self.iterations):
-                    level = hip_lib.pyramid_old_level((b, c, h, w), self.device, i, seed, stream, plane_offset)
-                    hip_lib.resample_acc_(out, level, self.discount**i, mode, True)
+                for i, (lh, lw, weight, sd) in enumerate(levels):
+                    level = hip_lib.level_normal((b, c, lh, lw), self.device, sd, seed, stream + i, plane_offset)
+                    hip_lib.resample_acc_(out, level, weight, mode, True)
                     del level
             return self.fix_output_frames(out)
         noise = torch.zeros((b, c, h, w), dtype=torch.float32, device=self.device)

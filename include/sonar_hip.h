@@ -363,18 +363,23 @@ int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, in
                             const float* level_weight, int mode, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                             float factor, float threshold_std_devs, double* partials, void* stream);
 
-/* PyramidOld with on-device draws (py/noise_generation.py:567-606: noise = sum_i discount^i * F.interpolate(normal(std = 0.5^i) at
- * (2^(i+1) H) x (2^(i+1) W), size = (H, W), mode)): the levels are never materialised.  Level i's value at (global plane, ys, xs) is a
- * counter-based normal keyed by its global element index (stream stream_id + i), and the kernel draws exactly the taps the shrinking
- * interpolation reads: mode 1 nearest-exact / 3 nearest one, 0 bilinear 2 x 2, 4 bicubic 4 x 4 per level and output (ids as
- * sonar_resample_acc_f32).  Mode 2 (area) averages r x r blocks of independent normals: the block mean is itself a normal of std
- * 0.5^i / r, independent from block to block, and is drawn as such (keyed by the output element; same joint distribution as drawing
- * the level and pooling it, no level values defined).  out[planes][H][W] is overwritten.  sonar_pyramid_old_level_f32 writes level `level_index` ([planes][2^(i+1) H][2^(i+1) W], already x 0.5^i) from the same
+/* Levels that are drawn only to be shrunk, with on-device draws: PyramidOld (py/noise_generation.py:567-606: noise = sum_i discount^i *
+ * F.interpolate(normal(std = 0.5^i) at (2^(i+1) H) x (2^(i+1) W), size = (H, W), mode)) and HighresPyramid (:517-564: levels of up to 15 x
+ * the latent's sides).  The levels are never materialised: level l's value at (global plane, ys, xs) is a counter-based normal keyed by
+ * its global element index (Philox4x32-10 of group e / 4, Box-Muller, slot e % 4; stream stream_id + l) times level_sd[l], and the kernel
+ * draws exactly the taps the interpolation reads -- mode 1 nearest-exact / 3 nearest one, 0 bilinear 2 x 2, 4 bicubic 4 x 4 per level and
+ * output, by the index and weight rules of sonar_resample_acc_f32 (same ids):
+ *     out[p][y][x] (+)= sum_l level_weight[l] * interpolate(level_l)[p][y][x]        (accumulate != 0: added to out)
+ * Mode 2 (area) only for levels of whole multiples of the output size: the mean of a block of independent normals is itself a normal of
+ * std level_sd / sqrt(block size), independent from block to block, and is drawn as such (keyed by the output element; the same joint
+ * distribution as drawing the level and pooling it); any other ratio: SONAR_ERR_UNSUPPORTED (the windows overlap: draw the level with
+ * sonar_level_normal_f32 and resample it).  At most 16 levels.  sonar_level_normal_f32 writes one whole level [planes][h][w] from the same
  * keys: resampling those levels with sonar_resample_acc_f32 gives the sampled kernel's values (the tests do). */
-int sonar_pyramid_old_sampled_f32(float* out, int64_t planes, int64_t H, int64_t W, int levels, float discount, int mode, uint64_t seed,
-                                  uint64_t stream_id, int64_t plane_offset, void* stream);
-int sonar_pyramid_old_level_f32(float* level, int64_t planes, int64_t H, int64_t W, int level_index, uint64_t seed, uint64_t stream_id,
-                                int64_t plane_offset, void* stream);
+int sonar_levels_sampled_f32(float* out, int64_t planes, int64_t H, int64_t W, int nlevels, const int64_t* level_h, const int64_t* level_w,
+                             const float* level_weight, const float* level_sd, int mode, uint64_t seed, uint64_t stream_id,
+                             int64_t plane_offset, int accumulate, void* stream);
+int sonar_level_normal_f32(float* level, int64_t planes, int64_t h, int64_t w, float sd, uint64_t seed, uint64_t stream_id,
+                           int64_t plane_offset, void* stream);
 
 /* ---------------------------------------------------------------- power-law rFFT noise (row PW) */
 /* Which kernel family serves an H x W plane of the power-noise path: 1 = the fixed-size LDS FFT kernels (powers of two, 16..256),

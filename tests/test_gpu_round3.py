@@ -227,34 +227,50 @@ def test_row_kernels_on_long_and_short_rows(api, rows, inner):
 
 
 @pytest.mark.parametrize("mode", ["nearest-exact", "nearest", "bilinear", "bicubic"])
-def test_pyramid_old_draws_only_the_taps_it_reads(api, mode):
-    """sonar_pyramid_old_sampled_f32 against its definition: the levels written out whole from the same keys (sonar_pyramid_old_level_f32),
-    shrunk by the resampler and summed -- the reference's loop (py/noise_generation.py:567-606).  Shards of a batch add up."""
+@pytest.mark.parametrize("kind", ["pyramid_old", "highres"])
+def test_shrunk_levels_draw_only_the_taps_they_read(api, mode, kind):
+    """sonar_levels_sampled_f32 against its definition: the levels written out whole from the same keys (sonar_level_normal_f32), shrunk
+    by the resampler and summed -- the reference's loops (py/noise_generation.py:517-606).  PyramidOld's power-of-two levels and
+    HighresPyramid's odd ratios (the resampler's own index rules either way); accumulation onto a base; shards of a batch add up."""
     hl = api.hl
-    shape, levels, discount = (3, 4, 24, 40), 4, 0.8
-    got = hl.pyramid_old_sampled(shape, "cuda", levels, discount, mode, 77, 5, plane_offset=8)
+    shape = (3, 4, 24, 40)
+    if kind == "pyramid_old":
+        levels = [(24 * (2 << i), 40 * (2 << i), 0.8**i, 0.5**i) for i in range(4)]
+    else:
+        levels = [(24, 40, 1.0, 1.0), (61, 93, 0.7, 1.0), (157, 331, 0.49, 1.0), (360, 600, 0.343, 1.0)]
+    got = hl.levels_sampled(shape, "cuda", levels, mode, 77, 5, plane_offset=8)
     want = torch.zeros(shape, device="cuda")
-    for i in range(levels):
-        level = hl.pyramid_old_level(shape, "cuda", i, 77, 5, plane_offset=8)
-        assert tuple(level.shape) == (3, 4, 24 * (2 << i), 40 * (2 << i)) and abs(level.std().item() - 0.5**i) < 0.02 * 0.5**i
-        hl.resample_acc_(want, level, discount**i, mode, True)
+    for i, (lh, lw, wt, sd) in enumerate(levels):
+        level = hl.level_normal((3, 4, lh, lw), "cuda", sd, 77, 5 + i, plane_offset=8)
+        assert abs(level.std().item() - sd) < 0.03 * sd
+        hl.resample_acc_(want, level, wt, mode, True)
     torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-6)
-    a = hl.pyramid_old_sampled((1, 4, 24, 40), "cuda", levels, discount, mode, 77, 5, plane_offset=8)
-    b = hl.pyramid_old_sampled((2, 4, 24, 40), "cuda", levels, discount, mode, 77, 5, plane_offset=12)
+    base = torch.randn(shape, device="cuda")
+    onto = hl.levels_sampled(shape, "cuda", levels, mode, 77, 5, plane_offset=8, out=base.clone())
+    torch.testing.assert_close(onto, base + got, rtol=1e-5, atol=2e-6)
+    a = hl.levels_sampled((1, 4, 24, 40), "cuda", levels, mode, 77, 5, plane_offset=8)
+    b = hl.levels_sampled((2, 4, 24, 40), "cuda", levels, mode, 77, 5, plane_offset=12)
     assert torch.equal(torch.cat([a, b]), got)
-    # area: the mean of a block of independent normals, drawn as one normal of the mean's variance -- same distribution as pooling the levels
-    area = hl.pyramid_old_sampled((8, 4, 64, 64), "cuda", levels, discount, "area", 77, 5)
+
+
+def test_area_mode_draws_the_block_means(api):
+    """The mean of a block of independent normals is one normal of the mean's variance: drawn as such for levels of whole multiples of the
+    output size (same distribution as pooling the levels); other ratios' windows overlap -- refused, the caller pools drawn levels."""
+    hl = api.hl
+    levels = [(64 * (2 << i), 64 * (2 << i), 0.8**i, 0.5**i) for i in range(4)]
+    area = hl.levels_sampled((8, 4, 64, 64), "cuda", levels, "area", 77, 5)
     pooled = torch.zeros((8, 4, 64, 64), device="cuda")
-    for i in range(levels):
-        hl.resample_acc_(pooled, hl.pyramid_old_level((8, 4, 64, 64), "cuda", i, 77, 5), discount**i, "area", True)
-    want_sd = sum((discount**i * 0.5**i / (2 << i)) ** 2 for i in range(levels)) ** 0.5
+    for i, (lh, lw, wt, sd) in enumerate(levels):
+        hl.resample_acc_(pooled, hl.level_normal((8, 4, lh, lw), "cuda", sd, 77, 5 + i), wt, "area", True)
+    want_sd = sum((wt * sd / (2 << i)) ** 2 for i, (_, _, wt, sd) in enumerate(levels)) ** 0.5
     assert abs(area.std().item() / want_sd - 1.0) < 0.01 and abs(pooled.std().item() / want_sd - 1.0) < 0.01 and abs(area.mean().item()) < 0.01 * want_sd
-    lag = (area[..., 1:] * area[..., :-1]).mean().item() / want_sd**2
-    assert abs(lag) < 0.01  # neighbours are independent
+    assert abs((area[..., 1:] * area[..., :-1]).mean().item()) / want_sd**2 < 0.01  # neighbours are independent
+    assert hl.levels_sampled((1, 4, 64, 64), "cuda", [(100, 130, 1.0, 1.0)], "area", 77, 5) is None
+    assert hl.levels_sampled((1, 4, 8, 8), "cuda", [(16, 16, 1.0, 1.0)] * 17, "bilinear", 77, 5) is None
 
 
-def test_pyramid_old_sampler_on_device(api):
-    """The registry type end to end: finite, shard invariant, the area variant through whole levels from the same keys."""
+def test_shrunk_level_samplers_on_device(api):
+    """The registry types end to end: finite, PyramidOld shard invariant, the area variants (block means / pooled levels from the same keys)."""
     ng = api.noise_generation
     SIG = (torch.tensor(14.6), torch.tensor(10.0))
 
@@ -268,3 +284,6 @@ def test_pyramid_old_sampler_on_device(api):
         whole = gen(name, 0, 4)
         assert bool(torch.isfinite(whole).all()) and 0.5 < float(whole.std()) < 3.0
         assert torch.equal(torch.cat([gen(name, 0, 2), gen(name, 2, 2)]), whole)
+    for name in ("highres_pyramid", "highres_pyramid_area"):  # their uniform base is normalised per call tensor: shards differ by design
+        whole = gen(name, 0, 4)
+        assert bool(torch.isfinite(whole).all()) and 0.3 < float(whole.std()) < 5.0
