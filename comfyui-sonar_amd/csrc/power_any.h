@@ -957,6 +957,71 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* 
     if constexpr (STATS) write_partial<kLinesThreads>(s, q, partials, red);
 }
 
+// Odd widths have no half-length trick: a row is transformed as W complex values (imaginary parts zero on the way in, discarded on the
+// way out) -- twice the arithmetic of an even neighbour, not the O(W) per value of the direct sums (135 = 15 x 9 runs as two codelets).
+__global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_odd_kernel(const float* __restrict__ x, c32* __restrict__ y, int64_t rows, int W, int n1,
+                                                                         int n2, int per) {
+    extern __shared__ __align__(16) unsigned char any_lds[];
+    const int K = W / 2 + 1, S = W | 1, tid = threadIdx.x;
+    c32* const A = reinterpret_cast<c32*>(any_lds);
+    c32* const tw = A + per * S;
+    lines_table(tw, W, tid);
+    for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
+        const int nr = (int)min<int64_t>(per, rows - r0);
+        __syncthreads();
+        for (int j = tid; j < nr * W; j += kLinesThreads) {
+            const int r = j / W, i = j - r * W;
+            A[r * S + i] = make_float2(x[(r0 + r) * W + i], 0.0f);
+        }
+        __syncthreads();
+        line_dft<kLinesThreads, true>(A, tw, W, 1, n1, n2, nr, 1, S, tid);
+        for (int j = tid; j < nr * K; j += kLinesThreads) {
+            const int r = j / K, k = j - r * K;
+            y[(r0 + r) * K + k] = A[r * S + k];
+        }
+    }
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_odd_kernel(const c32* __restrict__ y, float* __restrict__ out, int64_t rows, int W, int n1,
+                                                                         int n2, int per, float scale, double* partials) {
+    extern __shared__ __align__(16) unsigned char any_lds[];
+    __shared__ double red[2 * kLinesThreads / 64];
+    const int K = W / 2 + 1, S = W | 1, tid = threadIdx.x;
+    c32* const A = reinterpret_cast<c32*>(any_lds);
+    c32* const tw = A + per * S;
+    lines_table(tw, W, tid);
+    double s = 0.0, q = 0.0;
+    for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
+        const int nr = (int)min<int64_t>(per, rows - r0);
+        __syncthreads();
+        // the full Hermitian line: X[k] = y[k], X[W - k] = conj y[k]; the DC value's imaginary part is ignored, as irfft does
+        for (int j = tid; j < nr * K; j += kLinesThreads) {
+            const int r = j / K, k = j - r * K;
+            const c32 v = y[(r0 + r) * K + k];
+            if (k == 0) {
+                A[r * S] = make_float2(v.x, 0.0f);
+            } else {
+                A[r * S + k] = v;
+                A[r * S + W - k] = make_float2(v.x, -v.y);
+            }
+        }
+        __syncthreads();
+        line_dft<kLinesThreads, false>(A, tw, W, 1, n1, n2, nr, 1, S, tid);
+        for (int j = tid; j < nr * W; j += kLinesThreads) {
+            const int r = j / W, i = j - r * W;
+            const float a = A[r * S + i].x * scale;
+            out[(r0 + r) * W + i] = a;
+            if constexpr (STATS) {
+                const double da = a;
+                s += da;
+                q += da * da;
+            }
+        }
+    }
+    if constexpr (STATS) write_partial<kLinesThreads>(s, q, partials, red);
+}
+
 // rows per batch / columns per block that fit kLinesLds beside the twiddle table
 static inline int lines_per(size_t line_bytes, size_t table_bytes, int want) {
     const size_t room = kLinesLds > table_bytes ? kLinesLds - table_bytes : 0;
@@ -974,7 +1039,19 @@ static void lines_lds_attr(K kern) {
 // even widths / any height up to kLinesMax; false: not taken (the direct passes of dft_direct.hip run)
 bool sonar_lines_rows_r2c(const float* x, float* y, int64_t rows, int64_t W, hipStream_t st) {
     using namespace sonar;
-    if (W < 4 || (W & 1) || W > 2 * kLinesMax || (reinterpret_cast<uintptr_t>(x) & 7u)) return false;
+    if (W < 3 || W > kLinesMax || (!(W & 1) && W < 4)) return false;
+    if (W & 1) {
+        int n1, n2;
+        best_split((int)W, n1, n2);
+        if (n1 == 1) return false;  // a prime above the codelets: the direct sums' own kernel is the faster one (135 x 241: 2.4 against 2.65 ms)
+        const size_t line = (size_t)(W | 1) * sizeof(c32), table = (size_t)W * sizeof(c32);
+        const int per = lines_per(line, table, 512);
+        lines_lds_attr(lines_r2c_odd_kernel);
+        const int g = (int)std::max<int64_t>(1, std::min<int64_t>((rows + per - 1) / per, 1024));
+        hipLaunchKernelGGL(lines_r2c_odd_kernel, dim3(g), dim3(kLinesThreads), per * line + table, st, x, reinterpret_cast<c32*>(y), rows, (int)W, n1, n2, per);
+        return true;
+    }
+    if (reinterpret_cast<uintptr_t>(x) & 7u) return false;
     const int M = (int)W / 2;
     int n1, n2;
     best_split(M, n1, n2);
@@ -1019,7 +1096,26 @@ bool sonar_lines_cols(const float* in, const float* filter, float* out, int64_t 
 
 bool sonar_lines_rows_c2r(const float* y, float* out, int64_t rows, int64_t W, float scale, double* partials, hipStream_t st) {
     using namespace sonar;
-    if (W < 4 || (W & 1) || W > 2 * kLinesMax || (reinterpret_cast<uintptr_t>(out) & 7u)) return false;
+    if (W < 3 || W > kLinesMax || (!(W & 1) && W < 4)) return false;
+    if (W & 1) {
+        int n1, n2;
+        best_split((int)W, n1, n2);
+        if (n1 == 1) return false;
+        const size_t line = (size_t)(W | 1) * sizeof(c32), table = (size_t)W * sizeof(c32);
+        const int per = lines_per(line, table, 512);
+        const int g = (int)std::max<int64_t>(1, std::min<int64_t>((rows + per - 1) / per, kNPart));
+        if (partials) {
+            lines_lds_attr(lines_c2r_odd_kernel<true>);
+            hipLaunchKernelGGL(lines_c2r_odd_kernel<true>, dim3(g), dim3(kLinesThreads), per * line + table, st, reinterpret_cast<const c32*>(y), out, rows,
+                               (int)W, n1, n2, per, scale, partials);
+        } else {
+            lines_lds_attr(lines_c2r_odd_kernel<false>);
+            hipLaunchKernelGGL(lines_c2r_odd_kernel<false>, dim3(g), dim3(kLinesThreads), per * line + table, st, reinterpret_cast<const c32*>(y), out, rows,
+                               (int)W, n1, n2, per, scale, partials);
+        }
+        return true;
+    }
+    if (reinterpret_cast<uintptr_t>(out) & 7u) return false;
     const int M = (int)W / 2;
     int n1, n2;
     best_split(M, n1, n2);

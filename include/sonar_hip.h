@@ -541,9 +541,10 @@ int sonar_signed_rescale_f32(const float* x, int64_t rows, int64_t inner, double
  * 135-row latents -- or planes beyond the LDS budget): torch.fft.rfft2 / irfft2 (py/nodes/powernoise.py:338-408,
  * py/noise_generation.py:680-759, py/nodes/freeu_extreme.py:10-29) as rows r2c -> columns (optionally x a real filter [H][K] on the
  * way in; inverse: e^{+}) -> rows c2r (x scale; the imaginary parts of the DC / Nyquist columns are ignored, as irfft does), through a
- * caller-owned complex64 workspace [planes][H][W/2+1].  Lines of at most 2048; unscaled except for `scale`.  Even widths (rows) and
- * every height (columns) run the LDS line transforms of the general-size kernels (register codelets, a factor above 19 as direct sums),
- * 8-byte aligned buffers assumed; odd widths run direct sums, O(N) per output.  sonar_dft_cols_f32: inverse = 0 forward, 1 inverse (the
+ * caller-owned complex64 workspace [planes][H][W/2+1].  Lines of at most 2048; unscaled except for `scale`.  Rows and columns run the
+ * LDS line transforms of the general-size kernels (register codelets, a factor above 19 as direct sums; even widths with the
+ * half-length trick, odd widths as full-length complex lines); an odd width that is a prime above 19, or buffers that are not 8-byte
+ * aligned, run direct sums, O(N) per output.  sonar_dft_cols_f32: inverse = 0 forward, 1 inverse (the
  * filter multiplies the INPUT), 2 forward, x filter, inverse in one pass (the spectral filter's middle; SONAR_ERR_UNSUPPORTED when the
  * columns cannot go through LDS: run 0 then 1).  partials (nullable): (sum, sumsq) of the real output. */
 int sonar_dft_rows_r2c_f32(const float* x, float* y, int64_t rows, int64_t W, void* stream);

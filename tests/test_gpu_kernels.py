@@ -711,7 +711,9 @@ def test_fused_normalised_fill(hl, uniform, n, offset):
 @pytest.mark.parametrize("shape", [(3, 9, 7), (2, 135, 30), (5, 16, 21), (2, 33, 64), (1, 1, 5), (2, 6, 1), (1, 250, 250),
                                    # even widths run the LDS line transforms pass by pass (round 3): 16 x 16 codelets, a direct second pass (512 = 16 x
                                    # 32), the longest lines either way, a length with the factors 13 and 20
-                                   (1, 256, 256), (2, 384, 512), (1, 2048, 40), (1, 34, 2048), (1, 300, 520)])
+                                   (1, 256, 256), (2, 384, 512), (1, 2048, 40), (1, 34, 2048), (1, 300, 520),
+                                   # odd widths as full-length complex lines: 135 = 15 x 9, a prime, a prime above the codelets, the longest
+                                   (3, 135, 135), (2, 24, 241), (2, 16, 37), (1, 6, 2047)])
 def test_direct_dft_passes_match_torch_fft(hl, shape):
     """sonar_dft_rows_r2c / cols / rows_c2r (the route of planes the LDS FFT kernels do not take: odd sizes, big planes) against
     torch.fft: rfft2, irfft2 of a filtered spectrum (norm='ortho', imaginary parts of the DC / Nyquist columns ignored), and the
