@@ -162,7 +162,7 @@ constexpr int split_n1(int n) { return n >= 256 ? 16 : n >= 64 ? 8 : n == 32 ? 4
 #endif
 #ifdef SONAR_PW_TRACE  // profiling builds: per-phase s_memtime stamps of wave 0 of every workgroup (scratch/pw_trace.py)
 __device__ unsigned long long g_pw_trace[1024 * 8 * 12];
-#define SONAR_STAMP(slot) do { if (tid == 0 && pidx < 8) g_pw_trace[(blockIdx.x * 8 + pidx) * 12 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define SONAR_STAMP(slot) do { if (tid == 0 && pidx < 8 && blockIdx.x < 1024) g_pw_trace[(blockIdx.x * 8 + pidx) * 12 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define SONAR_STAMP(slot) do { } while (0)
 #endif
