@@ -255,6 +255,21 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
                                         "end to end adds the reference's sigma.max().item() sync and the host rule logic"))
         except Exception as exc:  # secondary figure only; the headline must still print
             extra[f"wavelet_cfg_{tag}_error"] = repr(exc)[:200]
+    # the rules the low-pass kernel does not take: per-orientation difference scales (one tensor, cond - uncond, through the band kernels)
+    # and cond / uncond scales beside the difference (both tensors transformed) -- three launches with the level-1 bands through HBM
+    band_rules = {"bands_difference": dict(difference=dict(yl_scale=5.0, yh_scales=[[3.0, 2.5, 2.0]] * 5)),
+                  "bands_pair": dict(cond=dict(yl_scale=1.1, yh_scales=1.0), uncond=dict(yl_scale=1.0, yh_scales=0.9),
+                                     difference=dict(yl_scale=5.0, yh_scales=3.0))}
+    for rtag, params in band_rules.items():
+        for tag, hp in (("fp64", True), ("fp32", False)):
+            try:
+                cfg_fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(**params, high_precision_mode=hp))
+                us = event_us(lambda: cfg_fn(wargs), 10, 3)
+                extra[f"wavelet_cfg_{rtag}_{tag}_end_to_end_us"] = us
+                kernels.append(kernel_entry(f"dwt2_tile / wcfg_deep / idwt2_tile kernels, WaveletCFG {rtag.replace('_', ' ')} rule, {tag}, batch 256 "
+                                            "(end to end)", us, 16 * N_LATENT * b4, tr.get(f"wcfg_{rtag}_{tag}_b256", {}).get("hbm_bytes_per_launch")))
+            except Exception as exc:  # secondary figure only
+                extra[f"wavelet_cfg_{rtag}_{tag}_error"] = repr(exc)[:200]
     # cfg5: one rank's shard (128 Flux latents), scheduled power + Perlin + Brownian chain, SonarDPMPPSDE with momentum, per step
     try:
         xf = torch.randn(128, 16, H, W, device=device) * 10.0
