@@ -106,10 +106,10 @@ __device__ __forceinline__ void prefix_draw(Xoshiro& rng, const Divider& div, co
     if constexpr (PRE == 1) {
         rng.normal4(x);
     } else {
-        rng.uniform4(x);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = div(x[k]);
-        x[0] += term.x; x[1] += term.y; x[2] += term.z; x[3] += term.w;
+        uint32_t r[4];
+        rng.words4_high(r);
+        x[0] = div.from_word(r[0], term.x); x[1] = div.from_word(r[1], term.y);
+        x[2] = div.from_word(r[2], term.z); x[3] = div.from_word(r[3], term.w);
     }
 }
 // v <- fold(y1, v) with y1 = x (fresh) or y * ya + x * f, y read from the running sum
@@ -465,14 +465,14 @@ __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v[4];
-                    rng.uniform4(v);
+                    uint32_t r[4];
+                    rng.words4_high(r);
                     const int64_t e = base + (4 * g + j) * 256;
                     if constexpr (!ALIGNED) {
                         if (e < 0 || e >= n) continue;  // the two ends of a shard that does not start / end on a tile (whole groups of 4)
                     }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = divide(v[k]);
-                    v[0] += cur[j].x; v[1] += cur[j].y; v[2] += cur[j].z; v[3] += cur[j].w;
+                    v[0] = divide.from_word(r[0], cur[j].x); v[1] = divide.from_word(r[1], cur[j].y);
+                    v[2] = divide.from_word(r[2], cur[j].z); v[3] = divide.from_word(r[3], cur[j].w);
                     if constexpr (MODE == 2) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[k] = norm(v[k]);
