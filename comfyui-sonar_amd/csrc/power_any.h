@@ -24,6 +24,9 @@ constexpr size_t kAnyLdsLimit = 160 * 1024 - 2048;
 // twiddles, A transforms of length B).  Every coefficient is a compile-time constant (static_for hands the loop indices to the
 // lambdas as types), so a codelet is straight-line packed arithmetic on register pairs.
 constexpr int kAnyCodelet = 16;
+#ifndef SONAR_ANY_STORE16
+#define SONAR_ANY_STORE16 1
+#endif
 #ifndef SONAR_ANY_PRIMES  // codelets for 17 and 19 too (136 = 8 x 17 and 152 = 8 x 19 are SDXL sides): 104 x 152 216 -> 152 us, the other sizes +3 %
 #define SONAR_ANY_PRIMES 1
 #endif
@@ -617,6 +620,32 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
             c2r_rows<NT>(A, twW, W, pl.mn1, pl.mn2, H, M, S, pl.c2r_fuse, tid);
             float* const oplane = out + plane * (int64_t)H * W;
             float ps = 0.0f, pq = 0.0f;
+            if (SONAR_ANY_STORE16 && (M & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {  // uniform
+                // two adjacent values of a row per item: 16-byte stores (the store phase is bound by its memory instructions)
+                const int Mh = M >> 1, hdr = NT / Mh, hdm = NT - hdr * Mh;
+                int hr = tid / Mh, hm = tid - hr * Mh;
+                for (int j = tid; j < H * Mh; j += NT) {
+                    const int r = hr, m = 2 * hm;
+                    hr += hdr;
+                    hm += hdm;
+                    if (hm >= Mh) {
+                        hm -= Mh;
+                        ++hr;
+                    }
+                    const c32 g0 = A[r * S + m], g1 = A[r * S + m + 1];
+                    float4 o;
+                    if constexpr (NORM) {
+                        o = make_float4(__builtin_fmaf(g0.x, nm, -nc), __builtin_fmaf(g0.y, nm, -nc), __builtin_fmaf(g1.x, nm, -nc), __builtin_fmaf(g1.y, nm, -nc));
+                    } else {
+                        o = make_float4(g0.x * scale, g0.y * scale, g1.x * scale, g1.y * scale);
+                    }
+                    *reinterpret_cast<float4*>(oplane + (int64_t)r * W + 2 * m) = o;
+                    if constexpr (STATS) {
+                        ps += (o.x + o.y) + (o.z + o.w);
+                        pq = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, __builtin_fmaf(o.z, o.z, __builtin_fmaf(o.w, o.w, pq))));
+                    }
+                }
+            } else {
             const int sdr = NT / M, sdm = NT - sdr * M;
             int sr = tid / M, sm = tid - sr * M;
             for (int j = tid; j < H * M; j += NT) {
@@ -641,6 +670,7 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
                     ps += a + b;
                     pq = __builtin_fmaf(a, a, __builtin_fmaf(b, b, pq));
                 }
+            }
             }
             if constexpr (STATS) {
                 s += (double)ps;
