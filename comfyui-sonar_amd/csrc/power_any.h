@@ -578,15 +578,48 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
             } else {
                 // ---- forward r2c: rows as W/2 complex values, forward DFT, split into the half-spectrum, forward columns, x filter
                 const float* xin = z + plane * (int64_t)H * W;
-                for (int j = tid; j < H * M; j += NT) {
-                    const int r = j / M, m = j - r * M;
-                    A[r * S + m] = *reinterpret_cast<const float2*>(xin + (int64_t)r * W + 2 * m);
+                if (SONAR_ANY_STORE16 && (M & 1) == 0 && (reinterpret_cast<uintptr_t>(z) & 15u) == 0) {  // uniform: 16-byte loads, two values per item
+                    const int Mh = M >> 1, hdr = NT / Mh, hdm = NT - hdr * Mh;
+                    int hr = tid / Mh, hm = tid - hr * Mh;
+                    for (int j = tid; j < H * Mh; j += NT) {
+                        const int r = hr, m = 2 * hm;
+                        hr += hdr;
+                        hm += hdm;
+                        if (hm >= Mh) {
+                            hm -= Mh;
+                            ++hr;
+                        }
+                        const float4 q4 = *reinterpret_cast<const float4*>(xin + (int64_t)r * W + 2 * m);
+                        A[r * S + m] = make_float2(q4.x, q4.y);
+                        A[r * S + m + 1] = make_float2(q4.z, q4.w);
+                    }
+                } else {
+                    const int ldr = NT / M, ldm = NT - ldr * M;
+                    int lr = tid / M, lm = tid - lr * M;
+                    for (int j = tid; j < H * M; j += NT) {
+                        const int r = lr, m = lm;
+                        lr += ldr;
+                        lm += ldm;
+                        if (lm >= M) {
+                            lm -= M;
+                            ++lr;
+                        }
+                        A[r * S + m] = *reinterpret_cast<const float2*>(xin + (int64_t)r * W + 2 * m);
+                    }
                 }
                 __syncthreads();
                 line_dft<NT, true>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, tid);
                 // X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i, w = e^{-2 pi i / W}
-                for (int j = tid; j < H * (M / 2 + 1); j += NT) {
-                    const int r = j / (M / 2 + 1), k = j - r * (M / 2 + 1);
+                const int FQ = M / 2 + 1, fdr = NT / FQ, fdk = NT - fdr * FQ;
+                int fr = tid / FQ, fk = tid - fr * FQ;
+                for (int j = tid; j < H * FQ; j += NT) {
+                    const int r = fr, k = fk;
+                    fr += fdr;
+                    fk += fdk;
+                    if (fk >= FQ) {
+                        fk -= FQ;
+                        ++fr;
+                    }
                     c32* row = A + r * S;
                     if (k == 0) {
                         const c32 c0 = row[0];
