@@ -858,6 +858,21 @@ constexpr int kLinesThreads = 512;
 constexpr int kLinesMax = 2048;
 constexpr size_t kLinesLds = 64 * 1024;  // two workgroups per CU
 
+// (row, column) of the flat item index j = thread + k x kLinesThreads over rows of `cols` items, walked instead of divided out
+struct LinesWalk {
+    int j, r, c, dr, dc;
+    __device__ __forceinline__ LinesWalk(int tid, int cols) : j(tid), r(tid / cols), c(tid - (tid / cols) * cols), dr(kLinesThreads / cols), dc(kLinesThreads - (kLinesThreads / cols) * cols) {}
+    __device__ __forceinline__ void next(int cols) {
+        j += kLinesThreads;
+        r += dr;
+        c += dc;
+        if (c >= cols) {
+            c -= cols;
+            ++r;
+        }
+    }
+};
+
 __device__ __forceinline__ void lines_table(c32* tw, int N, int tid) {  // e^{2 pi i j / N}
     for (int j = tid; j < N; j += kLinesThreads) {
         double sn, cs;
@@ -877,15 +892,15 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_kernel(const float
     for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
         const int nr = (int)min<int64_t>(per, rows - r0);
         __syncthreads();
-        for (int j = tid; j < nr * M; j += kLinesThreads) {
-            const int r = j / M, m = j - r * M;
+        for (LinesWalk lw(tid, M); lw.j < nr * M; lw.next(M)) {
+            const int r = lw.r, m = lw.c;
             A[r * S + m] = *reinterpret_cast<const float2*>(x + (r0 + r) * W + 2 * m);
         }
         __syncthreads();
         line_dft<kLinesThreads, true>(A, tw, W, 2, n1, n2, nr, 1, S, tid);
         // X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i, w = e^{-2 pi i / W}
-        for (int j = tid; j < nr * (M / 2 + 1); j += kLinesThreads) {
-            const int r = j / (M / 2 + 1), k = j - r * (M / 2 + 1);
+        for (LinesWalk lw(tid, (M / 2 + 1)); lw.j < nr * (M / 2 + 1); lw.next((M / 2 + 1))) {
+            const int r = lw.r, k = lw.c;
             c32* row = A + r * S;
             if (k == 0) {
                 const c32 c0 = row[0];
@@ -903,8 +918,8 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_kernel(const float
             }
         }
         __syncthreads();
-        for (int j = tid; j < nr * S; j += kLinesThreads) {
-            const int r = j / S, k = j - r * S;
+        for (LinesWalk lw(tid, S); lw.j < nr * S; lw.next(S)) {
+            const int r = lw.r, k = lw.c;
             y[(r0 + r) * S + k] = A[r * S + k];
         }
     }
@@ -928,8 +943,8 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32*
         const int k0 = (int)(u - p * blocks) * cols, nc = min(cols, K - k0);
         const c32* src = in + p * (int64_t)H * K + k0;
         __syncthreads();
-        for (int j = tid; j < H * nc; j += kLinesThreads) {
-            const int m = j / nc, c = j - m * nc;
+        for (LinesWalk lw(tid, nc); lw.j < H * nc; lw.next(nc)) {
+            const int m = lw.r, c = lw.c;
             c32 v = src[(int64_t)m * K + c];
             if (MODE == 1 && filter) {
                 const float f = filter[(int64_t)m * K + k0 + c];
@@ -941,8 +956,8 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32*
         __syncthreads();
         line_dft<kLinesThreads, MODE != 1>(A, tw, H, 1, n1, n2, nc, S, 1, tid);
         if constexpr (MODE == 2) {
-            for (int j = tid; j < H * nc; j += kLinesThreads) {
-                const int m = j / nc, c = j - m * nc;
+            for (LinesWalk lw(tid, nc); lw.j < H * nc; lw.next(nc)) {
+                const int m = lw.r, c = lw.c;
                 const float f = filter[(int64_t)m * K + k0 + c];
                 c32 v = A[m * S + c];
                 v.x *= f;
@@ -953,8 +968,8 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32*
             line_dft<kLinesThreads, false>(A, tw, H, 1, n1, n2, nc, S, 1, tid);
         }
         c32* dst = out + p * (int64_t)H * K + k0;
-        for (int j = tid; j < H * nc; j += kLinesThreads) {
-            const int m = j / nc, c = j - m * nc;
+        for (LinesWalk lw(tid, nc); lw.j < H * nc; lw.next(nc)) {
+            const int m = lw.r, c = lw.c;
             dst[(int64_t)m * K + c] = A[m * S + c];
         }
     }
@@ -974,14 +989,14 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* 
     for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
         const int nr = (int)min<int64_t>(per, rows - r0);
         __syncthreads();
-        for (int j = tid; j < nr * S; j += kLinesThreads) {
-            const int r = j / S, k = j - r * S;
+        for (LinesWalk lw(tid, S); lw.j < nr * S; lw.next(S)) {
+            const int r = lw.r, k = lw.c;
             A[r * S + k] = y[(r0 + r) * S + k];
         }
         __syncthreads();
         // G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k; X[0], X[M] contribute their real parts
-        for (int j = tid; j < nr * (M / 2 + 1); j += kLinesThreads) {
-            const int r = j / (M / 2 + 1), k = j - r * (M / 2 + 1);
+        for (LinesWalk lw(tid, (M / 2 + 1)); lw.j < nr * (M / 2 + 1); lw.next((M / 2 + 1))) {
+            const int r = lw.r, k = lw.c;
             c32* row = A + r * S;
             if (k == 0) {
                 const float x0 = row[0].x, xm = row[M].x;
@@ -1005,8 +1020,8 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* 
         }
         __syncthreads();
         line_dft<kLinesThreads, false>(A, tw, W, 2, n1, n2, nr, 1, S, tid);
-        for (int j = tid; j < nr * M; j += kLinesThreads) {
-            const int r = j / M, m = j - r * M;
+        for (LinesWalk lw(tid, M); lw.j < nr * M; lw.next(M)) {
+            const int r = lw.r, m = lw.c;
             const c32 g = A[r * S + m];
             const float a = g.x * scale, b = g.y * scale;
             *reinterpret_cast<float2*>(out + (r0 + r) * W + 2 * m) = make_float2(a, b);
@@ -1032,14 +1047,14 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_odd_kernel(const f
     for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
         const int nr = (int)min<int64_t>(per, rows - r0);
         __syncthreads();
-        for (int j = tid; j < nr * W; j += kLinesThreads) {
-            const int r = j / W, i = j - r * W;
+        for (LinesWalk lw(tid, W); lw.j < nr * W; lw.next(W)) {
+            const int r = lw.r, i = lw.c;
             A[r * S + i] = make_float2(x[(r0 + r) * W + i], 0.0f);
         }
         __syncthreads();
         line_dft<kLinesThreads, true>(A, tw, W, 1, n1, n2, nr, 1, S, tid);
-        for (int j = tid; j < nr * K; j += kLinesThreads) {
-            const int r = j / K, k = j - r * K;
+        for (LinesWalk lw(tid, K); lw.j < nr * K; lw.next(K)) {
+            const int r = lw.r, k = lw.c;
             y[(r0 + r) * K + k] = A[r * S + k];
         }
     }
@@ -1059,8 +1074,8 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_odd_kernel(const c
         const int nr = (int)min<int64_t>(per, rows - r0);
         __syncthreads();
         // the full Hermitian line: X[k] = y[k], X[W - k] = conj y[k]; the DC value's imaginary part is ignored, as irfft does
-        for (int j = tid; j < nr * K; j += kLinesThreads) {
-            const int r = j / K, k = j - r * K;
+        for (LinesWalk lw(tid, K); lw.j < nr * K; lw.next(K)) {
+            const int r = lw.r, k = lw.c;
             const c32 v = y[(r0 + r) * K + k];
             if (k == 0) {
                 A[r * S] = make_float2(v.x, 0.0f);
@@ -1071,8 +1086,8 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_odd_kernel(const c
         }
         __syncthreads();
         line_dft<kLinesThreads, false>(A, tw, W, 1, n1, n2, nr, 1, S, tid);
-        for (int j = tid; j < nr * W; j += kLinesThreads) {
-            const int r = j / W, i = j - r * W;
+        for (LinesWalk lw(tid, W); lw.j < nr * W; lw.next(W)) {
+            const int r = lw.r, i = lw.c;
             const float a = A[r * S + i].x * scale;
             out[(r0 + r) * W + i] = a;
             if constexpr (STATS) {
