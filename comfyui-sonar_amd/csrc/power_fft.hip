@@ -499,7 +499,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         // The general passes index by item = thread + k * NT: every LDS address of a plane is loop-invariant, the optimiser hoists them all
         // out of the plane loop (the 64 x 64 kernel then wants 184 registers, spills 47 at its 128 and reloads them plane after plane).
         // An opaque copy of the thread index per plane keeps the address arithmetic -- a few integer operations -- inside the loop
-        // (64 x 64: 106 -> 78 us per 33.5 M values, 256 x 64: 185 -> 91; the planes below 4096 values fit their budget as they are).
+        // (64 x 64: 106 -> 78 us per 33.5 M values, 256 x 64: 185 -> 91; the planes below 4096 values fit their budget as they are, or lose by it: 64 x 32 89 -> 98 us).
         int ptid = tid;
         if constexpr (!FAST && H * W >= 4096) asm volatile("" : "+v"(ptid));
         if constexpr (SRC < 2) {
