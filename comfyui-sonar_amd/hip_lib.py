@@ -171,16 +171,25 @@ SIGNATURES = {
     "sonar_wcfg_fused_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _I, _P, _I64, _P]),
     "sonar_wcfg_fused_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _I, _PD, _PD, _I, _D, _I, _I, _P, _I64, _P]),
     "sonar_cast_f32_f64": (_I, [_P, _P, _I64, _P]),
+    "sonar_plan_fn_id": (_I, [C.c_char_p]),
+    "sonar_plan_fn_nargs": (_I, [_I]),
+    "sonar_plan_create": (_P, [_I]),
+    "sonar_plan_destroy": (None, [_P]),
+    "sonar_plan_length": (_I, [_P]),
+    "sonar_plan_add": (_I, [_P, _I, C.POINTER(_U64), _I, _P, _I64, _P, _I]),
+    "sonar_plan_run": (_I, [_P, C.POINTER(_U64), _I, _U64, _U64, _P, C.POINTER(_I)]),
+    "sonar_pyramid_levels": (_I, [_I64, _I64, _I, _D, _U64, _U64, _PI64, _PI64, _PF]),
 }
 
 _lib: Optional[C.CDLL] = None
+_recorder = None  # the _Recorder of the call being traced into a plan (section "prepared call plans"), else None
 
 
 def load() -> C.CDLL:
     """Load libsonar_hip.so or raise (never falls back to anything else)."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if _recorder is None else _recorder.lib
     if not os.path.exists(LIB_PATH):
         raise SonarHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -263,6 +272,8 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
     if not t.is_contiguous():
         raise SonarHipError(f"{name}: tensor must be contiguous")
     _last_device = t.device.index
+    if _recorder is not None:
+        _recorder.seen[t.data_ptr()] = t
     return t.data_ptr()
 
 
@@ -910,6 +921,10 @@ def _pyramid_args(levels):
     hs = (C.c_int64 * max(n, 1))(*[int(lv[1]) for lv in levels])
     ws = (C.c_int64 * max(n, 1))(*[int(lv[2]) for lv in levels])
     wts = (C.c_float * max(n, 1))(*[float(lv[3]) for lv in levels])
+    rule = getattr(levels, "rule", None)
+    if rule is not None:  # the tables follow from (seed, stream): a plan recomputes them per call (PATCH_LEVELS)
+        hs._sonar_levels = rule
+        ptrs._sonar_levels_part = ws._sonar_levels_part = wts._sonar_levels_part = True
     return n, ptrs, hs, ws, wts
 
 
@@ -1032,8 +1047,11 @@ def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_o
     lib = load()
     seed &= 2**64 - 1
     if lookahead is not None and lib.sonar_power_noise_ahead_ok(planes, H, W, group):
-        def key_for(stream):
-            return (filt.data_ptr(), filt._version, tuple(shape), seed, stream, plane_offset, group, filt.device)
+        st = _stream()
+
+        def key_for(stream, seed=seed, st=st):
+            # the HIP stream is part of the key: the statistics are written and read in stream order only
+            return (filt.data_ptr(), filt._version, tuple(shape), seed, stream, plane_offset, group, filt.device, st)
 
         have = lookahead.key is not None and lookahead.key == key_for(stream_id)
         ws = lookahead.partials if have else new_partials(filt.device)
@@ -1047,12 +1065,17 @@ def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_o
         _check(
             lib.sonar_power_noise_ahead_f32(_dev(filt, "filter"), _dev(out, "out"), planes, H, W, seed, stream_id, plane_offset, group,
                                             float(factor), float(threshold_std_devs), _dev(ws, "ws", torch.float64), int(have), nxt,
-                                            _dev(nws, "ws_next", torch.float64), _stream()),
+                                            _dev(nws, "ws_next", torch.float64), st),
             "sonar_power_noise_ahead_f32",
         )
         lookahead.hits += int(have)
         lookahead.misses += int(not have)
         lookahead.key, lookahead.partials, lookahead.last_stream = key_for(nxt), nws, stream_id
+        if _recorder is not None:  # a plan replays the steady state only: statistics present, the step settled
+            if have and lookahead.last_delta == lookahead.step:
+                _recorder.hooks.append(_PowerAheadHook(lookahead, key_for, ws, nws, stream_id - _recorder.base, lookahead.step, filt.device))
+            else:
+                _recorder.fail("power-law look-ahead not in its steady state")
         return out
     ws = new_partials(filt.device)
     _check(
@@ -1526,3 +1549,579 @@ def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tenso
         return None
     _check(rc, "sonar_wcfg_fused")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ prepared call plans
+# A sampler step whose launches depend on nothing but the RNG position and fresh output tensors (generate-mode Gaussian / uniform / Perlin
+# / pyramid / power-law items and chains of them) is traced ONCE -- the entry points it calls, in order, with their arguments -- and from
+# then on issued by one foreign call (include/sonar_hip.h, "prepared call plans"; csrc/plan.hip).  The replay calls the same entry points
+# with the same arguments, so the output bits are those of the ordinary path; what disappears is the interpreter work per step (~50 us
+# for a two-item chain at any batch size, against 20-35 us of kernels at batch 64).
+PLANS_ENABLED = os.environ.get("SONAR_PLANS", "1") != "0"
+PLAN_WARM_CALLS = 2     # ordinary calls before a step is traced (first-call setup, look-ahead misses)
+PLAN_MAX_ATTEMPTS = 3   # traces that may fail (a call that took a fallback route) before the step stays on the ordinary path
+NOT_RUN = object()      # Plan.run: the step was not issued (a guard changed, an entry point refused): take the ordinary path
+_M64 = 2**64 - 1
+_HOST_QUERIES = frozenset(("sonar_abi_version", "sonar_last_error", "sonar_power_noise_ahead_ok", "sonar_power_plane_kind", "sonar_dwt_out_len",
+                           "sonar_dwt2_ws_bytes", "sonar_wcfg_lowpass_lds_bytes", "sonar_wcfg_fused_ws_bytes", "sonar_pyramid_levels",
+                           "sonar_plan_fn_id", "sonar_plan_fn_nargs"))
+PATCH_SLOT, PATCH_STREAM, PATCH_SEED, PATCH_BLOB, PATCH_LEVELS = range(5)
+
+
+class PlanPatch(C.Structure):
+    """``sonar_plan_patch`` (include/sonar_hip.h)."""
+
+    _fields_ = [("source", C.c_int32), ("target", C.c_int32), ("index", C.c_int32), ("width", C.c_int32), ("addend", C.c_int64)]
+
+
+class PlanLevels(C.Structure):
+    """``sonar_plan_levels`` (include/sonar_hip.h)."""
+
+    _fields_ = [("H", C.c_int64), ("W", C.c_int64), ("discount", C.c_double), ("iterations", C.c_int32), ("reserved", C.c_int32),
+                ("h_offset", C.c_int64), ("w_offset", C.c_int64), ("weight_offset", C.c_int64)]
+
+
+class AutoLevels(list):
+    """The level list of a device-mode pyramid draw together with the rule it came from (``sonar_pyramid_levels``: sizes and weights are a
+    function of (seed, stream)), so that a plan can recompute the table per call instead of freezing one call's sizes."""
+
+    def __init__(self, h: int, w: int, iterations: int, discount: float, seed: int, stream: int):
+        hs, ws, wts = (C.c_int64 * max(iterations, 1))(), (C.c_int64 * max(iterations, 1))(), (C.c_float * max(iterations, 1))()
+        n = load().sonar_pyramid_levels(h, w, iterations, float(discount), seed & _M64, stream & _M64, hs, ws, wts)
+        if n < 0:
+            _check(n, "sonar_pyramid_levels")
+        super().__init__((None, int(hs[i]), int(ws[i]), float(wts[i])) for i in range(n))
+        self.rule = (int(h), int(w), int(iterations), float(discount), stream & _M64)
+
+
+class PlanError(Exception):
+    """The traced call cannot be replayed (an entry point outside the replayable set, an address nobody accounts for, ...)."""
+
+
+class _RecordingLib:
+    """Stands in for the library while a call is traced: every entry point is called as usual and noted with its arguments."""
+
+    def __init__(self, lib, rec):
+        self._lib, self._rec = lib, rec
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        rec = self._rec
+
+        def call(*args):
+            rc = fn(*args)
+            rec.on_call(name, args, rc)
+            return rc
+
+        setattr(self, name, call)
+        return call
+
+
+class _Recorder:
+    def __init__(self, lib):
+        self.lib = _RecordingLib(lib, self)
+        self.calls = []       # (name, args)
+        self.seen = {}        # address -> tensor handed to a kernel through _dev (constants the plan keeps alive)
+        self.temps = []       # tensors allocated while the call ran
+        self.seed = None
+        self.base = None      # first RNG stream id the call took
+        self.count = 0        # stream ids taken
+        self.hooks = []       # PlanHook objects registered by wrappers whose arguments follow host state (power look-ahead)
+        self.failed = None
+
+    def fail(self, why: str):
+        if self.failed is None:
+            self.failed = why
+
+    def on_call(self, name, args, rc):
+        if name in _HOST_QUERIES:
+            return
+        if load_raw().sonar_plan_fn_id(name.encode()) < 0:
+            return self.fail(f"{name} is not replayable")
+        if rc != 0:
+            return self.fail(f"{name} returned {rc} during the trace")
+        self.calls.append((name, args))
+
+    def on_take(self, seed: int, stream: int, count: int):
+        seed &= _M64
+        if self.base is None:
+            self.seed, self.base = seed, stream
+        elif seed != self.seed or stream != self.base + self.count:
+            self.fail("the RNG position moved during the call")
+        self.count += count
+
+    def on_alloc(self, t):
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            self.temps.append(t)
+        return t
+
+
+def load_raw() -> C.CDLL:
+    return _lib if _lib is not None else load()
+
+
+class PlanHook:
+    """A wrapper whose arguments follow host state between calls (the power-law look-ahead) takes part in a plan through this protocol:
+    ``managed`` maps the addresses it supplies per call to names, ``bind`` learns their slot numbers, ``pre_run`` decides whether the
+    recorded call is still the right one and fills its slots, ``post_run`` updates the host state as the ordinary path would."""
+
+    managed: dict = {}
+
+    def bind(self, slot_of: dict):
+        raise NotImplementedError
+
+    def pre_run(self, seed: int, base: int, slots, stream: int) -> bool:
+        raise NotImplementedError
+
+    def post_run(self, seed: int, base: int):
+        pass
+
+
+class _PowerAheadHook(PlanHook):
+    """``power_noise(lookahead=...)`` inside a plan: the statistics input is what the previous call left (``lookahead.partials``), the
+    statistics output alternates between two tensors of the plan's own, and the call is only replayed while the sampler's stream ids
+    advance by the settled step -- anything else is the ordinary path's business, which shares the ``PowerLookahead`` state."""
+
+    def __init__(self, la, key_for, ws, nws, rel: int, step: int, device):
+        self.la, self.key_for, self.rel, self.step, self.device = la, key_for, rel, step, device
+        self.managed = {ws.data_ptr(): "ws", nws.data_ptr(): "nws"}
+        self.pair = None
+        self.flip = 0
+        self.now = None
+
+    def bind(self, slot_of):
+        self.ws_slot, self.nws_slot = slot_of["ws"], slot_of["nws"]
+
+    def pre_run(self, seed, base, table, st):
+        la = self.la
+        stream = base + self.rel
+        if (la.key is None or la.step != self.step or la.last_stream is None or stream - la.last_stream != self.step
+                or la.key != self.key_for(stream, seed, st)):
+            return False
+        if self.pair is None:
+            self.pair = (new_partials(self.device), new_partials(self.device))
+        nws = self.pair[self.flip]
+        if nws is la.partials:
+            self.flip ^= 1
+            nws = self.pair[self.flip]
+        table[self.ws_slot] = la.partials.data_ptr()
+        table[self.nws_slot] = nws.data_ptr()
+        self.now = (stream, seed, st, nws)
+        return True
+
+    def post_run(self, seed, base):
+        stream, seed, st, nws = self.now
+        la = self.la
+        la.hits += 1
+        la.key, la.partials, la.last_stream, la.last_delta = self.key_for((stream + self.step) & _M64, seed, st), nws, stream, self.step
+        self.flip ^= 1
+
+
+def _float_word(v: float) -> int:
+    return int.from_bytes(C.c_float(v), "little")  # the bit pattern of the rounded float
+
+
+def _double_word(v: float) -> int:
+    return int.from_bytes(C.c_double(v), "little")
+
+
+class _PlanBuilder:
+    """Turns a recorded call into a ``sonar_plan`` + the Python-side description of its slots and result."""
+
+    def __init__(self, rec: _Recorder, result):
+        self.rec = rec
+        self.slots = []      # [tensor template] in slot order
+        self.slot_of = {}    # id(tensor) or hook key -> slot index
+        self.constants = []  # tensors the plan only reads (kept alive)
+        self.managed = {}    # address -> hook key
+        for h in rec.hooks:
+            self.managed.update(h.managed)
+        self.temp_ranges = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), t) for t in rec.temps if t.numel()]
+        self.result = result
+        self.scratch_refs = []  # weak references to the temporaries the plan will own copies of
+
+    def resolve(self, addr: int):
+        """(slot index, byte offset) for an address the plan supplies per call, or None for a constant the caller owns."""
+        if addr in self.managed:
+            key = ("hook", self.managed[addr])
+            if key not in self.slot_of:
+                self.slot_of[key] = len(self.slots)
+                self.slots.append(None)
+            return self.slot_of[key], 0
+        for lo, hi, t in self.temp_ranges:
+            if lo <= addr < hi:
+                if id(t) not in self.slot_of:
+                    self.slot_of[id(t)] = len(self.slots)
+                    self.slots.append(t)
+                return self.slot_of[id(t)], addr - lo
+        t = self.rec.seen.get(addr)
+        if t is None:
+            for base, cand in self.rec.seen.items():
+                if base <= addr < base + cand.numel() * cand.element_size():
+                    t = cand
+                    break
+        if t is None:
+            raise PlanError(f"address {addr:#x} belongs to no tensor the trace knows")
+        self.constants.append(t)
+        return None
+
+    def stream_addend(self, value: int) -> int:
+        if self.rec.base is None or value < self.rec.base or value - self.rec.base > self.rec.count + 64:
+            raise PlanError("a stream id that does not follow from the call's RNG position")
+        return value - self.rec.base
+
+    def struct_blob(self, obj, blob: bytearray, patches: list) -> int:
+        """Copy a by-reference struct into the blob; its addresses, seed and stream fields become patches.  Returns its offset."""
+        off = _blob_reserve(blob, C.sizeof(obj), bytes(obj))
+        for name, ftype in obj._fields_:
+            fo = off + getattr(type(obj), name).offset
+            val = getattr(obj, name)
+            if ftype is C.c_void_p:
+                if val:
+                    where = self.resolve(int(val))
+                    if where is not None:
+                        patches.append(PlanPatch(PATCH_SLOT, -(fo + 1), where[0], 8, where[1]))
+            elif ftype is C.c_uint64:
+                if name == "seed":
+                    if val != self.rec.seed:
+                        raise PlanError("a seed that is not the call's RNG seed")
+                    patches.append(PlanPatch(PATCH_SEED, -(fo + 1), 0, 8, 0))
+                elif name == "stream_id":
+                    patches.append(PlanPatch(PATCH_STREAM, -(fo + 1), 0, 8, self.stream_addend(val)))
+                else:
+                    raise PlanError(f"unknown 64-bit field {name}")
+        return off
+
+    def record(self, name: str, args):
+        argtypes = SIGNATURES[name][1]
+        if len(args) != len(argtypes):
+            raise PlanError(f"{name}: argument count")
+        words, blob, patches = [], bytearray(), []
+        u64_seen = 0
+        i = 0
+        last = len(args) - 1
+        for i, (at, val) in enumerate(zip(argtypes, args)):
+            if i == last:  # the stream: patched by every run
+                words.append(0)
+            elif at is _U64:
+                u64_seen += 1
+                if u64_seen == 1:
+                    if int(val) & _M64 != self.rec.seed:
+                        raise PlanError(f"{name}: a seed that is not the call's RNG seed")
+                    patches.append(PlanPatch(PATCH_SEED, i, 0, 8, 0))
+                else:
+                    patches.append(PlanPatch(PATCH_STREAM, i, 0, 8, self.stream_addend(int(val) & _M64)))
+                words.append(0)
+            elif at in (_I64, _I, C.c_int32):
+                words.append(int(val) & _M64)
+            elif at is _F:
+                words.append(_float_word(val))
+            elif at is _D:
+                words.append(_double_word(val))
+            elif val is None:
+                words.append(0)
+            elif isinstance(val, int):  # a device address
+                where = self.resolve(val)
+                if where is None:
+                    words.append(val)
+                else:
+                    patches.append(PlanPatch(PATCH_SLOT, i, where[0], 8, where[1]))
+                    words.append(0)
+            elif isinstance(val, C.Array):
+                rule = getattr(val, "_sonar_levels", None)
+                if rule is not None:
+                    self.levels_patch(rule, i, args, blob, patches)
+                else:
+                    if val._type_ is C.c_void_p and any(val):
+                        raise PlanError(f"{name}: an array of addresses")
+                    if getattr(val, "_sonar_levels_part", False):
+                        words.append(0)  # ws / weights / level pointers: placed by the levels patch of this record
+                        continue
+                    patches.append(PlanPatch(PATCH_BLOB, i, 0, 8, _blob_reserve(blob, C.sizeof(val), bytes(val))))
+                words.append(0)
+            elif hasattr(val, "_obj") and isinstance(val._obj, C.Structure):
+                patches.append(PlanPatch(PATCH_BLOB, i, 0, 8, self.struct_blob(val._obj, blob, patches)))
+                words.append(0)
+            else:
+                raise PlanError(f"{name}: argument {i} ({type(val).__name__}) cannot be replayed")
+        return name, words, bytes(blob), patches
+
+    def levels_patch(self, rule, i: int, args, blob: bytearray, patches: list):
+        """Argument i is the level-height table of a pyramid entry point (..., nlevels, level_ptrs, level_h, level_w, weight, ...)."""
+        h, w, iterations, discount, stream = rule
+        n = max(iterations, 1)
+        ptr_off = _blob_reserve(blob, 8 * n, bytes(8 * n))
+        h_off = _blob_reserve(blob, 8 * n, bytes(8 * n))
+        w_off = _blob_reserve(blob, 8 * n, bytes(8 * n))
+        wt_off = _blob_reserve(blob, 4 * n, bytes(4 * n))
+        rule_off = _blob_reserve(blob, C.sizeof(PlanLevels), bytes(PlanLevels(h, w, discount, iterations, 0, h_off, w_off, wt_off)))
+        for arg, off in ((i - 1, ptr_off), (i, h_off), (i + 1, w_off), (i + 2, wt_off)):
+            patches.append(PlanPatch(PATCH_BLOB, arg, 0, 8, off))
+        patches.append(PlanPatch(PATCH_LEVELS, i - 2, rule_off, 8, self.stream_addend(stream)))
+
+
+def _blob_reserve(blob: bytearray, size: int, data: bytes) -> int:
+    while len(blob) % 16:
+        blob.append(0)
+    off = len(blob)
+    blob.extend(data[:size].ljust(size, b"\0"))
+    return off
+
+
+class Plan:
+    """A recorded step (``sonar_plan``) with what the host must supply per call: fresh tensors for everything the result owns, the
+    plan's own scratch tensors (one set per HIP stream), the RNG position, and the hooks' values."""
+
+    def __init__(self, handle, nslots, fresh, scratch, result_spec, constants, rec: _Recorder, take, rewind, guards, device):
+        self.handle, self.nslots = handle, nslots
+        self.fresh = fresh            # [(slot, shape, dtype)] allocated per run
+        self.scratch = scratch        # [(slot, shape, dtype)] allocated once per stream
+        self.result_spec = result_spec
+        self.constants = constants
+        self.hooks = rec.hooks
+        self.rng_count = rec.count
+        self.take, self.rewind, self.guards, self.device = take, rewind, guards, device
+        self.by_stream = {}           # hipStream_t -> (ctypes slot table, scratch tensors)
+        self.failed = C.c_int(-1)
+        self.runs = 0
+
+    def __del__(self):
+        if self.handle and _lib is not None:
+            _lib.sonar_plan_destroy(self.handle)
+            self.handle = None
+
+    def _table(self, st: int):
+        entry = self.by_stream.get(st)
+        if entry is None:
+            table = (C.c_uint64 * max(self.nslots, 1))()
+            keep = []
+            for slot, shape, dtype in self.scratch:
+                t = torch.empty(shape, dtype=dtype, device=self.device)
+                table[slot] = t.data_ptr()
+                keep.append(t)
+            entry = self.by_stream[st] = (table, keep)
+        return entry[0]
+
+    def run(self):
+        for getter, want in self.guards:
+            if getter() != want:
+                return NOT_RUN
+        cur = torch.cuda.current_device()
+        if cur != self.device.index:
+            return NOT_RUN
+        st = _RAW_STREAM(cur) if _RAW_STREAM is not None else torch.cuda.current_stream().cuda_stream
+        table = self._table(st)
+        seed, base = self.take(self.rng_count) if self.rng_count else (0, 0)
+        seed &= _M64
+        for h in self.hooks:
+            if not h.pre_run(seed, base, table, st):
+                if self.rng_count:
+                    self.rewind(base)
+                return NOT_RUN
+        fresh = []
+        device = self.device
+        for slot, shape, dtype in self.fresh:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            table[slot] = t.data_ptr()
+            fresh.append(t)
+        rc = _lib.sonar_plan_run(self.handle, table, self.nslots, seed, base, st, self.failed)
+        if rc != 0:
+            if self.rng_count:
+                self.rewind(base)
+            if rc == ERR_UNSUPPORTED:
+                return NOT_RUN  # an entry point refused this call's values (e.g. a level table the plane kernel cannot hold): ordinary path
+            _check(rc, f"sonar_plan_run (record {self.failed.value})")
+        for h in self.hooks:
+            h.post_run(seed, base)
+        self.runs += 1
+        return _rebuild(self.result_spec, fresh)
+
+
+def _rebuild(spec, fresh):
+    kind = spec[0]
+    if kind == "t":
+        _k, idx, view, tag_idx = spec
+        t = fresh[idx]
+        if view is not None:
+            t = t.view(view)
+        if tag_idx is not None:
+            setattr(t, STATS_ATTR, (fresh[tag_idx], t._version))
+            tag_register(t)
+        return t
+    if kind == "n":
+        return None
+    return tuple(_rebuild(s, fresh) for s in spec[1])
+
+
+def _alloc_hooks(rec: _Recorder):
+    """torch.empty / torch.empty_like as seen by the traced call: every tensor it allocates is noted (and kept alive until the trace
+    ends, so two of them never share an address)."""
+    real_empty, real_empty_like = torch.empty, torch.empty_like
+
+    def empty(*a, **k):
+        return rec.on_alloc(real_empty(*a, **k))
+
+    def empty_like(*a, **k):
+        return rec.on_alloc(real_empty_like(*a, **k))
+
+    return real_empty, real_empty_like, empty, empty_like
+
+
+import threading as _threading  # noqa: E402
+
+_trace_lock = _threading.Lock()
+
+
+def trace_plan(fn, args, *, take, rewind, guards):
+    """Run ``fn(*args)`` once on the ordinary path while recording it.  Returns (result, Plan or None): the result is the call's real
+    result either way; the plan is None when the call cannot be replayed (``PlanError`` reasons are kept in ``trace_plan.last_reason``)."""
+    global _recorder
+    lib = load()
+    if not _trace_lock.acquire(blocking=False):
+        return fn(*args), None
+    rec = _Recorder(lib)
+    real_empty, real_empty_like, empty, empty_like = _alloc_hooks(rec)
+    try:
+        _recorder = rec
+        torch.empty, torch.empty_like = empty, empty_like
+        try:
+            result = fn(*args)
+        finally:
+            torch.empty, torch.empty_like = real_empty, real_empty_like
+            _recorder = None
+        plan = None
+        try:
+            if rec.failed is not None:
+                raise PlanError(rec.failed)
+            plan = _build_plan(rec, result, take, rewind, guards)
+            trace_plan.last_reason = None
+        except PlanError as exc:
+            trace_plan.last_reason = str(exc)
+        if plan is not None:
+            refs, plan.scratch_refs = plan.scratch_refs, None
+            rec.temps.clear()
+            rec.seen.clear()
+            rec.calls.clear()
+            if any(r() is not None for r in refs):  # somebody kept a tensor the call allocated (and did not return): not ours to replace
+                trace_plan.last_reason = "a tensor allocated during the call outlives it"
+                plan = None
+        return result, plan
+    finally:
+        _trace_lock.release()
+
+
+trace_plan.last_reason = None
+
+
+def _build_plan(rec: _Recorder, result, take, rewind, guards) -> Plan:
+    if not rec.calls:
+        raise PlanError("the call launched nothing")
+    b = _PlanBuilder(rec, result)
+    records = [b.record(name, args) for name, args in rec.calls]
+    # what the result owns must be fresh per call: the tensors handed back and the statistics partials tagged onto them
+    owned = {}  # id(temp) -> index in the fresh list
+
+    def spec_of(obj):
+        if obj is None:
+            return ("n",)
+        if isinstance(obj, tuple):
+            return ("u", tuple(spec_of(o) for o in obj))
+        if not isinstance(obj, torch.Tensor):
+            raise PlanError(f"a result of type {type(obj).__name__}")
+        base = next((t for lo, hi, t in b.temp_ranges if lo == obj.data_ptr()), None)
+        if base is None or not obj.is_contiguous() or obj.numel() != base.numel() or obj.dtype != base.dtype:
+            raise PlanError("the result is not a whole tensor the call allocated")
+        tag = obj.__dict__.get(STATS_ATTR)
+        tag_idx = None
+        if tag is not None:
+            partials, version = tag
+            if version != obj._version:
+                tag = None
+            else:
+                pt = next((t for lo, hi, t in b.temp_ranges if lo == partials.data_ptr()), None)
+                if pt is None or pt.numel() != partials.numel():
+                    raise PlanError("a statistics tag the call did not allocate")
+                tag_idx = owned.setdefault(id(pt), len(owned))
+        idx = owned.setdefault(id(base), len(owned))
+        return ("t", idx, None if tuple(obj.shape) == tuple(base.shape) else tuple(obj.shape), tag_idx)
+
+    result_spec = spec_of(result)
+    fresh = [None] * len(owned)
+    scratch = []
+    by_id = {id(t): t for _lo, _hi, t in b.temp_ranges}
+    for tid, idx in owned.items():
+        t = by_id[tid]
+        if tid not in b.slot_of:  # a result no kernel wrote?  (cannot happen on a device path)
+            raise PlanError("a result tensor that no entry point was handed")
+        fresh[idx] = (b.slot_of[tid], tuple(t.shape), t.dtype)
+    hook_slots = {}
+    for key, slot in b.slot_of.items():
+        if isinstance(key, tuple) and key[0] == "hook":
+            hook_slots[key[1]] = slot
+        elif key not in owned:
+            t = by_id[key]
+            # a scratch tensor somebody else still holds after the call (a generator's cache filled during this very call) is not scratch:
+            # views of it show in the storage's use count, the tensor object itself is checked by trace_plan once the trace lets go of it
+            if torch._C._storage_Use_Count(t.untyped_storage()._cdata) > 2:
+                raise PlanError("a tensor allocated during the call outlives it (a view of it is still held)")
+            scratch.append((slot, tuple(t.shape), t.dtype))
+            b.scratch_refs.append(weakref.ref(t))
+    for h in rec.hooks:
+        h.bind(hook_slots)
+    device = next(iter(by_id.values())).device if by_id else torch.device("cuda", torch.cuda.current_device())
+    lib = load_raw()
+    nslots = len(b.slots)
+    handle = lib.sonar_plan_create(nslots)
+    if not handle:
+        raise PlanError("sonar_plan_create failed")
+    try:
+        for name, words, blob, patches in records:
+            arr = (C.c_uint64 * len(words))(*words)
+            parr = (PlanPatch * max(len(patches), 1))(*patches)
+            buf = (C.c_char * max(len(blob), 1)).from_buffer_copy(blob.ljust(1, b"\0"))
+            rc = lib.sonar_plan_add(handle, lib.sonar_plan_fn_id(name.encode()), arr, len(words), C.cast(buf, C.c_void_p), len(blob),
+                                    C.cast(parr, C.c_void_p), len(patches))
+            if rc != 0:
+                raise PlanError(f"sonar_plan_add({name}): {lib.sonar_last_error().decode('utf-8', 'replace')}")
+    except Exception:
+        lib.sonar_plan_destroy(handle)
+        raise
+    plan = Plan(handle, nslots, fresh, scratch, result_spec, b.constants, rec, take, rewind, guards, device)
+    plan.scratch_refs = b.scratch_refs
+    # the recursive spec_of closure keeps this frame (and through it every traced tensor) in a reference cycle: let go explicitly
+    b.temp_ranges, b.slots, b.slot_of = [], [], {}
+    by_id.clear()
+    return plan
+
+
+class Planned:
+    """``fn(sigma, sigma_next)`` with a prepared plan in front of it: the first calls take the ordinary path, one of them is traced, and
+    from then on a call is ``Plan.run()`` -- unless a guard changed or an entry point refused, in which case that call is the ordinary
+    path again.  Only for steps that do not depend on their arguments (the caller vouches for that: ``plan_static``)."""
+
+    def __init__(self, fn, *, take, rewind, guards=()):
+        self.fn, self.take, self.rewind, self.guards = fn, take, rewind, tuple(guards)
+        self.plan = None
+        self.calls = 0
+        self.attempts = 0
+        self.reason = None
+        for name in ("unscaled", "accumulate", "fold_prefix", "accepts_prefix", "normalized_call", "plan_static"):
+            if hasattr(fn, name):
+                setattr(self, name, getattr(fn, name))
+
+    def __call__(self, sigma=None, sigma_next=None):
+        if PLANS_ENABLED and _recorder is None:
+            plan = self.plan
+            if plan is not None:
+                out = plan.run()
+                if out is not NOT_RUN:
+                    return out
+            elif self.attempts < PLAN_MAX_ATTEMPTS:
+                self.calls += 1
+                if self.calls > PLAN_WARM_CALLS:
+                    self.attempts += 1
+                    guards = tuple((g, g()) for g in self.guards)
+                    out, self.plan = trace_plan(self.fn, (sigma, sigma_next), take=self.take, rewind=self.rewind, guards=guards)
+                    self.reason = trace_plan.last_reason
+                    return out
+        return self.fn(sigma, sigma_next)

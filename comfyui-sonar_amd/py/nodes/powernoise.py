@@ -222,6 +222,12 @@ class PowerNoiseItem(CustomNoiseItemBase):
                     defer_factor = False
 
             sampler.unscaled = unscaled
+        if getattr(noise_sampler, "draws_on_device", False) and not self.time_brownian:
+            # a device-drawn call depends on nothing but the RNG position: traced once, then one foreign call per step (hip_lib.Planned)
+            planned = hip_lib.Planned(sampler, take=DeviceRNG.take, rewind=DeviceRNG.rewind,
+                                      guards=(current_batch_offset, lambda: (self.factor, self.time_brownian)))
+            planned.plan_static = True
+            return planned
         return sampler
 
     def make_noise_sampler(self, x: Tensor, sigma_min, sigma_max, *, seed, cpu: bool = True, normalized=True):
@@ -239,6 +245,8 @@ class PowerNoiseItem(CustomNoiseItemBase):
         else:
             def draw(_s, _sn):
                 return None
+
+            draw.draws_on_device = True
         return self.make_noise_sampler_internal(x, draw, filter_rfft, normalized=normalized)
 
 

@@ -19,6 +19,8 @@ from .. import hip_lib
 from . import utils
 from .noise_generation import *  # noqa: F401,F403  (the reference re-exports the generators from here)
 from .noise_generation import (
+    DeviceRNG,
+    current_batch_offset,
     BrownianNoiseGenerator,
     CollatzNoiseGenerator,
     DistroNoiseGenerator,
@@ -252,8 +254,20 @@ class CustomNoiseChain:
                 return scale_noise(total, factor, normalized=normalized), None
             return total, hip_lib.norm_decision(partials, total.numel(), factor)
 
+        if all(getattr(ns, "plan_static", False) for ns in samplers):
+            # every item draws on the device from nothing but the RNG position: the step is traced once and then issued by one foreign
+            # call (hip_lib.Planned: the same entry points with the same arguments, the same bits)
+            planned = _planned(noise_sampler)
+            planned.deferred = _planned(deferred)
+            planned.plan_static = True
+            return planned
         noise_sampler.deferred = deferred
         return noise_sampler
+
+
+def _planned(fn, *guards):
+    """``fn`` behind a prepared plan keyed to this module's RNG bookkeeping and shard position."""
+    return hip_lib.Planned(fn, take=DeviceRNG.take, rewind=DeviceRNG.rewind, guards=(current_batch_offset, *guards))
 
 
 class NoiseSampler:
@@ -277,6 +291,14 @@ class NoiseSampler:
             if "unexpected keyword" not in str(exc) and "positional argument" not in str(exc):
                 raise
             self.noise_sampler = make_noise_sampler(x)
+        self._planned = _planned(self._call, lambda: (self.factor, self.normalized)) if self.plan_static else None
+
+    @property
+    def plan_static(self) -> bool:
+        """True when a call's launches depend on nothing but the RNG position (a device-mode generator that ignores its sigmas): the step
+        may be replayed from a prepared plan (``hip_lib.Planned``)."""
+        gen = self.noise_sampler
+        return bool(getattr(gen, "PLAN_STATIC", False)) and getattr(gen, "cpu", True) is False and self.dtype == torch.float32
 
     @classmethod
     def simple(cls, f):
@@ -364,6 +386,11 @@ class NoiseSampler:
         return self(*args), None
 
     def __call__(self, *args, **kwargs):
+        if self._planned is not None and not kwargs and len(args) == 2:
+            return self._planned(*args)
+        return self._call(*args, **kwargs)
+
+    def _call(self, *args, **kwargs):
         args = tuple(self.transform(torch.as_tensor(s)) if s is not None else s for s in args)
         fused = getattr(self.noise_sampler, "generate_normalized", None) if self.normalized and not kwargs else None
         noise = fused(self.factor, *args) if fused is not None else None

@@ -99,7 +99,16 @@ class DeviceRNG:
         with cls._lock:
             offset = gen.get_offset()
             gen.set_offset(offset + 4 * int(count))  # Philox offsets move in units of 4
-        return gen.initial_seed(), offset // 4
+        seed = gen.initial_seed()
+        rec = hip_lib._recorder
+        if rec is not None:  # the call is being traced into a prepared plan: its stream ids are relative to this position
+            rec.on_take(seed, offset // 4, int(count))
+        return seed, offset // 4
+
+    @classmethod
+    def rewind(cls, stream: int) -> None:
+        """Put the position back to ``stream`` (a prepared plan that took its streams and then could not issue the step)."""
+        torch.cuda.default_generators[torch.cuda.current_device()].set_offset(4 * int(stream))
 
 
 class _Shard(threading.local):
@@ -316,6 +325,7 @@ class GaussianNoiseGenerator(NoiseGenerator):
     """py/noise_generation.py:252-260."""
 
     name = "gaussian"
+    PLAN_STATIC = True  # device-mode calls depend on nothing but the RNG position: a prepared plan may replay them (hip_lib.Planned)
 
     @classmethod
     def ng_params(cls):
@@ -363,6 +373,7 @@ class UniformNoiseGenerator(NoiseGenerator):
     """py/noise_generation.py:496-514: (U[0,1) - sub_fac) * mul_fac + mean_fac."""
 
     name = "uniform"
+    PLAN_STATIC = True
 
     @classmethod
     def ng_params(cls):
@@ -393,6 +404,7 @@ class PerlinOldNoiseGenerator(FramesToChannelsNoiseGenerator):
     latent of the batch; the kernels implement exactly that case (``sonar_perlin_*``)."""
 
     name = "perlin_old"
+    PLAN_STATIC = True
 
     @classmethod
     def ng_params(cls):
@@ -485,6 +497,7 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
     sizes shrink by a random ratio r in [2,4) per level (cumulative), weighted discount**i."""
 
     name = "pyramid"
+    PLAN_STATIC = True
 
     @classmethod
     def ng_params(cls):
@@ -535,8 +548,7 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
         keys = self.device_key(2 + self.iterations)
         seed, stream = keys
         if w % 4 == 0 and mode in hip_lib.PYRAMID_FUSED_MODES:
-            plan = list(self._plan(h, w, _level_ratios(seed, stream)))
-            if hip_lib.pyramid_generate_acc_(y.view(b, c, h, w), y_mul, x_mul, [(None, ch, cw, self.discount**i) for i, ch, cw in plan], mode,
+            if hip_lib.pyramid_generate_acc_(y.view(b, c, h, w), y_mul, x_mul, self._auto_levels(h, w, seed, stream), mode,
                                              seed, stream, self.latent_elem_offset(c * h * w), partials, pre=pre):
                 return True
         if pre is not None:
@@ -548,11 +560,15 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
             hip_lib.stats(y, partials)
         return True
 
+    def _auto_levels(self, h, w, seed, stream):
+        """The all-device level list [(None, h_i, w_i, discount**i)] of ``_plan`` with ``_level_ratios(seed, stream)``, computed by the
+        library (``sonar_pyramid_levels``: the same doubles in the same order) so that a prepared plan can recompute it per call."""
+        return hip_lib.AutoLevels(h, w, self.iterations, self.discount, seed, stream)
+
     def _device_generate(self, partials, fused_factor, keys=None):
         mode = self.upscale_mode
         b, c, h, w = self.get_adjusted_shape()
         seed, stream = self.device_key(2 + self.iterations) if keys is None else keys
-        plan = list(self._plan(h, w, _level_ratios(seed, stream)))  # shared by all ranks
         plane_offset = current_batch_offset() * c
         offs = self.latent_elem_offset(c * h * w)
 
@@ -566,9 +582,10 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
         if fusable:
             # every level drawn on device: full-resolution levels fold into the base draw, the small grids are drawn by the
             # plane kernel (no launches, no HBM round trip for them); if that kernel cannot run this shape, explicit grids
-            out = run([(None, ch, cw, self.discount**i) for i, ch, cw in plan])
+            out = run(self._auto_levels(h, w, seed, stream))
             if out is not None:
                 return out
+        plan = list(self._plan(h, w, _level_ratios(seed, stream)))  # shared by all ranks
         levels = []
         for i, ch, cw in plan:
             if (ch, cw) == (h, w) and not any(lv[0] is None for lv in levels):

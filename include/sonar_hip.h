@@ -581,6 +581,52 @@ int sonar_wcfg_output_f32(const float* x, const void* result, int result_is_f64,
 /* fp32 -> fp64 conversion of a contiguous buffer (get_context cast, py/wavelet_cfg.py:707,764-765) */
 int sonar_cast_f32_f64(const float* in, double* out, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------- prepared call plans (host floor of rows C, G1, P, Y, PW) */
+/* The reference composes a sampler step from Python closures (py/noise.py:137-257, py/noise_generation.py:134-258); at the batch sizes
+ * a ComfyUI run uses (1-4, cfg3's 64) the interpreter work per step outweighs the kernels.  A plan is the step resolved once: the entry
+ * points of this header it issues, in order, with their arguments.  sonar_plan_run patches the values that change from call to call into
+ * the recorded arguments -- tensor addresses (slots), the RNG seed and stream ids, the pyramid's level table -- and calls the same entry
+ * points: same launches, same bits, one foreign call per step.  Host-side objects; not thread safe per plan. */
+typedef struct sonar_plan sonar_plan;
+#define SONAR_PATCH_SLOT 0   /* slots[index] + addend: a device address (or scalar) handed to sonar_plan_run */
+#define SONAR_PATCH_STREAM 1 /* stream_base + addend: an RNG stream id */
+#define SONAR_PATCH_SEED 2   /* the RNG seed */
+#define SONAR_PATCH_BLOB 3   /* address of byte `addend` of the record's blob (array and struct arguments) */
+#define SONAR_PATCH_LEVELS 4 /* pyramid level table (sonar_plan_levels at blob offset `index`) recomputed from (seed, stream_base + addend);
+                                the level count goes to argument `target` */
+typedef struct sonar_plan_patch {
+    int32_t source; /* SONAR_PATCH_* */
+    int32_t target; /* >= 0: argument index; < 0: byte offset -(target + 1) into the record's blob */
+    int32_t index;  /* SLOT: slot number; LEVELS: blob offset of the rule */
+    int32_t width;  /* bytes written at a blob target: 4 or 8 */
+    int64_t addend;
+} sonar_plan_patch;
+typedef struct sonar_plan_levels {
+    int64_t H, W;
+    double discount;
+    int32_t iterations;
+    int32_t reserved;
+    int64_t h_offset, w_offset, weight_offset; /* blob offsets of the int64 / int64 / float tables (`iterations` entries each) */
+} sonar_plan_levels;
+/* index of a replayable entry point (one that only launches on its last argument, the stream) or -1; its argument count */
+int sonar_plan_fn_id(const char* name);
+int sonar_plan_fn_nargs(int fn_id);
+sonar_plan* sonar_plan_create(int nslots);
+void sonar_plan_destroy(sonar_plan* plan);
+int sonar_plan_length(const sonar_plan* plan);
+/* append one call: `args` = one 64-bit word per argument (integers sign-extended, float / double bit patterns, addresses), `blob` = bytes
+ * the arguments point into (copied), `patches` = what sonar_plan_run rewrites before the call (the last argument, the stream, always is) */
+int sonar_plan_add(sonar_plan* plan, int fn_id, const uint64_t* args, int nargs, const void* blob, int64_t blob_bytes,
+                   const sonar_plan_patch* patches, int npatches);
+/* issue every record on `stream`; stops at the first entry point that fails and returns its code (`failed_record`, nullable: its index,
+ * -1 when all ran; sonar_last_error() is that entry point's message) */
+int sonar_plan_run(sonar_plan* plan, const uint64_t* slots, int nslots, uint64_t seed, uint64_t stream_base, void* stream,
+                   int* failed_record);
+/* the level sizes and weights of a device-mode pyramid draw (py/noise_generation.py:609-649: r = rand * 2 + 2 per level from a host
+ * splitmix64 sequence keyed by (seed, stream_id)); returns the level count.  Pure host arithmetic. */
+int sonar_pyramid_levels(int64_t H, int64_t W, int iterations, double discount, uint64_t seed, uint64_t stream_id, int64_t* level_h,
+                         int64_t* level_w, float* weight);
+
 #ifdef __cplusplus
 }
 #endif
