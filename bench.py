@@ -123,6 +123,22 @@ def event_us(fn, steps=20, warmup=5):
     return e0.elapsed_time(e1) / steps * 1e3
 
 
+def host_and_event_us(fn, steps=200, warmup=100):
+    """(host issue time per call, GPU span per call) in microseconds: what a launch-bound step costs on either side."""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    host = (time.perf_counter() - t0) / steps * 1e6
+    e1.record()
+    torch.cuda.synchronize()
+    return host, e0.elapsed_time(e1) / steps * 1e3
+
+
 def traffic_table() -> dict:
     if os.path.exists(TRAFFIC_FILE):
         with open(TRAFFIC_FILE) as fh:
@@ -167,6 +183,28 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
         chain3.add(nz.CustomNoiseItem(0.5, noise_type="pyramid"))
         ns3 = chain3.make_noise_sampler(xb, 0.03, 14.6, seed=None, cpu=False, normalized=True)
         extra[f"cfg3_chain_{tag}_latents_per_s"] = xb.shape[0] / (event_us(lambda: ns3(*sig), 30, 10) * 1e-6)
+    # the configurations as BASELINE.json writes them and as a ComfyUI run calls them: cfg2 at 1 and 4 latents, cfg3's chain at 4 --
+    # launch-bound steps, so the host's issue time per call stands beside the GPU's (prepared plans: one foreign call per step)
+    for tag, bsz in (("b1", 1), ("b4", 4)):
+        xs_ = torch.zeros((bsz, C, H, W), device=device)
+        item = power_item(pn)
+        ns_small = item.make_noise_sampler(xs_, None, None, seed=None, cpu=False, normalized=True)
+        host, gpu = host_and_event_us(lambda: ns_small(*sig))
+        extra[f"power_noise_{tag}_us"] = gpu
+        extra[f"power_noise_{tag}_host_us_per_call"] = host
+    for tag, xb in (("b4", torch.zeros((4, C, H, W), device=device)), ("b64", x64)):
+        chain3 = nz.CustomNoiseChain()
+        chain3.add(nz.CustomNoiseItem(0.5, noise_type="perlin"))
+        chain3.add(nz.CustomNoiseItem(0.5, noise_type="pyramid"))
+        ns3 = chain3.make_noise_sampler(xb, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+        host, gpu = host_and_event_us(lambda: ns3(*sig))
+        extra[f"cfg3_chain_{tag}_us"] = gpu
+        extra[f"cfg3_chain_{tag}_host_us_per_call"] = host
+    for name in ("perlin", "pyramid"):
+        ns1 = nz.get_noise_sampler(name, x64, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+        host, gpu = host_and_event_us(lambda: ns1(*sig))
+        extra[f"{name}_b64_us"] = gpu
+        extra[f"{name}_b64_host_us_per_call"] = host
     # momentum step (row M): 3 reads + 2 writes
     sonar = importlib.import_module("comfyui_sonar_amd.py.sonar")
     sb = sonar.SonarBase(sonar.SonarBase.get_config(None, {}))
@@ -417,6 +455,16 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         ev1.record()
+        # the cold figure (what `--prewarm 0` measures): W + K steps from an idle GPU, before the clock ramp below
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(args.steps):
+            step()
+        ev1.record()
+        torch.cuda.synchronize()
+        cold_us = ev0.elapsed_time(ev1) / args.steps * 1e3
         for _ in range(max(args.prewarm, 0)):  # clock ramp, outside the W + K steps of the contract
             step()
         torch.cuda.synchronize()
@@ -485,6 +533,7 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.no_extra:
         kernels, extra = secondary_rows(device, hl, pn, ng, nz, x, sig)
         ns_two = make_sampler(False)
+        extra["power_noise_cold_us"] = cold_us
         extra["power_noise_two_launch_us"] = event_us(lambda: ns_two(*sig), 100, 300)
         ns_one = make_sampler(True)
         extra["power_noise_lookahead_us"] = event_us(lambda: ns_one(*sig), 100, 300)

@@ -1,0 +1,279 @@
+"""-m gpu, round 4: prepared call plans (include/sonar_hip.h "prepared call plans") -- a replayed step is the ordinary step bit for bit,
+and every condition under which a plan must stand aside hands the call back to the ordinary path."""
+import importlib
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIG = (torch.tensor(14.6), torch.tensor(10.0))
+
+
+@pytest.fixture(scope="module")
+def api(pkg):
+    pkg.hip_lib.load()
+    return types.SimpleNamespace(hl=pkg.hip_lib, pn=importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise"),
+                                 nz=importlib.import_module("comfyui_sonar_amd.py.noise"),
+                                 ng=importlib.import_module("comfyui_sonar_amd.py.noise_generation"))
+
+
+def _power(api, factor=1.0):
+    return api.pn.PowerNoiseItem(factor, time_brownian=False, alpha=1.0, max_freq=0.7071, min_freq=0.0, stretch=1.0, rotate=0.0, pnorm=2.0, mix=1.0,
+                                 common_mode=0.0, channel_correlation="1,1,1,1,1,1")
+
+
+def _maker(api, x, what, normalized=True):
+    nz = api.nz
+    if what == "power":
+        return lambda: _power(api).make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=normalized)
+    if what.startswith("chain:"):
+        def make():
+            chain = nz.CustomNoiseChain()
+            for part in what[6:].split("+"):
+                name, factor = part.split("*")
+                chain.add(_power(api, float(factor)) if name == "power" else nz.CustomNoiseItem(float(factor), noise_type=name))
+            return chain.make_noise_sampler(x, 0.03, 14.6, seed=None, cpu=False, normalized=normalized)
+        return make
+    return lambda: nz.get_noise_sampler(what, x, 0.03, 14.6, seed=None, cpu=False, normalized=normalized, factor=1.0 if normalized else 0.7)
+
+
+def _planned(api, ns):
+    return ns if isinstance(ns, api.hl.Planned) else getattr(ns, "_planned", None)
+
+
+def _run(api, ns, calls, plans, seed=4321, fn=None):
+    hl = api.hl
+    old = hl.PLANS_ENABLED
+    hl.PLANS_ENABLED = plans
+    try:
+        torch.manual_seed(seed)
+        out = []
+        for _ in range(calls):
+            res = (fn or ns)(*SIG)
+            res = res if isinstance(res, tuple) else (res,)
+            out.append(tuple(None if t is None else t.clone() for t in res) + (getattr(res[0], hl.STATS_ATTR, None) is not None,))
+        return out
+    finally:
+        hl.PLANS_ENABLED = old
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(
+        len(p) == len(q) and all((u is None and v is None) or (isinstance(u, bool) and u == v) or (torch.is_tensor(u) and torch.equal(u, v))
+                                 for u, v in zip(p, q)) for p, q in zip(a, b))
+
+
+CASES = ["gaussian", "uniform", "perlin", "pyramid", "pyramid_area", "power", "chain:perlin*0.5+pyramid*0.5", "chain:gaussian*0.6+perlin*0.4",
+         "chain:power*0.5+perlin*0.3+gaussian*0.2", "chain:pyramid*1.0", "chain:uniform*0.3+pyramid*0.7"]
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 128, 128), (3, 4, 128, 128), (64, 4, 128, 128), (2, 16, 64, 64), (2, 4, 3, 64, 64)])
+@pytest.mark.parametrize("what", CASES)
+@pytest.mark.parametrize("normalized", [True, False])
+def test_a_replayed_step_is_the_ordinary_step(api, shape, what, normalized):
+    """Nine calls with plans (two ordinary, one traced, six replayed) == nine ordinary calls from the same RNG position: tensors, the
+    statistics tags on them, and the (tensor, decision) pairs of the chains' deferred form."""
+    if len(shape) == 5 and "power" in what:
+        pytest.skip("video latents: the power item's planes are not [B, C*F] planes of the other generators")
+    x = torch.zeros(shape, device="cuda")
+    make = _maker(api, x, what, normalized)
+    a, b = make(), make()
+    assert _same(_run(api, a, 9, True), _run(api, b, 9, False))
+    planned = _planned(api, a)
+    assert planned is not None and planned.plan is not None, getattr(planned, "reason", "no Planned wrapper")
+    assert planned.plan.runs == 6
+    if hasattr(a, "deferred"):
+        assert _same(_run(api, a, 7, True, fn=a.deferred), _run(api, b, 7, False, fn=b.deferred))
+        assert a.deferred.plan is not None and a.deferred.plan.runs == 4
+
+
+def test_plans_follow_the_rng_position(api):
+    """A reseed, a draw by somebody else and torch.cuda.set_rng_state move the stream ids of the next call: the replay takes its ids from
+    the same generator state as the ordinary path."""
+    x = torch.zeros((4, 4, 128, 128), device="cuda")
+    for what in ("chain:perlin*0.5+pyramid*0.5", "power", "pyramid"):
+        make = _maker(api, x, what)
+
+        def script(ns, plans):
+            api.hl.PLANS_ENABLED = plans
+            try:
+                got = []
+                torch.manual_seed(9)
+                for i in range(12):
+                    if i == 5:
+                        torch.manual_seed(10)
+                    if i == 7:
+                        torch.randn(3, device="cuda")  # another consumer of the device generator
+                    if i == 9:
+                        state = torch.cuda.get_rng_state()
+                    if i == 11:
+                        torch.cuda.set_rng_state(state)
+                    got.append(ns(*SIG).clone())
+                return got
+            finally:
+                api.hl.PLANS_ENABLED = True
+
+        a, b = make(), make()
+        ra, rb = script(a, True), script(b, False)
+        assert all(torch.equal(p, q) for p, q in zip(ra, rb)), what
+        assert torch.equal(ra[9], ra[11])
+        assert _planned(api, a).plan.runs >= 6
+
+
+def test_a_plan_stands_aside_when_its_guards_change(api):
+    """Another shard position, another factor, plans switched off: the call is the ordinary path's (and still right)."""
+    hl, ng, nz = api.hl, api.ng, api.nz
+    x = torch.zeros((4, 4, 128, 128), device="cuda")
+    ns = nz.get_noise_sampler("perlin", x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+    ref = nz.get_noise_sampler("perlin", x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+    torch.manual_seed(1)
+    for _ in range(5):
+        ns(*SIG)
+    plan = ns._planned.plan
+    assert plan is not None and plan.runs == 2
+    with ng.shard_offset(8):
+        torch.manual_seed(2)
+        got = ns(*SIG).clone()
+        assert plan.runs == 2  # guard: the traced call sat at shard offset 0
+        old, hl.PLANS_ENABLED = hl.PLANS_ENABLED, False
+        torch.manual_seed(2)
+        want = ref(*SIG).clone()
+        hl.PLANS_ENABLED = old
+    assert torch.equal(got, want)
+    ns(*SIG)
+    assert plan.runs == 3
+    ns.factor = 0.5
+    torch.manual_seed(3)
+    got = ns(*SIG).clone()
+    assert plan.runs == 3
+    ref.factor = 0.5
+    hl.PLANS_ENABLED = False
+    torch.manual_seed(3)
+    want = ref(*SIG).clone()
+    hl.PLANS_ENABLED = True
+    assert torch.equal(got, want)
+
+
+def test_a_refused_replay_rewinds_the_generator_and_takes_the_ordinary_path(api, monkeypatch):
+    """An entry point that answers SONAR_ERR_UNSUPPORTED inside sonar_plan_run (a level table the plane kernel cannot hold, say): the step
+    is issued again by the ordinary path from the SAME stream ids."""
+    hl = api.hl
+    x = torch.zeros((2, 4, 128, 128), device="cuda")
+    make = _maker(api, x, "chain:perlin*0.5+pyramid*0.5")
+    a, b = make(), make()
+    want = _run(api, b, 8, False)
+    real = hl._lib
+    calls = {"n": 0}
+
+    class Lib:
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def sonar_plan_run(self, *args):
+            calls["n"] += 1
+            if calls["n"] in (2, 3):
+                return hl.ERR_UNSUPPORTED
+            return real.sonar_plan_run(*args)
+
+    monkeypatch.setattr(hl, "_lib", Lib())
+    got = _run(api, a, 8, True)
+    assert calls["n"] == 5 and _same(got, want)
+
+
+def test_a_failing_replay_raises(api, monkeypatch):
+    hl = api.hl
+    x = torch.zeros((2, 4, 128, 128), device="cuda")
+    ns = _maker(api, x, "gaussian")()
+    for _ in range(4):
+        ns(*SIG)
+    real = hl._lib
+
+    class Lib:
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def sonar_plan_run(self, *args):
+            return hl.ERR_ARG
+
+    monkeypatch.setattr(hl, "_lib", Lib())
+    with pytest.raises(hl.SonarHipError, match="sonar_plan_run"):
+        ns(*SIG)
+
+
+def test_plans_keep_their_scratch_per_stream(api):
+    """The same sampler called from two HIP streams in turn: each stream has its own scratch tensors (partials, lattice), the power item's
+    look-ahead statistics are only trusted on the stream that wrote them -- and the values do not care."""
+    x = torch.zeros((8, 4, 128, 128), device="cuda")
+    side = torch.cuda.Stream()
+    for what in ("chain:perlin*0.5+pyramid*0.5", "power"):
+        make = _maker(api, x, what)
+        a, b = make(), make()
+        want = [t[0] for t in _run(api, b, 10, False)]
+        torch.manual_seed(4321)
+        got = []
+        for i in range(10):
+            if i % 3 == 2:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    got.append(a(*SIG).clone())
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                got.append(a(*SIG).clone())
+        torch.cuda.synchronize()
+        assert all(torch.equal(p, q) for p, q in zip(got, want)), what
+        plan = _planned(api, a).plan
+        assert plan is not None and len(plan.by_stream) == 2
+
+
+def test_steps_that_depend_on_their_arguments_are_not_planned(api):
+    """Brownian noise (a function of the two sigmas), replay-mode generators (host draws) and scheduled noise keep the ordinary path."""
+    nz, hl = api.nz, api.hl
+    x = torch.zeros((2, 4, 64, 64), device="cuda")
+    chain = nz.CustomNoiseChain()
+    chain.add(nz.CustomNoiseItem(0.5, noise_type="perlin"))
+    chain.add(nz.CustomNoiseItem(0.5, noise_type="brownian"))
+    ns = chain.make_noise_sampler(x, 0.03, 14.6, seed=3, cpu=False, normalized=True)
+    assert not isinstance(ns, hl.Planned)
+    replay = nz.get_noise_sampler("perlin", x, 0.03, 14.6, seed=None, cpu=True, normalized=True)
+    assert replay._planned is None
+    sched = nz.CustomNoiseChain()
+    inner = nz.CustomNoiseChain()
+    inner.add(nz.CustomNoiseItem(1.0, noise_type="gaussian"))
+    sched.add(nz.ScheduledNoise(1.0, noise=inner, start_sigma=20.0, end_sigma=0.0, normalize=None, fallback_noise=None))
+    assert not isinstance(sched.make_noise_sampler(x, 0.03, 14.6, seed=None, cpu=False, normalized=True), hl.Planned)
+
+
+def test_trace_refuses_what_it_cannot_replay(api):
+    """A step that calls an entry point outside the replayable set, or hands a kernel an address nobody accounts for, gets no plan (and
+    its traced call is still an ordinary, correct call)."""
+    hl, ng = api.hl, api.ng
+    x = torch.zeros((2, 4, 64, 64), device="cuda")
+
+    def with_readback(_s, _sn):
+        t = hl.philox_normal((2, 4, 64, 64), "cuda", *ng.DeviceRNG.take())
+        hl.max_to_host(t)
+        return t
+
+    res, plan = hl.trace_plan(with_readback, SIG, take=ng.DeviceRNG.take, rewind=ng.DeviceRNG.rewind, guards=())
+    assert plan is None and "not replayable" in hl.trace_plan.last_reason and res.shape == x.shape
+    hidden = torch.zeros(2 * 4 * 64 * 64, device="cuda")
+
+    def with_hidden_buffer(_s, _sn):
+        lib = hl.load()
+        seed, stream = ng.DeviceRNG.take()
+        hl._check(lib.sonar_philox_normal_f32(hidden.data_ptr(), hidden.numel(), seed, stream, 0, None, hl._stream()), "fill")
+        return hidden
+
+    res, plan = hl.trace_plan(with_hidden_buffer, SIG, take=ng.DeviceRNG.take, rewind=ng.DeviceRNG.rewind, guards=())
+    assert plan is None and "no tensor the trace knows" in hl.trace_plan.last_reason
+    keep = []
+
+    def with_escaping_scratch(_s, _sn):
+        t = hl.philox_normal((2, 4, 64, 64), "cuda", *ng.DeviceRNG.take())
+        keep.append(hl.stats(t))  # the partials outlive the call without being its result
+        return t
+
+    res, plan = hl.trace_plan(with_escaping_scratch, SIG, take=ng.DeviceRNG.take, rewind=ng.DeviceRNG.rewind, guards=())
+    assert plan is None and "outlives" in hl.trace_plan.last_reason
