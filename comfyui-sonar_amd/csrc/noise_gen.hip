@@ -9,6 +9,13 @@ namespace sonar {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+#ifdef SONAR_NG_TRACE  // profiling builds: cycle stamps of thread 0 of the first 256 workgroups at the phase boundaries (scratch/ng_trace.py)
+__device__ unsigned long long g_ng_trace[256 * 16];
+#define SONAR_NG_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_ng_trace[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SONAR_NG_STAMP(slot) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Draw loop shared by every generator: one wave per tile (common.h: kTileElems elements), each lane
 // runs its own Philox-seeded xoshiro128++ burst and hands 4 consecutive elements per step to `f`.
@@ -850,6 +857,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                                                                double* partials, int grid_floats, Accum fold, Prefix pre) {
     extern __shared__ __align__(16) float pyr_lds[];
     __shared__ double red[2 * kPyrBlock / 64];
+    SONAR_NG_STAMP(0);
     double s = 0.0, q = 0.0;
     const int HW = H * W;
     const uint32_t lane = threadIdx.x & 63;
@@ -893,8 +901,10 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
             }
         }
     }
+    SONAR_NG_STAMP(1);
     for (int64_t p = blockIdx.x; p < planes; p += gridDim.x) {
         __syncthreads();
+        SONAR_NG_STAMP(2);
         int off = 0;
         for (int l = 0; l < lv.count; ++l) {
             const int n = lv.h[l] * lv.w[l];
@@ -913,7 +923,9 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
             }
             off += n;
         }
+        SONAR_NG_STAMP(3);
         __syncthreads();
+        SONAR_NG_STAMP(4);
         if constexpr (XROWS) {
             int go = 0, ro = 0;
             for (int l = 0; l < lv.count; ++l) {
@@ -936,8 +948,10 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                 go += h * w;
                 ro += h * W;
             }
+            SONAR_NG_STAMP(5);
             __syncthreads();
         }
+        SONAR_NG_STAMP(6);
         float* const oplane = out + p * (int64_t)HW;
         const Accum pfold{fold.y, pre.ya, pre.f};
         const Divider pdiv(PRE == 2 ? pre.div_fac : 1.0f);
@@ -961,6 +975,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                 rng.next();
                 if constexpr (PRE != 0) prng.next();
             }
+            SONAR_NG_STAMP(7);
             // element index inside the plane; < 0 or >= HW: not ours
             int e = (int)(t * kTileElems - g0) + (int)lane * 4 + part * kIters * 256;
             int y = e >= 0 ? e / W : -((-e + W - 1) / W);        // floor
@@ -1042,7 +1057,9 @@ SONAR_PYR_UNROLL
             }
         }
     }
+    SONAR_NG_STAMP(8);
     if constexpr (STATS) write_partial<kPyrBlock>(s, q, partials, red);
+    SONAR_NG_STAMP(9);
 }
 
 // true if the plane kernel was launched
@@ -1725,3 +1742,9 @@ extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, in
                        (int)W, lv, mode, seed, stream_id, elem_offset, nullptr, na);
     return check_launch("sonar_pyramid_noise_f32");
 }
+
+#ifdef SONAR_NG_TRACE
+extern "C" int sonar_debug_ng_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sonar::g_ng_trace), sizeof(sonar::g_ng_trace));
+}
+#endif

@@ -84,7 +84,7 @@ def test_a_replayed_step_is_the_ordinary_step(api, shape, what, normalized):
     planned = _planned(api, a)
     assert planned is not None and planned.plan is not None, getattr(planned, "reason", "no Planned wrapper")
     assert planned.plan.runs == 6
-    if hasattr(a, "deferred"):
+    if isinstance(getattr(a, "deferred", None), api.hl.Planned):
         assert _same(_run(api, a, 7, True, fn=a.deferred), _run(api, b, 7, False, fn=b.deferred))
         assert a.deferred.plan is not None and a.deferred.plan.runs == 4
 
