@@ -1,0 +1,434 @@
+// WaveletCFG's transform-domain step with ANY per-level, per-orientation band scales, in ONE launch with the coefficients in LDS
+// (py/wavelet_cfg.py:750-791, py/wavelet_functions.py:193-238: yl *= l; yh[j][:, :, k] *= s_jk; inverse).
+//
+// The scaled reconstruction of one tensor v is linear, and with perfect reconstruction along each axis (S_lo A_lo + S_hi A_hi = I,
+// the same wavelet both ways) two of a level's three detail bands never have to be formed.  With X = LL_{j-1} (X = v for j = 1),
+// lowW = A^W_lo X, LL_j = A^H_lo lowW, cH = A^H_hi lowW, cV = A^H_lo A^W_hi X, cD = A^H_hi A^W_hi X and scales (a_h, a_v, a_d):
+//     S^H_hi cH = lowW - S^H_lo LL_j,   S^H_hi cD = highW - S^H_lo cV,   S^W_hi highW = X - S^W_lo lowW
+//     R_{j-1} = a_d X + S^W_lo[ (a_h - a_d) lowW + S^H_lo (R_j - a_h LL_j) ] + S^W_hi[ (a_v - a_d) S^H_lo cV ],   R_J = l LL_J
+// so a level keeps LL_j and ONE band, cV_j (nothing when a_v == a_d: with one scale per level this is dwt_lowpass.h's pyramid), and
+// lowW is one filter pass over a row of the plane below, recomputed on the way up.  For a 128 x 128 plane and db4 that is 2 (67^2 + 37^2 +
+// 22^2 + 14^2 + 10^2) values: 53 KB in fp32 (two workgroups per CU), 106 KB in fp64 (one 1024-thread workgroup per CU).  The bands never
+// cross HBM: the tensors are read (cond and uncond twice: the level-1 analysis, then the output rows) and the result is written --
+// where the three band kernels of dwt_tile.h moved 2.5-3.85 x the 16N bytes of the step.
+//   difference-only rules (cond / uncond / final scales all 1):  out = x - (ku u + kt Phi_D(c - u))           one launch
+//   any other linear rule: blend(s_u U, s_d (s_c C - s_u U), t) s_f = A C + B U per band:                      two launches,
+//       out1 = x - Phi_B(u), out = out1 - Phi_A(c)   (b == nullptr: v = a)
+#pragma once
+#include "dwt_lowpass.h"
+
+namespace sonar {
+
+template <typename T>
+struct BandsArgs {
+    int64_t planes;
+    int levels;
+    int H[kLowMaxLevels + 1], W[kLowMaxLevels + 1];  // [0]: the latent plane; [j]: coefficient plane of level j
+    int off_ll[kLowMaxLevels + 1];                    // LDS offsets (elements of T) of LL_j
+    int off_v[kLowMaxLevels + 1];                     // ... of cV_j (low H, high W); unused when av == ad at that level
+    int off_tmp;                                      // scratch (elements of T)
+    int off_tmp1, rows1;                              // level-1 analysis scratch (overlays the deeper levels and the scratch), its tile height
+    int rows_up[kLowMaxLevels + 1];                   // rows of level j - 1 per tile of the way up from level j (even)
+    int rows_out;                                     // output rows per tile of the last stage (even)
+    int off_cu;                                       // byte offset of the staged (a, b) rows of the last stage
+    int off_maps;                                     // byte offset of the extension tables
+    int map_h[kLowMaxLevels + 1], map_w[kLowMaxLevels + 1];
+    T ah[kLowMaxLevels + 1], av[kLowMaxLevels + 1], ad[kLowMaxLevels + 1];  // [1 .. J]: scales of cH, cV, cD
+    T yl;                                             // scale of the approximation
+    T ku, kt;                                         // result = ku b + kt Phi(v)
+    int subtract_from_x, mode_fwd, mode_inv;
+    TapsSmall<T> dec, rec;
+};
+
+template <int NT>
+struct WalkN {
+    int r, c, dr, dc;
+    __device__ __forceinline__ WalkN(int tid, int cols) : r(tid / cols), c(tid - (tid / cols) * cols), dr(NT / cols), dc(NT - (NT / cols) * cols) {}
+    __device__ __forceinline__ void next(int cols) {
+        r += dr;
+        c += dc;
+        if (c >= cols) {
+            c -= cols;
+            r += 1;
+        }
+    }
+};
+
+// TIO: the tensors' element type -- float (the latents) or T (a coefficient plane in the band kernels' workspace: the deeper levels of
+// sonar_wcfg_fused_* run through this kernel with the level-1 approximation as their "latent")
+template <typename TIO>
+struct alignas(2 * sizeof(TIO)) Pair2 {
+    TIO x, y;
+};
+
+template <typename T, typename TIO, int FT, int NT>
+__global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ ta, const TIO* __restrict__ tb, const TIO* xin, TIO* out,
+                                                        BandsArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char bands_smem[];
+    T* const lds = reinterpret_cast<T*>(bands_smem);
+    int* const maps = reinterpret_cast<int*>(bands_smem + a.off_maps);
+    using In2 = Pair2<TIO>;
+    In2* const cu = reinterpret_cast<In2*>(bands_smem + a.off_cu);
+    T* const tmp = lds + a.off_tmp;
+    const int tid = threadIdx.x;
+    const int J = a.levels;
+    // extension tables, the same for every plane: tap j of output i reads table[2 i + F - 1 - j] (source index, -1 = implicit zero)
+    for (int j = 1; j <= J; ++j) {
+        const int off = a.mode_fwd == kPeriodization ? FT / 2 : 1;
+        const int Hp = a.H[j - 1], Wp = a.W[j - 1];
+        const int He = (a.mode_fwd == kPeriodization && (Hp & 1)) ? Hp + 1 : Hp, We = (a.mode_fwd == kPeriodization && (Wp & 1)) ? Wp + 1 : Wp;
+        for (int i = tid; i < 2 * a.H[j] + FT - 2; i += NT) maps[a.map_h[j] + i] = src_index(i + off - (FT - 1), Hp, He, a.mode_fwd);
+        for (int i = tid; i < 2 * a.W[j] + FT - 2; i += NT) maps[a.map_w[j] + i] = src_index(i + off - (FT - 1), Wp, We, a.mode_fwd);
+    }
+    const int H = a.H[0], W = a.W[0], h1 = a.H[1], w1 = a.W[1];
+    const int Wh = (W + 1) >> 1, Ws = 2 * Wh;  // parity-split row of the level-1 scratch: slot(x) = (x & 1) Wh + x / 2
+    for (int64_t p = blockIdx.x; p < a.planes; p += gridDim.x) {
+        const TIO* pa = ta + p * (int64_t)H * W;
+        const TIO* pb = tb ? tb + p * (int64_t)H * W : nullptr;
+        __syncthreads();  // tables are built; the previous plane's readers are done
+        // ---------------------------------------------------------------- level 1 down: v = a - b from global, along H in registers, along W out of LDS
+        {
+            T* const ll1 = lds + a.off_ll[1];
+            T* const cv1 = lds + a.off_v[1];
+            const bool want_v = a.av[1] != a.ad[1];
+            const int* const ymap = maps + a.map_h[1];
+            const int* const xmap = maps + a.map_w[1];
+            constexpr int THS = 4, NRS = 2 * THS + FT - 2;
+            T* const tmp1 = lds + a.off_tmp1;
+            for (int y0 = 0; y0 < h1; y0 += a.rows1) {
+                const int th = min(a.rows1, h1 - y0);
+                for (WalkN<NT> wk(tid, W); wk.r * THS < th; wk.next(W)) {
+                    const int sub = wk.r, x = wk.c;
+                    T v[NRS];
+#pragma unroll
+                    for (int r = 0; r < NRS; ++r) {
+                        const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h1 + FT - 3)];
+                        const int at = max(sy, 0) * W + x;
+                        const T d = pb ? (T)pa[at] - (T)pb[at] : (T)pa[at];
+                        v[r] = sy >= 0 ? d : T(0);
+                    }
+                    T* dst = tmp1 + (x & 1) * Wh + (x >> 1);
+#pragma unroll
+                    for (int yl = 0; yl < THS; ++yl) {
+                        T lo = T(0);
+#pragma unroll
+                        for (int j = 0; j < FT; ++j) lo = fma_t(a.dec.lo[j], v[2 * yl + FT - 1 - j], lo);
+                        if (sub * THS + yl < th) dst[(sub * THS + yl) * Ws] = lo;
+                    }
+                }
+                __syncthreads();
+                for (WalkN<NT> wk(tid, w1); wk.r < th; wk.next(w1)) {
+                    const int yl = wk.r, xo = wk.c;
+                    const T* row = tmp1 + yl * Ws;
+                    const int* xm = xmap + 2 * xo + (FT - 1);
+                    T lo = T(0), hi = T(0);
+#pragma unroll
+                    for (int j = 0; j < FT; ++j) {
+                        const int sx = xm[-j];
+                        const T q0 = row[sx >= 0 ? (sx & 1) * Wh + (sx >> 1) : 0];
+                        const T q = sx >= 0 ? q0 : T(0);
+                        lo = fma_t(a.dec.lo[j], q, lo);
+                        hi = fma_t(a.dec.hi[j], q, hi);
+                    }
+                    ll1[(y0 + yl) * w1 + xo] = lo;
+                    if (want_v) cv1[(y0 + yl) * w1 + xo] = hi;
+                }
+                __syncthreads();
+            }
+        }
+        // ---------------------------------------------------------------- deeper levels down: LL_j, cV_j from LL_{j-1}, all in LDS
+        for (int j = 2; j <= J; ++j) {
+            const int Wp = a.W[j - 1], h = a.H[j], w = a.W[j];
+            const T* const src = lds + a.off_ll[j - 1];
+            T* const dll = lds + a.off_ll[j];
+            T* const dcv = lds + a.off_v[j];
+            const bool want_v = a.av[j] != a.ad[j];
+            const int* const ymap = maps + a.map_h[j];
+            const int* const xmap = maps + a.map_w[j];
+            for (WalkN<NT> wk(tid, Wp); wk.r < h; wk.next(Wp)) {   // along H (low)
+                const int yo = wk.r, x = wk.c;
+                const int* ym = ymap + 2 * yo + (FT - 1);
+                T acc = T(0);
+#pragma unroll
+                for (int t = 0; t < FT; ++t) {
+                    const int sy = ym[-t];
+                    const T q = src[max(sy, 0) * Wp + x];
+                    acc = fma_t(a.dec.lo[t], sy >= 0 ? q : T(0), acc);
+                }
+                tmp[yo * Wp + x] = acc;
+            }
+            __syncthreads();
+            for (WalkN<NT> wk(tid, w); wk.r < h; wk.next(w)) {    // along W (low and high)
+                const int yo = wk.r, xo = wk.c;
+                const int* xm = xmap + 2 * xo + (FT - 1);
+                const T* row = tmp + yo * Wp;
+                T lo = T(0), hi = T(0);
+#pragma unroll
+                for (int t = 0; t < FT; ++t) {
+                    const int sx = xm[-t];
+                    const T q0 = row[max(sx, 0)];
+                    const T q = sx >= 0 ? q0 : T(0);
+                    lo = fma_t(a.dec.lo[t], q, lo);
+                    hi = fma_t(a.dec.hi[t], q, hi);
+                }
+                dll[yo * w + xo] = lo;
+                if (want_v) dcv[yo * w + xo] = hi;
+            }
+            __syncthreads();
+        }
+        // ---------------------------------------------------------------- top: B_J = (l - a_h^J) LL_J
+        {
+            T* const top = lds + a.off_ll[J];
+            const T gJ = a.yl - a.ah[J];
+            for (int it = tid; it < a.H[J] * a.W[J]; it += NT) top[it] *= gJ;
+            __syncthreads();
+        }
+        // ---------------------------------------------------------------- way up: B_{j-1} = (a_d^j - a_h^{j-1}) LL_{j-1} + S^W_lo[(a_h - a_d) lowW + S^H_lo B_j] + S^W_hi[(a_v - a_d) S^H_lo cV_j]
+        for (int j = J; j >= 2; --j) {
+            const int h = a.H[j], w = a.W[j], Ho = a.H[j - 1], Wo = a.W[j - 1];
+            const T* const B = lds + a.off_ll[j];
+            const T* const V = lds + a.off_v[j];
+            T* const dst = lds + a.off_ll[j - 1];
+            const int* const xmap = maps + a.map_w[j];
+            const T c_low = a.ah[j] - a.ad[j], c_v = a.av[j] - a.ad[j], c_x = a.ad[j] - a.ah[j - 1];
+            const bool want_v = a.av[j] != a.ad[j];
+            const int wp = (Wo + 1) >> 1;
+            T* const tA = tmp;
+            T* const tB = tmp + a.rows_up[j] * w;
+            for (int ya = 0; ya < Ho; ya += a.rows_up[j]) {
+                const int th = min(a.rows_up[j], Ho - ya);
+                for (WalkN<NT> wk(tid, w); 2 * wk.r < th; wk.next(w)) {   // along H: rows (2m, 2m + 1) of column xo, plus lowW of those rows
+                    const int mp = wk.r, xo = wk.c, m = (ya >> 1) + mp;
+                    T e, o, e2 = T(0), o2 = T(0);
+                    synth_low_pair<T, FT>(m, h, a.mode_inv, a.rec.lo, [&](int i) { return B[i * w + xo]; }, e, o);
+                    if (want_v) synth_low_pair<T, FT>(m, h, a.mode_inv, a.rec.lo, [&](int i) { return V[i * w + xo]; }, e2, o2);
+                    const int* xm = xmap + 2 * xo + (FT - 1);
+                    const T* r0 = dst + (ya + 2 * mp) * Wo;
+                    const bool two = 2 * mp + 1 < th;
+                    const T* r1 = two ? r0 + Wo : r0;
+                    T l0 = T(0), l1 = T(0);
+                    if (c_low != T(0)) {
+#pragma unroll
+                        for (int t = 0; t < FT; ++t) {
+                            const int sx = xm[-t];
+                            const int at = max(sx, 0);
+                            l0 = fma_t(a.dec.lo[t], sx >= 0 ? r0[at] : T(0), l0);
+                            l1 = fma_t(a.dec.lo[t], sx >= 0 ? r1[at] : T(0), l1);
+                        }
+                    }
+                    tA[(2 * mp) * w + xo] = fma_t(c_low, l0, e);
+                    tB[(2 * mp) * w + xo] = c_v * e2;
+                    if (two) {
+                        tA[(2 * mp + 1) * w + xo] = fma_t(c_low, l1, o);
+                        tB[(2 * mp + 1) * w + xo] = c_v * o2;
+                    }
+                }
+                __syncthreads();
+                for (WalkN<NT> wk(tid, wp); wk.r < th; wk.next(wp)) {    // along W: both channels, accumulate into the plane below
+                    const int yl = wk.r, m = wk.c;
+                    const T* ra = tA + yl * w;
+                    const T* rb = tB + yl * w;
+                    T e, o;
+                    if (want_v) SynthPair<T, FT>::run(m, w, a.mode_inv, a.rec, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
+                    else synth_low_pair<T, FT>(m, w, a.mode_inv, a.rec.lo, [&](int i) { return ra[i]; }, e, o);
+                    T* d = dst + (ya + yl) * Wo + 2 * m;
+                    d[0] = fma_t(c_x, d[0], e);
+                    if (2 * m + 1 < Wo) d[1] = fma_t(c_x, d[1], o);
+                }
+                __syncthreads();
+            }
+        }
+        // ---------------------------------------------------------------- level 1 up + the elementwise tail, straight to global
+        {
+            const T* const B = lds + a.off_ll[1];
+            const T* const V = lds + a.off_v[1];
+            const TIO* px = a.subtract_from_x ? xin + p * (int64_t)H * W : nullptr;
+            TIO* po = out + p * (int64_t)H * W;
+            const int* const xmap = maps + a.map_w[1];
+            const T c_low = a.ah[1] - a.ad[1], c_v = a.av[1] - a.ad[1], a_d = a.ad[1];
+            const bool want_v = a.av[1] != a.ad[1];
+            const int wp = (W + 1) >> 1;
+            T* const tA = tmp;
+            T* const tB = tmp + a.rows_out * w1;
+            for (int y0 = 0; y0 < H; y0 += a.rows_out) {
+                const int th = min(a.rows_out, H - y0);
+                // the tile's rows of (a, b): read once here, used for lowW, for a_d v and for ku b
+                for (int it = tid; it < th * W; it += NT) {
+                    const int at = y0 * W + it;
+                    cu[it] = In2{pa[at], pb ? pb[at] : TIO(0)};
+                }
+                __syncthreads();
+                for (WalkN<NT> wk(tid, w1); 2 * wk.r < th; wk.next(w1)) {
+                    const int mp = wk.r, xo = wk.c, m = (y0 >> 1) + mp;
+                    T e, o, e2 = T(0), o2 = T(0);
+                    synth_low_pair<T, FT>(m, h1, a.mode_inv, a.rec.lo, [&](int i) { return B[i * w1 + xo]; }, e, o);
+                    if (want_v) synth_low_pair<T, FT>(m, h1, a.mode_inv, a.rec.lo, [&](int i) { return V[i * w1 + xo]; }, e2, o2);
+                    const int* xm = xmap + 2 * xo + (FT - 1);
+                    const bool two = 2 * mp + 1 < th;
+                    const In2* r0 = cu + (2 * mp) * W;
+                    const In2* r1 = two ? r0 + W : r0;
+                    T l0 = T(0), l1 = T(0);
+                    if (c_low != T(0)) {
+#pragma unroll
+                        for (int t = 0; t < FT; ++t) {
+                            const int sx = xm[-t];
+                            const In2 q0 = r0[max(sx, 0)], q1 = r1[max(sx, 0)];
+                            l0 = fma_t(a.dec.lo[t], sx >= 0 ? (T)q0.x - (T)q0.y : T(0), l0);
+                            l1 = fma_t(a.dec.lo[t], sx >= 0 ? (T)q1.x - (T)q1.y : T(0), l1);
+                        }
+                    }
+                    tA[(2 * mp) * w1 + xo] = fma_t(c_low, l0, e);
+                    tB[(2 * mp) * w1 + xo] = c_v * e2;
+                    if (two) {
+                        tA[(2 * mp + 1) * w1 + xo] = fma_t(c_low, l1, o);
+                        tB[(2 * mp + 1) * w1 + xo] = c_v * o2;
+                    }
+                }
+                __syncthreads();
+                for (WalkN<NT> wk(tid, wp); wk.r < th; wk.next(wp)) {
+                    const int yl = wk.r, m = wk.c;
+                    const T* ra = tA + yl * w1;
+                    const T* rb = tB + yl * w1;
+                    T e, o;
+                    if (want_v) SynthPair<T, FT>::run(m, w1, a.mode_inv, a.rec, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
+                    else synth_low_pair<T, FT>(m, w1, a.mode_inv, a.rec.lo, [&](int i) { return ra[i]; }, e, o);
+                    const int at = (y0 + yl) * W + 2 * m;
+                    const bool pair = 2 * m + 1 < W;
+                    const In2 q0 = cu[yl * W + 2 * m];
+                    const In2 q1 = pair ? cu[yl * W + 2 * m + 1] : q0;
+                    const T r0 = fma_t(a.ku, (T)q0.y, a.kt * fma_t(a_d, (T)q0.x - (T)q0.y, e));
+                    const T r1 = fma_t(a.ku, (T)q1.y, a.kt * fma_t(a_d, (T)q1.x - (T)q1.y, o));
+                    if (pair && (W & 1) == 0) {
+                        In2 res{(TIO)r0, (TIO)r1};
+                        if (px) {
+                            const In2 x2 = *reinterpret_cast<const In2*>(px + at);
+                            res = In2{x2.x - res.x, x2.y - res.y};
+                        }
+                        *reinterpret_cast<In2*>(po + at) = res;
+                    } else {
+                        po[at] = px ? px[at] - (TIO)r0 : (TIO)r0;
+                        if (pair) po[at + 1] = px ? px[at + 1] - (TIO)r1 : (TIO)r1;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// LDS plan; false when the plane's coefficients do not fit one workgroup (the caller takes the band-by-band kernels)
+template <typename T>
+static bool bands_plan(BandsArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W, int levels, int flen, int mode_fwd, int mode_inv, bool any_v,
+                       size_t io_size = sizeof(float)) {
+    if (levels < 1 || levels > kLowMaxLevels || !tile_taps_ok(flen) || flen > kDeepTaps || !dims_ok(H, W) || H > 4096 || W > 4096) return false;
+    if (flen > 2 && (mode_fwd == kPeriodization) != (mode_inv == kPeriodization)) return false;  // a shifted reconstruction: not the identity used here
+    a.levels = levels;
+    a.H[0] = (int)H;
+    a.W[0] = (int)W;
+    int at = 0, ints = 0;
+    for (int j = 1; j <= levels; ++j) {
+        a.H[j] = (int)dwt_len(a.H[j - 1], flen, mode_fwd);
+        a.W[j] = (int)dwt_len(a.W[j - 1], flen, mode_fwd);
+        const int Hr = mode_inv == kPeriodization ? 2 * a.H[j] : 2 * a.H[j] - flen + 2;
+        const int Wr = mode_inv == kPeriodization ? 2 * a.W[j] : 2 * a.W[j] - flen + 2;
+        if (Hr < a.H[j - 1] || Wr < a.W[j - 1]) return false;  // the inverse cannot cover the level below
+        a.off_ll[j] = at;
+        at += a.H[j] * a.W[j];
+        a.off_v[j] = at;
+        if (any_v) at += a.H[j] * a.W[j];
+        a.map_h[j] = ints;
+        ints += 2 * a.H[j] + flen;
+        a.map_w[j] = ints;
+        ints += 2 * a.W[j] + flen;
+    }
+    // scratch: the deeper levels' H pass (h_j x W_{j-1}), the way up's two channel planes per row tile, the last stage's two channel planes
+    const size_t budget = 158 * 1024;
+    const int resident = at;
+    auto layout = [&](int rows_out) {
+        int tmp = std::max(rows_out * 2 * a.W[1], kLowRows * 2 * (((int)W + 1) / 2));
+        for (int j = 2; j <= levels; ++j) tmp = std::max(tmp, a.H[j] * a.W[j - 1]);
+        for (int j = 2; j <= levels; ++j) {  // as many rows of the plane below per tile as the scratch the other phases need anyway holds
+            const int full = (a.H[j - 1] + 1) / 2 * 2;
+            a.rows_up[j] = std::max(2, std::min(full, tmp / (2 * a.W[j]) / 2 * 2));
+            tmp = std::max(tmp, a.rows_up[j] * 2 * a.W[j]);
+        }
+        a.rows_out = rows_out;
+        a.off_tmp = resident;
+        int end = resident + tmp;
+        a.off_tmp1 = levels >= 2 ? a.off_ll[2] : a.off_tmp;
+        const int ws1 = 2 * (((int)W + 1) / 2);
+        a.rows1 = std::max(kLowRows, std::min((a.H[1] + 3) / 4 * 4, (end - a.off_tmp1) / ws1 / 4 * 4));
+        end = std::max(end, a.off_tmp1 + a.rows1 * ws1);
+        a.off_cu = (int)(((size_t)end * sizeof(T) + 15) / 16 * 16);
+        a.off_maps = (int)((a.off_cu + (size_t)rows_out * (size_t)W * 2 * io_size + 15) / 16 * 16);
+        return (size_t)a.off_maps + (size_t)ints * sizeof(int);
+    };
+    auto per_cu = [](size_t bytes) { return (160 * 1024) / (bytes + 512); };
+    const size_t tall = layout(kLowRows), low = layout(kLowRows / 2);
+    lds_bytes = per_cu(low) > per_cu(tall) ? low : layout(kLowRows);  // shorter output tiles when they buy another resident workgroup
+    return lds_bytes <= budget;
+}
+
+template <typename T, typename TIO, int FT, int NT>
+static void launch_bands(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
+    auto kern = wcfg_bands_kernel<T, TIO, FT, NT>;
+    static bool raised = false;  // per instantiation: dynamic LDS above the 64 KB default needs the attribute once
+    if (lds > 64 * 1024 && !raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ta, tb, x, out, a);
+}
+
+template <typename T, typename TIO>
+static int wcfg_bands(const TIO* ta, const TIO* tb, const TIO* x, TIO* out, int64_t planes, int64_t H, int64_t W, int levels,
+                      const double* dec_lo, const double* dec_hi, const double* rec_lo, const double* rec_hi, int flen, int mode_fwd, int mode_inv,
+                      const double* yh_scales, double yl_scale, double ku, double kt, int subtract_from_x, hipStream_t st, const char* what) {
+    SONAR_REQUIRE(ta && out && (x || !subtract_from_x) && dec_lo && dec_hi && rec_lo && rec_hi && yh_scales && planes >= 0 && mode_fwd >= 0 &&
+                      mode_fwd <= 5 && mode_inv >= 0 && mode_inv <= 5,
+                  SONAR_ERR_ARG, "%s: bad argument", what);
+    SONAR_REQUIRE(levels >= 1 && levels <= kLowMaxLevels, SONAR_ERR_UNSUPPORTED, "%s: 1 .. %d levels", what, kLowMaxLevels);
+    BandsArgs<T> a{};
+    bool any_v = false;
+    for (int j = 1; j <= levels; ++j) {
+        a.ah[j] = (T)yh_scales[3 * (j - 1) + 0];
+        a.av[j] = (T)yh_scales[3 * (j - 1) + 1];
+        a.ad[j] = (T)yh_scales[3 * (j - 1) + 2];
+        any_v = any_v || a.av[j] != a.ad[j];
+    }
+    size_t lds = 0;
+    SONAR_REQUIRE(bands_plan(a, lds, H, W, levels, flen, mode_fwd, mode_inv, any_v, sizeof(TIO)), SONAR_ERR_UNSUPPORTED,
+                  "%s: the plane's coefficients do not fit in LDS (or unsupported filter length / extension pair)", what);
+    if (planes == 0) return SONAR_OK;
+    a.planes = planes;
+    a.yl = (T)yl_scale;
+    a.ku = (T)ku;
+    a.kt = (T)kt;
+    a.subtract_from_x = subtract_from_x;
+    a.mode_fwd = mode_fwd;
+    a.mode_inv = mode_inv;
+    for (int i = 0; i < kDeepTaps; ++i) {
+        a.dec.lo[i] = i < flen ? (T)dec_lo[i] : T(0);
+        a.dec.hi[i] = i < flen ? (T)dec_hi[i] : T(0);
+        a.rec.lo[i] = i < flen ? (T)rec_lo[i] : T(0);
+        a.rec.hi[i] = i < flen ? (T)rec_hi[i] : T(0);
+    }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
+    // one workgroup per CU leaves half of the SIMDs' wave slots empty at 512 threads: such planes (fp64 at SDXL size) take 1024
+    const bool wide = per_cu == 1;
+    (void)wide;
+    const int grid = (int)std::min<int64_t>(planes, (int64_t)256 * per_cu);
+    with_taps(flen, [&](auto ft) {
+        constexpr int FT = decltype(ft)::value;
+        if constexpr (std::is_same<T, double>::value && std::is_same<TIO, float>::value) {
+            if (wide) {  // whole latent planes in fp64: the only shape that leaves a CU with one workgroup
+                launch_bands<T, TIO, FT, 1024>(grid, lds, st, ta, tb, x, out, a);
+                return;
+            }
+        }
+        launch_bands<T, TIO, FT, 512>(grid, lds, st, ta, tb, x, out, a);
+    });
+    return check_launch(what);
+}
+
+}  // namespace sonar

@@ -602,6 +602,13 @@ static bool dwt2_inv_tiled(const T* ll, int ll_h, int ll_w, const T* hi, T* out,
     return true;
 }
 
+// dwt_bands.hip: levels 2 .. J with their coefficients resident in LDS (dwt_bands.h), on the level-1 approximation planes `ll`
+// [planes][H1][W1]: out <- Phi_D(ll), or acc + Phi_D(ll) when `acc` is given.  False (nothing launched): not taken.
+bool bands_deep(const float* ll, float* acc, float* out, int64_t planes, int H1, int W1, int levels, const double* dec_lo, const double* dec_hi,
+                const double* rec_lo, const double* rec_hi, int flen, int mode_fwd, int mode_inv, const double* yh_scales, double yl_scale, hipStream_t st);
+bool bands_deep(const double* ll, double* acc, double* out, int64_t planes, int H1, int W1, int levels, const double* dec_lo, const double* dec_hi,
+                const double* rec_lo, const double* rec_hi, int flen, int mode_fwd, int mode_inv, const double* yh_scales, double yl_scale, hipStream_t st);
+
 // ---- whole WaveletCFG transform-domain step (py/wavelet_cfg.py:750-791 + 729-748), `levels` launches each way
 struct WcfgPlan {
     int levels;
@@ -756,7 +763,48 @@ static int wcfg_fused(const float* cond, const float* uncond, const float* x, fl
             });
         }
     };
-    if (deep) {
+    // With a perfect-reconstruction pair the deeper levels are a LINEAR map of the level-1 approximation(s) with per-band coefficients
+    // (blend(s_u U, s_d (s_c C - s_u U), t) s_f = A C + B U), and dwt_bands.h evaluates it with the coefficients resident in LDS: no
+    // workspace round trips between the levels, a quarter of the old deep kernel's time.
+    const bool pr_pair = perfect_reconstruction && dec_len == rec_len && (dec_len == 2 || (mode_fwd == kPeriodization) == (mode_inv == kPeriodization));
+    bool deep_done = false;
+    if (deep && pr_pair && levels - 1 <= kDeepMaxLevels) {
+        const double t = strength, sign = blend_mode == SONAR_BLEND_SUBTRACT_B ? -1.0 : 1.0, keep = blend_mode == SONAR_BLEND_LERP ? 1.0 - t : 1.0;
+        double sa[3 * kMaxLevels], sb[3 * kMaxLevels];
+        for (int j = 2; j <= levels; ++j) {
+            const double* row = yh_scales + (int64_t)(j - 1) * 12;
+            for (int g = 0; g < 3; ++g) {
+                const double s_c = row[g], s_u = row[3 + g], s_d = row[6 + g], s_f = row[9 + g];
+                sa[3 * (j - 2) + g] = diff_only ? s_d : sign * t * s_d * s_c * s_f;
+                sb[3 * (j - 2) + g] = (keep - sign * t * s_d) * s_u * s_f;
+            }
+        }
+        const double yl_a = diff_only ? yl_scales[2] : sign * t * yl_scales[2] * yl_scales[0] * yl_scales[3];
+        const double yl_b = (keep - sign * t * yl_scales[2]) * yl_scales[1] * yl_scales[3];
+        T* const c1 = base + pl.off_c[1];
+        T* const r1 = base + pl.off_r[2];  // [planes][Hr[2]][Wr[2]] holds a [planes][H[1]][W[1]] image
+        // probe with the first launch; a refusal (LDS, ...) leaves the workspace untouched apart from level 1, which the old route redoes
+        launch_fwd(1);
+        if (diff_only) {
+            deep_done = bands_deep(c1, (T*)nullptr, r1, planes, pl.H[1], pl.W[1], levels - 1, dec_lo, dec_hi, rec_lo, rec_hi, dec_len, mode_fwd, mode_inv,
+                                   sa, yl_a, st);
+        } else {
+            T* const u1 = base + pl.off_u[1];
+            deep_done = bands_deep(u1, (T*)nullptr, r1, planes, pl.H[1], pl.W[1], levels - 1, dec_lo, dec_hi, rec_lo, rec_hi, dec_len, mode_fwd, mode_inv,
+                                   sb, yl_b, st) &&
+                        bands_deep(c1, r1, r1, planes, pl.H[1], pl.W[1], levels - 1, dec_lo, dec_hi, rec_lo, rec_hi, dec_len, mode_fwd, mode_inv, sa,
+                                   yl_a, st);
+        }
+        if (deep_done) {
+            ll = r1;
+            ll_h = pl.H[1];
+            ll_w = pl.W[1];
+            launch_inv(1);
+        }
+    }
+    if (deep_done) {
+        // issued above
+    } else if (deep) {
         launch_fwd(1);  // reads the fp32 inputs (cast in registers)
         DeepArgs<T> a{};
         a.planes = planes;

@@ -1533,6 +1533,7 @@ namespace {
 // one request in flight per host thread and device: the pinned word it lands in and the ticket it carries
 struct MaxSlot {
     unsigned long long* word = nullptr;
+    hipEvent_t done = nullptr;  // recorded right behind the reduction: the wait must not include what the caller queues after `begin`
     unsigned ticket = 0;
     bool pending = false;
 };
@@ -1550,9 +1551,16 @@ extern "C" int sonar_max_to_host_begin_f32(const float* x, int64_t n, void* stre
                       "sonar_max_to_host_begin_f32: pinned allocation failed");
         *s.word = 0;
     }
+    if (!s.done)
+        SONAR_REQUIRE(hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess, SONAR_ERR_HIP,
+                      "sonar_max_to_host_begin_f32: event creation failed");
     s.ticket = s.ticket + 1 ? s.ticket + 1 : 1;  // never 0: the word starts as 0
     hipLaunchKernelGGL(max_to_host_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, x, n, s.word, s.ticket);
-    const int rc = check_launch("sonar_max_to_host_begin_f32");
+    int rc = check_launch("sonar_max_to_host_begin_f32");
+    if (rc == SONAR_OK && hipEventRecord(s.done, (hipStream_t)stream) != hipSuccess) {
+        set_error("sonar_max_to_host_begin_f32: event record failed");
+        rc = SONAR_ERR_HIP;
+    }
     s.pending = rc == SONAR_OK;
     return rc;
 }
@@ -1572,7 +1580,8 @@ extern "C" int sonar_max_to_host_end_f32(float* result, void* stream) {
         seen = (unsigned)(word >> 32) == s.ticket;
     }
     if (!seen) {
-        SONAR_REQUIRE(hipStreamSynchronize((hipStream_t)stream) == hipSuccess, SONAR_ERR_HIP, "sonar_max_to_host_end_f32: stream wait failed");
+        // not the stream: WaveletCFG queues its kernels behind the reduction before it asks for the value
+        SONAR_REQUIRE(hipEventSynchronize(s.done) == hipSuccess, SONAR_ERR_HIP, "sonar_max_to_host_end_f32: wait failed");
         word = __atomic_load_n(s.word, __ATOMIC_ACQUIRE);
         SONAR_REQUIRE((unsigned)(word >> 32) == s.ticket, SONAR_ERR_HIP, "sonar_max_to_host_end_f32: the result never arrived");
     }

@@ -149,6 +149,9 @@ SIGNATURES = {
     "sonar_wcfg_lowpass_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_lowpass_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _I, _I, _I, _PD, _D, _D, _I, _P]),
     "sonar_wcfg_output_f32": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _I64, _I64, _I, _P]),
+    "sonar_wcfg_bands_lds_bytes": (_I64, [_I64, _I64, _I, _I, _I, _I, _I, _I]),
+    "sonar_wcfg_bands_f32": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _PD, _PD, _I, _I, _I, _PD, _D, _D, _D, _I, _P]),
+    "sonar_wcfg_bands_f64": (_I, [_P, _P, _P, _P, _I64, _I64, _I64, _I, _PD, _PD, _PD, _PD, _I, _I, _I, _PD, _D, _D, _D, _I, _P]),
     "sonar_minmax_rescale_f32": (_I, [_P, _I64, _I64, _P, _P, _F, _D, _D, _P, _P]),
     "sonar_axis_taps_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _I, _I, _P]),
     "sonar_axis_taps_f64": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _I, _I, _P]),
@@ -1418,6 +1421,28 @@ _WCFG_NEED: dict = {}
 _TAPS: dict = {}
 
 
+def wcfg_bands(a: torch.Tensor, b: Optional[torch.Tensor], x: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, *, levels: int, dec_lo,
+               dec_hi, rec_lo, rec_hi, mode: str, inv_mode: str, yh_scales, yl_scale: float, ku: float, kt: float, subtract_from_x: bool,
+               high_precision: bool) -> Optional[torch.Tensor]:
+    """x - (ku * b + kt * Phi(a - b)) (or without the x) with Phi(v) = IDWT(D DWT(v)), D = ``yl_scale`` for the approximation and
+    ``yh_scales[level][3]`` (cH, cV, cD; finest level first) for the details: ONE launch, the coefficients stay in LDS
+    (``sonar_wcfg_bands_*``).  ``b`` None: v = a.  ``out`` may be ``x`` (the second launch of a cond / uncond rule).  None when the
+    kernel does not take the shape / wavelet (callers use ``wcfg_fused``)."""
+    B, Cc, H, W = a.shape
+    flat = [float(v) for row in yh_scales for v in row]
+    if len(flat) != 3 * levels or not (len(dec_lo) == len(dec_hi) == len(rec_lo) == len(rec_hi)):
+        raise SonarHipError("wcfg_bands: scale table must be [levels][3], the four filters of one length")
+    out = torch.empty_like(a) if out is None else out
+    fn = load().sonar_wcfg_bands_f64 if high_precision else load().sonar_wcfg_bands_f32
+    rc = fn(_dev(a, "a"), _opt(b, "b"), _opt(x, "x"), _dev(out, "out"), B * Cc, H, W, int(levels), _taps_arr(dec_lo), _taps_arr(dec_hi),
+            _taps_arr(rec_lo), _taps_arr(rec_hi), len(dec_lo), DWT_MODE_IDS[mode], DWT_MODE_IDS[inv_mode], _darr(flat), float(yl_scale), float(ku),
+            float(kt), int(bool(subtract_from_x)), _stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    _check(rc, "sonar_wcfg_bands")
+    return out
+
+
 def _taps_arr(vals):
     """ctypes double array of a filter-tap list, built once per distinct list (the taps of a Wavelet never change)."""
     key = tuple(vals)
@@ -1514,41 +1539,53 @@ def max_to_host_end(token) -> float:
     return slot.value
 
 
-def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], *, levels: int, dec_lo, dec_hi, mode: str, rec_lo, rec_hi,
-               inv_mode: str, yl_scales, yh_scales, blend_mode: str, strength: float, subtract_from_x: bool, high_precision: bool,
-               perfect_reconstruction: bool = False):
-    """WaveletCFG's transform-domain step for fp32 [B, C, H, W] cond / uncond (and x) in 2 * levels launches; returns the
-    fp32 output, or None when a level does not fit the LDS tile (caller uses the per-pass kernels).  ``perfect_reconstruction``:
-    the analysis / synthesis pair is one wavelet both ways, which lets difference-only rules transform cond - uncond alone."""
-    B, Cc, H, W = cond.shape
-    planes = B * Cc
-    lib = load()
-    elem = 8 if high_precision else 4
-    nkey = (planes, H, W, levels, len(dec_lo), mode, len(rec_lo), inv_mode, elem)
-    need = _WCFG_NEED.get(nkey)
-    if need is None:
-        need = _WCFG_NEED[nkey] = lib.sonar_wcfg_fused_ws_bytes(planes, H, W, levels, len(dec_lo), DWT_MODE_IDS[mode], len(rec_lo),
-                                                                DWT_MODE_IDS[inv_mode], elem)
-    if need < 0:
-        return None
-    stream = _stream()
-    key = (cond.device, stream)
-    ws = _WCFG_WS.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _WCFG_WS[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=cond.device)  # reused across steps of a sampling run
-    out = torch.empty_like(cond)
-    flat = [float(v) for lvl in yh_scales for name in lvl for v in name]
-    if len(flat) != levels * 12 or len(yl_scales) != 4:
-        raise SonarHipError("wcfg_fused: scale tables must be [levels][4][3] and [4]")
-    fn = lib.sonar_wcfg_fused_f64 if high_precision else lib.sonar_wcfg_fused_f32
-    rc = fn(_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), planes, H, W, levels, _taps_arr(dec_lo), _taps_arr(dec_hi),
-            len(dec_lo), DWT_MODE_IDS[mode], _taps_arr(rec_lo), _taps_arr(rec_hi), len(rec_lo), DWT_MODE_IDS[inv_mode],
-            _darr([float(v) for v in yl_scales]), _darr(flat), BLEND_IDS[blend_mode], float(strength), int(bool(subtract_from_x)),
-            int(bool(perfect_reconstruction)), ws.data_ptr(), ws.numel(), stream)
-    if rc == ERR_UNSUPPORTED:
-        return None
-    _check(rc, "sonar_wcfg_fused")
-    return out
+class FusedCall:
+    """``sonar_wcfg_fused_*`` with everything but the tensors converted once: the taps, scale tables and scalars of a rule that is not
+    scheduled are the same numbers at every step (WaveletCFG keeps one per rule), a step supplies cond / uncond / x."""
+
+    def __init__(self, *, levels: int, dec_lo, dec_hi, mode: str, rec_lo, rec_hi, inv_mode: str, yl_scales, yh_scales, blend_mode: str,
+                 strength: float, subtract_from_x: bool, high_precision: bool, perfect_reconstruction: bool = False):
+        flat = [float(v) for lvl in yh_scales for name in lvl for v in name]
+        if len(flat) != levels * 12 or len(yl_scales) != 4:
+            raise SonarHipError("wcfg_fused: scale tables must be [levels][4][3] and [4]")
+        lib = load()
+        self.levels, self.elem = int(levels), 8 if high_precision else 4
+        self.dec_len, self.rec_len, self.mode, self.inv_mode = len(dec_lo), len(rec_lo), DWT_MODE_IDS[mode], DWT_MODE_IDS[inv_mode]
+        self.fn = lib.sonar_wcfg_fused_f64 if high_precision else lib.sonar_wcfg_fused_f32
+        self.mid = (self.levels, _taps_arr(dec_lo), _taps_arr(dec_hi), self.dec_len, self.mode, _taps_arr(rec_lo), _taps_arr(rec_hi), self.rec_len,
+                    self.inv_mode, _darr([float(v) for v in yl_scales]), _darr(flat), BLEND_IDS[blend_mode], float(strength), int(bool(subtract_from_x)),
+                    int(bool(perfect_reconstruction)))
+
+    def __call__(self, cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        B, Cc, H, W = cond.shape
+        planes = B * Cc
+        nkey = (planes, H, W, self.levels, self.dec_len, self.mode, self.rec_len, self.inv_mode, self.elem)
+        need = _WCFG_NEED.get(nkey)
+        if need is None:
+            need = _WCFG_NEED[nkey] = load().sonar_wcfg_fused_ws_bytes(planes, H, W, self.levels, self.dec_len, self.mode, self.rec_len, self.inv_mode,
+                                                                       self.elem)
+        if need < 0:
+            return None
+        stream = _stream()
+        key = (cond.device, stream)
+        ws = _WCFG_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _WCFG_WS[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=cond.device)  # reused across steps of a sampling run
+        out = torch.empty_like(cond)
+        rc = self.fn(_dev(cond, "cond"), _dev(uncond, "uncond"), _opt(x, "x"), _dev(out, "out"), planes, H, W, *self.mid, ws.data_ptr(), ws.numel(),
+                     stream)
+        if rc == ERR_UNSUPPORTED:
+            return None
+        _check(rc, "sonar_wcfg_fused")
+        return out
+
+
+def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tensor], **params):
+    """WaveletCFG's transform-domain step for fp32 [B, C, H, W] cond / uncond (and x) in three launches (level-1 analysis, the deeper
+    levels, level-1 synthesis); returns the fp32 output, or None when a level does not fit the LDS tile (caller uses the per-pass
+    kernels).  ``perfect_reconstruction``: the analysis / synthesis pair is one wavelet both ways, which lets difference-only rules
+    transform cond - uncond alone and every rule run its deeper levels with the coefficients resident in LDS.  Parameters: ``FusedCall``."""
+    return FusedCall(**params)(cond, uncond, x)
 
 
 # ------------------------------------------------------------------------------------------------ prepared call plans

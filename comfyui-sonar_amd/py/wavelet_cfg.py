@@ -567,6 +567,7 @@ def _to_dtype(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 _LOWPASS_ARGS: dict = {}
+_FUSED_CALLS: dict = {}
 
 
 def _rule_is_static(rule: "WCFGRule") -> bool:
@@ -617,6 +618,8 @@ def _reconstructs(w) -> bool:
 class WaveletCFG:
     """py/wavelet_cfg.py:626-842 — a ComfyUI ``sampler_cfg_function``."""
 
+    single_launch_bands = False  # see __call__, fast path 1
+
     def __init__(self, *, existing_cfg: Optional[Callable], rules: WCFGRules, operation_cond=None, operation_uncond=None,
                  operation_fallback_cfg=None, operation_wavelet_cfg=None, operation_result=None):
         self.wavelet_cache = {}
@@ -627,7 +630,7 @@ class WaveletCFG:
         self.operation_fallback_cfg = operation_fallback_cfg
         self.operation_wavelet_cfg = operation_wavelet_cfg
         self.operation_result = operation_result
-        self._likely_rule = rules[0] if rules else None  # the rule the next call is prepared for before its sigma is known
+        self._likely_rule = None  # the rule the previous call matched: the next call launches for it before its own sigma is known
 
     @staticmethod
     def basic_cfg_function(args: dict) -> torch.Tensor:
@@ -686,7 +689,49 @@ class WaveletCFG:
         levels = w.level
         if levels < 1 or getattr(w, "use_dtcwt", False):
             return None  # the dual-tree transform goes band by band (wavelet_cfg_raw)
+        static = _rule_is_static(rule)
+        pr = _reconstructs(w)
+        key = (id(rule), ctx.dtype, pr)
+        hit = _FUSED_CALLS.get(key) if static else None
+        if hit is not None and hit[0] is rule and hit[1] is w:
+            call = hit[2]
+        else:
+            fake_yh = [_BandShape] * levels
+            tabs = {name: rule.scale_table(name, pcts, fake_yh) for name in ("cond", "uncond", "diff", "final")}
 
+            def row(name, j):
+                table = tabs[name][1]
+                if table is None or j >= len(table):
+                    return (1.0, 1.0, 1.0)
+                sc = table[j]
+                sc = (float(sc),) * 3 if isinstance(sc, (int, float)) else tuple(float(v) for v in sc)
+                return (sc + (1.0,) * 3)[:3]
+
+            names = ("cond", "uncond", "diff", "final")
+            call = hip_lib.FusedCall(
+                levels=levels, dec_lo=w.dec_lo, dec_hi=w.dec_hi, mode=w.mode, rec_lo=w.rec_lo, rec_hi=w.rec_hi, inv_mode=w.inv_mode,
+                yl_scales=[tabs[n][0] for n in names], yh_scales=[[row(n, j) for n in names] for j in range(levels)],
+                blend_mode=rule.difference_blend_mode, strength=rule.difference_blend_strength.get_value(pcts), subtract_from_x=True,
+                high_precision=ctx.dtype == torch.float64, perfect_reconstruction=pr)
+            if static:  # the tables of an unscheduled rule are the same numbers at every step: converted once
+                if len(_FUSED_CALLS) > 64:
+                    _FUSED_CALLS.clear()
+                _FUSED_CALLS[key] = (rule, w, call)
+        return call(ctx.cond.contiguous(), ctx.uncond.contiguous(), ctx.x.contiguous())
+
+    @classmethod
+    def wavelet_cfg_bands(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts) -> Optional[torch.Tensor]:
+        """x - result with the coefficient bands resident in LDS (``sonar_wcfg_bands_*``, csrc/dwt_bands.h) for any scale tables, when the
+        wavelet pair reconstructs and the blend is linear in the bands (lerp / inject / subtract_b): difference-only rules are ONE launch
+        on cond - uncond; a rule that also scales cond / uncond / final is A . DWT(cond) + B . DWT(uncond) per band -- two launches, one
+        tensor each.  None when the rule / wavelet / shape is outside that scope."""
+        w = ctx.wavelet
+        if ctx.cond.ndim != 4 or ctx.cond.dtype != torch.float32 or ctx.uncond.dtype != torch.float32 or ctx.dtype not in (torch.float32, torch.float64):
+            return None
+        levels = w.level
+        mode = rule.difference_blend_mode
+        if levels < 1 or getattr(w, "use_dtcwt", False) or not _reconstructs(w) or mode not in ("lerp", "inject", "subtract_b"):
+            return None
         fake_yh = [_BandShape] * levels
         tabs = {name: rule.scale_table(name, pcts, fake_yh) for name in ("cond", "uncond", "diff", "final")}
 
@@ -698,13 +743,26 @@ class WaveletCFG:
             sc = (float(sc),) * 3 if isinstance(sc, (int, float)) else tuple(float(v) for v in sc)
             return (sc + (1.0,) * 3)[:3]
 
-        names = ("cond", "uncond", "diff", "final")
-        return hip_lib.wcfg_fused(
-            ctx.cond.contiguous(), ctx.uncond.contiguous(), ctx.x.contiguous(), levels=levels, dec_lo=w.dec_lo, dec_hi=w.dec_hi, mode=w.mode,
-            rec_lo=w.rec_lo, rec_hi=w.rec_hi, inv_mode=w.inv_mode, yl_scales=[tabs[n][0] for n in names],
-            yh_scales=[[row(n, j) for n in names] for j in range(levels)], blend_mode=rule.difference_blend_mode,
-            strength=rule.difference_blend_strength.get_value(pcts), subtract_from_x=True, high_precision=ctx.dtype == torch.float64,
-            perfect_reconstruction=_reconstructs(w))
+        t = float(rule.difference_blend_strength.get_value(pcts))
+        sign = -1.0 if mode == "subtract_b" else 1.0
+        keep = 1.0 - t if mode == "lerp" else 1.0  # blend(a, b, t) = keep * a + sign * t * b
+        common = dict(levels=levels, dec_lo=w.dec_lo, dec_hi=w.dec_hi, rec_lo=w.rec_lo, rec_hi=w.rec_hi, mode=w.mode, inv_mode=w.inv_mode,
+                      subtract_from_x=True, high_precision=ctx.dtype == torch.float64)
+        cond, uncond, x = ctx.cond.contiguous(), ctx.uncond.contiguous(), ctx.x.contiguous()
+        plain = all(float(tabs[n][0]) == 1.0 and all(v == 1.0 for j in range(levels) for v in row(n, j)) for n in ("cond", "uncond", "final"))
+        if plain:
+            return hip_lib.wcfg_bands(cond, uncond, x, yh_scales=[row("diff", j) for j in range(levels)], yl_scale=float(tabs["diff"][0]),
+                                      ku=keep, kt=sign * t, **common)
+
+        def coeffs(s_c, s_u, s_d, s_f):  # blend(s_u U, s_d (s_c C - s_u U), t) s_f = A C + B U
+            return sign * t * s_d * s_c * s_f, (keep - sign * t * s_d) * s_u * s_f
+
+        per_band = [[coeffs(*(row(n, j)[k] for n in ("cond", "uncond", "diff", "final"))) for k in range(3)] for j in range(levels)]
+        yl_a, yl_b = coeffs(*(float(tabs[n][0]) for n in ("cond", "uncond", "diff", "final")))
+        out = hip_lib.wcfg_bands(uncond, None, x, yh_scales=[[ab[1] for ab in lvl] for lvl in per_band], yl_scale=yl_b, ku=0.0, kt=1.0, **common)
+        if out is None:
+            return None
+        return hip_lib.wcfg_bands(cond, None, out, out, yh_scales=[[ab[0] for ab in lvl] for lvl in per_band], yl_scale=yl_a, ku=0.0, kt=1.0, **common)
 
     @classmethod
     def wavelet_cfg_lowpass(cls, *, rule: WCFGRule, ctx: WCFGContext, pcts) -> Optional[torch.Tensor]:
@@ -741,9 +799,11 @@ class WaveletCFG:
                                          high_precision=ctx.dtype == torch.float64)
 
     def _speculate(self, args: dict):
-        """While the sigma read is in flight: (rule, context, launch) of the one-launch path for the rule the previous call matched,
-        when that rule is unscheduled and nothing in its preparation depends on sigma's VALUE or runs user operations.  None otherwise
-        (and on any error: the ordinary path raises it where the reference does)."""
+        """While the sigma read is in flight: (rule, context, result) of the fast path for the rule the previous call matched, LAUNCHED
+        before sigma's value is known, when that rule is unscheduled and nothing in its preparation depends on the value or runs user
+        operations.  The kernels only write their own fresh output, so a call that turns out to match another rule (a window boundary)
+        drops the tensor and takes the ordinary order; the GPU works instead of waiting for the host to learn a number that almost
+        always selects the same rule.  None otherwise (and on any error: the ordinary path raises it where the reference does)."""
         rule = self._likely_rule
         if rule is None or self.operation_cond is not None or self.operation_uncond is not None or self.operation_wavelet_cfg is not None:
             return None
@@ -754,9 +814,15 @@ class WaveletCFG:
         try:
             ctx = self.get_context(rule=rule, args=args)
             launch = self._lowpass_launch(rule=rule, ctx=ctx, pcts=None)
+            if launch is not None:
+                result = launch()
+            else:
+                result = self.wavelet_cfg_bands(rule=rule, ctx=ctx, pcts=None) if self.single_launch_bands else None
+                if result is None:
+                    result = self.wavelet_cfg_fused(rule=rule, ctx=ctx, pcts=None)
         except Exception:  # noqa: BLE001 -- reported by the ordinary path, in the reference's order
             return None
-        return None if launch is None else (rule, ctx, launch)
+        return None if result is None else (rule, ctx, result)
 
     @staticmethod
     def _lowpass_plan(rule: WCFGRule, pcts, levels: int):
@@ -848,14 +914,14 @@ class WaveletCFG:
         else:
             sigma_f = sigma.max().item()
         rule = self.rules.get_rule(sigma_f)
+        self._likely_rule = rule  # None: outside every rule's window -- the next call most likely is too, and launches nothing ahead
         if rule is None:
             return self.fallback_cfg_function(args)
-        self._likely_rule = rule
         if rule.verbose:
             _say(f"\nWCFG: Rule matched, sigma={sigma_f:.4f}, rule={rule.pretty_non_default()}")
         if ready is not None and ready[0] is rule:
-            # launch first; the percentages (whose errors are the reference's errors, py/wavelet_cfg.py:155-222) are checked under the kernel
-            low = ready[2]()
+            # already launched; the percentages (whose errors are the reference's errors, py/wavelet_cfg.py:155-222) are checked under the kernel
+            low = ready[2]
             WCFGPercentages.build(ms=args["model"].model_sampling, start_sigma=rule.start_sigma, end_sigma=rule.end_sigma, sigma=sigma_f,
                                   sigmas=args.get("model_options", {}).get("transformer_options", {}).get("sample_sigmas"))
             return self.maybe_op(low, self.operation_result, **ready[1].op_kwargs).contiguous()
@@ -875,12 +941,19 @@ class WaveletCFG:
             low = self.wavelet_cfg_lowpass(rule=rule, ctx=ctx, pcts=pcts)
             if low is not None:
                 return self.maybe_op(low, self.operation_result, **ctx.op_kwargs).contiguous()
-            # fast path 1: the whole transform-domain step in 2 * level LDS-staged launches (cond + uncond analysed together, band
-            # arithmetic before the store, last synthesis pass writes x - result)
+            # fast path 1 (off by default, `single_launch_bands`): any scale tables with ALL coefficient bands resident in LDS -- one launch
+            # for difference-only rules, two otherwise.  Least HBM traffic, but a plane's coefficients fill half a CU's LDS and the
+            # launch runs at one or two workgroups per CU: measured slower than fast path 2 at SDXL size
+            if self.single_launch_bands:
+                bands = self.wavelet_cfg_bands(rule=rule, ctx=ctx, pcts=pcts)
+                if bands is not None:
+                    return self.maybe_op(bands, self.operation_result, **ctx.op_kwargs).contiguous()
+            # fast path 2: level 1 in two LDS-staged tile launches (cond + uncond analysed together, band arithmetic before the store, the
+            # synthesis writes x - result), the deeper levels in one launch with their coefficients resident in LDS
             fused = self.wavelet_cfg_fused(rule=rule, ctx=ctx, pcts=pcts)
             if fused is not None:
                 return self.maybe_op(fused, self.operation_result, **ctx.op_kwargs).contiguous()
-            # fast path 2: cast + crop + (x - result) fused in one kernel straight from the fp64/fp32 reconstruction
+            # fast path 3: cast + crop + (x - result) fused in one kernel straight from the fp64/fp32 reconstruction
             raw = self.wavelet_cfg_raw(rule=rule, ctx=ctx, pcts=pcts)
             result = hip_lib.wcfg_output(x.contiguous(), raw, x.shape, True)
             return self.maybe_op(result, self.operation_result, **ctx.op_kwargs).contiguous()

@@ -574,6 +574,22 @@ int sonar_wcfg_lowpass_f32(const float* cond, const float* uncond, const float* 
 int sonar_wcfg_lowpass_f64(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H,
                            int64_t W, int levels, const double* dec_lo, const double* rec_lo, int flen, int mode_fwd,
                            int mode_inv, const double* g, double ku, double kt, int subtract_from_x, void* stream);
+/* WaveletCFG with ANY per-level, per-orientation band scales in one launch, the coefficients resident in LDS (py/wavelet_cfg.py:750-791,
+ * py/wavelet_functions.py:193-238).  Phi_D(v) = IDWT(D DWT(v)) with D = (yl_scale for the approximation, yh_scales[levels][3] = (cH, cV,
+ * cD) per level, finest first) is linear in v, and with a perfect-reconstruction pair a level needs its approximation and ONE detail band
+ * on chip (csrc/dwt_bands.h).  v = a - b (b nullable: v = a);  result = ku * b + kt * Phi_D(v);  out = x - (float)result
+ * (subtract_from_x) or (float)result; x may alias out.  Difference-only rules: a = cond, b = uncond, D = the difference scales, (ku, kt)
+ * as in sonar_wcfg_lowpass_*.  Any other rule with a linear blend is Phi_A(cond) + Phi_B(uncond): two launches, the second with x = out of
+ * the first.  fp32 tensors, _f32 / _f64 = arithmetic type; dec / rec: the four filters (flen taps each, even, <= 20) of ONE wavelet.
+ * SONAR_ERR_UNSUPPORTED when the coefficients do not fit in LDS (sonar_wcfg_bands_lds_bytes < 0) or the extension pair does not
+ * reconstruct: callers use sonar_wcfg_fused_* then. */
+int64_t sonar_wcfg_bands_lds_bytes(int64_t H, int64_t W, int levels, int flen, int mode_fwd, int mode_inv, int elem_size, int per_orientation);
+int sonar_wcfg_bands_f32(const float* a, const float* b, const float* x, float* out, int64_t planes, int64_t H, int64_t W, int levels,
+                         const double* dec_lo, const double* dec_hi, const double* rec_lo, const double* rec_hi, int flen, int mode_fwd,
+                         int mode_inv, const double* yh_scales, double yl_scale, double ku, double kt, int subtract_from_x, void* stream);
+int sonar_wcfg_bands_f64(const float* a, const float* b, const float* x, float* out, int64_t planes, int64_t H, int64_t W, int levels,
+                         const double* dec_lo, const double* dec_hi, const double* rec_lo, const double* rec_hi, int flen, int mode_fwd,
+                         int mode_inv, const double* yh_scales, double yl_scale, double ku, double kt, int subtract_from_x, void* stream);
 /* process_output, py/wavelet_cfg.py:729-748: out = x - (float)crop(result)  (subtract_from_x = 1, target DENOISED)
  * or out = (float)crop(result); result is [planes][Hr][Wr] (f64 or f32), x/out are [planes][H][W] fp32 */
 int sonar_wcfg_output_f32(const float* x, const void* result, int result_is_f64, float* out, int64_t planes,

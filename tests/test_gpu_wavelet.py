@@ -221,8 +221,8 @@ def test_wavelet_cfg_fused_equals_per_pass_path(api, monkeypatch, high_precision
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
     monkeypatch.setattr(api.wc.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))  # this test is about the band kernels
     calls = []
-    real = api.hl.wcfg_fused
-    monkeypatch.setattr(api.hl, "wcfg_fused", lambda *a, **k: calls.append(1) or real(*a, **k))
+    real = api.hl.FusedCall.__call__
+    monkeypatch.setattr(api.hl.FusedCall, "__call__", lambda self, *a: calls.append(1) or real(self, *a))
     fused = fn(args)
     assert calls, "the fused entry point was not used"
     monkeypatch.setattr(api.wc.WaveletCFG, "wavelet_cfg_fused", classmethod(lambda cls, **_k: None))
@@ -290,9 +290,9 @@ def test_difference_route_equals_pair_route(api, monkeypatch, wave, mode, level,
                       padding_mode=mode, high_precision_mode=high_precision, difference_blend_mode=blend, difference_blend_strength=strength)
         fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
         seen = []
-        real = api.hl.wcfg_fused
+        real = api.hl.FusedCall.__init__
         with monkeypatch.context() as m:
-            m.setattr(api.hl, "wcfg_fused", lambda *a, **k: seen.append(k.get("perfect_reconstruction")) or real(*a, **k))
+            m.setattr(api.hl.FusedCall, "__init__", lambda self, **k: seen.append(k.get("perfect_reconstruction")) or real(self, **k))
             single = fn(args)
         assert seen == [True], "the fused entry point was not used with the reconstruction flag"
         with monkeypatch.context() as m:

@@ -119,7 +119,41 @@ def test_lowpass_path_is_taken_where_it_applies(api, monkeypatch):
 
 @pytest.mark.parametrize("name", FOUR_D)
 def test_wavelet_cfg_band_path_matches_reference(api, name, monkeypatch):
-    """The same cases with the low-pass shortcut disabled: cond and uncond analysed band by band (sonar_wcfg_fused_*, 3 launches)."""
+    """The same cases with the low-pass shortcut disabled: the bands resident in LDS (sonar_wcfg_bands_*: one launch for difference-only
+    rules, two for rules that scale cond / uncond / final) where the wavelet pair reconstructs, the tile kernels elsewhere."""
+    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))
+    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "single_launch_bands", True)
+    calls = []
+    real = api.hl.wcfg_bands
+    monkeypatch.setattr(api.hl, "wcfg_bands", lambda *a, **k: calls.append(1) or real(*a, **k))
+    case = wc.WCFG_CASES[name]
+    args = wh.wcfg_args(case, name, wc.FakeModel(), device="cuda")
+    want = WCFG[f"{name}__out"]
+    np.testing.assert_allclose(wh.build_wcfg(api.wavelet_cfg, case)(args).cpu().numpy(), want, rtol=0, atol=_wcfg_tol(case, want))
+    BANDS_USED[name] = len(calls)
+
+
+BANDS_USED: dict = {}
+
+
+def test_band_kernel_is_taken_where_it_applies():
+    """One launch for difference-only rules, two when cond / uncond / final are scaled as well, none where the extension pair does not
+    reconstruct, the target is not the denoised prediction or the call blends with the fallback CFG."""
+    if len(BANDS_USED) < len(FOUR_D):
+        pytest.skip("runs after test_wavelet_cfg_band_path_matches_reference")
+    for name in ("placeholder", "placeholder_f32", "placeholder_128", "identity_scales", "haar_per", "lerp_diff_small_t", "subtract_diff", "lerp_diff"):
+        assert BANDS_USED[name] == 1, (name, BANDS_USED[name])
+    for name in ("all_scales", "all_scales_f32"):
+        assert BANDS_USED[name] == 2, (name, BANDS_USED[name])
+    for name in ("target_noise", "blend_half", "outside_window"):
+        assert BANDS_USED[name] == 0, (name, BANDS_USED[name])
+
+
+@pytest.mark.parametrize("name", FOUR_D)
+def test_wavelet_cfg_tile_kernels_match_reference(api, name, monkeypatch):
+    """Low-pass shortcut disabled, the default route for rules that need the bands: level 1 by the tile kernels through the workspace,
+    the deeper levels by the LDS-resident kernel where the wavelet pair reconstructs (sonar_wcfg_fused_*, 3 launches; 4 for cond /
+    uncond rules), by the old per-level walk elsewhere."""
     monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))
     case = wc.WCFG_CASES[name]
     args = wh.wcfg_args(case, name, wc.FakeModel(), device="cuda")
@@ -131,6 +165,7 @@ def test_wavelet_cfg_band_path_matches_reference(api, name, monkeypatch):
 def test_wavelet_cfg_per_pass_path_matches_reference(api, name, monkeypatch):
     """The same cases with both fast entry points disabled: the per-level kernels behind Wavelet.forward / inverse."""
     monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))
+    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "wavelet_cfg_bands", classmethod(lambda cls, **_k: None))
     monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "wavelet_cfg_fused", classmethod(lambda cls, **_k: None))
     case = wc.WCFG_CASES[name]
     args = wh.wcfg_args(case, name, wc.FakeModel(), device="cuda")
@@ -139,8 +174,9 @@ def test_wavelet_cfg_per_pass_path_matches_reference(api, name, monkeypatch):
 
 
 def test_prepared_launch_equals_ordinary_path(api):
-    """While the sigma read is in flight the call prepares the one-launch path for the rule the previous call matched
-    (WaveletCFG._speculate).  Same bits as the ordinary order, across a change of rule, and the prepared launch is really used."""
+    """While the sigma read is in flight the call LAUNCHES the fast path for the rule the previous call matched (WaveletCFG._speculate)
+    and keeps the result when its own sigma selects that rule.  Same bits as the ordinary order, across changes of rule and calls outside
+    every window, and the launch made ahead is really the one returned."""
     case = wc.WCFG_CASES["second_rule"]
     fn = wh.build_wcfg(api.wavelet_cfg, case)
     plain = wh.build_wcfg(api.wavelet_cfg, case)
@@ -149,13 +185,17 @@ def test_prepared_launch_equals_ordinary_path(api):
     fn._speculate = lambda a: seen.append(real(a)) or seen[-1]
     plain._speculate = lambda a: None
     base = wh.wcfg_args(case, "second_rule", wc.FakeModel(), device="cuda")
-    for k, sigma in enumerate((3.0, 3.0, 9.0, 9.0, 3.0, 20.0, 3.0)):
+    for k, sigma in enumerate((3.0, 3.0, 9.0, 9.0, 3.0, 20.0, 3.0, 3.0)):
         args = dict(base, sigma=torch.full_like(base["sigma"], sigma))
         got, want = fn(args), plain(args)
         assert torch.equal(got, want), (k, sigma)
         rule = fn.rules.get_rule(sigma)
-        # prepared for the rule of the previous call: used when this call matches the same rule
-        assert seen[-1] is not None and (seen[-1][0] is rule) == (k in (1, 3, 6)), (k, sigma)
+        # launched for the rule of the previous call (nothing after a call that matched no rule, or before the first): kept when this
+        # call matches the same rule
+        assert (seen[-1] is None) == (k in (0, 6)), (k, sigma)
+        assert (seen[-1] is not None and seen[-1][0] is rule) == (k in (1, 3, 7)), (k, sigma)
+        if k in (1, 3, 7):
+            assert got.data_ptr() == seen[-1][2].data_ptr()
     np.testing.assert_allclose(fn(base).cpu().numpy(), WCFG["second_rule__out"], rtol=0, atol=_wcfg_tol(case, WCFG["second_rule__out"]))
     # the percentages are still built (under the kernel), so their errors still surface: no sample_sigmas -> the reference's error
     bad = dict(base, model_options={"transformer_options": {}})
