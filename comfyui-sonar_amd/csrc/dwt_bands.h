@@ -37,6 +37,7 @@ struct BandsArgs {
     T yl;                                             // scale of the approximation
     T ku, kt;                                         // result = ku b + kt Phi(v)
     int subtract_from_x, mode_fwd, mode_inv;
+    int vec2;                                         // x and out are aligned for pair accesses
     TapsSmall<T> dec, rec;
 };
 
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     const In2 q1 = pair ? cu[yl * W + 2 * m + 1] : q0;
                     const T r0 = fma_t(a.ku, (T)q0.y, a.kt * fma_t(a_d, (T)q0.x - (T)q0.y, e));
                     const T r1 = fma_t(a.ku, (T)q1.y, a.kt * fma_t(a_d, (T)q1.x - (T)q1.y, o));
-                    if (pair && (W & 1) == 0) {
+                    if (pair && (W & 1) == 0 && a.vec2) {
                         In2 res{(TIO)r0, (TIO)r1};
                         if (px) {
                             const In2 x2 = *reinterpret_cast<const In2*>(px + at);
@@ -407,6 +408,7 @@ static int wcfg_bands(const TIO* ta, const TIO* tb, const TIO* x, TIO* out, int6
     a.subtract_from_x = subtract_from_x;
     a.mode_fwd = mode_fwd;
     a.mode_inv = mode_inv;
+    a.vec2 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & (2 * sizeof(TIO) - 1)) == 0;
     for (int i = 0; i < kDeepTaps; ++i) {
         a.dec.lo[i] = i < flen ? (T)dec_lo[i] : T(0);
         a.dec.hi[i] = i < flen ? (T)dec_hi[i] : T(0);

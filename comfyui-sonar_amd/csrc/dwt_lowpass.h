@@ -34,6 +34,8 @@ struct LowArgs {
     T g[kLowMaxLevels + 1];                           // g[0] = d_1; g[j] = d_{j+1} - d_j; g[J] = l - d_J
     T ku, kt;                                         // result = ku u + kt (g[0] v + Up_1(...))
     int subtract_from_x, mode_fwd, mode_inv;
+    int vec2;                                         // ... 8-byte aligned (a view at an odd storage offset is not): pairs as one access
+    int vec4;                                         // cond, uncond, x and out are 16-byte aligned: the output phase may use 16-byte accesses
     T dlo[kDeepTaps], rlo[kDeepTaps];
 };
 
@@ -257,7 +259,7 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
                     if (2 * mp + 1 < th) tmp[(2 * mp + 1) * w1 + xo] = o;
                 }
                 __syncthreads();
-                if ((W & 3) == 0 && a.mode_inv != kPeriodization) {
+                if ((W & 3) == 0 && a.vec4 && a.mode_inv != kPeriodization) {
                     // four consecutive outputs per item: one 16-byte access per tensor instead of two 8-byte ones (this phase is bound by
                     // the number of memory instructions, like every store phase on this chip), and the two output pairs share all but one of
                     // their K coefficients
@@ -294,7 +296,7 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
                     const T* row = tmp + yl * w1;
                     const int at = (y0 + yl) * W + 2 * m;
                     const bool pair = 2 * m + 1 < W;
-                    const bool vec = pair && (W & 1) == 0;  // rows are 8-byte aligned: one vector access per tensor
+                    const bool vec = pair && (W & 1) == 0 && a.vec2;  // rows are 8-byte aligned: one vector access per tensor
                     // the three global reads are requested BEFORE the synthesis out of LDS, not after it: the compiler keeps source order
                     // here and otherwise waits for them with nothing left to overlap (-2..3 % on the kernel; requesting them a whole
                     // item ahead measured the same for fp32 and slower for fp64)
@@ -391,6 +393,10 @@ static int wcfg_lowpass(const float* cond, const float* uncond, const float* x, 
     a.subtract_from_x = subtract_from_x;
     a.mode_fwd = mode_fwd;
     a.mode_inv = mode_inv;
+    a.vec2 = ((reinterpret_cast<uintptr_t>(cond) | reinterpret_cast<uintptr_t>(uncond) | reinterpret_cast<uintptr_t>(x) |
+               reinterpret_cast<uintptr_t>(out)) & 7u) == 0;
+    a.vec4 = ((reinterpret_cast<uintptr_t>(cond) | reinterpret_cast<uintptr_t>(uncond) | reinterpret_cast<uintptr_t>(x) |
+               reinterpret_cast<uintptr_t>(out)) & 15u) == 0;  // a view at an odd storage offset, or any direct caller of the C ABI
     for (int i = 0; i < kDeepTaps; ++i) {
         a.dlo[i] = i < flen ? (T)dec_lo[i] : T(0);
         a.rlo[i] = i < flen ? (T)rec_lo[i] : T(0);

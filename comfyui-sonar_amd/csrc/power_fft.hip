@@ -1611,16 +1611,21 @@ static int power_grid(int64_t planes, bool owns_partials = true) {
 //       2 = dump the drawn spectrum into `out`, 3 = spectral filter of the real planes `z`, 4 = forward rfft2 of the real planes `z` into `out`
 // look-ahead of a normalised generate call (sonar_power_noise_ahead_f32): `have_stats` -- the partials already hold this call's
 // statistics (left by the previous call's look-ahead), `next` -- where to leave those of the call with stream id `next_stream`
+constexpr int kAheadMaxGroup = 4;  // planes per unit the look-ahead statistics cover
+constexpr int kMaxRngGroup = 8;    // planes per RNG group: the edge-column area of the generate kernels holds eight
 struct Ahead {
     int have_stats = 0;
     uint64_t next_stream = 0;
     double* next = nullptr;
 };
 
-static bool pipe_enabled() {
-    static const bool on = [] { const char* e = getenv("SONAR_POWER_PIPE"); return !(e && e[0] == '0'); }();
+// process-wide: the pipelined generate kernel (default) or the phase-serial one for every batch size -- same streams, same bits;
+// SONAR_POWER_PIPE=0 in the environment or sonar_power_pipeline(0) (A/B timing, and the test that the two kernels agree bit for bit)
+static int& pipe_switch() {
+    static int on = [] { const char* e = getenv("SONAR_POWER_PIPE"); return (e && e[0] == '0') ? 0 : 1; }();
     return on;
 }
+static bool pipe_enabled() { return pipe_switch() != 0; }
 // the pipelined kernel's work units for `planes` planes in RNG groups of `group`
 static int64_t pipe_units(int64_t planes, int group, int* psplit) {
     *psplit = group > 1 && planes / group < 256 ? 1 : 0;  // fewer RNG groups than CUs: single planes as units
@@ -1723,6 +1728,7 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
     SONAR_REQUIRE(group >= 1 && planes % group == 0 && plane_offset % group == 0, SONAR_ERR_ARG,
                   "sonar_power_*: planes (%lld) and plane_offset (%lld) must be multiples of the RNG group (%d)", (long long)planes,
                   (long long)plane_offset, group);
+    SONAR_REQUIRE(group <= kMaxRngGroup, SONAR_ERR_UNSUPPORTED, "sonar_power_*: RNG groups of at most %d planes (got %d)", kMaxRngGroup, group);
 #define SONAR_CASE(HH, WW) \
     if (H == HH && W == WW) return launch_power<HH, WW>(what, z, filter, out, planes, seed, stream_id, plane_offset, group, partials, na, st)
     if (H == 128 && W == 128) return launch_power<128, 128>(what, z, filter, out, planes, seed, stream_id, plane_offset, group, partials, na, st, ah);
@@ -1788,10 +1794,20 @@ extern "C" int sonar_power_noise_f32(const float* filter, float* out, int64_t pl
                           NormArgs{partials, planes * H * W, factor, threshold_std_devs}, (hipStream_t)stream);
 }
 
+extern "C" int sonar_power_pipeline(int enable) {
+    const int before = pipe_switch();
+    if (enable >= 0) pipe_switch() = enable != 0;
+    return before;
+}
+
 extern "C" int sonar_power_noise_ahead_ok(int64_t planes, int64_t H, int64_t W, int rng_group) {
     if (H != 128 || W != 128 || !pipe_enabled() || planes <= 256 || rng_group < 1 || planes % rng_group) return 0;
     int psplit;
-    return pipe_units(planes, rng_group, &psplit) <= 2 * 256 ? 1 : 0;  // one look-ahead unit per team: at most two units per workgroup
+    const int64_t units = pipe_units(planes, rng_group, &psplit);
+    // the look-ahead statistics walk at most four planes per unit (TeamStats::radii, the edge columns' area): larger RNG groups only
+    // when the units are single planes
+    if (!psplit && rng_group > kAheadMaxGroup) return 0;
+    return units <= 2 * 256 ? 1 : 0;  // one look-ahead unit per team: at most two units per workgroup
 }
 
 extern "C" int sonar_power_noise_ahead_f32(const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,

@@ -290,35 +290,40 @@ class MixedNoiseGenerator(NoiseGenerator):
         # rides in the accumulation kernel -- y * a + x * b rounds each product before the add, exactly like the multiply pass followed
         # by the add -- and so does an output multiply by a power of two (it commutes with every rounding); the last accumulation also
         # leaves the statistics the caller's normalisation would otherwise sweep the tensor for.  Same bits, three to four passes less.
-        parts = []
-        for gen, transform in self.ng_list:
+        out_factor = getattr(self.output_fun, "scale_factor", None) if self.output_fun is not None else 1.0
+        fold_out = out_factor is not None and out_factor != 0.0 and math.frexp(out_factor)[0] in (0.5, -0.5)
+        g = out_factor if fold_out else 1.0
+        total, pending = None, 1.0  # pending: the multiplier the running sum still owes (rides in the next accumulation)
+        count = len(self.ng_list)
+        for idx, (gen, transform) in enumerate(self.ng_list):
+            # one part alive at a time: drawn just before its accumulation, dropped after it (several 134 MB tensors at batch 512 otherwise)
             part = gen(*args)
             utils.pop_stats(part)
             factor = getattr(transform, "scale_factor", None) if transform is not None else 1.0
             if factor is None:
                 part, factor = transform(part), 1.0
                 utils.pop_stats(part)
-            parts.append((part, float(factor)))
-        out_factor = getattr(self.output_fun, "scale_factor", None) if self.output_fun is not None else 1.0
-        fold_out = out_factor is not None and out_factor != 0.0 and math.frexp(out_factor)[0] in (0.5, -0.5)
-        g = out_factor if fold_out else 1.0
-        total, f0 = parts[0]
-        fusable = (len(parts) > 1 and all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() and p.shape == total.shape for p, _ in parts))
-        if not fusable:
-            total = None
-            for (part, factor), (_, transform) in zip(parts, self.ng_list):
+            factor = float(factor) * g
+            if total is None:
+                total, pending = part, factor
+                continue
+            fusable = all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() for p in (total, part)) and part.shape == total.shape
+            if fusable:
+                if idx == count - 1 and (fold_out or self.output_fun is None):
+                    total, partials = hip_lib.axpby_stats_(total, pending, part, factor)
+                    return attach_stats(total, partials)
+                hip_lib.axpby_(total, pending, part, factor)
+            else:
+                if pending != 1.0:
+                    total = hip_lib.scale_noise_(total, pending, False, None)
                 if factor != 1.0:
                     part = hip_lib.scale_noise_(part, factor, False, None)
-                total = part if total is None else hip_lib.axpby_(total, 1.0, part, 1.0)
-            return self.output_fun(total) if self.output_fun is not None else total
-        for idx in range(1, len(parts)):
-            part, factor = parts[idx]
-            ymul = f0 * g if idx == 1 else 1.0
-            if idx == len(parts) - 1 and (fold_out or self.output_fun is None):
-                total, partials = hip_lib.axpby_stats_(total, ymul, part, factor * g)
-                return attach_stats(total, partials)
-            hip_lib.axpby_(total, ymul, part, factor * g)
-        return self.output_fun(total) if self.output_fun is not None else total
+                total = hip_lib.axpby_(total, 1.0, part, 1.0)
+            pending = 1.0
+            del part
+        if pending != 1.0:
+            total = hip_lib.scale_noise_(total, pending, False, None)
+        return self.output_fun(total) if self.output_fun is not None and not fold_out else total
 
 
 class GaussianNoiseGenerator(NoiseGenerator):

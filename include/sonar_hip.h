@@ -413,6 +413,10 @@ int sonar_power_noise_f32(const float* filter, float* out, int64_t planes, int64
  * sonar_power_noise_f32 either way.  Only where sonar_power_noise_ahead_ok() says 1 (pipelined 128 x 128 path, at most 512 work
  * units); SONAR_ERR_UNSUPPORTED elsewhere.  Same call site: py/nodes/powernoise.py:338-408 followed by py/utils.py:85-106. */
 int sonar_power_noise_ahead_ok(int64_t planes, int64_t H, int64_t W, int rng_group);
+/* process-wide switch between the two generate kernels for 128 x 128 planes: 1 (default) the pipelined kernel where it applies (more than
+ * 256 planes), 0 the phase-serial kernel everywhere; < 0 only asks.  Same stream definition, the same bits either way
+ * (tests/test_gpu_round3.py); returns the previous setting.  For A/B timing and that test -- not a per-call option. */
+int sonar_power_pipeline(int enable);
 int sonar_power_noise_ahead_f32(const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
                                 uint64_t stream_id, int64_t plane_offset, int rng_group, float factor, float threshold_std_devs,
                                 double* partials, int have_stats, uint64_t next_stream_id, double* partials_next, void* stream);

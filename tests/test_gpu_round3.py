@@ -28,20 +28,40 @@ def _filter(api, shape):
 
 
 @pytest.mark.parametrize("shape", [(512, 4, 128, 128), (96, 4, 128, 128), (171, 3, 128, 128), (65, 4, 128, 128), (300, 4, 128, 128)])
-def test_pipelined_power_kernel_equals_the_phase_serial_kernel(api, shape, monkeypatch):
-    """The pipelined generate kernel (drawing team / transforming team, planes > 256) against the spectrum the same streams dump and
-    torch's irfft2 (sampled planes), and normalised == (raw - mean) / std of the raw call: what the phase-serial kernel is tested on."""
+def test_pipelined_power_kernel_equals_the_phase_serial_kernel(api, shape):
+    """The pipelined generate kernel (drawing team / transforming team, planes > 256) and the phase-serial kernel serve ONE stream
+    definition: run on the same (seed, stream) -- sonar_power_pipeline(0) selects the phase-serial kernel for every batch size -- they
+    write the same bits, raw, with statistics, and normalised.  The phase-serial kernel itself is pinned to the spectrum the streams dump
+    and torch's irfft2 (sampled planes)."""
     hl = api.hl
+    lib = hl.load()
     filt = _filter(api, shape)
     planes = shape[0] * shape[1]
-    raw = hl.power_irfft2(None, filt, shape, seed=11, stream_id=5, plane_offset=0)
+
+    def run_all():
+        part = hl.new_partials("cuda")
+        return (hl.power_irfft2(None, filt, shape, seed=11, stream_id=5, plane_offset=0),
+                hl.power_irfft2(None, filt, shape, seed=11, stream_id=6, plane_offset=0, partials=part), part,
+                hl.power_noise(filt, shape, seed=11, stream_id=5, plane_offset=0, factor=0.75))
+
+    assert lib.sonar_power_pipeline(-1) == 1
+    piped = run_all()
+    assert lib.sonar_power_pipeline(0) == 1
+    try:
+        assert lib.sonar_power_noise_ahead_ok(planes, 128, 128, hl.rng_group_for(shape)) == 0  # the look-ahead belongs to the pipelined kernel
+        serial = run_all()
+    finally:
+        lib.sonar_power_pipeline(1)
+    raw, _, part, norm = piped
+    assert torch.equal(raw, serial[0]) and torch.equal(piped[1], serial[1]) and torch.equal(norm, serial[3])
+    # the statistics partials are reduced in each kernel's own grouping: the same totals to fp64 rounding
+    torch.testing.assert_close(part.view(-1, 2).sum(0), serial[2].view(-1, 2).sum(0), rtol=1e-12, atol=0)
     spec = hl.power_spectrum(shape, "cuda", seed=11, stream_id=5)
     for pl in (0, 1, 255, 256, planes // 2 + 3, planes - 1):
         z = spec.reshape(planes, 128, 65)[pl] * filt
         want = torch.fft.irfft2(z, s=(128, 128), norm="ortho")
-        got = raw.reshape(planes, 128, 128)[pl]
+        got = serial[0].reshape(planes, 128, 128)[pl]
         assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item(), pl
-    norm = hl.power_noise(filt, shape, seed=11, stream_id=5, plane_offset=0, factor=0.75)
     d = raw.double()
     want = ((d - d.mean()) / d.std()).float() * 0.75
     torch.testing.assert_close(norm, want, rtol=2e-5, atol=2e-6)
@@ -51,6 +71,32 @@ def test_pipelined_power_kernel_equals_the_phase_serial_kernel(api, shape, monke
         a = hl.power_irfft2(None, filt, (half, *shape[1:]), seed=11, stream_id=5, plane_offset=0)
         b = hl.power_irfft2(None, filt, (half, *shape[1:]), seed=11, stream_id=5, plane_offset=half * shape[1])
         assert torch.equal(torch.cat([a, b]), raw)
+
+
+def test_rng_groups_beyond_the_lookahead(api):
+    """The C ABI takes any RNG group up to 8 planes (the host passes 1 or 4): the look-ahead statistics cover four planes per unit, so
+    larger unsplit groups must be refused by sonar_power_noise_ahead_ok / _ahead_f32 and served by the two-launch form, whose
+    statistics cover every plane; beyond 8 planes per group nothing is launched."""
+    hl = api.hl
+    lib = hl.load()
+    shape = (256, 8, 128, 128)
+    planes = shape[0] * shape[1]
+    filt = _filter(api, shape)
+    assert lib.sonar_power_noise_ahead_ok(planes, 128, 128, 4) == 1      # 512 units of four planes
+    assert lib.sonar_power_noise_ahead_ok(planes, 128, 128, 8) == 0      # 256 units of eight planes: beyond the look-ahead's four
+    assert lib.sonar_power_noise_ahead_ok(64 * 8, 128, 128, 8) == 1      # 64 groups: single planes as units, any group size
+    out = torch.empty(shape, device="cuda")
+    ws, nws = hl.new_partials("cuda"), hl.new_partials("cuda")
+    st = hl._stream()
+    rc = lib.sonar_power_noise_ahead_f32(filt.data_ptr(), out.data_ptr(), planes, 128, 128, 3, 9, 0, 8, 1.0, 2.5, ws.data_ptr(), 0, 10, nws.data_ptr(), st)
+    assert rc == hl.ERR_UNSUPPORTED
+    raw = torch.empty(shape, device="cuda")
+    assert lib.sonar_power_irfft2_f32(None, filt.data_ptr(), raw.data_ptr(), planes, 128, 128, 3, 9, 0, 8, None, st) == 0
+    assert lib.sonar_power_noise_f32(filt.data_ptr(), out.data_ptr(), planes, 128, 128, 3, 9, 0, 8, 1.0, 2.5, ws.data_ptr(), st) == 0
+    d = raw.double()
+    torch.testing.assert_close(out, ((d - d.mean()) / d.std()).float(), rtol=2e-5, atol=2e-6)
+    assert abs(out.std().item() - 1.0) < 1e-4
+    assert lib.sonar_power_noise_f32(filt.data_ptr(), out.data_ptr(), planes, 128, 128, 3, 9, 0, 16, 1.0, 2.5, ws.data_ptr(), st) == hl.ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("shape", [(512, 4, 128, 128), (128, 4, 128, 128), (100, 3, 128, 128)])

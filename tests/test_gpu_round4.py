@@ -277,3 +277,63 @@ def test_trace_refuses_what_it_cannot_replay(api):
 
     res, plan = hl.trace_plan(with_escaping_scratch, SIG, take=ng.DeviceRNG.take, rewind=ng.DeviceRNG.rewind, guards=())
     assert plan is None and "outlives" in hl.trace_plan.last_reason
+
+
+def test_wavelet_kernels_take_tensors_at_odd_storage_offsets(api):
+    """cond / uncond / x / out as contiguous views one float into their storage (4-byte aligned only): the low-pass and band kernels
+    fall back from their 16- and 8-byte accesses instead of faulting or reading shifted data (advisor finding of round 3)."""
+    hl = api.hl
+    wf = importlib.import_module("comfyui_sonar_amd.py.wavelet_functions")
+    w = wf.Wavelet(wave="db4", level=3, mode="symmetric")
+    shape = (3, 4, 32, 32)
+    n = 3 * 4 * 32 * 32
+    torch.manual_seed(3)
+    base = [torch.randn(n + 4, device="cuda") for _ in range(3)]
+    aligned = [b[:n].clone().view(shape) for b in base]
+    for off in (1, 2):
+        odd = []
+        for b in base:
+            t = torch.empty(n + 4, device="cuda")
+            t[off:off + n] = b[:n]
+            odd.append(t[off:off + n].view(shape))
+        assert all(t.data_ptr() % 16 == 4 * off for t in odd)
+        for hp in (True, False):
+            kw = dict(levels=3, dec_lo=w.dec_lo, rec_lo=w.rec_lo, mode="symmetric", inv_mode="symmetric", g=[3.0, 0.5, -1.0, 2.0], ku=1.0, kt=0.7,
+                      subtract_from_x=True, high_precision=hp)
+            assert torch.equal(hl.wcfg_lowpass(*odd, **kw), hl.wcfg_lowpass(*aligned, **kw))
+            kb = dict(levels=3, dec_lo=w.dec_lo, dec_hi=w.dec_hi, rec_lo=w.rec_lo, rec_hi=w.rec_hi, mode="symmetric", inv_mode="symmetric",
+                      yh_scales=[[3.0, 2.5, 2.0], [1.0, 0.5, 0.25], [2.0, 2.0, 1.0]], yl_scale=1.5, ku=1.0, kt=0.7, subtract_from_x=True, high_precision=hp)
+            out_odd = torch.empty(n + 4, device="cuda")[off:off + n].view(shape)
+            assert torch.equal(hl.wcfg_bands(odd[0], odd[1], odd[2], out_odd, **kb), hl.wcfg_bands(*aligned, **kb))
+
+
+def test_folded_multiplies_are_the_multiply_passes(api):
+    """y * a + x * b in the accumulation kernel == multiply pass, multiply pass, add pass, bit for bit, for multipliers that are not powers
+    of two (MixedNoiseGenerator and the chains fold their factors this way; advisor finding of round 3) -- and the mixed presets draw
+    one part at a time."""
+    hl, nz = api.hl, api.nz
+    torch.manual_seed(8)
+    y, x = torch.randn(2, 4, 128, 128, device="cuda") * 3, torch.randn(2, 4, 128, 128, device="cuda")
+    for a, b in ((0.3, 0.7), (1.0, -0.8), (0.55, 1.0), (1.15, 0.2), (-0.3, 1e-3)):
+        fused = hl.axpby_(y.clone(), a, x, b)
+        seq = hl.axpby_(hl.scale_noise_(y.clone(), a, False, None) if a != 1.0 else y.clone(), 1.0,
+                        hl.scale_noise_(x.clone(), b, False, None) if b != 1.0 else x.clone(), 1.0)
+        assert torch.equal(fused, seq), (a, b)
+        with_stats, part = hl.axpby_stats_(y.clone(), a, x, b)
+        assert torch.equal(with_stats, seq)
+        torch.testing.assert_close(part.view(-1, 2).sum(0)[0], seq.double().sum(), rtol=1e-9, atol=1e-6)
+    # pyramid_mix = 0.2 * pyramid - 0.8 * pyramid, rainbow_mild = (0.55 g + 0.7 g) * 1.15: the same values from explicit passes
+    lat = torch.zeros((2, 4, 64, 64), device="cuda")
+    for name in ("pyramid_mix", "rainbow_mild", "onef_pinkishgreenish"):
+        torch.manual_seed(21)
+        got = nz.get_noise_sampler(name, lat, 0.03, 14.6, seed=None, cpu=False, normalized=False)(*SIG)
+        torch.manual_seed(21)
+        sampler = nz.get_noise_sampler(name, lat, 0.03, 14.6, seed=None, cpu=False, normalized=False)
+        gen = sampler.noise_sampler
+        total = None
+        for sub, transform in gen.ng_list:
+            part = sub(*SIG)
+            part = transform(part) if transform is not None else part
+            total = part if total is None else hl.axpby_(total, 1.0, part, 1.0)
+        total = gen.output_fun(total) if gen.output_fun is not None else total
+        torch.testing.assert_close(got, total, rtol=0, atol=0)
