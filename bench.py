@@ -310,29 +310,77 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
                 extra[f"wavelet_cfg_{rtag}_{tag}_error"] = repr(exc)[:200]
     # cfg5: one rank's shard (128 Flux latents), scheduled power + Perlin + Brownian chain, SonarDPMPPSDE with momentum, per step
     try:
-        xf = torch.randn(128, 16, H, W, device=device) * 10.0
-        inner = nz.CustomNoiseChain()
-        inner.add(power_item(pn, 0.5, "1"))
-        inner.add(nz.CustomNoiseItem(0.3, noise_type="perlin"))
-        inner.add(nz.CustomNoiseItem(0.2, noise_type="brownian"))
-        fallback = nz.CustomNoiseChain()
-        fallback.add(nz.CustomNoiseItem(1.0, noise_type="gaussian"))
-        chain = nz.CustomNoiseChain()
-        chain.add(nz.ScheduledNoise(1.0, noise=inner, start_sigma=20.0, end_sigma=0.0, normalize=None, fallback_noise=fallback))
-        sigmas = torch.cat([torch.linspace(14.6, 0.5, 11), torch.zeros(1)])
-        ns5 = chain.make_noise_sampler(xf, 0.5, 14.6, seed=3, cpu=False, normalized=True)
-
-        def run5():
-            return sonar.SonarDPMPPSDE.sampler(lambda t, sigma, **_k: hl.mul_scalar(t, 0.5), xf, sigmas[:6], {"seed": 3}, None, True, None, dict(momentum=0.95),
-                                               1.0, 1.0, ns5)
-
-        us = event_us(run5, 3, 1)
-        extra["cfg5_step_ms"] = us / 5 / 1e3  # 5 sampler steps per run (10 noise calls, 10 fake-model scalings)
-        extra["cfg5_latent_steps_per_s"] = 128 * 5 / (us * 1e-6)
-        del xf
+        extra["cfg5_step_ms"] = cfg5_shard_step_ms(device, hl, pn, nz, sonar)
+        extra["cfg5_latent_steps_per_s"] = 128 / (extra["cfg5_step_ms"] * 1e-3)
     except Exception as exc:
         extra["cfg5_error"] = repr(exc)[:200]
     return kernels, extra
+
+
+def cfg5_shard_step_ms(device, hl, pn, nz, sonar):
+    """cfg5 on one rank's shard (128 Flux latents): scheduled power + Perlin + Brownian chain, SonarDPMPPSDE with momentum; ms per sampler step
+    (5 steps per run: 10 noise calls, 10 stand-in model evaluations)."""
+    xf = torch.randn(128, 16, H, W, device=device) * 10.0
+    inner = nz.CustomNoiseChain()
+    inner.add(power_item(pn, 0.5, "1"))
+    inner.add(nz.CustomNoiseItem(0.3, noise_type="perlin"))
+    inner.add(nz.CustomNoiseItem(0.2, noise_type="brownian"))
+    fallback = nz.CustomNoiseChain()
+    fallback.add(nz.CustomNoiseItem(1.0, noise_type="gaussian"))
+    chain = nz.CustomNoiseChain()
+    chain.add(nz.ScheduledNoise(1.0, noise=inner, start_sigma=20.0, end_sigma=0.0, normalize=None, fallback_noise=fallback))
+    sigmas = torch.cat([torch.linspace(14.6, 0.5, 11), torch.zeros(1)])
+    ns5 = chain.make_noise_sampler(xf, 0.5, 14.6, seed=3, cpu=False, normalized=True)
+
+    def run5():
+        return sonar.SonarDPMPPSDE.sampler(lambda t, sigma, **_k: hl.mul_scalar(t, 0.5), xf, sigmas[:6], {"seed": 3}, None, True, None, dict(momentum=0.95),
+                                           1.0, 1.0, ns5)
+
+    return event_us(run5, 3, 1) / 5 / 1e3
+
+
+def cfg3_chain_us(device, nz, batch, sig):
+    """(host issue time, GPU span) per call of cfg3's chain -- Perlin + pyramid items of one CustomNoiseChain, normalised -- at `batch` latents."""
+    xb = torch.zeros((batch, C, H, W), device=device)
+    chain3 = nz.CustomNoiseChain()
+    chain3.add(nz.CustomNoiseItem(0.5, noise_type="perlin"))
+    chain3.add(nz.CustomNoiseItem(0.5, noise_type="pyramid"))
+    ns3 = chain3.make_noise_sampler(xb, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+    return host_and_event_us(lambda: ns3(*sig))
+
+
+def gpus_on_this_node() -> int:
+    """GPUs of this node counted WITHOUT a HIP / HSA call (the launcher role must not initialise the GPU: it starts other programs): KFD's
+    topology lists every compute agent, GPUs are the nodes with SIMDs; the visibility variables narrow the count like the runtime would."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    count = 0
+    try:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as fh:
+                    props = dict(line.split(None, 1) for line in fh if line.strip())
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            count = min(count, len([v for v in val.split(",") if v.strip()]))
+    return count
+
+
+def device_identity(index: int) -> dict:
+    """What tells two ranks' GPUs apart in the result line: PCI address, UUID, architecture."""
+    props = torch.cuda.get_device_properties(index)
+    ident = {"device_name": props.name, "gcn_arch": getattr(props, "gcnArchName", None)}
+    if all(hasattr(props, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        ident["pci_bus_id"] = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+    if getattr(props, "uuid", None) is not None:
+        ident["uuid"] = str(props.uuid)
+    return ident
 
 
 def _free_port() -> int:
@@ -343,9 +391,9 @@ def _free_port() -> int:
 
 def launch_ranks(n: int) -> None:
     """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes (torch.distributed.run, one per GPU)
-    and relay rank 0's JSON line and the launcher's exit code.  This process never touches the GPU (no HIP call, no library load:
-    `torch.cuda.device_count()` only counts), so starting other programs from it is safe on this pool."""
-    have = torch.cuda.device_count()
+    and relay rank 0's JSON line and the launcher's exit code.  This process never touches the GPU -- no HIP / HSA call, no library load;
+    the GPUs are counted from KFD's sysfs topology -- so starting other programs from it is safe on this pool."""
+    have = gpus_on_this_node()
     if have < n and os.environ.get("SONAR_BENCH_BACKEND", "nccl") == "nccl":
         print(f"[bench] --gpus {n} needs {n} GPUs on this node, {have} visible: not measuring fewer GPUs under that label",
               file=sys.stderr, flush=True)
@@ -491,7 +539,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank's wall clock and launch-pair time
             elapsed, pair_us_max = t[0].item(), t[1].item()
             ranks = [None] * n_gpus
-            dist.all_gather_object(ranks, {"rank": rank, "device": f"cuda:{device_index}", "device_name": torch.cuda.get_device_name(device_index),
+            dist.all_gather_object(ranks, {"rank": rank, "device": f"cuda:{device_index}", **device_identity(device_index),
                                            "shard_start": rank * BATCH, "shard_count": BATCH, "pair_us": pair_us_local})
         else:
             pair_us_max = pair_us_local
@@ -541,6 +589,43 @@ def main():
         out["extra"] = extra
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    if distributed and not args.no_extra:
+        # N > 1: the two configurations BASELINE.json defines beside the headline, on EVERY rank's own shard -- cfg5 is an 8-GPU job of 128
+        # Flux latents per rank, cfg3's chain runs at its configured 64 -- with the slowest and fastest rank in the line
+        sonar_mod = importlib.import_module("comfyui_sonar_amd.py.sonar")
+        mine = {"rank": rank}
+        with ng.shard_offset(rank * 128):
+            try:
+                mine["cfg5_step_ms"] = cfg5_shard_step_ms(device, hl, pn, nz, sonar_mod)
+            except Exception as exc:  # secondary figure only
+                mine["cfg5_error"] = repr(exc)[:200]
+        with ng.shard_offset(rank * 64):
+            try:
+                mine["cfg3_chain_b64_host_us"], mine["cfg3_chain_b64_us"] = cfg3_chain_us(device, nz, 64, sig)
+            except Exception as exc:
+                mine["cfg3_error"] = repr(exc)[:200]
+        per_rank = [None] * n_gpus
+        dist.all_gather_object(per_rank, mine)
+        if rank == 0:
+            def spread(key):
+                vals = [r[key] for r in per_rank if key in r]
+                return {"max": max(vals), "min": min(vals), "ranks": len(vals)} if vals else None
+
+            out["extra"] = {"per_rank": per_rank, "cfg5_shard_step_ms": spread("cfg5_step_ms"), "cfg3_chain_b64_us": spread("cfg3_chain_b64_us")}
+            ms = out["extra"]["cfg5_shard_step_ms"]
+            if ms:  # the job's rate: every rank steps its 128-latent shard, the slowest sets the pace
+                out["extra"]["cfg5_latent_steps_per_s"] = 128 * n_gpus / (ms["max"] * 1e-3)
+            us = out["extra"]["cfg3_chain_b64_us"]
+            if us:
+                out["extra"]["cfg3_chain_b64_latents_per_s"] = 64 * n_gpus / (us["max"] * 1e-6)
+    if rank == 0 and distributed:
+        rccl = None
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001 -- a build without the binding
+            pass
+        out["collectives"] = {"backend": dist.get_backend(), "rccl_version": rccl, "world_size": dist.get_world_size(),
+                              "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
     if rank == 0 and ranks is not None:
         out["ranks"] = ranks
     if distributed:

@@ -63,6 +63,16 @@ def test_bench_starts_its_own_ranks():
     g = out["extra"]["gather"]
     assert g["backend"] == backend and g["rccl_all_gather_ms"] > 0 and g["direct_peer_copies_ms"] > 0, g
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    # the line says which devices ran (two ranks sharing cuda:0 show the same address), what carried the collectives, and times the
+    # 8-GPU configurations on every rank's own shard
+    for r in out["ranks"]:
+        assert r["gcn_arch"].startswith("gfx950") and r["device_name"]
+        assert "pci_bus_id" in r or "uuid" in r
+    assert out["collectives"]["backend"] == backend and out["collectives"]["world_size"] == 2 and "rccl_version" in out["collectives"]
+    ex = out["extra"]
+    assert [r["rank"] for r in ex["per_rank"]] == [0, 1]
+    assert ex["cfg5_shard_step_ms"]["ranks"] == 2 and 0 < ex["cfg5_shard_step_ms"]["min"] <= ex["cfg5_shard_step_ms"]["max"]
+    assert ex["cfg3_chain_b64_us"]["ranks"] == 2 and ex["cfg3_chain_b64_latents_per_s"] > 0 and ex["cfg5_latent_steps_per_s"] > 0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() >= 3, reason="the box really has 3 GPUs")
