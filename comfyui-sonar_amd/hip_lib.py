@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading as _threading
 import weakref
 from typing import Optional, Sequence
 
@@ -193,7 +194,8 @@ def load() -> C.CDLL:
     """Load libsonar_hip.so or raise (never falls back to anything else)."""
     global _lib
     if _lib is not None:
-        return _lib if _recorder is None else _recorder.lib
+        # a call being traced into a plan sees the recording proxy -- on the tracing thread only (a preview thread keeps the plain library)
+        return _lib if _recorder is None or _recorder.thread != _threading.get_ident() else _recorder.lib
     if not os.path.exists(LIB_PATH):
         raise SonarHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -276,7 +278,7 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
     if not t.is_contiguous():
         raise SonarHipError(f"{name}: tensor must be contiguous")
     _last_device = t.device.index
-    if _recorder is not None:
+    if _recorder is not None and _recorder.thread == _threading.get_ident():
         _recorder.seen[t.data_ptr()] = t
     return t.data_ptr()
 
@@ -1658,6 +1660,7 @@ class _RecordingLib:
 class _Recorder:
     def __init__(self, lib):
         self.lib = _RecordingLib(lib, self)
+        self.thread = _threading.get_ident()  # only this thread's calls and allocations belong to the trace
         self.calls = []       # (name, args)
         self.seen = {}        # address -> tensor handed to a kernel through _dev (constants the plan keeps alive)
         self.temps = []       # tensors allocated while the call ran
@@ -1689,7 +1692,7 @@ class _Recorder:
         self.count += count
 
     def on_alloc(self, t):
-        if isinstance(t, torch.Tensor) and t.is_cuda:
+        if isinstance(t, torch.Tensor) and t.is_cuda and self.thread == _threading.get_ident():
             self.temps.append(t)
         return t
 
@@ -2005,7 +2008,6 @@ def _alloc_hooks(rec: _Recorder):
     return real_empty, real_empty_like, empty, empty_like
 
 
-import threading as _threading  # noqa: E402
 
 _trace_lock = _threading.Lock()
 
@@ -2148,7 +2150,7 @@ class Planned:
                 setattr(self, name, getattr(fn, name))
 
     def __call__(self, sigma=None, sigma_next=None):
-        if PLANS_ENABLED and _recorder is None:
+        if PLANS_ENABLED and (_recorder is None or _recorder.thread != _threading.get_ident()):
             plan = self.plan
             if plan is not None:
                 out = plan.run()

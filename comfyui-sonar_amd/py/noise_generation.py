@@ -101,7 +101,7 @@ class DeviceRNG:
             gen.set_offset(offset + 4 * int(count))  # Philox offsets move in units of 4
         seed = gen.initial_seed()
         rec = hip_lib._recorder
-        if rec is not None:  # the call is being traced into a prepared plan: its stream ids are relative to this position
+        if rec is not None and rec.thread == threading.get_ident():  # this call is being traced into a prepared plan: its stream ids are relative to this position
             rec.on_take(seed, offset // 4, int(count))
         return seed, offset // 4
 

@@ -337,3 +337,39 @@ def test_folded_multiplies_are_the_multiply_passes(api):
             total = part if total is None else hl.axpby_(total, 1.0, part, 1.0)
         total = gen.output_fun(total) if gen.output_fun is not None else total
         torch.testing.assert_close(got, total, rtol=0, atol=0)
+
+
+def test_a_trace_only_sees_its_own_thread(api):
+    """While one thread traces a step into a plan another thread (ComfyUI's preview thread, say) keeps calling the library: its calls
+    and allocations are not the trace's, and both get their usual results."""
+    import threading
+
+    hl, nz = api.hl, api.nz
+    x = torch.zeros((2, 4, 64, 64), device="cuda")
+    ns = nz.get_noise_sampler("perlin", x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+    ref = nz.get_noise_sampler("perlin", x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+    stop, errors, side = threading.Event(), [], []
+
+    def other():
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                t = torch.randn(4096, device="cuda")
+                while not stop.is_set():
+                    side.append(float(hl.stats_finalize(hl.stats(t), t.numel())[0].item()))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    th = threading.Thread(target=other)
+    th.start()
+    try:
+        while len(side) < 3 and not errors:
+            pass
+        got = _run(api, ns, 8, True)
+    finally:
+        stop.set()
+        th.join()
+    assert not errors and len(set(side)) == 1
+    assert ns._planned.plan is not None and hl.load().sonar_plan_length(ns._planned.plan.handle) == 2
+    assert _same(got, _run(api, ref, 8, False))
