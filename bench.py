@@ -123,20 +123,29 @@ def event_us(fn, steps=20, warmup=5):
     return e0.elapsed_time(e1) / steps * 1e3
 
 
-def host_and_event_us(fn, steps=200, warmup=100):
-    """(host issue time per call, GPU span per call) in microseconds: what a launch-bound step costs on either side."""
+def host_and_event_us(fn, steps=200, warmup=100, burst=25):
+    """(host issue time per call, GPU span per call) in microseconds: what a launch-bound step costs on either side.  Issued in bursts of
+    `burst` calls with a synchronisation between them: a host that issues a step in 10 us runs hundreds of steps ahead of a GPU that needs
+    30, and once the runtime's command queue is full every further launch blocks in the driver for far longer than either figure (seen
+    as 200+ us per call on both clocks).  A sampler never queues more than a few noise calls ahead."""
     for _ in range(warmup):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
-        fn()
-    host = (time.perf_counter() - t0) / steps * 1e6
-    e1.record()
-    torch.cuda.synchronize()
-    return host, e0.elapsed_time(e1) / steps * 1e3
+    host = gpu = 0.0
+    done = 0
+    while done < steps:
+        n = min(burst, steps - done)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(n):
+            fn()
+        host += time.perf_counter() - t0
+        e1.record()
+        torch.cuda.synchronize()
+        gpu += e0.elapsed_time(e1)
+        done += n
+    return host / steps * 1e6, gpu / steps * 1e3
 
 
 def traffic_table() -> dict:

@@ -90,6 +90,39 @@ const Replayable kReplayable[] = {
     SONAR_REPLAYABLE(sonar_std_scale_f32),
     SONAR_REPLAYABLE(sonar_powerlaw_f32),
     SONAR_REPLAYABLE(sonar_mul_table_f32),
+    SONAR_REPLAYABLE(sonar_stats_finalize),
+    SONAR_REPLAYABLE(sonar_scale_noise_rows_f32),
+    SONAR_REPLAYABLE(sonar_blend_f32),
+    SONAR_REPLAYABLE(sonar_blend_tensor_f32),
+    SONAR_REPLAYABLE(sonar_scalar_op_f32),
+    SONAR_REPLAYABLE(sonar_rowstats_f32),
+    SONAR_REPLAYABLE(sonar_row_affine_f32),
+    SONAR_REPLAYABLE(sonar_amax_mid_f32),
+    SONAR_REPLAYABLE(sonar_div_mid_f32),
+    SONAR_REPLAYABLE(sonar_mask_mix_f32),
+    SONAR_REPLAYABLE(sonar_minmax_rows_f32),
+    SONAR_REPLAYABLE(sonar_minmax_rescale_f32),
+    SONAR_REPLAYABLE(sonar_levels_sampled_f32),
+    SONAR_REPLAYABLE(sonar_level_normal_f32),
+    SONAR_REPLAYABLE(sonar_resample_acc_f32),
+    SONAR_REPLAYABLE(sonar_power_spectrum_f32),
+    SONAR_REPLAYABLE(sonar_rfft2_f32),
+    SONAR_REPLAYABLE(sonar_cdft_mid_f32),
+    SONAR_REPLAYABLE(sonar_spectral_logamp_f32),
+    SONAR_REPLAYABLE(sonar_spectral_signum_mask_f32),
+    SONAR_REPLAYABLE(sonar_std_mid_f32),
+    SONAR_REPLAYABLE(sonar_bcast_gain_f32),
+    SONAR_REPLAYABLE(sonar_ratio_mix_f32),
+    SONAR_REPLAYABLE(sonar_sq_acc_f32),
+    SONAR_REPLAYABLE(sonar_studentt_f32),
+    SONAR_REPLAYABLE(sonar_abs_quantile_rows_f32),
+    SONAR_REPLAYABLE(sonar_clamp_signpow_rows_f32),
+    SONAR_REPLAYABLE(sonar_laplace_add_f32),
+    SONAR_REPLAYABLE(sonar_dft_rows_r2c_f32),
+    SONAR_REPLAYABLE(sonar_dft_cols_f32),
+    SONAR_REPLAYABLE(sonar_dft_rows_c2r_f32),
+    SONAR_REPLAYABLE(sonar_perlin_terms_f32),
+    SONAR_REPLAYABLE(sonar_perlin_apply_f32),
 };
 #undef SONAR_REPLAYABLE
 constexpr int kReplayableCount = (int)(sizeof(kReplayable) / sizeof(kReplayable[0]));

@@ -1994,19 +1994,41 @@ def _rebuild(spec, fresh):
     return tuple(_rebuild(s, fresh) for s in spec[1])
 
 
-def _alloc_hooks(rec: _Recorder):
-    """torch.empty / torch.empty_like as seen by the traced call: every tensor it allocates is noted (and kept alive until the trace
-    ends, so two of them never share an address)."""
-    real_empty, real_empty_like = torch.empty, torch.empty_like
+# torch operations a traced step may run on device tensors: allocations (noted) and metadata-only views.  Anything else on a device
+# tensor -- an arithmetic kernel of torch's own, a copy, an .item() -- is work the recorded entry points would not replay: no plan.
+_TRACE_ALLOCS = frozenset(("empty", "empty_like", "empty_strided", "new_empty"))
+_TRACE_VIEWS = frozenset(("view", "reshape", "_unsafe_view", "as_strided", "alias", "detach", "expand", "slice", "select", "t", "transpose", "permute",
+                          "unsqueeze", "squeeze", "flatten", "unflatten", "narrow", "view_as", "_reshape_alias", "lift_fresh", "unbind", "split",
+                          "is_same_size", "sym_size", "sym_stride", "sym_numel", "sym_storage_offset", "size", "stride", "numel", "dim",
+                          "is_contiguous", "storage_offset", "data_ptr"))
 
-    def empty(*a, **k):
-        return rec.on_alloc(real_empty(*a, **k))
 
-    def empty_like(*a, **k):
-        return rec.on_alloc(real_empty_like(*a, **k))
+def _tensors_in(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors_in(o)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors_in(o)
 
-    return real_empty, real_empty_like, empty, empty_like
 
+def _trace_mode(rec: _Recorder):
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class TraceMode(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            name = func.overloadpacket.__name__ if hasattr(func, "overloadpacket") else str(func)
+            if name in _TRACE_ALLOCS:
+                for t in _tensors_in(out):
+                    rec.on_alloc(t)
+            elif name not in _TRACE_VIEWS and any(t.is_cuda for t in _tensors_in((args, kwargs, out))):
+                rec.fail(f"torch operation aten.{name} on a device tensor inside the step")
+            return out
+
+    return TraceMode()
 
 
 _trace_lock = _threading.Lock()
@@ -2020,14 +2042,12 @@ def trace_plan(fn, args, *, take, rewind, guards):
     if not _trace_lock.acquire(blocking=False):
         return fn(*args), None
     rec = _Recorder(lib)
-    real_empty, real_empty_like, empty, empty_like = _alloc_hooks(rec)
     try:
         _recorder = rec
-        torch.empty, torch.empty_like = empty, empty_like
         try:
-            result = fn(*args)
+            with _trace_mode(rec):  # thread-local: sees this thread's torch operations only
+                result = fn(*args)
         finally:
-            torch.empty, torch.empty_like = real_empty, real_empty_like
             _recorder = None
         plan = None
         try:
@@ -2058,6 +2078,9 @@ def _build_plan(rec: _Recorder, result, take, rewind, guards) -> Plan:
         raise PlanError("the call launched nothing")
     b = _PlanBuilder(rec, result)
     records = [b.record(name, args) for name, args in rec.calls]
+    # the tensors the entry points were handed are known now (constants are kept by the builder): let go of them, so that the only
+    # holders of a temporary's storage left are this trace's own note of the allocation -- and whoever else kept it (checked below)
+    rec.seen.clear()
     # what the result owns must be fresh per call: the tensors handed back and the statistics partials tagged onto them
     owned = {}  # id(temp) -> index in the fresh list
 
@@ -2101,9 +2124,9 @@ def _build_plan(rec: _Recorder, result, take, rewind, guards) -> Plan:
         elif key not in owned:
             t = by_id[key]
             # a scratch tensor somebody else still holds after the call (a generator's cache filled during this very call) is not scratch:
-            # views of it show in the storage's use count, the tensor object itself is checked by trace_plan once the trace lets go of it
+            # every live tensor on its storage shows in the storage's use count (2 = the trace's own note + the handle asked for here)
             if torch._C._storage_Use_Count(t.untyped_storage()._cdata) > 2:
-                raise PlanError("a tensor allocated during the call outlives it (a view of it is still held)")
+                raise PlanError("a tensor allocated during the call outlives it")
             scratch.append((slot, tuple(t.shape), t.dtype))
             b.scratch_refs.append(weakref.ref(t))
     for h in rec.hooks:

@@ -285,6 +285,10 @@ class MixedNoiseGenerator(NoiseGenerator):
         passed = {k: v for k, v in kwargs.items() if k in self.pass_args}
         self.ng_list = [(klass(x, **klass_kwargs, **passed), transform) for klass, klass_kwargs, transform in self.noise_mix]
 
+    @property
+    def PLAN_STATIC(self) -> bool:  # noqa: N802 -- the generators' class attribute, here a function of the parts
+        return all(getattr(gen, "PLAN_STATIC", False) for gen, _ in self.ng_list)
+
     def generate(self, *args):
         # total = sum_i transform_i(part_i), then output_fun.  A transform that only multiplies (``scale_factor``: the presets' _scaled)
         # rides in the accumulation kernel -- y * a + x * b rounds each product before the add, exactly like the multiply pass followed
@@ -685,6 +689,7 @@ class PyramidOldNoiseGenerator(FramesToChannelsNoiseGenerator):
     """py/noise_generation.py:567-606: levels at 2x..32x resolution, normal(std=0.5**i), scaled down."""
 
     name = "pyramid_old"
+    PLAN_STATIC = True
 
     @classmethod
     def ng_params(cls):
@@ -724,6 +729,7 @@ class LaplacianNoiseGenerator(NoiseGenerator):
     (eps - 1, 1) from the global generator, then loc - scale * sign(u) * log1p(-|u|))."""
 
     name = "laplacian"
+    PLAN_STATIC = True
 
     @classmethod
     def ng_params(cls):
@@ -748,6 +754,7 @@ class PowerOldNoiseGenerator(NoiseGenerator):
     k / (batch index + 1)^alpha per latent and standardises every [H, W] plane ((x - mean) / std, unbiased); same steps here."""
 
     name = "power_old"
+    PLAN_STATIC = True
 
     @classmethod
     def ng_params(cls):
@@ -834,6 +841,7 @@ class PowerLawNoiseGenerator(NoiseGenerator):
     (sign(x) or x) * |x|**alpha, optionally divided by the max |.| over ``div_max_dims``."""
 
     name = "powerlaw"
+    PLAN_STATIC = True
 
     @classmethod
     def ng_params(cls):
@@ -912,6 +920,7 @@ class PinkOldNoiseGenerator(NoiseGenerator):
     """py/noise_generation.py:707-718 (a scalar gain; the reference itself calls it wrong)."""
 
     name = "pink_old"
+    PLAN_STATIC = True
 
     @classmethod
     def ng_params(cls):
@@ -934,6 +943,7 @@ class _SpectralGainNoiseGenerator(FramesToChannelsNoiseGenerator):
 
     MIN_DIMS = 4
     MAX_DIMS = 5
+    PLAN_STATIC = True
 
     def spectral_gain(self) -> torch.Tensor:  # full [H, W] real gain, host (setup arithmetic as the reference writes it)
         raise NotImplementedError
