@@ -373,3 +373,51 @@ def test_a_trace_only_sees_its_own_thread(api):
     assert not errors and len(set(side)) == 1
     assert ns._planned.plan is not None and hl.load().sonar_plan_length(ns._planned.plan.handle) == 2
     assert _same(got, _run(api, ref, 8, False))
+
+
+REGISTRY_TYPES = ["gaussian", "uniform", "perlin", "pyramid", "pyramid_area", "pyramid_discount5", "pyramid_mix", "pyramid_mix_area", "pyramid_old",
+                  "pyramid_old_area", "highres_pyramid", "laplacian", "power_old", "pink_old", "white", "grey", "velvet", "violet", "onef_pinkish",
+                  "onef_greenish", "onef_pinkishgreenish", "onef_pinkish_mix", "onef_greenish_mix", "green_test", "rainbow_mild", "rainbow_intense",
+                  "studentt", "wavelet", "brownian"]
+NOT_STATIC = {"highres_pyramid", "studentt", "wavelet", "brownian"}  # host draws per call / torch arithmetic / functions of the sigmas
+
+
+@pytest.mark.parametrize("normalized", [True, False])
+@pytest.mark.parametrize("name", REGISTRY_TYPES)
+def test_every_registry_type_replays_or_declines(api, name, normalized):
+    """Every registry type the path runs, at 2 latents: the types whose step is a function of the RNG position get a plan and the replayed
+    step is the ordinary step bit for bit (NaN where the reference's own arithmetic gives NaN); the others keep the ordinary path."""
+    x = torch.zeros((2, 4, 64, 64), device="cuda")
+    make = lambda: api.nz.get_noise_sampler(name, x, 0.03, 14.6, seed=5, cpu=False, normalized=normalized)  # noqa: E731
+    a, b = make(), make()
+    ra, rb = _run(api, a, 7, True), _run(api, b, 7, False)
+    for p, q in zip(ra, rb):
+        assert torch.equal(torch.isnan(p[0]), torch.isnan(q[0])) and torch.equal(torch.nan_to_num(p[0]), torch.nan_to_num(q[0]))
+        assert p[-1] == q[-1]
+    planned = _planned(api, a)
+    if name in NOT_STATIC:
+        assert planned is None
+    else:
+        assert planned is not None and planned.plan is not None, getattr(planned, "reason", None)
+        assert planned.plan.runs == 4
+
+
+def test_torch_work_inside_a_step_means_no_plan(api):
+    """A step that runs a torch kernel of its own on a device tensor (here: an in-place multiply between two entry points) cannot be
+    replayed from the recorded entry points alone: the trace sees the operation and declines."""
+    hl, ng = api.hl, api.ng
+
+    def step(_s, _sn):
+        t = hl.philox_normal((2, 4, 64, 64), "cuda", *ng.DeviceRNG.take())
+        t.mul_(2.0)
+        return hl.scale_noise_(t, 0.5, False, None)
+
+    res, plan = hl.trace_plan(step, SIG, take=ng.DeviceRNG.take, rewind=ng.DeviceRNG.rewind, guards=())
+    assert plan is None and "torch operation aten.mul_" in hl.trace_plan.last_reason and res.shape == (2, 4, 64, 64)
+
+    def with_item(_s, _sn):
+        t = hl.philox_normal((2, 4, 64, 64), "cuda", *ng.DeviceRNG.take())
+        return hl.scale_noise_(t, float(t[0, 0, 0, 0].item()), False, None)
+
+    _res, plan = hl.trace_plan(with_item, SIG, take=ng.DeviceRNG.take, rewind=ng.DeviceRNG.rewind, guards=())
+    assert plan is None and "torch operation" in hl.trace_plan.last_reason
