@@ -51,9 +51,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 if not os.path.exists(TRAFFIC_FILE):
-    TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 BATCH = 512
 C, H, W = 4, 128, 128
 N_LATENT = C * H * W
@@ -153,6 +153,25 @@ def traffic_table() -> dict:
         with open(TRAFFIC_FILE) as fh:
             return json.load(fh)
     return {}
+
+
+def valu_active_per_launch():
+    """SQ_ACTIVE_INST_VALU of the headline kernel per dispatch (rocprofv3 --pmc pass of the round's profile set, profiles/r04_pmc_issue_a.txt):
+    vector-ALU busy cycles summed over the chip's 1024 SIMDs; None when the profile file is absent."""
+    path = os.path.join(ROOT, "profiles", "r04_pmc_issue_a.txt")
+    try:
+        inside = False
+        with open(path) as fh:
+            for line in fh:
+                if "power_pipe_kernel" in line:
+                    inside = True
+                elif inside and "SQ_ACTIVE_INST_VALU" in line:
+                    return float(line.split()[-1])
+                elif inside and line.startswith("void "):
+                    inside = False
+    except OSError:
+        pass
+    return None
 
 
 def kernel_entry(name, us, bytes_per_launch, traffic, note=None):
@@ -302,8 +321,9 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
                                         "end to end adds the reference's sigma.max().item() sync and the host rule logic"))
         except Exception as exc:  # secondary figure only; the headline must still print
             extra[f"wavelet_cfg_{tag}_error"] = repr(exc)[:200]
-    # the rules the low-pass kernel does not take: per-orientation difference scales (one tensor, cond - uncond, through the band kernels)
-    # and cond / uncond scales beside the difference (both tensors transformed) -- three launches with the level-1 bands through HBM
+    # the rules the low-pass kernel does not take: per-orientation difference scales (one tensor, cond - uncond) and cond / uncond scales
+    # beside the difference (both tensors transformed): level 1 by the tile kernels (its bands cross HBM), levels 2-5 by the LDS-resident
+    # band kernel, launched before the sigma value is known (round 4)
     band_rules = {"bands_difference": dict(difference=dict(yl_scale=5.0, yh_scales=[[3.0, 2.5, 2.0]] * 5)),
                   "bands_pair": dict(cond=dict(yl_scale=1.1, yh_scales=1.0), uncond=dict(yl_scale=1.0, yh_scales=0.9),
                                      difference=dict(yl_scale=5.0, yh_scales=3.0))}
@@ -313,8 +333,16 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
                 cfg_fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(**params, high_precision_mode=hp))
                 us = event_us(lambda: cfg_fn(wargs), 10, 3)
                 extra[f"wavelet_cfg_{rtag}_{tag}_end_to_end_us"] = us
-                kernels.append(kernel_entry(f"dwt2_tile / wcfg_deep / idwt2_tile kernels, WaveletCFG {rtag.replace('_', ' ')} rule, {tag}, batch 256 "
-                                            "(end to end)", us, 16 * N_LATENT * b4, tr.get(f"wcfg_{rtag}_{tag}_b256", {}).get("hbm_bytes_per_launch")))
+                kernels.append(kernel_entry(f"dwt2_tile + wcfg_bands (levels 2-5 resident in LDS) + idwt2_tile kernels, WaveletCFG {rtag.replace('_', ' ')} "
+                                            f"rule, {tag}, batch 256 (end to end)", us, 16 * N_LATENT * b4,
+                                            tr.get(f"wcfg_{rtag}_{tag}_b256", {}).get("hbm_bytes_per_launch")))
+                # the same rule with EVERY band resident in LDS (sonar_wcfg_bands_*: one launch, two for the cond / uncond rule): least traffic,
+                # one or two workgroups per CU -- off by default
+                wc.WaveletCFG.single_launch_bands = True
+                try:
+                    extra[f"wavelet_cfg_{rtag}_{tag}_single_launch_us"] = event_us(lambda: cfg_fn(wargs), 10, 3)
+                finally:
+                    wc.WaveletCFG.single_launch_bands = False
             except Exception as exc:  # secondary figure only
                 extra[f"wavelet_cfg_{rtag}_{tag}_error"] = repr(exc)[:200]
     # cfg5: one rank's shard (128 Flux latents), scheduled power + Perlin + Brownian chain, SonarDPMPPSDE with momentum, per step
@@ -559,7 +587,7 @@ def main():
             peak = HBM_PEAK_GBPS * n_gpus  # the job's roofline: N x 8 TB/s
             # one call = the final pass (draw, filter, LDS-resident C2R FFT, normalise, ONE write) + one statistics computation (re-draw
             # of the radius words, Parseval, no stores: in the final pass's idle waves, or its own launch): 4N bytes per latent really
-            # cross HBM (profiles/r03_traffic.json)
+            # cross HBM (profiles/r04_traffic.json)
             real_bytes = 4 * N_LATENT * BATCH * n_gpus  # all ranks' launches together
             contract_bytes = 12 * N_LATENT * BATCH * n_gpus
             achieved = real_bytes / (pair_us * 1e-6) / 1e9
@@ -574,10 +602,14 @@ def main():
                            "stats_lookahead": not args.no_lookahead,
                            "parallelism": f"batch-shard x{n_gpus}"},
                 "roofline": {"bound": "valu", "limiter": "vector-ALU issue + LDS / barrier latency of two 8-wave teams per CU (phase timeline and counters: "
-                                                         "profiles/r03_power_kernel.md); HBM moves 4N per latent and would allow ~21 us per launch",
+                                                         "profiles/r04_power_kernel.md); HBM moves 4N per latent and would allow ~21 us per launch",
                              "kernel": "power_pipe_kernel<128,128,NORM> with the next call's statistics in its idle waves (one C-ABI call, "
                                        "sonar_power_noise_ahead_f32); --no-lookahead: power_stats_kernel<128,128> + power_pipe_kernel",
                              "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                             "frac_valu": None if valu_active_per_launch() is None else 4.0 * valu_active_per_launch() / 1024 / (pair_us * 2400.0),
+                             "frac_valu_note": "what `bound` names: vector-ALU busy cycles per SIMD (4 x SQ_ACTIVE_INST_VALU -- the counter ticks "
+                                               "once per 4-cycle issue -- / 1024 SIMDs, profiles/r04_pmc_issue_a.txt) over the launch's cycles at "
+                                               "the 2.4 GHz engine clock",
                              "traffic": tr.get("power_noise_b512", {}).get("hbm_bytes_per_launch"), "bytes_per_launch": real_bytes,
                              "avg_launch_us": pair_us, "achieved_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9,
                              "frac_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9 / peak,

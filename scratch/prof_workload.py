@@ -1,4 +1,4 @@
-"""Workload for the round-2 PMC passes: every kernel whose HBM traffic profiles/r02_traffic.json reports, a few launches each, at the
+"""Workload for the PMC passes (rounds 2-4): every kernel whose HBM traffic profiles/r02_traffic.json reports, a few launches each, at the
 sizes bench.py times them, plus three calibration kernels with known byte counts (see scratch/calib.py)."""
 import importlib, os, sys, types, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,15 +39,21 @@ cond, uncond, xin = (torch.randn(b4, 4, 128, 128, device=dev) for _ in range(3))
 wargs = {"cond_denoised": cond, "uncond_denoised": uncond, "cond": xin - cond, "uncond": xin - uncond, "input": xin, "cond_scale": 7.0,
          "sigma": torch.full((b4,), 7.0, device=dev), "model": types.SimpleNamespace(model_sampling=ms),
          "model_options": {"transformer_options": {"sample_sigmas": torch.cat([torch.linspace(14.6, 0.03, 20), torch.zeros(1)])}}}
-real_low, real_pr = wc.WaveletCFG._lowpass_launch, wc._reconstructs
+# WaveletCFG: the placeholder rule (low-pass kernel), a rule with per-orientation difference scales and one that also scales cond / uncond
+# (level 1 by the tile kernels, deeper levels by the LDS-resident band kernel), then the same two rules through the single-launch band kernel
+rules = {"placeholder": dict(difference=dict(yl_scale=5.0, yh_scales=3.0)),
+         "bands_difference": dict(difference=dict(yl_scale=5.0, yh_scales=[[3.0, 2.5, 2.0]] * 5)),
+         "bands_pair": dict(cond=dict(yl_scale=1.1, yh_scales=1.0), uncond=dict(yl_scale=1.0, yh_scales=0.9), difference=dict(yl_scale=5.0, yh_scales=3.0))}
 for hp in (True, False):
-    fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(difference=dict(yl_scale=5.0, yh_scales=3.0), high_precision_mode=hp))
-    for _ in range(REPS): fn(wargs)                       # low-pass path (one launch)
-    wc.WaveletCFG._lowpass_launch = classmethod(lambda cls, **_k: None)
-    for _ in range(REPS): fn(wargs)                       # band path, one tensor (cond - uncond): dwt2_tile_kernel<.., 2, ..>, wcfg_deep_kernel<.., true>, idwt2_tile_kernel<.., 2, ..>
-    wc._reconstructs = lambda w: False
-    for _ in range(REPS): fn(wargs)                       # band path, cond and uncond side by side (any rule): <.., 1, ..>, <.., false>, <.., 1, ..>
-    wc.WaveletCFG._lowpass_launch, wc._reconstructs = real_low, real_pr
+    fns = {k: wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(**v, high_precision_mode=hp)) for k, v in rules.items()}
+    for k in ("placeholder", "bands_difference", "bands_pair"):
+        for _ in range(REPS): fns[k](wargs)
+    wc.WaveletCFG.single_launch_bands = hp  # fp64 only: in fp32 the single-launch kernel and the deeper levels' kernel are one instantiation
+    for k in (("bands_difference", "bands_pair") if hp else ()):
+        fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(**rules[k], high_precision_mode=hp))
+        for _ in range(REPS): fn(wargs)
+    wc.WaveletCFG.single_launch_bands = False
+    torch.cuda.synchronize()
 del cond, uncond, xin, wargs
 # cfg5's Brownian source on one rank's shard (128 Flux latents): one new path point per call, bridged between kept tensors; then the
 # same folded into a running sum (the chain form)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/rNN_traffic.json from tools/rocpd_traffic.py's per-kernel table (scratch/prof_r03.sh writes it as traffic_raw.json):
+"""profiles/rNN_traffic.json from tools/rocpd_traffic.py's per-kernel table (scratch/prof_r04.sh writes it as traffic_raw.json):
     python tools/make_traffic_json.py gpurun_out/r03/traffic_raw.json > profiles/r03_traffic.json
 Kernels are picked by name fragments; batch-512 and batch-64 launches of one kernel (same name) are split in proportion to the batch."""
 import json
@@ -21,7 +21,7 @@ def total(*rows):
 
 def main(path):
     raw = json.load(open(path))
-    out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over scratch/prof_workload.py (scratch/prof_r03.sh, "
+    out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over scratch/prof_workload.py (scratch/prof_r04.sh, "
                    "tools/rocpd_traffic.py, tools/make_traffic_json.py); raw counters are KiB per dispatch.  hbm_bytes_per_launch = 2 x FETCH_SIZE + "
                    "WRITE_SIZE: the gfx950 correction of MI355X_MICROARCH.md, confirmed in the same run by the calibration kernels below "
                    "(one 134 217 728-byte tensor written / read / read + written)."}
@@ -56,14 +56,23 @@ def main(path):
         low = pick(raw, f"wcfg_lowpass_kernel<{T},")
         out[f"wcfg_lowpass_{tag}_b256"] = dict(low, algorithmic_bytes_16N=4 * 256 * N, ratio_to_16N=round(low["hbm_bytes_per_launch"] / (4 * 256 * N), 2),
                                                note="cond and uncond are read twice (analysis, then the output phase); the second read mostly comes out of the "
-                                                    "256 MB memory-side cache: removing it (profiling build) saves 8-10 us of the kernel's 97 / 112 us")
-        for route, mode, deep in (("bands_difference", "2", "true"), ("bands_pair", "1", "false")):
+                                                    "256 MB memory-side cache: removing it (profiling build) saves 8-10 us of the kernel's time")
+        # round 4: the deeper levels run in wcfg_bands_kernel<T, T> (coefficients resident in LDS) -- once for difference-only rules, twice
+        # (A . DWT(cond) + B . DWT(uncond)) for rules that scale cond / uncond / final as well
+        deep = pick(raw, f"wcfg_bands_kernel<{T}, {T},")
+        for route, mode, ndeep in (("bands_difference", "2", 1), ("bands_pair", "1", 2)):
             ks = {"dwt2_tile_kernel (level 1 analysis)": pick(raw, f"dwt2_tile_kernel<{T}, float, {mode},"),
-                  "wcfg_deep_kernel (levels 2..5)": pick(raw, f"wcfg_deep_kernel<{T},", f", {deep}>"),
+                  f"wcfg_bands_kernel<{T}, {T}> (levels 2..5 in LDS) x {ndeep}": dict(deep, launches=ndeep),
                   "idwt2_tile_kernel (level 1 synthesis + output)": pick(raw, f"idwt2_tile_kernel<{T}, {mode},")}
-            tot = total(*ks.values())
+            tot = int(sum(v["hbm_bytes_per_launch"] * v.get("launches", 1) for v in ks.values()))
             out[f"wcfg_{route}_{tag}_b256"] = {"kernels": ks, "hbm_bytes_per_launch": tot, "algorithmic_bytes_16N": 4 * 256 * N,
                                                "ratio_to_16N": round(tot / (4 * 256 * N), 2)}
+        if T == "float":
+            continue  # the fp32 single-launch kernel is the deep kernel's instantiation (<float, float>): the workload runs it in fp64 only
+        one = pick(raw, f"wcfg_bands_kernel<{T}, float,")
+        out[f"wcfg_single_launch_bands_{tag}_b256"] = dict(one, algorithmic_bytes_16N=4 * 256 * N, ratio_to_16N=round(one["hbm_bytes_per_launch"] / (4 * 256 * N), 2),
+                                                           note="sonar_wcfg_bands_*: every coefficient band resident in LDS, one launch per difference-only rule "
+                                                                "(two for cond / uncond rules; bytes per launch here); off by default -- see DESIGN.md 3.6")
     br = pick(raw, "brownian_burst_kernel<0>")
     out["brownian_bridge_cfg5_shard"] = dict(br, tensor_bytes=128 * 16 * 128 * 128 * 4,
                                              note="128 x 16 x 128 x 128: reads the kept neighbour tensor(s), writes W(t) and the increment (or reads and "
