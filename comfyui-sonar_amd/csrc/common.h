@@ -194,18 +194,23 @@ __device__ __forceinline__ void block_sum2(double& s, double& q, double* red) {
 
 // Every stats-producing kernel owns partial slot blockIdx.x (grid <= kNPart); block 0 zeroes the
 // slots no block owns, so consumers can always reduce all kNPart pairs in a fixed order.
+// `bid` of `nb`: the block's index among the blocks that own a slot (a kernel whose grid also holds other work passes its own)
 template <int BLOCK>
-__device__ __forceinline__ void write_partial(double s, double q, double* partials, double* red) {
+__device__ __forceinline__ void write_partial_at(double s, double q, double* partials, double* red, int bid, int nb) {
     block_sum2<BLOCK>(s, q, red);
     if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x + 0] = s;
-        partials[2 * blockIdx.x + 1] = q;
+        partials[2 * bid + 0] = s;
+        partials[2 * bid + 1] = q;
     }
-    if (blockIdx.x == 0)
-        for (int j = gridDim.x + threadIdx.x; j < kNPart; j += BLOCK) {
+    if (bid == 0)
+        for (int j = nb + threadIdx.x; j < kNPart; j += BLOCK) {
             partials[2 * j] = 0.0;
             partials[2 * j + 1] = 0.0;
         }
+}
+template <int BLOCK>
+__device__ __forceinline__ void write_partial(double s, double q, double* partials, double* red) {
+    write_partial_at<BLOCK>(s, q, partials, red, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- normalisation decision (py/utils.py:100-105), identical in every block ---------------------

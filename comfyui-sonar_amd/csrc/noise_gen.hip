@@ -337,11 +337,12 @@ __global__ void __launch_bounds__(kBlock) perlin_terms_kernel(const float* __res
 // counter-based uniform (Philox4x32-10, counter = (lattice point, iteration group), key = seed; word `it % 4`), so the four
 // corners of a cell are random-access and a neighbouring cell recomputes the same values.  Writes the SUM over iterations
 // of the cell-centre terms: one launch instead of angle fill + terms + pre-add.
-__global__ void __launch_bounds__(kBlock) perlin_lattice_kernel(float* terms_sum, int iters, int64_t C, int H, int W, int blend_mode,
-                                                                uint64_t seed, uint64_t stream_id) {
+// block `bid` of `nb` blocks of the lattice's work (the kernel below: the whole grid; perlin_ahead_kernel: its leading blocks)
+__device__ __forceinline__ void perlin_lattice_cells(float* terms_sum, int iters, int64_t C, int H, int W, int blend_mode, uint64_t seed,
+                                                     uint64_t stream_id, int64_t bid, int64_t nb) {
     const int64_t total = C * H * W;
     const int gw = W + 1;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    for (int64_t i = bid * kBlock + threadIdx.x; i < total; i += nb * kBlock) {
         const int x = (int)(i % W);
         const int y = (int)((i / W) % H);
         const int64_t c = i / ((int64_t)W * H);
@@ -367,6 +368,11 @@ __global__ void __launch_bounds__(kBlock) perlin_lattice_kernel(float* terms_sum
         }
         terms_sum[i] = acc;
     }
+}
+
+__global__ void __launch_bounds__(kBlock) perlin_lattice_kernel(float* terms_sum, int iters, int64_t C, int H, int W, int blend_mode,
+                                                                uint64_t seed, uint64_t stream_id) {
+    perlin_lattice_cells(terms_sum, iters, C, H, W, blend_mode, seed, stream_id, blockIdx.x, gridDim.x);
 }
 
 // out[b][i] = base[b][i]/div + terms[0][i] + terms[1][i] + ...   (terms broadcast over batch)
@@ -417,6 +423,75 @@ __global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __res
     if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
 }
 
+// The fast path's tile loop (device-drawn calls: ONE summed term table, vector-aligned latents): wave `wave` of `nwaves` takes the tiles
+// first + wave, first + wave + nwaves, ...  MODE as in perlin_generate_kernel.  Shared by that kernel and perlin_ahead_kernel.
+template <int MODE, bool STATS, bool ALIGNED>
+__device__ __forceinline__ void perlin_fast_tiles(const float* __restrict__ terms, float* out, int64_t n, int64_t chw, uint64_t seed,
+                                                  uint64_t stream_id, int64_t elem_offset, const NormFast& norm, const Divider& divide,
+                                                  const Accum& acc, int64_t wave, int64_t nwaves, double& s, double& q) {
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
+    const int ichw = (int)chw;
+    for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+        const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
+        // position of the tile's first vector inside the latent; the prefetch cursor walks on in steps of 256 elements and wraps
+        // at the latent's end (a tile may straddle two latents when chw is not a multiple of the tile)
+        int rp = (int)(((base % chw) + chw) % chw);
+        const float4* const trow = reinterpret_cast<const float4*>(terms + rp);  // ALIGNED: the tile's vectors sit at trow[it * 64]
+        int fetched = 0;
+        auto next_terms = [&]() {
+            if constexpr (ALIGNED) return trow[64 * fetched++];  // unrolled callers: constant offsets in the load instructions
+            const float4 t = *reinterpret_cast<const float4*>(terms + rp);
+            rp += 256;
+            rp -= rp >= ichw ? ichw : 0;  // chw >= 256 (launcher)
+            return t;
+        };
+        float4 cur[4], nxt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = next_terms();
+        float ts = 0.0f, tq = 0.0f;  // the tile's 64 values per lane in fp32, folded into the fp64 sums once per tile
+#pragma unroll
+        for (int g = 0; g < kTileIters / 4; ++g) {
+            if (g + 1 < kTileIters / 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nxt[j] = next_terms();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+                uint32_t r[4];
+                rng.words4_high(r);
+                const int64_t e = base + (4 * g + j) * 256;
+                if constexpr (!ALIGNED) {
+                    if (e < 0 || e >= n) continue;  // the two ends of a shard that does not start / end on a tile (whole groups of 4)
+                }
+                v[0] = divide.from_word(r[0], cur[j].x); v[1] = divide.from_word(r[1], cur[j].y);
+                v[2] = divide.from_word(r[2], cur[j].z); v[3] = divide.from_word(r[3], cur[j].w);
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = norm(v[k]);
+                }
+                if constexpr (MODE != 1) {
+                    if constexpr (MODE == 0) accumulate_group<true>(acc, n, e, v);
+                    double unused_s = 0.0, unused_q = 0.0;
+                    store_group<true>(out, n, e, v, unused_s, unused_q, false);
+                }
+                if constexpr (STATS || MODE == 1) {
+                    ts += (v[0] + v[1]) + (v[2] + v[3]);
+                    tq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[3], v[3], tq))));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        }
+        if constexpr (STATS || MODE == 1) {
+            s += (double)ts;
+            q += (double)tq;
+        }
+    }
+}
+
 // Normalisation folded into the generating pass (SURVEY.md §8d "stats-before-write"): MODE 0 writes the
 // raw values (+ optional statistics), MODE 1 only reduces the statistics (no stores), MODE 2 re-draws the
 // same values, normalises them with the decision derived from `norm_partials` and writes the final tensor.
@@ -444,64 +519,7 @@ __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __
     const int ichw = (int)chw;  // launcher guarantees chw < 2^31
     if constexpr (FAST) {
         static_assert(VEC, "the fast path is a vector path");
-        for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
-            Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
-            const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
-            // position of the tile's first vector inside the latent; the prefetch cursor walks on in steps of 256 elements and wraps
-            // at the latent's end (a tile may straddle two latents when chw is not a multiple of the tile)
-            int rp = (int)(((base % chw) + chw) % chw);
-            const float4* const trow = reinterpret_cast<const float4*>(terms + rp);  // ALIGNED: the tile's vectors sit at trow[it * 64]
-            int fetched = 0;
-            auto next_terms = [&]() {
-                if constexpr (ALIGNED) return trow[64 * fetched++];  // unrolled callers: constant offsets in the load instructions
-                const float4 t = *reinterpret_cast<const float4*>(terms + rp);
-                rp += 256;
-                rp -= rp >= ichw ? ichw : 0;  // chw >= 256 (launcher)
-                return t;
-            };
-            float4 cur[4], nxt[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cur[j] = next_terms();
-            float ts = 0.0f, tq = 0.0f;  // the tile's 64 values per lane in fp32, folded into the fp64 sums once per tile
-#pragma unroll
-            for (int g = 0; g < kTileIters / 4; ++g) {
-                if (g + 1 < kTileIters / 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) nxt[j] = next_terms();
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v[4];
-                    uint32_t r[4];
-                    rng.words4_high(r);
-                    const int64_t e = base + (4 * g + j) * 256;
-                    if constexpr (!ALIGNED) {
-                        if (e < 0 || e >= n) continue;  // the two ends of a shard that does not start / end on a tile (whole groups of 4)
-                    }
-                    v[0] = divide.from_word(r[0], cur[j].x); v[1] = divide.from_word(r[1], cur[j].y);
-                    v[2] = divide.from_word(r[2], cur[j].z); v[3] = divide.from_word(r[3], cur[j].w);
-                    if constexpr (MODE == 2) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = norm(v[k]);
-                    }
-                    if constexpr (MODE != 1) {
-                        if constexpr (MODE == 0) accumulate_group<true>(acc, n, e, v);
-                        double unused_s = 0.0, unused_q = 0.0;
-                        store_group<true>(out, n, e, v, unused_s, unused_q, false);
-                    }
-                    if constexpr (STATS || MODE == 1) {
-                        ts += (v[0] + v[1]) + (v[2] + v[3]);
-                        tq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[3], v[3], tq))));
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
-            }
-            if constexpr (STATS || MODE == 1) {
-                s += (double)ts;
-                q += (double)tq;
-            }
-        }
+        perlin_fast_tiles<MODE, STATS, ALIGNED>(terms, out, n, chw, seed, stream_id, elem_offset, norm, divide, acc, wave, nwaves, s, q);
         if constexpr (STATS || MODE == 1) write_partial<kBlock>(s, q, partials, red);
         return;
     }
@@ -602,6 +620,57 @@ static int launch_perlin_generate(const float* terms, float* out, int64_t B, int
 #undef SONAR_PG
 #undef SONAR_PGF
     return check_launch(what);
+}
+
+// A sampler's steady state at launch-bound batch sizes (prepared plans: the stream ids of the calls that follow are known): the three
+// dependent launches of a normalised Perlin call -- lattice, statistics pass, final pass -- become ONE, with nothing inside the launch
+// depending on anything else inside it.  Blocks [lat_blocks, ...) run the final pass of THIS call (lattice `terms`, statistics `partials`:
+// both left by earlier launches) and then the statistics pass of the NEXT call (its lattice `terms_next` left by the previous launch) into
+// `partials_next`; blocks [0, lat_blocks) compute a lattice for a LATER call into `lattice_out`.  Same tile -> wave -> slot mapping, same
+// arithmetic as perlin_generate_kernel<1 / 2, FAST, ALIGNED> and perlin_lattice_kernel: the same bits.
+struct PerlinAhead {
+    const float* terms;
+    float* out;
+    int64_t n, chw;
+    float div_fac;
+    uint64_t seed, stream_id;
+    int64_t elem_offset;
+    NormArgs na;                  // this call's statistics (complete before the launch) and its normalisation
+    uint64_t next_stream_id;      // statistics of the next call: tiles drawn with this stream id against terms_next
+    const float* terms_next;      // nullable: no statistics ahead
+    double* partials_next;
+    float* lattice_out;           // nullable: no lattice ahead
+    int lat_blocks, tile_blocks, lat_iters, blend_mode;
+    int64_t C;
+    int H, W;
+    uint64_t lattice_stream_id;
+};
+
+__global__ void __launch_bounds__(kBlock) perlin_ahead_kernel(PerlinAhead a) {
+    __shared__ double red[2 * kBlock / 64];
+    __shared__ NormDecision sh;
+    if ((int)blockIdx.x < a.lat_blocks) {
+        perlin_lattice_cells(a.lattice_out, a.lat_iters, a.C, a.H, a.W, a.blend_mode, a.seed, a.lattice_stream_id, blockIdx.x, a.lat_blocks);
+        return;
+    }
+    // the final pass of this call and the statistics pass of the next one are independent: separate blocks, so that at the launch-bound
+    // sizes a wave runs ONE tile's chain, not two back to back
+    const int nb = a.tile_blocks;
+    const bool ahead = (int)blockIdx.x >= a.lat_blocks + nb;
+    const int bid = (int)blockIdx.x - a.lat_blocks - (ahead ? nb : 0);
+    const Divider divide(a.div_fac);
+    const int64_t wave = ((int64_t)bid * kBlock + threadIdx.x) >> 6, nwaves = ((int64_t)nb * kBlock) >> 6;
+    double s = 0.0, q = 0.0;
+    if (!ahead) {
+        const NormDecision dec = decide_norm<kBlock>(a.na.partials, kNPart, a.na.n_total, a.na.thr_sd, red, &sh);
+        const NormFast norm(dec, a.na.factor);
+        perlin_fast_tiles<2, false, true>(a.terms, a.out, a.n, a.chw, a.seed, a.stream_id, a.elem_offset, norm, divide, kNoAccum, wave, nwaves, s, q);
+    } else {
+        const NormFast norm(NormDecision{0.f, 1.f, 0, 0}, 1.0f);
+        perlin_fast_tiles<1, false, true>(a.terms_next, nullptr, a.n, a.chw, a.seed, a.next_stream_id, a.elem_offset, norm, divide, kNoAccum, wave,
+                                          nwaves, s, q);
+        write_partial_at<kBlock>(s, q, a.partials_next, red, bid, nb);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1594,6 +1663,59 @@ extern "C" int sonar_perlin_noise_f32(const float* terms, float* out, int64_t B,
     if (rc != SONAR_OK) return rc;
     return launch_perlin_generate<2>(terms, out, B, chw, iters, div_fac, seed, stream_id, elem_offset, nullptr, na, st,
                                      "sonar_perlin_noise_f32(write)");
+}
+
+extern "C" int sonar_perlin_noise_ahead_ok(int64_t B, int64_t chw, int64_t elem_offset) {
+    // the fast, tile-aligned shape of the device-drawn call (whole RNG tiles per latent, shards on tile boundaries), and few enough tiles
+    // that the launches are latency-bound: beyond that the statistics pass of its own costs what it costs inside the final pass
+    const int64_t n = B * chw;
+    return (n > 0 && chw >= 256 && chw < (1LL << 31) && chw % kTileElems == 0 && elem_offset >= 0 && elem_offset % kTileElems == 0 &&
+            n / kTileElems <= 4096) ? 1 : 0;
+}
+
+extern "C" int sonar_perlin_noise_ahead_f32(const float* terms, float* out, int64_t B, int64_t chw, float div_fac, uint64_t seed, uint64_t stream_id,
+                                            int64_t elem_offset, float factor, float threshold_std_devs, double* partials, int have_stats,
+                                            uint64_t next_stream_id, const float* terms_next, double* partials_next, float* lattice_out,
+                                            int64_t lattice_iters, int64_t C, int64_t H, int64_t W, int blend_mode, uint64_t lattice_stream_id,
+                                            void* stream) {
+    const char* what = "sonar_perlin_noise_ahead_f32";
+    SONAR_REQUIRE(terms && out && partials && B >= 0 && chw > 0 && elem_offset >= 0 && (!terms_next || partials_next) &&
+                      partials_next != partials, SONAR_ERR_ARG, "%s: bad argument", what);
+    SONAR_REQUIRE(!lattice_out || (lattice_iters >= 0 && lattice_iters < (1 << 20) && C > 0 && H > 0 && W > 0 && H < (1 << 20) && W < (1 << 20) &&
+                                   C * H * W == chw && blend_mode >= 0 && blend_mode <= 2 && lattice_out != terms && lattice_out != terms_next),
+                  SONAR_ERR_ARG, "%s: bad lattice request", what);
+    SONAR_REQUIRE(sonar_perlin_noise_ahead_ok(B, chw, elem_offset) && aligned16(out) && aligned16(terms) && (!terms_next || aligned16(terms_next)),
+                  SONAR_ERR_UNSUPPORTED, "%s: whole 4096-element tiles per latent, 16-byte aligned tensors, at most 4096 tiles", what);
+    if (B == 0) return SONAR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (!have_stats) {
+        const int rc = launch_perlin_generate<1>(terms, out, B, chw, 1, div_fac, seed, stream_id, elem_offset, partials, NormArgs{}, st, what);
+        if (rc != SONAR_OK) return rc;
+    }
+    PerlinAhead a{};
+    a.terms = terms;
+    a.out = out;
+    a.n = B * chw;
+    a.chw = chw;
+    a.div_fac = div_fac;
+    a.seed = seed;
+    a.stream_id = stream_id;
+    a.elem_offset = elem_offset;
+    a.na = NormArgs{partials, B * chw, factor, threshold_std_devs};
+    a.next_stream_id = next_stream_id;
+    a.terms_next = terms_next;
+    a.partials_next = partials_next;
+    a.lattice_out = lattice_out;
+    a.lat_blocks = lattice_out ? grid_for(chw, kBlock) : 0;
+    a.lat_iters = (int)lattice_iters;
+    a.blend_mode = blend_mode;
+    a.C = C;
+    a.H = (int)H;
+    a.W = (int)W;
+    a.lattice_stream_id = lattice_stream_id;
+    a.tile_blocks = tile_grid(a.n, elem_offset);
+    hipLaunchKernelGGL(perlin_ahead_kernel, dim3(a.lat_blocks + a.tile_blocks * (terms_next ? 2 : 1)), dim3(kBlock), 0, st, a);
+    return check_launch(what);
 }
 
 extern "C" int sonar_resample_acc_f32(float* dst, const float* src, int64_t planes, int64_t H, int64_t W, int64_t h,

@@ -79,6 +79,7 @@ const Replayable kReplayable[] = {
     SONAR_REPLAYABLE(sonar_perlin_generate_acc_f32),
     SONAR_REPLAYABLE(sonar_perlin_generate_chain_f32),
     SONAR_REPLAYABLE(sonar_perlin_noise_f32),
+    SONAR_REPLAYABLE(sonar_perlin_noise_ahead_f32),
     SONAR_REPLAYABLE(sonar_pyramid_generate_f32),
     SONAR_REPLAYABLE(sonar_pyramid_generate_acc_f32),
     SONAR_REPLAYABLE(sonar_pyramid_noise_f32),

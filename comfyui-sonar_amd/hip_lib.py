@@ -105,6 +105,8 @@ SIGNATURES = {
     "sonar_perlin_apply_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _F, _P, _P]),
     "sonar_perlin_generate_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _P, _P]),
     "sonar_perlin_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _F, _F, _P, _P]),
+    "sonar_perlin_noise_ahead_ok": (_I, [_I64, _I64, _I64]),
+    "sonar_perlin_noise_ahead_f32": (_I, [_P, _P, _I64, _I64, _F, _U64, _U64, _I64, _F, _F, _P, _I, _U64, _P, _P, _P, _I64, _I64, _I64, _I64, _I, _U64, _P]),
     "sonar_resample_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I64, _F, _I, _I, _P, _P]),
     "sonar_pyramid_generate_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _P, _P]),
     "sonar_pyramid_noise_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _F, _F, _P, _P]),
@@ -1600,9 +1602,10 @@ def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tenso
 PLANS_ENABLED = os.environ.get("SONAR_PLANS", "1") != "0"
 PLAN_WARM_CALLS = 2     # ordinary calls before a step is traced (first-call setup, look-ahead misses)
 PLAN_MAX_ATTEMPTS = 3   # traces that may fail (a call that took a fallback route) before the step stays on the ordinary path
+PERLIN_AHEAD = os.environ.get("SONAR_PERLIN_AHEAD", "1") != "0"  # plans fuse a normalised Perlin call's three launches (_PerlinAheadHook)
 NOT_RUN = object()      # Plan.run: the step was not issued (a guard changed, an entry point refused): take the ordinary path
 _M64 = 2**64 - 1
-_HOST_QUERIES = frozenset(("sonar_abi_version", "sonar_last_error", "sonar_power_noise_ahead_ok", "sonar_power_pipeline", "sonar_power_plane_kind", "sonar_dwt_out_len",
+_HOST_QUERIES = frozenset(("sonar_abi_version", "sonar_last_error", "sonar_power_noise_ahead_ok", "sonar_perlin_noise_ahead_ok", "sonar_power_pipeline", "sonar_power_plane_kind", "sonar_dwt_out_len",
                            "sonar_dwt2_ws_bytes", "sonar_wcfg_lowpass_lds_bytes", "sonar_wcfg_fused_ws_bytes", "sonar_pyramid_levels",
                            "sonar_plan_fn_id", "sonar_plan_fn_nargs"))
 PATCH_SLOT, PATCH_STREAM, PATCH_SEED, PATCH_BLOB, PATCH_LEVELS = range(5)
@@ -1756,6 +1759,116 @@ class _PowerAheadHook(PlanHook):
         la.hits += 1
         la.key, la.partials, la.last_stream, la.last_delta = self.key_for((stream + self.step) & _M64, seed, st), nws, stream, self.step
         self.flip ^= 1
+
+
+class _PerlinAheadHook(PlanHook):
+    """A normalised Perlin call inside a plan, ONE launch per call in the steady state (``sonar_perlin_noise_ahead_f32``): the plan knows
+    the stream ids of the calls that follow (this call's + the streams a call takes), so a call's launch also runs the statistics pass
+    of the next call and the lattice of the call after it.  This hook keeps what earlier launches left -- three lattice buffers, two
+    statistics buffers per HIP stream, keyed by (seed, stream id) -- and supplies whatever is missing the ordinary way (a lattice launch;
+    ``have_stats`` = 0 makes the entry point launch the statistics pass): a reseed or a draw by somebody else costs one call its
+    shortcuts, never its values."""
+
+    KEYS = ("t_now", "p_now", "have", "t_next", "p_next", "t_out", "l_out")
+
+    def __init__(self, sa: int, la: int, count: int, lattice, device):
+        self.sa, self.la, self.count, self.lattice, self.device = sa, la, count, lattice, device  # lattice: (iters, C, H, W, blend)
+        self.managed = {}
+        self.by_stream = {}
+        self.now = None
+        self.hits = self.misses = 0
+
+    def bind(self, slot_of):
+        self.slot = {k: slot_of["perlin_" + k] for k in self.KEYS}
+
+    def pre_run(self, seed, base, table, st):
+        state = self.by_stream.get(st)
+        if state is None:
+            _it, c, h, w, _bl = self.lattice
+            state = self.by_stream[st] = {"terms": [torch.empty((1, c, h, w), dtype=torch.float32, device=self.device) for _ in range(3)],
+                                          "parts": [new_partials(self.device) for _ in range(2)], "ready_terms": {}, "ready_parts": {}}
+        terms, parts = state["terms"], state["parts"]
+        l_now, s_now = (base + self.la) & _M64, (base + self.sa) & _M64
+        l_next, s_next, l_next2 = (l_now + self.count) & _M64, (s_now + self.count) & _M64, (l_now + 2 * self.count) & _M64
+        ti = state["ready_terms"].get((seed, l_now))
+        tn = state["ready_terms"].get((seed, l_next))
+        it, c, h, w, bl = self.lattice
+        if ti is None or tn is None:
+            # nobody left this call's lattice, or the next call's (the first run; after a reseed or somebody else's draw): the ordinary
+            # launch for whichever is missing, so that from the next call on every launch finds both its inputs
+            self.misses += 1
+            if ti is None:
+                ti = next(i for i in range(3) if i != tn)
+                _check(_lib.sonar_perlin_lattice_f32(terms[ti].data_ptr(), it, c, h, w, bl, seed, l_now, st), "sonar_perlin_lattice_f32")
+            if tn is None:
+                tn = next(i for i in range(3) if i != ti)
+                _check(_lib.sonar_perlin_lattice_f32(terms[tn].data_ptr(), it, c, h, w, bl, seed, l_next, st), "sonar_perlin_lattice_f32")
+        else:
+            self.hits += 1
+        pi = state["ready_parts"].get((seed, s_now))
+        have = pi is not None
+        if not have:
+            pi = 0
+        pn = 1 - pi
+        to = next(i for i in range(3) if i != ti and i != tn)
+        target = l_next2
+        sl = self.slot
+        table[sl["t_now"]] = terms[ti].data_ptr()
+        table[sl["p_now"]] = parts[pi].data_ptr()
+        table[sl["have"]] = int(have)
+        table[sl["t_next"]] = terms[tn].data_ptr()
+        table[sl["p_next"]] = parts[pn].data_ptr()
+        table[sl["t_out"]] = terms[to].data_ptr()
+        table[sl["l_out"]] = target
+        self.now = (state, {(seed, target): to, (seed, l_next): tn}, {(seed, s_next): pn})
+        return True
+
+    def post_run(self, seed, base):
+        state, terms_ready, parts_ready = self.now
+        state["ready_terms"], state["ready_parts"] = terms_ready, parts_ready
+
+
+def _peephole_perlin_ahead(records, b, rec):
+    """[sonar_perlin_lattice_f32 -> terms] [sonar_perlin_noise_f32(terms, ...)] of a traced step become one sonar_perlin_noise_ahead_f32
+    record driven by a ``_PerlinAheadHook`` -- where the entry point takes the shape (launch-bound sizes, whole tiles)."""
+    lib = load_raw()
+    out = []
+    i = 0
+    while i < len(records):
+        name, words, blob, patches = records[i]
+        nxt = records[i + 1] if i + 1 < len(records) else None
+        done = False
+        if name == "sonar_perlin_lattice_f32" and nxt is not None and nxt[0] == "sonar_perlin_noise_f32" and not blob and not nxt[2]:
+            lp = {pt.target: pt for pt in patches}
+            np_ = {pt.target: pt for pt in nxt[3]}
+            nw = nxt[1]
+            same_terms = (0 in lp and 0 in np_ and lp[0].source == PATCH_SLOT and np_[0].source == PATCH_SLOT and lp[0].index == np_[0].index
+                          and lp[0].addend == 0 and np_[0].addend == 0)
+            signed = lambda v: v - (1 << 64) if v >> 63 else v  # noqa: E731
+            B, chw, iters, offs = signed(nw[2]), signed(nw[3]), signed(nw[4]), signed(nw[8])
+            lat = tuple(signed(words[k]) for k in (1, 2, 3, 4, 5))  # iters, C, H, W, blend
+            if (same_terms and iters == 1 and lat[1] * lat[2] * lat[3] == chw and lib.sonar_perlin_noise_ahead_ok(B, chw, offs)
+                    and all(k in np_ for k in (1, 6, 7, 11)) and 7 in lp and lp[7].source == PATCH_STREAM and np_[7].source == PATCH_STREAM):
+                hook = _PerlinAheadHook(int(np_[7].addend), int(lp[7].addend), rec.count, lat, next(iter(b.temp_ranges))[2].device)
+                slots = {}
+                for key in hook.KEYS:
+                    slots[key] = b.slot_of[("hook", "perlin_" + key)] = len(b.slots)
+                    b.slots.append(None)
+                w2 = [0, 0, nw[2], nw[3], nw[5], 0, 0, nw[8], nw[9], nw[10], 0, 0, 0, 0, 0, 0, words[1], words[2], words[3], words[4], words[5], 0, 0]
+                p2 = [PlanPatch(PATCH_SLOT, 0, slots["t_now"], 8, 0), PlanPatch(PATCH_SLOT, 1, np_[1].index, 8, np_[1].addend),
+                      PlanPatch(PATCH_SEED, 5, 0, 8, 0), PlanPatch(PATCH_STREAM, 6, 0, 8, np_[7].addend),
+                      PlanPatch(PATCH_SLOT, 10, slots["p_now"], 8, 0), PlanPatch(PATCH_SLOT, 11, slots["have"], 8, 0),
+                      PlanPatch(PATCH_STREAM, 12, 0, 8, np_[7].addend + rec.count), PlanPatch(PATCH_SLOT, 13, slots["t_next"], 8, 0),
+                      PlanPatch(PATCH_SLOT, 14, slots["p_next"], 8, 0), PlanPatch(PATCH_SLOT, 15, slots["t_out"], 8, 0),
+                      PlanPatch(PATCH_SLOT, 21, slots["l_out"], 8, 0)]
+                out.append(("sonar_perlin_noise_ahead_f32", w2, b"", p2))
+                rec.hooks.append(hook)
+                i += 2
+                done = True
+        if not done:
+            out.append(records[i])
+            i += 1
+    return out
 
 
 def _float_word(v: float) -> int:
@@ -2081,6 +2194,8 @@ def _build_plan(rec: _Recorder, result, take, rewind, guards) -> Plan:
     # the tensors the entry points were handed are known now (constants are kept by the builder): let go of them, so that the only
     # holders of a temporary's storage left are this trace's own note of the allocation -- and whoever else kept it (checked below)
     rec.seen.clear()
+    if PERLIN_AHEAD:
+        records = _peephole_perlin_ahead(records, b, rec)
     # what the result owns must be fresh per call: the tensors handed back and the statistics partials tagged onto them
     owned = {}  # id(temp) -> index in the fresh list
 

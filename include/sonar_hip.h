@@ -339,6 +339,20 @@ int sonar_perlin_generate_f32(const float* terms, float* out, int64_t B, int64_t
 int sonar_perlin_noise_f32(const float* terms, float* out, int64_t B, int64_t chw, int64_t iters, float div_fac,
                            uint64_t seed, uint64_t stream_id, int64_t elem_offset, float factor, float threshold_std_devs,
                            double* partials /*workspace, SONAR_NPART pairs*/, void* stream);
+/* sonar_perlin_lattice_f32 + sonar_perlin_noise_f32 for a sampler that is called step after step with stream ids it can foresee (the
+ * prepared plans, below): ONE launch per call in the steady state.  The launch runs this call's final pass (`terms`: its summed lattice,
+ * `partials` + have_stats: its statistics, both left by the previous launches; have_stats == 0: the statistics pass is launched first),
+ * then the statistics pass of the NEXT call (tile stream `next_stream_id` against `terms_next`, nullable) into `partials_next`, and in
+ * extra blocks the lattice of a LATER call (`lattice_out`, nullable; `lattice_iters`, C, H, W, `blend_mode`, `lattice_stream_id` as
+ * sonar_perlin_lattice_f32 takes them) -- nothing inside the launch depends on anything else inside it.  The output bits are those of the
+ * two entry points it replaces.  Only where sonar_perlin_noise_ahead_ok() says 1 (whole 4096-element tiles per latent, at most 4096
+ * tiles: the launch-bound sizes); SONAR_ERR_UNSUPPORTED otherwise. */
+int sonar_perlin_noise_ahead_ok(int64_t B, int64_t chw, int64_t elem_offset);
+int sonar_perlin_noise_ahead_f32(const float* terms, float* out, int64_t B, int64_t chw, float div_fac, uint64_t seed, uint64_t stream_id,
+                                 int64_t elem_offset, float factor, float threshold_std_devs, double* partials, int have_stats,
+                                 uint64_t next_stream_id, const float* terms_next, double* partials_next, float* lattice_out,
+                                 int64_t lattice_iters, int64_t C, int64_t H, int64_t W, int blend_mode, uint64_t lattice_stream_id,
+                                 void* stream);
 
 /* ---------------------------------------------------------------- Pyramid (row Y) */
 /* dst[B*C][H][W] += bilinear_upsample(src[B*C][h][w]) * scale   (F.interpolate(mode="bilinear",

@@ -1,6 +1,7 @@
 """-m gpu, round 4: prepared call plans (include/sonar_hip.h "prepared call plans") -- a replayed step is the ordinary step bit for bit,
 and every condition under which a plan must stand aside hands the call back to the ordinary path."""
 import importlib
+import math
 import types
 
 import pytest
@@ -93,7 +94,7 @@ def test_plans_follow_the_rng_position(api):
     """A reseed, a draw by somebody else and torch.cuda.set_rng_state move the stream ids of the next call: the replay takes its ids from
     the same generator state as the ordinary path."""
     x = torch.zeros((4, 4, 128, 128), device="cuda")
-    for what in ("chain:perlin*0.5+pyramid*0.5", "power", "pyramid"):
+    for what in ("chain:perlin*0.5+pyramid*0.5", "power", "pyramid", "perlin"):
         make = _maker(api, x, what)
 
         def script(ns, plans):
@@ -371,7 +372,7 @@ def test_a_trace_only_sees_its_own_thread(api):
         stop.set()
         th.join()
     assert not errors and len(set(side)) == 1
-    assert ns._planned.plan is not None and hl.load().sonar_plan_length(ns._planned.plan.handle) == 2
+    assert ns._planned.plan is not None and hl.load().sonar_plan_length(ns._planned.plan.handle) == 1  # lattice + call fused (look-ahead)
     assert _same(got, _run(api, ref, 8, False))
 
 
@@ -421,3 +422,64 @@ def test_torch_work_inside_a_step_means_no_plan(api):
 
     _res, plan = hl.trace_plan(with_item, SIG, take=ng.DeviceRNG.take, rewind=ng.DeviceRNG.rewind, guards=())
     assert plan is None and "torch operation" in hl.trace_plan.last_reason
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 128, 128), (4, 4, 128, 128), (64, 4, 128, 128), (2, 16, 64, 64), (2, 4, 3, 64, 64)])
+def test_a_planned_perlin_call_is_one_launch(api, shape):
+    """Inside a plan a normalised Perlin call is ONE launch in the steady state (sonar_perlin_noise_ahead_f32: this call's final pass, the
+    next call's statistics pass, the lattice of the call after it): same bits as lattice + statistics + final launch, whatever the hook
+    finds or misses -- a reseed and a foreign draw in the middle of the run cost shortcuts, not values."""
+    hl = api.hl
+    x = torch.zeros(shape, device="cuda")
+    make = _maker(api, x, "perlin")
+    a, b = make(), make()
+
+    def script(ns, plans):
+        hl.PLANS_ENABLED = plans
+        try:
+            torch.manual_seed(31)
+            got = []
+            for i in range(14):
+                if i == 8:
+                    torch.manual_seed(32)
+                if i == 11:
+                    torch.randn(5, device="cuda")
+                got.append(ns(*SIG).clone())
+            return got
+        finally:
+            hl.PLANS_ENABLED = True
+
+    ra, rb = script(a, True), script(b, False)
+    assert all(torch.equal(p, q) for p, q in zip(ra, rb))
+    plan = a._planned.plan
+    assert plan is not None and hl.load().sonar_plan_length(plan.handle) == 1
+    hook = plan.hooks[0]
+    assert isinstance(hook, hl._PerlinAheadHook) and hook.hits >= 6 and hook.misses >= 3  # first run, the reseed, the foreign draw
+    # the entry point itself: every combination of what a call may find, against the three launches it replaces
+    lib = hl.load()
+    b_, c, h, w = (shape[0], math.prod(shape[1:-2]), shape[-2], shape[-1])
+    chw = c * h * w
+    assert lib.sonar_perlin_noise_ahead_ok(b_, chw, 0) == 1
+    st = hl._stream()
+    lat = lambda stream: hl.perlin_lattice(2, c, h, w, "cuda", "lerp", 9, stream)  # noqa: E731
+    t0, t1 = lat(101), lat(103)
+    want0 = hl.perlin_noise((b_, c, h, w), t0, 2.0, 9, 100, 0, 0.9)
+    want1 = hl.perlin_noise((b_, c, h, w), t1, 2.0, 9, 102, 0, 0.9)
+    for have_stats in (0, 1):
+        for with_next in (0, 1):
+            out0, out1 = torch.empty((b_, c, h, w), device="cuda"), torch.empty((b_, c, h, w), device="cuda")
+            p0, p1, p2 = hl.new_partials("cuda"), hl.new_partials("cuda"), hl.new_partials("cuda")
+            if have_stats:
+                hl.perlin_generate((b_, c, h, w), t0, 2.0, 9, 100, 0, partials=None)  # (no statistics-only entry point: take them from a dry call)
+                ws = hl.new_partials("cuda")
+                assert lib.sonar_perlin_noise_ahead_f32(t0.data_ptr(), out0.data_ptr(), b_, chw, 2.0, 9, 100, 0, 0.9, 2.5, ws.data_ptr(), 0, 100, t0.data_ptr(),
+                                                        p0.data_ptr(), None, 0, 0, 0, 0, 0, 0, st) == 0  # leaves call 100's statistics in p0
+            t_out = torch.empty_like(t1)
+            rc = lib.sonar_perlin_noise_ahead_f32(t0.data_ptr(), out0.data_ptr(), b_, chw, 2.0, 9, 100, 0, 0.9, 2.5, p0.data_ptr(), have_stats, 102,
+                                                  t1.data_ptr() if with_next else None, p1.data_ptr() if with_next else None, t_out.data_ptr(), 2, c, h, w, 0,
+                                                  103, st)
+            assert rc == 0 and torch.equal(out0, want0) and torch.equal(t_out, t1)
+            rc = lib.sonar_perlin_noise_ahead_f32(t1.data_ptr(), out1.data_ptr(), b_, chw, 2.0, 9, 102, 0, 0.9, 2.5, (p1 if with_next else p2).data_ptr(),
+                                                  with_next, 104, None, None, None, 0, 0, 0, 0, 0, 0, st)
+            assert rc == 0 and torch.equal(out1, want1)
+    assert lib.sonar_perlin_noise_ahead_ok(b_, chw + 4, 0) == 0 and lib.sonar_perlin_noise_ahead_ok(8192, 65536, 0) == 0
