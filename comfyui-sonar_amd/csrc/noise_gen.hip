@@ -338,11 +338,12 @@ __global__ void __launch_bounds__(kBlock) perlin_terms_kernel(const float* __res
 // corners of a cell are random-access and a neighbouring cell recomputes the same values.  Writes the SUM over iterations
 // of the cell-centre terms: one launch instead of angle fill + terms + pre-add.
 // block `bid` of `nb` blocks of the lattice's work (the kernel below: the whole grid; perlin_ahead_kernel: its leading blocks)
+template <int BLOCK = kBlock>
 __device__ __forceinline__ void perlin_lattice_cells(float* terms_sum, int iters, int64_t C, int H, int W, int blend_mode, uint64_t seed,
                                                      uint64_t stream_id, int64_t bid, int64_t nb) {
     const int64_t total = C * H * W;
     const int gw = W + 1;
-    for (int64_t i = bid * kBlock + threadIdx.x; i < total; i += nb * kBlock) {
+    for (int64_t i = bid * BLOCK + threadIdx.x; i < total; i += nb * BLOCK) {
         const int x = (int)(i % W);
         const int y = (int)((i / W) % H);
         const int64_t c = i / ((int64_t)W * H);
@@ -920,12 +921,27 @@ static_assert((kPyrParts & (kPyrParts - 1)) == 0 && kTileIters % kPyrParts == 0,
 // fold (nullable y): the values are folded into a chain's running sum, out == fold.y (sonar_pyramid_generate_acc_f32); PRE != 0: the
 // chain's previous item rides along (Prefix above) -- its generator shares this kernel's tile keying, so its state simply walks the
 // same (tile, iteration) sequence.
+// A Perlin lattice computed in `blocks` extra leading workgroups of a plane-kernel launch: the lattice of a LATER call's hosted Perlin item
+// (sonar_pyramid_generate_acc_ahead_f32) -- independent of everything else in the launch.  blocks == 0: none.
+struct LatticeJob {
+    float* out;
+    int blocks, iters, blend_mode;
+    int64_t C;
+    uint64_t seed, stream_id;
+};
+static constexpr LatticeJob kNoLattice{nullptr, 0, 0, 0, 0, 0, 0};
+
 template <bool STATS, bool XROWS, int PRE = 0>
 __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
                                                                uint64_t seed, uint64_t stream_id, int64_t elem_offset,
-                                                               double* partials, int grid_floats, Accum fold, Prefix pre) {
+                                                               double* partials, int grid_floats, Accum fold, Prefix pre, LatticeJob lat) {
     extern __shared__ __align__(16) float pyr_lds[];
     __shared__ double red[2 * kPyrBlock / 64];
+    if ((int)blockIdx.x < lat.blocks) {
+        perlin_lattice_cells<kPyrBlock>(lat.out, lat.iters, lat.C, H, W, lat.blend_mode, lat.seed, lat.stream_id, blockIdx.x, lat.blocks);
+        return;
+    }
+    const int bid = (int)blockIdx.x - lat.blocks, nblocks = (int)gridDim.x - lat.blocks;  // this workgroup among those that own planes
     SONAR_NG_STAMP(0);
     double s = 0.0, q = 0.0;
     const int HW = H * W;
@@ -971,7 +987,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
         }
     }
     SONAR_NG_STAMP(1);
-    for (int64_t p = blockIdx.x; p < planes; p += gridDim.x) {
+    for (int64_t p = bid; p < planes; p += nblocks) {
         __syncthreads();
         SONAR_NG_STAMP(2);
         int off = 0;
@@ -1127,14 +1143,14 @@ SONAR_PYR_UNROLL
         }
     }
     SONAR_NG_STAMP(8);
-    if constexpr (STATS) write_partial<kPyrBlock>(s, q, partials, red);
+    if constexpr (STATS) write_partial_at<kPyrBlock>(s, q, partials, red, bid, nblocks);
     SONAR_NG_STAMP(9);
 }
 
 // true if the plane kernel was launched
 static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t W, const PyramidLevels& lv, int mode, uint64_t seed,
                                  uint64_t stream_id, int64_t elem_offset, double* partials, hipStream_t st, Accum fold = kNoAccum,
-                                 int pre_kind = 0, Prefix pre = Prefix{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1, 0}) {
+                                 int pre_kind = 0, Prefix pre = Prefix{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1, 0}, LatticeJob lat = kNoLattice) {
     size_t grid_floats = 0, rows = 0;
     for (int l = 0; l < lv.count; ++l) {
         grid_floats += (size_t)lv.h[l] * lv.w[l];
@@ -1147,8 +1163,8 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     const bool xrows = mode == 0 && W % 4 == 0 && lds_x <= kPyramidLdsBudget;
     const int g = (int)std::min<int64_t>(planes, kNPart);
 #define SONAR_PP(ST, XR, P) \
-    hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P>), dim3(g), dim3(kPyrBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
-                       seed, stream_id, elem_offset, partials, (int)grid_floats, fold, pre)
+    hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P>), dim3(g + lat.blocks), dim3(kPyrBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
+                       seed, stream_id, elem_offset, partials, (int)grid_floats, fold, pre, lat)
 #define SONAR_PPK(ST, XR) \
     do { \
         if (pre_kind == SONAR_PREFIX_NORMAL) SONAR_PP(ST, XR, 1); \
@@ -1770,11 +1786,10 @@ extern "C" int sonar_pyramid_generate_f32(float* out, int64_t planes, int64_t H,
 
 // The same values folded into a chain's running sum (y <- y * y_mul + pyramid * x_mul, sonar_accumulate), optionally with the chain's
 // previous item riding along (sonar_fold_prefix).  Plane kernel only: SONAR_ERR_UNSUPPORTED when it cannot run this shape.
-extern "C" int sonar_pyramid_generate_acc_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, int64_t planes, int64_t H, int64_t W,
-                                              int64_t nlevels, const float* const* level_ptrs, const int64_t* level_h,
-                                              const int64_t* level_w, const float* level_weight, int mode, uint64_t seed,
-                                              uint64_t stream_id, int64_t elem_offset, void* stream) {
-    const char* what = "sonar_pyramid_generate_acc_f32";
+static int pyramid_generate_acc(const char* what, const sonar_accumulate* acc, const sonar_fold_prefix* pre, int64_t planes, int64_t H, int64_t W,
+                                int64_t nlevels, const float* const* level_ptrs, const int64_t* level_h, const int64_t* level_w,
+                                const float* level_weight, int mode, uint64_t seed, uint64_t stream_id, int64_t elem_offset, LatticeJob lat,
+                                void* stream) {
     SONAR_REQUIRE(acc && acc->y, SONAR_ERR_ARG, "%s: bad argument", what);
     int rc = pyramid_common(what, acc->y, planes, H, W, mode, elem_offset);
     if (rc != SONAR_OK) return rc;
@@ -1791,9 +1806,32 @@ extern "C" int sonar_pyramid_generate_acc_f32(const sonar_accumulate* acc, const
     }
     if (planes == 0) return SONAR_OK;
     SONAR_REQUIRE(launch_pyramid_plane(acc->y, planes, H, W, lv, mode, seed, stream_id, elem_offset, acc->partials, (hipStream_t)stream,
-                                       Accum{acc->y, acc->y_mul, acc->x_mul}, pre ? pre->kind : 0, px),
+                                       Accum{acc->y, acc->y_mul, acc->x_mul}, pre ? pre->kind : 0, px, lat),
                   SONAR_ERR_UNSUPPORTED, "%s: the plane kernel cannot run this shape (whole planes, grids within the LDS budget)", what);
     return check_launch(what);
+}
+
+extern "C" int sonar_pyramid_generate_acc_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, int64_t planes, int64_t H, int64_t W,
+                                              int64_t nlevels, const float* const* level_ptrs, const int64_t* level_h,
+                                              const int64_t* level_w, const float* level_weight, int mode, uint64_t seed,
+                                              uint64_t stream_id, int64_t elem_offset, void* stream) {
+    return pyramid_generate_acc("sonar_pyramid_generate_acc_f32", acc, pre, planes, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, mode,
+                                seed, stream_id, elem_offset, kNoLattice, stream);
+}
+
+extern "C" int sonar_pyramid_generate_acc_ahead_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, int64_t planes, int64_t H, int64_t W,
+                                                    int64_t nlevels, const float* const* level_ptrs, const int64_t* level_h,
+                                                    const int64_t* level_w, const float* level_weight, int mode, uint64_t seed,
+                                                    uint64_t stream_id, int64_t elem_offset, float* lattice_out, int64_t lattice_iters,
+                                                    int64_t lattice_channels, int blend_mode, uint64_t lattice_stream_id, void* stream) {
+    const char* what = "sonar_pyramid_generate_acc_ahead_f32";
+    SONAR_REQUIRE(pre && pre->kind == SONAR_PREFIX_PERLIN && lattice_out && lattice_out != pre->terms && lattice_iters >= 0 &&
+                      lattice_iters < (1 << 20) && lattice_channels > 0 && blend_mode >= 0 && blend_mode <= 2 && H > 0 && W > 0 &&
+                      lattice_channels * H * W == pre->chw,
+                  SONAR_ERR_ARG, "%s: a hosted Perlin item and a lattice buffer for the later call's [C, H, W] table are required", what);
+    LatticeJob lat{lattice_out, grid_for(pre->chw, kPyrBlock), (int)lattice_iters, blend_mode, lattice_channels, seed, lattice_stream_id};
+    return pyramid_generate_acc(what, acc, pre, planes, H, W, nlevels, level_ptrs, level_h, level_w, level_weight, mode, seed, stream_id, elem_offset,
+                                lat, stream);
 }
 
 extern "C" int sonar_levels_sampled_f32(float* out, int64_t planes, int64_t H, int64_t W, int nlevels, const int64_t* level_h,

@@ -82,6 +82,7 @@ const Replayable kReplayable[] = {
     SONAR_REPLAYABLE(sonar_perlin_noise_ahead_f32),
     SONAR_REPLAYABLE(sonar_pyramid_generate_f32),
     SONAR_REPLAYABLE(sonar_pyramid_generate_acc_f32),
+    SONAR_REPLAYABLE(sonar_pyramid_generate_acc_ahead_f32),
     SONAR_REPLAYABLE(sonar_pyramid_noise_f32),
     SONAR_REPLAYABLE(sonar_power_noise_f32),
     SONAR_REPLAYABLE(sonar_power_noise_ahead_f32),

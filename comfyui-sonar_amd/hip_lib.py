@@ -166,6 +166,7 @@ SIGNATURES = {
     "sonar_philox_normal_chain_f32": (_I, [_P, _P, _I64, _U64, _U64, _I64, _P]),
     "sonar_perlin_generate_chain_f32": (_I, [_P, _P, _P, _I64, _I64, _F, _U64, _U64, _I64, _P]),
     "sonar_pyramid_generate_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I, _U64, _U64, _I64, _P]),
+    "sonar_pyramid_generate_acc_ahead_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I, _U64, _U64, _I64, _P, _I64, _I64, _I, _U64, _P]),
     "sonar_brownian_bridge_chain_f32": (_I, [_P, _P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _I64, _P]),
     "sonar_signed_rescale_f32": (_I, [_P, _I64, _I64, _D, _D, _D, _D, _F, _P, _P, _P]),
     "sonar_dft_rows_r2c_f32": (_I, [_P, _P, _I64, _I64, _P]),
@@ -1871,6 +1872,91 @@ def _peephole_perlin_ahead(records, b, rec):
     return out
 
 
+class _LatticeAheadHook(PlanHook):
+    """A chain whose Perlin item is hosted by the pyramid kernel, inside a plan: the lattice launch leaves the call's critical path --
+    the plane kernel's launch of call n computes the lattice of call n + 1 in extra workgroups (``sonar_pyramid_generate_acc_ahead_f32``).
+    Two buffers per HIP stream, keyed by (seed, stream id); a call that finds nothing (the first, or after a reseed) launches its lattice
+    the ordinary way."""
+
+    KEYS = ("t_now", "t_out", "l_out")
+
+    def __init__(self, la: int, count: int, lattice, device):
+        self.la, self.count, self.lattice, self.device = la, count, lattice, device  # lattice: (iters, C, H, W, blend)
+        self.managed = {}
+        self.by_stream = {}
+        self.now = None
+        self.hits = self.misses = 0
+
+    def bind(self, slot_of):
+        self.slot = {k: slot_of["lattice_" + k] for k in self.KEYS}
+
+    def pre_run(self, seed, base, table, st):
+        it, c, h, w, bl = self.lattice
+        state = self.by_stream.get(st)
+        if state is None:
+            state = self.by_stream[st] = {"terms": [torch.empty((1, c, h, w), dtype=torch.float32, device=self.device) for _ in range(2)], "ready": {}}
+        terms = state["terms"]
+        l_now = (base + self.la) & _M64
+        l_next = (l_now + self.count) & _M64
+        ti = state["ready"].get((seed, l_now))
+        if ti is None:
+            ti = 0
+            _check(_lib.sonar_perlin_lattice_f32(terms[ti].data_ptr(), it, c, h, w, bl, seed, l_now, st), "sonar_perlin_lattice_f32")
+            self.misses += 1
+        else:
+            self.hits += 1
+        sl = self.slot
+        table[sl["t_now"]] = terms[ti].data_ptr()
+        table[sl["t_out"]] = terms[1 - ti].data_ptr()
+        table[sl["l_out"]] = l_next
+        self.now = (state, {(seed, l_next): 1 - ti})
+        return True
+
+    def post_run(self, seed, base):
+        self.now[0]["ready"] = self.now[1]
+
+
+def _peephole_lattice_ahead(records, b, rec):
+    """[sonar_perlin_lattice_f32 -> terms] ... [sonar_pyramid_generate_acc_f32(pre = Perlin prefix over those terms)] of a traced chain step:
+    the lattice record goes, the plane kernel's record becomes sonar_pyramid_generate_acc_ahead_f32 driven by a ``_LatticeAheadHook``."""
+    signed = lambda v: v - (1 << 64) if v >> 63 else v  # noqa: E731
+    terms_off = FoldPrefixArg.terms.offset
+    for i, (name, words, blob, patches) in enumerate(records):
+        if name != "sonar_perlin_lattice_f32" or blob:
+            continue
+        lp = {pt.target: pt for pt in patches}
+        if 0 not in lp or lp[0].source != PATCH_SLOT or 7 not in lp or lp[7].source != PATCH_STREAM:
+            continue
+        tslot = lp[0].index
+        users = [j for j, r in enumerate(records) if j != i and any(pt.source == PATCH_SLOT and pt.index == tslot for pt in r[3])]
+        if len(users) != 1 or records[users[0]][0] != "sonar_pyramid_generate_acc_f32" or users[0] < i:
+            continue
+        j = users[0]
+        _n, w2, blob2, p2 = records[j]
+        pre_arg = next((pt for pt in p2 if pt.source == PATCH_BLOB and pt.target == 1), None)
+        if pre_arg is None:
+            continue
+        field = -(int(pre_arg.addend) + terms_off + 1)  # the blob patch that fills pre.terms
+        tpatch = next((pt for pt in p2 if pt.source == PATCH_SLOT and pt.index == tslot and pt.target == field and pt.addend == 0), None)
+        lat = tuple(signed(words[k]) for k in (1, 2, 3, 4, 5))  # iters, C, H, W, blend
+        if tpatch is None or (signed(w2[3]), signed(w2[4])) != (lat[2], lat[3]):
+            continue
+        hook = _LatticeAheadHook(int(lp[7].addend), rec.count, lat, next(iter(b.temp_ranges))[2].device)
+        slots = {}
+        for key in hook.KEYS:
+            slots[key] = b.slot_of[("hook", "lattice_" + key)] = len(b.slots)
+            b.slots.append(None)
+        new_patches = [PlanPatch(PATCH_SLOT, field, slots["t_now"], 8, 0) if pt is tpatch else pt for pt in p2]
+        new_patches += [PlanPatch(PATCH_SLOT, 14, slots["t_out"], 8, 0), PlanPatch(PATCH_SLOT, 18, slots["l_out"], 8, 0)]
+        new_words = list(w2[:14]) + [0, words[1], words[2], words[5], 0, 0]
+        out = list(records)
+        out[j] = ("sonar_pyramid_generate_acc_ahead_f32", new_words, blob2, new_patches)
+        del out[i]
+        rec.hooks.append(hook)
+        return _peephole_lattice_ahead(out, b, rec)
+    return records
+
+
 def _float_word(v: float) -> int:
     return int.from_bytes(C.c_float(v), "little")  # the bit pattern of the rounded float
 
@@ -2195,7 +2281,7 @@ def _build_plan(rec: _Recorder, result, take, rewind, guards) -> Plan:
     # holders of a temporary's storage left are this trace's own note of the allocation -- and whoever else kept it (checked below)
     rec.seen.clear()
     if PERLIN_AHEAD:
-        records = _peephole_perlin_ahead(records, b, rec)
+        records = _peephole_lattice_ahead(_peephole_perlin_ahead(records, b, rec), b, rec)
     # what the result owns must be fresh per call: the tensors handed back and the statistics partials tagged onto them
     owned = {}  # id(temp) -> index in the fresh list
 

@@ -314,6 +314,15 @@ int sonar_pyramid_generate_acc_f32(const sonar_accumulate* acc, const sonar_fold
                                    int64_t nlevels, const float* const* level_ptrs, const int64_t* level_h, const int64_t* level_w,
                                    const float* level_weight, int mode, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                                    void* stream);
+/* sonar_pyramid_generate_acc_f32 hosting a Perlin item (`pre`, kind PERLIN) for a chain that is called step after step with stream ids it
+ * can foresee (the prepared plans): extra leading workgroups of the same launch compute the summed lattice [lattice_channels][H][W] of a
+ * LATER call's Perlin item into `lattice_out` (as sonar_perlin_lattice_f32 with `seed`, `lattice_stream_id` would) -- independent of the
+ * rest of the launch, and one launch less on that later call's critical path. */
+int sonar_pyramid_generate_acc_ahead_f32(const sonar_accumulate* acc, const sonar_fold_prefix* pre, int64_t planes, int64_t H, int64_t W,
+                                         int64_t nlevels, const float* const* level_ptrs, const int64_t* level_h, const int64_t* level_w,
+                                         const float* level_weight, int mode, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                         float* lattice_out, int64_t lattice_iters, int64_t lattice_channels, int blend_mode,
+                                         uint64_t lattice_stream_id, void* stream);
 
 /* ---------------------------------------------------------------- Perlin (row P) */
 /* py/noise_generation.py:465-476,388-405 at the only position generate() uses (grid == output,
