@@ -400,6 +400,21 @@ __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane
 template <int H, int W, int NW, bool STATS, bool NORM>
 __device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, int lane, float scale, float nm, float nc, double& s, double& q);
 
+// Look-ahead of the phase-serial generate kernel (launch-bound batch sizes: every workgroup of the launch is resident at once): the
+// workgroups from `main_blocks` on compute the statistics of the NEXT call (stream `stream_id`, same seed / shape / filter) into
+// `partials` while the first `main_blocks` produce this call's planes -- independent workgroups, no ordering between them.
+constexpr int kStatsBatch = 4;  // statistics: planes per batch -- their edge columns wait in LDS for ONE barrier (a barrier per plane
+                                // made the eight waves of a group wait for each other four times per group)
+struct StatsAhead {
+    double* partials = nullptr;
+    uint64_t stream_id = 0;
+    int main_blocks = 0;
+};
+template <int H, int W>
+__device__ __forceinline__ void power_stats_body(const float* __restrict__ filter, int64_t planes, uint64_t seed, uint64_t stream_id,
+                                                 int64_t plane_offset, int group, int split, double* partials, int64_t bid, int64_t nb,
+                                                 c32 (*EDGE)[2][H], double* red);
+
 // SRC: 0 = spectrum `z` supplied (replay), 1 = spectrum drawn on device, 2 = `z` is a REAL H x W plane: forward r2c FFT in
 // LDS, x filter, then the same inverse (spectral filter: out = irfft2(rfft2(x) * filter), py/nodes/powernoise.py:356-366)
 template <int H, int W, int SRC, bool STATS, bool NORM>
@@ -407,7 +422,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
                                                                        const float* __restrict__ filter, float* out,
                                                                        int64_t planes, uint64_t seed, uint64_t stream_id,
                                                                        int64_t plane_offset, int group, int split, double* partials,
-                                                                       NormArgs na) {
+                                                                       NormArgs na, StatsAhead sa) {
     using C = PlaneCfg<H, W>;
     constexpr int NT = plane_threads<H, W>();
     constexpr int M = C::M, S = C::S;
@@ -427,6 +442,18 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
     __shared__ NormDecision shd;
     __shared__ int edge_seq;  // FAST generate path: edge-column waves drawn so far (two per plane), see the fill
     const int tid = threadIdx.x;
+    int64_t bid = blockIdx.x, nblk = gridDim.x;
+    if constexpr (SRC == 1 && NORM && !STATS) {
+        static_assert(kStatsBatch * 2 * H <= C::kLdsComplex, "the statistics' edge columns borrow the plane's LDS");
+        if (sa.partials) {
+            if ((int)blockIdx.x >= sa.main_blocks) {
+                power_stats_body<H, W>(filter, planes, seed, sa.stream_id, plane_offset, group, split, sa.partials, bid - sa.main_blocks,
+                                       nblk - sa.main_blocks, reinterpret_cast<c32(*)[2][H]>(A), red);
+                return;
+            }
+            nblk = sa.main_blocks;
+        }
+    }
     constexpr bool GEN = SRC == 1;
     // norm="ortho" on the inverse; the spectral filter also carries the forward transform's 1/sqrt(HW)
     float scale = SRC == 2 ? 1.0f / ((float)H * (float)W) : 1.0f / sqrtf((float)H * (float)W);
@@ -485,7 +512,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
     [[maybe_unused]] int edge_want = 0;
     if (tid == 0) edge_seq = 0;  // visible after the first plane's top-of-loop barrier
     // one workgroup draws the `group` planes of an RNG group back to back (group = 1 unless generating)
-    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+    for (int64_t unit = bid; unit < (split ? planes : planes / group); unit += nblk) {
     const GroupWalk gw(unit, group, split);
     SpectrumRng rng;
     if constexpr (GEN) {
@@ -1493,15 +1520,14 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
 //   sum   x  = sqrt(H W) * Re(Zf[0][0])
 //   sum x^2  = sum_ky ( |sym(Zf[:,0])[ky]|^2 + |sym(Zf[:,M])[ky]|^2 ) + 2 sum_ky sum_{0<kx<M} |Zf[ky][kx]|^2
 // (only the Hermitian-symmetric part of the kx = 0 and kx = M columns survives the c2r stage).
+// workgroup `bid` of `nb`: the statistics kernel's grid, or the trailing workgroups of a phase-serial generate launch that computes the
+// NEXT call's statistics beside this call's planes (power_irfft2_kernel, look-ahead at the launch-bound batch sizes)
 template <int H, int W>
-__global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(const float* __restrict__ filter, int64_t planes, uint64_t seed,
-                                                                   uint64_t stream_id, int64_t plane_offset, int group, int split,
-                                                                   double* partials) {
+__device__ __forceinline__ void power_stats_body(const float* __restrict__ filter, int64_t planes, uint64_t seed, uint64_t stream_id,
+                                                 int64_t plane_offset, int group, int split, double* partials, int64_t bid, int64_t nb,
+                                                 c32 (*EDGE)[2][H] /* [plane of the batch][kx = 0 | kx = M][ky] */, double* red) {
     constexpr int NT = plane_threads<H, W>(), M = W / 2, Wh = M + 1;
-    constexpr int NB = 4;  // planes per batch: their edge columns wait in LDS for ONE barrier (a barrier per plane made the eight
-                           // waves of a group wait for each other four times per group)
-    __shared__ c32 EDGE[NB][2][H];  // [plane of the batch][kx = 0 | kx = M][ky]
-    __shared__ double red[2 * NT / 64];
+    constexpr int NB = kStatsBatch;
     const int tid = threadIdx.x;
     double s = 0.0, q = 0.0;
     auto edge_terms = [&](int p) {
@@ -1529,19 +1555,19 @@ __global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(co
         wgt[it + ITER] = kNegLn2 * (fb * fb);
     }
     const float f0 = tid < H ? filter[tid * Wh] : 0.0f, fm = tid < H ? filter[tid * Wh + M] : 0.0f;
-    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+    for (int64_t unit = bid; unit < (split ? planes : planes / group); unit += nb) {
         const GroupWalk gw(unit, group, split);
         SpectrumRng rng = spectrum_rng<H, false>(seed, stream_id, plane_offset / group + gw.grp, tid);
         for (int i = 0; i < gw.first; ++i) skip_plane<H, W, false>(rng, tid);
         for (int g0 = 0; g0 < gw.count; g0 += NB) {
-            const int nb = min(NB, gw.count - g0);
+            const int cnt = min(NB, gw.count - g0);
             // The planes of a batch meet the same weight at the same slot, so sum_planes w log2 u = w log2(prod_planes u): ONE logarithm
             // per slot and batch instead of one per plane (the product of four u in [2^-23, 1] stays a normal float, and its rounding
             // error, 3 x 2^-24 relative, is below the logarithm's own).
             float prod[2 * ITER];
 #pragma unroll
             for (int it = 0; it < 2 * ITER; ++it) prod[it] = 1.0f;
-            for (int b = 0; b < nb; ++b) {
+            for (int b = 0; b < cnt; ++b) {
                 draw_plane<H, W, false>(
                     rng, tid,
                     [&](uint32_t r0, uint32_t rm, uint32_t t) {
@@ -1558,11 +1584,20 @@ __global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(co
             for (int it = 0; it < 2 * ITER; ++it) acc = __builtin_fmaf(wgt[it], __builtin_amdgcn_logf(prod[it]), acc);
             q += 2.0 * (double)acc;
             __syncthreads();  // the batch's edge columns are complete
-            for (int b = 0; b < nb; ++b) edge_terms(b);
+            for (int b = 0; b < cnt; ++b) edge_terms(b);
             __syncthreads();  // ... and read, before the next batch overwrites them
         }
     }
-    write_partial<NT>(s, q, partials, red);
+    write_partial_at<NT>(s, q, partials, red, (int)bid, (int)nb);
+}
+
+template <int H, int W>
+__global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(const float* __restrict__ filter, int64_t planes, uint64_t seed,
+                                                                   uint64_t stream_id, int64_t plane_offset, int group, int split,
+                                                                   double* partials) {
+    __shared__ c32 EDGE[kStatsBatch][2][H];
+    __shared__ double red[2 * plane_threads<H, W>() / 64];
+    power_stats_body<H, W>(filter, planes, seed, stream_id, plane_offset, group, split, partials, blockIdx.x, gridDim.x, EDGE, red);
 }
 
 // the spectrum draw_plane yields for (seed, stream_id, plane_offset, group), unit filter: zout[planes][H][W/2+1] complex64
@@ -1664,7 +1699,7 @@ static int launch_power(int what, const float* z, const float* filter, float* ou
     const int64_t ngroups = split ? planes : planes / group;  // work units
     const dim3 blk(plane_threads<H, W>());
 #define SONAR_PW(G, ST, NM, PART) \
-    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(power_grid<H, W>(ngroups, ST)), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, group, split, PART, na)
+    hipLaunchKernelGGL((power_irfft2_kernel<H, W, G, ST, NM>), dim3(power_grid<H, W>(ngroups, ST)), blk, 0, st, z, filter, out, planes, seed, stream_id, plane_offset, group, split, PART, na, StatsAhead())
     if (what == 4) {
         SONAR_PW(3, false, false, nullptr);
     } else if (what == 3) {
@@ -1672,9 +1707,19 @@ static int launch_power(int what, const float* z, const float* filter, float* ou
     } else if (what == 2) {
         hipLaunchKernelGGL((power_spectrum_kernel<H, W>), dim3(std::min<int64_t>(ngroups, 2048)), blk, 0, st, out, planes, seed, stream_id, plane_offset, group, split);
     } else if (what == 1) {
-        hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(ngroups, kNPart)), blk, 0, st, filter, planes, seed, stream_id,
-                           plane_offset, group, split, partials);
-        SONAR_PW(1, false, true, nullptr);
+        if (!ah.have_stats)
+            hipLaunchKernelGGL((power_stats_kernel<H, W>), dim3(std::min<int64_t>(ngroups, kNPart)), blk, 0, st, filter, planes, seed, stream_id,
+                               plane_offset, group, split, partials);
+        if (ah.next) {  // sonar_power_noise_ahead_ok: every workgroup resident at once -- the next call's statistics in the same launch
+            StatsAhead sa;
+            sa.partials = ah.next;
+            sa.stream_id = ah.next_stream;
+            sa.main_blocks = power_grid<H, W>(ngroups, false);
+            hipLaunchKernelGGL((power_irfft2_kernel<H, W, 1, false, true>), dim3(sa.main_blocks + (int)std::min<int64_t>(ngroups, kNPart)), blk, 0, st, z,
+                               filter, out, planes, seed, stream_id, plane_offset, group, split, (double*)nullptr, na, sa);
+        } else {
+            SONAR_PW(1, false, true, nullptr);
+        }
     } else if (z == nullptr) {
         if (partials) SONAR_PW(1, true, false, partials); else SONAR_PW(1, false, false, partials);
     } else {
@@ -1730,8 +1775,8 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
                   (long long)plane_offset, group);
     SONAR_REQUIRE(group <= kMaxRngGroup, SONAR_ERR_UNSUPPORTED, "sonar_power_*: RNG groups of at most %d planes (got %d)", kMaxRngGroup, group);
 #define SONAR_CASE(HH, WW) \
-    if (H == HH && W == WW) return launch_power<HH, WW>(what, z, filter, out, planes, seed, stream_id, plane_offset, group, partials, na, st)
-    if (H == 128 && W == 128) return launch_power<128, 128>(what, z, filter, out, planes, seed, stream_id, plane_offset, group, partials, na, st, ah);
+    if (H == HH && W == WW) return launch_power<HH, WW>(what, z, filter, out, planes, seed, stream_id, plane_offset, group, partials, na, st, ah)
+    SONAR_CASE(128, 128);
     SONAR_CASE(64, 64);
     SONAR_CASE(32, 32);
     SONAR_CASE(16, 16);
@@ -1801,7 +1846,13 @@ extern "C" int sonar_power_pipeline(int enable) {
 }
 
 extern "C" int sonar_power_noise_ahead_ok(int64_t planes, int64_t H, int64_t W, int rng_group) {
-    if (H != 128 || W != 128 || !pipe_enabled() || planes <= 256 || rng_group < 1 || planes % rng_group) return 0;
+    if (sonar_power_plane_kind(H, W) != 1 || planes < 1 || rng_group < 1 || rng_group > kMaxRngGroup || planes % rng_group) return 0;
+    if (H != 128 || W != 128 || !pipe_enabled() || planes <= 256) {
+        // the phase-serial kernel (launch_power): the next call's statistics are extra workgroups of the launch -- while all of them are
+        // resident at once (at most one plane and one statistics workgroup per CU; beyond that the two-launch form is as fast)
+        const int split = rng_group > 1 && planes / rng_group < 2 * 256 ? 1 : 0;
+        return (split ? planes : planes / rng_group) <= 256 ? 1 : 0;
+    }
     int psplit;
     const int64_t units = pipe_units(planes, rng_group, &psplit);
     // the look-ahead statistics walk at most four planes per unit (TeamStats::radii, the edge columns' area): larger RNG groups only

@@ -48,7 +48,8 @@ def test_pipelined_power_kernel_equals_the_phase_serial_kernel(api, shape):
     piped = run_all()
     assert lib.sonar_power_pipeline(0) == 1
     try:
-        assert lib.sonar_power_noise_ahead_ok(planes, 128, 128, hl.rng_group_for(shape)) == 0  # the look-ahead belongs to the pipelined kernel
+        # beyond 256 work units the look-ahead belongs to the pipelined kernel (the phase-serial kernel has its own below that)
+        assert lib.sonar_power_noise_ahead_ok(planes, 128, 128, hl.rng_group_for(shape)) == 0
         serial = run_all()
     finally:
         lib.sonar_power_pipeline(1)
@@ -99,7 +100,9 @@ def test_rng_groups_beyond_the_lookahead(api):
     assert lib.sonar_power_noise_f32(filt.data_ptr(), out.data_ptr(), planes, 128, 128, 3, 9, 0, 16, 1.0, 2.5, ws.data_ptr(), st) == hl.ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("shape", [(512, 4, 128, 128), (128, 4, 128, 128), (100, 3, 128, 128)])
+@pytest.mark.parametrize("shape", [(512, 4, 128, 128), (128, 4, 128, 128), (100, 3, 128, 128),
+                                   # launch-bound batches: the phase-serial kernel, the next call's statistics in extra workgroups of its launch
+                                   (64, 4, 128, 128), (1, 4, 128, 128), (16, 3, 128, 128), (5, 16, 128, 128), (8, 4, 64, 64), (3, 4, 128, 64), (2, 4, 32, 32)])
 def test_lookahead_statistics_are_the_statistics_kernels(api, shape):
     """The statistics a call leaves for the next stream id == what the statistics launch of that call computes (same pairs, bit for bit:
     one unit per slot, the same order of additions), and a call that uses them writes the same tensor."""
@@ -107,13 +110,14 @@ def test_lookahead_statistics_are_the_statistics_kernels(api, shape):
     lib = hl.load()
     filt = _filter(api, shape)
     planes = shape[0] * shape[1]
+    H, W = shape[-2:]
     group = hl.rng_group_for(shape)
-    assert lib.sonar_power_noise_ahead_ok(planes, 128, 128, group) == 1
+    assert lib.sonar_power_noise_ahead_ok(planes, H, W, group) == 1
     st = torch.cuda.current_stream().cuda_stream
 
     def call(stream_id, ws, have, nxt, nws):
         out = torch.empty(shape, device="cuda")
-        rc = lib.sonar_power_noise_ahead_f32(filt.data_ptr(), out.data_ptr(), planes, 128, 128, 3, stream_id, 0, group, 1.0, 2.5, ws.data_ptr(), int(have),
+        rc = lib.sonar_power_noise_ahead_f32(filt.data_ptr(), out.data_ptr(), planes, H, W, 3, stream_id, 0, group, 1.0, 2.5, ws.data_ptr(), int(have),
                                              nxt, 0 if nws is None else nws.data_ptr(), st)
         assert rc == 0, lib.sonar_last_error()
         return out
