@@ -320,3 +320,5 @@ __device__ __forceinline__ T blend(int mode, T a, T b, T t) {
 bool sonar_lines_rows_r2c(const float* x, float* y, int64_t rows, int64_t W, hipStream_t st);
 bool sonar_lines_cols(const float* in, const float* filter, float* out, int64_t planes, int64_t H, int64_t K, int inverse, hipStream_t st);
 bool sonar_lines_rows_c2r(const float* y, float* out, int64_t rows, int64_t W, float scale, double* partials, hipStream_t st);
+bool sonar_lines_rows_c2r_norm(const float* y, float* out, int64_t rows, int64_t W, float scale, double* partials, const sonar::NormArgs* norm,
+                               hipStream_t st);

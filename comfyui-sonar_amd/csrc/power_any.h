@@ -873,6 +873,28 @@ struct LinesWalk {
     }
 };
 
+// A staging loop over `total` items in rows of `cols`, kLinesDepth global loads in flight per thread before the first use: one load per
+// iteration waited for a memory latency per item (a workgroup stages 15-30 items per thread and batch).
+constexpr int kLinesDepth = 8;
+template <typename T, typename Load, typename Use>
+__device__ __forceinline__ void lines_stage(int tid, int cols, int total, Load&& load, Use&& use) {
+    LinesWalk lw(tid, cols);
+    while (lw.j < total) {
+        T v[kLinesDepth];
+        int rr[kLinesDepth], cc[kLinesDepth];
+#pragma unroll
+        for (int u = 0; u < kLinesDepth; ++u) {
+            rr[u] = lw.j < total ? lw.r : -1;
+            cc[u] = lw.c;
+            if (rr[u] >= 0) v[u] = load(rr[u], cc[u]);
+            lw.next(cols);
+        }
+#pragma unroll
+        for (int u = 0; u < kLinesDepth; ++u)
+            if (rr[u] >= 0) use(rr[u], cc[u], v[u]);
+    }
+}
+
 __device__ __forceinline__ void lines_table(c32* tw, int N, int tid) {  // e^{2 pi i j / N}
     for (int j = tid; j < N; j += kLinesThreads) {
         double sn, cs;
@@ -892,10 +914,8 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_kernel(const float
     for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
         const int nr = (int)min<int64_t>(per, rows - r0);
         __syncthreads();
-        for (LinesWalk lw(tid, M); lw.j < nr * M; lw.next(M)) {
-            const int r = lw.r, m = lw.c;
-            A[r * S + m] = *reinterpret_cast<const float2*>(x + (r0 + r) * W + 2 * m);
-        }
+        lines_stage<float2>(tid, M, nr * M, [&](int r, int m) { return *reinterpret_cast<const float2*>(x + (r0 + r) * W + 2 * m); },
+                            [&](int r, int m, float2 v) { A[r * S + m] = v; });
         __syncthreads();
         line_dft<kLinesThreads, true>(A, tw, W, 2, n1, n2, nr, 1, S, tid);
         // X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i, w = e^{-2 pi i / W}
@@ -943,16 +963,15 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32*
         const int k0 = (int)(u - p * blocks) * cols, nc = min(cols, K - k0);
         const c32* src = in + p * (int64_t)H * K + k0;
         __syncthreads();
-        for (LinesWalk lw(tid, nc); lw.j < H * nc; lw.next(nc)) {
-            const int m = lw.r, c = lw.c;
-            c32 v = src[(int64_t)m * K + c];
-            if (MODE == 1 && filter) {
-                const float f = filter[(int64_t)m * K + k0 + c];
-                v.x *= f;
-                v.y *= f;
-            }
-            A[m * S + c] = v;
-        }
+        lines_stage<c32>(tid, nc, H * nc, [&](int m, int c) { return src[(int64_t)m * K + c]; },
+                         [&](int m, int c, c32 v) {
+                             if (MODE == 1 && filter) {
+                                 const float f = filter[(int64_t)m * K + k0 + c];
+                                 v.x *= f;
+                                 v.y *= f;
+                             }
+                             A[m * S + c] = v;
+                         });
         __syncthreads();
         line_dft<kLinesThreads, MODE != 1>(A, tw, H, 1, n1, n2, nc, S, 1, tid);
         if constexpr (MODE == 2) {
@@ -976,22 +995,46 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32*
 }
 
 // out[row][x] = scale * (Re y0 + sum_{k >= 1} w_k Re(y_k e^{+2 pi i k x / W})), w_k = 2 (1 for the Nyquist column)
-template <bool STATS>
+// NORM: out = (v * scale - mean) / std * factor by the statistics in na.partials (computed before the rows exist: power_block.h)
+template <bool STATS, bool NORM = false>
 __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* __restrict__ y, float* __restrict__ out, int64_t rows, int W, int n1,
-                                                                     int n2, int per, float scale, double* partials) {
+                                                                     int n2, int per, float scale, double* partials, NormArgs na) {
     extern __shared__ __align__(16) unsigned char any_lds[];
     __shared__ double red[2 * kLinesThreads / 64];
+    __shared__ NormDecision shd;
     const int M = W / 2, S = M + 1, tid = threadIdx.x;
     c32* const A = reinterpret_cast<c32*>(any_lds);
     c32* const tw = A + per * S;
     lines_table(tw, W, tid);
+    [[maybe_unused]] float nc = 0.0f;
+    if constexpr (NORM) {
+        const NormDecision dec = decide_norm<kLinesThreads>(na.partials, kNPart, na.n_total, na.thr_sd, red, &shd);
+        const float g = (dec.do_div ? 1.0f / dec.stdv : 1.0f) * na.factor;
+        scale *= g;
+        nc = dec.do_sub ? dec.mean * g : 0.0f;
+    }
     double s = 0.0, q = 0.0;
     for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
         const int nr = (int)min<int64_t>(per, rows - r0);
         __syncthreads();
-        for (LinesWalk lw(tid, S); lw.j < nr * S; lw.next(S)) {
-            const int r = lw.r, k = lw.c;
-            A[r * S + k] = y[(r0 + r) * S + k];
+        {   // the batch is one contiguous run of the workspace and of LDS (same row stride): eight loads in flight per thread -- one at a
+            // time, a batch of 61 rows of 129 values waited for sixteen memory latencies in a row
+            const c32* __restrict__ src = y + r0 * S;
+            const int total = nr * S;
+            constexpr int U = 8;
+            for (int i0 = tid; i0 < total; i0 += U * kLinesThreads) {
+                c32 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * kLinesThreads;
+                    v[u] = src[i < total ? i : i0];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * kLinesThreads;
+                    if (i < total) A[i] = v[u];
+                }
+            }
         }
         __syncthreads();
         // G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k; X[0], X[M] contribute their real parts
@@ -1023,7 +1066,7 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* 
         for (LinesWalk lw(tid, M); lw.j < nr * M; lw.next(M)) {
             const int r = lw.r, m = lw.c;
             const c32 g = A[r * S + m];
-            const float a = g.x * scale, b = g.y * scale;
+            const float a = NORM ? __builtin_fmaf(g.x, scale, -nc) : g.x * scale, b = NORM ? __builtin_fmaf(g.y, scale, -nc) : g.y * scale;
             *reinterpret_cast<float2*>(out + (r0 + r) * W + 2 * m) = make_float2(a, b);
             if constexpr (STATS) {  // fp64 per value, like the direct pass (its callers compare the sums with the tensor's)
                 const double da = a, db = b;
@@ -1173,8 +1216,16 @@ bool sonar_lines_cols(const float* in, const float* filter, float* out, int64_t 
 }
 
 bool sonar_lines_rows_c2r(const float* y, float* out, int64_t rows, int64_t W, float scale, double* partials, hipStream_t st) {
+    return sonar_lines_rows_c2r_norm(y, out, rows, W, scale, partials, nullptr, st);
+}
+
+// `norm`: write the rows normalised by the statistics it names (even widths only; no statistics of the output then)
+bool sonar_lines_rows_c2r_norm(const float* y, float* out, int64_t rows, int64_t W, float scale, double* partials, const sonar::NormArgs* norm,
+                               hipStream_t st) {
     using namespace sonar;
     if (W < 3 || W > kLinesMax || (!(W & 1) && W < 4)) return false;
+    if (norm && ((W & 1) || partials)) return false;
+    const NormArgs na = norm ? *norm : NormArgs{nullptr, 0, 1.0f, 0.0f};
     if (W & 1) {
         int n1, n2;
         best_split((int)W, n1, n2);
@@ -1200,14 +1251,18 @@ bool sonar_lines_rows_c2r(const float* y, float* out, int64_t rows, int64_t W, f
     const size_t line = (size_t)(M + 1) * sizeof(c32), table = (size_t)W * sizeof(c32);
     const int per = lines_per(line, table, 512);
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>((rows + per - 1) / per, kNPart));
-    if (partials) {
+    if (norm) {
+        lines_lds_attr(lines_c2r_kernel<false, true>);
+        hipLaunchKernelGGL((lines_c2r_kernel<false, true>), dim3(g), dim3(kLinesThreads), per * line + table, st, reinterpret_cast<const c32*>(y), out, rows,
+                           (int)W, n1, n2, per, scale, partials, na);
+    } else if (partials) {
         lines_lds_attr(lines_c2r_kernel<true>);
         hipLaunchKernelGGL(lines_c2r_kernel<true>, dim3(g), dim3(kLinesThreads), per * line + table, st, reinterpret_cast<const c32*>(y), out, rows, (int)W,
-                           n1, n2, per, scale, partials);
+                           n1, n2, per, scale, partials, na);
     } else {
         lines_lds_attr(lines_c2r_kernel<false>);
         hipLaunchKernelGGL(lines_c2r_kernel<false>, dim3(g), dim3(kLinesThreads), per * line + table, st, reinterpret_cast<const c32*>(y), out, rows, (int)W,
-                           n1, n2, per, scale, partials);
+                           n1, n2, per, scale, partials, na);
     }
     return true;
 }

@@ -1762,6 +1762,7 @@ __global__ void __launch_bounds__(kBlock) channel_mix_kernel(const float* __rest
 }  // namespace sonar
 
 #include "power_any.h"
+#include "power_block.h"
 
 using namespace sonar;
 
@@ -1813,7 +1814,30 @@ extern "C" int sonar_power_plane_kind(int64_t H, int64_t W) {
                                   {256, 64}, {64, 256}};
     for (const auto& f : fast)
         if (H == f[0] && W == f[1]) return 1;
-    return any_plane_ok(H, W) ? 2 : 0;
+    if (any_plane_ok(H, W)) return 2;
+    return block_plane_ok(H, W) ? 4 : 0;  // 4: generated in column blocks through a workspace (sonar_power_block_f32); 3 is the host's name for the direct passes
+}
+
+extern "C" int64_t sonar_power_block_ws_bytes(int64_t planes, int64_t H, int64_t W) {
+    if (planes < 0 || sonar_power_plane_kind(H, W) != 4) return -1;
+    return planes * H * (W / 2 + 1) * (int64_t)sizeof(c32);
+}
+
+extern "C" int sonar_power_block_f32(const float* filter, float* ws, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,
+                                     int64_t plane_offset, int rng_group, int mode, float factor, float threshold_std_devs, double* partials,
+                                     void* stream) {
+    SONAR_REQUIRE(ws && planes >= 0 && plane_offset >= 0 && mode >= 0 && mode <= 2 && (mode == 2 || (filter && out)) && (mode != 1 || partials),
+                  SONAR_ERR_ARG, "sonar_power_block_f32: bad argument");
+    SONAR_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0 && (mode == 2 || (reinterpret_cast<uintptr_t>(out) & 7u) == 0), SONAR_ERR_ARG,
+                  "sonar_power_block_f32: misaligned buffer");
+    SONAR_REQUIRE(sonar_power_plane_kind(H, W) == 4, SONAR_ERR_UNSUPPORTED,
+                  "sonar_power_block_f32: %lld x %lld is not a column-block plane (sonar_power_plane_kind != 4)", (long long)H, (long long)W);
+    SONAR_REQUIRE(rng_group >= 1 && rng_group <= kMaxRngGroup && planes % rng_group == 0 && plane_offset % rng_group == 0, SONAR_ERR_ARG,
+                  "sonar_power_block_f32: planes (%lld) and plane_offset (%lld) must be multiples of the RNG group (%d, at most %d)", (long long)planes,
+                  (long long)plane_offset, rng_group, kMaxRngGroup);
+    if (planes == 0) return SONAR_OK;
+    return launch_power_block(mode, filter, ws, out, planes, H, W, seed, stream_id, plane_offset, rng_group, partials,
+                              NormArgs{partials, planes * H * W, factor, threshold_std_devs}, (hipStream_t)stream);
 }
 
 extern "C" int sonar_power_irfft2_f32(const float* z, const float* filter, float* out, int64_t planes, int64_t H,

@@ -134,6 +134,8 @@ SIGNATURES = {
     "sonar_mul_table_f32": (_I, [_P, _P, _I64, _I64, _I64, _I, _P]),
     "sonar_laplace_add_f32": (_I, [_P, _P, _F, _F, _F, _I64, _P]),
     "sonar_power_plane_kind": (_I, [_I64, _I64]),
+    "sonar_power_block_ws_bytes": (_I64, [_I64, _I64, _I64]),
+    "sonar_power_block_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _I, _F, _F, _P, _P]),
     "sonar_rfft2_f32": (_I, [_P, _P, _I64, _I64, _I64, _P]),
     "sonar_cdft_mid_f32": (_I, [_P, _P, _I64, _I64, _I64, _I, _I, _I, _P]),
     "sonar_spectral_logamp_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P]),
@@ -1008,7 +1010,10 @@ def power_irfft2(z: Optional[torch.Tensor], filt: torch.Tensor, shape, *, seed: 
         zp = z.data_ptr()
     if filt.numel() != H * (W // 2 + 1):
         raise SonarHipError("power_irfft2: filter size mismatch")
-    if power_plane_kind(H, W) == 3:
+    kind = power_plane_kind(H, W)
+    if kind == 4 and z is None:
+        return _power_block(0, filt, out, seed, stream_id, plane_offset, partials=partials)
+    if kind in (3, 4):
         if z is None:
             # the reference's own route: white noise, rfft2, x filter, irfft2 (py/nodes/powernoise.py:356-366); global element keys
             white = philox_normal(tuple(shape), filt.device, seed, stream_id, plane_offset * H * W)
@@ -1048,7 +1053,11 @@ def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_o
     H, W = shape[-2:]
     out = torch.empty(shape, dtype=torch.float32, device=filt.device)
     planes = out.numel() // (H * W)
-    if power_plane_kind(H, W) == 3:
+    kind = power_plane_kind(H, W)
+    if kind == 4:
+        return _power_block(1, filt, out, seed, stream_id, plane_offset, partials=new_partials(filt.device), factor=factor,
+                            threshold_std_devs=threshold_std_devs)
+    if kind == 3:
         ws = new_partials(filt.device)
         white = philox_normal(tuple(shape), filt.device, seed, stream_id, plane_offset * H * W)
         return scale_noise_(_direct_spectral_filter(white, filt, ws), factor, True, ws, threshold_std_devs=threshold_std_devs)
@@ -1101,7 +1110,7 @@ def spectral_filter(x: torch.Tensor, filt: torch.Tensor, partials: Optional[torc
     planes = x.numel() // (H * W)
     if filt.numel() != H * (W // 2 + 1):
         raise SonarHipError("spectral_filter: filter size mismatch")
-    if power_plane_kind(H, W) == 3:
+    if power_plane_kind(H, W) in (3, 4):
         return _direct_spectral_filter(x, filt, partials)
     out = torch.empty_like(x)
     _check(load().sonar_spectral_filter_f32(_dev(x, "x"), _dev(filt, "filter"), _dev(out, "out"), planes, H, W,
@@ -1167,6 +1176,10 @@ def power_spectrum(shape, device, *, seed: int, stream_id: int, plane_offset: in
     H, W = shape[-2:]
     z = torch.empty((*shape[:-1], W // 2 + 1), dtype=torch.complex64, device=device)
     planes = z.numel() // (H * (W // 2 + 1))
+    if power_plane_kind(H, W) == 4:
+        _check(load().sonar_power_block_f32(None, z.data_ptr(), None, planes, H, W, seed & (2**64 - 1), stream_id, plane_offset, rng_group_for(shape), 2,
+                                            1.0, 0.0, None, _stream()), "sonar_power_block_f32")
+        return z
     _check(load().sonar_power_spectrum_f32(z.data_ptr(), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset, rng_group_for(shape), _stream()),
            "sonar_power_spectrum_f32")
     return z
@@ -1175,8 +1188,22 @@ def power_spectrum(shape, device, *, seed: int, stream_id: int, plane_offset: in
 DIRECT_DFT_MAX = 2048
 
 
+def _power_block(mode: int, filt: torch.Tensor, out: torch.Tensor, seed: int, stream_id: int, plane_offset: int, *, partials=None, factor: float = 1.0,
+                 threshold_std_devs: float = 2.5) -> torch.Tensor:
+    """Kind-4 planes (half-spectrum beyond LDS), spectrum drawn on device: draw + filter + columns into a complex workspace, rows out of it
+    (``sonar_power_block_f32``); mode 1 writes the tensor normalised (Parseval statistics first)."""
+    H, W = out.shape[-2:]
+    planes = out.numel() // (H * W)
+    ws = torch.empty((planes, H, W // 2 + 1), dtype=torch.complex64, device=out.device)
+    _check(load().sonar_power_block_f32(_dev(filt, "filter"), _dev(ws, "ws", torch.complex64), _dev(out, "out"), planes, H, W, seed & (2**64 - 1), stream_id, plane_offset,
+                                        rng_group_for(out.shape), mode, float(factor), float(threshold_std_devs), _opt(partials, "partials", torch.float64),
+                                        _stream()), "sonar_power_block_f32")
+    return out
+
+
 def power_plane_kind(H: int, W: int) -> int:
-    """1: fixed-size LDS kernels, 2: general-size LDS kernels (even sizes that fit), 3: direct DFT passes (any size up to 2048), 0: none."""
+    """1: fixed-size LDS kernels, 2: general-size LDS kernels (even sizes that fit), 4: beyond LDS, generated in column blocks (a supplied
+    spectrum / the spectral filter: the direct passes, as 3), 3: direct DFT passes (any size up to 2048), 0: none."""
     kind = int(load().sonar_power_plane_kind(int(H), int(W)))
     if kind == 0 and 1 <= H <= DIRECT_DFT_MAX and 1 <= W <= DIRECT_DFT_MAX:
         return 3

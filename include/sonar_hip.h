@@ -407,8 +407,24 @@ int sonar_level_normal_f32(float* level, int64_t planes, int64_t h, int64_t w, f
 /* ---------------------------------------------------------------- power-law rFFT noise (row PW) */
 /* Which kernel family serves an H x W plane of the power-noise path: 1 = the fixed-size LDS FFT kernels (powers of two, 16..256),
  * 2 = the general-size kernels (any even H <= 512, even W <= 1024 with H*(W/2+1) + H + W <= 20224 complex values: two-factor table-twiddle DFTs in LDS;
- * e.g. 104 x 152 for 832 x 1216 px), 0 = unsupported (the sonar_power_* / sonar_spectral_filter_f32 calls return -2). */
+ * e.g. 104 x 152 for 832 x 1216 px), 4 = half-spectrum beyond LDS (even H <= 512, even W <= 2048: 256 x 256 for 2048 px): GENERATED noise runs
+ * in column blocks through a complex workspace (sonar_power_block_f32); a supplied spectrum and the spectral filter take the
+ * sonar_dft_* passes as for kind 0, 0 = unsupported by the LDS kernels (the sonar_power_* / sonar_spectral_filter_f32 calls return -2 for
+ * kinds 0 and 4). */
 int sonar_power_plane_kind(int64_t H, int64_t W);
+/* Kind-4 planes, spectrum drawn on device (py/nodes/powernoise.py:338-366 -- the reference filters the rfft2 of white noise, which IS
+ * a complex-normal half-spectrum: drawn directly, no forward transform):
+ *   mode 0: out = irfft2(drawn * filter, norm="ortho"); statistics of out into `partials` when given
+ *   mode 1: the same, normalised like sonar_power_noise_f32 (Parseval statistics of the draw first, `partials` is their workspace): the
+ *           tensor is written once, the workspace written and read once (3 x the tensor of HBM traffic)
+ *   mode 2: the drawn spectrum itself into `ws` as [planes][H][W/2+1] complex64 (filter, out unused): what modes 0 / 1 transform
+ *   ws      [planes][H][W/2+1] complex64 scratch, sonar_power_block_ws_bytes(planes, H, W) bytes (-1: not a kind-4 plane)
+ * Streams are keyed by (rng_group of global planes, block of <= 32 spectrum columns, thread slot): shards of a batch agree; the values
+ * differ from the white-noise route round 3 used for these planes. */
+int64_t sonar_power_block_ws_bytes(int64_t planes, int64_t H, int64_t W);
+int sonar_power_block_f32(const float* filter, float* ws, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed, uint64_t stream_id,
+                          int64_t plane_offset, int rng_group, int mode, float factor, float threshold_std_devs, double* partials /*mode 1: required*/,
+                          void* stream);
 /* py/nodes/powernoise.py:366-377: out = irfft2(z * filter, s=(H,W), norm="ortho").
  *   z      [planes][H][W/2+1] complex64 (interleaved re,im) or NULL -> drawn on device: complex normal
  *          (a+ib)*sqrt(1/2); plane p of this call is global plane plane_offset + p of the logical batch.

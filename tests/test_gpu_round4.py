@@ -483,3 +483,91 @@ def test_a_planned_perlin_call_is_one_launch(api, shape):
                                                   with_next, 104, None, None, None, 0, 0, 0, 0, 0, 0, st)
             assert rc == 0 and torch.equal(out1, want1)
     assert lib.sonar_perlin_noise_ahead_ok(b_, chw + 4, 0) == 0 and lib.sonar_perlin_noise_ahead_ok(8192, 65536, 0) == 0
+
+
+# ------------------------------------------------------------------------------------------------ planes beyond LDS, generated (kind 4)
+@pytest.mark.parametrize("shape", [(8, 4, 256, 256), (2, 4, 256, 256), (1, 4, 512, 512), (3, 1, 384, 512), (2, 3, 320, 256), (1, 2, 64, 2048), (1, 4, 512, 4),
+                                   (70, 4, 256, 256)])
+def test_planes_beyond_lds_are_generated_in_column_blocks(api, shape):
+    """Kind-4 planes (2048 px latents: 256 x 256): the spectrum is drawn in blocks of columns, filtered and column-transformed into a complex
+    workspace, the rows come out of it (sonar_power_block_f32).  The tensor is irfft2(drawn spectrum x filter) -- the spectrum itself is mode
+    2's dump --, the normalised call (Parseval statistics first, no pass over the tensor) is the raw tensor normalised, the statistics of
+    mode 0 are the tensor's, and two shards of a batch are the batch."""
+    hl = api.hl
+    lib = hl.load()
+    b, c, H, W = shape
+    K = W // 2 + 1
+    planes = b * c
+    if hl.power_plane_kind(H, W) != 4:
+        assert (H, W) == (512, 4)  # fits LDS: the general-size kernels' plane
+        return
+    assert lib.sonar_power_block_ws_bytes(planes, H, W) == planes * H * K * 8 and lib.sonar_power_block_ws_bytes(1, 128, 128) == -1
+    g = torch.Generator(device="cuda").manual_seed(5)
+    filt = torch.rand(H, K, device="cuda", generator=g) + 0.25
+    spec = hl.power_spectrum(shape, "cuda", seed=7, stream_id=3)
+    assert tuple(spec.shape) == (b, c, H, K)
+    mag = (spec.real.double() ** 2 + spec.imag.double() ** 2)
+    assert (mag > 0).double().mean().item() > 0.999999  # every column of every block is drawn (a zero radius has probability 2^-23)
+    n = spec.numel()
+    assert abs(mag.mean().item() - 1.0) < 6.0 / n ** 0.5 and abs(spec.real.double().mean().item()) < 4.0 / n ** 0.5  # unit complex normals
+    part = hl.new_partials("cuda")
+    raw = hl.power_irfft2(None, filt, shape, seed=7, stream_id=3, plane_offset=0, partials=part)
+    want = torch.fft.irfft2(spec * filt, s=(H, W), norm="ortho")
+    torch.testing.assert_close(raw, want, rtol=0, atol=2e-5 * float(want.abs().max()))
+    d = raw.double()
+    torch.testing.assert_close(part.view(-1, 2).sum(0), torch.stack([d.sum(), (d * d).sum()]), rtol=1e-9, atol=1e-6)
+    assert torch.equal(raw, hl.power_irfft2(None, filt, shape, seed=7, stream_id=3, plane_offset=0))
+    norm = hl.power_noise(filt, shape, seed=7, stream_id=3, plane_offset=0, factor=0.75)
+    # scale_noise's rule (a mean inside its band is left alone), by the tensor's own statistics in place of the draw's Parseval sums
+    torch.testing.assert_close(norm, hl.scale_noise_(raw.clone(), 0.75, True, part), rtol=2e-5, atol=4e-6)
+    assert abs(norm.double().std().item() - 0.75) < 1e-4
+    if b % 2 == 0:
+        h = b // 2
+        lo = hl.power_irfft2(None, filt, (h, c, H, W), seed=7, stream_id=3, plane_offset=0)
+        hi = hl.power_irfft2(None, filt, (h, c, H, W), seed=7, stream_id=3, plane_offset=h * c)
+        assert torch.equal(torch.cat([lo, hi]), raw)
+    other = hl.power_irfft2(None, filt, shape, seed=7, stream_id=4, plane_offset=0)
+    assert abs(torch.corrcoef(torch.stack([raw.flatten(), other.flatten()]))[0, 1].item()) < 5.0 / raw.numel() ** 0.5 + 1e-3
+
+
+def test_block_planes_refusals(api):
+    hl = api.hl
+    lib = hl.load()
+    st = hl._stream()
+    filt = torch.ones(256, 129, device="cuda")
+    ws = torch.empty(4, 256, 129, dtype=torch.complex64, device="cuda")
+    out = torch.full((4, 256, 256), 7.0, device="cuda")
+    part = hl.new_partials("cuda")
+    args = (filt.data_ptr(), ws.data_ptr(), out.data_ptr(), 4, 256, 256, 1, 2, 0, 4)
+    assert lib.sonar_power_block_f32(*args, 1, 1.0, 2.5, None, st) == hl.ERR_ARG  # the normalised mode needs its statistics workspace
+    assert lib.sonar_power_block_f32(*args, 3, 1.0, 2.5, part.data_ptr(), st) == hl.ERR_ARG
+    assert lib.sonar_power_block_f32(filt.data_ptr(), ws.data_ptr(), out.data_ptr(), 4, 256, 256, 1, 2, 0, 3, 0, 1.0, 2.5, None, st) == hl.ERR_ARG
+    assert lib.sonar_power_block_f32(filt.data_ptr(), ws.data_ptr(), out.data_ptr(), 4, 128, 128, 1, 2, 0, 4, 0, 1.0, 2.5, None, st) == hl.ERR_UNSUPPORTED
+    assert lib.sonar_power_noise_f32(filt.data_ptr(), out.data_ptr(), 4, 256, 256, 1, 2, 0, 4, 1.0, 2.5, part.data_ptr(), st) == hl.ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+    assert bool((out == 7.0).all())
+
+
+def test_power_sampler_on_a_2048px_latent(api):
+    """The power-law item on a 256 x 256 latent (kind 4) from the node down: unit statistics, a plan after the warm calls with the same bits
+    as the ordinary path, and an isotropic 1/f spectrum (the filter reaches the draw: low radii carry more power than high ones)."""
+    hl = api.hl
+    x = torch.zeros(2, 4, 256, 256, device="cuda")
+    item = _power(api)
+
+    def run(plans):
+        hl.PLANS_ENABLED = plans
+        try:
+            torch.manual_seed(77)
+            ns = item.make_noise_sampler(x, None, None, seed=None, cpu=False, normalized=True)
+            return [ns(None, None).clone() for _ in range(6)]
+        finally:
+            hl.PLANS_ENABLED = True
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    t = a[-1].double()
+    assert abs(t.std().item() - 1.0) < 1e-3 and abs(t.mean().item()) < 1e-3 and not torch.equal(a[0], a[1])
+    p = torch.fft.rfft2(a[-1], norm="ortho").abs().pow(2).mean((0, 1))
+    assert p[2:6, 2:6].mean().item() > 4.0 * p[60:100, 60:100].mean().item()
