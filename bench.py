@@ -249,7 +249,8 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
     kernels.append(kernel_entry("power_irfft2_kernel<SRC=2> spectral filter, batch 512", us, 8 * N_LATENT * BATCH,
                                 tr.get("spectral_filter_b512", {}).get("hbm_bytes_per_launch")))
     # the same call on planes off the 128 x 128 path, 33.5 M values each: SD 1.5 latents (the fixed-size kernels' general passes), an
-    # SDXL portrait bucket (general-size kernels: codelets 13 x 8 and 19 x 4), 2048 px (beyond LDS: line transforms pass by pass)
+    # SDXL portrait bucket (general-size kernels: codelets 13 x 8 and 19 x 4), 2048 px (beyond LDS: drawn and column-transformed in blocks of
+    # columns into a complex workspace, rows out of it -- sonar_power_block_f32)
     for tag, (hh, ww, nb) in {"64x64": (64, 64, 2048), "104x152": (104, 152, 530), "256x256": (256, 256, 128)}.items():
         try:
             fz = torch.rand(hh, ww // 2 + 1, device=device) + 0.5
@@ -262,7 +263,7 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
             us = event_us(sized_call, 20, 5)
             extra[f"power_noise_{tag}_us"] = us
             kernels.append(kernel_entry(f"power noise, normalised generate, {nb} latents of {C} x {hh} x {ww}", us, 4 * nb * C * hh * ww, None,
-                                        "two launches (statistics + final pass; five passes for 256 x 256); bytes = the tensor written once"))
+                                        "two launches (statistics + final pass; 256 x 256: statistics + columns into a workspace + rows, 3 x the tensor of traffic); bytes = the tensor written once"))
         except Exception as exc:  # secondary figure only
             extra[f"power_noise_{tag}_error"] = repr(exc)[:200]
     # brownian (cfg5's third source): one new path point per call, bridged between the kept tensors of its neighbours

@@ -1037,32 +1037,9 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* 
             }
         }
         __syncthreads();
-        // G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k; X[0], X[M] contribute their real parts
-        for (LinesWalk lw(tid, (M / 2 + 1)); lw.j < nr * (M / 2 + 1); lw.next((M / 2 + 1))) {
-            const int r = lw.r, k = lw.c;
-            c32* row = A + r * S;
-            if (k == 0) {
-                const float x0 = row[0].x, xm = row[M].x;
-                row[0] = make_float2(x0 + xm, x0 - xm);
-            } else {
-                const int kk = M - k;
-                const c32 xa = row[k], xb = row[kk];
-                {
-                    const c32 e = make_float2(xa.x + xb.x, xa.y - xb.y), d = make_float2(xa.x - xb.x, xa.y + xb.y);
-                    const c32 w = tw[k];
-                    const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
-                    row[k] = make_float2(e.x - o.y, e.y + o.x);
-                }
-                if (kk != k) {
-                    const c32 e = make_float2(xb.x + xa.x, xb.y - xa.y), d = make_float2(xb.x - xa.x, xb.y + xa.y);
-                    const c32 w = tw[kk];
-                    const c32 o = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
-                    row[kk] = make_float2(e.x - o.y, e.y + o.x);
-                }
-            }
-        }
-        __syncthreads();
-        line_dft<kLinesThreads, false>(A, tw, W, 2, n1, n2, nr, 1, S, tid);
+        // G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k (X[0], X[M] contribute their real parts), formed by the first pass as it
+        // loads when that pass is a codelet (c2r_pass0: one LDS round trip and one barrier fewer per batch), then the length-M inverse DFT
+        c2r_rows<kLinesThreads>(A, tw, W, n1, n2, nr, M, S, 1, tid);
         for (LinesWalk lw(tid, M); lw.j < nr * M; lw.next(M)) {
             const int r = lw.r, m = lw.c;
             const c32 g = A[r * S + m];

@@ -415,8 +415,9 @@ int sonar_power_plane_kind(int64_t H, int64_t W);
 /* Kind-4 planes, spectrum drawn on device (py/nodes/powernoise.py:338-366 -- the reference filters the rfft2 of white noise, which IS
  * a complex-normal half-spectrum: drawn directly, no forward transform):
  *   mode 0: out = irfft2(drawn * filter, norm="ortho"); statistics of out into `partials` when given
- *   mode 1: the same, normalised like sonar_power_noise_f32 (Parseval statistics of the draw first, `partials` is their workspace): the
- *           tensor is written once, the workspace written and read once (3 x the tensor of HBM traffic)
+ *   mode 1: the same, normalised like sonar_power_noise_f32 (the column pass sums the Parseval statistics of the filtered spectrum it holds
+ *           into `partials`, the row pass writes normalised values): two launches, the tensor written once, the workspace written and read
+ *           once (3 x the tensor of HBM traffic)
  *   mode 2: the drawn spectrum itself into `ws` as [planes][H][W/2+1] complex64 (filter, out unused): what modes 0 / 1 transform
  *   ws      [planes][H][W/2+1] complex64 scratch, sonar_power_block_ws_bytes(planes, H, W) bytes (-1: not a kind-4 plane)
  * Streams are keyed by (rng_group of global planes, block of <= 32 spectrum columns, thread slot): shards of a batch agree; the values

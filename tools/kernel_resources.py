@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "comfyui-sonar_amd", "csrc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "--cuda-device-only", "-Wno-unused-function", "-S"]
 HEADLINE = ("power_pipe_kernel", "power_irfft2_kernelILi128ELi128", "power_irfft2_kernelILi64ELi64", "power_irfft2_any_kernel", "power_stats_kernel",
-            "lines_", "levels_sampled_kernel", "wcfg_lowpass_kernel", "pyramid_plane_kernel", "perlin_generate_kernel")
+            "lines_", "power_block", "levels_sampled_kernel", "wcfg_lowpass_kernel", "pyramid_plane_kernel", "perlin_generate_kernel")
 
 
 def demangle(names):
