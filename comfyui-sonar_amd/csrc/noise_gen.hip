@@ -937,6 +937,11 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                                                                double* partials, int grid_floats, Accum fold, Prefix pre, LatticeJob lat) {
     extern __shared__ __align__(16) float pyr_lds[];
     __shared__ double red[2 * kPyrBlock / 64];
+    // the levels' parameters where a thread can index them by a run-time level (kernel arguments live in scalar registers: per-level
+    // loops over them are sixteen short dependent loops; flattened over (level, item) a thread has four independent items in flight)
+    __shared__ int lvl_h[kMaxLevels], lvl_w[kMaxLevels], lvl_off[kMaxLevels + 1], lvl_item0[kMaxLevels + 1];
+    __shared__ float lvl_weight[kMaxLevels];
+    __shared__ unsigned long long lvl_stream[kMaxLevels];
     if ((int)blockIdx.x < lat.blocks) {
         perlin_lattice_cells<kPyrBlock>(lat.out, lat.iters, lat.C, H, W, lat.blend_mode, lat.seed, lat.stream_id, blockIdx.x, lat.blocks);
         return;
@@ -947,7 +952,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     const int HW = H * W;
     const uint32_t lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int part = threadIdx.x / kBlock, slot = threadIdx.x % kBlock;  // 256-thread parts of the workgroup
+    const int part = threadIdx.x / kBlock;  // 256-thread parts of the workgroup
     const int dy = 256 / W, dx = 256 - dy * W;  // one burst step advances 256 elements
     // bilinear source coordinates depend on (level, x) and (level, y) only: tabulated once per workgroup
     Lin* const xtab = reinterpret_cast<Lin*>(pyr_lds + grid_floats);  // [level][W]
@@ -969,18 +974,56 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
             }
         }
     }
-    if (mode == 0) {
-        for (int l = 0; l < lv.count; ++l) {
-            const float sy = (float)lv.h[l] / (float)H, sx = (float)lv.w[l] / (float)W;
-            for (int i = threadIdx.x; i < W; i += kPyrBlock) xtab[l * W + i] = lin_coord(i, sx, lv.w[l]);
-            for (int i = threadIdx.x; i < H; i += kPyrBlock) {
-                Lin ly = lin_coord(i, sy, lv.h[l]);
-                const int pitch = XROWS ? W : lv.w[l];
+    // The parts other than the first reach their share of a tile's burst by stepping their generators over the iterations before it: a
+    // dependent chain (~160 cycles per word at two waves per SIMD, 5 k cycles for half a burst -- those waves left the tile loop 2.2 us
+    // after part 0's).  For the workgroup's first plane they do it HERE, while part 0 builds the coordinate tables alone.
+    constexpr int kIters = kTileIters / kPyrParts;
+    const int64_t t_ahead = part != 0 ? (elem_offset + (int64_t)bid * HW) / kTileElems + wave % (kBlock / 64) : -1;
+    Xoshiro rng_ahead, prng_ahead;
+    if (threadIdx.x == 0) {
+        int off = 0, item = 0;
+#pragma unroll
+        for (int l = 0; l < kMaxLevels; ++l) {
+            if (l < lv.count) {
+                const int n = lv.h[l] * lv.w[l];
+                lvl_h[l] = lv.h[l];
+                lvl_w[l] = lv.w[l];
+                lvl_weight[l] = lv.weight[l];
+                lvl_stream[l] = lv.draw_stream[l];
+                lvl_off[l] = off;
+                lvl_item0[l] = item;
+                off += n;
+                item += lv.ptr[l] ? 0 : min(kBlock, (n + 3) / 4);  // drawn levels: one item per active generator slot
+            }
+        }
+        lvl_off[lv.count] = off;
+        lvl_item0[lv.count] = item;
+    }
+    __syncthreads();
+    if (part != 0 && bid < planes) {
+        rng_ahead = rng_stream(seed, stream_id, (uint64_t)t_ahead, lane);
+        if constexpr (PRE != 0) prng_ahead = rng_stream(pre.seed, pre.stream_id, (uint64_t)t_ahead, lane);
+        for (int k = 0; k < part * kIters * 4; ++k) {
+            rng_ahead.next();
+            if constexpr (PRE != 0) prng_ahead.next();
+        }
+    }
+    if (mode == 0 && part == 0) {
+        const int per = W + H;
+        for (int j = threadIdx.x; j < lv.count * per; j += kBlock) {
+            const int l = j / per, r = j - l * per, h = lvl_h[l], w = lvl_w[l];
+            if (r < W) {
+                xtab[l * W + r] = lin_coord(r, (float)w / (float)W, w);
+            } else {
+                const int i = r - W;
+                Lin ly = lin_coord(i, (float)h / (float)H, h);
+                const int pitch = XROWS ? W : w;
                 ly.i0 *= pitch;  // row offsets
                 ly.i1 *= pitch;
                 if constexpr (XROWS) {
-                    ly.w0 *= lv.weight[l];
-                    ly.w1 *= lv.weight[l];
+                    const float wt = lvl_weight[l];
+                    ly.w0 *= wt;
+                    ly.w1 *= wt;
                 }
                 ytab[l * H + i] = ly;
             }
@@ -990,23 +1033,30 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     for (int64_t p = bid; p < planes; p += nblocks) {
         __syncthreads();
         SONAR_NG_STAMP(2);
-        int off = 0;
-        for (int l = 0; l < lv.count; ++l) {
-            const int n = lv.h[l] * lv.w[l];
-            if (lv.ptr[l]) {
-                const float* src = lv.ptr[l] + p * (int64_t)n;
-                for (int i = threadIdx.x; i < n; i += kPyrBlock) pyr_lds[off + i] = src[i];
-            } else if ((l & (kPyrParts - 1)) == part && slot * 4 < n) {
-                // the grid is drawn here: stream (level stream id, global plane, slot), slot t of 256 owns elements 4t.., 4(t + 256)..;
-                // the levels alternate between the workgroup's 256-thread parts
-                Xoshiro rng = rng_stream(seed, lv.draw_stream[l], (uint64_t)(elem_offset / HW + p), slot);
-                for (int i = slot * 4; i < n; i += kBlock * 4) {
-                    float z[4];
-                    rng.normal4(z);
-                    for (int k = 0; k < 4 && i + k < n; ++k) pyr_lds[off + i + k] = z[k];
+        {
+            int off = 0;
+            for (int l = 0; l < lv.count; ++l) {  // supplied levels (replay mode): copied
+                const int n = lv.h[l] * lv.w[l];
+                if (lv.ptr[l]) {
+                    const float* src = lv.ptr[l] + p * (int64_t)n;
+                    for (int i = threadIdx.x; i < n; i += kPyrBlock) pyr_lds[off + i] = src[i];
                 }
+                off += n;
             }
-            off += n;
+        }
+        // drawn levels: stream (level stream id, global plane, slot), slot t of 256 owns elements 4t.., 4(t + 256)..; the (level, slot)
+        // items of all levels are dealt to the workgroup's threads in one go (per level, the small levels left most threads idle
+        // behind a generator seeding each)
+        for (int item = threadIdx.x; item < lvl_item0[lv.count]; item += kPyrBlock) {
+            int l = 0;
+            while (item >= lvl_item0[l + 1]) ++l;
+            const int gslot = item - lvl_item0[l], off = lvl_off[l], n = lvl_off[l + 1] - off;
+            Xoshiro rng = rng_stream(seed, lvl_stream[l], (uint64_t)(elem_offset / HW + p), gslot);
+            for (int i = gslot * 4; i < n; i += kBlock * 4) {
+                float z[4];
+                rng.normal4(z);
+                for (int k = 0; k < 4 && i + k < n; ++k) pyr_lds[off + i + k] = z[k];
+            }
         }
         SONAR_NG_STAMP(3);
         __syncthreads();
@@ -1051,14 +1101,18 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
 #endif
         // a tile's burst is split between the parts: part k runs iterations [k, k + 1) * kTileIters / kPyrParts after stepping its
         // generators over the iterations before them (8 plain instructions per word instead of a Box-Muller pair)
-        constexpr int kIters = kTileIters / kPyrParts;
         for (int64_t t = tile_first + wave % (kBlock / 64); t <= tile_last; t += kBlock / 64) {
-            Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)t, lane);
-            Xoshiro prng;
-            if constexpr (PRE != 0) prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)t, lane);
-            for (int k = 0; k < part * kIters * 4; ++k) {
-                rng.next();
-                if constexpr (PRE != 0) prng.next();
+            Xoshiro rng, prng;
+            if (t == t_ahead && p == bid) {  // wave-uniform: stepped ahead before the tables
+                rng = rng_ahead;
+                if constexpr (PRE != 0) prng = prng_ahead;
+            } else {
+                rng = rng_stream(seed, stream_id, (uint64_t)t, lane);
+                if constexpr (PRE != 0) prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)t, lane);
+                for (int k = 0; k < part * kIters * 4; ++k) {
+                    rng.next();
+                    if constexpr (PRE != 0) prng.next();
+                }
             }
             SONAR_NG_STAMP(7);
             // element index inside the plane; < 0 or >= HW: not ours
@@ -1143,6 +1197,9 @@ SONAR_PYR_UNROLL
         }
     }
     SONAR_NG_STAMP(8);
+#ifdef SONAR_NG_TRACE  // when each of the waves 1..6 left the tile loop (wave 0 is slot 8)
+    if (lane == 0 && wave >= 1 && wave <= 6 && blockIdx.x < 256) g_ng_trace[blockIdx.x * 16 + 9 + wave] = __builtin_readcyclecounter();
+#endif
     if constexpr (STATS) write_partial_at<kPyrBlock>(s, q, partials, red, bid, nblocks);
     SONAR_NG_STAMP(9);
 }
