@@ -262,7 +262,8 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
 
             us = event_us(sized_call, 20, 5)
             extra[f"power_noise_{tag}_us"] = us
-            kernels.append(kernel_entry(f"power noise, normalised generate, {nb} latents of {C} x {hh} x {ww}", us, 4 * nb * C * hh * ww, None,
+            kernels.append(kernel_entry(f"power noise, normalised generate, {nb} latents of {C} x {hh} x {ww}", us, 4 * nb * C * hh * ww,
+                                        tr.get(f"power_noise_{tag}_b{nb}", {}).get("hbm_bytes_per_launch"),
                                         "two launches (statistics + final pass; 256 x 256: statistics + columns into a workspace + rows, 3 x the tensor of traffic); bytes = the tensor written once"))
         except Exception as exc:  # secondary figure only
             extra[f"power_noise_{tag}_error"] = repr(exc)[:200]

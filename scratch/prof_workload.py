@@ -4,6 +4,7 @@ import importlib, os, sys, types, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sonar_pkg
 pkg = sonar_pkg.load(); hl = pkg.hip_lib; hl.load()
+hl.PLANS_ENABLED = False  # the ordinary launches (a plan's Perlin call is another kernel at batch 64: make_traffic_json.py splits by kernel name)
 pn = importlib.import_module("comfyui_sonar_amd.py.nodes.powernoise")
 nz = importlib.import_module("comfyui_sonar_amd.py.noise")
 sonar = importlib.import_module("comfyui_sonar_amd.py.sonar")
@@ -33,6 +34,10 @@ sb.momentum_step(0, xs, den, torch.tensor(10.0), torch.tensor(8.0))
 for _ in range(REPS): sb.momentum_step(1, xs, den, torch.tensor(8.0), torch.tensor(6.0))
 filt = torch.rand(128, 65, device=dev) + 0.5
 for _ in range(REPS): hl.spectral_filter(xs, filt)
+# a 2048 px latent: 128 latents of 4 x 256 x 256 (33.5 M values) through the column-block route (workspace written and read once)
+f256 = torch.rand(256, 129, device=dev) + 0.5
+for i in range(REPS): hl.power_noise(f256, (128, 4, 256, 256), seed=1, stream_id=100 + i, plane_offset=0, factor=1.0)
+torch.cuda.synchronize()
 b4 = 256
 ms = types.SimpleNamespace(sigma_min=torch.tensor(0.03), sigma_max=torch.tensor(14.6), timestep=lambda sg: (999 * (1 - (sg.log() - math.log(0.03)) / (math.log(14.6) - math.log(0.03)))).clamp(0, 999))
 cond, uncond, xin = (torch.randn(b4, 4, 128, 128, device=dev) for _ in range(3))

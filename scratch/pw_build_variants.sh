@@ -10,7 +10,7 @@ build_one() {
   name=$1; flags=$2
   (cd comfyui-sonar_amd/csrc && hipcc $BASE $flags -c power_fft.hip -o ../../scratch/bin/pwvar/power_fft_$name.o)
   hipcc -shared -fPIC --offload-arch=gfx950 -o scratch/bin/pwvar/lib_$name.so scratch/bin/pwvar/power_fft_$name.o \
-    comfyui-sonar_amd/build/elementwise.o comfyui-sonar_amd/build/noise_gen.o comfyui-sonar_amd/build/dwt.o comfyui-sonar_amd/build/runtime.o comfyui-sonar_amd/build/dft_direct.o comfyui-sonar_amd/build/dtcwt.o
+    comfyui-sonar_amd/build/elementwise.o comfyui-sonar_amd/build/noise_gen.o comfyui-sonar_amd/build/dwt.o comfyui-sonar_amd/build/runtime.o comfyui-sonar_amd/build/dft_direct.o comfyui-sonar_amd/build/dtcwt.o comfyui-sonar_amd/build/plan.o comfyui-sonar_amd/build/dwt_bands.o
   rm -f scratch/bin/pwvar/power_fft_$name.o
   echo built $name
 }
