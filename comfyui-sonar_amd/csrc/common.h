@@ -300,6 +300,22 @@ struct Divider {
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// 16-byte store of a result nobody in this launch reads again.  `nt`: with the non-temporal hint the lines leave the L2 as they are
+// written instead of sitting dirty until the end-of-kernel write-back -- a launch-bound kernel that leaves 16.8 MB dirty pays 2-3 us for
+// that flush after its last workgroup has finished (batch 64: pyramid 26.4 -> 24.5 us, the cfg3 chain 31.1 -> 28.6 us per call); a
+// bandwidth-bound launch is better off with the write-back cache (batch 512: Perlin 45.5 -> 47.8 us with the hint), hence by size:
+// nt_stores_host(n) for tensors up to 8 Mi elements (32 MiB), in the pyramid plane kernel and scale_noise_kernel.  Not in the fills and the
+// Perlin kernels (batch 64: +0.4-0.5 us with the hint), and not where a wave's stores do not cover whole cache lines: the power kernels' row
+// pass writes 64-byte runs per four lanes and loses with it (batch 64: 14.9 -> 16.0 us).
+constexpr int64_t kNtMaxElems = 8 << 20;
+static inline bool nt_stores_host(int64_t n) { return n <= kNtMaxElems; }
+typedef float sonar_v4f __attribute__((ext_vector_type(4)));
+template <bool NT>  // a template parameter of the kernel: a run-time branch per store cost the batch-512 launches ~1 %
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    if constexpr (NT) __builtin_nontemporal_store(sonar_v4f{a, b, c, d}, reinterpret_cast<sonar_v4f*>(p));
+    else *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+
 // torch.lerp as the CPU reference's vectorised kernel evaluates it (ATen/native/cpu/Lerp.h
 // lerp_vec): coeff = |w| < 0.5 ? w : w - 1, base = |w| < 0.5 ? a : b, result = fma(coeff, b - a, base).
 template <typename T>

@@ -25,10 +25,10 @@ __device__ __forceinline__ Pack<V> load(const float* p, int64_t i) {
     }
     return r;
 }
-template <int V>
+template <int V, bool NT = false>
 __device__ __forceinline__ void store(float* p, int64_t i, const Pack<V>& r) {
     if constexpr (V == 4) {
-        *reinterpret_cast<float4*>(p + i) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+        store4<NT>(p + i, r.v[0], r.v[1], r.v[2], r.v[3]);
     } else {
         p[i] = r.v[0];
     }
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(kBlock) stats_finalize_kernel(const double* __
     }
 }
 
-template <int V>
+template <int V, bool NT = false /* common.h store4: launch-bound sizes */>
 __global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n, float factor, int normalized,
                                                              float thr_sd, const double* __restrict__ partials,
                                                              int64_t npart, int64_t n_total, double* out_partials) {
@@ -168,14 +168,14 @@ __global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n
             a.v[k] = f(a.v[k]);
             b.v[k] = f(b.v[k]);
         }
-        store<V>(x, i * V, a);
-        store<V>(x, (i + stride) * V, b);
+        store<V, NT>(x, i * V, a);
+        store<V, NT>(x, (i + stride) * V, b);
     }
     for (; i < nv; i += stride) {
         Pack<V> a = load<V>(x, i * V);
 #pragma unroll
         for (int k = 0; k < V; ++k) a.v[k] = f(a.v[k]);
-        store<V>(x, i * V, a);
+        store<V, NT>(x, i * V, a);
     }
     if (V > 1 && blockIdx.x == 0)
         for (int64_t j = nv * V + threadIdx.x; j < n; j += kBlock) x[j] = f(x[j]);
@@ -1237,7 +1237,10 @@ static int scale_noise_launch(float* x, int64_t n, float factor, int normalized,
                   "sonar_scale_noise_stats_f32: result statistics need normalized=1 and a separate buffer");
     if (n == 0 || (!normalized && factor == 1.0f)) return SONAR_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (aligned16(x)) {
+    if (aligned16(x) && nt_stores_host(n)) {
+        hipLaunchKernelGGL((scale_noise_kernel<4, true>), dim3(grid_for(n / 4 + 1, kBlock * 2)), dim3(kBlock), 0, st, x, n,
+                           factor, normalized, threshold_std_devs, partials, npart, n_total, out_partials);
+    } else if (aligned16(x)) {
         hipLaunchKernelGGL((scale_noise_kernel<4>), dim3(grid_for(n / 4 + 1, kBlock * 2)), dim3(kBlock), 0, st, x, n,
                            factor, normalized, threshold_std_devs, partials, npart, n_total, out_partials);
     } else {

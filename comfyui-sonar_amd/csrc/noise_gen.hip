@@ -931,7 +931,7 @@ struct LatticeJob {
 };
 static constexpr LatticeJob kNoLattice{nullptr, 0, 0, 0, 0, 0, 0};
 
-template <bool STATS, bool XROWS, int PRE = 0>
+template <bool STATS, bool XROWS, int PRE = 0, bool NT = false /* common.h store4: launch-bound sizes */>
 __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
                                                                uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                                                                double* partials, int grid_floats, Accum fold, Prefix pre, LatticeJob lat) {
@@ -1186,7 +1186,7 @@ SONAR_PYR_UNROLL
                     const float4 yv = *reinterpret_cast<const float4*>(fold.y + p * (int64_t)HW + e);
                     v[0] = fold(yv.x, v[0]); v[1] = fold(yv.y, v[1]); v[2] = fold(yv.z, v[2]); v[3] = fold(yv.w, v[3]);
                 }
-                *reinterpret_cast<float4*>(oplane + e) = make_float4(v[0], v[1], v[2], v[3]);
+                store4<NT>(oplane + e, v[0], v[1], v[2], v[3]);
                 if constexpr (STATS) {
                     const float ps = (v[0] + v[1]) + (v[2] + v[3]);
                     const float pq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3])));
@@ -1219,9 +1219,14 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     if (W % 4 != 0 || elem_offset % (H * W) != 0 || lds > kPyramidLdsBudget) return false;
     const bool xrows = mode == 0 && W % 4 == 0 && lds_x <= kPyramidLdsBudget;
     const int g = (int)std::min<int64_t>(planes, kNPart);
-#define SONAR_PP(ST, XR, P) \
-    hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P>), dim3(g + lat.blocks), dim3(kPyrBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
+    const bool nt = nt_stores_host(planes * H * W);
+#define SONAR_PPN(ST, XR, P, N) \
+    hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P, N>), dim3(g + lat.blocks), dim3(kPyrBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
                        seed, stream_id, elem_offset, partials, (int)grid_floats, fold, pre, lat)
+#define SONAR_PP(ST, XR, P) \
+    do { \
+        if (nt) SONAR_PPN(ST, XR, P, true); else SONAR_PPN(ST, XR, P, false); \
+    } while (0)
 #define SONAR_PPK(ST, XR) \
     do { \
         if (pre_kind == SONAR_PREFIX_NORMAL) SONAR_PP(ST, XR, 1); \
@@ -1235,6 +1240,7 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     }
 #undef SONAR_PPK
 #undef SONAR_PP
+#undef SONAR_PPN
     return true;
 }
 
