@@ -951,6 +951,9 @@ SONAR_UNROLL_ITEMS
 // per plane; the draw is cut into chunks of whole pair iterations that follow the transform phases' durations (SONAR_PIPE_CHUNKS =
 // iterations in phases 1 and 2; the rest, with column pass a, in phase 3).  Thread slot = thread within the drawing team: streams,
 // draw order and arithmetic -- therefore every output bit -- are those of power_irfft2_kernel<H, W, 1, ...>.
+#ifndef SONAR_PIPE_NT
+#define SONAR_PIPE_NT 0  // profiling builds: the row pass's 16-byte stores with the non-temporal hint (64-byte runs per four lanes: slower, common.h)
+#endif
 #ifndef SONAR_PIPE_CHUNKS
 #define SONAR_PIPE_CHUNKS 3, 5
 #endif
@@ -1151,7 +1154,7 @@ __device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, i
         if constexpr (SONAR_PIPE_SKIP & 1) {
             if (o[0] == 123.456f && o[1] == 654.321f) *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);  // keeps the arithmetic alive
         } else if constexpr (NK == 2) {
-            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            store4<(SONAR_PIPE_NT != 0)>(dst, o[0], o[1], o[2], o[3]);
         } else {
             *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
         }
