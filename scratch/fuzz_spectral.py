@@ -49,6 +49,17 @@ for it in range(iters):
             a = hl.power_irfft2(None, filt, sh4, seed=it, stream_id=3, plane_offset=4)
             b = hl.power_irfft2(zz, filt, sh4)
             err3 = 0.0 if torch.equal(a, b) else (a - b).abs().max().item() + 1.0
+        if kind == 4:  # generated in column blocks: against the direct passes over its own dumped spectrum, and the normalised call against scale_noise
+            sh4 = (planes, 4, H, W)
+            zz = hl.power_spectrum(sh4, "cuda", seed=it, stream_id=3, plane_offset=4)
+            p4 = hl.new_partials("cuda")
+            a = hl.power_irfft2(None, filt, sh4, seed=it, stream_id=3, plane_offset=4, partials=p4)
+            b = hl.power_irfft2(zz, filt, sh4)
+            e_ab = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+            nrm = hl.power_noise(filt, sh4, seed=it, stream_id=3, plane_offset=4, factor=0.8)
+            ref = hl.scale_noise_(a.clone(), 0.8, True, p4)
+            e_n = (nrm - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+            err3 = 0.0 if (e_ab < 3e-5 and e_n < 3e-5) else 1.0 + e_ab + e_n
         if not (err < 3e-5 and err2 < 3e-5 and serr < 1e-5 and err3 == 0.0):
             bad += 1
             print(f"MISMATCH {tag}: irfft2 {err:.2e} filter {err2:.2e} sumsq {serr:.2e} generate-vs-replay {err3:.2e}")
