@@ -397,6 +397,12 @@ extern "C" int sonar_wcfg_fused_f32(const float* cond, const float* uncond, cons
                              mode_inv, yl_scales, yh_scales, blend_mode, strength, subtract_from_x, ws, ws_bytes, (hipStream_t)stream,
                              "sonar_wcfg_fused_f32", perfect_reconstruction != 0);
 }
+extern "C" int sonar_wcfg_hi_storage(int fp32) {
+    const int before = wcfg_hi_fp32_switch();
+    if (fp32 >= 0) wcfg_hi_fp32_switch() = fp32 != 0;
+    return before;
+}
+
 extern "C" int sonar_wcfg_fused_f64(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H,
                                     int64_t W, int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd,
                                     const double* rec_lo, const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales,

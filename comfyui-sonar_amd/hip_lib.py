@@ -115,6 +115,7 @@ SIGNATURES = {
     "sonar_power_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _P]),
     "sonar_power_noise_ahead_ok": (_I, [_I64, _I64, _I64, _I]),
     "sonar_power_pipeline": (_I, [_I]),
+    "sonar_wcfg_hi_storage": (_I, [_I]),
     "sonar_power_noise_ahead_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _I, _U64, _P, _P]),
     "sonar_power_spectrum_f32": (_I, [_P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _P]),
     "sonar_power_irfft2_f32": (_I, [_P, _P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _P, _P]),
@@ -1633,7 +1634,7 @@ PLAN_MAX_ATTEMPTS = 3   # traces that may fail (a call that took a fallback rout
 PERLIN_AHEAD = os.environ.get("SONAR_PERLIN_AHEAD", "1") != "0"  # plans fuse a normalised Perlin call's three launches (_PerlinAheadHook)
 NOT_RUN = object()      # Plan.run: the step was not issued (a guard changed, an entry point refused): take the ordinary path
 _M64 = 2**64 - 1
-_HOST_QUERIES = frozenset(("sonar_abi_version", "sonar_last_error", "sonar_power_noise_ahead_ok", "sonar_perlin_noise_ahead_ok", "sonar_power_pipeline", "sonar_power_plane_kind", "sonar_dwt_out_len",
+_HOST_QUERIES = frozenset(("sonar_abi_version", "sonar_last_error", "sonar_power_noise_ahead_ok", "sonar_perlin_noise_ahead_ok", "sonar_power_pipeline", "sonar_wcfg_hi_storage", "sonar_power_plane_kind", "sonar_dwt_out_len",
                            "sonar_dwt2_ws_bytes", "sonar_wcfg_lowpass_lds_bytes", "sonar_wcfg_fused_ws_bytes", "sonar_pyramid_levels",
                            "sonar_plan_fn_id", "sonar_plan_fn_nargs"))
 PATCH_SLOT, PATCH_STREAM, PATCH_SEED, PATCH_BLOB, PATCH_LEVELS = range(5)

@@ -553,6 +553,10 @@ int sonar_wcfg_fused_f32(const float* cond, const float* uncond, const float* x,
                          const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,
                          int blend_mode, double strength, int subtract_from_x, int perfect_reconstruction, void* ws, int64_t ws_bytes,
                          void* stream);
+/* sonar_wcfg_fused_f64 keeps level 1's three detail bands -- 3/4 of that level's coefficients, written once and read once -- in fp32 in
+ * its workspace (arithmetic on both sides and every other band stay fp64; the result is an fp32 tensor): 110 MB less HBM traffic per 256 SDXL
+ * latents.  sonar_wcfg_hi_storage(0) stores them in fp64 (1: fp32, the default; -1: query); returns the previous setting.  Process-wide. */
+int sonar_wcfg_hi_storage(int fp32);
 int sonar_wcfg_fused_f64(const float* cond, const float* uncond, const float* x, float* out, int64_t planes, int64_t H, int64_t W,
                          int levels, const double* dec_lo, const double* dec_hi, int dec_len, int mode_fwd, const double* rec_lo,
                          const double* rec_hi, int rec_len, int mode_inv, const double* yl_scales, const double* yh_scales,

@@ -30,11 +30,15 @@ for tag, params in rules.items():
         fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(**params, high_precision_mode=hp))
         row = []
         outs = []
-        for path in ("lds", "tiles"):
+        for path in ("lds", "tiles", "tiles, fp64 detail storage"):
             wc.WaveletCFG.single_launch_bands = path == "lds"
+            hl.load().sonar_wcfg_hi_storage(0 if "fp64 detail" in path else 1)
+            if "fp64 detail" in path and not hp:
+                continue
             outs.append(fn(args).clone())
             wall, ev = timed(lambda: fn(args))
             row.append(f"{path} {ev:6.1f} us (wall {wall:6.1f})")
         wc.WaveletCFG.single_launch_bands = False
+        hl.load().sonar_wcfg_hi_storage(1)
         err = (outs[0] - outs[1]).abs().max().item() / outs[1].abs().max().item()
         print(f"{tag:22s} {'fp64' if hp else 'fp32'}: " + " | ".join(row) + f" | max rel diff {err:.1e}", flush=True)

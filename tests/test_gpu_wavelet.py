@@ -225,9 +225,20 @@ def test_wavelet_cfg_fused_equals_per_pass_path(api, monkeypatch, high_precision
     monkeypatch.setattr(api.hl.FusedCall, "__call__", lambda self, *a: calls.append(1) or real(self, *a))
     fused = fn(args)
     assert calls, "the fused entry point was not used"
+    # fp64 mode stores level 1's detail bands in fp32 (sonar_wcfg_hi_storage, default on): with fp64 storage the fused route IS the
+    # per-pass route to 1e-11; with fp32 storage to a fraction of the fp32 result's own rounding
+    lib = api.hl.load()
+    assert lib.sonar_wcfg_hi_storage(0) == 1
+    try:
+        fused_hi64 = fn(args)
+    finally:
+        lib.sonar_wcfg_hi_storage(1)
     monkeypatch.setattr(api.wc.WaveletCFG, "wavelet_cfg_fused", classmethod(lambda cls, **_k: None))
     per_pass = fn(args)
-    torch.testing.assert_close(fused, per_pass, rtol=1e-5, atol=(1e-11 if high_precision else 4e-5))
+    torch.testing.assert_close(fused_hi64, per_pass, rtol=1e-5, atol=(1e-11 if high_precision else 4e-5))
+    torch.testing.assert_close(fused, per_pass, rtol=1e-5, atol=(2e-6 if high_precision else 4e-5))
+    if not high_precision:
+        assert torch.equal(fused, fused_hi64)  # the switch concerns fp64 mode only
 
 
 def test_wavelet_cfg_fused_full_batch_identity(api):
