@@ -12,6 +12,9 @@
 // high_precision_mode default) or fp32 arithmetic; results agree with the band-by-band path to rounding (tests compare both with
 // the reference-run fixtures).
 #pragma once
+#ifndef SONAR_LOWPASS_NT
+#define SONAR_LOWPASS_NT 0  // profiling builds: the output phase's 16-byte stores with the non-temporal hint
+#endif
 #include "dwt_tile.h"
 
 namespace sonar {
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
                         const T r3 = fma_t(a.ku, (T)u4.w, a.kt * fma_t(g0, (T)c4.w - (T)u4.w, o1));
                         float4 res = make_float4((float)r0, (float)r1, (float)r2, (float)r3);
                         if (px) res = make_float4(x4.x - res.x, x4.y - res.y, x4.z - res.z, x4.w - res.w);
-                        *reinterpret_cast<float4*>(po + at) = res;
+                        store4<(SONAR_LOWPASS_NT != 0)>(po + at, res.x, res.y, res.z, res.w);
                     }
                 } else
                 for (Walk2 wk(tid, wp); wk.r < th; wk.next(wp)) {
