@@ -47,7 +47,7 @@ def driver_source() -> str:
             if ret == "const char*":
                 lines.append(f"    (void){call}; ++calls;")
             else:
-                query = re.search(r"version|kind|bytes|_len$|_pipeline$|_fn_nargs$|_fn_id$|_plan_length$|_pyramid_levels$|_ahead_ok$", name) is not None  # pure queries / switches answer with a number
+                query = re.search(r"version|kind|bytes|_len$|_pipeline$|_hi_storage$|_fn_nargs$|_fn_id$|_plan_length$|_pyramid_levels$|_ahead_ok$", name) is not None  # pure queries / switches answer with a number
                 check = f'if (rc > 0) {{ std::printf("{name}: rc %lld\\n", rc); ++bad; }}' if ret == "int" and not query else ""
                 lines.append(f"    {{ long long rc = (long long){call}; ++calls; (void)rc; {check} }}")
     lines += ['    std::printf("%d calls through the C ABI with NULL / degenerate arguments, %d unexpected return codes; last error text: %s\\n", calls, bad, sonar_last_error());',

@@ -26,7 +26,7 @@ def main(path):
                    "WRITE_SIZE: the gfx950 correction of MI355X_MICROARCH.md, confirmed in the same run by the calibration kernels below "
                    "(one 134 217 728-byte tensor written / read / read + written)."}
     out["calibration"] = {k: raw[k] for k in raw if k.startswith(("stream_fill_kernel<", "stats_kernel<", "scale_noise_kernel<"))}
-    scale = pick(raw, "scale_noise_kernel<")
+    scale = pick(raw, "scale_noise_kernel<4, false>")  # the calibration launch at 512 latents (the 32 MiB-and-below form is <4, true>)
     fin = pick(raw, "power_pipe_kernel<128, 128, false, true>")
     out["power_noise_b512"] = {"kernels": {"power_pipe_kernel<128,128,NORM> (final pass + the next call's statistics in its idle waves)": fin},
                                "hbm_bytes_per_launch": total(fin), "algorithmic_bytes_4N": 512 * N, "contract_bytes_12N": 3 * 512 * N,
@@ -49,13 +49,15 @@ def main(path):
     out["perlin_b512"] = {"hbm_bytes_per_launch": int(both * 512 / 576), "algorithmic_bytes_4N": 512 * N, "contract_bytes_12N": 3 * 512 * N,
                           "note": "lattice + statistics pass (no stores) + final pass; the workload ran batch 512 and batch 64 equally often, bytes split in proportion to the batch"}
     out["perlin_b64"] = {"hbm_bytes_per_launch": int(both * 64 / 576), "algorithmic_bytes_4N": 64 * N, "contract_bytes_12N": 3 * 64 * N}
-    pyr = pick(raw, "pyramid_plane_kernel<true, true, 0>")
-    both = 2 * pyr["hbm_bytes_per_launch"]
-    out["pyramid_b512"] = {"hbm_bytes_per_launch": int(both * 512 / 576) + 2 * 512 * N,
-                           "kernels": {"pyramid_plane_kernel": int(both * 512 / 576), "scale_noise_kernel (in place, read + write)": 2 * 512 * N},
+    # round 4: the plane kernel is a different instantiation at batch 512 and batch 64 (non-temporal stores up to 32 MiB): no split by batch
+    pyr512 = pick(raw, "pyramid_plane_kernel<true, true, 0, false>")["hbm_bytes_per_launch"]
+    pyr64 = pick(raw, "pyramid_plane_kernel<true, true, 0, true>")["hbm_bytes_per_launch"]
+    out["pyramid_b512"] = {"hbm_bytes_per_launch": int(pyr512) + 2 * 512 * N,
+                           "kernels": {"pyramid_plane_kernel": int(pyr512), "scale_noise_kernel (in place, read + write)": 2 * 512 * N},
                            "algorithmic_bytes_12N": 3 * 512 * N,
-                           "note": "generate pass with statistics (one write) + in-place scale_noise (calibrated read + write above); plane kernel bytes split by batch"}
-    out["pyramid_b64"] = {"hbm_bytes_per_launch": int(both * 64 / 576) + 2 * 64 * N, "algorithmic_bytes_12N": 3 * 64 * N}
+                           "note": "generate pass with statistics (one write) + in-place scale_noise (calibrated read + write above)"}
+    out["pyramid_b64"] = {"hbm_bytes_per_launch": int(pyr64) + 2 * 64 * N, "algorithmic_bytes_12N": 3 * 64 * N,
+                          "note": "both launches store with the non-temporal hint at this size"}
     mom = pick(raw, "EulerOp")
     out["momentum_euler_b512"] = dict(mom, algorithmic_bytes_20N=5 * 512 * N, note="x, denoised, history in; x', history' out")
     for tag, T in (("fp64", "double"), ("fp32", "float")):
