@@ -516,12 +516,23 @@ template <int NT, int SRC, bool STATS, bool NORM>
 __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __restrict__ z, const float* __restrict__ filter,
                                                                        float* out, int64_t planes, AnyPlan pl, uint64_t seed,
                                                                        uint64_t stream_id, int64_t plane_offset, int group, int split,
-                                                                       double* partials, NormArgs na) {
+                                                                       double* partials, NormArgs na, StatsAhead sa) {
     extern __shared__ __align__(16) unsigned char any_lds[];
     __shared__ double red[2 * NT / 64];
     __shared__ NormDecision shd;
     const int H = pl.H, W = pl.W, M = pl.M, S = pl.S, NC = H * S;
     c32* const A = reinterpret_cast<c32*>(any_lds);
+    int64_t bid = blockIdx.x, nblk = gridDim.x;
+    if constexpr (NT == kFftThreads && SRC == 1 && NORM && !STATS) {  // the launch-bound batch sizes: the next call's statistics in this launch
+        if (sa.partials) {
+            if ((int)blockIdx.x >= sa.main_blocks) {
+                power_stats_any_body(filter, planes, pl, seed, sa.stream_id, plane_offset, group, split, sa.partials, bid - sa.main_blocks,
+                                     nblk - sa.main_blocks, A /* 4 H values: the launcher checks they fit the plane buffer */, red);
+                return;
+            }
+            nblk = sa.main_blocks;
+        }
+    }
     c32* const twH = A + NC;   // e^{2 pi i j / H}
     c32* const twW = twH + H;  // e^{2 pi i j / W}
     const int tid = threadIdx.x;
@@ -540,7 +551,7 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
         nc = dec.do_sub ? dec.mean * g : 0.0f;
     }
     double s = 0.0, q = 0.0;
-    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+    for (int64_t unit = bid; unit < (split ? planes : planes / group); unit += nblk) {
         const GroupWalk gw(unit, group, split);
         SpectrumRng rng;
         if constexpr (SRC == 1) {
@@ -714,18 +725,17 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
     if constexpr (STATS) write_partial<NT>(s, q, partials, red);
 }
 
-// Parseval statistics of the drawn, filtered spectrum (see power_stats_kernel), run-time sizes; kAnySlots threads
-__global__ void __launch_bounds__(kFftThreads) power_stats_any_kernel(const float* __restrict__ filter, int64_t planes, AnyPlan pl,
-                                                                      uint64_t seed, uint64_t stream_id, int64_t plane_offset, int group,
-                                                                      int split, double* partials) {
-    extern __shared__ __align__(16) unsigned char any_lds[];
-    __shared__ double red[2 * kFftThreads / 64];
+// Parseval statistics of the drawn, filtered spectrum (see power_stats_kernel), run-time sizes; kAnySlots threads.  Workgroup `bid` of
+// `nb`: the statistics kernel's grid, or the trailing workgroups of a generate launch that computes the NEXT call's statistics beside
+// this call's planes (power_irfft2_any_kernel's StatsAhead, as in the fixed-size kernels).  EDGE: [parity][column 0 | column M][ky].
+__device__ __forceinline__ void power_stats_any_body(const float* __restrict__ filter, int64_t planes, const AnyPlan& pl, uint64_t seed,
+                                                     uint64_t stream_id, int64_t plane_offset, int group, int split, double* partials, int64_t bid,
+                                                     int64_t nb, c32* EDGE, double* red) {
     const int H = pl.H, M = pl.M, S = pl.S;
-    c32* const EDGE = reinterpret_cast<c32*>(any_lds);  // [parity][column 0 | column M][ky]
     const int tid = threadIdx.x;
     double s = 0.0, q = 0.0;
     int par = 0;
-    for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
+    for (int64_t unit = bid; unit < (split ? planes : planes / group); unit += nb) {
         const GroupWalk gw(unit, group, split);
         SpectrumRng rng = spectrum_rng_dyn<false>(seed, stream_id, plane_offset / group + gw.grp, tid, H);
         for (int i = 0; i < gw.first; ++i)
@@ -761,7 +771,16 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_any_kernel(const floa
             par ^= 1;
         }
     }
-    write_partial<kFftThreads>(s, q, partials, red);
+    write_partial_at<kFftThreads>(s, q, partials, red, (int)bid, (int)nb);
+}
+
+__global__ void __launch_bounds__(kFftThreads) power_stats_any_kernel(const float* __restrict__ filter, int64_t planes, AnyPlan pl,
+                                                                      uint64_t seed, uint64_t stream_id, int64_t plane_offset, int group,
+                                                                      int split, double* partials) {
+    extern __shared__ __align__(16) unsigned char any_lds[];
+    __shared__ double red[2 * kFftThreads / 64];
+    power_stats_any_body(filter, planes, pl, seed, stream_id, plane_offset, group, split, partials, blockIdx.x, gridDim.x,
+                         reinterpret_cast<c32*>(any_lds), red);
 }
 
 __global__ void __launch_bounds__(kFftThreads) power_spectrum_any_kernel(float* zout, int64_t planes, AnyPlan pl, uint64_t seed,
@@ -792,8 +811,18 @@ __global__ void __launch_bounds__(kFftThreads) power_spectrum_any_kernel(float* 
 }
 
 // what: as launch_power
+// the look-ahead of the general-size kernels (launch_power_any): two workgroups per CU, every workgroup resident at once
+static inline bool any_ahead_ok(int64_t planes, int64_t H, int64_t W, int group) {
+    if (!any_plane_ok(H, W) || W < 6 || group < 1 || planes < 1 || planes % group) return false;
+    const size_t lds = ((size_t)H * (W / 2 + 1) + H + W) * sizeof(c32);
+    if (2 * (lds + 1024) > 160 * 1024) return false;
+    const int split = group > 1 && planes / group < 512 ? 1 : 0;
+    return (split ? planes : planes / group) <= 256;
+}
+
 static int launch_power_any(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
-                            uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st) {
+                            uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st,
+                            Ahead ah = Ahead()) {
     AnyPlan pl;
     pl.H = (int)H;
     pl.W = (int)W;
@@ -823,7 +852,7 @@ static int launch_power_any(int what, const float* z, const float* filter, float
             hipSuccess)                                                                                                                    \
             (void)hipGetLastError();                                                                                                       \
         hipLaunchKernelGGL(kern, dim3(g), dim3(NT), lds, st, z, filter, out, planes, pl, seed, stream_id, plane_offset, group, split,      \
-                           PART, na);                                                                                                      \
+                           PART, na, StatsAhead());                                                                                        \
     } while (0)
 #define SONAR_PA(G, ST, NM, PART)                                                                                                          \
     do {                                                                                                                                   \
@@ -836,9 +865,22 @@ static int launch_power_any(int what, const float* z, const float* filter, float
         hipLaunchKernelGGL(power_spectrum_any_kernel, dim3((int)std::min<int64_t>(units, 2048)), dim3(kFftThreads), 0, st, out, planes, pl, seed,
                            stream_id, plane_offset, group, split);
     } else if (what == 1) {
-        hipLaunchKernelGGL(power_stats_any_kernel, dim3((int)std::min<int64_t>(units, kNPart)), dim3(kFftThreads), lds_stats, st, filter, planes,
-                           pl, seed, stream_id, plane_offset, group, split, partials);
-        SONAR_PA(1, false, true, nullptr);
+        if (!ah.have_stats)
+            hipLaunchKernelGGL(power_stats_any_kernel, dim3((int)std::min<int64_t>(units, kNPart)), dim3(kFftThreads), lds_stats, st, filter, planes,
+                               pl, seed, stream_id, plane_offset, group, split, partials);
+        if (ah.next) {  // any_ahead_ok: the next call's statistics as extra workgroups of this launch
+            StatsAhead sa;
+            sa.partials = ah.next;
+            sa.stream_id = ah.next_stream;
+            sa.main_blocks = g;
+            auto kern = power_irfft2_any_kernel<kAnySlots, 1, false, true>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAnyLdsLimit) != hipSuccess)
+                (void)hipGetLastError();
+            hipLaunchKernelGGL(kern, dim3(g + (int)std::min<int64_t>(units, kNPart)), dim3(kAnySlots), lds, st, z, filter, out, planes, pl, seed, stream_id,
+                               plane_offset, group, split, (double*)nullptr, na, sa);
+        } else {
+            SONAR_PA(1, false, true, nullptr);
+        }
     } else if (z == nullptr) {
         if (partials) SONAR_PA(1, true, false, partials); else SONAR_PA(1, false, false, partials);
     } else {

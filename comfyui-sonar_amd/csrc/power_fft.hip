@@ -1797,7 +1797,7 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
         set_error("sonar_rfft2_f32: power-of-two planes from 16 x 16 to 256 x 128 only (got %lld x %lld)", (long long)H, (long long)W);
         return SONAR_ERR_UNSUPPORTED;
     }
-    if (any_plane_ok(H, W)) return launch_power_any(what, z, filter, out, planes, H, W, seed, stream_id, plane_offset, group, partials, na, st);
+    if (any_plane_ok(H, W)) return launch_power_any(what, z, filter, out, planes, H, W, seed, stream_id, plane_offset, group, partials, na, st, ah);
     set_error("sonar_power_*: unsupported plane %lld x %lld (even sizes whose half-spectrum fits in LDS: H <= 512, W <= 1024, about 19k complex values)",
               (long long)H, (long long)W);
     return SONAR_ERR_UNSUPPORTED;
@@ -1873,7 +1873,9 @@ extern "C" int sonar_power_pipeline(int enable) {
 }
 
 extern "C" int sonar_power_noise_ahead_ok(int64_t planes, int64_t H, int64_t W, int rng_group) {
-    if (sonar_power_plane_kind(H, W) != 1 || planes < 1 || rng_group < 1 || rng_group > kMaxRngGroup || planes % rng_group) return 0;
+    if (planes < 1 || rng_group < 1 || rng_group > kMaxRngGroup || planes % rng_group) return 0;
+    if (sonar_power_plane_kind(H, W) == 2) return any_ahead_ok(planes, H, W, rng_group) ? 1 : 0;  // general-size planes at launch-bound sizes
+    if (sonar_power_plane_kind(H, W) != 1) return 0;
     if (H != 128 || W != 128 || !pipe_enabled() || planes <= 256) {
         // the phase-serial kernel (launch_power): the next call's statistics are extra workgroups of the launch -- while all of them are
         // resident at once (at most one plane and one statistics workgroup per CU; beyond that the two-launch form is as fast)

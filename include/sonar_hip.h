@@ -450,8 +450,9 @@ int sonar_power_noise_f32(const float* filter, float* out, int64_t planes, int64
  * filter / shape / seed / stream_id / plane_offset / rng_group): the statistics launch is skipped.  partials_next (may be NULL):
  * receives the statistics of the same call with stream id next_stream_id, computed by the final pass's otherwise idle waves -- pass it
  * as `partials` with have_stats = 1 if the next call turns out to be that one, ignore it otherwise.  Output bits are those of
- * sonar_power_noise_f32 either way.  Only where sonar_power_noise_ahead_ok() says 1 (pipelined 128 x 128 path, at most 512 work
- * units); SONAR_ERR_UNSUPPORTED elsewhere.  Same call site: py/nodes/powernoise.py:338-408 followed by py/utils.py:85-106. */
+ * sonar_power_noise_f32 either way.  Only where sonar_power_noise_ahead_ok() says 1: the pipelined 128 x 128 path with at most 512 work
+ * units (idle waves of the final pass), and -- as extra workgroups of the final pass's launch -- every fixed-size or general-size
+ * LDS-resident plane with at most 256 work units (the launch-bound batch sizes: one launch per call); SONAR_ERR_UNSUPPORTED elsewhere.  Same call site: py/nodes/powernoise.py:338-408 followed by py/utils.py:85-106. */
 int sonar_power_noise_ahead_ok(int64_t planes, int64_t H, int64_t W, int rng_group);
 /* process-wide switch between the two generate kernels for 128 x 128 planes: 1 (default) the pipelined kernel where it applies (more than
  * 256 planes), 0 the phase-serial kernel everywhere; < 0 only asks.  Same stream definition, the same bits either way

@@ -102,7 +102,9 @@ def test_rng_groups_beyond_the_lookahead(api):
 
 @pytest.mark.parametrize("shape", [(512, 4, 128, 128), (128, 4, 128, 128), (100, 3, 128, 128),
                                    # launch-bound batches: the phase-serial kernel, the next call's statistics in extra workgroups of its launch
-                                   (64, 4, 128, 128), (1, 4, 128, 128), (16, 3, 128, 128), (5, 16, 128, 128), (8, 4, 64, 64), (3, 4, 128, 64), (2, 4, 32, 32)])
+                                   (64, 4, 128, 128), (1, 4, 128, 128), (16, 3, 128, 128), (5, 16, 128, 128), (8, 4, 64, 64), (3, 4, 128, 64), (2, 4, 32, 32),
+                                   # general-size planes (SDXL's portrait buckets ...) at launch-bound sizes: the same in power_irfft2_any_kernel
+                                   (4, 4, 104, 152), (1, 4, 96, 96), (8, 4, 72, 120), (3, 3, 112, 144), (1, 16, 80, 80)])
 def test_lookahead_statistics_are_the_statistics_kernels(api, shape):
     """The statistics a call leaves for the next stream id == what the statistics launch of that call computes (same pairs, bit for bit:
     one unit per slot, the same order of additions), and a call that uses them writes the same tensor."""
