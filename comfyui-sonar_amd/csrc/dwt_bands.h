@@ -62,9 +62,13 @@ struct alignas(2 * sizeof(TIO)) Pair2 {
     TIO x, y;
 };
 
-template <typename T, typename TIO, int FT, int NT>
+// ZERO: the analysis extension is zero padding -- the only mode whose tables hold "no source" entries (-1); every other mode reads a real
+// sample for every tap, and its taps carry no clamp and no select (the kernel is instruction-bound: a third of a tap's instructions)
+template <typename T, typename TIO, int FT, int NT, bool ZERO>
 __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ ta, const TIO* __restrict__ tb, const TIO* xin, TIO* out,
                                                         BandsArgs<T> a) {
+    auto at0 = [](int s) { return ZERO ? max(s, 0) : s; };                       // index of a tap's sample
+    auto live = [](int s, T v) { return ZERO ? (s >= 0 ? v : T(0)) : v; };       // its value
     extern __shared__ __align__(16) unsigned char bands_smem[];
     T* const lds = reinterpret_cast<T*>(bands_smem);
     int* const maps = reinterpret_cast<int*>(bands_smem + a.off_maps);
@@ -104,9 +108,9 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
 #pragma unroll
                     for (int r = 0; r < NRS; ++r) {
                         const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h1 + FT - 3)];
-                        const int at = max(sy, 0) * W + x;
+                        const int at = at0(sy) * W + x;
                         const T d = pb ? (T)pa[at] - (T)pb[at] : (T)pa[at];
-                        v[r] = sy >= 0 ? d : T(0);
+                        v[r] = live(sy, d);
                     }
                     T* dst = tmp1 + (x & 1) * Wh + (x >> 1);
 #pragma unroll
@@ -126,8 +130,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
 #pragma unroll
                     for (int j = 0; j < FT; ++j) {
                         const int sx = xm[-j];
-                        const T q0 = row[sx >= 0 ? (sx & 1) * Wh + (sx >> 1) : 0];
-                        const T q = sx >= 0 ? q0 : T(0);
+                        const int sc = at0(sx);
+                        const T q = live(sx, row[(sc & 1) * Wh + (sc >> 1)]);
                         lo = fma_t(a.dec.lo[j], q, lo);
                         hi = fma_t(a.dec.hi[j], q, hi);
                     }
@@ -153,8 +157,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
 #pragma unroll
                 for (int t = 0; t < FT; ++t) {
                     const int sy = ym[-t];
-                    const T q = src[max(sy, 0) * Wp + x];
-                    acc = fma_t(a.dec.lo[t], sy >= 0 ? q : T(0), acc);
+                    const T q = src[at0(sy) * Wp + x];
+                    acc = fma_t(a.dec.lo[t], live(sy, q), acc);
                 }
                 tmp[yo * Wp + x] = acc;
             }
@@ -167,8 +171,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
 #pragma unroll
                 for (int t = 0; t < FT; ++t) {
                     const int sx = xm[-t];
-                    const T q0 = row[max(sx, 0)];
-                    const T q = sx >= 0 ? q0 : T(0);
+                    const T q = live(sx, row[at0(sx)]);
                     lo = fma_t(a.dec.lo[t], q, lo);
                     hi = fma_t(a.dec.hi[t], q, hi);
                 }
@@ -212,9 +215,9 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
 #pragma unroll
                         for (int t = 0; t < FT; ++t) {
                             const int sx = xm[-t];
-                            const int at = max(sx, 0);
-                            l0 = fma_t(a.dec.lo[t], sx >= 0 ? r0[at] : T(0), l0);
-                            l1 = fma_t(a.dec.lo[t], sx >= 0 ? r1[at] : T(0), l1);
+                            const int at = at0(sx);
+                            l0 = fma_t(a.dec.lo[t], live(sx, r0[at]), l0);
+                            l1 = fma_t(a.dec.lo[t], live(sx, r1[at]), l1);
                         }
                     }
                     tA[(2 * mp) * w + xo] = fma_t(c_low, l0, e);
@@ -273,9 +276,9 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
 #pragma unroll
                         for (int t = 0; t < FT; ++t) {
                             const int sx = xm[-t];
-                            const In2 q0 = r0[max(sx, 0)], q1 = r1[max(sx, 0)];
-                            l0 = fma_t(a.dec.lo[t], sx >= 0 ? (T)q0.x - (T)q0.y : T(0), l0);
-                            l1 = fma_t(a.dec.lo[t], sx >= 0 ? (T)q1.x - (T)q1.y : T(0), l1);
+                            const In2 q0 = r0[at0(sx)], q1 = r1[at0(sx)];
+                            l0 = fma_t(a.dec.lo[t], live(sx, (T)q0.x - (T)q0.y), l0);
+                            l1 = fma_t(a.dec.lo[t], live(sx, (T)q1.x - (T)q1.y), l1);
                         }
                     }
                     tA[(2 * mp) * w1 + xo] = fma_t(c_low, l0, e);
@@ -370,15 +373,20 @@ static bool bands_plan(BandsArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W,
     return lds_bytes <= budget;
 }
 
-template <typename T, typename TIO, int FT, int NT>
-static void launch_bands(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
-    auto kern = wcfg_bands_kernel<T, TIO, FT, NT>;
+template <typename T, typename TIO, int FT, int NT, bool ZERO>
+static void launch_bands_z(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
+    auto kern = wcfg_bands_kernel<T, TIO, FT, NT, ZERO>;
     static bool raised = false;  // per instantiation: dynamic LDS above the 64 KB default needs the attribute once
     if (lds > 64 * 1024 && !raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ta, tb, x, out, a);
+}
+template <typename T, typename TIO, int FT, int NT>
+static void launch_bands(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
+    if (a.mode_fwd == kZero) launch_bands_z<T, TIO, FT, NT, true>(grid, lds, st, ta, tb, x, out, a);
+    else launch_bands_z<T, TIO, FT, NT, false>(grid, lds, st, ta, tb, x, out, a);
 }
 
 template <typename T, typename TIO>
