@@ -25,6 +25,7 @@ for it in range(iters):
     if kind == 0: continue
     kinds[kind] = kinds.get(kind, 0) + 1
     planes = rnd.choice([1, 2, 3, 5, 8])
+    if it < int(os.environ.get("FUZZ_FROM", "0")): continue  # replay a tail of the sequence (the shapes still follow the seed)
     K = W // 2 + 1
     g = torch.Generator(device="cuda").manual_seed(it)
     z = torch.randn(planes, H, K, dtype=torch.complex64, device="cuda", generator=g)
@@ -60,11 +61,34 @@ for it in range(iters):
             ref = hl.scale_noise_(a.clone(), 0.8, True, p4)
             e_n = (nrm - ref).abs().max().item() / max(1.0, ref.abs().max().item())
             err3 = 0.0 if (e_ab < 3e-5 and e_n < 3e-5) else 1.0 + e_ab + e_n
+        if not (err < 3e-5 and err2 < 3e-5 and serr < 1e-5 and err3 == 0.0) and H * W <= 65536:
+            # who is right?  irfft2 by explicit DFT sums in fp64 (Hermitian extension of the half-spectrum, imaginary parts of the DC / Nyquist
+            # columns ignored as irfft does), against both
+            zf = (z * filt).to(torch.complex128)
+            ky = torch.arange(H, device="cuda", dtype=torch.float64)
+            cols = torch.fft.ifft(zf, dim=1, norm="ortho") if False else torch.einsum("yk,pkx->pyx", torch.exp(2j * torch.pi * ky[:, None] * ky[None, :] / H), zf) / H ** 0.5
+            kx = torch.arange(K, device="cuda", dtype=torch.float64)
+            xs = torch.arange(W, device="cuda", dtype=torch.float64)
+            wgt = torch.full((K,), 2.0, device="cuda", dtype=torch.float64); wgt[0] = 1.0
+            if W % 2 == 0: wgt[-1] = 1.0
+            ph = torch.exp(2j * torch.pi * kx[:, None] * xs[None, :] / W)
+            c = cols.clone(); c[:, :, 0] = c[:, :, 0].real + 0j
+            if W % 2 == 0: c[:, :, -1] = c[:, :, -1].real + 0j
+            exact = (torch.einsum("pyk,kx->pyx", c * wgt, ph)).real / W ** 0.5
+            e_mine = (got.double() - exact).abs().max().item() / max(1.0, exact.abs().max().item())
+            e_torch = (want.double() - exact).abs().max().item() / max(1.0, exact.abs().max().item())
+            print(f"   {tag}: against explicit fp64 DFT sums: this library {e_mine:.2e}, torch.fft.irfft2 {e_torch:.2e}")
+            if e_mine < 3e-5 and e_torch > 3e-5 and serr < 1e-5 and err3 == 0.0:
+                # seen once in 1500 iterations (seed 3, iteration 298, 8 x 16 x 16, only after the ~290 sizes before it in the same process):
+                # torch.fft.irfft2 itself returned a wrong transform (3.6e-1), reproducibly; the checker, not the library
+                torch_off = globals().get("torch_off", 0) + 1
+                globals()["torch_off"] = torch_off
+                continue
         if not (err < 3e-5 and err2 < 3e-5 and serr < 1e-5 and err3 == 0.0):
             bad += 1
             print(f"MISMATCH {tag}: irfft2 {err:.2e} filter {err2:.2e} sumsq {serr:.2e} generate-vs-replay {err3:.2e}")
     except Exception as exc:
         bad += 1
         print(f"ERROR {tag}: {type(exc).__name__}: {str(exc)[:160]}")
-print(f"{iters} iterations, routes {kinds}, {bad} bad")
+print(f"{iters} iterations, routes {kinds}, {bad} bad" + (f", {globals()['torch_off']} where torch.fft (the checker) was the one off" if globals().get("torch_off") else ""))
 sys.exit(1 if bad else 0)
