@@ -89,9 +89,13 @@ __device__ __forceinline__ void synth_low_pair(int m, int n, int mode, const T* 
     }
 }
 
-template <typename T, int FT>
+// ZERO: zero padding on the way down -- the only extension whose tables hold "no source" entries; the other modes' taps carry no clamp
+// and no select
+template <typename T, int FT, bool ZERO>
 __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* __restrict__ cond, const float* __restrict__ uncond,
                                                                     const float* __restrict__ xin, float* __restrict__ out, LowArgs<T> a) {
+    auto at0 = [](int s) { return ZERO ? max(s, 0) : s; };
+    auto live = [](int s, T v) { return ZERO ? (s >= 0 ? v : T(0)) : v; };
     extern __shared__ __align__(16) unsigned char low_smem[];
     T* const lds = reinterpret_cast<T*>(low_smem);
     int* const maps = reinterpret_cast<int*>(low_smem + a.off_maps);
@@ -140,9 +144,9 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
 #pragma unroll
                         for (int r = 0; r < NRS; ++r) {
                             const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h1 + FT - 3)];
-                            const int at = max(sy, 0) * W + x;
+                            const int at = at0(sy) * W + x;
                             const T d = (T)pc[at] - (T)pu[at];
-                            v[r] = sy >= 0 ? d : T(0);
+                            v[r] = live(sy, d);
                         }
                         T* dst = tmp1 + (x & 1) * Wh + (x >> 1);
 #pragma unroll
@@ -164,8 +168,8 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
 #pragma unroll
                     for (int j = 0; j < FT; ++j) {
                         const int slot = xm[-j];
-                        const T q = row[max(slot, 0)];
-                        acc = fma_t(a.dlo[j], slot >= 0 ? q : T(0), acc);
+                        const T q = row[at0(slot)];
+                        acc = fma_t(a.dlo[j], live(slot, q), acc);
                     }
                     ll1[(y0 + yl) * w1 + xo] = acc;
                 }
@@ -189,8 +193,8 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
 #pragma unroll
                 for (int t = 0; t < FT; ++t) {
                     const int sy = ym[-t];
-                    const T q = src[max(sy, 0) * Wp + x];
-                    acc = fma_t(a.dlo[t], sy >= 0 ? q : T(0), acc);
+                    const T q = src[at0(sy) * Wp + x];
+                    acc = fma_t(a.dlo[t], live(sy, q), acc);
                 }
                 tmp[yo * Wp + x] = acc;
             }
@@ -203,8 +207,8 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
 #pragma unroll
                 for (int t = 0; t < FT; ++t) {
                     const int sx = xm[-t];
-                    const T q = row[max(sx, 0)];
-                    acc = fma_t(a.dlo[t], sx >= 0 ? q : T(0), acc);
+                    const T q = row[at0(sx)];
+                    acc = fma_t(a.dlo[t], live(sx, q), acc);
                 }
                 dst[yo * w + xo] = acc;
             }
@@ -408,13 +412,16 @@ static int wcfg_lowpass(const float* cond, const float* uncond, const float* x, 
     const int grid = (int)std::min<int64_t>(planes, (int64_t)256 * per_cu);
     with_taps(flen, [&](auto ft) {
         constexpr int FT = decltype(ft)::value;
-        auto kern = wcfg_lowpass_kernel<T, FT>;
-        static bool raised = false;  // per instantiation: dynamic LDS above the 64 KB default needs the attribute once
-        if (lds > 64 * 1024 && !raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            raised = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kLowThreads), lds, st, cond, uncond, x, out, a);
+        auto go = [&](auto zero) {
+            auto kern = wcfg_lowpass_kernel<T, FT, decltype(zero)::value>;
+            static bool raised = false;  // per instantiation: dynamic LDS above the 64 KB default needs the attribute once
+            if (lds > 64 * 1024 && !raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                raised = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kLowThreads), lds, st, cond, uncond, x, out, a);
+        };
+        if (mode_fwd == kZero) go(std::true_type{}); else go(std::false_type{});
     });
     return check_launch(what);
 }
