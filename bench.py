@@ -220,6 +220,14 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
         host, gpu = host_and_event_us(lambda: ns_small(*sig))
         extra[f"power_noise_{tag}_us"] = gpu
         extra[f"power_noise_{tag}_host_us_per_call"] = host
+    # the same single-latent call on latents off the 128 x 128 path: an SDXL portrait bucket (general-size kernels; the next call's statistics
+    # ride in the launch) and a 2048 px latent (column blocks through a workspace: two launches)
+    for tag, (hh, ww) in (("104x152", (104, 152)), ("256x256", (256, 256))):
+        xs_ = torch.zeros((1, C, hh, ww), device=device)
+        ns_off = power_item(pn).make_noise_sampler(xs_, None, None, seed=None, cpu=False, normalized=True)
+        host, gpu = host_and_event_us(lambda: ns_off(*sig))
+        extra[f"power_noise_{tag}_b1_us"] = gpu
+        extra[f"power_noise_{tag}_b1_host_us_per_call"] = host
     for tag, xb in (("b4", torch.zeros((4, C, H, W), device=device)), ("b64", x64)):
         chain3 = nz.CustomNoiseChain()
         chain3.add(nz.CustomNoiseItem(0.5, noise_type="perlin"))
