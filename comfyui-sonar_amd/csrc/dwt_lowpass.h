@@ -276,7 +276,11 @@ __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* 
                         const int yl = wk.r, m = 2 * wk.c;
                         const T* row = tmp + yl * w1;
                         const int at = (y0 + yl) * W + 4 * wk.c;
+#ifdef SONAR_LOW_NOREREAD  // profiling builds: what the second read of cond / uncond costs
+                        float4 c4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f), u4 = make_float4(2.0f, 2.0f, 2.0f, 2.0f);
+#else
                         float4 c4 = *reinterpret_cast<const float4*>(pc + at), u4 = *reinterpret_cast<const float4*>(pu + at);
+#endif
                         float4 x4 = px ? *reinterpret_cast<const float4*>(px + at) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         T cf[K + 1];  // coefficients m .. m + K (clamped as synth_low_pair clamps: beyond the valid length only)
 #pragma unroll
