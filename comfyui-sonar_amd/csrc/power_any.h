@@ -196,8 +196,8 @@ __device__ __forceinline__ SpectrumRng spectrum_rng_dyn(uint64_t seed, uint64_t 
 template <bool NEED_T, typename Edge, typename Pair>
 __device__ __forceinline__ void draw_plane_dyn(SpectrumRng& g, int tid, int H, int M, Edge&& edge, Pair&& pair) {
     if (tid < H) {
-        const uint32_t r0 = g.E.next_high();
-        const uint32_t rm = g.E.next_high();
+        const uint32_t r0 = g.E.next();
+        const uint32_t rm = g.E.next();
         const uint32_t t = g.E.next();
         edge(r0, rm, t);
     }
@@ -205,8 +205,8 @@ __device__ __forceinline__ void draw_plane_dyn(SpectrumRng& g, int tid, int H, i
     const int pairs = (H / 2) * M, dky = kAnySlots / M, dkx = kAnySlots - dky * M;
     int ky = tid / M, kx = 1 + tid - ky * M;
     for (int p = tid; p < pairs; p += kAnySlots) {
-        const uint32_t ra = g.R.next_high();
-        const uint32_t rb = g.R.next_high();
+        const uint32_t ra = g.R.next();
+        const uint32_t rb = g.R.next();
         const uint32_t t = NEED_T ? g.T.next() : 0u;
         pair(ky, kx, ra, rb, t);
         ky += dky;
@@ -569,14 +569,14 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
                     draw_plane_dyn<true>(
                         rng, tid, H, M,
                         [&](uint32_t r0, uint32_t rm, uint32_t t) {
-                            A[tid * S] = drawn_elem(r0, t & 0xFFFFu, filter[tid * S]);
-                            A[tid * S + M] = drawn_elem(rm, t >> 16, filter[tid * S + M]);
+                            A[tid * S] = drawn_elem(r0, angle_lo(t), filter[tid * S]);
+                            A[tid * S + M] = drawn_elem(rm, angle_hi(t), filter[tid * S + M]);
                         },
                         [&](int ky, int kx, uint32_t ra, uint32_t rb, uint32_t t) {
                             if (kx < M) {
                                 const int a = ky * S + kx, b = a + (H / 2) * S;
-                                A[a] = drawn_elem(ra, t & 0xFFFFu, filter[a]);
-                                A[b] = drawn_elem(rb, t >> 16, filter[b]);
+                                A[a] = drawn_elem(ra, angle_lo(t), filter[a]);
+                                A[b] = drawn_elem(rb, angle_hi(t), filter[b]);
                             }
                         });
             } else if constexpr (SRC == 0) {
@@ -747,8 +747,8 @@ __device__ __forceinline__ void power_stats_any_body(const float* __restrict__ f
             draw_plane_dyn<false>(
                 rng, tid, H, M,
                 [&](uint32_t r0, uint32_t rm, uint32_t t) {
-                    e0[tid] = drawn_elem(r0, t & 0xFFFFu, filter[tid * S]);
-                    em[tid] = drawn_elem(rm, t >> 16, filter[tid * S + M]);
+                    e0[tid] = drawn_elem(r0, angle_lo(t), filter[tid * S]);
+                    em[tid] = drawn_elem(rm, angle_hi(t), filter[tid * S + M]);
                 },
                 [&](int ky, int kx, uint32_t ra, uint32_t rb, uint32_t) {
                     if (kx < M) {
@@ -797,13 +797,13 @@ __global__ void __launch_bounds__(kFftThreads) power_spectrum_any_kernel(float* 
             draw_plane_dyn<true>(
                 rng, tid, H, M,
                 [&](uint32_t r0, uint32_t rm, uint32_t t) {
-                    zp[tid * S] = unit_complex_normal(r0, t & 0xFFFFu);
-                    zp[tid * S + M] = unit_complex_normal(rm, t >> 16);
+                    zp[tid * S] = unit_complex_normal(r0, angle_lo(t));
+                    zp[tid * S + M] = unit_complex_normal(rm, angle_hi(t));
                 },
                 [&](int ky, int kx, uint32_t ra, uint32_t rb, uint32_t t) {
                     if (kx < M) {
-                        zp[ky * S + kx] = unit_complex_normal(ra, t & 0xFFFFu);
-                        zp[(ky + H / 2) * S + kx] = unit_complex_normal(rb, t >> 16);
+                        zp[ky * S + kx] = unit_complex_normal(ra, angle_lo(t));
+                        zp[(ky + H / 2) * S + kx] = unit_complex_normal(rb, angle_hi(t));
                     }
                 });
         }

@@ -73,8 +73,8 @@ __device__ __forceinline__ void draw_block(SpectrumRng& g, int tid, int H, int n
         w.next();
         auto nxt = cur;
         if (p + kBlockSlots < pairs) nxt = pre(it + 1, w.ky, w.c);
-        const uint32_t ra = g.R.next_high();
-        const uint32_t rb = g.R.next_high();
+        const uint32_t ra = g.R.next();
+        const uint32_t rb = g.R.next();
         const uint32_t t = NEED_T ? g.T.next() : 0u;
         pair(ky, c, ra, rb, t, cur);
         cur = nxt;
@@ -111,8 +111,8 @@ __global__ void __launch_bounds__(kBlockSlots, 4) power_block_cols_kernel(const 
             c32* const dst = ws + (gw.grp * group + gp) * (int64_t)H * S + c0;
             if constexpr (MODE == 1) {
                 draw_block<true>(rng, tid, H, ncd, [](int, int, int) { return 0; }, [&](int ky, int c, uint32_t ra, uint32_t rb, uint32_t t, int) {
-                    dst[(int64_t)ky * S + c] = unit_complex_normal(ra, t & 0xFFFFu);
-                    dst[(int64_t)(ky + H / 2) * S + c] = unit_complex_normal(rb, t >> 16);
+                    dst[(int64_t)ky * S + c] = unit_complex_normal(ra, angle_lo(t));
+                    dst[(int64_t)(ky + H / 2) * S + c] = unit_complex_normal(rb, angle_hi(t));
                 });
             } else {
                 __syncthreads();  // the previous plane's block is stored (and the table visible)
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(kBlockSlots, 4) power_block_cols_kernel(const 
                         return make_float2(f[0], f[(int64_t)(H / 2) * S]);
                     },
                     [&](int ky, int c, uint32_t ra, uint32_t rb, uint32_t t, float2 f) {
-                        const c32 za = drawn_elem(ra, t & 0xFFFFu, f.x), zb = drawn_elem(rb, t >> 16, f.y);
+                        const c32 za = drawn_elem(ra, angle_lo(t), f.x), zb = drawn_elem(rb, angle_hi(t), f.y);
                         A[ky * Sb + c] = za;
                         A[(ky + H / 2) * Sb + c] = zb;
                         if constexpr (STATS) {

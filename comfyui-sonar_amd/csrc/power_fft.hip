@@ -203,17 +203,15 @@ struct PlaneCfg {
 // workgroup draws back to back, so the Philox seeding cost is paid once per group instead of once per plane.
 // Three streams per slot:  R = radius words and T = angle words of the interior columns 0 < kx < W/2,
 // E = both for the two edge columns kx = 0, W/2 (slot ky).  The statistics pass (Parseval) needs only R and E:
-// |z|^2 = -ln(u_R) for a unit complex normal, so it skips half of the generator steps and all of sqrt / sin / cos.
+// |z|^2 = -ln(u_R) for a unit complex normal, so it skips the angle words and all of sqrt / sin / cos.
+// Round 5: multiply-with-carry streams (common.h, Mwc) instead of xoshiro128 -- a third of the generator's cost per word.
 struct SpectrumRng {
-    Xoshiro R, T, E;
+    Mwc R, T, E;
 };
 
-// The three streams of a (group, thread slot) start from ONE Philox4x32 counter block, read at three depths: R after the standard
-// 10 rounds (the same state as rng_stream of tile 4 * group), E after 12, T after 14.  Each extra pair of rounds is a keyed
-// multiplicative bijection of an already mixed block, so the states are unrelated as far as the GF(2)-linear xoshiro recurrences are
-// concerned, and seeding costs 14 rounds per slot instead of 30 (12 instead of 20 in the statistics pass, which never draws T).
-// 32-bit multiplies are the slow instructions here (v_mad_u64_u32, about a sixth of the plain rate): seeding was 3.7 us of the
-// statistics pass's 9.7 us and 5.5 us of vector-ALU time in the final pass (512 SDXL latents).
+// The three streams of a (group, thread slot) start from ONE Philox4x32 counter block: R and T from the four words after the standard
+// 10 rounds (the counter of rng_stream's tile 4 * group), E from the first two words after two more rounds (a keyed bijection of an
+// already mixed block).  Seeding costs 10 rounds per slot (12 for the H edge slots); 20 multiplies at the cost of a shift each.
 struct PhiloxBlock {
     uint32_t c0, c1, c2, c3, k0, k1;
     template <int ROUNDS>
@@ -230,7 +228,6 @@ struct PhiloxBlock {
             k0 += W0; k1 += W1;
         }
     }
-    __device__ __forceinline__ Xoshiro state() const { return Xoshiro{c0, c1, c2, c3 | 1u}; }  // never the all-zero state
 };
 
 template <bool NEED_T>
@@ -240,16 +237,12 @@ __device__ __forceinline__ SpectrumRng spectrum_seed(uint64_t seed, uint64_t str
                   (uint32_t)seed, (uint32_t)(seed >> 32)};
     SpectrumRng g;
     b.rounds<10>();
-    g.R = b.state();
-    g.E = Xoshiro{0, 0, 0, 1};
-    g.T = Xoshiro{0, 0, 0, 1};
-    if (NEED_T || edge_slot) {  // whole waves: the edge slots are the first H threads, H a multiple of 64 on every fixed-size plane
+    g.R = Mwc::seeded(b.c0, b.c1);
+    g.T = Mwc::seeded(b.c2, b.c3);
+    g.E = Mwc{0, 1};
+    if (edge_slot) {  // whole waves: the edge slots are the first H threads, H a multiple of 64 on every fixed-size plane
         b.rounds<2>();
-        g.E = b.state();
-    }
-    if constexpr (NEED_T) {
-        b.rounds<2>();
-        g.T = b.state();
+        g.E = Mwc::seeded(b.c0, b.c1);
     }
     return g;
 }
@@ -275,8 +268,8 @@ __device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge,
     constexpr int NT = plane_threads<H, W>(), M = W / 2, PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
     constexpr int UNR = UNROLL > 0 ? UNROLL : ITER;  // 0 = full (the statistics pass indexes registers by `it`)
     if (tid < H) {  // row ky = tid of the edge columns: radius word of kx = 0, of kx = M, then one angle word for both
-        const uint32_t r0 = g.E.next_high();
-        const uint32_t rm = g.E.next_high();
+        const uint32_t r0 = g.E.next();
+        const uint32_t rm = g.E.next();
         const uint32_t t = g.E.next();
         edge(r0, rm, t);
     }
@@ -284,8 +277,8 @@ __device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge,
     for (int it = 0; it < ITER; ++it) {
         const int p = tid + it * NT;
         if (PAIRS % NT == 0 || p < PAIRS) {
-            const uint32_t ra = g.R.next_high();  // radius words keep bits 31..9 only
-            const uint32_t rb = g.R.next_high();
+            const uint32_t ra = g.R.next();  // radius words keep bits 31..9 only
+            const uint32_t rb = g.R.next();
             const uint32_t t = NEED_T ? g.T.next() : 0u;
             pair(it, p, ra, rb, t);
         }
@@ -308,30 +301,39 @@ struct GroupWalk {
         : grp(split ? unit / group : unit), first(split ? (int)(unit % group) : 0), count(split ? 1 : group) {}
 };
 
-// ---- unit complex normal z = rho e^{i theta}, E|z|^2 = 1, from raw generator bits (about 30 instruction slots) --------------
-// radius: 23 random bits become the mantissa of a float f in [1, 2) in ONE v_alignbit; u = 2 - f is uniform on (0, 1] and
+// ---- unit complex normal z = rho e^{i theta}, E|z|^2 = 1, times a filter value, from raw generator bits (about 20 instruction slots) ----
+// radius: 23 random bits become the mantissa of a float m in [1, 2) in ONE v_alignbit; u = 2 - m is uniform on (0, 1] and
 //   rho^2 = -ln u (the 1/sqrt(2) of "(a + ib) / sqrt 2" folded into the radius), so rho <= sqrt(23 ln 2) = 3.99 (5.65 sigma
-//   per component).
-// angle: 16 random bits -> f in [1, 2) the same way; v_sin / v_cos take revolutions and are periodic, so they are fed f
-//   directly.  One 32-bit draw serves two elements; 65536 directions x a 23-bit radius is far below fp32 output resolution
-//   after the 8192-term FFT sums.
+//   per component).  The filter value f rides UNDER the square root: |z f|^2 = f^2 rho^2 = w log2 u with the weight
+//   w = -ln2 f^2 -- one multiply for "- ln 2", the logarithm's base and the filter together, and exactly the term the Parseval
+//   statistics sum (power_stats_body, TeamStats): rho_f = sqrt(w log2 u); the sign of f goes back on with v_bfi (copysign).
+//   Round 5: up to round 4 the element was (rho cos, rho sin) f with rho = sqrt(-ln2 log2 u) -- four multiplies more per value; the
+//   two forms differ in the last bit, a break of the generate-mode seeds like round 3's.
+// angle: 16 random bits per value, one 32-bit draw for two values.  v_sin / v_cos take revolutions, are periodic and accept
+//   |x| <= 256, so the bits are dropped into the mantissa of a float in [128, 256) where the low 16 mantissa bits weigh
+//   2^-1 .. 2^-16 revolutions and whatever sits above them whole revolutions: ONE instruction per angle (v_and_or for the low
+//   half, its junk bits 22..16 being whole turns; v_alignbit for the high half) instead of mask / shift + or.  65536 directions x a
+//   23-bit radius is far below fp32 output resolution after the 8192-term FFT sums.
+constexpr float kNegLn2 = -0.6931471805599453f;
 __device__ __forceinline__ float unit_mantissa(uint32_t hi_bits_in_msb) {  // bits 31..9 -> [1, 2)
     return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, hi_bits_in_msb, 9));
 }
-__device__ __forceinline__ float neg_ln_u(uint32_t r) {  // -ln(u), u = 2 - f in (0, 1]
-    return -0.6931471805599453f * __builtin_amdgcn_logf(2.0f - unit_mantissa(r));
+__device__ __forceinline__ float log2_u(uint32_t r) { return __builtin_amdgcn_logf(2.0f - unit_mantissa(r)); }  // log2 u <= 0, u = 2 - m in (0, 1]
+__device__ __forceinline__ float neg_ln_u(uint32_t r) { return kNegLn2 * log2_u(r); }                            // -ln u
+__device__ __forceinline__ float filter_weight(float f) { return kNegLn2 * (f * f); }                            // w <= 0: |z f|^2 = w log2 u
+__device__ __forceinline__ float angle_lo(uint32_t t) { return __uint_as_float(__builtin_amdgcn_bitop3_b32(t, 0x007FFFFFu, 0x43000000u, 0xEA)); }  // (t & mask) | 128.0f
+__device__ __forceinline__ float angle_hi(uint32_t t) { return __uint_as_float(__builtin_amdgcn_alignbit(0x4300u, t, 16)); }
+// |f| z for the weight w = filter_weight(f): the magnitude part (the pipelined kernel keeps its slots' weights in registers)
+__device__ __forceinline__ c32 drawn_weighted(uint32_t r, float angle, float w) {
+    const float rho = __builtin_amdgcn_sqrtf(w * log2_u(r));
+    return cc(v2f{__builtin_amdgcn_cosf(angle), __builtin_amdgcn_sinf(angle)} * rho);
 }
-__device__ __forceinline__ c32 unit_complex_normal(uint32_t r, uint32_t t16) {
-    const float rho = __builtin_amdgcn_sqrtf(neg_ln_u(r));
-    const float f = __uint_as_float(0x3f800000u | (t16 << 7));
-    return make_float2(rho * __builtin_amdgcn_cosf(f), rho * __builtin_amdgcn_sinf(f));
+// one drawn spectrum element times the filter value f (any sign)
+__device__ __forceinline__ c32 drawn_elem(uint32_t r, float angle, float f) {
+    const float rho = __builtin_copysignf(__builtin_amdgcn_sqrtf(filter_weight(f) * log2_u(r)), f);
+    return cc(v2f{__builtin_amdgcn_cosf(angle), __builtin_amdgcn_sinf(angle)} * rho);
 }
-// one drawn spectrum element times the filter value (the replay path multiplies the dumped element by f the same way)
-__device__ __forceinline__ c32 drawn_elem(uint32_t r, uint32_t t16, float f) {
-    const c32 z = unit_complex_normal(r, t16);
-    return make_float2(z.x * f, z.y * f);
-}
-
+__device__ __forceinline__ c32 unit_complex_normal(uint32_t r, float angle) { return drawn_elem(r, angle, 1.0f); }
 // filtered spectrum of one generated plane: interior straight into the LDS plane A (row stride S; the discarded kx = M slots
 // land in A's never-read last column), edge columns into the side buffers T0 / TM.  The filter values of pair it + 1 are
 // requested while pair it is drawn (the compiler otherwise issues each load right in front of its use).
@@ -345,8 +347,8 @@ __device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter,
     draw_plane<H, W, true, SONAR_DRAW_UNROLL>(
         g, tid,
         [&](uint32_t r0, uint32_t rm, uint32_t t) {
-            T0[tid] = drawn_elem(r0, t & 0xFFFFu, filter[tid * Wh]);
-            TM[tid] = drawn_elem(rm, t >> 16, filter[tid * Wh + M]);
+            T0[tid] = drawn_elem(r0, angle_lo(t), filter[tid * Wh]);
+            TM[tid] = drawn_elem(rm, angle_hi(t), filter[tid * Wh + M]);
             if (edge_seq) {  // whole waves take this branch (H is a multiple of 64): publish "this wave's edge rows are in LDS"
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if ((tid & 63) == 0) __hip_atomic_fetch_add(edge_seq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -356,8 +358,8 @@ __device__ __forceinline__ void fill_plane_gen(const float* __restrict__ filter,
             const int pn = min(p + NT, PAIRS - 1);
             const float na = filter[fpos(pn)], nb = filter[fpos(pn) + (H / 2) * Wh];
             c32* const a = A + (p >> LM) * S + 1 + (p & (M - 1));
-            a[0] = drawn_elem(ra, t & 0xFFFFu, fa);
-            a[(H / 2) * S] = drawn_elem(rb, t >> 16, fb);
+            a[0] = drawn_elem(ra, angle_lo(t), fa);
+            a[(H / 2) * S] = drawn_elem(rb, angle_hi(t), fb);
             fa = na;
             fb = nb;
         });
@@ -395,8 +397,14 @@ __device__ __forceinline__ void fill_plane(const float* __restrict__ z, const fl
 // the 8-wave passes of the pipelined kernel below, shared with the 128-row fast path here (defined with power_pipe_kernel)
 template <int H, int W, int NW>
 __device__ __forceinline__ void pipe_col_b(const c32* X, c32* Y, int w, int lane);
+template <int W>
+struct RowATw {  // row pass a's wave-uniform twiddles (scalar registers), see pipe_row_a
+    c32 g[8], p[8];
+};
+template <int W>
+__device__ __forceinline__ RowATw<W> row_a_twiddles(int w);
 template <int H, int W, int NW, bool INPLACE = false>
-__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane, const c32 (&gtw)[8], const c32 (&ptw)[8]);
+__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane, const RowATw<W>& tw);
 template <int H, int W, int NW, bool STATS, bool NORM>
 __device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, int lane, float scale, float nm, float nc, double& s, double& q);
 
@@ -503,6 +511,8 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         for (int k1 = 0; k1 < RN1; ++k1) ptw[k1] = c_tw256[((w * k1) * (256 / M)) & 255];
     };
     if constexpr (FAST) load_twiddles(wv);
+    [[maybe_unused]] RowATw<W> rtw;
+    if constexpr (FAST && H == 128) rtw = row_a_twiddles<W>(wv);
 
 #ifdef SONAR_PW_DESYNC  // profiling builds: the second resident workgroup of every CU starts late (out of phase with the first)
     if (blockIdx.x >= gridDim.x / 2)
@@ -730,7 +740,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             // front, row pass a leaves element (k1, n2) at column 8 n2 + k1 for the 16-byte stores of pass b
             if constexpr (!(SONAR_PW_SKIP & 2)) pipe_col_b<H, W, 8>(A, A, wv, lane);  // in place: an item reads and writes the same 8 rows of its column
             __syncthreads();
-            if constexpr (!(SONAR_PW_SKIP & 4)) pipe_row_a<H, W, 8, true>(A, A, wv, lane, gtw, ptw);
+            if constexpr (!(SONAR_PW_SKIP & 4)) pipe_row_a<H, W, 8, true>(A, A, wv, lane, rtw);
             __syncthreads();
             } else {
             // ------------------------------------------------------------ columns, pass b: radix 8, rows 8 k1 .. 8 k1 + 7
@@ -987,29 +997,37 @@ __device__ unsigned long long g_pipe_trace[256 * 16 * 10 * 4];
 #endif
 
 // iterations [IT0, IT1) of one thread slot's draw, kept in registers: iteration `it` is element (ky = n2 + 8 it, kx) and its partner
-// 64 rows below = inputs n1 = it and n1 = it + H / 16 of the slot's column-pass-a item
+// 64 rows below = inputs n1 = it and n1 = it + H / 16 of the slot's column-pass-a item.  The slot meets the same 16 filter values in
+// every plane: their weights wa / wb (filter_weight) stay in registers for the whole launch -- no filter loads, address registers or
+// waits inside the draw (round 4 loaded the pair's two values one iteration ahead: sixteen 64-bit address registers and a vmcnt wait per
+// iteration at two waves per SIMD).
 template <int H, int W, int IT0, int IT1>
-__device__ __forceinline__ void draw_chunk_regs(const float* __restrict__ filter, SpectrumRng& g, int tid, c32 (&v)[H / 8], float& fa, float& fb) {
-    constexpr int NT = plane_threads<H, W>(), M = W / 2, Wh = M + 1, LM = draw_shift<W>(), PAIRS = (H / 2) * M;
+__device__ __forceinline__ void draw_chunk_regs(SpectrumRng& g, c32 (&v)[H / 8], const float (&wa)[H / 16], const float (&wb)[H / 16]) {
+    constexpr int NT = plane_threads<H, W>(), M = W / 2, PAIRS = (H / 2) * M;
     static_assert(PAIRS % NT == 0 && IT0 <= IT1 && IT1 <= PAIRS / NT && NT == 8 * M && PAIRS / NT == H / 16, "slot = (wave n2, column)");
-    auto fpos = [&](int p) { return (p >> LM) * Wh + 1 + (p & (M - 1)); };
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
-        const int p = tid + it * NT;
-        const uint32_t ra = g.R.next_high();
-        const uint32_t rb = g.R.next_high();
+        const uint32_t ra = g.R.next();
+        const uint32_t rb = g.R.next();
         const uint32_t t = g.T.next();
-        const int pn = (p + NT) & (PAIRS - 1);  // the last iteration requests the next plane's first pair
-        const float na = filter[fpos(pn)], nb = filter[fpos(pn) + (H / 2) * Wh];
         if constexpr (SONAR_PIPE_SKIP & 2) {
-            v[it] = make_float2(fa + (float)ra, fb);
-            v[it + H / 16] = make_float2(fb + (float)t, fa + (float)rb);
+            v[it] = make_float2(wa[it] + (float)ra, wb[it]);
+            v[it + H / 16] = make_float2(wb[it] + (float)t, wa[it] + (float)rb);
         } else {
-        v[it] = drawn_elem(ra, t & 0xFFFFu, fa);
-        v[it + H / 16] = drawn_elem(rb, t >> 16, fb);
+            v[it] = drawn_weighted(ra, angle_lo(t), wa[it]);
+            v[it + H / 16] = drawn_weighted(rb, angle_hi(t), wb[it]);
         }
-        fa = na;
-        fb = nb;
+    }
+}
+// a filter with negative values (a wave that met one: uniform branch): the sign the weights dropped goes back on, read from the filter
+template <int H, int W, int IT0, int IT1>
+__device__ __forceinline__ void draw_chunk_signs(const float* __restrict__ filter, int tid, c32 (&v)[H / 8]) {
+    constexpr int NT = plane_threads<H, W>(), M = W / 2, Wh = M + 1, LM = draw_shift<W>();
+#pragma unroll
+    for (int it = IT0; it < IT1; ++it) {
+        const int p = tid + it * NT, pos = (p >> LM) * Wh + 1 + (p & (M - 1));
+        if (filter[pos] < 0.0f) v[it] = make_float2(-v[it].x, -v[it].y);
+        if (filter[pos + (H / 2) * Wh] < 0.0f) v[it + H / 16] = make_float2(-v[it + H / 16].x, -v[it + H / 16].y);
     }
 }
 
@@ -1037,68 +1055,124 @@ __device__ __forceinline__ void pipe_col_b(const c32* X, c32* Y, int w, int lane
     }
 }
 
-// rows, pass a (c2r pre-twiddle fused): residue n2 = w % 8 (its twiddles are wave-uniform: scalar registers), rows lane + 64 it; Y -> X,
-// element (k1, n2) of a row lands at column 8 n2 + k1.  INPLACE (one plane buffer, X == Y: the phase-serial kernel): a workgroup barrier
-// between the loads and the stores
+// rows, pass a (c2r pre-twiddle fused), Y -> X: G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k, w = e^{2 pi i / W}, then the
+// radix-8 over n1 of k = 8 n1 + n2 and the twiddle e^{2 pi i n2 k1 / M}; element (k1, n2) of a row lands at column 8 n2 + k1.
+// G[k] and G[M-k] are made of the SAME two operands: with S = X[k] + conj X[M-k], D = (X[k] - conj X[M-k]) w^k,
+//     G[k] = S + i D,   G[M-k] = conj(S - i D)        (w^{M-k} = -conj w^k)
+// and k -> M - k maps residue n2 to 8 - n2 (n1 to 7 - n1; 8 - n1 for residue 0).  Round 5: a thread therefore takes BOTH residues of
+// one row -- half the LDS reads of the pass and 5 instead of 2 x 5 packed operations per pair of G -- where round 4 took one residue of
+// two rows and read every operand twice.  The mirrored residue needs no twiddle table of its own: e^{2 pi i (8 - n2) k1 / M} =
+// e^{2 pi i k1 / 8} conj(p[k1]), and the factor e^{2 pi i k1 / 8} is a circular shift of the radix-8's INPUT by one place (register naming).
+// Waves 0-5: residue pairs (1,7) (2,6) (3,5), rows lane + 64 (w & 1).  Residues 0 and 4 mirror onto themselves (four operand pairs
+// per item): waves 6 and 7, two rows each -- the same 133-140 packed operations for every wave.  Twiddles are wave-uniform (scalar registers).
+// INPLACE (one plane buffer, X == Y: the phase-serial kernel): a workgroup barrier between the loads and the stores.
+template <int W>
+__device__ __forceinline__ RowATw<W> row_a_twiddles(int w) {
+    constexpr int M = W / 2;
+    const int a = w < 6 ? 1 + (w >> 1) : (w == 6 ? 0 : 4);
+    RowATw<W> t;
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) t.g[n1] = c_tw256[((8 * n1 + a) * (256 / W)) & 255];
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) t.p[k1] = c_tw256[((a * k1) * (256 / M)) & 255];
+    return t;
+}
+__device__ __forceinline__ c32 cconj(c32 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ c32 cmul_conj(c32 a, c32 b) {  // a * conj(b), packed like cmul
+    const v2f A = vv(a), B = vv(b);
+    return cc(__builtin_elementwise_fma(A.yx, v2f{B.y, -B.y}, A * B.xx));
+}
+
 template <int H, int W, int NW, bool INPLACE>
-__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane, const c32 (&gtw)[8], const c32 (&ptw)[8]) {
+__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane, const RowATw<W>& tw) {
     using C = PlaneCfg<H, W>;
-    constexpr int M = C::M, S = C::S, RN1 = C::RN1, RN2 = C::RN2, ROWS = H / 64, ITEMS = ROWS * 8 / NW;
-    static_assert(RN1 == 8 && RN2 == 8 && (NW == 8 || NW == 8 * ROWS), "one residue per wave");
-    const int n2 = w & 7, it0 = NW == 8 ? 0 : w >> 3;
-    auto load = [&](int it, c32 (&xa)[RN1], c32 (&xb)[RN1]) {
-        const c32* row = Y + (lane + 64 * (it0 + it)) * S;
-#pragma unroll
-        for (int n1 = 0; n1 < RN1; ++n1) {
-            const int k = RN2 * n1 + n2;
-            if (k == 0) {  // uniform: residue 0, n1 = 0 -- the packed column holds Re = column 0, Im = column M
-                const c32 p = row[0];
-                xa[n1] = make_float2(p.x, 0.0f);
-                xb[n1] = make_float2(p.y, 0.0f);
-            } else {
-                xa[n1] = row[k];
-                xb[n1] = row[M - k];
-            }
-        }
+    constexpr int M = C::M, S = C::S, RN1 = C::RN1, RN2 = C::RN2;
+    static_assert(H == 128 && RN1 == 8 && RN2 == 8 && NW == 8, "three residue pairs x two row halves + two self-mirrored residues x all rows");
+    // S + i D and S - i D of one operand pair
+    auto pair = [&](c32 xa, c32 xb, c32 g, c32& plus, c32& minus) {
+        const c32 xc = cconj(xb);
+        const c32 s = cadd(xa, xc), d = cmul(csub(xa, xc), g);
+        plus = cadd_i(s, d);
+        minus = csub_i(s, d);
     };
-    auto transform = [&](const c32 (&xa)[RN1], const c32 (&xb)[RN1], c32 (&g)[RN1]) {
+    if (w < 6) {  // uniform
+        const int a = 1 + (w >> 1), b = 8 - a, r = lane + 64 * (w & 1);
+        const c32* row = Y + r * S;
+        c32 xa[8], xb[8];
 #pragma unroll
-        for (int n1 = 0; n1 < RN1; ++n1) {
-            const c32 xc = make_float2(xb[n1].x, -xb[n1].y);  // conj
-            g[n1] = cadd_i(cadd(xa[n1], xc), cmul(csub(xa[n1], xc), gtw[n1]));
+        for (int n1 = 0; n1 < 8; ++n1) {
+            xa[n1] = row[8 * n1 + a];
+            xb[n1] = row[M - 8 * n1 - a];
         }
-        idft<RN1>(g);
-#pragma unroll
-        for (int k1 = 1; k1 < RN1; ++k1) g[k1] = cmul(g[k1], ptw[k1]);
-    };
-    auto store = [&](int it, const c32 (&g)[RN1]) {
-#pragma unroll
-        for (int k1 = 0; k1 < RN1; ++k1) X[(lane + 64 * (it0 + it)) * S + RN1 * n2 + k1] = g[k1];
-    };
-    if constexpr (INPLACE) {
-        // one plane buffer: only the ITEMS x 8 results cross the barrier (the operands of both items would: 64 registers beside the
-        // phase-serial kernel's draw state)
-        c32 g[ITEMS][RN1];
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            c32 xa[RN1], xb[RN1];
-            load(it, xa, xb);
-            __builtin_amdgcn_sched_barrier(0);
-            transform(xa, xb, g[it]);
-        }
-        __syncthreads();  // every wave holds its results: the (mirrored) operands of all rows have been read
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) store(it, g[it]);
-    } else {
-        c32 xa[ITEMS][RN1], xb[ITEMS][RN1];
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) load(it, xa[it], xb[it]);
         __builtin_amdgcn_sched_barrier(0);
+        c32 ga[8], tb[8];
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            c32 g[RN1];
-            transform(xa[it], xb[it], g);
-            store(it, g);
+        for (int n1 = 0; n1 < 8; ++n1) {
+            c32 m;
+            pair(xa[n1], xb[n1], tw.g[n1], ga[n1], m);
+            tb[(8 - n1) & 7] = cconj(m);  // G of residue b at n1' = 7 - n1, shifted by one place
+        }
+        idft<8>(ga);
+        idft<8>(tb);
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) ga[k1] = cmul(ga[k1], tw.p[k1]);
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) tb[k1] = cmul_conj(tb[k1], tw.p[k1]);
+        if constexpr (INPLACE) __syncthreads();  // every wave holds its results: all operands of all rows have been read
+        c32* orow = X + r * S;
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) orow[8 * a + k1] = ga[k1];
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) orow[8 * b + k1] = tb[k1];
+    } else {
+        const bool zero = w == 6;  // uniform: residue 0 (its first element is the packed column: Re = column 0, Im = column M) or residue 4
+        const int a = zero ? 0 : 4;
+        c32 x[2][8];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const c32* row = Y + (lane + 64 * it) * S;
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) x[it][n1] = row[8 * n1 + a];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c32 g[2][8];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            if (zero) {
+                const c32 p = x[it][0];
+                // k = 0: X[0] = Re p, X[M] = Im p, both real: G = (Re p + Im p) + i (Re p - Im p) -- through the general expression
+                // (same bits as round 4's)
+                {
+                    const c32 xa = make_float2(p.x, 0.0f), xc = make_float2(p.y, -0.0f);
+                    g[it][0] = cadd_i(cadd(xa, xc), cmul(csub(xa, xc), tw.g[0]));
+                }
+                {  // k = M / 2 mirrors onto itself
+                    const c32 xa = x[it][4], xc = cconj(xa);
+                    g[it][4] = cadd_i(cadd(xa, xc), cmul(csub(xa, xc), tw.g[4]));
+                }
+#pragma unroll
+                for (int n1 = 1; n1 < 4; ++n1) {
+                    c32 m;
+                    pair(x[it][n1], x[it][8 - n1], tw.g[n1], g[it][n1], m);
+                    g[it][8 - n1] = cconj(m);
+                }
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < 4; ++n1) {
+                    c32 m;
+                    pair(x[it][n1], x[it][7 - n1], tw.g[n1], g[it][n1], m);
+                    g[it][7 - n1] = cconj(m);
+                }
+            }
+            idft<8>(g[it]);
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) g[it][k1] = cmul(g[it][k1], tw.p[k1]);
+        }
+        if constexpr (INPLACE) __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) X[(lane + 64 * it) * S + 8 * a + k1] = g[it][k1];
         }
     }
 }
@@ -1183,16 +1257,20 @@ struct TeamStats {
     int planes_in_unit;
 
     // weights, stream states, and the unit's edge columns (all planes: the E stream is its own) into `edge` [plane][2][H]
+    // `wa`, `wb`: the slot's weights when the caller holds them already (the drawing team), else read from the filter
     __device__ __forceinline__ void begin(const float* __restrict__ filter, uint64_t seed, uint64_t stream_id, int64_t plane_offset, int group,
-                                          const GroupWalk& gw, int tid, c32* edge) {
-        constexpr float kNegLn2 = -0.6931471805599453f;
+                                          const GroupWalk& gw, int tid, c32* edge, const float* wa = nullptr, const float* wb = nullptr) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int p = tid + it * NT, ky = p >> LM, kx = 1 + (p & (M - 1));
             const bool live = p < PAIRS && kx < M;
-            const float fa = live ? filter[ky * Wh + kx] : 0.0f, fb = live ? filter[(ky + H / 2) * Wh + kx] : 0.0f;
-            wgt[it] = kNegLn2 * (fa * fa);
-            wgt[it + ITER] = kNegLn2 * (fb * fb);
+            if (wa) {
+                wgt[it] = live ? wa[it] : 0.0f;
+                wgt[it + ITER] = live ? wb[it] : 0.0f;
+            } else {
+                wgt[it] = filter_weight(live ? filter[ky * Wh + kx] : 0.0f);
+                wgt[it + ITER] = filter_weight(live ? filter[(ky + H / 2) * Wh + kx] : 0.0f);
+            }
             prod[it] = 1.0f;
             prod[it + ITER] = 1.0f;
         }
@@ -1205,11 +1283,11 @@ struct TeamStats {
         for (int i = 0; i < gw.first; ++i) skip_plane<H, W, false>(rng, tid);
         if (tid < H) {
             for (int b = 0; b < gw.count; ++b) {
-                const uint32_t r0 = rng.E.next_high();
-                const uint32_t rm = rng.E.next_high();
+                const uint32_t r0 = rng.E.next();
+                const uint32_t rm = rng.E.next();
                 const uint32_t t = rng.E.next();
-                edge[(2 * b) * H + tid] = drawn_elem(r0, t & 0xFFFFu, f0);
-                edge[(2 * b + 1) * H + tid] = drawn_elem(rm, t >> 16, fm);
+                edge[(2 * b) * H + tid] = drawn_elem(r0, angle_lo(t), f0);
+                edge[(2 * b + 1) * H + tid] = drawn_elem(rm, angle_hi(t), fm);
             }
         }
     }
@@ -1218,8 +1296,8 @@ struct TeamStats {
         for (int b = b0; b < min(b1, planes_in_unit); ++b) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
-                const uint32_t ra = rng.R.next_high();
-                const uint32_t rb = rng.R.next_high();
+                const uint32_t ra = rng.R.next();
+                const uint32_t rb = rng.R.next();
                 prod[it] *= 2.0f - unit_mantissa(ra);
                 prod[it + ITER] *= 2.0f - unit_mantissa(rb);
             }
@@ -1295,8 +1373,8 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
     __shared__ c32 EDGE[3 * H];  // raw columns kx = 0 and kx = M of the plane being drawn, and the packed column built from them
     // stream states of this workgroup's SECOND unit, seeded by the transforming team while it waits for the first plane (the draw team
     // would spend ~0.8 us on the Philox rounds at the unit switch: 32-bit multiplies at a sixth of the plain rate)
-    __shared__ uint4 SEED_RT[2 * NT];
-    __shared__ uint4 SEED_E[H];
+    __shared__ uint4 SEED_RT[2 * NT];  // (R, T) per slot; twice the size: the drawing team's look-ahead edge columns borrow the area
+    __shared__ uint2 SEED_E[H];
     __shared__ double sred[2 * NT / 64];  // wave sums of a team's look-ahead statistics (TeamStats)
     __shared__ double red[2 * NALL / 64];
     __shared__ NormDecision shd;
@@ -1335,8 +1413,18 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         c32* const TM = EDGE + H;
         c32* const Q = EDGE + 2 * H;
         SpectrumRng rng;
-        auto fpos = [&](int p) { return (p >> LM) * Wh + 1 + (p & (M - 1)); };
-        float fa = filter[fpos(tid)], fb = filter[fpos(tid) + (H / 2) * Wh];
+        // the slot's 16 filter weights, for every plane of the launch (and the look-ahead statistics of the epilogue)
+        float wa[ITER], wb[ITER];
+        bool neg = false;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int p = tid + it * NT, pos = (p >> LM) * Wh + 1 + (p & (M - 1));
+            const float fa = filter[pos], fb = filter[pos + (H / 2) * Wh];
+            wa[it] = filter_weight(fa);
+            wb[it] = filter_weight(fb);
+            neg = neg || fa < 0.0f || fb < 0.0f;
+        }
+        const bool wave_neg = __builtin_amdgcn_ballot_w64(neg) != 0;  // uniform: some slot of this wave has a negative filter value
         const float f0 = tid < H ? filter[tid * Wh] : 0.0f, fm = tid < H ? filter[tid * Wh + M] : 0.0f;
         c32 ctw[CN1];  // e^{2 pi i n2 k1 / H}: wave-uniform, loop-invariant
 #pragma unroll
@@ -1353,12 +1441,12 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             if (gp == 0) {
                 const GroupWalk gw(unit, group, split);
                 if (j == per_unit) {  // the second unit: states left in LDS by the transforming team (visible: barriers since)
-                    const uint4 r = SEED_RT[tid], t = SEED_RT[NT + tid];
-                    rng.R = Xoshiro{r.x, r.y, r.z, r.w};
-                    rng.T = Xoshiro{t.x, t.y, t.z, t.w};
+                    const uint4 rt = SEED_RT[tid];
+                    rng.R = Mwc{rt.x, rt.y};
+                    rng.T = Mwc{rt.z, rt.w};
                     if (tid < H) {
-                        const uint4 e = SEED_E[tid];
-                        rng.E = Xoshiro{e.x, e.y, e.z, e.w};
+                        const uint2 e = SEED_E[tid];
+                        rng.E = Mwc{e.x, e.y};
                     }
                 } else {
                     rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + gw.grp, tid);
@@ -1366,13 +1454,14 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
                 for (int i = 0; i < gw.first; ++i) skip_plane<H, W, true>(rng, tid);
             }
             if (tid < H) {  // row ky = tid of the edge columns (waves 0-1 of the team)
-                const uint32_t r0 = rng.E.next_high();
-                const uint32_t rm = rng.E.next_high();
+                const uint32_t r0 = rng.E.next();
+                const uint32_t rm = rng.E.next();
                 const uint32_t t = rng.E.next();
-                T0[tid] = drawn_elem(r0, t & 0xFFFFu, f0);
-                TM[tid] = drawn_elem(rm, t >> 16, fm);
+                T0[tid] = drawn_elem(r0, angle_lo(t), f0);
+                TM[tid] = drawn_elem(rm, angle_hi(t), fm);
             }
-            draw_chunk_regs<H, W, 0, E0>(filter, rng, tid, v, fa, fb);
+            draw_chunk_regs<H, W, 0, E0>(rng, v, wa, wb);
+            if (wave_neg) draw_chunk_signs<H, W, 0, E0>(filter, tid, v);
             pin_chunk<0, E0>(v);
             SONAR_PIPE_STAMP(1);
             __syncthreads();
@@ -1381,11 +1470,13 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
                 const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
                 Q[ky] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
             }
-            draw_chunk_regs<H, W, E0, E1>(filter, rng, tid, v, fa, fb);
+            draw_chunk_regs<H, W, E0, E1>(rng, v, wa, wb);
+            if (wave_neg) draw_chunk_signs<H, W, E0, E1>(filter, tid, v);
             pin_chunk<E0, E1>(v);
             SONAR_PIPE_STAMP(2);
             __syncthreads();
-            draw_chunk_regs<H, W, E1, ITER>(filter, rng, tid, v, fa, fb);
+            draw_chunk_regs<H, W, E1, ITER>(rng, v, wa, wb);
+            if (wave_neg) draw_chunk_signs<H, W, E1, ITER>(filter, tid, v);
             if (lane == M - 1) {
 #pragma unroll
                 for (int n1 = 0; n1 < CN1; ++n1) v[n1] = Q[CN2 * n1 + wv];
@@ -1412,7 +1503,7 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             TeamStats<H, W> ts;
             c32* const edge = reinterpret_cast<c32*>(SEED_RT);
             const GroupWalk gw((int64_t)blockIdx.x + gridDim.x, group, split);
-            ts.begin(filter, seed, next_stream, plane_offset, group, gw, tid, edge);
+            ts.begin(filter, seed, next_stream, plane_offset, group, gw, tid, edge, wa, wb);
             ts.radii(0, SONAR_AHEAD_SPLIT_A, tid);
             SONAR_PIPE_STAMP(1);
             __syncthreads();
@@ -1436,19 +1527,14 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         // ------------------------------------------------------------------------------------------------ transforming team
         // wave wv owns residue n2 = wv in the twiddled row pass: every twiddle is wave-uniform and loop-invariant (scalar registers)
         __builtin_amdgcn_s_setprio(SONAR_PIPE_PRIO_FFT);
-        c32 gtw[RN1], ptw[RN1];
-#pragma unroll
-        for (int n1 = 0; n1 < RN1; ++n1) gtw[n1] = c_tw256[((RN2 * n1 + wv) * (256 / W)) & 255];
-#pragma unroll
-        for (int k1 = 0; k1 < RN1; ++k1) ptw[k1] = c_tw256[((wv * k1) * (256 / M)) & 255];
+        const RowATw<W> rtw = row_a_twiddles<W>(wv);
         int64_t unit = blockIdx.x;
         int gp = 0;
         if (n > per_unit) {  // nothing to transform yet: seed the second unit's streams for the drawing team
             const GroupWalk gw(unit + gridDim.x, group, split);
             const SpectrumRng g2 = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + gw.grp, tid);
-            SEED_RT[tid] = make_uint4(g2.R.s0, g2.R.s1, g2.R.s2, g2.R.s3);
-            SEED_RT[NT + tid] = make_uint4(g2.T.s0, g2.T.s1, g2.T.s2, g2.T.s3);
-            if (tid < H) SEED_E[tid] = make_uint4(g2.E.s0, g2.E.s1, g2.E.s2, g2.E.s3);
+            SEED_RT[tid] = make_uint4(g2.R.x, g2.R.c, g2.T.x, g2.T.c);
+            if (tid < H) SEED_E[tid] = make_uint2(g2.E.x, g2.E.c);
         }
         // iteration 0: the first plane is being drawn.  The next call's statistics of this workgroup's first unit (edge columns in the
         // second plane buffer, untouched until iteration 1), over the iteration's three barriers
@@ -1496,7 +1582,7 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             if (work && !(SONAR_PIPE_SKIP & 16)) pipe_col_b<H, W, NW>(X, Y, wv, lane);
             SONAR_PIPE_STAMP(1);
             __syncthreads();
-            if (work && !(SONAR_PIPE_SKIP & 8)) pipe_row_a<H, W, NW>(Y, X, wv, lane, gtw, ptw);
+            if (work && !(SONAR_PIPE_SKIP & 8)) pipe_row_a<H, W, NW>(Y, X, wv, lane, rtw);
             SONAR_PIPE_STAMP(2);
             __syncthreads();
             if (work) {
@@ -1547,15 +1633,13 @@ __device__ __forceinline__ void power_stats_body(const float* __restrict__ filte
     // A thread meets the same (ky, kx) in every plane: its weights -ln2 f^2 (|z f|^2 = f^2 rho^2 = -ln2 f^2 log2 u, the radius
     // word alone) live in registers; the discarded kx = M slots weigh 0.
     constexpr int LM = draw_shift<W>(), PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
-    constexpr float kNegLn2 = -0.6931471805599453f;
     float wgt[2 * ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int p = tid + it * NT, ky = p >> LM, kx = 1 + (p & (M - 1));
         const bool live = p < PAIRS && kx < M;
-        const float fa = live ? filter[ky * Wh + kx] : 0.0f, fb = live ? filter[(ky + H / 2) * Wh + kx] : 0.0f;
-        wgt[it] = kNegLn2 * (fa * fa);
-        wgt[it + ITER] = kNegLn2 * (fb * fb);
+        wgt[it] = filter_weight(live ? filter[ky * Wh + kx] : 0.0f);
+        wgt[it + ITER] = filter_weight(live ? filter[(ky + H / 2) * Wh + kx] : 0.0f);
     }
     const float f0 = tid < H ? filter[tid * Wh] : 0.0f, fm = tid < H ? filter[tid * Wh + M] : 0.0f;
     for (int64_t unit = bid; unit < (split ? planes : planes / group); unit += nb) {
@@ -1574,8 +1658,8 @@ __device__ __forceinline__ void power_stats_body(const float* __restrict__ filte
                 draw_plane<H, W, false>(
                     rng, tid,
                     [&](uint32_t r0, uint32_t rm, uint32_t t) {
-                        EDGE[b][0][tid] = drawn_elem(r0, t & 0xFFFFu, f0);
-                        EDGE[b][1][tid] = drawn_elem(rm, t >> 16, fm);
+                        EDGE[b][0][tid] = drawn_elem(r0, angle_lo(t), f0);
+                        EDGE[b][1][tid] = drawn_elem(rm, angle_hi(t), fm);
                     },
                     [&](int it, int, uint32_t ra, uint32_t rb, uint32_t) {
                         prod[it] *= 2.0f - unit_mantissa(ra);
@@ -1618,14 +1702,14 @@ __global__ void __launch_bounds__((plane_threads<H, W>())) power_spectrum_kernel
             draw_plane<H, W, true>(
                 rng, tid,
                 [&](uint32_t r0, uint32_t rm, uint32_t t) {
-                    zp[tid * Wh] = unit_complex_normal(r0, t & 0xFFFFu);
-                    zp[tid * Wh + M] = unit_complex_normal(rm, t >> 16);
+                    zp[tid * Wh] = unit_complex_normal(r0, angle_lo(t));
+                    zp[tid * Wh + M] = unit_complex_normal(rm, angle_hi(t));
                 },
                 [&](int, int p, uint32_t ra, uint32_t rb, uint32_t t) {
                     const int ky = p >> draw_shift<W>(), kx = 1 + (p & (M - 1));
                     if (kx < M) {
-                        zp[ky * Wh + kx] = unit_complex_normal(ra, t & 0xFFFFu);
-                        zp[(ky + H / 2) * Wh + kx] = unit_complex_normal(rb, t >> 16);
+                        zp[ky * Wh + kx] = unit_complex_normal(ra, angle_lo(t));
+                        zp[(ky + H / 2) * Wh + kx] = unit_complex_normal(rb, angle_hi(t));
                     }
                 });
         }
@@ -1764,8 +1848,22 @@ __global__ void __launch_bounds__(kBlock) channel_mix_kernel(const float* __rest
 
 }  // namespace sonar
 
+#ifdef SONAR_PW_ONLY_128  // profiling builds (scratch/pw_build_variants.sh): the 128 x 128 kernels alone compile in under a minute
+namespace sonar {
+static bool any_plane_ok(int64_t, int64_t) { return false; }
+static bool block_plane_ok(int64_t, int64_t) { return false; }
+static bool any_ahead_ok(int64_t, int64_t, int64_t, int) { return false; }
+static int launch_power_any(int, const float*, const float*, float*, int64_t, int64_t, int64_t, uint64_t, uint64_t, int64_t, int, double*, NormArgs, hipStream_t, Ahead) { return SONAR_ERR_UNSUPPORTED; }
+static int launch_power_block(int, const float*, float*, float*, int64_t, int64_t, int64_t, uint64_t, uint64_t, int64_t, int, double*, NormArgs, hipStream_t) { return SONAR_ERR_UNSUPPORTED; }
+}  // namespace sonar
+bool sonar_lines_rows_r2c(const float*, float*, int64_t, int64_t, hipStream_t) { return false; }
+bool sonar_lines_cols(const float*, const float*, float*, int64_t, int64_t, int64_t, int, hipStream_t) { return false; }
+bool sonar_lines_rows_c2r(const float*, float*, int64_t, int64_t, float, double*, hipStream_t) { return false; }
+bool sonar_lines_rows_c2r_norm(const float*, float*, int64_t, int64_t, float, double*, const sonar::NormArgs*, hipStream_t) { return false; }
+#else
 #include "power_any.h"
 #include "power_block.h"
+#endif
 
 using namespace sonar;
 
@@ -1781,6 +1879,7 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
 #define SONAR_CASE(HH, WW) \
     if (H == HH && W == WW) return launch_power<HH, WW>(what, z, filter, out, planes, seed, stream_id, plane_offset, group, partials, na, st, ah)
     SONAR_CASE(128, 128);
+#ifndef SONAR_PW_ONLY_128
     SONAR_CASE(64, 64);
     SONAR_CASE(32, 32);
     SONAR_CASE(16, 16);
@@ -1792,6 +1891,7 @@ static int power_dispatch(int what, const float* z, const float* filter, float* 
     SONAR_CASE(32, 64);
     SONAR_CASE(256, 64);
     SONAR_CASE(64, 256);
+#endif
 #undef SONAR_CASE
     if (what == 4) {
         set_error("sonar_rfft2_f32: power-of-two planes from 16 x 16 to 256 x 128 only (got %lld x %lld)", (long long)H, (long long)W);
