@@ -245,24 +245,46 @@ struct NormDecision {
     int do_sub, do_div;
 };
 
+// fp64 reciprocal and reciprocal square root from the fp32 hardware seeds and Newton steps in fp64 (error 2^-23 -> 2^-46 -> 2^-92: the
+// last bit of a double at most).  The compiler's IEEE double division and sqrt are chains of ~30 dependent instructions each, half of them
+// quarter-rate; the normalisation decision below ran five of them in ONE thread with the whole workgroup waiting at a barrier: 1.6 us at
+// the top of every normalising kernel (pipelined power kernel, trace build, round 5) -- as long as a 33 MB fill.
+__device__ __forceinline__ double rcp_f64(double x) {
+    double r = (double)__builtin_amdgcn_rcpf((float)x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double rsqrt_f64(double x) {  // x > 0, in fp32 range
+    double r = (double)__builtin_amdgcn_rsqf((float)x);
+    r = __builtin_fma(r * __builtin_fma(-x * r, r, 1.0), 0.5, r);
+    r = __builtin_fma(r * __builtin_fma(-x * r, r, 1.0), 0.5, r);
+    return r;
+}
+
+// the decision from the totals (sum, sumsq) of n_total values
+__device__ __forceinline__ NormDecision decision_from_totals(double s, double q, int64_t n_total, float thr_sd) {
+    const double nt = (double)n_total;
+    const double mean = s * rcp_f64(nt);
+    // unbiased (py/utils.py:100: noise.std()); n_total == 1 -> NaN like torch (0 x inf)
+    const double var = (q - s * mean) * rcp_f64(nt - 1.0);
+    double sd;
+    if (var > 1e-30 && var < 1e30) sd = var * rsqrt_f64(var);             // every sensible tensor
+    else sd = sqrt(var > 0.0 || !(var == var) ? var : 0.0);                // degenerate: zero, denormal, huge or NaN variance
+    NormDecision d;
+    d.mean = (float)mean;
+    d.stdv = (float)sd;
+    const double thr = (double)thr_sd * rsqrt_f64(nt);
+    d.do_sub = fabs((double)d.mean) > thr;
+    d.do_div = fabs(1.0 - (double)d.stdv) > thr;
+    return d;
+}
+
 // the decision from this thread's share (s, q) of the (sum, sumsq) partials; every thread of the block takes part
 template <int BLOCK>
 __device__ __forceinline__ NormDecision decide_from_sums(double s, double q, int64_t n_total, float thr_sd, double* red, NormDecision* sh) {
     block_sum2<BLOCK>(s, q, red);
-    if (threadIdx.x == 0) {
-        const double nt = (double)n_total;
-        const double mean = s / nt;
-        // unbiased (py/utils.py:100: noise.std()); n_total == 1 -> NaN like torch
-        const double var = (q - s * mean) / (nt - 1.0);
-        const double sd = sqrt(var > 0.0 || !(var == var) ? var : 0.0);
-        NormDecision d;
-        d.mean = (float)mean;
-        d.stdv = (float)sd;
-        const double thr = (double)thr_sd / sqrt(nt);
-        d.do_sub = fabs((double)d.mean) > thr;
-        d.do_div = fabs(1.0 - (double)d.stdv) > thr;
-        *sh = d;
-    }
+    if (threadIdx.x == 0) *sh = decision_from_totals(s, q, n_total, thr_sd);
     __syncthreads();
     return *sh;
 }

@@ -205,6 +205,7 @@ struct PlaneCfg {
 // E = both for the two edge columns kx = 0, W/2 (slot ky).  The statistics pass (Parseval) needs only R and E:
 // |z|^2 = -ln(u_R) for a unit complex normal, so it skips the angle words and all of sqrt / sin / cos.
 // Round 5: multiply-with-carry streams (common.h, Mwc) instead of xoshiro128 -- a third of the generator's cost per word.
+// (Measured and dropped: one radius stream per element of a pair -- two short multiply chains instead of one long one -- changes nothing.)
 struct SpectrumRng {
     Mwc R, T, E;
 };
@@ -263,11 +264,11 @@ constexpr int draw_shift() { int l = 0; while ((1 << l) < W / 2) ++l; return l; 
 template <int H, int W>
 constexpr int draw_iters() { return ((H / 2) * (W / 2) + plane_threads<H, W>() - 1) / plane_threads<H, W>(); }
 
-template <int H, int W, bool NEED_T, int UNROLL = 0, typename Edge, typename Pair>
+template <int H, int W, bool NEED_T, int UNROLL = 0, bool EDGES = true, typename Edge, typename Pair>
 __device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge, Pair&& pair) {
     constexpr int NT = plane_threads<H, W>(), M = W / 2, PAIRS = (H / 2) * M, ITER = draw_iters<H, W>();
     constexpr int UNR = UNROLL > 0 ? UNROLL : ITER;  // 0 = full (the statistics pass indexes registers by `it`)
-    if (tid < H) {  // row ky = tid of the edge columns: radius word of kx = 0, of kx = M, then one angle word for both
+    if (EDGES && tid < H) {  // row ky = tid of the edge columns: radius word of kx = 0, of kx = M, then one angle word for both
         const uint32_t r0 = g.E.next();
         const uint32_t rm = g.E.next();
         const uint32_t t = g.E.next();
@@ -286,9 +287,9 @@ __device__ __forceinline__ void draw_plane(SpectrumRng& g, int tid, Edge&& edge,
 }
 
 // advance the streams past one plane's draws without using them (a workgroup that starts in the middle of an RNG group)
-template <int H, int W, bool NEED_T>
+template <int H, int W, bool NEED_T, bool EDGES = true>
 __device__ __forceinline__ void skip_plane(SpectrumRng& g, int tid) {
-    draw_plane<H, W, NEED_T>(g, tid, [](uint32_t, uint32_t, uint32_t) {}, [](int, int, uint32_t, uint32_t, uint32_t) {});
+    draw_plane<H, W, NEED_T, 0, EDGES>(g, tid, [](uint32_t, uint32_t, uint32_t) {}, [](int, int, uint32_t, uint32_t, uint32_t) {});
 }
 
 // A kernel's work units: whole RNG groups (one workgroup draws the group's planes back to back; the seeding is paid once
@@ -401,16 +402,16 @@ template <int W>
 struct RowATw {  // row pass a's wave-uniform twiddles (scalar registers), see pipe_row_a
     c32 g[8], p[8];
 };
-template <int W>
-__device__ __forceinline__ RowATw<W> row_a_twiddles(int w);
 template <int H, int W, int NW, bool INPLACE = false>
-__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane, const RowATw<W>& tw);
+__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane);
 template <int H, int W, int NW, bool STATS, bool NORM>
 __device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, int lane, float scale, float nm, float nc, double& s, double& q);
 
 // Look-ahead of the phase-serial generate kernel (launch-bound batch sizes: every workgroup of the launch is resident at once): the
 // workgroups from `main_blocks` on compute the statistics of the NEXT call (stream `stream_id`, same seed / shape / filter) into
 // `partials` while the first `main_blocks` produce this call's planes -- independent workgroups, no ordering between them.
+constexpr int kAheadMaxGroup = 4;  // planes per unit the look-ahead statistics cover
+constexpr int kMaxRngGroup = 8;    // planes per RNG group: the edge-column area of the generate kernels holds eight
 constexpr int kStatsBatch = 4;  // statistics: planes per batch -- their edge columns wait in LDS for ONE barrier (a barrier per plane
                                 // made the eight waves of a group wait for each other four times per group)
 struct StatsAhead {
@@ -511,8 +512,6 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
         for (int k1 = 0; k1 < RN1; ++k1) ptw[k1] = c_tw256[((w * k1) * (256 / M)) & 255];
     };
     if constexpr (FAST) load_twiddles(wv);
-    [[maybe_unused]] RowATw<W> rtw;
-    if constexpr (FAST && H == 128) rtw = row_a_twiddles<W>(wv);
 
 #ifdef SONAR_PW_DESYNC  // profiling builds: the second resident workgroup of every CU starts late (out of phase with the first)
     if (blockIdx.x >= gridDim.x / 2)
@@ -740,7 +739,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (H * W >= 32768 ? 2 :
             // front, row pass a leaves element (k1, n2) at column 8 n2 + k1 for the 16-byte stores of pass b
             if constexpr (!(SONAR_PW_SKIP & 2)) pipe_col_b<H, W, 8>(A, A, wv, lane);  // in place: an item reads and writes the same 8 rows of its column
             __syncthreads();
-            if constexpr (!(SONAR_PW_SKIP & 4)) pipe_row_a<H, W, 8, true>(A, A, wv, lane, rtw);
+            if constexpr (!(SONAR_PW_SKIP & 4)) pipe_row_a<H, W, 8, true>(A, A, wv, lane);
             __syncthreads();
             } else {
             // ------------------------------------------------------------ columns, pass b: radix 8, rows 8 k1 .. 8 k1 + 7
@@ -1066,16 +1065,23 @@ __device__ __forceinline__ void pipe_col_b(const c32* X, c32* Y, int w, int lane
 // Waves 0-5: residue pairs (1,7) (2,6) (3,5), rows lane + 64 (w & 1).  Residues 0 and 4 mirror onto themselves (four operand pairs
 // per item): waves 6 and 7, two rows each -- the same 133-140 packed operations for every wave.  Twiddles are wave-uniform (scalar registers).
 // INPLACE (one plane buffer, X == Y: the phase-serial kernel): a workgroup barrier between the loads and the stores.
+// The pass's sixteen twiddles come from a contiguous per-class table (c_rowa_tw128, twiddles256.h) with two scalar loads PER PASS, behind
+// an opaque class index so that the loads stay inside the plane loop: held across the loop, 32 more long-lived scalar registers made the
+// allocator spill the twiddles themselves into vector-register lanes and read them back one v_readlane (and its hazard nops) in front of
+// every use -- 46 of the pass's 207 instructions; pinned in vector registers instead they spilled 64 of those to scratch.
 template <int W>
 __device__ __forceinline__ RowATw<W> row_a_twiddles(int w) {
-    constexpr int M = W / 2;
-    const int a = w < 6 ? 1 + (w >> 1) : (w == 6 ? 0 : 4);
-    RowATw<W> t;
+    static_assert(W == 128, "c_rowa_tw128");
+    int cls = w < 6 ? (w >> 1) : w - 3;
+    asm volatile("" : "+s"(cls));
+    const c32* t = c_rowa_tw128[cls];
+    RowATw<W> r;
 #pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) t.g[n1] = c_tw256[((8 * n1 + a) * (256 / W)) & 255];
-#pragma unroll
-    for (int k1 = 0; k1 < 8; ++k1) t.p[k1] = c_tw256[((a * k1) * (256 / M)) & 255];
-    return t;
+    for (int i = 0; i < 8; ++i) {
+        r.g[i] = t[i];
+        r.p[i] = t[8 + i];
+    }
+    return r;
 }
 __device__ __forceinline__ c32 cconj(c32 a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ c32 cmul_conj(c32 a, c32 b) {  // a * conj(b), packed like cmul
@@ -1084,16 +1090,17 @@ __device__ __forceinline__ c32 cmul_conj(c32 a, c32 b) {  // a * conj(b), packed
 }
 
 template <int H, int W, int NW, bool INPLACE>
-__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane, const RowATw<W>& tw) {
+__device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane) {
     using C = PlaneCfg<H, W>;
+    const RowATw<W> tw = row_a_twiddles<W>(__builtin_amdgcn_readfirstlane(w));
     constexpr int M = C::M, S = C::S, RN1 = C::RN1, RN2 = C::RN2;
     static_assert(H == 128 && RN1 == 8 && RN2 == 8 && NW == 8, "three residue pairs x two row halves + two self-mirrored residues x all rows");
-    // S + i D and S - i D of one operand pair
-    auto pair = [&](c32 xa, c32 xb, c32 g, c32& plus, c32& minus) {
+    // S + i D and conj(S - i D) = (S.x + D.y, D.x - S.y) of one operand pair: six packed operations (the conjugates are operand modifiers)
+    auto pair = [&](c32 xa, c32 xb, c32 g, c32& plus, c32& minus_conj) {
         const c32 xc = cconj(xb);
         const c32 s = cadd(xa, xc), d = cmul(csub(xa, xc), g);
         plus = cadd_i(s, d);
-        minus = csub_i(s, d);
+        minus_conj = cc(vv(d).yx + v2f{s.x, -s.y});
     };
     if (w < 6) {  // uniform
         const int a = 1 + (w >> 1), b = 8 - a, r = lane + 64 * (w & 1);
@@ -1110,7 +1117,7 @@ __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane
         for (int n1 = 0; n1 < 8; ++n1) {
             c32 m;
             pair(xa[n1], xb[n1], tw.g[n1], ga[n1], m);
-            tb[(8 - n1) & 7] = cconj(m);  // G of residue b at n1' = 7 - n1, shifted by one place
+            tb[(8 - n1) & 7] = m;  // G of residue b at n1' = 7 - n1, shifted by one place
         }
         idft<8>(ga);
         idft<8>(tb);
@@ -1154,14 +1161,14 @@ __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane
                 for (int n1 = 1; n1 < 4; ++n1) {
                     c32 m;
                     pair(x[it][n1], x[it][8 - n1], tw.g[n1], g[it][n1], m);
-                    g[it][8 - n1] = cconj(m);
+                    g[it][8 - n1] = m;
                 }
             } else {
 #pragma unroll
                 for (int n1 = 0; n1 < 4; ++n1) {
                     c32 m;
                     pair(x[it][n1], x[it][7 - n1], tw.g[n1], g[it][n1], m);
-                    g[it][7 - n1] = cconj(m);
+                    g[it][7 - n1] = m;
                 }
             }
             idft<8>(g[it]);
@@ -1373,8 +1380,8 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
     __shared__ c32 EDGE[3 * H];  // raw columns kx = 0 and kx = M of the plane being drawn, and the packed column built from them
     // stream states of this workgroup's SECOND unit, seeded by the transforming team while it waits for the first plane (the draw team
     // would spend ~0.8 us on the Philox rounds at the unit switch: 32-bit multiplies at a sixth of the plain rate)
-    __shared__ uint4 SEED_RT[2 * NT];  // (R, T) per slot; twice the size: the drawing team's look-ahead edge columns borrow the area
-    __shared__ uint2 SEED_E[H];
+    __shared__ uint4 SEED_RT[NT];  // (R, T) per slot; the drawing team's look-ahead edge columns borrow the area later (8 KB: four planes)
+    static_assert(sizeof(uint4) * NT >= sizeof(c32) * 2 * H * kAheadMaxGroup, "edge columns of a look-ahead unit fit the seed area");
     __shared__ double sred[2 * NT / 64];  // wave sums of a team's look-ahead statistics (TeamStats)
     __shared__ double red[2 * NALL / 64];
     __shared__ NormDecision shd;
@@ -1397,9 +1404,37 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         pre_s = na.partials[2 * threadIdx.x];
         pre_q = na.partials[2 * threadIdx.x + 1];
     }
-    auto decide = [&]() {
+    // The decision in three steps that ride on barriers the pipeline has anyway (round 4 ran decide_from_sums at the top of iteration 1:
+    // two extra workgroup barriers and a chain of fp64 divisions and square roots in ONE thread with fifteen waves waiting, 1.7 us per
+    // launch): every wave leaves its sums in LDS before the last barrier of iteration 0; wave 0 of the transforming team adds them up
+    // in wave order (the order of block_sum2: same bits) and decides during phase 1 of iteration 1; the transforming team picks the
+    // decision up behind the second barrier, in front of its first stores.  The drawing team never needs it.
+    auto leave_wave_sums = [&]() {
         if constexpr (NORM) {
-            const NormDecision dec = decide_from_sums<NALL>(pre_s, pre_q, na.n_total, na.thr_sd, red, &shd);
+            const double ws = wave_sum(pre_s), wq = wave_sum(pre_q);
+            if (lane == 0) {
+                red[wv_all] = ws;
+                red[NALL / 64 + wv_all] = wq;
+            }
+        }
+    };
+    auto decide_in_wave0 = [&]() {
+        if constexpr (NORM) {
+            if (wv_all == 0) {
+                double ss = 0.0, qq = 0.0;
+#pragma unroll
+                for (int i = 0; i < NALL / 64; ++i) {
+                    ss += red[i];
+                    qq += red[NALL / 64 + i];
+                }
+                const NormDecision dec = decision_from_totals(ss, qq, na.n_total, na.thr_sd);
+                if (lane == 0) shd = dec;
+            }
+        }
+    };
+    auto pick_up_decision = [&]() {
+        if constexpr (NORM) {
+            const NormDecision dec = shd;
             const float g = (dec.do_div ? 1.0f / dec.stdv : 1.0f) * na.factor;
             nm = scale * g;
             nc = dec.do_sub ? dec.mean * g : 0.0f;
@@ -1409,9 +1444,7 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
     if (drawer) {
         // ------------------------------------------------------------------------------------------------ drawing team
         __builtin_amdgcn_s_setprio(SONAR_PIPE_PRIO_DRAW);
-        c32* const T0 = EDGE;
-        c32* const TM = EDGE + H;
-        c32* const Q = EDGE + 2 * H;
+        const c32* const Q = EDGE + 2 * H;  // the packed column 0 of the plane being drawn, left by the transforming team in phase 2
         SpectrumRng rng;
         // the slot's 16 filter weights, for every plane of the launch (and the look-ahead statistics of the epilogue)
         float wa[ITER], wb[ITER];
@@ -1425,7 +1458,6 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             neg = neg || fa < 0.0f || fb < 0.0f;
         }
         const bool wave_neg = __builtin_amdgcn_ballot_w64(neg) != 0;  // uniform: some slot of this wave has a negative filter value
-        const float f0 = tid < H ? filter[tid * Wh] : 0.0f, fm = tid < H ? filter[tid * Wh + M] : 0.0f;
         c32 ctw[CN1];  // e^{2 pi i n2 k1 / H}: wave-uniform, loop-invariant
 #pragma unroll
         for (int k1 = 0; k1 < CN1; ++k1) ctw[k1] = c_tw256[((wv * k1) * (256 / H)) & 255];
@@ -1434,7 +1466,6 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         int64_t unit = blockIdx.x;
         int gp = 0;
         for (int j = 0; j < n; ++j) {
-            if (j == 1) decide();
             c32* const A = PLANES + (j & 1) * BUF;
             c32 v[CN1];
             SONAR_PIPE_STAMP(0);
@@ -1444,32 +1475,16 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
                     const uint4 rt = SEED_RT[tid];
                     rng.R = Mwc{rt.x, rt.y};
                     rng.T = Mwc{rt.z, rt.w};
-                    if (tid < H) {
-                        const uint2 e = SEED_E[tid];
-                        rng.E = Mwc{e.x, e.y};
-                    }
                 } else {
-                    rng = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + gw.grp, tid);
+                    rng = spectrum_seed<true>(seed, stream_id, plane_offset / group + gw.grp, tid, false);  // the edge stream is the other team's
                 }
-                for (int i = 0; i < gw.first; ++i) skip_plane<H, W, true>(rng, tid);
-            }
-            if (tid < H) {  // row ky = tid of the edge columns (waves 0-1 of the team)
-                const uint32_t r0 = rng.E.next();
-                const uint32_t rm = rng.E.next();
-                const uint32_t t = rng.E.next();
-                T0[tid] = drawn_elem(r0, angle_lo(t), f0);
-                TM[tid] = drawn_elem(rm, angle_hi(t), fm);
+                for (int i = 0; i < gw.first; ++i) skip_plane<H, W, true, false>(rng, tid);
             }
             draw_chunk_regs<H, W, 0, E0>(rng, v, wa, wb);
             if (wave_neg) draw_chunk_signs<H, W, 0, E0>(filter, tid, v);
             pin_chunk<0, E0>(v);
             SONAR_PIPE_STAMP(1);
             __syncthreads();
-            if (tid >= NT - H) {  // packed column 0 (Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky]) from the edge rows, by the team's last waves
-                const int ky = tid - (NT - H), kn = (H - ky) & (H - 1);
-                const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
-                Q[ky] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
-            }
             draw_chunk_regs<H, W, E0, E1>(rng, v, wa, wb);
             if (wave_neg) draw_chunk_signs<H, W, E0, E1>(filter, tid, v);
             pin_chunk<E0, E1>(v);
@@ -1491,12 +1506,12 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
                 gp = 0;
                 unit += gridDim.x;
             }
+            if (j == 0) leave_wave_sums();
             SONAR_PIPE_STAMP(3);
             __syncthreads();
         }
         // nothing left to draw while the other team transforms the last plane (the same three barriers): the next call's statistics of
         // this workgroup's second unit; its edge columns wait in the seed area, which nobody reads any more
-        if (n == 1) decide();
         [[maybe_unused]] const int j = n;  // (trace builds)
         SONAR_PIPE_STAMP(0);
         if (ahead && my_units == 2) {
@@ -1527,14 +1542,48 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         // ------------------------------------------------------------------------------------------------ transforming team
         // wave wv owns residue n2 = wv in the twiddled row pass: every twiddle is wave-uniform and loop-invariant (scalar registers)
         __builtin_amdgcn_s_setprio(SONAR_PIPE_PRIO_FFT);
-        const RowATw<W> rtw = row_a_twiddles<W>(wv);
         int64_t unit = blockIdx.x;
         int gp = 0;
-        if (n > per_unit) {  // nothing to transform yet: seed the second unit's streams for the drawing team
+        // The two edge columns kx = 0, M of the plane being DRAWN are this team's (round 5; they were the drawing team's, which every
+        // barrier waited for): rows ky = tid by waves 0-1 in phase 1, the packed column Q[ky] = sym(Z0)[ky] + i sym(ZM)[ky] from them
+        // by waves 6-7 in phase 2 -- the drawing team's lane M - 1 reads Q in phase 3.  Same stream (slot ky's E), same arithmetic.
+        c32* const T0 = EDGE;
+        c32* const TM = EDGE + H;
+        c32* const Q = EDGE + 2 * H;
+        const float f0 = tid < H ? filter[tid * Wh] : 0.0f, fm = tid < H ? filter[tid * Wh + M] : 0.0f;
+        Mwc rngE{0, 1}, rngE2{0, 1};
+        int64_t eunit = blockIdx.x;
+        int egp = 0;
+        auto draw_edges = [&](int je) {  // plane je's edge rows (je < n)
+            if (tid < H && je < n) {  // whole waves
+                if (egp == 0) {
+                    const GroupWalk gw(eunit, group, split);
+                    rngE = je == per_unit ? rngE2 : spectrum_seed<false>(seed, stream_id, plane_offset / group + gw.grp, tid, true).E;
+                    for (int i = 0; i < 3 * gw.first; ++i) rngE.next();
+                }
+                const uint32_t r0 = rngE.next();
+                const uint32_t rm = rngE.next();
+                const uint32_t t = rngE.next();
+                T0[tid] = drawn_elem(r0, angle_lo(t), f0);
+                TM[tid] = drawn_elem(rm, angle_hi(t), fm);
+                if (++egp == per_unit) {
+                    egp = 0;
+                    eunit += gridDim.x;
+                }
+            }
+        };
+        auto pack_edges = [&](int je) {
+            if (tid >= NT - H && je < n) {
+                const int ky = tid - (NT - H), kn = (H - ky) & (H - 1);
+                const c32 a = T0[ky], an = T0[kn], b = TM[ky], bn = TM[kn];
+                Q[ky] = make_float2(0.5f * (a.x + an.x) - 0.5f * (b.y - bn.y), 0.5f * (a.y - an.y) + 0.5f * (b.x + bn.x));
+            }
+        };
+        if (n > per_unit) {  // nothing to transform yet: seed the second unit's streams (R, T for the drawing team through LDS)
             const GroupWalk gw(unit + gridDim.x, group, split);
             const SpectrumRng g2 = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + gw.grp, tid);
             SEED_RT[tid] = make_uint4(g2.R.x, g2.R.c, g2.T.x, g2.T.c);
-            if (tid < H) SEED_E[tid] = make_uint2(g2.E.x, g2.E.c);
+            rngE2 = g2.E;
         }
         // iteration 0: the first plane is being drawn.  The next call's statistics of this workgroup's first unit (edge columns in the
         // second plane buffer, untouched until iteration 1), over the iteration's three barriers
@@ -1550,42 +1599,51 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
                     partials_next[2 * slot + 1] = 0.0;
                 }
             __builtin_amdgcn_s_setprio(SONAR_AHEAD_PRIO);
+            draw_edges(0);
             ts.begin(filter, seed, next_stream, plane_offset, group, gw, tid, edge);
             ts.radii(0, SONAR_AHEAD_SPLIT_C, tid);
             SONAR_PIPE_STAMP(1);
             __syncthreads();
+            pack_edges(0);
             ts.radii(SONAR_AHEAD_SPLIT_C, SONAR_AHEAD_SPLIT_D, tid);
             SONAR_PIPE_STAMP(2);
             __syncthreads();
             ts.radii(SONAR_AHEAD_SPLIT_D, 4, tid);
             ts.products();
             ts.edges_and_wave_sums(edge, tid, sred);
+            leave_wave_sums();
             SONAR_PIPE_STAMP(3);
             __syncthreads();
             TeamStats<H, W>::store(sred, tid, partials_next, unit);
             __builtin_amdgcn_s_setprio(SONAR_PIPE_PRIO_FFT);
         } else {
+            draw_edges(0);
             SONAR_PIPE_STAMP(1);
             __syncthreads();
+            pack_edges(0);
             SONAR_PIPE_STAMP(2);
             __syncthreads();
+            leave_wave_sums();
             SONAR_PIPE_STAMP(3);
             __syncthreads();
         }
-        for (int j = 1; j <= n; ++j) {  // iteration j transforms plane j - 1
+        for (int j = 1; j <= n; ++j) {  // iteration j transforms plane j - 1 (and prepares the edge columns of plane j)
             constexpr int NW = 8;
-            if (j == 1) decide();
             const bool work = j >= 1;
             c32* const X = PLANES + ((j + 1) & 1) * BUF;  // plane j - 1 (pass a's output)
             c32* const Y = PLANES + (j & 1) * BUF;        // free until the drawing team writes plane j in phase 3
             SONAR_PIPE_STAMP(0);
             if (work && !(SONAR_PIPE_SKIP & 16)) pipe_col_b<H, W, NW>(X, Y, wv, lane);
+            draw_edges(j);
+            if (j == 1) decide_in_wave0();
             SONAR_PIPE_STAMP(1);
             __syncthreads();
-            if (work && !(SONAR_PIPE_SKIP & 8)) pipe_row_a<H, W, NW>(Y, X, wv, lane, rtw);
+            if (work && !(SONAR_PIPE_SKIP & 8)) pipe_row_a<H, W, NW>(Y, X, wv, lane);
+            pack_edges(j);
             SONAR_PIPE_STAMP(2);
             __syncthreads();
             if (work) {
+                if (j == 1) pick_up_decision();
                 const GroupWalk gw(unit, group, split);
                 float* const oplane = out + (gw.grp * group + gw.first + gp) * (int64_t)H * W;
                 pipe_row_b<H, W, NW, STATS, NORM>(X, oplane, wv, lane, scale, nm, nc, s, q);
@@ -1733,8 +1791,6 @@ static int power_grid(int64_t planes, bool owns_partials = true) {
 //       2 = dump the drawn spectrum into `out`, 3 = spectral filter of the real planes `z`, 4 = forward rfft2 of the real planes `z` into `out`
 // look-ahead of a normalised generate call (sonar_power_noise_ahead_f32): `have_stats` -- the partials already hold this call's
 // statistics (left by the previous call's look-ahead), `next` -- where to leave those of the call with stream id `next_stream`
-constexpr int kAheadMaxGroup = 4;  // planes per unit the look-ahead statistics cover
-constexpr int kMaxRngGroup = 8;    // planes per RNG group: the edge-column area of the generate kernels holds eight
 struct Ahead {
     int have_stats = 0;
     uint64_t next_stream = 0;

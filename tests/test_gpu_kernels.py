@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-5, 1e-6
 FFT_ATOL = 2e-5
+GEN_VS_REPLAY_ATOL = 2e-6  # generated planes against the replay of their own dumped spectrum: two roundings' difference per spectrum value
 
 
 @pytest.fixture(scope="module")
@@ -410,7 +411,9 @@ def test_power_generate_equals_replay_of_device_draws(hl):
     p1 = hl.new_partials("cuda")
     got = hl.power_irfft2(None, filt, shape, seed=77, stream_id=9, plane_offset=12, partials=p1)
     want = hl.power_irfft2(z, filt, shape)
-    assert torch.equal(got, want)
+    # the generate path takes the filter value under the radius' square root (|z f| = sqrt(-ln2 f^2 log2 u), one rounding), the replay
+    # multiplies the dumped z by f (three): the two agree to the last bits of every spectrum value, not bit for bit (round 5)
+    close(got, want, rtol=0, atol=GEN_VS_REPLAY_ATOL)
     ref = torch.fft.irfft2(z.cpu() * filt.cpu(), s=(h, w), norm="ortho")
     close(got, ref, rtol=0, atol=FFT_ATOL)
     tot = hl.stats_finalize(p1, got.numel()).cpu()
@@ -436,7 +439,7 @@ def test_power_generate_equals_replay_of_device_draws(hl):
 
 
 def test_power_spectrum_draws_are_unit_complex_normals(hl):
-    """Generate-mode spectrum elements z = rho e^{i theta} (23-bit radius word, 16-bit angle word, xoshiro128++ / + bursts
+    """Generate-mode spectrum elements z = rho e^{i theta} (23-bit radius word, 16-bit angle word, multiply-with-carry streams
     seeded by Philox): first moments, E|z|^2 = 1, E|z|^4 = 2, uncorrelated parts, uniform angle, no correlation between
     neighbouring elements / planes / the two halves of an angle word, and the expected tail."""
     z = hl.power_spectrum((64, 4, 128, 128), "cuda", seed=2024, stream_id=3).to(torch.complex128)  # 2.1 M elements
@@ -542,7 +545,7 @@ def test_power_generate_general_size_planes(hl, hw):
     assert abs((z.abs() ** 2).mean().item() - 1.0) < 1.5e-2
     p1 = hl.new_partials("cuda")
     got = hl.power_irfft2(None, filt, shape, seed=77, stream_id=9, plane_offset=12, partials=p1)
-    assert torch.equal(got, hl.power_irfft2(z, filt, shape))
+    close(got, hl.power_irfft2(z, filt, shape), rtol=0, atol=GEN_VS_REPLAY_ATOL)  # last-bit differences per spectrum value (see above)
     close(got, torch.fft.irfft2(z.cpu() * filt.cpu(), s=(h, w), norm="ortho"), rtol=0, atol=FFT_ATOL)
     a = hl.power_spectrum((2, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=12)
     b = hl.power_spectrum((3, 4, h, w), "cuda", seed=77, stream_id=9, plane_offset=20)
