@@ -17,6 +17,9 @@ constexpr int kNPart = SONAR_NPART;   // (sum,sumsq) partial pairs written by st
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// hipFuncAttributeMaxDynamicSharedMemorySize for `kern`, set ONCE per (kernel, device) of the process (runtime.hip): the attribute belongs
+// to the device's copy of the function, so a flag per instantiation alone leaves a second GPU of the process at the 64 KB default.
+void lds_attr(const void* kern, int bytes);
 
 #define SONAR_REQUIRE(cond, code, ...)   \
     do {                                 \

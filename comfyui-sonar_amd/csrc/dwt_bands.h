@@ -376,11 +376,7 @@ static bool bands_plan(BandsArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W,
 template <typename T, typename TIO, int FT, int NT, bool ZERO>
 static void launch_bands_z(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
     auto kern = wcfg_bands_kernel<T, TIO, FT, NT, ZERO>;
-    static bool raised = false;  // per instantiation: dynamic LDS above the 64 KB default needs the attribute once
-    if (lds > 64 * 1024 && !raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
-    }
+    if (lds > 64 * 1024) lds_attr(reinterpret_cast<const void*>(kern), 160 * 1024);  // dynamic LDS above the 64 KB default: once per kernel and device
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ta, tb, x, out, a);
 }
 template <typename T, typename TIO, int FT, int NT>

@@ -418,11 +418,7 @@ static int wcfg_lowpass(const float* cond, const float* uncond, const float* x, 
         constexpr int FT = decltype(ft)::value;
         auto go = [&](auto zero) {
             auto kern = wcfg_lowpass_kernel<T, FT, decltype(zero)::value>;
-            static bool raised = false;  // per instantiation: dynamic LDS above the 64 KB default needs the attribute once
-            if (lds > 64 * 1024 && !raised) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                raised = true;
-            }
+            if (lds > 64 * 1024) lds_attr(reinterpret_cast<const void*>(kern), 80 * 1024);  // dynamic LDS above the 64 KB default: once per kernel and device
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kLowThreads), lds, st, cond, uncond, x, out, a);
         };
         if (mode_fwd == kZero) go(std::true_type{}); else go(std::false_type{});

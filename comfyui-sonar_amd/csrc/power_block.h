@@ -41,7 +41,7 @@ static inline BlockPlan block_plan(int64_t H, int64_t W) {
     pl.S = pl.M + 1;
     pl.nblk = (pl.S + kBlockColsMax - 1) / kBlockColsMax;
     pl.bw = (pl.S + pl.nblk - 1) / pl.nblk;
-    best_split(pl.H, pl.hn1, pl.hn2);
+    best_split(pl.H, pl.hn1, pl.hn2, kSetLines);
     return pl;
 }
 
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(kBlockSlots, 4) power_block_cols_kernel(const 
                         __syncthreads();  // the transform's first pass writes in place
                     }
                 }
-                line_dft<kBlockSlots, false>(A, tw, H, 1, pl.hn1, pl.hn2, ncd, Sb, 1, tid);
+                line_dft<kBlockSlots, false, 0, 0, kSetLines>(A, tw, H, 1, pl.hn1, pl.hn2, ncd, Sb, 1, tid);
                 for (LinesWalk lw(tid, ncd); lw.j < H * ncd; lw.next(ncd)) dst[(int64_t)lw.r * S + lw.c] = A[lw.r * Sb + lw.c];
             }
         }

@@ -1,6 +1,11 @@
 // Error plumbing + ABI version for libsonar_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "common.h"
 
@@ -22,6 +27,19 @@ int check_launch(const char* what) {
         return SONAR_ERR_HIP;
     }
     return SONAR_OK;
+}
+
+void lds_attr(const void* kern, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    static const bool always = [] { const char* e = getenv("SONAR_LDS_ATTR_ALWAYS"); return e && e[0] == '1'; }();  // (A/B of the per-launch form)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+    if (!always) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done.insert({kern, dev}).second) return;
+    }
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) (void)hipGetLastError();
 }
 
 }  // namespace sonar
