@@ -39,6 +39,7 @@ import json
 import math
 import os
 import socket
+import statistics
 import subprocess
 import sys
 import threading
@@ -51,9 +52,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
-if not os.path.exists(TRAFFIC_FILE):
-    TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (5, 4, 3)) if os.path.exists(p)),
+                    os.path.join(ROOT, "profiles", "r05_traffic.json"))
 BATCH = 512
 C, H, W = 4, 128, 128
 N_LATENT = C * H * W
@@ -123,15 +123,21 @@ def event_us(fn, steps=20, warmup=5):
     return e0.elapsed_time(e1) / steps * 1e3
 
 
-def host_and_event_us(fn, steps=200, warmup=100, burst=25):
+BURSTS = {}  # row tag -> {"host_us": {min, median, max}, "gpu_us": {...}, "bursts": n} of the launch-bound rows (extra.bursts)
+
+
+def host_and_event_us(fn, steps=200, warmup=100, burst=25, tag=None):
     """(host issue time per call, GPU span per call) in microseconds: what a launch-bound step costs on either side.  Issued in bursts of
     `burst` calls with a synchronisation between them: a host that issues a step in 10 us runs hundreds of steps ahead of a GPU that needs
     30, and once the runtime's command queue is full every further launch blocks in the driver for far longer than either figure (seen
-    as 200+ us per call on both clocks).  A sampler never queues more than a few noise calls ahead."""
+    as 200+ us per call on both clocks).  A sampler never queues more than a few noise calls ahead.
+    The figures are the MEDIAN over the bursts (round 5): one burst in a few hundred meets a 50-90 ms freeze of the whole process that is
+    not the kernels' (the container's CPU quota throttling torch's CPU thread pool after a sampler is built), and a mean
+    over eight bursts then reads 400 us per call.  `BURSTS[tag]` keeps min / median / max of both clocks."""
     for _ in range(warmup):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    host = gpu = 0.0
+    hosts, gpus = [], []
     done = 0
     while done < steps:
         n = min(burst, steps - done)
@@ -140,12 +146,16 @@ def host_and_event_us(fn, steps=200, warmup=100, burst=25):
         e0.record()
         for _ in range(n):
             fn()
-        host += time.perf_counter() - t0
+        hosts.append((time.perf_counter() - t0) / n * 1e6)
         e1.record()
         torch.cuda.synchronize()
-        gpu += e0.elapsed_time(e1)
+        gpus.append(e0.elapsed_time(e1) / n * 1e3)
         done += n
-    return host / steps * 1e6, gpu / steps * 1e3
+    if tag is not None:
+        BURSTS[tag] = {"bursts": len(hosts), "calls_per_burst": burst,
+                       "host_us": {"min": min(hosts), "median": statistics.median(hosts), "max": max(hosts)},
+                       "gpu_us": {"min": min(gpus), "median": statistics.median(gpus), "max": max(gpus)}}
+    return statistics.median(hosts), statistics.median(gpus)
 
 
 def traffic_table() -> dict:
@@ -155,10 +165,14 @@ def traffic_table() -> dict:
     return {}
 
 
+VALU_PMC_FILE = "profiles/r05_pmc_issue_a.txt"
+
+
 def valu_active_per_launch():
-    """SQ_ACTIVE_INST_VALU of the headline kernel per dispatch (rocprofv3 --pmc pass of the round's profile set, profiles/r04_pmc_issue_a.txt):
-    vector-ALU busy cycles summed over the chip's 1024 SIMDs; None when the profile file is absent."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_issue_a.txt")
+    """SQ_ACTIVE_INST_VALU of the headline kernel per dispatch (rocprofv3 --pmc pass of the round's profile set, VALU_PMC_FILE):
+    vector-ALU busy cycles summed over the chip's 1024 SIMDs; None when the profile file is absent.  A DERIVED figure in the bench
+    line: the counter comes from that tracked file, not from this run."""
+    path = os.path.join(ROOT, VALU_PMC_FILE)
     try:
         inside = False
         with open(path) as fh:
@@ -217,15 +231,15 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
         xs_ = torch.zeros((bsz, C, H, W), device=device)
         item = power_item(pn)
         ns_small = item.make_noise_sampler(xs_, None, None, seed=None, cpu=False, normalized=True)
-        host, gpu = host_and_event_us(lambda: ns_small(*sig))
+        host, gpu = host_and_event_us(lambda: ns_small(*sig), tag=f"power_noise_{tag}")
         extra[f"power_noise_{tag}_us"] = gpu
         extra[f"power_noise_{tag}_host_us_per_call"] = host
     # the same single-latent call on latents off the 128 x 128 path: an SDXL portrait bucket (general-size kernels; the next call's statistics
     # ride in the launch) and a 2048 px latent (column blocks through a workspace: two launches)
-    for tag, (hh, ww) in (("104x152", (104, 152)), ("256x256", (256, 256))):
+    for tag, (hh, ww) in (("104x152", (104, 152)), ("112x144", (112, 144)), ("96x168", (96, 168)), ("256x256", (256, 256))):
         xs_ = torch.zeros((1, C, hh, ww), device=device)
         ns_off = power_item(pn).make_noise_sampler(xs_, None, None, seed=None, cpu=False, normalized=True)
-        host, gpu = host_and_event_us(lambda: ns_off(*sig))
+        host, gpu = host_and_event_us(lambda: ns_off(*sig), tag=f"power_noise_{tag}_b1")
         extra[f"power_noise_{tag}_b1_us"] = gpu
         extra[f"power_noise_{tag}_b1_host_us_per_call"] = host
     for tag, xb in (("b4", torch.zeros((4, C, H, W), device=device)), ("b64", x64)):
@@ -233,12 +247,12 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
         chain3.add(nz.CustomNoiseItem(0.5, noise_type="perlin"))
         chain3.add(nz.CustomNoiseItem(0.5, noise_type="pyramid"))
         ns3 = chain3.make_noise_sampler(xb, 0.03, 14.6, seed=None, cpu=False, normalized=True)
-        host, gpu = host_and_event_us(lambda: ns3(*sig))
+        host, gpu = host_and_event_us(lambda: ns3(*sig), tag=f"cfg3_chain_{tag}")
         extra[f"cfg3_chain_{tag}_us"] = gpu
         extra[f"cfg3_chain_{tag}_host_us_per_call"] = host
     for name in ("perlin", "pyramid"):
         ns1 = nz.get_noise_sampler(name, x64, 0.03, 14.6, seed=None, cpu=False, normalized=True)
-        host, gpu = host_and_event_us(lambda: ns1(*sig))
+        host, gpu = host_and_event_us(lambda: ns1(*sig), tag=f"{name}_b64")
         extra[f"{name}_b64_us"] = gpu
         extra[f"{name}_b64_host_us_per_call"] = host
     # momentum step (row M): 3 reads + 2 writes
@@ -259,7 +273,8 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
     # the same call on planes off the 128 x 128 path, 33.5 M values each: SD 1.5 latents (the fixed-size kernels' general passes), an
     # SDXL portrait bucket (general-size kernels: codelets 13 x 8 and 19 x 4), 2048 px (beyond LDS: drawn and column-transformed in blocks of
     # columns into a complex workspace, rows out of it -- sonar_power_block_f32)
-    for tag, (hh, ww, nb) in {"64x64": (64, 64, 2048), "104x152": (104, 152, 530), "256x256": (256, 256, 128)}.items():
+    for tag, (hh, ww, nb) in {"64x64": (64, 64, 2048), "104x152": (104, 152, 530), "112x144": (112, 144, 520), "96x168": (96, 168, 520),
+                              "256x256": (256, 256, 128)}.items():
         try:
             fz = torch.rand(hh, ww // 2 + 1, device=device) + 0.5
             shp, ctr = (nb, C, hh, ww), [0]
@@ -272,7 +287,8 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
             extra[f"power_noise_{tag}_us"] = us
             kernels.append(kernel_entry(f"power noise, normalised generate, {nb} latents of {C} x {hh} x {ww}", us, 4 * nb * C * hh * ww,
                                         tr.get(f"power_noise_{tag}_b{nb}", {}).get("hbm_bytes_per_launch"),
-                                        "two launches (statistics + final pass; 256 x 256: statistics + columns into a workspace + rows, 3 x the tensor of traffic); bytes = the tensor written once"))
+                                        "two launches (statistics + final pass; 256 x 256: statistics + columns into a workspace + rows, 3 x the tensor of traffic); bytes = the tensor written once"
+                                        + ("; SDXL bucket: the general-size kernel with compile-time factor pairs (power_buckets_*.hip)" if (hh, ww) in ((104, 152), (112, 144), (96, 168)) else "")))
         except Exception as exc:  # secondary figure only
             extra[f"power_noise_{tag}_error"] = repr(exc)[:200]
     # brownian (cfg5's third source): one new path point per call, bridged between the kept tensors of its neighbours
@@ -597,7 +613,7 @@ def main():
             peak = HBM_PEAK_GBPS * n_gpus  # the job's roofline: N x 8 TB/s
             # one call = the final pass (draw, filter, LDS-resident C2R FFT, normalise, ONE write) + one statistics computation (re-draw
             # of the radius words, Parseval, no stores: in the final pass's idle waves, or its own launch): 4N bytes per latent really
-            # cross HBM (profiles/r04_traffic.json)
+            # cross HBM (profiles/r05_traffic.json)
             real_bytes = 4 * N_LATENT * BATCH * n_gpus  # all ranks' launches together
             contract_bytes = 12 * N_LATENT * BATCH * n_gpus
             achieved = real_bytes / (pair_us * 1e-6) / 1e9
@@ -608,18 +624,20 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "cfg2: power-law (pink, alpha=1) rFFT noise, normalised, SDXL 4x128x128, batch 512 per GPU, "
-                                       "generate mode (in-kernel Philox-seeded xoshiro128++)", "batch_per_gpu": BATCH, "global_batch": BATCH * n_gpus, "prewarm_steps": max(args.prewarm, 0),
+                                       "generate mode (in-kernel Philox-seeded multiply-with-carry streams)", "batch_per_gpu": BATCH, "global_batch": BATCH * n_gpus, "prewarm_steps": max(args.prewarm, 0),
                            "stats_lookahead": not args.no_lookahead,
                            "parallelism": f"batch-shard x{n_gpus}"},
                 "roofline": {"bound": "valu", "limiter": "vector-ALU issue + LDS / barrier latency of two 8-wave teams per CU (phase timeline and counters: "
-                                                         "profiles/r04_power_kernel.md); HBM moves 4N per latent and would allow ~21 us per launch",
+                                                         "profiles/r05_power_kernel.md); HBM moves 4N per latent and would allow ~21 us per launch",
                              "kernel": "power_pipe_kernel<128,128,NORM> with the next call's statistics in its idle waves (one C-ABI call, "
                                        "sonar_power_noise_ahead_f32); --no-lookahead: power_stats_kernel<128,128> + power_pipe_kernel",
                              "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                              "frac_valu": None if valu_active_per_launch() is None else 4.0 * valu_active_per_launch() / 1024 / (pair_us * 2400.0),
+                             "frac_valu_derived": {"derived": True, "counter": "SQ_ACTIVE_INST_VALU per dispatch", "source": VALU_PMC_FILE,
+                                                   "assumed_clock_ghz": 2.4, "measured_in_this_run": False},
                              "frac_valu_note": "what `bound` names: vector-ALU busy cycles per SIMD (4 x SQ_ACTIVE_INST_VALU -- the counter ticks "
-                                               "once per 4-cycle issue -- / 1024 SIMDs, profiles/r04_pmc_issue_a.txt) over the launch's cycles at "
-                                               "the 2.4 GHz engine clock",
+                                               "once per 4-cycle issue -- / 1024 SIMDs) over this run's launch time at an assumed 2.4 GHz engine "
+                                               "clock; the counter is read from the tracked profile file, not measured by this run",
                              "traffic": tr.get("power_noise_b512", {}).get("hbm_bytes_per_launch"), "bytes_per_launch": real_bytes,
                              "avg_launch_us": pair_us, "achieved_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9,
                              "frac_contract_12N": contract_bytes / (pair_us * 1e-6) / 1e9 / peak,
@@ -636,6 +654,12 @@ def main():
         extra["power_noise_two_launch_us"] = event_us(lambda: ns_two(*sig), 100, 300)
         ns_one = make_sampler(True)
         extra["power_noise_lookahead_us"] = event_us(lambda: ns_one(*sig), 100, 300)
+        copy_gbps = extra.get("hbm_copy_GBps_read_plus_write")
+        if copy_gbps:
+            for k in kernels:
+                k["frac_of_copy"] = k["achieved"] / copy_gbps  # against what a device-to-device copy reaches on this box (read + write)
+            out["roofline"]["frac_of_copy"] = out["roofline"]["achieved"] / copy_gbps
+        extra["bursts"] = BURSTS
         out["roofline"]["kernels"] = kernels
         out["extra"] = extra
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 
 from ... import hip_lib
+from ..utils import host_setup_threads
 from .powernoise import PowerFilter
 
 
@@ -27,7 +28,9 @@ def ffilter(x: torch.Tensor, pfilter: PowerFilter, normalization_factor: float =
     if not x.is_cuda:
         raise hip_lib.SonarHipError(f"ffilter: got a {x.device} tensor; this implementation only runs on a ROCm device")
     if filter_rfft is None:
-        filter_rfft = PowerFilter.normalize(pfilter.build(x.shape), x.shape, normalization_factor=normalization_factor).to(x.device, torch.float32)
+        with host_setup_threads():
+            filter_rfft = PowerFilter.normalize(pfilter.build(x.shape), x.shape, normalization_factor=normalization_factor)
+        filter_rfft = filter_rfft.to(x.device, torch.float32)
     filter_cache[cache_key] = filter_rfft
     h, w = x.shape[-2:]
     if not hip_lib.power_supported(h, w):

@@ -16,6 +16,7 @@ from torch import Tensor
 from ... import hip_lib
 from ..noise import CustomNoiseItemBase
 from ..noise_generation import BrownianTreeNoiseSampler, DeviceRNG, current_batch_offset
+from .. import utils
 from ..utils import attach_stats, pop_stats, scale_noise
 
 
@@ -163,8 +164,9 @@ class PowerNoiseItem(CustomNoiseItemBase):
         super().__init__(factor, power_filter=power_filter, channel_correlation=channel_correlation, **kwargs)
 
     def make_filter(self, shape, oversample=None):
-        return PowerFilter.normalize(self.power_filter.build(shape, override_oversample=oversample), shape, mix=self.mix,
-                                     normalization_factor=getattr(self, "filter_norm_factor", 1.0))
+        with utils.host_setup_threads():  # a few CPU threads: see there
+            return PowerFilter.normalize(self.power_filter.build(shape, override_oversample=oversample), shape, mix=self.mix,
+                                         normalization_factor=getattr(self, "filter_norm_factor", 1.0))
 
     def make_noise_sampler_internal(self, x: Tensor, noise_sampler, filter_rfft, normalized=True):
         """``noise_sampler`` returns a complex64 half-spectrum (replay) or None (draw on device)."""
@@ -176,8 +178,9 @@ class PowerNoiseItem(CustomNoiseItemBase):
             raise _device_irfft2_fallback_error(h, w)
         device = x.device
         filt = filter_rfft.to(device, torch.float32).reshape(h, w // 2 + 1).contiguous()
-        mixer = ChannelMixer(shape[1], self.common_mode, self.channel_correlation)
-        identity = mixer.is_identity
+        with utils.host_setup_threads():  # the 4 x 4 LDL factorisation goes through LAPACK: its thread pool too (see there)
+            mixer = ChannelMixer(shape[1], self.common_mode, self.channel_correlation)
+            identity = mixer.is_identity
         mixer.to(device)
         planes_per_latent = math.prod(shape[1:-2])  # 5-D (video) latents: every [H, W] slice is a plane, as in the reference's irfft2
         # a sampler's calls take consecutive stream ids: each call leaves the next one's statistics (`stats_lookahead = False` on the item

@@ -6,6 +6,7 @@ evaluates the thresholds on device, so there is no ``.item()`` host sync.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -17,6 +18,29 @@ Tensor = torch.Tensor
 UPSCALE_METHODS = ("bilinear", "nearest-exact", "nearest", "area", "bicubic", "bislerp", "adaptive_avg_pool2d")
 
 _STATS_ATTR = hip_lib.STATS_ATTR
+
+
+_HOST_SETUP_THREADS = 4
+
+
+@contextlib.contextmanager
+def host_setup_threads():
+    """The host-side, once-per-sampler tensor work of the path (the power filter's oversampled grid, py/nodes/powernoise.py:156-266) on a
+    few CPU threads instead of torch's default of one per logical CPU.  Round 5 traced an intermittent 50-90 ms freeze of launch-bound
+    steps (round 4's bench read 434 us for a 27 us call) to this: a 256-thread intra-op pool spins for a while after every parallel
+    region, a container with a CPU quota (the GPU pool's: 16 CPUs per 100 ms) runs out of quota, and the kernel's bandwidth control
+    throttles the WHOLE process -- the thread that launches kernels included -- until the period ends (cpu.stat nr_throttled 0 -> 100
+    over three 4-second runs; none with 4 threads; scratch/stall_fresh.py).  The tensors are a few hundred kilobytes:
+    four threads lose nothing, and elementwise results do not depend on the thread count."""
+    before = torch.get_num_threads()
+    if before <= _HOST_SETUP_THREADS:
+        yield
+        return
+    torch.set_num_threads(_HOST_SETUP_THREADS)
+    try:
+        yield
+    finally:
+        torch.set_num_threads(before)
 
 
 def fallback(val, default=None):
