@@ -644,7 +644,12 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
     extern __shared__ __align__(16) unsigned char any_lds[];
     __shared__ double red[2 * NT / 64];
     __shared__ NormDecision shd;
-    const int H = pl.H, W = pl.W, M = pl.M, S = pl.S, NC = H * S;
+    // a bucket's plane size is its factor pairs' product: every stride, trip count and division of the passes folds at compile time
+    const int H = HN1 > 0 ? HN1 * HN2 : pl.H, M = MN1 > 0 ? MN1 * MN2 : pl.M, W = 2 * M, S = M + 1, NC = H * S;
+    if constexpr (HN1 > 0) {
+        pl.H = H, pl.W = W, pl.M = M, pl.S = S;
+        pl.hn1 = HN1, pl.hn2 = HN2, pl.mn1 = MN1, pl.mn2 = MN2;
+    }
     c32* const A = reinterpret_cast<c32*>(any_lds);
     int64_t bid = blockIdx.x, nblk = gridDim.x;
     if constexpr (NT == kFftThreads && SRC == 1 && NORM && !STATS) {  // the launch-bound batch sizes: the next call's statistics in this launch
@@ -688,6 +693,11 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
         for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
             const int64_t plane = gw.grp * group + gp;
             __syncthreads();  // previous plane fully consumed (and the twiddle tables visible)
+            // With the sizes known at compile time every LDS address of a plane is loop-invariant and the optimiser hoists them ALL out of
+            // the plane loop -- and spills 2-31 registers to hold them.  An opaque copy of the thread index per plane keeps the address
+            // arithmetic (now a few constant multiplies) inside the loop, as in the fixed-size kernels (power_fft.hip).
+            int ptid = tid;
+            if constexpr (HN1 > 0) asm volatile("" : "+v"(ptid));
             if constexpr (SRC == 1) {
                 if (tid < kAnySlots)
                     draw_plane_dyn<true>(
@@ -743,7 +753,7 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
                     }
                 }
                 __syncthreads();
-                line_dft<NT, true, MN1, MN2>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, tid);
+                line_dft<NT, true, MN1, MN2>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, ptid);
                 // X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i, w = e^{-2 pi i / W}
                 const int FQ = M / 2 + 1, fdr = NT / FQ, fdk = NT - fdr * FQ;
                 int fr = tid / FQ, fk = tid - fr * FQ;
@@ -772,7 +782,7 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
                     }
                 }
                 __syncthreads();
-                line_dft<NT, true, HN1, HN2>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, tid);
+                line_dft<NT, true, HN1, HN2>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, ptid);
                 for (int j = tid; j < NC; j += NT) {
                     const float f = filter[j];
                     c32 v = A[j];
@@ -783,9 +793,9 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
             }
             __syncthreads();
             // ---- inverse columns: every one of the W/2 + 1 columns, length H
-            line_dft<NT, false, HN1, HN2>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, tid);
+            line_dft<NT, false, HN1, HN2>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, ptid);
             // ---- rows: c2r pre-twiddle + length-M complex inverse DFT; value m of a row is (x[2m], x[2m+1])
-            c2r_rows<NT, MN1, MN2>(A, twW, W, pl.mn1, pl.mn2, H, M, S, pl.c2r_fuse, tid);
+            c2r_rows<NT, MN1, MN2>(A, twW, W, pl.mn1, pl.mn2, H, M, S, pl.c2r_fuse, ptid);
             float* const oplane = out + plane * (int64_t)H * W;
             float ps = 0.0f, pq = 0.0f;
             if (SONAR_ANY_STORE16 && (M & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {  // uniform

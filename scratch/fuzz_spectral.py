@@ -49,7 +49,10 @@ for it in range(iters):
             zz = hl.power_spectrum(sh4, "cuda", seed=it, stream_id=3, plane_offset=4)
             a = hl.power_irfft2(None, filt, sh4, seed=it, stream_id=3, plane_offset=4)
             b = hl.power_irfft2(zz, filt, sh4)
-            err3 = 0.0 if torch.equal(a, b) else (a - b).abs().max().item() + 1.0
+            # round 5: the generate path takes the filter under the radius' square root, the replay multiplies the dumped value by it: the
+            # two agree to the last bits of every spectrum value (tests/test_gpu_kernels.py GEN_VS_REPLAY_ATOL), not bit for bit
+            d3 = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+            err3 = 0.0 if d3 < 2e-6 else d3 + 1.0
         if kind == 4:  # generated in column blocks: against the direct passes over its own dumped spectrum, and the normalised call against scale_noise
             sh4 = (planes, 4, H, W)
             zz = hl.power_spectrum(sh4, "cuda", seed=it, stream_id=3, plane_offset=4)
