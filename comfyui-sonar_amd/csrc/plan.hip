@@ -139,11 +139,12 @@ struct Record {
     std::vector<sonar_plan_patch> patches;
 };
 
-inline void put(Record& r, int32_t target, int32_t width, uint64_t value) {
+// a patched value goes into the CALL's copy of the argument words / blob: the plan's records are read-only while it runs
+inline void put(uint64_t* args, uint8_t* blob, int32_t target, int32_t width, uint64_t value) {
     if (target >= 0) {
-        r.args[target] = value;
+        args[target] = value;
     } else {
-        memcpy(r.blob.data() + (size_t)(-(target + 1)), &value, (size_t)width);  // little endian: the low `width` bytes
+        memcpy(blob + (size_t)(-(target + 1)), &value, (size_t)width);  // little endian: the low `width` bytes
     }
 }
 
@@ -241,9 +242,11 @@ extern "C" int sonar_plan_add(sonar_plan* plan, int fn_id, const uint64_t* args,
                 sonar_plan_levels lv;
                 memcpy(&lv, r.blob.data() + pt.index, sizeof lv);
                 const int64_t n = lv.iterations;
-                SONAR_REQUIRE(n >= 0 && lv.h_offset >= 0 && lv.w_offset >= 0 && lv.weight_offset >= 0 && lv.h_offset + 8 * n <= blob_bytes &&
-                                  lv.w_offset + 8 * n <= blob_bytes && lv.weight_offset + 4 * n <= blob_bytes,
-                              SONAR_ERR_ARG, "sonar_plan_add: patch %d: level tables outside the blob", i);
+                // every bound without an addition of caller-supplied 64-bit values (a huge offset must not wrap past the check); the tables
+                // are read and written as int64 / float: their offsets must be aligned for that
+                auto inside = [&](int64_t off, int64_t elem) { return off >= 0 && off % elem == 0 && n <= (blob_bytes - off) / elem && off <= blob_bytes; };
+                SONAR_REQUIRE(n >= 0 && n <= 64 && lv.H > 0 && lv.W > 0 && inside(lv.h_offset, 8) && inside(lv.w_offset, 8) && inside(lv.weight_offset, 4),
+                              SONAR_ERR_ARG, "sonar_plan_add: patch %d: level rule out of range (H, W > 0, 0 <= iterations <= 64, aligned tables inside the blob)", i);
                 break;
             }
             default:
@@ -255,36 +258,53 @@ extern "C" int sonar_plan_add(sonar_plan* plan, int fn_id, const uint64_t* args,
     return SONAR_OK;
 }
 
+// Re-entrant: the per-call values are patched into a copy of each record's argument words (and of its blob, when a patch or an argument
+// points into it) on this call's stack -- two threads may replay the SAME plan at once on their own streams (round 5; round 4 patched the
+// shared records in place).
 extern "C" int sonar_plan_run(sonar_plan* plan, const uint64_t* slots, int nslots, uint64_t seed, uint64_t stream_base, void* stream,
                               int* failed_record) {
     SONAR_REQUIRE(plan && nslots == plan->nslots && (nslots == 0 || slots), SONAR_ERR_ARG, "sonar_plan_run: bad plan / slot table");
     if (failed_record) *failed_record = -1;
     int idx = 0;
-    for (Record& r : plan->records) {
+    constexpr size_t kStackBlob = 1024;
+    alignas(16) uint8_t stack_blob[kStackBlob];
+    std::vector<uint8_t> heap_blob;
+    for (const Record& r : plan->records) {
+        uint64_t args[kMaxArgs];
+        memcpy(args, r.args, sizeof(uint64_t) * (size_t)r.nargs);
+        uint8_t* blob = nullptr;
+        if (!r.blob.empty()) {
+            if (r.blob.size() <= kStackBlob) {
+                blob = stack_blob;
+            } else {
+                heap_blob.resize(r.blob.size());
+                blob = heap_blob.data();
+            }
+            memcpy(blob, r.blob.data(), r.blob.size());
+        }
         for (const sonar_plan_patch& pt : r.patches) {
             switch (pt.source) {
-                case SONAR_PATCH_SLOT: put(r, pt.target, pt.width, slots[pt.index] + (uint64_t)pt.addend); break;
-                case SONAR_PATCH_STREAM: put(r, pt.target, pt.width, stream_base + (uint64_t)pt.addend); break;
-                case SONAR_PATCH_SEED: put(r, pt.target, pt.width, seed); break;
-                case SONAR_PATCH_BLOB: put(r, pt.target, pt.width, (uint64_t)(uintptr_t)(r.blob.data() + pt.addend)); break;
+                case SONAR_PATCH_SLOT: put(args, blob, pt.target, pt.width, slots[pt.index] + (uint64_t)pt.addend); break;
+                case SONAR_PATCH_STREAM: put(args, blob, pt.target, pt.width, stream_base + (uint64_t)pt.addend); break;
+                case SONAR_PATCH_SEED: put(args, blob, pt.target, pt.width, seed); break;
+                case SONAR_PATCH_BLOB: put(args, blob, pt.target, pt.width, (uint64_t)(uintptr_t)(blob + pt.addend)); break;
                 case SONAR_PATCH_LEVELS: {
                     sonar_plan_levels lv;
-                    memcpy(&lv, r.blob.data() + pt.index, sizeof lv);
+                    memcpy(&lv, blob + pt.index, sizeof lv);
                     const int n = sonar_pyramid_levels(lv.H, lv.W, lv.iterations, lv.discount, seed, stream_base + (uint64_t)pt.addend,
-                                                       reinterpret_cast<int64_t*>(r.blob.data() + lv.h_offset),
-                                                       reinterpret_cast<int64_t*>(r.blob.data() + lv.w_offset),
-                                                       reinterpret_cast<float*>(r.blob.data() + lv.weight_offset));
+                                                       reinterpret_cast<int64_t*>(blob + lv.h_offset), reinterpret_cast<int64_t*>(blob + lv.w_offset),
+                                                       reinterpret_cast<float*>(blob + lv.weight_offset));
                     if (n < 0) {
                         if (failed_record) *failed_record = idx;
                         return n;
                     }
-                    r.args[pt.target] = (uint64_t)(int64_t)n;
+                    args[pt.target] = (uint64_t)(int64_t)n;
                     break;
                 }
             }
         }
-        r.args[r.nargs - 1] = (uint64_t)(uintptr_t)stream;
-        const int rc = kReplayable[r.fn].thunk(r.args);
+        args[r.nargs - 1] = (uint64_t)(uintptr_t)stream;
+        const int rc = kReplayable[r.fn].thunk(args);
         if (rc != SONAR_OK) {
             if (failed_record) *failed_record = idx;
             return rc;

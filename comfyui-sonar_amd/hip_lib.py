@@ -1090,11 +1090,12 @@ def power_noise(filt: torch.Tensor, shape, *, seed: int, stream_id: int, plane_o
         lookahead.hits += int(have)
         lookahead.misses += int(not have)
         lookahead.key, lookahead.partials, lookahead.last_stream = key_for(nxt), nws, stream_id
-        if _recorder is not None:  # a plan replays the steady state only: statistics present, the step settled
+        rec = _recorder  # (one read: another thread's trace may end meanwhile)
+        if rec is not None and rec.thread == _threading.get_ident():  # THIS thread's call is being traced: a plan replays the steady state only
             if have and lookahead.last_delta == lookahead.step:
-                _recorder.hooks.append(_PowerAheadHook(lookahead, key_for, ws, nws, stream_id - _recorder.base, lookahead.step, filt.device))
+                rec.hooks.append(_PowerAheadHook(lookahead, key_for, ws, nws, stream_id - rec.base, lookahead.step, filt.device))
             else:
-                _recorder.fail("power-law look-ahead not in its steady state")
+                rec.fail("power-law look-ahead not in its steady state")
         return out
     ws = new_partials(filt.device)
     _check(
@@ -1850,6 +1851,9 @@ class _PerlinAheadHook(PlanHook):
         table[sl["t_out"]] = terms[to].data_ptr()
         table[sl["l_out"]] = target
         self.now = (state, {(seed, target): to, (seed, l_next): tn}, {(seed, s_next): pn})
+        # the launch overwrites a lattice buffer and a statistics buffer: until post_run says what they hold, nothing is "ready" -- a run
+        # that fails in between (an entry point refusing the call) must not leave keys pointing at overwritten buffers
+        state["ready_terms"], state["ready_parts"] = {}, {}
         return True
 
     def post_run(self, seed, base):
@@ -1938,6 +1942,7 @@ class _LatticeAheadHook(PlanHook):
         table[sl["t_out"]] = terms[1 - ti].data_ptr()
         table[sl["l_out"]] = l_next
         self.now = (state, {(seed, l_next): 1 - ti})
+        state["ready"] = {}  # (as in _PerlinAheadHook: valid again in post_run)
         return True
 
     def post_run(self, seed, base):
@@ -2192,7 +2197,9 @@ class Plan:
             t = torch.empty(shape, dtype=dtype, device=device)
             table[slot] = t.data_ptr()
             fresh.append(t)
-        rc = _lib.sonar_plan_run(self.handle, table, self.nslots, seed, base, st, self.failed)
+        failed = C.c_int(-1)
+        rc = _lib.sonar_plan_run(self.handle, table, self.nslots, seed, base, st, failed)
+        self.failed = failed
         if rc != 0:
             if self.rng_count:
                 self.rewind(base)
@@ -2284,6 +2291,9 @@ def trace_plan(fn, args, *, take, rewind, guards):
             trace_plan.last_reason = None
         except PlanError as exc:
             trace_plan.last_reason = str(exc)
+        except Exception as exc:  # noqa: BLE001 -- the step itself ran and has its result: a builder bug must not become a failed sampler step
+            trace_plan.last_reason = f"plan builder: {type(exc).__name__}: {exc}"
+            plan = None
         if plan is not None:
             refs, plan.scratch_refs = plan.scratch_refs, None
             rec.temps.clear()
@@ -2397,11 +2407,19 @@ class Planned:
         self.calls = 0
         self.attempts = 0
         self.reason = None
+        # A sampler is a stateful object: it consumes an RNG sequence and keeps what one call leaves for the next (look-ahead statistics,
+        # lattices, the plan's per-stream slot table).  Two threads calling the SAME sampler are serialised here (the C side of a replay is
+        # re-entrant, sonar_plan_run; different samplers do not share the lock): each call gets its own RNG position and its own result.
+        self.lock = _threading.RLock()
         for name in ("unscaled", "accumulate", "fold_prefix", "accepts_prefix", "normalized_call", "plan_static"):
             if hasattr(fn, name):
                 setattr(self, name, getattr(fn, name))
 
     def __call__(self, sigma=None, sigma_next=None):
+        with self.lock:
+            return self._call(sigma, sigma_next)
+
+    def _call(self, sigma, sigma_next):
         if PLANS_ENABLED and (_recorder is None or _recorder.thread != _threading.get_ident()):
             plan = self.plan
             if plan is not None:

@@ -108,7 +108,8 @@ class DeviceRNG:
     @classmethod
     def rewind(cls, stream: int) -> None:
         """Put the position back to ``stream`` (a prepared plan that took its streams and then could not issue the step)."""
-        torch.cuda.default_generators[torch.cuda.current_device()].set_offset(4 * int(stream))
+        with cls._lock:
+            torch.cuda.default_generators[torch.cuda.current_device()].set_offset(4 * int(stream))
 
 
 class _Shard(threading.local):

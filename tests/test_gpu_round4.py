@@ -376,6 +376,72 @@ def test_a_trace_only_sees_its_own_thread(api):
     assert _same(got, _run(api, ref, 8, False))
 
 
+@pytest.mark.parametrize("what", ["chain:perlin*0.5+pyramid*0.5", "power", "pyramid"])
+def test_two_threads_replay_the_same_sampler(api, what):
+    """Round 5: two threads call the SAME planned sampler at once, each on its own HIP stream (a preview thread beside the sampling thread).
+    sonar_plan_run patches a per-call copy of the argument words and level tables (it used to patch the shared records), and a sampler
+    serialises its callers: every call gets its own RNG position and the values that position gives -- the 2 x 12 results are, as a
+    multiset, the 24 results of one thread calling 24 times from the same position."""
+    import hashlib
+    import threading
+
+    hl = api.hl
+    x = torch.zeros((4, 4, 128, 128), device="cuda")
+    make = _maker(api, x, what, True)
+    ns, ref = make(), make()
+    old = hl.PLANS_ENABLED
+    hl.PLANS_ENABLED = True
+    try:
+        torch.manual_seed(99)
+        for _ in range(6):  # warm calls + the traced one: the plan exists before the threads start
+            ns(*SIG)
+        planned = _planned(api, ns)
+        assert planned is not None and planned.plan is not None, getattr(planned, "reason", None)
+        runs_before = planned.plan.runs
+        direct = not planned.plan.hooks
+        assert direct == (what == "pyramid")
+        state = torch.cuda.get_rng_state()
+        results, errors = {0: [], 1: []}, []
+        barrier = threading.Barrier(2)
+
+        def worker(k):
+            try:
+                torch.cuda.set_device(0)
+                with torch.cuda.stream(torch.cuda.Stream()):
+                    barrier.wait()
+                    for _ in range(12):
+                        # a plan without hooks keeps nothing between calls: its replay needs no lock at all -- sonar_plan_run itself runs
+                        # concurrently on the two threads then (the pyramid's plan patches level tables in its records' blobs)
+                        out = planned.plan.run() if direct else ns(*SIG)
+                        assert out is not hl.NOT_RUN
+                        out = out[0] if isinstance(out, tuple) else out
+                        torch.cuda.current_stream().synchronize()
+                        results[k].append(hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest())
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        if what != "power":  # (the power item's look-ahead statistics are tied to ONE HIP stream: two streams taking turns send every call down
+            # the ordinary path -- right values, no replay)
+            assert planned.plan.runs - runs_before >= 20  # replays, not fall-backs
+        torch.cuda.set_rng_state(state)
+        hl.PLANS_ENABLED = False
+        single = []
+        for _ in range(24):
+            out = ref(*SIG)
+            out = out[0] if isinstance(out, tuple) else out
+            single.append(hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest())
+        assert len(set(single)) == 24
+        assert sorted(results[0] + results[1]) == sorted(single)
+    finally:
+        hl.PLANS_ENABLED = old
+
+
 REGISTRY_TYPES = ["gaussian", "uniform", "perlin", "pyramid", "pyramid_area", "pyramid_discount5", "pyramid_mix", "pyramid_mix_area", "pyramid_old",
                   "pyramid_old_area", "highres_pyramid", "laplacian", "power_old", "pink_old", "white", "grey", "velvet", "violet", "onef_pinkish",
                   "onef_greenish", "onef_pinkishgreenish", "onef_pinkish_mix", "onef_greenish_mix", "green_test", "rainbow_mild", "rainbow_intense",
