@@ -85,58 +85,17 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t stream_id
     box_muller(p.v[2], p.v[3], z[2], z[3]);
 }
 
-// ---- tile-keyed xoshiro128++ streams ------------------------------------------------------------
-// 32-bit integer multiplies are ~1/8 rate on CDNA4, so Philox4x32-10 (20 multiplies per 4 words) is
-// used only to SEED short xoshiro128++ bursts (add / rotate / xor, full rate).  A stream is keyed by
-// (seed, stream id, tile, lane): every draw is still a pure function of the global position, so
-// batches can be sharded over GPUs without changing values.
-struct Xoshiro {
-    uint32_t s0, s1, s2, s3;
-    // the state update of xoshiro128: s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= s1 << 9; s3 = rotl(s3, 11) -- with gfx950's
-    // three-input bit operation (v_bitop3_b32, truth table 0x96 = a ^ b ^ c) four instructions for the five exclusive-ors, and three of the
-    // four new words no longer wait for an intermediate one.  (The compiler does not form it from a ^ b ^ c by itself.)
-    static __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
-    __device__ __forceinline__ void step() {
-        const uint32_t t = s1 << 9;
-        const uint32_t n1 = xor3(s1, s2, s0), n0 = xor3(s0, s3, s1), n2 = xor3(s2, s0, t), x3 = s3 ^ s1;
-        s0 = n0; s1 = n1; s2 = n2;
-        s3 = __builtin_amdgcn_alignbit(x3, x3, 32 - 11);
-    }
-    __device__ __forceinline__ uint32_t next() {
-        const uint32_t sum = s0 + s3;
-        const uint32_t r = __builtin_amdgcn_alignbit(sum, sum, 32 - 7) + s0;  // rotl(s0 + s3, 7) + s0
-        step();
-        return r;
-    }
-    // xoshiro128+ output (two fewer operations): only the HIGH bits are equidistributed well enough to use
-    // (its low 4 bits fail linearity tests) -- for consumers that keep bits 31..9 and drop the rest
-    __device__ __forceinline__ uint32_t next_high() {
-        const uint32_t r = s0 + s3;
-        step();
-        return r;
-    }
-    __device__ __forceinline__ void normal4(float (&z)[4]) {
-        const uint32_t a = next(), b = next(), c = next(), d = next();
-        box_muller(a, b, z[0], z[1]);
-        box_muller(c, d, z[2], z[3]);
-    }
-    // uniforms keep bits 31..8 of a word: the xoshiro128+ output (two operations fewer per word) serves them
-    __device__ __forceinline__ void words4_high(uint32_t (&r)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = next_high();
-    }
-    __device__ __forceinline__ void uniform4(float (&u)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) u[k] = u01(next_high());
-    }
-};
-
-// ---- multiply-with-carry streams (the power-law kernels' spectrum draws) -------------------------
-// MWC64X (D. B. Thomas): 64-bit state (x, c), x' : c' = A x + c, output x ^ c; period (A 2^32 - 2) / 2 ~ 2^63, passes TestU01's BigCrush.
-// On gfx950 the whole state update is ONE v_mad_u64_u32 (32 x 32 + 64 -> 64; measured 1.8 ns per wave-instruction and SIMD, the cost of
-// a shift) and a word costs 2.8 ns with the exclusive-or, against 8.8 ns for a xoshiro128+ step (seven operations, two of them
-// half-rate shifts: scratch/ubench/valu_rate.hip) -- the draw of a spectrum value was one third generator.  Two registers per stream
-// instead of four.  Streams are seeded from Philox blocks (random points of the one cycle: 2^63 against at most 2^12 words per stream).
+// ---- tile-keyed random streams ---------------------------------------------------------------------
+// 32-bit integer multiplies and the 20 of a Philox4x32-10 block are used only to SEED short bursts of a cheap generator.  A stream
+// is keyed by (seed, stream id, tile, lane): every draw is still a pure function of the global position, so batches can be sharded
+// over GPUs without changing values.
+//
+// The burst generator is a multiply-with-carry: MWC64X (D. B. Thomas), 64-bit state (x, c), x' : c' = A x + c, output x ^ c; period
+// (A 2^32 - 2) / 2 ~ 2^63, passes TestU01's BigCrush.  On gfx950 the whole state update is ONE v_mad_u64_u32 (32 x 32 + 64 -> 64;
+// measured 1.8 ns per wave-instruction and SIMD, the cost of a shift) and a word costs 2.8 ns with the exclusive-or, against 8.8 ns
+// for the xoshiro128+ step rounds 1-4 used (seven operations, two of them half-rate shifts: scratch/ubench/valu_rate.hip) -- the draw
+// of a spectrum value was one third generator.  Two registers per stream instead of four.  Streams are random points of the one
+// cycle (2^63 against at most 2^12 words per stream).  Round 5; the change moved every generate-mode value (replay mode is untouched).
 struct Mwc {
     uint32_t x, c;
     static constexpr uint32_t A = 4294883355u;
@@ -147,14 +106,29 @@ struct Mwc {
         c = (uint32_t)(t >> 32);
         return r;
     }
+    __device__ __forceinline__ uint32_t next_high() { return next(); }  // (callers that keep only a word's high bits: every bit is good here)
     // (x, c) from two random words: c in [1, 2^31) -- below A and never the all-zero state
     static __device__ __forceinline__ Mwc seeded(uint32_t a, uint32_t b) { return Mwc{a, (b >> 1) | 1u}; }
+    __device__ __forceinline__ void normal4(float (&z)[4]) {
+        const uint32_t a = next(), b = next(), c2 = next(), d = next();
+        box_muller(a, b, z[0], z[1]);
+        box_muller(c2, d, z[2], z[3]);
+    }
+    __device__ __forceinline__ void words4_high(uint32_t (&r)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = next();
+    }
+    __device__ __forceinline__ void uniform4(float (&u)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = u01(next());
+    }
 };
+using TileRng = Mwc;
 
-__device__ __forceinline__ Xoshiro rng_stream(uint64_t seed, uint64_t stream_id, uint64_t tile, uint32_t lane) {
+__device__ __forceinline__ TileRng rng_stream(uint64_t seed, uint64_t stream_id, uint64_t tile, uint32_t lane) {
     const Philox4 p = philox4x32_10((uint32_t)tile, (uint32_t)(tile >> 32), (uint32_t)stream_id,
                                     (uint32_t)((stream_id >> 32) << 16) ^ lane, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return Xoshiro{p.v[0], p.v[1], p.v[2], p.v[3] | 1u};  // never the all-zero state
+    return Mwc::seeded(p.v[0] ^ p.v[2], p.v[1] ^ p.v[3]);
 }
 
 // Flat buffers are drawn in tiles of kTileIters x 64 lanes x 4 elements: global element e belongs to

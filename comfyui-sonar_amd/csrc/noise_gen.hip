@@ -18,7 +18,7 @@ __device__ unsigned long long g_ng_trace[256 * 16];
 
 // ------------------------------------------------------------------------------------------------
 // Draw loop shared by every generator: one wave per tile (common.h: kTileElems elements), each lane
-// runs its own Philox-seeded xoshiro128++ burst and hands 4 consecutive elements per step to `f`.
+// runs its own Philox-seeded multiply-with-carry burst (common.h, Mwc) and hands 4 consecutive elements per step to `f`.
 // `f(e, v)` receives the LOCAL index e (may be < 0 or >= n at the two ends of a shard) of v[0].
 enum class Dist { Normal, Uniform };
 
@@ -29,7 +29,7 @@ __device__ __forceinline__ void for_each_group(int64_t n, uint64_t seed, uint64_
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
     const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
     for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
-        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+        TileRng rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
         const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
 #pragma unroll 4
         for (int it = 0; it < kTileIters; ++it) {
@@ -109,7 +109,7 @@ struct Prefix {
 // kind: 0 none, 1 Gaussian draw, 2 Perlin (summed lattice).  One group of four values: x drawn by the caller's copy of the prefix's
 // generator (`rng`, advanced here), `term` the lattice vector of these four elements (Perlin).
 template <int PRE>
-__device__ __forceinline__ void prefix_draw(Xoshiro& rng, const Divider& div, const float4& term, float (&x)[4]) {
+__device__ __forceinline__ void prefix_draw(TileRng& rng, const Divider& div, const float4& term, float (&x)[4]) {
     if constexpr (PRE == 1) {
         rng.normal4(x);
     } else {
@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(kBlock) pair_fold_kernel(Accum fold, int64_t n
     const Accum pfold{fold.y, pre.ya, pre.f};
     const Divider hdiv(HOST == 2 ? host.div_fac : 1.0f), pdiv(PRE == 2 ? pre.div_fac : 1.0f);
     for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
-        Xoshiro hrng = rng_stream(host.seed, host.stream_id, (uint64_t)tile, lane);
-        Xoshiro prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)tile, lane);
+        TileRng hrng = rng_stream(host.seed, host.stream_id, (uint64_t)tile, lane);
+        TileRng prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)tile, lane);
         const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
         // positions inside the latent (the lattices repeat per latent; shards start on a latent boundary), kept incrementally
         int rh = HOST == 2 ? (int)(((base % host.chw) + host.chw) % host.chw) : 0;
@@ -434,7 +434,7 @@ __device__ __forceinline__ void perlin_fast_tiles(const float* __restrict__ term
     const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
     const int ichw = (int)chw;
     for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
-        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+        TileRng rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
         const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
         // position of the tile's first vector inside the latent; the prefetch cursor walks on in steps of 256 elements and wraps
         // at the latent's end (a tile may straddle two latents when chw is not a multiple of the tile)
@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __
         return;
     }
     for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
-        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+        TileRng rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
         const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
         // position inside the latent (terms repeat per latent; shards start on a latent boundary), kept incrementally
         int r = (int)(((base % chw) + chw) % chw);
@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, in
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
     const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
     for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
-        Xoshiro rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+        TileRng rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
         const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
         for (int it = 0; it < kTileIters; ++it) {
             float v[4];
@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     // after part 0's).  For the workgroup's first plane they do it HERE, while part 0 builds the coordinate tables alone.
     constexpr int kIters = kTileIters / kPyrParts;
     const int64_t t_ahead = part != 0 ? (elem_offset + (int64_t)bid * HW) / kTileElems + wave % (kBlock / 64) : -1;
-    Xoshiro rng_ahead, prng_ahead;
+    TileRng rng_ahead, prng_ahead;
     if (threadIdx.x == 0) {
         int off = 0, item = 0;
 #pragma unroll
@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
             int l = 0;
             while (item >= lvl_item0[l + 1]) ++l;
             const int gslot = item - lvl_item0[l], off = lvl_off[l], n = lvl_off[l + 1] - off;
-            Xoshiro rng = rng_stream(seed, lvl_stream[l], (uint64_t)(elem_offset / HW + p), gslot);
+            TileRng rng = rng_stream(seed, lvl_stream[l], (uint64_t)(elem_offset / HW + p), gslot);
             for (int i = gslot * 4; i < n; i += kBlock * 4) {
                 float z[4];
                 rng.normal4(z);
@@ -1102,7 +1102,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
         // a tile's burst is split between the parts: part k runs iterations [k, k + 1) * kTileIters / kPyrParts after stepping its
         // generators over the iterations before them (8 plain instructions per word instead of a Box-Muller pair)
         for (int64_t t = tile_first + wave % (kBlock / 64); t <= tile_last; t += kBlock / 64) {
-            Xoshiro rng, prng;
+            TileRng rng, prng;
             if (t == t_ahead && p == bid) {  // wave-uniform: stepped ahead before the tables
                 rng = rng_ahead;
                 if constexpr (PRE != 0) prng = prng_ahead;
@@ -1347,7 +1347,7 @@ struct BrownianTerms {
     int count;
 };
 
-// Burst variant (latents of a multiple of kTileElems elements, one seed): z(node, .) is a tile-keyed xoshiro stream with
+// Burst variant (latents of a multiple of kTileElems elements, one seed): z(node, .) is a tile-keyed random stream (common.h, Mwc) with
 // stream id `node` (the Gaussian fill's generator, here in sub-tiles of 4 steps x 64 lanes x 4 = 1024 elements), so the
 // Philox seeding is paid once per (node, sub-tile, lane) for 16 values instead of once per 4 values.  A wave owns a
 // sub-tile and keeps its 4 x 4 partial sums in registers over the nodes.
@@ -1378,7 +1378,7 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
     const Accum pfold{fold.y, pre.ya, pre.f};
     const Divider pdiv(PRE == 2 ? pre.div_fac : 1.0f);
     for (int64_t T = wave; T < tiles / SUB; T += nwaves) {
-        Xoshiro prng;
+        TileRng prng;
         const float4* trow = nullptr;
         if constexpr (PRE != 0) {
             prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)(elem_offset / kTileElems + T), lane);
@@ -1405,7 +1405,7 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
                 acc[it][0] = v.x; acc[it][1] = v.y; acc[it][2] = v.z; acc[it][3] = v.w;
             }
             for (int k = 0; k < terms.count; ++k) {
-                Xoshiro rng = rng_stream(seed, terms.node[k], (uint64_t)(first + t), lane);
+                TileRng rng = rng_stream(seed, terms.node[k], (uint64_t)(first + t), lane);
                 const float c = terms.coef[k];
 #pragma unroll
                 for (int it = 0; it < kBrownIters; ++it) {
