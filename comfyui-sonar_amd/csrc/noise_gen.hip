@@ -655,10 +655,13 @@ __global__ void __launch_bounds__(kBlock) perlin_ahead_kernel(PerlinAhead a) {
         return;
     }
     // the final pass of this call and the statistics pass of the next one are independent: separate blocks, so that at the launch-bound
-    // sizes a wave runs ONE tile's chain, not two back to back
+    // sizes a wave runs ONE tile's chain, not two back to back -- and INTERLEAVED block by block (round 5), so that at the bandwidth-bound
+    // sizes the two kinds are resident side by side: the final pass waits for its stores (a 134 MB tensor: 29 us, 21 of them the
+    // write itself) with the vector ALUs idle, the statistics pass is nothing but vector ALU work (13 us as a launch of its own)
     const int nb = a.tile_blocks;
-    const bool ahead = (int)blockIdx.x >= a.lat_blocks + nb;
-    const int bid = (int)blockIdx.x - a.lat_blocks - (ahead ? nb : 0);
+    const int blk = (int)blockIdx.x - a.lat_blocks;
+    const bool ahead = a.terms_next != nullptr && (blk & 1);
+    const int bid = a.terms_next != nullptr ? blk >> 1 : blk;
     const Divider divide(a.div_fac);
     const int64_t wave = ((int64_t)bid * kBlock + threadIdx.x) >> 6, nwaves = ((int64_t)nb * kBlock) >> 6;
     double s = 0.0, q = 0.0;
@@ -1745,11 +1748,12 @@ extern "C" int sonar_perlin_noise_f32(const float* terms, float* out, int64_t B,
 }
 
 extern "C" int sonar_perlin_noise_ahead_ok(int64_t B, int64_t chw, int64_t elem_offset) {
-    // the fast, tile-aligned shape of the device-drawn call (whole RNG tiles per latent, shards on tile boundaries), and few enough tiles
-    // that the launches are latency-bound: beyond that the statistics pass of its own costs what it costs inside the final pass
+    // the fast, tile-aligned shape of the device-drawn call (whole RNG tiles per latent, shards on tile boundaries).  (Up to round 4 also
+    // "at most 4096 tiles": the launch-bound sizes only.  At 512 SDXL latents the statistics of the next call ride under the final pass's
+    // stores: 41.9 -> see profiles/r05_fill_rates.txt.)
     const int64_t n = B * chw;
     return (n > 0 && chw >= 256 && chw < (1LL << 31) && chw % kTileElems == 0 && elem_offset >= 0 && elem_offset % kTileElems == 0 &&
-            n / kTileElems <= 4096) ? 1 : 0;
+            n / kTileElems <= (1 << 20)) ? 1 : 0;
 }
 
 extern "C" int sonar_perlin_noise_ahead_f32(const float* terms, float* out, int64_t B, int64_t chw, float div_fac, uint64_t seed, uint64_t stream_id,
@@ -1764,7 +1768,7 @@ extern "C" int sonar_perlin_noise_ahead_f32(const float* terms, float* out, int6
                                    C * H * W == chw && blend_mode >= 0 && blend_mode <= 2 && lattice_out != terms && lattice_out != terms_next),
                   SONAR_ERR_ARG, "%s: bad lattice request", what);
     SONAR_REQUIRE(sonar_perlin_noise_ahead_ok(B, chw, elem_offset) && aligned16(out) && aligned16(terms) && (!terms_next || aligned16(terms_next)),
-                  SONAR_ERR_UNSUPPORTED, "%s: whole 4096-element tiles per latent, 16-byte aligned tensors, at most 4096 tiles", what);
+                  SONAR_ERR_UNSUPPORTED, "%s: whole 4096-element tiles per latent, 16-byte aligned tensors", what);
     if (B == 0) return SONAR_OK;
     hipStream_t st = (hipStream_t)stream;
     if (!have_stats) {

@@ -1,0 +1,13 @@
+#!/bin/bash
+# gpurun_out/r05 (scratch/prof_r05.sh) + gpurun_out/r05_sizes.txt (scratch/size_sweep.py) -> profiles/r05_*
+cd "$(dirname "$0")/.."
+O=gpurun_out/r05
+python tools/make_traffic_json.py $O/traffic_raw.json > profiles/r05_traffic.json
+cp $O/bench.json profiles/r05_bench_line.json
+cp $O/kernel_trace.md profiles/r05_bench_kernel_trace.md
+cp $O/pmc_sq_a.txt profiles/r05_pmc_issue_a.txt
+cp $O/pmc_sq_b.txt profiles/r05_pmc_issue_b.txt
+[ -f gpurun_out/r05_sizes.txt ] && cp gpurun_out/r05_sizes.txt profiles/r05_sizes.txt
+{ grep -v amdgpu $O/pair_time.txt; echo "final pass alone, then a sampler's steady state (MODE=ahead):"; grep -v amdgpu $O/pipe_time.txt; } > profiles/r05_pair_time.txt
+{ echo "== final pass alone (sonar_power_irfft2_f32, z = NULL) =="; grep -v amdgpu $O/pipe_phases_plain.txt
+  echo "== with the next call's statistics (sonar_power_noise_ahead_f32; the trace build's stamps cost ~10 % of the kernel) =="; grep -v amdgpu $O/pipe_phases_ahead.txt; } > profiles/r05_power_phases.txt

@@ -548,7 +548,8 @@ def test_a_planned_perlin_call_is_one_launch(api, shape):
             rc = lib.sonar_perlin_noise_ahead_f32(t1.data_ptr(), out1.data_ptr(), b_, chw, 2.0, 9, 102, 0, 0.9, 2.5, (p1 if with_next else p2).data_ptr(),
                                                   with_next, 104, None, None, None, 0, 0, 0, 0, 0, 0, st)
             assert rc == 0 and torch.equal(out1, want1)
-    assert lib.sonar_perlin_noise_ahead_ok(b_, chw + 4, 0) == 0 and lib.sonar_perlin_noise_ahead_ok(8192, 65536, 0) == 0
+    # (round 5: no upper size limit any more -- at 512 latents the next call's statistics ride under the final pass's stores)
+    assert lib.sonar_perlin_noise_ahead_ok(b_, chw + 4, 0) == 0 and lib.sonar_perlin_noise_ahead_ok(8192, 65536, 0) == 1
 
 
 # ------------------------------------------------------------------------------------------------ planes beyond LDS, generated (kind 4)
