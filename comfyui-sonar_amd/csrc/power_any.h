@@ -46,12 +46,16 @@ __global__ void __launch_bounds__(kFftThreads) power_spectrum_any_kernel(float* 
 // size runs the run-time-size kernel.
 int launch_power_bucket(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
                         uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st, Ahead ah);
+int launch_power_any_all(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
+                         uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st, Ahead ah);  // power_any_all.hip
 static int launch_power_any(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
                             uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st,
                             Ahead ah = Ahead()) {
     if (what != 2) {
         const int rc = launch_power_bucket(what, z, filter, out, planes, H, W, seed, stream_id, plane_offset, group, partials, na, st, ah);
         if (rc != kNotABucket) return rc;
+        if (any_needs_all(H, W))
+            return launch_power_any_all(what, z, filter, out, planes, H, W, seed, stream_id, plane_offset, group, partials, na, st, ah);
     }
     return launch_power_any_t<0, 0, 0, 0>(what, z, filter, out, planes, H, W, seed, stream_id, plane_offset, group, partials, na, st, ah);
 }

@@ -636,7 +636,9 @@ __device__ __forceinline__ void power_stats_any_body(const float* __restrict__ f
 
 // SRC as in power_irfft2_kernel: 0 = spectrum supplied, 1 = drawn on device, 2 = real plane in (forward, x filter, inverse)
 // HN1 x HN2 = H and MN1 x MN2 = W / 2: the factor pairs when the plane size is known at compile time (0: taken from `pl` at run time)
-template <int NT, int SRC, bool STATS, bool NORM, int HN1 = 0, int HN2 = 0, int MN1 = 0, int MN2 = 0>
+// SET: the codelets of the run-time switches (HN1 = 0): kSetSmall, or kSetAll for the plane sizes that need a factor of 13 .. 19 and are no
+// bucket (that instantiation spills 5-48 registers; direct sums instead cost those sizes 25-60 % more time than the spills do)
+template <int NT, int SRC, bool STATS, bool NORM, int HN1 = 0, int HN2 = 0, int MN1 = 0, int MN2 = 0, int SET = kSetSmall>
 __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __restrict__ z, const float* __restrict__ filter,
                                                                        float* out, int64_t planes, AnyPlan pl, uint64_t seed,
                                                                        uint64_t stream_id, int64_t plane_offset, int group, int split,
@@ -753,7 +755,7 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
                     }
                 }
                 __syncthreads();
-                line_dft<NT, true, MN1, MN2>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, ptid);
+                line_dft<NT, true, MN1, MN2, SET>(A, twW, W, 2, pl.mn1, pl.mn2, H, 1, S, ptid);
                 // X[k] = E + w^k O, X[M-k] = conj(E - w^k O), E = (C[k] + conj C[M-k]) / 2, O = (C[k] - conj C[M-k]) / 2i, w = e^{-2 pi i / W}
                 const int FQ = M / 2 + 1, fdr = NT / FQ, fdk = NT - fdr * FQ;
                 int fr = tid / FQ, fk = tid - fr * FQ;
@@ -782,7 +784,7 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
                     }
                 }
                 __syncthreads();
-                line_dft<NT, true, HN1, HN2>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, ptid);
+                line_dft<NT, true, HN1, HN2, SET>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, ptid);
                 for (int j = tid; j < NC; j += NT) {
                     const float f = filter[j];
                     c32 v = A[j];
@@ -793,9 +795,9 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
             }
             __syncthreads();
             // ---- inverse columns: every one of the W/2 + 1 columns, length H
-            line_dft<NT, false, HN1, HN2>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, ptid);
+            line_dft<NT, false, HN1, HN2, SET>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, ptid);
             // ---- rows: c2r pre-twiddle + length-M complex inverse DFT; value m of a row is (x[2m], x[2m+1])
-            c2r_rows<NT, MN1, MN2>(A, twW, W, pl.mn1, pl.mn2, H, M, S, pl.c2r_fuse, ptid);
+            c2r_rows<NT, MN1, MN2, SET>(A, twW, W, pl.mn1, pl.mn2, H, M, S, pl.c2r_fuse, ptid);
             float* const oplane = out + plane * (int64_t)H * W;
             float ps = 0.0f, pq = 0.0f;
             if (SONAR_ANY_STORE16 && (M & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {  // uniform
@@ -868,13 +870,21 @@ static inline bool any_ahead_ok(int64_t planes, int64_t H, int64_t W, int group)
     return (split ? planes : planes / group) <= 256;
 }
 
+// does a plane size (no bucket) need a codelet outside kSetSmall?  Then its kernel is the kSetAll instantiation (power_any_all.hip).
+static inline bool any_needs_all(int64_t H, int64_t W) {
+    int a, b, c2, d;
+    best_split((int)H, a, b, kSetAll);
+    best_split((int)W / 2, c2, d, kSetAll);
+    auto big = [](int n) { return n > 1 && radix_in_set(n, kSetAll) && !radix_in_set(n, kSetSmall); };
+    return big(a) || big(b) || big(c2) || big(d);
+}
 // the kernels of one call (what: as launch_power), with the plane kernel's factor pairs as template arguments (0: run time)
 constexpr int kNotABucket = -1000;
 __global__ void __launch_bounds__(kFftThreads) power_stats_any_kernel(const float* __restrict__ filter, int64_t planes, AnyPlan pl, uint64_t seed,
                                                                       uint64_t stream_id, int64_t plane_offset, int group, int split, double* partials);
 __global__ void __launch_bounds__(kFftThreads) power_spectrum_any_kernel(float* zout, int64_t planes, AnyPlan pl, uint64_t seed, uint64_t stream_id,
                                                                          int64_t plane_offset, int group, int split);
-template <int HN1, int HN2, int MN1, int MN2>
+template <int HN1, int HN2, int MN1, int MN2, int SET = kSetSmall>
 static int launch_power_any_t(int what, const float* z, const float* filter, float* out, int64_t planes, int64_t H, int64_t W, uint64_t seed,
                               uint64_t stream_id, int64_t plane_offset, int group, double* partials, NormArgs na, hipStream_t st, Ahead ah) {
     AnyPlan pl;
@@ -886,8 +896,8 @@ static int launch_power_any_t(int what, const float* z, const float* filter, flo
         if (HN1 * HN2 != pl.H || MN1 * MN2 != pl.M) return kNotABucket;
         pl.hn1 = HN1, pl.hn2 = HN2, pl.mn1 = MN1, pl.mn2 = MN2;
     } else {
-        best_split(pl.H, pl.hn1, pl.hn2, kSetSmall);
-        best_split(pl.M, pl.mn1, pl.mn2, kSetSmall);
+        best_split(pl.H, pl.hn1, pl.hn2, SET);
+        best_split(pl.M, pl.mn1, pl.mn2, SET);
     }
     const size_t lds = ((size_t)H * pl.S + H + W) * sizeof(c32);
     {
@@ -895,7 +905,7 @@ static int launch_power_any_t(int what, const float* z, const float* filter, flo
         // 143 us, 144 x 112 (2 x 511) 142 -> 139; 96 x 96 (2 x 288) 137 -> 140, 192 x 192 and 160 x 160 (three batches) +6 %
         const int nt = 2 * (lds + 1024) <= 160 * 1024 ? kAnySlots : kAnyThreads;
         const int families = pl.H * pl.mn2, batches = (pl.H + std::max(1, nt / pl.mn2) - 1) / std::max(1, nt / pl.mn2);
-        pl.c2r_fuse = (HN1 > 0 || codelet_len(pl.mn1, kSetSmall)) && pl.mn1 > 1 && batches <= 2 && 5 * families >= 4 * batches * nt ? 1 : 0;
+        pl.c2r_fuse = (HN1 > 0 || codelet_len(pl.mn1, SET)) && pl.mn1 > 1 && batches <= 2 && 5 * families >= 4 * batches * nt ? 1 : 0;
     }
     const size_t lds_stats = (size_t)4 * H * sizeof(c32);
     const int split = group > 1 && planes / group < 512 ? 1 : 0;
@@ -906,7 +916,7 @@ static int launch_power_any_t(int what, const float* z, const float* filter, flo
     const int g = (int)std::min<int64_t>(std::min<int64_t>(units, 256 * per_cu), kNPart);
 #define SONAR_PA_NT(NT, G, ST, NM, PART)                                                                                                   \
     do {                                                                                                                                   \
-        auto kern = power_irfft2_any_kernel<NT, G, ST, NM, HN1, HN2, MN1, MN2>;                                                                                \
+        auto kern = power_irfft2_any_kernel<NT, G, ST, NM, HN1, HN2, MN1, MN2, SET>;                                                                                \
         lds_attr(reinterpret_cast<const void*>(kern), (int)kAnyLdsLimit);                                                                 \
         hipLaunchKernelGGL(kern, dim3(g), dim3(NT), lds, st, z, filter, out, planes, pl, seed, stream_id, plane_offset, group, split,      \
                            PART, na, StatsAhead());                                                                                        \
@@ -930,7 +940,7 @@ static int launch_power_any_t(int what, const float* z, const float* filter, flo
             sa.partials = ah.next;
             sa.stream_id = ah.next_stream;
             sa.main_blocks = g;
-            auto kern = power_irfft2_any_kernel<kAnySlots, 1, false, true, HN1, HN2, MN1, MN2>;
+            auto kern = power_irfft2_any_kernel<kAnySlots, 1, false, true, HN1, HN2, MN1, MN2, SET>;
             lds_attr(reinterpret_cast<const void*>(kern), (int)kAnyLdsLimit);
             hipLaunchKernelGGL(kern, dim3(g + (int)std::min<int64_t>(units, kNPart)), dim3(kAnySlots), lds, st, z, filter, out, planes, pl, seed, stream_id,
                                plane_offset, group, split, (double*)nullptr, na, sa);

@@ -30,10 +30,11 @@ def test_library_builds_and_exports_every_header_symbol(pkg):
     assert lib.sonar_last_error() is not None
 
 
-def test_no_kernel_of_the_library_uses_scratch_memory(pkg):
-    """Round 5: a kernel with a private (scratch) segment -- spilled registers or a stack -- costs the PROCESS that dispatches it a 50-90 ms
-    stall of its queue a moment later, when the HSA runtime sizes the scratch (scratch/stall_fresh.py: 13 of 16 fresh processes that ran a
-    spilling general-size kernel, 0 of 8 that did not).  The built library's code objects say what every kernel needs."""
+def test_only_the_catch_all_plane_kernel_spills(pkg):
+    """Round 5: no kernel of the library spills registers / uses a scratch segment, with ONE named exception -- the general-size plane kernel
+    instantiated with every codelet length in its run-time switches (power_any_all.hip: plane sizes with a factor of 13 .. 19 that are no
+    SDXL bucket; direct sums instead would cost them 25-60 % more time than the spills).  Round 4 had 37 spilling kernels, the ones serving
+    every non-square SDXL latent among them (62 vector registers).  The built library's code objects say what every kernel needs."""
     import __graft_entry__
     import importlib.util
 
@@ -43,10 +44,12 @@ def test_no_kernel_of_the_library_uses_scratch_memory(pkg):
     spec.loader.exec_module(mod)
     rows = mod.kernels(os.path.join(ROOT, "comfyui-sonar_amd", "libsonar_hip.so"))
     assert len(rows) > 900, "the library's code objects were not found"
-    bad = [f"{r['pretty']}: {r['scratch']} B ({r['spill_v']} vector registers spilled)" for r in rows if r["scratch"] > 0]
+    catch_all = re.compile(r"power_irfft2_any_kernel<\d+, \d, (true|false), (true|false), 0, 0, 0, 0, 2>")
+    bad = [f"{r['pretty']}: {r['scratch']} B ({r['spill_v']} vector registers spilled)" for r in rows
+           if r["scratch"] > 0 and not catch_all.search(r["pretty"])]
     assert not bad, "kernels with a scratch segment:\n" + "\n".join(bad)
     # the SDXL buckets' general-size kernels exist with compile-time factor pairs (104 x 152: 13 x 8 rows, 19 x 4 half-columns)
-    assert any("power_irfft2_any_kernel<512, 1, false, true, 13, 8, 19, 4>" in r["pretty"] for r in rows)
+    assert any("power_irfft2_any_kernel<512, 1, false, true, 13, 8, 19, 4, 0>" in r["pretty"] for r in rows)
 
 
 def test_product_never_touches_the_oracle():
