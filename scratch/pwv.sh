@@ -12,7 +12,7 @@ BASE="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-f
 build_one() {
   name=$1; flags=$2
   (cd $SRC && hipcc $BASE $flags -c power_fft.hip -o $ROOT/scratch/bin/pwvar/power_fft_$name.o)
-  objs=$(ls comfyui-sonar_amd/build/*.o | grep -v "power_fft.o\|power_buckets_")
+  objs=$(ls comfyui-sonar_amd/build/*.o | grep -v "power_fft.o\|power_buckets_\|power_any_all")
   hipcc -shared -fPIC --offload-arch=gfx950 -o scratch/bin/pwvar/lib_$name.so scratch/bin/pwvar/power_fft_$name.o $objs
   rm -f scratch/bin/pwvar/power_fft_$name.o
   echo built $name
