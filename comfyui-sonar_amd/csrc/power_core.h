@@ -391,10 +391,19 @@ template <int W>
 struct RowATw {  // row pass a's wave-uniform twiddles (scalar registers), see pipe_row_a
     c32 g[8], p[8];
 };
-template <int H, int W, int NW, bool INPLACE = false>
+// Layout of a row between / around the row passes.  kRowsTwoBuffers: pass a reads spectrum column k at k and leaves element (k1, n2) at
+// 8 n2 + k1 in the other buffer (the pipelined kernel).  kRowsInPlace: the same in ONE buffer, a workgroup barrier between pass a's loads
+// and stores (the phase-serial kernel's 128-row path).  kRowsSwizzled (the spectral filter, round 5): spectrum column k = 8 n1 + n2 lives
+// at PlaneCfg::rpos(n1, n2) through every column pass and pass a leaves element (k1, n2) at rpos(k1, n2) -- a thread's reads and writes
+// are the same sixteen places, no barrier inside the pass.
+enum RowLayout { kRowsTwoBuffers = 0, kRowsInPlace = 1, kRowsSwizzled = 2 };
+template <int H, int W, int NW, int LAYOUT = kRowsTwoBuffers>
 __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane);
-template <int H, int W, int NW, bool STATS, bool NORM>
+template <int H, int W, int NW, bool STATS, bool NORM, int LAYOUT = kRowsTwoBuffers>
 __device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, int lane, float scale, float nm, float nc, double& s, double& q);
+#ifndef SONAR_SF_V2
+#define SONAR_SF_V2 1  // 0: the round-4 forward half (separate split / unpack / fix-up phases: 12 barriers per plane instead of 7)
+#endif
 
 // Look-ahead of the phase-serial generate kernel (launch-bound batch sizes: every workgroup of the launch is resident at once): the
 // workgroups from `main_blocks` on compute the statistics of the NEXT call (stream `stream_id`, same seed / shape / filter) into

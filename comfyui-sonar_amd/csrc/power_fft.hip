@@ -348,7 +348,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (plane_min_waves<H, W
             // front, row pass a leaves element (k1, n2) at column 8 n2 + k1 for the 16-byte stores of pass b
             if constexpr (!(SONAR_PW_SKIP & 2)) pipe_col_b<H, W, 8>(A, A, wv, lane);  // in place: an item reads and writes the same 8 rows of its column
             __syncthreads();
-            if constexpr (!(SONAR_PW_SKIP & 4)) pipe_row_a<H, W, 8, true>(A, A, wv, lane);
+            if constexpr (!(SONAR_PW_SKIP & 4)) pipe_row_a<H, W, 8, kRowsInPlace>(A, A, wv, lane);
             __syncthreads();
             } else {
             // ------------------------------------------------------------ columns, pass b: radix 8, rows 8 k1 .. 8 k1 + 7
@@ -711,9 +711,20 @@ __device__ __forceinline__ c32 cmul_conj(c32 a, c32 b) {  // a * conj(b), packed
     return cc(__builtin_elementwise_fma(A.yx, v2f{B.y, -B.y}, A * B.xx));
 }
 
-template <int H, int W, int NW, bool INPLACE>
+template <int H, int W, int NW, int LAYOUT>
 __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane) {
     using C = PlaneCfg<H, W>;
+    constexpr bool INPLACE = LAYOUT == kRowsInPlace, SWZ = LAYOUT == kRowsSwizzled;
+    // column of spectrum element 8 n1 + res on the way in, of element (k1, res) on the way out (`res` is wave-uniform, not a constant)
+    // (swizzled: the residue's offset goes through an opaque scalar per pass, see sf_row_a_split)
+    auto swz_base = [](int res) {
+        int b = (res & 1) + 16 * (res >> 1);
+        if constexpr (SWZ) asm volatile("" : "+s"(b));
+        return b;
+    };
+    auto cin = [&](int n1, int res, int base) { return SWZ ? 2 * n1 + base : 8 * n1 + res; };
+    auto cout = [&](int k1, int res, int base) { return SWZ ? 2 * k1 + base : 8 * res + k1; };
+    static_assert(!SWZ || (C::kRowSwizzle && C::rpos(3, 5) == 2 * 3 + 1 + 16 * 2), "cin / cout restate PlaneCfg::rpos");
     const RowATw<W> tw = row_a_twiddles<W>(__builtin_amdgcn_readfirstlane(w));
     constexpr int M = C::M, S = C::S, RN1 = C::RN1, RN2 = C::RN2;
     static_assert(H == 128 && RN1 == 8 && RN2 == 8 && NW == 8, "three residue pairs x two row halves + two self-mirrored residues x all rows");
@@ -726,12 +737,13 @@ __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane
     };
     if (w < 6) {  // uniform
         const int a = 1 + (w >> 1), b = 8 - a, r = lane + 64 * (w & 1);
+        const int ba = swz_base(a), bb = swz_base(b);
         const c32* row = Y + r * S;
         c32 xa[8], xb[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
-            xa[n1] = row[8 * n1 + a];
-            xb[n1] = row[M - 8 * n1 - a];
+            xa[n1] = row[cin(n1, a, ba)];
+            xb[n1] = row[cin(7 - n1, b, bb)];  // column M - (8 n1 + a)
         }
         __builtin_amdgcn_sched_barrier(0);
         c32 ga[8], tb[8];
@@ -750,18 +762,18 @@ __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane
         if constexpr (INPLACE) __syncthreads();  // every wave holds its results: all operands of all rows have been read
         c32* orow = X + r * S;
 #pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) orow[8 * a + k1] = ga[k1];
+        for (int k1 = 0; k1 < 8; ++k1) orow[cout(k1, a, ba)] = ga[k1];
 #pragma unroll
-        for (int k1 = 0; k1 < 8; ++k1) orow[8 * b + k1] = tb[k1];
+        for (int k1 = 0; k1 < 8; ++k1) orow[cout(k1, b, bb)] = tb[k1];
     } else {
         const bool zero = w == 6;  // uniform: residue 0 (its first element is the packed column: Re = column 0, Im = column M) or residue 4
-        const int a = zero ? 0 : 4;
+        const int a = zero ? 0 : 4, ba = swz_base(a);
         c32 x[2][8];
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const c32* row = Y + (lane + 64 * it) * S;
 #pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) x[it][n1] = row[8 * n1 + a];
+            for (int n1 = 0; n1 < 8; ++n1) x[it][n1] = row[cin(n1, a, ba)];
         }
         __builtin_amdgcn_sched_barrier(0);
         c32 g[2][8];
@@ -801,7 +813,7 @@ __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
 #pragma unroll
-            for (int k1 = 0; k1 < 8; ++k1) X[(lane + 64 * it) * S + 8 * a + k1] = g[it][k1];
+            for (int k1 = 0; k1 < 8; ++k1) X[(lane + 64 * it) * S + cout(k1, a, ba)] = g[it][k1];
         }
     }
 }
@@ -812,13 +824,16 @@ __device__ __forceinline__ void pipe_row_a(const c32* Y, c32* X, int w, int lane
 // 8 n2 + k1, so the thread's two inputs of an n2 sit side by side (one ds_read2_b64).  Lane -> row: a read2's access groups are 16
 // consecutive lanes over 32 banks; they hold rows r0 + {0, 1, 8, 9} x a < 4, whose 2-dword windows start at 2 r + 4 a (mod 32) =
 // {0, 2, 16, 18} + 4 a with the odd row stride -- all different.  NW = 16 (last plane): the second eight waves take k1 = 2a + 1.
-template <int H, int W, int NW, bool STATS, bool NORM>
+// kRowsSwizzled: the inputs sit at rpos(k1, n2) = 2 k1 + n2 % 2 + 16 (n2 / 2) -- the thread's two inputs of an n2 are two places apart
+// (still one ds_read2_b64), windows start at 2 r + 8 a (mod 32): the 16 lanes of an access group take rows r0 + {0, 1, 2, 3} instead.
+template <int H, int W, int NW, bool STATS, bool NORM, int LAYOUT>
 __device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, int lane, float scale, float nm, float nc, double& s, double& q) {
     using C = PlaneCfg<H, W>;
     constexpr int S = C::S, RN1 = C::RN1, RN2 = C::RN2, CN1 = H / 8, CN2 = 8, NK = NW == 8 ? 2 : 1;
+    constexpr bool SWZ = LAYOUT == kRowsSwizzled;
     static_assert(H == 128 && RN1 == 8 && RN2 == 8 && (NW == 8 || NW == 16), "16 rows x 4 residue pairs per wave");
     const int a = lane & 3, w8 = w & 7, k0 = 2 * a + (NW == 8 ? 0 : w >> 3);
-    const int r = 16 * w8 + 2 * (lane >> 4) + 8 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
+    const int r = SWZ ? 16 * w8 + (lane >> 2) : 16 * w8 + 2 * (lane >> 4) + 8 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
     const int y = (r / CN2) + CN1 * (r % CN2);
     c32 u[NK][RN2];
 #pragma unroll
@@ -826,7 +841,7 @@ __device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, i
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
             if constexpr (SONAR_PIPE_SKIP & 4) u[i][n2] = make_float2((float)(lane + n2), 1.0f + i);
-            else u[i][n2] = X[r * S + RN1 * n2 + k0 + i];
+            else u[i][n2] = X[r * S + (SWZ ? C::rpos(k0 + i, n2) : RN1 * n2 + k0 + i)];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -866,6 +881,314 @@ __device__ __forceinline__ void pipe_row_b(const c32* X, float* oplane, int w, i
         s += (double)ps;
         q += (double)pq;
     }
+}
+
+// ---- the spectral filter's forward half at 128 x 128 (round 5) --------------------------------------------------------------------
+// Mirror images of the inverse passes above.  All values carry a factor 2 (the r2c split's halves are left to the final scale).
+// rows, pass a' + r2c split: the radix-8 over k1 of residues a and 8 - a of one row, then
+//     2 X[k] = s - i d conj(g),  2 X[M-k] = conj(s + i d conj(g)),   s = C[k] + conj C[M-k],  d = C[k] - conj C[M-k],  g = e^{2 pi i k / W}
+// on the pair (k, M - k) = (8 n1 + a, 8 (7 - n1) + 8 - a) the thread holds -- round 4 ran the split as a pass of its own (a barrier, an LDS
+// round trip) behind a pass a' that moved from swizzled to natural columns through a barrier of its own.  In place at rpos(., residue).
+template <int H, int W>
+__device__ __forceinline__ void sf_row_a_split(c32* A, int w, int lane) {
+    using C = PlaneCfg<H, W>;
+    constexpr int S = C::S;
+    static_assert(H == 128 && W == 128 && C::RN1 == 8 && C::RN2 == 8 && C::kRowSwizzle, "three residue pairs x two row halves + two self-mirrored residues");
+    const RowATw<W> tw = row_a_twiddles<W>(__builtin_amdgcn_readfirstlane(w));
+    // PlaneCfg::rpos with a wave-uniform residue; its offset is recomputed per pass (hoisted out of the plane loop, the sixteen column
+    // offsets of every pass become long-lived scalar registers and spill into vector-register lanes)
+    auto res_base = [](int res) {
+        int b = (res & 1) + 16 * (res >> 1);
+        asm volatile("" : "+s"(b));
+        return b;
+    };
+    auto split = [&](c32 ck, c32 cm, c32 g, c32& xk, c32& xm) {
+        const c32 cj = cconj(cm);
+        const c32 s = cadd(ck, cj), d = cmul_conj(csub(ck, cj), g);
+        xk = csub_i(s, d);
+        xm = cc(v2f{s.x, -s.y} - vv(d).yx);
+    };
+    if (w < 6) {  // uniform
+        const int a = 1 + (w >> 1), b = 8 - a;
+        c32* const row = A + (lane + 64 * (w & 1)) * S;
+        c32* const rowa = row + res_base(a);
+        c32* const rowb = row + res_base(b);
+        c32 ua[8], ub[8];
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) {
+            ua[k1] = rowa[2 * k1];
+            ub[k1] = rowb[2 * k1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fdft<8>(ua);
+        fdft<8>(ub);
+        c32 xa[8], xb[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) split(ua[n1], ub[7 - n1], tw.g[n1], xa[n1], xb[7 - n1]);
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) rowa[2 * n1] = xa[n1];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) rowb[2 * n1] = xb[n1];
+    } else {
+        const bool zero = w == 6;  // uniform: residue 0 (k = 0 becomes the packed pair X[0] + i X[M], both real; k = M / 2 mirrors onto itself) or 4
+        c32* const row0 = A + lane * S + res_base(zero ? 0 : 4);
+        c32 u[2][8];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) u[it][k1] = row0[64 * it * S + 2 * k1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            fdft<8>(u[it]);
+            c32 x[8];
+            if (zero) {
+                const c32 c0 = u[it][0], c4 = u[it][4];
+                x[0] = make_float2(2.0f * (c0.x + c0.y), 2.0f * (c0.x - c0.y));
+                x[4] = make_float2(2.0f * c4.x, -2.0f * c4.y);
+#pragma unroll
+                for (int n1 = 1; n1 < 4; ++n1) split(u[it][n1], u[it][8 - n1], tw.g[n1], x[n1], x[8 - n1]);
+            } else {
+#pragma unroll
+                for (int n1 = 0; n1 < 4; ++n1) split(u[it][n1], u[it][7 - n1], tw.g[n1], x[n1], x[7 - n1]);
+            }
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) row0[64 * it * S + 2 * n1] = x[n1];
+        }
+    }
+}
+
+// columns, pass b': forward radix 8 over rows 8 k1 .. 8 k1 + 7 of column `lane` (k1 = w, w + 8), twiddle e^{-2 pi i n2 k1 / H}; in place
+template <int H, int W>
+__device__ __forceinline__ void sf_col_b(c32* A, int w, int lane) {
+    constexpr int S = PlaneCfg<H, W>::S, ITEMS = H / 64;
+    c32 u[ITEMS][8];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) u[it][k2] = A[(8 * (w + 8 * it) + k2) * S + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        int k1 = __builtin_amdgcn_readfirstlane(w + 8 * it);
+        asm volatile("" : "+s"(k1));  // the twiddles are fetched per pass (see row_a_twiddles)
+        const c32* const t = c_colb_tw128[k1];
+        fdft<8>(u[it]);
+#pragma unroll
+        for (int n2 = 1; n2 < 8; ++n2) u[it][n2] = cmul_conj(u[it][n2], t[n2]);
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) A[(8 * k1 + n2) * S + lane] = u[it][n2];
+    }
+}
+
+// columns: forward pass a', x filter, inverse pass a -- the same sixteen rows 8 j + w of column `lane` go in and come out, so the
+// spectrum itself only ever exists in registers.  (Round 3 measured this fusion as a dead end: it spilled.  What made it fit: offsets
+// and twiddles that are made per pass instead of living across the plane loop, see row_a_twiddles.)
+// Column 0 is the packed pair: P = DFT(X0 + i XM) needs its mirror P[-ky], which another wave holds -- lane 0 leaves P in `xch`,
+// and after ONE workgroup barrier lanes 0-15 build what the inverse wants from it, one ky each,
+//     Q[ky] = sym(Z0 f0)[ky] + i sym(ZM fM)[ky] = a1 P[ky] + a2 conj P[-ky],
+//     a1, a2 = (g0 +- gM) / 2,  g.[ky] = (f.[ky] + f.[-ky]) / 2      (Z0, ZM are spectra of real columns: Hermitian already)
+// and hand the sixteen values back to lane 0 through LDS (in order within a wave: no barrier) -- round 4 unpacked Z0 / ZM, filtered
+// them and packed them again in three phases.  `xch`: [0] the (a1, a2) table, made once per workgroup, [1] P, [2] Q; each indexed
+// [16 w + j] for ky = 8 j + w.  `f`: the thread's sixteen filter values, requested by the caller a pass ahead.
+template <int H>
+struct SfExchange {
+    c32 wgt[H], p[H], q[H];
+};
+template <int H, int W>
+__device__ __forceinline__ void sf_filter_values(const float* __restrict__ filter, int w, int lane, float (&f)[H / 8]) {
+    constexpr int Wh = W / 2 + 1;
+    // this lane's spectrum column: the inverse of rpos.  The values are the same for every plane: their loads (L2 hits) stay in the plane
+    // loop behind an opaque index -- kept across it they would hold sixteen registers the row passes need.
+    int kx = 8 * ((lane & 15) >> 1) + 2 * (lane >> 4) + (lane & 1);
+    asm volatile("" : "+v"(kx));
+    const float* const fcol = filter + w * Wh + kx;
+#pragma unroll
+    for (int n1 = 0; n1 < H / 8; ++n1) f[n1] = fcol[8 * n1 * Wh];
+}
+template <int H, int W>
+__device__ __forceinline__ void sf_col_a_filter_col_a(c32* A, SfExchange<H>* xch, const float (&f)[H / 8], int w, int lane, int pidx) {
+    using C = PlaneCfg<H, W>;
+    constexpr int S = C::S, N = H / 8;
+    static_assert(N == 16, "radix 16");
+    [[maybe_unused]] const int tid = w * 64 + lane;  // (trace builds' stamps)
+    c32 v[N];
+#pragma unroll
+    for (int k1 = 0; k1 < N; ++k1) v[k1] = A[(8 * k1 + w) * S + lane];
+    fdft<N>(v);
+    SONAR_STAMP(7);
+    int wo = __builtin_amdgcn_readfirstlane(w);
+    asm volatile("" : "+s"(wo));  // the exchange's offsets and the twiddles are made / fetched per pass (see row_a_twiddles)
+    if (lane == 0) {
+        float4* const dst = reinterpret_cast<float4*>(xch->p + 16 * wo);
+#pragma unroll
+        for (int n1 = 0; n1 < N; n1 += 2) dst[n1 / 2] = make_float4(v[n1].x, v[n1].y, v[n1 + 1].x, v[n1 + 1].y);
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < N; ++n1) v[n1] = cscale(v[n1], f[n1]);  // (lane 0's are replaced below)
+    __syncthreads();
+    SONAR_STAMP(8);
+    if (lane < 16) {
+        const int mirror = wo == 0 ? ((16 - lane) & 15) : 16 * (8 - wo) + 15 - lane;  // ky -> H - ky: residue 8 - w, j -> 15 - j (16 - j for residue 0)
+        const c32 p = xch->p[16 * wo + lane], pn = xch->p[mirror], a = xch->wgt[16 * wo + lane];
+        xch->q[16 * wo + lane] = make_float2(__builtin_fmaf(a.x, p.x, a.y * pn.x), __builtin_fmaf(a.x, p.y, -(a.y * pn.y)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+        const float4* const src = reinterpret_cast<const float4*>(xch->q + 16 * wo);
+#pragma unroll
+        for (int n1 = 0; n1 < N; n1 += 2) {
+            const float4 t = src[n1 / 2];
+            v[n1] = make_float2(t.x, t.y);
+            v[n1 + 1] = make_float2(t.z, t.w);
+        }
+    }
+    SONAR_STAMP(9);
+    idft<N>(v);
+    const c32* const t = c_cola_tw128[wo];
+#pragma unroll
+    for (int k1 = 1; k1 < N; ++k1) v[k1] = cmul(v[k1], t[k1]);
+    SONAR_STAMP(10);
+#pragma unroll
+    for (int k1 = 0; k1 < N; ++k1) A[(8 * k1 + w) * S + lane] = v[k1];
+}
+
+// The spectral filter at 128 x 128: out = irfft2(rfft2(x) * filter), py/nodes/powernoise.py:356-366.  Two 8-wave workgroups per CU, a
+// plane in LDS each, SEVEN workgroup barriers per plane (round 4: twelve):
+//   rows b'    global -> registers -> radix 8 over k2, twiddle -> LDS (the next plane's loads are requested three passes ahead: a
+//              workgroup used to sit 5.4 of a plane's 19.7 us behind its own loads, profiles/r05_spectral_filter.md)
+//   rows a'    + r2c split in registers (sf_row_a_split)                  cols b'   radix 8, twiddle (sf_col_b)
+//   cols a' x filter, cols a   radix 16 forward, the filter, radix 16 inverse in registers (sf_col_a_filter_col_a; one barrier inside)
+//   cols b, rows a, rows b     the pipelined generate kernel's passes on the swizzled row layout (kRowsSwizzled: row pass a in place
+//              without the barrier between its loads and stores)
+#ifndef SONAR_SF_FILTER_EARLY
+#define SONAR_SF_FILTER_EARLY 1
+#endif
+#ifndef SONAR_SF_PREFETCH
+#define SONAR_SF_PREFETCH 1  // 0: a plane's loads are requested at its own start (A/B)
+#endif
+#ifndef SONAR_SF_WIDE
+#define SONAR_SF_WIDE 1  // rows b' takes items (k1 = 2 (t % 4) + i, LDS row t / 4) with eight 16-byte loads per thread; 0: (k1 = t % 8, LDS rows
+#endif                   // t / 8 + 64 i) with sixteen 8-byte ones (+1 us per 512 latents).  (Global accesses need dword alignment, whatever their width.)
+template <int H, int W, bool STATS>
+__global__ void __launch_bounds__(512, 4) spectral_filter128_kernel(const float* __restrict__ x, const float* __restrict__ filter, float* out, int64_t planes,
+                                                                     double* partials) {
+    using C = PlaneCfg<H, W>;
+    constexpr int NT = 512, M = C::M, S = C::S, Wh = C::Wh, RN1 = C::RN1, RN2 = C::RN2, CN1 = H / 8, CN2 = 8;
+    static_assert(H == 128 && W == 128 && RN1 == 8 && RN2 == 8 && plane_threads<H, W>() == NT, "8 waves, 8 x 8 rows, 16 x 8 columns");
+    __shared__ __attribute__((aligned(16))) c32 A[H * S];
+    __shared__ __attribute__((aligned(16))) SfExchange<H> xch;
+    __shared__ c32 TW[M];  // e^{2 pi i j / M}: pass b''s lane-dependent twiddles
+    __shared__ double red[2 * NT / 64];
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int j = tid; j < M; j += NT) TW[j] = c_tw256[j * (256 / M)];
+    for (int i = tid; i < H; i += NT) {  // the packed column's weights, i = 16 w + j for ky = 8 j + w
+        const int ky = 8 * (i & 15) + (i >> 4), kn = (H - ky) & (H - 1);
+        const float g0 = 0.5f * (filter[ky * Wh] + filter[kn * Wh]), gm = 0.5f * (filter[ky * Wh + M] + filter[kn * Wh + M]);
+        xch.wgt[i] = make_float2(0.5f * (g0 + gm), 0.5f * (g0 - gm));
+    }
+    // both transforms unscaled, the split's halves left out: 1 / (2 H W)
+    const float scale = 0.5f / ((float)H * (float)W);
+    __shared__ double sums[STATS ? 2 * NT : 1];
+    if constexpr (STATS) {
+        sums[tid] = 0.0;
+        sums[NT + tid] = 0.0;
+    }
+    [[maybe_unused]] int pidx = 0;
+    // rows b': item (k1 = tid % 8, LDS row r = tid / 8 + 64 it); LDS row r holds spatial row y = r / 8 + 16 (r % 8) (what the column passes
+    // expect); complex element m = k1 + 8 k2 of a row is (x[2m], x[2m+1])
+    c32 u[2][RN2];
+    constexpr bool WIDE = SONAR_SF_WIDE != 0;
+    auto request = [&](int64_t plane, int t) {
+        if constexpr (WIDE) {
+            const int r = t >> 2, y = (r / CN2) + CN1 * (r % CN2);
+            const float* xrow = x + plane * (int64_t)H * W + (int64_t)y * W + 4 * (t & 3);
+#pragma unroll
+            for (int k2 = 0; k2 < RN2; ++k2) {
+                const float4 v = *reinterpret_cast<const float4*>(xrow + 2 * RN1 * k2);
+                u[0][k2] = make_float2(v.x, v.y);
+                u[1][k2] = make_float2(v.z, v.w);
+            }
+        } else {
+            const int k1 = t & 7;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = (t >> 3) + 64 * it, y = (r / CN2) + CN1 * (r % CN2);
+                const float* xrow = x + plane * (int64_t)H * W + (int64_t)y * W;
+#pragma unroll
+                for (int k2 = 0; k2 < RN2; ++k2) u[it][k2] = *reinterpret_cast<const float2*>(xrow + 2 * (k1 + RN1 * k2));
+            }
+        }
+    };
+    // the inverse's last three passes (the next plane's loads are in flight through them)
+    auto finish = [&](int64_t plane, int lane) {
+        pipe_col_b<H, W, 8>(A, A, wv, lane);  // in place: an item reads and writes the same 8 rows of its column
+        __syncthreads();
+        SONAR_STAMP(5);
+        pipe_row_a<H, W, 8, kRowsSwizzled>(A, A, wv, lane);
+        __syncthreads();
+        SONAR_STAMP(6);
+        // (the statistics variant is four registers over its 128: the thread's two running fp64 sums wait in LDS between planes)
+        double ps = 0.0, pq = 0.0;
+        pipe_row_b<H, W, 8, STATS, false, kRowsSwizzled>(A, out + plane * (int64_t)H * W, wv, lane, scale, scale, 0.0f, ps, pq);
+        if constexpr (STATS) {
+            sums[tid] += ps;
+            sums[NT + tid] += pq;
+        }
+        SONAR_STAMP(11);
+        ++pidx;
+    };
+    int64_t plane = blockIdx.x;
+    if (plane >= planes) return;  // (never: the grid is at most `planes`)
+    if (SONAR_SF_PREFETCH) request(plane, tid);
+    for (;;) {
+        __syncthreads();  // the previous plane's LDS reads are done (and the tables are visible)
+        SONAR_STAMP(0);
+        int ptid = tid;  // per plane: every LDS address of a plane is loop-invariant, and hoisted they spill (power_irfft2_kernel)
+        asm volatile("" : "+v"(ptid));
+        const int lane = ptid & 63;
+        if (!SONAR_SF_PREFETCH) request(plane, ptid);
+        {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int k1 = WIDE ? 2 * (ptid & 3) + it : ptid & 7, r = WIDE ? ptid >> 2 : (ptid >> 3) + 64 * it;
+                fdft<RN2>(u[it]);
+#pragma unroll
+                for (int n2 = 1; n2 < RN2; ++n2) u[it][n2] = cmulc(u[it][n2], TW[(n2 * k1) & (M - 1)]);
+#pragma unroll
+                for (int n2 = 0; n2 < RN2; ++n2) A[r * S + C::rpos(k1, n2)] = u[it][n2];
+            }
+        }
+        __syncthreads();
+        SONAR_STAMP(1);
+        sf_row_a_split<H, W>(A, wv, lane);
+        __syncthreads();
+        SONAR_STAMP(2);
+        float f[CN1];
+        if (SONAR_SF_FILTER_EARLY) sf_filter_values<H, W>(filter, wv, lane, f);  // a pass ahead of their use
+        sf_col_b<H, W>(A, wv, lane);
+        __syncthreads();
+        SONAR_STAMP(3);
+        if (!SONAR_SF_FILTER_EARLY) sf_filter_values<H, W>(filter, wv, lane, f);
+        sf_col_a_filter_col_a<H, W>(A, &xch, f, wv, lane, pidx);
+        __syncthreads();
+        SONAR_STAMP(4);
+        // The loop is split at the prefetch, not closed behind the last pass: with the request under a condition the loaded registers
+        // merge with their old values in a copy, and the copy waits for the loads right where they were issued.
+        const int64_t next = plane + gridDim.x;
+        if (next >= planes) {  // uniform
+            finish(plane, lane);
+            break;
+        }
+        if (SONAR_SF_PREFETCH) request(next, ptid);
+        finish(plane, lane);
+        plane = next;
+    }
+    if constexpr (STATS) write_partial<NT>(sums[tid], sums[NT + tid], partials, red);
 }
 
 // ---- statistics of the NEXT call, computed in the pipelined kernel's idle corners -------------------------------------------------
@@ -1458,7 +1781,11 @@ static int launch_power(int what, const float* z, const float* filter, float* ou
     if (what == 4) {
         SONAR_PW(3, false, false, nullptr);
     } else if (what == 3) {
-        if (partials) SONAR_PW(2, true, false, partials); else SONAR_PW(2, false, false, partials);
+        if constexpr (H == 128 && W == 128 && SONAR_SF_V2) {
+            const dim3 grid(power_grid<H, W>(planes, partials != nullptr));
+            if (partials) hipLaunchKernelGGL((spectral_filter128_kernel<H, W, true>), grid, blk, 0, st, z, filter, out, planes, partials);
+            else hipLaunchKernelGGL((spectral_filter128_kernel<H, W, false>), grid, blk, 0, st, z, filter, out, planes, partials);
+        } else if (partials) SONAR_PW(2, true, false, partials); else SONAR_PW(2, false, false, partials);
     } else if (what == 2) {
         hipLaunchKernelGGL((power_spectrum_kernel<H, W>), dim3(std::min<int64_t>(ngroups, 2048)), blk, 0, st, out, planes, seed, stream_id, plane_offset, group, split);
     } else if (what == 1) {
