@@ -601,6 +601,27 @@ SONAR_UNROLL_ITEMS
 #ifndef SONAR_AHEAD_PRIO
 #define SONAR_AHEAD_PRIO 0  // the transforming team's issue priority while it computes look-ahead statistics beside the first draw
 #endif
+// Measured and left off (round 5, gpurun_out/dc, profiles/r05_power_kernel.md): with SONAR_PIPE_DECOUPLE the teams meet at ONE workgroup
+// barrier per plane -- the transforming team's two exchanges inside an iteration become a team-only rendezvous (below), the drawing team
+// draws its plane in one stretch and only looks at the other team's counter before it writes -- same bits, no hang, and no faster:
+// 42.3-42.5 against 41.6-42.0 us per call, 39.4 = 39.4 us for the final pass alone (spinning at low priority, longer sleeps, equal
+// priorities: 42.5-43.8).  The three lock-step phases are not what bounds the kernel; its instruction streams are.
+#ifndef SONAR_PIPE_DECOUPLE
+#define SONAR_PIPE_DECOUPLE 0
+#endif
+// A team's own exchange (SONAR_PIPE_DECOUPLE): the hardware barrier counts all sixteen waves, so a team-only rendezvous is a counter in
+// LDS -- every wave's lane 0 adds one when the wave's LDS operations are complete (LDS executes a wave's operations in order, and the
+// waves' in arrival order: who sees the count sees what was written in front of it), then the wave polls until the count reaches
+// `target`.  team_wait alone is the other team looking at that counter.
+__device__ __forceinline__ void team_wait(const int* ctr, int target) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void team_barrier(int* ctr, int target, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    team_wait(ctr, target);
+}
 #ifndef SONAR_PIPE_PRIO_DRAW
 #define SONAR_PIPE_PRIO_DRAW 0
 #endif
@@ -1329,6 +1350,16 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
     static_assert(sizeof(uint4) * NT >= sizeof(c32) * 2 * H * kAheadMaxGroup, "edge columns of a look-ahead unit fit the seed area");
     __shared__ double sred[2 * NT / 64];  // wave sums of a team's look-ahead statistics (TeamStats)
     __shared__ double red[2 * NALL / 64];
+    // SONAR_PIPE_DECOUPLE: arrivals at the transforming team's exchanges (two per iteration: behind column pass b, behind row pass a) and
+    // at the drawing team's one (its look-ahead statistics)
+    __shared__ int tbar, dbar;
+    if constexpr (SONAR_PIPE_DECOUPLE) {
+        if (threadIdx.x == 0) {
+            tbar = 0;
+            dbar = 0;
+        }
+        __syncthreads();
+    }
     __shared__ NormDecision shd;
     const int wv_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const bool drawer = wv_all >= NT / 64;
@@ -1425,6 +1456,16 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
                 }
                 for (int i = 0; i < gw.first; ++i) skip_plane<H, W, true, false>(rng, tid);
             }
+            if constexpr (SONAR_PIPE_DECOUPLE) {
+                // the whole draw in one stretch: the only things this team needs from the other one are the free buffer (its row pass a
+                // has read Y) and the packed column -- both behind the transforming team's second exchange of this iteration
+                draw_chunk_regs<H, W, 0, ITER>(rng, v, wa, wb);
+                if (wave_neg) draw_chunk_signs<H, W, 0, ITER>(filter, tid, v);
+                pin_chunk<0, ITER>(v);
+                SONAR_PIPE_STAMP(1);
+                SONAR_PIPE_STAMP(2);
+                team_wait(&tbar, 2 * (NT / 64) * (j + 1));
+            } else {
             draw_chunk_regs<H, W, 0, E0>(rng, v, wa, wb);
             if (wave_neg) draw_chunk_signs<H, W, 0, E0>(filter, tid, v);
             pin_chunk<0, E0>(v);
@@ -1437,6 +1478,7 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             __syncthreads();
             draw_chunk_regs<H, W, E1, ITER>(rng, v, wa, wb);
             if (wave_neg) draw_chunk_signs<H, W, E1, ITER>(filter, tid, v);
+            }
             if (lane == M - 1) {
 #pragma unroll
                 for (int n1 = 0; n1 < CN1; ++n1) v[n1] = Q[CN2 * n1 + wv];
@@ -1466,10 +1508,11 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             ts.begin(filter, seed, next_stream, plane_offset, group, gw, tid, edge, wa, wb);
             ts.radii(0, SONAR_AHEAD_SPLIT_A, tid);
             SONAR_PIPE_STAMP(1);
-            __syncthreads();
+            if constexpr (SONAR_PIPE_DECOUPLE) team_barrier(&dbar, NT / 64, lane);  // the unit's edge columns are complete
+            else __syncthreads();
             ts.radii(SONAR_AHEAD_SPLIT_A, SONAR_AHEAD_SPLIT_B, tid);
             SONAR_PIPE_STAMP(2);
-            __syncthreads();
+            if constexpr (!SONAR_PIPE_DECOUPLE) __syncthreads();
             ts.radii(SONAR_AHEAD_SPLIT_B, 4, tid);
             ts.products();
             ts.edges_and_wave_sums(edge, tid, sred);
@@ -1477,9 +1520,9 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             __syncthreads();
         } else {
             SONAR_PIPE_STAMP(1);
-            __syncthreads();
+            if constexpr (!SONAR_PIPE_DECOUPLE) __syncthreads();
             SONAR_PIPE_STAMP(2);
-            __syncthreads();
+            if constexpr (!SONAR_PIPE_DECOUPLE) __syncthreads();
             SONAR_PIPE_STAMP(3);
             __syncthreads();
         }
@@ -1534,6 +1577,11 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         // second plane buffer, untouched until iteration 1), over the iteration's three barriers
         [[maybe_unused]] const int j = 0;  // (trace builds; shadowed by the loop below)
         SONAR_PIPE_STAMP(0);
+        int tb = 0;  // this team's exchanges so far
+        auto exchange = [&]() {
+            if constexpr (SONAR_PIPE_DECOUPLE) team_barrier(&tbar, (NT / 64) * ++tb, lane);
+            else __syncthreads();
+        };
         if (ahead && my_units >= 1) {
             TeamStats<H, W> ts;
             c32* const edge = PLANES + BUF;
@@ -1548,11 +1596,11 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             ts.begin(filter, seed, next_stream, plane_offset, group, gw, tid, edge);
             ts.radii(0, SONAR_AHEAD_SPLIT_C, tid);
             SONAR_PIPE_STAMP(1);
-            __syncthreads();
+            exchange();
             pack_edges(0);
             ts.radii(SONAR_AHEAD_SPLIT_C, SONAR_AHEAD_SPLIT_D, tid);
             SONAR_PIPE_STAMP(2);
-            __syncthreads();
+            exchange();
             ts.radii(SONAR_AHEAD_SPLIT_D, 4, tid);
             ts.products();
             ts.edges_and_wave_sums(edge, tid, sred);
@@ -1564,10 +1612,10 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         } else {
             draw_edges(0);
             SONAR_PIPE_STAMP(1);
-            __syncthreads();
+            exchange();
             pack_edges(0);
             SONAR_PIPE_STAMP(2);
-            __syncthreads();
+            exchange();
             leave_wave_sums();
             SONAR_PIPE_STAMP(3);
             __syncthreads();
@@ -1582,11 +1630,11 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             draw_edges(j);
             if (j == 1) decide_in_wave0();
             SONAR_PIPE_STAMP(1);
-            __syncthreads();
+            exchange();
             if (work && !(SONAR_PIPE_SKIP & 8)) pipe_row_a<H, W, NW>(Y, X, wv, lane);
             pack_edges(j);
             SONAR_PIPE_STAMP(2);
-            __syncthreads();
+            exchange();
             if (work) {
                 if (j == 1) pick_up_decision();
                 const GroupWalk gw(unit, group, split);
