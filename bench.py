@@ -268,7 +268,7 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
     filt = torch.rand(H, W // 2 + 1, device=device) + 0.5
     us = event_us(lambda: hl.spectral_filter(xs, filt))
     extra["spectral_filter_latents_per_s"] = BATCH / (us * 1e-6)
-    kernels.append(kernel_entry("power_irfft2_kernel<SRC=2> spectral filter, batch 512", us, 8 * N_LATENT * BATCH,
+    kernels.append(kernel_entry("spectral_filter128_kernel (rfft2 x filter, irfft2 in LDS), batch 512", us, 8 * N_LATENT * BATCH,
                                 tr.get("spectral_filter_b512", {}).get("hbm_bytes_per_launch")))
     # the same call on planes off the 128 x 128 path, 33.5 M values each: SD 1.5 latents (the fixed-size kernels' general passes), an
     # SDXL portrait bucket (general-size kernels: codelets 13 x 8 and 19 x 4), 2048 px (beyond LDS: drawn and column-transformed in blocks of

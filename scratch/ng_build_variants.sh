@@ -9,7 +9,7 @@ build_one() {
   name=$1; flags=$2
   (cd comfyui-sonar_amd/csrc && hipcc $BASE $flags -c noise_gen.hip -o ../../scratch/bin/ngvar/noise_gen_$name.o)
   hipcc -shared -fPIC --offload-arch=gfx950 -o scratch/bin/ngvar/lib_$name.so scratch/bin/ngvar/noise_gen_$name.o \
-    comfyui-sonar_amd/build/elementwise.o comfyui-sonar_amd/build/power_fft.o comfyui-sonar_amd/build/dwt.o comfyui-sonar_amd/build/runtime.o comfyui-sonar_amd/build/dft_direct.o comfyui-sonar_amd/build/dtcwt.o comfyui-sonar_amd/build/plan.o comfyui-sonar_amd/build/dwt_bands.o
+    $(ls comfyui-sonar_amd/build/*.o | grep -v "/noise_gen.o")
   rm -f scratch/bin/ngvar/noise_gen_$name.o
   echo built $name
 }

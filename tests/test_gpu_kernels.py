@@ -386,6 +386,30 @@ def test_spectral_filter_all_supported_shapes(hl, hw):
     close(hl.spectral_filter(dev(x), dev(torch.ones(h, w // 2 + 1))), x, rtol=0, atol=FFT_ATOL)
 
 
+@pytest.mark.parametrize("planes", [1, 5, 513, 1027])
+def test_spectral_filter_128_kernel_of_its_own(hl, planes):
+    """Round 5: 128 x 128 planes run spectral_filter128_kernel (paired forward row pass, fused forward / filter / inverse column pass).
+    A filter with signs and zeros whose kx = 0 and kx = W/2 columns differ and are not even in ky exercises the packed column's
+    weights; plane counts that leave the persistent workgroups unequal shares exercise the loop split at the prefetch; an input that is
+    aligned to 8 bytes only is the ABI's contract (the kernel loads 16 bytes at a time)."""
+    torch.manual_seed(planes)
+    filt = torch.randn(128, 65)
+    filt[3, 0] = 0.0
+    filt[:, 64] *= 2.0
+    filt[7, 9] = 0.0
+    flat = torch.randn(planes * 128 * 128 + 2, device="cuda")
+    x = flat[2:].view(planes, 128, 128)
+    assert x.data_ptr() % 16 == 8
+    part = hl.new_partials("cuda")
+    got = hl.spectral_filter(x, dev(filt), part)
+    want = torch.fft.irfft2(torch.fft.rfft2(x.double()) * filt.double().cuda(), s=(128, 128))
+    assert (got.double() - want).abs().max().item() < 2e-6 * want.abs().max().item()
+    tot = hl.stats_finalize(part, got.numel()).cpu()
+    assert abs(tot[0].item() - got.double().sum().item()) < 1e-6 * got.numel() * max(1.0, got.abs().max().item())
+    assert abs(tot[1].item() / (got.double() ** 2).sum().item() - 1.0) < 1e-6
+    assert torch.equal(got, hl.spectral_filter(x.clone(), dev(filt)))  # the statistics variant stores the same values, whatever the alignment
+
+
 def test_spectral_filter_full_batch_linearity_and_std_scale(hl):
     """BASELINE size (512 x 4 x 128 x 128): linearity F(a x + b y) = a F(x) + b F(y), and x *= mul / std."""
     torch.manual_seed(2)
