@@ -377,6 +377,30 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
         extra["cfg5_latent_steps_per_s"] = 128 / (extra["cfg5_step_ms"] * 1e-3)
     except Exception as exc:
         extra["cfg5_error"] = repr(exc)[:200]
+    # the same step with the opt-in virtual Brownian tree (W(t) a function of (seed, t) alone: noise_generation.BROWNIAN_TREE_DEPTH = 24,
+    # up to 25 normals per element and evaluation instead of one), and its noise call alone on the shard
+    ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
+    depth0 = ng.BROWNIAN_TREE_DEPTH
+    try:
+        ng.BROWNIAN_TREE_DEPTH = 24
+        extra["cfg5_step_brownian_tree_ms"] = cfg5_shard_step_ms(device, hl, pn, nz, sonar)
+        xs5 = torch.zeros((128, 16, H, W), device=device)
+        ns_t = nz.get_noise_sampler("brownian", xs5, 0.03, 14.6, seed=7, cpu=False, normalized=False)
+        sch = torch.linspace(14.6, 0.5, 21).tolist()
+        calls = [pair for k in range(20) for pair in ((sch[k], math.sqrt(sch[k] * sch[k + 1])), (sch[k], sch[k + 1]))]
+        at = [0]
+
+        def tree_step():
+            a, b = calls[at[0] % len(calls)]
+            at[0] += 1
+            return ns_t(torch.tensor(a), torch.tensor(b))
+
+        extra["brownian_tree_cfg5_shard_us_per_call"] = event_us(tree_step, 20, 4)
+        del xs5, ns_t
+    except Exception as exc:  # secondary figure only
+        extra["cfg5_brownian_tree_error"] = repr(exc)[:200]
+    finally:
+        ng.BROWNIAN_TREE_DEPTH = depth0
     return kernels, extra
 
 

@@ -1221,7 +1221,8 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     const size_t lds_x = lds + rows * W * sizeof(float);
     if (W % 4 != 0 || elem_offset % (H * W) != 0 || lds > kPyramidLdsBudget) return false;
     const bool xrows = mode == 0 && W % 4 == 0 && lds_x <= kPyramidLdsBudget;
-    const int g = (int)std::min<int64_t>(planes, kNPart);
+    static const int grid_cap = [] { const char* e = getenv("SONAR_PYR_GRID"); return e ? atoi(e) : kNPart; }();
+    const int g = (int)std::min<int64_t>(planes, std::min(grid_cap, kNPart));
     const bool nt = nt_stores_host(planes * H * W);
 #define SONAR_PPN(ST, XR, P, N) \
     hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P, N>), dim3(g + lat.blocks), dim3(kPyrBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \

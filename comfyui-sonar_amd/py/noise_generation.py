@@ -11,6 +11,7 @@ Two RNG modes, selected by the reference's own ``cpu`` flag:
 from __future__ import annotations
 
 import math
+import os
 import threading
 from enum import Enum, auto
 from typing import NamedTuple, Optional
@@ -1040,24 +1041,73 @@ class BrownianPath:
     not only on (seed, t).  One sampler run is self-consistent (every increment it sees comes from one path), and two runs that ask for
     the same times in the same order see the same path; two runs over the same range with different step counts, or a resumed run
     that re-creates the sampler, see different (equally valid) paths at the times they share -- as they do with torchsde's
-    BrownianInterval without its dyadic pre-tree.  ``tests/test_abi_and_host.py::test_brownian_path_depends_on_the_query_order``."""
+    BrownianInterval without its dyadic pre-tree.  ``tests/test_abi_and_host.py::test_brownian_path_depends_on_the_query_order``.
+
+    TREE MODE (``tree_depth`` = D > 0; opt-in, ``BROWNIAN_TREE_DEPTH`` below): the virtual Brownian tree -- what ComfyUI's BrownianTree
+    is, up to its tolerance.  A time inside (t_lo, t_hi) is snapped to the grid of 2**D cells (D = 24: 6e-8 of the range), and a grid
+    point is defined through its dyadic ancestors only, top down: the midpoint of [t_lo, t_hi], then the midpoint of the half that holds
+    it, ... each a bridge between the ends of ITS dyadic interval with the node id of its place in the tree (heap index: 1, then 2h /
+    2h + 1).  W(t) is then a fixed function of (seed, t) -- no history: any query order, any step count, a sampler re-created half way
+    through a run all see the same path -- at the price of up to D + 1 normals per element and evaluation where the default needs
+    one (cfg5's shard: ~0.6 ms per call instead of 0.09).  Times outside [t_lo, t_hi] keep the default's extensions."""
 
     ROOT = 0              # node ids are creation numbers; they stay below 2**40 (the kernel's stream-id field has 48 bits)
     MEMO = 512            # expansions remembered (each can hold every earlier node: a run of n monotone queries makes them O(n) long)
+    MAX_TREE_DEPTH = 36
 
-    def __init__(self, t_lo: float, t_hi: float):
+    def __init__(self, t_lo: float, t_hi: float, tree_depth: int = 0):
         self.t_lo, self.t_hi = float(t_lo), float(t_hi)
         if not self.t_hi > self.t_lo:
             raise ValueError("Brownian noise needs sigma_min < sigma_max")
+        self.tree_depth = int(tree_depth)
+        if not 0 <= self.tree_depth <= self.MAX_TREE_DEPTH:
+            raise ValueError(f"Brownian noise: tree depth 0 (off) .. {self.MAX_TREE_DEPTH}")
         self.times = [self.t_lo, self.t_hi]  # sorted; W(lo) = 0, W(hi) ~ N(0, hi - lo)
         self.bridge: dict = {}               # t -> (a, b or None, fa, fb, sd, node)
-        self._next = 1
+        # tree mode: the dyadic nodes own the ids 1 .. 2**D - 1; creation numbers (extensions beyond the range) start above them
+        self._next = 1 << self.tree_depth if self.tree_depth else 1
         self._memo: dict = {}
+
+    # ---- tree mode: grid index g in [0, 2**D] <-> time
+    def _grid_time(self, g: int) -> float:
+        cells = 1 << self.tree_depth
+        return self.t_lo if g <= 0 else self.t_hi if g >= cells else self.t_lo + g * ((self.t_hi - self.t_lo) / cells)
+
+    def resolve(self, t: float) -> float:
+        """The time a query of t stands for: t itself, or in tree mode the nearest grid point when t lies inside the range."""
+        t = float(t)
+        if not self.tree_depth or not self.t_lo < t < self.t_hi:
+            return t
+        cells = 1 << self.tree_depth
+        return self._grid_time(int(round((t - self.t_lo) / (self.t_hi - self.t_lo) * cells)))
+
+    def _define_dyadic(self, t: float) -> None:
+        """t (a grid time) and every dyadic ancestor that is not a point yet, top down."""
+        import bisect
+
+        cells = 1 << self.tree_depth
+        g = int(round((t - self.t_lo) / (self.t_hi - self.t_lo) * cells))
+        lo, hi, h = 0, cells, 1
+        while hi - lo > 1:
+            m = (lo + hi) // 2
+            tm = self._grid_time(m)
+            if tm not in self.bridge:
+                a, b = self._grid_time(lo), self._grid_time(hi)
+                fb = (tm - a) / (b - a)
+                self.bridge[tm] = (a, b, 1.0 - fb, fb, math.sqrt((tm - a) * (b - tm) / (b - a)), h)
+                bisect.insort(self.times, tm)
+            if m == g:
+                return
+            lo, hi, h = (lo, m, 2 * h) if g < m else (m, hi, 2 * h + 1)
+        raise AssertionError("grid point not reached")  # (unreachable: every interior grid index is some interval's midpoint)
 
     def define(self, t: float) -> None:
         """Make t a point of the path (a bridge between its neighbours, or an extension beyond the outermost known time)."""
-        t = float(t)
+        t = self.resolve(t)
         if t in self.bridge or t == self.t_lo or t == self.t_hi:
+            return
+        if self.tree_depth and self.t_lo < t < self.t_hi:
+            self._define_dyadic(t)
             return
         import bisect
 
@@ -1078,7 +1128,7 @@ class BrownianPath:
 
     def coefficients(self, t: float) -> dict:
         """{node id: coefficient} with W(t) = sum coefficient * z(node); defines the point if it is new."""
-        t = float(t)
+        t = self.resolve(t)
         self.define(t)
         memo = self._memo
         if len(memo) > self.MEMO:
@@ -1105,6 +1155,7 @@ class BrownianPath:
 
     def increment(self, t0: float, t1: float):
         """(node ids, coefficients) of (W(t_max) - W(t_min)) / sqrt(t_max - t_min); the smaller time is defined first."""
+        t0, t1 = self.resolve(t0), self.resolve(t1)
         ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
         if ta == tb:
             raise ValueError("Brownian noise needs two distinct times")
@@ -1119,16 +1170,27 @@ class BrownianPath:
         return ids, [terms[k] for k in ids]
 
 
-class BrownianTreeNoiseSampler:
-    """Interface of k-diffusion's BrownianTreeNoiseSampler (x, sigma_min, sigma_max, seed, transform, cpu) -> (sigma, sigma_next)."""
+def _env_tree_depth() -> int:
+    v = os.environ.get("SONAR_BROWNIAN_TREE", "0").strip().lower()
+    return 0 if v in ("", "0", "off", "false") else 24 if v in ("1", "on", "true") else int(v)
 
-    def __init__(self, x: Tensor, sigma_min, sigma_max, seed=None, transform=lambda t: t, cpu: bool = False):
+
+# Depth of the virtual Brownian tree (BrownianPath, TREE MODE) for samplers made from now on; 0 = the default path of bridges between the
+# times asked for.  Environment: SONAR_BROWNIAN_TREE=1 (depth 24) or =<depth>.
+BROWNIAN_TREE_DEPTH = _env_tree_depth()
+
+
+class BrownianTreeNoiseSampler:
+    """Interface of k-diffusion's BrownianTreeNoiseSampler (x, sigma_min, sigma_max, seed, transform, cpu) -> (sigma, sigma_next);
+    ``tree_depth``: BrownianPath's tree mode for this sampler (None: the module's BROWNIAN_TREE_DEPTH)."""
+
+    def __init__(self, x: Tensor, sigma_min, sigma_max, seed=None, transform=lambda t: t, cpu: bool = False, tree_depth: Optional[int] = None):
         if not x.is_cuda:
             raise hip_lib.SonarHipError("Brownian noise: the latent must live on a ROCm device")
         self.transform = transform
         t0, t1 = float(transform(torch.as_tensor(sigma_min))), float(transform(torch.as_tensor(sigma_max)))
         self.sign = 1.0 if t0 <= t1 else -1.0
-        self.path = BrownianPath(min(t0, t1), max(t0, t1))
+        self.path = BrownianPath(min(t0, t1), max(t0, t1), BROWNIAN_TREE_DEPTH if tree_depth is None else tree_depth)
         self.shape, self.device = tuple(x.shape), x.device
         if seed is None:
             seed = int(torch.randint(0, 2**63 - 1, []).item())
@@ -1188,7 +1250,8 @@ class BrownianTreeNoiseSampler:
         """(scale * (W(t) - prev) or None, W(t)) for a time that is not kept: the bridge between its two kept neighbours, else its expansion."""
         made = self.path.bridge.get(t)
         out = w = None
-        if made is not None and self.CACHE_POINTS > 0:
+        # (tree mode always expands: W(t) is then the same bits whatever happens to be kept, a function of (seed, t) alone)
+        if made is not None and self.CACHE_POINTS > 0 and not self.path.tree_depth:
             a, b, fa, fb, sd, node = made
             wa = None if a == self.path.t_lo else self._cached(a, cheap=True)  # W(t_lo) = 0
             wb = None if b is None else self._cached(b, cheap=True)            # b is None: an extension beyond the known times
@@ -1216,6 +1279,7 @@ class BrownianTreeNoiseSampler:
         t0, t1 = float(self.transform(torch.as_tensor(sigma))), float(self.transform(torch.as_tensor(sigma_next)))
         sign = self.sign * (1.0 if t0 <= t1 else -1.0)
         ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
+        ta, tb = self.path.resolve(ta), self.path.resolve(tb)  # (tree mode: the grid points the two times stand for)
         if self.CACHE_POINTS <= 0 or ta == tb:
             ids, coefs = self.path.increment(t0, t1)
             out, _ = self._emit(ids, [c * sign for c in coefs], want_w=False, fold=fold, partials=partials)

@@ -191,6 +191,50 @@ def test_brownian_path_coefficients_are_a_brownian_motion(pkg):
     assert len(c) == 3000 and abs(var(c) - (1.0 - 2999 / 3001.0)) < 1e-9 and len(long._memo) <= long.MEMO + 3000
 
 
+def test_brownian_tree_mode_is_a_function_of_the_time_alone(pkg):
+    """BrownianPath(tree_depth = D), the opt-in virtual Brownian tree (ComfyUI's BrownianTree up to its tolerance): a time is snapped to
+    the grid of 2**D cells and defined through its dyadic ancestors, whose node ids are their places in the tree -- the expansion of
+    W(t) is the same whatever was asked before (another order, other step counts, a fresh instance), still has a Brownian motion's
+    variances and covariances exactly, and holds at most D + 1 normals."""
+    import importlib
+    import random
+
+    ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
+    lo, hi, D = 0.03, 14.6, 24
+    var = lambda c: sum(v * v for v in c.values())  # noqa: E731
+    cov = lambda c1, c2: sum(v * c2.get(k, 0.0) for k, v in c1.items())  # noqa: E731
+    rnd = random.Random(5)
+    times = [rnd.uniform(lo, hi) for _ in range(60)] + [hi * 0.93**k for k in range(1, 40)]
+    a, b = ng.BrownianPath(lo, hi, D), ng.BrownianPath(lo, hi, D)
+    ca = {t: dict(a.coefficients(t)) for t in times}
+    cb = {t: dict(b.coefficients(t)) for t in sorted(times)}          # another order ...
+    fresh = {t: dict(ng.BrownianPath(lo, hi, D).coefficients(t)) for t in times[:10]}  # ... and no history at all
+    assert all(ca[t] == cb[t] for t in times) and all(fresh[t] == ca[t] for t in times[:10])
+    cells = 1 << D
+    for t in times:
+        ts = a.resolve(t)
+        assert abs(ts - t) <= (hi - lo) / cells and a.resolve(ts) == ts
+        assert 1 <= len(ca[t]) <= D + 1 and all(0 <= k < cells for k in ca[t])
+        assert abs(var(ca[t]) - (ts - lo)) < 1e-9
+    for s_, t in zip(times[:-1], times[1:]):
+        assert abs(cov(ca[s_], ca[t]) - (min(a.resolve(s_), a.resolve(t)) - lo)) < 1e-9
+        if a.resolve(s_) != a.resolve(t):
+            ids, co = a.increment(s_, t)
+            assert abs(sum(c * c for c in co) - 1.0) < 1e-6 and ids == sorted(ids) and len(ids) <= 2 * D + 2
+    # the ends and their normals are the default's; a point's node id is its place in the tree
+    assert a.coefficients(lo) == {} and set(a.coefficients(hi)) == {a.ROOT}
+    mid = a.resolve((lo + hi) / 2)
+    assert a.bridge[mid][5] == 1 and a.bridge[a.resolve(lo + (hi - lo) / 4)][5] == 2 and a.bridge[a.resolve(lo + 3 * (hi - lo) / 4)][5] == 3
+    # outside the range: the default's extensions, with ids above the tree's
+    out = a.coefficients(20.0)
+    assert abs(var(out) - (20.0 - lo)) < 1e-9 and max(out) >= cells
+    with pytest.raises(ValueError):
+        a.increment(1.0, 1.0 + (hi - lo) / cells / 8)  # two times in one cell
+    with pytest.raises(ValueError):
+        ng.BrownianPath(lo, hi, 99)
+    assert ng.BrownianPath(lo, hi).tree_depth == 0 and ng.BrownianPath(lo, hi).resolve(1.2345) == 1.2345
+
+
 def test_every_tagged_view_of_a_storage_loses_its_tag(pkg):
     """Two tensors on one storage may each carry a statistics tag; a kernel handed either of them (or any third view) must drop BOTH:
     raw-pointer kernels do not bump torch's version counter, so a surviving tag would normalise with statistics of other contents."""

@@ -315,6 +315,44 @@ def test_brownian_bridge_route_equals_expansion_route(api, seeds):
     torch.testing.assert_close(whole, direct, rtol=0, atol=2e-5)
 
 
+def test_brownian_tree_mode_does_not_depend_on_the_query_history(api, monkeypatch):
+    """The opt-in virtual Brownian tree (BrownianPath tree mode: what ComfyUI's BrownianTree is up to its tolerance): an increment is
+    the same BITS after any history -- a run with other step counts, a sampler made half way through a run, the other order -- where
+    the default path of bridges is only self-consistent per instance; still N(0, 1), additive over abutting intervals, and the
+    module switch / environment default reach the registry's generator."""
+    NG = api.noise_generation
+    x = torch.zeros(2, 4, 64, 64, device="cuda")
+    s = lambda v: torch.tensor(v)  # noqa: E731
+    mk = lambda depth=24: NG.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=99, tree_depth=depth)  # noqa: E731
+    fine, coarse, late = mk(), mk(), mk()
+    sig = [14.6 * 0.8**k for k in range(16)]
+    steps_fine = [fine(s(sig[k]), s(sig[k + 1])) for k in range(15)]         # 15 steps down
+    steps_coarse = [coarse(s(sig[k]), s(sig[k + 3])) for k in (0, 3, 6)]     # 3 steps over the same times
+    assert torch.equal(late(s(sig[7]), s(sig[8])), steps_fine[7])            # no history at all
+    assert torch.equal(coarse(s(sig[7]), s(sig[8])), steps_fine[7])          # another history
+    assert torch.equal(fine(s(sig[3]), s(sig[6])), steps_coarse[1])
+    assert torch.equal(fine(s(sig[8]), s(sig[7])), -steps_fine[7])
+    dt = lambda i, j: fine.path.resolve(sig[i]) - fine.path.resolve(sig[j])  # noqa: E731
+    recomposed = sum(steps_fine[k] * math.sqrt(dt(k, k + 1)) for k in (3, 4, 5)) / math.sqrt(dt(3, 6))
+    torch.testing.assert_close(steps_coarse[1], recomposed, rtol=0, atol=2e-5)
+    n = steps_fine[0].numel()
+    for a in (steps_fine[0], steps_fine[9], steps_coarse[2]):
+        assert abs(a.mean().item()) < 5 / math.sqrt(n) and abs(a.var().item() - 1.0) < 15 / math.sqrt(n)
+    assert abs((steps_fine[2] * steps_fine[3]).mean().item()) < 5 / math.sqrt(n)
+    # the default (depth 0) is a function of the history: the same query after another history gives other values
+    d1, d2 = mk(0), mk(0)
+    d1(s(10.0), s(6.0))
+    assert not torch.equal(d1(s(8.0), s(7.0)), d2(s(8.0), s(7.0)))
+    # the switch: samplers made while it is set are trees
+    monkeypatch.setattr(NG, "BROWNIAN_TREE_DEPTH", 24)
+    ns = api.noise.get_noise_sampler("brownian", x, 0.03, 14.6, seed=99, cpu=False, normalized=False)
+    assert torch.equal(ns(s(sig[7]), s(sig[8])), steps_fine[7])
+    # a chain folds a tree sampler's increments like any other item's
+    acc = torch.ones_like(x)
+    assert late.accumulate(acc, 0.5, 2.0, None, s(sig[7]), s(sig[8]))
+    torch.testing.assert_close(acc, 0.5 + 2.0 * steps_fine[7], rtol=0, atol=1e-6)
+
+
 def test_brownian_batched_seeds_and_time_brownian_power_noise(api):
     x = torch.zeros(3, 4, 32, 32, device="cuda")
     tree = api.noise_generation.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=[5, 6, 5])
