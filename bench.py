@@ -52,8 +52,6 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic.json") for r in (5, 4, 3)) if os.path.exists(p)),
-                    os.path.join(ROOT, "profiles", "r05_traffic.json"))
 BATCH = 512
 C, H, W = 4, 128, 128
 N_LATENT = C * H * W
@@ -159,9 +157,16 @@ def host_and_event_us(fn, steps=200, warmup=100, burst=25, tag=None):
 
 
 def traffic_table() -> dict:
-    if os.path.exists(TRAFFIC_FILE):
-        with open(TRAFFIC_FILE) as fh:
-            return json.load(fh)
+    """The newest tracked PMC traffic table that parses (an annotation: a missing or damaged file must not cost the run its line)."""
+    for r in (5, 4, 3):
+        path = os.path.join(ROOT, "profiles", f"r0{r}_traffic.json")
+        try:
+            with open(path) as fh:
+                table = json.load(fh)
+            if isinstance(table, dict) and table:
+                return table
+        except (OSError, ValueError):
+            continue
     return {}
 
 
@@ -183,7 +188,7 @@ def valu_active_per_launch():
                     return float(line.split()[-1])
                 elif inside and line.startswith("void "):
                     inside = False
-    except OSError:
+    except (OSError, ValueError, IndexError):
         pass
     return None
 

@@ -2,7 +2,8 @@
 # gpurun_out/r05 (scratch/prof_r05.sh) + gpurun_out/r05_sizes.txt (scratch/size_sweep.py) -> profiles/r05_*
 cd "$(dirname "$0")/.."
 O=gpurun_out/r05
-python tools/make_traffic_json.py $O/traffic_raw.json > profiles/r05_traffic.json
+python tools/make_traffic_json.py $O/traffic_raw.json > $O/traffic.json && python -c "import json,sys; json.load(open(sys.argv[1]))" $O/traffic.json \
+  && cp $O/traffic.json profiles/r05_traffic.json || echo "traffic table NOT updated (tools/make_traffic_json.py failed)"
 cp $O/bench.json profiles/r05_bench_line.json
 cp $O/kernel_trace.md profiles/r05_bench_kernel_trace.md
 cp $O/pmc_sq_a.txt profiles/r05_pmc_issue_a.txt

@@ -92,3 +92,26 @@ def test_bench_refuses_to_mislabel_the_gpu_count():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
                          capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and '"metric"' not in res.stdout and "needs 2 GPUs" in res.stderr
+
+
+def test_bench_annotations_survive_a_damaged_profile_file(tmp_path, monkeypatch):
+    """The bench line's HBM-traffic and vector-ALU annotations come from tracked profile files; a missing, empty or damaged one must not
+    cost the run its line (round 5: an empty profiles/r05_traffic.json made every rank of `bench.py --gpus 2` exit with a JSON error)."""
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sonar_bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert isinstance(bench.traffic_table(), dict) and bench.traffic_table()  # the tracked table of the round parses
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.traffic_table() == {} and bench.valu_active_per_launch() is None           # nothing there
+    (tmp_path / "profiles" / "r05_traffic.json").write_text("")
+    (tmp_path / "profiles" / "r04_traffic.json").write_text(json.dumps({"power_noise_b512": {"hbm_bytes_per_launch": 1}}))
+    assert bench.traffic_table() == {"power_noise_b512": {"hbm_bytes_per_launch": 1}}        # the newest one that parses
+    (tmp_path / "profiles" / "r04_traffic.json").write_text("{not json")
+    assert bench.traffic_table() == {}
+    (tmp_path / "profiles" / "r05_pmc_issue_a.txt").write_text("void sonar::power_pipe_kernel<128, 128, false, true>\n  SQ_ACTIVE_INST_VALU\n")
+    assert bench.valu_active_per_launch() is None

@@ -41,7 +41,7 @@ def main(path):
                                        "hbm_bytes_per_launch": total(cols, rows), "algorithmic_bytes_4N": 128 * 4 * 256 * 256 * 4,
                                        "workspace_bytes": 128 * 4 * 256 * 129 * 8,
                                        "note": "128 latents of 4 x 256 x 256: the complex workspace is written and read once, the tensor written once (12.2N)"}
-    sf = pick(raw, "power_irfft2_kernel<128, 128, 2,")
+    sf = pick(raw, "spectral_filter128_kernel<128, 128,")  # (rounds 1-4: power_irfft2_kernel<128, 128, 2, ...>)
     out["spectral_filter_b512"] = dict(sf, algorithmic_bytes_8N=2 * 512 * N)
     # Perlin: lattice + statistics pass + final pass, run equally often at batch 512 and 64 (same kernel names)
     per = [pick(raw, "perlin_lattice_kernel"), pick(raw, "perlin_generate_kernel<1,"), pick(raw, "perlin_generate_kernel<2,")]
