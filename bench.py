@@ -296,7 +296,12 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
                                         + ("; SDXL bucket: the general-size kernel with compile-time factor pairs (power_buckets_*.hip)" if (hh, ww) in ((104, 152), (112, 144), (96, 168)) else "")))
         except Exception as exc:  # secondary figure only
             extra[f"power_noise_{tag}_error"] = repr(exc)[:200]
-    # brownian (cfg5's third source): one new path point per call, bridged between the kept tensors of its neighbours
+    # brownian (cfg5's third source).  Default since round 5: the virtual Brownian tree (W(t) a function of (seed, t) alone, up to 25 normals
+    # per element and evaluation); the rows below keep measuring the path of bridges (SONAR_BROWNIAN_TREE=0: one new path point per call,
+    # bridged between the kept tensors of its neighbours -- rounds 2-4's default), the tree's rows follow cfg5's
+    ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
+    tree_default = ng.BROWNIAN_TREE_DEPTH
+    ng.BROWNIAN_TREE_DEPTH = 0
     ns_b = nz.get_noise_sampler("brownian", x64, 0.03, 14.6, seed=7, cpu=False, normalized=False)
     sched = torch.linspace(14.6, 0.03, 41).tolist()
     pos = [0]
@@ -322,12 +327,14 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
 
         us = event_us(shard_step, 30, 4)
         extra["brownian_cfg5_shard_us_per_call"] = us
-        kernels.append(kernel_entry("brownian_burst_kernel, bridge route, cfg5 shard (128 x 16 x 128 x 128)", us, int(3.5 * xs5.numel() * 4),
+        kernels.append(kernel_entry("brownian_burst_kernel, bridge route (SONAR_BROWNIAN_TREE=0), cfg5 shard (128 x 16 x 128 x 128)", us, int(3.5 * xs5.numel() * 4),
                                     tr.get("brownian_bridge_cfg5_shard", {}).get("hbm_bytes_per_launch"),
                                     "reads the kept neighbour tensor(s), writes W(t) and the increment: 3 or 4 tensors per call, 3.5 on average"))
         del xs5, ns_s
     except Exception as exc:  # secondary figure only
         extra["brownian_cfg5_shard_error"] = repr(exc)[:200]
+    finally:
+        ng.BROWNIAN_TREE_DEPTH = tree_default
     # cfg4: WaveletCFG db4 / level 5 / symmetric, fp32 I/O, 256 latents (cond, uncond, x -> out: 16N bytes per latent)
     wc = importlib.import_module("comfyui_sonar_amd.py.wavelet_cfg")
     b4 = 256
@@ -382,13 +389,15 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
         extra["cfg5_latent_steps_per_s"] = 128 / (extra["cfg5_step_ms"] * 1e-3)
     except Exception as exc:
         extra["cfg5_error"] = repr(exc)[:200]
-    # the same step with the opt-in virtual Brownian tree (W(t) a function of (seed, t) alone: noise_generation.BROWNIAN_TREE_DEPTH = 24,
-    # up to 25 normals per element and evaluation instead of one), and its noise call alone on the shard
+    # the same step on the path of bridges (SONAR_BROWNIAN_TREE=0, rounds 2-4's default: one normal per element and Brownian call, but a
+    # function of the query history), and the tree's noise call alone on the shard
     ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
     depth0 = ng.BROWNIAN_TREE_DEPTH
+    extra["brownian_tree_depth"] = depth0
     try:
-        ng.BROWNIAN_TREE_DEPTH = 24
-        extra["cfg5_step_brownian_tree_ms"] = cfg5_shard_step_ms(device, hl, pn, nz, sonar)
+        ng.BROWNIAN_TREE_DEPTH = 0
+        extra["cfg5_step_brownian_bridges_ms"] = cfg5_shard_step_ms(device, hl, pn, nz, sonar)
+        ng.BROWNIAN_TREE_DEPTH = depth0 or 24
         xs5 = torch.zeros((128, 16, H, W), device=device)
         ns_t = nz.get_noise_sampler("brownian", xs5, 0.03, 14.6, seed=7, cpu=False, normalized=False)
         sch = torch.linspace(14.6, 0.5, 21).tolist()
@@ -403,7 +412,7 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
         extra["brownian_tree_cfg5_shard_us_per_call"] = event_us(tree_step, 20, 4)
         del xs5, ns_t
     except Exception as exc:  # secondary figure only
-        extra["cfg5_brownian_tree_error"] = repr(exc)[:200]
+        extra["cfg5_brownian_error"] = repr(exc)[:200]
     finally:
         ng.BROWNIAN_TREE_DEPTH = depth0
     return kernels, extra

@@ -1024,8 +1024,8 @@ class OneFNoiseGenerator(_SpectralGainNoiseGenerator):
 # BrownianTree; un-vendored, not installed, no reference tests at that boundary): "parity unpinned".  Same contract here --
 # W(t) is ONE Brownian path per element and seed, a call returns (W(t1) - W(t0)) / sqrt|t1 - t0| with the reference's sign
 # convention, so every call is N(0,1) and repeated / nested / abutting intervals are mutually consistent -- but the path is
-# this build's own: Brownian bridges between the times asked for, with counter-based normals (sonar_brownian_bridge_f32), so values
-# differ from torchsde's.
+# this build's own: counter-based normals (sonar_brownian_bridge_f32) on a virtual Brownian tree (default; BrownianPath's tree mode) or
+# as bridges between the times asked for (SONAR_BROWNIAN_TREE=0), so values differ from torchsde's.
 class BrownianPath:
     """W(t) on [t_lo, t_hi] as a linear combination of per-node standard normals: host side of sonar_brownian_*_f32.
 
@@ -1043,13 +1043,14 @@ class BrownianPath:
     that re-creates the sampler, see different (equally valid) paths at the times they share -- as they do with torchsde's
     BrownianInterval without its dyadic pre-tree.  ``tests/test_abi_and_host.py::test_brownian_path_depends_on_the_query_order``.
 
-    TREE MODE (``tree_depth`` = D > 0; opt-in, ``BROWNIAN_TREE_DEPTH`` below): the virtual Brownian tree -- what ComfyUI's BrownianTree
-    is, up to its tolerance.  A time inside (t_lo, t_hi) is snapped to the grid of 2**D cells (D = 24: 6e-8 of the range), and a grid
+    TREE MODE (``tree_depth`` = D > 0; what samplers get by default since round 5, ``BROWNIAN_TREE_DEPTH`` below): the virtual Brownian
+    tree -- what ComfyUI's BrownianTree is, up to its tolerance.  A time inside (t_lo, t_hi) is snapped to the grid of 2**D cells (D = 24: 6e-8 of the range), and a grid
     point is defined through its dyadic ancestors only, top down: the midpoint of [t_lo, t_hi], then the midpoint of the half that holds
     it, ... each a bridge between the ends of ITS dyadic interval with the node id of its place in the tree (heap index: 1, then 2h /
     2h + 1).  W(t) is then a fixed function of (seed, t) -- no history: any query order, any step count, a sampler re-created half way
-    through a run all see the same path -- at the price of up to D + 1 normals per element and evaluation where the default needs
-    one (cfg5's shard: ~0.6 ms per call instead of 0.09).  Times outside [t_lo, t_hi] keep the default's extensions."""
+    through a run all see the same path -- at the price of up to D + 1 normals per element and evaluation where the path of bridges
+    (``tree_depth`` = 0) needs one (cfg5's shard: 0.34 ms per call instead of 0.10).  Times outside [t_lo, t_hi] keep
+    the bridge path's extensions (history-dependent there)."""
 
     ROOT = 0              # node ids are creation numbers; they stay below 2**40 (the kernel's stream-id field has 48 bits)
     MEMO = 512            # expansions remembered (each can hold every earlier node: a run of n monotone queries makes them O(n) long)
@@ -1171,12 +1172,13 @@ class BrownianPath:
 
 
 def _env_tree_depth() -> int:
-    v = os.environ.get("SONAR_BROWNIAN_TREE", "0").strip().lower()
-    return 0 if v in ("", "0", "off", "false") else 24 if v in ("1", "on", "true") else int(v)
+    v = os.environ.get("SONAR_BROWNIAN_TREE", "1").strip().lower()
+    return 0 if v in ("0", "off", "false") else 24 if v in ("", "1", "on", "true") else int(v)
 
 
-# Depth of the virtual Brownian tree (BrownianPath, TREE MODE) for samplers made from now on; 0 = the default path of bridges between the
-# times asked for.  Environment: SONAR_BROWNIAN_TREE=1 (depth 24) or =<depth>.
+# Depth of the virtual Brownian tree (BrownianPath, TREE MODE) for samplers made from now on: 24 (BrownianTree's tolerance of 1e-6 on a
+# sigma range of ~15) unless the environment says otherwise -- SONAR_BROWNIAN_TREE=<depth>, or =0 for the path of bridges between the
+# times asked for (3.4 x cheaper per call, but a function of the query history; the default of rounds 2-4).
 BROWNIAN_TREE_DEPTH = _env_tree_depth()
 
 

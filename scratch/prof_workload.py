@@ -64,7 +64,7 @@ del cond, uncond, xin, wargs
 # same folded into a running sum (the chain form)
 ng = importlib.import_module("comfyui_sonar_amd.py.noise_generation")
 xf = torch.zeros((128, 16, 128, 128), device=dev)
-bt = ng.BrownianTreeNoiseSampler(xf, 0.03, 14.6, seed=7)
+bt = ng.BrownianTreeNoiseSampler(xf, 0.03, 14.6, seed=7, tree_depth=0)  # the path of bridges (the traffic row is its)
 sg = torch.linspace(14.6, 1.0, 2 * REPS + 3).tolist()
 for k in range(REPS): bt(torch.tensor(sg[k]), torch.tensor(sg[k + 1]))
 acc = torch.randn_like(xf)

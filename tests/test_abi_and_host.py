@@ -192,7 +192,7 @@ def test_brownian_path_coefficients_are_a_brownian_motion(pkg):
 
 
 def test_brownian_tree_mode_is_a_function_of_the_time_alone(pkg):
-    """BrownianPath(tree_depth = D), the opt-in virtual Brownian tree (ComfyUI's BrownianTree up to its tolerance): a time is snapped to
+    """BrownianPath(tree_depth = D), the virtual Brownian tree samplers use by default (ComfyUI's BrownianTree up to its tolerance): a time is snapped to
     the grid of 2**D cells and defined through its dyadic ancestors, whose node ids are their places in the tree -- the expansion of
     W(t) is the same whatever was asked before (another order, other step counts, a fresh instance), still has a Brownian motion's
     variances and covariances exactly, and holds at most D + 1 normals."""
@@ -233,6 +233,10 @@ def test_brownian_tree_mode_is_a_function_of_the_time_alone(pkg):
     with pytest.raises(ValueError):
         ng.BrownianPath(lo, hi, 99)
     assert ng.BrownianPath(lo, hi).tree_depth == 0 and ng.BrownianPath(lo, hi).resolve(1.2345) == 1.2345
+    # samplers are trees of depth 24 unless the environment says otherwise
+    import os
+    assert ng._env_tree_depth() == (24 if "SONAR_BROWNIAN_TREE" not in os.environ else ng._env_tree_depth())
+    assert ng.BROWNIAN_TREE_DEPTH == ng._env_tree_depth()
 
 
 def test_every_tagged_view_of_a_storage_loses_its_tag(pkg):

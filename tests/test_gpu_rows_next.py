@@ -293,8 +293,8 @@ def test_brownian_bridge_route_equals_expansion_route(api, seeds):
     NG = api.noise_generation
     x = torch.zeros(3, 4, 64, 64, device="cuda")
     seed = 77 if seeds is None else seeds
-    kept = NG.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=seed)
-    bare = NG.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=seed)
+    kept = NG.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=seed, tree_depth=0)  # (the path of bridges: the tree mode always expands)
+    bare = NG.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=seed, tree_depth=0)
     bare.CACHE_POINTS = 0
     sig = [14.6 * 0.9**k for k in range(61)]
     worst = 0.0
@@ -316,10 +316,10 @@ def test_brownian_bridge_route_equals_expansion_route(api, seeds):
 
 
 def test_brownian_tree_mode_does_not_depend_on_the_query_history(api, monkeypatch):
-    """The opt-in virtual Brownian tree (BrownianPath tree mode: what ComfyUI's BrownianTree is up to its tolerance): an increment is
-    the same BITS after any history -- a run with other step counts, a sampler made half way through a run, the other order -- where
-    the default path of bridges is only self-consistent per instance; still N(0, 1), additive over abutting intervals, and the
-    module switch / environment default reach the registry's generator."""
+    """The virtual Brownian tree (BrownianPath tree mode, the default: what ComfyUI's BrownianTree is up to its tolerance): an increment
+    is the same BITS after any history -- a run with other step counts, a sampler made half way through a run, the other order --
+    where the path of bridges (depth 0) is only self-consistent per instance; still N(0, 1), additive over abutting intervals, and the
+    module switch reaches the registry's generator."""
     NG = api.noise_generation
     x = torch.zeros(2, 4, 64, 64, device="cuda")
     s = lambda v: torch.tensor(v)  # noqa: E731
@@ -339,14 +339,17 @@ def test_brownian_tree_mode_does_not_depend_on_the_query_history(api, monkeypatc
     for a in (steps_fine[0], steps_fine[9], steps_coarse[2]):
         assert abs(a.mean().item()) < 5 / math.sqrt(n) and abs(a.var().item() - 1.0) < 15 / math.sqrt(n)
     assert abs((steps_fine[2] * steps_fine[3]).mean().item()) < 5 / math.sqrt(n)
-    # the default (depth 0) is a function of the history: the same query after another history gives other values
+    # the path of bridges (depth 0) is a function of the history: the same query after another history gives other values
     d1, d2 = mk(0), mk(0)
     d1(s(10.0), s(6.0))
     assert not torch.equal(d1(s(8.0), s(7.0)), d2(s(8.0), s(7.0)))
-    # the switch: samplers made while it is set are trees
+    # the registry's generator follows the module switch: a tree of depth 24 unless SONAR_BROWNIAN_TREE says otherwise
     monkeypatch.setattr(NG, "BROWNIAN_TREE_DEPTH", 24)
     ns = api.noise.get_noise_sampler("brownian", x, 0.03, 14.6, seed=99, cpu=False, normalized=False)
     assert torch.equal(ns(s(sig[7]), s(sig[8])), steps_fine[7])
+    assert NG.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=99).path.tree_depth == 24
+    monkeypatch.setattr(NG, "BROWNIAN_TREE_DEPTH", 0)
+    assert NG.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=99).path.tree_depth == 0
     # a chain folds a tree sampler's increments like any other item's
     acc = torch.ones_like(x)
     assert late.accumulate(acc, 0.5, 2.0, None, s(sig[7]), s(sig[8]))
