@@ -31,3 +31,15 @@ want = torch.fft.irfft2(torch.fft.rfft2(xo.double()) * f.double(), s=(128, 128))
 got = hl.spectral_filter(xo, f)
 assert (got.double() - want).abs().max().item() < 2e-6 * want.abs().max().item()
 print("8-byte aligned input ok")
+# ... and an OUTPUT aligned to 8 bytes only, through the C ABI itself (the store pass writes 16 bytes at a time)
+import ctypes as C
+lib = hl.load()
+oflat = torch.zeros(2 * 4 * 128 * 128 + 2, device="cuda")
+o = oflat[2:]
+assert o.data_ptr() % 16 == 8
+fn = lib.sonar_spectral_filter_f32
+fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+assert fn(xo.data_ptr(), f.data_ptr(), o.data_ptr(), 8, 128, 128, None, torch.cuda.current_stream().cuda_stream) == 0
+torch.cuda.synchronize()
+assert torch.equal(o.view(2, 4, 128, 128), got) and float(oflat[:2].abs().sum()) == 0.0
+print("8-byte aligned output ok")
