@@ -371,16 +371,19 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
                 cfg_fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(**params, high_precision_mode=hp))
                 us = event_us(lambda: cfg_fn(wargs), 10, 3)
                 extra[f"wavelet_cfg_{rtag}_{tag}_end_to_end_us"] = us
-                kernels.append(kernel_entry(f"dwt2_tile + wcfg_bands (levels 2-5 resident in LDS) + idwt2_tile kernels, WaveletCFG {rtag.replace('_', ' ')} "
-                                            f"rule, {tag}, batch 256 (end to end)", us, 16 * N_LATENT * b4,
-                                            tr.get(f"wcfg_{rtag}_{tag}_b256", {}).get("hbm_bytes_per_launch")))
-                # the same rule with EVERY band resident in LDS (sonar_wcfg_bands_*: one launch, two for the cond / uncond rule): least traffic,
-                # one or two workgroups per CU -- off by default
-                wc.WaveletCFG.single_launch_bands = True
-                try:
-                    extra[f"wavelet_cfg_{rtag}_{tag}_single_launch_us"] = event_us(lambda: cfg_fn(wargs), 10, 3)
-                finally:
-                    wc.WaveletCFG.single_launch_bands = False
+                single = tag == "fp32"  # WaveletCFG.single_launch_bands = None: by precision (py/wavelet_cfg.py)
+                route = ("wcfg_bands_kernel, every band resident in LDS (one launch; two for the cond / uncond rule)" if single else
+                         "dwt2_tile + wcfg_bands (levels 2-5 resident in LDS) + idwt2_tile kernels")
+                kernels.append(kernel_entry(f"{route}, WaveletCFG {rtag.replace('_', ' ')} rule, {tag}, batch 256 (end to end, the default route)",
+                                            us, 16 * N_LATENT * b4, tr.get(f"wcfg_{rtag}_{tag}_b256", {}).get("hbm_bytes_per_launch")))
+                # both routes forced, whichever is the default: every band resident in LDS (sonar_wcfg_bands_*: least traffic, one or two
+                # workgroups per CU) and level 1 through the tile kernels
+                for forced, key in ((True, "single_launch_us"), (False, "tile_route_us")):
+                    wc.WaveletCFG.single_launch_bands = forced
+                    try:
+                        extra[f"wavelet_cfg_{rtag}_{tag}_{key}"] = event_us(lambda: cfg_fn(wargs), 10, 3)
+                    finally:
+                        wc.WaveletCFG.single_launch_bands = None
             except Exception as exc:  # secondary figure only
                 extra[f"wavelet_cfg_{rtag}_{tag}_error"] = repr(exc)[:200]
     # cfg5: one rank's shard (128 Flux latents), scheduled power + Perlin + Brownian chain, SonarDPMPPSDE with momentum, per step

@@ -41,6 +41,18 @@ struct BandsArgs {
     TapsSmall<T> dec, rec;
 };
 
+#ifndef SONAR_BANDS_STAGE_AHEAD
+#define SONAR_BANDS_STAGE_AHEAD 4  // values per thread of the last stage's NEXT tile requested a tile ahead (0: a tile's loads at its own start)
+#endif
+#ifndef SONAR_BANDS_ROWS_AHEAD
+#define SONAR_BANDS_ROWS_AHEAD 1  // level 1 down: the next item's rows requested an item ahead (0: every item waits for its own loads)
+#endif
+#ifdef SONAR_BANDS_TRACE  // profiling builds (scratch/bands_trace.py): thread 0's cycle stamps of the first plane of every workgroup
+__device__ unsigned long long g_bands_trace[512 * 32];
+#define SONAR_BANDS_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && p == (int64_t)blockIdx.x) g_bands_trace[blockIdx.x * 32 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SONAR_BANDS_STAMP(slot) do { } while (0)
+#endif
 template <int NT>
 struct WalkN {
     int r, c, dr, dc;
@@ -64,7 +76,9 @@ struct alignas(2 * sizeof(TIO)) Pair2 {
 
 // ZERO: the analysis extension is zero padding -- the only mode whose tables hold "no source" entries (-1); every other mode reads a real
 // sample for every tap, and its taps carry no clamp and no select (the kernel is instruction-bound: a third of a tap's instructions)
-template <typename T, typename TIO, int FT, int NT, bool ZERO>
+// AHEAD: level 1 down requests an item's rows an item ahead (2 NRS more registers per thread: chosen by the launcher when LDS, not
+// registers, decides how many workgroups a CU holds)
+template <typename T, typename TIO, int FT, int NT, bool ZERO, bool AHEAD = false>
 __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ ta, const TIO* __restrict__ tb, const TIO* xin, TIO* out,
                                                         BandsArgs<T> a) {
     auto at0 = [](int s) { return ZERO ? max(s, 0) : s; };                       // index of a tap's sample
@@ -91,6 +105,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
         const TIO* pa = ta + p * (int64_t)H * W;
         const TIO* pb = tb ? tb + p * (int64_t)H * W : nullptr;
         __syncthreads();  // tables are built; the previous plane's readers are done
+        SONAR_BANDS_STAMP(0);
         // ---------------------------------------------------------------- level 1 down: v = a - b from global, along H in registers, along W out of LDS
         {
             T* const ll1 = lds + a.off_ll[1];
@@ -102,15 +117,44 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             T* const tmp1 = lds + a.off_tmp1;
             for (int y0 = 0; y0 < h1; y0 += a.rows1) {
                 const int th = min(a.rows1, h1 - y0);
-                for (WalkN<NT> wk(tid, W); wk.r * THS < th; wk.next(W)) {
+                // An item's NRS rows come straight from global memory; a thread walks ~4 items per tile and used to wait for each item's loads in
+                // turn (`scratch/bands_trace.py`: this stage is a third of a plane's time in the single-launch kernel).  Round 5: the NEXT item's
+                // values are requested before this one's are filtered -- unconditionally (a thread's last item asks for itself again), so
+                // that the loaded registers never merge with old values in a waiting copy.
+                // (2 NRS more registers per thread: an instantiation of its own, launched when at most two workgroups fit a CU's LDS anyway --
+                // with the smaller footprints of rules without a cV band, or of the tile route's deeper levels, they cost a resident workgroup:
+                // 208 -> 277 us on the pair rule)
+                constexpr bool kRowsAhead = AHEAD;
+                TIO na[kRowsAhead ? NRS : 1], nb[kRowsAhead ? NRS : 1];
+                auto request_rows = [&](int sub, int x) {
+#pragma unroll
+                    for (int r = 0; r < NRS; ++r) {
+                        const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h1 + FT - 3)];
+                        const int at = at0(sy) * W + x;
+                        na[r] = pa[at];
+                        nb[r] = pb ? pb[at] : TIO(0);
+                    }
+                };
+                WalkN<NT> wk(tid, W);
+                if (kRowsAhead && wk.r * THS < th) request_rows(wk.r, wk.c);
+                for (; wk.r * THS < th;) {
                     const int sub = wk.r, x = wk.c;
                     T v[NRS];
 #pragma unroll
                     for (int r = 0; r < NRS; ++r) {
                         const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h1 + FT - 3)];
-                        const int at = at0(sy) * W + x;
-                        const T d = pb ? (T)pa[at] - (T)pb[at] : (T)pa[at];
-                        v[r] = live(sy, d);
+                        if constexpr (kRowsAhead) {
+                            v[r] = live(sy, (T)na[r] - (T)nb[r]);
+                        } else {
+                            const int at = at0(sy) * W + x;
+                            const T d = pb ? (T)pa[at] - (T)pb[at] : (T)pa[at];
+                            v[r] = live(sy, d);
+                        }
+                    }
+                    wk.next(W);
+                    if constexpr (kRowsAhead) {
+                        const bool more = wk.r * THS < th;
+                        request_rows(more ? wk.r : sub, more ? wk.c : x);
                     }
                     T* dst = tmp1 + (x & 1) * Wh + (x >> 1);
 #pragma unroll
@@ -141,6 +185,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                 __syncthreads();
             }
         }
+        SONAR_BANDS_STAMP(1);
         // ---------------------------------------------------------------- deeper levels down: LL_j, cV_j from LL_{j-1}, all in LDS
         for (int j = 2; j <= J; ++j) {
             const int Wp = a.W[j - 1], h = a.H[j], w = a.W[j];
@@ -179,6 +224,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                 if (want_v) dcv[yo * w + xo] = hi;
             }
             __syncthreads();
+            SONAR_BANDS_STAMP(j);
         }
         // ---------------------------------------------------------------- top: B_J = (l - a_h^J) LL_J
         {
@@ -186,6 +232,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             const T gJ = a.yl - a.ah[J];
             for (int it = tid; it < a.H[J] * a.W[J]; it += NT) top[it] *= gJ;
             __syncthreads();
+            SONAR_BANDS_STAMP(8);
         }
         // ---------------------------------------------------------------- way up: B_{j-1} = (a_d^j - a_h^{j-1}) LL_{j-1} + S^W_lo[(a_h - a_d) lowW + S^H_lo B_j] + S^W_hi[(a_v - a_d) S^H_lo cV_j]
         for (int j = J; j >= 2; --j) {
@@ -241,6 +288,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                 }
                 __syncthreads();
             }
+            SONAR_BANDS_STAMP(8 + (J - j + 1));
         }
         // ---------------------------------------------------------------- level 1 up + the elementwise tail, straight to global
         {
@@ -254,14 +302,39 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             const int wp = (W + 1) >> 1;
             T* const tA = tmp;
             T* const tB = tmp + a.rows_out * w1;
+            // The tile's rows of (a, b) are read once, used for lowW, for a_d v and for ku b.  Round 5: a thread's first kStageAhead values of
+            // the NEXT tile are requested while this one is synthesised -- the stage sat behind its own loads at the top of every tile
+            // (`scratch/bands_trace.py`: this stage is 46 % of a plane's time in the single-launch kernel, 42 % in the deeper levels' call).
+            // The request is unconditional (the last tile asks for itself again, from L2): under a condition the loaded registers would
+            // merge with their old values in a copy that waits for the loads on the spot (see spectral_filter128_kernel).
+            constexpr int KP = SONAR_BANDS_STAGE_AHEAD;
+            [[maybe_unused]] In2 pre[KP > 0 ? KP : 1];
+            // (Measured and dropped: the x pairs the tail subtracts from, requested the same way -- the tail's item loop then keeps 70 more
+            // registers alive and a CU holds one workgroup instead of two: 198 -> 310 us.)
+            auto request = [&](int y0n) {
+                const int lim = min(a.rows_out, H - y0n) * W;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    const int it = tid + k * NT, at = y0n * W + (it < lim ? it : 0);
+                    pre[k] = In2{pa[at], pb ? pb[at] : TIO(0)};
+                }
+            };
+            if constexpr (KP > 0) request(0);
             for (int y0 = 0; y0 < H; y0 += a.rows_out) {
                 const int th = min(a.rows_out, H - y0);
-                // the tile's rows of (a, b): read once here, used for lowW, for a_d v and for ku b
-                for (int it = tid; it < th * W; it += NT) {
+                if constexpr (KP > 0) {
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const int it = tid + k * NT;
+                        if (it < th * W) cu[it] = pre[k];
+                    }
+                }
+                for (int it = tid + KP * NT; it < th * W; it += NT) {
                     const int at = y0 * W + it;
                     cu[it] = In2{pa[at], pb ? pb[at] : TIO(0)};
                 }
                 __syncthreads();
+                if constexpr (KP > 0) request(y0 + a.rows_out < H ? y0 + a.rows_out : y0);
                 for (WalkN<NT> wk(tid, w1); 2 * wk.r < th; wk.next(w1)) {
                     const int mp = wk.r, xo = wk.c, m = (y0 >> 1) + mp;
                     T e, o, e2 = T(0), o2 = T(0);
@@ -317,6 +390,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                 __syncthreads();
             }
         }
+        SONAR_BANDS_STAMP(16);
     }
 }
 
@@ -368,16 +442,50 @@ static bool bands_plan(BandsArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W,
         return (size_t)a.off_maps + (size_t)ints * sizeof(int);
     };
     auto per_cu = [](size_t bytes) { return (160 * 1024) / (bytes + 512); };
+    static const int forced_rows = [] { const char* e = getenv("SONAR_BANDS_ROWS_OUT"); return e ? atoi(e) : 0; }();  // (experiments)
+    if (forced_rows > 0) {
+        lds_bytes = layout(forced_rows);
+        return lds_bytes <= budget;
+    }
+    // Output rows per tile of the last stage.  First what LDS allows: shorter tiles when they buy another resident workgroup.  Then, among
+    // the heights that keep that many workgroups resident, the one whose item counts waste the fewest rounds of the workgroup's threads
+    // (round 5): the stage's second phase has (rows / 2) x W1 items, its third rows x ceil(W / 2), each a dependent chain of LDS reads
+    // -- 16 rows of a 128 x 128 plane (db4: W1 = 67) are 536 items for 512 threads, TWO rounds for 24 items' sake, where 14 rows are one:
+    // single-launch rules 180 -> 169 us, 209 -> 199 us; the deeper levels of the tile route (67-row planes, W1 = 37) take 24 rows.
     const size_t tall = layout(kLowRows), low = layout(kLowRows / 2);
-    lds_bytes = per_cu(low) > per_cu(tall) ? low : layout(kLowRows);  // shorter output tiles when they buy another resident workgroup
+    const size_t want_cu = std::max(per_cu(low), per_cu(tall));
+    const int nt = sizeof(T) == 8 && io_size == 4 && want_cu <= 1 ? 1024 : 512;  // (wcfg_bands: whole latent planes in fp64 take 1024 threads)
+    int best_rows = per_cu(low) > per_cu(tall) ? kLowRows / 2 : kLowRows;
+    double best_cost = 1e30;
+    for (int r = 8; r <= 40; r += 2) {
+        if (layout(r) > budget || per_cu(layout(r)) < want_cu) continue;
+        const int tiles = ((int)H + r - 1) / r, items2 = (r / 2) * a.W[1], items3 = r * (((int)W + 1) / 2);
+        const double cost = tiles * (2.0 * ((items2 + nt - 1) / nt) + 1.0 * ((items3 + nt - 1) / nt) + 1.5);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best_rows = r;
+        }
+    }
+    lds_bytes = layout(best_rows);
     return lds_bytes <= budget;
 }
 
-template <typename T, typename TIO, int FT, int NT, bool ZERO>
-static void launch_bands_z(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
-    auto kern = wcfg_bands_kernel<T, TIO, FT, NT, ZERO>;
+constexpr bool bands_rows_ahead_ok(size_t io_size, int ft) { return SONAR_BANDS_ROWS_AHEAD && io_size == 4 && ft <= 10; }  // (12 taps spill at the 1024-thread instantiation's 128 registers)
+template <typename T, typename TIO, int FT, int NT, bool ZERO, bool AHEAD = false>
+static void launch_bands_za(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
+    auto kern = wcfg_bands_kernel<T, TIO, FT, NT, ZERO, AHEAD>;
     if (lds > 64 * 1024) lds_attr(reinterpret_cast<const void*>(kern), 160 * 1024);  // dynamic LDS above the 64 KB default: once per kernel and device
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ta, tb, x, out, a);
+}
+template <typename T, typename TIO, int FT, int NT, bool ZERO>
+static void launch_bands_z(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
+    if constexpr (bands_rows_ahead_ok(sizeof(TIO), FT)) {
+        if (3 * (lds + 512) > 160 * 1024) {  // at most two workgroups fit a CU's LDS: eight waves per SIMD at most, 128 registers each
+            launch_bands_za<T, TIO, FT, NT, ZERO, true>(grid, lds, st, ta, tb, x, out, a);
+            return;
+        }
+    }
+    launch_bands_za<T, TIO, FT, NT, ZERO, false>(grid, lds, st, ta, tb, x, out, a);
 }
 template <typename T, typename TIO, int FT, int NT>
 static void launch_bands(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {

@@ -54,3 +54,9 @@ extern "C" int sonar_wcfg_bands_f64(const float* a, const float* b, const float*
     return wcfg_bands<double, float>(a, b, x, out, planes, H, W, levels, dec_lo, dec_hi, rec_lo, rec_hi, flen, mode_fwd, mode_inv, yh_scales, yl_scale,
                                      ku, kt, subtract_from_x, (hipStream_t)stream, "sonar_wcfg_bands_f64");
 }
+
+#ifdef SONAR_BANDS_TRACE
+extern "C" int sonar_debug_bands_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sonar::g_bands_trace), sizeof(sonar::g_bands_trace));
+}
+#endif

@@ -618,7 +618,15 @@ def _reconstructs(w) -> bool:
 class WaveletCFG:
     """py/wavelet_cfg.py:626-842 — a ComfyUI ``sampler_cfg_function``."""
 
-    single_launch_bands = False  # see __call__, fast path 1
+    # Rules that need the coefficient bands: the single-launch kernel with every band resident in LDS (fast path 1: 1.14 x the step's
+    # 16N bytes of traffic) or level 1 in tile launches + the deeper levels resident (fast path 2: 2.2-2.9 x).  None: by precision --
+    # fp32 arithmetic takes the single-launch kernel (round 5: as fast as the tiles on difference-only rules, 12 % faster on rules that
+    # also scale cond / uncond, at half the traffic), fp64 the tiles (its planes leave a CU one workgroup: 247 against 232 us).  True /
+    # False force a route (bench.py and the tests time and check both).
+    single_launch_bands = None
+
+    def _bands_first(self, ctx) -> bool:
+        return ctx.dtype == torch.float32 if self.single_launch_bands is None else bool(self.single_launch_bands)
 
     def __init__(self, *, existing_cfg: Optional[Callable], rules: WCFGRules, operation_cond=None, operation_uncond=None,
                  operation_fallback_cfg=None, operation_wavelet_cfg=None, operation_result=None):
@@ -817,7 +825,7 @@ class WaveletCFG:
             if launch is not None:
                 result = launch()
             else:
-                result = self.wavelet_cfg_bands(rule=rule, ctx=ctx, pcts=None) if self.single_launch_bands else None
+                result = self.wavelet_cfg_bands(rule=rule, ctx=ctx, pcts=None) if self._bands_first(ctx) else None
                 if result is None:
                     result = self.wavelet_cfg_fused(rule=rule, ctx=ctx, pcts=None)
         except Exception:  # noqa: BLE001 -- reported by the ordinary path, in the reference's order
@@ -941,10 +949,10 @@ class WaveletCFG:
             low = self.wavelet_cfg_lowpass(rule=rule, ctx=ctx, pcts=pcts)
             if low is not None:
                 return self.maybe_op(low, self.operation_result, **ctx.op_kwargs).contiguous()
-            # fast path 1 (off by default, `single_launch_bands`): any scale tables with ALL coefficient bands resident in LDS -- one launch
-            # for difference-only rules, two otherwise.  Least HBM traffic, but a plane's coefficients fill half a CU's LDS and the
-            # launch runs at one or two workgroups per CU: measured slower than fast path 2 at SDXL size
-            if self.single_launch_bands:
+            # fast path 1 (`single_launch_bands`: the default with fp32 arithmetic): any scale tables with ALL coefficient bands resident in
+            # LDS -- one launch for difference-only rules, two otherwise.  Least HBM traffic, but a plane's coefficients fill half a CU's
+            # LDS and the launch runs at one or two workgroups per CU: slower than fast path 2 in fp64 at SDXL size
+            if self._bands_first(ctx):
                 bands = self.wavelet_cfg_bands(rule=rule, ctx=ctx, pcts=pcts)
                 if bands is not None:
                     return self.maybe_op(bands, self.operation_result, **ctx.op_kwargs).contiguous()

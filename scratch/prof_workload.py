@@ -57,7 +57,7 @@ for hp in (True, False):
     for k in (("bands_difference", "bands_pair") if hp else ()):
         fn = wc.WaveletCFG(existing_cfg=None, rules=wc.WCFGRules.build(**rules[k], high_precision_mode=hp))
         for _ in range(REPS): fn(wargs)
-    wc.WaveletCFG.single_launch_bands = False
+    wc.WaveletCFG.single_launch_bands = None
     torch.cuda.synchronize()
 del cond, uncond, xin, wargs
 # cfg5's Brownian source on one rank's shard (128 Flux latents): one new path point per call, bridged between kept tensors; then the

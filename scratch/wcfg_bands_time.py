@@ -38,7 +38,7 @@ for tag, params in rules.items():
             outs.append(fn(args).clone())
             wall, ev = timed(lambda: fn(args))
             row.append(f"{path} {ev:6.1f} us (wall {wall:6.1f})")
-        wc.WaveletCFG.single_launch_bands = False
+        wc.WaveletCFG.single_launch_bands = None
         hl.load().sonar_wcfg_hi_storage(1)
         err = (outs[0] - outs[1]).abs().max().item() / outs[1].abs().max().item()
         print(f"{tag:22s} {'fp64' if hp else 'fp32'}: " + " | ".join(row) + f" | max rel diff {err:.1e}", flush=True)

@@ -220,6 +220,7 @@ def test_wavelet_cfg_fused_equals_per_pass_path(api, monkeypatch, high_precision
             "sigma": torch.full((3,), 7.0, device="cuda"), "model": FakeModel(), "model_options": MODEL_OPTIONS}
     fn = api.wc.WaveletCFG(existing_cfg=None, rules=api.wc.WCFGRules.build(**params))
     monkeypatch.setattr(api.wc.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))  # this test is about the band kernels
+    monkeypatch.setattr(api.wc.WaveletCFG, "single_launch_bands", False)  # ... of the tile route (fp32's default is the single-launch kernel)
     calls = []
     real = api.hl.FusedCall.__call__
     monkeypatch.setattr(api.hl.FusedCall, "__call__", lambda self, *a: calls.append(1) or real(self, *a))
@@ -291,7 +292,9 @@ def test_lowpass_path_equals_band_path(api, monkeypatch, wave, mode, level, shap
     ("db4", "zero", 5, (1, 4, 128, 128))])
 def test_difference_route_equals_pair_route(api, monkeypatch, wave, mode, level, shape, high_precision):
     """Difference-only rules with per-orientation scales: ``sonar_wcfg_fused_*`` transforms cond - uncond alone when the wavelet pair
-    reconstructs (perfect_reconstruction = 1) and must agree with the route that transforms cond and uncond side by side."""
+    reconstructs (perfect_reconstruction = 1) and must agree with the route that transforms cond and uncond side by side.  (The tile
+    route forced: with fp32 arithmetic the default is the single-launch kernel, WaveletCFG.single_launch_bands.)"""
+    monkeypatch.setattr(api.wc.WaveletCFG, "single_launch_bands", False)
     torch.manual_seed(11)
     cond, uncond, x = (torch.randn(shape, device="cuda") for _ in range(3))
     args = {"input": x, "cond_scale": 7.0, "cond": x - cond, "uncond": x - uncond, "cond_denoised": cond, "uncond_denoised": uncond,

@@ -151,10 +151,12 @@ def test_band_kernel_is_taken_where_it_applies():
 
 @pytest.mark.parametrize("name", FOUR_D)
 def test_wavelet_cfg_tile_kernels_match_reference(api, name, monkeypatch):
-    """Low-pass shortcut disabled, the default route for rules that need the bands: level 1 by the tile kernels through the workspace,
-    the deeper levels by the LDS-resident kernel where the wavelet pair reconstructs (sonar_wcfg_fused_*, 3 launches; 4 for cond /
-    uncond rules), by the old per-level walk elsewhere."""
+    """Low-pass shortcut disabled, the tile route forced (the default route for rules that need the bands in fp64 arithmetic; fp32 takes
+    the single-launch kernel of the test above unless told otherwise: WaveletCFG.single_launch_bands): level 1 by the tile kernels through
+    the workspace, the deeper levels by the LDS-resident kernel where the wavelet pair reconstructs (sonar_wcfg_fused_*, 3 launches; 4
+    for cond / uncond rules), by the old per-level walk elsewhere."""
     monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "_lowpass_launch", classmethod(lambda cls, **_k: None))
+    monkeypatch.setattr(api.wavelet_cfg.WaveletCFG, "single_launch_bands", False)
     case = wc.WCFG_CASES[name]
     args = wh.wcfg_args(case, name, wc.FakeModel(), device="cuda")
     want = WCFG[f"{name}__out"]
