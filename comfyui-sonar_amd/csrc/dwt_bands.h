@@ -50,8 +50,13 @@ struct BandsArgs {
 #ifdef SONAR_BANDS_TRACE  // profiling builds (scratch/bands_trace.py): thread 0's cycle stamps of the first plane of every workgroup
 __device__ unsigned long long g_bands_trace[512 * 32];
 #define SONAR_BANDS_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && p == (int64_t)blockIdx.x) g_bands_trace[blockIdx.x * 32 + (slot)] = __builtin_readcyclecounter(); } while (0)
+// the last stage's three phases, summed over its tiles into slots 20 .. 22
+#define SONAR_BANDS_LAP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && p == (int64_t)blockIdx.x) { const unsigned long long now_ = __builtin_readcyclecounter(); g_bands_trace[blockIdx.x * 32 + (slot)] = (y0 == 0 ? 0ull : g_bands_trace[blockIdx.x * 32 + (slot)]) + (now_ - lap_); lap_ = now_; } } while (0)
+#define SONAR_BANDS_LAP_BEGIN() unsigned long long lap_ = __builtin_readcyclecounter()
 #else
 #define SONAR_BANDS_STAMP(slot) do { } while (0)
+#define SONAR_BANDS_LAP(slot) do { } while (0)
+#define SONAR_BANDS_LAP_BEGIN() do { } while (0)
 #endif
 template <int NT>
 struct WalkN {
@@ -309,8 +314,9 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             // merge with their old values in a copy that waits for the loads on the spot (see spectral_filter128_kernel).
             constexpr int KP = SONAR_BANDS_STAGE_AHEAD;
             [[maybe_unused]] In2 pre[KP > 0 ? KP : 1];
-            // (Measured and dropped: the x pairs the tail subtracts from, requested the same way -- the tail's item loop then keeps 70 more
-            // registers alive and a CU holds one workgroup instead of two: 198 -> 310 us.)
+            // (Measured and dropped, twice: the x pairs the tail subtracts from, requested a tile ahead -- selected by item number inside the
+            // tail's loop they keep 70 more registers alive and a CU holds one workgroup instead of two: 198 -> 310 us -- or a phase ahead
+            // with the first two items peeled off the loop: 30-40 more registers, 171 -> 240 us.)
             auto request = [&](int y0n) {
                 const int lim = min(a.rows_out, H - y0n) * W;
 #pragma unroll
@@ -320,6 +326,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                 }
             };
             if constexpr (KP > 0) request(0);
+            SONAR_BANDS_LAP_BEGIN();
             for (int y0 = 0; y0 < H; y0 += a.rows_out) {
                 const int th = min(a.rows_out, H - y0);
                 if constexpr (KP > 0) {
@@ -334,6 +341,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     cu[it] = In2{pa[at], pb ? pb[at] : TIO(0)};
                 }
                 __syncthreads();
+                SONAR_BANDS_LAP(20);
                 if constexpr (KP > 0) request(y0 + a.rows_out < H ? y0 + a.rows_out : y0);
                 for (WalkN<NT> wk(tid, w1); 2 * wk.r < th; wk.next(w1)) {
                     const int mp = wk.r, xo = wk.c, m = (y0 >> 1) + mp;
@@ -362,6 +370,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     }
                 }
                 __syncthreads();
+                SONAR_BANDS_LAP(21);
                 for (WalkN<NT> wk(tid, wp); wk.r < th; wk.next(wp)) {
                     const int yl = wk.r, m = wk.c;
                     const T* ra = tA + yl * w1;
@@ -388,6 +397,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     }
                 }
                 __syncthreads();
+                SONAR_BANDS_LAP(22);
             }
         }
         SONAR_BANDS_STAMP(16);

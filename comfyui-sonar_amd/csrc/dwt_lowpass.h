@@ -380,6 +380,25 @@ static bool lowpass_plan(LowArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W,
     const int ws1 = 2 * (((int)W + 1) / 2);
     a.rows1 = std::max(kLowRows, std::min((a.H[1] + 3) / 4 * 4, (at - a.off_tmp1) / ws1 / 4 * 4));
     a.rows_out = std::max(kLowRows, std::min(((int)H + 1) / 2 * 2, (tmp / a.W[1] - 1) / 2 * 2));
+    // ... and of the heights the scratch holds, the one whose phases waste the fewest rounds of the workgroup's threads (round 5, as in
+    // dwt_bands.h's plan): the synthesis along H has (rows / 2) x W1 items, the pass along W rows x W / 4 -- 36 rows of a 128 x 128 plane
+    // (db4) are 1206 and 1152 items for 512 threads, three rounds each; 30 rows are two (fp32 85.3 -> 83.3 us, fp64 92.5 -> 89.7 us)
+    static const int forced_rows = [] { const char* e = getenv("SONAR_LOW_ROWS_OUT"); return e ? atoi(e) : 0; }();  // (experiments: at most the scratch's)
+    if (forced_rows > 0) {
+        a.rows_out = std::min(a.rows_out, std::max(2, forced_rows / 2 * 2));
+    } else {
+        int best = a.rows_out;
+        long best_cost = -1;
+        for (int r = a.rows_out; r >= kLowRows; r -= 2) {
+            const long tiles = ((int)H + r - 1) / r, items2 = (long)(r / 2) * a.W[1], items3 = (long)r * (((int)W + 3) / 4);
+            const long cost = tiles * ((items2 + kLowThreads - 1) / kLowThreads + (items3 + kLowThreads - 1) / kLowThreads + 1);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best = r;
+            }
+        }
+        a.rows_out = best;
+    }
     a.off_maps = (int)(((size_t)at * sizeof(T) + 15) / 16 * 16);
     lds_bytes = (size_t)a.off_maps + (size_t)ints * sizeof(int);
     return lds_bytes <= 80 * 1024;  // two workgroups per CU

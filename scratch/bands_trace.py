@@ -30,4 +30,5 @@ for hp in (False, True):
         for a_, b_ in zip(order[:-1], order[1:]):
             print(f"   {names[b_]:24s} {np.mean(t[:, b_] - t[:, a_]):9.0f}")
         print(f"   {'whole plane':24s} {np.mean(t[:, 16] - t[:, 0]):9.0f}")
+        print(f"   last stage by phase, summed over its tiles: stage the tile's rows {np.mean(t[:, 20]):.0f}, along H + lowW {np.mean(t[:, 21]):.0f}, along W + tail + stores {np.mean(t[:, 22]):.0f}")
 wc.WaveletCFG.single_launch_bands = None
