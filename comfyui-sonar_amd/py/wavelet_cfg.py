@@ -618,11 +618,12 @@ def _reconstructs(w) -> bool:
 class WaveletCFG:
     """py/wavelet_cfg.py:626-842 — a ComfyUI ``sampler_cfg_function``."""
 
-    # Rules that need the coefficient bands: the single-launch kernel with every band resident in LDS (fast path 1: 1.14 x the step's
+    # Rules that need the coefficient bands: the single-launch kernel with every band resident in LDS (fast path 1: 1.1-2.0 x the step's
     # 16N bytes of traffic) or level 1 in tile launches + the deeper levels resident (fast path 2: 2.2-2.9 x).  None: by precision --
-    # fp32 arithmetic takes the single-launch kernel (round 5: as fast as the tiles on difference-only rules, 12 % faster on rules that
-    # also scale cond / uncond, at half the traffic), fp64 the tiles (its planes leave a CU one workgroup: 247 against 232 us).  True /
-    # False force a route (bench.py and the tests time and check both).
+    # fp32 arithmetic takes the single-launch kernel (round 5: 8 % faster than the tiles on difference-only rules, 12 % on rules that
+    # also scale cond / uncond, at 1.5 x / 2.0 x of 16N instead of 2.3 x / 2.2 x), fp64 the tiles (its planes leave a CU one workgroup:
+    # 231 against 223-233 us on difference rules, 331 against 275 on the others).  True / False force a route (bench.py and the tests
+    # time and check both).
     single_launch_bands = None
 
     def _bands_first(self, ctx) -> bool:

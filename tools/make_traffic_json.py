@@ -65,8 +65,21 @@ def main(path):
         out[f"wcfg_lowpass_{tag}_b256"] = dict(low, algorithmic_bytes_16N=4 * 256 * N, ratio_to_16N=round(low["hbm_bytes_per_launch"] / (4 * 256 * N), 2),
                                                note="cond and uncond are read twice (analysis, then the output phase); the second read mostly comes out of the "
                                                     "256 MB memory-side cache: removing it (profiling build) saves 8-10 us of the kernel's time")
-        # round 4: the deeper levels run in wcfg_bands_kernel<T, T> (coefficients resident in LDS) -- once for difference-only rules, twice
-        # (A . DWT(cond) + B . DWT(uncond)) for rules that scale cond / uncond / final as well
+        if T == "float":
+            # round 5: fp32 arithmetic runs the single-launch kernel by default (every band resident in LDS): ONE launch for difference-only rules
+            # (the AHEAD instantiation: LDS leaves it two workgroups per CU), TWO for rules that scale cond / uncond / final as well
+            one = pick(raw, "wcfg_bands_kernel<float, float,", ", true>")
+            two = pick(raw, "wcfg_bands_kernel<float, float,", ", false>")
+            out["wcfg_bands_difference_fp32_b256"] = {"kernels": {"wcfg_bands_kernel<float, float, AHEAD> (one launch)": one},
+                                                      "hbm_bytes_per_launch": total(one), "algorithmic_bytes_16N": 4 * 256 * N,
+                                                      "ratio_to_16N": round(total(one) / (4 * 256 * N), 2),
+                                                      "note": "cond and uncond are read twice (level 1's analysis, then the output stage), like the low-pass kernel's"}
+            out["wcfg_bands_pair_fp32_b256"] = {"kernels": {"wcfg_bands_kernel<float, float> x 2 (B . DWT(uncond) into out, then A . DWT(cond))": dict(two, launches=2)},
+                                                "hbm_bytes_per_launch": 2 * total(two), "algorithmic_bytes_16N": 4 * 256 * N,
+                                                "ratio_to_16N": round(2 * total(two) / (4 * 256 * N), 2)}
+            continue
+        # fp64 arithmetic: level 1 by the tile kernels, the deeper levels in wcfg_bands_kernel<T, T> (coefficients resident in LDS) -- once for
+        # difference-only rules, twice (A . DWT(cond) + B . DWT(uncond)) for rules that scale cond / uncond / final as well
         deep = pick(raw, f"wcfg_bands_kernel<{T}, {T},")
         for route, mode, ndeep in (("bands_difference", "2", 1), ("bands_pair", "1", 2)):
             ks = {"dwt2_tile_kernel (level 1 analysis)": pick(raw, f"dwt2_tile_kernel<{T}, float, {mode},"),
@@ -75,12 +88,10 @@ def main(path):
             tot = int(sum(v["hbm_bytes_per_launch"] * v.get("launches", 1) for v in ks.values()))
             out[f"wcfg_{route}_{tag}_b256"] = {"kernels": ks, "hbm_bytes_per_launch": tot, "algorithmic_bytes_16N": 4 * 256 * N,
                                                "ratio_to_16N": round(tot / (4 * 256 * N), 2)}
-        if T == "float":
-            continue  # the fp32 single-launch kernel is the deep kernel's instantiation (<float, float>): the workload runs it in fp64 only
         one = pick(raw, f"wcfg_bands_kernel<{T}, float,")
         out[f"wcfg_single_launch_bands_{tag}_b256"] = dict(one, algorithmic_bytes_16N=4 * 256 * N, ratio_to_16N=round(one["hbm_bytes_per_launch"] / (4 * 256 * N), 2),
                                                            note="sonar_wcfg_bands_*: every coefficient band resident in LDS, one launch per difference-only rule "
-                                                                "(two for cond / uncond rules; bytes per launch here); off by default -- see DESIGN.md 3.6")
+                                                                "(two for cond / uncond rules; bytes per launch here); fp64's default stays the tile route -- see DESIGN.md 7")
     br = pick(raw, "brownian_burst_kernel<0>")
     out["brownian_bridge_cfg5_shard"] = dict(br, tensor_bytes=128 * 16 * 128 * 128 * 4,
                                              note="128 x 16 x 128 x 128: reads the kept neighbour tensor(s), writes W(t) and the increment (or reads and "
