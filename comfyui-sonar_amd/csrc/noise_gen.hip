@@ -12,8 +12,10 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 #ifdef SONAR_NG_TRACE  // profiling builds: cycle stamps of thread 0 of the first 256 workgroups at the phase boundaries (scratch/ng_trace.py)
 __device__ unsigned long long g_ng_trace[256 * 16];
 #define SONAR_NG_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_ng_trace[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define SONAR_NG_STAMP_T(thread, slot) do { if ((int)threadIdx.x == (thread) && blockIdx.x < 256) g_ng_trace[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define SONAR_NG_STAMP(slot) do { } while (0)
+#define SONAR_NG_STAMP_T(thread, slot) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1003,6 +1005,8 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
         lvl_item0[lv.count] = item;
     }
     __syncthreads();
+    SONAR_NG_STAMP(13);               // (trace builds: the level parameters are in LDS)
+    SONAR_NG_STAMP_T(kBlock, 14);
     if (part != 0 && bid < planes) {
         rng_ahead = rng_stream(seed, stream_id, (uint64_t)t_ahead, lane);
         if constexpr (PRE != 0) prng_ahead = rng_stream(pre.seed, pre.stream_id, (uint64_t)t_ahead, lane);
@@ -1011,6 +1015,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
             if constexpr (PRE != 0) prng_ahead.next();
         }
     }
+    SONAR_NG_STAMP_T(kBlock, 15);     // (trace builds: the second part's generators are stepped ahead)
     if (mode == 0 && part == 0) {
         const int per = W + H;
         for (int j = threadIdx.x; j < lv.count * per; j += kBlock) {
@@ -1201,7 +1206,7 @@ SONAR_PYR_UNROLL
     }
     SONAR_NG_STAMP(8);
 #ifdef SONAR_NG_TRACE  // when each of the waves 1..6 left the tile loop (wave 0 is slot 8)
-    if (lane == 0 && wave >= 1 && wave <= 6 && blockIdx.x < 256) g_ng_trace[blockIdx.x * 16 + 9 + wave] = __builtin_readcyclecounter();
+    if (lane == 0 && wave >= 1 && wave <= 3 && blockIdx.x < 256) g_ng_trace[blockIdx.x * 16 + 9 + wave] = __builtin_readcyclecounter();
 #endif
     if constexpr (STATS) write_partial_at<kPyrBlock>(s, q, partials, red, bid, nblocks);
     SONAR_NG_STAMP(9);

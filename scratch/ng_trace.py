@@ -23,6 +23,8 @@ for B in [int(v) for v in (sys.argv[1:] or ["64"])]:
         deltas = [sum(r[k + 1] - r[k] for r in rows) / n for k in range(9)]
         total = sum(r[9] - r[0] for r in rows) / n
         spread = (max(r[9] for r in rows) - min(r[0] for r in rows))
-        waves = [sum(buf[b * 16 + 9 + w] - buf[b * 16] for b in range(n)) / n for w in range(1, 7)]
-        print("   tile loop left, cycles after start: wave 0 " + f"{sum(r[8] - r[0] for r in rows) / n:.0f}, waves 1-6 " + ", ".join(f"{v:.0f}" for v in waves))
+        waves = [sum(buf[b * 16 + 9 + w] - buf[b * 16] for b in range(n)) / n for w in range(1, 4)]
+        extra = [sum(buf[b * 16 + k] - buf[b * 16] for b in range(n)) / n for k in (13, 14, 15)]
+        print(f"   cycles after start: level parameters in LDS {extra[0]:.0f} (thread 0) / {extra[1]:.0f} (part 1), part 1's generators stepped ahead {extra[2]:.0f}")
+        print("   tile loop left, cycles after start: wave 0 " + f"{sum(r[8] - r[0] for r in rows) / n:.0f}, waves 1-3 " + ", ".join(f"{v:.0f}" for v in waves))
         print(f"B={B} {tag}: " + ", ".join(f"{names[k + 1]} {deltas[k]:.0f}" for k in range(9)) + f" | workgroup total {total:.0f} cycles, first start to last end {spread} (100 MHz counter: x10 ns)")
