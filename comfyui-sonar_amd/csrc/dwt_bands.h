@@ -78,12 +78,21 @@ template <typename TIO>
 struct alignas(2 * sizeof(TIO)) Pair2 {
     TIO x, y;
 };
+// what the last stage keeps of a tile's rows: (a, b), or a alone when there is no second tensor (b reads as zero)
+template <typename TIO>
+struct One1 {
+    TIO x;
+    static constexpr TIO y = TIO(0);
+};
 
 // ZERO: the analysis extension is zero padding -- the only mode whose tables hold "no source" entries (-1); every other mode reads a real
 // sample for every tap, and its taps carry no clamp and no select (the kernel is instruction-bound: a third of a tap's instructions)
 // AHEAD: level 1 down requests an item's rows an item ahead (2 NRS more registers per thread: chosen by the launcher when LDS, not
 // registers, decides how many workgroups a CU holds)
-template <typename T, typename TIO, int FT, int NT, bool ZERO, bool AHEAD = false>
+// TV: storage type of the cV planes (float under fp64 arithmetic when the process stores detail bands in fp32: sonar_wcfg_hi_storage, the
+// deeper levels' call of the tile route).  HASB: a second tensor b (v = a - b, result = ku b + ...); without one the last stage stages single
+// values instead of (a, b) pairs.  Both halve an LDS area: the fp64 deeper-levels call fits a CU four times instead of three (round 5).
+template <typename T, typename TIO, int FT, int NT, bool ZERO, bool AHEAD = false, typename TV = T, bool HASB = true>
 __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ ta, const TIO* __restrict__ tb, const TIO* xin, TIO* out,
                                                         BandsArgs<T> a) {
     auto at0 = [](int s) { return ZERO ? max(s, 0) : s; };                       // index of a tap's sample
@@ -92,7 +101,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
     T* const lds = reinterpret_cast<T*>(bands_smem);
     int* const maps = reinterpret_cast<int*>(bands_smem + a.off_maps);
     using In2 = Pair2<TIO>;
-    In2* const cu = reinterpret_cast<In2*>(bands_smem + a.off_cu);
+    using St = std::conditional_t<HASB, Pair2<TIO>, One1<TIO>>;
+    St* const cu = reinterpret_cast<St*>(bands_smem + a.off_cu);
     T* const tmp = lds + a.off_tmp;
     const int tid = threadIdx.x;
     const int J = a.levels;
@@ -114,7 +124,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
         // ---------------------------------------------------------------- level 1 down: v = a - b from global, along H in registers, along W out of LDS
         {
             T* const ll1 = lds + a.off_ll[1];
-            T* const cv1 = lds + a.off_v[1];
+            TV* const cv1 = reinterpret_cast<TV*>(lds + a.off_v[1]);
             const bool want_v = a.av[1] != a.ad[1];
             const int* const ymap = maps + a.map_h[1];
             const int* const xmap = maps + a.map_w[1];
@@ -185,7 +195,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                         hi = fma_t(a.dec.hi[j], q, hi);
                     }
                     ll1[(y0 + yl) * w1 + xo] = lo;
-                    if (want_v) cv1[(y0 + yl) * w1 + xo] = hi;
+                    if (want_v) cv1[(y0 + yl) * w1 + xo] = (TV)hi;
                 }
                 __syncthreads();
             }
@@ -196,7 +206,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             const int Wp = a.W[j - 1], h = a.H[j], w = a.W[j];
             const T* const src = lds + a.off_ll[j - 1];
             T* const dll = lds + a.off_ll[j];
-            T* const dcv = lds + a.off_v[j];
+            TV* const dcv = reinterpret_cast<TV*>(lds + a.off_v[j]);
             const bool want_v = a.av[j] != a.ad[j];
             const int* const ymap = maps + a.map_h[j];
             const int* const xmap = maps + a.map_w[j];
@@ -226,7 +236,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     hi = fma_t(a.dec.hi[t], q, hi);
                 }
                 dll[yo * w + xo] = lo;
-                if (want_v) dcv[yo * w + xo] = hi;
+                if (want_v) dcv[yo * w + xo] = (TV)hi;
             }
             __syncthreads();
             SONAR_BANDS_STAMP(j);
@@ -243,7 +253,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
         for (int j = J; j >= 2; --j) {
             const int h = a.H[j], w = a.W[j], Ho = a.H[j - 1], Wo = a.W[j - 1];
             const T* const B = lds + a.off_ll[j];
-            const T* const V = lds + a.off_v[j];
+            const TV* const V = reinterpret_cast<const TV*>(lds + a.off_v[j]);
             T* const dst = lds + a.off_ll[j - 1];
             const int* const xmap = maps + a.map_w[j];
             const T c_low = a.ah[j] - a.ad[j], c_v = a.av[j] - a.ad[j], c_x = a.ad[j] - a.ah[j - 1];
@@ -257,7 +267,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     const int mp = wk.r, xo = wk.c, m = (ya >> 1) + mp;
                     T e, o, e2 = T(0), o2 = T(0);
                     synth_low_pair<T, FT>(m, h, a.mode_inv, a.rec.lo, [&](int i) { return B[i * w + xo]; }, e, o);
-                    if (want_v) synth_low_pair<T, FT>(m, h, a.mode_inv, a.rec.lo, [&](int i) { return V[i * w + xo]; }, e2, o2);
+                    if (want_v) synth_low_pair<T, FT>(m, h, a.mode_inv, a.rec.lo, [&](int i) { return (T)V[i * w + xo]; }, e2, o2);
                     const int* xm = xmap + 2 * xo + (FT - 1);
                     const T* r0 = dst + (ya + 2 * mp) * Wo;
                     const bool two = 2 * mp + 1 < th;
@@ -298,7 +308,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
         // ---------------------------------------------------------------- level 1 up + the elementwise tail, straight to global
         {
             const T* const B = lds + a.off_ll[1];
-            const T* const V = lds + a.off_v[1];
+            const TV* const V = reinterpret_cast<const TV*>(lds + a.off_v[1]);
             const TIO* px = a.subtract_from_x ? xin + p * (int64_t)H * W : nullptr;
             TIO* po = out + p * (int64_t)H * W;
             const int* const xmap = maps + a.map_w[1];
@@ -313,7 +323,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             // The request is unconditional (the last tile asks for itself again, from L2): under a condition the loaded registers would
             // merge with their old values in a copy that waits for the loads on the spot (see spectral_filter128_kernel).
             constexpr int KP = SONAR_BANDS_STAGE_AHEAD;
-            [[maybe_unused]] In2 pre[KP > 0 ? KP : 1];
+            [[maybe_unused]] St pre[KP > 0 ? KP : 1];
             // (Measured and dropped, twice: the x pairs the tail subtracts from, requested a tile ahead -- selected by item number inside the
             // tail's loop they keep 70 more registers alive and a CU holds one workgroup instead of two: 198 -> 310 us -- or a phase ahead
             // with the first two items peeled off the loop: 30-40 more registers, 171 -> 240 us.)
@@ -322,7 +332,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
 #pragma unroll
                 for (int k = 0; k < KP; ++k) {
                     const int it = tid + k * NT, at = y0n * W + (it < lim ? it : 0);
-                    pre[k] = In2{pa[at], pb ? pb[at] : TIO(0)};
+                    if constexpr (HASB) pre[k] = St{pa[at], pb ? pb[at] : TIO(0)};
+                    else pre[k] = St{pa[at]};
                 }
             };
             if constexpr (KP > 0) request(0);
@@ -338,7 +349,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                 }
                 for (int it = tid + KP * NT; it < th * W; it += NT) {
                     const int at = y0 * W + it;
-                    cu[it] = In2{pa[at], pb ? pb[at] : TIO(0)};
+                    if constexpr (HASB) cu[it] = St{pa[at], pb ? pb[at] : TIO(0)};
+                    else cu[it] = St{pa[at]};
                 }
                 __syncthreads();
                 SONAR_BANDS_LAP(20);
@@ -347,17 +359,17 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     const int mp = wk.r, xo = wk.c, m = (y0 >> 1) + mp;
                     T e, o, e2 = T(0), o2 = T(0);
                     synth_low_pair<T, FT>(m, h1, a.mode_inv, a.rec.lo, [&](int i) { return B[i * w1 + xo]; }, e, o);
-                    if (want_v) synth_low_pair<T, FT>(m, h1, a.mode_inv, a.rec.lo, [&](int i) { return V[i * w1 + xo]; }, e2, o2);
+                    if (want_v) synth_low_pair<T, FT>(m, h1, a.mode_inv, a.rec.lo, [&](int i) { return (T)V[i * w1 + xo]; }, e2, o2);
                     const int* xm = xmap + 2 * xo + (FT - 1);
                     const bool two = 2 * mp + 1 < th;
-                    const In2* r0 = cu + (2 * mp) * W;
-                    const In2* r1 = two ? r0 + W : r0;
+                    const St* r0 = cu + (2 * mp) * W;
+                    const St* r1 = two ? r0 + W : r0;
                     T l0 = T(0), l1 = T(0);
                     if (c_low != T(0)) {
 #pragma unroll
                         for (int t = 0; t < FT; ++t) {
                             const int sx = xm[-t];
-                            const In2 q0 = r0[at0(sx)], q1 = r1[at0(sx)];
+                            const St q0 = r0[at0(sx)], q1 = r1[at0(sx)];
                             l0 = fma_t(a.dec.lo[t], live(sx, (T)q0.x - (T)q0.y), l0);
                             l1 = fma_t(a.dec.lo[t], live(sx, (T)q1.x - (T)q1.y), l1);
                         }
@@ -380,8 +392,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     else synth_low_pair<T, FT>(m, w1, a.mode_inv, a.rec.lo, [&](int i) { return ra[i]; }, e, o);
                     const int at = (y0 + yl) * W + 2 * m;
                     const bool pair = 2 * m + 1 < W;
-                    const In2 q0 = cu[yl * W + 2 * m];
-                    const In2 q1 = pair ? cu[yl * W + 2 * m + 1] : q0;
+                    const St q0 = cu[yl * W + 2 * m];
+                    const St q1 = pair ? cu[yl * W + 2 * m + 1] : q0;
                     const T r0 = fma_t(a.ku, (T)q0.y, a.kt * fma_t(a_d, (T)q0.x - (T)q0.y, e));
                     const T r1 = fma_t(a.ku, (T)q1.y, a.kt * fma_t(a_d, (T)q1.x - (T)q1.y, o));
                     if (pair && (W & 1) == 0 && a.vec2) {
@@ -407,7 +419,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
 // LDS plan; false when the plane's coefficients do not fit one workgroup (the caller takes the band-by-band kernels)
 template <typename T>
 static bool bands_plan(BandsArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W, int levels, int flen, int mode_fwd, int mode_inv, bool any_v,
-                       size_t io_size = sizeof(float)) {
+                       size_t io_size = sizeof(float), size_t v_size = sizeof(T) /* storage of a cV value */, bool hasb = true /* (a, b) pairs staged */) {
     if (levels < 1 || levels > kLowMaxLevels || !tile_taps_ok(flen) || flen > kDeepTaps || !dims_ok(H, W) || H > 4096 || W > 4096) return false;
     if (flen > 2 && (mode_fwd == kPeriodization) != (mode_inv == kPeriodization)) return false;  // a shifted reconstruction: not the identity used here
     a.levels = levels;
@@ -423,7 +435,7 @@ static bool bands_plan(BandsArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W,
         a.off_ll[j] = at;
         at += a.H[j] * a.W[j];
         a.off_v[j] = at;
-        if (any_v) at += a.H[j] * a.W[j];
+        if (any_v) at += (int)(((size_t)a.H[j] * a.W[j] * v_size + sizeof(T) - 1) / sizeof(T));
         a.map_h[j] = ints;
         ints += 2 * a.H[j] + flen;
         a.map_w[j] = ints;
@@ -432,8 +444,10 @@ static bool bands_plan(BandsArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W,
     // scratch: the deeper levels' H pass (h_j x W_{j-1}), the way up's two channel planes per row tile, the last stage's two channel planes
     const size_t budget = 158 * 1024;
     const int resident = at;
-    auto layout = [&](int rows_out) {
-        int tmp = std::max(rows_out * 2 * a.W[1], kLowRows * 2 * (((int)W + 1) / 2));
+    // lean: without the room for a level-1 analysis tile in the scratch proper -- that tile lies over the deeper levels' planes (off_tmp1) and
+    // `end` below grows when they do not hold it; the shorter scratch means shorter tiles on the way up, so only when it buys a workgroup
+    auto layout = [&](int rows_out, bool lean = false) {
+        int tmp = lean ? rows_out * 2 * a.W[1] : std::max(rows_out * 2 * a.W[1], kLowRows * 2 * (((int)W + 1) / 2));
         for (int j = 2; j <= levels; ++j) tmp = std::max(tmp, a.H[j] * a.W[j - 1]);
         for (int j = 2; j <= levels; ++j) {  // as many rows of the plane below per tile as the scratch the other phases need anyway holds
             const int full = (a.H[j - 1] + 1) / 2 * 2;
@@ -448,7 +462,7 @@ static bool bands_plan(BandsArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W,
         a.rows1 = std::max(kLowRows, std::min((a.H[1] + 3) / 4 * 4, (end - a.off_tmp1) / ws1 / 4 * 4));
         end = std::max(end, a.off_tmp1 + a.rows1 * ws1);
         a.off_cu = (int)(((size_t)end * sizeof(T) + 15) / 16 * 16);
-        a.off_maps = (int)((a.off_cu + (size_t)rows_out * (size_t)W * 2 * io_size + 15) / 16 * 16);
+        a.off_maps = (int)((a.off_cu + (size_t)rows_out * (size_t)W * (hasb ? 2 : 1) * io_size + 15) / 16 * 16);
         return (size_t)a.off_maps + (size_t)ints * sizeof(int);
     };
     auto per_cu = [](size_t bytes) { return (160 * 1024) / (bytes + 512); };
@@ -462,27 +476,73 @@ static bool bands_plan(BandsArgs<T>& a, size_t& lds_bytes, int64_t H, int64_t W,
     // (round 5): the stage's second phase has (rows / 2) x W1 items, its third rows x ceil(W / 2), each a dependent chain of LDS reads
     // -- 16 rows of a 128 x 128 plane (db4: W1 = 67) are 536 items for 512 threads, TWO rounds for 24 items' sake, where 14 rows are one:
     // single-launch rules 180 -> 169 us, 209 -> 199 us; the deeper levels of the tile route (67-row planes, W1 = 37) take 24 rows.
-    const size_t tall = layout(kLowRows), low = layout(kLowRows / 2);
-    const size_t want_cu = std::max(per_cu(low), per_cu(tall));
+    size_t want_cu = 0;
+    for (int lean = 0; lean < 2; ++lean)
+        for (int r : {kLowRows / 2, kLowRows}) want_cu = std::max(want_cu, (size_t)per_cu(layout(r, lean != 0)));
+    // ... and what the registers allow: the 512-thread instantiations take 67-77 of them (six or seven waves per SIMD: three workgroups);
+    // a plan for four pays for them with short tiles and gets three (fp64 deeper levels: 231 against 217 us on the difference rule)
+    static const int cap_cu = [] { const char* e = getenv("SONAR_BANDS_WANT_CU"); return e ? atoi(e) : 3; }();  // (the variable: experiments)
+    if (cap_cu > 0) want_cu = std::min(want_cu, (size_t)cap_cu);
     const int nt = sizeof(T) == 8 && io_size == 4 && want_cu <= 1 ? 1024 : 512;  // (wcfg_bands: whole latent planes in fp64 take 1024 threads)
-    int best_rows = per_cu(low) > per_cu(tall) ? kLowRows / 2 : kLowRows;
+    int best_rows = kLowRows / 2;
+    bool best_lean = true;
     double best_cost = 1e30;
-    for (int r = 8; r <= 40; r += 2) {
-        if (layout(r) > budget || per_cu(layout(r)) < want_cu) continue;
-        const int tiles = ((int)H + r - 1) / r, items2 = (r / 2) * a.W[1], items3 = r * (((int)W + 1) / 2);
-        const double cost = tiles * (2.0 * ((items2 + nt - 1) / nt) + 1.0 * ((items3 + nt - 1) / nt) + 1.5);
-        if (cost < best_cost - 1e-9) {
-            best_cost = cost;
-            best_rows = r;
+    for (int lean = 0; lean < 2; ++lean) {
+        for (int r = 8; r <= 40; r += 2) {
+            const size_t bytes = layout(r, lean != 0);
+            if (bytes > budget || (size_t)per_cu(bytes) < want_cu) continue;
+            const int tiles = ((int)H + r - 1) / r, items2 = (r / 2) * a.W[1], items3 = r * (((int)W + 1) / 2);
+            double cost = tiles * (2.0 * ((items2 + nt - 1) / nt) + 1.0 * ((items3 + nt - 1) / nt) + 1.5);
+            for (int j = 2; j <= levels; ++j) cost += 2.0 * ((a.H[j - 1] + a.rows_up[j] - 1) / a.rows_up[j]);  // the way up's tiles (two phases each)
+            if (cost < best_cost - 1e-9) {
+                best_cost = cost;
+                best_rows = r;
+                best_lean = lean != 0;
+            }
         }
     }
-    lds_bytes = layout(best_rows);
+    if (best_cost > 1e29) return false;
+    lds_bytes = layout(best_rows, best_lean);
+    static const bool plan_debug = getenv("SONAR_BANDS_PLAN_DEBUG") != nullptr;  // (experiments)
+    if (plan_debug)
+        fprintf(stderr, "bands_plan %dx%d T%zu io%zu v%zu hasb%d: rows_out %d lean %d cost %.1f lds %zu per_cu %zu want %zu rows1 %d rows_up %d %d %d\n", (int)H, (int)W,
+                sizeof(T), io_size, v_size, (int)hasb, best_rows, (int)best_lean, best_cost, lds_bytes, (size_t)per_cu(lds_bytes), want_cu, a.rows1, a.rows_up[2],
+                a.rows_up[3], a.rows_up[4]);
     return lds_bytes <= budget;
 }
 
 constexpr bool bands_rows_ahead_ok(size_t io_size, int ft) { return SONAR_BANDS_ROWS_AHEAD && io_size == 4 && ft <= 10; }  // (12 taps spill at the 1024-thread instantiation's 128 registers)
+// what the plan assumed about the kernel's two LDS-halving parameters: the cV planes in fp32 (fp64 arithmetic, coefficient-plane I/O: the
+// tile route's deeper levels, when the process keeps detail bands in fp32), single staged values (no second tensor; coefficient-plane or
+// fp32 I/O -- the fp64 latent kernel holds one workgroup per CU either way and keeps the pair form)
+template <typename T, typename TIO>
+struct BandsForm {
+    bool v_float, hasb;
+    static BandsForm of(const TIO* tb) {
+        constexpr bool same = std::is_same<T, TIO>::value, dbl = std::is_same<T, double>::value;
+        return BandsForm{same && dbl && wcfg_hi_fp32_switch() != 0, !(same && tb == nullptr)};
+    }
+    size_t v_size() const { return v_float ? sizeof(float) : sizeof(T); }
+};
+template <typename T, typename TIO, int FT, int NT, bool ZERO, bool AHEAD, typename TV, bool HASB>
+static void launch_bands_zav(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
+    auto kern = wcfg_bands_kernel<T, TIO, FT, NT, ZERO, AHEAD, TV, HASB>;
+    if (lds > 64 * 1024) lds_attr(reinterpret_cast<const void*>(kern), 160 * 1024);  // dynamic LDS above the 64 KB default: once per kernel and device
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ta, tb, x, out, a);
+}
 template <typename T, typename TIO, int FT, int NT, bool ZERO, bool AHEAD = false>
 static void launch_bands_za(int grid, size_t lds, hipStream_t st, const TIO* ta, const TIO* tb, const TIO* x, TIO* out, const BandsArgs<T>& a) {
+    const BandsForm<T, TIO> form = BandsForm<T, TIO>::of(tb);
+    if constexpr (std::is_same<T, TIO>::value && std::is_same<T, double>::value) {  // coefficient planes in fp64: never a second tensor
+        if (form.hasb) return;  // (wcfg_bands refuses it)
+        if (form.v_float) launch_bands_zav<T, TIO, FT, NT, ZERO, AHEAD, float, false>(grid, lds, st, ta, tb, x, out, a);
+        else launch_bands_zav<T, TIO, FT, NT, ZERO, AHEAD, T, false>(grid, lds, st, ta, tb, x, out, a);
+        return;
+    } else if constexpr (std::is_same<T, TIO>::value) {
+        if (form.hasb) launch_bands_zav<T, TIO, FT, NT, ZERO, AHEAD, T, true>(grid, lds, st, ta, tb, x, out, a);
+        else launch_bands_zav<T, TIO, FT, NT, ZERO, AHEAD, T, false>(grid, lds, st, ta, tb, x, out, a);
+        return;
+    }
     auto kern = wcfg_bands_kernel<T, TIO, FT, NT, ZERO, AHEAD>;
     if (lds > 64 * 1024) lds_attr(reinterpret_cast<const void*>(kern), 160 * 1024);  // dynamic LDS above the 64 KB default: once per kernel and device
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, ta, tb, x, out, a);
@@ -520,7 +580,10 @@ static int wcfg_bands(const TIO* ta, const TIO* tb, const TIO* x, TIO* out, int6
         any_v = any_v || a.av[j] != a.ad[j];
     }
     size_t lds = 0;
-    SONAR_REQUIRE(bands_plan(a, lds, H, W, levels, flen, mode_fwd, mode_inv, any_v, sizeof(TIO)), SONAR_ERR_UNSUPPORTED,
+    const BandsForm<T, TIO> form = BandsForm<T, TIO>::of(tb);
+    SONAR_REQUIRE(!(std::is_same<T, TIO>::value && std::is_same<T, double>::value && tb != nullptr), SONAR_ERR_UNSUPPORTED,
+                  "%s: no second tensor with fp64 coefficient planes", what);
+    SONAR_REQUIRE(bands_plan(a, lds, H, W, levels, flen, mode_fwd, mode_inv, any_v, sizeof(TIO), form.v_size(), form.hasb), SONAR_ERR_UNSUPPORTED,
                   "%s: the plane's coefficients do not fit in LDS (or unsupported filter length / extension pair)", what);
     if (planes == 0) return SONAR_OK;
     a.planes = planes;

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sonar_pkg
 pkg = sonar_pkg.load(); hl = pkg.hip_lib; hl.load()
 wc = importlib.import_module("comfyui_sonar_amd.py.wavelet_cfg")
-b4, C, H, W = 256, 4, 128, 128
+b4, C, H, W = int(os.environ.get("WCFG_BATCH", "256")), 4, 128, 128
 ms = types.SimpleNamespace(sigma_min=torch.tensor(0.03), sigma_max=torch.tensor(14.6), timestep=lambda sg: (
     999 * (1 - (sg.log() - math.log(0.03)) / (math.log(14.6) - math.log(0.03)))).clamp(0, 999))
 cond, uncond, xin = (torch.randn(b4, C, H, W, device="cuda") for _ in range(3))
