@@ -638,6 +638,12 @@ __device__ __forceinline__ void power_stats_any_body(const float* __restrict__ f
 // HN1 x HN2 = H and MN1 x MN2 = W / 2: the factor pairs when the plane size is known at compile time (0: taken from `pl` at run time)
 // SET: the codelets of the run-time switches (HN1 = 0): kSetSmall, or kSetAll for the plane sizes that need a factor of 13 .. 19 and are no
 // bucket (that instantiation spills 5-48 registers; direct sums instead cost those sizes 25-60 % more time than the spills do)
+#ifdef SONAR_ANY_TRACE  // profiling builds (scratch/any_trace.py): thread 0's cycle stamps of a workgroup's planes
+static __device__ unsigned long long g_any_trace[512 * 8 * 8];
+#define SONAR_ANY_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && any_pidx < 8) g_any_trace[(blockIdx.x * 8 + any_pidx) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SONAR_ANY_STAMP(slot) do { } while (0)
+#endif
 template <int NT, int SRC, bool STATS, bool NORM, int HN1 = 0, int HN2 = 0, int MN1 = 0, int MN2 = 0, int SET = kSetSmall>
 __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __restrict__ z, const float* __restrict__ filter,
                                                                        float* out, int64_t planes, AnyPlan pl, uint64_t seed,
@@ -682,7 +688,8 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
         nc = dec.do_sub ? dec.mean * g : 0.0f;
     }
     double s = 0.0, q = 0.0;
-    for (int64_t unit = bid; unit < (split ? planes : planes / group); unit += nblk) {
+    [[maybe_unused]] int any_pidx = 0;  // (trace builds)
+    for (int64_t unit = bid; unit < group_units(planes, group, split); unit += nblk) {  // (split may be the mixed form: power_core.h)
         const GroupWalk gw(unit, group, split);
         SpectrumRng rng;
         if constexpr (SRC == 1) {
@@ -695,6 +702,7 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
         for (int gp = gw.first; gp < gw.first + gw.count; ++gp) {
             const int64_t plane = gw.grp * group + gp;
             __syncthreads();  // previous plane fully consumed (and the twiddle tables visible)
+            SONAR_ANY_STAMP(0);
             // With the sizes known at compile time every LDS address of a plane is loop-invariant and the optimiser hoists them ALL out of
             // the plane loop -- and spills 2-31 registers to hold them.  An opaque copy of the thread index per plane keeps the address
             // arithmetic (now a few constant multiplies) inside the loop, as in the fixed-size kernels (power_fft.hip).
@@ -793,11 +801,15 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
                     A[j] = v;
                 }
             }
+            SONAR_ANY_STAMP(1);
             __syncthreads();
+            SONAR_ANY_STAMP(2);
             // ---- inverse columns: every one of the W/2 + 1 columns, length H
             line_dft<NT, false, HN1, HN2, SET>(A, twH, H, 1, pl.hn1, pl.hn2, S, S, 1, ptid);
+            SONAR_ANY_STAMP(3);
             // ---- rows: c2r pre-twiddle + length-M complex inverse DFT; value m of a row is (x[2m], x[2m+1])
             c2r_rows<NT, MN1, MN2, SET>(A, twW, W, pl.mn1, pl.mn2, H, M, S, pl.c2r_fuse, ptid);
+            SONAR_ANY_STAMP(4);
             float* const oplane = out + plane * (int64_t)H * W;
             float ps = 0.0f, pq = 0.0f;
             if (SONAR_ANY_STORE16 && (M & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {  // uniform
@@ -856,6 +868,8 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
                 s += (double)ps;
                 q += (double)pq;
             }
+            SONAR_ANY_STAMP(5);
+            ++any_pidx;
         }
     }
     if constexpr (STATS) write_partial<NT>(s, q, partials, red);
@@ -913,12 +927,24 @@ static int launch_power_any_t(int what, const float* z, const float* filter, flo
     // resident workgroups: 16 waves per CU at the codelets' 128-register budget -- two 512-thread workgroups when two plane buffers fit
     // (two planes in flight per CU: one's barriers under the other's passes), else one of 1024 threads
     const int per_cu = 2 * (lds + 1024) <= 160 * 1024 ? 2 : 1;
-    const int g = (int)std::min<int64_t>(std::min<int64_t>(units, 256 * per_cu), kNPart);
+    // The plane kernel's units (generate mode): whole groups for the launch's full rounds of workgroups, single planes for what is left
+    // when that is cheaper than a last round of whole groups on a few workgroups (a single-plane unit costs ~1.3 planes: it seeds and
+    // skips).  530 latents of 104 x 152 on 512 workgroups: 2 x 4 plane-times -> 4 + 1.3 (`scratch/any_trace.py`: 14.5 us per plane).
+    int split_main = split;
+    if (group > 1 && !split && what <= 1 && z == nullptr && !ah.next && planes / group < (int64_t)1 << 29) {
+        const int64_t slots = std::min<int64_t>(256 * per_cu, kNPart), G = planes / group, rounds = G / slots, tail = G % slots;
+        if (tail > 0) {
+            const double whole = (double)group, single = 1.3 * (double)((tail * group + slots - 1) / slots);
+            if (single < whole) split_main = 2 + (int)(rounds * slots);
+        }
+    }
+    const int64_t units_main = group_units(planes, group, split_main);
+    const int g = (int)std::min<int64_t>(std::min<int64_t>(units_main, 256 * per_cu), kNPart);
 #define SONAR_PA_NT(NT, G, ST, NM, PART)                                                                                                   \
     do {                                                                                                                                   \
         auto kern = power_irfft2_any_kernel<NT, G, ST, NM, HN1, HN2, MN1, MN2, SET>;                                                                                \
         lds_attr(reinterpret_cast<const void*>(kern), (int)kAnyLdsLimit);                                                                 \
-        hipLaunchKernelGGL(kern, dim3(g), dim3(NT), lds, st, z, filter, out, planes, pl, seed, stream_id, plane_offset, group, split,      \
+        hipLaunchKernelGGL(kern, dim3(g), dim3(NT), lds, st, z, filter, out, planes, pl, seed, stream_id, plane_offset, group, split_main, \
                            PART, na, StatsAhead());                                                                                        \
     } while (0)
 #define SONAR_PA(G, ST, NM, PART)                                                                                                          \

@@ -12,3 +12,9 @@ int launch_power_bucket(SONAR_BUCKET_ARGS) {
 }
 
 }  // namespace sonar
+
+#ifdef SONAR_ANY_TRACE
+extern "C" int sonar_debug_any_trace_a(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sonar::g_any_trace), sizeof(sonar::g_any_trace));
+}
+#endif

@@ -284,11 +284,31 @@ __device__ __forceinline__ void skip_plane(SpectrumRng& g, int tid) {
 // A kernel's work units: whole RNG groups (one workgroup draws the group's planes back to back; the seeding is paid once
 // per group), or -- `split`, chosen by the launcher when there are too few groups to fill the chip -- single planes, the
 // workgroup fast-forwarding the group's streams to its plane.  Same values either way.
+// Work units of a launch over RNG groups of `group` planes.  split = 0: a unit is a whole group; 1: a single plane (the workgroup
+// fast-forwards the group's streams to it); 2 + F (round 5, kernels that say so): the first F groups whole, the planes of the others
+// singly -- F = the groups of the launch's FULL rounds of workgroups, so that a tail of a few groups spreads over all workgroups as planes
+// instead of costing a few of them a whole group each (530 groups on 512 workgroups: eight plane-times became 5.3).
+__host__ __device__ inline int64_t group_units(int64_t planes, int group, int split) {
+    if (split == 0) return planes / group;
+    if (split == 1) return planes;
+    const int64_t full = (int64_t)split - 2;
+    return full + (planes - full * group);
+}
 struct GroupWalk {
     int64_t grp;
     int first, count;
     __device__ __forceinline__ GroupWalk(int64_t unit, int group, int split)
-        : grp(split ? unit / group : unit), first(split ? (int)(unit % group) : 0), count(split ? 1 : group) {}
+        : grp(split ? unit / group : unit), first(split ? (int)(unit % group) : 0), count(split ? 1 : group) {
+        if (split >= 2) {
+            const int64_t full = (int64_t)split - 2;
+            if (unit < full) {
+                grp = unit, first = 0, count = group;
+            } else {
+                const int64_t pl = unit - full;
+                grp = full + pl / group, first = (int)(pl % group), count = 1;
+            }
+        }
+    }
 };
 
 // ---- unit complex normal z = rho e^{i theta}, E|z|^2 = 1, times a filter value, from raw generator bits (about 20 instruction slots) ----

@@ -586,6 +586,25 @@ def test_power_generate_general_size_planes(hl, hw):
         assert abs(fused.std().item() - factor) < 3e-4
 
 
+@pytest.mark.parametrize("latents", [530, 519, 1030])
+def test_power_general_size_mixed_units_draw_the_same_planes(hl, latents):
+    """Round 5: with more RNG groups than resident workgroups the general-size plane kernel takes whole groups for its full rounds and the
+    planes of the remaining groups one by one (csrc/power_core.h, group_units / GroupWalk) -- a work decomposition, not part of the stream
+    definition: the planes are the ones a small launch at the same offsets draws (per-plane units), the ones the spectrum dump replays."""
+    h, w = 104, 152
+    filt = dev(torch.rand(h, w // 2 + 1) + 0.25)
+    shape = (latents, 4, h, w)
+    got = hl.power_irfft2(None, filt, shape, seed=21, stream_id=4)
+    for first, count in ((0, 3), (511, 2), (latents - 4, 4), (latents - 1, 1)):
+        part = hl.power_irfft2(None, filt, (count, 4, h, w), seed=21, stream_id=4, plane_offset=4 * first)
+        assert torch.equal(part, got[first : first + count]), first
+    z = hl.power_spectrum((6, 4, h, w), "cuda", seed=21, stream_id=4, plane_offset=4 * (latents - 6))
+    close(got[latents - 6 :], hl.power_irfft2(z, filt, (6, 4, h, w)), rtol=0, atol=GEN_VS_REPLAY_ATOL)
+    # the normalised call (statistics kernel with its own units + the final pass) has unit variance over the whole tensor
+    out = hl.power_noise(filt, shape, seed=21, stream_id=4, plane_offset=0, factor=1.0)
+    assert abs(out.double().std().item() - 1.0) < 1e-4 and abs(out.double().mean().item()) < 1e-4
+
+
 def test_power_general_size_full_batch(hl):
     """512 SDXL-portrait latents (104 x 152): normalised generation has unit variance, zero mean, flat-filter output is white."""
     shape = (512, 4, 104, 152)
