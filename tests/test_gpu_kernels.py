@@ -600,6 +600,11 @@ def test_power_general_size_mixed_units_draw_the_same_planes(hl, latents):
         assert torch.equal(part, got[first : first + count]), first
     z = hl.power_spectrum((6, 4, h, w), "cuda", seed=21, stream_id=4, plane_offset=4 * (latents - 6))
     close(got[latents - 6 :], hl.power_irfft2(z, filt, (6, 4, h, w)), rtol=0, atol=GEN_VS_REPLAY_ATOL)
+    # the statistics variant of the same launch: the same planes, partials = the tensor's sums
+    p1 = hl.new_partials("cuda")
+    assert torch.equal(hl.power_irfft2(None, filt, shape, seed=21, stream_id=4, partials=p1), got)
+    tot = hl.stats_finalize(p1, got.numel()).cpu()
+    assert abs(tot[0].item() - got.double().sum().item()) < 1e-6 * got.numel() and abs(tot[1].item() / (got.double() ** 2).sum().item() - 1.0) < 1e-6
     # the normalised call (statistics kernel with its own units + the final pass) has unit variance over the whole tensor
     out = hl.power_noise(filt, shape, seed=21, stream_id=4, plane_offset=0, factor=1.0)
     assert abs(out.double().std().item() - 1.0) < 1e-4 and abs(out.double().mean().item()) < 1e-4
