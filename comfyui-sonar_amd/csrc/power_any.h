@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32*
 
 // out[row][x] = scale * (Re y0 + sum_{k >= 1} w_k Re(y_k e^{+2 pi i k x / W})), w_k = 2 (1 for the Nyquist column)
 // NORM: out = (v * scale - mean) / std * factor by the statistics in na.partials (computed before the rows exist: power_block.h)
-template <bool STATS, bool NORM = false>
+// CR1, CR2 > 0: the row length's factor pair at compile time (256-wide rows: 128 = 16 x 8 -- the planes beyond LDS of 2048 px latents)
+template <bool STATS, bool NORM = false, int CR1 = 0, int CR2 = 0>
 __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* __restrict__ y, float* __restrict__ out, int64_t rows, int W, int n1,
                                                                      int n2, int per, float scale, double* partials, NormArgs na) {
     extern __shared__ __align__(16) unsigned char any_lds[];
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* 
         __syncthreads();
         // G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k (X[0], X[M] contribute their real parts), formed by the first pass as it
         // loads when that pass is a codelet (c2r_pass0: one LDS round trip and one barrier fewer per batch), then the length-M inverse DFT
-        c2r_rows<kLinesThreads, 0, 0, kSetLines>(A, tw, W, n1, n2, nr, M, S, 1, tid);
+        c2r_rows<kLinesThreads, CR1, CR2, kSetLines>(A, tw, W, n1, n2, nr, M, S, 1, tid);
         for (LinesWalk lw(tid, M); lw.j < nr * M; lw.next(M)) {
             const int r = lw.r, m = lw.c;
             const c32 g = A[r * S + m];
@@ -438,7 +439,11 @@ bool sonar_lines_rows_c2r_norm(const float* y, float* out, int64_t rows, int64_t
     const size_t line = (size_t)(M + 1) * sizeof(c32), table = (size_t)W * sizeof(c32);
     const int per = lines_per(line, table, 512);
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>((rows + per - 1) / per, kNPart));
-    if (norm) {
+    if (norm && n1 == 16 && n2 == 8) {
+        lines_lds_attr(lines_c2r_kernel<false, true, 16, 8>);
+        hipLaunchKernelGGL((lines_c2r_kernel<false, true, 16, 8>), dim3(g), dim3(kLinesThreads), per * line + table, st, reinterpret_cast<const c32*>(y), out,
+                           rows, (int)W, n1, n2, per, scale, partials, na);
+    } else if (norm) {
         lines_lds_attr(lines_c2r_kernel<false, true>);
         hipLaunchKernelGGL((lines_c2r_kernel<false, true>), dim3(g), dim3(kLinesThreads), per * line + table, st, reinterpret_cast<const c32*>(y), out, rows,
                            (int)W, n1, n2, per, scale, partials, na);

@@ -89,7 +89,8 @@ __device__ __forceinline__ void skip_block(SpectrumRng& g, int tid, int H, int n
 // STATS: the statistics of the tensor the row pass will make of the workspace, by Parseval on the filtered spectrum while it is in hand
 // (ortho-normalised transforms): sum x = sqrt(H W) Re Zf[0][0]; sum x^2 = twice the interior columns' |Zf|^2 + the Hermitian parts of
 // columns 0 and M (what the row pass keeps of them) -- two FMAs per drawn value, no pass over anything.
-template <int MODE, bool STATS = false>
+// CR1, CR2 > 0: the column length's factor pair at compile time (256 rows = 16 x 16)
+template <int MODE, bool STATS = false, int CR1 = 0, int CR2 = 0>
 __global__ void __launch_bounds__(kBlockSlots, 4) power_block_cols_kernel(const float* __restrict__ filter, c32* __restrict__ ws, int64_t planes,
                                                                           BlockPlan pl, uint64_t seed, uint64_t stream_id, int64_t plane_offset,
                                                                           int group, int split, double* partials) {
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(kBlockSlots, 4) power_block_cols_kernel(const 
                         __syncthreads();  // the transform's first pass writes in place
                     }
                 }
-                line_dft<kBlockSlots, false, 0, 0, kSetLines>(A, tw, H, 1, pl.hn1, pl.hn2, ncd, Sb, 1, tid);
+                line_dft<kBlockSlots, false, CR1, CR2, kSetLines>(A, tw, H, 1, pl.hn1, pl.hn2, ncd, Sb, 1, tid);
                 for (LinesWalk lw(tid, ncd); lw.j < H * ncd; lw.next(ncd)) dst[(int64_t)lw.r * S + lw.c] = A[lw.r * Sb + lw.c];
             }
         }
@@ -191,7 +192,11 @@ static int launch_power_block(int mode, const float* filter, float* ws, float* o
                            plane_offset, group, split, (double*)nullptr);
         return check_launch("sonar_power_block_f32");
     }
-    if (mode == 1) {  // the statistics ride in the column kernel
+    if (mode == 1 && pl.hn1 == 16 && pl.hn2 == 16) {
+        lines_lds_attr(power_block_cols_kernel<0, true, 16, 16>);
+        hipLaunchKernelGGL((power_block_cols_kernel<0, true, 16, 16>), grid, blk, lds, st, filter, wsc, planes, pl, seed, stream_id, plane_offset, group,
+                           split, partials);
+    } else if (mode == 1) {  // the statistics ride in the column kernel
         lines_lds_attr(power_block_cols_kernel<0, true>);
         hipLaunchKernelGGL((power_block_cols_kernel<0, true>), grid, blk, lds, st, filter, wsc, planes, pl, seed, stream_id, plane_offset, group, split,
                            partials);
