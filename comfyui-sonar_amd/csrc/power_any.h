@@ -66,6 +66,9 @@ static int launch_power_any(int what, const float* z, const float* filter, float
 // columns of one plane -- runs line_dft over them and writes the result; lengths up to kLinesMax, any factorisation (a factor the
 // codelets do not cover costs that pass its direct sums: 512 = 16 x 32 is sixteen terms per value, not 512).
 constexpr int kLinesThreads = 512;
+#ifndef SONAR_LINES_AHEAD
+#define SONAR_LINES_AHEAD 2  // lines_c2r_kernel<.., CR1 > 0>: chunks of 8 values per thread of the next batch requested a batch ahead (0: none)
+#endif
 constexpr int kLinesMax = 2048;
 constexpr size_t kLinesLds = 64 * 1024;  // two workgroups per CU
 
@@ -207,6 +210,12 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32*
 
 // out[row][x] = scale * (Re y0 + sum_{k >= 1} w_k Re(y_k e^{+2 pi i k x / W})), w_k = 2 (1 for the Nyquist column)
 // NORM: out = (v * scale - mean) / std * factor by the statistics in na.partials (computed before the rows exist: power_block.h)
+#ifdef SONAR_LINES_TRACE  // profiling builds (scratch/lines_trace.py): thread 0's cycle stamps of a workgroup's first batches
+static __device__ unsigned long long g_lines_trace[512 * 4 * 8];
+#define SONAR_LINES_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512 && lt_b < 4) g_lines_trace[(blockIdx.x * 4 + lt_b) * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SONAR_LINES_STAMP(slot) do { } while (0)
+#endif
 // CR1, CR2 > 0: the row length's factor pair at compile time (256-wide rows: 128 = 16 x 8 -- the planes beyond LDS of 2048 px latents)
 template <bool STATS, bool NORM = false, int CR1 = 0, int CR2 = 0>
 __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* __restrict__ y, float* __restrict__ out, int64_t rows, int W, int n1,
@@ -226,32 +235,31 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* 
         nc = dec.do_sub ? dec.mean * g : 0.0f;
     }
     double s = 0.0, q = 0.0;
-    for (int64_t r0 = (int64_t)blockIdx.x * per; r0 < rows; r0 += (int64_t)gridDim.x * per) {
-        const int nr = (int)min<int64_t>(per, rows - r0);
-        __syncthreads();
-        {   // the batch is one contiguous run of the workspace and of LDS (same row stride): eight loads in flight per thread -- one at a
-            // time, a batch of 61 rows of 129 values waited for sixteen memory latencies in a row
-            const c32* __restrict__ src = y + r0 * S;
-            const int total = nr * S;
-            constexpr int U = 8;
-            for (int i0 = tid; i0 < total; i0 += U * kLinesThreads) {
-                c32 v[U];
+    [[maybe_unused]] int lt_b = 0;  // (trace builds)
+    // A batch is one contiguous run of the workspace and of LDS (same row stride).  The compile-time-pair instantiation (256-wide rows)
+    // requests the NEXT batch's values -- all of them: 2 x 8 per thread -- before the current one is transformed and stored: a workgroup sat a
+    // third of a batch's time behind its own loads (`scratch/lines_trace.py`: 8.5 k of 26 k ticks).  The run-time instantiation has no
+    // registers to spare for it (it spilled 4-12 and lost what the request gained).  The loop is split at the request, not closed behind the
+    // stores (see spectral_filter128_kernel).
+    constexpr int U = 8, PF = CR1 > 0 ? SONAR_LINES_AHEAD : 0;
+    [[maybe_unused]] c32 ahead[PF > 0 ? PF : 1][U];
+    auto request = [&](int64_t r0) {
+        const c32* __restrict__ src = y + r0 * S;
+        const int total = (int)min<int64_t>(per, rows - r0) * S;
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u * kLinesThreads;
-                    v[u] = src[i < total ? i : i0];
-                }
+        for (int c = 0; c < PF; ++c) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u * kLinesThreads;
-                    if (i < total) A[i] = v[u];
-                }
+            for (int u = 0; u < U; ++u) {
+                const int i = tid + (c * U + u) * kLinesThreads;
+                ahead[c][u] = src[i < total ? i : 0];
             }
         }
-        __syncthreads();
+    };
+    auto transform_and_store = [&](int64_t r0, int nr) {
         // G[k] = (X[k] + conj X[M-k]) + i (X[k] - conj X[M-k]) w^k (X[0], X[M] contribute their real parts), formed by the first pass as it
         // loads when that pass is a codelet (c2r_pass0: one LDS round trip and one barrier fewer per batch), then the length-M inverse DFT
         c2r_rows<kLinesThreads, CR1, CR2, kSetLines>(A, tw, W, n1, n2, nr, M, S, 1, tid);
+        SONAR_LINES_STAMP(2);
         for (LinesWalk lw(tid, M); lw.j < nr * M; lw.next(M)) {
             const int r = lw.r, m = lw.c;
             const c32 g = A[r * S + m];
@@ -263,9 +271,62 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* 
                 q += da * da + db * db;
             }
         }
+        SONAR_LINES_STAMP(3);
+        ++lt_b;
+    };
+    int64_t r0 = (int64_t)blockIdx.x * per;
+    if (r0 < rows) {
+        if constexpr (PF > 0) request(r0);
+        for (;;) {
+            const int nr = (int)min<int64_t>(per, rows - r0);
+            const int total = nr * S;
+            __syncthreads();
+            SONAR_LINES_STAMP(0);
+            if constexpr (PF > 0) {
+#pragma unroll
+                for (int c = 0; c < PF; ++c) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = tid + (c * U + u) * kLinesThreads;
+                        if (i < total) A[i] = ahead[c][u];
+                    }
+                }
+            }
+            {   // what the request did not cover: eight loads in flight per thread
+                const c32* __restrict__ src = y + r0 * S;
+                for (int i0 = tid + PF * U * kLinesThreads; i0 < total; i0 += U * kLinesThreads) {
+                    c32 v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = i0 + u * kLinesThreads;
+                        v[u] = src[i < total ? i : i0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = i0 + u * kLinesThreads;
+                        if (i < total) A[i] = v[u];
+                    }
+                }
+            }
+            __syncthreads();
+            SONAR_LINES_STAMP(1);
+            const int64_t next = r0 + (int64_t)gridDim.x * per;
+            if (next >= rows) {  // uniform
+                transform_and_store(r0, nr);
+                break;
+            }
+            if constexpr (PF > 0) request(next);
+            transform_and_store(r0, nr);
+            r0 = next;
+        }
     }
     if constexpr (STATS) write_partial<kLinesThreads>(s, q, partials, red);
 }
+#ifdef SONAR_LINES_TRACE
+extern "C" int sonar_debug_lines_trace(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sonar::g_lines_trace), sizeof(sonar::g_lines_trace));
+}
+#endif
 
 // Odd widths have no half-length trick: a row is transformed as W complex values (imaginary parts zero on the way in, discarded on the
 // way out) -- twice the arithmetic of an even neighbour, not the O(W) per value of the direct sums (135 = 15 x 9 runs as two codelets).
