@@ -35,7 +35,7 @@ def main(path):
     stats = [v for k, v in raw.items() if "power_stats_kernel" in k]
     if stats:
         out["power_noise_b512"]["kernels"]["power_stats_kernel<128,128> (first call only)"] = stats[0]
-    cols, rows = pick(raw, "power_block_cols_kernel<0, true>"), pick(raw, "lines_c2r_kernel<false, true>")
+    cols, rows = pick(raw, "power_block_cols_kernel<0, true"), pick(raw, "lines_c2r_kernel<false, true")
     out["power_noise_256x256_b128"] = {"kernels": {"power_block_cols_kernel<0, STATS> (draw + filter + statistics + columns -> workspace)": cols,
                                                    "lines_c2r_kernel<NORM> (workspace -> rows, normalised)": rows},
                                        "hbm_bytes_per_launch": total(cols, rows), "algorithmic_bytes_4N": 128 * 4 * 256 * 256 * 4,
