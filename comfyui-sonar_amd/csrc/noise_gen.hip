@@ -913,6 +913,17 @@ constexpr size_t kPyramidLdsBudget = 64 * 1024;
 #define SONAR_PYR_PARTS 2
 #endif
 constexpr int kPyrParts = SONAR_PYR_PARTS;
+#ifndef SONAR_PYR_STRETCH
+#define SONAR_PYR_STRETCH 4
+#endif
+constexpr int kPyrStretch = SONAR_PYR_STRETCH;  // items a thread stretches along x per round (XROWS)
+#ifndef SONAR_PYR_GROUP
+#define SONAR_PYR_GROUP 1
+#endif
+#ifndef SONAR_PYR_GROUP_PRE
+#define SONAR_PYR_GROUP_PRE 1
+#endif
+constexpr int kPyrGroup = SONAR_PYR_GROUP, kPyrGroupPre = SONAR_PYR_GROUP_PRE;  // burst steps whose level reads are in flight together (XROWS)
 constexpr int kPyrBlock = kPyrParts * kBlock;
 static_assert((kPyrParts & (kPyrParts - 1)) == 0 && kTileIters % kPyrParts == 0, "parts split a tile's burst evenly");
 #ifndef SONAR_PYR_UNROLL_N
@@ -928,6 +939,26 @@ static_assert((kPyrParts & (kPyrParts - 1)) == 0 && kTileIters % kPyrParts == 0,
 // same (tile, iteration) sequence.
 // A Perlin lattice computed in `blocks` extra leading workgroups of a plane-kernel launch: the lattice of a LATER call's hosted Perlin item
 // (sonar_pyramid_generate_acc_ahead_f32) -- independent of everything else in the launch.  blocks == 0: none.
+// Every 64-byte line of a kernel's argument block requested at its first instruction.  The compiler loads arguments where it first needs
+// them, a batch and a wait at a time; with ~560 bytes of arguments (the levels' tables) that was four or five scalar-cache misses one after
+// the other before the first table entry could be written: 2.2-2.4 k cycles, 1 us, at the top of every workgroup (trace build, round 5).
+template <size_t BYTES>
+__device__ __forceinline__ void kernarg_touch() {
+    const uint32_t __attribute__((address_space(4)))* ka = (const uint32_t __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t any = 0;
+#pragma unroll
+    for (size_t k = 0; k < BYTES; k += 64) any |= ka[k / 4];
+    asm volatile("" ::"s"(any));
+}
+
+// N words of a stream passed over as straight-line code: a counted loop around one multiply-add spent 96 cycles per word on its own
+// bookkeeping (vector-exec loop, trace build of round 5: 3.1 k cycles for the 32 words of half a burst)
+template <int N>
+__device__ __forceinline__ void skip_words(TileRng& r) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.next();
+}
+
 struct LatticeJob {
     float* out;
     int blocks, iters, blend_mode;
@@ -944,9 +975,11 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     __shared__ double red[2 * kPyrBlock / 64];
     // the levels' parameters where a thread can index them by a run-time level (kernel arguments live in scalar registers: per-level
     // loops over them are sixteen short dependent loops; flattened over (level, item) a thread has four independent items in flight)
-    __shared__ int lvl_h[kMaxLevels], lvl_w[kMaxLevels], lvl_off[kMaxLevels + 1], lvl_item0[kMaxLevels + 1];
+    __shared__ int lvl_h[kMaxLevels], lvl_w[kMaxLevels], lvl_off[kMaxLevels + 1], lvl_item0[kMaxLevels + 1], lvl_row0[kMaxLevels];
     __shared__ float lvl_weight[kMaxLevels];
     __shared__ unsigned long long lvl_stream[kMaxLevels];
+    kernarg_touch<sizeof(float*) + sizeof(int64_t) + 2 * sizeof(int) + sizeof(PyramidLevels) + sizeof(int) + 2 * sizeof(uint64_t) + sizeof(int64_t) +
+                  sizeof(double*) + sizeof(int) + sizeof(Accum) + sizeof(Prefix) + sizeof(LatticeJob)>();
     if ((int)blockIdx.x < lat.blocks) {
         perlin_lattice_cells<kPyrBlock>(lat.out, lat.iters, lat.C, H, W, lat.blend_mode, lat.seed, lat.stream_id, blockIdx.x, lat.blocks);
         return;
@@ -956,8 +989,8 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     double s = 0.0, q = 0.0;
     const int HW = H * W;
     const uint32_t lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int part = threadIdx.x / kBlock;  // 256-thread parts of the workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int part = wave / (kBlock / 64);  // 256-thread parts of the workgroup (wave-uniform: the step-ahead below is straight-line code)
     const int dy = 256 / W, dx = 256 - dy * W;  // one burst step advances 256 elements
     // bilinear source coordinates depend on (level, x) and (level, y) only: tabulated once per workgroup
     Lin* const xtab = reinterpret_cast<Lin*>(pyr_lds + grid_floats);  // [level][W]
@@ -986,11 +1019,13 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     const int64_t t_ahead = part != 0 ? (elem_offset + (int64_t)bid * HW) / kTileElems + wave % (kBlock / 64) : -1;
     TileRng rng_ahead, prng_ahead;
     if (threadIdx.x == 0) {
-        int off = 0, item = 0;
+        int off = 0, item = 0, row = 0;
 #pragma unroll
         for (int l = 0; l < kMaxLevels; ++l) {
             if (l < lv.count) {
                 const int n = lv.h[l] * lv.w[l];
+                lvl_row0[l] = row;  // XROWS: the level's first stretched row
+                row += lv.h[l];
                 lvl_h[l] = lv.h[l];
                 lvl_w[l] = lv.w[l];
                 lvl_weight[l] = lv.weight[l];
@@ -1010,9 +1045,9 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     if (part != 0 && bid < planes) {
         rng_ahead = rng_stream(seed, stream_id, (uint64_t)t_ahead, lane);
         if constexpr (PRE != 0) prng_ahead = rng_stream(pre.seed, pre.stream_id, (uint64_t)t_ahead, lane);
-        for (int k = 0; k < part * kIters * 4; ++k) {
-            rng_ahead.next();
-            if constexpr (PRE != 0) prng_ahead.next();
+        for (int k = 0; k < part; ++k) {
+            skip_words<kIters * 4>(rng_ahead);
+            if constexpr (PRE != 0) skip_words<kIters * 4>(prng_ahead);
         }
     }
     SONAR_NG_STAMP_T(kBlock, 15);     // (trace builds: the second part's generators are stepped ahead)
@@ -1029,6 +1064,8 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                 ly.i0 *= pitch;  // row offsets
                 ly.i1 *= pitch;
                 if constexpr (XROWS) {
+                    ly.i0 += lvl_row0[l] * W;  // ... from the first level's first stretched row
+                    ly.i1 += lvl_row0[l] * W;
                     const float wt = lvl_weight[l];
                     ly.w0 *= wt;
                     ly.w1 *= wt;
@@ -1077,16 +1114,53 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                 const Lin* xt = xtab + l * W;
                 int yy = (int)threadIdx.x / W, xx = (int)threadIdx.x - yy * W;
                 const int sy = kPyrBlock / W, sx = kPyrBlock - sy * W;
-                for (int i = threadIdx.x; i < h * W; i += kPyrBlock) {
-                    const Lin lx = xt[xx];
-                    const float* row = g + yy * w;
-                    xrows[ro + i] = __builtin_fmaf(row[lx.i1], lx.w1, row[lx.i0] * lx.w0);
-                    yy += sy;
-                    xx += sx;
-                    if (xx >= W) {
-                        xx -= W;
-                        yy += 1;
+                // kPyrStretch items per thread and round: their table reads and gathers are in flight together (one at a time, a level of
+                // 45 rows was 13 rounds of three dependent LDS latencies: 4.4-4.9 k cycles per plane, as long as half the tile loop)
+                if (sx == 0) {
+                    // the workgroup's threads cover whole rows (W divides 512: every power-of-two width): a thread keeps its column, so
+                    // its table entry is read once per level and an item is two gathers at a fixed stride, a multiply-add and a store
+                    if (yy < h) {
+                        const Lin lx = xt[xx];
+                        const float* c0 = g + lx.i0;
+                        const float* c1 = g + lx.i1;
+                        for (int r = yy; r < h; r += kPyrStretch * sy) {
+                            float a[kPyrStretch], b[kPyrStretch];
+#pragma unroll
+                            for (int u = 0; u < kPyrStretch; ++u) {
+                                const int ru = r + u * sy < h ? r + u * sy : r;
+                                a[u] = c0[ru * w];
+                                b[u] = c1[ru * w];
+                            }
+#pragma unroll
+                            for (int u = 0; u < kPyrStretch; ++u)
+                                if (r + u * sy < h) xrows[ro + (r + u * sy) * W + xx] = __builtin_fmaf(b[u], lx.w1, a[u] * lx.w0);
+                        }
                     }
+                    go += h * w;
+                    ro += h * W;
+                    continue;
+                }
+                for (int i = threadIdx.x; i < h * W; i += kPyrStretch * kPyrBlock) {
+                    float a[kPyrStretch], b[kPyrStretch], wa[kPyrStretch], wb[kPyrStretch];
+#pragma unroll
+                    for (int u = 0; u < kPyrStretch; ++u) {
+                        const bool on = i + u * kPyrBlock < h * W;
+                        const Lin lx = xt[on ? xx : 0];
+                        const float* row = g + (on ? yy : 0) * w;
+                        a[u] = row[lx.i0];
+                        b[u] = row[lx.i1];
+                        wa[u] = lx.w0;
+                        wb[u] = lx.w1;
+                        yy += sy;
+                        xx += sx;
+                        if (xx >= W) {
+                            xx -= W;
+                            yy += 1;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kPyrStretch; ++u)
+                        if (i + u * kPyrBlock < h * W) xrows[ro + i + u * kPyrBlock] = __builtin_fmaf(b[u], wb[u], a[u] * wa[u]);
                 }
                 go += h * w;
                 ro += h * W;
@@ -1117,9 +1191,9 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
             } else {
                 rng = rng_stream(seed, stream_id, (uint64_t)t, lane);
                 if constexpr (PRE != 0) prng = rng_stream(pre.seed, pre.stream_id, (uint64_t)t, lane);
-                for (int k = 0; k < part * kIters * 4; ++k) {
-                    rng.next();
-                    if constexpr (PRE != 0) prng.next();
+                for (int k = 0; k < part; ++k) {
+                    skip_words<kIters * 4>(rng);
+                    if constexpr (PRE != 0) skip_words<kIters * 4>(prng);
                 }
             }
             SONAR_NG_STAMP(7);
@@ -1127,6 +1201,93 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
             int e = (int)(t * kTileElems - g0) + (int)lane * 4 + part * kIters * 256;
             int y = e >= 0 ? e / W : -((-e + W - 1) / W);        // floor
             int x4 = e - y * W;
+            if constexpr (XROWS) {
+                // kPyrGroup burst steps at a time: a level's table entries, then its row pairs, are requested for the whole group before
+                // the first is used.  Step by step a level was two dependent LDS latencies (table entry -> row addresses -> rows) and a
+                // scalar load of its height: ~675 cycles per step with three levels at one or two workgroups per CU (trace build of round
+                // 5), the arithmetic of a step being ~120 instructions.  Same draws, same operation order per value: the same bits.
+                constexpr int G = PRE != 0 ? kPyrGroupPre : kPyrGroup;
+                static_assert(kIters % G == 0, "groups tile a part's share of the burst");
+                const float base_mul = lv.fullres ? lv.base_scale : 1.0f;  // (x 1 is exact: no select per value)
+                // WHOLE: the tile lies inside the plane (always, when planes are whole tiles): no per-lane ownership test around the stores
+                auto burst = [&](auto whole_c) {
+                    constexpr bool WHOLE = decltype(whole_c)::value;
+                    for (int it0 = 0; it0 < kIters; it0 += G) {
+                        float v[G][4], px[G][4];
+                        int ee[G], yy[G], xx[G];
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            rng.normal4(v[j]);
+                            const bool ours = WHOLE || (e >= 0 && e < HW);
+                            if constexpr (PRE != 0) {  // the prefix's generator walks every iteration of the tile, ours or not
+                                const float4 tv = PRE == 2 && ours ? *reinterpret_cast<const float4*>(tplane + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                prefix_draw<PRE>(prng, pdiv, tv, px[j]);
+                            }
+                            ee[j] = e;
+                            yy[j] = ours ? y : 0;  // (not ours: any entry of the tables, the values are dropped)
+                            xx[j] = ours ? x4 : 0;
+                            e += 256;
+                            y += dy;
+                            x4 += dx;
+                            if (x4 >= W) {
+                                x4 -= W;
+                                y += 1;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[j][k] *= base_mul;
+                        }
+                        // the four values of a step as ONE 16-byte register value from the draw to the store: the level sums are packed
+                        // multiply-adds on its halves, the store takes it as it is (as four scalars the compiler moved them between
+                        // register pairs around the level loop and again before the store: 8-11 moves per step)
+                        sonar_v4f vv[G];
+#pragma unroll
+                        for (int j = 0; j < G; ++j) vv[j] = sonar_v4f{v[j][0], v[j][1], v[j][2], v[j][3]};
+                        const int nl = lv.count;
+                        for (int l = 0; l < nl; ++l) {
+                            Lin ly[G];
+#pragma unroll
+                            for (int j = 0; j < G; ++j) ly[j] = ytab[l * H + yy[j]];
+                            sonar_v4f a[G], b[G];
+#pragma unroll
+                            for (int j = 0; j < G; ++j) {
+                                a[j] = *reinterpret_cast<const sonar_v4f*>(xrows + ly[j].i0 + xx[j]);
+                                b[j] = *reinterpret_cast<const sonar_v4f*>(xrows + ly[j].i1 + xx[j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < G; ++j) {
+                                const sonar_v4f w0 = {ly[j].w0, ly[j].w0, ly[j].w0, ly[j].w0}, w1 = {ly[j].w1, ly[j].w1, ly[j].w1, ly[j].w1};
+                                vv[j] = __builtin_elementwise_fma(a[j], w0, __builtin_elementwise_fma(b[j], w1, vv[j]));
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const int ej = ee[j];
+                            if (!WHOLE && (ej < 0 || ej >= HW)) continue;
+                            if constexpr (PRE != 0) {
+                                float w[4] = {vv[j].x, vv[j].y, vv[j].z, vv[j].w};
+                                prefix_fold(pre, pfold, fold, p * (int64_t)HW + ej, px[j], w);
+                                vv[j] = sonar_v4f{w[0], w[1], w[2], w[3]};
+                            } else if (fold.y) {
+                                const float4 yv = *reinterpret_cast<const float4*>(fold.y + p * (int64_t)HW + ej);
+                                vv[j] = sonar_v4f{fold(yv.x, vv[j].x), fold(yv.y, vv[j].y), fold(yv.z, vv[j].z), fold(yv.w, vv[j].w)};
+                            }
+                            if constexpr (NT) __builtin_nontemporal_store(vv[j], reinterpret_cast<sonar_v4f*>(oplane + ej));
+                            else *reinterpret_cast<sonar_v4f*>(oplane + ej) = vv[j];
+                            if constexpr (STATS) {
+                                float s01 = vv[j].x + vv[j].y;
+                                asm volatile("" : "+v"(s01));  // (two scalar adds: paired into one packed add they cost three moves)
+                                const float ps = s01 + (vv[j].z + vv[j].w);
+                                const float pq = __builtin_fmaf(vv[j].x, vv[j].x, __builtin_fmaf(vv[j].y, vv[j].y, __builtin_fmaf(vv[j].z, vv[j].z, vv[j].w * vv[j].w)));
+                                s += (double)ps;
+                                q += (double)pq;
+                            }
+                        }
+                    }
+                };
+                if (t * kTileElems >= g0 && (t + 1) * kTileElems <= g0 + HW) burst(std::true_type{});
+                else burst(std::false_type{});
+                continue;
+            }
 SONAR_PYR_UNROLL
             for (int it = 0; it < kIters; ++it, e += 256, y += dy, x4 += dx, y += x4 >= W, x4 -= x4 >= W ? W : 0) {
                 float v[4];
@@ -1145,17 +1306,6 @@ SONAR_PYR_UNROLL
                 int lo = 0;
                 for (int l = 0; l < lv.count; ++l) {
                     const int h = lv.h[l], w = lv.w[l];
-                    if constexpr (XROWS) {
-                        const Lin ly = ytab[l * H + y];
-                        const float4 a = *reinterpret_cast<const float4*>(xrows + lo + ly.i0 + x4);
-                        const float4 b = *reinterpret_cast<const float4*>(xrows + lo + ly.i1 + x4);
-                        lo += h * W;
-                        v[0] = __builtin_fmaf(a.x, ly.w0, __builtin_fmaf(b.x, ly.w1, v[0]));
-                        v[1] = __builtin_fmaf(a.y, ly.w0, __builtin_fmaf(b.y, ly.w1, v[1]));
-                        v[2] = __builtin_fmaf(a.z, ly.w0, __builtin_fmaf(b.z, ly.w1, v[2]));
-                        v[3] = __builtin_fmaf(a.w, ly.w0, __builtin_fmaf(b.w, ly.w1, v[3]));
-                        continue;
-                    }
                     const float* plane = pyr_lds + lo;
                     lo += h * w;
                     const float wt = lv.weight[l];
@@ -1206,7 +1356,11 @@ SONAR_PYR_UNROLL
     }
     SONAR_NG_STAMP(8);
 #ifdef SONAR_NG_TRACE  // when each of the waves 1..6 left the tile loop (wave 0 is slot 8)
+#ifdef SONAR_NG_TRACE_PART1  // (the second part's waves 4..6 instead)
+    if (lane == 0 && wave >= 4 && wave <= 6 && blockIdx.x < 256) g_ng_trace[blockIdx.x * 16 + 6 + wave] = __builtin_readcyclecounter();
+#else
     if (lane == 0 && wave >= 1 && wave <= 3 && blockIdx.x < 256) g_ng_trace[blockIdx.x * 16 + 9 + wave] = __builtin_readcyclecounter();
+#endif
 #endif
     if constexpr (STATS) write_partial_at<kPyrBlock>(s, q, partials, red, bid, nblocks);
     SONAR_NG_STAMP(9);
