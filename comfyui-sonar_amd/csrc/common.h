@@ -136,6 +136,35 @@ __device__ __forceinline__ TileRng rng_stream(uint64_t seed, uint64_t stream_id,
 constexpr int kTileIters = 16;
 constexpr int kTileElems = kTileIters * 256;
 
+// Every 64-byte line of a kernel's argument block requested at its first instruction.  The compiler loads arguments where it first needs
+// them, a batch and a wait at a time; with ~560 bytes of arguments (the levels' tables) that was four or five scalar-cache misses one after
+// the other before the pyramid plane kernel's first table entry could be written: 2.2-2.4 k cycles, 1 us, at the top of every workgroup
+// (trace build, round 5: 1.35 k with this line); the pipelined power kernel, two lines of arguments, 40.6 -> 39.9 us per call.  Every kernel
+// of the library starts with it: nothing for one line of arguments, one early batch of scalar loads otherwise.
+template <size_t BYTES>
+__device__ __forceinline__ void kernarg_touch() {
+#ifdef SONAR_NO_KERNARG_TOUCH  // (profiling builds: the A/B of this line)
+    return;
+#endif
+    if constexpr (BYTES <= 64) return;  // one line: the kernel's own first load is the touch
+    const uint32_t __attribute__((address_space(4)))* ka = (const uint32_t __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t any = 0;
+#pragma unroll
+    for (size_t k = 0; k < BYTES; k += 64) any |= ka[k / 4];
+    asm volatile("" ::"s"(any));
+}
+// ... for a kernel's parameter list (passed as it is declared): the block's size from the parameters' types, in declaration order
+template <typename... T>
+constexpr size_t kernarg_bytes() {
+    size_t off = 0;
+    ((off = (off + alignof(T) - 1) / alignof(T) * alignof(T) + sizeof(T)), ...);
+    return off;
+}
+template <typename... T>
+__device__ __forceinline__ void kernarg_touch_for(const T&...) {
+    kernarg_touch<kernarg_bytes<T...>()>();
+}
+
 // ---- reductions -----------------------------------------------------------------------------
 // Wave-wide sums on the DPP data path (no LDS crossbar traffic, unlike __shfl / ds_bpermute): butterfly inside each quad
 // (quad_perm), rotate-and-add inside each row of 16 lanes (row_ror:4, row_ror:8), then the row totals travel down the wave with

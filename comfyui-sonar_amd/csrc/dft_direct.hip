@@ -25,6 +25,7 @@ __device__ __forceinline__ void build_table(float2* tw, int N, int sign) {
 
 // y[row][k] = sum_x x[row][x] e^{-2 pi i k x / W}, k = 0 .. W/2
 __global__ void __launch_bounds__(kBlock) dft_rows_r2c_kernel(const float* __restrict__ x, float2* __restrict__ y, int64_t rows, int W) {
+    kernarg_touch_for(x, y, rows, W);
     extern __shared__ __align__(16) unsigned char dft_lds[];
     float2* tw = reinterpret_cast<float2*>(dft_lds);
     float* line = reinterpret_cast<float*>(tw + W);
@@ -52,6 +53,7 @@ __global__ void __launch_bounds__(kBlock) dft_rows_r2c_kernel(const float* __res
 // out[p][n][k] = sum_m in[p][m][k] (* filter[m][k]) e^{-+ 2 pi i m n / H}; lanes = consecutive k (coalesced), one wave per n
 __global__ void __launch_bounds__(kBlock) dft_cols_kernel(const float2* __restrict__ in, const float* __restrict__ filter, float2* __restrict__ out,
                                                           int64_t planes, int H, int K, int inverse) {
+    kernarg_touch_for(in, filter, out, planes, H, K, inverse);
     extern __shared__ __align__(16) unsigned char dft_lds[];
     float2* tw = reinterpret_cast<float2*>(dft_lds);
     build_table(tw, H, inverse ? 1 : -1);
@@ -92,6 +94,7 @@ __global__ void __launch_bounds__(kBlock) dft_cols_kernel(const float2* __restri
 template <bool STATS>
 __global__ void __launch_bounds__(kBlock) dft_rows_c2r_kernel(const float2* __restrict__ y, float* __restrict__ out, int64_t rows, int W, float scale,
                                                               double* partials) {
+    kernarg_touch_for(y, out, rows, W, scale, partials);
     extern __shared__ __align__(16) unsigned char dft_lds[];
     __shared__ double red[2 * kBlock / 64];
     float2* tw = reinterpret_cast<float2*>(dft_lds);

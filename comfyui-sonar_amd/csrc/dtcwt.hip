@@ -15,6 +15,7 @@ namespace sonar {
 template <typename T>
 __global__ void __launch_bounds__(kBlock) axis_taps_kernel(const T* __restrict__ x, T* out, int64_t outer, int n_in, int n_out, int inner,
                                                             const int* __restrict__ idx, const T* __restrict__ coef, int taps, int accumulate) {
+    kernarg_touch_for(x, out, outer, n_in, n_out, inner, idx, coef, taps, accumulate);
     const int64_t per = (int64_t)n_out * inner, total = outer * per;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
         const int64_t o = e / per;
@@ -34,6 +35,7 @@ __global__ void __launch_bounds__(kBlock) axis_taps_kernel(const T* __restrict__
 template <typename T>
 __global__ void __launch_bounds__(kBlock) dtcwt_q2c_kernel(const T* __restrict__ lh, const T* __restrict__ hh, const T* __restrict__ hl, T* out,
                                                             int64_t planes, int h, int w) {
+    kernarg_touch_for(lh, hh, hl, out, planes, h, w);
     const int64_t hw = (int64_t)h * w, total = planes * 3 * hw;
     const T s = (T)0.70710678118654752440;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
@@ -57,6 +59,7 @@ __global__ void __launch_bounds__(kBlock) dtcwt_q2c_kernel(const T* __restrict__
 // c2q: the inverse shuffle
 template <typename T>
 __global__ void __launch_bounds__(kBlock) dtcwt_c2q_kernel(const T* __restrict__ bands, T* lh, T* hh, T* hl, int64_t planes, int h, int w) {
+    kernarg_touch_for(bands, lh, hh, hl, planes, h, w);
     const int64_t hw = (int64_t)h * w, total = planes * 3 * hw;
     const T s = (T)0.70710678118654752440;
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {

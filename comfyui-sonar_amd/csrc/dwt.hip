@@ -16,6 +16,7 @@ namespace sonar {
 template <typename T>
 __global__ void __launch_bounds__(kBlock) dwt_rows_kernel(const T* __restrict__ x, T* __restrict__ tmp, int64_t rows, int W,
                                                            int w, Taps<T> tp, int mode) {
+    kernarg_touch_for(x, tmp, rows, W, w, tp, mode);
     const int64_t total = rows * w;
     const int F = tp.len;
     const int We = (mode == kPeriodization && (W & 1)) ? W + 1 : W;
@@ -48,6 +49,7 @@ __global__ void __launch_bounds__(kBlock) dwt_rows_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) dwt_cols_kernel(const T* __restrict__ tmp, T* __restrict__ ll, T* __restrict__ hi,
                                                            int64_t planes, int H, int h, int w, Taps<T> tp, int mode) {
+    kernarg_touch_for(tmp, ll, hi, planes, H, h, w, tp, mode);
     const int64_t total = planes * h * w;
     const int F = tp.len;
     const int He = (mode == kPeriodization && (H & 1)) ? H + 1 : H;
@@ -89,6 +91,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock) idwt_cols_kernel(const T* __restrict__ ll, int ll_h, int ll_w,
                                                             const T* __restrict__ hi, T* __restrict__ tmp, int64_t planes, int h,
                                                             int w, int Hr, Taps<T> tp, int mode) {
+    kernarg_touch_for(ll, ll_h, ll_w, hi, tmp, planes, h, w, Hr, tp, mode);
     const int64_t total = planes * Hr * w;
     const int64_t hw = (int64_t)h * w;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -108,6 +111,7 @@ __global__ void __launch_bounds__(kBlock) idwt_cols_kernel(const T* __restrict__
 template <typename T>
 __global__ void __launch_bounds__(kBlock) idwt_rows_kernel(const T* __restrict__ tmp, T* __restrict__ out, int64_t planes, int w,
                                                             int Hr, int Ho, int Wo, Taps<T> tp, int mode) {
+    kernarg_touch_for(tmp, out, planes, w, Hr, Ho, Wo, tp, mode);
     const int64_t total = planes * Ho * Wo;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int xo = (int)(i % Wo);
@@ -124,6 +128,7 @@ __global__ void __launch_bounds__(kBlock) idwt_rows_kernel(const T* __restrict__
 template <typename T, bool HEAD>
 __global__ void __launch_bounds__(kBlock) wcfg_band_kernel(const T* cond, const T* uncond, T* out /* may alias cond / uncond */, int64_t n, int64_t group_size, int groups,
                                                             BandScales<T> sc, int blend_mode, T strength) {
+    kernarg_touch_for(cond, uncond, out, n, group_size, groups, sc, blend_mode, strength);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const int g = HEAD ? (int)(i % group_size != 0) : groups > 1 ? (int)((i / group_size) % groups) : 0;
         out[i] = band_combine<T>(cond[i], uncond[i], sc, g, blend_mode, strength);
@@ -134,6 +139,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock) wcfg_output_kernel(const float* __restrict__ x, const T* __restrict__ res,
                                                               float* __restrict__ out, int64_t planes, int H, int W, int Hr,
                                                               int Wr, int subtract) {
+    kernarg_touch_for(x, res, out, planes, H, W, Hr, Wr, subtract);
     const int64_t total = planes * H * W;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int xo = (int)(i % W);
@@ -150,6 +156,7 @@ __global__ void __launch_bounds__(kBlock) wcfg_output_kernel(const float* __rest
 template <typename T>
 __global__ void __launch_bounds__(kBlock) dwt1_fwd_kernel(const T* __restrict__ x, T* __restrict__ lo, T* __restrict__ hi,
                                                            int64_t rows, int L, int n, Taps<T> tp, int mode) {
+    kernarg_touch_for(x, lo, hi, rows, L, n, tp, mode);
     const int64_t total = rows * n;
     const int F = tp.len;
     const int Le = (mode == kPeriodization && (L & 1)) ? L + 1 : L;
@@ -191,6 +198,7 @@ __global__ void __launch_bounds__(kBlock) dwt1_fwd_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(kBlock) dwt1_inv_kernel(const T* __restrict__ lo, int lo_len, const T* __restrict__ hi,
                                                            T* __restrict__ out, int64_t rows, int n, int Lo, Taps<T> tp, int mode) {
+    kernarg_touch_for(lo, lo_len, hi, out, rows, n, Lo, tp, mode);
     const int64_t total = rows * Lo;
     const int F = tp.len;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {

@@ -95,6 +95,7 @@ struct One1 {
 template <typename T, typename TIO, int FT, int NT, bool ZERO, bool AHEAD = false, typename TV = T, bool HASB = true>
 __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ ta, const TIO* __restrict__ tb, const TIO* xin, TIO* out,
                                                         BandsArgs<T> a) {
+    kernarg_touch_for(ta, tb, xin, out, a);
     auto at0 = [](int s) { return ZERO ? max(s, 0) : s; };                       // index of a tap's sample
     auto live = [](int s, T v) { return ZERO ? (s >= 0 ? v : T(0)) : v; };       // its value
     extern __shared__ __align__(16) unsigned char bands_smem[];

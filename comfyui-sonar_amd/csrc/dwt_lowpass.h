@@ -94,6 +94,7 @@ __device__ __forceinline__ void synth_low_pair(int m, int n, int mode, const T* 
 template <typename T, int FT, bool ZERO>
 __global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* __restrict__ cond, const float* __restrict__ uncond,
                                                                     const float* __restrict__ xin, float* __restrict__ out, LowArgs<T> a) {
+    kernarg_touch_for(cond, uncond, xin, out, a);
     auto at0 = [](int s) { return ZERO ? max(s, 0) : s; };
     auto live = [](int s, T v) { return ZERO ? (s >= 0 ? v : T(0)) : v; };
     extern __shared__ __align__(16) unsigned char low_smem[];

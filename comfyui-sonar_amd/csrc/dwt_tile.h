@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(kTileThreads) dwt2_tile_kernel(const TIn* __re
                                                                  T* __restrict__ llc, T* __restrict__ llu, THi* __restrict__ hi,
                                                                  int64_t planes, int H, int W, int h, int w, int tiles, Taps<T> tp,
                                                                  int mode, BandArgs<T> ba) {
+    kernarg_touch_for(xc, xu, llc, llu, hi, planes, H, W, h, w, tiles, tp, mode, ba);
     extern __shared__ __align__(16) unsigned char tile_smem[];
     constexpr bool PAIR = MODE == kFwdPair, TWO = PAIR || MODE == kFwdDiff;
     const FwdLds<T, PAIR ? 4 : 2, FT> lds(tile_smem, W, w);
@@ -459,6 +460,7 @@ __global__ void __launch_bounds__(kTileThreads) idwt2_tile_kernel(const T* __res
                                                                   const float* __restrict__ xsub, float* __restrict__ outf,
                                                                   int64_t planes, int h, int w, int Ho, int Wo, int tiles, Taps<T> tp,
                                                                   int mode, int subtract, FinalMix mix) {
+    kernarg_touch_for(ll, ll_h, ll_w, hi, out, xsub, outf, planes, h, w, Ho, Wo, tiles, tp, mode, subtract, mix);
     extern __shared__ __align__(16) unsigned char tile_smem[];
     T* const tmp = reinterpret_cast<T*>(tile_smem);  // [kInvRows][lo_w | hi_w]
     const int64_t hw = (int64_t)h * w, ohw = (int64_t)Ho * Wo;
@@ -501,6 +503,7 @@ struct DeepArgs {
 
 template <typename T, int FT, bool ZERO, bool DIFF>
 __global__ void __launch_bounds__(kTileThreads) wcfg_deep_kernel(T* base, DeepArgs<T> a) {
+    kernarg_touch_for(base, a);
     extern __shared__ __align__(16) unsigned char tile_smem[];
     for (int64_t p = blockIdx.x; p < a.planes; p += gridDim.x) {
         // ---- analysis, finest deep level first

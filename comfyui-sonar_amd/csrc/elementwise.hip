@@ -40,6 +40,7 @@ __device__ __forceinline__ void store(float* p, int64_t i, const Pack<V>& r) {
 // Generic driver: op.template run<V>(elem_index) handles V consecutive elements.
 template <int V, typename Op>
 __global__ void __launch_bounds__(kBlock) ew_kernel(Op op, int64_t n) {
+    kernarg_touch_for(op, n);
     const int64_t nv = n / V;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += stride) op.template run<V>(i * V);
@@ -70,6 +71,7 @@ static int launch_ew(Op op, int64_t n, bool vec_ok, hipStream_t st, const char* 
 // stats: (sum, sumsq) partials in fp64
 template <int V>
 __global__ void __launch_bounds__(kBlock) stats_kernel(const float* __restrict__ x, int64_t n, double* partials) {
+    kernarg_touch_for(x, n, partials);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const int64_t nv = n / V;
@@ -104,6 +106,7 @@ __global__ void __launch_bounds__(kBlock) stats_kernel(const float* __restrict__
 
 __global__ void __launch_bounds__(kBlock) stats_finalize_kernel(const double* __restrict__ partials, int64_t npart,
                                                                  int64_t n, double* out3) {
+    kernarg_touch_for(partials, npart, n, out3);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     for (int64_t i = threadIdx.x; i < npart; i += kBlock) {
@@ -122,6 +125,7 @@ template <int V, bool NT = false /* common.h store4: launch-bound sizes */>
 __global__ void __launch_bounds__(kBlock) scale_noise_kernel(float* x, int64_t n, float factor, int normalized,
                                                              float thr_sd, const double* __restrict__ partials,
                                                              int64_t npart, int64_t n_total, double* out_partials) {
+    kernarg_touch_for(x, n, factor, normalized, thr_sd, partials, npart, n_total, out_partials);
     __shared__ double red[2 * kBlock / 64];
     __shared__ NormDecision sh;
     NormDecision d{0.f, 1.f, 0, 0};
@@ -222,6 +226,7 @@ __device__ __forceinline__ void row_visit(const float* __restrict__ row, int64_t
 // normalize_dims variant (py/utils.py:96-99): one block per row of `inner` contiguous elements
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) scale_rows_kernel(float* x, int64_t rows, int64_t inner, float factor) {
+    kernarg_touch_for(x, rows, inner, factor);
     __shared__ double red[2 * THREADS / 64];
     __shared__ float sh_val;
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
@@ -264,6 +269,7 @@ __global__ void __launch_bounds__(THREADS) scale_rows_kernel(float* x, int64_t r
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) minmax_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
                                                               float* out_min, float* out_max) {
+    kernarg_touch_for(x, rows, inner, out_min, out_max);
     __shared__ float smin[THREADS / 64], smax[THREADS / 64];
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float* row = x + r * inner;
@@ -377,6 +383,7 @@ struct ScalarOp {
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) rowstats_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
                                                            float* mean, float* stdv) {
+    kernarg_touch_for(x, rows, inner, mean, stdv);
     __shared__ double red[2 * THREADS / 64];
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float* row = x + r * inner;
@@ -399,6 +406,7 @@ __global__ void __launch_bounds__(THREADS) rowstats_kernel(const float* __restri
 __global__ void __launch_bounds__(kBlock) row_affine_kernel(int op, const float* __restrict__ x, int64_t rows,
                                                              int64_t inner, const float* __restrict__ a,
                                                              const float* __restrict__ b, float* out) {
+    kernarg_touch_for(op, x, rows, inner, a, b, out);
     const int64_t total = rows * inner;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / inner;
@@ -412,6 +420,7 @@ __global__ void __launch_bounds__(kBlock) row_affine_kernel(int op, const float*
 __global__ void __launch_bounds__(kBlock) minmax_rescale_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
                                                                  const float* __restrict__ lo, const float* __restrict__ hi, float eps,
                                                                  float tmin, float tmax, float span, float* out) {
+    kernarg_touch_for(x, rows, inner, lo, hi, eps, tmin, tmax, span, out);
     const int64_t total = rows * inner;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / inner;
@@ -425,6 +434,7 @@ __global__ void __launch_bounds__(kBlock) minmax_rescale_kernel(const float* __r
 // normalize_to_scale_adv (py/utils.py:473-510): the negative and the positive values of a row are rescaled separately, each between its
 // own extremes.  Pass 1: per row (min, max) over the negatives and over the positives (+-inf where a sign has no value).
 __global__ void __launch_bounds__(kBlock) signed_minmax_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner, float4* __restrict__ out) {
+    kernarg_touch_for(x, rows, inner, out);
     __shared__ float red[4][kBlock / 64];
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         float nlo = INFINITY, nhi = -INFINITY, plo = INFINITY, phi = -INFINITY;
@@ -469,6 +479,7 @@ __global__ void __launch_bounds__(kBlock) signed_minmax_rows_kernel(const float*
 __global__ void __launch_bounds__(kBlock) signed_rescale_kernel(const float* __restrict__ x, int64_t rows, int64_t inner,
                                                                  const float4* __restrict__ stats, double min_neg, double max_neg, double min_pos,
                                                                  double max_pos, int skip_neg, int skip_pos, float eps, float* __restrict__ out) {
+    kernarg_touch_for(x, rows, inner, stats, min_neg, max_neg, min_pos, max_pos, skip_neg, skip_pos, eps, out);
     const int64_t total = rows * inner;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const float4 st = stats[i / inner];
@@ -499,6 +510,7 @@ __global__ void __launch_bounds__(kBlock) signed_rescale_kernel(const float* __r
 
 __global__ void __launch_bounds__(kBlock) amax_mid_kernel(const float* __restrict__ x, int64_t outer, int64_t mid,
                                                            int64_t inner, int use_abs, float* peak) {
+    kernarg_touch_for(x, outer, mid, inner, use_abs, peak);
     const int64_t total = outer * inner;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
         const int64_t o = t / inner, i = t - o * inner;
@@ -519,6 +531,7 @@ __global__ void __launch_bounds__(kBlock) amax_mid_kernel(const float* __restric
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) amax_row_kernel(const float* __restrict__ x, int64_t rows, int64_t len, int use_abs,
                                                                 float* peak) {
+    kernarg_touch_for(x, rows, len, use_abs, peak);
     __shared__ float smax[THREADS / 64];
     __shared__ int snan[THREADS / 64];
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
@@ -552,6 +565,7 @@ __global__ void __launch_bounds__(THREADS) amax_row_kernel(const float* __restri
 
 __global__ void __launch_bounds__(kBlock) div_mid_kernel(float* x, int64_t outer, int64_t mid, int64_t inner,
                                                           const float* __restrict__ d) {
+    kernarg_touch_for(x, outer, mid, inner, d);
     const int64_t total = outer * mid * inner, plane = mid * inner;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
         const int64_t o = t / plane;
@@ -564,6 +578,7 @@ __global__ void __launch_bounds__(kBlock) div_mid_kernel(float* x, int64_t outer
 // unbiased std over the middle axis of x[outer][mid][inner] (torch.std(dim=-3, keepdim=True)); mid == 1 gives NaN like torch
 __global__ void __launch_bounds__(kBlock) std_mid_kernel(const float* __restrict__ x, int64_t outer, int64_t mid, int64_t inner,
                                                           float* stdv) {
+    kernarg_touch_for(x, outer, mid, inner, stdv);
     const int64_t total = outer * inner;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
         const int64_t o = t / inner, i = t - o * inner;
@@ -585,6 +600,7 @@ __global__ void __launch_bounds__(kBlock) std_mid_kernel(const float* __restrict
 __global__ void __launch_bounds__(kBlock) bcast_gain_kernel(const float* __restrict__ x, const float* __restrict__ stdv, int64_t outer,
                                                              int64_t mid, int64_t inner, int64_t so, int64_t sm, int64_t si,
                                                              float abs_strength, float k, float* out, double* partials) {
+    kernarg_touch_for(x, stdv, outer, mid, inner, so, sm, si, abs_strength, k, out, partials);
     __shared__ double red[2 * kBlock / 64];
     const int64_t total = outer * mid * inner, plane = mid * inner;
     double sx = 0.0, sv = 0.0;
@@ -607,6 +623,7 @@ __global__ void __launch_bounds__(kBlock) bcast_gain_kernel(const float* __restr
 __global__ void __launch_bounds__(kBlock) ratio_mix_kernel(const float* __restrict__ a, float a_mul, const float* __restrict__ x,
                                                             float x_mul, const double* __restrict__ num, double num_mul,
                                                             const double* __restrict__ den, float* out, int64_t n) {
+    kernarg_touch_for(a, a_mul, x, x_mul, num, num_mul, den, out, n);
     __shared__ double red[2 * kBlock / 64];
     __shared__ float srho;
     double sn = 0.0, sd = 0.0;
@@ -672,6 +689,7 @@ constexpr int kQuantReplicas = 32;
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) abs_quantile_rows_kernel(const float* __restrict__ x, int64_t rows, int64_t inner, int64_t lo,
                                                                         float frac, float* out) {
+    kernarg_touch_for(x, rows, inner, lo, frac, out);
     __shared__ unsigned hist[256 * kQuantReplicas];
     __shared__ unsigned total[256];
     __shared__ unsigned sh_prefix, sh_k, sh_cnt, sh_min;
@@ -768,6 +786,7 @@ __global__ void __launch_bounds__(THREADS) abs_quantile_rows_kernel(const float*
 // x = copysign(|clamp(x, -lim, lim)|^p, x) per row, lim = limit[row] * mul (StudentT: clamp to the quantile, compress the tails)
 __global__ void __launch_bounds__(kBlock) clamp_signpow_rows_kernel(float* x, int64_t rows, int64_t inner, const float* __restrict__ limit,
                                                                      float mul, float p) {
+    kernarg_touch_for(x, rows, inner, limit, mul, p);
     const int64_t total = rows * inner;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const float lim = limit[i / inner] * mul;
@@ -798,6 +817,7 @@ struct SqAccOp {
 // normalisation without a separate statistics sweep
 __global__ void __launch_bounds__(kBlock) axpby_stats_kernel(float* y, float ymul, const float* __restrict__ x, float xmul, int64_t n,
                                                               double* partials) {
+    kernarg_touch_for(y, ymul, x, xmul, n, partials);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const int64_t nv = n / 4;
@@ -829,6 +849,7 @@ __global__ void __launch_bounds__(kBlock) axpby_stats_kernel(float* y, float ymu
 // tensor; with `follow_sign` the result takes the sign of 1 - s (torch.copysign(result, 1 - s))
 __global__ void __launch_bounds__(kBlock) mul_table_kernel(float* x, const float* __restrict__ s, int64_t n, int64_t inner, int64_t len,
                                                             int follow_sign) {
+    kernarg_touch_for(x, s, n, inner, len, follow_sign);
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const float sv = s[(i / inner) % len];
         float v = x[i] * sv;
@@ -955,6 +976,7 @@ struct PendingNorm {  // one thread's copy of the decision (read once per item, 
 
 __global__ void __launch_bounds__(kBlock) norm_decision_kernel(const double* __restrict__ partials, int64_t npart, int64_t n_total, float factor,
                                                                 float thr_sd, sonar_noise_norm* out) {
+    kernarg_touch_for(partials, npart, n_total, factor, thr_sd, out);
     __shared__ double red[2 * kBlock / 64];
     __shared__ NormDecision sh;
     const NormDecision d = decide_norm<kBlock>(partials, npart, n_total, thr_sd, red, &sh);
@@ -1122,6 +1144,7 @@ struct CastOp {
 // real_out: only the real part is written, to a float array.  C <= 64: every output sums C terms read through L1 / L2.
 __global__ void __launch_bounds__(kBlock) cdft_mid_kernel(const float* __restrict__ zin, float* __restrict__ zout, int64_t outer, int C,
                                                           int64_t inner, int inverse, int real_in, int real_out) {
+    kernarg_touch_for(zin, zout, outer, C, inner, inverse, real_in, real_out);
     const int64_t total = outer * C * inner;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (int64_t)gridDim.x * kBlock) {
         const int64_t i = t % inner;
@@ -1155,6 +1178,7 @@ __global__ void __launch_bounds__(kBlock) cdft_mid_kernel(const float* __restric
 // partners ((C - c) % C, (H - ky) % H, W - kx) -- C > 1 when a channel DFT was applied on top (fftn over (-3, -2, -1)).
 __global__ void __launch_bounds__(kBlock) spectral_logamp_kernel(const float2* __restrict__ z, float* __restrict__ la, float* __restrict__ full,
                                                                  int64_t planes, int C, int H, int W, int Wz) {
+    kernarg_touch_for(z, la, full, planes, C, H, W, Wz);
     const int64_t nz = planes * H * Wz;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < nz; t += (int64_t)gridDim.x * kBlock) {
         const float2 v = z[t];
@@ -1164,6 +1188,7 @@ __global__ void __launch_bounds__(kBlock) spectral_logamp_kernel(const float2* _
 }
 __global__ void __launch_bounds__(kBlock) spectral_full_kernel(const float* __restrict__ la, float* __restrict__ full, int64_t planes, int C,
                                                                int H, int W, int Wz) {
+    kernarg_touch_for(la, full, planes, C, H, W, Wz);
     const int64_t nf = planes * H * W;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < nf; t += (int64_t)gridDim.x * kBlock) {
         const int kx = (int)(t % W), ky = (int)((t / W) % H);
@@ -1196,6 +1221,7 @@ __device__ __forceinline__ float signum_mult(float a, const float* __restrict__ 
 __global__ void __launch_bounds__(kBlock) spectral_signum_mask_kernel(float2* z, const float* __restrict__ la, const float* __restrict__ q, int nq,
                                                                       int64_t planes, int C, int64_t plane_elems, float intensity, float gain,
                                                                       int channel_sym) {
+    kernarg_touch_for(z, la, q, nq, planes, C, plane_elems, intensity, gain, channel_sym);
     const int64_t n = planes * plane_elems;
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n; t += (int64_t)gridDim.x * kBlock) {
         const int64_t p = t / plane_elems;
@@ -1511,6 +1537,7 @@ extern "C" int sonar_spectral_signum_mask_f32(float* z, const float* la, const f
 // sees the value.
 __global__ void __launch_bounds__(kBlock) max_to_host_kernel(const float* __restrict__ x, int64_t n, unsigned long long* __restrict__ host_out,
                                                              unsigned ticket) {
+    kernarg_touch_for(x, n, host_out, ticket);
     __shared__ float part[kBlock / 64];
     __shared__ int nan_part[kBlock / 64];
     float m = -INFINITY;

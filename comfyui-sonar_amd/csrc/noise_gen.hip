@@ -155,6 +155,7 @@ struct Affine {
 template <Dist D, bool VEC, bool STATS>
 __global__ void __launch_bounds__(kBlock) stream_fill_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
                                                              int64_t elem_offset, Affine aff, double* partials, Accum acc) {
+    kernarg_touch_for(out, n, seed, stream_id, elem_offset, aff, partials, acc);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     for_each_group<D>(n, seed, stream_id, elem_offset, [&](int64_t e, float (&v)[4]) {
@@ -193,6 +194,7 @@ static int launch_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
 // fly.  Whole groups of four only (n, elem_offset multiples of 4, 16-byte aligned tensors, Perlin latents of a multiple of 4).
 template <int HOST, int PRE, bool STATS>
 __global__ void __launch_bounds__(kBlock) pair_fold_kernel(Accum fold, int64_t n, int64_t elem_offset, Prefix host, Prefix pre, double* partials) {
+    kernarg_touch_for(fold, n, elem_offset, host, pre, partials);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const uint32_t lane = threadIdx.x & 63;
@@ -263,6 +265,7 @@ static int launch_pair_fold(const sonar_accumulate* acc, const sonar_fold_prefix
 template <Dist D, bool VEC, int MODE>
 __global__ void __launch_bounds__(kBlock) stream_fill_norm_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
                                                                   int64_t elem_offset, Affine aff, double* partials, NormArgs na) {
+    kernarg_touch_for(out, n, seed, stream_id, elem_offset, aff, partials, na);
     __shared__ double red[2 * kBlock / 64];
     __shared__ NormDecision sh;
     NormDecision dec{0.f, 1.f, 0, 0};
@@ -315,6 +318,7 @@ static int launch_fill_norm(float* out, int64_t n, uint64_t seed, uint64_t strea
 // Perlin: lattice term at cell centre (py/noise_generation.py:388-405 with positions == (0.5, 0.5)).
 __global__ void __launch_bounds__(kBlock) perlin_terms_kernel(const float* __restrict__ angles, float* terms,
                                                                int64_t planes /*iters*C*/, int H, int W, int blend_mode) {
+    kernarg_touch_for(angles, terms, planes, H, W, blend_mode);
     const int64_t total = planes * H * W;
     const int gw = W + 1;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -375,6 +379,7 @@ __device__ __forceinline__ void perlin_lattice_cells(float* terms_sum, int iters
 
 __global__ void __launch_bounds__(kBlock) perlin_lattice_kernel(float* terms_sum, int iters, int64_t C, int H, int W, int blend_mode,
                                                                 uint64_t seed, uint64_t stream_id) {
+    kernarg_touch_for(terms_sum, iters, C, H, W, blend_mode, seed, stream_id);
     perlin_lattice_cells(terms_sum, iters, C, H, W, blend_mode, seed, stream_id, blockIdx.x, gridDim.x);
 }
 
@@ -384,6 +389,7 @@ template <bool STATS, int V>
 __global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __restrict__ base,
                                                                const float* __restrict__ terms, float* out, int64_t B,
                                                                int64_t chw, int iters, float div_fac, double* partials) {
+    kernarg_touch_for(base, terms, out, B, chw, iters, div_fac, partials);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const int64_t n = B * chw;
@@ -507,6 +513,7 @@ __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __
                                                                   int64_t chw, int iters, float div_fac, uint64_t seed,
                                                                   uint64_t stream_id, int64_t elem_offset, double* partials,
                                                                   NormArgs na, Accum acc) {
+    kernarg_touch_for(terms, out, B, chw, iters, div_fac, seed, stream_id, elem_offset, partials, na, acc);
     __shared__ double red[2 * kBlock / 64];
     __shared__ NormDecision sh;
     NormDecision dec{0.f, 1.f, 0, 0};
@@ -650,6 +657,7 @@ struct PerlinAhead {
 };
 
 __global__ void __launch_bounds__(kBlock) perlin_ahead_kernel(PerlinAhead a) {
+    kernarg_touch_for(a);
     __shared__ double red[2 * kBlock / 64];
     __shared__ NormDecision sh;
     if ((int)blockIdx.x < a.lat_blocks) {
@@ -778,6 +786,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(kBlock) resample_acc_kernel(float* dst, const float* __restrict__ src, int64_t planes,
                                                                int H, int W, int h, int w, float scale, int mode,
                                                                int accumulate, double* partials) {
+    kernarg_touch_for(dst, src, planes, H, W, h, w, scale, mode, accumulate, partials);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const int64_t total = planes * H * W;
@@ -837,6 +846,7 @@ __global__ void __launch_bounds__(kBlock) pyramid_generate_kernel(float* out, in
                                                                   PyramidLevels lv, int mode, uint64_t seed,
                                                                   uint64_t stream_id, int64_t elem_offset,
                                                                   double* partials, NormArgs na) {
+    kernarg_touch_for(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, na);
     __shared__ double red[2 * kBlock / 64];
     __shared__ NormDecision sh;
     NormDecision dec{0.f, 1.f, 0, 0};
@@ -939,18 +949,6 @@ static_assert((kPyrParts & (kPyrParts - 1)) == 0 && kTileIters % kPyrParts == 0,
 // same (tile, iteration) sequence.
 // A Perlin lattice computed in `blocks` extra leading workgroups of a plane-kernel launch: the lattice of a LATER call's hosted Perlin item
 // (sonar_pyramid_generate_acc_ahead_f32) -- independent of everything else in the launch.  blocks == 0: none.
-// Every 64-byte line of a kernel's argument block requested at its first instruction.  The compiler loads arguments where it first needs
-// them, a batch and a wait at a time; with ~560 bytes of arguments (the levels' tables) that was four or five scalar-cache misses one after
-// the other before the first table entry could be written: 2.2-2.4 k cycles, 1 us, at the top of every workgroup (trace build, round 5).
-template <size_t BYTES>
-__device__ __forceinline__ void kernarg_touch() {
-    const uint32_t __attribute__((address_space(4)))* ka = (const uint32_t __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t any = 0;
-#pragma unroll
-    for (size_t k = 0; k < BYTES; k += 64) any |= ka[k / 4];
-    asm volatile("" ::"s"(any));
-}
-
 // N words of a stream passed over as straight-line code: a counted loop around one multiply-add spent 96 cycles per word on its own
 // bookkeeping (vector-exec loop, trace build of round 5: 3.1 k cycles for the 32 words of half a burst)
 template <int N>
@@ -971,6 +969,7 @@ template <bool STATS, bool XROWS, int PRE = 0, bool NT = false /* common.h store
 __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
                                                                uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                                                                double* partials, int grid_floats, Accum fold, Prefix pre, LatticeJob lat) {
+    kernarg_touch_for(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, grid_floats, fold, pre, lat);
     extern __shared__ __align__(16) float pyr_lds[];
     __shared__ double red[2 * kPyrBlock / 64];
     // the levels' parameters where a thread can index them by a run-time level (kernel arguments live in scalar registers: per-level
@@ -978,8 +977,6 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     __shared__ int lvl_h[kMaxLevels], lvl_w[kMaxLevels], lvl_off[kMaxLevels + 1], lvl_item0[kMaxLevels + 1], lvl_row0[kMaxLevels];
     __shared__ float lvl_weight[kMaxLevels];
     __shared__ unsigned long long lvl_stream[kMaxLevels];
-    kernarg_touch<sizeof(float*) + sizeof(int64_t) + 2 * sizeof(int) + sizeof(PyramidLevels) + sizeof(int) + 2 * sizeof(uint64_t) + sizeof(int64_t) +
-                  sizeof(double*) + sizeof(int) + sizeof(Accum) + sizeof(Prefix) + sizeof(LatticeJob)>();
     if ((int)blockIdx.x < lat.blocks) {
         perlin_lattice_cells<kPyrBlock>(lat.out, lat.iters, lat.C, H, W, lat.blend_mode, lat.seed, lat.stream_id, blockIdx.x, lat.blocks);
         return;
@@ -1436,6 +1433,7 @@ struct SampledLevels {
 template <int MODE>
 __global__ void __launch_bounds__(kBlock) levels_sampled_kernel(float* out, int64_t planes, int H, int W, SampledLevels lv, uint64_t seed,
                                                                  uint64_t stream0, int64_t plane_offset, int accumulate) {
+    kernarg_touch_for(out, planes, H, W, lv, seed, stream0, plane_offset, accumulate);
     const int64_t total = planes * H * W;
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
         const int64_t p = idx / ((int64_t)H * W);
@@ -1479,6 +1477,7 @@ __global__ void __launch_bounds__(kBlock) levels_sampled_kernel(float* out, int6
 
 __global__ void __launch_bounds__(kBlock) level_normal_kernel(float* level, int64_t n, float sd, uint64_t seed, uint64_t stream,
                                                                int64_t elem_offset) {
+    kernarg_touch_for(level, n, sd, seed, stream, elem_offset);
     // a thread per Philox group of four consecutive elements (the ends of the range may cut a group)
     const int64_t g0 = elem_offset >> 2, g1 = (elem_offset + n + 3) >> 2;
     for (int64_t g = g0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; g < g1; g += (int64_t)gridDim.x * kBlock) {
@@ -1531,6 +1530,7 @@ template <int PRE>
 __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
                                                                 uint64_t seed, const float* prev, float* w_out, float scale,
                                                                 BrownianBase base, Accum fold, double* partials, Prefix pre) {
+    kernarg_touch_for(out, n, elem_offset, terms, seed, prev, w_out, scale, base, fold, partials, pre);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     const uint32_t lane = threadIdx.x & 63;
@@ -1611,6 +1611,7 @@ __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n,
                                                           uint64_t seed, const unsigned long long* __restrict__ latent_seeds,
                                                           int64_t latent_elems, const float* prev, float* w_out, float scale,
                                                           BrownianBase base, Accum fold, double* partials) {
+    kernarg_touch_for(out, n, elem_offset, terms, seed, latent_seeds, latent_elems, prev, w_out, scale, base, fold, partials);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
     // a thread owns one GLOBAL group of four elements (the counter of its draws): a shard whose first element is not a multiple of

@@ -9,6 +9,7 @@ namespace sonar {
 __global__ void __launch_bounds__(kFftThreads) power_stats_any_kernel(const float* __restrict__ filter, int64_t planes, AnyPlan pl,
                                                                       uint64_t seed, uint64_t stream_id, int64_t plane_offset, int group,
                                                                       int split, double* partials) {
+    kernarg_touch_for(filter, planes, pl, seed, stream_id, plane_offset, group, split, partials);
     extern __shared__ __align__(16) unsigned char any_lds[];
     __shared__ double red[2 * kFftThreads / 64];
     power_stats_any_body(filter, planes, pl, seed, stream_id, plane_offset, group, split, partials, blockIdx.x, gridDim.x,
@@ -17,6 +18,7 @@ __global__ void __launch_bounds__(kFftThreads) power_stats_any_kernel(const floa
 
 __global__ void __launch_bounds__(kFftThreads) power_spectrum_any_kernel(float* zout, int64_t planes, AnyPlan pl, uint64_t seed,
                                                                          uint64_t stream_id, int64_t plane_offset, int group, int split) {
+    kernarg_touch_for(zout, planes, pl, seed, stream_id, plane_offset, group, split);
     const int H = pl.H, M = pl.M, S = pl.S, NC = H * S;
     const int tid = threadIdx.x;
     for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
@@ -120,6 +122,7 @@ __device__ __forceinline__ void lines_table(c32* tw, int N, int tid) {  // e^{2 
 // y[row][k] = sum_x x[row][x] e^{-2 pi i k x / W}, k = 0 .. W/2; `per` rows per batch
 __global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_kernel(const float* __restrict__ x, c32* __restrict__ y, int64_t rows, int W, int n1,
                                                                      int n2, int per) {
+    kernarg_touch_for(x, y, rows, W, n1, n2, per);
     extern __shared__ __align__(16) unsigned char any_lds[];
     const int M = W / 2, S = M + 1, tid = threadIdx.x;
     c32* const A = reinterpret_cast<c32*>(any_lds);
@@ -166,6 +169,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kLinesThreads, 4) lines_cols_kernel(const c32* __restrict__ in, const float* __restrict__ filter,
                                                                       c32* __restrict__ out, int64_t planes, int H, int K, int n1, int n2,
                                                                       int cols) {
+    kernarg_touch_for(in, filter, out, planes, H, K, n1, n2, cols);
     extern __shared__ __align__(16) unsigned char any_lds[];
     const int S = cols | 1, tid = threadIdx.x;  // odd row stride
     c32* const A = reinterpret_cast<c32*>(any_lds);
@@ -220,6 +224,7 @@ static __device__ unsigned long long g_lines_trace[512 * 4 * 8];
 template <bool STATS, bool NORM = false, int CR1 = 0, int CR2 = 0>
 __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_kernel(const c32* __restrict__ y, float* __restrict__ out, int64_t rows, int W, int n1,
                                                                      int n2, int per, float scale, double* partials, NormArgs na) {
+    kernarg_touch_for(y, out, rows, W, n1, n2, per, scale, partials, na);
     extern __shared__ __align__(16) unsigned char any_lds[];
     __shared__ double red[2 * kLinesThreads / 64];
     __shared__ NormDecision shd;
@@ -332,6 +337,7 @@ extern "C" int sonar_debug_lines_trace(unsigned long long* host_out) {
 // way out) -- twice the arithmetic of an even neighbour, not the O(W) per value of the direct sums (135 = 15 x 9 runs as two codelets).
 __global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_odd_kernel(const float* __restrict__ x, c32* __restrict__ y, int64_t rows, int W, int n1,
                                                                          int n2, int per) {
+    kernarg_touch_for(x, y, rows, W, n1, n2, per);
     extern __shared__ __align__(16) unsigned char any_lds[];
     const int K = W / 2 + 1, S = W | 1, tid = threadIdx.x;
     c32* const A = reinterpret_cast<c32*>(any_lds);
@@ -356,6 +362,7 @@ __global__ void __launch_bounds__(kLinesThreads, 4) lines_r2c_odd_kernel(const f
 template <bool STATS>
 __global__ void __launch_bounds__(kLinesThreads, 4) lines_c2r_odd_kernel(const c32* __restrict__ y, float* __restrict__ out, int64_t rows, int W, int n1,
                                                                          int n2, int per, float scale, double* partials) {
+    kernarg_touch_for(y, out, rows, W, n1, n2, per, scale, partials);
     extern __shared__ __align__(16) unsigned char any_lds[];
     __shared__ double red[2 * kLinesThreads / 64];
     const int K = W / 2 + 1, S = W | 1, tid = threadIdx.x;

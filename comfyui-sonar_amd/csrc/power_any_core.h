@@ -649,6 +649,7 @@ __global__ void __launch_bounds__(NT, 4) power_irfft2_any_kernel(const float* __
                                                                        float* out, int64_t planes, AnyPlan pl, uint64_t seed,
                                                                        uint64_t stream_id, int64_t plane_offset, int group, int split,
                                                                        double* partials, NormArgs na, StatsAhead sa) {
+    kernarg_touch_for(z, filter, out, planes, pl, seed, stream_id, plane_offset, group, split, partials, na, sa);
     extern __shared__ __align__(16) unsigned char any_lds[];
     __shared__ double red[2 * NT / 64];
     __shared__ NormDecision shd;

@@ -94,6 +94,7 @@ template <int MODE, bool STATS = false, int CR1 = 0, int CR2 = 0>
 __global__ void __launch_bounds__(kBlockSlots, 4) power_block_cols_kernel(const float* __restrict__ filter, c32* __restrict__ ws, int64_t planes,
                                                                           BlockPlan pl, uint64_t seed, uint64_t stream_id, int64_t plane_offset,
                                                                           int group, int split, double* partials) {
+    kernarg_touch_for(filter, ws, planes, pl, seed, stream_id, plane_offset, group, split, partials);
     extern __shared__ __align__(16) unsigned char any_lds[];
     __shared__ double red[2 * kBlockSlots / 64];
     const int H = pl.H, S = pl.S, Sb = pl.bw | 1, tid = threadIdx.x;  // odd LDS row stride

@@ -35,6 +35,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>()), (plane_min_waves<H, W
                                                                        int64_t planes, uint64_t seed, uint64_t stream_id,
                                                                        int64_t plane_offset, int group, int split, double* partials,
                                                                        NormArgs na, StatsAhead sa) {
+    kernarg_touch_for(z, filter, out, planes, seed, stream_id, plane_offset, group, split, partials, na, sa);
     using C = PlaneCfg<H, W>;
     constexpr int NT = plane_threads<H, W>();
     constexpr int M = C::M, S = C::S;
@@ -1098,6 +1099,7 @@ __device__ __forceinline__ void sf_col_a_filter_col_a(c32* A, SfExchange<H>* xch
 template <int H, int W, bool STATS>
 __global__ void __launch_bounds__(512, 4) spectral_filter128_kernel(const float* __restrict__ x, const float* __restrict__ filter, float* out, int64_t planes,
                                                                      double* partials) {
+    kernarg_touch_for(x, filter, out, planes, partials);
     using C = PlaneCfg<H, W>;
     constexpr int NT = 512, M = C::M, S = C::S, Wh = C::Wh, RN1 = C::RN1, RN2 = C::RN2, CN1 = H / 8, CN2 = 8;
     static_assert(H == 128 && W == 128 && RN1 == 8 && RN2 == 8 && plane_threads<H, W>() == NT, "8 waves, 8 x 8 rows, 16 x 8 columns");
@@ -1329,10 +1331,16 @@ __device__ __forceinline__ void pin_chunk(c32 (&v)[N]) {
     }
 }
 
+#ifndef SONAR_PIPE_KERNARG_TOUCH
+#define SONAR_PIPE_KERNARG_TOUCH 1
+#endif
 template <int H, int W, bool STATS, bool NORM>
 __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restrict__ filter, float* out, int64_t planes, uint64_t seed,
                                                           uint64_t stream_id, int64_t plane_offset, int group, int split, double* partials,
                                                           NormArgs na, uint64_t next_stream, double* partials_next) {
+#if SONAR_PIPE_KERNARG_TOUCH
+    kernarg_touch_for(filter, out, planes, seed, stream_id, plane_offset, group, split, partials, na, next_stream, partials_next);
+#endif
     using C = PlaneCfg<H, W>;
     constexpr int NT = 512, NALL = 1024;
     static_assert(plane_threads<H, W>() == NT && W == 128 && H == 128, "one 8-wave team per plane, slot = one radix-16 column item");
@@ -1733,6 +1741,7 @@ template <int H, int W>
 __global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(const float* __restrict__ filter, int64_t planes, uint64_t seed,
                                                                    uint64_t stream_id, int64_t plane_offset, int group, int split,
                                                                    double* partials) {
+    kernarg_touch_for(filter, planes, seed, stream_id, plane_offset, group, split, partials);
     __shared__ c32 EDGE[kStatsBatch][2][H];
     __shared__ double red[2 * plane_threads<H, W>() / 64];
     power_stats_body<H, W>(filter, planes, seed, stream_id, plane_offset, group, split, partials, blockIdx.x, gridDim.x, EDGE, red);
@@ -1742,6 +1751,7 @@ __global__ void __launch_bounds__((plane_threads<H, W>())) power_stats_kernel(co
 template <int H, int W>
 __global__ void __launch_bounds__((plane_threads<H, W>())) power_spectrum_kernel(float* zout, int64_t planes, uint64_t seed, uint64_t stream_id,
                                                                       int64_t plane_offset, int group, int split) {
+    kernarg_touch_for(zout, planes, seed, stream_id, plane_offset, group, split);
     constexpr int M = W / 2, Wh = M + 1, NC = H * Wh;
     const int tid = threadIdx.x;
     for (int64_t unit = blockIdx.x; unit < (split ? planes : planes / group); unit += gridDim.x) {
@@ -1865,6 +1875,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(kBlock) channel_mix_kernel(const float* __restrict__ in,
                                                               const float* __restrict__ mixer, float* out, int64_t B,
                                                               int C, int64_t hw, double* partials) {
+    kernarg_touch_for(in, mixer, out, B, C, hw, partials);
     __shared__ double red[2 * kBlock / 64];
     __shared__ float m[kMaxMixC * kMaxMixC];
     for (int i = threadIdx.x; i < C * C; i += kBlock) m[i] = mixer[i];
