@@ -1209,7 +1209,27 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                 // WHOLE: the tile lies inside the plane (always, when planes are whole tiles): no per-lane ownership test around the stores
                 auto burst = [&](auto whole_c) {
                     constexpr bool WHOLE = decltype(whole_c)::value;
+                    // A hosted Perlin item's lattice vectors.  Launch-bound sizes (NT, one workgroup per CU): all of the part's share of
+                    // the burst requested before the first step, the loop unrolled so that the steps index them statically -- a step that
+                    // asks for its own waits for it with one other wave on its SIMD to cover: 7 k of the chain's 15.5 k cycles per tile
+                    // (trace build of round 5), chain at batch 64 26.1 -> 25.2 us.  At batch 512 (four waves per SIMD cover the load) the
+                    // same form is 3 % SLOWER (120 registers, eight copies of the step), and so is a request one step ahead in the rolled
+                    // loop (+5 %): there a step loads its own.
+                    constexpr bool AHEAD = PRE == 2 && NT;
+                    auto lattice = [&](int ei) {
+                        return PRE == 2 && (WHOLE || (ei >= 0 && ei < HW)) ? *reinterpret_cast<const float4*>(tplane + ei) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    };
+                    constexpr int NTV = AHEAD ? kIters : 1;
+                    float4 tva[NTV];
+                    if constexpr (AHEAD) {
+#pragma unroll
+                        for (int i = 0; i < kIters; ++i) tva[i] = lattice(e + 256 * i);
+                    }
+#pragma unroll NTV
                     for (int it0 = 0; it0 < kIters; it0 += G) {
+                        float4 tvs[G];
+#pragma unroll
+                        for (int j = 0; j < G; ++j) tvs[j] = AHEAD ? tva[AHEAD ? it0 + j : 0] : lattice(e + 256 * j);
                         float v[G][4], px[G][4];
                         int ee[G], yy[G], xx[G];
 #pragma unroll
@@ -1217,7 +1237,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                             rng.normal4(v[j]);
                             const bool ours = WHOLE || (e >= 0 && e < HW);
                             if constexpr (PRE != 0) {  // the prefix's generator walks every iteration of the tile, ours or not
-                                const float4 tv = PRE == 2 && ours ? *reinterpret_cast<const float4*>(tplane + e) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                const float4 tv = tvs[j];
                                 prefix_draw<PRE>(prng, pdiv, tv, px[j]);
                             }
                             ee[j] = e;
