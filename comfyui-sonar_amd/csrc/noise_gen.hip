@@ -1383,10 +1383,11 @@ SONAR_PYR_UNROLL
     SONAR_NG_STAMP(9);
 }
 
-// true if the plane kernel was launched
+// true if the plane kernel was launched; *slots (optional): the number of partial pairs its workgroups own (the rest are zeroed)
 static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t W, const PyramidLevels& lv, int mode, uint64_t seed,
                                  uint64_t stream_id, int64_t elem_offset, double* partials, hipStream_t st, Accum fold = kNoAccum,
-                                 int pre_kind = 0, Prefix pre = Prefix{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1, 0}, LatticeJob lat = kNoLattice) {
+                                 int pre_kind = 0, Prefix pre = Prefix{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1, 0}, LatticeJob lat = kNoLattice,
+                                 int* slots = nullptr) {
     size_t grid_floats = 0, rows = 0;
     for (int l = 0; l < lv.count; ++l) {
         grid_floats += (size_t)lv.h[l] * lv.w[l];
@@ -1399,6 +1400,7 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     const bool xrows = mode == 0 && W % 4 == 0 && lds_x <= kPyramidLdsBudget;
     static const int grid_cap = [] { const char* e = getenv("SONAR_PYR_GRID"); return e ? atoi(e) : kNPart; }();
     const int g = (int)std::min<int64_t>(planes, std::min(grid_cap, kNPart));
+    if (slots) *slots = g;
     const bool nt = nt_stores_host(planes * H * W);
 #define SONAR_PPN(ST, XR, P, N) \
     hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P, N>), dim3(g + lat.blocks), dim3(kPyrBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
@@ -2136,10 +2138,14 @@ extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, in
     if (rc != SONAR_OK) return rc;
     if (planes == 0) return SONAR_OK;
     // The level gathers make a re-draw cost more than a sweep: generate once (with statistics), then normalise in place
-    if (launch_pyramid_plane(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, (hipStream_t)stream)) {
+    int slots = kNPart;
+    if (launch_pyramid_plane(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, (hipStream_t)stream, kNoAccum, 0,
+                             Prefix{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1, 0}, kNoLattice, &slots)) {
         rc = check_launch("sonar_pyramid_noise_f32");
         if (rc != SONAR_OK) return rc;
-        return sonar_scale_noise_f32(out, planes * H * W, factor, 1, threshold_std_devs, partials, kNPart, planes * H * W, stream);
+        // the normalising pass reduces only the pairs the plane kernel's workgroups own (the others are zeros: the same sums, bit for bit,
+        // from a quarter of the reads at batch 64, where every one of its 2048 workgroups reduced 16 KB of partials for 8 KB of values)
+        return sonar_scale_noise_f32(out, planes * H * W, factor, 1, threshold_std_devs, partials, slots, planes * H * W, stream);
     }
     SONAR_REQUIRE(!drawn, SONAR_ERR_UNSUPPORTED, "sonar_pyramid_noise_f32: in-kernel level grids need the plane kernel: pass the grids explicitly");
     const int g = tile_grid(planes * H * W, elem_offset);
