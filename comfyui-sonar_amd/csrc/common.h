@@ -160,6 +160,8 @@ constexpr size_t kernarg_bytes() {
     ((off = (off + alignof(T) - 1) / alignof(T) * alignof(T) + sizeof(T)), ...);
     return off;
 }
+static_assert(kernarg_bytes<float*, int64_t>() == 16 && kernarg_bytes<int, double*>() == 16 && kernarg_bytes<char, int64_t, int>() == 20,
+              "the argument block's layout: every parameter at its natural alignment, in declaration order");
 template <typename... T>
 __device__ __forceinline__ void kernarg_touch_for(const T&...) {
     kernarg_touch<kernarg_bytes<T...>()>();

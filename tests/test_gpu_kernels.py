@@ -531,6 +531,24 @@ def test_perlin_and_pyramid_fused_normalisation(hl, factor):
     close(one, two, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("planes", [(3, 4), (64, 4), (300, 4)])
+def test_pyramid_fused_call_reduces_only_the_partials_its_planes_own(hl, planes):
+    """sonar_pyramid_noise_f32 hands its normalising pass the number of partial pairs the plane kernel's workgroups own (12 / 256 / 1024
+    here) instead of all SONAR_NPART: the rest are zeros, so the decision and the values are the two-step path's bit for bit
+    (generate with statistics, then sonar_scale_noise_f32 over every pair) -- also with levels drawn in the kernel."""
+    b, c = planes
+    shape = (b, c, 64, 64)  # whole RNG tiles per plane: the plane kernel runs
+    n = b * c
+    small = [hl.philox_normal((n, hh, ww), "cuda", 42, 10 + i) for i, (hh, ww) in enumerate(((21, 21), (5, 5)))]
+    for levels in ([(None, 64, 64, 1.0), (small[0], 21, 21, 0.7), (small[1], 5, 5, 0.49)], hl.AutoLevels(64, 64, 10, 0.7, 42, 3)):
+        part = hl.new_partials("cuda")
+        two = hl.pyramid_generate(shape, "cuda", levels, "bilinear", 42, 3, 4096 * 8, part)
+        hl.scale_noise_(two, 1.3, True, part)
+        one = hl.pyramid_noise(shape, "cuda", levels, "bilinear", 42, 3, 4096 * 8, 1.3)
+        assert torch.equal(one, two)
+        assert abs(one.std().item() - 1.3) < 1e-3
+
+
 GENERAL_PLANES = [(104, 152), (152, 104), (96, 96), (72, 88), (90, 50), (34, 38), (20, 12), (2, 4), (168, 96), (128, 160), (192, 192), (512, 64), (26, 1024),
                   # register codelets of every length 2..16 in either pass (round 3): 11 x 2 / 13 x 2, 15 x 2 / 14, 9 x 2 / 10, 12 x 2 / 9 x 2,
                   # 12 x 12 / 8 x 7, 12 x 10 / 10 x 8, 11 x 8 / 13 x 4, 16 x 11 / 8 x 5, 14 x 9 / 9 x 5, one-pass lengths, 16 x 15 / 15 x 2
