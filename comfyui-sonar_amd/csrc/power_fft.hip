@@ -1377,6 +1377,7 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
     const int tid = threadIdx.x & (NT - 1), lane = threadIdx.x & 63, wv = wv_all & (NT / 64 - 1);
     // this workgroup's plane sequence: units blockIdx.x, blockIdx.x + gridDim.x, ...; `per_unit` planes each
     const int64_t nunits = split ? planes : planes / group;
+    const int64_t group0 = plane_offset / group;  // the call's first RNG group (once: a 64-bit division per unit and stream otherwise)
     const int per_unit = split ? 1 : group;
     const int64_t my_units = (int64_t)blockIdx.x < nunits ? (nunits - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int n = (int)(my_units * per_unit);
@@ -1463,7 +1464,7 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
                     rng.R = Mwc{rt.x, rt.y};
                     rng.T = Mwc{rt.z, rt.w};
                 } else {
-                    rng = spectrum_seed<true>(seed, stream_id, plane_offset / group + gw.grp, tid, false);  // the edge stream is the other team's
+                    rng = spectrum_seed<true>(seed, stream_id, group0 + gw.grp, tid, false);  // the edge stream is the other team's
                 }
                 for (int i = 0; i < gw.first; ++i) skip_plane<H, W, true, false>(rng, tid);
             }
@@ -1557,7 +1558,7 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
             if (tid < H && je < n) {  // whole waves
                 if (egp == 0) {
                     const GroupWalk gw(eunit, group, split);
-                    rngE = je == per_unit ? rngE2 : spectrum_seed<false>(seed, stream_id, plane_offset / group + gw.grp, tid, true).E;
+                    rngE = je == per_unit ? rngE2 : spectrum_seed<false>(seed, stream_id, group0 + gw.grp, tid, true).E;
                     for (int i = 0; i < 3 * gw.first; ++i) rngE.next();
                 }
                 const uint32_t r0 = rngE.next();
@@ -1580,7 +1581,7 @@ __global__ void __launch_bounds__(1024) power_pipe_kernel(const float* __restric
         };
         if (n > per_unit) {  // nothing to transform yet: seed the second unit's streams (R, T for the drawing team through LDS)
             const GroupWalk gw(unit + gridDim.x, group, split);
-            const SpectrumRng g2 = spectrum_rng<H, true>(seed, stream_id, plane_offset / group + gw.grp, tid);
+            const SpectrumRng g2 = spectrum_rng<H, true>(seed, stream_id, group0 + gw.grp, tid);
             SEED_RT[tid] = make_uint4(g2.R.x, g2.R.c, g2.T.x, g2.T.c);
             rngE2 = g2.E;
         }
