@@ -834,6 +834,7 @@ struct PyramidLevels {
     int h[kMaxLevels], w[kMaxLevels];
     float weight[kMaxLevels];
     int count;       // small-grid levels
+    int supplied;    // ... of them with a grid passed in (ptr != nullptr: replay mode)
     unsigned long long draw_stream[kMaxLevels];  // ptr == nullptr: the level grid is drawn by the plane kernel from this stream id
     int fullres;     // number of leading full-resolution levels folded into the base draw (0 or 1)
     float fullres_weight;
@@ -1075,7 +1076,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
     for (int64_t p = bid; p < planes; p += nblocks) {
         __syncthreads();
         SONAR_NG_STAMP(2);
-        {
+        if (lv.supplied) {  // (generate mode has none: the walk below costs a wait for three scalar loads per level to find that out)
             int off = 0;
             for (int l = 0; l < lv.count; ++l) {  // supplied levels (replay mode): copied
                 const int n = lv.h[l] * lv.w[l];
@@ -1097,7 +1098,12 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
             for (int i = gslot * 4; i < n; i += kBlock * 4) {
                 float z[4];
                 rng.normal4(z);
-                for (int k = 0; k < 4 && i + k < n; ++k) pyr_lds[off + i + k] = z[k];
+                float* const g = pyr_lds + off + i;
+                if (i + 3 < n) {  // (four plain stores: the guarded loop below is a vector loop with a select chain per value, ~80 instructions)
+                    g[0] = z[0]; g[1] = z[1]; g[2] = z[2]; g[3] = z[3];
+                } else {
+                    for (int k = 0; k < 4 && i + k < n; ++k) g[k] = z[k];
+                }
             }
         }
         SONAR_NG_STAMP(3);
@@ -1702,6 +1708,7 @@ static int fill_levels(PyramidLevels& lv, int64_t H, int64_t W, int64_t nlevels,
         lv.ptr[lv.count] = level_ptrs[l];
         lv.draw_stream[lv.count] = stream_id + 2 + (uint64_t)l;  // used when ptr is NULL: the plane kernel draws the grid
         if (!level_ptrs[l]) *drawn = true;
+        else ++lv.supplied;
         lv.h[lv.count] = (int)level_h[l];
         lv.w[lv.count] = (int)level_w[l];
         lv.weight[lv.count] = level_weight[l];
