@@ -92,6 +92,25 @@ struct One1 {
 // TV: storage type of the cV planes (float under fp64 arithmetic when the process stores detail bands in fp32: sonar_wcfg_hi_storage, the
 // deeper levels' call of the tile route).  HASB: a second tensor b (v = a - b, result = ku b + ...); without one the last stage stages single
 // values instead of (a, b) pairs.  Both halve an LDS area: the fp64 deeper-levels call fits a CU four times instead of three (round 5).
+#ifndef SONAR_BANDS_TAPS_LOCAL
+#define SONAR_BANDS_TAPS_LOCAL 1
+#endif
+// fp64 taps: three filters of FT doubles are 6 FT scalar registers; loaded where the compiler likes (once, in front of the plane loop) they do
+// not fit beside the stages' other scalars and come back from vector-register lanes -- a v_readlane and its hazard wait in front of every
+// use (90-170 of them in the loops of the db4 instantiations, 17-51 with this).  An opaque zero added to the tap index at the top of every
+// stage keeps each stage's loads inside it: two or three 64-byte scalar loads per stage that hit the scalar cache.  Up to 14 taps: beyond,
+// the compiler answers the run-time index with a private copy of the argument block (scratch: never).
+template <typename T, int FT>
+__device__ __forceinline__ int bands_tap_zero() {
+    int z = 0;
+    if constexpr (sizeof(T) == 8 && FT <= 14 && SONAR_BANDS_TAPS_LOCAL) asm volatile("" : "+s"(z));
+    return z;
+}
+template <typename T>
+struct BandsTapView {
+    const T* lo;
+    const T* hi;
+};
 template <typename T, typename TIO, int FT, int NT, bool ZERO, bool AHEAD = false, typename TV = T, bool HASB = true>
 __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ ta, const TIO* __restrict__ tb, const TIO* xin, TIO* out,
                                                         BandsArgs<T> a) {
@@ -117,6 +136,10 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
     }
     const int H = a.H[0], W = a.W[0], h1 = a.H[1], w1 = a.W[1];
     const int Wh = (W + 1) >> 1, Ws = 2 * Wh;  // parity-split row of the level-1 scratch: slot(x) = (x & 1) Wh + x / 2
+    // fp64 taps: three filters of FT doubles are 6 FT scalar registers; loaded where the compiler likes (once, in front of the plane loop)
+    // they do not fit beside the stages' other scalars and come back from vector-register lanes -- one v_readlane and its hazard wait in
+    // front of every use (100-170 of them in the loops of the db4 instantiations).  An opaque zero added to the tap index at the top of
+    // every stage keeps each stage's loads inside it: two or three 64-byte scalar loads per stage that hit the scalar cache.
     for (int64_t p = blockIdx.x; p < a.planes; p += gridDim.x) {
         const TIO* pa = ta + p * (int64_t)H * W;
         const TIO* pb = tb ? tb + p * (int64_t)H * W : nullptr;
@@ -132,6 +155,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             constexpr int THS = 4, NRS = 2 * THS + FT - 2;
             T* const tmp1 = lds + a.off_tmp1;
             for (int y0 = 0; y0 < h1; y0 += a.rows1) {
+                const int tz = bands_tap_zero<T, FT>();
                 const int th = min(a.rows1, h1 - y0);
                 // An item's NRS rows come straight from global memory; a thread walks ~4 items per tile and used to wait for each item's loads in
                 // turn (`scratch/bands_trace.py`: this stage is a third of a plane's time in the single-launch kernel).  Round 5: the NEXT item's
@@ -177,7 +201,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     for (int yl = 0; yl < THS; ++yl) {
                         T lo = T(0);
 #pragma unroll
-                        for (int j = 0; j < FT; ++j) lo = fma_t(a.dec.lo[j], v[2 * yl + FT - 1 - j], lo);
+                        for (int j = 0; j < FT; ++j) lo = fma_t(a.dec.lo[tz + j], v[2 * yl + FT - 1 - j], lo);
                         if (sub * THS + yl < th) dst[(sub * THS + yl) * Ws] = lo;
                     }
                 }
@@ -192,8 +216,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                         const int sx = xm[-j];
                         const int sc = at0(sx);
                         const T q = live(sx, row[(sc & 1) * Wh + (sc >> 1)]);
-                        lo = fma_t(a.dec.lo[j], q, lo);
-                        hi = fma_t(a.dec.hi[j], q, hi);
+                        lo = fma_t(a.dec.lo[tz + j], q, lo);
+                        hi = fma_t(a.dec.hi[tz + j], q, hi);
                     }
                     ll1[(y0 + yl) * w1 + xo] = lo;
                     if (want_v) cv1[(y0 + yl) * w1 + xo] = (TV)hi;
@@ -204,6 +228,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
         SONAR_BANDS_STAMP(1);
         // ---------------------------------------------------------------- deeper levels down: LL_j, cV_j from LL_{j-1}, all in LDS
         for (int j = 2; j <= J; ++j) {
+            const int tz = bands_tap_zero<T, FT>();
             const int Wp = a.W[j - 1], h = a.H[j], w = a.W[j];
             const T* const src = lds + a.off_ll[j - 1];
             T* const dll = lds + a.off_ll[j];
@@ -219,7 +244,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                 for (int t = 0; t < FT; ++t) {
                     const int sy = ym[-t];
                     const T q = src[at0(sy) * Wp + x];
-                    acc = fma_t(a.dec.lo[t], live(sy, q), acc);
+                    acc = fma_t(a.dec.lo[tz + t], live(sy, q), acc);
                 }
                 tmp[yo * Wp + x] = acc;
             }
@@ -233,8 +258,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                 for (int t = 0; t < FT; ++t) {
                     const int sx = xm[-t];
                     const T q = live(sx, row[at0(sx)]);
-                    lo = fma_t(a.dec.lo[t], q, lo);
-                    hi = fma_t(a.dec.hi[t], q, hi);
+                    lo = fma_t(a.dec.lo[tz + t], q, lo);
+                    hi = fma_t(a.dec.hi[tz + t], q, hi);
                 }
                 dll[yo * w + xo] = lo;
                 if (want_v) dcv[yo * w + xo] = (TV)hi;
@@ -263,12 +288,13 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             T* const tA = tmp;
             T* const tB = tmp + a.rows_up[j] * w;
             for (int ya = 0; ya < Ho; ya += a.rows_up[j]) {
+                const int tz = bands_tap_zero<T, FT>();
                 const int th = min(a.rows_up[j], Ho - ya);
                 for (WalkN<NT> wk(tid, w); 2 * wk.r < th; wk.next(w)) {   // along H: rows (2m, 2m + 1) of column xo, plus lowW of those rows
                     const int mp = wk.r, xo = wk.c, m = (ya >> 1) + mp;
                     T e, o, e2 = T(0), o2 = T(0);
-                    synth_low_pair<T, FT>(m, h, a.mode_inv, a.rec.lo, [&](int i) { return B[i * w + xo]; }, e, o);
-                    if (want_v) synth_low_pair<T, FT>(m, h, a.mode_inv, a.rec.lo, [&](int i) { return (T)V[i * w + xo]; }, e2, o2);
+                    synth_low_pair<T, FT>(m, h, a.mode_inv, a.rec.lo + tz, [&](int i) { return B[i * w + xo]; }, e, o);
+                    if (want_v) synth_low_pair<T, FT>(m, h, a.mode_inv, a.rec.lo + tz, [&](int i) { return (T)V[i * w + xo]; }, e2, o2);
                     const int* xm = xmap + 2 * xo + (FT - 1);
                     const T* r0 = dst + (ya + 2 * mp) * Wo;
                     const bool two = 2 * mp + 1 < th;
@@ -279,8 +305,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                         for (int t = 0; t < FT; ++t) {
                             const int sx = xm[-t];
                             const int at = at0(sx);
-                            l0 = fma_t(a.dec.lo[t], live(sx, r0[at]), l0);
-                            l1 = fma_t(a.dec.lo[t], live(sx, r1[at]), l1);
+                            l0 = fma_t(a.dec.lo[tz + t], live(sx, r0[at]), l0);
+                            l1 = fma_t(a.dec.lo[tz + t], live(sx, r1[at]), l1);
                         }
                     }
                     tA[(2 * mp) * w + xo] = fma_t(c_low, l0, e);
@@ -296,8 +322,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     const T* ra = tA + yl * w;
                     const T* rb = tB + yl * w;
                     T e, o;
-                    if (want_v) SynthPair<T, FT>::run(m, w, a.mode_inv, a.rec, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
-                    else synth_low_pair<T, FT>(m, w, a.mode_inv, a.rec.lo, [&](int i) { return ra[i]; }, e, o);
+                    if (want_v) SynthPair<T, FT>::run(m, w, a.mode_inv, BandsTapView<T>{a.rec.lo + tz, a.rec.hi + tz}, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
+                    else synth_low_pair<T, FT>(m, w, a.mode_inv, a.rec.lo + tz, [&](int i) { return ra[i]; }, e, o);
                     T* d = dst + (ya + yl) * Wo + 2 * m;
                     d[0] = fma_t(c_x, d[0], e);
                     if (2 * m + 1 < Wo) d[1] = fma_t(c_x, d[1], o);
@@ -340,6 +366,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             if constexpr (KP > 0) request(0);
             SONAR_BANDS_LAP_BEGIN();
             for (int y0 = 0; y0 < H; y0 += a.rows_out) {
+                const int tz = bands_tap_zero<T, FT>();
                 const int th = min(a.rows_out, H - y0);
                 if constexpr (KP > 0) {
 #pragma unroll
@@ -359,8 +386,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                 for (WalkN<NT> wk(tid, w1); 2 * wk.r < th; wk.next(w1)) {
                     const int mp = wk.r, xo = wk.c, m = (y0 >> 1) + mp;
                     T e, o, e2 = T(0), o2 = T(0);
-                    synth_low_pair<T, FT>(m, h1, a.mode_inv, a.rec.lo, [&](int i) { return B[i * w1 + xo]; }, e, o);
-                    if (want_v) synth_low_pair<T, FT>(m, h1, a.mode_inv, a.rec.lo, [&](int i) { return (T)V[i * w1 + xo]; }, e2, o2);
+                    synth_low_pair<T, FT>(m, h1, a.mode_inv, a.rec.lo + tz, [&](int i) { return B[i * w1 + xo]; }, e, o);
+                    if (want_v) synth_low_pair<T, FT>(m, h1, a.mode_inv, a.rec.lo + tz, [&](int i) { return (T)V[i * w1 + xo]; }, e2, o2);
                     const int* xm = xmap + 2 * xo + (FT - 1);
                     const bool two = 2 * mp + 1 < th;
                     const St* r0 = cu + (2 * mp) * W;
@@ -371,8 +398,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                         for (int t = 0; t < FT; ++t) {
                             const int sx = xm[-t];
                             const St q0 = r0[at0(sx)], q1 = r1[at0(sx)];
-                            l0 = fma_t(a.dec.lo[t], live(sx, (T)q0.x - (T)q0.y), l0);
-                            l1 = fma_t(a.dec.lo[t], live(sx, (T)q1.x - (T)q1.y), l1);
+                            l0 = fma_t(a.dec.lo[tz + t], live(sx, (T)q0.x - (T)q0.y), l0);
+                            l1 = fma_t(a.dec.lo[tz + t], live(sx, (T)q1.x - (T)q1.y), l1);
                         }
                     }
                     tA[(2 * mp) * w1 + xo] = fma_t(c_low, l0, e);
@@ -389,8 +416,8 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     const T* ra = tA + yl * w1;
                     const T* rb = tB + yl * w1;
                     T e, o;
-                    if (want_v) SynthPair<T, FT>::run(m, w1, a.mode_inv, a.rec, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
-                    else synth_low_pair<T, FT>(m, w1, a.mode_inv, a.rec.lo, [&](int i) { return ra[i]; }, e, o);
+                    if (want_v) SynthPair<T, FT>::run(m, w1, a.mode_inv, BandsTapView<T>{a.rec.lo + tz, a.rec.hi + tz}, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
+                    else synth_low_pair<T, FT>(m, w1, a.mode_inv, a.rec.lo + tz, [&](int i) { return ra[i]; }, e, o);
                     const int at = (y0 + yl) * W + 2 * m;
                     const bool pair = 2 * m + 1 < W;
                     const St q0 = cu[yl * W + 2 * m];
