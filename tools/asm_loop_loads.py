@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
 """Scalar loads inside loops, per kernel, from the compiler's assembly (hipcc -S --cuda-device-only): a loop that loads a kernel argument
 or a table entry through the scalar cache and waits for it every iteration runs at that latency (the pyramid plane kernel's level loop
-did: round 5).  Usage: python tools/asm_loop_loads.py file.s [name-filter]"""
+did: round 5).  With --lanes: v_readlane / v_writelane inside loops instead -- scalar values spilled to vector-register lanes and fetched
+back in front of every use (the fp64 band kernel's filter taps did: round 5).
+Usage: python tools/asm_loop_loads.py [--lanes] file.s [name-filter]"""
 import re, subprocess, sys
 
-text = open(sys.argv[1]).read().splitlines()
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
+argv = [a for a in sys.argv[1:] if a != "--lanes"]
+LANES = "--lanes" in sys.argv
+text = open(argv[0]).read().splitlines()
+flt = argv[1] if len(argv) > 1 else ""
+PATTERN = r"\bv_(readlane|writelane)_b32" if LANES else r"\bs_(load|buffer_load)_"
+WHAT = "lane moves" if LANES else "scalar loads"
 kernel, inloop, depth, found = None, False, 0, {}
 for line in text:
     m = re.match(r"^(_Z\w+):", line)
@@ -25,7 +31,7 @@ for line in text:
         if d:
             depth = max(depth, int(d.group(1)))
         continue
-    if inloop and re.search(r"\bs_(load|buffer_load)_", line):
+    if inloop and re.search(PATTERN, line):
         found.setdefault(kernel, []).append((depth, line.strip()))
     if "s_endpgm" in line:
         inloop = False
@@ -35,4 +41,4 @@ for n, d in zip(names, dem):
     if flt and flt not in d:
         continue
     rows = found[n]
-    print(f"{len(rows):3d} scalar loads in loops (deepest {max(r[0] for r in rows)})  {d[:150]}")
+    print(f"{len(rows):4d} {WHAT} in loops (deepest {max(r[0] for r in rows)})  {d[:150]}")
