@@ -92,25 +92,6 @@ struct One1 {
 // TV: storage type of the cV planes (float under fp64 arithmetic when the process stores detail bands in fp32: sonar_wcfg_hi_storage, the
 // deeper levels' call of the tile route).  HASB: a second tensor b (v = a - b, result = ku b + ...); without one the last stage stages single
 // values instead of (a, b) pairs.  Both halve an LDS area: the fp64 deeper-levels call fits a CU four times instead of three (round 5).
-#ifndef SONAR_BANDS_TAPS_LOCAL
-#define SONAR_BANDS_TAPS_LOCAL 1
-#endif
-// fp64 taps: three filters of FT doubles are 6 FT scalar registers; loaded where the compiler likes (once, in front of the plane loop) they do
-// not fit beside the stages' other scalars and come back from vector-register lanes -- a v_readlane and its hazard wait in front of every
-// use (90-170 of them in the loops of the db4 instantiations, 17-51 with this).  An opaque zero added to the tap index at the top of every
-// stage keeps each stage's loads inside it: two or three 64-byte scalar loads per stage that hit the scalar cache.  Up to 14 taps: beyond,
-// the compiler answers the run-time index with a private copy of the argument block (scratch: never).
-template <typename T, int FT>
-__device__ __forceinline__ int bands_tap_zero() {
-    int z = 0;
-    if constexpr (sizeof(T) == 8 && FT <= 14 && SONAR_BANDS_TAPS_LOCAL) asm volatile("" : "+s"(z));
-    return z;
-}
-template <typename T>
-struct BandsTapView {
-    const T* lo;
-    const T* hi;
-};
 template <typename T, typename TIO, int FT, int NT, bool ZERO, bool AHEAD = false, typename TV = T, bool HASB = true>
 __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ ta, const TIO* __restrict__ tb, const TIO* xin, TIO* out,
                                                         BandsArgs<T> a) {
@@ -155,7 +136,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             constexpr int THS = 4, NRS = 2 * THS + FT - 2;
             T* const tmp1 = lds + a.off_tmp1;
             for (int y0 = 0; y0 < h1; y0 += a.rows1) {
-                const int tz = bands_tap_zero<T, FT>();
+                const int tz = tap_zero<T, FT>();
                 const int th = min(a.rows1, h1 - y0);
                 // An item's NRS rows come straight from global memory; a thread walks ~4 items per tile and used to wait for each item's loads in
                 // turn (`scratch/bands_trace.py`: this stage is a third of a plane's time in the single-launch kernel).  Round 5: the NEXT item's
@@ -228,7 +209,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
         SONAR_BANDS_STAMP(1);
         // ---------------------------------------------------------------- deeper levels down: LL_j, cV_j from LL_{j-1}, all in LDS
         for (int j = 2; j <= J; ++j) {
-            const int tz = bands_tap_zero<T, FT>();
+            const int tz = tap_zero<T, FT>();
             const int Wp = a.W[j - 1], h = a.H[j], w = a.W[j];
             const T* const src = lds + a.off_ll[j - 1];
             T* const dll = lds + a.off_ll[j];
@@ -288,7 +269,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             T* const tA = tmp;
             T* const tB = tmp + a.rows_up[j] * w;
             for (int ya = 0; ya < Ho; ya += a.rows_up[j]) {
-                const int tz = bands_tap_zero<T, FT>();
+                const int tz = tap_zero<T, FT>();
                 const int th = min(a.rows_up[j], Ho - ya);
                 for (WalkN<NT> wk(tid, w); 2 * wk.r < th; wk.next(w)) {   // along H: rows (2m, 2m + 1) of column xo, plus lowW of those rows
                     const int mp = wk.r, xo = wk.c, m = (ya >> 1) + mp;
@@ -322,7 +303,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     const T* ra = tA + yl * w;
                     const T* rb = tB + yl * w;
                     T e, o;
-                    if (want_v) SynthPair<T, FT>::run(m, w, a.mode_inv, BandsTapView<T>{a.rec.lo + tz, a.rec.hi + tz}, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
+                    if (want_v) SynthPair<T, FT>::run(m, w, a.mode_inv, TapView<T>{a.rec.lo + tz, a.rec.hi + tz}, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
                     else synth_low_pair<T, FT>(m, w, a.mode_inv, a.rec.lo + tz, [&](int i) { return ra[i]; }, e, o);
                     T* d = dst + (ya + yl) * Wo + 2 * m;
                     d[0] = fma_t(c_x, d[0], e);
@@ -366,7 +347,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             if constexpr (KP > 0) request(0);
             SONAR_BANDS_LAP_BEGIN();
             for (int y0 = 0; y0 < H; y0 += a.rows_out) {
-                const int tz = bands_tap_zero<T, FT>();
+                const int tz = tap_zero<T, FT>();
                 const int th = min(a.rows_out, H - y0);
                 if constexpr (KP > 0) {
 #pragma unroll
@@ -416,7 +397,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
                     const T* ra = tA + yl * w1;
                     const T* rb = tB + yl * w1;
                     T e, o;
-                    if (want_v) SynthPair<T, FT>::run(m, w1, a.mode_inv, BandsTapView<T>{a.rec.lo + tz, a.rec.hi + tz}, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
+                    if (want_v) SynthPair<T, FT>::run(m, w1, a.mode_inv, TapView<T>{a.rec.lo + tz, a.rec.hi + tz}, [&](int i) { return ra[i]; }, [&](int i) { return rb[i]; }, e, o);
                     else synth_low_pair<T, FT>(m, w1, a.mode_inv, a.rec.lo + tz, [&](int i) { return ra[i]; }, e, o);
                     const int at = (y0 + yl) * W + 2 * m;
                     const bool pair = 2 * m + 1 < W;

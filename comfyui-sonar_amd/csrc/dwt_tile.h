@@ -16,6 +16,25 @@
 #include "dwt_common.h"
 
 namespace sonar {
+// fp64 taps are two scalar registers each; a kernel that loads its filters once, in front of its job loop, gets them back from
+// vector-register lanes (a v_readlane and its hazard wait in front of every use: tools/asm_loop_loads.py --lanes).  A view of the
+// argument's tap arrays behind an opaque zero, made per stage, keeps the loads inside it (they hit the scalar cache; used by the band kernel,
+// dwt_bands.h -- in the tile kernels below the lane moves are not the taps: no change there).  Up to 14
+// taps: beyond, the compiler answers the run-time index with a private copy of the argument block (scratch: never).
+#ifndef SONAR_TAPS_LOCAL
+#define SONAR_TAPS_LOCAL 1
+#endif
+template <typename T, int FT>
+__device__ __forceinline__ int tap_zero() {
+    int z = 0;
+    if constexpr (sizeof(T) == 8 && FT <= 14 && SONAR_TAPS_LOCAL) asm volatile("" : "+s"(z));
+    return z;
+}
+template <typename T>
+struct TapView {
+    const T* lo;
+    const T* hi;
+};
 
 constexpr int kTileThreads = 256;
 constexpr int kFwdRows = 8;    // output rows per analysis tile (register window = 2 * kFwdRows + F - 2 input rows)
