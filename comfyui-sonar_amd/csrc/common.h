@@ -352,6 +352,23 @@ struct Divider {
     }
 };
 
+// Divider::from_word with the `exact` decision taken once, by the caller (a launch has ONE divisor): inside a tile loop the run-time flag was
+// a scalar branch, or two, in front of every value -- 64 per tile and lane in the Perlin kernels (round 5).  Same expressions, same bits.
+struct WordScale {     // power-of-two divisor
+    float k;           // inv * 2^-24
+    __device__ __forceinline__ float from_word(uint32_t r, float term) const { return __builtin_fmaf((float)(r >> 8), k, term); }
+};
+struct WordDivide {    // any other divisor
+    float d;
+    __device__ __forceinline__ float from_word(uint32_t r, float term) const { return u01(r) / d + term; }
+};
+// f(word-to-value converter): the tile loop instantiated for the divisor's kind
+template <typename F>
+__device__ __forceinline__ void with_divider(const Divider& div, F&& f) {
+    if (div.exact) f(WordScale{div.inv * 0x1p-24f});
+    else f(WordDivide{div.d});
+}
+
 // ---- blend modes (py/utils.py:17-21) -----------------------------------------------------------
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }

@@ -110,8 +110,8 @@ struct Prefix {
 };
 // kind: 0 none, 1 Gaussian draw, 2 Perlin (summed lattice).  One group of four values: x drawn by the caller's copy of the prefix's
 // generator (`rng`, advanced here), `term` the lattice vector of these four elements (Perlin).
-template <int PRE>
-__device__ __forceinline__ void prefix_draw(TileRng& rng, const Divider& div, const float4& term, float (&x)[4]) {
+template <int PRE, typename DIV>
+__device__ __forceinline__ void prefix_draw(TileRng& rng, const DIV& div, const float4& term, float (&x)[4]) {
     if constexpr (PRE == 1) {
         rng.normal4(x);
     } else {
@@ -434,9 +434,9 @@ __global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __res
 
 // The fast path's tile loop (device-drawn calls: ONE summed term table, vector-aligned latents): wave `wave` of `nwaves` takes the tiles
 // first + wave, first + wave + nwaves, ...  MODE as in perlin_generate_kernel.  Shared by that kernel and perlin_ahead_kernel.
-template <int MODE, bool STATS, bool ALIGNED>
+template <int MODE, bool STATS, bool ALIGNED, typename DIV>
 __device__ __forceinline__ void perlin_fast_tiles(const float* __restrict__ terms, float* out, int64_t n, int64_t chw, uint64_t seed,
-                                                  uint64_t stream_id, int64_t elem_offset, const NormFast& norm, const Divider& divide,
+                                                  uint64_t stream_id, int64_t elem_offset, const NormFast& norm, const DIV& divide,
                                                   const Accum& acc, int64_t wave, int64_t nwaves, double& s, double& q) {
     const uint32_t lane = threadIdx.x & 63;
     const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
@@ -529,7 +529,9 @@ __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __
     const int ichw = (int)chw;  // launcher guarantees chw < 2^31
     if constexpr (FAST) {
         static_assert(VEC, "the fast path is a vector path");
-        perlin_fast_tiles<MODE, STATS, ALIGNED>(terms, out, n, chw, seed, stream_id, elem_offset, norm, divide, acc, wave, nwaves, s, q);
+        with_divider(divide, [&](auto dv) {
+            perlin_fast_tiles<MODE, STATS, ALIGNED>(terms, out, n, chw, seed, stream_id, elem_offset, norm, dv, acc, wave, nwaves, s, q);
+        });
         if constexpr (STATS || MODE == 1) write_partial<kBlock>(s, q, partials, red);
         return;
     }
@@ -678,11 +680,15 @@ __global__ void __launch_bounds__(kBlock) perlin_ahead_kernel(PerlinAhead a) {
     if (!ahead) {
         const NormDecision dec = decide_norm<kBlock>(a.na.partials, kNPart, a.na.n_total, a.na.thr_sd, red, &sh);
         const NormFast norm(dec, a.na.factor);
-        perlin_fast_tiles<2, false, true>(a.terms, a.out, a.n, a.chw, a.seed, a.stream_id, a.elem_offset, norm, divide, kNoAccum, wave, nwaves, s, q);
+        with_divider(divide, [&](auto dv) {
+            perlin_fast_tiles<2, false, true>(a.terms, a.out, a.n, a.chw, a.seed, a.stream_id, a.elem_offset, norm, dv, kNoAccum, wave, nwaves, s, q);
+        });
     } else {
         const NormFast norm(NormDecision{0.f, 1.f, 0, 0}, 1.0f);
-        perlin_fast_tiles<1, false, true>(a.terms_next, nullptr, a.n, a.chw, a.seed, a.next_stream_id, a.elem_offset, norm, divide, kNoAccum, wave,
-                                          nwaves, s, q);
+        with_divider(divide, [&](auto dv) {
+            perlin_fast_tiles<1, false, true>(a.terms_next, nullptr, a.n, a.chw, a.seed, a.next_stream_id, a.elem_offset, norm, dv, kNoAccum, wave,
+                                              nwaves, s, q);
+        });
         write_partial_at<kBlock>(s, q, a.partials_next, red, bid, nb);
     }
 }
@@ -1213,7 +1219,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                 static_assert(kIters % G == 0, "groups tile a part's share of the burst");
                 const float base_mul = lv.fullres ? lv.base_scale : 1.0f;  // (x 1 is exact: no select per value)
                 // WHOLE: the tile lies inside the plane (always, when planes are whole tiles): no per-lane ownership test around the stores
-                auto burst = [&](auto whole_c) {
+                auto burst = [&](auto whole_c, const auto& dv) {  // dv: the hosted Perlin item's word-to-value converter (with_divider)
                     constexpr bool WHOLE = decltype(whole_c)::value;
                     // A hosted Perlin item's lattice vectors.  Launch-bound sizes (NT, one workgroup per CU): all of the part's share of
                     // the burst requested before the first step, the loop unrolled so that the steps index them statically -- a step that
@@ -1244,7 +1250,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                             const bool ours = WHOLE || (e >= 0 && e < HW);
                             if constexpr (PRE != 0) {  // the prefix's generator walks every iteration of the tile, ours or not
                                 const float4 tv = tvs[j];
-                                prefix_draw<PRE>(prng, pdiv, tv, px[j]);
+                                prefix_draw<PRE>(prng, dv, tv, px[j]);
                             }
                             ee[j] = e;
                             yy[j] = ours ? y : 0;  // (not ours: any entry of the tables, the values are dropped)
@@ -1307,8 +1313,13 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                         }
                     }
                 };
-                if (t * kTileElems >= g0 && (t + 1) * kTileElems <= g0 + HW) burst(std::true_type{});
-                else burst(std::false_type{});
+                const bool whole = t * kTileElems >= g0 && (t + 1) * kTileElems <= g0 + HW;
+                auto run = [&](const auto& dv) {
+                    if (whole) burst(std::true_type{}, dv);
+                    else burst(std::false_type{}, dv);
+                };
+                if constexpr (PRE == 2) with_divider(pdiv, run);
+                else run(pdiv);
                 continue;
             }
 SONAR_PYR_UNROLL
