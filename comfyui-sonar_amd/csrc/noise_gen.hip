@@ -1579,6 +1579,7 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
     constexpr int SUB = PRE ? kBrownPerTile : 1;
     const Accum pfold{fold.y, pre.ya, pre.f};
     const Divider pdiv(PRE == 2 ? pre.div_fac : 1.0f);
+    auto tiles_loop = [&](const auto& dv) {  // dv: a hosted Perlin item's word-to-value converter (with_divider: its kind decided once)
     for (int64_t T = wave; T < tiles / SUB; T += nwaves) {
         TileRng prng;
         const float4* trow = nullptr;
@@ -1633,7 +1634,7 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
                         float x[4];
                         float4 tv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         if constexpr (PRE == 2) tv = trow[64 * (sub * kBrownIters + it)];
-                        prefix_draw<PRE>(prng, pdiv, tv, x);
+                        prefix_draw<PRE>(prng, dv, tv, x);
                         prefix_fold(pre, pfold, fold, o + it * 256, x, v);
                     } else {
                         accumulate_group<true>(fold, n, o + it * 256, v);
@@ -1643,6 +1644,9 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
             }
         }
     }
+    };
+    if constexpr (PRE == 2) with_divider(pdiv, tiles_loop);
+    else tiles_loop(pdiv);
     if (partials) write_partial<kBlock>(s, q, partials, red);  // uniform branch (kernel argument)
 }
 
