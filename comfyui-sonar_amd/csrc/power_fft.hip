@@ -590,7 +590,8 @@ SONAR_UNROLL_ITEMS
 #define SONAR_PIPE_NT 0  // profiling builds: the row pass's 16-byte stores with the non-temporal hint (64-byte runs per four lanes: slower, common.h)
 #endif
 #ifndef SONAR_PIPE_CHUNKS
-#define SONAR_PIPE_CHUNKS 2, 4  // round 5 (the draw is 30 % shorter, the edge columns are the other team's): 2 + 4 + 2 iterations per phase; 3 + 5 + 0: +1.6 us per launch
+#define SONAR_PIPE_CHUNKS 0, 4  // round 5: 0 + 4 + 4 iterations per phase.  Re-swept at the round's end (`scratch/pipe_ab.py`, same box, us per call): 2 + 4 + 2 (the
+                                // setting while the draw was being shortened) 39.6; 1 + 4 + 3 39.5; 1 + 3 + 4 38.9; **0 + 4 + 4 38.6**; 0 + 5 + 3 39.2; 0 + 3 + 5 40.0; 0 + 6 + 2 39.8; 3 + 5 + 0 (round 4) 41.5+
 #endif
 // look-ahead statistics (TeamStats): planes of the unit whose radius words are drawn in the first / by the end of the second of the
 // three phases; A, B drawing team (while the last plane is transformed), C, D transforming team (while the first plane is drawn)
