@@ -931,9 +931,12 @@ constexpr size_t kPyramidLdsBudget = 64 * 1024;
 #endif
 constexpr int kPyrParts = SONAR_PYR_PARTS;
 #ifndef SONAR_PYR_STRETCH
-#define SONAR_PYR_STRETCH 4
+#define SONAR_PYR_STRETCH 1
 #endif
-constexpr int kPyrStretch = SONAR_PYR_STRETCH;  // items a thread stretches along x per round (XROWS)
+// items a thread stretches along x per round (XROWS).  Re-swept once the column-fixed path had made an item cheap (same box, batch 512 / 64,
+// normalised call): 8 items 92.1 / 22.3 us, 4 items (the setting while an item was a table read and two dependent gathers) 89.7 / 21.9, 3 items
+// 88.6 / 22.0, 2 items 88.5 / 21.7, **1 item 87.3 / 21.6**
+constexpr int kPyrStretch = SONAR_PYR_STRETCH;
 #ifndef SONAR_PYR_GROUP
 #define SONAR_PYR_GROUP 1
 #endif
