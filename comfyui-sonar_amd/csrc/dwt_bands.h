@@ -44,6 +44,11 @@ struct BandsArgs {
 #ifndef SONAR_BANDS_STAGE_AHEAD
 #define SONAR_BANDS_STAGE_AHEAD 4  // values per thread of the last stage's NEXT tile requested a tile ahead (0: a tile's loads at its own start)
 #endif
+#ifndef SONAR_BANDS_STAGE_AHEAD_ONE
+#define SONAR_BANDS_STAGE_AHEAD_ONE 6  // ... when the stage reads ONE tensor in fp32 arithmetic (the two launches of a cond / uncond rule): 6 values 187 us per rule,
+                                       // 4 values 194; with two tensors staged (difference rules) 4 values 170 us, 6 values 177; in fp64 arithmetic (the tile route's
+                                       // deeper-levels call is this form) 6 values cost 12-29 us per rule (same-box sweeps, round 5)
+#endif
 #ifndef SONAR_BANDS_ROWS_AHEAD
 #define SONAR_BANDS_ROWS_AHEAD 1  // level 1 down: the next item's rows requested an item ahead (0: every item waits for its own loads)
 #endif
@@ -330,7 +335,7 @@ __global__ void __launch_bounds__(NT) wcfg_bands_kernel(const TIO* __restrict__ 
             // (`scratch/bands_trace.py`: this stage is 46 % of a plane's time in the single-launch kernel, 42 % in the deeper levels' call).
             // The request is unconditional (the last tile asks for itself again, from L2): under a condition the loaded registers would
             // merge with their old values in a copy that waits for the loads on the spot (see spectral_filter128_kernel).
-            constexpr int KP = SONAR_BANDS_STAGE_AHEAD;
+            constexpr int KP = (!HASB && sizeof(T) == 4) ? SONAR_BANDS_STAGE_AHEAD_ONE : SONAR_BANDS_STAGE_AHEAD;
             [[maybe_unused]] St pre[KP > 0 ? KP : 1];
             // (Measured and dropped, twice: the x pairs the tail subtracts from, requested a tile ahead -- selected by item number inside the
             // tail's loop they keep 70 more registers alive and a CU holds one workgroup instead of two: 198 -> 310 us -- or a phase ahead
