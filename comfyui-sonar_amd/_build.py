@@ -42,7 +42,28 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def _deps_digest(obj: str, src: str) -> str | None:
+    """Hash of the flags, the source and every header the last compile of ``obj`` read (its -MD file); None: never compiled."""
+    dep = obj[:-2] + ".d"
+    if not (os.path.exists(obj) and os.path.exists(dep)):
+        return None
+    text = open(dep).read().replace("\\\n", " ")
+    files = [f for f in text.split(":", 1)[1].split() if f.startswith(("/root", HERE, CSRC)) or not f.startswith("/")]
+    h = hashlib.sha256((" ".join(CXXFLAGS) + src).encode())
+    for f in sorted(set(os.path.normpath(os.path.join(CSRC, f)) for f in files)):
+        if f.startswith("/opt/"):
+            continue  # the toolchain's own headers
+        try:
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+        except OSError:
+            return None
+    return h.hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
+    """One object per .hip source; an object is recompiled when the flags, its source or a header it included changed (per-object
+    stamps from the compiler's dependency files), the library relinked when any object was."""
     stamp = os.path.join(OBJDIR, "stamp")
     digest = _digest()
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read() == digest:
@@ -52,10 +73,15 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *CXXFLAGS, "-c", src, "-o", obj]
+        ostamp = obj[:-2] + ".stamp"
+        if not force and os.path.exists(ostamp) and open(ostamp).read() == _deps_digest(obj, src):
+            return obj
+        cmd = [hipcc, *CXXFLAGS, "-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)
+        with open(ostamp, "w") as fh:
+            fh.write(_deps_digest(obj, src) or "")
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as pool:

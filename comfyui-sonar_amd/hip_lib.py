@@ -201,7 +201,8 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         # a call being traced into a plan sees the recording proxy -- on the tracing thread only (a preview thread keeps the plain library)
-        return _lib if _recorder is None or _recorder.thread != _threading.get_ident() else _recorder.lib
+        rec = _recorder  # (one read: the tracing thread sets the global back to None at the end of its trace)
+        return _lib if rec is None or rec.thread != _threading.get_ident() else rec.lib
     if not os.path.exists(LIB_PATH):
         raise SonarHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -284,8 +285,9 @@ def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
     if not t.is_contiguous():
         raise SonarHipError(f"{name}: tensor must be contiguous")
     _last_device = t.device.index
-    if _recorder is not None and _recorder.thread == _threading.get_ident():
-        _recorder.seen[t.data_ptr()] = t
+    rec = _recorder  # (one read, as in load())
+    if rec is not None and rec.thread == _threading.get_ident():
+        rec.seen[t.data_ptr()] = t
     return t.data_ptr()
 
 
@@ -2189,7 +2191,7 @@ class Plan:
         for h in self.hooks:
             if not h.pre_run(seed, base, table, st):
                 if self.rng_count:
-                    self.rewind(base)
+                    self.rewind(base, self.rng_count)
                 return NOT_RUN
         fresh = []
         device = self.device
@@ -2202,7 +2204,7 @@ class Plan:
         self.failed = failed
         if rc != 0:
             if self.rng_count:
-                self.rewind(base)
+                self.rewind(base, self.rng_count)
             if rc == ERR_UNSUPPORTED:
                 return NOT_RUN  # an entry point refused this call's values (e.g. a level table the plane kernel cannot hold): ordinary path
             _check(rc, f"sonar_plan_run (record {self.failed.value})")
@@ -2420,7 +2422,8 @@ class Planned:
             return self._call(sigma, sigma_next)
 
     def _call(self, sigma, sigma_next):
-        if PLANS_ENABLED and (_recorder is None or _recorder.thread != _threading.get_ident()):
+        rec = _recorder  # (one read, as in load())
+        if PLANS_ENABLED and (rec is None or rec.thread != _threading.get_ident()):
             plan = self.plan
             if plan is not None:
                 out = plan.run()

@@ -107,10 +107,17 @@ class DeviceRNG:
         return seed, offset // 4
 
     @classmethod
-    def rewind(cls, stream: int) -> None:
-        """Put the position back to ``stream`` (a prepared plan that took its streams and then could not issue the step)."""
+    def rewind(cls, stream: int, count: int | None = None) -> bool:
+        """Put the position back to ``stream`` (a prepared plan that took ``count`` streams there and then could not issue the step).
+        With ``count`` given the position only moves back if nobody took streams since -- it still reads ``stream + count``: another
+        sampler on another thread may have drawn in between, and handing ITS ids out again would make two samplers draw the same
+        noise, whereas a gap of unused ids costs nothing.  Returns whether the position moved."""
+        gen = torch.cuda.default_generators[torch.cuda.current_device()]
         with cls._lock:
-            torch.cuda.default_generators[torch.cuda.current_device()].set_offset(4 * int(stream))
+            if count is not None and gen.get_offset() != 4 * (int(stream) + int(count)):
+                return False
+            gen.set_offset(4 * int(stream))
+            return True
 
 
 class _Shard(threading.local):
@@ -1173,7 +1180,15 @@ class BrownianPath:
 
 def _env_tree_depth() -> int:
     v = os.environ.get("SONAR_BROWNIAN_TREE", "1").strip().lower()
-    return 0 if v in ("0", "off", "false") else 24 if v in ("", "1", "on", "true") else int(v)
+    if v in ("0", "off", "false"):
+        return 0
+    if v in ("", "1", "on", "true"):
+        return 24
+    try:
+        depth = int(v)
+    except ValueError:  # a malformed value must not make the package fail to import
+        return 24
+    return depth if 0 <= depth <= BrownianPath.MAX_TREE_DEPTH else 24
 
 
 # Depth of the virtual Brownian tree (BrownianPath, TREE MODE) for samplers made from now on: 24 (BrownianTree's tolerance of 1e-6 on a

@@ -7,6 +7,7 @@ evaluates the thresholds on device, so there is no ``.item()`` host sync.
 from __future__ import annotations
 
 import contextlib
+import threading
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -21,6 +22,9 @@ _STATS_ATTR = hip_lib.STATS_ATTR
 
 
 _HOST_SETUP_THREADS = 4
+_host_setup_lock = threading.Lock()
+_host_setup_users = 0
+_host_setup_before = None
 
 
 @contextlib.contextmanager
@@ -31,16 +35,26 @@ def host_setup_threads():
     region, a container with a CPU quota (the GPU pool's: 16 CPUs per 100 ms) runs out of quota, and the kernel's bandwidth control
     throttles the WHOLE process -- the thread that launches kernels included -- until the period ends (cpu.stat nr_throttled 0 -> 100
     over three 4-second runs; none with 4 threads; scratch/stall_fresh.py).  The tensors are a few hundred kilobytes:
-    four threads lose nothing, and elementwise results do not depend on the thread count."""
-    before = torch.get_num_threads()
-    if before <= _HOST_SETUP_THREADS:
-        yield
-        return
-    torch.set_num_threads(_HOST_SETUP_THREADS)
+    four threads lose nothing, and elementwise results do not depend on the thread count.
+    The count is process-global, so concurrent users share ONE lowering: the first to enter lowers it and remembers the old value, the
+    last to leave puts it back (a lock and a count of users; interleaved enter / exit pairs used to be able to leave the pool at four
+    threads, or restore a stale value)."""
+    global _host_setup_users, _host_setup_before
+    with _host_setup_lock:
+        if _host_setup_users == 0:
+            before = torch.get_num_threads()
+            _host_setup_before = before if before > _HOST_SETUP_THREADS else None
+            if _host_setup_before is not None:
+                torch.set_num_threads(_HOST_SETUP_THREADS)
+        _host_setup_users += 1
     try:
         yield
     finally:
-        torch.set_num_threads(before)
+        with _host_setup_lock:
+            _host_setup_users -= 1
+            if _host_setup_users == 0 and _host_setup_before is not None:
+                torch.set_num_threads(_host_setup_before)
+                _host_setup_before = None
 
 
 def fallback(val, default=None):

@@ -83,3 +83,91 @@ def test_blob_words(pkg):
     blob = bytearray(b"abc")
     off = hl._blob_reserve(blob, 8, b"\x01\x02")
     assert off == 16 and len(blob) == 24 and blob[16:18] == b"\x01\x02" and blob[18:24] == bytes(6)
+
+
+def test_a_trace_ending_on_one_thread_does_not_break_callers_on_another(pkg):
+    """Round 6 (review item 7): `load()`, `_dev()` and `Planned._call` read the module's `_recorder` ONCE.  One thread starts and ends traces in
+    a loop (the global flips between a recorder and None); the other keeps asking for the library and registering tags.  With two reads
+    (`_recorder is None or _recorder.thread != ...`) the second could meet None: AttributeError.  Here the switch interval is set to its
+    minimum so that the interleaving is exercised thousands of times."""
+    import sys
+    import threading
+
+    import torch
+
+    hl = pkg.hip_lib
+    raw = hl.load()
+    stop, errors, seen = threading.Event(), [], [0, 0]
+    old = sys.getswitchinterval()
+    sys.setswitchinterval(1e-6)
+
+    def tracer():
+        try:
+            while not stop.is_set():
+                result, plan = hl.trace_plan(lambda: 7, (), take=None, rewind=None, guards=())
+                assert result == 7 and plan is None  # "the call launched nothing"
+                seen[0] += 1
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    def caller():
+        try:
+            t = torch.zeros(4)
+            planned_check = hl.Planned._call
+            assert planned_check is not None
+            while not stop.is_set():
+                assert hl.load() is raw  # never the recording proxy: the trace belongs to the other thread
+                hl.tag_register(t)
+                hl.tag_forget(t)
+                with pytest.raises(hl.SonarHipError):  # CPU tensor: refused, after the recorder check's code path is compiled in
+                    hl._dev(t, "t")
+                seen[1] += 1
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=tracer), threading.Thread(target=caller)]
+    try:
+        for th in threads:
+            th.start()
+        import time
+
+        time.sleep(1.5)
+    finally:
+        stop.set()
+        for th in threads:
+            th.join()
+        sys.setswitchinterval(old)
+    assert not errors, errors
+    assert seen[0] > 50 and seen[1] > 50, seen
+
+
+def test_every_reader_takes_the_recorder_global_once(pkg):
+    """The deterministic half of the test above: no function of hip_lib other than trace_plan (which owns the global) loads `_recorder`
+    more than once per call, so no reader can see a recorder in its test and None in its use."""
+    import dis
+    import types
+
+    hl = pkg.hip_lib
+
+    def functions(ns):
+        for obj in ns.values():
+            if isinstance(obj, types.FunctionType) and obj.__module__ == hl.__name__:
+                yield obj
+            elif isinstance(obj, type) and obj.__module__ == hl.__name__:
+                yield from functions(vars(obj))
+
+    def code_objects(code):
+        yield code
+        for const in code.co_consts:
+            if isinstance(const, types.CodeType):
+                yield from code_objects(const)
+
+    readers = 0
+    for fn in functions(vars(hl)):
+        if fn.__name__ == "trace_plan":
+            continue
+        for code in code_objects(fn.__code__):
+            loads = [i for i in dis.get_instructions(code) if i.opname in ("LOAD_GLOBAL", "LOAD_NAME") and i.argval == "_recorder"]
+            assert len(loads) <= 1, f"{fn.__qualname__} reads _recorder {len(loads)} times"
+            readers += len(loads)
+    assert readers >= 4  # load, _dev, the power look-ahead wrapper, Planned._call
