@@ -2,6 +2,7 @@
 // noise.  Output-write-bound: every kernel streams 16 B/lane stores of contiguous NCHW latents
 // and, when asked, folds the whole-tensor (sum, sumsq) partials of the normaliser into the same pass.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -314,6 +315,150 @@ static int launch_fill_norm(float* out, int64_t n, uint64_t seed, uint64_t strea
     return check_launch(what);
 }
 
+// A sampler's steady state inside a prepared plan (the stream id of the call that follows is known): the final pass of THIS call and
+// the statistics pass of the NEXT call as ONE launch (round 6; sonar_philox_noise_ahead_f32).  The final pass is store-bound (a 134 MB
+// tensor: 24 us, 21 of them the write itself) with the vector ALUs idle most of the time; the statistics pass is nothing but vector-ALU
+// work (15 us as a launch of its own).  A wave draws the next call's tile right behind this call's -- its statistics arithmetic issues
+// while the stores of the step before are in flight.  Same grid, same tile -> wave -> step order, same per-thread sums and block
+// reduction as stream_fill_norm_kernel<D, VEC, 1>: the partials left for the next call are the bits its own statistics pass would write.
+// the affine map and the normalisation with their run-time switches decided ONCE per launch (template flags): inside the tile loop every
+// switch was a v_cndmask per value, and the range checks of a shard's ragged ends a branch per group -- 220 instructions per step of
+// eight values where the arithmetic needs 90 (the launch was instruction-bound: 33 us against the 24 us of its stores)
+template <bool ACTIVE>
+struct AffineT {
+    float sub, mul, add;
+    __device__ __forceinline__ float operator()(float u) const {
+        if constexpr (ACTIVE) return (u - sub) * mul + add;
+        else return u;
+    }
+};
+template <bool SUB, bool SCALE>
+struct NormT {
+    float mean, inv_std, factor;
+    __device__ __forceinline__ float operator()(float v) const {
+        if constexpr (SUB) v = v - mean;
+        if constexpr (SCALE) v = v * inv_std * factor;
+        return v;
+    }
+};
+template <typename F>
+__device__ __forceinline__ void with_affine_norm(const Affine& aff, const NormFast& nf, F&& f) {
+    auto with_norm = [&](auto a) {
+        if (nf.do_sub) {
+            if (nf.do_scale) f(a, NormT<true, true>{nf.mean, nf.inv_std, nf.factor});
+            else f(a, NormT<true, false>{nf.mean, nf.inv_std, nf.factor});
+        } else {
+            if (nf.do_scale) f(a, NormT<false, true>{nf.mean, nf.inv_std, nf.factor});
+            else f(a, NormT<false, false>{nf.mean, nf.inv_std, nf.factor});
+        }
+    };
+    if (aff.active) with_norm(AffineT<true>{aff.sub, aff.mul, aff.add});
+    else with_norm(AffineT<false>{aff.sub, aff.mul, aff.add});
+}
+
+template <typename F>
+__device__ __forceinline__ void with_norm_flags(const NormFast& nf, F&& f) {
+    if (nf.do_sub) {
+        if (nf.do_scale) f(NormT<true, true>{nf.mean, nf.inv_std, nf.factor});
+        else f(NormT<true, false>{nf.mean, nf.inv_std, nf.factor});
+    } else {
+        if (nf.do_scale) f(NormT<false, true>{nf.mean, nf.inv_std, nf.factor});
+        else f(NormT<false, false>{nf.mean, nf.inv_std, nf.factor});
+    }
+}
+
+// ALIGNED: whole tiles only (n and elem_offset multiples of kTileElems, 16-byte aligned output): no range checks at all
+template <Dist D, bool VEC, bool ALIGNED>
+__global__ void __launch_bounds__(kBlock) stream_fill_ahead_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t next_stream,
+                                                                   int64_t elem_offset, Affine aff, NormArgs na, double* partials_next) {
+    kernarg_touch_for(out, n, seed, stream_id, next_stream, elem_offset, aff, na, partials_next);
+    __shared__ double red[2 * kBlock / 64];
+    __shared__ NormDecision sh;
+    const NormDecision dec = decide_norm<kBlock>(na.partials, kNPart, na.n_total, na.thr_sd, red, &sh);
+    const NormFast norm(dec, na.factor);
+    double s = 0.0, q = 0.0;
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
+    if constexpr (ALIGNED) {
+        with_affine_norm(aff, norm, [&](auto af, auto nm) {
+            for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+                TileRng now = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+                TileRng nxt = rng_stream(seed, next_stream, (uint64_t)tile, lane);
+                float* const o = out + (tile * kTileElems + (int64_t)lane * 4 - elem_offset);
+#pragma unroll 4
+                for (int it = 0; it < kTileIters; ++it) {
+                    float v[4], u[4];
+                    if constexpr (D == Dist::Normal) now.normal4(v); else now.uniform4(v);
+                    *reinterpret_cast<float4*>(o + it * 256) = make_float4(nm(af(v[0])), nm(af(v[1])), nm(af(v[2])), nm(af(v[3])));
+                    if constexpr (D == Dist::Normal) nxt.normal4(u); else nxt.uniform4(u);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) u[k] = af(u[k]);
+                    const float ps = (u[0] + u[1]) + (u[2] + u[3]);
+                    const float pq = __builtin_fmaf(u[0], u[0], __builtin_fmaf(u[1], u[1], __builtin_fmaf(u[2], u[2], u[3] * u[3])));
+                    s += (double)ps;
+                    q += (double)pq;
+                }
+            }
+        });
+    } else {
+        double unused_s = 0.0, unused_q = 0.0;
+        for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+            TileRng now = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+            TileRng nxt = rng_stream(seed, next_stream, (uint64_t)tile, lane);
+            const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
+#pragma unroll 4
+            for (int it = 0; it < kTileIters; ++it) {
+                const int64_t e = base + it * 256;
+                float v[4], u[4];
+                if constexpr (D == Dist::Normal) now.normal4(v); else now.uniform4(v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = norm(aff(v[k]));
+                store_group<VEC>(out, n, e, v, unused_s, unused_q, false);
+                if constexpr (D == Dist::Normal) nxt.normal4(u); else nxt.uniform4(u);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u[k] = aff(u[k]);
+                if (e >= 0 && e + 4 <= n) {
+                    const float ps = (u[0] + u[1]) + (u[2] + u[3]);
+                    const float pq = __builtin_fmaf(u[0], u[0], __builtin_fmaf(u[1], u[1], __builtin_fmaf(u[2], u[2], u[3] * u[3])));
+                    s += (double)ps;
+                    q += (double)pq;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (e + k >= 0 && e + k < n) {
+                            s += (double)u[k];
+                            q += (double)u[k] * (double)u[k];
+                        }
+                }
+            }
+        }
+    }
+    __syncthreads();  // (red: the decision's reduction above, the partial's below)
+    write_partial<kBlock>(s, q, partials_next, red);
+}
+
+template <Dist D>
+static int launch_fill_ahead(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset, Affine aff, float factor, float thr,
+                             double* partials, int have_stats, uint64_t next_stream, double* partials_next, hipStream_t st, const char* what) {
+    if (n == 0) return SONAR_OK;
+    const bool vec = aligned16(out) && (elem_offset & 3) == 0;
+    const int g = tile_grid(n, elem_offset);
+    const NormArgs na{partials, n, factor, thr};
+    if (!have_stats)  // nobody left this call's statistics (the first call, a reseed, another generator drew in between): its own pass
+        hipLaunchKernelGGL((stream_fill_norm_kernel<D, true, 1>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials,
+                           NormArgs{nullptr, 0, 1.0f, 0.0f});
+    const bool whole = vec && n % kTileElems == 0 && elem_offset % kTileElems == 0;
+#define SONAR_FA(V, AL) \
+    hipLaunchKernelGGL((stream_fill_ahead_kernel<D, V, AL>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, next_stream, elem_offset, aff, na, partials_next)
+    if (whole) SONAR_FA(true, true);
+    else if (vec) SONAR_FA(true, false);
+    else SONAR_FA(false, false);
+#undef SONAR_FA
+    return check_launch(what);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Perlin: lattice term at cell centre (py/noise_generation.py:388-405 with positions == (0.5, 0.5)).
 __global__ void __launch_bounds__(kBlock) perlin_terms_kernel(const float* __restrict__ angles, float* terms,
@@ -434,9 +579,9 @@ __global__ void __launch_bounds__(kBlock) perlin_apply_kernel(const float* __res
 
 // The fast path's tile loop (device-drawn calls: ONE summed term table, vector-aligned latents): wave `wave` of `nwaves` takes the tiles
 // first + wave, first + wave + nwaves, ...  MODE as in perlin_generate_kernel.  Shared by that kernel and perlin_ahead_kernel.
-template <int MODE, bool STATS, bool ALIGNED, typename DIV>
+template <int MODE, bool STATS, bool ALIGNED, typename DIV, typename NORM>
 __device__ __forceinline__ void perlin_fast_tiles(const float* __restrict__ terms, float* out, int64_t n, int64_t chw, uint64_t seed,
-                                                  uint64_t stream_id, int64_t elem_offset, const NormFast& norm, const DIV& divide,
+                                                  uint64_t stream_id, int64_t elem_offset, const NORM& norm, const DIV& divide,
                                                   const Accum& acc, int64_t wave, int64_t nwaves, double& s, double& q) {
     const uint32_t lane = threadIdx.x & 63;
     const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
@@ -483,8 +628,12 @@ __device__ __forceinline__ void perlin_fast_tiles(const float* __restrict__ term
                 }
                 if constexpr (MODE != 1) {
                     if constexpr (MODE == 0) accumulate_group<true>(acc, n, e, v);
-                    double unused_s = 0.0, unused_q = 0.0;
-                    store_group<true>(out, n, e, v, unused_s, unused_q, false);
+                    if constexpr (ALIGNED) {  // whole tiles inside the shard: no range checks (store_group's were a branch per group)
+                        *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        double unused_s = 0.0, unused_q = 0.0;
+                        store_group<true>(out, n, e, v, unused_s, unused_q, false);
+                    }
                 }
                 if constexpr (STATS || MODE == 1) {
                     ts += (v[0] + v[1]) + (v[2] + v[3]);
@@ -498,6 +647,64 @@ __device__ __forceinline__ void perlin_fast_tiles(const float* __restrict__ term
             s += (double)ts;
             q += (double)tq;
         }
+    }
+}
+
+// The final pass of one call (MODE 2: `terms`, `stream_id`, normalised, stored) and the statistics pass of the next (MODE 1: `terms_next`,
+// `next_stream`, summed) for the same tiles in ONE wave, step by step (round 6): the statistics arithmetic issues while the stores of the
+// steps before are in flight.  Per tile and lane the same values in the same order as the two separate loops above -- the stored bits and
+// the (sum, sumsq) this thread adds up are theirs.  Whole tiles per latent only (ALIGNED).
+template <typename DIV, typename NORM>
+__device__ __forceinline__ void perlin_fast_tiles_pair(const float* __restrict__ terms, const float* __restrict__ terms_next, float* out, int64_t n,
+                                                       int64_t chw, uint64_t seed, uint64_t stream_id, uint64_t next_stream, int64_t elem_offset,
+                                                       const NORM& norm, const DIV& divide, int64_t wave, int64_t nwaves, double& s, double& q) {
+    const uint32_t lane = threadIdx.x & 63;
+    const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
+    for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+        TileRng rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+        TileRng rnx = rng_stream(seed, next_stream, (uint64_t)tile, lane);
+        const int64_t base = tile * kTileElems + (int64_t)lane * 4 - elem_offset;
+        const int rp = (int)(((base % chw) + chw) % chw);
+        const float4* const trow = reinterpret_cast<const float4*>(terms + rp);
+        const float4* const tnxt = reinterpret_cast<const float4*>(terms_next + rp);
+        float4 cur[4], nxt[4], curn[4], nxtn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cur[j] = trow[64 * j];
+            curn[j] = tnxt[64 * j];
+        }
+        float ts = 0.0f, tq = 0.0f;
+#pragma unroll
+        for (int g = 0; g < kTileIters / 4; ++g) {
+            if (g + 1 < kTileIters / 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    nxt[j] = trow[64 * (4 * (g + 1) + j)];
+                    nxtn[j] = tnxt[64 * (4 * (g + 1) + j)];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t r[4];
+                rng.words4_high(r);
+                *reinterpret_cast<float4*>(out + base + (4 * g + j) * 256) =
+                    make_float4(norm(divide.from_word(r[0], cur[j].x)), norm(divide.from_word(r[1], cur[j].y)),
+                                norm(divide.from_word(r[2], cur[j].z)), norm(divide.from_word(r[3], cur[j].w)));
+                uint32_t w[4];
+                rnx.words4_high(w);
+                const float v0 = divide.from_word(w[0], curn[j].x), v1 = divide.from_word(w[1], curn[j].y);
+                const float v2 = divide.from_word(w[2], curn[j].z), v3 = divide.from_word(w[3], curn[j].w);
+                ts += (v0 + v1) + (v2 + v3);
+                tq = __builtin_fmaf(v0, v0, __builtin_fmaf(v1, v1, __builtin_fmaf(v2, v2, __builtin_fmaf(v3, v3, tq))));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cur[j] = nxt[j];
+                curn[j] = nxtn[j];
+            }
+        }
+        s += (double)ts;
+        q += (double)tq;
     }
 }
 
@@ -530,7 +737,13 @@ __global__ void __launch_bounds__(kBlock) perlin_generate_kernel(const float* __
     if constexpr (FAST) {
         static_assert(VEC, "the fast path is a vector path");
         with_divider(divide, [&](auto dv) {
-            perlin_fast_tiles<MODE, STATS, ALIGNED>(terms, out, n, chw, seed, stream_id, elem_offset, norm, dv, acc, wave, nwaves, s, q);
+            if constexpr (MODE == 2) {  // the normalisation's switches decided once per launch, not per value
+                with_norm_flags(norm, [&](auto nm) {
+                    perlin_fast_tiles<MODE, STATS, ALIGNED>(terms, out, n, chw, seed, stream_id, elem_offset, nm, dv, acc, wave, nwaves, s, q);
+                });
+            } else {
+                perlin_fast_tiles<MODE, STATS, ALIGNED>(terms, out, n, chw, seed, stream_id, elem_offset, norm, dv, acc, wave, nwaves, s, q);
+            }
         });
         if constexpr (STATS || MODE == 1) write_partial<kBlock>(s, q, partials, red);
         return;
@@ -653,6 +866,7 @@ struct PerlinAhead {
     double* partials_next;
     float* lattice_out;           // nullable: no lattice ahead
     int lat_blocks, tile_blocks, lat_iters, blend_mode;
+    int fused;                    // one wave runs both passes for its tiles (the bandwidth-bound sizes); 0: separate, interleaved blocks
     int64_t C;
     int H, W;
     uint64_t lattice_stream_id;
@@ -672,16 +886,34 @@ __global__ void __launch_bounds__(kBlock) perlin_ahead_kernel(PerlinAhead a) {
     // write itself) with the vector ALUs idle, the statistics pass is nothing but vector ALU work (13 us as a launch of its own)
     const int nb = a.tile_blocks;
     const int blk = (int)blockIdx.x - a.lat_blocks;
+    const Divider divide(a.div_fac);
+    double s = 0.0, q = 0.0;
+    if (a.fused) {
+        // bandwidth-bound sizes (round 6): ONE wave runs this call's final pass and the next call's statistics pass for its tiles, step by
+        // step -- the interleaved blocks below left the statistics waves done after 13 us and the storing waves on their own for the rest
+        const int64_t wave = ((int64_t)blk * kBlock + threadIdx.x) >> 6, nwaves = ((int64_t)nb * kBlock) >> 6;
+        const NormDecision dec = decide_norm<kBlock>(a.na.partials, kNPart, a.na.n_total, a.na.thr_sd, red, &sh);
+        const NormFast norm(dec, a.na.factor);
+        with_divider(divide, [&](auto dv) {
+            with_norm_flags(norm, [&](auto nm) {
+                perlin_fast_tiles_pair(a.terms, a.terms_next, a.out, a.n, a.chw, a.seed, a.stream_id, a.next_stream_id, a.elem_offset, nm, dv, wave, nwaves,
+                                       s, q);
+            });
+        });
+        __syncthreads();  // (red: the decision's reduction above, the partial's below)
+        write_partial_at<kBlock>(s, q, a.partials_next, red, blk, nb);
+        return;
+    }
     const bool ahead = a.terms_next != nullptr && (blk & 1);
     const int bid = a.terms_next != nullptr ? blk >> 1 : blk;
-    const Divider divide(a.div_fac);
     const int64_t wave = ((int64_t)bid * kBlock + threadIdx.x) >> 6, nwaves = ((int64_t)nb * kBlock) >> 6;
-    double s = 0.0, q = 0.0;
     if (!ahead) {
         const NormDecision dec = decide_norm<kBlock>(a.na.partials, kNPart, a.na.n_total, a.na.thr_sd, red, &sh);
         const NormFast norm(dec, a.na.factor);
         with_divider(divide, [&](auto dv) {
-            perlin_fast_tiles<2, false, true>(a.terms, a.out, a.n, a.chw, a.seed, a.stream_id, a.elem_offset, norm, dv, kNoAccum, wave, nwaves, s, q);
+            with_norm_flags(norm, [&](auto nm) {
+                perlin_fast_tiles<2, false, true>(a.terms, a.out, a.n, a.chw, a.seed, a.stream_id, a.elem_offset, nm, dv, kNoAccum, wave, nwaves, s, q);
+            });
         });
     } else {
         const NormFast norm(NormDecision{0.f, 1.f, 0, 0}, 1.0f);
@@ -1777,6 +2009,27 @@ extern "C" int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64
                                           (hipStream_t)stream, "sonar_philox_noise_f32");
 }
 
+extern "C" int sonar_philox_noise_ahead_ok(int uniform, int64_t n, float factor) {
+    // N(0,1) with factor 1 keeps its one-pass route (sonar_philox_noise_f32: no statistics pass to move)
+    return n > 0 && (uniform || factor != 1.0f) ? 1 : 0;
+}
+
+extern "C" int sonar_philox_noise_ahead_f32(int uniform, float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                            float sub, float mul, float add, float factor, float threshold_std_devs, double* partials,
+                                            int have_stats, uint64_t next_stream_id, double* partials_next, void* stream) {
+    SONAR_REQUIRE(out && partials && partials_next && partials != partials_next && n >= 0 && elem_offset >= 0, SONAR_ERR_ARG,
+                  "sonar_philox_noise_ahead_f32: bad argument");
+    SONAR_REQUIRE(sonar_philox_noise_ahead_ok(uniform, n, factor) || n == 0, SONAR_ERR_UNSUPPORTED,
+                  "sonar_philox_noise_ahead_f32: N(0,1) with factor 1 has no statistics pass to run ahead (sonar_philox_noise_f32)");
+    const int active = !(sub == 0.0f && mul == 1.0f && add == 0.0f);
+    const Affine aff{sub, mul, add, uniform ? active : 0};
+    if (uniform)
+        return launch_fill_ahead<Dist::Uniform>(out, n, seed, stream_id, elem_offset, aff, factor, threshold_std_devs, partials, have_stats,
+                                                next_stream_id, partials_next, (hipStream_t)stream, "sonar_philox_noise_ahead_f32");
+    return launch_fill_ahead<Dist::Normal>(out, n, seed, stream_id, elem_offset, aff, factor, threshold_std_devs, partials, have_stats,
+                                           next_stream_id, partials_next, (hipStream_t)stream, "sonar_philox_noise_ahead_f32");
+}
+
 static int brownian_launch(float* out, float* w_out, const float* prev, float scale, int64_t n, int64_t elem_offset,
                            const uint64_t* node_ids, const float* coefs, int nnodes, uint64_t seed, const uint64_t* latent_seeds,
                            int64_t latent_elems, void* stream, const char* what, BrownianBase base = BrownianBase{nullptr, nullptr, 0.0f, 0.0f},
@@ -2005,7 +2258,11 @@ extern "C" int sonar_perlin_noise_ahead_f32(const float* terms, float* out, int6
     a.W = (int)W;
     a.lattice_stream_id = lattice_stream_id;
     a.tile_blocks = tile_grid(a.n, elem_offset);
-    hipLaunchKernelGGL(perlin_ahead_kernel, dim3(a.lat_blocks + a.tile_blocks * (terms_next ? 2 : 1)), dim3(kBlock), 0, st, a);
+    // a wave with a tile or more of its own to store has stores in flight to hide the next call's statistics behind (batch >= 256 SDXL
+    // latents: the capped grid); below that the two passes go to separate blocks, twice as many waves with one short chain each
+    static const int fuse_env = [] { const char* e = getenv("SONAR_PERLIN_FUSED"); return e ? atoi(e) : -1; }();  // (A/B)
+    a.fused = terms_next && (fuse_env >= 0 ? fuse_env != 0 : a.tile_blocks == kNPart) ? 1 : 0;
+    hipLaunchKernelGGL(perlin_ahead_kernel, dim3(a.lat_blocks + a.tile_blocks * (terms_next && !a.fused ? 2 : 1)), dim3(kBlock), 0, st, a);
     return check_launch(what);
 }
 

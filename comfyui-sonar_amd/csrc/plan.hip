@@ -72,6 +72,7 @@ const Replayable kReplayable[] = {
     SONAR_REPLAYABLE(sonar_philox_normal_f32),
     SONAR_REPLAYABLE(sonar_philox_uniform_f32),
     SONAR_REPLAYABLE(sonar_philox_noise_f32),
+    SONAR_REPLAYABLE(sonar_philox_noise_ahead_f32),
     SONAR_REPLAYABLE(sonar_philox_normal_acc_f32),
     SONAR_REPLAYABLE(sonar_philox_normal_chain_f32),
     SONAR_REPLAYABLE(sonar_perlin_lattice_f32),

@@ -94,6 +94,8 @@ SIGNATURES = {
     "sonar_philox_normal_f32": (_I, [_P, _I64, _U64, _U64, _I64, _P, _P]),
     "sonar_philox_uniform_f32": (_I, [_P, _I64, _U64, _U64, _I64, _F, _F, _F, _P, _P]),
     "sonar_philox_noise_f32": (_I, [_I, _P, _I64, _U64, _U64, _I64, _F, _F, _F, _F, _F, _P, _P]),
+    "sonar_philox_noise_ahead_ok": (_I, [_I, _I64, _F]),
+    "sonar_philox_noise_ahead_f32": (_I, [_I, _P, _I64, _U64, _U64, _I64, _F, _F, _F, _F, _F, _P, _I, _U64, _P, _P]),
     "sonar_brownian_f32": (_I, [_P, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_brownian_bridge_acc_f32": (_I, [_P, _P, _P, _F, _P, _F, _P, _F, _I64, _I64, _P, _P, _I, _U64, _P, _I64, _P]),
     "sonar_philox_normal_acc_f32": (_I, [_P, _I64, _U64, _U64, _I64, _P]),
@@ -1634,10 +1636,11 @@ def wcfg_fused(cond: torch.Tensor, uncond: torch.Tensor, x: Optional[torch.Tenso
 PLANS_ENABLED = os.environ.get("SONAR_PLANS", "1") != "0"
 PLAN_WARM_CALLS = 2     # ordinary calls before a step is traced (first-call setup, look-ahead misses)
 PLAN_MAX_ATTEMPTS = 3   # traces that may fail (a call that took a fallback route) before the step stays on the ordinary path
+FILL_AHEAD = os.environ.get("SONAR_FILL_AHEAD", "1") != "0"  # plans run a normalised uniform / Gaussian fill's statistics a call ahead (_FillAheadHook)
 PERLIN_AHEAD = os.environ.get("SONAR_PERLIN_AHEAD", "1") != "0"  # plans fuse a normalised Perlin call's three launches (_PerlinAheadHook)
 NOT_RUN = object()      # Plan.run: the step was not issued (a guard changed, an entry point refused): take the ordinary path
 _M64 = 2**64 - 1
-_HOST_QUERIES = frozenset(("sonar_abi_version", "sonar_last_error", "sonar_power_noise_ahead_ok", "sonar_perlin_noise_ahead_ok", "sonar_power_pipeline", "sonar_wcfg_hi_storage", "sonar_power_plane_kind", "sonar_dwt_out_len",
+_HOST_QUERIES = frozenset(("sonar_abi_version", "sonar_last_error", "sonar_power_noise_ahead_ok", "sonar_perlin_noise_ahead_ok", "sonar_philox_noise_ahead_ok", "sonar_power_pipeline", "sonar_wcfg_hi_storage", "sonar_power_plane_kind", "sonar_dwt_out_len",
                            "sonar_dwt2_ws_bytes", "sonar_wcfg_lowpass_lds_bytes", "sonar_wcfg_fused_ws_bytes", "sonar_pyramid_levels",
                            "sonar_plan_fn_id", "sonar_plan_fn_nargs"))
 PATCH_SLOT, PATCH_STREAM, PATCH_SEED, PATCH_BLOB, PATCH_LEVELS = range(5)
@@ -1903,6 +1906,78 @@ def _peephole_perlin_ahead(records, b, rec):
         if not done:
             out.append(records[i])
             i += 1
+    return out
+
+
+class _FillAheadHook(PlanHook):
+    """A normalised uniform / Gaussian fill inside a plan (``sonar_philox_noise_ahead_f32``, round 6): the plan knows the stream id of the
+    call that follows, so this call's launch also runs that call's statistics pass -- in the same waves, behind the stores of the final
+    pass.  Two statistics buffers per HIP stream, keyed by (seed, stream id); a call that finds nothing (the first, after a reseed or
+    somebody else's draw) gets ``have_stats`` = 0 and the entry point runs the ordinary statistics pass first: it loses its shortcut,
+    never its values."""
+
+    KEYS = ("p_now", "have", "p_next")
+
+    def __init__(self, tag: str, sa: int, count: int, device):
+        self.tag, self.sa, self.count, self.device = tag, sa, count, device
+        self.managed = {}
+        self.by_stream = {}
+        self.now = None
+        self.hits = self.misses = 0
+
+    def bind(self, slot_of):
+        self.slot = {k: slot_of[self.tag + k] for k in self.KEYS}
+
+    def pre_run(self, seed, base, table, st):
+        state = self.by_stream.get(st)
+        if state is None:
+            state = self.by_stream[st] = {"parts": [new_partials(self.device) for _ in range(2)], "ready": {}}
+        s_now = (base + self.sa) & _M64
+        s_next = (s_now + self.count) & _M64
+        pi = state["ready"].get((seed, s_now))
+        have = pi is not None
+        if have:
+            self.hits += 1
+        else:
+            self.misses += 1
+            pi = 0
+        sl = self.slot
+        table[sl["p_now"]] = state["parts"][pi].data_ptr()
+        table[sl["have"]] = int(have)
+        table[sl["p_next"]] = state["parts"][1 - pi].data_ptr()
+        self.now = (state, {(seed, s_next): 1 - pi})
+        state["ready"] = {}  # (as in _PerlinAheadHook: valid again in post_run)
+        return True
+
+    def post_run(self, seed, base):
+        self.now[0]["ready"] = self.now[1]
+
+
+def _peephole_fill_ahead(records, b, rec):
+    """Every [sonar_philox_noise_f32] record of a traced step whose shape has a statistics pass (uniform draws, or factor != 1) becomes a
+    sonar_philox_noise_ahead_f32 record driven by a ``_FillAheadHook``."""
+    lib = load_raw()
+    out = []
+    signed = lambda v: v - (1 << 64) if v >> 63 else v  # noqa: E731
+    for k, (name, words, blob, patches) in enumerate(records):
+        if name == "sonar_philox_noise_f32" and not blob:
+            pt = {p.target: p for p in patches}
+            factor = C.c_float.from_buffer_copy(int(words[9] & 0xFFFFFFFF).to_bytes(4, "little")).value
+            if (all(t in pt for t in (1, 3, 4, 11)) and pt[3].source == PATCH_SEED and pt[4].source == PATCH_STREAM
+                    and lib.sonar_philox_noise_ahead_ok(int(signed(words[0])), signed(words[2]), factor)):
+                tag = f"fill{k}_"
+                hook = _FillAheadHook(tag, int(pt[4].addend), rec.count, next(iter(b.temp_ranges))[2].device)
+                slots = {}
+                for key in hook.KEYS:
+                    slots[key] = b.slot_of[("hook", tag + key)] = len(b.slots)
+                    b.slots.append(None)
+                w2 = list(words[:11]) + [0, 0, 0, 0, 0]
+                p2 = [pt[1], pt[3], pt[4], PlanPatch(PATCH_SLOT, 11, slots["p_now"], 8, 0), PlanPatch(PATCH_SLOT, 12, slots["have"], 8, 0),
+                      PlanPatch(PATCH_STREAM, 13, 0, 8, pt[4].addend + rec.count), PlanPatch(PATCH_SLOT, 14, slots["p_next"], 8, 0)]
+                out.append(("sonar_philox_noise_ahead_f32", w2, b"", p2))
+                rec.hooks.append(hook)
+                continue
+        out.append((name, words, blob, patches))
     return out
 
 
@@ -2322,6 +2397,8 @@ def _build_plan(rec: _Recorder, result, take, rewind, guards) -> Plan:
     rec.seen.clear()
     if PERLIN_AHEAD:
         records = _peephole_lattice_ahead(_peephole_perlin_ahead(records, b, rec), b, rec)
+    if FILL_AHEAD:
+        records = _peephole_fill_ahead(records, b, rec)
     # what the result owns must be fresh per call: the tensors handed back and the statistics partials tagged onto them
     owned = {}  # id(temp) -> index in the fresh list
 

@@ -233,6 +233,16 @@ int sonar_philox_uniform_f32(float* out, int64_t n, uint64_t seed, uint64_t stre
 int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                            float sub, float mul, float add, float factor, float threshold_std_devs, double* partials,
                            void* stream);
+/* The same call in a sampler's steady state, for prepared plans (round 6): ONE launch runs this call's final pass (statistics in
+ * `partials`: left there by the previous call's launch when `have_stats`, else computed first by the ordinary statistics pass) and the
+ * statistics pass of the call that will draw with `next_stream_id`, into `partials_next` (another 1024 fp64 pairs) -- the final pass is
+ * store-bound, the statistics pass pure vector-ALU work, one wave does both for its tiles.  Output bits and `partials_next` are those of
+ * sonar_philox_noise_f32's two launches.  Where sonar_philox_noise_ahead_ok() says 1 (every shape except N(0,1) with factor 1, which has
+ * a one-pass route already); SONAR_ERR_UNSUPPORTED otherwise. */
+int sonar_philox_noise_ahead_ok(int uniform, int64_t n, float factor);
+int sonar_philox_noise_ahead_f32(int uniform, float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                 float sub, float mul, float add, float factor, float threshold_std_devs, double* partials,
+                                 int have_stats, uint64_t next_stream_id, double* partials_next, void* stream);
 
 /* Brownian-interval noise (the reference wraps ComfyUI's BrownianTreeNoiseSampler -> torchsde, un-vendored:
  * py/noise_generation.py:262-286, py/nodes/powernoise.py:383-393).  out[e] = sum_k coefs[k] * z(node_ids[k], e) with
