@@ -356,6 +356,26 @@ __device__ __forceinline__ void with_affine_norm(const Affine& aff, const NormFa
     else with_norm(AffineT<false>{aff.sub, aff.mul, aff.add});
 }
 
+// scale_noise_kernel's own sequence (subtract, IEEE division; factor 1): what the one-pass N(0,1) route applies when a threshold fails
+template <bool SUB, bool DIV>
+struct NormExactT {
+    float mean, stdv;
+    __device__ __forceinline__ float operator()(float v) const {
+        if constexpr (SUB) v = v - mean;
+        if constexpr (DIV) v = v / stdv;
+        return v;
+    }
+};
+template <typename F>
+__device__ __forceinline__ void with_exact_norm(const NormDecision& d, F&& f) {
+    if (d.do_sub) {
+        if (d.do_div) f(NormExactT<true, true>{d.mean, d.stdv});
+        else f(NormExactT<true, false>{d.mean, d.stdv});
+    } else {
+        if (d.do_div) f(NormExactT<false, true>{d.mean, d.stdv});
+        else f(NormExactT<false, false>{d.mean, d.stdv});
+    }
+}
 template <typename F>
 __device__ __forceinline__ void with_norm_flags(const NormFast& nf, F&& f) {
     if (nf.do_sub) {
@@ -368,7 +388,8 @@ __device__ __forceinline__ void with_norm_flags(const NormFast& nf, F&& f) {
 }
 
 // ALIGNED: whole tiles only (n and elem_offset multiples of kTileElems, 16-byte aligned output): no range checks at all
-template <Dist D, bool VEC, bool ALIGNED>
+// EXACT: N(0,1) with factor 1, whose ordinary route stores the raw draws and leaves the (rare) correction to scale_noise_kernel
+template <Dist D, bool VEC, bool ALIGNED, bool EXACT = false>
 __global__ void __launch_bounds__(kBlock) stream_fill_ahead_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t next_stream,
                                                                    int64_t elem_offset, Affine aff, NormArgs na, double* partials_next) {
     kernarg_touch_for(out, n, seed, stream_id, next_stream, elem_offset, aff, na, partials_next);
@@ -382,7 +403,7 @@ __global__ void __launch_bounds__(kBlock) stream_fill_ahead_kernel(float* out, i
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
     const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
     if constexpr (ALIGNED) {
-        with_affine_norm(aff, norm, [&](auto af, auto nm) {
+        auto tiles = [&](auto af, auto nm) {
             for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
                 TileRng now = rng_stream(seed, stream_id, (uint64_t)tile, lane);
                 TileRng nxt = rng_stream(seed, next_stream, (uint64_t)tile, lane);
@@ -401,7 +422,9 @@ __global__ void __launch_bounds__(kBlock) stream_fill_ahead_kernel(float* out, i
                     q += (double)pq;
                 }
             }
-        });
+        };
+        if constexpr (EXACT) with_exact_norm(dec, [&](auto nm) { tiles(AffineT<false>{0.0f, 1.0f, 0.0f}, nm); });
+        else with_affine_norm(aff, norm, tiles);
     } else {
         double unused_s = 0.0, unused_q = 0.0;
         for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
@@ -414,12 +437,14 @@ __global__ void __launch_bounds__(kBlock) stream_fill_ahead_kernel(float* out, i
                 float v[4], u[4];
                 if constexpr (D == Dist::Normal) now.normal4(v); else now.uniform4(v);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = norm(aff(v[k]));
+                for (int k = 0; k < 4; ++k) v[k] = EXACT ? apply_norm(v[k], dec, 1.0f, false) : norm(aff(v[k]));
                 store_group<VEC>(out, n, e, v, unused_s, unused_q, false);
                 if constexpr (D == Dist::Normal) nxt.normal4(u); else nxt.uniform4(u);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) u[k] = aff(u[k]);
-                if (e >= 0 && e + 4 <= n) {
+                // (EXACT: the statistics the next call's own launch would leave are store_group<VEC>'s -- per element when the shape has no
+                // vector path; the other shapes' statistics pass always takes whole groups where it can)
+                if ((VEC || !EXACT) && e >= 0 && e + 4 <= n) {
                     const float ps = (u[0] + u[1]) + (u[2] + u[3]);
                     const float pq = __builtin_fmaf(u[0], u[0], __builtin_fmaf(u[1], u[1], __builtin_fmaf(u[2], u[2], u[3] * u[3])));
                     s += (double)ps;
@@ -446,13 +471,28 @@ static int launch_fill_ahead(float* out, int64_t n, uint64_t seed, uint64_t stre
     const bool vec = aligned16(out) && (elem_offset & 3) == 0;
     const int g = tile_grid(n, elem_offset);
     const NormArgs na{partials, n, factor, thr};
-    if (!have_stats)  // nobody left this call's statistics (the first call, a reseed, another generator drew in between): its own pass
-        hipLaunchKernelGGL((stream_fill_norm_kernel<D, true, 1>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials,
-                           NormArgs{nullptr, 0, 1.0f, 0.0f});
+    const bool unit_normal = D == Dist::Normal && factor == 1.0f;
+    if (!have_stats) {  // nobody left this call's statistics (the first call, a reseed, another generator drew in between): its own pass
+        if (unit_normal) {
+            // the ordinary route's first launch (raw draws stored with their statistics; the stores are repeated below): its partials
+            const int rc = launch_fill<D>(out, n, seed, stream_id, elem_offset, aff, partials, st, what);
+            if (rc != SONAR_OK) return rc;
+        } else {
+            hipLaunchKernelGGL((stream_fill_norm_kernel<D, true, 1>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials,
+                               NormArgs{nullptr, 0, 1.0f, 0.0f});
+        }
+    }
     const bool whole = vec && n % kTileElems == 0 && elem_offset % kTileElems == 0;
 #define SONAR_FA(V, AL) \
     hipLaunchKernelGGL((stream_fill_ahead_kernel<D, V, AL>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, next_stream, elem_offset, aff, na, partials_next)
-    if (whole) SONAR_FA(true, true);
+    if (unit_normal) {
+#define SONAR_FAE(V, AL) \
+    hipLaunchKernelGGL((stream_fill_ahead_kernel<Dist::Normal, V, AL, true>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, next_stream, elem_offset, aff, na, partials_next)
+        if (whole) SONAR_FAE(true, true);
+        else if (vec) SONAR_FAE(true, false);
+        else SONAR_FAE(false, false);
+#undef SONAR_FAE
+    } else if (whole) SONAR_FA(true, true);
     else if (vec) SONAR_FA(true, false);
     else SONAR_FA(false, false);
 #undef SONAR_FA
@@ -2010,8 +2050,10 @@ extern "C" int sonar_philox_noise_f32(int uniform, float* out, int64_t n, uint64
 }
 
 extern "C" int sonar_philox_noise_ahead_ok(int uniform, int64_t n, float factor) {
-    // N(0,1) with factor 1 keeps its one-pass route (sonar_philox_noise_f32: no statistics pass to move)
-    return n > 0 && (uniform || factor != 1.0f) ? 1 : 0;
+    // N(0,1) with factor 1 has a one-pass route (draw once, store with statistics, a no-op scale_noise launch): drawing every normal twice
+    // only pays while the call is launch-bound (batch 64: 12.4 -> 9.7 us; batch 512: 31.3 -> 35.8 us, the vector ALUs become the bound)
+    if (!uniform && factor == 1.0f) return n > 0 && n <= kNtMaxElems ? 1 : 0;
+    return n > 0 ? 1 : 0;
 }
 
 extern "C" int sonar_philox_noise_ahead_f32(int uniform, float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
@@ -2019,8 +2061,6 @@ extern "C" int sonar_philox_noise_ahead_f32(int uniform, float* out, int64_t n, 
                                             int have_stats, uint64_t next_stream_id, double* partials_next, void* stream) {
     SONAR_REQUIRE(out && partials && partials_next && partials != partials_next && n >= 0 && elem_offset >= 0, SONAR_ERR_ARG,
                   "sonar_philox_noise_ahead_f32: bad argument");
-    SONAR_REQUIRE(sonar_philox_noise_ahead_ok(uniform, n, factor) || n == 0, SONAR_ERR_UNSUPPORTED,
-                  "sonar_philox_noise_ahead_f32: N(0,1) with factor 1 has no statistics pass to run ahead (sonar_philox_noise_f32)");
     const int active = !(sub == 0.0f && mul == 1.0f && add == 0.0f);
     const Affine aff{sub, mul, add, uniform ? active : 0};
     if (uniform)
