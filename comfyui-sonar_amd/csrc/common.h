@@ -131,6 +131,15 @@ __device__ __forceinline__ TileRng rng_stream(uint64_t seed, uint64_t stream_id,
     return Mwc::seeded(p.v[0] ^ p.v[2], p.v[1] ^ p.v[3]);
 }
 
+// One-instruction conversions of generator words (power_core.h has the derivation): 23 bits into the mantissa of a float in [1, 2)
+// (u = 2 - m is a uniform in (0, 1]); 16 bits as a fraction of a revolution inside a float in [128, 256) -- v_sin / v_cos take
+// revolutions, are periodic and accept |x| <= 256 -- from the low or the high half of one word.
+__device__ __forceinline__ float unit_mantissa(uint32_t hi_bits_in_msb) {  // bits 31..9 -> [1, 2)
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, hi_bits_in_msb, 9));
+}
+__device__ __forceinline__ float angle_lo(uint32_t t) { return __uint_as_float(__builtin_amdgcn_bitop3_b32(t, 0x007FFFFFu, 0x43000000u, 0xEA)); }  // (t & mask) | 128.0f
+__device__ __forceinline__ float angle_hi(uint32_t t) { return __uint_as_float(__builtin_amdgcn_alignbit(0x4300u, t, 16)); }
+
 // Flat buffers are drawn in tiles of kTileIters x 64 lanes x 4 elements: global element e belongs to
 // tile e / kTileElems, lane (e % 256) / 4, burst step (e % kTileElems) / 256, slot e % 4.
 constexpr int kTileIters = 16;

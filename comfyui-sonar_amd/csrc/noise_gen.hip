@@ -1823,12 +1823,61 @@ struct BrownianTerms {
     int count;
 };
 
-// Burst variant (latents of a multiple of kTileElems elements, one seed): z(node, .) is a tile-keyed random stream (common.h, Mwc) with
-// stream id `node` (the Gaussian fill's generator, here in sub-tiles of 4 steps x 64 lanes x 4 = 1024 elements), so the
-// Philox seeding is paid once per (node, sub-tile, lane) for 16 values instead of once per 4 values.  A wave owns a
-// sub-tile and keeps its 4 x 4 partial sums in registers over the nodes.
+// Burst variant (latents of a multiple of kTileElems elements, one seed): a wave owns a sub-tile of 4 steps x 64 lanes x 4 = 1024
+// elements and keeps its 4 x 4 partial sums in registers over the nodes; z(node, .) on the sub-tile is a multiply-with-carry burst
+// (common.h, Mwc) of 12 words per lane.
+// Round 6 (the virtual Brownian tree made a call 25 of these bursts per element, 354 us on cfg5's shard -- 22 ns of SIMD time per
+// wave-normal, a fifth of it the Philox block that seeded every (node, sub-tile, lane) burst):
+//  * ONE Philox block per (sub-tile, lane) and call -- the sub-tile's base state, keyed by (seed, kBrownStream, sub-tile, lane) -- and per
+//    node a burst seeded by hashing the base with the node: x = fmix32(base.x ^ hx(node)), c = fmix32(base.c ^ hc(node)), where
+//    (hx, hc) = splitmix64(node id) comes from the host and fmix32 is MurmurHash3's 32-bit finaliser (full avalanche: bursts of different
+//    nodes start at unrelated points of the generator's one cycle, as Philox-seeded ones do): 16 instructions instead of ~60;
+//  * the conversions of the power-law draw (common.h): 23 radius bits through the mantissa of a float in [1, 2), 16 angle bits per value
+//    as a fraction of a revolution, one angle word for two Box-Muller pairs: 12 words and 20 conversion instructions per 16 normals
+//    instead of 16 and 56;
+//  * the coefficient rides under the radius' square root (c r = sqrt(-2 ln2 c^2 log2 u)) and its sign on the accumulating FMA's operand:
+//    one multiply per pair instead of three.
+// 230 -> ~150 instructions per node and sub-tile.  Every Brownian value changed with it (they were never pinned: torchsde is absent).
 constexpr int kBrownIters = 4;
 constexpr int kBrownTile = kBrownIters * 256;
+// eight waves per workgroup where the expansion is long: a launch that reduces statistics has at most kNPart workgroups (one partial
+// slot each), and with four waves each that left a compute-bound kernel at four waves per SIMD where it has the registers for eight
+// (tree call on cfg5's shard 264 -> 244 us); the bridge route (one term, HBM-bound) keeps four (89 us; 101 with eight)
+constexpr int kBrownBlock = 512;
+constexpr int kBrownLongTerms = 4;
+constexpr uint64_t kBrownStream = 0xB0B000000001ull;  // the base states' stream id (48 bits; node ids no longer are stream ids)
+struct BrownianBurstTerms {
+    uint32_t hx[kMaxBrownianNodes], hc[kMaxBrownianNodes];
+    float coef[kMaxBrownianNodes];
+    int count;
+};
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+// acc[it][j] += c z(node)[4 it + j] for the sub-tile's 16 values of one lane: w = -2 ln2 c^2, NEG = (c < 0)
+template <bool NEG>
+__device__ __forceinline__ void brownian_burst_add(Mwc rng, float w, float (&acc)[kBrownIters][4]) {
+#pragma unroll
+    for (int it = 0; it < kBrownIters; ++it) {
+        const uint32_t ra = rng.next(), rb = rng.next(), t = rng.next();
+        float r0 = __builtin_amdgcn_sqrtf(w * __builtin_amdgcn_logf(2.0f - unit_mantissa(ra)));
+        float r1 = __builtin_amdgcn_sqrtf(w * __builtin_amdgcn_logf(2.0f - unit_mantissa(rb)));
+        if constexpr (NEG) {
+            r0 = -r0;  // (folds into the FMAs as an operand modifier)
+            r1 = -r1;
+        }
+        const float a0 = angle_lo(t), a1 = angle_hi(t);
+        acc[it][0] = __builtin_fmaf(r0, __builtin_amdgcn_cosf(a0), acc[it][0]);
+        acc[it][1] = __builtin_fmaf(r0, __builtin_amdgcn_sinf(a0), acc[it][1]);
+        acc[it][2] = __builtin_fmaf(r1, __builtin_amdgcn_cosf(a1), acc[it][2]);
+        acc[it][3] = __builtin_fmaf(r1, __builtin_amdgcn_sinf(a1), acc[it][3]);
+    }
+}
 // Both kernels: acc = fa base_a + fb base_b + sum_k coef_k z(node_k) (either base may be null); out = scale * (acc - prev) (prev
 // may be null), w_out = acc (may be null) -- ONE path point W(t), differenced against a cached W(t') (sonar_brownian_point_f32 /
 // sonar_brownian_bridge_f32).  No __restrict__ on the inputs: prev is usually one of the bases.
@@ -1840,16 +1889,16 @@ struct BrownianBase {
 // PRE: 0 none, 1 Gaussian draw, 2 Perlin (summed lattice, tile-aligned latents).  With a prefix a wave walks the kBrownPerTile
 // consecutive Brownian tiles of one generator tile, carrying the prefix's generator state across them.
 constexpr int kBrownPerTile = kTileElems / (4 * 256);
-template <int PRE>
-__global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
+template <int PRE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) brownian_burst_kernel(float* out, int64_t n, int64_t elem_offset, BrownianBurstTerms terms,
                                                                 uint64_t seed, const float* prev, float* w_out, float scale,
                                                                 BrownianBase base, Accum fold, double* partials, Prefix pre) {
     kernarg_touch_for(out, n, elem_offset, terms, seed, prev, w_out, scale, base, fold, partials, pre);
-    __shared__ double red[2 * kBlock / 64];
+    __shared__ double red[2 * BLOCK / 64];
     double s = 0.0, q = 0.0;
     const uint32_t lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * BLOCK) >> 6;
     const int64_t first = elem_offset / kBrownTile, tiles = n / kBrownTile;  // both aligned (launcher)
     constexpr int SUB = PRE ? kBrownPerTile : 1;
     const Accum pfold{fold.y, pre.ya, pre.f};
@@ -1882,15 +1931,14 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
                 }
                 acc[it][0] = v.x; acc[it][1] = v.y; acc[it][2] = v.z; acc[it][3] = v.w;
             }
-            for (int k = 0; k < terms.count; ++k) {
-                TileRng rng = rng_stream(seed, terms.node[k], (uint64_t)(first + t), lane);
-                const float c = terms.coef[k];
-#pragma unroll
-                for (int it = 0; it < kBrownIters; ++it) {
-                    float z[4];
-                    rng.normal4(z);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[it][j] = __builtin_fmaf(c, z[j], acc[it][j]);
+            if (terms.count > 0) {
+                const Mwc seedpoint = rng_stream(seed, kBrownStream, (uint64_t)(first + t), lane);
+                for (int k = 0; k < terms.count; ++k) {
+                    const Mwc rng = Mwc::seeded(fmix32(seedpoint.x ^ terms.hx[k]), fmix32(seedpoint.c ^ terms.hc[k]));
+                    const float c = terms.coef[k];
+                    const float w = -1.3862943611198906f * (c * c);
+                    if (c < 0.0f) brownian_burst_add<true>(rng, w, acc);  // (uniform: a kernel argument)
+                    else brownian_burst_add<false>(rng, w, acc);
                 }
             }
 #pragma unroll
@@ -1922,7 +1970,7 @@ __global__ void __launch_bounds__(kBlock) brownian_burst_kernel(float* out, int6
     };
     if constexpr (PRE == 2) with_divider(pdiv, tiles_loop);
     else tiles_loop(pdiv);
-    if (partials) write_partial<kBlock>(s, q, partials, red);  // uniform branch (kernel argument)
+    if (partials) write_partial<BLOCK>(s, q, partials, red);  // uniform branch (kernel argument)
 }
 
 __global__ void __launch_bounds__(kBlock) brownian_kernel(float* out, int64_t n, int64_t elem_offset, BrownianTerms terms,
@@ -2083,10 +2131,17 @@ static int brownian_launch(float* out, float* w_out, const float* prev, float sc
     for (int k = 0; k < nnodes; ++k) SONAR_REQUIRE((node_ids[k] >> 48) == 0, SONAR_ERR_ARG, "%s: node ids are 48-bit", what);
     if (n == 0) return SONAR_OK;
     BrownianTerms t;
-    t.count = nnodes;
+    BrownianBurstTerms bt;
+    t.count = bt.count = nnodes;
     for (int k = 0; k < nnodes; ++k) {
         t.node[k] = node_ids[k];
-        t.coef[k] = coefs[k];
+        t.coef[k] = bt.coef[k] = coefs[k];
+        uint64_t h = node_ids[k] + 0x9E3779B97F4A7C15ull;  // splitmix64 of the node id
+        h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+        h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+        h ^= h >> 31;
+        bt.hx[k] = (uint32_t)h;
+        bt.hc[k] = (uint32_t)(h >> 32);
     }
     auto al = [](const void* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     // the variant is a function of the latent size and the seed kind only, so every shard of a batch picks the same one
@@ -2103,15 +2158,21 @@ static int brownian_launch(float* out, float* w_out, const float* prev, float sc
         SONAR_REQUIRE(burst && acc.y && out == acc.y && (pre->kind != SONAR_PREFIX_PERLIN || pre->chw == latent_elems), SONAR_ERR_UNSUPPORTED,
                       "%s: this shape cannot host a fold prefix (apply it with its own entry point)", what);
     }
+#define SONAR_BBL(P, BL) \
+    hipLaunchKernelGGL((brownian_burst_kernel<P, BL>), dim3(std::min(cap, grid_for(n / (kBrownTile * (P ? kBrownPerTile : 1)), BL / 64))), dim3(BL), 0, \
+                       (hipStream_t)stream, out, n, elem_offset, bt, seed, prev, w_out, scale, base, acc, partials, px)
 #define SONAR_BB(P) \
-    hipLaunchKernelGGL((brownian_burst_kernel<P>), dim3(std::min(cap, grid_for(n / (kBrownTile * (P ? kBrownPerTile : 1)), 4))), dim3(kBlock), 0, \
-                       (hipStream_t)stream, out, n, elem_offset, t, seed, prev, w_out, scale, base, acc, partials, px)
+    do { \
+        if (nnodes >= kBrownLongTerms) SONAR_BBL(P, kBrownBlock); \
+        else SONAR_BBL(P, kBlock); \
+    } while (0)
     if (burst && pre && pre->kind == SONAR_PREFIX_NORMAL)
         SONAR_BB(1);
     else if (burst && pre)
         SONAR_BB(2);
     else if (burst)
         SONAR_BB(0);
+#undef SONAR_BBL
 #undef SONAR_BB
     else
         hipLaunchKernelGGL(brownian_kernel, dim3(std::min(cap, grid_for((n + 6) / 4, kBlock))), dim3(kBlock), 0, (hipStream_t)stream, out, n,

@@ -325,14 +325,10 @@ struct GroupWalk {
 //   half, its junk bits 22..16 being whole turns; v_alignbit for the high half) instead of mask / shift + or.  65536 directions x a
 //   23-bit radius is far below fp32 output resolution after the 8192-term FFT sums.
 constexpr float kNegLn2 = -0.6931471805599453f;
-__device__ __forceinline__ float unit_mantissa(uint32_t hi_bits_in_msb) {  // bits 31..9 -> [1, 2)
-    return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, hi_bits_in_msb, 9));
-}
+// (unit_mantissa, angle_lo, angle_hi: common.h -- the Brownian tile kernel draws its normals the same way since round 6)
 __device__ __forceinline__ float log2_u(uint32_t r) { return __builtin_amdgcn_logf(2.0f - unit_mantissa(r)); }  // log2 u <= 0, u = 2 - m in (0, 1]
 __device__ __forceinline__ float neg_ln_u(uint32_t r) { return kNegLn2 * log2_u(r); }                            // -ln u
 __device__ __forceinline__ float filter_weight(float f) { return kNegLn2 * (f * f); }                            // w <= 0: |z f|^2 = w log2 u
-__device__ __forceinline__ float angle_lo(uint32_t t) { return __uint_as_float(__builtin_amdgcn_bitop3_b32(t, 0x007FFFFFu, 0x43000000u, 0xEA)); }  // (t & mask) | 128.0f
-__device__ __forceinline__ float angle_hi(uint32_t t) { return __uint_as_float(__builtin_amdgcn_alignbit(0x4300u, t, 16)); }
 // |f| z for the weight w = filter_weight(f): the magnitude part (the pipelined kernel keeps its slots' weights in registers)
 __device__ __forceinline__ c32 drawn_weighted(uint32_t r, float angle, float w) {
     const float rho = __builtin_amdgcn_sqrtf(w * log2_u(r));

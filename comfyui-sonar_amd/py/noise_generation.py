@@ -1070,6 +1070,11 @@ class BrownianPath:
         self.tree_depth = int(tree_depth)
         if not 0 <= self.tree_depth <= self.MAX_TREE_DEPTH:
             raise ValueError(f"Brownian noise: tree depth 0 (off) .. {self.MAX_TREE_DEPTH}")
+        # grid times are floats: a cell narrower than a few ulps of the largest time (a narrow range at a large offset, a very deep tree)
+        # would make neighbouring grid points collide -- the tree is only as deep as the range resolves
+        ulp = math.ulp(max(abs(self.t_lo), abs(self.t_hi)))
+        while self.tree_depth > 1 and (self.t_hi - self.t_lo) / (1 << self.tree_depth) < 4.0 * ulp:
+            self.tree_depth -= 1
         self.times = [self.t_lo, self.t_hi]  # sorted; W(lo) = 0, W(hi) ~ N(0, hi - lo)
         self.bridge: dict = {}               # t -> (a, b or None, fa, fb, sd, node)
         # tree mode: the dyadic nodes own the ids 1 .. 2**D - 1; creation numbers (extensions beyond the range) start above them
@@ -1080,6 +1085,11 @@ class BrownianPath:
     def _grid_time(self, g: int) -> float:
         cells = 1 << self.tree_depth
         return self.t_lo if g <= 0 else self.t_hi if g >= cells else self.t_lo + g * ((self.t_hi - self.t_lo) / cells)
+
+    def grid_index(self, t: float) -> int:
+        """Tree mode: the index in [0, 2**D] of the grid point a time inside [t_lo, t_hi] stands for."""
+        cells = 1 << self.tree_depth
+        return min(cells, max(0, int(round((float(t) - self.t_lo) / (self.t_hi - self.t_lo) * cells))))
 
     def resolve(self, t: float) -> float:
         """The time a query of t stands for: t itself, or in tree mode the nearest grid point when t lies inside the range."""
@@ -1222,10 +1232,20 @@ class BrownianTreeNoiseSampler:
             self.seed = int(seed)
         self.elem_offset = current_batch_offset() * (x.numel() // x.shape[0])  # batch shards draw their own global elements
         self._points: dict = {}  # t -> W(t) tensor, least recently used first
+        self._coarse_pts: dict = {}  # tree mode: coarse-grid index -> W tensor, least recently used first
 
     # W(t) tensors kept: a sampler step ends where the next begins and DPM++ SDE asks (t, s) and (t, t') per step, so the two times a
     # new one is bridged between are the previous step's and the interval's end -- ONE fresh normal per element per call
     CACHE_POINTS = 4
+    # Tree mode, round 6: W(t) is evaluated in TWO stages, always -- W at the two ends a, b of the cell of a coarse dyadic grid (2**4 cells)
+    # that holds t, each an fp32 tensor from its own expansion over the tree's top levels (at most five normals), then
+    # W(t) = fa W(a) + fb W(b) + sum over the nodes below that level.  By the bridge construction the top levels' share of W(t) IS that
+    # interpolation, so the value is the expansion's up to rounding -- and because the rule never depends on what happens to be kept, W(t)
+    # is still a function of (seed, t) alone, bit for bit.  What it buys: the coarse tensors are the same for every time in the cell
+    # (a sampler walks through a cell in several steps and into the next one across a shared end), so a call draws D - 4 normals per
+    # element instead of D + 1 (cfg5's shard: 250 -> 205 us per call); a sampler made half way through a run pays the two coarse ends once.
+    TREE_COARSE_LEVEL = 4
+    COARSE_POINTS = 3
 
     def _remember(self, t: float, w: Tensor) -> None:
         self._points.pop(t, None)
@@ -1263,10 +1283,56 @@ class BrownianTreeNoiseSampler:
                                             pre=pre)
         return y, (made if w is None else w)
 
+    def _coarse(self, g: int) -> Optional[Tensor]:
+        """Tree mode: the kept W at index g of the coarse grid (None: W(t_lo) = 0), evaluated from its own expansion when it is not kept."""
+        path = self.path
+        cells = 1 << path.tree_depth
+        if g <= 0:
+            return None
+        if g >= cells:
+            return self._cached(path.t_hi, cheap=True)
+        kept = self._coarse_pts
+        w = kept.pop(g, None)
+        if w is None:
+            terms = path.coefficients(path._grid_time(g))
+            ids = sorted(terms)
+            _, w = hip_lib.brownian_bridge(self.shape, self.device, ids, [terms[k] for k in ids], self.seed, self.elem_offset, self.latent_seeds,
+                                           want_out=False)
+        kept[g] = w
+        while len(kept) > self.COARSE_POINTS:
+            kept.pop(next(iter(kept)))
+        return w
+
+    def _tree_point(self, t: float, *, prev, scale, want_out, fold, partials):
+        """Tree mode's two-stage evaluation of a time inside the range (see TREE_COARSE_LEVEL); None: not applicable (a shallow tree)."""
+        path = self.path
+        shift = path.tree_depth - self.TREE_COARSE_LEVEL
+        if shift < 2 or not path.t_lo < t < path.t_hi:
+            return None
+        g = path.grid_index(t)
+        ga = (g >> shift) << shift
+        terms = path.coefficients(t)
+        if g == ga:  # a point of the coarse grid itself: its expansion only holds top-level nodes
+            return None
+        gb = ga + (1 << shift)
+        ta, tb = path._grid_time(ga), path._grid_time(gb)
+        top = 1 << self.TREE_COARSE_LEVEL  # heap indices below it (and the root's id 0) belong to the coarse grid
+        ids = sorted(k for k in terms if k >= top)
+        wa, wb = self._coarse(ga), self._coarse(gb)
+        fb = (t - ta) / (tb - ta)
+        return self._emit(ids, [terms[k] for k in ids], base_a=wa, fa=1.0 - fb, base_b=wb, fb=fb, prev=prev, scale=scale, want_out=want_out, fold=fold,
+                          partials=partials)
+
     def _point(self, t: float, *, prev: Optional[Tensor] = None, scale: float = 1.0, want_out: bool = True, fold=None, partials=None):
         """(scale * (W(t) - prev) or None, W(t)) for a time that is not kept: the bridge between its two kept neighbours, else its expansion."""
         made = self.path.bridge.get(t)
         out = w = None
+        if self.path.tree_depth and self.CACHE_POINTS > 0:
+            two_stage = self._tree_point(t, prev=prev, scale=scale, want_out=want_out, fold=fold, partials=partials)
+            if two_stage is not None:
+                out, w = two_stage
+                self._remember(t, w)
+                return out, w
         # (tree mode always expands: W(t) is then the same bits whatever happens to be kept, a function of (seed, t) alone)
         if made is not None and self.CACHE_POINTS > 0 and not self.path.tree_depth:
             a, b, fa, fb, sd, node = made
@@ -1297,6 +1363,11 @@ class BrownianTreeNoiseSampler:
         sign = self.sign * (1.0 if t0 <= t1 else -1.0)
         ta, tb = (t0, t1) if t0 <= t1 else (t1, t0)
         ta, tb = self.path.resolve(ta), self.path.resolve(tb)  # (tree mode: the grid points the two times stand for)
+        if ta == tb and t0 != t1:
+            # two distinct times inside one cell of the tree's grid (closer than its tolerance, 6e-8 of the range at depth 24): the path does
+            # not move between them -- torchsde's tree returns W(t1) - W(t0) = 0 there as well
+            out, _ = self._emit([], [], want_w=False, fold=fold, partials=partials)
+            return out
         if self.CACHE_POINTS <= 0 or ta == tb:
             ids, coefs = self.path.increment(t0, t1)
             out, _ = self._emit(ids, [c * sign for c in coefs], want_w=False, fold=fold, partials=partials)

@@ -237,6 +237,22 @@ def test_brownian_tree_mode_is_a_function_of_the_time_alone(pkg):
     import os
     assert ng._env_tree_depth() == (24 if "SONAR_BROWNIAN_TREE" not in os.environ else ng._env_tree_depth())
     assert ng.BROWNIAN_TREE_DEPTH == ng._env_tree_depth()
+    # a malformed or out-of-range value cannot make the package fail to import: the default applies
+    saved = os.environ.get("SONAR_BROWNIAN_TREE")
+    try:
+        for text, want in (("banana", 24), ("99", 24), ("-3", 24), ("16", 16), ("off", 0), ("", 24)):
+            os.environ["SONAR_BROWNIAN_TREE"] = text
+            assert ng._env_tree_depth() == want, text
+    finally:
+        if saved is None:
+            os.environ.pop("SONAR_BROWNIAN_TREE", None)
+        else:
+            os.environ["SONAR_BROWNIAN_TREE"] = saved
+    # grid times are floats: a range too narrow for its offset gets a shallower tree, and its grid points stay distinct
+    narrow = ng.BrownianPath(1.0e6, 1.0e6 + 1e-3, 24)
+    assert 1 <= narrow.tree_depth < 24
+    pts = [narrow._grid_time(g) for g in range((1 << narrow.tree_depth) + 1)]
+    assert all(b > a for a, b in zip(pts, pts[1:]))
 
 
 def test_every_tagged_view_of_a_storage_loses_its_tag(pkg):

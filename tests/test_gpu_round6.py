@@ -108,3 +108,66 @@ def test_a_planned_normalised_fill_runs_its_statistics_a_call_ahead(api, name, s
     finally:
         hl.FILL_AHEAD = old
     assert all(torch.equal(p, q) for p, q in zip(rc, rb))
+
+
+# ------------------------------------------------------------------------------------------------ Brownian noise, round 6
+def test_brownian_node_bursts_are_independent_unit_normals(api):
+    """Round 6 seeds a node's burst by hashing the sub-tile's Philox-drawn base state with the node id (fmix32 of base ^ splitmix64(node))
+    instead of a Philox block per (node, sub-tile, lane), and draws with 23 radius / 16 angle bits.  What a Brownian path needs of them:
+    every node's field is N(0, 1) (moments, a 64-bin chi-square against the normal law, the tail), fields of different nodes -- siblings,
+    parent and child, consecutive ids, ids that differ in one high bit -- are uncorrelated, and so are a field's neighbours at the lags the
+    generator's layout could couple (the next value of a lane, the next lane, the next step, the next sub-tile)."""
+    import math
+
+    hl = api.hl
+    shape = (32, 16, 128, 128)
+    n = math.prod(shape)
+    nodes = [1, 2, 3, 4, 5, 1 << 23, (1 << 23) + 1, (1 << 24) - 1, 12345677, 12345678, (1 << 40) + 7]
+    fields = {k: hl.brownian(shape, "cuda", [k], [1.0], 20240607) for k in nodes}
+    tol = 5.0 / math.sqrt(n)
+    edges = torch.linspace(-4.0, 4.0, 65, device="cuda", dtype=torch.float64)
+    cdf = 0.5 * (1.0 + torch.erf(edges / math.sqrt(2.0)))
+    expect = torch.cat([cdf[:1], cdf[1:] - cdf[:-1], 1.0 - cdf[-1:]]) * n
+    for k, z in fields.items():
+        zd = z.double().flatten()
+        assert abs(zd.mean().item()) < tol and abs(zd.var().item() - 1.0) < 3 * tol, k
+        assert abs((zd**4).mean().item() - 3.0) < 40 * tol and abs((zd**3).mean().item()) < 20 * tol, k
+        counts = torch.bincount(torch.bucketize(zd, edges), minlength=66).double()
+        chi2 = (((counts - expect) ** 2) / expect).sum().item()
+        assert chi2 < 66 + 6 * math.sqrt(2 * 66), (k, chi2)  # 65 degrees of freedom
+        assert 4.0 < zd.abs().max().item() < 5.7  # 23 radius bits: |z| <= sqrt(2 ln 2^23) = 5.65
+        for lag in (1, 2, 4, 256, 1024, 4096, 65536):
+            assert abs((zd[:-lag] * zd[lag:]).mean().item()) < tol, (k, lag)
+        # squares too: a shared radius (the two values of a Box-Muller pair) must not show as correlated magnitudes beyond the pair itself
+        sq = zd * zd - 1.0
+        for lag in (2, 4, 256, 1024):
+            assert abs((sq[:-lag] * sq[lag:]).mean().item()) < 3 * tol, (k, lag)
+    keys = list(fields)
+    for i, a in enumerate(keys):
+        for b in keys[i + 1:]:
+            za, zb = fields[a].double().flatten(), fields[b].double().flatten()
+            assert abs((za * zb).mean().item()) < tol, (a, b)
+            assert abs(((za * za - 1.0) * (zb * zb - 1.0)).mean().item()) < 3 * tol, (a, b)
+    # another seed: another field; the same seed: the same bits; a shard: its part of the batch
+    again = hl.brownian(shape, "cuda", [5], [1.0], 20240607)
+    other = hl.brownian(shape, "cuda", [5], [1.0], 20240608)
+    assert torch.equal(again, fields[5]) and abs((other.double() * fields[5].double()).mean().item()) < tol
+    part = hl.brownian((8, *shape[1:]), "cuda", [5], [1.0], 20240607, elem_offset=8 * math.prod(shape[1:]))
+    assert torch.equal(part, fields[5][8:16])
+
+
+def test_brownian_times_inside_one_tree_cell_give_a_zero_increment(api):
+    """Two distinct sigmas closer than the tree's grid (6e-8 of the range at depth 24) are the same point of the path: the increment is 0, as
+    torchsde's tree with its tolerance returns (it used to raise ValueError); a chain folds it as zeros."""
+    ng = api.ng
+    x = torch.zeros(2, 4, 64, 64, device="cuda")
+    ns = ng.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=3, tree_depth=24)
+    cell = (14.6 - 0.03) / (1 << 24)
+    out = ns(torch.tensor(7.0, dtype=torch.float64), torch.tensor(7.0 + cell / 16, dtype=torch.float64))
+    assert out.shape == x.shape and float(out.abs().max()) == 0.0
+    acc = torch.full_like(x, 2.0)
+    assert ns.accumulate(acc, 0.5, 3.0, None, torch.tensor(7.0, dtype=torch.float64), torch.tensor(7.0 + cell / 16, dtype=torch.float64))
+    assert torch.equal(acc, torch.full_like(x, 1.0))
+    # a narrow range at a large offset cannot resolve 24 levels: the tree is clamped to what float times can tell apart
+    assert ng.BrownianPath(1.0e6, 1.0e6 + 1e-3, 24).tree_depth < 24
+    assert ng.BrownianPath(0.03, 14.6, 24).tree_depth == 24
