@@ -57,4 +57,5 @@ void lds_attr(const void* kern, int bytes) {
 }  // namespace sonar
 
 extern "C" int sonar_abi_version(void) { return 1; }
+extern "C" int sonar_noise_stream_version(void) { return 6; }
 extern "C" const char* sonar_last_error(void) { return sonar::g_err; }

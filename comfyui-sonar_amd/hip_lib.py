@@ -67,6 +67,7 @@ _PF = C.POINTER(C.c_float)
 # name -> (restype, argtypes); must list every symbol declared in include/sonar_hip.h
 SIGNATURES = {
     "sonar_abi_version": (_I, []),
+    "sonar_noise_stream_version": (_I, []),
     "sonar_last_error": (C.c_char_p, []),
     "sonar_stats_f32": (_I, [_P, _I64, _P, _P]),
     "sonar_stats_finalize": (_I, [_P, _I64, _I64, _P, _P]),
@@ -1640,7 +1641,7 @@ FILL_AHEAD = os.environ.get("SONAR_FILL_AHEAD", "1") != "0"  # plans run a norma
 PERLIN_AHEAD = os.environ.get("SONAR_PERLIN_AHEAD", "1") != "0"  # plans fuse a normalised Perlin call's three launches (_PerlinAheadHook)
 NOT_RUN = object()      # Plan.run: the step was not issued (a guard changed, an entry point refused): take the ordinary path
 _M64 = 2**64 - 1
-_HOST_QUERIES = frozenset(("sonar_abi_version", "sonar_last_error", "sonar_power_noise_ahead_ok", "sonar_perlin_noise_ahead_ok", "sonar_philox_noise_ahead_ok", "sonar_power_pipeline", "sonar_wcfg_hi_storage", "sonar_power_plane_kind", "sonar_dwt_out_len",
+_HOST_QUERIES = frozenset(("sonar_abi_version", "sonar_noise_stream_version", "sonar_last_error", "sonar_power_noise_ahead_ok", "sonar_perlin_noise_ahead_ok", "sonar_philox_noise_ahead_ok", "sonar_power_pipeline", "sonar_wcfg_hi_storage", "sonar_power_plane_kind", "sonar_dwt_out_len",
                            "sonar_dwt2_ws_bytes", "sonar_wcfg_lowpass_lds_bytes", "sonar_wcfg_fused_ws_bytes", "sonar_pyramid_levels",
                            "sonar_plan_fn_id", "sonar_plan_fn_nargs"))
 PATCH_SLOT, PATCH_STREAM, PATCH_SEED, PATCH_BLOB, PATCH_LEVELS = range(5)

@@ -50,6 +50,14 @@ extern "C" {
 
 int sonar_abi_version(void);
 const char* sonar_last_error(void);
+/* Version of the GENERATE-mode value streams (device draws, cpu = False): the number changes whenever a seed gives other values than the
+ * build before did -- saved seeds and workflows that use device draws are reproducible only within one version.  Replay mode (the
+ * reference's host-generator draws handed in, cpu = True: the parity mode) is not versioned, its values are the reference's.
+ *   3: round 3 (xoshiro128 bursts seeded by Philox4x32-10 at three depths)
+ *   5: round 5 (MWC64X bursts; power-law spectra: filter weight under the radius' square root, 23 radius / 16 angle bits)
+ *   6: round 6 (Brownian noise only: node bursts seeded by hashing a per-sub-tile Philox state with the node id, the power-law draw's
+ *      conversions; every other generator's values are version 5's) */
+int sonar_noise_stream_version(void);
 
 /* ---------------------------------------------------------------- normalisation (row N) */
 /* py/utils.py:100 — whole-tensor mean/std inputs: writes SONAR_NPART fp64 (sum,sumsq) pairs */

@@ -27,6 +27,7 @@ def test_library_builds_and_exports_every_header_symbol(pkg):
         assert hasattr(lib, name), f"{name} declared in include/sonar_hip.h but not exported"
     assert set(syms) == set(pkg.hip_lib.SIGNATURES), "ctypes table and header disagree"
     assert lib.sonar_abi_version() == 1
+    assert lib.sonar_noise_stream_version() == 6  # generate-mode values: changes with every seed break (include/sonar_hip.h lists them)
     assert lib.sonar_last_error() is not None
 
 

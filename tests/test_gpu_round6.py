@@ -171,3 +171,49 @@ def test_brownian_times_inside_one_tree_cell_give_a_zero_increment(api):
     # a narrow range at a large offset cannot resolve 24 levels: the tree is clamped to what float times can tell apart
     assert ng.BrownianPath(1.0e6, 1.0e6 + 1e-3, 24).tree_depth < 24
     assert ng.BrownianPath(0.03, 14.6, 24).tree_depth == 24
+
+
+def test_power_spectrum_angle_and_radius_are_independent_at_1e8_draws(api):
+    """The power-law draw takes 16 angle bits per value (two values per angle word) and 23 radius bits.  Over 10^8 drawn
+    spectrum values: a 64 x 32 chi-square of (angle, radius^2 quantile) against independence with uniform margins, the angle's own 4096-bin
+    histogram (65 536 directions: sixteen per bin), lag correlations of the angle itself (next column, next row, next plane, the
+    partner row that shares the angle word), and the discreteness of the directions -- a measured choice, not an assumed one."""
+    import math
+
+    hl = api.hl
+    tot = 0
+    joint = torch.zeros(64 * 32, dtype=torch.float64, device="cuda")
+    fine = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    lag_sums = {name: 0.0 for name in ("column", "row", "plane", "partner")}
+    lag_counts = dict.fromkeys(lag_sums, 0)
+    for call in range(13):  # 13 x 256 latents x 4 planes x 128 x 63 interior values = 1.07e8
+        z = hl.power_spectrum((256, 4, 128, 128), "cuda", seed=777, stream_id=10 + 3 * call)[..., 1:64]  # the interior columns (edge columns: own stream)
+        re, im = z.real.double(), z.imag.double()
+        # direction in revolutions, [0, 1): the drawn directions are multiples of 2^-16, and v_sin / v_cos leave them ~1e-3 of such a step
+        # off -- half a step is added so that a direction never sits on a bin edge
+        rev = (torch.atan2(im, re) / (2 * math.pi) + 0.5 / 65536) % 1.0
+        q = 1.0 - torch.exp(-(re * re + im * im))                 # radius^2 ~ Exp(1): its CDF value is uniform
+        a_bin = (rev * 64).long().clamp_(0, 63)
+        r_bin = (q * 32).long().clamp_(0, 31)
+        joint += torch.bincount((a_bin * 32 + r_bin).flatten(), minlength=64 * 32).double()
+        fine += torch.bincount((rev * 4096).long().clamp_(0, 4095).flatten(), minlength=4096).double()
+        tot += rev.numel()
+        c = torch.cos(2 * math.pi * rev)                          # (a circular statistic: mean zero, variance 1/2)
+        half = c.shape[-2] // 2
+        for name, a, b in (("column", c[..., :-1], c[..., 1:]), ("row", c[..., :-1, :], c[..., 1:, :]), ("plane", c[:, :-1], c[:, 1:]),
+                           ("partner", c[..., :half, :], c[..., half:, :])):
+            lag_sums[name] += float((a * b).sum())
+            lag_counts[name] += a.numel()
+        # every direction is a multiple of 2^-16 revolutions (sampled: the rounding of atan2 in fp64 leaves ~1e-12)
+        sample = rev.flatten()[:: 4099][:200000] * 65536.0 - 0.5
+        assert float((sample - sample.round()).abs().max()) < 0.05
+    assert tot >= 10**8
+    expect = tot / (64 * 32)
+    chi2 = float((((joint - expect) ** 2) / expect).sum())
+    dof = 64 * 32 - 1
+    assert abs(chi2 - dof) < 6 * math.sqrt(2 * dof), chi2
+    exp_fine = tot / 4096
+    chi2f = float((((fine - exp_fine) ** 2) / exp_fine).sum())
+    assert abs(chi2f - 4095) < 6 * math.sqrt(2 * 4095), chi2f
+    for name, total in lag_sums.items():
+        assert abs(total / lag_counts[name]) < 5 * 0.5 / math.sqrt(lag_counts[name]), (name, total / lag_counts[name])
