@@ -19,7 +19,10 @@
 
 namespace sonar {
 
-constexpr int kLowThreads = 512;   // 8 waves per plane: the phases are short and latency-bound, more waves hide more of it
+#ifndef SONAR_LOW_THREADS
+#define SONAR_LOW_THREADS 512
+#endif
+constexpr int kLowThreads = SONAR_LOW_THREADS;   // 8 waves per plane: the phases are short and latency-bound, more waves hide more of it
 constexpr int kLowRows = 16;       // output rows per level-1 analysis tile / final synthesis tile
 constexpr int kLowMaxLevels = 8;
 
@@ -92,7 +95,7 @@ __device__ __forceinline__ void synth_low_pair(int m, int n, int mode, const T* 
 // ZERO: zero padding on the way down -- the only extension whose tables hold "no source" entries; the other modes' taps carry no clamp
 // and no select
 template <typename T, int FT, bool ZERO>
-__global__ void __launch_bounds__(kLowThreads) wcfg_lowpass_kernel(const float* __restrict__ cond, const float* __restrict__ uncond,
+__global__ void __launch_bounds__(kLowThreads, (kLowThreads > 512 ? 8 : 1)) wcfg_lowpass_kernel(const float* __restrict__ cond, const float* __restrict__ uncond,
                                                                     const float* __restrict__ xin, float* __restrict__ out, LowArgs<T> a) {
     kernarg_touch_for(cond, uncond, xin, out, a);
     auto at0 = [](int s) { return ZERO ? max(s, 0) : s; };
