@@ -151,8 +151,8 @@ def host_and_event_us(fn, steps=200, warmup=100, burst=25, tag=None):
         done += n
     if tag is not None:
         BURSTS[tag] = {"bursts": len(hosts), "calls_per_burst": burst,
-                       "host_us": {"min": min(hosts), "median": statistics.median(hosts), "max": max(hosts)},
-                       "gpu_us": {"min": min(gpus), "median": statistics.median(gpus), "max": max(gpus)}}
+                       "host_us": {"min": min(hosts), "median": statistics.median(hosts), "mean": statistics.fmean(hosts), "max": max(hosts)},
+                       "gpu_us": {"min": min(gpus), "median": statistics.median(gpus), "mean": statistics.fmean(gpus), "max": max(gpus)}}
     return statistics.median(hosts), statistics.median(gpus)
 
 
@@ -222,6 +222,13 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
             real = (4 if name == "perlin" else 12) * N_LATENT * b  # Perlin is written once; pyramid generates, then scales in place
             kernels.append(kernel_entry(f"{name} normalised generate, batch {b}", us, real, tr.get(f"{name}_{tag}", {}).get("hbm_bytes_per_launch"),
                                         "4N real (12N contract)" if name == "perlin" else "12N real = contract"))
+    # rows G1 / G2 normalised at the north_star batch: the fill look-ahead of round 6 (a plan runs the next call's statistics pass in the
+    # storing waves; N(0,1) with factor 1 keeps its one-pass route at this size)
+    for name in ("uniform", "gaussian"):
+        ns = nz.get_noise_sampler(name, x, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+        us = event_us(lambda: ns(*sig))
+        extra[f"{name}_b512_latents_per_s"] = BATCH / (us * 1e-6)
+        kernels.append(kernel_entry(f"{name} normalised generate, batch {BATCH}", us, 4 * N_LATENT * BATCH, None, "4N real (12N contract): one write"))
     # cfg3 as a chain: Perlin + pyramid items of one CustomNoiseChain, normalised (the Perlin item is evaluated inside the pyramid
     # kernel: lattice + ONE generating launch + the normalisation pass)
     for tag, xb in (("b512", x), ("b64", x64)):
@@ -713,6 +720,14 @@ def main():
         with ng.shard_offset(rank * 128):
             try:
                 mine["cfg5_step_ms"] = cfg5_shard_step_ms(device, hl, pn, nz, sonar_mod)
+                # the same step on the path of bridges: the difference is what the seed-determined Brownian tree costs on this rank
+                depth0 = ng.BROWNIAN_TREE_DEPTH
+                try:
+                    ng.BROWNIAN_TREE_DEPTH = 0
+                    mine["cfg5_step_brownian_bridges_ms"] = cfg5_shard_step_ms(device, hl, pn, nz, sonar_mod)
+                finally:
+                    ng.BROWNIAN_TREE_DEPTH = depth0
+                mine["brownian_tree_depth"] = depth0
             except Exception as exc:  # secondary figure only
                 mine["cfg5_error"] = repr(exc)[:200]
         with ng.shard_offset(rank * 64):
@@ -727,7 +742,9 @@ def main():
                 vals = [r[key] for r in per_rank if key in r]
                 return {"max": max(vals), "min": min(vals), "ranks": len(vals)} if vals else None
 
-            out["extra"] = {"per_rank": per_rank, "cfg5_shard_step_ms": spread("cfg5_step_ms"), "cfg3_chain_b64_us": spread("cfg3_chain_b64_us")}
+            out["extra"] = {"per_rank": per_rank, "cfg5_shard_step_ms": spread("cfg5_step_ms"),
+                            "cfg5_shard_step_brownian_bridges_ms": spread("cfg5_step_brownian_bridges_ms"),
+                            "cfg3_chain_b64_us": spread("cfg3_chain_b64_us")}
             ms = out["extra"]["cfg5_shard_step_ms"]
             if ms:  # the job's rate: every rank steps its 128-latent shard, the slowest sets the pace
                 out["extra"]["cfg5_latent_steps_per_s"] = 128 * n_gpus / (ms["max"] * 1e-3)

@@ -1247,25 +1247,91 @@ struct LatticeJob {
 };
 static constexpr LatticeJob kNoLattice{nullptr, 0, 0, 0, 0, 0, 0};
 
-template <bool STATS, bool XROWS, int PRE = 0, bool NT = false /* common.h store4: launch-bound sizes */>
-__global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
-                                                               uint64_t seed, uint64_t stream_id, int64_t elem_offset,
-                                                               double* partials, int grid_floats, Accum fold, Prefix pre, LatticeJob lat) {
-    kernarg_touch_for(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, grid_floats, fold, pre, lat);
+// AHEAD (round 6, sonar_pyramid_noise_ahead_f32): a normalised call inside a prepared plan as ONE launch.  Workgroups [0, ah.main_blocks)
+// run THIS call's planes and store them normalised -- the statistics were left by the previous call's launch -- with scale_noise_kernel's own
+// operation sequence (ExactNorm: the same bits as the in-place pass); the workgroups behind them run the NEXT call's planes (its level
+// table `ah.lv`, its stream ids) without storing anything and leave that call's (sum, sumsq) partials, workgroup by workgroup what its own
+// generating launch would leave.  At the launch-bound sizes the two kinds sit side by side on the chip (one plane workgroup per CU before).
+struct PyrAhead {
+    NormArgs na;
+    int npart;                      // partial pairs of THIS call's statistics (the workgroups of the launch that left them)
+    PyramidLevels lv;               // the next call's level table, stream id and grid size
+    unsigned long long stream_id;
+    int grid_floats;
+    int main_blocks;
+    double* partials;               // the next call's statistics
+};
+// the decision as scale_noise_kernel's 256-thread blocks take it (same strides, same reduction order: same bits), inside a larger block
+template <int SUB, int BLOCK>
+__device__ __forceinline__ NormDecision decide_norm_as(const double* __restrict__ partials, int64_t npart, int64_t n_total, float thr_sd, double* red,
+                                                       NormDecision* sh) {
+    static_assert(BLOCK >= SUB && SUB % 64 == 0, "the first SUB threads of the block");
+    constexpr int NW = SUB / 64;
+    double s = 0.0, q = 0.0;
+    if ((int)threadIdx.x < SUB)
+        for (int64_t i = threadIdx.x; i < npart; i += SUB) {
+            s += partials[2 * i];
+            q += partials[2 * i + 1];
+        }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0 && wid < NW) {
+        red[wid] = s;
+        red[NW + wid] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            ss += red[i];
+            qq += red[NW + i];
+        }
+        *sh = decision_from_totals(ss, qq, n_total, thr_sd);
+    }
+    __syncthreads();
+    return *sh;
+}
+// scale_noise_kernel's value sequence -- subtract, IEEE quotient, multiply -- with the quotient by the correctly rounded reciprocal and one
+// residual step (elementwise.hip, PendingNorm: the same bits as `v / std` for every v in the normal range)
+struct ExactNorm {
+    float mean, stdv, inv_std, factor;
+    bool sub, div, mul;
+    __device__ __forceinline__ ExactNorm(const NormDecision& d, float f)
+        : mean(d.mean), stdv(d.stdv), inv_std(1.0f / d.stdv), factor(f), sub(d.do_sub != 0), div(d.do_div != 0), mul(f != 1.0f) {}
+    __device__ __forceinline__ float operator()(float v) const {
+        if (sub) v = v - mean;
+        if (div) {
+            const float q = v * inv_std;
+            v = __builtin_fmaf(__builtin_fmaf(-stdv, q, v), inv_std, q);
+        }
+        if (mul) v = v * factor;
+        return v;
+    }
+};
+
+// ROLE: 0 an ordinary launch; the look-ahead launch's workgroups: 1 this call's planes (normalised stores, no statistics), 2 the next call's
+// planes (statistics into ah.partials, no stores).  The body is instantiated per role and handed ITS level table by reference -- the kernel
+// arguments stay in scalar registers (selecting between the two tables at run time put a copy in scratch memory: 2 x slower).
+template <bool STATS, bool XROWS, int PRE, bool NT, int ROLE>
+__device__ __forceinline__ void pyramid_plane_body(float* out, int64_t planes, int H, int W, const PyramidLevels& lv, int mode, uint64_t seed,
+                                                   uint64_t stream_id, int64_t elem_offset, double* partials, int grid_floats, const Accum& fold,
+                                                   const Prefix& pre, const PyrAhead& ah, const int bid, const int nblocks) {
+    static_assert(ROLE == 0 || (XROWS && !STATS && PRE == 0), "the look-ahead form is the stretched-rows kernel of a single generator");
     extern __shared__ __align__(16) float pyr_lds[];
     __shared__ double red[2 * kPyrBlock / 64];
+    __shared__ NormDecision sh_dec;
     // the levels' parameters where a thread can index them by a run-time level (kernel arguments live in scalar registers: per-level
     // loops over them are sixteen short dependent loops; flattened over (level, item) a thread has four independent items in flight)
     __shared__ int lvl_h[kMaxLevels], lvl_w[kMaxLevels], lvl_off[kMaxLevels + 1], lvl_item0[kMaxLevels + 1], lvl_row0[kMaxLevels];
     __shared__ float lvl_weight[kMaxLevels];
     __shared__ unsigned long long lvl_stream[kMaxLevels];
-    if ((int)blockIdx.x < lat.blocks) {
-        perlin_lattice_cells<kPyrBlock>(lat.out, lat.iters, lat.C, H, W, lat.blend_mode, lat.seed, lat.stream_id, blockIdx.x, lat.blocks);
-        return;
-    }
-    const int bid = (int)blockIdx.x - lat.blocks, nblocks = (int)gridDim.x - lat.blocks;  // this workgroup among those that own planes
     SONAR_NG_STAMP(0);
     double s = 0.0, q = 0.0;
+    NormDecision dec{0.f, 1.f, 0, 0};
+    if constexpr (ROLE == 1) dec = decide_norm_as<kBlock, kPyrBlock>(ah.na.partials, ah.npart, ah.na.n_total, ah.na.thr_sd, red, &sh_dec);
+    const ExactNorm enorm(dec, ROLE == 1 ? ah.na.factor : 1.0f);
     const int HW = H * W;
     const uint32_t lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1502,13 +1568,13 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                     // (trace build of round 5), chain at batch 64 26.1 -> 25.2 us.  At batch 512 (four waves per SIMD cover the load) the
                     // same form is 3 % SLOWER (120 registers, eight copies of the step), and so is a request one step ahead in the rolled
                     // loop (+5 %): there a step loads its own.
-                    constexpr bool AHEAD = PRE == 2 && NT;
+                    constexpr bool LAT_AHEAD = PRE == 2 && NT;
                     auto lattice = [&](int ei) {
                         return PRE == 2 && (WHOLE || (ei >= 0 && ei < HW)) ? *reinterpret_cast<const float4*>(tplane + ei) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     };
-                    constexpr int NTV = AHEAD ? kIters : 1;
+                    constexpr int NTV = LAT_AHEAD ? kIters : 1;
                     float4 tva[NTV];
-                    if constexpr (AHEAD) {
+                    if constexpr (LAT_AHEAD) {
 #pragma unroll
                         for (int i = 0; i < kIters; ++i) tva[i] = lattice(e + 256 * i);
                     }
@@ -1516,7 +1582,7 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                     for (int it0 = 0; it0 < kIters; it0 += G) {
                         float4 tvs[G];
 #pragma unroll
-                        for (int j = 0; j < G; ++j) tvs[j] = AHEAD ? tva[AHEAD ? it0 + j : 0] : lattice(e + 256 * j);
+                        for (int j = 0; j < G; ++j) tvs[j] = LAT_AHEAD ? tva[LAT_AHEAD ? it0 + j : 0] : lattice(e + 256 * j);
                         float v[G][4], px[G][4];
                         int ee[G], yy[G], xx[G];
 #pragma unroll
@@ -1575,9 +1641,12 @@ __global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, in
                                 const float4 yv = *reinterpret_cast<const float4*>(fold.y + p * (int64_t)HW + ej);
                                 vv[j] = sonar_v4f{fold(yv.x, vv[j].x), fold(yv.y, vv[j].y), fold(yv.z, vv[j].z), fold(yv.w, vv[j].w)};
                             }
-                            if constexpr (NT) __builtin_nontemporal_store(vv[j], reinterpret_cast<sonar_v4f*>(oplane + ej));
-                            else *reinterpret_cast<sonar_v4f*>(oplane + ej) = vv[j];
-                            if constexpr (STATS) {
+                            if constexpr (ROLE == 1) vv[j] = sonar_v4f{enorm(vv[j].x), enorm(vv[j].y), enorm(vv[j].z), enorm(vv[j].w)};
+                            if constexpr (ROLE != 2) {
+                                if constexpr (NT) __builtin_nontemporal_store(vv[j], reinterpret_cast<sonar_v4f*>(oplane + ej));
+                                else *reinterpret_cast<sonar_v4f*>(oplane + ej) = vv[j];
+                            }
+                            if constexpr (STATS || ROLE == 2) {
                                 float s01 = vv[j].x + vv[j].y;
                                 asm volatile("" : "+v"(s01));  // (two scalar adds: paired into one packed add they cost three moves)
                                 const float ps = s01 + (vv[j].z + vv[j].w);
@@ -1672,7 +1741,31 @@ SONAR_PYR_UNROLL
 #endif
 #endif
     if constexpr (STATS) write_partial_at<kPyrBlock>(s, q, partials, red, bid, nblocks);
+    if constexpr (ROLE == 2) write_partial_at<kPyrBlock>(s, q, ah.partials, red, bid, nblocks);
     SONAR_NG_STAMP(9);
+}
+
+template <bool STATS, bool XROWS, int PRE = 0, bool NT = false /* common.h store4: launch-bound sizes */, bool AHEAD = false>
+__global__ void __launch_bounds__(kPyrBlock) pyramid_plane_kernel(float* out, int64_t planes, int H, int W, PyramidLevels lv, int mode,
+                                                               uint64_t seed, uint64_t stream_id, int64_t elem_offset,
+                                                               double* partials, int grid_floats, Accum fold, Prefix pre, LatticeJob lat,
+                                                               PyrAhead ah) {
+    kernarg_touch_for(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, grid_floats, fold, pre, lat, ah);
+    if ((int)blockIdx.x < lat.blocks) {
+        perlin_lattice_cells<kPyrBlock>(lat.out, lat.iters, lat.C, H, W, lat.blend_mode, lat.seed, lat.stream_id, blockIdx.x, lat.blocks);
+        return;
+    }
+    const int bid = (int)blockIdx.x - lat.blocks;  // this workgroup among those that own planes
+    if constexpr (!AHEAD) {
+        pyramid_plane_body<STATS, XROWS, PRE, NT, 0>(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, partials, grid_floats, fold, pre, ah, bid,
+                                                     (int)gridDim.x - lat.blocks);
+    } else if (bid < ah.main_blocks) {  // (workgroup-uniform)
+        pyramid_plane_body<false, true, 0, NT, 1>(out, planes, H, W, lv, mode, seed, stream_id, elem_offset, nullptr, grid_floats, fold, pre, ah, bid,
+                                                  ah.main_blocks);
+    } else {
+        pyramid_plane_body<false, true, 0, NT, 2>(out, planes, H, W, ah.lv, mode, seed, ah.stream_id, elem_offset, nullptr, ah.grid_floats, fold, pre, ah,
+                                                  bid - ah.main_blocks, (int)gridDim.x - lat.blocks - ah.main_blocks);
+    }
 }
 
 // true if the plane kernel was launched; *slots (optional): the number of partial pairs its workgroups own (the rest are zeroed)
@@ -1696,7 +1789,7 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
     const bool nt = nt_stores_host(planes * H * W);
 #define SONAR_PPN(ST, XR, P, N) \
     hipLaunchKernelGGL((pyramid_plane_kernel<ST, XR, P, N>), dim3(g + lat.blocks), dim3(kPyrBlock), XR ? lds_x : lds, st, out, planes, (int)H, (int)W, lv, mode, \
-                       seed, stream_id, elem_offset, partials, (int)grid_floats, fold, pre, lat)
+                       seed, stream_id, elem_offset, partials, (int)grid_floats, fold, pre, lat, PyrAhead{})
 #define SONAR_PP(ST, XR, P) \
     do { \
         if (nt) SONAR_PPN(ST, XR, P, true); else SONAR_PPN(ST, XR, P, false); \
@@ -1715,6 +1808,48 @@ static bool launch_pyramid_plane(float* out, int64_t planes, int64_t H, int64_t 
 #undef SONAR_PPK
 #undef SONAR_PP
 #undef SONAR_PPN
+    return true;
+}
+
+// LDS of the stretched-rows form for one level table; 0: the form does not take it
+static size_t pyramid_xrows_lds(const PyramidLevels& lv, int64_t H, int64_t W, int* grid_floats) {
+    size_t gf = 0, rows = 0;
+    for (int l = 0; l < lv.count; ++l) {
+        gf += (size_t)lv.h[l] * lv.w[l];
+        rows += (size_t)lv.h[l];
+    }
+    gf = (gf + 3) & ~(size_t)3;
+    *grid_floats = (int)gf;
+    const size_t lds = gf * sizeof(float) + (size_t)lv.count * (H + W) * sizeof(Lin) + rows * W * sizeof(float);
+    return lds <= kPyramidLdsBudget ? lds : 0;
+}
+// The look-ahead launch: `now` planes of this call (null: none -- the statistics of `next` alone, for a call that found none left), `next`
+// the call whose statistics go to partials_next.  false: a level table is beyond the stretched-rows form (nothing launched).
+static bool launch_pyramid_ahead(float* out, int64_t planes, int64_t H, int64_t W, const PyramidLevels* now, uint64_t stream_now,
+                                 const PyramidLevels& next, uint64_t stream_next, uint64_t seed, int64_t elem_offset, NormArgs na, int npart,
+                                 double* partials_next, hipStream_t st) {
+    int gf_now = 0, gf_next = 0;
+    const size_t lds_now = now ? pyramid_xrows_lds(*now, H, W, &gf_now) : 1, lds_next = pyramid_xrows_lds(next, H, W, &gf_next);
+    if (W % 4 != 0 || elem_offset % (H * W) != 0 || !lds_now || !lds_next) return false;
+    static const int grid_cap = [] { const char* e = getenv("SONAR_PYR_GRID"); return e ? atoi(e) : kNPart; }();
+    const int g = (int)std::min<int64_t>(planes, std::min(grid_cap, kNPart));  // launch_pyramid_plane's grid: the partials' grouping
+    PyrAhead ah{};
+    ah.na = na;
+    ah.npart = npart;
+    ah.lv = next;
+    ah.stream_id = stream_next;
+    ah.grid_floats = gf_next;
+    ah.main_blocks = now ? g : 0;
+    ah.partials = partials_next;
+    const PyramidLevels& first = now ? *now : next;
+    const size_t lds = std::max(now ? lds_now : 0, lds_next);
+    const Prefix nopre{1.0f, 1.0f, 1.0f, 0, 0, nullptr, 1, 0};
+    if (nt_stores_host(planes * H * W))
+        hipLaunchKernelGGL((pyramid_plane_kernel<false, true, 0, true, true>), dim3(ah.main_blocks + g), dim3(kPyrBlock), lds, st, out, planes, (int)H, (int)W, first,
+                           0, seed, stream_now, elem_offset, (double*)nullptr, gf_now, kNoAccum, nopre, kNoLattice, ah);
+    else
+        hipLaunchKernelGGL((pyramid_plane_kernel<false, true, 0, false, true>), dim3(ah.main_blocks + g), dim3(kPyrBlock), lds, st, out, planes, (int)H, (int)W, first,
+                           0, seed, stream_now, elem_offset, (double*)nullptr, gf_now, kNoAccum, nopre, kNoLattice, ah);
     return true;
 }
 
@@ -2538,6 +2673,43 @@ extern "C" int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, in
     hipLaunchKernelGGL((pyramid_generate_kernel<2, false>), dim3(g), dim3(kBlock), 0, (hipStream_t)stream, out, planes, (int)H,
                        (int)W, lv, mode, seed, stream_id, elem_offset, nullptr, na);
     return check_launch("sonar_pyramid_noise_f32");
+}
+
+extern "C" int sonar_pyramid_noise_ahead_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels, const int64_t* level_h,
+                                             const int64_t* level_w, const float* level_weight, int mode, uint64_t seed, uint64_t stream_id,
+                                             int64_t elem_offset, float factor, float threshold_std_devs, double* partials, int have_stats,
+                                             uint64_t next_stream_id, int64_t next_nlevels, const int64_t* next_level_h,
+                                             const int64_t* next_level_w, const float* next_level_weight, double* partials_next, void* stream) {
+    const char* what = "sonar_pyramid_noise_ahead_f32";
+    int rc = pyramid_common(what, out, planes, H, W, mode, elem_offset);
+    if (rc != SONAR_OK) return rc;
+    SONAR_REQUIRE(partials && partials_next && partials != partials_next, SONAR_ERR_ARG, "%s: two statistics workspaces required", what);
+    SONAR_REQUIRE(mode == 0 && nlevels <= kMaxLevels && next_nlevels <= kMaxLevels, SONAR_ERR_UNSUPPORTED,
+                  "%s: bilinear levels drawn in the kernel only (sonar_pyramid_noise_f32 takes the rest)", what);
+    const float* none[kMaxLevels] = {};
+    PyramidLevels now, next;
+    bool drawn = false;
+    rc = fill_levels(now, H, W, nlevels, none, level_h, level_w, level_weight, stream_id, &drawn, what);
+    if (rc != SONAR_OK) return rc;
+    rc = fill_levels(next, H, W, next_nlevels, none, next_level_h, next_level_w, next_level_weight, next_stream_id, &drawn, what);
+    if (rc != SONAR_OK) return rc;
+    if (planes == 0) return SONAR_OK;
+    int gf = 0;
+    SONAR_REQUIRE(W % 4 == 0 && pyramid_xrows_lds(now, H, W, &gf) && pyramid_xrows_lds(next, H, W, &gf), SONAR_ERR_UNSUPPORTED,
+                  "%s: a level table is beyond the plane kernel's stretched-rows form (nothing was launched)", what);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = planes * H * W;
+    static const int grid_cap = [] { const char* e = getenv("SONAR_PYR_GRID"); return e ? atoi(e) : kNPart; }();
+    const int slots = (int)std::min<int64_t>(planes, std::min(grid_cap, kNPart));
+    if (!have_stats) {
+        // nobody left this call's statistics: its planes once without stores (the same partials the ordinary generating launch leaves)
+        SONAR_REQUIRE(launch_pyramid_ahead(out, planes, H, W, nullptr, stream_id, now, stream_id, seed, elem_offset, NormArgs{}, 0, partials, st),
+                      SONAR_ERR_UNSUPPORTED, "%s: shape not taken", what);
+    }
+    SONAR_REQUIRE(launch_pyramid_ahead(out, planes, H, W, &now, stream_id, next, next_stream_id, seed, elem_offset,
+                                       NormArgs{partials, n, factor, threshold_std_devs}, slots, partials_next, st),
+                  SONAR_ERR_UNSUPPORTED, "%s: shape not taken", what);
+    return check_launch(what);
 }
 
 #ifdef SONAR_NG_TRACE

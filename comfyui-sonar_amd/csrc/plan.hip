@@ -85,6 +85,7 @@ const Replayable kReplayable[] = {
     SONAR_REPLAYABLE(sonar_pyramid_generate_acc_f32),
     SONAR_REPLAYABLE(sonar_pyramid_generate_acc_ahead_f32),
     SONAR_REPLAYABLE(sonar_pyramid_noise_f32),
+    SONAR_REPLAYABLE(sonar_pyramid_noise_ahead_f32),
     SONAR_REPLAYABLE(sonar_power_noise_f32),
     SONAR_REPLAYABLE(sonar_power_block_f32),
     SONAR_REPLAYABLE(sonar_power_noise_ahead_f32),

@@ -113,6 +113,8 @@ SIGNATURES = {
     "sonar_resample_acc_f32": (_I, [_P, _P, _I64, _I64, _I64, _I64, _I64, _F, _I, _I, _P, _P]),
     "sonar_pyramid_generate_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _P, _P]),
     "sonar_pyramid_noise_f32": (_I, [_P, _I64, _I64, _I64, _I64, C.POINTER(_P), _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _F, _F, _P, _P]),
+    "sonar_pyramid_noise_ahead_f32": (_I, [_P, _I64, _I64, _I64, _I64, _PI64, _PI64, _PF, _I, _U64, _U64, _I64, _F, _F, _P, _I, _U64, _I64, _PI64, _PI64, _PF, _P,
+                                           _P]),
     "sonar_levels_sampled_f32": (_I, [_P, _I64, _I64, _I64, _I, _PI64, _PI64, _PF, _PF, _I, _U64, _U64, _I64, _I, _P]),
     "sonar_level_normal_f32": (_I, [_P, _I64, _I64, _I64, _F, _U64, _U64, _I64, _P]),
     "sonar_power_noise_f32": (_I, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I, _F, _F, _P, _P]),
@@ -1638,6 +1640,7 @@ PLANS_ENABLED = os.environ.get("SONAR_PLANS", "1") != "0"
 PLAN_WARM_CALLS = 2     # ordinary calls before a step is traced (first-call setup, look-ahead misses)
 PLAN_MAX_ATTEMPTS = 3   # traces that may fail (a call that took a fallback route) before the step stays on the ordinary path
 FILL_AHEAD = os.environ.get("SONAR_FILL_AHEAD", "1") != "0"  # plans run a normalised uniform / Gaussian fill's statistics a call ahead (_FillAheadHook)
+PYRAMID_AHEAD = os.environ.get("SONAR_PYRAMID_AHEAD", "1") != "0"  # plans run a normalised pyramid call's statistics a call ahead, one launch per call
 PERLIN_AHEAD = os.environ.get("SONAR_PERLIN_AHEAD", "1") != "0"  # plans fuse a normalised Perlin call's three launches (_PerlinAheadHook)
 NOT_RUN = object()      # Plan.run: the step was not issued (a guard changed, an entry point refused): take the ordinary path
 _M64 = 2**64 - 1
@@ -1979,6 +1982,48 @@ def _peephole_fill_ahead(records, b, rec):
                 rec.hooks.append(hook)
                 continue
         out.append((name, words, blob, patches))
+    return out
+
+
+def _peephole_pyramid_ahead(records, b, rec):
+    """A [sonar_pyramid_noise_f32] record of a traced step whose levels are all drawn in the kernel (a level rule: PATCH_LEVELS) with the
+    bilinear mode becomes a sonar_pyramid_noise_ahead_f32 record: a second level rule -- the next call's, its stream ids ``rec.count``
+    further on -- joins the blob, a ``_FillAheadHook`` supplies the two statistics buffers."""
+    out = []
+    for k, (name, words, blob, patches) in enumerate(records):
+        done = False
+        if name == "sonar_pyramid_noise_f32" and blob:
+            pt = {p.target: p for p in patches}
+            lev = pt.get(4)
+            if (lev is not None and lev.source == PATCH_LEVELS and all(t in pt for t in (0, 6, 7, 8, 10, 11, 15)) and pt[10].source == PATCH_SEED
+                    and pt[11].source == PATCH_STREAM and all(pt[t].source == PATCH_BLOB for t in (6, 7, 8)) and int(words[9]) == 0):
+                rule = PlanLevels.from_buffer_copy(bytes(blob[lev.index:lev.index + C.sizeof(PlanLevels)]))
+                n = max(int(rule.iterations), 1)
+                blob2 = bytearray(blob)
+                h_off = _blob_reserve(blob2, 8 * n, bytes(8 * n))
+                w_off = _blob_reserve(blob2, 8 * n, bytes(8 * n))
+                wt_off = _blob_reserve(blob2, 4 * n, bytes(4 * n))
+                rule_off = _blob_reserve(blob2, C.sizeof(PlanLevels),
+                                         bytes(PlanLevels(rule.H, rule.W, rule.discount, rule.iterations, 0, h_off, w_off, wt_off)))
+                tag = f"pyr{k}_"
+                hook = _FillAheadHook(tag, int(pt[11].addend), rec.count, next(iter(b.temp_ranges))[2].device)
+                slots = {}
+                for key in hook.KEYS:
+                    slots[key] = b.slot_of[("hook", tag + key)] = len(b.slots)
+                    b.slots.append(None)
+                w2 = [0, words[1], words[2], words[3], 0, 0, 0, 0, words[9], 0, 0, words[12], words[13], words[14], 0, 0, 0, 0, 0, 0, 0, 0, 0]
+                p2 = [PlanPatch(PATCH_SLOT, 0, pt[0].index, 8, pt[0].addend), PlanPatch(PATCH_LEVELS, 4, lev.index, 8, lev.addend),
+                      PlanPatch(PATCH_BLOB, 5, 0, 8, pt[6].addend), PlanPatch(PATCH_BLOB, 6, 0, 8, pt[7].addend), PlanPatch(PATCH_BLOB, 7, 0, 8, pt[8].addend),
+                      PlanPatch(PATCH_SEED, 9, 0, 8, 0), PlanPatch(PATCH_STREAM, 10, 0, 8, pt[11].addend),
+                      PlanPatch(PATCH_SLOT, 14, slots["p_now"], 8, 0), PlanPatch(PATCH_SLOT, 15, slots["have"], 8, 0),
+                      PlanPatch(PATCH_STREAM, 16, 0, 8, pt[11].addend + rec.count), PlanPatch(PATCH_LEVELS, 17, rule_off, 8, lev.addend + rec.count),
+                      PlanPatch(PATCH_BLOB, 18, 0, 8, h_off), PlanPatch(PATCH_BLOB, 19, 0, 8, w_off), PlanPatch(PATCH_BLOB, 20, 0, 8, wt_off),
+                      PlanPatch(PATCH_SLOT, 21, slots["p_next"], 8, 0)]
+                out.append(("sonar_pyramid_noise_ahead_f32", w2, bytes(blob2), p2))
+                rec.hooks.append(hook)
+                done = True
+        if not done:
+            out.append((name, words, blob, patches))
     return out
 
 
@@ -2400,6 +2445,8 @@ def _build_plan(rec: _Recorder, result, take, rewind, guards) -> Plan:
         records = _peephole_lattice_ahead(_peephole_perlin_ahead(records, b, rec), b, rec)
     if FILL_AHEAD:
         records = _peephole_fill_ahead(records, b, rec)
+    if PYRAMID_AHEAD:
+        records = _peephole_pyramid_ahead(records, b, rec)
     # what the result owns must be fresh per call: the tensors handed back and the statistics partials tagged onto them
     owned = {}  # id(temp) -> index in the fresh list
 

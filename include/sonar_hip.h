@@ -405,6 +405,18 @@ int sonar_pyramid_noise_f32(float* out, int64_t planes, int64_t H, int64_t W, in
                             const float* const* level_ptrs, const int64_t* level_h, const int64_t* level_w,
                             const float* level_weight, int mode, uint64_t seed, uint64_t stream_id, int64_t elem_offset,
                             float factor, float threshold_std_devs, double* partials, void* stream);
+/* The same call (every level drawn in the kernel, bilinear: the generate-mode call of PyramidNoiseGenerator) in a sampler's steady state,
+ * for prepared plans (round 6): ONE launch.  Half of its workgroups run this call's planes and store them normalised -- with the
+ * statistics in `partials` (left there by the previous call's launch when `have_stats`; else a launch of this call's planes without
+ * stores computes them first) and scale_noise's own operation sequence: the output bits are sonar_pyramid_noise_f32's -- the other half
+ * run the planes of the call that will draw with `next_stream_id` and the `next_*` level table without storing anything and leave its
+ * (sum, sumsq) partials in `partials_next`, the ones its own generating launch would leave.  SONAR_ERR_UNSUPPORTED (nothing launched) when
+ * a level table is beyond the plane kernel's stretched-rows form. */
+int sonar_pyramid_noise_ahead_f32(float* out, int64_t planes, int64_t H, int64_t W, int64_t nlevels, const int64_t* level_h,
+                                  const int64_t* level_w, const float* level_weight, int mode, uint64_t seed, uint64_t stream_id,
+                                  int64_t elem_offset, float factor, float threshold_std_devs, double* partials, int have_stats,
+                                  uint64_t next_stream_id, int64_t next_nlevels, const int64_t* next_level_h, const int64_t* next_level_w,
+                                  const float* next_level_weight, double* partials_next, void* stream);
 
 /* Levels that are drawn only to be shrunk, with on-device draws: PyramidOld (py/noise_generation.py:567-606: noise = sum_i discount^i *
  * F.interpolate(normal(std = 0.5^i) at (2^(i+1) H) x (2^(i+1) W), size = (H, W), mode)) and HighresPyramid (:517-564: levels of up to 15 x

@@ -217,3 +217,83 @@ def test_power_spectrum_angle_and_radius_are_independent_at_1e8_draws(api):
     assert abs(chi2f - 4095) < 6 * math.sqrt(2 * 4095), chi2f
     for name, total in lag_sums.items():
         assert abs(total / lag_counts[name]) < 5 * 0.5 / math.sqrt(lag_counts[name]), (name, total / lag_counts[name])
+
+
+# ------------------------------------------------------------------------------------------------ pyramid look-ahead
+@pytest.mark.parametrize("shape", [(1, 4, 128, 128), (64, 4, 128, 128), (3, 4, 104, 152), (2, 4, 3, 64, 64), (300, 4, 64, 64)])
+def test_a_planned_normalised_pyramid_call_is_one_launch(api, shape):
+    """Inside a plan a normalised pyramid call (py/noise_generation.py:609-649 + py/utils.py:85-106) is ONE launch in the steady state
+    (sonar_pyramid_noise_ahead_f32: this call's planes stored normalised, the next call's planes evaluated for their statistics only): the
+    same bits as the generating launch + the in-place scale_noise pass, whatever the hook finds -- a reseed and a foreign draw cost
+    shortcuts, not values -- and the same bits with the look-ahead switched off."""
+    hl, nz = api.hl, api.nz
+    x = torch.zeros(shape, device="cuda")
+    make = lambda: nz.get_noise_sampler("pyramid", x, 0.03, 14.6, seed=None, cpu=False, normalized=True)  # noqa: E731
+
+    def script(ns, plans):
+        old = hl.PLANS_ENABLED
+        hl.PLANS_ENABLED = plans
+        try:
+            torch.manual_seed(41)
+            got = []
+            for i in range(16):
+                if i == 9:
+                    torch.manual_seed(42)
+                if i == 12:
+                    torch.randn(5, device="cuda")
+                got.append(ns(*SIG).clone())
+            return got
+        finally:
+            hl.PLANS_ENABLED = old
+
+    a, b = make(), make()
+    ra, rb = script(a, True), script(b, False)
+    assert all(torch.equal(p, q) for p, q in zip(ra, rb)), [i for i, (p, q) in enumerate(zip(ra, rb)) if not torch.equal(p, q)]
+    planned = a if isinstance(a, hl.Planned) else getattr(a, "_planned", None)
+    plan = planned.plan
+    assert plan is not None, getattr(planned, "reason", None)
+    assert hl.load().sonar_plan_length(plan.handle) == 1
+    hooks = [h for h in plan.hooks if isinstance(h, hl._FillAheadHook)]
+    assert len(hooks) == 1 and hooks[0].hits >= 5 and hooks[0].misses >= 2, (hooks[0].hits, hooks[0].misses)
+    old = hl.PYRAMID_AHEAD
+    hl.PYRAMID_AHEAD = False
+    try:
+        rc = script(make(), True)
+    finally:
+        hl.PYRAMID_AHEAD = old
+    assert all(torch.equal(p, q) for p, q in zip(rc, rb))
+
+
+def test_pyramid_ahead_entry_point_is_the_two_launches(api):
+    """The entry point itself against sonar_pyramid_noise_f32: with and without statistics left by an earlier launch, and the partials it
+    leaves for the next call against the ones that call's own generating launch writes."""
+    import ctypes as C
+
+    hl = api.hl
+    lib = hl.load()
+    st = hl._stream()
+    shape, planes, h, w = (6, 4, 128, 128), 24, 128, 128
+    lv0, lv1 = hl.AutoLevels(h, w, 10, 0.7, 9, 50), hl.AutoLevels(h, w, 10, 0.7, 9, 57)
+    want0 = hl.pyramid_noise(shape, "cuda", lv0, "bilinear", 9, 50, 0, 0.9)
+    want1 = hl.pyramid_noise(shape, "cuda", lv1, "bilinear", 9, 57, 0, 0.9)
+    assert want0 is not None and want1 is not None
+    own = hl.new_partials("cuda")
+    assert hl.pyramid_generate(shape, "cuda", lv1, "bilinear", 9, 57, 0, partials=own) is not None  # call 57's own statistics
+
+    def tables(lv):
+        n = len(lv)
+        return (n, (C.c_int64 * n)(*[v[1] for v in lv]), (C.c_int64 * n)(*[v[2] for v in lv]), (C.c_float * n)(*[v[3] for v in lv]))
+
+    t0, t1 = tables(lv0), tables(lv1)
+    p0, p1, p2 = hl.new_partials("cuda"), hl.new_partials("cuda"), hl.new_partials("cuda")
+    out0, out1 = torch.empty(shape, device="cuda"), torch.empty(shape, device="cuda")
+    rc = lib.sonar_pyramid_noise_ahead_f32(out0.data_ptr(), planes, h, w, *t0, 0, 9, 50, 0, 0.9, 2.5, p0.data_ptr(), 0, 57, *t1, p1.data_ptr(), st)
+    assert rc == 0, hl.load().sonar_last_error()
+    assert torch.equal(out0, want0)
+    g = min(planes, 1024)
+    assert torch.equal(p1[:2 * g], own[:2 * g]) and float(p1[2 * g:].abs().max()) == 0.0
+    rc = lib.sonar_pyramid_noise_ahead_f32(out1.data_ptr(), planes, h, w, *t1, 0, 9, 57, 0, 0.9, 2.5, p1.data_ptr(), 1, 64, *t0, p2.data_ptr(), st)
+    assert rc == 0 and torch.equal(out1, want1)
+    # refusals: one workspace for both calls' statistics; a resampling mode the look-ahead form does not take
+    assert lib.sonar_pyramid_noise_ahead_f32(out1.data_ptr(), planes, h, w, *t1, 0, 9, 57, 0, 0.9, 2.5, p1.data_ptr(), 1, 64, *t0, p1.data_ptr(), st) == hl.ERR_ARG
+    assert lib.sonar_pyramid_noise_ahead_f32(out1.data_ptr(), planes, h, w, *t1, 1, 9, 57, 0, 0.9, 2.5, p1.data_ptr(), 1, 64, *t0, p2.data_ptr(), st) == hl.ERR_UNSUPPORTED
