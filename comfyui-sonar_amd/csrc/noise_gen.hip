@@ -152,19 +152,117 @@ struct Affine {
     __device__ __forceinline__ float operator()(float u) const { return active ? (u - sub) * mul + add : u; }
 };
 
+// the affine map and the normalisation with their run-time switches decided ONCE per launch (template flags): inside the tile loop every
+// switch was a v_cndmask per value, and the range checks of a shard's ragged ends a branch per group -- 220 instructions per step of
+// eight values where the arithmetic needs 90 (the launch was instruction-bound: 33 us against the 24 us of its stores)
+template <bool ACTIVE>
+struct AffineT {
+    float sub, mul, add;
+    __device__ __forceinline__ float operator()(float u) const {
+        if constexpr (ACTIVE) return (u - sub) * mul + add;
+        else return u;
+    }
+};
+template <bool SUB, bool SCALE>
+struct NormT {
+    float mean, inv_std, factor;
+    __device__ __forceinline__ float operator()(float v) const {
+        if constexpr (SUB) v = v - mean;
+        if constexpr (SCALE) v = v * inv_std * factor;
+        return v;
+    }
+};
+template <typename F>
+__device__ __forceinline__ void with_affine_norm(const Affine& aff, const NormFast& nf, F&& f) {
+    auto with_norm = [&](auto a) {
+        if (nf.do_sub) {
+            if (nf.do_scale) f(a, NormT<true, true>{nf.mean, nf.inv_std, nf.factor});
+            else f(a, NormT<true, false>{nf.mean, nf.inv_std, nf.factor});
+        } else {
+            if (nf.do_scale) f(a, NormT<false, true>{nf.mean, nf.inv_std, nf.factor});
+            else f(a, NormT<false, false>{nf.mean, nf.inv_std, nf.factor});
+        }
+    };
+    if (aff.active) with_norm(AffineT<true>{aff.sub, aff.mul, aff.add});
+    else with_norm(AffineT<false>{aff.sub, aff.mul, aff.add});
+}
+
+// scale_noise_kernel's own sequence (subtract, IEEE division; factor 1): what the one-pass N(0,1) route applies when a threshold fails
+template <bool SUB, bool DIV>
+struct NormExactT {
+    float mean, stdv;
+    __device__ __forceinline__ float operator()(float v) const {
+        if constexpr (SUB) v = v - mean;
+        if constexpr (DIV) v = v / stdv;
+        return v;
+    }
+};
+template <typename F>
+__device__ __forceinline__ void with_exact_norm(const NormDecision& d, F&& f) {
+    if (d.do_sub) {
+        if (d.do_div) f(NormExactT<true, true>{d.mean, d.stdv});
+        else f(NormExactT<true, false>{d.mean, d.stdv});
+    } else {
+        if (d.do_div) f(NormExactT<false, true>{d.mean, d.stdv});
+        else f(NormExactT<false, false>{d.mean, d.stdv});
+    }
+}
+template <typename F>
+__device__ __forceinline__ void with_norm_flags(const NormFast& nf, F&& f) {
+    if (nf.do_sub) {
+        if (nf.do_scale) f(NormT<true, true>{nf.mean, nf.inv_std, nf.factor});
+        else f(NormT<true, false>{nf.mean, nf.inv_std, nf.factor});
+    } else {
+        if (nf.do_scale) f(NormT<false, true>{nf.mean, nf.inv_std, nf.factor});
+        else f(NormT<false, false>{nf.mean, nf.inv_std, nf.factor});
+    }
+}
+
 // VEC: out 16-B aligned and elem_offset % 4 == 0 -> dwordx4 stores
-template <Dist D, bool VEC, bool STATS>
+// WHOLE (round 6): whole tiles only, a plain store (no running sum to fold into): no range checks, the affine map's switch decided once per
+// launch (store_group's checks and the switch were a branch and a select per group: the fill of 134 MB was ~10 % instruction-bound).  The
+// same values, the same per-thread sums in the same order.
+template <Dist D, bool VEC, bool STATS, bool WHOLE = false>
 __global__ void __launch_bounds__(kBlock) stream_fill_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
                                                              int64_t elem_offset, Affine aff, double* partials, Accum acc) {
     kernarg_touch_for(out, n, seed, stream_id, elem_offset, aff, partials, acc);
     __shared__ double red[2 * kBlock / 64];
     double s = 0.0, q = 0.0;
-    for_each_group<D>(n, seed, stream_id, elem_offset, [&](int64_t e, float (&v)[4]) {
+    if constexpr (WHOLE) {
+        const uint32_t lane = threadIdx.x & 63;
+        const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+        const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+        const int64_t first = elem_offset / kTileElems, last = (elem_offset + n - 1) / kTileElems;
+        auto tiles = [&](auto af) {
+            for (int64_t tile = first + wave; tile <= last; tile += nwaves) {
+                TileRng rng = rng_stream(seed, stream_id, (uint64_t)tile, lane);
+                float* const o = out + (tile * kTileElems + (int64_t)lane * 4 - elem_offset);
+#pragma unroll 4
+                for (int it = 0; it < kTileIters; ++it) {
+                    float v[4];
+                    if constexpr (D == Dist::Normal) rng.normal4(v); else rng.uniform4(v);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = aff(v[k]);
-        accumulate_group<VEC>(acc, n, e, v);
-        store_group<VEC>(out, n, e, v, s, q, STATS);
-    });
+                    for (int k = 0; k < 4; ++k) v[k] = af(v[k]);
+                    *reinterpret_cast<float4*>(o + it * 256) = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (STATS) {
+                        const float ps = (v[0] + v[1]) + (v[2] + v[3]);
+                        const float pq = __builtin_fmaf(v[0], v[0], __builtin_fmaf(v[1], v[1], __builtin_fmaf(v[2], v[2], v[3] * v[3])));
+                        s += (double)ps;
+                        q += (double)pq;
+                    }
+                }
+            }
+        };
+        if (aff.active) tiles(AffineT<true>{aff.sub, aff.mul, aff.add});
+        else tiles(AffineT<false>{aff.sub, aff.mul, aff.add});
+    } else {
+        for_each_group<D>(n, seed, stream_id, elem_offset, [&](int64_t e, float (&v)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = aff(v[k]);
+            accumulate_group<VEC>(acc, n, e, v);
+            store_group<VEC>(out, n, e, v, s, q, STATS);
+        });
+    }
     if constexpr (STATS) write_partial<kBlock>(s, q, partials, red);
 }
 
@@ -179,6 +277,11 @@ static int launch_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
     if (n == 0) return SONAR_OK;
     const bool vec = aligned16(out) && aligned16(acc.y) && (elem_offset & 3) == 0;
     const int g = tile_grid(n, elem_offset);
+    if (vec && !acc.y && n % kTileElems == 0 && elem_offset % kTileElems == 0) {
+        if (partials) hipLaunchKernelGGL((stream_fill_kernel<D, true, true, true>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials, acc);
+        else hipLaunchKernelGGL((stream_fill_kernel<D, true, false, true>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials, acc);
+        return check_launch(what);
+    }
 #define SONAR_FILL(A, S) \
     hipLaunchKernelGGL((stream_fill_kernel<D, A, S>), dim3(g), dim3(kBlock), 0, st, out, n, seed, stream_id, elem_offset, aff, partials, acc)
     if (vec) {
@@ -321,72 +424,6 @@ static int launch_fill_norm(float* out, int64_t n, uint64_t seed, uint64_t strea
 // work (15 us as a launch of its own).  A wave draws the next call's tile right behind this call's -- its statistics arithmetic issues
 // while the stores of the step before are in flight.  Same grid, same tile -> wave -> step order, same per-thread sums and block
 // reduction as stream_fill_norm_kernel<D, VEC, 1>: the partials left for the next call are the bits its own statistics pass would write.
-// the affine map and the normalisation with their run-time switches decided ONCE per launch (template flags): inside the tile loop every
-// switch was a v_cndmask per value, and the range checks of a shard's ragged ends a branch per group -- 220 instructions per step of
-// eight values where the arithmetic needs 90 (the launch was instruction-bound: 33 us against the 24 us of its stores)
-template <bool ACTIVE>
-struct AffineT {
-    float sub, mul, add;
-    __device__ __forceinline__ float operator()(float u) const {
-        if constexpr (ACTIVE) return (u - sub) * mul + add;
-        else return u;
-    }
-};
-template <bool SUB, bool SCALE>
-struct NormT {
-    float mean, inv_std, factor;
-    __device__ __forceinline__ float operator()(float v) const {
-        if constexpr (SUB) v = v - mean;
-        if constexpr (SCALE) v = v * inv_std * factor;
-        return v;
-    }
-};
-template <typename F>
-__device__ __forceinline__ void with_affine_norm(const Affine& aff, const NormFast& nf, F&& f) {
-    auto with_norm = [&](auto a) {
-        if (nf.do_sub) {
-            if (nf.do_scale) f(a, NormT<true, true>{nf.mean, nf.inv_std, nf.factor});
-            else f(a, NormT<true, false>{nf.mean, nf.inv_std, nf.factor});
-        } else {
-            if (nf.do_scale) f(a, NormT<false, true>{nf.mean, nf.inv_std, nf.factor});
-            else f(a, NormT<false, false>{nf.mean, nf.inv_std, nf.factor});
-        }
-    };
-    if (aff.active) with_norm(AffineT<true>{aff.sub, aff.mul, aff.add});
-    else with_norm(AffineT<false>{aff.sub, aff.mul, aff.add});
-}
-
-// scale_noise_kernel's own sequence (subtract, IEEE division; factor 1): what the one-pass N(0,1) route applies when a threshold fails
-template <bool SUB, bool DIV>
-struct NormExactT {
-    float mean, stdv;
-    __device__ __forceinline__ float operator()(float v) const {
-        if constexpr (SUB) v = v - mean;
-        if constexpr (DIV) v = v / stdv;
-        return v;
-    }
-};
-template <typename F>
-__device__ __forceinline__ void with_exact_norm(const NormDecision& d, F&& f) {
-    if (d.do_sub) {
-        if (d.do_div) f(NormExactT<true, true>{d.mean, d.stdv});
-        else f(NormExactT<true, false>{d.mean, d.stdv});
-    } else {
-        if (d.do_div) f(NormExactT<false, true>{d.mean, d.stdv});
-        else f(NormExactT<false, false>{d.mean, d.stdv});
-    }
-}
-template <typename F>
-__device__ __forceinline__ void with_norm_flags(const NormFast& nf, F&& f) {
-    if (nf.do_sub) {
-        if (nf.do_scale) f(NormT<true, true>{nf.mean, nf.inv_std, nf.factor});
-        else f(NormT<true, false>{nf.mean, nf.inv_std, nf.factor});
-    } else {
-        if (nf.do_scale) f(NormT<false, true>{nf.mean, nf.inv_std, nf.factor});
-        else f(NormT<false, false>{nf.mean, nf.inv_std, nf.factor});
-    }
-}
-
 // ALIGNED: whole tiles only (n and elem_offset multiples of kTileElems, 16-byte aligned output): no range checks at all
 // EXACT: N(0,1) with factor 1, whose ordinary route stores the raw draws and leaves the (rare) correction to scale_noise_kernel
 template <Dist D, bool VEC, bool ALIGNED, bool EXACT = false>

@@ -70,4 +70,17 @@ for k in range(REPS): bt(torch.tensor(sg[k]), torch.tensor(sg[k + 1]))
 acc = torch.randn_like(xf)
 for k in range(REPS, 2 * REPS): bt.accumulate(acc, 0.5, 0.2, hl.new_partials(dev), torch.tensor(sg[k]), torch.tensor(sg[k + 1]))
 torch.cuda.synchronize()
+# round 6: the look-ahead forms a prepared plan runs in a sampler's steady state (one launch per call): normalised uniform fill, Perlin
+# (fused: final pass + the next call's statistics in the same waves), pyramid (this call's planes + the next call's statistics), and the
+# Brownian tree call (two-stage evaluation over the coarse grid, ~20 node bursts per element)
+hl.PLANS_ENABLED = True
+for name, xb in (("uniform", x), ("perlin", x), ("pyramid", x), ("pyramid", x64)):
+    s = nz.get_noise_sampler(name, xb, 0.03, 14.6, seed=None, cpu=False, normalized=True)
+    for _ in range(REPS + 6): s(*sig)   # warm calls, the traced call, then replays
+    torch.cuda.synchronize()
+hl.PLANS_ENABLED = False
+bt = ng.BrownianTreeNoiseSampler(xf, 0.03, 14.6, seed=7, tree_depth=24)
+sg = torch.linspace(14.6, 1.0, 2 * REPS + 3).tolist()
+for k in range(2 * REPS): bt(torch.tensor(sg[k]), torch.tensor(sg[k + 1]))
+torch.cuda.synchronize()
 print("workload done")

@@ -92,7 +92,28 @@ def main(path):
         out[f"wcfg_single_launch_bands_{tag}_b256"] = dict(one, algorithmic_bytes_16N=4 * 256 * N, ratio_to_16N=round(one["hbm_bytes_per_launch"] / (4 * 256 * N), 2),
                                                            note="sonar_wcfg_bands_*: every coefficient band resident in LDS, one launch per difference-only rule "
                                                                 "(two for cond / uncond rules; bytes per launch here); fp64's default stays the tile route -- see DESIGN.md 7")
-    br = pick(raw, "brownian_burst_kernel<0>")
+    # round 6: the look-ahead forms of the plans (one launch per call in a sampler's steady state) and the Brownian tree call; optional rows
+    # (a table made from an older workload has none of them)
+    def maybe(*frags, exclude=()):
+        hits = {k: v for k, v in raw.items() if all(f in k for f in frags) and not any(e in k for e in exclude)}
+        return next(iter(hits.values())) if len(hits) == 1 else None
+
+    fa = maybe("stream_fill_ahead_kernel")
+    if fa:
+        out["uniform_ahead_b512"] = dict(fa, algorithmic_bytes_4N=512 * N, note="normalised uniform fill inside a plan: this call's final pass + the next call's statistics pass (no stores) in one launch")
+    pa = maybe("perlin_ahead_kernel")
+    if pa:
+        out["perlin_ahead_b512"] = dict(pa, algorithmic_bytes_4N=512 * N, note="normalised Perlin call inside a plan (fused form): final pass + next call's statistics in the same waves + a later call's lattice")
+    pya = maybe("pyramid_plane_kernel<false, true, 0, false, true>")
+    if pya:
+        out["pyramid_ahead_b512"] = dict(pya, algorithmic_bytes_4N=512 * N, note="normalised pyramid call inside a plan: this call's planes stored normalised + the next call's planes for their statistics (no stores); the two-launch form moves 12N")
+    pya64 = maybe("pyramid_plane_kernel<false, true, 0, true, true>")
+    if pya64:
+        out["pyramid_ahead_b64"] = dict(pya64, algorithmic_bytes_4N=64 * N)
+    bt = maybe("brownian_burst_kernel<0, 512>")
+    if bt:
+        out["brownian_tree_cfg5_shard"] = dict(bt, tensor_bytes=128 * 16 * 128 * 128 * 4, note="tree mode, two-stage evaluation: reads the two coarse-grid tensors and the kept previous point, writes W(t) and the increment; ~20 node bursts per element (compute-bound)")
+    br = pick(raw, "brownian_burst_kernel<0, 256>")
     out["brownian_bridge_cfg5_shard"] = dict(br, tensor_bytes=128 * 16 * 128 * 128 * 4,
                                              note="128 x 16 x 128 x 128: reads the kept neighbour tensor(s), writes W(t) and the increment (or reads and "
                                                   "writes the chain's running sum): 3-4 tensors per call")
