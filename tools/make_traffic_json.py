@@ -50,8 +50,8 @@ def main(path):
                           "note": "lattice + statistics pass (no stores) + final pass; the workload ran batch 512 and batch 64 equally often, bytes split in proportion to the batch"}
     out["perlin_b64"] = {"hbm_bytes_per_launch": int(both * 64 / 576), "algorithmic_bytes_4N": 64 * N, "contract_bytes_12N": 3 * 64 * N}
     # round 4: the plane kernel is a different instantiation at batch 512 and batch 64 (non-temporal stores up to 32 MiB): no split by batch
-    pyr512 = pick(raw, "pyramid_plane_kernel<true, true, 0, false>")["hbm_bytes_per_launch"]
-    pyr64 = pick(raw, "pyramid_plane_kernel<true, true, 0, true>")["hbm_bytes_per_launch"]
+    pyr512 = pick(raw, "pyramid_plane_kernel<true, true, 0, false, false>")["hbm_bytes_per_launch"]
+    pyr64 = pick(raw, "pyramid_plane_kernel<true, true, 0, true, false>")["hbm_bytes_per_launch"]
     out["pyramid_b512"] = {"hbm_bytes_per_launch": int(pyr512) + 2 * 512 * N,
                            "kernels": {"pyramid_plane_kernel": int(pyr512), "scale_noise_kernel (in place, read + write)": 2 * 512 * N},
                            "algorithmic_bytes_12N": 3 * 512 * N,
@@ -106,7 +106,7 @@ def main(path):
         out["perlin_ahead_b512"] = dict(pa, algorithmic_bytes_4N=512 * N, note="normalised Perlin call inside a plan (fused form): final pass + next call's statistics in the same waves + a later call's lattice")
     pya = maybe("pyramid_plane_kernel<false, true, 0, false, true>")
     if pya:
-        out["pyramid_ahead_b512"] = dict(pya, algorithmic_bytes_4N=512 * N, note="normalised pyramid call inside a plan: this call's planes stored normalised + the next call's planes for their statistics (no stores); the two-launch form moves 12N")
+        out["pyramid_ahead_b512"] = dict(pya, algorithmic_bytes_4N=512 * N, note="normalised pyramid call inside a plan: this call's planes stored normalised + the next call's planes for their statistics (no stores); the two-launch form moves 12N; the average includes the store-less launches a call without statistics left for it runs first")
     pya64 = maybe("pyramid_plane_kernel<false, true, 0, true, true>")
     if pya64:
         out["pyramid_ahead_b64"] = dict(pya64, algorithmic_bytes_4N=64 * N)
