@@ -603,6 +603,13 @@ class PyramidNoiseGenerator(FramesToChannelsNoiseGenerator):
             out = run(self._auto_levels(h, w, seed, stream))
             if out is not None:
                 return out
+        # From here on the level grids are tensors whose SIZES this call computed on the host from (seed, stream): a prepared plan that
+        # recorded these launches would replay one call's sizes for every later call (round 6: scratch/fuzz_plans_r6.py found exactly that
+        # on widths that are not multiples of four -- replayed values that were not the ordinary path's).  A trace that comes through here
+        # yields no plan; the step stays on the ordinary path.
+        rec = hip_lib._recorder
+        if rec is not None and rec.thread == threading.get_ident():
+            rec.fail("pyramid level grids with sizes computed per call on the host (a shape the plane kernel does not take)")
         plan = list(self._plan(h, w, _level_ratios(seed, stream)))  # shared by all ranks
         levels = []
         for i, ch, cw in plan:
