@@ -1101,9 +1101,18 @@ class BrownianPath:
     def resolve(self, t: float) -> float:
         """The time a query of t stands for: t itself, or in tree mode the nearest grid point when t lies inside the range."""
         t = float(t)
-        if not self.tree_depth or not self.t_lo < t < self.t_hi:
+        if not self.tree_depth:
             return t
         cells = 1 << self.tree_depth
+        if not self.t_lo < t < self.t_hi:
+            # within half a grid cell beyond an end: the end itself (a sigma_max handed over as a float32 tensor and queried as a float64
+            # one differs in the eighth digit; without the snap that query is an extension beyond the range -- a history-dependent point)
+            half = 0.5 * (self.t_hi - self.t_lo) / cells
+            if self.t_lo - half < t <= self.t_lo:
+                return self.t_lo
+            if self.t_hi <= t < self.t_hi + half:
+                return self.t_hi
+            return t
         return self._grid_time(int(round((t - self.t_lo) / (self.t_hi - self.t_lo) * cells)))
 
     def _define_dyadic(self, t: float) -> None:
