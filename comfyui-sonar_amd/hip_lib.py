@@ -228,6 +228,7 @@ def _check(rc: int, what: str) -> None:
         raise SonarHipError(f"{what} failed (code {rc}): {msg}")
 
 
+_CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device  # (a replayed step has used the device already: no lazy init to check)
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # ~1 us; torch.cuda.current_stream() builds a Stream object (~10 us)
 _last_device = -1  # device index of the tensor most recently checked by _dev (arguments are evaluated before _stream())
 
@@ -1826,7 +1827,9 @@ class _PerlinAheadHook(PlanHook):
             _it, c, h, w, _bl = self.lattice
             state = self.by_stream[st] = {"terms": [torch.empty((1, c, h, w), dtype=torch.float32, device=self.device) for _ in range(3)],
                                           "parts": [new_partials(self.device) for _ in range(2)], "ready_terms": {}, "ready_parts": {}}
-        terms, parts = state["terms"], state["parts"]
+            state["tptr"] = [t.data_ptr() for t in state["terms"]]  # (the addresses never change: one foreign call each, once)
+            state["pptr"] = [t.data_ptr() for t in state["parts"]]
+        terms, tptr, pptr = state["terms"], state["tptr"], state["pptr"]
         l_now, s_now = (base + self.la) & _M64, (base + self.sa) & _M64
         l_next, s_next, l_next2 = (l_now + self.count) & _M64, (s_now + self.count) & _M64, (l_now + 2 * self.count) & _M64
         ti = state["ready_terms"].get((seed, l_now))
@@ -1849,15 +1852,15 @@ class _PerlinAheadHook(PlanHook):
         if not have:
             pi = 0
         pn = 1 - pi
-        to = next(i for i in range(3) if i != ti and i != tn)
+        to = 3 - ti - tn  # the third of the buffers 0, 1, 2
         target = l_next2
         sl = self.slot
-        table[sl["t_now"]] = terms[ti].data_ptr()
-        table[sl["p_now"]] = parts[pi].data_ptr()
+        table[sl["t_now"]] = tptr[ti]
+        table[sl["p_now"]] = pptr[pi]
         table[sl["have"]] = int(have)
-        table[sl["t_next"]] = terms[tn].data_ptr()
-        table[sl["p_next"]] = parts[pn].data_ptr()
-        table[sl["t_out"]] = terms[to].data_ptr()
+        table[sl["t_next"]] = tptr[tn]
+        table[sl["p_next"]] = pptr[pn]
+        table[sl["t_out"]] = tptr[to]
         table[sl["l_out"]] = target
         self.now = (state, {(seed, target): to, (seed, l_next): tn}, {(seed, s_next): pn})
         # the launch overwrites a lattice buffer and a statistics buffer: until post_run says what they hold, nothing is "ready" -- a run
@@ -2302,7 +2305,7 @@ class Plan:
         for getter, want in self.guards:
             if getter() != want:
                 return NOT_RUN
-        cur = torch.cuda.current_device()
+        cur = _CUR_DEVICE()  # (the raw query: torch.cuda.current_device() is a Python wrapper around it with a lazy-init check, ~0.6 us more)
         if cur != self.device.index:
             return NOT_RUN
         st = _RAW_STREAM(cur) if _RAW_STREAM is not None else torch.cuda.current_stream().cuda_stream

@@ -96,7 +96,11 @@ class DeviceRNG:
 
     @classmethod
     def take(cls, count: int = 1) -> tuple[int, int]:
-        gen = torch.cuda.default_generators[torch.cuda.current_device()]
+        gens = torch.cuda.default_generators
+        if not gens:  # the runtime is not initialised yet: the wrapper's lazy initialisation fills the table
+            torch.cuda.current_device()
+            gens = torch.cuda.default_generators
+        gen = gens[hip_lib._CUR_DEVICE()]
         with cls._lock:
             offset = gen.get_offset()
             gen.set_offset(offset + 4 * int(count))  # Philox offsets move in units of 4
