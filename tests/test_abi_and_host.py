@@ -249,6 +249,14 @@ def test_brownian_tree_mode_is_a_function_of_the_time_alone(pkg):
             os.environ.pop("SONAR_BROWNIAN_TREE", None)
         else:
             os.environ["SONAR_BROWNIAN_TREE"] = saved
+    # a time within half a grid cell beyond an end IS that end (a sigma_max handed over as float32 and queried as float64 differs in the
+    # eighth digit); further out it stays an extension point of its own
+    tree = ng.BrownianPath(0.03, 14.6, 24)
+    cell = (14.6 - 0.03) / (1 << 24)
+    assert tree.resolve(14.6 + 0.4 * cell) == 14.6 and tree.resolve(0.03 - 0.4 * cell) == 0.03
+    assert tree.resolve(14.6 + 0.6 * cell) == 14.6 + 0.6 * cell and tree.resolve(0.03 - 2 * cell) == 0.03 - 2 * cell
+    assert tree.grid_index(0.03) == 0 and tree.grid_index(14.6) == 1 << 24 and tree.grid_index((0.03 + 14.6) / 2) == 1 << 23
+    assert ng.BrownianPath(0.03, 14.6, 0).resolve(14.6 + 0.4 * cell) == 14.6 + 0.4 * cell  # (the path of bridges snaps nothing)
     # grid times are floats: a range too narrow for its offset gets a shallower tree, and its grid points stay distinct
     narrow = ng.BrownianPath(1.0e6, 1.0e6 + 1e-3, 24)
     assert 1 <= narrow.tree_depth < 24
