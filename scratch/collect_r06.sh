@@ -15,3 +15,6 @@ cp $O/pmc_sq_b.txt profiles/r06_pmc_issue_b.txt
 for f in fill_rates fill_ahead brownian_tree pyramid_ahead sizes_sampler lowpass; do
   [ -f $O/$f.txt ] && grep -v amdgpu $O/$f.txt > profiles/r06_$f.txt
 done
+for f in sizes_split perlin_parts pipe_scaling; do
+  [ -f $O/$f.txt ] && grep -v amdgpu $O/$f.txt > profiles/r06_$f.txt
+done
