@@ -20,9 +20,9 @@
 namespace sonar {
 
 #ifndef SONAR_LOW_THREADS
-#define SONAR_LOW_THREADS 512
+#define SONAR_LOW_THREADS 512  // (A/B, round 6: 768 / 1024 threads per plane are SLOWER -- 122.9 / 116.2 us against 95.5 fp64, profiles/r06_experiments.md)
 #endif
-constexpr int kLowThreads = SONAR_LOW_THREADS;   // 8 waves per plane: the phases are short and latency-bound, more waves hide more of it
+constexpr int kLowThreads = SONAR_LOW_THREADS;   // 8 waves per plane: more than the 4 of round 2 hide more of the phases' latency; beyond 8 the phases' fixed cost wins
 constexpr int kLowRows = 16;       // output rows per level-1 analysis tile / final synthesis tile
 constexpr int kLowMaxLevels = 8;
 

@@ -6,7 +6,7 @@
 The driver is generated from include/sonar_hip.h: every entry point is called (a) with every argument zero / NULL and (b) with sizes
 of 4 and 1 but NULL buffers -- the argument-validation paths, which must return an error code (or 0 / -1 for the pure size queries)
 before anything touches the HIP runtime.  The sanitizers watch the host code those paths run (table copies, plan arithmetic, error
-formatting).  Output: the driver's log, also written to profiles/r05_host_sanitizer.txt."""
+formatting).  Output: the driver's log, also written to profiles/r06_host_sanitizer.txt."""
 import os
 import re
 import subprocess
@@ -77,7 +77,7 @@ def main():
     report = (f"host sanitizer run (tools/host_sanitize.py): hipcc {' '.join(FLAGS[6:9])}, {len(objs)} sources + generated driver, "
               f"exit code {run.returncode}\n" + log)
     print(report)
-    with open(os.path.join(ROOT, "profiles", "r05_host_sanitizer.txt"), "w") as fh:
+    with open(os.path.join(ROOT, "profiles", "r06_host_sanitizer.txt"), "w") as fh:
         fh.write(report)
     sys.exit(run.returncode)
 
