@@ -1347,7 +1347,7 @@ class BrownianTreeNoiseSampler:
         """(scale * (W(t) - prev) or None, W(t)) for a time that is not kept: the bridge between its two kept neighbours, else its expansion."""
         made = self.path.bridge.get(t)
         out = w = None
-        if self.path.tree_depth and self.CACHE_POINTS > 0:
+        if self.path.tree_depth:  # (whatever CACHE_POINTS says: the tree's values are defined by the two-stage rule)
             two_stage = self._tree_point(t, prev=prev, scale=scale, want_out=want_out, fold=fold, partials=partials)
             if two_stage is not None:
                 out, w = two_stage
@@ -1388,7 +1388,7 @@ class BrownianTreeNoiseSampler:
             # not move between them -- torchsde's tree returns W(t1) - W(t0) = 0 there as well
             out, _ = self._emit([], [], want_w=False, fold=fold, partials=partials)
             return out
-        if self.CACHE_POINTS <= 0 or ta == tb:
+        if (self.CACHE_POINTS <= 0 and not self.path.tree_depth) or ta == tb:  # (CACHE_POINTS = 0: the path of bridges without kept tensors)
             ids, coefs = self.path.increment(t0, t1)
             out, _ = self._emit(ids, [c * sign for c in coefs], want_w=False, fold=fold, partials=partials)
             return out

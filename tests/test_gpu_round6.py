@@ -334,3 +334,20 @@ def test_pyramid_levels_sized_on_the_host_are_never_frozen_into_a_plan(api, shap
         assert planned is None or planned.plan is None
     else:
         assert planned is not None and planned.plan is not None
+
+
+def test_brownian_tree_values_do_not_depend_on_what_is_kept(api):
+    """The tree's two-stage rule defines W(t); CACHE_POINTS / COARSE_POINTS only say how many tensors a sampler keeps.  A sampler that keeps
+    nothing gives the bits of one that keeps everything."""
+    ng = api.ng
+    x = torch.zeros(2, 4, 64, 64, device="cuda")
+    T = lambda v: torch.tensor(v)  # noqa: E731
+    keep, bare = (ng.BrownianTreeNoiseSampler(x, 0.03, 14.6, seed=21, tree_depth=24) for _ in range(2))
+    bare.CACHE_POINTS = 0
+    bare.COARSE_POINTS = 0
+    sig = [14.6 * 0.85**k for k in range(12)]
+    for k in range(11):
+        mid = (sig[k] * sig[k + 1]) ** 0.5
+        for a, b in ((sig[k], mid), (sig[k], sig[k + 1])):
+            assert torch.equal(keep(T(a), T(b)), bare(T(a), T(b))), (k, a, b)
+    assert not bare._points and len(bare._coarse_pts) == 0 and 0 < len(keep._coarse_pts) <= keep.COARSE_POINTS
