@@ -1917,11 +1917,12 @@ def _peephole_perlin_ahead(records, b, rec):
 
 
 class _FillAheadHook(PlanHook):
-    """A normalised uniform / Gaussian fill inside a plan (``sonar_philox_noise_ahead_f32``, round 6): the plan knows the stream id of the
-    call that follows, so this call's launch also runs that call's statistics pass -- in the same waves, behind the stores of the final
-    pass.  Two statistics buffers per HIP stream, keyed by (seed, stream id); a call that finds nothing (the first, after a reseed or
-    somebody else's draw) gets ``have_stats`` = 0 and the entry point runs the ordinary statistics pass first: it loses its shortcut,
-    never its values."""
+    """A normalised uniform / Gaussian fill (``sonar_philox_noise_ahead_f32``) or pyramid call (``sonar_pyramid_noise_ahead_f32``) inside a
+    plan, round 6: the plan knows the stream ids of the call that follows, so this call's launch also computes that call's statistics
+    -- the fill in the same waves, behind the stores of the final pass; the pyramid in workgroups of their own.  Two statistics buffers
+    per HIP stream, keyed by (seed, stream id); a call that finds nothing (the first, after a reseed, somebody else's draw or a call
+    the entry point refused) gets ``have_stats`` = 0 and the entry point computes the statistics first: it loses its shortcut, never
+    its values."""
 
     KEYS = ("p_now", "have", "p_next")
 
