@@ -45,6 +45,19 @@ struct LowArgs {
     T dlo[kDeepTaps], rlo[kDeepTaps];
 };
 
+// base[elem] with the BYTE offset formed in 32 bits: "uniform base + zero-extended 32-bit offset" is the one form the compiler turns into a
+// scalar-base global access (`global_load_dword v, v_off, s[base:base+1]`); indexed with an int -- or an unsigned element index, whose
+// scaling by four may leave 32 bits as far as the compiler knows -- it builds a 64-bit vector address per access: six instructions per row
+// and tensor in the level-1 analysis (round 6: 155 -> ~100 instructions per item).  A plane is far below 4 GiB.
+template <typename V>
+__device__ __forceinline__ const V& at_u32(const float* base, uint32_t elem) {
+    return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (uint32_t)(elem * 4u));
+}
+template <typename V>
+__device__ __forceinline__ V& at_u32(float* base, uint32_t elem) {
+    return *reinterpret_cast<V*>(reinterpret_cast<char*>(base) + (uint32_t)(elem * 4u));
+}
+
 // items (row, col) of a rows x cols grid dealt to the workgroup's threads in flat order, without a division per item
 struct Walk2 {
     int r, c, dr, dc;
@@ -148,8 +161,10 @@ __global__ void __launch_bounds__(kLowThreads, (kLowThreads > 512 ? 8 : 1)) wcfg
 #pragma unroll
                         for (int r = 0; r < NRS; ++r) {
                             const int sy = ymap[min(2 * (y0 + sub * THS) + r, 2 * h1 + FT - 3)];
-                            const int at = at0(sy) * W + x;
-                            const T d = (T)pc[at] - (T)pu[at];
+                            // (an UNSIGNED 32-bit element offset from the plane's uniform base: one scalar-base load per tensor; as a signed int
+                            // the compiler sign-extended it and built two 64-bit addresses per row: eight instructions where two do)
+                            const uint32_t at = (uint32_t)(at0(sy) * W + x);
+                            const T d = (T)at_u32<float>(pc, at) - (T)at_u32<float>(pu, at);
                             v[r] = live(sy, d);
                         }
                         T* dst = tmp1 + (x & 1) * Wh + (x >> 1);
@@ -279,13 +294,13 @@ __global__ void __launch_bounds__(kLowThreads, (kLowThreads > 512 ? 8 : 1)) wcfg
                     for (Walk2 wk(tid, wq); wk.r < th; wk.next(wq)) {
                         const int yl = wk.r, m = 2 * wk.c;
                         const T* row = tmp + yl * w1;
-                        const int at = (y0 + yl) * W + 4 * wk.c;
+                        const uint32_t at = (uint32_t)((y0 + yl) * W + 4 * wk.c);
 #ifdef SONAR_LOW_NOREREAD  // profiling builds: what the second read of cond / uncond costs
                         float4 c4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f), u4 = make_float4(2.0f, 2.0f, 2.0f, 2.0f);
 #else
-                        float4 c4 = *reinterpret_cast<const float4*>(pc + at), u4 = *reinterpret_cast<const float4*>(pu + at);
+                        float4 c4 = at_u32<float4>(pc, at), u4 = at_u32<float4>(pu, at);
 #endif
-                        float4 x4 = px ? *reinterpret_cast<const float4*>(px + at) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        float4 x4 = px ? at_u32<float4>(px, at) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         T cf[K + 1];  // coefficients m .. m + K (clamped as synth_low_pair clamps: beyond the valid length only)
 #pragma unroll
                         for (int i = 0; i <= K; ++i) cf[i] = row[min(m + i, w1 - 1)];
@@ -303,7 +318,7 @@ __global__ void __launch_bounds__(kLowThreads, (kLowThreads > 512 ? 8 : 1)) wcfg
                         const T r3 = fma_t(a.ku, (T)u4.w, a.kt * fma_t(g0, (T)c4.w - (T)u4.w, o1));
                         float4 res = make_float4((float)r0, (float)r1, (float)r2, (float)r3);
                         if (px) res = make_float4(x4.x - res.x, x4.y - res.y, x4.z - res.z, x4.w - res.w);
-                        store4<(SONAR_LOWPASS_NT != 0)>(po + at, res.x, res.y, res.z, res.w);
+                        store4<(SONAR_LOWPASS_NT != 0)>(&at_u32<float>(po, at), res.x, res.y, res.z, res.w);
                     }
                 } else
                 for (Walk2 wk(tid, wp); wk.r < th; wk.next(wp)) {
