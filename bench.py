@@ -297,6 +297,11 @@ def secondary_rows(device, hl, pn, ng, nz, x, sig):
 
             us = event_us(sized_call, 20, 5)
             extra[f"power_noise_{tag}_us"] = us
+            # the same call through the sampler API (a prepared plan issues its launches with one foreign call: no host gap between them)
+            xs_sz = torch.zeros(shp, device=device)
+            ns_sz = power_item(pn).make_noise_sampler(xs_sz, None, None, seed=None, cpu=False, normalized=True)
+            extra[f"power_noise_{tag}_sampler_us"] = event_us(lambda: ns_sz(*sig), 20, 8)
+            del xs_sz, ns_sz
             kernels.append(kernel_entry(f"power noise, normalised generate, {nb} latents of {C} x {hh} x {ww}", us, 4 * nb * C * hh * ww,
                                         tr.get(f"power_noise_{tag}_b{nb}", {}).get("hbm_bytes_per_launch"),
                                         "two launches (statistics + final pass; 256 x 256: statistics + columns into a workspace + rows, 3 x the tensor of traffic); bytes = the tensor written once"
